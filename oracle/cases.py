@@ -1,0 +1,138 @@
+"""Seeded parity cases shared by tools/make_golden.py (reference side) and tests/ (oracle and
+HIP side).  A case is fully determined by its name: weights, inputs and noise draws come from
+numpy RandomState streams, so tests/golden/*.npz store only the reference's OUTPUTS.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from . import weights as W
+
+H = 8       # num_heads in every shipped config (example_configs/*.py)
+I = 64      # num_inducers in every shipped config
+
+LAYER_CASES = {  # name: (d, N, B, seed)
+    "layer_d64_N64": (64, 64, 2, 11),
+    "layer_d128_N256": (128, 256, 2, 12),
+    "layer_d384_N64": (384, 64, 2, 13),
+}
+
+UNCOND_CASES = {  # name: (d, L, N, seed)
+    "uncond_d128_L4_N256": (128, 4, 256, 21),
+    "uncond_d384_L6_N128": (384, 6, 128, 22),
+}
+SIGMAS5 = (0.002, 0.1, 1.0, 20.0, 165.0)
+
+COND_CASES = {  # name: (d, L, N, hw, context_dims, seed)
+    "cond_d128_L2_N96": (128, 2, 96, 64, (96, 192, 384), 31),
+}
+SIGMAS3 = (0.01, 1.0, 50.0)
+
+LOOKUP_CASES = {  # name: (B, N, hw, context_dims, seed)
+    "lookup_small": (2, 200, 64, (8, 16, 24), 41),
+    "lookup_convnext": (2, 24, 224, (96, 192, 384), 42),
+}
+
+
+def _randn(seed, *shape, dtype=np.float32):
+    return torch.from_numpy(np.random.RandomState(seed).randn(*shape).astype(dtype))
+
+
+def layer_inputs(name):
+    d, N, B, seed = LAYER_CASES[name]
+    p = W.layer_state_dict(np.random.RandomState(seed), d, I, H)
+    x = _randn(seed + 1, B, N, d) * 1.5 + 0.3
+    sigma = torch.tensor([0.05, 30.0][:B], dtype=torch.float32)
+    t = (sigma.log() / 4).reshape(B, 1, 1)
+    return p, x, t
+
+
+def uncond_inputs(name, sigmas=SIGMAS5):
+    d, L, N, seed = UNCOND_CASES[name]
+    p = W.linear_lift_state_dict(seed, d, L, I, H)
+    B = len(sigmas)
+    sigma = torch.tensor(sigmas, dtype=torch.float32)
+    data = _randn(seed + 1, B, N, 3)
+    x = data + sigma.reshape(-1, 1, 1) * _randn(seed + 2, B, N, 3)
+    return p, x, sigma
+
+
+def cached_inputs(name="uncond_d128_L4_N256", n_new=96):
+    p, x, sigma = uncond_inputs(name)
+    d, L, N, seed = UNCOND_CASES[name]
+    x_new = _randn(seed + 3, x.shape[0], n_new, 3) * (1 + sigma.reshape(-1, 1, 1))
+    return p, x, sigma, x_new
+
+
+def lookup_inputs(name):
+    B, N, hw, cdims, seed = LOOKUP_CASES[name]
+    feats, K = W.synthetic_context(seed, B, hw=hw, context_dims=cdims)
+    uvl_mean = torch.tensor([0.0, 0.0, 1.38])
+    uvl_std = torch.tensor([0.56, 0.60, 0.49])
+    # diffusion-space geometry: tanh(u*std)*1.1 spreads over (and up to 5% beyond) the image,
+    # so border taps and fully out-of-bounds taps are both exercised (zeros padding)
+    geom_diff = _randn(seed + 1, B, N, 3) * torch.tensor([2.0, 2.0, 0.7])
+    geom_diff[:, :3, :2] *= 4.0  # saturated tanh: far outside the frustum
+    return feats, K, geom_diff, uvl_mean, uvl_std
+
+
+def cond_inputs(name, sigmas=SIGMAS3):
+    d, L, N, hw, cdims, seed = COND_CASES[name]
+    B = len(sigmas)
+    p = W.ray_network_state_dict(seed, d, L, I, H, context_dims=cdims)
+    feats, K = W.synthetic_context(seed + 5, B, hw=hw, context_dims=cdims)
+    sigma = torch.tensor(sigmas, dtype=torch.float32)
+    data = _randn(seed + 1, B, N, 3)
+    x = data + sigma.reshape(-1, 1, 1) * _randn(seed + 2, B, N, 3)
+    return p, x, sigma, K, feats
+
+
+SAMPLER_CASE = dict(d=64, L=2, N=64, B=2, seed=51, num_steps=6, sigma_max=165.0)
+UPSAMPLE_CASE = dict(d=64, L=2, N=64, B=2, seed=52, n_new=32, num_steps=3, num_substeps=2, sigma_max=165.0)
+LOSS_CASE = dict(d=64, L=2, N=64, B=4, seed=53, sigma_max=165.0)
+GAUSS_MEAN = (0.0, 0.01, 0.05)
+GAUSS_SIGMA = (0.11, 0.04, 0.17)
+
+
+def sampler_inputs():
+    c = SAMPLER_CASE
+    p = W.linear_lift_state_dict(c["seed"], c["d"], c["L"], I, H)
+    latents = _randn(c["seed"] + 1, c["B"], c["N"], 3)
+    noises = [_randn(c["seed"] + 10 + i, c["B"], c["N"], 3) for i in range(c["num_steps"])]
+    return p, latents, noises
+
+
+def upsample_inputs():
+    c = UPSAMPLE_CASE
+    p = W.linear_lift_state_dict(c["seed"], c["d"], c["L"], I, H)
+    data = _randn(c["seed"] + 1, c["B"], c["N"], 3) * torch.tensor(GAUSS_SIGMA) + torch.tensor(GAUSS_MEAN)
+    return p, data
+
+
+def upsample_draw_list():
+    """All randn draws of the upsample case, in the reference's call order."""
+    c = UPSAMPLE_CASE
+    rs = np.random.RandomState(c["seed"] + 2)
+    B, N, n_new, S, U = c["B"], c["N"], c["n_new"], c["num_steps"], c["num_substeps"]
+    out = [torch.from_numpy(rs.randn(B, n_new, 3).astype(np.float32))]  # new_latents
+    for i in range(S):
+        out.append(torch.from_numpy(rs.randn(B, N, 3).astype(np.float32)))  # data_ctx noise
+        for u in range(U):
+            out.append(torch.from_numpy(rs.randn(B, n_new, 3).astype(np.float32)))  # churn noise
+            if u < U - 1 and i < S - 1:
+                out.append(torch.from_numpy(rs.randn(B, n_new, 3).astype(np.float32)))  # redo noise
+    return out
+
+
+def loss_inputs():
+    c = LOSS_CASE
+    p = W.linear_lift_state_dict(c["seed"], c["d"], c["L"], I, H)
+    ex = _randn(c["seed"] + 1, c["B"], c["N"], 3)
+    u = torch.from_numpy(np.random.RandomState(c["seed"] + 2).uniform(size=c["B"]).astype(np.float32))
+    noise = _randn(c["seed"] + 3, c["B"], c["N"], 3)
+    return p, ex, u, noise

@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Benchmark of the GECCO denoiser forward on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+
+A "step" is one Diffusion.forward (EDMPrecond + LinearLift + 6-layer set transformer) over one batch
+of synthetic clouds resident in HBM: config C2 = B=64, N=2048, d=384, L=6, I=64, H=8.  With N > 1
+(launched by torch.distributed.run, one rank per GPU) every rank evaluates its own batch — samples
+are independent, there is no data-path collective ("replicas only", weak scaling) — and the time is
+the max over ranks.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline     — the dominant kernel (fp32-MFMA fused GEMM, 42 launches per forward): algorithmic
+                 FLOPs of its five call-site shapes / their event-timed durations, vs the 157.3 TF
+                 dense fp32 MFMA peak (MI355X_MICROARCH.md).  The rocprofv3 summary of this same
+                 command lives in profiles/.
+  cpu_baseline — the oracle (plain PyTorch CPU restatement of the reference) on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B, N, D, L, I, H = 64, 2048, 384, 6, 64, 8
+PEAK_F32_MFMA_TFLOPS = 157.3
+
+
+def flops_per_sample():
+    per_layer = 16 * N * D * D + 8 * N * I * D + 14 * I * D * D
+    return L * per_layer + 2 * (2 * N * 3 * D)
+
+
+def random_state_dict(seed):
+    """Random-init weights of the C2 architecture, keyed like the reference state dict
+    (LinearLift: lift / inner.layers.i.* / lower.1); AdaGN and alpha deliberately non-default."""
+    g = torch.Generator().manual_seed(seed)
+    u = lambda o, i_: (torch.rand(o, i_, generator=g) * 2 - 1) / i_ ** 0.5
+    ub = lambda o, i_: (torch.rand(o, generator=g) * 2 - 1) / i_ ** 0.5
+    sd = {"lift.weight": u(D, 3), "lift.bias": ub(D, 3), "lower.1.weight": u(3, D), "lower.1.bias": ub(3, D)}
+
+    def adagn(pre):
+        sd[pre + "scale.weight"] = 0.2 * torch.randn(D, 1, generator=g)
+        sd[pre + "scale.bias"] = 1 + 0.1 * torch.randn(D, generator=g)
+        sd[pre + "bias.weight"] = 0.2 * torch.randn(D, 1, generator=g)
+        sd[pre + "bias.bias"] = 0.1 * torch.randn(D, generator=g)
+
+    def mlp(pre):
+        sd[pre + "0.weight"], sd[pre + "0.bias"] = u(2 * D, D), ub(2 * D, D)
+        sd[pre + "1.alpha"] = torch.tensor(1.0) + 0.1 * torch.randn((), generator=g)
+        sd[pre + "2.weight"], sd[pre + "2.bias"] = u(D, 2 * D), ub(D, 2 * D)
+
+    for li in range(L):
+        pre = f"inner.layers.{li}."
+        adagn(pre + "broadcast_norm.")
+        sd[pre + "broadcast.pool.inducers"] = torch.randn(1, H, I, D // H, generator=g)
+        sd[pre + "broadcast.pool.kv_proj.weight"] = u(2 * D, D)
+        sd[pre + "broadcast.pool.out_proj.weight"] = u(D, D)
+        adagn(pre + "broadcast.norm_1.")
+        mlp(pre + "broadcast.mlp.")
+        adagn(pre + "broadcast.norm_2.")
+        sd[pre + "broadcast.unpool.in_proj_weight"] = u(3 * D, D)
+        sd[pre + "broadcast.unpool.in_proj_bias"] = ub(3 * D, D)
+        sd[pre + "broadcast.unpool.out_proj.weight"] = u(D, D)
+        sd[pre + "broadcast.unpool.out_proj.bias"] = ub(D, D)
+        adagn(pre + "mlp_norm.")
+        mlp(pre + "mlp.")
+    return {k: v.float().contiguous() for k, v in sd.items()}
+
+
+def synthetic_cloud(seed):
+    """unit-variance data, stratified log-uniform sigma in [0.002, 165], x = data + sigma*noise."""
+    g = torch.Generator().manual_seed(seed)
+    import math
+    data = torch.randn(B, N, 3, generator=g)
+    u = (torch.arange(B) + torch.rand(B, generator=g)) / B
+    sigma = torch.exp(math.log(0.002) + u * (math.log(165.0) - math.log(0.002)))
+    return (data + sigma[:, None, None] * torch.randn(B, N, 3, generator=g)).contiguous(), sigma.float().contiguous()
+
+
+def gemm_call_sites(ops, dev):
+    """The five (B*N)-row GEMM call sites of one layer, as closures launching the unit operator."""
+    g = torch.Generator(device="cpu").manual_seed(1)
+    rn = lambda *s: torch.randn(*s, generator=g).to(dev)
+    x, big = rn(B, N, D), rn(B, N, 2 * D)
+    pa, po = 1 + 0.1 * rn(B, D), 0.1 * rn(B, D)
+    Wkv, Wq, Wo, W1, W2 = rn(2 * D, D) / 20, rn(D, D) / 20, rn(D, D) / 20, rn(2 * D, D) / 20, rn(D, 2 * D) / 28
+    bq, b1, b2 = rn(D) / 20, rn(2 * D) / 20, rn(D) / 20
+    alpha = torch.tensor(1.0, device=dev)
+    o768, o384 = torch.empty(B, N, 2 * D, device=dev), torch.empty(B, N, D, device=dev)
+    res = x.clone()
+    sites = [
+        ("kv_proj", 2 * B * N * D * 2 * D, lambda: ops.linear(x, Wkv, None, (pa, po), out=o768)),
+        ("q_proj", 2 * B * N * D * D, lambda: ops.linear(x, Wq, bq, (pa, po), out=o384)),
+        ("out_proj+res+stats", 2 * B * N * D * D, lambda: ops.linear(x, Wo, bq, residual=res, want_stats=True, out=o384)),
+        ("mlp.0+act", 2 * B * N * D * 2 * D, lambda: ops.linear(x, W1, b1, (pa, po), act_alpha=alpha, out=o768)),
+        ("mlp.2+res+stats", 2 * B * N * 2 * D * D, lambda: ops.linear(big, W2, b2, residual=res, want_stats=True, out=o384)),
+    ]
+    return sites
+
+
+def time_events(fn, iters, warmup=2):
+    for _ in range(warmup):
+        fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    e.synchronize()
+    return s.elapsed_time(e) / iters  # ms
+
+
+def cpu_baseline(p, x, sigma, budget_s=15.0):
+    from oracle import cpu_ref
+    nb = 4
+    xs, ss = x[:nb].cpu(), sigma[:nb].cpu()
+    cores = torch.get_num_threads()
+    Dn = cpu_ref.uncond_denoiser({k: v.cpu() for k, v in p.items()}, "", H)
+    with torch.no_grad():
+        Dn(xs, ss)  # warm-up
+        t0 = time.perf_counter()
+        it = 0
+        while True:
+            Dn(xs, ss)
+            it += 1
+            dt = time.perf_counter() - t0
+            if dt > budget_s or it >= 20:
+                break
+    return {"value": nb * N * it / dt, "unit": "points/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/cpu_ref.py fp32 forward on {nb} of the {B} clouds (N={N}, d={D}, L={L}), {it} iterations, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import __graft_entry__ as ge
+    if rank == 0 and not os.path.exists(ge.LIB):
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    from gecco_amd import hip_ops as ops
+
+    p_cpu = random_state_dict(seed=3)
+    p = {k: v.to(dev) for k, v in p_cpu.items()}
+    x_cpu, sigma_cpu = synthetic_cloud(seed=rank)  # each rank: its own batch (weak scaling)
+    x, sigma = x_cpu.to(dev), sigma_cpu.to(dev)
+    net = ops.LinearLiftPlan(p, H, I)
+    out = torch.empty_like(x)
+
+    def step():
+        net.forward(x, sigma, out=out)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(out).all(), "non-finite denoiser output"
+
+    ms = dt / args.steps * 1e3
+    value = world * B * N * args.steps / dt
+    rec = {
+        "metric": "denoiser_fwd_points_per_sec", "value": value, "unit": "points/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"C2 unconditional denoiser forward: B={B}/GPU, N={N}, d={D}, L={L}, I={I}, H={H}, "
+                               "EDMPrecond(LinearLift(SetTransformer)), fp32 MFMA, random-init weights",
+                   "parallelism": "replicas (batch-sharded, no data-path collective)" if world > 1 else "single GPU"},
+        "forward_tflops": flops_per_sample() * B / (ms * 1e-3) / 1e12,
+        "target_points_per_sec_per_gpu": 2.0e6,
+    }
+    if rank == 0 and not args.no_roofline:
+        sites = gemm_call_sites(ops, dev)
+        tot_f, tot_ms, per = 0.0, 0.0, {}
+        for name, fl, fn in sites:
+            t = time_events(fn, 10)
+            per[name] = {"ms": round(t, 4), "tflops": round(fl / (t * 1e-3) / 1e12, 2)}
+            tot_f += fl
+            tot_ms += t
+        ach = tot_f / (tot_ms * 1e-3) / 1e12
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "gemm_hbm_traffic.json")
+        if os.path.exists(tj):
+            traffic = json.load(open(tj)).get("bytes_per_launch")
+        rec["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                           "kernel": "gemm_f32_kernel<128,128,2,2> (v_mfma_f32_32x32x2_f32), mean over its 5 call-site shapes",
+                           "per_site": per}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        rec["cpu_baseline"] = cpu_baseline(p_cpu, x_cpu, sigma_cpu)
+    if rank == 0:
+        print(json.dumps(rec))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

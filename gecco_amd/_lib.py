@@ -1,0 +1,103 @@
+"""ctypes binding of libgecco_hip.so (C ABI declared in include/gecco_hip.h).
+
+`load()` fails loudly when the library is absent — the product path never falls back to a CPU or
+eager-PyTorch implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgecco_hip.so")
+ABI_VERSION = 1
+
+c_f = C.c_void_p  # device pointers travel as void*
+
+
+class GeccoAdaGN(C.Structure):
+    _fields_ = [("scale_w", c_f), ("scale_b", c_f), ("bias_w", c_f), ("bias_b", c_f)]
+
+
+class GeccoMLP(C.Structure):
+    _fields_ = [("w0", c_f), ("b0", c_f), ("alpha", c_f), ("w2", c_f), ("b2", c_f)]
+
+
+class GeccoLayer(C.Structure):
+    _fields_ = [("broadcast_norm", GeccoAdaGN), ("inducers", c_f), ("kv_proj_w", c_f), ("pool_out_w", c_f),
+                ("norm_1", GeccoAdaGN), ("bmlp", GeccoMLP), ("norm_2", GeccoAdaGN), ("in_proj_w", c_f),
+                ("in_proj_b", c_f), ("unpool_out_w", c_f), ("unpool_out_b", c_f), ("mlp_norm", GeccoAdaGN),
+                ("mlp", GeccoMLP)]
+
+
+class GeccoSetTransformer(C.Structure):
+    _fields_ = [("n_layers", C.c_int), ("C", C.c_int), ("H", C.c_int), ("I", C.c_int), ("ctx_dim", C.c_int),
+                ("G", C.c_int), ("width", C.c_int), ("act", C.c_int), ("layers", C.POINTER(GeccoLayer))]
+
+
+class GeccoLinearLift(C.Structure):
+    _fields_ = [("inner", GeccoSetTransformer), ("lift_w", c_f), ("lift_b", c_f), ("lower_w", c_f),
+                ("lower_b", c_f), ("sigma_data", C.c_float)]
+
+
+i, sz, vp, fl = C.c_int, C.c_size_t, C.c_void_p, C.c_float
+PP = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes); every symbol include/gecco_hip.h declares
+SIGNATURES = {
+    "gecco_abi_version": (i, []),
+    "gecco_build_arch": (C.c_char_p, []),
+    "gecco_last_error": (C.c_char_p, []),
+    "gecco_linear_f32": (i, [vp] * 9 + [i, i, i, i, i, vp]),
+    "gecco_linear_row_tiles": (i, [i]),
+    "gecco_col_stats_f32": (i, [vp, vp, i, i, i, vp]),
+    "gecco_stats_row_tiles": (i, [i]),
+    "gecco_adagn_coeffs_f32": (i, [vp, i, i, vp, i, C.POINTER(GeccoAdaGN), vp, vp, i, i, i, fl, vp]),
+    "gecco_affine_apply_f32": (i, [vp, vp, vp, vp, i, i, i, vp]),
+    "gecco_adagn_f32": (i, [vp, vp, i, C.POINTER(GeccoAdaGN), vp, i, i, i, i, fl, vp, sz, vp]),
+    "gecco_adagn_workspace_bytes": (sz, [i, i, i]),
+    "gecco_pool_attn_f32": (i, [vp, vp, vp, i, i, i, i, i, vp, sz, vp]),
+    "gecco_pool_attn_workspace_bytes": (sz, [i, i, i, i, i]),
+    "gecco_unpool_attn_f32": (i, [vp, vp, vp, i, i, i, i, i, vp]),
+    "gecco_edm_coeffs_f32": (i, [vp, fl, vp, i, vp]),
+    "gecco_lift_f32": (i, [vp, vp, vp, vp, vp, vp, i, i, i, vp]),
+    "gecco_lower_edm_f32": (i, [vp] * 9 + [i, i, i, fl, vp]),
+    "gecco_set_transformer_fwd_f32": (i, [C.POINTER(GeccoSetTransformer), vp, vp, vp, i, PP, PP, vp, i, i, vp, sz, vp]),
+    "gecco_set_transformer_workspace_bytes": (sz, [C.POINTER(GeccoSetTransformer), i, i]),
+    "gecco_linear_lift_fwd_f32": (i, [C.POINTER(GeccoLinearLift), vp, vp, vp, vp, PP, PP, i, i, vp, sz, vp]),
+    "gecco_linear_lift_workspace_bytes": (sz, [C.POINTER(GeccoLinearLift), i, i]),
+}
+
+_lib = None
+
+
+class GeccoHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """dlopen the library (after torch, so its libamdhip64.so.7 dependency resolves to the HIP
+    runtime torch already loaded) and bind every declared symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GeccoHipError(
+            f"{LIB_PATH} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
+            "gecco_amd has no CPU fallback.")
+    import torch  # noqa: F401  (loads the HIP runtime first)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gecco_abi_version() != ABI_VERSION:
+        raise GeccoHipError(f"ABI mismatch: library {lib.gecco_abi_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().gecco_last_error().decode()
+        raise GeccoHipError(f"{what} failed with code {rc}: {msg}")

@@ -1,0 +1,328 @@
+// C ABI of libgecco_hip.so (declared in include/gecco_hip.h) and the host-side orchestration of a
+// SetTransformer evaluation: which kernel runs when, which buffer feeds which.  Nothing here
+// allocates, synchronises or reads device memory, so a caller may capture any entry point in a
+// hipGraph.
+#include "../../include/gecco_hip.h"
+#include "kernels.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int rc, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return rc;
+}
+int check(int rc, const char* what) {
+    if (rc == 0) return 0;
+    if (rc > 0) return fail(rc, "%s: HIP error %d (%s)", what, rc, hipGetErrorString((hipError_t)rc));
+    return fail(rc, "%s: unsupported arguments (code %d)", what, rc);
+}
+#define TRY(expr, what)                  \
+    do {                                 \
+        int rc_ = check((expr), (what)); \
+        if (rc_) return rc_;             \
+    } while (0)
+
+// Bump allocator over the caller's workspace (256-byte aligned carves).  With base == nullptr it
+// only measures, so *_workspace_bytes() and the forward use the same code path.
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(void* b) : base(static_cast<char*>(b)) {}
+    float* f32(size_t n) {
+        off = (off + 255) & ~size_t(255);
+        float* p = base ? reinterpret_cast<float*>(base + off) : nullptr;
+        off += n * sizeof(float);
+        return p;
+    }
+};
+
+struct STWorkspace {
+    float *big, *q, *attn;             // (B,N,2C), (B,N,C), (B,N,C)
+    float *stats_x, *stats_s;          // (B,T,2,C) stream partials; (B,1,2,2C) inducer partials
+    float *a1, *o1, *a2, *o2, *as, *os;  // AdaGN coefficients (B,C)
+    float *part_o, *part_ml;           // pool partials
+    float *merged, *h0, *u, *h2, *h, *kvh;  // inducer chain (B,I,*)
+    size_t bytes;
+};
+
+int max_i(int a, int b) { return a > b ? a : b; }
+int row_tiles_gemm(int rows) { const int bm = gemm_row_tile(rows); return (rows + bm - 1) / bm; }
+int row_tiles_stats(int rows) { const int bm = stats_row_tile(rows); return (rows + bm - 1) / bm; }
+
+STWorkspace carve_st(const GeccoSetTransformer* st, int B, int N, void* base) {
+    Carver c(base);
+    STWorkspace w;
+    const size_t C = st->C, I = st->I, W = st->width;
+    const size_t big = (size_t)B * N * (2 * C > W ? 2 * C : W);
+    w.big = c.f32(big);
+    w.q = c.f32((size_t)B * N * C);
+    w.attn = c.f32((size_t)B * N * C);
+    const int T = max_i(row_tiles_gemm(N), row_tiles_stats(N));
+    w.stats_x = c.f32((size_t)B * T * 2 * C);
+    w.stats_s = c.f32((size_t)B * 2 * 2 * (2 * C > W ? 2 * C : W));
+    w.a1 = c.f32(B * C); w.o1 = c.f32(B * C);
+    w.a2 = c.f32(B * C); w.o2 = c.f32(B * C);
+    w.as = c.f32(B * C); w.os = c.f32(B * C);
+    const int ns = pool_attn_nsplit(B, N, st->H);
+    const size_t HD = C / st->H;
+    w.part_o = c.f32((size_t)B * st->H * ns * 64 * HD);
+    w.part_ml = c.f32((size_t)B * st->H * ns * 64 * 2);
+    w.merged = c.f32(B * I * C);
+    w.h0 = c.f32(B * I * C);
+    w.u = c.f32(B * I * W);
+    w.h2 = c.f32(B * I * C);
+    w.h = c.f32(B * I * C);
+    w.kvh = c.f32(B * I * 2 * C);
+    w.bytes = (c.off + 255) & ~size_t(255);
+    return w;
+}
+
+int linear(const float* A, const float* W, const float* bias, const float* pa, const float* po, const float* alpha,
+           const float* res, float* C, float* stats, int B, int rows, int K, int Nout, int act, hipStream_t s) {
+    GemmArgs g;
+    g.A = A; g.W = W; g.bias = bias; g.pro_a = pa; g.pro_o = po; g.alpha = alpha; g.residual = res; g.C = C;
+    g.stats = stats; g.B = B; g.rows = rows; g.K = K; g.Nout = Nout;
+    g.lda = K; g.ldw = K; g.ldc = Nout; g.ldr = Nout; g.act = act;
+    if (act && !alpha) return -6;
+    return gemm_f32_launch(g, s);
+}
+
+int coeffs(const float* stats, int T, int rows, const float* t, int ctx, const GeccoAdaGN* p, float* a, float* o,
+           int B, int C, int G, hipStream_t s) {
+    return adagn_coeffs_launch(stats, T, rows, t, ctx, p ? p->scale_w : nullptr, p ? p->scale_b : nullptr,
+                               p ? p->bias_w : nullptr, p ? p->bias_b : nullptr, a, o, B, C, G, 1e-5f, s);
+}
+
+int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const float* stats_x, int stats_T,
+               const float* const* h_in, float* const* h_out, float* stats_out, int B, int N, void* ws,
+               size_t ws_bytes, hipStream_t s) {
+    if (!st || !x || !t) return fail(-1, "set_transformer: null argument");
+    if (st->I != 64) return fail(-3, "set_transformer: num_inducers must be 64 (got %d)", st->I);
+    if (st->C % st->H || st->C % st->G || st->C % 4) return fail(-3, "set_transformer: bad feature_dim %d", st->C);
+    STWorkspace w = carve_st(st, B, N, ws);
+    if (ws_bytes < w.bytes) return fail(-7, "set_transformer: workspace too small (%zu < %zu)", ws_bytes, w.bytes);
+    const int C = st->C, I = st->I, H = st->H, G = st->G, Wd = st->width, ctx = st->ctx_dim, act = st->act;
+    const int Tn = row_tiles_gemm(N), Ti = row_tiles_gemm(I);
+    const int ns = pool_attn_nsplit(B, N, H);
+
+    const float* sx = stats_x;
+    int sT = stats_T;
+    if (!sx) {
+        TRY(col_stats_launch(x, w.stats_x, B, N, C, s), "col_stats");
+        sx = w.stats_x;
+        sT = row_tiles_stats(N);
+    }
+    for (int li = 0; li < st->n_layers; ++li) {
+        const GeccoLayer& L = st->layers[li];
+        // y = AdaGN(x) is never materialised: (a1, o1) ride in the prologue of the two GEMMs that read x
+        TRY(coeffs(sx, sT, N, t, ctx, &L.broadcast_norm, w.a1, w.o1, B, C, G, s), "adagn_coeffs(broadcast_norm)");
+        const float* h = h_in ? h_in[li] : nullptr;
+        if (!h) {
+            // pool: KV projection, 64 inducer queries over the N points, out_proj
+            TRY(linear(x, L.kv_proj_w, nullptr, w.a1, w.o1, nullptr, nullptr, w.big, nullptr, B, N, C, 2 * C, 0, s),
+                "kv_proj");
+            TRY(pool_attn_launch(w.big, L.inducers, w.part_o, w.part_ml, w.merged, B, N, C, H, I, ns, s), "pool_attn");
+            TRY(linear(w.merged, L.pool_out_w, nullptr, nullptr, nullptr, nullptr, nullptr, w.h0, w.stats_s, B, I, C, C,
+                       0, s), "pool.out_proj");
+            // h = norm_2(mlp(norm_1(h0)))
+            TRY(coeffs(w.stats_s, Ti, I, t, ctx, &L.norm_1, w.as, w.os, B, C, G, s), "adagn_coeffs(norm_1)");
+            TRY(linear(w.h0, L.bmlp.w0, L.bmlp.b0, w.as, w.os, L.bmlp.alpha, nullptr, w.u, nullptr, B, I, C, Wd, act, s),
+                "broadcast.mlp.0");
+            TRY(linear(w.u, L.bmlp.w2, L.bmlp.b2, nullptr, nullptr, nullptr, nullptr, w.h2, w.stats_s, B, I, Wd, C, 0, s),
+                "broadcast.mlp.2");
+            TRY(coeffs(w.stats_s, Ti, I, t, ctx, &L.norm_2, w.as, w.os, B, C, G, s), "adagn_coeffs(norm_2)");
+            float* hdst = (h_out && h_out[li]) ? h_out[li] : w.h;
+            TRY(affine_apply_launch(w.h2, w.as, w.os, hdst, B, I, C, s), "norm_2 apply");
+            h = hdst;
+        }
+        // unpool: k|v of the 64 inducer states, q of the N points, attention, out_proj + residual
+        TRY(linear(h, L.in_proj_w + (size_t)C * C, L.in_proj_b + C, nullptr, nullptr, nullptr, nullptr, w.kvh, nullptr,
+                   B, I, C, 2 * C, 0, s), "unpool.in_proj(kv)");
+        TRY(linear(x, L.in_proj_w, L.in_proj_b, w.a1, w.o1, nullptr, nullptr, w.q, nullptr, B, N, C, C, 0, s),
+            "unpool.in_proj(q)");
+        TRY(unpool_attn_launch(w.q, w.kvh, w.attn, B, N, C, H, I, s), "unpool_attn");
+        TRY(linear(w.attn, L.unpool_out_w, L.unpool_out_b, nullptr, nullptr, nullptr, x, x, w.stats_x, B, N, C, C, 0, s),
+            "unpool.out_proj+residual");
+        // x += mlp(AdaGN(x))
+        TRY(coeffs(w.stats_x, Tn, N, t, ctx, &L.mlp_norm, w.a2, w.o2, B, C, G, s), "adagn_coeffs(mlp_norm)");
+        TRY(linear(x, L.mlp.w0, L.mlp.b0, w.a2, w.o2, L.mlp.alpha, nullptr, w.big, nullptr, B, N, C, Wd, act, s), "mlp.0");
+        float* so = (li + 1 < st->n_layers) ? w.stats_x : stats_out;
+        TRY(linear(w.big, L.mlp.w2, L.mlp.b2, nullptr, nullptr, nullptr, x, x, so, B, N, Wd, C, 0, s), "mlp.2+residual");
+        sx = w.stats_x;
+        sT = Tn;
+    }
+    return 0;
+}
+
+struct LLWorkspace {
+    float *feat, *coef, *stats;
+    void* st_ws;
+    size_t st_bytes, bytes;
+};
+
+LLWorkspace carve_ll(const GeccoLinearLift* m, int B, int N, void* base) {
+    Carver c(base);
+    LLWorkspace w;
+    w.feat = c.f32((size_t)B * N * m->inner.C);
+    w.coef = c.f32((size_t)B * 5);
+    w.stats = c.f32((size_t)B * row_tiles_stats(N) * 2 * m->inner.C);
+    c.off = (c.off + 255) & ~size_t(255);
+    w.st_bytes = carve_st(&m->inner, B, N, nullptr).bytes;
+    w.st_ws = base ? static_cast<char*>(base) + c.off : nullptr;
+    w.bytes = c.off + w.st_bytes;
+    return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gecco_abi_version(void) { return GECCO_ABI_VERSION; }
+const char* gecco_build_arch(void) { return "gfx950"; }
+const char* gecco_last_error(void) { return g_err; }
+
+int gecco_linear_row_tiles(int rows) { return row_tiles_gemm(rows); }
+int gecco_stats_row_tiles(int rows) { return row_tiles_stats(rows); }
+
+int gecco_linear_f32(const float* A, const float* W, const float* bias, const float* pro_a, const float* pro_o,
+                     const float* alpha, const float* residual, float* C, float* stats, int B, int rows, int K,
+                     int Nout, int act, void* stream) {
+    if (!A || !W || !C) return fail(-1, "linear: null argument");
+    if ((pro_a == nullptr) != (pro_o == nullptr)) return fail(-1, "linear: pro_a/pro_o must both be set");
+    TRY(linear(A, W, bias, pro_a, pro_o, alpha, residual, C, stats, B, rows, K, Nout, act, (hipStream_t)stream),
+        "linear");
+    return 0;
+}
+
+int gecco_col_stats_f32(const float* x, float* stats, int B, int rows, int C, void* stream) {
+    TRY(col_stats_launch(x, stats, B, rows, C, (hipStream_t)stream), "col_stats");
+    return 0;
+}
+
+int gecco_adagn_coeffs_f32(const float* stats, int T, int rows, const float* t, int ctx_dim, const GeccoAdaGN* p,
+                           float* a, float* o, int B, int C, int G, float eps, void* stream) {
+    TRY(adagn_coeffs_launch(stats, T, rows, t, ctx_dim, p ? p->scale_w : nullptr, p ? p->scale_b : nullptr,
+                            p ? p->bias_w : nullptr, p ? p->bias_b : nullptr, a, o, B, C, G, eps,
+                            (hipStream_t)stream), "adagn_coeffs");
+    return 0;
+}
+
+int gecco_affine_apply_f32(const float* x, const float* a, const float* o, float* y, int B, int rows, int C,
+                           void* stream) {
+    TRY(affine_apply_launch(x, a, o, y, B, rows, C, (hipStream_t)stream), "affine_apply");
+    return 0;
+}
+
+size_t gecco_adagn_workspace_bytes(int B, int rows, int C) {
+    Carver c(nullptr);
+    c.f32((size_t)B * row_tiles_stats(rows) * 2 * C);
+    c.f32((size_t)B * C);
+    c.f32((size_t)B * C);
+    return (c.off + 255) & ~size_t(255);
+}
+
+int gecco_adagn_f32(const float* x, const float* t, int ctx_dim, const GeccoAdaGN* p, float* y, int B, int rows,
+                    int C, int G, float eps, void* ws, size_t ws_bytes, void* stream) {
+    if (ws_bytes < gecco_adagn_workspace_bytes(B, rows, C)) return fail(-7, "adagn: workspace too small");
+    Carver c(ws);
+    float* stats = c.f32((size_t)B * row_tiles_stats(rows) * 2 * C);
+    float* a = c.f32((size_t)B * C);
+    float* o = c.f32((size_t)B * C);
+    hipStream_t s = (hipStream_t)stream;
+    TRY(col_stats_launch(x, stats, B, rows, C, s), "col_stats");
+    TRY(adagn_coeffs_launch(stats, row_tiles_stats(rows), rows, t, ctx_dim, p ? p->scale_w : nullptr,
+                            p ? p->scale_b : nullptr, p ? p->bias_w : nullptr, p ? p->bias_b : nullptr, a, o, B, C, G,
+                            eps, s), "adagn_coeffs");
+    TRY(affine_apply_launch(x, a, o, y, B, rows, C, s), "affine_apply");
+    return 0;
+}
+
+size_t gecco_pool_attn_workspace_bytes(int B, int N, int C, int H, int I) {
+    (void)I;
+    Carver c(nullptr);
+    const int ns = pool_attn_nsplit(B, N, H);
+    c.f32((size_t)B * H * ns * 64 * (C / H));
+    c.f32((size_t)B * H * ns * 64 * 2);
+    return (c.off + 255) & ~size_t(255);
+}
+
+int gecco_pool_attn_f32(const float* KV, const float* inducers, float* merged, int B, int N, int C, int H, int I,
+                        void* ws, size_t ws_bytes, void* stream) {
+    if (ws_bytes < gecco_pool_attn_workspace_bytes(B, N, C, H, I)) return fail(-7, "pool_attn: workspace too small");
+    Carver c(ws);
+    const int ns = pool_attn_nsplit(B, N, H);
+    float* po = c.f32((size_t)B * H * ns * 64 * (C / H));
+    float* pml = c.f32((size_t)B * H * ns * 64 * 2);
+    TRY(pool_attn_launch(KV, inducers, po, pml, merged, B, N, C, H, I, ns, (hipStream_t)stream), "pool_attn");
+    return 0;
+}
+
+int gecco_unpool_attn_f32(const float* q, const float* kvh, float* out, int B, int N, int C, int H, int I,
+                          void* stream) {
+    TRY(unpool_attn_launch(q, kvh, out, B, N, C, H, I, (hipStream_t)stream), "unpool_attn");
+    return 0;
+}
+
+int gecco_edm_coeffs_f32(const float* sigma, float sigma_data, float* coef, int B, void* stream) {
+    TRY(edm_coeffs_launch(sigma, sigma_data, coef, B, (hipStream_t)stream), "edm_coeffs");
+    return 0;
+}
+
+int gecco_lift_f32(const float* x, const float* coef, const float* W, const float* bias, float* out, float* stats,
+                   int B, int N, int C, void* stream) {
+    TRY(lift_launch(x, coef, W, bias, out, stats, B, N, C, (hipStream_t)stream), "lift");
+    return 0;
+}
+
+int gecco_lower_edm_f32(const float* feat, const float* x, const float* coef, const float* W, const float* bias,
+                        const float* gn_a, const float* gn_o, float* out, float* raw, int B, int N, int C, float eps,
+                        void* stream) {
+    if (coef && !x) return fail(-1, "lower_edm: x required with coef");
+    TRY(lower_edm_launch(feat, x, coef, W, bias, gn_a, gn_o, out, raw, B, N, C, eps, (hipStream_t)stream), "lower_edm");
+    return 0;
+}
+
+size_t gecco_set_transformer_workspace_bytes(const GeccoSetTransformer* st, int B, int N) {
+    return carve_st(st, B, N, nullptr).bytes;
+}
+
+int gecco_set_transformer_fwd_f32(const GeccoSetTransformer* st, float* x, const float* t, const float* stats_x,
+                                  int stats_T, const float* const* h_in, float* const* h_out, float* stats_out,
+                                  int B, int N, void* ws, size_t ws_bytes, void* stream) {
+    return st_forward(st, x, t, stats_x, stats_T, h_in, h_out, stats_out, B, N, ws, ws_bytes, (hipStream_t)stream);
+}
+
+size_t gecco_linear_lift_workspace_bytes(const GeccoLinearLift* m, int B, int N) {
+    return carve_ll(m, B, N, nullptr).bytes;
+}
+
+int gecco_linear_lift_fwd_f32(const GeccoLinearLift* m, const float* x, const float* sigma, float* denoised,
+                              float* raw, const float* const* h_in, float* const* h_out, int B, int N, void* ws,
+                              size_t ws_bytes, void* stream) {
+    if (!m || !x || !sigma || !(denoised || raw)) return fail(-1, "linear_lift: null argument");
+    LLWorkspace w = carve_ll(m, B, N, ws);
+    if (ws_bytes < w.bytes) return fail(-7, "linear_lift: workspace too small (%zu < %zu)", ws_bytes, w.bytes);
+    hipStream_t s = (hipStream_t)stream;
+    const int C = m->inner.C;
+    TRY(edm_coeffs_launch(sigma, m->sigma_data, w.coef, B, s), "edm_coeffs");
+    TRY(lift_launch(x, w.coef, m->lift_w, m->lift_b, w.feat, w.stats, B, N, C, s), "lift");
+    // AdaGN reads t as a packed (B, ctx_dim) array; under EDMPrecond ctx_dim == 1 and t = c_noise,
+    // which edm_coeffs also writes packed at coef[4B .. 5B).
+    if (m->inner.ctx_dim != 1) return fail(-3, "linear_lift: t_embed_dim must be 1 under EDMPrecond");
+    int rc = st_forward(&m->inner, w.feat, w.coef + 4 * (size_t)B, w.stats, row_tiles_stats(N), h_in, h_out, nullptr, B,
+                        N, w.st_ws, w.st_bytes, s);
+    if (rc) return rc;
+    TRY(lower_edm_launch(w.feat, x, w.coef, m->lower_w, m->lower_b, nullptr, nullptr, denoised, raw, B, N, C, 1e-5f, s),
+        "lower_edm");
+    return 0;
+}
+
+}  // extern "C"

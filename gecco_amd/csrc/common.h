@@ -1,0 +1,33 @@
+// Shared device helpers for the gfx950 (MI355X) GECCO kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define GECCO_WAVE 64
+
+// Row of accumulator register `reg` (0..15) for lane-half `h` of a 32x32 MFMA tile
+// (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)).
+__device__ __forceinline__ int mfma_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// D = A(32xK=2) * B(2x32) + C, exact fp32 (v_mfma_f32_32x32x2_f32).
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
+
+// Blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous chunk of the virtual
+// grid so neighbouring tiles (which share an operand panel) hit the same L2.  Bijective for any n.
+__device__ __forceinline__ int xcd_remap(int bid, int n) {
+    const int q = n >> 3, r = n & 7, x = bid & 7, k = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
+// GaussianActivation (reference models/activation.py:17-24): (exp(-u^2/(2 a^2)) - 0.7)/0.28
+__device__ __forceinline__ float gauss_act(float u, float neg_inv_2a2, bool normalized) {
+    float y = __expf(u * u * neg_inv_2a2);
+    return normalized ? (y - 0.7f) / 0.28f : y;
+}

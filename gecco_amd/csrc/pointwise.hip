@@ -1,0 +1,249 @@
+// HBM-bound pointwise / reduction kernels of the GECCO denoiser (gfx950): GroupNorm statistics,
+// AdaGN coefficient finalisation, EDM preconditioning, lift (3 -> d) and lower (d -> 3).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int STATS_ROWS = 128;  // row-tile height of the stand-alone / lift statistics producers
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- column statistics of a (B, rows, C) tensor: stats[b][tile][{sum,sumsq}][c]
+// Used where no producer epilogue exists (unit-level AdaGN, cached-mode first touch).
+__global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ x, float* __restrict__ stats,
+                                                        int rows, int C, int T) {
+    const int tile = blockIdx.x % T, b = blockIdx.x / T;
+    const int m0 = tile * STATS_ROWS, m1 = min(rows, m0 + STATS_ROWS);
+    const float* xb = x + (size_t)b * rows * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int m = m0; m < m1; ++m) {
+            const float v = xb[(size_t)m * C + c];
+            s1 += v;
+            s2 += v * v;
+        }
+        stats[(((size_t)b * T + tile) * 2 + 0) * C + c] = s1;
+        stats[(((size_t)b * T + tile) * 2 + 1) * C + c] = s2;
+    }
+}
+
+// ---- AdaGN coefficients (reference models/normalization.py:36-44 folded into y = a*x + o):
+//   mean/var per (b, group) over rows * C/G elements (biased), rstd = 1/sqrt(var + eps)
+//   s = t . scale_w[c] + scale_b[c],  z = t . bias_w[c] + bias_b[c]
+//   a[b,c] = s * rstd,  o[b,c] = z - s * mean * rstd
+// With null scale/bias weights: plain GroupNorm(affine=False) (GroupNormBNC, models/ray.py:20-30).
+// Partial sums are fp32 per tile, combined in fp64 (E[x^2] - mean^2 cancellation stays < 1e-7).
+__global__ __launch_bounds__(256) void adagn_coeffs_kernel(const float* __restrict__ stats, int T, int rows,
+                                                           const float* __restrict__ t, int ctx_dim,
+                                                           const float* __restrict__ scale_w,
+                                                           const float* __restrict__ scale_b,
+                                                           const float* __restrict__ bias_w,
+                                                           const float* __restrict__ bias_b, float* __restrict__ a,
+                                                           float* __restrict__ o, int C, int G, float eps) {
+    extern __shared__ double dsm[];  // [2][C] column sums, then [2][G] mean / rstd
+    double* cs = dsm;
+    double* gm = dsm + 2 * C;
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < T; ++k) {
+            s1 += (double)stats[(((size_t)b * T + k) * 2 + 0) * C + c];
+            s2 += (double)stats[(((size_t)b * T + k) * 2 + 1) * C + c];
+        }
+        cs[c] = s1;
+        cs[C + c] = s2;
+    }
+    __syncthreads();
+    const int cpg = C / G;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+            s1 += cs[c];
+            s2 += cs[C + c];
+        }
+        const double n = (double)rows * cpg;
+        const double mean = s1 / n;
+        double var = s2 / n - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        gm[g] = mean;
+        gm[G + g] = 1.0 / sqrt(var + (double)eps);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g = c / cpg;
+        const float mean = (float)gm[g], rstd = (float)gm[G + g];
+        float s = 1.f, z = 0.f;
+        if (scale_w) {
+            s = scale_b[c];
+            z = bias_b[c];
+            for (int j = 0; j < ctx_dim; ++j) {
+                const float tj = t[(size_t)b * ctx_dim + j];
+                s += tj * scale_w[(size_t)c * ctx_dim + j];
+                z += tj * bias_w[(size_t)c * ctx_dim + j];
+            }
+        }
+        a[(size_t)b * C + c] = s * rstd;
+        o[(size_t)b * C + c] = z - s * mean * rstd;
+    }
+}
+
+// ---- y[b,m,c] = a[b,c] * x[b,m,c] + o[b,c]   (stand-alone AdaGN apply; inducer states h)
+__global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restrict__ x, const float* __restrict__ a,
+                                                           const float* __restrict__ o, float* __restrict__ y,
+                                                           size_t total4, int rowsC4, int C4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / rowsC4;
+        const int c4 = (int)(i % C4);
+        const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+        const f32x4 av = reinterpret_cast<const f32x4*>(a)[b * C4 + c4];
+        const f32x4 ov = reinterpret_cast<const f32x4*>(o)[b * C4 + c4];
+        reinterpret_cast<f32x4*>(y)[i] = xv * av + ov;
+    }
+}
+
+// ---- EDM preconditioning coefficients (reference diffusion.py:46-51):
+// coef[4b .. 4b+3] = {c_skip, c_out, c_in, c_noise}; coef[4B + b] = c_noise again, packed (the AdaGN `t`).
+__global__ void edm_coeffs_kernel(const float* __restrict__ sigma, float sd, float* __restrict__ coef, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float s = sigma[b];
+    const float q = s * s + sd * sd;
+    coef[4 * b + 0] = sd * sd / q;
+    coef[4 * b + 1] = s * sd / sqrtf(q);
+    coef[4 * b + 2] = 1.0f / sqrtf(sd * sd + s * s);
+    coef[4 * b + 3] = logf(s) / 4.0f;
+    coef[4 * B + b] = logf(s) / 4.0f;
+}
+
+// ---- lift: out[b,m,:] = (c_in[b] * x[b,m,:3]) @ W^T + bias   (reference linear_lift.py:44 with
+// diffusion.py:54; also RayNetwork.xyz_embed, models/ray.py:99) + column statistics of the result.
+// One block = one (sample, 128-row tile); thread = channel (coalesced 4-byte stores along c).
+__global__ __launch_bounds__(256) void lift_kernel(const float* __restrict__ x, const float* __restrict__ coef,
+                                                   const float* __restrict__ W, const float* __restrict__ bias,
+                                                   float* __restrict__ out, float* __restrict__ stats, int N, int C,
+                                                   int T) {
+    __shared__ float xs[STATS_ROWS * 3];
+    const int tile = blockIdx.x % T, b = blockIdx.x / T;
+    const int m0 = tile * STATS_ROWS, m1 = min(N, m0 + STATS_ROWS);
+    const float cin = coef ? coef[4 * b + 2] : 1.0f;
+    for (int i = threadIdx.x; i < (m1 - m0) * 3; i += blockDim.x) xs[i] = cin * x[((size_t)b * N + m0) * 3 + i];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float w0 = W[c * 3 + 0], w1 = W[c * 3 + 1], w2 = W[c * 3 + 2], bb = bias[c];
+        float s1 = 0.f, s2 = 0.f;
+        for (int m = 0; m < m1 - m0; ++m) {
+            // same association as F.linear's dot product order: ((x0*w0 + x1*w1) + x2*w2) + b
+            const float v = xs[m * 3 + 0] * w0 + xs[m * 3 + 1] * w1 + xs[m * 3 + 2] * w2 + bb;
+            out[((size_t)b * N + m0 + m) * C + c] = v;
+            s1 += v;
+            s2 += v * v;
+        }
+        if (stats) {
+            stats[(((size_t)b * T + tile) * 2 + 0) * C + c] = s1;
+            stats[(((size_t)b * T + tile) * 2 + 1) * C + c] = s2;
+        }
+    }
+}
+
+// ---- lower + EDM combine: one wave per point.
+//   LinearLift: F = Linear(d->3)(LayerNorm_d(feat))                 (reference linear_lift.py:25-29,46)
+//   RayNetwork: F = Linear(d->3)(gn_a[b,:] * feat + gn_o[b,:])      (GroupNormBNC(16), models/ray.py:56-59,120)
+//   D = c_skip * x + c_out * F                                      (diffusion.py:57)
+__global__ __launch_bounds__(256) void lower_edm_kernel(const float* __restrict__ feat, const float* __restrict__ x,
+                                                        const float* __restrict__ coef, const float* __restrict__ W,
+                                                        const float* __restrict__ bias,
+                                                        const float* __restrict__ gn_a,
+                                                        const float* __restrict__ gn_o, float* __restrict__ out,
+                                                        float* __restrict__ raw, int B, int N, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (size_t)B * N) return;
+    const int b = (int)(row / N);
+    const float* f = feat + row * C;
+    float mean = 0.f, rstd = 1.f;
+    if (!gn_a) {
+        float s1 = 0.f;
+        for (int c = lane; c < C; c += 64) s1 += f[c];
+        mean = wave_sum(s1) / C;
+        float s2 = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float d = f[c] - mean;
+            s2 += d * d;
+        }
+        rstd = rsqrtf(wave_sum(s2) / C + eps);
+    }
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float v = gn_a ? f[c] * gn_a[(size_t)b * C + c] + gn_o[(size_t)b * C + c] : (f[c] - mean) * rstd;
+        a0 += v * W[c];
+        a1 += v * W[C + c];
+        a2 += v * W[2 * C + c];
+    }
+    a0 = wave_sum(a0);
+    a1 = wave_sum(a1);
+    a2 = wave_sum(a2);
+    if (lane < 3) {
+        const float Fv = (lane == 0 ? a0 : lane == 1 ? a1 : a2) + bias[lane];
+        if (raw) raw[row * 3 + lane] = Fv;
+        if (out) {
+            const float cs = coef ? coef[4 * b + 0] : 0.f, co = coef ? coef[4 * b + 1] : 1.f;
+            out[row * 3 + lane] = coef ? cs * x[row * 3 + lane] + co * Fv : Fv;
+        }
+    }
+}
+
+}  // namespace
+
+int stats_row_tile(int rows) { (void)rows; return STATS_ROWS; }
+
+int col_stats_launch(const float* x, float* stats, int B, int rows, int C, hipStream_t st) {
+    const int T = (rows + STATS_ROWS - 1) / STATS_ROWS;
+    hipLaunchKernelGGL(col_stats_kernel, dim3(B * T), dim3(256), 0, st, x, stats, rows, C, T);
+    return (int)hipGetLastError();
+}
+
+int adagn_coeffs_launch(const float* stats, int T, int rows, const float* t, int ctx_dim, const float* scale_w,
+                        const float* scale_b, const float* bias_w, const float* bias_b, float* a, float* o, int B,
+                        int C, int G, float eps, hipStream_t st) {
+    if (C % G) return -5;
+    const size_t lds = (size_t)(2 * C + 2 * G) * sizeof(double);
+    hipLaunchKernelGGL(adagn_coeffs_kernel, dim3(B), dim3(256), lds, st, stats, T, rows, t, ctx_dim, scale_w, scale_b,
+                       bias_w, bias_b, a, o, C, G, eps);
+    return (int)hipGetLastError();
+}
+
+int affine_apply_launch(const float* x, const float* a, const float* o, float* y, int B, int rows, int C,
+                        hipStream_t st) {
+    if (C % 4) return -2;
+    const size_t total4 = (size_t)B * rows * C / 4;
+    const unsigned grid = (unsigned)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(affine_apply_kernel, dim3(grid ? grid : 1), dim3(256), 0, st, x, a, o, y, total4, rows * C / 4,
+                       C / 4);
+    return (int)hipGetLastError();
+}
+
+int edm_coeffs_launch(const float* sigma, float sigma_data, float* coef, int B, hipStream_t st) {
+    hipLaunchKernelGGL(edm_coeffs_kernel, dim3((B + 63) / 64), dim3(64), 0, st, sigma, sigma_data, coef, B);
+    return (int)hipGetLastError();
+}
+
+int lift_launch(const float* x, const float* coef, const float* W, const float* bias, float* out, float* stats, int B,
+                int N, int C, hipStream_t st) {
+    const int T = (N + STATS_ROWS - 1) / STATS_ROWS;
+    hipLaunchKernelGGL(lift_kernel, dim3(B * T), dim3(256), 0, st, x, coef, W, bias, out, stats, N, C, T);
+    return (int)hipGetLastError();
+}
+
+int lower_edm_launch(const float* feat, const float* x, const float* coef, const float* W, const float* bias,
+                     const float* gn_a, const float* gn_o, float* out, float* raw, int B, int N, int C, float eps,
+                     hipStream_t st) {
+    const size_t rows = (size_t)B * N;
+    hipLaunchKernelGGL(lower_edm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, feat, x, coef, W, bias,
+                       gn_a, gn_o, out, raw, B, N, C, eps);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,272 @@
+"""Tensor-level wrappers over the C ABI (include/gecco_hip.h).
+
+PyTorch is used for device memory and the current HIP stream only; every FLOP runs in
+libgecco_hip.so.  All wrappers raise on non-HIP / non-fp32 / non-contiguous tensors — there is
+no fallback path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Mapping, Sequence
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import GeccoAdaGN, GeccoLayer, GeccoLinearLift, GeccoMLP, GeccoSetTransformer, check
+
+GN_EPS = 1e-5
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Tensor | None) -> C.c_void_p:
+    if t is None:
+        return C.c_void_p(0)
+    if not t.is_cuda:
+        raise _lib.GeccoHipError("gecco_amd operators need tensors on the HIP device (no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise _lib.GeccoHipError(f"expected float32, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.GeccoHipError("expected a contiguous tensor")
+    return C.c_void_p(t.data_ptr())
+
+
+def _ws(nbytes: int, device) -> Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------------------- unit operators
+def linear(A: Tensor, W: Tensor, bias: Tensor | None = None, pro: tuple[Tensor, Tensor] | None = None,
+           act_alpha: Tensor | None = None, residual: Tensor | None = None, want_stats: bool = False,
+           normalized: bool = True, out: Tensor | None = None):
+    """C = residual + act((A*pro_a + pro_o) @ W^T + bias) on (B, rows, K) x (Nout, K)."""
+    lib = _lib.load()
+    B, rows, K = A.shape
+    Nout = W.shape[0]
+    assert W.shape[1] == K
+    out = torch.empty(B, rows, Nout, device=A.device, dtype=torch.float32) if out is None else out
+    stats = None
+    if want_stats:
+        stats = torch.empty(B, lib.gecco_linear_row_tiles(rows), 2, Nout, device=A.device, dtype=torch.float32)
+    act = 0 if act_alpha is None else (1 if normalized else 2)
+    check(lib.gecco_linear_f32(_ptr(A), _ptr(W), _ptr(bias), _ptr(pro[0]) if pro else None,
+                               _ptr(pro[1]) if pro else None, _ptr(act_alpha), _ptr(residual), _ptr(out), _ptr(stats),
+                               B, rows, K, Nout, act, _stream()), "gecco_linear_f32")
+    return (out, stats) if want_stats else out
+
+
+def col_stats(x: Tensor) -> Tensor:
+    lib = _lib.load()
+    B, rows, Cc = x.shape
+    stats = torch.empty(B, lib.gecco_stats_row_tiles(rows), 2, Cc, device=x.device, dtype=torch.float32)
+    check(lib.gecco_col_stats_f32(_ptr(x), _ptr(stats), B, rows, Cc, _stream()), "gecco_col_stats_f32")
+    return stats
+
+
+def _adagn_struct(scale_w, scale_b, bias_w, bias_b) -> GeccoAdaGN:
+    return GeccoAdaGN(_ptr(scale_w), _ptr(scale_b), _ptr(bias_w), _ptr(bias_b))
+
+
+def adagn_coeffs(stats: Tensor, rows: int, t: Tensor | None, params: Sequence[Tensor] | None, G: int,
+                 eps: float = GN_EPS):
+    """(a, o) with AdaGN(x) = a*x + o.  params = (scale.weight, scale.bias, bias.weight, bias.bias) or
+    None for a plain GroupNorm."""
+    lib = _lib.load()
+    B, T, _, Cc = stats.shape
+    a = torch.empty(B, Cc, device=stats.device, dtype=torch.float32)
+    o = torch.empty_like(a)
+    st = _adagn_struct(*params) if params is not None else None
+    ctx = 0 if t is None else t.shape[-1]
+    check(lib.gecco_adagn_coeffs_f32(_ptr(stats), T, rows, _ptr(t), ctx, C.byref(st) if st is not None else None,
+                                     _ptr(a), _ptr(o), B, Cc, G, eps, _stream()), "gecco_adagn_coeffs_f32")
+    return a, o
+
+
+def affine_apply(x: Tensor, a: Tensor, o: Tensor) -> Tensor:
+    lib = _lib.load()
+    B, rows, Cc = x.shape
+    y = torch.empty_like(x)
+    check(lib.gecco_affine_apply_f32(_ptr(x), _ptr(a), _ptr(o), _ptr(y), B, rows, Cc, _stream()),
+          "gecco_affine_apply_f32")
+    return y
+
+
+def adagn(x: Tensor, t: Tensor | None, params: Sequence[Tensor] | None, G: int, eps: float = GN_EPS) -> Tensor:
+    """AdaGN.forward (or GroupNormBNC when params is None) on (B, rows, C)."""
+    lib = _lib.load()
+    B, rows, Cc = x.shape
+    y = torch.empty_like(x)
+    nb = lib.gecco_adagn_workspace_bytes(B, rows, Cc)
+    ws = _ws(nb, x.device)
+    st = _adagn_struct(*params) if params is not None else None
+    t2 = None if t is None else t.reshape(B, -1).contiguous()
+    ctx = 0 if t2 is None else t2.shape[-1]
+    check(lib.gecco_adagn_f32(_ptr(x), _ptr(t2), ctx, C.byref(st) if st is not None else None, _ptr(y), B, rows, Cc,
+                              G, eps, C.c_void_p(ws.data_ptr()), nb, _stream()), "gecco_adagn_f32")
+    return y
+
+
+def pool_attn(KV: Tensor, inducers: Tensor, H: int) -> Tensor:
+    """AttentionPool core: KV (B, N, 2C), inducers (1, H, I, hd) -> (B, I, C) merged heads (before out_proj)."""
+    lib = _lib.load()
+    B, N, C2 = KV.shape
+    Cc = C2 // 2
+    I = inducers.shape[-2]
+    merged = torch.empty(B, I, Cc, device=KV.device, dtype=torch.float32)
+    nb = lib.gecco_pool_attn_workspace_bytes(B, N, Cc, H, I)
+    ws = _ws(nb, KV.device)
+    check(lib.gecco_pool_attn_f32(_ptr(KV), _ptr(inducers), _ptr(merged), B, N, Cc, H, I, C.c_void_p(ws.data_ptr()),
+                                  nb, _stream()), "gecco_pool_attn_f32")
+    return merged
+
+
+def unpool_attn(q: Tensor, kvh: Tensor, H: int) -> Tensor:
+    lib = _lib.load()
+    B, N, Cc = q.shape
+    I = kvh.shape[1]
+    out = torch.empty_like(q)
+    check(lib.gecco_unpool_attn_f32(_ptr(q), _ptr(kvh), _ptr(out), B, N, Cc, H, I, _stream()), "gecco_unpool_attn_f32")
+    return out
+
+
+def edm_coeffs(sigma: Tensor, sigma_data: float = 1.0) -> Tensor:
+    lib = _lib.load()
+    B = sigma.numel()
+    coef = torch.empty(5 * B, device=sigma.device, dtype=torch.float32)
+    check(lib.gecco_edm_coeffs_f32(_ptr(sigma), sigma_data, _ptr(coef), B, _stream()), "gecco_edm_coeffs_f32")
+    return coef
+
+
+def lift(x: Tensor, coef: Tensor | None, W: Tensor, bias: Tensor, want_stats: bool = False):
+    lib = _lib.load()
+    B, N, three = x.shape
+    assert three == 3 and W.shape[1] == 3
+    Cc = W.shape[0]
+    out = torch.empty(B, N, Cc, device=x.device, dtype=torch.float32)
+    stats = torch.empty(B, lib.gecco_stats_row_tiles(N), 2, Cc, device=x.device, dtype=torch.float32) if want_stats else None
+    check(lib.gecco_lift_f32(_ptr(x), _ptr(coef), _ptr(W), _ptr(bias), _ptr(out), _ptr(stats), B, N, Cc, _stream()),
+          "gecco_lift_f32")
+    return (out, stats) if want_stats else out
+
+
+def lower_edm(feat: Tensor, x: Tensor | None, coef: Tensor | None, W: Tensor, bias: Tensor,
+              gn: tuple[Tensor, Tensor] | None = None, want_raw: bool = False, eps: float = GN_EPS):
+    lib = _lib.load()
+    B, N, Cc = feat.shape
+    out = torch.empty(B, N, 3, device=feat.device, dtype=torch.float32)
+    raw = torch.empty_like(out) if want_raw else None
+    check(lib.gecco_lower_edm_f32(_ptr(feat), _ptr(x), _ptr(coef), _ptr(W), _ptr(bias), _ptr(gn[0]) if gn else None,
+                                  _ptr(gn[1]) if gn else None, _ptr(out), _ptr(raw), B, N, Cc, eps, _stream()),
+          "gecco_lower_edm_f32")
+    return (out, raw) if want_raw else out
+
+
+# ------------------------------------------------------------------------------- parameter tables
+def _adagn_from(p: Mapping[str, Tensor], pre: str) -> GeccoAdaGN:
+    return _adagn_struct(p[pre + "scale.weight"], p[pre + "scale.bias"], p[pre + "bias.weight"], p[pre + "bias.bias"])
+
+
+def _mlp_from(p: Mapping[str, Tensor], pre: str) -> GeccoMLP:
+    return GeccoMLP(_ptr(p[pre + "0.weight"]), _ptr(p[pre + "0.bias"]), _ptr(p[pre + "1.alpha"]),
+                    _ptr(p[pre + "2.weight"]), _ptr(p[pre + "2.bias"]))
+
+
+def layer_table(p: Mapping[str, Tensor], pre: str) -> GeccoLayer:
+    """One BroadcastingLayer's device pointers, keyed like the reference state dict."""
+    return GeccoLayer(
+        _adagn_from(p, pre + "broadcast_norm."), _ptr(p[pre + "broadcast.pool.inducers"]),
+        _ptr(p[pre + "broadcast.pool.kv_proj.weight"]), _ptr(p[pre + "broadcast.pool.out_proj.weight"]),
+        _adagn_from(p, pre + "broadcast.norm_1."), _mlp_from(p, pre + "broadcast.mlp."),
+        _adagn_from(p, pre + "broadcast.norm_2."), _ptr(p[pre + "broadcast.unpool.in_proj_weight"]),
+        _ptr(p[pre + "broadcast.unpool.in_proj_bias"]), _ptr(p[pre + "broadcast.unpool.out_proj.weight"]),
+        _ptr(p[pre + "broadcast.unpool.out_proj.bias"]), _adagn_from(p, pre + "mlp_norm."), _mlp_from(p, pre + "mlp."))
+
+
+class SetTransformerPlan:
+    """Host-side parameter table + workspace cache for gecco_set_transformer_fwd_f32.  Holds references to the
+    parameter tensors so the raw pointers stay valid; rebuild it if parameters are re-allocated."""
+
+    def __init__(self, p: Mapping[str, Tensor], pre: str, H: int, I: int = 64, G: int = 32, normalized: bool = True):
+        self.lib = _lib.load()
+        self.p = p  # keep tensors alive
+        L = 0
+        while f"{pre}layers.{L}.mlp.0.weight" in p:
+            L += 1
+        if L == 0:
+            raise KeyError(f"no layers under prefix {pre!r}")
+        w0 = p[f"{pre}layers.0.mlp.0.weight"]
+        self.width, self.C = w0.shape
+        self.L, self.H, self.I, self.G = L, H, I, G
+        self.ctx_dim = p[f"{pre}layers.0.mlp_norm.scale.weight"].shape[1]
+        self.device = w0.device
+        self._layers = (GeccoLayer * L)(*[layer_table(p, f"{pre}layers.{i}.") for i in range(L)])
+        self.table = GeccoSetTransformer(L, self.C, H, I, self.ctx_dim, G, self.width, 1 if normalized else 2,
+                                         self._layers)
+        self._ws: dict[tuple[int, int], Tensor] = {}
+
+    def workspace(self, B: int, N: int) -> Tensor:
+        key = (B, N)
+        if key not in self._ws:
+            self._ws[key] = _ws(self.lib.gecco_set_transformer_workspace_bytes(C.byref(self.table), B, N), self.device)
+        return self._ws[key]
+
+    @staticmethod
+    def _ptr_array(ts: Sequence[Tensor | None] | None, L: int):
+        if ts is None:
+            return None
+        assert len(ts) == L
+        return (C.c_void_p * L)(*[(t.data_ptr() if t is not None else 0) for t in ts])
+
+    def forward_(self, x: Tensor, t: Tensor, stats: Tensor | None = None, hs: Sequence[Tensor | None] | None = None,
+                 return_h: bool = False, want_stats_out: bool = False):
+        """In place on x (B, N, C).  Returns (x, hs_out | None, stats_out | None)."""
+        B, N, Cc = x.shape
+        assert Cc == self.C
+        ws = self.workspace(B, N)
+        t2 = t.reshape(B, -1).contiguous()
+        h_out = [torch.empty(B, self.I, Cc, device=x.device, dtype=torch.float32) for _ in range(self.L)] if return_h else None
+        if return_h and hs is not None:  # layers with a cached h just hand it back (reference semantics)
+            h_out = [h if h is not None else o for h, o in zip(hs, h_out)]
+        so = torch.empty(B, self.lib.gecco_linear_row_tiles(N), 2, Cc, device=x.device, dtype=torch.float32) if want_stats_out else None
+        hin = self._ptr_array(hs, self.L)
+        hout = self._ptr_array([None if (hs is not None and hs[i] is not None) else h_out[i] for i in range(self.L)], self.L) if return_h else None
+        check(self.lib.gecco_set_transformer_fwd_f32(
+            C.byref(self.table), _ptr(x), _ptr(t2), _ptr(stats), 0 if stats is None else stats.shape[1],
+            hin, hout, _ptr(so), B, N, C.c_void_p(ws.data_ptr()), ws.numel(), _stream()), "gecco_set_transformer_fwd_f32")
+        return x, h_out, so
+
+
+class LinearLiftPlan:
+    """EDMPrecond(LinearLift(SetTransformer)) = the unconditional Diffusion.forward, one C call."""
+
+    def __init__(self, p: Mapping[str, Tensor], H: int, I: int = 64, pre: str = "", sigma_data: float = 1.0):
+        self.st = SetTransformerPlan(p, pre + "inner.", H, I)
+        self.p = p
+        self.lib = self.st.lib
+        self.table = GeccoLinearLift(self.st.table, _ptr(p[pre + "lift.weight"]), _ptr(p[pre + "lift.bias"]),
+                                     _ptr(p[pre + "lower.1.weight"]), _ptr(p[pre + "lower.1.bias"]), sigma_data)
+        self._ws: dict[tuple[int, int], Tensor] = {}
+
+    def workspace(self, B: int, N: int) -> Tensor:
+        key = (B, N)
+        if key not in self._ws:
+            self._ws[key] = _ws(self.lib.gecco_linear_lift_workspace_bytes(C.byref(self.table), B, N), self.st.device)
+        return self._ws[key]
+
+    def forward(self, x: Tensor, sigma: Tensor, return_raw: bool = False, cache: Sequence[Tensor] | None = None,
+                do_cache: bool = False, out: Tensor | None = None):
+        B, N, _ = x.shape
+        ws = self.workspace(B, N)
+        den = torch.empty_like(x) if out is None else out
+        raw = torch.empty_like(x) if return_raw else None
+        L = self.st.L
+        h_out = [torch.empty(B, self.st.I, self.st.C, device=x.device, dtype=torch.float32) for _ in range(L)] if do_cache else None
+        check(self.lib.gecco_linear_lift_fwd_f32(
+            C.byref(self.table), _ptr(x), _ptr(sigma), _ptr(den), _ptr(raw), self.st._ptr_array(cache, L),
+            self.st._ptr_array(h_out, L), B, N, C.c_void_p(ws.data_ptr()), ws.numel(), _stream()),
+            "gecco_linear_lift_fwd_f32")
+        res = (den, raw) if return_raw else den
+        return (res, h_out) if do_cache else res

@@ -1,0 +1,149 @@
+/* gecco_hip.h — C ABI of libgecco_hip.so: the MI355X (gfx950) implementation of the GECCO
+ * denoiser hot path.
+ *
+ * The reference (cvlab-epfl/gecco, gecco-torch) has no FFI/plugin layer: its extension surface
+ * is "Python that constructs nn.Modules".  This header is therefore the boundary a maintainer
+ * binds (ctypes stub in INTEGRATION.md) underneath the same-named Python modules; every entry
+ * point cites the reference code it replaces (paths relative to
+ * gecco-torch/src/gecco_torch/).
+ *
+ * Conventions
+ *  - all pointers are raw DEVICE pointers to contiguous fp32 (fp64 where the name says so);
+ *    activations are channels-last (B, n, C) row-major, weights are nn.Linear layout (out, in);
+ *  - `stream` is a hipStream_t (0 = default stream); calls only enqueue work: no allocation, no
+ *    synchronisation, no host reads — they are hipGraph-capture safe;
+ *  - scratch memory is caller-provided (`ws`, size from the matching *_workspace_bytes());
+ *  - return value 0 = success; negative = argument error (see gecco_last_error()); positive =
+ *    hipError_t of the launch.
+ */
+#ifndef GECCO_HIP_H
+#define GECCO_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GECCO_ABI_VERSION 1
+
+int gecco_abi_version(void);
+const char* gecco_build_arch(void);   /* "gfx950" */
+const char* gecco_last_error(void);   /* thread-local description of the last non-zero return */
+
+/* ---- parameter tables (device pointers into the module's own state-dict tensors) ------------ */
+typedef struct GeccoAdaGN {   /* AdaGN, models/normalization.py:14-44 */
+    const float* scale_w;     /* scale.weight (C, ctx_dim) */
+    const float* scale_b;     /* scale.bias   (C)          */
+    const float* bias_w;      /* bias.weight  (C, ctx_dim) */
+    const float* bias_b;      /* bias.bias    (C)          */
+} GeccoAdaGN;
+
+typedef struct GeccoMLP {     /* MLP(depth=1) + GaussianActivation, models/mlp.py:5-39, activation.py */
+    const float* w0;          /* 0.weight (width, C) */
+    const float* b0;          /* 0.bias   (width)    */
+    const float* alpha;       /* 1.alpha  ()         */
+    const float* w2;          /* 2.weight (C, width) */
+    const float* b2;          /* 2.bias   (C)        */
+} GeccoMLP;
+
+typedef struct GeccoLayer {   /* BroadcastingLayer, models/set_transformer.py:120-168 */
+    GeccoAdaGN broadcast_norm;
+    const float* inducers;    /* broadcast.pool.inducers (1, H, I, hd)   */
+    const float* kv_proj_w;   /* broadcast.pool.kv_proj.weight (2C, C)   */
+    const float* pool_out_w;  /* broadcast.pool.out_proj.weight (C, C)   */
+    GeccoAdaGN norm_1;
+    GeccoMLP bmlp;            /* broadcast.mlp */
+    GeccoAdaGN norm_2;
+    const float* in_proj_w;   /* broadcast.unpool.in_proj_weight (3C, C) */
+    const float* in_proj_b;   /* broadcast.unpool.in_proj_bias (3C)      */
+    const float* unpool_out_w;/* broadcast.unpool.out_proj.weight (C, C) */
+    const float* unpool_out_b;/* broadcast.unpool.out_proj.bias (C)      */
+    GeccoAdaGN mlp_norm;
+    GeccoMLP mlp;
+} GeccoLayer;
+
+typedef struct GeccoSetTransformer {  /* SetTransformer, models/set_transformer.py:171-216 */
+    int n_layers, C, H, I, ctx_dim, G, width, act;  /* act: 1 GaussianActivation(normalized) 2 raw */
+    const GeccoLayer* layers;                       /* HOST array of n_layers tables */
+} GeccoSetTransformer;
+
+/* ---- unit operators --------------------------------------------------------------------- */
+
+/* C = residual + act((A*pro_a + pro_o) @ W^T + bias); optional GroupNorm partial statistics of C.
+ * Replaces nn.Linear call sites of models/set_transformer.py:49,65,112,165-166 and models/mlp.py.
+ * stats: (B, T, 2, Nout) with T = gecco_linear_row_tiles(rows).  Any of bias/pro/alpha/residual/stats
+ * may be NULL. */
+int gecco_linear_f32(const float* A, const float* W, const float* bias, const float* pro_a, const float* pro_o,
+                     const float* alpha, const float* residual, float* C, float* stats, int B, int rows, int K,
+                     int Nout, int act, void* stream);
+int gecco_linear_row_tiles(int rows);
+
+/* GroupNorm partial statistics of x (B, rows, C): stats (B, T, 2, C), T = gecco_stats_row_tiles(rows). */
+int gecco_col_stats_f32(const float* x, float* stats, int B, int rows, int C, void* stream);
+int gecco_stats_row_tiles(int rows);
+
+/* AdaGN folded to y = a*x + o (models/normalization.py:36-44); p == NULL -> plain GroupNorm (models/ray.py:20-30).
+ * t: (B, ctx_dim).  a, o: (B, C). */
+int gecco_adagn_coeffs_f32(const float* stats, int T, int rows, const float* t, int ctx_dim, const GeccoAdaGN* p,
+                           float* a, float* o, int B, int C, int G, float eps, void* stream);
+int gecco_affine_apply_f32(const float* x, const float* a, const float* o, float* y, int B, int rows, int C,
+                           void* stream);
+/* Full AdaGN.forward: y = AdaGN(x, t).  ws >= gecco_adagn_workspace_bytes(B, rows, C). */
+int gecco_adagn_f32(const float* x, const float* t, int ctx_dim, const GeccoAdaGN* p, float* y, int B, int rows,
+                    int C, int G, float eps, void* ws, size_t ws_bytes, void* stream);
+size_t gecco_adagn_workspace_bytes(int B, int rows, int C);
+
+/* AttentionPool core (models/set_transformer.py:47-63, without out_proj): KV (B, N, 2C) -> merged (B, I, C). */
+int gecco_pool_attn_f32(const float* KV, const float* inducers, float* merged, int B, int N, int C, int H, int I,
+                        void* ws, size_t ws_bytes, void* stream);
+size_t gecco_pool_attn_workspace_bytes(int B, int N, int C, int H, int I);
+
+/* nn.MultiheadAttention core (models/set_transformer.py:112, between in_proj and out_proj):
+ * q (B, N, C) projected queries, kvh (B, I, 2C) projected inducer keys|values -> out (B, N, C). */
+int gecco_unpool_attn_f32(const float* q, const float* kvh, float* out, int B, int N, int C, int H, int I,
+                          void* stream);
+
+/* coef: 5*B floats: coef[4b..4b+3] = {c_skip, c_out, c_in, c_noise} (diffusion.py:46-51) and
+ * coef[4B + b] = c_noise packed (the AdaGN `t` input for t_embed_dim == 1). */
+int gecco_edm_coeffs_f32(const float* sigma, float sigma_data, float* coef, int B, void* stream);
+/* out = (c_in * x) @ W^T + b  (linear_lift.py:44 / ray.py:99); coef may be NULL (c_in = 1);
+ * stats (B, gecco_stats_row_tiles(N), 2, C) may be NULL. */
+int gecco_lift_f32(const float* x, const float* coef, const float* W, const float* bias, float* out, float* stats,
+                   int B, int N, int C, void* stream);
+/* F = Linear(C->3)(norm(feat)); D = c_skip*x + c_out*F (linear_lift.py:25-29,46; ray.py:56-59,120;
+ * diffusion.py:57).  gn_a/gn_o NULL -> per-point LayerNorm; else y = gn_a*feat + gn_o.  out and/or raw. */
+int gecco_lower_edm_f32(const float* feat, const float* x, const float* coef, const float* W, const float* bias,
+                        const float* gn_a, const float* gn_o, float* out, float* raw, int B, int N, int C, float eps,
+                        void* stream);
+
+/* ---- network-level entry points ------------------------------------------------------------ */
+
+/* SetTransformer.forward (models/set_transformer.py:198-216), in place on x (B, N, C).
+ * t (B, ctx_dim).  stats_x/stats_T: GroupNorm partials of x from its producer (NULL -> computed here).
+ * h_in: NULL or host array of n_layers device pointers (B, I, C) = cached inducer states (`hs`).
+ * h_out: NULL or host array of n_layers device pointers to receive them (`return_h`).
+ * stats_out: NULL or (B, gecco_linear_row_tiles(N), 2, C) partials of the output (for a GN head). */
+int gecco_set_transformer_fwd_f32(const GeccoSetTransformer* st, float* x, const float* t, const float* stats_x,
+                                  int stats_T, const float* const* h_in, float* const* h_out, float* stats_out,
+                                  int B, int N, void* ws, size_t ws_bytes, void* stream);
+size_t gecco_set_transformer_workspace_bytes(const GeccoSetTransformer* st, int B, int N);
+
+typedef struct GeccoLinearLift {   /* EDMPrecond(LinearLift(SetTransformer)), diffusion.py:22-62, linear_lift.py */
+    GeccoSetTransformer inner;
+    const float* lift_w;    /* lift.weight (C, 3)    */
+    const float* lift_b;    /* lift.bias (C)         */
+    const float* lower_w;   /* lower.1.weight (3, C) */
+    const float* lower_b;   /* lower.1.bias (3)      */
+    float sigma_data;
+} GeccoLinearLift;
+
+/* Diffusion.forward for the unconditional model (diffusion.py:233-247): x (B, N, 3), sigma (B) ->
+ * denoised (B, N, 3); raw (optional) receives F_x. */
+int gecco_linear_lift_fwd_f32(const GeccoLinearLift* m, const float* x, const float* sigma, float* denoised,
+                              float* raw, const float* const* h_in, float* const* h_out, int B, int N, void* ws,
+                              size_t ws_bytes, void* stream);
+size_t gecco_linear_lift_workspace_bytes(const GeccoLinearLift* m, int B, int N);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

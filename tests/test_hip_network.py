@@ -1,0 +1,106 @@
+"""GPU parity of the layer / network level entry points against the golden vectors captured from
+the real reference (tests/golden, tools/make_golden.py) and against the oracle on the same seeded
+inputs.  Bar (BASELINE.json north_star): 1e-3 relative fp32; the fp32-MFMA path sits ~1e-6."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cases, cpu_ref
+
+pytestmark = pytest.mark.gpu
+TOL = 5e-5
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import __graft_entry__ as ge
+    ge.build()
+    from gecco_amd import hip_ops
+    return hip_ops
+
+
+def _load(golden_dir, name):
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(golden_dir, name + ".npz")).items()}
+
+
+def _close(got, ref, tol=TOL):
+    e = cpu_ref.rel_err(got.cpu(), ref)
+    assert e[0] <= tol, e
+    return e
+
+
+def _cuda(p):
+    return {k: v.cuda() for k, v in p.items()}
+
+
+@pytest.mark.parametrize("name", list(cases.LAYER_CASES))
+def test_layer_golden(ops, golden_dir, name):
+    g = _load(golden_dir, name)
+    p, x, t = cases.layer_inputs(name)
+    plan = ops.SetTransformerPlan(_cuda({"layers.0." + k: v for k, v in p.items()}), "", cases.H, cases.I)
+    y, hs, _ = plan.forward_(x.cuda().clone(), t.cuda(), return_h=True)
+    _close(y, g["x_out"])
+    _close(hs[0], g["h"])
+    N = x.shape[1]
+    y2, _, _ = plan.forward_((x[:, : N // 2] * 0.5).contiguous().cuda(), t.cuda(), hs=[g["h"].cuda()])
+    _close(y2, g["x_out_cached"])
+
+
+@pytest.mark.parametrize("name", list(cases.UNCOND_CASES))
+def test_uncond_golden(ops, golden_dir, name):
+    g = _load(golden_dir, name)
+    p, x, sigma = cases.uncond_inputs(name)
+    net = ops.LinearLiftPlan(_cuda(p), cases.H, cases.I)
+    den, raw = net.forward(x.cuda(), sigma.cuda(), return_raw=True)
+    e1 = _close(den, g["denoised"])
+    e2 = _close(raw, g["F_x"])
+    print(name, "denoised", e1, "F_x", e2)
+    # determinism: same inputs -> bit-identical outputs (no atomics anywhere on the path)
+    den2 = net.forward(x.cuda(), sigma.cuda())
+    assert torch.equal(den, den2)
+
+
+def test_cached_mode_golden(ops, golden_dir):
+    g = _load(golden_dir, "cached_d128_L4")
+    p, x, sigma, x_new = cases.cached_inputs()
+    net = ops.LinearLiftPlan(_cuda(p), cases.H, cases.I)
+    den, cache = net.forward(x.cuda(), sigma.cuda(), do_cache=True)
+    _close(torch.stack(cache), g["cache"])
+    out = net.forward(x_new.cuda(), sigma.cuda(), cache=[c.cuda() for c in g["cache"]])
+    _close(out, g["out_new"])
+
+
+@pytest.mark.parametrize("B,N,d,L", [(3, 333, 128, 2), (2, 2048, 384, 1), (1, 4096, 512, 1), (2, 100, 64, 3)])
+def test_uncond_vs_oracle_ragged(ops, B, N, d, L):
+    """Sizes the golden set does not hold (ragged N, d=512, N=4096), oracle computed on the fly."""
+    from oracle import weights as W
+    p = W.linear_lift_state_dict(77 + N, d, L, cases.I, cases.H)
+    x, sigma = W.synthetic_cloud(N, B, N)
+    with torch.no_grad():
+        ref, raw_ref = cpu_ref.uncond_denoiser(p, "", cases.H)(x, sigma, return_raw=True)
+    den, raw = ops.LinearLiftPlan(_cuda(p), cases.H, cases.I).forward(x.cuda(), sigma.cuda(), return_raw=True)
+    _close(den, ref)
+    _close(raw, raw_ref)
+
+
+def test_full_size_properties(ops):
+    """BASELINE config C2 (B=64, N=2048, d=384, L=6) is too slow for the CPU oracle inside a test, so
+    check size-independent properties: (1) samples are independent — evaluating a batch equals
+    evaluating its samples in two half batches, bit for bit; (2) permutation equivariance over the
+    points of a cloud (the set transformer has no positional input) within fp32 re-association."""
+    from oracle import weights as W
+    B, N, d, L = 64, 2048, 384, 6
+    p = _cuda(W.linear_lift_state_dict(3, d, L, cases.I, cases.H))
+    x, sigma = W.synthetic_cloud(0, B, N)
+    x, sigma = x.cuda(), sigma.cuda()
+    net = ops.LinearLiftPlan(p, cases.H, cases.I)
+    full = net.forward(x, sigma)
+    assert torch.isfinite(full).all()
+    lo = net.forward(x[:32].contiguous(), sigma[:32].contiguous())
+    hi = net.forward(x[32:].contiguous(), sigma[32:].contiguous())
+    assert torch.equal(full, torch.cat([lo, hi]))
+    perm = torch.randperm(N, device="cuda")
+    full_p = net.forward(x[:4, perm].contiguous(), sigma[:4].contiguous())
+    _close(full_p, full[:4, perm].cpu(), 1e-4)

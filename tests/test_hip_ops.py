@@ -1,0 +1,150 @@
+"""GPU parity of the unit operators (through the C ABI) against the CPU oracle.
+fp32 MFMA is an exact-fp32 fma chain, so the tolerance is the fp32 re-association noise floor."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import cpu_ref
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import __graft_entry__ as ge
+    ge.build()
+    from gecco_amd import hip_ops
+    return hip_ops
+
+
+def _rs(seed):
+    return np.random.RandomState(seed)
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+
+
+def _close(got, ref, tol=TOL):
+    e = cpu_ref.rel_err(got.cpu(), ref)
+    assert e[0] <= tol, e
+
+
+@pytest.mark.parametrize("B,rows,K,Nout", [(2, 256, 128, 256), (3, 100, 36, 70), (2, 64, 384, 768), (1, 2048, 384, 384),
+                                           (2, 200, 672, 128), (2, 64, 768, 384)])
+def test_linear_fused(ops, B, rows, K, Nout):
+    rs = _rs(B * 1000 + rows + K + Nout)
+    A, W, b = _t(rs.randn(B, rows, K)), _t(rs.randn(Nout, K) / math.sqrt(K)), _t(rs.randn(Nout))
+    pa, po = _t(1 + 0.3 * rs.randn(B, K)), _t(0.3 * rs.randn(B, K))
+    R = _t(rs.randn(B, rows, Nout))
+    alpha = _t(np.array(0.9))
+    ref = R + cpu_ref.gaussian_activation(F.linear(A * pa[:, None] + po[:, None], W, b), alpha)
+    out, stats = ops.linear(A.cuda(), W.cuda(), b.cuda(), (pa.cuda(), po.cuda()), alpha.cuda(), R.cuda(), want_stats=True)
+    _close(out, ref)
+    s = stats.cpu().double().sum(1)  # (B, 2, Nout)
+    _close(s[:, 0], ref.double().sum(1), 1e-4)
+    _close(s[:, 1], (ref.double() ** 2).sum(1), 1e-5)
+    # plain variant: no prologue / bias / act / residual
+    out2 = ops.linear(A.cuda(), W.cuda())
+    _close(out2, F.linear(A, W))
+    # in-place residual (C aliases residual) as the layer uses it
+    Rc = R.cuda().clone()
+    ops.linear(A.cuda(), W.cuda(), b.cuda(), residual=Rc, out=Rc)
+    _close(Rc, R + F.linear(A, W, b))
+
+
+@pytest.mark.parametrize("B,rows,C,G,ctx", [(2, 256, 128, 32, 1), (3, 77, 64, 32, 1), (2, 64, 384, 32, 3), (2, 300, 672, 16, 0)])
+def test_adagn(ops, B, rows, C, G, ctx):
+    rs = _rs(rows + C)
+    x = _t(rs.randn(B, rows, C) * 2 + 0.7)
+    if ctx:
+        t = _t(rs.randn(B, 1, ctx))
+        p = {"scale.weight": _t(rs.randn(C, ctx) * .2), "scale.bias": _t(1 + .1 * rs.randn(C)),
+             "bias.weight": _t(rs.randn(C, ctx) * .2), "bias.bias": _t(.1 * rs.randn(C))}
+        ref = cpu_ref.adagn(x, t, p, "", G)
+        params = [p[k].cuda() for k in ("scale.weight", "scale.bias", "bias.weight", "bias.bias")]
+        got = ops.adagn(x.cuda(), t.cuda(), params, G)
+    else:
+        ref = cpu_ref.group_norm_bnc(x, G)
+        got = ops.adagn(x.cuda(), None, None, G)
+    _close(got, ref)
+
+
+def test_adagn_large_mean(ops):
+    """E[x^2]-mean^2 cancellation: mean 50x the std must still be accurate (fp64 combine)."""
+    rs = _rs(5)
+    x = _t(rs.randn(2, 2048, 64) * 0.1 + 5.0)
+    _close(ops.adagn(x.cuda(), None, None, 32), cpu_ref.group_norm_bnc(x.double(), 32).float(), 2e-3)
+
+
+@pytest.mark.parametrize("B,N,C,H", [(2, 256, 128, 8), (2, 1000, 384, 8), (1, 64, 64, 8), (3, 33, 512, 8), (2, 2048, 256, 8)])
+def test_pool_attn(ops, B, N, C, H):
+    rs = _rs(N + C)
+    y = _t(rs.randn(B, N, C))
+    p = {"kv_proj.weight": _t(rs.randn(2 * C, C) / math.sqrt(C) * 2), "inducers": _t(rs.randn(1, H, 64, C // H)),
+         "out_proj.weight": torch.eye(C)}
+    ref = cpu_ref.attention_pool(y, p, "", H)
+    KV = F.linear(y, p["kv_proj.weight"])
+    got = ops.pool_attn(KV.cuda(), p["inducers"].cuda(), H)
+    _close(got, ref)
+
+
+def test_pool_attn_online_softmax_rescale(ops):
+    """Force the running max to jump late in the key stream (rule: a rare branch needs its own test)."""
+    B, N, C, H = 1, 1024, 128, 8
+    rs = _rs(9)
+    y = _t(rs.randn(B, N, C))
+    ind = _t(rs.randn(1, H, 64, C // H))
+    Wkv = _t(rs.randn(2 * C, C) / math.sqrt(C))
+    KV = F.linear(y, Wkv)
+    KV[0, 900, :C] = ind[0, :, 3, :].reshape(-1) * 6.0   # key 900 aligned with query 3 of every head
+    KV[0, 17, :C] = ind[0, :, 5, :].reshape(-1) * 6.0
+    p = {"inducers": ind}
+    hd = C // H
+    k = KV[..., :C].reshape(B, N, H, hd).permute(0, 2, 1, 3)
+    v = KV[..., C:].reshape(B, N, H, hd).permute(0, 2, 1, 3)
+    a = torch.softmax(ind @ k.transpose(-1, -2) / math.sqrt(hd), -1)
+    ref = (a @ v).permute(0, 2, 1, 3).reshape(B, 64, C)
+    _close(ops.pool_attn(KV.cuda(), ind.cuda(), H), ref)
+
+
+@pytest.mark.parametrize("B,N,C,H", [(2, 256, 128, 8), (2, 1000, 384, 8), (1, 50, 64, 8), (2, 640, 512, 8)])
+def test_unpool_attn(ops, B, N, C, H):
+    rs = _rs(N + C + 1)
+    y, h = _t(rs.randn(B, N, C)), _t(rs.randn(B, 64, C))
+    p = {"in_proj_weight": _t(rs.randn(3 * C, C) / math.sqrt(C) * 1.5), "in_proj_bias": _t(rs.randn(3 * C) * .1),
+         "out_proj.weight": torch.eye(C), "out_proj.bias": torch.zeros(C)}
+    ref = cpu_ref.mha_unpool(y, h, p, "", H)
+    q = F.linear(y, p["in_proj_weight"][:C], p["in_proj_bias"][:C])
+    kvh = F.linear(h, p["in_proj_weight"][C:], p["in_proj_bias"][C:])
+    _close(ops.unpool_attn(q.cuda(), kvh.cuda(), H), ref)
+
+
+@pytest.mark.parametrize("B,N,C", [(3, 200, 128), (2, 2048, 384)])
+def test_lift_lower_edm(ops, B, N, C):
+    rs = _rs(N)
+    x = _t(rs.randn(B, N, 3) * 3)
+    sigma = _t(np.exp(rs.uniform(np.log(.002), np.log(165), size=B)))
+    Wl, bl = _t(rs.randn(C, 3)), _t(rs.randn(C))
+    Wo, bo = _t(rs.randn(3, C) / math.sqrt(C)), _t(rs.randn(3))
+    c_skip, c_out, c_in, c_noise = cpu_ref.edm_coeffs(sigma)
+    coef = ops.edm_coeffs(sigma.cuda())
+    _close(coef[: 4 * B].reshape(B, 4), torch.cat([c_skip, c_out, c_in, c_noise], -1).reshape(B, 4), 1e-6)
+    _close(coef[4 * B:], c_noise.reshape(B), 1e-6)
+    feat_ref = F.linear(c_in * x, Wl, bl)
+    feat, stats = ops.lift(x.cuda(), coef, Wl.cuda(), bl.cuda(), want_stats=True)
+    _close(feat, feat_ref)
+    _close(stats.cpu().double().sum(1)[:, 0], feat_ref.double().sum(1), 1e-4)
+    F_ref = F.linear(F.layer_norm(feat_ref, (C,), eps=1e-5), Wo, bo)
+    out, raw = ops.lower_edm(feat, x.cuda(), coef, Wo.cuda(), bo.cuda(), want_raw=True)
+    _close(raw, F_ref)
+    _close(out, c_skip * x + c_out * F_ref)
+    # GroupNorm(16) head variant (RayNetwork.output_proj)
+    st = ops.col_stats(feat)
+    a, o = ops.adagn_coeffs(st, N, None, None, 16)
+    F2 = F.linear(cpu_ref.group_norm_bnc(feat_ref, 16), Wo, bo)
+    _close(ops.lower_edm(feat, None, None, Wo.cuda(), bo.cuda(), gn=(a, o)), F2)

@@ -22,7 +22,7 @@ namespace {
 constexpr int BK = 32;
 constexpr int LDP = BK + 4;  // padded LDS row stride (floats)
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool HAS_PRO>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs g) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -43,48 +43,63 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs g) {
 
     const float* __restrict__ A = g.A + (size_t)b * g.rows * g.lda;
     const float* __restrict__ W = g.W;
-    const float* pa = g.pro_a ? g.pro_a + (size_t)b * g.K : nullptr;
-    const float* po = g.pro_a ? g.pro_o + (size_t)b * g.K : nullptr;
+    const float* pa = HAS_PRO ? g.pro_a + (size_t)b * g.K : nullptr;
+    const float* po = HAS_PRO ? g.pro_o + (size_t)b * g.K : nullptr;
 
     constexpr int STAGE = (BM + BN) * LDP;  // floats per stage: A tile then B tile
 
     const int lrow = tid >> 3, lk4 = tid & 7;  // this thread's (row, 16-byte k chunk) in a K-step
     constexpr int ROWS_PER_IT = NT / 8;
 
-    f32x4 ra[A_IT], rb[B_IT];
+    // Branch-free staging: out-of-range rows / k are CLAMPED for the load and zeroed when the
+    // registers are written to LDS, so every global load of a K-step is issued back to back and
+    // the only wait sits after the MFMA block (the AdaGN affine is applied there too).
+    const float* arow[A_IT];
+    const float* brow[B_IT];
+    unsigned okmask = 0;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int m = m0 + lrow + i * ROWS_PER_IT;
+        arow[i] = A + (size_t)min(m, g.rows - 1) * g.lda;
+        okmask |= (m < g.rows ? 1u : 0u) << i;
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int n = n0 + lrow + i * ROWS_PER_IT;
+        brow[i] = W + (size_t)min(n, g.Nout - 1) * g.ldw;
+        okmask |= (n < g.Nout ? 1u : 0u) << (16 + i);
+    }
+
+    f32x4 ra[A_IT], rb[B_IT], rpa, rpo;
+    bool kok_next = true;
     auto load_global = [&](int kt) {
         const int k = kt * BK + lk4 * 4;
-        const bool kok = k < g.K;
-        f32x4 va = {1.f, 1.f, 1.f, 1.f}, vo = {0.f, 0.f, 0.f, 0.f};
-        if (pa && kok) {
-            va = *reinterpret_cast<const f32x4*>(pa + k);
-            vo = *reinterpret_cast<const f32x4*>(po + k);
-        }
+        kok_next = k < g.K;
+        const int kc = kok_next ? k : 0;
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const int m = m0 + lrow + i * ROWS_PER_IT;
-            f32x4 x = {0.f, 0.f, 0.f, 0.f};
-            if (kok && m < g.rows) {
-                x = *reinterpret_cast<const f32x4*>(A + (size_t)m * g.lda + k);
-                x = x * va + vo;
-            }
-            ra[i] = x;
-        }
+        for (int i = 0; i < A_IT; ++i) ra[i] = *reinterpret_cast<const f32x4*>(arow[i] + kc);
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            const int n = n0 + lrow + i * ROWS_PER_IT;
-            f32x4 x = {0.f, 0.f, 0.f, 0.f};
-            if (kok && n < g.Nout) x = *reinterpret_cast<const f32x4*>(W + (size_t)n * g.ldw + k);
-            rb[i] = x;
+        for (int i = 0; i < B_IT; ++i) rb[i] = *reinterpret_cast<const f32x4*>(brow[i] + kc);
+        if (HAS_PRO) {
+            rpa = *reinterpret_cast<const f32x4*>(pa + kc);
+            rpo = *reinterpret_cast<const f32x4*>(po + kc);
         }
     };
     auto store_lds = [&](int s) {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i)
-            *reinterpret_cast<f32x4*>(smem + s * STAGE + (lrow + i * ROWS_PER_IT) * LDP + lk4 * 4) = ra[i];
+        for (int i = 0; i < A_IT; ++i) {
+            f32x4 x = ra[i];
+            if (HAS_PRO) x = x * rpa + rpo;
+            if (!(kok_next && ((okmask >> i) & 1u))) x = zero;
+            *reinterpret_cast<f32x4*>(smem + s * STAGE + (lrow + i * ROWS_PER_IT) * LDP + lk4 * 4) = x;
+        }
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i)
-            *reinterpret_cast<f32x4*>(smem + s * STAGE + (BM + lrow + i * ROWS_PER_IT) * LDP + lk4 * 4) = rb[i];
+        for (int i = 0; i < B_IT; ++i) {
+            f32x4 x = rb[i];
+            if (!(kok_next && ((okmask >> (16 + i)) & 1u))) x = zero;
+            *reinterpret_cast<f32x4*>(smem + s * STAGE + (BM + lrow + i * ROWS_PER_IT) * LDP + lk4 * 4) = x;
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -129,25 +144,42 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs g) {
     float* Cb = g.C + (size_t)b * g.rows * g.ldc;
     const float* Rb = g.residual ? g.residual + (size_t)b * g.rows * g.ldr : nullptr;
     float csum[TN], csq[TN];
+    const bool has_act = g.act != 0, act_norm = g.act == 1;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + (wn * TN + j) * 32 + r;
         const bool nok = n < g.Nout;
-        const float bias = (g.bias && nok) ? g.bias[n] : 0.f;
+        const int nc = nok ? n : g.Nout - 1;
+        const float bias = g.bias ? g.bias[nc] : 0.f;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + (wm * TM + i) * 32 + 4 * h;  // row of register e: mb + (e&3) + 8*(e>>2)
+            f32x16 val = acc[i][j];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) val[e] += bias;
+            if (has_act) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) val[e] = gauss_act(val[e], neg_inv_2a2, act_norm);
+            }
+            if (Rb) {  // 16 independent loads in flight, then one add pass
+                f32x16 rr;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = min(mb + (e & 3) + 8 * (e >> 2), g.rows - 1);
+                    rr[e] = Rb[(size_t)m * g.ldr + nc];
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) val[e] += rr[e];
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = m0 + (wm * TM + i) * 32 + mfma_row(e, h);
-                if (nok && m < g.rows) {
-                    float val = acc[i][j][e] + bias;
-                    if (g.act) val = gauss_act(val, neg_inv_2a2, g.act == 1);
-                    if (Rb) val += Rb[(size_t)m * g.ldr + n];
-                    Cb[(size_t)m * g.ldc + n] = val;
-                    s1 += val;
-                    s2 += val * val;
-                }
+                const int m = mb + (e & 3) + 8 * (e >> 2);
+                const bool ok = nok && m < g.rows;
+                if (ok) Cb[(size_t)m * g.ldc + n] = val[e];
+                const float vz = ok ? val[e] : 0.f;
+                s1 += vz;
+                s2 += vz * vz;
             }
         }
         csum[j] = s1 + xor32(s1);
@@ -178,17 +210,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs g) {
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool HAS_PRO>
 int launch(const GemmArgs& g, hipStream_t st) {
     const int tilesM = (g.rows + BM - 1) / BM, tilesN = (g.Nout + BN - 1) / BN;
     const size_t lds = 2 * (BM + BN) * LDP * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<BM, BN, WM, WN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<BM, BN, WM, WN, HAS_PRO>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN>), dim3(g.B * tilesM * tilesN), dim3(WM * WN * 64), lds, st, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, HAS_PRO>), dim3(g.B * tilesM * tilesN), dim3(WM * WN * 64), lds, st, g);
     return (int)hipGetLastError();
 }
 
@@ -198,6 +230,7 @@ int gemm_row_tile(int rows) { return rows >= 128 ? 128 : 64; }
 
 int gemm_f32_launch(const GemmArgs& g, hipStream_t st) {
     if (g.K % 4 || g.lda % 4 || g.ldw % 4) return -2;  // 16-byte vector loads
-    if (gemm_row_tile(g.rows) == 128) return launch<128, 128, 2, 2>(g, st);
-    return launch<64, 64, 2, 2>(g, st);
+    const bool pro = g.pro_a != nullptr;
+    if (gemm_row_tile(g.rows) == 128) return pro ? launch<128, 128, 2, 2, true>(g, st) : launch<128, 128, 2, 2, false>(g, st);
+    return pro ? launch<64, 64, 2, 2, true>(g, st) : launch<64, 64, 2, 2, false>(g, st);
 }

@@ -40,7 +40,20 @@ class GeccoLinearLift(C.Structure):
                 ("lower_b", c_f), ("sigma_data", C.c_float)]
 
 
-i, sz, vp, fl = C.c_int, C.c_size_t, C.c_void_p, C.c_float
+class GeccoPyramid(C.Structure):
+    _fields_ = [("n_levels", C.c_int), ("C", C.c_int * 4), ("H", C.c_int * 4), ("W", C.c_int * 4), ("feat", c_f * 4)]
+
+
+class GeccoReparam(C.Structure):
+    _fields_ = [("kind", C.c_int), ("mean", c_f), ("std", c_f), ("logit_scale", C.c_float)]
+
+
+class GeccoRayNetwork(C.Structure):
+    _fields_ = [("backbone", GeccoSetTransformer), ("xyz_w", c_f), ("xyz_b", c_f), ("img_w", c_f), ("img_b", c_f),
+                ("out_w", c_f), ("out_b", c_f), ("reparam", GeccoReparam), ("sigma_data", C.c_float)]
+
+
+i, sz, vp, fl, db = C.c_int, C.c_size_t, C.c_void_p, C.c_float, C.c_double
 PP = C.POINTER(C.c_void_p)
 
 # name -> (restype, argtypes); every symbol include/gecco_hip.h declares
@@ -66,6 +79,22 @@ SIGNATURES = {
     "gecco_set_transformer_workspace_bytes": (sz, [C.POINTER(GeccoSetTransformer), i, i]),
     "gecco_linear_lift_fwd_f32": (i, [C.POINTER(GeccoLinearLift), vp, vp, vp, vp, PP, PP, i, i, vp, sz, vp]),
     "gecco_linear_lift_workspace_bytes": (sz, [C.POINTER(GeccoLinearLift), i, i]),
+    "gecco_nchw_to_nhwc_f32": (i, [vp, vp, i, i, i, i, vp]),
+    "gecco_bilinear_taps_f32": (i, [vp, i, i, vp, vp, vp, vp, sz, vp]),
+    "gecco_ray_lookup_f32": (i, [vp, vp, vp, C.POINTER(GeccoReparam), C.POINTER(GeccoPyramid), vp, vp, i, i, vp]),
+    "gecco_lookup_row_tiles": (i, [i]),
+    "gecco_ray_network_fwd_f32": (i, [C.POINTER(GeccoRayNetwork), vp, vp, vp, C.POINTER(GeccoPyramid), vp, vp, PP, PP,
+                                      i, i, vp, sz, vp]),
+    "gecco_ray_network_workspace_bytes": (sz, [C.POINTER(GeccoRayNetwork), C.POINTER(GeccoPyramid), i, i]),
+    "gecco_gaussian_reparam": (i, [vp, vp, vp, vp, sz, i, i, i, vp]),
+    "gecco_uvl_reparam": (i, [vp, vp, vp, vp, db, vp, i, i, i, i, vp]),
+    "gecco_gaussian_act_f32": (i, [vp, vp, vp, sz, i, vp]),
+    "gecco_sampler_add_noise_f64": (i, [vp, vp, sz, vp, vp, i, i, vp, vp, vp, sz, i, vp]),
+    "gecco_sampler_add_noise_f32": (i, [vp, vp, sz, vp, vp, i, vp, vp, sz, i, vp]),
+    "gecco_sampler_euler_f64": (i, [vp, vp, vp, vp, vp, vp, vp, vp, sz, i, vp]),
+    "gecco_sampler_heun_f64": (i, [vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "gecco_sampler_advance": (i, [vp, i, vp]),
+    "gecco_sampler_scale_f64": (i, [vp, db, vp, sz, vp]),
 }
 
 _lib = None

@@ -325,4 +325,174 @@ int gecco_linear_lift_fwd_f32(const GeccoLinearLift* m, const float* x, const fl
     return 0;
 }
 
+// ---------------------------------------------------------------------------- conditional path
+int gecco_nchw_to_nhwc_f32(const float* src, float* dst, int B, int C, int H, int W, void* stream) {
+    TRY(nchw_to_nhwc_launch(src, dst, B, C, H, W, (hipStream_t)stream), "nchw_to_nhwc");
+    return 0;
+}
+
+int gecco_bilinear_taps_f32(const float* uv, int H, int W, int* x0, int* y0, float* wx1, float* wy1, size_t n,
+                            void* stream) {
+    TRY(bilinear_taps_launch(uv, H, W, x0, y0, wx1, wy1, n, (hipStream_t)stream), "bilinear_taps");
+    return 0;
+}
+
+int gecco_lookup_row_tiles(int N) { return (N + lookup_row_tile() - 1) / lookup_row_tile(); }
+
+}  // extern "C"
+
+namespace {
+
+int make_lookup_args(const GeccoReparam* rp, const GeccoPyramid* pyr, LookupArgs* a) {
+    if (!pyr || pyr->n_levels < 1 || pyr->n_levels > 4) return fail(-8, "lookup: 1..4 pyramid levels required");
+    a->n_levels = pyr->n_levels;
+    a->c_total = 0;
+    for (int l = 0; l < 4; ++l) {
+        const bool on = l < pyr->n_levels;
+        a->C[l] = on ? pyr->C[l] : 0;
+        a->H[l] = on ? pyr->H[l] : 1;
+        a->W[l] = on ? pyr->W[l] : 1;
+        a->feat[l] = on ? pyr->feat[l] : nullptr;
+        if (on && !pyr->feat[l]) return fail(-1, "lookup: null pyramid level %d", l);
+        a->c_total += a->C[l];
+    }
+    a->reparam_kind = rp ? rp->kind : 0;
+    a->rp_mean = rp ? rp->mean : nullptr;
+    a->rp_std = rp ? rp->std : nullptr;
+    a->logit_scale = rp ? rp->logit_scale : 1.1f;
+    if (a->reparam_kind && (!a->rp_mean || !a->rp_std)) return fail(-1, "lookup: reparam buffers missing");
+    return 0;
+}
+
+struct RNWorkspace {
+    float *feat, *raw, *coef, *stats_raw, *stats_x, *stats_out, *a_raw, *o_raw, *a_out, *o_out;
+    void* st_ws;
+    size_t st_bytes, bytes;
+};
+
+RNWorkspace carve_rn(const GeccoRayNetwork* m, int c_total, int B, int N, void* base) {
+    Carver c(base);
+    RNWorkspace w;
+    const size_t C = m->backbone.C;
+    w.feat = c.f32((size_t)B * N * C);
+    w.raw = c.f32((size_t)B * N * c_total);
+    w.coef = c.f32((size_t)B * 5);
+    w.stats_raw = c.f32((size_t)B * gecco_lookup_row_tiles(N) * 2 * c_total);
+    w.stats_x = c.f32((size_t)B * row_tiles_gemm(N) * 2 * C);
+    w.stats_out = c.f32((size_t)B * row_tiles_gemm(N) * 2 * C);
+    w.a_raw = c.f32((size_t)B * c_total);
+    w.o_raw = c.f32((size_t)B * c_total);
+    w.a_out = c.f32((size_t)B * C);
+    w.o_out = c.f32((size_t)B * C);
+    c.off = (c.off + 255) & ~size_t(255);
+    w.st_bytes = carve_st(&m->backbone, B, N, nullptr).bytes;
+    w.st_ws = base ? static_cast<char*>(base) + c.off : nullptr;
+    w.bytes = c.off + w.st_bytes;
+    return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gecco_ray_lookup_f32(const float* geom, const float* coef, const float* K, const GeccoReparam* rp,
+                         const GeccoPyramid* pyr, float* out, float* stats, int B, int N, void* stream) {
+    if (!geom || !K || !out) return fail(-1, "ray_lookup: null argument");
+    LookupArgs a;
+    int rc = make_lookup_args(rp, pyr, &a);
+    if (rc) return rc;
+    TRY(ray_lookup_launch(geom, coef, K, a, out, stats, B, N, (hipStream_t)stream), "ray_lookup");
+    return 0;
+}
+
+size_t gecco_ray_network_workspace_bytes(const GeccoRayNetwork* m, const GeccoPyramid* pyr, int B, int N) {
+    int ct = 0;
+    for (int l = 0; l < pyr->n_levels && l < 4; ++l) ct += pyr->C[l];
+    return carve_rn(m, ct, B, N, nullptr).bytes;
+}
+
+int gecco_ray_network_fwd_f32(const GeccoRayNetwork* m, const float* x, const float* sigma, const float* K,
+                              const GeccoPyramid* pyr, float* denoised, float* raw, const float* const* h_in,
+                              float* const* h_out, int B, int N, void* ws, size_t ws_bytes, void* stream) {
+    if (!m || !x || !sigma || !K || !(denoised || raw)) return fail(-1, "ray_network: null argument");
+    if (m->backbone.ctx_dim != 1) return fail(-3, "ray_network: t_embed_dim must be 1 under EDMPrecond");
+    LookupArgs a;
+    int rc = make_lookup_args(&m->reparam, pyr, &a);
+    if (rc) return rc;
+    RNWorkspace w = carve_rn(m, a.c_total, B, N, ws);
+    if (ws_bytes < w.bytes) return fail(-7, "ray_network: workspace too small (%zu < %zu)", ws_bytes, w.bytes);
+    hipStream_t s = (hipStream_t)stream;
+    const int C = m->backbone.C;
+    TRY(edm_coeffs_launch(sigma, m->sigma_data, w.coef, B, s), "edm_coeffs");
+    // xyz_embed(c_in * x)  (models/ray.py:99)
+    TRY(lift_launch(x, w.coef, m->xyz_w, m->xyz_b, w.feat, nullptr, B, N, C, s), "xyz_embed");
+    // projective lookup on c_in * x, fp32 always (models/ray.py:103-109) + GN(16) partials
+    TRY(ray_lookup_launch(x, w.coef, K, a, w.raw, w.stats_raw, B, N, s), "ray_lookup");
+    TRY(adagn_coeffs_launch(w.stats_raw, gecco_lookup_row_tiles(N), N, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
+                            w.a_raw, w.o_raw, B, a.c_total, 16, 1e-5f, s), "gn16(img)");
+    // point_features = xyz_features + Linear(GN16(lookup))  (models/ray.py:112-113): GN apply in the GEMM
+    // prologue, the add as its residual, the first AdaGN's statistics in its epilogue
+    TRY(linear(w.raw, m->img_w, m->img_b, w.a_raw, w.o_raw, nullptr, w.feat, w.feat, w.stats_x, B, N, a.c_total, C, 0,
+               s), "img_feature_proj");
+    rc = st_forward(&m->backbone, w.feat, w.coef + 4 * (size_t)B, w.stats_x, row_tiles_gemm(N), h_in, h_out,
+                    w.stats_out, B, N, w.st_ws, w.st_bytes, s);
+    if (rc) return rc;
+    // output_proj = Linear(GN16(.)) (models/ray.py:56-59,120) + EDM combine (diffusion.py:57)
+    TRY(adagn_coeffs_launch(w.stats_out, row_tiles_gemm(N), N, nullptr, 0, nullptr, nullptr, nullptr, nullptr, w.a_out,
+                            w.o_out, B, C, 16, 1e-5f, s), "gn16(out)");
+    TRY(lower_edm_launch(w.feat, x, w.coef, m->out_w, m->out_b, w.a_out, w.o_out, denoised, raw, B, N, C, 1e-5f, s),
+        "output_proj+edm");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------- reparam / activation / sampler
+int gecco_gaussian_reparam(const void* x, const float* mean, const float* sigma, void* y, size_t n_elems, int dim,
+                           int inverse, int is_f64, void* stream) {
+    TRY(gaussian_reparam_launch(x, mean, sigma, y, n_elems, dim, inverse, is_f64, (hipStream_t)stream),
+        "gaussian_reparam");
+    return 0;
+}
+int gecco_uvl_reparam(const void* x, const float* K, const float* uvl_mean, const float* uvl_std, double logit_scale,
+                      void* y, int B, int N, int inverse, int is_f64, void* stream) {
+    TRY(uvl_reparam_launch(x, K, uvl_mean, uvl_std, logit_scale, y, B, N, inverse, is_f64, (hipStream_t)stream),
+        "uvl_reparam");
+    return 0;
+}
+int gecco_gaussian_act_f32(const float* x, const float* alpha, float* y, size_t n, int normalized, void* stream) {
+    TRY(gaussian_act_launch(x, alpha, y, n, normalized, (hipStream_t)stream), "gaussian_act");
+    return 0;
+}
+int gecco_sampler_add_noise_f64(const double* x_cur, const float* noise, size_t noise_step_stride, const double* sched,
+                                const int* step, int col, int sigma_col, double* x_out, float* x_in, float* sigma,
+                                size_t n, int B, void* stream) {
+    TRY(sampler_add_noise_f64_launch(x_cur, noise, noise_step_stride, sched, step, col, sigma_col, x_out, x_in, sigma,
+                                     n, B, (hipStream_t)stream), "sampler_add_noise_f64");
+    return 0;
+}
+int gecco_sampler_add_noise_f32(const float* x, const float* noise, size_t noise_step_stride, const double* sched,
+                                const int* step, int col, float* out, float* sigma, size_t n, int B, void* stream) {
+    TRY(sampler_add_noise_f32_launch(x, noise, noise_step_stride, sched, step, col, out, sigma, n, B,
+                                     (hipStream_t)stream), "sampler_add_noise_f32");
+    return 0;
+}
+int gecco_sampler_euler_f64(const double* x_hat, const float* den, const double* sched, const int* step, double* d_cur,
+                            double* x_next, float* x_in, float* sigma, size_t n, int B, void* stream) {
+    TRY(sampler_euler_launch(x_hat, den, sched, step, d_cur, x_next, x_in, sigma, n, B, (hipStream_t)stream),
+        "sampler_euler");
+    return 0;
+}
+int gecco_sampler_heun_f64(const double* x_hat, const double* x_next, const float* den, const double* d_cur,
+                           const double* sched, const int* step, double* x_out, size_t n, void* stream) {
+    TRY(sampler_heun_launch(x_hat, x_next, den, d_cur, sched, step, x_out, n, (hipStream_t)stream), "sampler_heun");
+    return 0;
+}
+int gecco_sampler_advance(int* step, int delta, void* stream) {
+    TRY(sampler_advance_launch(step, delta, (hipStream_t)stream), "sampler_advance");
+    return 0;
+}
+int gecco_sampler_scale_f64(const float* latents, double t0, double* x, size_t n, void* stream) {
+    TRY(sampler_scale_launch(latents, t0, x, n, (hipStream_t)stream), "sampler_scale");
+    return 0;
+}
+
 }  // extern "C"

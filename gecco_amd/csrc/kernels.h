@@ -28,6 +28,41 @@ int pool_attn_nsplit(int B, int N, int H);
 int unpool_attn_launch(const float* q, const float* kvh, float* out, int B, int N, int C, int H, int I,
                        hipStream_t st);
 
+// lookup.hip
+struct LookupArgs {
+    int n_levels, c_total;
+    int C[4], H[4], W[4];
+    const float* feat[4];  // channels-last (B, H, W, C) per level
+    int reparam_kind;      // 0 none, 1 gaussian (mean, sigma), 2 UVL (uvl_mean, uvl_std, logit_scale)
+    const float* rp_mean;
+    const float* rp_std;
+    float logit_scale;
+};
+int lookup_row_tile();
+int ray_lookup_launch(const float* geom, const float* coef, const float* K, const LookupArgs& a, float* out,
+                      float* stats, int B, int N, hipStream_t st);
+int bilinear_taps_launch(const float* uv, int Hh, int Ww, int* x0, int* y0, float* wx1, float* wy1, size_t n,
+                         hipStream_t st);
+int nchw_to_nhwc_launch(const float* src, float* dst, int B, int C, int Hh, int Ww, hipStream_t st);
+
+// sampler.hip
+int sampler_add_noise_f64_launch(const double* x_cur, const float* noise, size_t noise_step_stride, const double* sched,
+                                 const int* step, int col, int sigma_col, double* x_out, float* x_in, float* sigma,
+                                 size_t n, int B, hipStream_t st);
+int sampler_add_noise_f32_launch(const float* x, const float* noise, size_t noise_step_stride, const double* sched,
+                                 const int* step, int col, float* out, float* sigma, size_t n, int B, hipStream_t st);
+int sampler_euler_launch(const double* x_hat, const float* den, const double* sched, const int* step, double* d_cur,
+                         double* x_next, float* x_in, float* sigma, size_t n, int B, hipStream_t st);
+int sampler_heun_launch(const double* x_hat, const double* x_next, const float* den, const double* d_cur,
+                        const double* sched, const int* step, double* x_out, size_t n, hipStream_t st);
+int sampler_advance_launch(int* step, int delta, hipStream_t st);
+int sampler_scale_launch(const float* latents, double t, double* x, size_t n, hipStream_t st);
+int gaussian_reparam_launch(const void* x, const float* mean, const float* sigma, void* y, size_t n, int dim,
+                            int inverse, int is_f64, hipStream_t st);
+int uvl_reparam_launch(const void* x, const float* K, const float* mean, const float* std_, double logit_scale, void* y,
+                       int B, int N, int inverse, int is_f64, hipStream_t st);
+int gaussian_act_launch(const float* x, const float* alpha, float* y, size_t n, int normalized, hipStream_t st);
+
 // pointwise.hip
 int stats_row_tile(int rows);
 int col_stats_launch(const float* x, float* stats, int B, int rows, int C, hipStream_t st);

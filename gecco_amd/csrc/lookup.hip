@@ -1,0 +1,216 @@
+// Projective feature lookup (RayNetwork.extract_image_features, reference models/ray.py:64-87):
+// diffusion-space geometry -> data space (reparam.py) -> pinhole projection (kornia
+// project_points) -> bilinear taps of F.grid_sample(align_corners=False,
+// padding zeros) on every pyramid level -> concatenated (B, N, sum C_l) features, plus the
+// GroupNorm(16) partial statistics the following img_feature_proj needs (models/ray.py:52-55).
+//
+// HBM/L2-gather bound: 4 taps x sum(C_l) floats read + sum(C_l) written per point.  The pyramids
+// are consumed channels-last (B, H, W, C): one texel's channels are contiguous, so a wave reads a
+// tap as whole 128-byte lines (the reference's NCHW layout would make every channel a separate
+// 4-byte gather).  One wave handles one point at a time; lanes run over 16-byte channel chunks.
+#include "common.h"
+#include "kernels.h"
+
+#pragma clang fp contract(off)  // index math must round like the reference's separate fp32 ops
+
+namespace {
+
+constexpr int LOOKUP_ROWS = 128;  // points per block == row tile of the GN statistics partials
+
+struct Taps {
+    int x0, y0;
+    float ix, iy;
+};
+
+// F.grid_sample's coordinate pipeline in torch's op order:
+//   g = uv*2 - 1 (models/ray.py:81);  ix = ((g + 1) * W - 1) / 2;  x0 = floor(ix)
+__device__ __forceinline__ Taps bilinear_taps(float u, float v, int Hh, int Ww) {
+    const float gx = u * 2.0f - 1.0f, gy = v * 2.0f - 1.0f;
+    const float ix = ((gx + 1.0f) * (float)Ww - 1.0f) / 2.0f;
+    const float iy = ((gy + 1.0f) * (float)Hh - 1.0f) / 2.0f;
+    const float fx = floorf(ix), fy = floorf(iy);
+    Taps t;
+    t.x0 = (int)fx;
+    t.y0 = (int)fy;
+    t.ix = ix;
+    t.iy = iy;
+    return t;
+}
+
+// geometry (diffusion space, optionally scaled by c_in) -> normalised image coordinates (u, v)
+__device__ __forceinline__ void project_uv(float g0, float g1, float g2, const float* __restrict__ Kb, int kind,
+                                           const float* __restrict__ mean, const float* __restrict__ std_,
+                                           float logit_scale, float& u, float& v) {
+    float X = g0, Y = g1, Z = g2;
+    const float fx = Kb[0], fy = Kb[4], cx = Kb[2], cy = Kb[5];
+    if (kind == 1) {  // GaussianReparam.diffusion_to_data (reparam.py:61-63)
+        X = g0 * std_[0] + mean[0];
+        Y = g1 * std_[1] + mean[1];
+        Z = g2 * std_[2] + mean[2];
+    } else if (kind == 2) {  // UVLReparam.diffusion_to_data (reparam.py:159-177,131-137)
+        const float uu = g0 * std_[0] + mean[0], vv = g1 * std_[1] + mean[1], l = g2 * std_[2] + mean[2];
+        const float su = (tanhf(uu) * logit_scale + 1.0f) / 2.0f, sv = (tanhf(vv) * logit_scale + 1.0f) / 2.0f;
+        const float d = expf(l);
+        const float xx = (su - cx) / fx, yy = (sv - cy) / fy;
+        float nrm = sqrtf(xx * xx + yy * yy + 1.0f);
+        nrm = fmaxf(nrm, 1e-12f);
+        X = xx / nrm * d;
+        Y = yy / nrm * d;
+        Z = 1.0f / nrm * d;
+    }
+    // kornia project_points: eps-guarded perspective divide, then fx*x + cx
+    const float sc = fabsf(Z) > 1e-8f ? 1.0f / (Z + 1e-8f) : 1.0f;
+    u = sc * X * fx + cx;
+    v = sc * Y * fy + cy;
+}
+
+__global__ __launch_bounds__(256) void ray_lookup_kernel(const float* __restrict__ geom,
+                                                         const float* __restrict__ coef,
+                                                         const float* __restrict__ K, LookupArgs a,
+                                                         float* __restrict__ out, float* __restrict__ stats, int N,
+                                                         int T) {
+    __shared__ float red[4][2][1024];  // per-wave column partials (sum C_l <= 1024)
+    const int tile = blockIdx.x % T, b = blockIdx.x / T;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int Ct = a.c_total, C4 = Ct / 4;
+    const float cin = coef ? coef[4 * b + 2] : 1.0f;
+    const float* Kb = K + (size_t)b * 9;
+
+    constexpr int MAXCH = 4;  // float4 chunks per lane: 64 * 4 * 4 = 1024 channels max
+    f32x4 s1[MAXCH], s2[MAXCH];
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) {
+        s1[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        s2[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // this lane's chunks: level and channel offset are point-independent
+    int lvl[MAXCH], coff[MAXCH];
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) {
+        const int ch = (c * 64 + lane) * 4;
+        int l = 0, base = 0;
+        while (l + 1 < a.n_levels && ch >= base + a.C[l]) {
+            base += a.C[l];
+            ++l;
+        }
+        lvl[c] = l;
+        coff[c] = ch - base;
+    }
+
+    const int m0 = tile * LOOKUP_ROWS, m1 = min(N, m0 + LOOKUP_ROWS);
+    for (int m = m0 + wave; m < m1; m += 4) {
+        const float* gp = geom + ((size_t)b * N + m) * 3;
+        float u, v;
+        project_uv(cin * gp[0], cin * gp[1], cin * gp[2], Kb, a.reparam_kind, a.rp_mean, a.rp_std, a.logit_scale, u, v);
+        Taps tp[4];
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+            if (l < a.n_levels) tp[l] = bilinear_taps(u, v, a.H[l], a.W[l]);
+        float* orow = out + ((size_t)b * N + m) * Ct;
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) {
+            const int c4 = c * 64 + lane;
+            if (c4 >= C4) continue;
+            const int l = lvl[c];
+            Taps t = tp[0];
+#pragma unroll
+            for (int q = 1; q < 4; ++q)
+                if (l == q) t = tp[q];
+            const int Hh = a.H[l], Ww = a.W[l], Cl = a.C[l];
+            const float* fb = a.feat[l] + (size_t)b * Hh * Ww * Cl + coff[c];
+            const int x1 = t.x0 + 1, y1 = t.y0 + 1;
+            // torch's weights: nw = (x1 - ix)(y1 - iy), ne = (ix - x0)(y1 - iy), sw = (x1 - ix)(iy - y0), se = ...
+            const float wx0 = (float)x1 - t.ix, wy0 = (float)y1 - t.iy;
+            const float wx1 = t.ix - (float)t.x0, wy1 = t.iy - (float)t.y0;
+            const bool bx0 = t.x0 >= 0 && t.x0 <= Ww - 1, bx1 = x1 >= 0 && x1 <= Ww - 1;
+            const bool by0 = t.y0 >= 0 && t.y0 <= Hh - 1, by1 = y1 >= 0 && y1 <= Hh - 1;
+            const int cx0 = min(max(t.x0, 0), Ww - 1), cx1 = min(max(x1, 0), Ww - 1);
+            const int cy0 = min(max(t.y0, 0), Hh - 1), cy1 = min(max(y1, 0), Hh - 1);
+            const f32x4 nw = *reinterpret_cast<const f32x4*>(fb + ((size_t)cy0 * Ww + cx0) * Cl);
+            const f32x4 ne = *reinterpret_cast<const f32x4*>(fb + ((size_t)cy0 * Ww + cx1) * Cl);
+            const f32x4 sw = *reinterpret_cast<const f32x4*>(fb + ((size_t)cy1 * Ww + cx0) * Cl);
+            const f32x4 se = *reinterpret_cast<const f32x4*>(fb + ((size_t)cy1 * Ww + cx1) * Cl);
+            const float w_nw = (bx0 && by0) ? wx0 * wy0 : 0.f, w_ne = (bx1 && by0) ? wx1 * wy0 : 0.f;
+            const float w_sw = (bx0 && by1) ? wx0 * wy1 : 0.f, w_se = (bx1 && by1) ? wx1 * wy1 : 0.f;
+            const f32x4 r = nw * w_nw + ne * w_ne + sw * w_sw + se * w_se;
+            *reinterpret_cast<f32x4*>(orow + c4 * 4) = r;
+            s1[c] += r;
+            s2[c] += r * r;
+        }
+    }
+    if (stats) {
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) {
+            const int c4 = c * 64 + lane;
+            if (c4 < C4) {
+                *reinterpret_cast<f32x4*>(&red[wave][0][c4 * 4]) = s1[c];
+                *reinterpret_cast<f32x4*>(&red[wave][1][c4 * 4]) = s2[c];
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * Ct; i += 256) {
+            const int which = i / Ct, ch = i % Ct;
+            const float t = red[0][which][ch] + red[1][which][ch] + red[2][which][ch] + red[3][which][ch];
+            stats[(((size_t)b * T + tile) * 2 + which) * Ct + ch] = t;
+        }
+    }
+}
+
+// integer tap indices + fractional weights for given uv (the bit-exact part, testable in isolation)
+__global__ void bilinear_taps_kernel(const float* __restrict__ uv, int Hh, int Ww, int* __restrict__ x0,
+                                     int* __restrict__ y0, float* __restrict__ wx1, float* __restrict__ wy1, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Taps t = bilinear_taps(uv[2 * i], uv[2 * i + 1], Hh, Ww);
+    x0[i] = t.x0;
+    y0[i] = t.y0;
+    wx1[i] = t.ix - (float)t.x0;
+    wy1[i] = t.iy - (float)t.y0;
+}
+
+// (B, C, H, W) -> (B, H, W, C) through a 32x33 LDS tile (both sides coalesced)
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int HW) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, p = p0 + tx;
+        tile[j][tx] = (c < C && p < HW) ? src[((size_t)b * C + c) * HW + p] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int p = p0 + j, c = c0 + tx;
+        if (c < C && p < HW) dst[((size_t)b * HW + p) * C + c] = tile[tx][j];
+    }
+}
+
+}  // namespace
+
+int lookup_row_tile() { return LOOKUP_ROWS; }
+
+int ray_lookup_launch(const float* geom, const float* coef, const float* K, const LookupArgs& a, float* out,
+                      float* stats, int B, int N, hipStream_t st) {
+    if (a.n_levels < 1 || a.n_levels > 4 || a.c_total > 1024 || a.c_total % 4) return -8;
+    int tot = 0;
+    for (int l = 0; l < a.n_levels; ++l) {
+        if (a.C[l] % 4) return -8;
+        tot += a.C[l];
+    }
+    if (tot != a.c_total) return -8;
+    const int T = (N + LOOKUP_ROWS - 1) / LOOKUP_ROWS;
+    hipLaunchKernelGGL(ray_lookup_kernel, dim3(B * T), dim3(256), 0, st, geom, coef, K, a, out, stats, N, T);
+    return (int)hipGetLastError();
+}
+
+int bilinear_taps_launch(const float* uv, int Hh, int Ww, int* x0, int* y0, float* wx1, float* wy1, size_t n,
+                         hipStream_t st) {
+    hipLaunchKernelGGL(bilinear_taps_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, uv, Hh, Ww, x0, y0,
+                       wx1, wy1, n);
+    return (int)hipGetLastError();
+}
+
+int nchw_to_nhwc_launch(const float* src, float* dst, int B, int C, int Hh, int Ww, hipStream_t st) {
+    const int HW = Hh * Ww;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(256), 0, st, src, dst, C, HW);
+    return (int)hipGetLastError();
+}

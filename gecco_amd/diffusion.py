@@ -1,0 +1,392 @@
+"""EDM diffusion logic on the MI355X HIP path (API of reference diffusion.py:22-470): preconditioning, noise
+schedules, loss, the stochastic Heun sampler and the inducer-cached upsampler.
+
+Differences from the reference are in *how*, not *what*:
+* `EDMPrecond` hands the whole evaluation (c_in scaling, lift / projective lookup, set transformer, lower, c_skip /
+  c_out combine) to one C call when the wrapped model offers `fused_edm` (LinearLift, RayNetwork);
+* the sampler keeps its fp64 state in HIP kernels driven by a device-resident schedule table and a device step
+  counter, so one captured hipGraph per step is replayed for the whole trajectory and the host never reads a
+  device scalar (the reference compares `t_cur` on the host every step, diffusion.py:318-322);
+* all noise of a trajectory is drawn up front (or injected with `noise=` for bit-reproducible parity tests).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Any, Sequence
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib, hip_ops
+from ._grad import GeccoTrainingNotSupported
+from .reparam import NoReparam, Reparam
+from .structs import Context3d, Example
+
+try:  # Lightning is the reference's training harness; optional here (not needed for sampling)
+    import lightning.pytorch as pl
+    _Base = pl.LightningModule
+except Exception:  # pragma: no cover - depends on the environment
+    class _Base(nn.Module):
+        def log(self, *args, **kwargs):
+            pass
+
+
+def ones(n: int):
+    return (1,) * n
+
+
+class EDMPrecond(nn.Module):
+    """Karras et al. preconditioning: D(x, sigma) = c_skip x + c_out F(c_in x, ln(sigma)/4)."""
+
+    def __init__(self, model: nn.Module, sigma_data=1.0):
+        super().__init__()
+        self.model = model
+        self.sigma_data = sigma_data
+
+    def forward(self, x: Tensor, sigma: Tensor, raw_context: Any, post_context: Any, do_cache: bool = False,
+                cache: list[Tensor] | None = None, out: Tensor | None = None):
+        sigma = sigma.reshape(-1)
+        if hasattr(self.model, "fused_edm"):
+            res = self.model.fused_edm(x, sigma, raw_context, post_context, do_cache, cache, float(self.sigma_data), out=out)
+            return res  # Tensor, or (Tensor, cache) iff do_cache — as the reference
+        raise NotImplementedError(
+            f"EDMPrecond on HIP wraps LinearLift or RayNetwork (got {type(self.model).__name__}); there is no eager fallback")
+
+
+class LogNormalSchedule(nn.Module):
+    """sigma = exp(N(mean, std)) (Karras et al.).  (The reference's forward reads undefined attributes,
+    diffusion.py:84; here it uses its own mean/std.)"""
+
+    def __init__(self, sigma_max: float, mean=-1.2, std=1.2):
+        super().__init__()
+        self.sigma_max = sigma_max
+        self.mean = mean
+        self.std = std
+
+    def extra_repr(self) -> str:
+        return f"sigma_max={self.sigma_max}, mean={self.mean}, std={self.std}"
+
+    def forward(self, data: Tensor) -> Tensor:
+        rnd = torch.randn([data.shape[0], *ones(data.ndim - 1)], device=data.device)
+        return (rnd * self.std + self.mean).exp()
+
+
+class LogUniformSchedule(nn.Module):
+    """Stratified log-uniform sigma in [min, max] (reference diffusion.py:87-115)."""
+
+    def __init__(self, max: float, min: float = 0.002, low_discrepancy: bool = True):
+        super().__init__()
+        self.sigma_min = min
+        self.sigma_max = max
+        self.log_sigma_min = math.log(min)
+        self.log_sigma_max = math.log(max)
+        self.low_discrepancy = low_discrepancy
+
+    def extra_repr(self) -> str:
+        return f"sigma_min={self.sigma_min}, sigma_max={self.sigma_max}, low_discrepancy={self.low_discrepancy}"
+
+    def forward(self, data: Tensor) -> Tensor:
+        u = torch.rand(data.shape[0], device=data.device)
+        if self.low_discrepancy:
+            div = 1 / data.shape[0]
+            u = div * u + div * torch.arange(data.shape[0], device=data.device)
+        sigma = (u * (self.log_sigma_max - self.log_sigma_min) + self.log_sigma_min).exp()
+        return sigma.reshape(-1, *ones(data.ndim - 1))
+
+
+class EDMLoss(nn.Module):
+    """Weighted denoising loss (reference diffusion.py:118-143).  Evaluating it needs only the forward kernels;
+    differentiating it needs the backward kernels (next scope row), so it refuses to build a grad graph."""
+
+    def __init__(self, schedule: nn.Module, sigma_data: float = 1.0, loss_scale: float = 100.0):
+        super().__init__()
+        self.schedule = schedule
+        self.sigma_data = sigma_data
+        self.loss_scale = loss_scale
+
+    def extra_repr(self) -> str:
+        return f"sigma_data={self.sigma_data}, loss_scale={self.loss_scale}"
+
+    def forward(self, net: "Diffusion", examples: Tensor, context: Context3d) -> Tensor:
+        ex_diff = net.reparam.data_to_diffusion(examples, context)
+        sigma = self.schedule(ex_diff)
+        weight = (sigma ** 2 + self.sigma_data ** 2) / ((sigma * self.sigma_data) ** 2)
+        n = torch.randn_like(ex_diff) * sigma
+        D_yn = net(ex_diff + n, sigma, context)
+        return (self.loss_scale * weight * ((D_yn - ex_diff) ** 2)).mean()
+
+
+class Conditioner(nn.Module):
+    def forward(self, raw_context):
+        raise NotImplementedError()
+
+
+class IdleConditioner(Conditioner):
+    def forward(self, raw_context: Context3d | None) -> None:
+        del raw_context
+        return None
+
+
+# ---------------------------------------------------------------------------------------------- sampler engine
+def karras_t_steps(num_steps: int, sigma_max: float, sigma_min: float, rho: float) -> Tensor:
+    """fp64 Karras schedule with t_N = 0 (reference diffusion.py:253-269), on the host."""
+    i = torch.arange(num_steps, dtype=torch.float64)
+    t = (sigma_max ** (1 / rho) + i / (num_steps - 1) * (sigma_min ** (1 / rho) - sigma_max ** (1 / rho))) ** rho
+    return torch.cat([t, torch.zeros_like(t[:1])])
+
+
+def build_schedule_table(t_steps: Tensor, num_steps: int, S_churn, S_min, S_max, S_noise) -> Tensor:
+    """Host table (num_steps, GECCO_SCHED_COLS) of fp64: {t_cur, t_hat, t_next, churn, redo, 0, 0, 0}."""
+    tab = torch.zeros(num_steps, 8, dtype=torch.float64)
+    for i in range(num_steps):
+        t_cur, t_next = t_steps[i], t_steps[i + 1]
+        gamma = min(S_churn / num_steps, math.sqrt(2.0) - 1) if S_min <= float(t_cur) <= S_max else 0
+        t_hat = t_cur + gamma * t_cur
+        tab[i, 0], tab[i, 1], tab[i, 2] = t_cur, t_hat, t_next
+        tab[i, 3] = (t_hat ** 2 - t_cur ** 2).sqrt() * S_noise
+        tab[i, 4] = (t_cur ** 2 - t_next ** 2).sqrt()
+    return tab
+
+
+def _vp(t: Tensor | None):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+class _SamplerState:
+    """Device buffers + kernel launches of one trajectory over `shape` = (B, n, 3)."""
+
+    def __init__(self, shape, device, sched_host: Tensor):
+        self.lib = _lib.load()
+        self.B = shape[0]
+        self.n = int(shape[0] * shape[1] * shape[2])
+        f64 = dict(device=device, dtype=torch.float64)
+        self.x_cur = torch.empty(shape, **f64)
+        self.x_hat = torch.empty(shape, **f64)
+        self.x_next = torch.empty(shape, **f64)
+        self.d_cur = torch.empty(shape, **f64)
+        self.x_in = torch.empty(shape, device=device, dtype=torch.float32)
+        self.den = torch.empty(shape, device=device, dtype=torch.float32)
+        self.sigma = torch.empty(self.B, device=device, dtype=torch.float32)
+        self.sched = sched_host.to(device).contiguous()
+        self.step = torch.zeros(1, device=device, dtype=torch.int32)
+
+    def _s(self):
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def init_from_latents(self, latents: Tensor, t0: float):
+        _lib.check(self.lib.gecco_sampler_scale_f64(_vp(latents), t0, _vp(self.x_cur), self.n, self._s()), "sampler_scale")
+
+    def churn(self, noise: Tensor, step_stride: int):
+        _lib.check(self.lib.gecco_sampler_add_noise_f64(_vp(self.x_cur), _vp(noise), step_stride, _vp(self.sched),
+                                                        _vp(self.step), 3, 1, _vp(self.x_hat), _vp(self.x_in),
+                                                        _vp(self.sigma), self.n, self.B, self._s()), "sampler_churn")
+
+    def redo(self, noise: Tensor):
+        _lib.check(self.lib.gecco_sampler_add_noise_f64(_vp(self.x_cur), _vp(noise), 0, _vp(self.sched), _vp(self.step),
+                                                        4, 0, _vp(self.x_cur), None, None, self.n, self.B, self._s()),
+                   "sampler_redo")
+
+    def euler(self):
+        _lib.check(self.lib.gecco_sampler_euler_f64(_vp(self.x_hat), _vp(self.den), _vp(self.sched), _vp(self.step),
+                                                    _vp(self.d_cur), _vp(self.x_next), _vp(self.x_in), _vp(self.sigma),
+                                                    self.n, self.B, self._s()), "sampler_euler")
+
+    def heun(self):
+        _lib.check(self.lib.gecco_sampler_heun_f64(_vp(self.x_hat), _vp(self.x_next), _vp(self.den), _vp(self.d_cur),
+                                                   _vp(self.sched), _vp(self.step), _vp(self.x_cur), self.n, self._s()),
+                   "sampler_heun")
+
+    def advance(self):
+        _lib.check(self.lib.gecco_sampler_advance(_vp(self.step), 1, self._s()), "sampler_advance")
+
+
+class Diffusion(_Base):
+    """Backbone + conditioner + loss + reparameterisation (reference diffusion.py:168-470)."""
+
+    def __init__(self, backbone: nn.Module, conditioner: Conditioner, loss: EDMLoss, reparam: Reparam = NoReparam(dim=3)):
+        super().__init__()
+        self.backbone = backbone
+        self.conditioner = conditioner
+        self.loss = loss
+        self.reparam = reparam
+        self.sampler_kwargs = dict(num_steps=64, sigma_min=0.002, sigma_max=self.sigma_max, rho=7, S_churn=0.5,
+                                   S_min=0, S_max=float("inf"), S_noise=1, with_pbar=False)
+
+    def extra_repr(self) -> str:
+        return str(self.sampler_kwargs)
+
+    @property
+    def sigma_max(self) -> float:
+        return self.loss.schedule.sigma_max
+
+    def configure_optimizers(self):
+        return torch.optim.Adam(self.parameters(), lr=1e-4)
+
+    def training_step(self, batch: Example, batch_idx):
+        x, ctx = batch
+        if torch.is_grad_enabled():
+            raise GeccoTrainingNotSupported(
+                "training_step needs the backward kernels (SURVEY.md 8(f) rank 1); this round ships the forward, "
+                "sampling and upsampling paths")
+        loss = self.loss(self, x, ctx)
+        self.log("train_loss", loss)
+        return loss
+
+    def validation_step(self, batch: Example, batch_idx):
+        x, ctx = batch
+        with torch.no_grad():
+            loss = self.loss(self, x, ctx)
+        self.log("val_loss", loss)
+
+    def forward(self, data: Tensor, sigma: Tensor, raw_context: Any | None, post_context: Any | None = None,
+                do_cache: bool = False, cache: Any | None = None, out: Tensor | None = None) -> Tensor:
+        if post_context is None:
+            post_context = self.conditioner(raw_context)
+        return self.backbone(data, sigma, raw_context, post_context, do_cache, cache, out=out)
+
+    @property
+    def example_param(self) -> Tensor:
+        return next(self.parameters())
+
+    def t_steps(self, num_steps: int, sigma_max: float, sigma_min: float, rho: float) -> Tensor:
+        return karras_t_steps(num_steps, sigma_max, sigma_min, rho).to(self.example_param.device)
+
+    # ------------------------------------------------------------------------------------------ sampling
+    @torch.no_grad()
+    def sample_stochastic(self, shape: Sequence[int], context: Context3d | None, rng: torch.Generator = None,
+                          noise: Tensor | Sequence[Tensor] | None = None, use_graph: bool = True, **kwargs) -> Tensor:
+        """EDM stochastic Heun sampler (the paper's SDE sampler): num_steps steps = 2*num_steps - 1 evaluations.
+
+        `noise` (optional): (num_steps + 1, *shape) tensor or sequence — entry 0 is the initial latent draw, entry
+        i + 1 the churn noise of step i — replacing the generator draws (parity tests)."""
+        kw = {**self.sampler_kwargs, **kwargs}
+        num_steps = kw["num_steps"]
+        device, dtype = self.example_param.device, self.example_param.dtype
+        if dtype != torch.float32:
+            raise NotImplementedError("the HIP denoiser computes in float32")
+        shape = tuple(shape)
+        if noise is None:
+            if rng is None:
+                rng = torch.Generator(device).manual_seed(42)
+            noise = torch.randn((num_steps + 1, *shape), device=device, generator=rng, dtype=dtype)
+        elif not torch.is_tensor(noise):
+            noise = torch.stack([n.to(device=device, dtype=dtype) for n in noise])
+        noise = noise.to(device=device, dtype=dtype).contiguous()
+        assert noise.shape == (num_steps + 1, *shape), noise.shape
+
+        post_context = self.conditioner(context)
+        ts = karras_t_steps(num_steps, kw["sigma_max"], kw["sigma_min"], kw["rho"])
+        sched = build_schedule_table(ts, num_steps, kw["S_churn"], kw["S_min"], kw["S_max"], kw["S_noise"])
+        st = _SamplerState(shape, device, sched)
+        stride = st.n
+        churn_noise = noise[1:]
+
+        def evaluate():
+            self(st.x_in, st.sigma, context, post_context, out=st.den)
+
+        def full_step():      # steps 0 .. num_steps-2: Euler + 2nd-order correction
+            st.churn(churn_noise, stride)
+            evaluate()
+            st.euler()
+            evaluate()
+            st.heun()
+            st.advance()
+
+        def last_step():      # t_next = 0: Euler only (reference diffusion.py:339)
+            st.churn(churn_noise, stride)
+            evaluate()
+            st.euler()
+
+        st.init_from_latents(noise[0], float(ts[0]))
+        pbar = None
+        if kw["with_pbar"]:
+            from tqdm.auto import tqdm
+            pbar = tqdm(total=num_steps, unit="step")
+        if use_graph and num_steps > 2:
+            st.x_in.zero_()
+            st.sigma.fill_(1.0)
+            evaluate()  # warm-up: allocates plans / workspaces outside the capture
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                full_step()
+            for _ in range(num_steps - 1):
+                g.replay()
+                if pbar:
+                    pbar.update(1)
+        else:
+            for _ in range(num_steps - 1):
+                full_step()
+                if pbar:
+                    pbar.update(1)
+        last_step()
+        if pbar:
+            pbar.update(1)
+            pbar.close()
+        return self.reparam.diffusion_to_data(st.x_next, context)
+
+    @torch.no_grad()
+    def upsample(self, data: Tensor, new_latents: Tensor | None = None, n_new: int | None = None,
+                 context: Context3d | None = None, seed: int | None = 42, num_substeps=5,
+                 noise: Sequence[Tensor] | None = None, **kwargs):
+        """Generates `n_new` extra points conditionally independent given the per-layer inducer states of the known
+        cloud (reference diffusion.py:354-470).  `noise` (optional): the randn draws in the reference's call order
+        ([new_latents,] then per outer step: data noise, per sub-step churn noise [, redo noise])."""
+        kw = {**self.sampler_kwargs, **kwargs}
+        num_steps = kw["num_steps"]
+        device, dtype = self.example_param.device, self.example_param.dtype
+        if dtype != torch.float32:
+            raise NotImplementedError("the HIP denoiser computes in float32")
+        rng = torch.Generator(device=device)
+        if seed is not None:
+            rng = rng.manual_seed(seed)
+        it = iter(noise) if noise is not None else None
+
+        def randn(shape):
+            if it is not None:
+                t = next(it).to(device=device, dtype=dtype).contiguous()
+                assert tuple(t.shape) == tuple(shape), (t.shape, shape)
+                return t
+            return torch.randn(tuple(shape), device=device, dtype=dtype, generator=rng)
+
+        if (new_latents is None) == (n_new is None):
+            raise ValueError("Either new_latents or n_new must be specified, but not both.")
+        if new_latents is None:
+            new_latents = randn((data.shape[0], n_new, data.shape[2]))
+        assert isinstance(new_latents, Tensor)
+        new_latents = new_latents.to(device=device, dtype=dtype).contiguous()
+
+        data = self.reparam.data_to_diffusion(data.to(device=device, dtype=dtype).contiguous(), context)
+        post_context = self.conditioner(context)  # once, not per evaluation (reference quirk diffusion.py:415-421)
+        ts = karras_t_steps(num_steps, kw["sigma_max"], kw["sigma_min"], kw["rho"])
+        sched = build_schedule_table(ts, num_steps, kw["S_churn"], kw["S_min"], kw["S_max"], kw["S_noise"])
+        st = _SamplerState(tuple(new_latents.shape), device, sched)
+        lib = st.lib
+        B = data.shape[0]
+        data_ctx = torch.empty_like(data)
+        sigma_d = torch.empty(B, device=device, dtype=torch.float32)
+        st.init_from_latents(new_latents, float(ts[0]))
+
+        steps = range(num_steps)
+        if kw["with_pbar"]:
+            from tqdm.auto import tqdm
+            steps = tqdm(steps, total=num_steps)
+        for i in steps:
+            nz = randn(data.shape)
+            _lib.check(lib.gecco_sampler_add_noise_f32(_vp(data), _vp(nz), 0, _vp(st.sched), _vp(st.step), 0, _vp(data_ctx),
+                                                       _vp(sigma_d), data.numel(), B, st._s()), "sampler_add_noise_f32")
+            _, cache = self(data_ctx, sigma_d, context, post_context, do_cache=True, cache=None)
+            for u in range(num_substeps):
+                st.churn(randn(new_latents.shape), 0)
+                self(st.x_in, st.sigma, context, post_context, cache=cache, out=st.den)
+                st.euler()
+                if i < num_steps - 1:
+                    self(st.x_in, st.sigma, context, post_context, cache=cache, out=st.den)
+                    st.heun()
+                else:
+                    st.x_cur.copy_(st.x_next)
+                if u < num_substeps - 1 and i < num_steps - 1:
+                    st.redo(randn(new_latents.shape))
+            st.advance()
+        return self.reparam.diffusion_to_data(st.x_cur, context)

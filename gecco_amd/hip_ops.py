@@ -270,3 +270,147 @@ class LinearLiftPlan:
             "gecco_linear_lift_fwd_f32")
         res = (den, raw) if return_raw else den
         return (res, h_out) if do_cache else res
+
+
+# ------------------------------------------------------------------------------- conditional path
+def nchw_to_nhwc(f: Tensor) -> Tensor:
+    """(B, C, H, W) contiguous -> (B, H, W, C) contiguous."""
+    lib = _lib.load()
+    B, Cc, Hh, Ww = f.shape
+    out = torch.empty(B, Hh, Ww, Cc, device=f.device, dtype=torch.float32)
+    check(lib.gecco_nchw_to_nhwc_f32(_ptr(f), _ptr(out), B, Cc, Hh, Ww, _stream()), "gecco_nchw_to_nhwc_f32")
+    return out
+
+
+def to_channels_last_levels(features: Sequence[Tensor]) -> list[Tensor]:
+    """Feature pyramid levels as (B, H, W, C) contiguous fp32.  A level that is NCHW-shaped but already stored
+    channels-last (torch.channels_last) is re-viewed without a copy."""
+    out = []
+    for f in features:
+        if f.dtype != torch.float32:
+            f = f.float()
+        if f.dim() != 4:
+            raise _lib.GeccoHipError("feature maps must be (B, C, H, W)")
+        if f.is_contiguous(memory_format=torch.channels_last) and not f.is_contiguous():
+            out.append(f.permute(0, 2, 3, 1))  # a view: already (B, H, W, C) in memory
+        else:
+            out.append(nchw_to_nhwc(f.contiguous()))
+    return out
+
+
+def make_pyramid(levels_nhwc: Sequence[Tensor]) -> _lib.GeccoPyramid:
+    n = len(levels_nhwc)
+    if not 1 <= n <= 4:
+        raise _lib.GeccoHipError("1..4 pyramid levels supported")
+    pyr = _lib.GeccoPyramid()
+    pyr.n_levels = n
+    for l, f in enumerate(levels_nhwc):
+        assert f.is_contiguous() or f.permute(0, 3, 1, 2).is_contiguous(memory_format=torch.channels_last)
+        pyr.C[l], pyr.H[l], pyr.W[l] = f.shape[3], f.shape[1], f.shape[2]
+        if not f.is_cuda or f.dtype != torch.float32:
+            raise _lib.GeccoHipError("pyramid levels must be fp32 HIP tensors")
+        pyr.feat[l] = f.data_ptr()
+    return pyr
+
+
+def make_reparam(kind: int, mean: Tensor | None = None, std: Tensor | None = None, logit_scale: float = 1.1):
+    return _lib.GeccoReparam(kind, _ptr(mean), _ptr(std), logit_scale)
+
+
+def bilinear_taps(uv: Tensor, Hh: int, Ww: int):
+    lib = _lib.load()
+    n = uv.numel() // 2
+    x0 = torch.empty(n, device=uv.device, dtype=torch.int32)
+    y0 = torch.empty_like(x0)
+    wx = torch.empty(n, device=uv.device, dtype=torch.float32)
+    wy = torch.empty_like(wx)
+    check(lib.gecco_bilinear_taps_f32(_ptr(uv), Hh, Ww, C.c_void_p(x0.data_ptr()), C.c_void_p(y0.data_ptr()), _ptr(wx),
+                                      _ptr(wy), n, _stream()), "gecco_bilinear_taps_f32")
+    shp = uv.shape[:-1]
+    return x0.reshape(shp), y0.reshape(shp), wx.reshape(shp), wy.reshape(shp)
+
+
+def ray_lookup(geom: Tensor, K: Tensor, levels_nhwc: Sequence[Tensor], reparam: _lib.GeccoReparam,
+               coef: Tensor | None = None, want_stats: bool = False):
+    lib = _lib.load()
+    B, N, _ = geom.shape
+    pyr = make_pyramid(levels_nhwc)
+    Ct = sum(f.shape[3] for f in levels_nhwc)
+    out = torch.empty(B, N, Ct, device=geom.device, dtype=torch.float32)
+    stats = torch.empty(B, lib.gecco_lookup_row_tiles(N), 2, Ct, device=geom.device, dtype=torch.float32) if want_stats else None
+    check(lib.gecco_ray_lookup_f32(_ptr(geom), _ptr(coef), _ptr(K), C.byref(reparam), C.byref(pyr), _ptr(out),
+                                   _ptr(stats), B, N, _stream()), "gecco_ray_lookup_f32")
+    return (out, stats) if want_stats else out
+
+
+class RayNetworkPlan:
+    """EDMPrecond(RayNetwork(SetTransformer, reparam)) with a precomputed pyramid = the image-conditional
+    Diffusion.forward, one C call."""
+
+    def __init__(self, p: Mapping[str, Tensor], H: int, I: int = 64, pre: str = "", reparam_kind: int = 2,
+                 rp_mean: Tensor | None = None, rp_std: Tensor | None = None, logit_scale: float = 1.1,
+                 sigma_data: float = 1.0):
+        self.st = SetTransformerPlan(p, pre + "backbone.", H, I)
+        self.p = p
+        self.lib = self.st.lib
+        if reparam_kind == 2 and rp_mean is None:
+            rp_mean, rp_std = p[pre + "reparam.uvl_mean"], p[pre + "reparam.uvl_std"]
+        self._rp = (rp_mean, rp_std)
+        self.table = _lib.GeccoRayNetwork(
+            self.st.table, _ptr(p[pre + "xyz_embed.weight"]), _ptr(p[pre + "xyz_embed.bias"]),
+            _ptr(p[pre + "img_feature_proj.1.weight"]), _ptr(p[pre + "img_feature_proj.1.bias"]),
+            _ptr(p[pre + "output_proj.1.weight"]), _ptr(p[pre + "output_proj.1.bias"]),
+            make_reparam(reparam_kind, rp_mean, rp_std, logit_scale), sigma_data)
+        self._ws: dict[tuple, Tensor] = {}
+
+    def forward(self, x: Tensor, sigma: Tensor, K: Tensor, levels_nhwc: Sequence[Tensor], return_raw: bool = False,
+                cache: Sequence[Tensor] | None = None, do_cache: bool = False, out: Tensor | None = None):
+        B, N, _ = x.shape
+        pyr = make_pyramid(levels_nhwc)
+        key = (B, N, tuple(f.shape[1:] for f in levels_nhwc))
+        if key not in self._ws:
+            self._ws[key] = _ws(self.lib.gecco_ray_network_workspace_bytes(C.byref(self.table), C.byref(pyr), B, N),
+                                self.st.device)
+        ws = self._ws[key]
+        den = torch.empty_like(x) if out is None else out
+        raw = torch.empty_like(x) if return_raw else None
+        L = self.st.L
+        h_out = [torch.empty(B, self.st.I, self.st.C, device=x.device, dtype=torch.float32) for _ in range(L)] if do_cache else None
+        check(self.lib.gecco_ray_network_fwd_f32(
+            C.byref(self.table), _ptr(x), _ptr(sigma), _ptr(K), C.byref(pyr), _ptr(den), _ptr(raw),
+            self.st._ptr_array(cache, L), self.st._ptr_array(h_out, L), B, N, C.c_void_p(ws.data_ptr()), ws.numel(),
+            _stream()), "gecco_ray_network_fwd_f32")
+        res = (den, raw) if return_raw else den
+        return (res, h_out) if do_cache else res
+
+
+# ------------------------------------------------------------------------------- reparam / activation
+def _ptr_any(t: Tensor) -> C.c_void_p:
+    if not t.is_cuda or not t.is_contiguous() or t.dtype not in (torch.float32, torch.float64):
+        raise _lib.GeccoHipError("expected a contiguous fp32/fp64 HIP tensor")
+    return C.c_void_p(t.data_ptr())
+
+
+def gaussian_reparam(x: Tensor, mean: Tensor, sigma: Tensor, inverse: bool) -> Tensor:
+    lib = _lib.load()
+    y = torch.empty_like(x)
+    check(lib.gecco_gaussian_reparam(_ptr_any(x), _ptr(mean), _ptr(sigma), _ptr_any(y), x.numel(), x.shape[-1],
+                                     int(inverse), int(x.dtype == torch.float64), _stream()), "gecco_gaussian_reparam")
+    return y
+
+
+def uvl_reparam(x: Tensor, K: Tensor, mean: Tensor, std: Tensor, logit_scale: float, inverse: bool) -> Tensor:
+    lib = _lib.load()
+    B, N, _ = x.shape
+    y = torch.empty_like(x)
+    check(lib.gecco_uvl_reparam(_ptr_any(x), _ptr(K), _ptr(mean), _ptr(std), logit_scale, _ptr_any(y), B, N,
+                                int(inverse), int(x.dtype == torch.float64), _stream()), "gecco_uvl_reparam")
+    return y
+
+
+def gaussian_act(x: Tensor, alpha: Tensor, normalized: bool = True) -> Tensor:
+    lib = _lib.load()
+    y = torch.empty_like(x)
+    check(lib.gecco_gaussian_act_f32(_ptr(x), _ptr(alpha), _ptr(y), x.numel(), int(normalized), _stream()),
+          "gecco_gaussian_act_f32")
+    return y

@@ -143,6 +143,82 @@ int gecco_linear_lift_fwd_f32(const GeccoLinearLift* m, const float* x, const fl
                               size_t ws_bytes, void* stream);
 size_t gecco_linear_lift_workspace_bytes(const GeccoLinearLift* m, int B, int N);
 
+/* ---- image-conditional path ------------------------------------------------------------------- */
+
+typedef struct GeccoPyramid {     /* FeaturePyramidContext.features, models/feature_pyramid.py:17-20 */
+    int n_levels;                 /* <= 4 */
+    int C[4], H[4], W[4];
+    const float* feat[4];         /* CHANNELS-LAST (B, H, W, C) fp32 per level (see gecco_nchw_to_nhwc_f32) */
+} GeccoPyramid;
+
+typedef struct GeccoReparam {     /* reparam.py: 0 NoReparam, 1 GaussianReparam(mean, sigma), 2 UVLReparam */
+    int kind;
+    const float* mean;            /* (3) mean | uvl_mean */
+    const float* std;             /* (3) sigma | uvl_std */
+    float logit_scale;            /* UVLReparam.logit_scale (1.1) */
+} GeccoReparam;
+
+/* (B, C, H, W) -> (B, H, W, C).  Once per conditioner call; the lookup then runs 2*steps-1 times. */
+int gecco_nchw_to_nhwc_f32(const float* src, float* dst, int B, int C, int H, int W, void* stream);
+
+/* F.grid_sample(bilinear, zeros, align_corners=False) tap indices for uv in [0,1]^2 (models/ray.py:79-82):
+ * x0,y0 int32 (n), wx1 = ix - x0, wy1 = iy - y0.  Bit-exact against the oracle's op order. */
+int gecco_bilinear_taps_f32(const float* uv, int H, int W, int* x0, int* y0, float* wx1, float* wy1, size_t n,
+                            void* stream);
+
+/* RayNetwork.extract_image_features (models/ray.py:64-87): geom (B, N, 3) diffusion-space geometry
+ * (multiplied by coef's c_in when coef != NULL), K (B, 3, 3) -> out (B, N, sum C).  stats: NULL or
+ * (B, gecco_lookup_row_tiles(N), 2, sum C) GroupNorm partials of out. */
+int gecco_ray_lookup_f32(const float* geom, const float* coef, const float* K, const GeccoReparam* rp,
+                         const GeccoPyramid* pyr, float* out, float* stats, int B, int N, void* stream);
+int gecco_lookup_row_tiles(int N);
+
+typedef struct GeccoRayNetwork {  /* EDMPrecond(RayNetwork(SetTransformer, reparam)), models/ray.py:33-120 */
+    GeccoSetTransformer backbone;
+    const float* xyz_w;  const float* xyz_b;   /* xyz_embed (C, 3), (C)                  */
+    const float* img_w;  const float* img_b;   /* img_feature_proj.1 (C, sum C_l), (C)   */
+    const float* out_w;  const float* out_b;   /* output_proj.1 (3, C), (3)              */
+    GeccoReparam reparam;
+    float sigma_data;
+} GeccoRayNetwork;
+
+/* Diffusion.forward for the image-conditional model with a precomputed feature pyramid
+ * (diffusion.py:233-247, post_context given). */
+int gecco_ray_network_fwd_f32(const GeccoRayNetwork* m, const float* x, const float* sigma, const float* K,
+                              const GeccoPyramid* pyr, float* denoised, float* raw, const float* const* h_in,
+                              float* const* h_out, int B, int N, void* ws, size_t ws_bytes, void* stream);
+size_t gecco_ray_network_workspace_bytes(const GeccoRayNetwork* m, const GeccoPyramid* pyr, int B, int N);
+
+/* ---- reparameterisations and activation (reparam.py, models/activation.py) -------------------- */
+/* inverse = 0: data_to_diffusion, 1: diffusion_to_data.  is_f64 selects float/double x, y (the sampler state is fp64). */
+int gecco_gaussian_reparam(const void* x, const float* mean, const float* sigma, void* y, size_t n_elems, int dim,
+                           int inverse, int is_f64, void* stream);
+int gecco_uvl_reparam(const void* x, const float* K, const float* uvl_mean, const float* uvl_std, double logit_scale,
+                      void* y, int B, int N, int inverse, int is_f64, void* stream);
+int gecco_gaussian_act_f32(const float* x, const float* alpha, float* y, size_t n, int normalized, void* stream);
+
+/* ---- sampler state kernels (diffusion.py:271-352, 354-470) ------------------------------------- */
+/* sched: DEVICE table of doubles, GECCO_SCHED_COLS per step: {t_cur, t_hat, t_next, churn, redo, 0, 0, 0} with
+ * churn = sqrt(t_hat^2 - t_cur^2) * S_noise, redo = sqrt(t_cur^2 - t_next^2); step: DEVICE int (current row).
+ * noise pointers are advanced by step * noise_step_stride elements inside the kernel. */
+#define GECCO_SCHED_COLS 8
+/* x_out = x_cur + (double)((float)sched[step][col] * noise); x_in = (float)x_out; sigma[b] = (float)sched[step][sigma_col] */
+int gecco_sampler_add_noise_f64(const double* x_cur, const float* noise, size_t noise_step_stride, const double* sched,
+                                const int* step, int col, int sigma_col, double* x_out, float* x_in, float* sigma,
+                                size_t n, int B, void* stream);
+/* out = x + noise * (float)sched[step][col]; sigma[b] = that coefficient (upsampler's data_ctx, diffusion.py:430) */
+int gecco_sampler_add_noise_f32(const float* x, const float* noise, size_t noise_step_stride, const double* sched,
+                                const int* step, int col, float* out, float* sigma, size_t n, int B, void* stream);
+/* d_cur = (x_hat - den)/t_hat; x_next = x_hat + (t_next - t_hat) d_cur; x_in = (float)x_next; sigma[b] = t_next */
+int gecco_sampler_euler_f64(const double* x_hat, const float* den, const double* sched, const int* step, double* d_cur,
+                            double* x_next, float* x_in, float* sigma, size_t n, int B, void* stream);
+/* x_out = x_hat + (t_next - t_hat) (0.5 d_cur + 0.5 (x_next - den)/t_next) */
+int gecco_sampler_heun_f64(const double* x_hat, const double* x_next, const float* den, const double* d_cur,
+                           const double* sched, const int* step, double* x_out, size_t n, void* stream);
+int gecco_sampler_advance(int* step, int delta, void* stream);
+/* x = (double)latents * t0 */
+int gecco_sampler_scale_f64(const float* latents, double t0, double* x, size_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -226,7 +226,11 @@ def grid_sample_bilinear_zeros(feat: Tensor, uv: Tensor) -> Tensor:
     x0 = x0.long()
     y0 = y0.long()
     x1, y1 = x0 + 1, y0 + 1
-    wx0, wy0 = 1 - wx1, 1 - wy1  # == (x1 - ix), (y1 - iy)
+    # torch's weights (GridSampler): nw = (x1 - ix)(y1 - iy), ne = (ix - x0)(y1 - iy), ...
+    g = uv * 2 - 1
+    ix = ((g[..., 0] + 1) * Ww - 1) / 2
+    iy = ((g[..., 1] + 1) * Hh - 1) / 2
+    wx0, wy0 = x1.to(ix.dtype) - ix, y1.to(iy.dtype) - iy
     flat = feat.reshape(B, C, Hh * Ww)
     out = torch.zeros(B, uv.shape[1], C, dtype=feat.dtype)
 

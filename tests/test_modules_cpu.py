@@ -1,0 +1,128 @@
+"""CPU-side checks of the drop-in module API: constructor signatures, state-dict contract (the seeded state dicts
+of oracle/weights.py were loaded strict=True into the real reference by tools/make_golden.py, so loading them
+strict=True here pins key names and shapes), the sampler's host-side schedule, refusal to run without HIP."""
+import math
+
+import pytest
+import torch
+
+from oracle import cases, cpu_ref
+from oracle import weights as W
+
+
+def build_uncond(d, L, sigma_max=165.0):
+    from gecco_amd.diffusion import Diffusion, EDMLoss, EDMPrecond, IdleConditioner, LogUniformSchedule
+    from gecco_amd.models.activation import GaussianActivation
+    from gecco_amd.models.linear_lift import LinearLift
+    from gecco_amd.models.set_transformer import SetTransformer
+    from gecco_amd.reparam import GaussianReparam
+    net = LinearLift(inner=SetTransformer(n_layers=L, num_inducers=cases.I, feature_dim=d, t_embed_dim=1,
+                                          num_heads=cases.H, activation=GaussianActivation), feature_dim=d)
+    return Diffusion(backbone=EDMPrecond(model=net), conditioner=IdleConditioner(),
+                     reparam=GaussianReparam(torch.tensor(cases.GAUSS_MEAN), torch.tensor(cases.GAUSS_SIGMA)),
+                     loss=EDMLoss(schedule=LogUniformSchedule(max=sigma_max)))
+
+
+def build_cond(d, L, context_dims=(96, 192, 384), conditioner=None):
+    from gecco_amd.diffusion import Conditioner, Diffusion, EDMLoss, EDMPrecond, LogUniformSchedule
+    from gecco_amd.models.activation import GaussianActivation
+    from gecco_amd.models.ray import RayNetwork
+    from gecco_amd.models.set_transformer import SetTransformer
+    from gecco_amd.reparam import UVLReparam
+    rp = UVLReparam(torch.tensor([0.0, 0.0, 1.38]), torch.tensor([0.56, 0.60, 0.49]))
+    net = RayNetwork(backbone=SetTransformer(n_layers=L, num_inducers=cases.I, feature_dim=d, t_embed_dim=1,
+                                             num_heads=cases.H, activation=GaussianActivation),
+                     reparam=rp, context_dims=context_dims)
+    return Diffusion(backbone=EDMPrecond(model=net), conditioner=conditioner or Conditioner(), reparam=rp,
+                     loss=EDMLoss(schedule=LogUniformSchedule(max=180.0)))
+
+
+def uncond_state_dict(p):
+    sd = {"backbone.model." + k: v for k, v in p.items()}
+    sd["reparam.mean"] = torch.tensor(cases.GAUSS_MEAN)
+    sd["reparam.sigma"] = torch.tensor(cases.GAUSS_SIGMA)
+    return sd
+
+
+def test_state_dict_contract_unconditional():
+    d, L = 384, 6
+    m = build_uncond(d, L)
+    sd = uncond_state_dict(W.linear_lift_state_dict(1, d, L, cases.I, cases.H))
+    assert len(sd) == 204
+    m.load_state_dict(sd, strict=True)
+    assert sum(p.numel() for p in m.parameters()) == 13_481_103
+    assert sorted(m.state_dict()) == sorted(sd)
+
+
+def test_state_dict_contract_conditional():
+    d, L = 128, 2
+    m = build_cond(d, L)
+    p = W.ray_network_state_dict(1, d, L, cases.I, cases.H)
+    sd = {"backbone.model." + k: v for k, v in p.items()}
+    sd["reparam.uvl_mean"], sd["reparam.uvl_std"] = p["reparam.uvl_mean"], p["reparam.uvl_std"]
+    m.load_state_dict(sd, strict=True)
+    assert sorted(m.state_dict()) == sorted(sd)
+
+
+def test_init_matches_reference_conventions():
+    from gecco_amd.models.activation import GaussianActivation
+    from gecco_amd.models.set_transformer import BroadcastingLayer
+    torch.manual_seed(0)
+    layer = BroadcastingLayer(64, 64, 1, num_heads=8, activation=GaussianActivation)
+    n = layer.broadcast_norm
+    assert n.scale.weight.abs().sum() == 0 and n.bias.weight.abs().sum() == 0 and n.bias.bias.abs().sum() == 0
+    assert torch.all(n.scale.bias == 1)
+    assert layer.mlp[1].alpha.item() == 1.0
+    assert layer.broadcast.pool.inducers.shape == (1, 8, 64, 8)
+    # residual branches are scaled by 0.1 at init: out_proj std << default in_proj std
+    assert layer.broadcast.unpool.out_proj.weight.std() < 0.3 * layer.broadcast.unpool.in_proj_weight.std()
+
+
+def test_schedule_table_matches_oracle():
+    from gecco_amd.diffusion import build_schedule_table, karras_t_steps
+    ts = karras_t_steps(128, 165.0, 0.002, 7)
+    assert torch.equal(ts, cpu_ref.t_steps(128, 165.0, 0.002, 7))
+    tab = build_schedule_table(ts, 128, 0.5, 0.0, float("inf"), 1.0)
+    for i in (0, 5, 127):
+        g = cpu_ref.churn_gamma(float(ts[i]), 128, 0.5, 0.0, float("inf"))
+        t_hat = ts[i] + g * ts[i]
+        assert tab[i, 0] == ts[i] and tab[i, 1] == t_hat and tab[i, 2] == ts[i + 1]
+        assert tab[i, 3] == (t_hat ** 2 - ts[i] ** 2).sqrt()
+    tab2 = build_schedule_table(ts, 128, 0.5, 1.0, 10.0, 1.0)  # churn only inside [S_min, S_max]
+    assert tab2[0, 3] == 0 and tab2[127, 3] == 0 and (tab2[:, 3] > 0).any()
+
+
+def test_modules_refuse_cpu_and_autograd():
+    from gecco_amd import _lib
+    from gecco_amd._grad import GeccoTrainingNotSupported
+    m = build_uncond(64, 1)
+    x, s = torch.randn(2, 64, 3), torch.tensor([1.0, 2.0])
+    with torch.no_grad(), pytest.raises(_lib.GeccoHipError):
+        m(x, s, None)
+    with pytest.raises(GeccoTrainingNotSupported):
+        m(x, s, None)  # grad enabled + trainable parameters: no silent grad-less forward
+    with pytest.raises(ValueError):
+        m.upsample(x, new_latents=None, n_new=None)
+
+
+def test_structs_and_config(tmp_path):
+    from gecco_amd import load_config
+    from gecco_amd.structs import Context3d, Example
+    ctx = Context3d(image=torch.zeros(2, 3, 8, 8), K=torch.eye(3).repeat(2, 1, 1))
+    ex = Example(data=torch.zeros(2, 5, 3), ctx=ctx)
+    ex64 = ex.apply_to_tensors(lambda t: t.double())
+    assert ex64.data.dtype == torch.float64 and ex64.ctx.K.dtype == torch.float64 and ex.data.dtype == torch.float32
+    assert "Context3d" in repr(ex)
+    cfg = tmp_path / "cfg.py"
+    cfg.write_text("model = 41 + 1\n")
+    assert load_config(str(cfg)).model == 42
+    with pytest.raises(ValueError):
+        load_config(str(tmp_path / "cfg.txt"))
+
+
+def test_log_uniform_schedule_is_stratified():
+    from gecco_amd.diffusion import LogUniformSchedule
+    s = LogUniformSchedule(max=165.0)(torch.zeros(64, 10, 3)).reshape(-1)
+    assert s.shape == (64,) and torch.all(s[1:] > s[:-1]) and s.min() >= 0.002 and s.max() <= 165.0
+    lo = math.log(0.002) + torch.arange(64) / 64 * (math.log(165.0) - math.log(0.002))
+    assert torch.all(s.log() >= lo - 1e-5)

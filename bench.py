@@ -185,16 +185,13 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    from gecco_amd import distributed as gd   # rendezvous / barrier / max-over-ranks (covered on gloo in tests/)
+    gd.init("nccl", dev)
 
     import __graft_entry__ as ge
     if rank == 0 and not os.path.exists(ge.LIB):
         ge.build()
-    if world > 1:
-        dist.barrier()
+    gd.barrier()
     from gecco_amd import hip_ops as ops
 
     p_cpu = random_state_dict(seed=3)
@@ -210,21 +207,15 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    gd.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    gd.barrier()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = gd.max_over_ranks(time.perf_counter() - t0, dev)
     assert torch.isfinite(out).all(), "non-finite denoiser output"
 
     ms = dt / args.steps * 1e3
@@ -273,6 +264,7 @@ def main():
     if rank == 0:
         print(json.dumps(rec))
     if world > 1:
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 

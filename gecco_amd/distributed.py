@@ -1,0 +1,92 @@
+"""Multi-GPU execution of the denoiser: one process per GPU, batch-sharded replicas.
+
+Every cross-element coupling of the network is *within* a sample (GroupNorm statistics per (sample, group), softmax
+per (sample, head)), so evaluation, sampling and upsampling shard by batch with NO data-path collective
+("replicas only").  torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in
+the CPU tests) is used for rendezvous, barriers, the max-over-ranks timing and — only when the caller wants the
+union on every rank — an all-gather of the finished (B, N, 3) clouds.
+
+Sharding invariance: the HIP forward is bit-identical for a sample whatever batch it is evaluated in (no summation
+order depends on B), and `sample_noise` derives each sample's noise from (seed, global sample index) alone, so a
+sharded `sample_stochastic` returns exactly the clouds a single GPU would.
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, Sequence
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+
+def env_rank_world() -> tuple[int, int, int]:
+    """(rank, world_size, local_rank) from the torch.distributed.run environment (1-process defaults)."""
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init(backend: str = "nccl", device: torch.device | None = None) -> tuple[int, int]:
+    """Initialise the default process group from the environment; no-op for world_size 1."""
+    rank, world, _ = env_rank_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+        dist.init_process_group(backend, **kw)
+    return rank, world
+
+
+def shard_range(total: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous [lo, hi) slice of `total` samples owned by `rank`; sizes differ by at most one."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def sample_noise(shape_per_sample: Sequence[int], num_draws: int, seed: int, lo: int, hi: int,
+                 device: torch.device | str, dtype=torch.float32) -> Tensor:
+    """(num_draws, hi - lo, *shape_per_sample) standard normal noise where sample g's draws depend only on
+    (seed, g): the same bits whichever rank / shard size generates them."""
+    out = torch.empty((num_draws, hi - lo, *shape_per_sample), device=device, dtype=dtype)
+    for j, g in enumerate(range(lo, hi)):
+        gen = torch.Generator(device=device).manual_seed((int(seed) * 1_000_003 + g) % (2 ** 63 - 1))
+        out[:, j] = torch.randn((num_draws, *shape_per_sample), device=device, dtype=dtype, generator=gen)
+    return out
+
+
+def max_over_ranks(seconds: float, device: torch.device | str = "cpu") -> float:
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier() -> None:
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def all_gather_batch(local: Tensor, total: int) -> Tensor:
+    """Concatenate the per-rank shards (possibly of unequal size) along dim 0 on every rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    sizes = [shard_range(total, r, world) for r in range(world)]
+    m = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((m, *local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0)
+
+
+def sample_stochastic_sharded(sample_fn: Callable[..., Tensor], shape: Sequence[int], num_steps: int, seed: int = 42,
+                              device: torch.device | str = "cuda", gather: bool = True, **kwargs) -> Tensor:
+    """Batch-sharded `Diffusion.sample_stochastic`: rank r draws the clouds [lo, hi) of the global batch `shape[0]`.
+    `sample_fn(shape, noise=..., num_steps=...)` is `functools.partial(model.sample_stochastic, context=ctx_shard)`.
+    Returns the local shard, or the whole batch on every rank when `gather`."""
+    rank, world = (dist.get_rank(), dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else (0, 1)
+    lo, hi = shard_range(shape[0], rank, world)
+    noise = sample_noise(tuple(shape[1:]), num_steps + 1, seed, lo, hi, device)
+    local = sample_fn((hi - lo, *shape[1:]), noise=noise, num_steps=num_steps, **kwargs)
+    return all_gather_batch(local, shape[0]) if gather else local

@@ -1,0 +1,75 @@
+"""The N > 1 path on CPU: two gloo processes exercise the batch-sharding helpers that bench.py --gpus N and a
+sharded sampler use on RCCL (no data-path collective: replicas only)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gecco_amd import distributed as gd
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _toy_sampler(shape, noise, num_steps):
+    """Stands in for Diffusion.sample_stochastic on CPU: a per-sample function of that sample's noise only."""
+    assert noise.shape == (num_steps + 1, *shape)
+    x = noise[0] * 3.0
+    for i in range(num_steps):
+        x = torch.tanh(x) + 0.1 * noise[i + 1]
+    return x.double()
+
+
+def _worker(rank, world, port, B, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    r, w = gd.init("gloo")
+    assert (r, w) == (rank, world)
+    full = gd.sample_stochastic_sharded(_toy_sampler, (B, 16, 3), num_steps=4, seed=7, device="cpu")
+    local = gd.sample_stochastic_sharded(_toy_sampler, (B, 16, 3), num_steps=4, seed=7, device="cpu", gather=False)
+    lo, hi = gd.shard_range(B, rank, world)
+    assert torch.equal(full[lo:hi], local)
+    t = gd.max_over_ranks(1.0 + rank)
+    gd.barrier()
+    q.put((rank, full, t))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [6, 5])
+def test_two_rank_sharded_sampling_equals_single_process(B):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    single = _toy_sampler((B, 16, 3), gd.sample_noise((16, 3), 5, 7, 0, B, "cpu"), 4)
+    for rank, full, t in got:
+        assert torch.equal(full, single)      # union of the shards == the single-process batch, bit for bit
+        assert t == 2.0                       # max over ranks
+
+
+def test_shard_range_partitions():
+    for total in (1, 7, 64, 65):
+        for world in (1, 2, 3, 8):
+            rs = [gd.shard_range(total, r, world) for r in range(world)]
+            assert rs[0][0] == 0 and rs[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
+            assert max(h - l for l, h in rs) - min(h - l for l, h in rs) <= 1
+
+
+def test_sample_noise_is_shard_invariant():
+    a = gd.sample_noise((8, 3), 3, 42, 0, 6, "cpu")
+    b = torch.cat([gd.sample_noise((8, 3), 3, 42, 0, 2, "cpu"), gd.sample_noise((8, 3), 3, 42, 2, 6, "cpu")], dim=1)
+    assert torch.equal(a, b)
+    assert not torch.equal(a[:, 0], a[:, 1])

@@ -1,11 +1,19 @@
-"""The HIP path is forward-only in this round (backward kernels are SURVEY.md 8(f) rank 1).  Rather than
-silently returning tensors without a grad graph, every module refuses to run when autograd would
-need one."""
+"""Autograd routing.  The fused inference entry points keep no intermediates; when autograd would record a call
+(`needs_grad`) the modules switch to the unfused training path of gecco_amd/autograd.py (forward and backward both
+in HIP).  Modules without a backward yet (RayNetwork's projective lookup) refuse instead of silently returning
+tensors without a grad graph."""
 import torch
 
 
 class GeccoTrainingNotSupported(NotImplementedError):
     pass
+
+
+def needs_grad(module, *tensors) -> bool:
+    """True when autograd would record this call: grad mode on and a trainable parameter or input involved."""
+    if not torch.is_grad_enabled():
+        return False
+    return any(torch.is_tensor(t) and t.requires_grad for t in tensors) or any(p.requires_grad for p in module.parameters())
 
 
 def require_no_grad(module, *tensors) -> None:

@@ -53,6 +53,14 @@ class GeccoRayNetwork(C.Structure):
                 ("out_w", c_f), ("out_b", c_f), ("reparam", GeccoReparam), ("sigma_data", C.c_float)]
 
 
+class GeccoGemm(C.Structure):
+    _fields_ = [("A", c_f), ("B", c_f), ("bias", c_f), ("C", c_f), ("Z", C.c_int), ("zdiv", C.c_int), ("M", C.c_int),
+                ("N", C.c_int), ("K", C.c_int), ("lda", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int),
+                ("sA1", C.c_longlong), ("sA2", C.c_longlong), ("sB1", C.c_longlong), ("sB2", C.c_longlong),
+                ("sC1", C.c_longlong), ("sC2", C.c_longlong), ("a_kmajor", C.c_int), ("b_kmajor", C.c_int),
+                ("scale", C.c_float)]
+
+
 i, sz, vp, fl, db = C.c_int, C.c_size_t, C.c_void_p, C.c_float, C.c_double
 PP = C.POINTER(C.c_void_p)
 
@@ -95,6 +103,19 @@ SIGNATURES = {
     "gecco_sampler_heun_f64": (i, [vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "gecco_sampler_advance": (i, [vp, i, vp]),
     "gecco_sampler_scale_f64": (i, [vp, db, vp, sz, vp]),
+    "gecco_gemm_f32": (i, [C.POINTER(GeccoGemm), vp]),
+    "gecco_reduce_batch_f32": (i, [vp, vp, sz, i, sz, i, vp]),
+    "gecco_softmax_fwd_f32": (i, [vp, vp, sz, i, fl, vp]),
+    "gecco_softmax_bwd_f32": (i, [vp, vp, vp, sz, i, fl, vp]),
+    "gecco_gauss_act_bwd_f32": (i, [vp, vp, vp, vp, vp, sz, i, vp]),
+    "gecco_gauss_act_bwd_blocks": (i, [sz]),
+    "gecco_col_dot_stats_f32": (i, [vp, vp, vp, i, i, i, vp]),
+    "gecco_adagn_bwd_coeffs_f32": (i, [vp, i, vp, i, i, vp, i, C.POINTER(GeccoAdaGN), vp, vp, vp, vp, vp, i, i, i, fl, vp]),
+    "gecco_affine2_apply_f32": (i, [vp, vp, vp, vp, vp, vp, i, i, i, vp]),
+    "gecco_adagn_param_grads_f32": (i, [vp, vp, vp, i, i, i, vp, vp, vp, vp, vp]),
+    "gecco_lift_bwd_f32": (i, [vp, vp, vp, i, i, i, vp]),
+    "gecco_lower_bwd_f32": (i, [vp, vp, vp, vp, vp, sz, i, fl, vp]),
+    "gecco_lower_bwd_blocks": (i, [sz]),
 }
 
 _lib = None

@@ -1,0 +1,369 @@
+"""Training path: torch.autograd Functions whose forward AND backward run in libgecco_hip.so.
+
+The inference path fuses a whole evaluation into one C call and keeps nothing; training needs the intermediates, so
+it runs the reference's op sequence unfused (models/set_transformer.py:155-168) with every op a Function:
+Linear / AdaGN / GaussianActivation / pool & unpool attention (scores materialised, products on the general
+strided-batched GEMM with per-operand layout flags, so no tensor is transposed for a backward product) / lift /
+lower.  Cross-workgroup reductions use per-block partials summed in a fixed order: gradients are bitwise
+reproducible.  EDM preconditioning and the loss are (B, N, 3) elementwise torch ops.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+from torch import Tensor
+
+from . import _lib, hip_ops
+from .hip_ops import _ptr, _stream
+
+GN_EPS = 1e-5
+
+
+def _f(t: Tensor) -> Tensor:
+    return t.contiguous() if not t.is_contiguous() else t
+
+
+def _gemm(A, B, out, *, Z, zdiv, M, N, K, lda, ldb, ldc, sA=(0, 0), sB=(0, 0), sC=(0, 0), a_km=False, b_km=False,
+          scale=1.0, bias=None, a_off=0, b_off=0, c_off=0):
+    lib = _lib.load()
+    es = 4
+    g = _lib.GeccoGemm(C.c_void_p(A.data_ptr() + a_off * es), C.c_void_p(B.data_ptr() + b_off * es),
+                       _ptr(bias), C.c_void_p(out.data_ptr() + c_off * es), Z, zdiv, M, N, K, lda, ldb, ldc,
+                       sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], int(a_km), int(b_km), scale)
+    _lib.check(lib.gecco_gemm_f32(C.byref(g), _stream()), "gecco_gemm_f32")
+    return out
+
+
+def _reduce(parts: Tensor, n: int, Z: int, stride: int) -> Tensor:
+    lib = _lib.load()
+    out = torch.empty(n, device=parts.device, dtype=torch.float32)
+    _lib.check(lib.gecco_reduce_batch_f32(_ptr(parts), _ptr(out), n, Z, stride, 0, _stream()), "gecco_reduce_batch_f32")
+    return out
+
+
+def _new(*shape, like: Tensor) -> Tensor:
+    return torch.empty(*shape, device=like.device, dtype=torch.float32)
+
+
+# ------------------------------------------------------------------------------------------- Linear
+class LinearFn(torch.autograd.Function):
+    """y = x @ W^T + b on (B, R, K)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        x = _f(x)
+        ctx.save_for_backward(x, W)
+        ctx.has_bias = b is not None
+        return hip_ops.linear(x, W, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dy = _f(dy)
+        B, R, K = x.shape
+        Nout = W.shape[0]
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:  # dx = dy W : W read k-major (reduction over its rows)
+            dx = _gemm(dy, W, _new(B, R, K, like=x), Z=1, zdiv=1, M=B * R, N=K, K=Nout, lda=Nout, ldb=K, ldc=K, b_km=True)
+        if ctx.needs_input_grad[1]:  # dW = dy^T x : both read k-major; one partial per sample, summed in order
+            parts = _gemm(dy, x, _new(B, Nout, K, like=x), Z=B, zdiv=1, M=Nout, N=K, K=R, lda=Nout, ldb=K, ldc=K,
+                          sA=(R * Nout, 0), sB=(R * K, 0), sC=(Nout * K, 0), a_km=True, b_km=True)
+            dW = _reduce(parts, Nout * K, B, Nout * K).reshape(Nout, K)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            st = hip_ops.col_stats(dy)  # (B, T, 2, Nout): [..., 0, :] = column sums
+            db = _reduce(st, Nout, B * st.shape[1], 2 * Nout)
+        return dx, dW, db
+
+
+# ------------------------------------------------------------------------------------------- AdaGN / GroupNorm
+class AdaGNFn(torch.autograd.Function):
+    """y = scale(t) * GroupNorm(x) + bias(t) on (B, R, C); params None -> plain GroupNorm."""
+
+    @staticmethod
+    def forward(ctx, x, t, sw, sb, bw, bb, G, eps):
+        x = _f(x)
+        lib = _lib.load()
+        B, R, Cc = x.shape
+        stats = hip_ops.col_stats(x)
+        params = None if sw is None else (sw, sb, bw, bb)
+        t2 = None if t is None else _f(t.reshape(B, -1).float())
+        a, o = hip_ops.adagn_coeffs(stats, R, t2, params, G, eps)
+        ctx.save_for_backward(x, stats, t2, sw, sb)
+        ctx.G, ctx.eps, ctx.affine = G, eps, sw is not None
+        return hip_ops.affine_apply(x, a, o)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats, t2, sw, sb = ctx.saved_tensors
+        dy = _f(dy)
+        lib = _lib.load()
+        B, R, Cc = x.shape
+        gst = torch.empty_like(stats)
+        _lib.check(lib.gecco_col_dot_stats_f32(_ptr(dy), _ptr(x), _ptr(gst), B, R, Cc, _stream()), "col_dot_stats")
+        cA, cB, cC, ds, dz = (_new(B, Cc, like=x) for _ in range(5))
+        p = _lib.GeccoAdaGN(_ptr(sw), _ptr(sb), None, None) if ctx.affine else None
+        ctxd = 0 if t2 is None else t2.shape[1]
+        _lib.check(lib.gecco_adagn_bwd_coeffs_f32(_ptr(stats), stats.shape[1], _ptr(gst), gst.shape[1], R, _ptr(t2), ctxd,
+                                                  C.byref(p) if p is not None else None, _ptr(cA), _ptr(cB), _ptr(cC),
+                                                  _ptr(ds), _ptr(dz), B, Cc, ctx.G, ctx.eps, _stream()), "adagn_bwd_coeffs")
+        dx = torch.empty_like(x)
+        _lib.check(lib.gecco_affine2_apply_f32(_ptr(dy), _ptr(x), _ptr(cA), _ptr(cB), _ptr(cC), _ptr(dx), B, R, Cc,
+                                               _stream()), "affine2_apply")
+        if not ctx.affine:
+            return dx, None, None, None, None, None, None, None
+        dsw, dbw = _new(Cc, ctxd, like=x), _new(Cc, ctxd, like=x)
+        dsb, dbb = _new(Cc, like=x), _new(Cc, like=x)
+        _lib.check(lib.gecco_adagn_param_grads_f32(_ptr(ds), _ptr(dz), _ptr(t2), B, Cc, ctxd, _ptr(dsw), _ptr(dsb),
+                                                   _ptr(dbw), _ptr(dbb), _stream()), "adagn_param_grads")
+        return dx, None, dsw, dsb, dbw, dbb, None, None
+
+
+# ------------------------------------------------------------------------------------------- activation
+class GaussActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, alpha, normalized):
+        u = _f(u)
+        ctx.save_for_backward(u, alpha)
+        ctx.normalized = normalized
+        return hip_ops.gaussian_act(u, alpha, normalized)
+
+    @staticmethod
+    def backward(ctx, dy):
+        u, alpha = ctx.saved_tensors
+        dy = _f(dy)
+        lib = _lib.load()
+        n = u.numel()
+        nb = lib.gecco_gauss_act_bwd_blocks(n)
+        du, part = torch.empty_like(u), _new(nb, like=u)
+        _lib.check(lib.gecco_gauss_act_bwd_f32(_ptr(u), _ptr(dy), _ptr(alpha), _ptr(du), _ptr(part), n, int(ctx.normalized),
+                                               _stream()), "gauss_act_bwd")
+        dalpha = _reduce(part, 1, nb, 1).reshape(alpha.shape)
+        return du, dalpha, None
+
+
+# ------------------------------------------------------------------------------------------- attention
+def _softmax(S: Tensor, scale: float) -> Tensor:
+    lib = _lib.load()
+    P = torch.empty_like(S)
+    _lib.check(lib.gecco_softmax_fwd_f32(_ptr(S), _ptr(P), S.numel() // S.shape[-1], S.shape[-1], scale, _stream()), "softmax_fwd")
+    return P
+
+
+def _softmax_bwd(P: Tensor, dP: Tensor, scale: float) -> Tensor:
+    lib = _lib.load()
+    dS = torch.empty_like(P)
+    _lib.check(lib.gecco_softmax_bwd_f32(_ptr(P), _ptr(dP), _ptr(dS), P.numel() // P.shape[-1], P.shape[-1], scale, _stream()),
+               "softmax_bwd")
+    return dS
+
+
+class PoolAttnFn(torch.autograd.Function):
+    """AttentionPool core: KV (B, N, 2C), inducers (1, H, I, hd) -> merged heads (B, I, C)."""
+
+    @staticmethod
+    def forward(ctx, KV, ind, H):
+        KV, ind = _f(KV), _f(ind)
+        B, N, C2 = KV.shape
+        Cc, I, hd = C2 // 2, ind.shape[2], ind.shape[3]
+        sc = 1.0 / math.sqrt(hd)
+        S = _new(B, H, I, N, like=KV)
+        _gemm(ind, KV, S, Z=B * H, zdiv=H, M=I, N=N, K=hd, lda=hd, ldb=C2, ldc=N, sA=(0, I * hd), sB=(N * C2, hd),
+              sC=(H * I * N, I * N))
+        P = _softmax(S, sc)
+        O = _new(B, I, Cc, like=KV)
+        _gemm(P, KV, O, Z=B * H, zdiv=H, M=I, N=hd, K=N, lda=N, ldb=C2, ldc=Cc, sA=(H * I * N, I * N), sB=(N * C2, hd),
+              sC=(I * Cc, hd), b_km=True, b_off=Cc)
+        ctx.save_for_backward(KV, ind, P)
+        ctx.H = H
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        KV, ind, P = ctx.saved_tensors
+        dO = _f(dO)
+        H = ctx.H
+        B, N, C2 = KV.shape
+        Cc, I, hd = C2 // 2, ind.shape[2], ind.shape[3]
+        sc = 1.0 / math.sqrt(hd)
+        zP, zKV = (H * I * N, I * N), (N * C2, hd)
+        dKV = torch.empty_like(KV)
+        # dV[n, d] = sum_i P[i, n] dO[i, d]
+        _gemm(P, dO, dKV, Z=B * H, zdiv=H, M=N, N=hd, K=I, lda=N, ldb=Cc, ldc=C2, sA=zP, sB=(I * Cc, hd), sC=zKV,
+              a_km=True, b_km=True, c_off=Cc)
+        # dP[i, n] = sum_d dO[i, d] V[n, d]
+        dP = torch.empty_like(P)
+        _gemm(dO, KV, dP, Z=B * H, zdiv=H, M=I, N=N, K=hd, lda=Cc, ldb=C2, ldc=N, sA=(I * Cc, hd), sB=zKV, sC=zP, b_off=Cc)
+        dS = _softmax_bwd(P, dP, sc)
+        # dK[n, d] = sum_i dS[i, n] Q[i, d]
+        _gemm(dS, ind, dKV, Z=B * H, zdiv=H, M=N, N=hd, K=I, lda=N, ldb=hd, ldc=C2, sA=zP, sB=(0, I * hd), sC=zKV,
+              a_km=True, b_km=True)
+        # dQ[i, d] = sum_b sum_n dS[i, n] K[n, d]
+        dQp = _new(B, H, I, hd, like=KV)
+        _gemm(dS, KV, dQp, Z=B * H, zdiv=H, M=I, N=hd, K=N, lda=N, ldb=C2, ldc=hd, sA=zP, sB=zKV, sC=(H * I * hd, I * hd),
+              b_km=True)
+        dind = _reduce(dQp, H * I * hd, B, H * I * hd).reshape(ind.shape)
+        return dKV, dind, None
+
+
+class UnpoolAttnFn(torch.autograd.Function):
+    """MultiheadAttention core: q (B, N, C), kvh (B, I, 2C) -> (B, N, C)."""
+
+    @staticmethod
+    def forward(ctx, q, kvh, H):
+        q, kvh = _f(q), _f(kvh)
+        B, N, Cc = q.shape
+        I, hd = kvh.shape[1], Cc // H
+        sc = 1.0 / math.sqrt(hd)
+        S = _new(B, H, N, I, like=q)
+        zq, zk, zS = (N * Cc, hd), (I * 2 * Cc, hd), (H * N * I, N * I)
+        _gemm(q, kvh, S, Z=B * H, zdiv=H, M=N, N=I, K=hd, lda=Cc, ldb=2 * Cc, ldc=I, sA=zq, sB=zk, sC=zS)
+        P = _softmax(S, sc)
+        O = torch.empty_like(q)
+        _gemm(P, kvh, O, Z=B * H, zdiv=H, M=N, N=hd, K=I, lda=I, ldb=2 * Cc, ldc=Cc, sA=zS, sB=zk, sC=zq, b_km=True, b_off=Cc)
+        ctx.save_for_backward(q, kvh, P)
+        ctx.H = H
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        q, kvh, P = ctx.saved_tensors
+        dO = _f(dO)
+        H = ctx.H
+        B, N, Cc = q.shape
+        I, hd = kvh.shape[1], Cc // H
+        sc = 1.0 / math.sqrt(hd)
+        zq, zk, zS = (N * Cc, hd), (I * 2 * Cc, hd), (H * N * I, N * I)
+        dkvh = torch.empty_like(kvh)
+        # dv[i, d] = sum_n P[n, i] dO[n, d]
+        _gemm(P, dO, dkvh, Z=B * H, zdiv=H, M=I, N=hd, K=N, lda=I, ldb=Cc, ldc=2 * Cc, sA=zS, sB=zq, sC=zk, a_km=True,
+              b_km=True, c_off=Cc)
+        # dP[n, i] = sum_d dO[n, d] v[i, d]
+        dP = torch.empty_like(P)
+        _gemm(dO, kvh, dP, Z=B * H, zdiv=H, M=N, N=I, K=hd, lda=Cc, ldb=2 * Cc, ldc=I, sA=zq, sB=zk, sC=zS, b_off=Cc)
+        dS = _softmax_bwd(P, dP, sc)
+        # dq[n, d] = sum_i dS[n, i] k[i, d]
+        dq = torch.empty_like(q)
+        _gemm(dS, kvh, dq, Z=B * H, zdiv=H, M=N, N=hd, K=I, lda=I, ldb=2 * Cc, ldc=Cc, sA=zS, sB=zk, sC=zq, b_km=True)
+        # dk[i, d] = sum_n dS[n, i] q[n, d]
+        _gemm(dS, q, dkvh, Z=B * H, zdiv=H, M=I, N=hd, K=N, lda=I, ldb=Cc, ldc=2 * Cc, sA=zS, sB=zq, sC=zk, a_km=True, b_km=True)
+        return dq, dkvh, None
+
+
+# ------------------------------------------------------------------------------------------- lift / lower
+class LiftFn(torch.autograd.Function):
+    """Linear(3 -> C) on (B, N, 3); the geometry input never needs a gradient."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        x = _f(x)
+        ctx.save_for_backward(x)
+        ctx.C = W.shape[0]
+        return hip_ops.lift(x, None, W, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _f(dy)
+        lib = _lib.load()
+        B, N, _ = x.shape
+        Cc = ctx.C
+        T = lib.gecco_stats_row_tiles(N)
+        part = _new(B, T, 4, Cc, like=x)
+        _lib.check(lib.gecco_lift_bwd_f32(_ptr(dy), _ptr(x), _ptr(part), B, N, Cc, _stream()), "lift_bwd")
+        red = _reduce(part, 4 * Cc, B * T, 4 * Cc).reshape(4, Cc)
+        return None, red[:3].t().contiguous(), red[3].contiguous()
+
+
+class LowerFn(torch.autograd.Function):
+    """F = Linear(C -> 3)(LayerNorm_C(feat)) on (B, N, C)."""
+
+    @staticmethod
+    def forward(ctx, feat, W, b, eps):
+        feat = _f(feat)
+        ctx.save_for_backward(feat, W)
+        ctx.eps = eps
+        return hip_ops.lower_edm(feat, None, None, W, b, eps=eps)
+
+    @staticmethod
+    def backward(ctx, dF):
+        feat, W = ctx.saved_tensors
+        dF = _f(dF)
+        lib = _lib.load()
+        B, N, Cc = feat.shape
+        rows = B * N
+        nb = lib.gecco_lower_bwd_blocks(rows)
+        dfeat, part = torch.empty_like(feat), _new(nb, 3 * Cc + 4, like=feat)
+        _lib.check(lib.gecco_lower_bwd_f32(_ptr(feat), _ptr(dF), _ptr(W), _ptr(dfeat), _ptr(part), rows, Cc, ctx.eps,
+                                           _stream()), "lower_bwd")
+        red = _reduce(part, 3 * Cc + 4, nb, 3 * Cc + 4)
+        return dfeat, red[: 3 * Cc].reshape(3, Cc), red[3 * Cc: 3 * Cc + 3].contiguous(), None
+
+
+# ------------------------------------------------------------------------------------------- network composition
+def adagn(mod, x, t):
+    return AdaGNFn.apply(x, t, mod.scale.weight, mod.scale.bias, mod.bias.weight, mod.bias.bias, mod.gn.num_groups, mod.gn.eps)
+
+
+def mlp(mod, x):
+    from .models.activation import GaussianActivation
+    mods = list(mod)
+    i = 0
+    while i < len(mods):
+        lin = mods[i]
+        x = LinearFn.apply(x, lin.weight, lin.bias)
+        if i + 1 < len(mods):
+            act = mods[i + 1]
+            if not isinstance(act, GaussianActivation):
+                raise NotImplementedError(f"training on HIP needs GaussianActivation (got {type(act).__name__})")
+            x = GaussActFn.apply(x, act.alpha, act.normalized)
+        i += 2
+    return x
+
+
+def broadcasting_layer(layer, x, t, h=None):
+    """BroadcastingLayer.forward with autograd (reference models/set_transformer.py:155-168, 92-117, 47-65)."""
+    bc = layer.broadcast
+    H = bc.pool.num_heads
+    Cc = x.shape[-1]
+    y = adagn(layer.broadcast_norm, x, t)
+    if h is None:
+        KV = LinearFn.apply(y, bc.pool.kv_proj.weight, None)
+        merged = PoolAttnFn.apply(KV, bc.pool.inducers, H)
+        h = LinearFn.apply(merged, bc.pool.out_proj.weight, None)
+        h = adagn(bc.norm_1, h, t)
+        h = mlp(bc.mlp, h)
+        h = adagn(bc.norm_2, h, t)
+    W, b = bc.unpool.in_proj_weight, bc.unpool.in_proj_bias
+    q = LinearFn.apply(y, W[:Cc], b[:Cc])
+    kvh = LinearFn.apply(h, W[Cc:], b[Cc:])
+    attn = UnpoolAttnFn.apply(q, kvh, H)
+    x = x + LinearFn.apply(attn, bc.unpool.out_proj.weight, bc.unpool.out_proj.bias)
+    y = adagn(layer.mlp_norm, x, t)
+    x = x + mlp(layer.mlp, y)
+    return x, h
+
+
+def set_transformer(st, feats, t, return_h=False, hs=None):
+    hs = [None] * len(st.layers) if hs is None else hs
+    stored = []
+    for layer, h in zip(st.layers, hs):
+        feats, h = broadcasting_layer(layer, feats, t, h)
+        stored.append(h)
+    return feats, (stored if return_h else None)
+
+
+def linear_lift_edm(net, x, sigma, sigma_data, do_cache=False, cache=None):
+    """EDMPrecond(LinearLift).forward with autograd (reference diffusion.py:46-57, linear_lift.py:44-46)."""
+    sigma = sigma.reshape(-1, 1, 1).float()
+    sd = float(sigma_data)
+    c_skip = sd ** 2 / (sigma ** 2 + sd ** 2)
+    c_out = sigma * sd / (sigma ** 2 + sd ** 2).sqrt()
+    c_in = 1 / (sd ** 2 + sigma ** 2).sqrt()
+    c_noise = sigma.log() / 4
+    feats = LiftFn.apply(c_in * x, net.lift.weight, net.lift.bias)
+    feats, out_cache = set_transformer(net.inner, feats, c_noise, do_cache, cache)
+    F_x = LowerFn.apply(feats, net.lower[1].weight, net.lower[1].bias, net.lower[0].eps)
+    den = c_skip * x + c_out * F_x
+    return (den, out_cache) if do_cache else den

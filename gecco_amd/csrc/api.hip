@@ -495,4 +495,67 @@ int gecco_sampler_scale_f64(const float* latents, double t0, double* x, size_t n
     return 0;
 }
 
+// ---------------------------------------------------------------------------- training path
+int gecco_gemm_f32(const GeccoGemm* g, void* stream) {
+    if (!g || !g->A || !g->B || !g->C) return fail(-1, "gemm: null argument");
+    GemmGeneralArgs a;
+    a.A = g->A; a.B = g->B; a.bias = g->bias; a.C = g->C; a.Z = g->Z; a.zdiv = g->zdiv > 0 ? g->zdiv : 1;
+    a.M = g->M; a.N = g->N; a.K = g->K; a.lda = g->lda; a.ldb = g->ldb; a.ldc = g->ldc;
+    a.sA1 = g->sA1; a.sA2 = g->sA2; a.sB1 = g->sB1; a.sB2 = g->sB2; a.sC1 = g->sC1; a.sC2 = g->sC2;
+    a.a_kmajor = g->a_kmajor; a.b_kmajor = g->b_kmajor; a.scale = g->scale;
+    TRY(gemm_general_launch(a, (hipStream_t)stream), "gemm");
+    return 0;
+}
+int gecco_reduce_batch_f32(const float* parts, float* out, size_t n, int Z, size_t stride, int accumulate, void* stream) {
+    TRY(reduce_batch_launch(parts, out, n, Z, stride, accumulate, (hipStream_t)stream), "reduce_batch");
+    return 0;
+}
+int gecco_softmax_fwd_f32(const float* S, float* P, size_t rows, int n, float scale, void* stream) {
+    TRY(softmax_fwd_launch(S, P, rows, n, scale, (hipStream_t)stream), "softmax_fwd");
+    return 0;
+}
+int gecco_softmax_bwd_f32(const float* P, const float* dP, float* dS, size_t rows, int n, float scale, void* stream) {
+    TRY(softmax_bwd_launch(P, dP, dS, rows, n, scale, (hipStream_t)stream), "softmax_bwd");
+    return 0;
+}
+int gecco_gauss_act_bwd_blocks(size_t n) { return gauss_act_bwd_blocks(n); }
+int gecco_gauss_act_bwd_f32(const float* u, const float* dy, const float* alpha, float* du, float* partial, size_t n,
+                            int normalized, void* stream) {
+    TRY(gauss_act_bwd_launch(u, dy, alpha, du, partial, n, normalized, (hipStream_t)stream), "gauss_act_bwd");
+    return 0;
+}
+int gecco_col_dot_stats_f32(const float* dy, const float* x, float* gstats, int B, int rows, int C, void* stream) {
+    TRY(col_dot_stats_launch(dy, x, gstats, B, rows, C, (hipStream_t)stream), "col_dot_stats");
+    return 0;
+}
+int gecco_adagn_bwd_coeffs_f32(const float* xstats, int Tx, const float* gstats, int Tg, int rows, const float* t,
+                               int ctx_dim, const GeccoAdaGN* p, float* cA, float* cB, float* cC, float* ds, float* dz,
+                               int B, int C, int G, float eps, void* stream) {
+    TRY(adagn_bwd_coeffs_launch(xstats, Tx, gstats, Tg, rows, t, ctx_dim, p ? p->scale_w : nullptr,
+                                p ? p->scale_b : nullptr, cA, cB, cC, ds, dz, B, C, G, eps, (hipStream_t)stream),
+        "adagn_bwd_coeffs");
+    return 0;
+}
+int gecco_affine2_apply_f32(const float* dy, const float* x, const float* cA, const float* cB, const float* cC,
+                            float* dx, int B, int rows, int C, void* stream) {
+    TRY(affine2_apply_launch(dy, x, cA, cB, cC, dx, B, rows, C, (hipStream_t)stream), "affine2_apply");
+    return 0;
+}
+int gecco_adagn_param_grads_f32(const float* ds, const float* dz, const float* t, int B, int C, int ctx_dim,
+                                float* d_scale_w, float* d_scale_b, float* d_bias_w, float* d_bias_b, void* stream) {
+    TRY(adagn_param_grads_launch(ds, dz, t, B, C, ctx_dim, d_scale_w, d_scale_b, d_bias_w, d_bias_b,
+                                 (hipStream_t)stream), "adagn_param_grads");
+    return 0;
+}
+int gecco_lift_bwd_f32(const float* dY, const float* xin, float* partial, int B, int N, int C, void* stream) {
+    TRY(lift_bwd_launch(dY, xin, partial, B, N, C, (hipStream_t)stream), "lift_bwd");
+    return 0;
+}
+int gecco_lower_bwd_blocks(size_t rows) { return lower_bwd_blocks(rows); }
+int gecco_lower_bwd_f32(const float* feat, const float* dF, const float* W, float* dfeat, float* partial, size_t rows,
+                        int C, float eps, void* stream) {
+    TRY(lower_bwd_launch(feat, dF, W, dfeat, partial, rows, C, eps, (hipStream_t)stream), "lower_bwd");
+    return 0;
+}
+
 }  // extern "C"

@@ -21,6 +21,41 @@ struct GemmArgs {
 int gemm_row_tile(int rows);  // row-tile height the GEMM uses for `rows` rows per sample
 int gemm_f32_launch(const GemmArgs& g, hipStream_t st);
 
+// gemm_general_f32.hip — C[z] = scale * op(A[z]) op(B[z]) (+ bias), per-operand layout flag, two-level batch strides
+struct GemmGeneralArgs {
+    const float* A;   // a_kmajor ? (K, lda>=M) : (M, lda>=K)
+    const float* B;   // b_kmajor ? (K, ldb>=N) : (N, ldb>=K)
+    const float* bias;  // (N) or null
+    float* C;         // (M, ldc>=N)
+    int Z, zdiv;      // batch count; z = z1 * zdiv + z2
+    int M, N, K;
+    int lda, ldb, ldc;
+    long long sA1, sA2, sB1, sB2, sC1, sC2;  // element strides of the outer / inner batch index
+    int a_kmajor, b_kmajor;
+    float scale;
+};
+int gemm_general_launch(const GemmGeneralArgs& g, hipStream_t st);
+int reduce_batch_launch(const float* parts, float* out, size_t n, int Z, size_t stride, int accumulate, hipStream_t st);
+
+// backward.hip
+int softmax_fwd_launch(const float* S, float* P, size_t rows, int n, float scale, hipStream_t st);
+int softmax_bwd_launch(const float* P, const float* dP, float* dS, size_t rows, int n, float scale, hipStream_t st);
+int gauss_act_bwd_blocks(size_t n);
+int gauss_act_bwd_launch(const float* u, const float* dy, const float* alpha, float* du, float* partial, size_t n,
+                         int normalized, hipStream_t st);
+int col_dot_stats_launch(const float* dy, const float* x, float* stats, int B, int rows, int C, hipStream_t st);
+int adagn_bwd_coeffs_launch(const float* xstats, int Tx, const float* gstats, int Tg, int rows, const float* t,
+                            int ctx_dim, const float* scale_w, const float* scale_b, float* cA, float* cB, float* cC,
+                            float* ds, float* dz, int B, int C, int G, float eps, hipStream_t st);
+int affine2_apply_launch(const float* dy, const float* x, const float* cA, const float* cB, const float* cC, float* dx,
+                         int B, int rows, int C, hipStream_t st);
+int adagn_param_grads_launch(const float* ds, const float* dz, const float* t, int B, int C, int ctx_dim,
+                             float* d_scale_w, float* d_scale_b, float* d_bias_w, float* d_bias_b, hipStream_t st);
+int lift_bwd_launch(const float* dY, const float* xin, float* partial, int B, int N, int C, hipStream_t st);
+int lower_bwd_blocks(size_t rows);
+int lower_bwd_launch(const float* feat, const float* dF, const float* W, float* dfeat, float* partial, size_t rows,
+                     int C, float eps, hipStream_t st);
+
 // attention_f32.hip
 int pool_attn_launch(const float* KV, const float* inducers, float* part_o, float* part_ml, float* merged,
                      int B, int N, int C, int H, int I, int nsplit, hipStream_t st);

@@ -96,8 +96,8 @@ class LogUniformSchedule(nn.Module):
 
 
 class EDMLoss(nn.Module):
-    """Weighted denoising loss (reference diffusion.py:118-143).  Evaluating it needs only the forward kernels;
-    differentiating it needs the backward kernels (next scope row), so it refuses to build a grad graph."""
+    """Weighted denoising loss (reference diffusion.py:118-143).  With grad enabled the denoiser runs on the unfused
+    HIP training path (gecco_amd/autograd.py), so `loss.backward()` produces every parameter gradient in HIP."""
 
     def __init__(self, schedule: nn.Module, sigma_data: float = 1.0, loss_scale: float = 100.0):
         super().__init__()
@@ -225,10 +225,6 @@ class Diffusion(_Base):
 
     def training_step(self, batch: Example, batch_idx):
         x, ctx = batch
-        if torch.is_grad_enabled():
-            raise GeccoTrainingNotSupported(
-                "training_step needs the backward kernels (SURVEY.md 8(f) rank 1); this round ships the forward, "
-                "sampling and upsampling paths")
         loss = self.loss(self, x, ctx)
         self.log("train_loss", loss)
         return loss

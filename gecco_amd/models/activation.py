@@ -3,7 +3,7 @@ import torch
 import torch.nn as nn
 
 from .. import hip_ops
-from .._grad import require_no_grad
+from .._grad import needs_grad
 
 
 class GaussianActivation(nn.Module):
@@ -15,5 +15,7 @@ class GaussianActivation(nn.Module):
         self.normalized = normalized
 
     def forward(self, x):
-        require_no_grad(self, x)
+        if needs_grad(self, x):
+            from ..autograd import GaussActFn
+            return GaussActFn.apply(x, self.alpha, self.normalized)
         return hip_ops.gaussian_act(x.contiguous(), self.alpha, self.normalized)

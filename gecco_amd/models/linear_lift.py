@@ -6,7 +6,7 @@ from typing import Any
 from torch import Tensor, nn
 
 from .. import hip_ops
-from .._grad import require_no_grad
+from .._grad import needs_grad
 from .set_transformer import SetTransformer, _PlanCache
 
 
@@ -30,8 +30,12 @@ class LinearLift(nn.Module):
     def forward(self, geometry: Tensor, embed: Tensor, raw_context: Any, post_context: Any, do_cache: bool = False,
                 cache: list[Tensor] | None = None):
         del raw_context, post_context
-        require_no_grad(self, geometry, embed)
         self._check()
+        if needs_grad(self, geometry, embed):
+            from .. import autograd as ag
+            feats = ag.LiftFn.apply(geometry.float(), self.lift.weight, self.lift.bias)
+            feats, out_cache = ag.set_transformer(self.inner, feats, embed.float(), do_cache, cache)
+            return ag.LowerFn.apply(feats, self.lower[1].weight, self.lower[1].bias, self.lower[0].eps), out_cache
         feats, stats = hip_ops.lift(geometry.float().contiguous(), None, self.lift.weight, self.lift.bias, want_stats=True)
         feats, out_cache, _ = self.inner.plan().forward_(feats, embed.float(), stats=stats, hs=cache, return_h=do_cache)
         out = hip_ops.lower_edm(feats, None, None, self.lower[1].weight, self.lower[1].bias, eps=self.lower[0].eps)
@@ -41,8 +45,10 @@ class LinearLift(nn.Module):
     def fused_edm(self, x: Tensor, sigma: Tensor, raw_context, post_context, do_cache: bool, cache, sigma_data: float,
                   out: Tensor | None = None):
         del raw_context, post_context
-        require_no_grad(self, x, sigma)
         self._check()
+        if needs_grad(self, x, sigma):
+            from .. import autograd as ag
+            return ag.linear_lift_edm(self, x.float(), sigma, sigma_data, do_cache, cache)
 
         def build():
             st = self.inner.plan()

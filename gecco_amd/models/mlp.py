@@ -7,7 +7,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from .. import hip_ops
-from .._grad import require_no_grad
+from .._grad import needs_grad
 from .activation import GaussianActivation
 
 
@@ -21,8 +21,11 @@ class MLP(nn.Sequential):
         super().__init__(*layers)
 
     def forward(self, x: Tensor) -> Tensor:
-        require_no_grad(self, x)
         shape = x.shape
+        if needs_grad(self, x):
+            from .. import autograd as ag
+            h3 = x.reshape(-1, shape[-2], shape[-1]) if x.dim() >= 3 else x.reshape(1, -1, shape[-1])
+            return ag.mlp(self, h3).reshape(*shape[:-1], -1)
         h = x.reshape(-1, shape[-2], shape[-1]) if x.dim() >= 3 else x.reshape(1, -1, shape[-1])
         h = h.contiguous()
         mods = list(self)

@@ -4,7 +4,7 @@ import torch
 from torch import Tensor, nn
 
 from .. import hip_ops
-from .._grad import require_no_grad
+from .._grad import needs_grad
 
 
 class AdaNorm(nn.Module):
@@ -27,8 +27,10 @@ class AdaGN(AdaNorm):
 
     def forward(self, x: Tensor, ctx: Tensor) -> Tensor:
         """x (B, n, C) [or (B, ..., C)], ctx (B, 1, ctx_dim)."""
-        require_no_grad(self, x, ctx)
         B, Cc = x.shape[0], x.shape[-1]
+        if needs_grad(self, x, ctx):
+            from .. import autograd as ag
+            return ag.adagn(self, x.reshape(B, -1, Cc), ctx.reshape(B, 1, -1).float()).reshape(x.shape)
         y = hip_ops.adagn(x.reshape(B, -1, Cc).contiguous(), ctx.reshape(B, 1, -1).float(),
                           (self.scale.weight, self.scale.bias, self.bias.weight, self.bias.bias),
                           self.gn.num_groups, self.gn.eps)

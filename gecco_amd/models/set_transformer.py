@@ -7,7 +7,7 @@ import torch
 from torch import Tensor, nn
 
 from .. import hip_ops
-from .._grad import require_no_grad
+from .._grad import needs_grad
 from .activation import GaussianActivation
 from .mlp import MLP
 from .normalization import AdaGN
@@ -57,7 +57,10 @@ class AttentionPool(nn.Module):
         self.dims_per_head = dims_per_head
 
     def forward(self, kv: Tensor) -> Tensor:
-        require_no_grad(self, kv)
+        if needs_grad(self, kv):
+            from .. import autograd as ag
+            KV = ag.LinearFn.apply(kv, self.kv_proj.weight, None)
+            return ag.LinearFn.apply(ag.PoolAttnFn.apply(KV, self.inducers, self.num_heads), self.out_proj.weight, None)
         KV = hip_ops.linear(kv.contiguous(), self.kv_proj.weight)
         merged = hip_ops.pool_attn(KV, self.inducers, self.num_heads)
         return hip_ops.linear(merged, self.out_proj.weight)
@@ -78,10 +81,17 @@ class Broadcast(nn.Module):
         self.unpool = nn.MultiheadAttention(feature_dim, num_heads, batch_first=True)
 
     def forward(self, x: Tensor, t_embed: Tensor, return_h: bool = False, h: Tensor | None = None):
-        require_no_grad(self, x, t_embed)
         x = x.contiguous()
         Cc = x.shape[-1]
         H = self.pool.num_heads
+        if needs_grad(self, x, t_embed):
+            from .. import autograd as ag
+            if h is None:
+                h = self.norm_2(self.mlp(self.norm_1(self.pool(x), t_embed)), t_embed)
+            W, b = self.unpool.in_proj_weight, self.unpool.in_proj_bias
+            attn = ag.UnpoolAttnFn.apply(ag.LinearFn.apply(x, W[:Cc], b[:Cc]), ag.LinearFn.apply(h, W[Cc:], b[Cc:]), H)
+            out = ag.LinearFn.apply(attn, self.unpool.out_proj.weight, self.unpool.out_proj.bias)
+            return (out, h) if return_h else (out, None)
         if h is None:
             h = self.pool(x)
             h = self.norm_1(h, t_embed)
@@ -121,7 +131,10 @@ class BroadcastingLayer(nn.Module):
         return self._cache.get(self, build)
 
     def forward(self, x: Tensor, t_embed: Tensor, return_h: bool = False, h: Tensor | None = None):
-        require_no_grad(self, x, t_embed)
+        if needs_grad(self, x, t_embed):
+            from .. import autograd as ag
+            y, h_out = ag.broadcasting_layer(self, x, t_embed.float(), h)
+            return y, (h_out if return_h else None)
         y, hs, _ = self._plan().forward_(x.contiguous().clone(), t_embed.float(), hs=None if h is None else [h.contiguous()],
                                          return_h=return_h)
         return y, (hs[0] if return_h else None)
@@ -149,6 +162,8 @@ class SetTransformer(nn.Module):
         return self._cache.get(self, build)
 
     def forward(self, features: Tensor, t_embed: Tensor, return_h: bool = False, hs: list[Tensor] | None = None):
-        require_no_grad(self, features, t_embed)
+        if needs_grad(self, features, t_embed):
+            from .. import autograd as ag
+            return ag.set_transformer(self, features, t_embed.float(), return_h, hs)
         y, stored, _ = self.plan().forward_(features.contiguous().clone(), t_embed.float(), hs=hs, return_h=return_h)
         return (y, stored) if return_h else (y, None)

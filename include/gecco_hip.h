@@ -219,6 +219,50 @@ int gecco_sampler_advance(int* step, int delta, void* stream);
 /* x = (double)latents * t0 */
 int gecco_sampler_scale_f64(const float* latents, double t0, double* x, size_t n, void* stream);
 
+/* ---- training path (EDMLoss.backward: diffusion.py:136-143 through autograd) ------------------------ */
+
+/* C[z](M x N) = scale * op(A[z]) op(B[z]) (+ bias[n]);  X row-major in its own index (k contiguous) or "k-major"
+ * (X[k][row]).  z = z1*zdiv + z2 with element strides (s?1, s?2) per operand.  Backward products use the SAME
+ * tensors as the forward ones, only with other layout flags (dX = dY W: B k-major; dW = dY^T X: both k-major). */
+typedef struct GeccoGemm {
+    const float* A; const float* B; const float* bias; float* C;
+    int Z, zdiv, M, N, K, lda, ldb, ldc;
+    long long sA1, sA2, sB1, sB2, sC1, sC2;
+    int a_kmajor, b_kmajor;
+    float scale;
+} GeccoGemm;
+int gecco_gemm_f32(const GeccoGemm* g, void* stream);
+/* out[i] (+)= sum_z parts[z*stride + i], fixed order (deterministic parameter gradients). */
+int gecco_reduce_batch_f32(const float* parts, float* out, size_t n, int Z, size_t stride, int accumulate, void* stream);
+
+/* Row softmax of the materialised attention scores: P = softmax(scale*S) over the last dim n; and its backward
+ * dS = scale * P * (dP - sum(P*dP)). */
+int gecco_softmax_fwd_f32(const float* S, float* P, size_t rows, int n, float scale, void* stream);
+int gecco_softmax_bwd_f32(const float* P, const float* dP, float* dS, size_t rows, int n, float scale, void* stream);
+
+/* GaussianActivation backward: du = dy*g'(u); partial (gecco_gauss_act_bwd_blocks(n)) per-block sums of dy*dg/dalpha. */
+int gecco_gauss_act_bwd_f32(const float* u, const float* dy, const float* alpha, float* du, float* partial, size_t n,
+                            int normalized, void* stream);
+int gecco_gauss_act_bwd_blocks(size_t n);
+
+/* AdaGN / GroupNorm backward.  gstats (B, gecco_stats_row_tiles(rows), 2, C) = {sum dy, sum dy*x};
+ * coefficients give dx = dy*cA + x*cB + cC; ds, dz (B, C) are the grads of the per-(b,c) scale and shift. */
+int gecco_col_dot_stats_f32(const float* dy, const float* x, float* gstats, int B, int rows, int C, void* stream);
+int gecco_adagn_bwd_coeffs_f32(const float* xstats, int Tx, const float* gstats, int Tg, int rows, const float* t,
+                               int ctx_dim, const GeccoAdaGN* p, float* cA, float* cB, float* cC, float* ds, float* dz,
+                               int B, int C, int G, float eps, void* stream);
+int gecco_affine2_apply_f32(const float* dy, const float* x, const float* cA, const float* cB, const float* cC,
+                            float* dx, int B, int rows, int C, void* stream);
+int gecco_adagn_param_grads_f32(const float* ds, const float* dz, const float* t, int B, int C, int ctx_dim,
+                                float* d_scale_w, float* d_scale_b, float* d_bias_w, float* d_bias_b, void* stream);
+
+/* lift backward: partial (B, gecco_stats_row_tiles(N), 4, C) = {dW[:,0], dW[:,1], dW[:,2], db} per row tile. */
+int gecco_lift_bwd_f32(const float* dY, const float* xin, float* partial, int B, int N, int C, void* stream);
+/* lower backward (LayerNorm + Linear(C->3)): dfeat (rows, C); partial (gecco_lower_bwd_blocks(rows), 3*C + 4). */
+int gecco_lower_bwd_f32(const float* feat, const float* dF, const float* W, float* dfeat, float* partial, size_t rows,
+                        int C, float eps, void* stream);
+int gecco_lower_bwd_blocks(size_t rows);
+
 #ifdef __cplusplus
 }
 #endif

@@ -99,8 +99,15 @@ def test_modules_refuse_cpu_and_autograd():
     x, s = torch.randn(2, 64, 3), torch.tensor([1.0, 2.0])
     with torch.no_grad(), pytest.raises(_lib.GeccoHipError):
         m(x, s, None)
+    with pytest.raises(_lib.GeccoHipError):
+        m(x, s, None)  # grad enabled: the HIP training path — still no CPU fallback
+    mc = build_cond(64, 1, (8, 16, 24))
+    from gecco_amd.models.feature_pyramid import FeaturePyramidContext
+    from gecco_amd.structs import Context3d
+    ctx = Context3d(image=torch.zeros(2, 3, 8, 8), K=torch.eye(3).repeat(2, 1, 1))
+    pyr = FeaturePyramidContext(features=[torch.zeros(2, c, 4, 4) for c in (8, 16, 24)], K=ctx.K)
     with pytest.raises(GeccoTrainingNotSupported):
-        m(x, s, None)  # grad enabled + trainable parameters: no silent grad-less forward
+        mc(x, s, ctx, pyr)  # RayNetwork has no backward yet: refuses rather than returning grad-less tensors
     with pytest.raises(ValueError):
         m.upsample(x, new_latents=None, n_new=None)
 

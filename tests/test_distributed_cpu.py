@@ -73,3 +73,49 @@ def test_sample_noise_is_shard_invariant():
     b = torch.cat([gd.sample_noise((8, 3), 3, 42, 0, 2, "cpu"), gd.sample_noise((8, 3), 3, 42, 2, 6, "cpu")], dim=1)
     assert torch.equal(a, b)
     assert not torch.equal(a[:, 0], a[:, 1])
+
+
+def _dp_worker(rank, world, port, q):
+    """Two ranks, each with its shard of a batch: flat-buffer gradient all-reduce == single-process full-batch grads."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    gd.init("gloo")
+    torch.manual_seed(rank + 5)                     # ranks start from different weights ...
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 3))
+    net[2].bias.requires_grad_(False)
+    gd.broadcast_parameters(net)                    # ... and agree after the broadcast
+    g = torch.Generator().manual_seed(0)
+    x, y = torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)
+    lo, hi = gd.shard_range(8, rank, world)
+    red = gd.GradAllReducer(net)
+    loss = ((net(x[lo:hi]) - y[lo:hi]) ** 2).mean()
+    loss.backward()
+    red.all_reduce_()
+    q.put((rank, [p.detach().clone() for p in net.parameters()], [p.grad.clone() for p in net.parameters() if p.requires_grad]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_all_reduce_matches_full_batch():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, w0, g0), (_, w1, g1) = got
+    assert all(torch.equal(a, b) for a, b in zip(w0, w1))
+    assert all(torch.equal(a, b) for a, b in zip(g0, g1))
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 3))
+    net[2].bias.requires_grad_(False)
+    with torch.no_grad():
+        for p, w in zip(net.parameters(), w0):
+            p.copy_(w)
+    g = torch.Generator().manual_seed(0)
+    x, y = torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)
+    ((net(x) - y) ** 2).mean().backward()           # equal shards: mean of shard means == full-batch mean
+    ref = [p.grad for p in net.parameters() if p.requires_grad]
+    assert all(torch.allclose(a, b, atol=1e-6) for a, b in zip(g0, ref))

@@ -29,5 +29,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
 // GaussianActivation (reference models/activation.py:17-24): (exp(-u^2/(2 a^2)) - 0.7)/0.28
 __device__ __forceinline__ float gauss_act(float u, float neg_inv_2a2, bool normalized) {
     float y = __expf(u * u * neg_inv_2a2);
-    return normalized ? (y - 0.7f) / 0.28f : y;
+    // (y - 0.7) / 0.28 as a multiply by the rounded reciprocal: <= 1 ulp from the IEEE division, ~9 VALU fewer
+    return normalized ? (y - 0.7f) * (1.0f / 0.28f) : y;
 }

@@ -370,6 +370,14 @@ int gemm_row_tile(int rows) { return rows >= 128 ? 128 : 64; }
 
 int gemm_f32_launch(const GemmArgs& g, hipStream_t st) {
     if (g.K % 4 || g.lda % 4 || g.ldw % 4) return -2;  // 16-byte vector loads
+    {
+        static int use_dma = -1;  // GECCO_GEMM_DMA=0 forces the register-staged kernel (A/B runs)
+        if (use_dma < 0) {
+            const char* e = getenv("GECCO_GEMM_DMA");
+            use_dma = e ? atoi(e) : 1;
+        }
+        if (use_dma && gemm_f32_dma_supported(g)) return gemm_f32_dma_launch(g, st);
+    }
     const bool pro = g.pro_a != nullptr;
     // 128x128x16: 41 KB LDS and <= 256 VGPR -> two persistent blocks per CU (BK = 32 would spill once the next
     // tile's prefetch registers are live across the epilogue)

@@ -20,6 +20,9 @@ struct GemmArgs {
 
 int gemm_row_tile(int rows);  // row-tile height the GEMM uses for `rows` rows per sample
 int gemm_f32_launch(const GemmArgs& g, hipStream_t st);
+// gemm_f32_dma.hip — LDS-DMA fast path of the same contract
+bool gemm_f32_dma_supported(const GemmArgs& g);
+int gemm_f32_dma_launch(const GemmArgs& g, hipStream_t st);
 
 // gemm_general_f32.hip — C[z] = scale * op(A[z]) op(B[z]) (+ bias), per-operand layout flag, two-level batch strides
 struct GemmGeneralArgs {

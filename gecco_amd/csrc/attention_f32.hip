@@ -18,9 +18,13 @@ namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
 
+// K/V/Q staging tiles are wave-private: a wave's own LDS writes are ordered before its later reads once they have
+// completed, so a counter wait replaces the workgroup barrier and the four waves run decoupled.
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 // ------------------------------------------------------------------------------------- pool
 template <int HD>
-__global__ __launch_bounds__(256) void pool_attn_kernel(const float* __restrict__ KV,
+__global__ __launch_bounds__(256, 2) void pool_attn_kernel(const float* __restrict__ KV,
                                                         const float* __restrict__ Qind,
                                                         float* __restrict__ part_o, float* __restrict__ part_ml,
                                                         int B, int N, int C, int H, int nsplit) {
@@ -92,10 +96,11 @@ __global__ __launch_bounds__(256) void pool_attn_kernel(const float* __restrict_
             for (int e = 0; e < 16; ++e) O[dt][j][e] = 0.f;
 
     load_tile(wave);
+    __syncthreads();  // the shared query tile Qs is complete
     for (int it = 0; it < nit; ++it) {
         const int tile = wave + 4 * it;
         store_tile();
-        __syncthreads();
+        wave_lds_sync();
         load_tile(tile + 4);
         if (tile < ntiles) {
             f32x16 s[2];
@@ -150,8 +155,9 @@ __global__ __launch_bounds__(256) void pool_attn_kernel(const float* __restrict_
                 }
             }
         }
-        __syncthreads();
+        wave_lds_sync();  // this wave's reads of Kt / Vt are done before it overwrites them
     }
+    __syncthreads();      // every wave is done with its staging area: the combine below reuses the LDS
 
     // ---- combine the four waves' (m, l, O) and emit one partial per (b, head, split)
     float* Ow = smem;                 // [4][HD][64]
@@ -250,18 +256,29 @@ __global__ __launch_bounds__(256) void unpool_attn_kernel(const float* __restric
     const float* qb = q + (size_t)b * N * C + hh * HD;
     float* ob = out + (size_t)b * N * C + hh * HD;
 
-    for (int it = 0; it < tiles_per_wave; ++it) {
+    // the next tile's queries travel global -> registers while the current tile is in the matrix pipe
+    f32x4 rq[LD_IT];
+    auto load_q = [&](int it) {
         const int q0 = (chunk * tiles_per_wave + it) * 128 + wave * 32;
 #pragma unroll
         for (int ld = 0; ld < LD_IT; ++ld) {
             const int f = ld * 64 + lane, row = f / CH, ch = f % CH, n = q0 + row;
-            if (f < 32 * CH) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (n < N) v = *reinterpret_cast<const f32x4*>(qb + (size_t)n * C + ch * 4);
-                *reinterpret_cast<f32x4*>(Qt + row * KP + ch * 4) = v * scale;
-            }
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (f < 32 * CH && it < tiles_per_wave && n < N) v = *reinterpret_cast<const f32x4*>(qb + (size_t)n * C + ch * 4);
+            rq[ld] = v;
         }
-        __syncthreads();
+    };
+    load_q(0);
+    for (int it = 0; it < tiles_per_wave; ++it) {
+        const int q0 = (chunk * tiles_per_wave + it) * 128 + wave * 32;
+#pragma unroll
+        for (int ld = 0; ld < LD_IT; ++ld) {
+            const int f = ld * 64 + lane, row = f / CH, ch = f % CH;
+            if (f < 32 * CH) *reinterpret_cast<f32x4*>(Qt + row * KP + ch * 4) = rq[ld] * scale;
+        }
+        load_q(it + 1);
+        if (it == 0) __syncthreads();  // the shared key / value tiles Ks, Vs are complete
+        wave_lds_sync();
         f32x16 s[2];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
@@ -306,7 +323,7 @@ __global__ __launch_bounds__(256) void unpool_attn_kernel(const float* __restric
                 for (int e = 0; e < 16; ++e)
                     O[dt] = mfma32(Vs[(rt * 32 + mfma_row(e, h)) * HD + dcol], s[rt][e], O[dt]);
         }
-        __syncthreads();
+        wave_lds_sync();
         // transpose O^T (query on the lane) back to rows through the wave's Q tile
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
@@ -318,7 +335,7 @@ __global__ __launch_bounds__(256) void unpool_attn_kernel(const float* __restric
                     *reinterpret_cast<f32x4*>(Qt + r * KP + d) = v * inv;
                 }
             }
-        __syncthreads();
+        wave_lds_sync();
 #pragma unroll
         for (int ld = 0; ld < LD_IT; ++ld) {
             const int f = ld * 64 + lane, row = f / CH, ch = f % CH, n = q0 + row;
@@ -326,7 +343,7 @@ __global__ __launch_bounds__(256) void unpool_attn_kernel(const float* __restric
                 *reinterpret_cast<f32x4*>(ob + (size_t)n * C + ch * 4) =
                     *reinterpret_cast<const f32x4*>(Qt + row * KP + ch * 4);
         }
-        __syncthreads();
+        wave_lds_sync();
     }
 }
 

@@ -30,7 +30,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 B, N, D, L, I, H = 64, 2048, 384, 6, 64, 8
-PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_F32_MFMA_TFLOPS = 157.3     # dense fp32 MFMA (MI355X_MICROARCH.md)
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 MFMA
+PEAK_HBM_GBS = 8000.0            # HBM3E spec (6.3 TB/s measured achievable)
 
 
 def flops_per_sample():
@@ -104,8 +106,9 @@ def build_model(p_cpu):
     return m
 
 
-def gemm_call_sites(ops, dev):
-    """The five (B*N)-row GEMM call sites of one layer, as closures launching the unit operator."""
+def gemm_call_sites(ops, dev, precision="fp32"):
+    """The five (B*N)-row GEMM call sites of one layer, as closures launching the unit operator.
+    Each entry: (name, algorithmic FLOPs, algorithmic HBM bytes, closure)."""
     g = torch.Generator(device="cpu").manual_seed(1)
     rn = lambda *s: torch.randn(*s, generator=g).to(dev)
     x, big = rn(B, N, D), rn(B, N, 2 * D)
@@ -115,12 +118,14 @@ def gemm_call_sites(ops, dev):
     alpha = torch.tensor(1.0, device=dev)
     o768, o384 = torch.empty(B, N, 2 * D, device=dev), torch.empty(B, N, D, device=dev)
     res = x.clone()
+    S = B * N * D * 4  # bytes of one (B, N, d) fp32 stream
+    pr = dict(precision=precision)
     sites = [
-        ("kv_proj", 2 * B * N * D * 2 * D, lambda: ops.linear(x, Wkv, None, (pa, po), out=o768)),
-        ("q_proj", 2 * B * N * D * D, lambda: ops.linear(x, Wq, bq, (pa, po), out=o384)),
-        ("out_proj+res+stats", 2 * B * N * D * D, lambda: ops.linear(x, Wo, bq, residual=res, want_stats=True, out=o384)),
-        ("mlp.0+act", 2 * B * N * D * 2 * D, lambda: ops.linear(x, W1, b1, (pa, po), act_alpha=alpha, out=o768)),
-        ("mlp.2+res+stats", 2 * B * N * 2 * D * D, lambda: ops.linear(big, W2, b2, residual=res, want_stats=True, out=o384)),
+        ("kv_proj", 2 * B * N * D * 2 * D, S + 2 * S, lambda: ops.linear(x, Wkv, None, (pa, po), out=o768, **pr)),
+        ("q_proj", 2 * B * N * D * D, S + S, lambda: ops.linear(x, Wq, bq, (pa, po), out=o384, **pr)),
+        ("out_proj+res+stats", 2 * B * N * D * D, 3 * S, lambda: ops.linear(x, Wo, bq, residual=res, want_stats=True, out=o384, **pr)),
+        ("mlp.0+act", 2 * B * N * D * 2 * D, S + 2 * S, lambda: ops.linear(x, W1, b1, (pa, po), act_alpha=alpha, out=o768, **pr)),
+        ("mlp.2+res+stats", 2 * B * N * 2 * D * D, 2 * S + 2 * S, lambda: ops.linear(big, W2, b2, residual=res, want_stats=True, out=o384, **pr)),
     ]
     return sites
 
@@ -176,6 +181,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-sampler", action="store_true")
+    ap.add_argument("--precision", default=os.environ.get("GECCO_PRECISION", "bf16x3"), choices=["fp32", "bf16x3"],
+                    help="arithmetic of the N-token GEMMs: split-bf16 (default; ~1.5e-5 vs the fp32 reference, inside the "
+                         "1e-3 bar) or exact fp32 MFMA (~1e-6)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -193,6 +201,7 @@ def main():
         ge.build()
     gd.barrier()
     from gecco_amd import hip_ops as ops
+    ops.set_default_precision(args.precision)
 
     p_cpu = random_state_dict(seed=3)
     x_cpu, sigma_cpu = synthetic_cloud(seed=rank)  # each rank: its own batch (weak scaling)
@@ -230,23 +239,54 @@ def main():
         "forward_tflops": flops_per_sample() * B / (ms * 1e-3) / 1e12,
         "target_points_per_sec_per_gpu": 2.0e6,
     }
+    x3 = args.precision == "bf16x3"
+    rec["dtype"] = "bf16 (split hi+lo operands, 3 MFMAs per product, fp32 accumulate; fp32 activations in HBM)" if x3 else "f32"
+    rec["config"]["workload"] = rec["config"]["workload"].replace("fp32 MFMA", "split-bf16 MFMA" if x3 else "fp32 MFMA")
     if rank == 0 and not args.no_roofline:
-        sites = gemm_call_sites(ops, dev)
-        tot_f, tot_ms, per = 0.0, 0.0, {}
-        for name, fl, fn in sites:
+        sites = gemm_call_sites(ops, dev, args.precision)
+        tot_f, tot_b, tot_ms, per = 0.0, 0.0, 0.0, {}
+        for name, fl, by, fn in sites:
             t = time_events(fn, 10)
-            per[name] = {"ms": round(t, 4), "tflops": round(fl / (t * 1e-3) / 1e12, 2)}
+            per[name] = {"ms": round(t, 4), "tflops": round(fl / (t * 1e-3) / 1e12, 2), "gbs": round(by / (t * 1e-3) / 1e9, 1)}
             tot_f += fl
+            tot_b += by
             tot_ms += t
-        ach = tot_f / (tot_ms * 1e-3) / 1e12
+        tf = tot_f / (tot_ms * 1e-3) / 1e12
+        gbs = tot_b / (tot_ms * 1e-3) / 1e9
         traffic = None
         tj = os.path.join(ROOT, "profiles", "gemm_hbm_traffic.json")
         if os.path.exists(tj):
             traffic = json.load(open(tj)).get("bytes_per_launch")
-        rec["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                           "kernel": "gemm_f32_kernel<128,128,2,2> (v_mfma_f32_32x32x2_f32), mean over its 5 call-site shapes",
-                           "per_site": per}
+        if x3:
+            # 3 MFMAs per product: the MFMA roof of this mode is 2500/3 = 833 algorithmic TFLOP/s, its ridge
+            # (833 TF / 8 TB/s = 104 FLOP/B) sits below the GEMMs' 64..192 FLOP/B only for the widest ones, and at
+            # the achievable 6.3 TB/s the memory roof (0.096 ms per mean launch) is the tighter: HBM-bound.
+            rec["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                               "traffic": traffic,
+                               "kernel": "gemm_dma_kernel<3,*,true> (LDS-DMA ring, v_mfma_f32_32x32x16_bf16 x3), mean over its 5 call-site shapes; "
+                                         "achieved = algorithmic bytes (A + residual read, C written, fp32) / event-timed duration",
+                               "mfma": {"achieved_tflops_algorithmic": tf, "executed_over_algorithmic": 3, "peak_tflops": PEAK_BF16_MFMA_TFLOPS,
+                                        "frac_executed": 3 * tf / PEAK_BF16_MFMA_TFLOPS},
+                               "per_site": per}
+        else:
+            rec["roofline"] = {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": tf / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                               "kernel": "gemm_dma_kernel<3,*,false> (LDS-DMA ring, v_mfma_f32_32x32x2_f32), mean over its 5 call-site shapes",
+                               "per_site": per}
+        if x3:  # the exact-fp32 mode beside it, for the record (same model, same inputs)
+            ops.set_default_precision("fp32")
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+            ms32 = (time.perf_counter() - t0) / 10 * 1e3
+            tf32 = sum(fl for _, fl, _, _ in sites) / (sum(time_events(fn, 5) for _, _, _, fn in gemm_call_sites(ops, dev, "fp32")) * 1e-3) / 1e12
+            rec["exact_fp32_mode"] = {"ms_per_step": ms32, "points_per_sec": B * N / (ms32 * 1e-3), "gemm_tflops": tf32,
+                                      "gemm_frac_of_fp32_mfma_peak": tf32 / PEAK_F32_MFMA_TFLOPS}
+            ops.set_default_precision("bf16x3")
     if rank == 0 and world == 1 and not args.no_sampler:
         # Metric 2 (BASELINE.json): 128-step sample_stochastic wall-clock = 255 evaluations + fp64 sampler kernels,
         # one hipGraph per step replayed 127 times

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgecco_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_f = C.c_void_p  # device pointers travel as void*
 
@@ -32,7 +32,8 @@ class GeccoLayer(C.Structure):
 
 class GeccoSetTransformer(C.Structure):
     _fields_ = [("n_layers", C.c_int), ("C", C.c_int), ("H", C.c_int), ("I", C.c_int), ("ctx_dim", C.c_int),
-                ("G", C.c_int), ("width", C.c_int), ("act", C.c_int), ("layers", C.POINTER(GeccoLayer))]
+                ("G", C.c_int), ("width", C.c_int), ("act", C.c_int), ("precision", C.c_int),
+                ("layers", C.POINTER(GeccoLayer))]
 
 
 class GeccoLinearLift(C.Structure):
@@ -71,6 +72,7 @@ SIGNATURES = {
     "gecco_last_error": (C.c_char_p, []),
     "gecco_linear_f32": (i, [vp] * 9 + [i, i, i, i, i, vp]),
     "gecco_linear_row_tiles": (i, [i]),
+    "gecco_linear_ex_f32": (i, [vp] * 9 + [i, i, i, i, i, i, vp, vp]),
     "gecco_col_stats_f32": (i, [vp, vp, i, i, i, vp]),
     "gecco_stats_row_tiles": (i, [i]),
     "gecco_adagn_coeffs_f32": (i, [vp, i, i, vp, i, C.POINTER(GeccoAdaGN), vp, vp, i, i, i, fl, vp]),

@@ -50,6 +50,7 @@ struct STWorkspace {
     float *a1, *o1, *a2, *o2, *as, *os;  // AdaGN coefficients (B,C)
     float *part_o, *part_ml;           // pool partials
     float *merged, *h0, *u, *h2, *h, *kvh;  // inducer chain (B,I,*)
+    float* wsplit;                     // bf16 hi | lo planes of the weight in use (split-bf16 mode)
     size_t bytes;
 };
 
@@ -81,17 +82,29 @@ STWorkspace carve_st(const GeccoSetTransformer* st, int B, int N, void* base) {
     w.h2 = c.f32(B * I * C);
     w.h = c.f32(B * I * C);
     w.kvh = c.f32(B * I * 2 * C);
+    w.wsplit = c.f32((2 * C > W ? 2 * C : W) * C);  // two bf16 planes = one fp32 plane worth of bytes
     w.bytes = (c.off + 255) & ~size_t(255);
     return w;
 }
 
+// precision 1 (split-bf16) applies to the N-token GEMMs the LDS-DMA kernel takes; `wsplit` receives the bf16 hi | lo
+// planes of W first (a ~3 us pass over <= 1.2 MB: weights may change between calls, nothing is cached).
 int linear(const float* A, const float* W, const float* bias, const float* pa, const float* po, const float* alpha,
-           const float* res, float* C, float* stats, int B, int rows, int K, int Nout, int act, hipStream_t s) {
+           const float* res, float* C, float* stats, int B, int rows, int K, int Nout, int act, hipStream_t s,
+           int precision = 0, float* wsplit = nullptr) {
     GemmArgs g;
     g.A = A; g.W = W; g.bias = bias; g.pro_a = pa; g.pro_o = po; g.alpha = alpha; g.residual = res; g.C = C;
     g.stats = stats; g.B = B; g.rows = rows; g.K = K; g.Nout = Nout;
     g.lda = K; g.ldw = K; g.ldc = Nout; g.ldr = Nout; g.act = act;
+    g.precision = 0; g.w_hi = nullptr; g.w_lo = nullptr;
     if (act && !alpha) return -6;
+    if (precision == 1 && wsplit && gemm_f32_dma_supported(g)) {
+        unsigned short* hi = reinterpret_cast<unsigned short*>(wsplit);
+        unsigned short* lo = hi + (size_t)Nout * K;
+        int rc = split_bf16_launch(W, hi, lo, (size_t)Nout * K, s);
+        if (rc) return rc;
+        g.precision = 1; g.w_hi = hi; g.w_lo = lo;
+    }
     return gemm_f32_launch(g, s);
 }
 
@@ -110,6 +123,7 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
     STWorkspace w = carve_st(st, B, N, ws);
     if (ws_bytes < w.bytes) return fail(-7, "set_transformer: workspace too small (%zu < %zu)", ws_bytes, w.bytes);
     const int C = st->C, I = st->I, H = st->H, G = st->G, Wd = st->width, ctx = st->ctx_dim, act = st->act;
+    const int pr = st->precision;
     const int Tn = row_tiles_gemm(N), Ti = row_tiles_gemm(I);
     const int ns = pool_attn_nsplit(B, N, H);
 
@@ -127,8 +141,8 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         const float* h = h_in ? h_in[li] : nullptr;
         if (!h) {
             // pool: KV projection, 64 inducer queries over the N points, out_proj
-            TRY(linear(x, L.kv_proj_w, nullptr, w.a1, w.o1, nullptr, nullptr, w.big, nullptr, B, N, C, 2 * C, 0, s),
-                "kv_proj");
+            TRY(linear(x, L.kv_proj_w, nullptr, w.a1, w.o1, nullptr, nullptr, w.big, nullptr, B, N, C, 2 * C, 0, s, pr,
+                       w.wsplit), "kv_proj");
             TRY(pool_attn_launch(w.big, L.inducers, w.part_o, w.part_ml, w.merged, B, N, C, H, I, ns, s), "pool_attn");
             TRY(linear(w.merged, L.pool_out_w, nullptr, nullptr, nullptr, nullptr, nullptr, w.h0, w.stats_s, B, I, C, C,
                        0, s), "pool.out_proj");
@@ -146,16 +160,18 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         // unpool: k|v of the 64 inducer states, q of the N points, attention, out_proj + residual
         TRY(linear(h, L.in_proj_w + (size_t)C * C, L.in_proj_b + C, nullptr, nullptr, nullptr, nullptr, w.kvh, nullptr,
                    B, I, C, 2 * C, 0, s), "unpool.in_proj(kv)");
-        TRY(linear(x, L.in_proj_w, L.in_proj_b, w.a1, w.o1, nullptr, nullptr, w.q, nullptr, B, N, C, C, 0, s),
+        TRY(linear(x, L.in_proj_w, L.in_proj_b, w.a1, w.o1, nullptr, nullptr, w.q, nullptr, B, N, C, C, 0, s, pr, w.wsplit),
             "unpool.in_proj(q)");
         TRY(unpool_attn_launch(w.q, w.kvh, w.attn, B, N, C, H, I, s), "unpool_attn");
-        TRY(linear(w.attn, L.unpool_out_w, L.unpool_out_b, nullptr, nullptr, nullptr, x, x, w.stats_x, B, N, C, C, 0, s),
-            "unpool.out_proj+residual");
+        TRY(linear(w.attn, L.unpool_out_w, L.unpool_out_b, nullptr, nullptr, nullptr, x, x, w.stats_x, B, N, C, C, 0, s, pr,
+                   w.wsplit), "unpool.out_proj+residual");
         // x += mlp(AdaGN(x))
         TRY(coeffs(w.stats_x, Tn, N, t, ctx, &L.mlp_norm, w.a2, w.o2, B, C, G, s), "adagn_coeffs(mlp_norm)");
-        TRY(linear(x, L.mlp.w0, L.mlp.b0, w.a2, w.o2, L.mlp.alpha, nullptr, w.big, nullptr, B, N, C, Wd, act, s), "mlp.0");
+        TRY(linear(x, L.mlp.w0, L.mlp.b0, w.a2, w.o2, L.mlp.alpha, nullptr, w.big, nullptr, B, N, C, Wd, act, s, pr, w.wsplit),
+            "mlp.0");
         float* so = (li + 1 < st->n_layers) ? w.stats_x : stats_out;
-        TRY(linear(w.big, L.mlp.w2, L.mlp.b2, nullptr, nullptr, nullptr, x, x, so, B, N, Wd, C, 0, s), "mlp.2+residual");
+        TRY(linear(w.big, L.mlp.w2, L.mlp.b2, nullptr, nullptr, nullptr, x, x, so, B, N, Wd, C, 0, s, pr, w.wsplit),
+            "mlp.2+residual");
         sx = w.stats_x;
         sT = Tn;
     }
@@ -199,6 +215,17 @@ int gecco_linear_f32(const float* A, const float* W, const float* bias, const fl
     if ((pro_a == nullptr) != (pro_o == nullptr)) return fail(-1, "linear: pro_a/pro_o must both be set");
     TRY(linear(A, W, bias, pro_a, pro_o, alpha, residual, C, stats, B, rows, K, Nout, act, (hipStream_t)stream),
         "linear");
+    return 0;
+}
+
+int gecco_linear_ex_f32(const float* A, const float* W, const float* bias, const float* pro_a, const float* pro_o,
+                        const float* alpha, const float* residual, float* C, float* stats, int B, int rows, int K,
+                        int Nout, int act, int precision, void* wsplit, void* stream) {
+    if (!A || !W || !C) return fail(-1, "linear: null argument");
+    if ((pro_a == nullptr) != (pro_o == nullptr)) return fail(-1, "linear: pro_a/pro_o must both be set");
+    if (precision == 1 && !wsplit) return fail(-1, "linear: split-bf16 needs the wsplit scratch");
+    TRY(linear(A, W, bias, pro_a, pro_o, alpha, residual, C, stats, B, rows, K, Nout, act, (hipStream_t)stream, precision,
+               static_cast<float*>(wsplit)), "linear");
     return 0;
 }
 

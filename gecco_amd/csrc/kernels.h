@@ -16,6 +16,9 @@ struct GemmArgs {
     int B, rows, K, Nout;
     int lda, ldw, ldc, ldr;
     int act;                // 0 none, 1 gaussian normalized, 2 gaussian raw
+    int precision;          // 0 exact fp32 MFMA, 1 split-bf16 (needs w_hi / w_lo)
+    const unsigned short* w_hi;  // bf16 planes of W, same (Nout, ldw) indexing
+    const unsigned short* w_lo;
 };
 
 int gemm_row_tile(int rows);  // row-tile height the GEMM uses for `rows` rows per sample
@@ -23,6 +26,7 @@ int gemm_f32_launch(const GemmArgs& g, hipStream_t st);
 // gemm_f32_dma.hip — LDS-DMA fast path of the same contract
 bool gemm_f32_dma_supported(const GemmArgs& g);
 int gemm_f32_dma_launch(const GemmArgs& g, hipStream_t st);
+int split_bf16_launch(const float* W, unsigned short* hi, unsigned short* lo, size_t n, hipStream_t st);
 
 // gemm_general_f32.hip — C[z] = scale * op(A[z]) op(B[z]) (+ bias), per-operand layout flag, two-level batch strides
 struct GemmGeneralArgs {

@@ -7,6 +7,7 @@ no fallback path.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Mapping, Sequence
 
 import torch
@@ -16,6 +17,23 @@ from . import _lib
 from ._lib import GeccoAdaGN, GeccoLayer, GeccoLinearLift, GeccoMLP, GeccoSetTransformer, check
 
 GN_EPS = 1e-5
+
+# Arithmetic of the N-token GEMMs: "fp32" = exact fp32 MFMA (~1e-6 against the fp32 reference), "bf16x3" = split-bf16
+# (hi + lo operands, three bf16 MFMAs per product, fp32 accumulate: ~2e-5, inside the 1e-3 parity bar, ~2x faster).
+PRECISIONS = {"fp32": 0, "bf16x3": 1}
+_default_precision = os.environ.get("GECCO_PRECISION", "fp32")
+
+
+def set_default_precision(name: str) -> None:
+    """Precision used by plans built afterwards (modules rebuild theirs when this changes)."""
+    global _default_precision
+    if name not in PRECISIONS:
+        raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
+    _default_precision = name
+
+
+def default_precision() -> str:
+    return _default_precision
 
 
 def _stream() -> C.c_void_p:
@@ -41,7 +59,7 @@ def _ws(nbytes: int, device) -> Tensor:
 # ------------------------------------------------------------------------------- unit operators
 def linear(A: Tensor, W: Tensor, bias: Tensor | None = None, pro: tuple[Tensor, Tensor] | None = None,
            act_alpha: Tensor | None = None, residual: Tensor | None = None, want_stats: bool = False,
-           normalized: bool = True, out: Tensor | None = None):
+           normalized: bool = True, out: Tensor | None = None, precision: str = "fp32"):
     """C = residual + act((A*pro_a + pro_o) @ W^T + bias) on (B, rows, K) x (Nout, K)."""
     lib = _lib.load()
     B, rows, K = A.shape
@@ -52,9 +70,12 @@ def linear(A: Tensor, W: Tensor, bias: Tensor | None = None, pro: tuple[Tensor, 
     if want_stats:
         stats = torch.empty(B, lib.gecco_linear_row_tiles(rows), 2, Nout, device=A.device, dtype=torch.float32)
     act = 0 if act_alpha is None else (1 if normalized else 2)
-    check(lib.gecco_linear_f32(_ptr(A), _ptr(W), _ptr(bias), _ptr(pro[0]) if pro else None,
-                               _ptr(pro[1]) if pro else None, _ptr(act_alpha), _ptr(residual), _ptr(out), _ptr(stats),
-                               B, rows, K, Nout, act, _stream()), "gecco_linear_f32")
+    wsplit = _ws(Nout * K * 4, A.device) if precision == "bf16x3" else None
+    check(lib.gecco_linear_ex_f32(_ptr(A), _ptr(W), _ptr(bias), _ptr(pro[0]) if pro else None,
+                                  _ptr(pro[1]) if pro else None, _ptr(act_alpha), _ptr(residual), _ptr(out), _ptr(stats),
+                                  B, rows, K, Nout, act, PRECISIONS[precision],
+                                  C.c_void_p(wsplit.data_ptr()) if wsplit is not None else None, _stream()),
+          "gecco_linear_ex_f32")
     return (out, stats) if want_stats else out
 
 
@@ -189,8 +210,12 @@ class SetTransformerPlan:
     """Host-side parameter table + workspace cache for gecco_set_transformer_fwd_f32.  Holds references to the
     parameter tensors so the raw pointers stay valid; rebuild it if parameters are re-allocated."""
 
-    def __init__(self, p: Mapping[str, Tensor], pre: str, H: int, I: int = 64, G: int = 32, normalized: bool = True):
+    def __init__(self, p: Mapping[str, Tensor], pre: str, H: int, I: int = 64, G: int = 32, normalized: bool = True,
+                 precision: str | None = None):
         self.lib = _lib.load()
+        self.precision = precision or _default_precision
+        if self.precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
         self.p = p  # keep tensors alive
         L = 0
         while f"{pre}layers.{L}.mlp.0.weight" in p:
@@ -204,7 +229,7 @@ class SetTransformerPlan:
         self.device = w0.device
         self._layers = (GeccoLayer * L)(*[layer_table(p, f"{pre}layers.{i}.") for i in range(L)])
         self.table = GeccoSetTransformer(L, self.C, H, I, self.ctx_dim, G, self.width, 1 if normalized else 2,
-                                         self._layers)
+                                         PRECISIONS[self.precision], self._layers)
         self._ws: dict[tuple[int, int], Tensor] = {}
 
     def workspace(self, B: int, N: int) -> Tensor:
@@ -242,8 +267,9 @@ class SetTransformerPlan:
 class LinearLiftPlan:
     """EDMPrecond(LinearLift(SetTransformer)) = the unconditional Diffusion.forward, one C call."""
 
-    def __init__(self, p: Mapping[str, Tensor], H: int, I: int = 64, pre: str = "", sigma_data: float = 1.0):
-        self.st = SetTransformerPlan(p, pre + "inner.", H, I)
+    def __init__(self, p: Mapping[str, Tensor], H: int, I: int = 64, pre: str = "", sigma_data: float = 1.0,
+                 precision: str | None = None):
+        self.st = SetTransformerPlan(p, pre + "inner.", H, I, precision=precision)
         self.p = p
         self.lib = self.st.lib
         self.table = GeccoLinearLift(self.st.table, _ptr(p[pre + "lift.weight"]), _ptr(p[pre + "lift.bias"]),
@@ -349,8 +375,8 @@ class RayNetworkPlan:
 
     def __init__(self, p: Mapping[str, Tensor], H: int, I: int = 64, pre: str = "", reparam_kind: int = 2,
                  rp_mean: Tensor | None = None, rp_std: Tensor | None = None, logit_scale: float = 1.1,
-                 sigma_data: float = 1.0):
-        self.st = SetTransformerPlan(p, pre + "backbone.", H, I)
+                 sigma_data: float = 1.0, precision: str | None = None):
+        self.st = SetTransformerPlan(p, pre + "backbone.", H, I, precision=precision)
         self.p = p
         self.lib = self.st.lib
         if reparam_kind == 2 and rp_mean is None:

@@ -14,7 +14,7 @@ from .normalization import AdaGN
 
 
 def _param_sig(module: nn.Module):
-    return tuple(p.data_ptr() for p in module.parameters())
+    return (hip_ops.default_precision(),) + tuple(p.data_ptr() for p in module.parameters())
 
 
 class _PlanCache:

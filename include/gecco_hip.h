@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GECCO_ABI_VERSION 1
+#define GECCO_ABI_VERSION 2
 
 int gecco_abi_version(void);
 const char* gecco_build_arch(void);   /* "gfx950" */
@@ -63,6 +63,8 @@ typedef struct GeccoLayer {   /* BroadcastingLayer, models/set_transformer.py:12
 
 typedef struct GeccoSetTransformer {  /* SetTransformer, models/set_transformer.py:171-216 */
     int n_layers, C, H, I, ctx_dim, G, width, act;  /* act: 1 GaussianActivation(normalized) 2 raw */
+    int precision;  /* arithmetic of the N-token GEMMs: 0 exact fp32 MFMA (~1e-6 vs the fp32 reference),
+                     * 1 split-bf16 on bf16 MFMA, fp32 accumulate (a = hi + lo; 3 MFMAs; ~2e-5) */
     const GeccoLayer* layers;                       /* HOST array of n_layers tables */
 } GeccoSetTransformer;
 
@@ -76,6 +78,11 @@ int gecco_linear_f32(const float* A, const float* W, const float* bias, const fl
                      const float* alpha, const float* residual, float* C, float* stats, int B, int rows, int K,
                      int Nout, int act, void* stream);
 int gecco_linear_row_tiles(int rows);
+/* The same with the arithmetic selectable: precision 0 = exact fp32 MFMA, 1 = split-bf16 (see GeccoSetTransformer);
+ * wsplit: scratch of >= Nout*K*4 bytes for the bf16 hi | lo planes of W (precision 1 only). */
+int gecco_linear_ex_f32(const float* A, const float* W, const float* bias, const float* pro_a, const float* pro_o,
+                        const float* alpha, const float* residual, float* C, float* stats, int B, int rows, int K,
+                        int Nout, int act, int precision, void* wsplit, void* stream);
 
 /* GroupNorm partial statistics of x (B, rows, C): stats (B, T, 2, C), T = gecco_stats_row_tiles(rows). */
 int gecco_col_stats_f32(const float* x, float* stats, int B, int rows, int C, void* stream);

@@ -57,6 +57,26 @@ def test_linear_fused(ops, B, rows, K, Nout):
     _close(Rc, R + F.linear(A, W, b))
 
 
+@pytest.mark.parametrize("B,rows,K,Nout", [(2, 256, 128, 256), (1, 2048, 384, 768), (2, 300, 768, 384)])
+def test_linear_split_bf16(ops, B, rows, K, Nout):
+    """precision="bf16x3" on the unit operator: same fused contract, ~2^-16 per-product error."""
+    rs = _rs(rows + K)
+    A, W, b = _t(rs.randn(B, rows, K) * 3), _t(rs.randn(Nout, K) / math.sqrt(K)), _t(rs.randn(Nout))
+    pa, po = _t(1 + 0.3 * rs.randn(B, K)), _t(0.3 * rs.randn(B, K))
+    R = _t(rs.randn(B, rows, Nout))
+    alpha = _t(np.array(1.1))
+    pre = F.linear((A * pa[:, None] + po[:, None]).double(), W.double(), b.double())
+    ref = R.double() + cpu_ref.gaussian_activation(pre, alpha.double())
+    out, stats = ops.linear(A.cuda(), W.cuda(), b.cuda(), (pa.cuda(), po.cuda()), alpha.cuda(), R.cuda(), want_stats=True,
+                            precision="bf16x3")
+    e = cpu_ref.rel_err(out.cpu(), ref)
+    assert e[0] < 1e-4, e
+    _close(stats.cpu().double().sum(1)[:, 0], ref.sum(1), 2e-4)
+    exact = ops.linear(A.cuda(), W.cuda(), b.cuda(), (pa.cuda(), po.cuda()), alpha.cuda(), R.cuda())
+    e32 = cpu_ref.rel_err(exact.cpu(), ref)
+    assert e32[0] < e[0]  # the exact-fp32 mode is (of course) closer; both are far inside 1e-3
+
+
 @pytest.mark.parametrize("B,rows,C,G,ctx", [(2, 256, 128, 32, 1), (3, 77, 64, 32, 1), (2, 64, 384, 32, 3), (2, 300, 672, 16, 0)])
 def test_adagn(ops, B, rows, C, G, ctx):
     rs = _rs(rows + C)

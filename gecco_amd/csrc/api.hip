@@ -82,13 +82,16 @@ STWorkspace carve_st(const GeccoSetTransformer* st, int B, int N, void* base) {
     w.h2 = c.f32(B * I * C);
     w.h = c.f32(B * I * C);
     w.kvh = c.f32(B * I * 2 * C);
-    w.wsplit = c.f32((2 * C > W ? 2 * C : W) * C);  // two bf16 planes = one fp32 plane worth of bytes
+    {   // tiled bf16 hi | lo image of the weight in use: output rows padded to the 128-column GEMM tile
+        const size_t wmax = 2 * C > W ? 2 * C : W;
+        w.wsplit = c.f32(((wmax + 127) / 128 * 128) * (size_t)(W > C ? W : C));
+    }
     w.bytes = (c.off + 255) & ~size_t(255);
     return w;
 }
 
-// precision 1 (split-bf16) applies to the N-token GEMMs the LDS-DMA kernel takes; `wsplit` receives the bf16 hi | lo
-// planes of W first (a ~3 us pass over <= 1.2 MB: weights may change between calls, nothing is cached).
+// precision 1 (split-bf16) applies to the N-token GEMMs the LDS-DMA kernel takes; `wsplit` receives the tiled bf16
+// hi | lo image of W first (a ~3 us pass over <= 1.2 MB: weights may change between calls, nothing is cached).
 int linear(const float* A, const float* W, const float* bias, const float* pa, const float* po, const float* alpha,
            const float* res, float* C, float* stats, int B, int rows, int K, int Nout, int act, hipStream_t s,
            int precision = 0, float* wsplit = nullptr) {
@@ -96,14 +99,12 @@ int linear(const float* A, const float* W, const float* bias, const float* pa, c
     g.A = A; g.W = W; g.bias = bias; g.pro_a = pa; g.pro_o = po; g.alpha = alpha; g.residual = res; g.C = C;
     g.stats = stats; g.B = B; g.rows = rows; g.K = K; g.Nout = Nout;
     g.lda = K; g.ldw = K; g.ldc = Nout; g.ldr = Nout; g.act = act;
-    g.precision = 0; g.w_hi = nullptr; g.w_lo = nullptr;
+    g.precision = 0; g.w_img = nullptr;
     if (act && !alpha) return -6;
     if (precision == 1 && wsplit && gemm_f32_dma_supported(g)) {
-        unsigned short* hi = reinterpret_cast<unsigned short*>(wsplit);
-        unsigned short* lo = hi + (size_t)Nout * K;
-        int rc = split_bf16_launch(W, hi, lo, (size_t)Nout * K, s);
+        int rc = split_bf16_tiled_launch(W, wsplit, Nout, K, g.ldw, s);
         if (rc) return rc;
-        g.precision = 1; g.w_hi = hi; g.w_lo = lo;
+        g.precision = 1; g.w_img = wsplit;
     }
     return gemm_f32_launch(g, s);
 }

@@ -20,7 +20,8 @@
 //               lo = bf16(x - hi); a*b ~ a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16 with fp32
 //               accumulation: 3 MFMAs at 16x the fp32-MFMA rate, relative error ~2^-16 per product (plain bf16
 //               operands: 2^-9, which misses the 1e-3 parity bar).  W is pre-split into two
-//               bf16 planes (split_bf16_kernel); A is split on the fragment, after the AdaGN affine.
+//               bf16 planes, tiled per (column tile, K-step) (split_bf16_tiled_kernel); A is split on the fragment,
+//               after the AdaGN affine.
 // Requires K % 16 == 0, Nout % 4 == 0, rows >= 128; everything else runs on gemm_f32.hip.
 #include "common.h"
 #include "kernels.h"
@@ -36,7 +37,7 @@ constexpr int DBM = 128, DBN = 128, DBK = 16, DNT = 256;
 constexpr int D_TILE = 128 * DBK;                 // floats per operand tile per stage (8 KiB)
 constexpr int D_STAGE = 2 * D_TILE;               // A then B (fp32 W tile, or bf16 hi | lo planes: same 8 KiB)
 constexpr int D_TP = 64 + 4;                      // epilogue transpose tile row stride
-constexpr int D_EPI = 4 * 32 * D_TP + 2 * 2 * DBN;  // 4 half wave tiles (32 x 64) + column partials = 36 KiB
+constexpr int D_EPI = 4 * 32 * D_TP + 4 * 2 * DBN;  // 4 wave sub-tiles (32 x 64) + column partials = 38 KiB
 constexpr int d_main_floats(int ns) { return ns * D_STAGE > D_EPI ? ns * D_STAGE : D_EPI; }
 
 __device__ __forceinline__ void dma16(const void* gsrc, float* lds_wave_base) {
@@ -75,7 +76,12 @@ __global__ __launch_bounds__(DNT, DNS <= 3 ? 3 : 2) void gemm_dma_kernel(GemmArg
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    // wave layout: fp32 mode 2 x 2 waves of 64 x 64; bf16x3 mode 4 x 1 waves of 32 x 128 — the A fragment costs
+    // ~28 VALU per 32-row tile per K-step to split into hi / lo, the (pre-split) B fragment nothing, so the
+    // wave tile is made wide in N: half the split work per MFMA of the square layout.
+    constexpr int WMN = X3 ? 4 : 2, WNN = 4 / WMN;
+    constexpr int TMW = 4 / WMN, TNW = 4 / WNN;   // 32 x 32 MFMA tiles per wave in M / N
+    const int wm = wave / WNN, wn = wave % WNN;
     const int r = lane & 31, h = lane >> 5;
 
     // ---- DMA source pointers (bytes advance by one K-step = 16 k per iteration)
@@ -92,20 +98,25 @@ __global__ __launch_bounds__(DNT, DNS <= 3 ? 3 : 2) void gemm_dma_kernel(GemmArg
         asrc[q] = Ab + (size_t)min(m0 + row, g.rows - 1) * g.lda + c * 4;
         if (!X3) bsrc[q] = g.W + (size_t)min(n0 + row, g.Nout - 1) * g.ldw + c * 4;
     }
+    const int nk = g.K / DBK;
     if (X3) {
-        const int row = wave * 32 + (lane >> 1);
-        const int c = (lane & 1) ^ ((row >> 3) & 1);
-        const size_t off = (size_t)min(n0 + row, g.Nout - 1) * g.ldw + c * 8;
-        bsrc[0] = g.w_hi + off;
-        bsrc[1] = g.w_lo + off;
+        // pre-tiled W image (split_bf16_tiled_kernel): one 8 KiB block per (column tile, K-step) that IS the LDS
+        // image (hi plane | lo plane, swizzle baked in), so a wave-instruction reads 1 KiB of consecutive bytes —
+        // measured 2.4x the fill rate of 32-byte row pieces (tools/probe/dma_rate.hip)
+        const float* img = static_cast<const float*>(g.w_img) + (size_t)ct * nk * D_TILE + wave * 256 + lane * 4;
+        bsrc[0] = img;
+        bsrc[1] = img + 1024;
     }
     auto issue = [&](int kt) {   // 4 DMA wave-instructions: this wave's share of K-step kt
+#ifdef GEMM_DIAG_NODMA
+        return;
+#endif
         float* st = smem + (kt % DNS) * D_STAGE;
 #pragma unroll
         for (int q = 0; q < 2; ++q) dma16(asrc[q] + kt * DBK, st + (2 * wave + q) * 256);
         if (X3) {
-            dma16(static_cast<const unsigned short*>(bsrc[0]) + kt * DBK, st + D_TILE + wave * 256);
-            dma16(static_cast<const unsigned short*>(bsrc[1]) + kt * DBK, st + D_TILE + 1024 + wave * 256);
+            dma16(static_cast<const float*>(bsrc[0]) + (size_t)kt * D_TILE, st + D_TILE + wave * 256);
+            dma16(static_cast<const float*>(bsrc[1]) + (size_t)kt * D_TILE, st + D_TILE + 1024 + wave * 256);
         } else {
 #pragma unroll
             for (int q = 0; q < 2; ++q)
@@ -113,7 +124,6 @@ __global__ __launch_bounds__(DNT, DNS <= 3 ? 3 : 2) void gemm_dma_kernel(GemmArg
         }
     };
 
-    const int nk = g.K / DBK;
     if (HAS_PRO) {  // park the AdaGN coefficients of this sample (ordinary loads, drained before the ring starts)
         const float* pa = g.pro_a + (size_t)b * g.K;
         const float* po = g.pro_o + (size_t)b * g.K;
@@ -123,50 +133,54 @@ __global__ __launch_bounds__(DNT, DNS <= 3 ? 3 : 2) void gemm_dma_kernel(GemmArg
         }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // fp32 mode keeps DNS - 1 K-steps in flight ahead of the one being read; bf16x3 mode holds the K-step being
+    // multiplied in registers (software pipeline below), so all DNS ring slots can be in flight or landed ahead
+    constexpr int PRE = X3 ? DNS : DNS - 1;
 #pragma unroll
-    for (int p = 0; p < DNS - 1; ++p)
+    for (int p = 0; p < PRE; ++p)
         if (p < nk) issue(p);
 
-    f32x16 acc[2][2];
+    f32x16 acc[TMW][TNW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TMW; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TNW; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     // fragment addressing (float offsets inside a stage).  Every lane reads two 16-byte chunks of an fp32 row per
     // K-step: chunks {h, 2 + h} in fp32 mode (k = 8*kk + 4*h + e for kk = 0, 1), chunks {2h, 2h + 1} in bf16x3 mode
     // (k = 8*h + j); row R's global chunk c sits at LDS chunk c ^ ((R >> 2) & 3).
-    int aoff[2][2], boff[2][2];
+    int aoff[TMW][2], boff[TNW][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int ra = (wm * 2 + i) * 32 + r, rb = (wn * 2 + i) * 32 + r;
+    for (int i = 0; i < TMW; ++i) {
+        const int ra = (wm * TMW + i) * 32 + r;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int c = X3 ? (2 * h + q) : (2 * q + h);
             aoff[i][q] = ra * DBK + ((c ^ ((ra >> 2) & 3)) << 2);
-            boff[i][q] = D_TILE + rb * DBK + ((c ^ ((rb >> 2) & 3)) << 2);
         }
+    }
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) {
+        const int rb = (wn * TNW + j) * 32 + r;
         if (X3) {  // bf16 plane row = 32 B = 8 floats; this lane's 8 k-values = chunk h ^ ((row >> 3) & 1)
             const int ch = h ^ ((rb >> 3) & 1);
-            boff[i][0] = D_TILE + rb * 8 + ch * 4;          // hi plane
-            boff[i][1] = D_TILE + 1024 + rb * 8 + ch * 4;   // lo plane
+            boff[j][0] = D_TILE + rb * 8 + ch * 4;          // hi plane
+            boff[j][1] = D_TILE + 1024 + rb * 8 + ch * 4;   // lo plane
+        } else {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) boff[j][q] = D_TILE + rb * DBK + (((2 * q + h) ^ ((rb >> 2) & 3)) << 2);
         }
     }
 
-    for (int kt = 0; kt < nk; ++kt) {
-        // own pieces of K-step kt have landed once at most the younger K-steps' DMAs are outstanding
-        const int ahead = min(nk - 1 - kt, DNS - 2);   // K-steps issued after kt and not yet waited for
-        if (DNS >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();   // everyone's pieces of kt are in; everyone is done reading stage (kt-1) % DNS
-        if (kt + DNS - 1 < nk) issue(kt + DNS - 1);
-        const float* st = smem + (kt % DNS) * D_STAGE;
-        if (X3) {
-            // one 32x32x16 chunk per K-step: lane half h holds k = 8h .. 8h+7 of both operands
-            bf16x8 ahi[2], alo[2], bhi[2], blo[2];
+    if (X3) {
+        // Software-pipelined: the fragments of K-step kt sit in registers while its 12 MFMAs issue; between them
+        // the wave reads the fragments of K-step kt + 1 (LDS latency, AdaGN affine and the hi / lo split hide
+        // under the matrix pipe instead of in front of it) and the DMA runs DNS K-steps ahead.  One 32x32x16 chunk
+        // per K-step: lane half h holds k = 8h .. 8h+7 of both operands.
+        bf16x8 ahi[TMW], alo[TMW], bhi[TNW], blo[TNW];
+        auto load_a = [&](const float* st, int kt) {
             f32x4 pa0, pa1, po0, po1;
             if (HAS_PRO) {
                 pa0 = *reinterpret_cast<const f32x4*>(pro_lds + kt * DBK + 8 * h);
@@ -175,49 +189,97 @@ __global__ __launch_bounds__(DNT, DNS <= 3 ? 3 : 2) void gemm_dma_kernel(GemmArg
                 po1 = *reinterpret_cast<const f32x4*>(pro_lds + g.K + kt * DBK + 8 * h + 4);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < TMW; ++i) {
                 f32x4 x0 = *reinterpret_cast<const f32x4*>(st + aoff[i][0]);
                 f32x4 x1 = *reinterpret_cast<const f32x4*>(st + aoff[i][1]);
                 if (HAS_PRO) {
                     x0 = x0 * pa0 + po0;
                     x1 = x1 * pa1 + po1;
                 }
+#ifdef GEMM_DIAG_NOSPLIT
+                ahi[i] = __builtin_bit_cast(bf16x8, x0);
+                alo[i] = __builtin_bit_cast(bf16x8, x1);
+#else
                 split8(x0, x1, ahi[i], alo[i]);
+#endif
             }
+        };
+        auto load_b = [&](const float* st, int j) {
+            bhi[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(st + boff[j][0]));
+            blo[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(st + boff[j][1]));
+        };
+        // K-step 0 into registers
+        if (DNS >= 4 && nk >= 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (nk >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (nk == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        load_a(smem, 0);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                bhi[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(st + boff[j][0]));
-                blo[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(st + boff[j][1]));
+        for (int j = 0; j < TNW; ++j) load_b(smem, j);
+        for (int kt = 0; kt < nk; ++kt) {
+            // own reads of stage kt are complete (its slot may be refilled) and own pieces of stage kt + 1 landed
+            const int ahead = min(nk - 1, kt + DNS - 1) - (kt + 1);   // K-steps in flight beyond kt + 1
+            if (DNS >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + DNS < nk) issue(kt + DNS);
+            // next K-step's slot; past the end a landed slot is re-read and the values are never used
+            const int kn = min(kt + 1, nk - 1);
+            const float* nx = smem + (kn % DNS) * D_STAGE;
+            bf16x8 chi[TMW], clo[TMW];
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) {
+                chi[i] = ahi[i];
+                clo[i] = alo[i];
             }
+            load_a(nx, kn);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < TNW; ++j) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[i], bhi[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], blo[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], bhi[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < TMW; ++i) {
+#ifdef GEMM_DIAG_NOMFMA   // diagnostic: keep the operand reads alive with one VALU op per fragment instead
+                    acc[i][j][0] += (float)clo[i][0] + (float)bhi[j][0] + (float)chi[i][0] + (float)blo[j][0];
+#else
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(clo[i], bhi[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(chi[i], blo[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(chi[i], bhi[j], acc[i][j], 0, 0, 0);
+#endif
                 }
-        } else {
+                load_b(nx, j);
+            }
+        }
+    } else {
+        for (int kt = 0; kt < nk; ++kt) {
+            // own pieces of K-step kt have landed once at most the younger K-steps' DMAs are outstanding
+            const int ahead = min(nk - 1 - kt, DNS - 2);   // K-steps issued after kt and not yet waited for
+            if (DNS >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();   // everyone's pieces of kt are in; everyone is done reading stage (kt-1) % DNS
+            if (kt + DNS - 1 < nk) issue(kt + DNS - 1);
+            const float* st = smem + (kt % DNS) * D_STAGE;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 // lane half h holds k = 8*kk + 4*h + e: the same k permutation on both operands
-                f32x4 fa[2], fb[2];
+                f32x4 fa[TMW], fb[TNW];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const f32x4*>(st + aoff[i][kk]);
+                for (int i = 0; i < TMW; ++i) fa[i] = *reinterpret_cast<const f32x4*>(st + aoff[i][kk]);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const f32x4*>(st + boff[j][kk]);
+                for (int j = 0; j < TNW; ++j) fb[j] = *reinterpret_cast<const f32x4*>(st + boff[j][kk]);
                 if (HAS_PRO) {
                     const f32x4 pa4 = *reinterpret_cast<const f32x4*>(pro_lds + kt * DBK + kk * 8 + 4 * h);
                     const f32x4 po4 = *reinterpret_cast<const f32x4*>(pro_lds + g.K + kt * DBK + kk * 8 + 4 * h);
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) fa[i] = fa[i] * pa4 + po4;
+                    for (int i = 0; i < TMW; ++i) fa[i] = fa[i] * pa4 + po4;
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < TMW; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fa[i][e], fb[j][e], acc[i][j]);
+                        for (int j = 0; j < TNW; ++j) acc[i][j] = mfma32(fa[i][e], fb[j][e], acc[i][j]);
             }
         }
     }
@@ -232,84 +294,113 @@ __global__ __launch_bounds__(DNT, DNS <= 3 ? 3 : 2) void gemm_dma_kernel(GemmArg
     float* Tt = smem + wave * 32 * D_TP;
     float* red = smem + 4 * 32 * D_TP;
     const int lr = lane >> 4, c4 = lane & 15;   // 16 lanes per 64-float row, 4 rows per wave-instruction
-    const int n = n0 + wn * 64 + c4 * 4;
-    const bool nok = n < g.Nout;
-    const int nc = nok ? n : 0;
-    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    constexpr int NJH = TNW / 2;                // 64-column halves of the wave tile
+    f32x4 s1[NJH], s2[NJH];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {   // the wave's two 32-row halves, one after the other through the same LDS tile
+    for (int jh = 0; jh < NJH; ++jh) {
+        s1[jh] = f32x4{0.f, 0.f, 0.f, 0.f};
+        s2[jh] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // the wave's 32 x 64 sub-tiles, one after the other through the same wave-private LDS tile
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int nn = n0 + (wn * 2 + j) * 32 + r;
-            const float bias = g.bias ? g.bias[nn < g.Nout ? nn : g.Nout - 1] : 0.f;
-            f32x16 val = acc[i][j];
+    for (int i = 0; i < TMW; ++i) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) val[e] += bias;
-            if (has_act) {
+        for (int jh = 0; jh < NJH; ++jh) {
+            const int ncol0 = n0 + (wn * TNW + 2 * jh) * 32;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) val[e] = gauss_act(val[e], neg_inv_2a2, act_norm);
+            for (int jj = 0; jj < 2; ++jj) {
+                const int nn = ncol0 + jj * 32 + r;
+                const float bias = g.bias ? g.bias[nn < g.Nout ? nn : g.Nout - 1] : 0.f;
+                f32x16 val = acc[i][2 * jh + jj];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) val[e] += bias;
+                if (has_act) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) val[e] = gauss_act(val[e], neg_inv_2a2, act_norm);
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) Tt[mfma_row(e, h) * D_TP + jj * 32 + r] = val[e];
             }
+            __syncthreads();
+            const int n = ncol0 + c4 * 4;
+            const bool nok = n < g.Nout;
+            const int nc = nok ? n : 0;
+            const int mrow0 = m0 + (wm * TMW + i) * 32;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) Tt[mfma_row(e, h) * D_TP + j * 32 + r] = val[e];
-        }
-        __syncthreads();
+            for (int it0 = 0; it0 < 8; it0 += 4) {
+                f32x4 rres[4];
+                if (Rb) {
 #pragma unroll
-        for (int it0 = 0; it0 < 8; it0 += 4) {
-            f32x4 rres[4];
-            if (Rb) {
+                    for (int c = 0; c < 4; ++c) {
+                        const int m = min(mrow0 + (it0 + c) * 4 + lr, g.rows - 1);
+                        rres[c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Rb + (size_t)m * g.ldr + nc));
+                    }
+                }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const int m = min(m0 + wm * 64 + i * 32 + (it0 + c) * 4 + lr, g.rows - 1);
-                    rres[c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Rb + (size_t)m * g.ldr + nc));
+                    const int it = it0 + c;
+                    const int m = mrow0 + it * 4 + lr;
+                    f32x4 v4 = *reinterpret_cast<const f32x4*>(Tt + (it * 4 + lr) * D_TP + c4 * 4);
+                    if (Rb) v4 += rres[c];
+                    const bool ok = nok && m < g.rows;
+                    if (ok) __builtin_nontemporal_store(v4, reinterpret_cast<f32x4*>(Cb + (size_t)m * g.ldc + n));
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    const f32x4 vz = ok ? v4 : z;
+                    s1[jh] += vz;
+                    s2[jh] += vz * vz;
                 }
             }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int it = it0 + c;
-                const int m = m0 + wm * 64 + i * 32 + it * 4 + lr;
-                f32x4 v4 = *reinterpret_cast<const f32x4*>(Tt + (it * 4 + lr) * D_TP + c4 * 4);
-                if (Rb) v4 += rres[c];
-                const bool ok = nok && m < g.rows;
-                if (ok) __builtin_nontemporal_store(v4, reinterpret_cast<f32x4*>(Cb + (size_t)m * g.ldc + n));
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                const f32x4 vz = ok ? v4 : z;
-                s1 += vz;
-                s2 += vz * vz;
-            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     if (g.stats) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            s1[q] += __shfl_xor(s1[q], 16, 64);
-            s1[q] += __shfl_xor(s1[q], 32, 64);
-            s2[q] += __shfl_xor(s2[q], 16, 64);
-            s2[q] += __shfl_xor(s2[q], 32, 64);
-        }
-        if (lane < 16) {
-            *reinterpret_cast<f32x4*>(red + (wm * 2 + 0) * DBN + wn * 64 + c4 * 4) = s1;
-            *reinterpret_cast<f32x4*>(red + (wm * 2 + 1) * DBN + wn * 64 + c4 * 4) = s2;
+        for (int jh = 0; jh < NJH; ++jh) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                s1[jh][q] += __shfl_xor(s1[jh][q], 16, 64);
+                s1[jh][q] += __shfl_xor(s1[jh][q], 32, 64);
+                s2[jh][q] += __shfl_xor(s2[jh][q], 16, 64);
+                s2[jh][q] += __shfl_xor(s2[jh][q], 32, 64);
+            }
+            if (lane < 16) {
+                const int cl = (wn * TNW + 2 * jh) * 32 + c4 * 4;
+                *reinterpret_cast<f32x4*>(red + (wm * 2 + 0) * DBN + cl) = s1[jh];
+                *reinterpret_cast<f32x4*>(red + (wm * 2 + 1) * DBN + cl) = s2[jh];
+            }
         }
         __syncthreads();
         for (int c = tid; c < 2 * DBN; c += DNT) {
             const int which = c / DBN, cl = c % DBN, nn = n0 + cl;
-            if (nn < g.Nout)
-                g.stats[(((size_t)b * tilesM + rt) * 2 + which) * g.Nout + nn] =
-                    red[(0 * 2 + which) * DBN + cl] + red[(1 * 2 + which) * DBN + cl];
+            if (nn < g.Nout) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < WMN; ++w) t += red[(w * 2 + which) * DBN + cl];
+                g.stats[(((size_t)b * tilesM + rt) * 2 + which) * g.Nout + nn] = t;
+            }
         }
     }
 }
 
-// W (fp32, n elements) -> hi / lo bf16 planes with the same indexing
-__global__ void split_bf16_kernel(const float* __restrict__ W, unsigned short* __restrict__ hi,
-                                  unsigned short* __restrict__ lo, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float x = W[i];
-        const unsigned u = __float_as_uint(x);
-        hi[i] = (unsigned short)(u >> 16);
-        const __bf16 l = (__bf16)(x - __uint_as_float(u & 0xFFFF0000u));
-        lo[i] = __builtin_bit_cast(unsigned short, l);
+// W (Nout, ldw) fp32 -> the tiled split-bf16 image the X3 kernel streams: for column tile ct (128 rows of W) and
+// K-step kt (16 k) the 8 KiB block at float offset (ct * K/16 + kt) * 2048 holds the hi plane (row rb at rb * 8
+// floats, its two 8-k chunks swapped when (rb >> 3) & 1 — the read-side swizzle) then the lo plane at +1024.
+// Rows past Nout repeat the last row (masked in the GEMM epilogue).  One thread per (block, row, chunk).
+__global__ void split_bf16_tiled_kernel(const float* __restrict__ W, float* __restrict__ img, int Nout, int K,
+                                        int ldw, size_t total) {
+    const int nk = K / DBK;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i & 1), rb = (int)((i >> 1) & 127);
+        const size_t blk = i >> 8;
+        const int kt = (int)(blk % nk), ct = (int)(blk / nk);
+        const int c = ch ^ ((rb >> 3) & 1);
+        const float* src = W + (size_t)min(ct * DBN + rb, Nout - 1) * ldw + kt * DBK + c * 8;
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(src), x1 = *reinterpret_cast<const f32x4*>(src + 4);
+        bf16x8 hi, lo;
+        split8(x0, x1, hi, lo);
+        float* dst = img + blk * D_TILE + rb * 8 + ch * 4;
+        *reinterpret_cast<u32x4*>(dst) = __builtin_bit_cast(u32x4, hi);
+        *reinterpret_cast<u32x4*>(dst + 1024) = __builtin_bit_cast(u32x4, lo);
     }
 }
 
@@ -344,12 +435,16 @@ int gemm_f32_dma_launch(const GemmArgs& g, hipStream_t st) {
         const char* e = getenv("GECCO_GEMM_STAGES");   // 3 stages = 51 KB LDS = three blocks per CU (measured best)
         ns3 = (e && atoi(e) == 4) ? 0 : 1;
     }
-    if (g.precision == 1 && g.w_hi && g.w_lo) return ns3 ? dma_launch_t<3, true>(g, st) : dma_launch_t<4, true>(g, st);
+    if (g.precision == 1 && g.w_img) return ns3 ? dma_launch_t<3, true>(g, st) : dma_launch_t<4, true>(g, st);
     return ns3 ? dma_launch_t<3, false>(g, st) : dma_launch_t<4, false>(g, st);
 }
 
-int split_bf16_launch(const float* W, unsigned short* hi, unsigned short* lo, size_t n, hipStream_t st) {
-    const unsigned grid = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    hipLaunchKernelGGL(split_bf16_kernel, dim3(grid ? grid : 1), dim3(256), 0, st, W, hi, lo, n);
+size_t split_bf16_image_bytes(int Nout, int K) { return (size_t)((Nout + DBN - 1) / DBN) * DBN * K * sizeof(float); }
+
+int split_bf16_tiled_launch(const float* W, void* img, int Nout, int K, int ldw, hipStream_t st) {
+    const size_t total = (size_t)((Nout + DBN - 1) / DBN) * (K / DBK) * 256;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(split_bf16_tiled_kernel, dim3(grid ? grid : 1), dim3(256), 0, st, W, static_cast<float*>(img),
+                       Nout, K, ldw, total);
     return (int)hipGetLastError();
 }

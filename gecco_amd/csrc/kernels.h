@@ -16,9 +16,8 @@ struct GemmArgs {
     int B, rows, K, Nout;
     int lda, ldw, ldc, ldr;
     int act;                // 0 none, 1 gaussian normalized, 2 gaussian raw
-    int precision;          // 0 exact fp32 MFMA, 1 split-bf16 (needs w_hi / w_lo)
-    const unsigned short* w_hi;  // bf16 planes of W, same (Nout, ldw) indexing
-    const unsigned short* w_lo;
+    int precision;          // 0 exact fp32 MFMA, 1 split-bf16 (needs w_img)
+    const void* w_img;      // tiled bf16 hi | lo image of W (split_bf16_tiled_launch)
 };
 
 int gemm_row_tile(int rows);  // row-tile height the GEMM uses for `rows` rows per sample
@@ -26,7 +25,8 @@ int gemm_f32_launch(const GemmArgs& g, hipStream_t st);
 // gemm_f32_dma.hip — LDS-DMA fast path of the same contract
 bool gemm_f32_dma_supported(const GemmArgs& g);
 int gemm_f32_dma_launch(const GemmArgs& g, hipStream_t st);
-int split_bf16_launch(const float* W, unsigned short* hi, unsigned short* lo, size_t n, hipStream_t st);
+size_t split_bf16_image_bytes(int Nout, int K);   // ceil(Nout / 128) * 128 * K * 4
+int split_bf16_tiled_launch(const float* W, void* img, int Nout, int K, int ldw, hipStream_t st);
 
 // gemm_general_f32.hip — C[z] = scale * op(A[z]) op(B[z]) (+ bias), per-operand layout flag, two-level batch strides
 struct GemmGeneralArgs {

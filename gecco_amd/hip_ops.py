@@ -70,7 +70,7 @@ def linear(A: Tensor, W: Tensor, bias: Tensor | None = None, pro: tuple[Tensor, 
     if want_stats:
         stats = torch.empty(B, lib.gecco_linear_row_tiles(rows), 2, Nout, device=A.device, dtype=torch.float32)
     act = 0 if act_alpha is None else (1 if normalized else 2)
-    wsplit = _ws(Nout * K * 4, A.device) if precision == "bf16x3" else None
+    wsplit = _ws((Nout + 127) // 128 * 128 * K * 4, A.device) if precision == "bf16x3" else None
     check(lib.gecco_linear_ex_f32(_ptr(A), _ptr(W), _ptr(bias), _ptr(pro[0]) if pro else None,
                                   _ptr(pro[1]) if pro else None, _ptr(act_alpha), _ptr(residual), _ptr(out), _ptr(stats),
                                   B, rows, K, Nout, act, PRECISIONS[precision],

@@ -79,7 +79,7 @@ int gecco_linear_f32(const float* A, const float* W, const float* bias, const fl
                      int Nout, int act, void* stream);
 int gecco_linear_row_tiles(int rows);
 /* The same with the arithmetic selectable: precision 0 = exact fp32 MFMA, 1 = split-bf16 (see GeccoSetTransformer);
- * wsplit: scratch of >= Nout*K*4 bytes for the bf16 hi | lo planes of W (precision 1 only). */
+ * wsplit: scratch of >= ceil(Nout/128)*128*K*4 bytes for the tiled bf16 hi | lo image of W (precision 1 only). */
 int gecco_linear_ex_f32(const float* A, const float* W, const float* bias, const float* pro_a, const float* pro_o,
                         const float* alpha, const float* residual, float* C, float* stats, int B, int rows, int K,
                         int Nout, int act, int precision, void* wsplit, void* stream);

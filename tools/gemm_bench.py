@@ -15,7 +15,9 @@ def main():
     only = set(sys.argv[2:])
     dev = torch.device("cuda", 0)
     tot_f = tot_ms = 0.0
-    for name, fl, fn in bench.gemm_call_sites(ops, dev):
+    precision = os.environ.get("GECCO_PRECISION", "bf16x3")
+    print("precision", precision)
+    for name, fl, _bytes, fn in bench.gemm_call_sites(ops, dev, precision):
         if only and name not in only:
             continue
         t = bench.time_events(fn, iters)

@@ -1,18 +1,21 @@
-// Diagnostic: time the fused GEMM with parts of its memory traffic aliased away (ldc = 0: every C row lands on the
-// same 512 bytes, ldr = 0 / lda = 0 likewise for the residual / A reads) to see which stream the kernel waits for.
+// Diagnostic: time the fused LDS-DMA GEMM (both arithmetic modes) with parts of its memory traffic aliased away
+// (ldc = 0: every C row lands on the same bytes; ldr = 0 / lda = 0 likewise for the residual / A reads) to see
+// which stream the kernel waits for.  Results are wrong by construction; timing only.
 #include <hip/hip_runtime.h>
-// build variants: -DGEMM_DIAG_NOSTAGE (no per-K-step staging), -DGEMM_DIAG_NOBARRIER (no per-K-step barrier): wrong results, timing only
-#include "../../gecco_amd/csrc/gemm_f32.hip"
+#include "../../gecco_amd/csrc/gemm_f32_dma.hip"
 #include <stdio.h>
 #include <vector>
+#ifndef PREC0
+#define PREC0 0
+#endif
 
 static float time_ms(const GemmArgs& g, int it = 8) {
-    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    gemm_f32_launch(g, 0); gemm_f32_launch(g, 0);
-    hipEventRecord(a, 0);
-    for (int i = 0; i < it; ++i) gemm_f32_launch(g, 0);
-    hipEventRecord(b, 0); hipEventSynchronize(b);
-    float ms; hipEventElapsedTime(&ms, a, b); return ms / it;
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    gemm_f32_dma_launch(g, 0); gemm_f32_dma_launch(g, 0);
+    (void)hipEventRecord(a, 0);
+    for (int i = 0; i < it; ++i) gemm_f32_dma_launch(g, 0);
+    (void)hipEventRecord(b, 0); (void)hipEventSynchronize(b);
+    float ms; (void)hipEventElapsedTime(&ms, a, b); return ms / it;
 }
 
 int main() {
@@ -20,27 +23,31 @@ int main() {
     struct Site { const char* name; int K, Nout; bool pro, res, stats, act; } sites[] = {
         {"kv_proj", 384, 768, true, false, false, false}, {"out_proj+res+stats", 384, 384, false, true, true, false},
         {"mlp.0+act", 384, 768, true, false, false, true}, {"mlp.2+res+stats", 768, 384, false, true, true, false}};
-    float *A, *W, *C, *R, *pa, *po, *bias, *alpha, *stats;
-    hipMalloc(&A, (size_t)B * N * 768 * 4); hipMalloc(&W, 768 * 768 * 4); hipMalloc(&C, (size_t)B * N * 768 * 4);
-    hipMalloc(&R, (size_t)B * N * 768 * 4); hipMalloc(&pa, B * 768 * 4); hipMalloc(&po, B * 768 * 4);
-    hipMalloc(&bias, 768 * 4); hipMalloc(&alpha, 4); hipMalloc(&stats, (size_t)B * 16 * 2 * 768 * 4);
+    float *A, *W, *C, *R, *pa, *po, *bias, *alpha, *stats; float* img;
+    (void)hipMalloc(&A, (size_t)B * N * 768 * 4); (void)hipMalloc(&W, 768 * 768 * 4); (void)hipMalloc(&C, (size_t)B * N * 768 * 4);
+    (void)hipMalloc(&R, (size_t)B * N * 768 * 4); (void)hipMalloc(&pa, B * 768 * 4); (void)hipMalloc(&po, B * 768 * 4);
+    (void)hipMalloc(&bias, 768 * 4); (void)hipMalloc(&alpha, 4); (void)hipMalloc(&stats, (size_t)B * 16 * 2 * 768 * 4);
+    (void)hipMalloc(&img, 768 * 768 * 4);
     std::vector<float> h((size_t)B * N * 768);
     for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) % 2001) / 1000.f - 1.f;
-    hipMemcpy(A, h.data(), h.size() * 4, hipMemcpyHostToDevice); hipMemcpy(R, h.data(), h.size() * 4, hipMemcpyHostToDevice);
-    hipMemcpy(W, h.data(), 768 * 768 * 4, hipMemcpyHostToDevice); hipMemcpy(pa, h.data(), B * 768 * 4, hipMemcpyHostToDevice);
-    hipMemcpy(po, h.data(), B * 768 * 4, hipMemcpyHostToDevice); hipMemcpy(bias, h.data(), 768 * 4, hipMemcpyHostToDevice);
-    float one = 1.f; hipMemcpy(alpha, &one, 4, hipMemcpyHostToDevice);
-    for (auto& s : sites) {
-        GemmArgs g{}; g.A = A; g.W = W; g.bias = bias; g.pro_a = s.pro ? pa : nullptr; g.pro_o = s.pro ? po : nullptr;
-        g.alpha = alpha; g.residual = s.res ? R : nullptr; g.C = C; g.stats = s.stats ? stats : nullptr;
-        g.B = B; g.rows = N; g.K = s.K; g.Nout = s.Nout; g.lda = s.K; g.ldw = s.K; g.ldc = s.Nout; g.ldr = s.Nout; g.act = s.act;
-        const double fl = 2.0 * B * N * s.K * s.Nout;
-        const float t0 = time_ms(g);
-        GemmArgs g1 = g; g1.ldc = 0;            const float t1 = time_ms(g1);
-        GemmArgs g2 = g1; g2.ldr = 0;           const float t2 = time_ms(g2);
-        GemmArgs g3 = g2; g3.lda = 0;           const float t3 = time_ms(g3);
-        printf("%-20s full %.3f ms (%5.1f TF) | C aliased %.3f (%5.1f) | +residual aliased %.3f (%5.1f) | +A aliased %.3f (%5.1f)\n",
-               s.name, t0, fl / t0 / 1e9, t1, fl / t1 / 1e9, t2, fl / t2 / 1e9, t3, fl / t3 / 1e9);
-    }
+    (void)hipMemcpy(A, h.data(), h.size() * 4, hipMemcpyHostToDevice); (void)hipMemcpy(R, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(W, h.data(), 768 * 768 * 4, hipMemcpyHostToDevice); (void)hipMemcpy(pa, h.data(), B * 768 * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(po, h.data(), B * 768 * 4, hipMemcpyHostToDevice); (void)hipMemcpy(bias, h.data(), 768 * 4, hipMemcpyHostToDevice);
+    float one = 1.f; (void)hipMemcpy(alpha, &one, 4, hipMemcpyHostToDevice);
+    for (int prec = PREC0; prec < 2; ++prec)
+        for (auto& s : sites) {
+            GemmArgs g{}; g.A = A; g.W = W; g.bias = bias; g.pro_a = s.pro ? pa : nullptr; g.pro_o = s.pro ? po : nullptr;
+            g.alpha = alpha; g.residual = s.res ? R : nullptr; g.C = C; g.stats = s.stats ? stats : nullptr;
+            g.B = B; g.rows = N; g.K = s.K; g.Nout = s.Nout; g.lda = s.K; g.ldw = s.K; g.ldc = s.Nout; g.ldr = s.Nout; g.act = s.act;
+            g.precision = prec; g.w_img = img;
+            if (prec) split_bf16_tiled_launch(W, img, s.Nout, s.K, s.K, 0);
+            const double fl = 2.0 * B * N * s.K * s.Nout;
+            const float t0 = time_ms(g);
+            GemmArgs g1 = g; g1.ldc = 0;            const float t1 = time_ms(g1);
+            GemmArgs g2 = g1; g2.ldr = 0;           const float t2 = time_ms(g2);
+            GemmArgs g3 = g2; g3.lda = 0;           const float t3 = time_ms(g3);
+            printf("%-6s %-20s full %.3f ms (%5.1f TF) | C aliased %.3f | +residual aliased %.3f | +A aliased %.3f (%5.1f TF)\n",
+                   prec ? "bf16x3" : "fp32", s.name, t0, fl / t0 / 1e9, t1, t2, t3, fl / t3 / 1e9);
+        }
     return 0;
 }

@@ -80,8 +80,10 @@ SIGNATURES = {
     "gecco_adagn_f32": (i, [vp, vp, i, C.POINTER(GeccoAdaGN), vp, i, i, i, i, fl, vp, sz, vp]),
     "gecco_adagn_workspace_bytes": (sz, [i, i, i]),
     "gecco_pool_attn_f32": (i, [vp, vp, vp, i, i, i, i, i, vp, sz, vp]),
+    "gecco_pool_attn_ex_f32": (i, [vp, vp, vp, i, i, i, i, i, i, vp, sz, vp]),
     "gecco_pool_attn_workspace_bytes": (sz, [i, i, i, i, i]),
     "gecco_unpool_attn_f32": (i, [vp, vp, vp, i, i, i, i, i, vp]),
+    "gecco_unpool_attn_ex_f32": (i, [vp, vp, vp, i, i, i, i, i, i, vp]),
     "gecco_edm_coeffs_f32": (i, [vp, fl, vp, i, vp]),
     "gecco_lift_f32": (i, [vp, vp, vp, vp, vp, vp, i, i, i, vp]),
     "gecco_lower_edm_f32": (i, [vp] * 9 + [i, i, i, fl, vp]),

@@ -144,7 +144,7 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
             // pool: KV projection, 64 inducer queries over the N points, out_proj
             TRY(linear(x, L.kv_proj_w, nullptr, w.a1, w.o1, nullptr, nullptr, w.big, nullptr, B, N, C, 2 * C, 0, s, pr,
                        w.wsplit), "kv_proj");
-            TRY(pool_attn_launch(w.big, L.inducers, w.part_o, w.part_ml, w.merged, B, N, C, H, I, ns, s), "pool_attn");
+            TRY(pool_attn_launch(w.big, L.inducers, w.part_o, w.part_ml, w.merged, B, N, C, H, I, ns, s, pr), "pool_attn");
             TRY(linear(w.merged, L.pool_out_w, nullptr, nullptr, nullptr, nullptr, nullptr, w.h0, w.stats_s, B, I, C, C,
                        0, s), "pool.out_proj");
             // h = norm_2(mlp(norm_1(h0)))
@@ -163,7 +163,7 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
                    B, I, C, 2 * C, 0, s), "unpool.in_proj(kv)");
         TRY(linear(x, L.in_proj_w, L.in_proj_b, w.a1, w.o1, nullptr, nullptr, w.q, nullptr, B, N, C, C, 0, s, pr, w.wsplit),
             "unpool.in_proj(q)");
-        TRY(unpool_attn_launch(w.q, w.kvh, w.attn, B, N, C, H, I, s), "unpool_attn");
+        TRY(unpool_attn_launch(w.q, w.kvh, w.attn, B, N, C, H, I, s, pr), "unpool_attn");
         TRY(linear(w.attn, L.unpool_out_w, L.unpool_out_b, nullptr, nullptr, nullptr, x, x, w.stats_x, B, N, C, C, 0, s, pr,
                    w.wsplit), "unpool.out_proj+residual");
         // x += mlp(AdaGN(x))
@@ -282,21 +282,33 @@ size_t gecco_pool_attn_workspace_bytes(int B, int N, int C, int H, int I) {
     return (c.off + 255) & ~size_t(255);
 }
 
-int gecco_pool_attn_f32(const float* KV, const float* inducers, float* merged, int B, int N, int C, int H, int I,
-                        void* ws, size_t ws_bytes, void* stream) {
+int gecco_pool_attn_ex_f32(const float* KV, const float* inducers, float* merged, int B, int N, int C, int H, int I,
+                           int precision, void* ws, size_t ws_bytes, void* stream) {
+    if (precision != 0 && precision != 1) return fail(-2, "pool_attn: precision must be 0 (fp32) or 1 (split-bf16)");
     if (ws_bytes < gecco_pool_attn_workspace_bytes(B, N, C, H, I)) return fail(-7, "pool_attn: workspace too small");
     Carver c(ws);
     const int ns = pool_attn_nsplit(B, N, H);
     float* po = c.f32((size_t)B * H * ns * 64 * (C / H));
     float* pml = c.f32((size_t)B * H * ns * 64 * 2);
-    TRY(pool_attn_launch(KV, inducers, po, pml, merged, B, N, C, H, I, ns, (hipStream_t)stream), "pool_attn");
+    TRY(pool_attn_launch(KV, inducers, po, pml, merged, B, N, C, H, I, ns, (hipStream_t)stream, precision), "pool_attn");
+    return 0;
+}
+
+int gecco_pool_attn_f32(const float* KV, const float* inducers, float* merged, int B, int N, int C, int H, int I,
+                        void* ws, size_t ws_bytes, void* stream) {
+    return gecco_pool_attn_ex_f32(KV, inducers, merged, B, N, C, H, I, 0, ws, ws_bytes, stream);
+}
+
+int gecco_unpool_attn_ex_f32(const float* q, const float* kvh, float* out, int B, int N, int C, int H, int I,
+                             int precision, void* stream) {
+    if (precision != 0 && precision != 1) return fail(-2, "unpool_attn: precision must be 0 (fp32) or 1 (split-bf16)");
+    TRY(unpool_attn_launch(q, kvh, out, B, N, C, H, I, (hipStream_t)stream, precision), "unpool_attn");
     return 0;
 }
 
 int gecco_unpool_attn_f32(const float* q, const float* kvh, float* out, int B, int N, int C, int H, int I,
                           void* stream) {
-    TRY(unpool_attn_launch(q, kvh, out, B, N, C, H, I, (hipStream_t)stream), "unpool_attn");
-    return 0;
+    return gecco_unpool_attn_ex_f32(q, kvh, out, B, N, C, H, I, 0, stream);
 }
 
 int gecco_edm_coeffs_f32(const float* sigma, float sigma_data, float* coef, int B, void* stream) {

@@ -1,0 +1,498 @@
+// Inducing-point attention in split-bf16 arithmetic ("bf16x3", see gemm_f32_dma.hip), gfx950.  Same contract and
+// the same S^T = K Q^T / O^T = V^T P^T orientation as attention_f32.hip, but every product runs as three
+// v_mfma_f32_32x32x16_bf16 (a_lo b_hi + a_hi b_lo + a_hi b_hi, fp32 accumulate): 42 matrix instructions of 32
+// cycles per 32-row tile instead of 112 fp32 ones of 64 cycles, which moves both kernels from the fp32 matrix pipe
+// to the HBM stream of their (B, N, C) operand.
+//   * operands live in LDS as bf16 hi | lo planes, rows padded to an odd number of 16-byte chunks (conflict-free
+//     ds_read_b128 fragments: lane half h takes k = 8h .. 8h+7 of a 16-wide chunk);
+//   * the probability tile never leaves registers: accumulator registers 8s .. 8s+7 of lane half h are keys
+//     16s + 8(j>>2) + 4h + (j&3), j = 0..7, and become the B fragment of key chunk s after the hi / lo split, so the
+//     V^T fragment is delivered in that key order:
+//       unpool — the 64 inducer values are block-constant: stored transposed and key-permuted once per block;
+//       pool   — the streamed value tile is stored row-major in 4-key x 32-column blocks of 256 B and read with
+//                ds_read_b64_tr_b16 (the hardware transpose), one conflict-free block per 32-lane half.
+// Head dims: multiples of 16 up to 64; anything else stays on the fp32 kernels.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16;
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// 4 fp32 -> 4 bf16 hi (top 16 bits) and 4 bf16 lo = rne(x - hi), each packed in two dwords
+__device__ __forceinline__ void split4(const f32x4& x, u32x2& hi, u32x2& lo) {
+    bf16x4 l;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const unsigned ua = __float_as_uint(x[2 * p]), uc = __float_as_uint(x[2 * p + 1]);
+        hi[p] = __builtin_amdgcn_perm(uc, ua, 0x07060302u);  // {hi16(x[2p+1]), hi16(x[2p])}
+        l[2 * p] = (__bf16)(x[2 * p] - __uint_as_float(ua & 0xFFFF0000u));
+        l[2 * p + 1] = (__bf16)(x[2 * p + 1] - __uint_as_float(uc & 0xFFFF0000u));
+    }
+    lo = __builtin_bit_cast(u32x2, l);
+}
+
+// accumulator registers e0 .. e0+7 -> the hi / lo fragments of one 16-key chunk
+__device__ __forceinline__ void split_acc8(const f32x16& s, int e0, bf16x8& hi, bf16x8& lo) {
+    u32x4 hb;
+    bf16x8 l;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float a = s[e0 + 2 * p], c = s[e0 + 2 * p + 1];
+        const unsigned ua = __float_as_uint(a), uc = __float_as_uint(c);
+        hb[p] = __builtin_amdgcn_perm(uc, ua, 0x07060302u);
+        l[2 * p] = (__bf16)(a - __uint_as_float(ua & 0xFFFF0000u));
+        l[2 * p + 1] = (__bf16)(c - __uint_as_float(uc & 0xFFFF0000u));
+    }
+    hi = __builtin_bit_cast(bf16x8, hb);
+    lo = l;
+}
+
+__device__ __forceinline__ bf16x8 frag(const u16* p) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p)); }
+
+__device__ __forceinline__ f32x16 mfma3(const bf16x8& ahi, const bf16x8& alo, const bf16x8& bhi, const bf16x8& blo,
+                                        f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------- pool
+// element offset of value (key, d) in a wave's value tile: 4-key x 32-column blocks of 128 elements (256 B)
+template <int DT>
+__device__ __forceinline__ int vt_off(int key, int d) {
+    return ((key >> 2) * DT + (d >> 5)) * 128 + (key & 3) * 32 + (d & 31);
+}
+
+template <int HD>
+__global__ __launch_bounds__(256, 2) void pool_attn_x3_kernel(const float* __restrict__ KV,
+                                                           const float* __restrict__ Qind,
+                                                           float* __restrict__ part_o, float* __restrict__ part_ml,
+                                                           int B, int N, int C, int H, int nsplit) {
+    constexpr int KS = HD + 8;            // bf16 elements per K / Q row: an odd number of 16-byte chunks
+    constexpr int DT = (HD + 31) / 32;
+    constexpr int CH = HD / 4;
+    constexpr int LD_IT = (32 * CH + 63) / 64;
+    constexpr int NC = HD / 16;           // 16-wide k chunks of the head dim
+    constexpr int VT = 8 * DT * 128;      // elements per value plane of one wave tile
+    constexpr int WAVE_E = 2 * 32 * KS + 2 * VT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    u16* lds = reinterpret_cast<u16*>(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
+    const int b = bh / H, hh = bh % H;
+
+    u16* Qhi = lds;
+    u16* Qlo = lds + 64 * KS;
+    u16* Khi = lds + 2 * 64 * KS + wave * WAVE_E;
+    u16* Klo = Khi + 32 * KS;
+    u16* Vhi = Klo + 32 * KS;
+    u16* Vlo = Vhi + VT;
+
+    const int ks = (((N + nsplit - 1) / nsplit) + 31) / 32 * 32;
+    const int k_begin = split * ks;
+    const int k_end = min(N, k_begin + ks);
+    const int ntiles = k_end > k_begin ? (k_end - k_begin + 31) / 32 : 0;
+    const int nit = (ntiles + 3) / 4;
+
+    const float scale = LOG2E * rsqrtf((float)HD);
+    for (int f = tid; f < 64 * CH; f += 256) {
+        const int row = f / CH, ch = f % CH;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(Qind + ((size_t)hh * 64 + row) * HD + ch * 4) * scale;
+        u32x2 hi, lo;
+        split4(v, hi, lo);
+        *reinterpret_cast<u32x2*>(Qhi + row * KS + ch * 4) = hi;
+        *reinterpret_cast<u32x2*>(Qlo + row * KS + ch * 4) = lo;
+    }
+
+    const size_t ldkv = 2 * (size_t)C;
+    const float* Kg = KV + (size_t)b * N * ldkv + hh * HD;
+    const float* Vg = Kg + C;
+
+    f32x4 rk[LD_IT], rv[LD_IT];
+    auto load_tile = [&](int tile) {
+        const int base = k_begin + tile * 32;
+#pragma unroll
+        for (int it = 0; it < LD_IT; ++it) {
+            const int f = it * 64 + lane, row = f / CH, ch = f % CH, key = base + row;
+            f32x4 zk = {0.f, 0.f, 0.f, 0.f}, zv = {0.f, 0.f, 0.f, 0.f};
+            if (f < 32 * CH && tile < ntiles && key < k_end) {
+                zk = *reinterpret_cast<const f32x4*>(Kg + key * ldkv + ch * 4);
+                zv = *reinterpret_cast<const f32x4*>(Vg + key * ldkv + ch * 4);
+            }
+            rk[it] = zk;
+            rv[it] = zv;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int it = 0; it < LD_IT; ++it) {
+            const int f = it * 64 + lane, row = f / CH, ch = f % CH;
+            if (f < 32 * CH) {
+                u32x2 hi, lo;
+                split4(rk[it], hi, lo);
+                *reinterpret_cast<u32x2*>(Khi + row * KS + ch * 4) = hi;
+                *reinterpret_cast<u32x2*>(Klo + row * KS + ch * 4) = lo;
+                split4(rv[it], hi, lo);
+                *reinterpret_cast<u32x2*>(Vhi + vt_off<DT>(row, ch * 4)) = hi;
+                *reinterpret_cast<u32x2*>(Vlo + vt_off<DT>(row, ch * 4)) = lo;
+            }
+        }
+    };
+    // transposed-read addressing: lane 4q+p of a 16-lane group points at row q, columns 4p .. 4p+3 of its block
+    const int tq = (lane & 15) >> 2, tp = lane & 3, tcol = 16 * ((lane >> 4) & 1) + 4 * tp;
+
+    float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+    f32x16 O[DT][2];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) O[dt][j][e] = 0.f;
+
+    load_tile(wave);
+    __syncthreads();  // the shared query planes are complete
+    for (int it = 0; it < nit; ++it) {
+        const int tile = wave + 4 * it;
+        store_tile();
+        wave_lds_sync();
+        load_tile(tile + 4);
+        if (tile < ntiles) {
+            f32x16 s[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s[j][e] = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const bf16x8 ah = frag(Khi + r * KS + c * 16 + 8 * h), al = frag(Klo + r * KS + c * 16 + 8 * h);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bf16x8 qh = frag(Qhi + (j * 32 + r) * KS + c * 16 + 8 * h);
+                    const bf16x8 ql = frag(Qlo + (j * 32 + r) * KS + c * 16 + 8 * h);
+                    s[j] = mfma3(ah, al, qh, ql, s[j]);
+                }
+            }
+            const int kbase = k_begin + tile * 32;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    if (kbase + mfma_row(e, h) >= k_end) s[j][e] = -INFINITY;
+                    mx = fmaxf(mx, s[j][e]);
+                }
+                mx = fmaxf(mx, xor32(mx));
+                const float mn = fmaxf(m[j], mx);  // finite: the tile holds >= 1 valid key
+                const float alpha = exp2f(m[j] - mn);
+                float ps = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    s[j][e] = exp2f(s[j][e] - mn);
+                    ps += s[j][e];
+                }
+                l[j] = l[j] * alpha + ps;
+                m[j] = mn;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) O[dt][j][e] *= alpha;
+            }
+#pragma unroll
+            for (int sg = 0; sg < 2; ++sg) {   // the tile's two 16-key chunks
+                bf16x8 ph[2], pl[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) split_acc8(s[j], 8 * sg, ph[j], pl[j]);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const int o0 = vt_off<DT>(16 * sg + 4 * h + tq, dt * 32 + tcol);
+                    const int o1 = vt_off<DT>(16 * sg + 8 + 4 * h + tq, dt * 32 + tcol);
+                    typedef __attribute__((address_space(3))) s16x4* lp;
+                    const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(Vhi + o0));
+                    const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(Vhi + o1));
+                    const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(Vlo + o0));
+                    const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(Vlo + o1));
+                    const bf16x8 vh = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    const bf16x8 vl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) O[dt][j] = mfma3(vh, vl, ph[j], pl[j], O[dt][j]);
+                }
+            }
+        }
+        wave_lds_sync();  // this wave's reads of its K / V tile are done before it overwrites them
+    }
+    __syncthreads();      // every wave is done with its staging area: the combine below reuses the LDS
+
+    // ---- combine the four waves' (m, l, O) and emit one partial per (b, head, split)
+    float* Ow = smem;                 // [4][HD][64]
+    float* Mw = smem + 4 * HD * 64;   // [4][64]
+    float* Lw = Mw + 256;             // [4][64]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float lt = l[j] + xor32(l[j]);
+        if (h == 0) {
+            Mw[wave * 64 + j * 32 + r] = m[j];
+            Lw[wave * 64 + j * 32 + r] = lt;
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int d = dt * 32 + mfma_row(e, h);
+                if (d < HD) Ow[(wave * HD + d) * 64 + j * 32 + r] = O[dt][j][e];
+            }
+    }
+    __syncthreads();
+    {
+        const int q = tid & 63, part = tid >> 6;
+        float M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) M = fmaxf(M, Mw[w * 64 + q]);
+        float f[4], L = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float mw = Mw[w * 64 + q];
+            f[w] = (mw == -INFINITY) ? 0.f : exp2f(mw - M);
+            L += f[w] * Lw[w * 64 + q];
+        }
+        const size_t pbase = ((size_t)bh * nsplit + split) * 64 + q;
+        for (int d = part; d < HD; d += 4) {
+            float o = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) o += f[w] * Ow[(w * HD + d) * 64 + q];
+            part_o[pbase * HD + d] = o;
+        }
+        if (part == 0) {
+            part_ml[pbase * 2 + 0] = M;
+            part_ml[pbase * 2 + 1] = L;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------- unpool
+template <int HD>
+__global__ __launch_bounds__(256, 2) void unpool_attn_x3_kernel(const float* __restrict__ q,
+                                                             const float* __restrict__ kvh, float* __restrict__ out,
+                                                             int B, int N, int C, int H, int tiles_per_wave,
+                                                             int nchunk) {
+    constexpr int KS = HD + 8;            // bf16 elements per K / Q row
+    constexpr int VS = 64 + 8;            // bf16 elements per V^T row (64 permuted keys + pad)
+    constexpr int DT = (HD + 31) / 32;
+    constexpr int CH = HD / 4;
+    constexpr int LD_IT = (32 * CH + 63) / 64;
+    constexpr int NC = HD / 16;
+    constexpr int OP = HD + 4;            // fp32 row stride of the output transpose tile (aliases the Q planes)
+    static_assert(32 * OP * 4 <= 2 * 32 * KS * 2, "output tile must fit in the wave's Q planes");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    u16* lds = reinterpret_cast<u16*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int chunk = blockIdx.x % nchunk, bh = blockIdx.x / nchunk;
+    const int b = bh / H, hh = bh % H;
+
+    u16* Khi = lds;                        // [64][KS]
+    u16* Klo = Khi + 64 * KS;
+    u16* Vthi = Klo + 64 * KS;             // [DT * 32][VS]: row = head-dim index, keys permuted inside 16-chunks
+    u16* Vtlo = Vthi + DT * 32 * VS;
+    u16* Qhi = Vtlo + DT * 32 * VS + wave * 2 * 32 * KS;
+    u16* Qlo = Qhi + 32 * KS;
+    float* Ot = reinterpret_cast<float*>(Qhi);   // [32][OP] fp32, after the Q fragments are consumed
+
+    for (int f = tid; f < DT * 32 * VS / 2; f += 256) {   // zero the value planes: padded head-dim rows stay finite
+        reinterpret_cast<unsigned*>(Vthi)[f] = 0u;
+        reinterpret_cast<unsigned*>(Vtlo)[f] = 0u;
+    }
+    __syncthreads();
+    for (int f = tid; f < 64 * CH; f += 256) {
+        const int key = f / CH, ch = f % CH;
+        const float* src = kvh + ((size_t)b * 64 + key) * 2 * C + hh * HD + ch * 4;
+        u32x2 hi, lo;
+        split4(*reinterpret_cast<const f32x4*>(src), hi, lo);
+        *reinterpret_cast<u32x2*>(Khi + key * KS + ch * 4) = hi;
+        *reinterpret_cast<u32x2*>(Klo + key * KS + ch * 4) = lo;
+        split4(*reinterpret_cast<const f32x4*>(src + C), hi, lo);
+        // key 16c + 8a + 4g + i sits at position 16c + 8g + 4a + i: lane half g reads its 8 keys contiguously
+        const int pos = (key & ~15) + 8 * ((key >> 2) & 1) + 4 * ((key >> 3) & 1) + (key & 3);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            Vthi[(ch * 4 + e) * VS + pos] = (u16)(hi[e >> 1] >> (16 * (e & 1)));
+            Vtlo[(ch * 4 + e) * VS + pos] = (u16)(lo[e >> 1] >> (16 * (e & 1)));
+        }
+    }
+    const float scale = LOG2E * rsqrtf((float)HD);
+    const float* qb = q + (size_t)b * N * C + hh * HD;
+    float* ob = out + (size_t)b * N * C + hh * HD;
+
+    f32x4 rq[LD_IT];
+    auto load_q = [&](int it) {
+        const int q0 = (chunk * tiles_per_wave + it) * 128 + wave * 32;
+#pragma unroll
+        for (int ld = 0; ld < LD_IT; ++ld) {
+            const int f = ld * 64 + lane, row = f / CH, ch = f % CH, n = q0 + row;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (f < 32 * CH && it < tiles_per_wave && n < N) v = *reinterpret_cast<const f32x4*>(qb + (size_t)n * C + ch * 4);
+            rq[ld] = v;
+        }
+    };
+    load_q(0);
+    for (int it = 0; it < tiles_per_wave; ++it) {
+        const int q0 = (chunk * tiles_per_wave + it) * 128 + wave * 32;
+#pragma unroll
+        for (int ld = 0; ld < LD_IT; ++ld) {
+            const int f = ld * 64 + lane, row = f / CH, ch = f % CH;
+            if (f < 32 * CH) {
+                u32x2 hi, lo;
+                split4(rq[ld] * scale, hi, lo);
+                *reinterpret_cast<u32x2*>(Qhi + row * KS + ch * 4) = hi;
+                *reinterpret_cast<u32x2*>(Qlo + row * KS + ch * 4) = lo;
+            }
+        }
+        load_q(it + 1);
+        if (it == 0) __syncthreads();  // the shared key / value planes are complete
+        wave_lds_sync();
+        f32x16 s[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[kt][e] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const bf16x8 qh = frag(Qhi + r * KS + c * 16 + 8 * h), ql = frag(Qlo + r * KS + c * 16 + 8 * h);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                const bf16x8 kh = frag(Khi + (kt * 32 + r) * KS + c * 16 + 8 * h);
+                const bf16x8 kl = frag(Klo + (kt * 32 + r) * KS + c * 16 + 8 * h);
+                s[kt] = mfma3(kh, kl, qh, ql, s[kt]);
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[kt][e]);
+        mx = fmaxf(mx, xor32(mx));
+        float ls = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                s[kt][e] = exp2f(s[kt][e] - mx);
+                ls += s[kt][e];
+            }
+        ls += xor32(ls);
+        const float inv = 1.0f / ls;
+        f32x16 O[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) O[dt][e] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int sg = 0; sg < 2; ++sg) {
+                bf16x8 ph, pl;
+                split_acc8(s[kt], 8 * sg, ph, pl);
+                const int c16 = 2 * kt + sg;   // 16-key chunk of the 64 inducers
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const bf16x8 vh = frag(Vthi + (dt * 32 + r) * VS + c16 * 16 + 8 * h);
+                    const bf16x8 vl = frag(Vtlo + (dt * 32 + r) * VS + c16 * 16 + 8 * h);
+                    O[dt] = mfma3(vh, vl, ph, pl, O[dt]);
+                }
+            }
+        wave_lds_sync();   // the Q fragments are consumed: their planes become the fp32 output tile
+        // transpose O^T (query on the lane) back to rows
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d = dt * 32 + 8 * g4 + 4 * h;
+                if (d < HD) {
+                    f32x4 v = {O[dt][4 * g4], O[dt][4 * g4 + 1], O[dt][4 * g4 + 2], O[dt][4 * g4 + 3]};
+                    *reinterpret_cast<f32x4*>(Ot + r * OP + d) = v * inv;
+                }
+            }
+        wave_lds_sync();
+#pragma unroll
+        for (int ld = 0; ld < LD_IT; ++ld) {
+            const int f = ld * 64 + lane, row = f / CH, ch = f % CH, n = q0 + row;
+            if (f < 32 * CH && n < N)
+                *reinterpret_cast<f32x4*>(ob + (size_t)n * C + ch * 4) =
+                    *reinterpret_cast<const f32x4*>(Ot + row * OP + ch * 4);
+        }
+        wave_lds_sync();
+    }
+}
+
+template <int HD>
+int pool_x3_launch_t(const float* KV, const float* ind, float* po, float* pml, int B, int N, int C, int H, int nsplit,
+                     hipStream_t st) {
+    constexpr int KS = HD + 8, DT = (HD + 31) / 32, VT = 8 * DT * 128;
+    const size_t a = ((size_t)2 * 64 * KS + 4 * (2 * 32 * KS + 2 * VT)) * 2, c = ((size_t)4 * HD * 64 + 512) * 4;
+    const size_t lds = a > c ? a : c;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pool_attn_x3_kernel<HD>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((pool_attn_x3_kernel<HD>), dim3(B * H * nsplit), dim3(256), lds, st, KV, ind, po, pml, B, N, C,
+                       H, nsplit);
+    return (int)hipGetLastError();
+}
+
+template <int HD>
+int unpool_x3_launch_t(const float* q, const float* kvh, float* out, int B, int N, int C, int H, hipStream_t st) {
+    constexpr int KS = HD + 8, VS = 72, DT = (HD + 31) / 32;
+    const size_t lds = ((size_t)2 * 64 * KS + 2 * DT * 32 * VS + 4 * 2 * 32 * KS) * 2;
+    const int tiles = (N + 127) / 128;
+    int tpw = 1;
+    while (tpw < 4 && (long)B * H * ((tiles + tpw * 2 - 1) / (tpw * 2)) >= 2048) tpw *= 2;
+    const int nchunk = (tiles + tpw - 1) / tpw;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(unpool_attn_x3_kernel<HD>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((unpool_attn_x3_kernel<HD>), dim3(B * H * nchunk), dim3(256), lds, st, q, kvh, out, B, N, C, H,
+                       tpw, nchunk);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+bool attn_x3_supported(int HD) { return HD == 16 || HD == 32 || HD == 48 || HD == 64; }
+
+int pool_attn_x3_partials_launch(const float* KV, const float* inducers, float* part_o, float* part_ml, int B, int N,
+                                 int C, int H, int nsplit, hipStream_t st) {
+    switch (C / H) {
+        case 16: return pool_x3_launch_t<16>(KV, inducers, part_o, part_ml, B, N, C, H, nsplit, st);
+        case 32: return pool_x3_launch_t<32>(KV, inducers, part_o, part_ml, B, N, C, H, nsplit, st);
+        case 48: return pool_x3_launch_t<48>(KV, inducers, part_o, part_ml, B, N, C, H, nsplit, st);
+        case 64: return pool_x3_launch_t<64>(KV, inducers, part_o, part_ml, B, N, C, H, nsplit, st);
+        default: return -4;
+    }
+}
+
+int unpool_attn_x3_launch(const float* q, const float* kvh, float* out, int B, int N, int C, int H, hipStream_t st) {
+    switch (C / H) {
+        case 16: return unpool_x3_launch_t<16>(q, kvh, out, B, N, C, H, st);
+        case 32: return unpool_x3_launch_t<32>(q, kvh, out, B, N, C, H, st);
+        case 48: return unpool_x3_launch_t<48>(q, kvh, out, B, N, C, H, st);
+        case 64: return unpool_x3_launch_t<64>(q, kvh, out, B, N, C, H, st);
+        default: return -4;
+    }
+}

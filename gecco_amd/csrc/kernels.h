@@ -64,11 +64,17 @@ int lower_bwd_launch(const float* feat, const float* dF, const float* W, float* 
                      int C, float eps, hipStream_t st);
 
 // attention_f32.hip
+// precision 1 = split-bf16 arithmetic (attention_x3.hip) when the head dim allows, else the exact fp32 kernels
 int pool_attn_launch(const float* KV, const float* inducers, float* part_o, float* part_ml, float* merged,
-                     int B, int N, int C, int H, int I, int nsplit, hipStream_t st);
+                     int B, int N, int C, int H, int I, int nsplit, hipStream_t st, int precision = 0);
 int pool_attn_nsplit(int B, int N, int H);
 int unpool_attn_launch(const float* q, const float* kvh, float* out, int B, int N, int C, int H, int I,
-                       hipStream_t st);
+                       hipStream_t st, int precision = 0);
+// attention_x3.hip
+bool attn_x3_supported(int HD);
+int pool_attn_x3_partials_launch(const float* KV, const float* inducers, float* part_o, float* part_ml, int B, int N,
+                                 int C, int H, int nsplit, hipStream_t st);
+int unpool_attn_x3_launch(const float* q, const float* kvh, float* out, int B, int N, int C, int H, hipStream_t st);
 
 // lookup.hip
 struct LookupArgs {

@@ -130,26 +130,29 @@ def adagn(x: Tensor, t: Tensor | None, params: Sequence[Tensor] | None, G: int, 
     return y
 
 
-def pool_attn(KV: Tensor, inducers: Tensor, H: int) -> Tensor:
+def pool_attn(KV: Tensor, inducers: Tensor, H: int, precision: str = "fp32") -> Tensor:
     """AttentionPool core: KV (B, N, 2C), inducers (1, H, I, hd) -> (B, I, C) merged heads (before out_proj)."""
     lib = _lib.load()
+    pr = PRECISIONS[precision]
     B, N, C2 = KV.shape
     Cc = C2 // 2
     I = inducers.shape[-2]
     merged = torch.empty(B, I, Cc, device=KV.device, dtype=torch.float32)
     nb = lib.gecco_pool_attn_workspace_bytes(B, N, Cc, H, I)
     ws = _ws(nb, KV.device)
-    check(lib.gecco_pool_attn_f32(_ptr(KV), _ptr(inducers), _ptr(merged), B, N, Cc, H, I, C.c_void_p(ws.data_ptr()),
-                                  nb, _stream()), "gecco_pool_attn_f32")
+    check(lib.gecco_pool_attn_ex_f32(_ptr(KV), _ptr(inducers), _ptr(merged), B, N, Cc, H, I, pr,
+                                     C.c_void_p(ws.data_ptr()), nb, _stream()), "gecco_pool_attn_ex_f32")
     return merged
 
 
-def unpool_attn(q: Tensor, kvh: Tensor, H: int) -> Tensor:
+def unpool_attn(q: Tensor, kvh: Tensor, H: int, precision: str = "fp32") -> Tensor:
     lib = _lib.load()
+    pr = PRECISIONS[precision]
     B, N, Cc = q.shape
     I = kvh.shape[1]
     out = torch.empty_like(q)
-    check(lib.gecco_unpool_attn_f32(_ptr(q), _ptr(kvh), _ptr(out), B, N, Cc, H, I, _stream()), "gecco_unpool_attn_f32")
+    check(lib.gecco_unpool_attn_ex_f32(_ptr(q), _ptr(kvh), _ptr(out), B, N, Cc, H, I, pr, _stream()),
+          "gecco_unpool_attn_ex_f32")
     return out
 
 

@@ -102,12 +102,18 @@ size_t gecco_adagn_workspace_bytes(int B, int rows, int C);
 /* AttentionPool core (models/set_transformer.py:47-63, without out_proj): KV (B, N, 2C) -> merged (B, I, C). */
 int gecco_pool_attn_f32(const float* KV, const float* inducers, float* merged, int B, int N, int C, int H, int I,
                         void* ws, size_t ws_bytes, void* stream);
+/* Same with the arithmetic selected: precision 0 = exact fp32 MFMA, 1 = split-bf16 (head dims 16/32/48/64;
+ * other head dims run the fp32 kernel).  Same workspace. */
+int gecco_pool_attn_ex_f32(const float* KV, const float* inducers, float* merged, int B, int N, int C, int H, int I,
+                           int precision, void* ws, size_t ws_bytes, void* stream);
 size_t gecco_pool_attn_workspace_bytes(int B, int N, int C, int H, int I);
 
 /* nn.MultiheadAttention core (models/set_transformer.py:112, between in_proj and out_proj):
  * q (B, N, C) projected queries, kvh (B, I, 2C) projected inducer keys|values -> out (B, N, C). */
 int gecco_unpool_attn_f32(const float* q, const float* kvh, float* out, int B, int N, int C, int H, int I,
                           void* stream);
+int gecco_unpool_attn_ex_f32(const float* q, const float* kvh, float* out, int B, int N, int C, int H, int I,
+                             int precision, void* stream);
 
 /* coef: 5*B floats: coef[4b..4b+3] = {c_skip, c_out, c_in, c_noise} (diffusion.py:46-51) and
  * coef[4B + b] = c_noise packed (the AdaGN `t` input for t_embed_dim == 1). */

@@ -102,18 +102,20 @@ def test_adagn_large_mean(ops):
 
 
 @pytest.mark.parametrize("B,N,C,H", [(2, 256, 128, 8), (2, 1000, 384, 8), (1, 64, 64, 8), (3, 33, 512, 8), (2, 2048, 256, 8)])
-def test_pool_attn(ops, B, N, C, H):
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16x3", 1e-4)])
+def test_pool_attn(ops, B, N, C, H, precision, tol):
     rs = _rs(N + C)
     y = _t(rs.randn(B, N, C))
     p = {"kv_proj.weight": _t(rs.randn(2 * C, C) / math.sqrt(C) * 2), "inducers": _t(rs.randn(1, H, 64, C // H)),
          "out_proj.weight": torch.eye(C)}
     ref = cpu_ref.attention_pool(y, p, "", H)
     KV = F.linear(y, p["kv_proj.weight"])
-    got = ops.pool_attn(KV.cuda(), p["inducers"].cuda(), H)
-    _close(got, ref)
+    got = ops.pool_attn(KV.cuda(), p["inducers"].cuda(), H, precision=precision)
+    _close(got, ref, tol)
 
 
-def test_pool_attn_online_softmax_rescale(ops):
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16x3", 1e-4)])
+def test_pool_attn_online_softmax_rescale(ops, precision, tol):
     """Force the running max to jump late in the key stream (rule: a rare branch needs its own test)."""
     B, N, C, H = 1, 1024, 128, 8
     rs = _rs(9)
@@ -129,11 +131,12 @@ def test_pool_attn_online_softmax_rescale(ops):
     v = KV[..., C:].reshape(B, N, H, hd).permute(0, 2, 1, 3)
     a = torch.softmax(ind @ k.transpose(-1, -2) / math.sqrt(hd), -1)
     ref = (a @ v).permute(0, 2, 1, 3).reshape(B, 64, C)
-    _close(ops.pool_attn(KV.cuda(), ind.cuda(), H), ref)
+    _close(ops.pool_attn(KV.cuda(), ind.cuda(), H, precision=precision), ref, tol)
 
 
-@pytest.mark.parametrize("B,N,C,H", [(2, 256, 128, 8), (2, 1000, 384, 8), (1, 50, 64, 8), (2, 640, 512, 8)])
-def test_unpool_attn(ops, B, N, C, H):
+@pytest.mark.parametrize("B,N,C,H", [(2, 256, 128, 8), (2, 1000, 384, 8), (1, 50, 64, 8), (2, 640, 512, 8), (2, 300, 256, 8)])
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16x3", 1e-4)])
+def test_unpool_attn(ops, B, N, C, H, precision, tol):
     rs = _rs(N + C + 1)
     y, h = _t(rs.randn(B, N, C)), _t(rs.randn(B, 64, C))
     p = {"in_proj_weight": _t(rs.randn(3 * C, C) / math.sqrt(C) * 1.5), "in_proj_bias": _t(rs.randn(3 * C) * .1),
@@ -141,7 +144,7 @@ def test_unpool_attn(ops, B, N, C, H):
     ref = cpu_ref.mha_unpool(y, h, p, "", H)
     q = F.linear(y, p["in_proj_weight"][:C], p["in_proj_bias"][:C])
     kvh = F.linear(h, p["in_proj_weight"][C:], p["in_proj_bias"][C:])
-    _close(ops.unpool_attn(q.cuda(), kvh.cuda(), H), ref)
+    _close(ops.unpool_attn(q.cuda(), kvh.cuda(), H, precision=precision), ref, tol)
 
 
 @pytest.mark.parametrize("B,N,C", [(3, 200, 128), (2, 2048, 384)])

@@ -83,7 +83,7 @@ STWorkspace carve_st(const GeccoSetTransformer* st, int B, int N, void* base) {
     w.h = c.f32(B * I * C);
     w.kvh = c.f32(B * I * 2 * C);
     {   // tiled bf16 hi | lo image of the weight in use: output rows padded to the 128-column GEMM tile
-        const size_t wmax = 2 * C > W ? 2 * C : W;
+        const size_t wmax = 3 * C + 128 > W ? 3 * C + 128 : W;   // kv_proj | q_proj share one image
         w.wsplit = c.f32(((wmax + 127) / 128 * 128) * (size_t)(W > C ? W : C));
     }
     w.bytes = (c.off + 255) & ~size_t(255);
@@ -95,7 +95,7 @@ STWorkspace carve_st(const GeccoSetTransformer* st, int B, int N, void* base) {
 int linear(const float* A, const float* W, const float* bias, const float* pa, const float* po, const float* alpha,
            const float* res, float* C, float* stats, int B, int rows, int K, int Nout, int act, hipStream_t s,
            int precision = 0, float* wsplit = nullptr) {
-    GemmArgs g;
+    GemmArgs g{};
     g.A = A; g.W = W; g.bias = bias; g.pro_a = pa; g.pro_o = po; g.alpha = alpha; g.residual = res; g.C = C;
     g.stats = stats; g.B = B; g.rows = rows; g.K = K; g.Nout = Nout;
     g.lda = K; g.ldw = K; g.ldc = Nout; g.ldr = Nout; g.act = act;
@@ -107,6 +107,28 @@ int linear(const float* A, const float* W, const float* bias, const float* pa, c
         g.precision = 1; g.w_img = wsplit;
     }
     return gemm_f32_launch(g, s);
+}
+
+// Two linears over the same (AdaGN-modulated) A in one launch: C1 = A' W1^T + b1 (Nout1 columns), C2 = A' W2^T + b2.
+// Returns 1 when the fused form does not apply (caller issues the two linears), 0 on success, <0 on error.
+int linear_pair(const float* A, const float* W1, const float* b1, int Nout1, float* C1, const float* W2,
+                const float* b2, int Nout2, float* C2, const float* pa, const float* po, int B, int rows, int K,
+                hipStream_t s, int precision, float* wsplit) {
+    GemmArgs g{};
+    g.A = A; g.W = W1; g.bias = b1; g.pro_a = pa; g.pro_o = po; g.C = C1;
+    g.B = B; g.rows = rows; g.K = K; g.Nout = Nout1 + Nout2;
+    g.lda = K; g.ldw = K; g.ldc = Nout1; g.ldr = Nout1;
+    g.C2 = C2; g.W2 = W2; g.bias2 = b2; g.n_split = Nout1; g.ldc2 = Nout2;
+    if (!gemm_f32_dma_supported(g)) return 1;
+    if (precision == 1) {
+        if (!wsplit) return 1;
+        int rc = split_bf16_tiled_launch(W1, wsplit, Nout1, K, K, s);
+        if (rc) return rc;
+        rc = split_bf16_tiled_launch(W2, wsplit + split_bf16_image_bytes(Nout1, K) / sizeof(float), Nout2, K, K, s);
+        if (rc) return rc;
+        g.precision = 1; g.w_img = wsplit;
+    }
+    return gemm_f32_dma_launch(g, s);
 }
 
 int coeffs(const float* stats, int T, int rows, const float* t, int ctx, const GeccoAdaGN* p, float* a, float* o,
@@ -140,10 +162,17 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         // y = AdaGN(x) is never materialised: (a1, o1) ride in the prologue of the two GEMMs that read x
         TRY(coeffs(sx, sT, N, t, ctx, &L.broadcast_norm, w.a1, w.o1, B, C, G, s), "adagn_coeffs(broadcast_norm)");
         const float* h = h_in ? h_in[li] : nullptr;
+        bool q_done = false;
         if (!h) {
             // pool: KV projection, 64 inducer queries over the N points, out_proj
-            TRY(linear(x, L.kv_proj_w, nullptr, w.a1, w.o1, nullptr, nullptr, w.big, nullptr, B, N, C, 2 * C, 0, s, pr,
-                       w.wsplit), "kv_proj");
+            // kv_proj and the unpool's q projection read the same AdaGN(x): one launch, x read once
+            int fused = linear_pair(x, L.kv_proj_w, nullptr, 2 * C, w.big, L.in_proj_w, L.in_proj_b, C, w.q, w.a1, w.o1, B,
+                                    N, C, s, pr, w.wsplit);
+            if (fused < 0) TRY(fused, "kv_proj|q_proj");
+            q_done = fused == 0;
+            if (!q_done)
+                TRY(linear(x, L.kv_proj_w, nullptr, w.a1, w.o1, nullptr, nullptr, w.big, nullptr, B, N, C, 2 * C, 0, s, pr,
+                           w.wsplit), "kv_proj");
             TRY(pool_attn_launch(w.big, L.inducers, w.part_o, w.part_ml, w.merged, B, N, C, H, I, ns, s, pr), "pool_attn");
             TRY(linear(w.merged, L.pool_out_w, nullptr, nullptr, nullptr, nullptr, nullptr, w.h0, w.stats_s, B, I, C, C,
                        0, s), "pool.out_proj");
@@ -161,8 +190,9 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         // unpool: k|v of the 64 inducer states, q of the N points, attention, out_proj + residual
         TRY(linear(h, L.in_proj_w + (size_t)C * C, L.in_proj_b + C, nullptr, nullptr, nullptr, nullptr, w.kvh, nullptr,
                    B, I, C, 2 * C, 0, s), "unpool.in_proj(kv)");
-        TRY(linear(x, L.in_proj_w, L.in_proj_b, w.a1, w.o1, nullptr, nullptr, w.q, nullptr, B, N, C, C, 0, s, pr, w.wsplit),
-            "unpool.in_proj(q)");
+        if (!q_done)
+            TRY(linear(x, L.in_proj_w, L.in_proj_b, w.a1, w.o1, nullptr, nullptr, w.q, nullptr, B, N, C, C, 0, s, pr,
+                       w.wsplit), "unpool.in_proj(q)");
         TRY(unpool_attn_launch(w.q, w.kvh, w.attn, B, N, C, H, I, s, pr), "unpool_attn");
         TRY(linear(w.attn, L.unpool_out_w, L.unpool_out_b, nullptr, nullptr, nullptr, x, x, w.stats_x, B, N, C, C, 0, s, pr,
                    w.wsplit), "unpool.out_proj+residual");

@@ -378,6 +378,7 @@ int gemm_f32_launch(const GemmArgs& g, hipStream_t st) {
         }
         if (use_dma && gemm_f32_dma_supported(g)) return gemm_f32_dma_launch(g, st);
     }
+    if (g.C2) return -8;   // the two-segment form exists on the LDS-DMA kernel only (callers check dma_supported)
     const bool pro = g.pro_a != nullptr;
     // 128x128x16: 41 KB LDS and <= 256 VGPR -> two persistent blocks per CU (BK = 32 would spill once the next
     // tile's prefetch registers are live across the epilogue)

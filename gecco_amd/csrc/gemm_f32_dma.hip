@@ -73,6 +73,15 @@ __global__ __launch_bounds__(DNT, DNS <= 3 ? 3 : 2) void gemm_dma_kernel(GemmArg
     const int ct = v % tilesN, panel = v / tilesN;
     const int rt = panel % tilesM, b = panel / tilesM;
     const int m0 = rt * DBM, n0 = ct * DBN;
+    // optional second output segment (two linears over the same A in one launch): whole column tiles belong to one
+    // segment (n_split % 128 == 0); from here on columns are relative to the segment
+    const bool seg2 = g.C2 != nullptr && n0 >= g.n_split;
+    const int nseg0 = seg2 ? n0 - g.n_split : n0;                       // first column of the tile inside its segment
+    const int nseg = g.C2 ? (seg2 ? g.Nout - g.n_split : g.n_split) : g.Nout;   // columns of the segment
+    const float* Wseg = seg2 ? g.W2 : g.W;
+    const float* bias_seg = seg2 ? g.bias2 : g.bias;
+    float* Cseg = seg2 ? g.C2 : g.C;
+    const int ldc_seg = seg2 ? g.ldc2 : g.ldc;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -96,7 +105,7 @@ __global__ __launch_bounds__(DNT, DNS <= 3 ? 3 : 2) void gemm_dma_kernel(GemmArg
         const int row = (2 * wave + q) * 16 + (lane >> 2);
         const int c = (lane & 3) ^ ((row >> 2) & 3);
         asrc[q] = Ab + (size_t)min(m0 + row, g.rows - 1) * g.lda + c * 4;
-        if (!X3) bsrc[q] = g.W + (size_t)min(n0 + row, g.Nout - 1) * g.ldw + c * 4;
+        if (!X3) bsrc[q] = Wseg + (size_t)min(nseg0 + row, nseg - 1) * g.ldw + c * 4;
     }
     const int nk = g.K / DBK;
     if (X3) {
@@ -289,7 +298,7 @@ __global__ __launch_bounds__(DNT, DNS <= 3 ? 3 : 2) void gemm_dma_kernel(GemmArg
     // ---------------------------------------------------------------- epilogue (wide: through an LDS transpose)
     const bool has_act = g.act != 0, act_norm = g.act == 1;
     const float neg_inv_2a2 = has_act ? -1.0f / (2.0f * g.alpha[0] * g.alpha[0]) : 0.f;
-    float* Cb = g.C + (size_t)b * g.rows * g.ldc;
+    float* Cb = Cseg + (size_t)b * g.rows * ldc_seg;
     const float* Rb = g.residual ? g.residual + (size_t)b * g.rows * g.ldr : nullptr;
     float* Tt = smem + wave * 32 * D_TP;
     float* red = smem + 4 * 32 * D_TP;
@@ -306,11 +315,11 @@ __global__ __launch_bounds__(DNT, DNS <= 3 ? 3 : 2) void gemm_dma_kernel(GemmArg
     for (int i = 0; i < TMW; ++i) {
 #pragma unroll
         for (int jh = 0; jh < NJH; ++jh) {
-            const int ncol0 = n0 + (wn * TNW + 2 * jh) * 32;
+            const int ncol0 = nseg0 + (wn * TNW + 2 * jh) * 32;
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const int nn = ncol0 + jj * 32 + r;
-                const float bias = g.bias ? g.bias[nn < g.Nout ? nn : g.Nout - 1] : 0.f;
+                const float bias = bias_seg ? bias_seg[nn < nseg ? nn : nseg - 1] : 0.f;
                 f32x16 val = acc[i][2 * jh + jj];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) val[e] += bias;
@@ -323,7 +332,7 @@ __global__ __launch_bounds__(DNT, DNS <= 3 ? 3 : 2) void gemm_dma_kernel(GemmArg
             }
             __syncthreads();
             const int n = ncol0 + c4 * 4;
-            const bool nok = n < g.Nout;
+            const bool nok = n < nseg;
             const int nc = nok ? n : 0;
             const int mrow0 = m0 + (wm * TMW + i) * 32;
 #pragma unroll
@@ -343,7 +352,7 @@ __global__ __launch_bounds__(DNT, DNS <= 3 ? 3 : 2) void gemm_dma_kernel(GemmArg
                     f32x4 v4 = *reinterpret_cast<const f32x4*>(Tt + (it * 4 + lr) * D_TP + c4 * 4);
                     if (Rb) v4 += rres[c];
                     const bool ok = nok && m < g.rows;
-                    if (ok) __builtin_nontemporal_store(v4, reinterpret_cast<f32x4*>(Cb + (size_t)m * g.ldc + n));
+                    if (ok) __builtin_nontemporal_store(v4, reinterpret_cast<f32x4*>(Cb + (size_t)m * ldc_seg + n));
                     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
                     const f32x4 vz = ok ? v4 : z;
                     s1[jh] += vz;
@@ -425,6 +434,8 @@ int dma_launch_t(const GemmArgs& g, hipStream_t st) {
 }  // namespace
 
 bool gemm_f32_dma_supported(const GemmArgs& g) {
+    if (g.C2 && ((g.n_split % DBN) || g.stats || g.residual || (g.ldc2 & 3) || g.n_split <= 0 || g.n_split >= g.Nout))
+        return false;
     return g.rows >= 128 && g.K % DBK == 0 && g.K <= 1024 && !(g.Nout & 3) && !(g.ldc & 3) && !(g.ldr & 3) &&
            !(g.lda & 3) && !(g.ldw & 7);
 }

@@ -18,6 +18,12 @@ struct GemmArgs {
     int act;                // 0 none, 1 gaussian normalized, 2 gaussian raw
     int precision;          // 0 exact fp32 MFMA, 1 split-bf16 (needs w_img)
     const void* w_img;      // tiled bf16 hi | lo image of W (split_bf16_tiled_launch)
+    // optional second output segment, LDS-DMA kernel only: columns [n_split, Nout) are a second linear over the same
+    // A (weights W2 (Nout - n_split, ldw), bias2) written to C2 (B, rows, ldc2); n_split % 128 == 0, no stats/residual
+    float* C2;
+    const float* W2;
+    const float* bias2;
+    int n_split, ldc2;
 };
 
 int gemm_row_tile(int rows);  // row-tile height the GEMM uses for `rows` rows per sample

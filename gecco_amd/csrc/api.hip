@@ -50,7 +50,9 @@ struct STWorkspace {
     float *a1, *o1, *a2, *o2, *as, *os;  // AdaGN coefficients (B,C)
     float *part_o, *part_ml;           // pool partials
     float *merged, *h0, *u, *h2, *h, *kvh;  // inducer chain (B,I,*)
-    float* wsplit;                     // bf16 hi | lo planes of the weight in use (split-bf16 mode)
+    float* wsplit;                     // tiled bf16 hi | lo image of the weight in use (unit calls, split-bf16 mode)
+    float* wimg;                       // images of every layer's N-token weights, built once per forward
+    size_t wimg_layer, o_q, o_out, o_w0, o_w2;   // floats per layer and the per-weight offsets inside (kv at 0)
     size_t bytes;
 };
 
@@ -86,6 +88,15 @@ STWorkspace carve_st(const GeccoSetTransformer* st, int B, int N, void* base) {
         const size_t wmax = 3 * C + 128 > W ? 3 * C + 128 : W;   // kv_proj | q_proj share one image
         w.wsplit = c.f32(((wmax + 127) / 128 * 128) * (size_t)(W > C ? W : C));
     }
+    {   // per layer: kv_proj | q_proj (contiguous: the fused pair streams them as one image), out_proj, mlp.0, mlp.2
+        auto pad = [](size_t n) { return (n + 127) / 128 * 128; };
+        w.o_q = pad(2 * C) * C;
+        w.o_out = w.o_q + pad(C) * C;
+        w.o_w0 = w.o_out + pad(C) * C;
+        w.o_w2 = w.o_w0 + pad(W) * C;
+        w.wimg_layer = w.o_w2 + pad(C) * W;
+        w.wimg = st->precision == 1 ? c.f32(w.wimg_layer * st->n_layers) : nullptr;
+    }
     w.bytes = (c.off + 255) & ~size_t(255);
     return w;
 }
@@ -94,17 +105,22 @@ STWorkspace carve_st(const GeccoSetTransformer* st, int B, int N, void* base) {
 // hi | lo image of W first (a ~3 us pass over <= 1.2 MB: weights may change between calls, nothing is cached).
 int linear(const float* A, const float* W, const float* bias, const float* pa, const float* po, const float* alpha,
            const float* res, float* C, float* stats, int B, int rows, int K, int Nout, int act, hipStream_t s,
-           int precision = 0, float* wsplit = nullptr) {
+           int precision = 0, float* wsplit = nullptr, const float* img_ready = nullptr) {
     GemmArgs g{};
     g.A = A; g.W = W; g.bias = bias; g.pro_a = pa; g.pro_o = po; g.alpha = alpha; g.residual = res; g.C = C;
     g.stats = stats; g.B = B; g.rows = rows; g.K = K; g.Nout = Nout;
     g.lda = K; g.ldw = K; g.ldc = Nout; g.ldr = Nout; g.act = act;
     g.precision = 0; g.w_img = nullptr;
     if (act && !alpha) return -6;
-    if (precision == 1 && wsplit && gemm_f32_dma_supported(g)) {
-        int rc = split_bf16_tiled_launch(W, wsplit, Nout, K, g.ldw, s);
-        if (rc) return rc;
-        g.precision = 1; g.w_img = wsplit;
+    if (precision == 1 && (wsplit || img_ready) && gemm_f32_dma_supported(g)) {
+        if (img_ready) {
+            g.w_img = img_ready;   // already split this forward
+        } else {
+            int rc = split_bf16_tiled_launch(W, wsplit, Nout, K, g.ldw, s);
+            if (rc) return rc;
+            g.w_img = wsplit;
+        }
+        g.precision = 1;
     }
     return gemm_f32_launch(g, s);
 }
@@ -113,7 +129,7 @@ int linear(const float* A, const float* W, const float* bias, const float* pa, c
 // Returns 1 when the fused form does not apply (caller issues the two linears), 0 on success, <0 on error.
 int linear_pair(const float* A, const float* W1, const float* b1, int Nout1, float* C1, const float* W2,
                 const float* b2, int Nout2, float* C2, const float* pa, const float* po, int B, int rows, int K,
-                hipStream_t s, int precision, float* wsplit) {
+                hipStream_t s, int precision, float* wsplit, const float* img_ready = nullptr) {
     GemmArgs g{};
     g.A = A; g.W = W1; g.bias = b1; g.pro_a = pa; g.pro_o = po; g.C = C1;
     g.B = B; g.rows = rows; g.K = K; g.Nout = Nout1 + Nout2;
@@ -121,12 +137,17 @@ int linear_pair(const float* A, const float* W1, const float* b1, int Nout1, flo
     g.C2 = C2; g.W2 = W2; g.bias2 = b2; g.n_split = Nout1; g.ldc2 = Nout2;
     if (!gemm_f32_dma_supported(g)) return 1;
     if (precision == 1) {
-        if (!wsplit) return 1;
-        int rc = split_bf16_tiled_launch(W1, wsplit, Nout1, K, K, s);
-        if (rc) return rc;
-        rc = split_bf16_tiled_launch(W2, wsplit + split_bf16_image_bytes(Nout1, K) / sizeof(float), Nout2, K, K, s);
-        if (rc) return rc;
-        g.precision = 1; g.w_img = wsplit;
+        if (img_ready) {
+            g.w_img = img_ready;
+        } else {
+            if (!wsplit) return 1;
+            int rc = split_bf16_tiled_launch(W1, wsplit, Nout1, K, K, s);
+            if (rc) return rc;
+            rc = split_bf16_tiled_launch(W2, wsplit + split_bf16_image_bytes(Nout1, K) / sizeof(float), Nout2, K, K, s);
+            if (rc) return rc;
+            g.w_img = wsplit;
+        }
+        g.precision = 1;
     }
     return gemm_f32_dma_launch(g, s);
 }
@@ -157,8 +178,35 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         sx = w.stats_x;
         sT = row_tiles_stats(N);
     }
+    if (pr == 1 && w.wimg && !(C % 16) && !(Wd % 16)) {
+        // split-bf16 mode: every N-token weight of every layer becomes its tiled hi | lo image in ONE launch per
+        // 6 layers (weights may change between calls; nothing is cached across forwards)
+        SplitJobs jobs;
+        jobs.n = 0;
+        auto push = [&](const float* Wp, float* img, int Nout, int K) -> int {
+            jobs.job[jobs.n++] = SplitJob{Wp, img, Nout, K, K, 0};
+            if (jobs.n == 32) {
+                int rc = split_bf16_tiled_multi_launch(jobs, s);
+                jobs.n = 0;
+                return rc;
+            }
+            return 0;
+        };
+        for (int li = 0; li < st->n_layers; ++li) {
+            const GeccoLayer& L = st->layers[li];
+            float* base = w.wimg + (size_t)li * w.wimg_layer;
+            if (!(h_in && h_in[li])) TRY(push(L.kv_proj_w, base, 2 * C, C), "split(kv_proj)");
+            TRY(push(L.in_proj_w, base + w.o_q, C, C), "split(q_proj)");
+            TRY(push(L.unpool_out_w, base + w.o_out, C, C), "split(out_proj)");
+            TRY(push(L.mlp.w0, base + w.o_w0, Wd, C), "split(mlp.0)");
+            TRY(push(L.mlp.w2, base + w.o_w2, C, Wd), "split(mlp.2)");
+        }
+        TRY(split_bf16_tiled_multi_launch(jobs, s), "split(weights)");
+    }
+    const bool imgs = pr == 1 && w.wimg && !(C % 16) && !(Wd % 16);
     for (int li = 0; li < st->n_layers; ++li) {
         const GeccoLayer& L = st->layers[li];
+        const float* im = imgs ? w.wimg + (size_t)li * w.wimg_layer : nullptr;
         // y = AdaGN(x) is never materialised: (a1, o1) ride in the prologue of the two GEMMs that read x
         TRY(coeffs(sx, sT, N, t, ctx, &L.broadcast_norm, w.a1, w.o1, B, C, G, s), "adagn_coeffs(broadcast_norm)");
         const float* h = h_in ? h_in[li] : nullptr;
@@ -167,12 +215,12 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
             // pool: KV projection, 64 inducer queries over the N points, out_proj
             // kv_proj and the unpool's q projection read the same AdaGN(x): one launch, x read once
             int fused = linear_pair(x, L.kv_proj_w, nullptr, 2 * C, w.big, L.in_proj_w, L.in_proj_b, C, w.q, w.a1, w.o1, B,
-                                    N, C, s, pr, w.wsplit);
+                                    N, C, s, pr, w.wsplit, (2 * C) % 128 == 0 ? im : nullptr);
             if (fused < 0) TRY(fused, "kv_proj|q_proj");
             q_done = fused == 0;
             if (!q_done)
                 TRY(linear(x, L.kv_proj_w, nullptr, w.a1, w.o1, nullptr, nullptr, w.big, nullptr, B, N, C, 2 * C, 0, s, pr,
-                           w.wsplit), "kv_proj");
+                           w.wsplit, im), "kv_proj");
             TRY(pool_attn_launch(w.big, L.inducers, w.part_o, w.part_ml, w.merged, B, N, C, H, I, ns, s, pr), "pool_attn");
             TRY(linear(w.merged, L.pool_out_w, nullptr, nullptr, nullptr, nullptr, nullptr, w.h0, w.stats_s, B, I, C, C,
                        0, s), "pool.out_proj");
@@ -192,17 +240,17 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
                    B, I, C, 2 * C, 0, s), "unpool.in_proj(kv)");
         if (!q_done)
             TRY(linear(x, L.in_proj_w, L.in_proj_b, w.a1, w.o1, nullptr, nullptr, w.q, nullptr, B, N, C, C, 0, s, pr,
-                       w.wsplit), "unpool.in_proj(q)");
+                       w.wsplit, im ? im + w.o_q : nullptr), "unpool.in_proj(q)");
         TRY(unpool_attn_launch(w.q, w.kvh, w.attn, B, N, C, H, I, s, pr), "unpool_attn");
         TRY(linear(w.attn, L.unpool_out_w, L.unpool_out_b, nullptr, nullptr, nullptr, x, x, w.stats_x, B, N, C, C, 0, s, pr,
-                   w.wsplit), "unpool.out_proj+residual");
+                   w.wsplit, im ? im + w.o_out : nullptr), "unpool.out_proj+residual");
         // x += mlp(AdaGN(x))
         TRY(coeffs(w.stats_x, Tn, N, t, ctx, &L.mlp_norm, w.a2, w.o2, B, C, G, s), "adagn_coeffs(mlp_norm)");
-        TRY(linear(x, L.mlp.w0, L.mlp.b0, w.a2, w.o2, L.mlp.alpha, nullptr, w.big, nullptr, B, N, C, Wd, act, s, pr, w.wsplit),
-            "mlp.0");
+        TRY(linear(x, L.mlp.w0, L.mlp.b0, w.a2, w.o2, L.mlp.alpha, nullptr, w.big, nullptr, B, N, C, Wd, act, s, pr, w.wsplit,
+                   im ? im + w.o_w0 : nullptr), "mlp.0");
         float* so = (li + 1 < st->n_layers) ? w.stats_x : stats_out;
-        TRY(linear(w.big, L.mlp.w2, L.mlp.b2, nullptr, nullptr, nullptr, x, x, so, B, N, Wd, C, 0, s, pr, w.wsplit),
-            "mlp.2+residual");
+        TRY(linear(w.big, L.mlp.w2, L.mlp.b2, nullptr, nullptr, nullptr, x, x, so, B, N, Wd, C, 0, s, pr, w.wsplit,
+                   im ? im + w.o_w2 : nullptr), "mlp.2+residual");
         sx = w.stats_x;
         sT = Tn;
     }

@@ -450,6 +450,36 @@ int gemm_f32_dma_launch(const GemmArgs& g, hipStream_t st) {
     return ns3 ? dma_launch_t<3, false>(g, st) : dma_launch_t<4, false>(g, st);
 }
 
+namespace {
+
+// several weights in one launch (blockIdx.y = job): the per-forward weight pass of the set transformer
+__global__ void split_bf16_tiled_multi_kernel(SplitJobs jobs) {
+    const SplitJob j = jobs.job[blockIdx.y];
+    const int nk = j.K / DBK;
+    const size_t total = (size_t)((j.Nout + DBN - 1) / DBN) * nk * 256;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i & 1), rb = (int)((i >> 1) & 127);
+        const size_t blk = i >> 8;
+        const int kt = (int)(blk % nk), ct = (int)(blk / nk);
+        const int c = ch ^ ((rb >> 3) & 1);
+        const float* src = j.W + (size_t)min(ct * DBN + rb, j.Nout - 1) * j.ldw + kt * DBK + c * 8;
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(src), x1 = *reinterpret_cast<const f32x4*>(src + 4);
+        bf16x8 hi, lo;
+        split8(x0, x1, hi, lo);
+        float* dst = j.img + blk * D_TILE + rb * 8 + ch * 4;
+        *reinterpret_cast<u32x4*>(dst) = __builtin_bit_cast(u32x4, hi);
+        *reinterpret_cast<u32x4*>(dst + 1024) = __builtin_bit_cast(u32x4, lo);
+    }
+}
+
+}  // namespace
+
+int split_bf16_tiled_multi_launch(const SplitJobs& jobs, hipStream_t st) {
+    if (jobs.n <= 0) return 0;
+    hipLaunchKernelGGL(split_bf16_tiled_multi_kernel, dim3(64, jobs.n), dim3(256), 0, st, jobs);
+    return (int)hipGetLastError();
+}
+
 size_t split_bf16_image_bytes(int Nout, int K) { return (size_t)((Nout + DBN - 1) / DBN) * DBN * K * sizeof(float); }
 
 int split_bf16_tiled_launch(const float* W, void* img, int Nout, int K, int ldw, hipStream_t st) {

@@ -33,6 +33,9 @@ bool gemm_f32_dma_supported(const GemmArgs& g);
 int gemm_f32_dma_launch(const GemmArgs& g, hipStream_t st);
 size_t split_bf16_image_bytes(int Nout, int K);   // ceil(Nout / 128) * 128 * K * 4
 int split_bf16_tiled_launch(const float* W, void* img, int Nout, int K, int ldw, hipStream_t st);
+struct SplitJob { const float* W; float* img; int Nout, K, ldw, pad_; };
+struct SplitJobs { SplitJob job[32]; int n; };
+int split_bf16_tiled_multi_launch(const SplitJobs& jobs, hipStream_t st);   // K % 16 == 0, ldw % 4 == 0 per job
 
 // gemm_general_f32.hip — C[z] = scale * op(A[z]) op(B[z]) (+ bias), per-operand layout flag, two-level batch strides
 struct GemmGeneralArgs {

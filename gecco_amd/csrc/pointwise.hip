@@ -197,6 +197,85 @@ __global__ __launch_bounds__(256) void lower_edm_kernel(const float* __restrict_
     }
 }
 
+// Same contract, 16 lanes per point (4 points per wave): the row sits in registers as CPL f32x4 chunks per lane, so
+// it is read once with 16-byte loads and the LayerNorm mean / variance / projection passes never touch memory again.
+template <int CPL>
+__global__ __launch_bounds__(256) void lower_edm_v4_kernel(const float* __restrict__ feat, const float* __restrict__ x,
+                                                           const float* __restrict__ coef, const float* __restrict__ W,
+                                                           const float* __restrict__ bias,
+                                                           const float* __restrict__ gn_a,
+                                                           const float* __restrict__ gn_o, float* __restrict__ out,
+                                                           float* __restrict__ raw, int B, int N, int C, float eps) {
+    const int sub = threadIdx.x & 15;
+    const size_t rows = (size_t)B * N;
+    const size_t row_raw = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool live = row_raw < rows;
+    const size_t row = live ? row_raw : rows - 1;   // idle groups shadow the last row: the shuffles stay full-width
+    const int b = (int)(row / N);
+    const int nch = C >> 2;
+    auto gsum = [](float v) {
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 1, 64);
+        return v;
+    };
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 v[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int ch = sub + 16 * i;
+        v[i] = ch < nch ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(feat + row * C) + ch) : z;
+    }
+    if (gn_a) {
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int ch = sub + 16 * i;
+            if (ch < nch)
+                v[i] = v[i] * reinterpret_cast<const f32x4*>(gn_a + (size_t)b * C)[ch] +
+                       reinterpret_cast<const f32x4*>(gn_o + (size_t)b * C)[ch];
+        }
+    } else {
+        float s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) s1 += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        const float mean = gsum(s1) / C;
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int ch = sub + 16 * i;
+            const f32x4 d = ch < nch ? v[i] - mean : z;
+            v[i] = d;
+            s2 += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+        const float rstd = rsqrtf(gsum(s2) / C + eps);
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) v[i] = v[i] * rstd;
+    }
+    float a[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int ch = sub + 16 * i;
+        if (ch < nch) {
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                const f32x4 w = reinterpret_cast<const f32x4*>(W + (size_t)o * C)[ch];
+                a[o] += (v[i][0] * w[0] + v[i][1] * w[1]) + (v[i][2] * w[2] + v[i][3] * w[3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 3; ++o) a[o] = gsum(a[o]);
+    if (live && sub < 3) {
+        const float Fv = (sub == 0 ? a[0] : sub == 1 ? a[1] : a[2]) + bias[sub];
+        if (raw) raw[row * 3 + sub] = Fv;
+        if (out) {
+            const float cs = coef ? coef[4 * b + 0] : 0.f, co = coef ? coef[4 * b + 1] : 1.f;
+            out[row * 3 + sub] = coef ? cs * x[row * 3 + sub] + co * Fv : Fv;
+        }
+    }
+}
+
 }  // namespace
 
 int stats_row_tile(int rows) { (void)rows; return STATS_ROWS; }
@@ -243,7 +322,26 @@ int lower_edm_launch(const float* feat, const float* x, const float* coef, const
                      const float* gn_a, const float* gn_o, float* out, float* raw, int B, int N, int C, float eps,
                      hipStream_t st) {
     const size_t rows = (size_t)B * N;
-    hipLaunchKernelGGL(lower_edm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, feat, x, coef, W, bias,
-                       gn_a, gn_o, out, raw, B, N, C, eps);
+    const int cpl = (C / 4 + 15) / 16;
+    const dim3 g16((unsigned)((rows + 15) / 16));
+#define LOWER_V4(CPL)                                                                                              \
+    hipLaunchKernelGGL((lower_edm_v4_kernel<CPL>), g16, dim3(256), 0, st, feat, x, coef, W, bias, gn_a, gn_o, out, raw, \
+                       B, N, C, eps)
+    if (C % 4 == 0 && cpl <= 8 && rows > 0) {
+        switch (cpl) {
+            case 1: LOWER_V4(1); break;
+            case 2: LOWER_V4(2); break;
+            case 3: LOWER_V4(3); break;
+            case 4: LOWER_V4(4); break;
+            case 5: LOWER_V4(5); break;
+            case 6: LOWER_V4(6); break;
+            case 7: LOWER_V4(7); break;
+            default: LOWER_V4(8); break;
+        }
+    } else {
+        hipLaunchKernelGGL(lower_edm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, feat, x, coef, W, bias,
+                           gn_a, gn_o, out, raw, B, N, C, eps);
+    }
+#undef LOWER_V4
     return (int)hipGetLastError();
 }

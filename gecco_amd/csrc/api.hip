@@ -53,6 +53,7 @@ struct STWorkspace {
     float* wsplit;                     // tiled bf16 hi | lo image of the weight in use (unit calls, split-bf16 mode)
     float* wimg;                       // images of every layer's N-token weights, built once per forward
     size_t wimg_layer, o_q, o_out, o_w0, o_w2;   // floats per layer and the per-weight offsets inside (kv at 0)
+    size_t o_pout, o_b0, o_b2, o_ukv;            // the 64-inducer chain: pool.out_proj, broadcast mlp, unpool k|v
     size_t bytes;
 };
 
@@ -94,7 +95,11 @@ STWorkspace carve_st(const GeccoSetTransformer* st, int B, int N, void* base) {
         w.o_out = w.o_q + pad(C) * C;
         w.o_w0 = w.o_out + pad(C) * C;
         w.o_w2 = w.o_w0 + pad(W) * C;
-        w.wimg_layer = w.o_w2 + pad(C) * W;
+        w.o_pout = w.o_w2 + pad(C) * W;
+        w.o_b0 = w.o_pout + pad(C) * C;
+        w.o_b2 = w.o_b0 + pad(W) * C;
+        w.o_ukv = w.o_b2 + pad(C) * W;
+        w.wimg_layer = w.o_ukv + pad(2 * C) * C;
         w.wimg = st->precision == 1 ? c.f32(w.wimg_layer * st->n_layers) : nullptr;
     }
     w.bytes = (c.off + 255) & ~size_t(255);
@@ -112,7 +117,7 @@ int linear(const float* A, const float* W, const float* bias, const float* pa, c
     g.lda = K; g.ldw = K; g.ldc = Nout; g.ldr = Nout; g.act = act;
     g.precision = 0; g.w_img = nullptr;
     if (act && !alpha) return -6;
-    if (precision == 1 && (wsplit || img_ready) && gemm_f32_dma_supported(g)) {
+    if (precision == 1 && (wsplit || img_ready) && gemm_f32_dma_supported(g, 1)) {
         if (img_ready) {
             g.w_img = img_ready;   // already split this forward
         } else {
@@ -195,7 +200,13 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         for (int li = 0; li < st->n_layers; ++li) {
             const GeccoLayer& L = st->layers[li];
             float* base = w.wimg + (size_t)li * w.wimg_layer;
-            if (!(h_in && h_in[li])) TRY(push(L.kv_proj_w, base, 2 * C, C), "split(kv_proj)");
+            if (!(h_in && h_in[li])) {
+                TRY(push(L.kv_proj_w, base, 2 * C, C), "split(kv_proj)");
+                TRY(push(L.pool_out_w, base + w.o_pout, C, C), "split(pool.out_proj)");
+                TRY(push(L.bmlp.w0, base + w.o_b0, Wd, C), "split(broadcast.mlp.0)");
+                TRY(push(L.bmlp.w2, base + w.o_b2, C, Wd), "split(broadcast.mlp.2)");
+            }
+            TRY(push(L.in_proj_w + (size_t)C * C, base + w.o_ukv, 2 * C, C), "split(unpool.in_proj kv)");
             TRY(push(L.in_proj_w, base + w.o_q, C, C), "split(q_proj)");
             TRY(push(L.unpool_out_w, base + w.o_out, C, C), "split(out_proj)");
             TRY(push(L.mlp.w0, base + w.o_w0, Wd, C), "split(mlp.0)");
@@ -223,13 +234,13 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
                            w.wsplit, im), "kv_proj");
             TRY(pool_attn_launch(w.big, L.inducers, w.part_o, w.part_ml, w.merged, B, N, C, H, I, ns, s, pr), "pool_attn");
             TRY(linear(w.merged, L.pool_out_w, nullptr, nullptr, nullptr, nullptr, nullptr, w.h0, w.stats_s, B, I, C, C,
-                       0, s), "pool.out_proj");
+                       0, s, pr, w.wsplit, im ? im + w.o_pout : nullptr), "pool.out_proj");
             // h = norm_2(mlp(norm_1(h0)))
             TRY(coeffs(w.stats_s, Ti, I, t, ctx, &L.norm_1, w.as, w.os, B, C, G, s), "adagn_coeffs(norm_1)");
-            TRY(linear(w.h0, L.bmlp.w0, L.bmlp.b0, w.as, w.os, L.bmlp.alpha, nullptr, w.u, nullptr, B, I, C, Wd, act, s),
-                "broadcast.mlp.0");
-            TRY(linear(w.u, L.bmlp.w2, L.bmlp.b2, nullptr, nullptr, nullptr, nullptr, w.h2, w.stats_s, B, I, Wd, C, 0, s),
-                "broadcast.mlp.2");
+            TRY(linear(w.h0, L.bmlp.w0, L.bmlp.b0, w.as, w.os, L.bmlp.alpha, nullptr, w.u, nullptr, B, I, C, Wd, act, s,
+                       pr, w.wsplit, im ? im + w.o_b0 : nullptr), "broadcast.mlp.0");
+            TRY(linear(w.u, L.bmlp.w2, L.bmlp.b2, nullptr, nullptr, nullptr, nullptr, w.h2, w.stats_s, B, I, Wd, C, 0, s,
+                       pr, w.wsplit, im ? im + w.o_b2 : nullptr), "broadcast.mlp.2");
             TRY(coeffs(w.stats_s, Ti, I, t, ctx, &L.norm_2, w.as, w.os, B, C, G, s), "adagn_coeffs(norm_2)");
             float* hdst = (h_out && h_out[li]) ? h_out[li] : w.h;
             TRY(affine_apply_launch(w.h2, w.as, w.os, hdst, B, I, C, s), "norm_2 apply");
@@ -237,7 +248,7 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         }
         // unpool: k|v of the 64 inducer states, q of the N points, attention, out_proj + residual
         TRY(linear(h, L.in_proj_w + (size_t)C * C, L.in_proj_b + C, nullptr, nullptr, nullptr, nullptr, w.kvh, nullptr,
-                   B, I, C, 2 * C, 0, s), "unpool.in_proj(kv)");
+                   B, I, C, 2 * C, 0, s, pr, w.wsplit, im ? im + w.o_ukv : nullptr), "unpool.in_proj(kv)");
         if (!q_done)
             TRY(linear(x, L.in_proj_w, L.in_proj_b, w.a1, w.o1, nullptr, nullptr, w.q, nullptr, B, N, C, C, 0, s, pr,
                        w.wsplit, im ? im + w.o_q : nullptr), "unpool.in_proj(q)");

@@ -33,7 +33,7 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int DBM = 128, DBN = 128, DBK = 16, DNT = 256;
+constexpr int DBN = 128, DBK = 16, DNT = 256;   // row tile BM: template parameter (128, or 64 in bf16x3 mode)
 constexpr int D_TILE = 128 * DBK;                 // floats per operand tile per stage (8 KiB)
 constexpr int D_STAGE = 2 * D_TILE;               // A then B (fp32 W tile, or bf16 hi | lo planes: same 8 KiB)
 constexpr int D_TP = 64 + 4;                      // epilogue transpose tile row stride
@@ -62,17 +62,19 @@ __device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, bf16x8&
     for (int e = 0; e < 8; ++e) lo[e] = (__bf16)l[e];
 }
 
-template <int DNS, bool HAS_PRO, bool X3>
+// BM = 128 rows per block; BM = 64 (bf16x3 only) serves the 64-inducer GEMMs (rows per sample < 128)
+template <int DNS, bool HAS_PRO, bool X3, int BM = 128>
 __global__ __launch_bounds__(DNT, DNS <= 3 ? 3 : 2) void gemm_dma_kernel(GemmArgs g) {
+    static_assert(BM == 128 || (BM == 64 && X3), "64-row tiles exist in split-bf16 mode only");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* pro_lds = smem + d_main_floats(DNS);   // pa[0..K) | po[0..K)
 
-    const int tilesM = (g.rows + DBM - 1) / DBM, tilesN = (g.Nout + DBN - 1) / DBN;
+    const int tilesM = (g.rows + BM - 1) / BM, tilesN = (g.Nout + DBN - 1) / DBN;
     const int nblk = g.B * tilesM * tilesN;
     const int v = xcd_remap(blockIdx.x, nblk);
     const int ct = v % tilesN, panel = v / tilesN;
     const int rt = panel % tilesM, b = panel / tilesM;
-    const int m0 = rt * DBM, n0 = ct * DBN;
+    const int m0 = rt * BM, n0 = ct * DBN;
     // optional second output segment (two linears over the same A in one launch): whole column tiles belong to one
     // segment (n_split % 128 == 0); from here on columns are relative to the segment
     const bool seg2 = g.C2 != nullptr && n0 >= g.n_split;
@@ -88,8 +90,11 @@ __global__ __launch_bounds__(DNT, DNS <= 3 ? 3 : 2) void gemm_dma_kernel(GemmArg
     // wave layout: fp32 mode 2 x 2 waves of 64 x 64; bf16x3 mode 4 x 1 waves of 32 x 128 — the A fragment costs
     // ~28 VALU per 32-row tile per K-step to split into hi / lo, the (pre-split) B fragment nothing, so the
     // wave tile is made wide in N: half the split work per MFMA of the square layout.
-    constexpr int WMN = X3 ? 4 : 2, WNN = 4 / WMN;
-    constexpr int TMW = 4 / WMN, TNW = 4 / WNN;   // 32 x 32 MFMA tiles per wave in M / N
+    // (64-row tiles: 2 x 2 waves of 32 x 64)
+    constexpr int WMN = (X3 && BM == 128) ? 4 : 2, WNN = 4 / WMN;
+    constexpr int TMW = (BM / 32) / WMN, TNW = 4 / WNN;   // 32 x 32 MFMA tiles per wave in M / N
+    constexpr int NAP = BM / 64;                  // A pieces (16 rows x 64 B) per wave per K-step
+    constexpr int NPIECE = NAP + 2;               // DMA wave-instructions per wave per K-step
     const int wm = wave / WNN, wn = wave % WNN;
     const int r = lane & 31, h = lane >> 5;
 
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(DNT, DNS <= 3 ? 3 : 2) void gemm_dma_kernel(GemmArg
     const void* bsrc[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        const int row = (2 * wave + q) * 16 + (lane >> 2);
+        const int row = (NAP * wave + (q < NAP ? q : 0)) * 16 + (lane >> 2);
         const int c = (lane & 3) ^ ((row >> 2) & 3);
         asrc[q] = Ab + (size_t)min(m0 + row, g.rows - 1) * g.lda + c * 4;
         if (!X3) bsrc[q] = Wseg + (size_t)min(nseg0 + row, nseg - 1) * g.ldw + c * 4;
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(DNT, DNS <= 3 ? 3 : 2) void gemm_dma_kernel(GemmArg
 #endif
         float* st = smem + (kt % DNS) * D_STAGE;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) dma16(asrc[q] + kt * DBK, st + (2 * wave + q) * 256);
+        for (int q = 0; q < NAP; ++q) dma16(asrc[q] + kt * DBK, st + (NAP * wave + q) * 256);
         if (X3) {
             dma16(static_cast<const float*>(bsrc[0]) + (size_t)kt * D_TILE, st + D_TILE + wave * 256);
             dma16(static_cast<const float*>(bsrc[1]) + (size_t)kt * D_TILE, st + D_TILE + 1024 + wave * 256);
@@ -218,10 +223,16 @@ __global__ __launch_bounds__(DNT, DNS <= 3 ? 3 : 2) void gemm_dma_kernel(GemmArg
             blo[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(st + boff[j][1]));
         };
         // K-step 0 into registers
-        if (DNS >= 4 && nk >= 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (nk >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (nk == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // counted waits: NPIECE wave-instructions per K-step in flight (4, or 3 with 64-row tiles)
+        if (DNS >= 4 && nk >= 4) {
+            if (NPIECE == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        } else if (nk >= 3) {
+            if (NPIECE == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else if (nk == 2) {
+            if (NPIECE == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         load_a(smem, 0);
 #pragma unroll
@@ -229,9 +240,13 @@ __global__ __launch_bounds__(DNT, DNS <= 3 ? 3 : 2) void gemm_dma_kernel(GemmArg
         for (int kt = 0; kt < nk; ++kt) {
             // own reads of stage kt are complete (its slot may be refilled) and own pieces of stage kt + 1 landed
             const int ahead = min(nk - 1, kt + DNS - 1) - (kt + 1);   // K-steps in flight beyond kt + 1
-            if (DNS >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-            else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (DNS >= 4 && ahead >= 2) {
+                if (NPIECE == 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            } else if (ahead >= 1) {
+                if (NPIECE == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_s_barrier();
             if (kt + DNS < nk) issue(kt + DNS);
             // next K-step's slot; past the end a landed slot is re-read and the values are never used
@@ -413,30 +428,31 @@ __global__ void split_bf16_tiled_kernel(const float* __restrict__ W, float* __re
     }
 }
 
-template <int DNS, bool X3>
+template <int DNS, bool X3, int BM = 128>
 int dma_launch_t(const GemmArgs& g, hipStream_t st) {
-    const int tilesM = (g.rows + DBM - 1) / DBM, tilesN = (g.Nout + DBN - 1) / DBN;
+    const int tilesM = (g.rows + BM - 1) / BM, tilesN = (g.Nout + DBN - 1) / DBN;
     const size_t lds = (size_t)(d_main_floats(DNS) + 2 * g.K) * sizeof(float);
     static size_t attr = 0;
     if (lds > attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma_kernel<DNS, true, X3>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma_kernel<DNS, true, X3, BM>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma_kernel<DNS, false, X3>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma_kernel<DNS, false, X3, BM>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = lds;
     }
     const dim3 grid(g.B * tilesM * tilesN);
-    if (g.pro_a) hipLaunchKernelGGL((gemm_dma_kernel<DNS, true, X3>), grid, dim3(DNT), lds, st, g);
-    else hipLaunchKernelGGL((gemm_dma_kernel<DNS, false, X3>), grid, dim3(DNT), lds, st, g);
+    if (g.pro_a) hipLaunchKernelGGL((gemm_dma_kernel<DNS, true, X3, BM>), grid, dim3(DNT), lds, st, g);
+    else hipLaunchKernelGGL((gemm_dma_kernel<DNS, false, X3, BM>), grid, dim3(DNT), lds, st, g);
     return (int)hipGetLastError();
 }
 
 }  // namespace
 
-bool gemm_f32_dma_supported(const GemmArgs& g) {
+bool gemm_f32_dma_supported(const GemmArgs& g, int precision) {
+    if (precision < 0) precision = g.precision;
     if (g.C2 && ((g.n_split % DBN) || g.stats || g.residual || (g.ldc2 & 3) || g.n_split <= 0 || g.n_split >= g.Nout))
         return false;
-    return g.rows >= 128 && g.K % DBK == 0 && g.K <= 1024 && !(g.Nout & 3) && !(g.ldc & 3) && !(g.ldr & 3) &&
+    return g.rows >= (precision == 1 ? 64 : 128) && g.K % DBK == 0 && g.K <= 1024 && !(g.Nout & 3) && !(g.ldc & 3) && !(g.ldr & 3) &&
            !(g.lda & 3) && !(g.ldw & 7);
 }
 
@@ -446,7 +462,10 @@ int gemm_f32_dma_launch(const GemmArgs& g, hipStream_t st) {
         const char* e = getenv("GECCO_GEMM_STAGES");   // 3 stages = 51 KB LDS = three blocks per CU (measured best)
         ns3 = (e && atoi(e) == 4) ? 0 : 1;
     }
-    if (g.precision == 1 && g.w_img) return ns3 ? dma_launch_t<3, true>(g, st) : dma_launch_t<4, true>(g, st);
+    if (g.precision == 1 && g.w_img) {
+        if (g.rows < 128) return dma_launch_t<3, true, 64>(g, st);
+        return ns3 ? dma_launch_t<3, true>(g, st) : dma_launch_t<4, true>(g, st);
+    }
     return ns3 ? dma_launch_t<3, false>(g, st) : dma_launch_t<4, false>(g, st);
 }
 

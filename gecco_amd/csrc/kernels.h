@@ -29,7 +29,7 @@ struct GemmArgs {
 int gemm_row_tile(int rows);  // row-tile height the GEMM uses for `rows` rows per sample
 int gemm_f32_launch(const GemmArgs& g, hipStream_t st);
 // gemm_f32_dma.hip — LDS-DMA fast path of the same contract
-bool gemm_f32_dma_supported(const GemmArgs& g);
+bool gemm_f32_dma_supported(const GemmArgs& g, int precision = -1);   // -1: g.precision; split-bf16 also takes 64 <= rows < 128
 int gemm_f32_dma_launch(const GemmArgs& g, hipStream_t st);
 size_t split_bf16_image_bytes(int Nout, int K);   // ceil(Nout / 128) * 128 * K * 4
 int split_bf16_tiled_launch(const float* W, void* img, int Nout, int K, int ldw, hipStream_t st);

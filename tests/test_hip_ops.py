@@ -57,7 +57,8 @@ def test_linear_fused(ops, B, rows, K, Nout):
     _close(Rc, R + F.linear(A, W, b))
 
 
-@pytest.mark.parametrize("B,rows,K,Nout", [(2, 256, 128, 256), (1, 2048, 384, 768), (2, 300, 768, 384)])
+@pytest.mark.parametrize("B,rows,K,Nout", [(2, 256, 128, 256), (1, 2048, 384, 768), (2, 300, 768, 384), (3, 64, 384, 768),
+                                           (2, 64, 768, 384), (2, 100, 128, 200)])
 def test_linear_split_bf16(ops, B, rows, K, Nout):
     """precision="bf16x3" on the unit operator: same fused contract, ~2^-16 per-product error."""
     rs = _rs(rows + K)

@@ -107,8 +107,8 @@ def build_model(p_cpu):
 
 
 def gemm_call_sites(ops, dev, precision="fp32"):
-    """The five (B*N)-row GEMM call sites of one layer, as closures launching the unit operator.
-    Each entry: (name, algorithmic FLOPs, algorithmic HBM bytes, closure)."""
+    """The four (B*N)-row GEMM launches of one layer (kv_proj and the unpool q projection share one), as closures
+    launching the unit operator.  Each entry: (name, algorithmic FLOPs = 2 M N K, algorithmic HBM bytes, closure)."""
     g = torch.Generator(device="cpu").manual_seed(1)
     rn = lambda *s: torch.randn(*s, generator=g).to(dev)
     x, big = rn(B, N, D), rn(B, N, 2 * D)
@@ -116,13 +116,12 @@ def gemm_call_sites(ops, dev, precision="fp32"):
     Wkv, Wq, Wo, W1, W2 = rn(2 * D, D) / 20, rn(D, D) / 20, rn(D, D) / 20, rn(2 * D, D) / 20, rn(D, 2 * D) / 28
     bq, b1, b2 = rn(D) / 20, rn(2 * D) / 20, rn(D) / 20
     alpha = torch.tensor(1.0, device=dev)
-    o768, o384 = torch.empty(B, N, 2 * D, device=dev), torch.empty(B, N, D, device=dev)
+    o768, o384, q384 = torch.empty(B, N, 2 * D, device=dev), torch.empty(B, N, D, device=dev), torch.empty(B, N, D, device=dev)
     res = x.clone()
     S = B * N * D * 4  # bytes of one (B, N, d) fp32 stream
     pr = dict(precision=precision)
     sites = [
-        ("kv_proj", 2 * B * N * D * 2 * D, S + 2 * S, lambda: ops.linear(x, Wkv, None, (pa, po), out=o768, **pr)),
-        ("q_proj", 2 * B * N * D * D, S + S, lambda: ops.linear(x, Wq, bq, (pa, po), out=o384, **pr)),
+        ("kv_proj|q_proj", 2 * B * N * D * 3 * D, S + 3 * S, lambda: ops.linear_pair(x, Wkv, None, Wq, bq, (pa, po), out=(o768, q384), **pr)),
         ("out_proj+res+stats", 2 * B * N * D * D, 3 * S, lambda: ops.linear(x, Wo, bq, residual=res, want_stats=True, out=o384, **pr)),
         ("mlp.0+act", 2 * B * N * D * 2 * D, S + 2 * S, lambda: ops.linear(x, W1, b1, (pa, po), act_alpha=alpha, out=o768, **pr)),
         ("mlp.2+res+stats", 2 * B * N * 2 * D * D, 2 * S + 2 * S, lambda: ops.linear(big, W2, b2, residual=res, want_stats=True, out=o384, **pr)),
@@ -258,20 +257,21 @@ def main():
         if os.path.exists(tj):
             traffic = json.load(open(tj)).get("bytes_per_launch")
         if x3:
-            # 3 MFMAs per product: the MFMA roof of this mode is 2500/3 = 833 algorithmic TFLOP/s, its ridge
-            # (833 TF / 8 TB/s = 104 FLOP/B) sits below the GEMMs' 64..192 FLOP/B only for the widest ones, and at
-            # the achievable 6.3 TB/s the memory roof (0.096 ms per mean launch) is the tighter: HBM-bound.
-            rec["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                               "traffic": traffic,
-                               "kernel": "gemm_dma_kernel<3,*,true> (LDS-DMA ring, v_mfma_f32_32x32x16_bf16 x3), mean over its 5 call-site shapes; "
-                                         "achieved = algorithmic bytes (A + residual read, C written, fp32) / event-timed duration",
-                               "mfma": {"achieved_tflops_algorithmic": tf, "executed_over_algorithmic": 3, "peak_tflops": PEAK_BF16_MFMA_TFLOPS,
-                                        "frac_executed": 3 * tf / PEAK_BF16_MFMA_TFLOPS},
+            # The split-bf16 algorithm issues 3 MFMAs per product, so its matrix roof is the dense bf16 peak / 3 =
+            # 833 TFLOP/s of 2MNK work.  The launches run at 96..192 FLOP/B (2MNK over fp32 A/residual/C bytes): at or
+            # above the ridge of that roof (833 TF / 8 TB/s = 104 FLOP/B), and the PMC counters agree — the matrix
+            # pipe is the busiest unit (44 % busy, HBM at 30 % of 8 TB/s; profiles/README.md).  Bound: mfma.
+            rec["roofline"] = {"bound": "mfma", "achieved": tf, "peak": PEAK_BF16_MFMA_TFLOPS / 3, "unit": "TFLOP/s",
+                               "frac": 3 * tf / PEAK_BF16_MFMA_TFLOPS, "traffic": traffic,
+                               "kernel": "gemm_dma_kernel<3,*,true,128> (LDS-DMA ring, 3 x v_mfma_f32_32x32x16_bf16 per product), mean over "
+                                         "its 4 per-layer launch shapes; achieved = 2MNK / event-timed duration, peak = dense bf16 MFMA "
+                                         "peak (2500 TFLOP/s) / 3 MFMAs per product",
+                               "hbm": {"achieved_gbs_algorithmic": gbs, "peak_gbs": PEAK_HBM_GBS, "frac": gbs / PEAK_HBM_GBS},
                                "per_site": per}
         else:
             rec["roofline"] = {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": tf / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                               "kernel": "gemm_dma_kernel<3,*,false> (LDS-DMA ring, v_mfma_f32_32x32x2_f32), mean over its 5 call-site shapes",
+                               "kernel": "gemm_dma_kernel<3,*,false,128> (LDS-DMA ring, v_mfma_f32_32x32x2_f32), mean over its 4 per-layer launch shapes",
                                "per_site": per}
         if x3:  # the exact-fp32 mode beside it, for the record (same model, same inputs)
             ops.set_default_precision("fp32")

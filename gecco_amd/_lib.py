@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgecco_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_f = C.c_void_p  # device pointers travel as void*
 
@@ -73,6 +73,7 @@ SIGNATURES = {
     "gecco_linear_f32": (i, [vp] * 9 + [i, i, i, i, i, vp]),
     "gecco_linear_row_tiles": (i, [i]),
     "gecco_linear_ex_f32": (i, [vp] * 9 + [i, i, i, i, i, i, vp, vp]),
+    "gecco_linear_pair_f32": (i, [vp, vp, vp, i, vp, vp, vp, i, vp, vp, vp, i, i, i, i, vp, vp]),
     "gecco_col_stats_f32": (i, [vp, vp, i, i, i, vp]),
     "gecco_stats_row_tiles": (i, [i]),
     "gecco_adagn_coeffs_f32": (i, [vp, i, i, vp, i, C.POINTER(GeccoAdaGN), vp, vp, i, i, i, fl, vp]),

@@ -319,6 +319,23 @@ int gecco_linear_ex_f32(const float* A, const float* W, const float* bias, const
     return 0;
 }
 
+int gecco_linear_pair_f32(const float* A, const float* W1, const float* bias1, int Nout1, float* C1, const float* W2,
+                          const float* bias2, int Nout2, float* C2, const float* pro_a, const float* pro_o, int B,
+                          int rows, int K, int precision, void* wsplit, void* stream) {
+    if (!A || !W1 || !W2 || !C1 || !C2) return fail(-1, "linear_pair: null argument");
+    if ((pro_a == nullptr) != (pro_o == nullptr)) return fail(-1, "linear_pair: pro_a/pro_o must both be set");
+    if (precision == 1 && !wsplit) return fail(-1, "linear_pair: split-bf16 needs the wsplit scratch");
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = static_cast<float*>(wsplit);
+    int rc = linear_pair(A, W1, bias1, Nout1, C1, W2, bias2, Nout2, C2, pro_a, pro_o, B, rows, K, s, precision, ws);
+    if (rc < 0) TRY(rc, "linear_pair");
+    if (rc == 1) {   // shape outside the fused kernel's reach: the two linears, same results
+        TRY(linear(A, W1, bias1, pro_a, pro_o, nullptr, nullptr, C1, nullptr, B, rows, K, Nout1, 0, s, precision, ws), "linear_pair[0]");
+        TRY(linear(A, W2, bias2, pro_a, pro_o, nullptr, nullptr, C2, nullptr, B, rows, K, Nout2, 0, s, precision, ws), "linear_pair[1]");
+    }
+    return 0;
+}
+
 int gecco_col_stats_f32(const float* x, float* stats, int B, int rows, int C, void* stream) {
     TRY(col_stats_launch(x, stats, B, rows, C, (hipStream_t)stream), "col_stats");
     return 0;

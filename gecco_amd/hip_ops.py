@@ -130,6 +130,23 @@ def adagn(x: Tensor, t: Tensor | None, params: Sequence[Tensor] | None, G: int, 
     return y
 
 
+def linear_pair(A: Tensor, W1: Tensor, b1: Tensor | None, W2: Tensor, b2: Tensor | None,
+                pro: tuple[Tensor, Tensor] | None = None, out: tuple[Tensor, Tensor] | None = None,
+                precision: str = "fp32") -> tuple[Tensor, Tensor]:
+    """(A' @ W1^T + b1, A' @ W2^T + b2) with A' = A*pro_a + pro_o, one launch (A read once)."""
+    lib = _lib.load()
+    B, rows, K = A.shape
+    n1, n2 = W1.shape[0], W2.shape[0]
+    c1, c2 = out if out is not None else (torch.empty(B, rows, n1, device=A.device, dtype=torch.float32),
+                                          torch.empty(B, rows, n2, device=A.device, dtype=torch.float32))
+    wsplit = _ws(((n1 + 127) // 128 + (n2 + 127) // 128) * 128 * K * 4, A.device) if precision == "bf16x3" else None
+    check(lib.gecco_linear_pair_f32(_ptr(A), _ptr(W1), _ptr(b1), n1, _ptr(c1), _ptr(W2), _ptr(b2), n2, _ptr(c2),
+                                    _ptr(pro[0]) if pro else None, _ptr(pro[1]) if pro else None, B, rows, K,
+                                    PRECISIONS[precision], C.c_void_p(wsplit.data_ptr()) if wsplit is not None else None,
+                                    _stream()), "gecco_linear_pair_f32")
+    return c1, c2
+
+
 def pool_attn(KV: Tensor, inducers: Tensor, H: int, precision: str = "fp32") -> Tensor:
     """AttentionPool core: KV (B, N, 2C), inducers (1, H, I, hd) -> (B, I, C) merged heads (before out_proj)."""
     lib = _lib.load()

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GECCO_ABI_VERSION 2
+#define GECCO_ABI_VERSION 3
 
 int gecco_abi_version(void);
 const char* gecco_build_arch(void);   /* "gfx950" */
@@ -83,6 +83,14 @@ int gecco_linear_row_tiles(int rows);
 int gecco_linear_ex_f32(const float* A, const float* W, const float* bias, const float* pro_a, const float* pro_o,
                         const float* alpha, const float* residual, float* C, float* stats, int B, int rows, int K,
                         int Nout, int act, int precision, void* wsplit, void* stream);
+/* Two linears over the same (optionally AdaGN-modulated) input in one launch, A read once:
+ *   C1 (B, rows, Nout1) = A' W1^T + bias1,  C2 (B, rows, Nout2) = A' W2^T + bias2,  A' = A*pro_a + pro_o.
+ * The layer uses it for AttentionPool.kv_proj and the q rows of nn.MultiheadAttention.in_proj, which both read
+ * broadcast_norm(x) (models/set_transformer.py:49 and :112 under :150-155).  Falls back to two launches when
+ * Nout1 % 128 != 0 or rows < 128.  wsplit: >= (ceil(Nout1/128) + ceil(Nout2/128))*128*K*4 bytes (precision 1). */
+int gecco_linear_pair_f32(const float* A, const float* W1, const float* bias1, int Nout1, float* C1, const float* W2,
+                          const float* bias2, int Nout2, float* C2, const float* pro_a, const float* pro_o, int B,
+                          int rows, int K, int precision, void* wsplit, void* stream);
 
 /* GroupNorm partial statistics of x (B, rows, C): stats (B, T, 2, C), T = gecco_stats_row_tiles(rows). */
 int gecco_col_stats_f32(const float* x, float* stats, int B, int rows, int C, void* stream);

@@ -78,6 +78,23 @@ def test_linear_split_bf16(ops, B, rows, K, Nout):
     assert e32[0] < e[0]  # the exact-fp32 mode is (of course) closer; both are far inside 1e-3
 
 
+@pytest.mark.parametrize("B,rows,K,n1,n2", [(2, 256, 128, 256, 128), (1, 2048, 384, 768, 384), (2, 200, 64, 96, 64), (3, 64, 384, 768, 384)])
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16x3", 1e-4)])
+def test_linear_pair(ops, B, rows, K, n1, n2, precision, tol):
+    """kv_proj | q_proj in one launch: each half must equal its own linear (bit-for-bit in the same arithmetic)."""
+    rs = _rs(rows + K + n1)
+    A = _t(rs.randn(B, rows, K) * 2)
+    W1, W2, b2 = _t(rs.randn(n1, K) / math.sqrt(K)), _t(rs.randn(n2, K) / math.sqrt(K)), _t(rs.randn(n2))
+    pa, po = _t(1 + 0.3 * rs.randn(B, K)), _t(0.3 * rs.randn(B, K))
+    An = (A * pa[:, None] + po[:, None]).double()
+    c1, c2 = ops.linear_pair(A.cuda(), W1.cuda(), None, W2.cuda(), b2.cuda(), (pa.cuda(), po.cuda()), precision=precision)
+    _close(c1, F.linear(An, W1.double()), tol)
+    _close(c2, F.linear(An, W2.double(), b2.double()), tol)
+    s1 = ops.linear(A.cuda(), W1.cuda(), None, (pa.cuda(), po.cuda()), precision=precision)
+    s2 = ops.linear(A.cuda(), W2.cuda(), b2.cuda(), (pa.cuda(), po.cuda()), precision=precision)
+    assert torch.equal(c1, s1) and torch.equal(c2, s2)
+
+
 @pytest.mark.parametrize("B,rows,C,G,ctx", [(2, 256, 128, 32, 1), (3, 77, 64, 32, 1), (2, 64, 384, 32, 3), (2, 300, 672, 16, 0)])
 def test_adagn(ops, B, rows, C, G, ctx):
     rs = _rs(rows + C)

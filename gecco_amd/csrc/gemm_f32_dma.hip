@@ -189,12 +189,13 @@ __global__ __launch_bounds__(DNT, DNS <= 3 ? 3 : 2) void gemm_dma_kernel(GemmArg
     }
 
     if (X3) {
-        // Software-pipelined: the fragments of K-step kt sit in registers while its 12 MFMAs issue; between them
-        // the wave reads the fragments of K-step kt + 1 (LDS latency, AdaGN affine and the hi / lo split hide
-        // under the matrix pipe instead of in front of it) and the DMA runs DNS K-steps ahead.  One 32x32x16 chunk
-        // per K-step: lane half h holds k = 8h .. 8h+7 of both operands.
-        bf16x8 ahi[TMW], alo[TMW], bhi[TNW], blo[TNW];
-        auto load_a = [&](const float* st, int kt) {
+        // Software-pipelined: the fragments of K-step kt sit in registers while its 12 MFMAs issue; under them the
+        // wave reads the fragments of K-step kt + 1 (LDS latency, AdaGN affine and the hi / lo split hide under the
+        // matrix pipe instead of in front of it) and the DMA runs DNS K-steps ahead.  One 32x32x16 chunk per K-step:
+        // lane half h holds k = 8h .. 8h+7 of both operands.  Two fragment sets: set (kt & 1) is multiplied while
+        // the other is filled, so every LDS read of the next step issues right after the barrier.
+        bf16x8 ahi[2][TMW], alo[2][TMW], bhi[2][TNW], blo[2][TNW];
+        auto load_frags = [&](const float* st, int kt, int f) {
             f32x4 pa0, pa1, po0, po1;
             if (HAS_PRO) {
                 pa0 = *reinterpret_cast<const f32x4*>(pro_lds + kt * DBK + 8 * h);
@@ -202,27 +203,31 @@ __global__ __launch_bounds__(DNT, DNS <= 3 ? 3 : 2) void gemm_dma_kernel(GemmArg
                 po0 = *reinterpret_cast<const f32x4*>(pro_lds + g.K + kt * DBK + 8 * h);
                 po1 = *reinterpret_cast<const f32x4*>(pro_lds + g.K + kt * DBK + 8 * h + 4);
             }
+            f32x4 x0[TMW], x1[TMW];
 #pragma unroll
             for (int i = 0; i < TMW; ++i) {
-                f32x4 x0 = *reinterpret_cast<const f32x4*>(st + aoff[i][0]);
-                f32x4 x1 = *reinterpret_cast<const f32x4*>(st + aoff[i][1]);
+                x0[i] = *reinterpret_cast<const f32x4*>(st + aoff[i][0]);
+                x1[i] = *reinterpret_cast<const f32x4*>(st + aoff[i][1]);
+            }
+#pragma unroll
+            for (int j = 0; j < TNW; ++j) {
+                bhi[f][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(st + boff[j][0]));
+                blo[f][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(st + boff[j][1]));
+            }
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) {
                 if (HAS_PRO) {
-                    x0 = x0 * pa0 + po0;
-                    x1 = x1 * pa1 + po1;
+                    x0[i] = x0[i] * pa0 + po0;
+                    x1[i] = x1[i] * pa1 + po1;
                 }
 #ifdef GEMM_DIAG_NOSPLIT
-                ahi[i] = __builtin_bit_cast(bf16x8, x0);
-                alo[i] = __builtin_bit_cast(bf16x8, x1);
+                ahi[f][i] = __builtin_bit_cast(bf16x8, x0[i]);
+                alo[f][i] = __builtin_bit_cast(bf16x8, x1[i]);
 #else
-                split8(x0, x1, ahi[i], alo[i]);
+                split8(x0[i], x1[i], ahi[f][i], alo[f][i]);
 #endif
             }
         };
-        auto load_b = [&](const float* st, int j) {
-            bhi[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(st + boff[j][0]));
-            blo[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(st + boff[j][1]));
-        };
-        // K-step 0 into registers
         // counted waits: NPIECE wave-instructions per K-step in flight (4, or 3 with 64-row tiles)
         if (DNS >= 4 && nk >= 4) {
             if (NPIECE == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
@@ -234,10 +239,8 @@ __global__ __launch_bounds__(DNT, DNS <= 3 ? 3 : 2) void gemm_dma_kernel(GemmArg
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
-        load_a(smem, 0);
-#pragma unroll
-        for (int j = 0; j < TNW; ++j) load_b(smem, j);
-        for (int kt = 0; kt < nk; ++kt) {
+        load_frags(smem, 0, 0);   // K-step 0 into set 0
+        auto kstep = [&](int kt, int cur) {
             // own reads of stage kt are complete (its slot may be refilled) and own pieces of stage kt + 1 landed
             const int ahead = min(nk - 1, kt + DNS - 1) - (kt + 1);   // K-steps in flight beyond kt + 1
             if (DNS >= 4 && ahead >= 2) {
@@ -251,29 +254,26 @@ __global__ __launch_bounds__(DNT, DNS <= 3 ? 3 : 2) void gemm_dma_kernel(GemmArg
             if (kt + DNS < nk) issue(kt + DNS);
             // next K-step's slot; past the end a landed slot is re-read and the values are never used
             const int kn = min(kt + 1, nk - 1);
-            const float* nx = smem + (kn % DNS) * D_STAGE;
-            bf16x8 chi[TMW], clo[TMW];
+            load_frags(smem + (kn % DNS) * D_STAGE, kn, cur ^ 1);
 #pragma unroll
-            for (int i = 0; i < TMW; ++i) {
-                chi[i] = ahi[i];
-                clo[i] = alo[i];
-            }
-            load_a(nx, kn);
-#pragma unroll
-            for (int j = 0; j < TNW; ++j) {
+            for (int j = 0; j < TNW; ++j)
 #pragma unroll
                 for (int i = 0; i < TMW; ++i) {
 #ifdef GEMM_DIAG_NOMFMA   // diagnostic: keep the operand reads alive with one VALU op per fragment instead
-                    acc[i][j][0] += (float)clo[i][0] + (float)bhi[j][0] + (float)chi[i][0] + (float)blo[j][0];
+                    acc[i][j][0] += (float)alo[cur][i][0] + (float)bhi[cur][j][0] + (float)ahi[cur][i][0] + (float)blo[cur][j][0];
 #else
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(clo[i], bhi[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(chi[i], blo[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(chi[i], bhi[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[cur][i], bhi[cur][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[cur][i], blo[cur][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[cur][i], bhi[cur][j], acc[i][j], 0, 0, 0);
 #endif
                 }
-                load_b(nx, j);
-            }
+        };
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) {
+            kstep(kt, 0);
+            kstep(kt + 1, 1);
         }
+        if (kt < nk) kstep(kt, 0);
     } else {
         for (int kt = 0; kt < nk; ++kt) {
             // own pieces of K-step kt have landed once at most the younger K-steps' DMAs are outstanding

@@ -180,7 +180,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-sampler", action="store_true")
-    ap.add_argument("--precision", default=os.environ.get("GECCO_PRECISION", "bf16x3"), choices=["fp32", "bf16x3"],
+    ap.add_argument("--precision", default=os.environ.get("GECCO_PRECISION", "bf16x3"), choices=["fp32", "bf16x3", "fp16"],
                     help="arithmetic of the N-token GEMMs: split-bf16 (default; ~1.5e-5 vs the fp32 reference, inside the "
                          "1e-3 bar) or exact fp32 MFMA (~1e-6)")
     args = ap.parse_args()

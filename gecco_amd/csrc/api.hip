@@ -90,7 +90,9 @@ STWorkspace carve_st(const GeccoSetTransformer* st, int B, int N, void* base) {
         w.wsplit = c.f32(((wmax + 127) / 128 * 128) * (size_t)(W > C ? W : C));
     }
     {   // per layer: kv_proj | q_proj (contiguous: the fused pair streams them as one image), out_proj, mlp.0, mlp.2
-        auto pad = [](size_t n) { return (n + 127) / 128 * 128; };
+        // (floats: 4 bytes per weight element in split-bf16 mode, 2 in fp16 mode)
+        const size_t half = st->precision == 2 ? 2 : 1;
+        auto pad = [half](size_t n) { return (n + 127) / 128 * 128 / half; };
         w.o_q = pad(2 * C) * C;
         w.o_out = w.o_q + pad(C) * C;
         w.o_w0 = w.o_out + pad(C) * C;
@@ -100,7 +102,7 @@ STWorkspace carve_st(const GeccoSetTransformer* st, int B, int N, void* base) {
         w.o_b2 = w.o_b0 + pad(W) * C;
         w.o_ukv = w.o_b2 + pad(C) * W;
         w.wimg_layer = w.o_ukv + pad(2 * C) * C;
-        w.wimg = st->precision == 1 ? c.f32(w.wimg_layer * st->n_layers) : nullptr;
+        w.wimg = st->precision >= 1 ? c.f32(w.wimg_layer * st->n_layers) : nullptr;
     }
     w.bytes = (c.off + 255) & ~size_t(255);
     return w;
@@ -110,22 +112,26 @@ STWorkspace carve_st(const GeccoSetTransformer* st, int B, int N, void* base) {
 // hi | lo image of W first (a ~3 us pass over <= 1.2 MB: weights may change between calls, nothing is cached).
 int linear(const float* A, const float* W, const float* bias, const float* pa, const float* po, const float* alpha,
            const float* res, float* C, float* stats, int B, int rows, int K, int Nout, int act, hipStream_t s,
-           int precision = 0, float* wsplit = nullptr, const float* img_ready = nullptr) {
+           int precision = 0, float* wsplit = nullptr, const float* img_ready = nullptr, int a_f16 = 0, int c_f16 = 0) {
     GemmArgs g{};
     g.A = A; g.W = W; g.bias = bias; g.pro_a = pa; g.pro_o = po; g.alpha = alpha; g.residual = res; g.C = C;
     g.stats = stats; g.B = B; g.rows = rows; g.K = K; g.Nout = Nout;
     g.lda = K; g.ldw = K; g.ldc = Nout; g.ldr = Nout; g.act = act;
     g.precision = 0; g.w_img = nullptr;
     if (act && !alpha) return -6;
-    if (precision == 1 && (wsplit || img_ready) && gemm_f32_dma_supported(g, 1)) {
+    g.a_f16 = a_f16; g.c_f16 = c_f16;   // fp16 tensors exist only between the fp16 kernels (st_forward checks support)
+    const bool fast = precision == 1 ? gemm_f32_dma_supported(g, 1) : precision == 2 ? gemm_f16_dma_supported(g) : false;
+    if ((a_f16 || c_f16) && !(fast && precision == 2 && (wsplit || img_ready))) return -9;
+    if (fast && (wsplit || img_ready)) {
         if (img_ready) {
-            g.w_img = img_ready;   // already split this forward
+            g.w_img = img_ready;   // already converted this forward
         } else {
-            int rc = split_bf16_tiled_launch(W, wsplit, Nout, K, g.ldw, s);
+            int rc = precision == 1 ? split_bf16_tiled_launch(W, wsplit, Nout, K, g.ldw, s)
+                                    : split_f16_tiled_launch(W, wsplit, Nout, K, g.ldw, s);
             if (rc) return rc;
             g.w_img = wsplit;
         }
-        g.precision = 1;
+        g.precision = precision;
     }
     return gemm_f32_launch(g, s);
 }
@@ -134,26 +140,32 @@ int linear(const float* A, const float* W, const float* bias, const float* pa, c
 // Returns 1 when the fused form does not apply (caller issues the two linears), 0 on success, <0 on error.
 int linear_pair(const float* A, const float* W1, const float* b1, int Nout1, float* C1, const float* W2,
                 const float* b2, int Nout2, float* C2, const float* pa, const float* po, int B, int rows, int K,
-                hipStream_t s, int precision, float* wsplit, const float* img_ready = nullptr) {
+                hipStream_t s, int precision, float* wsplit, const float* img_ready = nullptr, int c_f16 = 0) {
     GemmArgs g{};
+    g.c_f16 = c_f16;
+    if (c_f16 && precision != 2) return -9;
     g.A = A; g.W = W1; g.bias = b1; g.pro_a = pa; g.pro_o = po; g.C = C1;
     g.B = B; g.rows = rows; g.K = K; g.Nout = Nout1 + Nout2;
     g.lda = K; g.ldw = K; g.ldc = Nout1; g.ldr = Nout1;
     g.C2 = C2; g.W2 = W2; g.bias2 = b2; g.n_split = Nout1; g.ldc2 = Nout2;
-    if (!gemm_f32_dma_supported(g)) return 1;
-    if (precision == 1) {
+    if (precision == 2 ? !gemm_f16_dma_supported(g) : !gemm_f32_dma_supported(g)) return 1;
+    if (precision == 1 || precision == 2) {
         if (img_ready) {
             g.w_img = img_ready;
         } else {
             if (!wsplit) return 1;
-            int rc = split_bf16_tiled_launch(W1, wsplit, Nout1, K, K, s);
+            int rc = precision == 1 ? split_bf16_tiled_launch(W1, wsplit, Nout1, K, K, s)
+                                    : split_f16_tiled_launch(W1, wsplit, Nout1, K, K, s);
             if (rc) return rc;
-            rc = split_bf16_tiled_launch(W2, wsplit + split_bf16_image_bytes(Nout1, K) / sizeof(float), Nout2, K, K, s);
+            float* img2 = wsplit + (precision == 1 ? split_bf16_image_bytes(Nout1, K) : split_f16_image_bytes(Nout1, K)) / sizeof(float);
+            rc = precision == 1 ? split_bf16_tiled_launch(W2, img2, Nout2, K, K, s)
+                                : split_f16_tiled_launch(W2, img2, Nout2, K, K, s);
             if (rc) return rc;
             g.w_img = wsplit;
         }
-        g.precision = 1;
+        g.precision = precision;
     }
+    if (precision == 2) return gemm_f16_dma_launch(g, s);
     return gemm_f32_dma_launch(g, s);
 }
 
@@ -183,7 +195,8 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         sx = w.stats_x;
         sT = row_tiles_stats(N);
     }
-    if (pr == 1 && w.wimg && !(C % 16) && !(Wd % 16)) {
+    const int kmod = pr == 2 ? 32 : 16;   // K granularity of the fast kernels
+    if (pr >= 1 && w.wimg && !(C % kmod) && !(Wd % kmod)) {
         // split-bf16 mode: every N-token weight of every layer becomes its tiled hi | lo image in ONE launch per
         // 6 layers (weights may change between calls; nothing is cached across forwards)
         SplitJobs jobs;
@@ -191,7 +204,7 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         auto push = [&](const float* Wp, float* img, int Nout, int K) -> int {
             jobs.job[jobs.n++] = SplitJob{Wp, img, Nout, K, K, 0};
             if (jobs.n == 32) {
-                int rc = split_bf16_tiled_multi_launch(jobs, s);
+                int rc = pr == 2 ? split_f16_tiled_multi_launch(jobs, s) : split_bf16_tiled_multi_launch(jobs, s);
                 jobs.n = 0;
                 return rc;
             }
@@ -212,9 +225,13 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
             TRY(push(L.mlp.w0, base + w.o_w0, Wd, C), "split(mlp.0)");
             TRY(push(L.mlp.w2, base + w.o_w2, C, Wd), "split(mlp.2)");
         }
-        TRY(split_bf16_tiled_multi_launch(jobs, s), "split(weights)");
+        TRY(pr == 2 ? split_f16_tiled_multi_launch(jobs, s) : split_bf16_tiled_multi_launch(jobs, s), "split(weights)");
     }
-    const bool imgs = pr == 1 && w.wimg && !(C % 16) && !(Wd % 16);
+    const bool imgs = pr >= 1 && w.wimg && !(C % kmod) && !(Wd % kmod);
+    // fp16 mode: the point-stream intermediates every consumer rounds to fp16 anyway (K|V, q, the attention output,
+    // the MLP hidden layer) are STORED as fp16 — the same bits reach the matrix pipe, a third of the layer's HBM
+    // bytes never move.  x (the residual stream) and everything on the 64 inducers stay fp32.
+    const bool io16 = pr == 2 && imgs && N >= 128 && attn_x3_supported(C / H) && !(C % 8) && !(Wd % 8);
     for (int li = 0; li < st->n_layers; ++li) {
         const GeccoLayer& L = st->layers[li];
         const float* im = imgs ? w.wimg + (size_t)li * w.wimg_layer : nullptr;
@@ -226,13 +243,13 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
             // pool: KV projection, 64 inducer queries over the N points, out_proj
             // kv_proj and the unpool's q projection read the same AdaGN(x): one launch, x read once
             int fused = linear_pair(x, L.kv_proj_w, nullptr, 2 * C, w.big, L.in_proj_w, L.in_proj_b, C, w.q, w.a1, w.o1, B,
-                                    N, C, s, pr, w.wsplit, (2 * C) % 128 == 0 ? im : nullptr);
+                                    N, C, s, pr, w.wsplit, (2 * C) % 128 == 0 ? im : nullptr, io16);
             if (fused < 0) TRY(fused, "kv_proj|q_proj");
             q_done = fused == 0;
             if (!q_done)
                 TRY(linear(x, L.kv_proj_w, nullptr, w.a1, w.o1, nullptr, nullptr, w.big, nullptr, B, N, C, 2 * C, 0, s, pr,
-                           w.wsplit, im), "kv_proj");
-            TRY(pool_attn_launch(w.big, L.inducers, w.part_o, w.part_ml, w.merged, B, N, C, H, I, ns, s, pr), "pool_attn");
+                           w.wsplit, im, 0, io16), "kv_proj");
+            TRY(pool_attn_launch(w.big, L.inducers, w.part_o, w.part_ml, w.merged, B, N, C, H, I, ns, s, pr, io16), "pool_attn");
             TRY(linear(w.merged, L.pool_out_w, nullptr, nullptr, nullptr, nullptr, nullptr, w.h0, w.stats_s, B, I, C, C,
                        0, s, pr, w.wsplit, im ? im + w.o_pout : nullptr), "pool.out_proj");
             // h = norm_2(mlp(norm_1(h0)))
@@ -251,17 +268,17 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
                    B, I, C, 2 * C, 0, s, pr, w.wsplit, im ? im + w.o_ukv : nullptr), "unpool.in_proj(kv)");
         if (!q_done)
             TRY(linear(x, L.in_proj_w, L.in_proj_b, w.a1, w.o1, nullptr, nullptr, w.q, nullptr, B, N, C, C, 0, s, pr,
-                       w.wsplit, im ? im + w.o_q : nullptr), "unpool.in_proj(q)");
-        TRY(unpool_attn_launch(w.q, w.kvh, w.attn, B, N, C, H, I, s, pr), "unpool_attn");
+                       w.wsplit, im ? im + w.o_q : nullptr, 0, io16), "unpool.in_proj(q)");
+        TRY(unpool_attn_launch(w.q, w.kvh, w.attn, B, N, C, H, I, s, pr, io16), "unpool_attn");
         TRY(linear(w.attn, L.unpool_out_w, L.unpool_out_b, nullptr, nullptr, nullptr, x, x, w.stats_x, B, N, C, C, 0, s, pr,
-                   w.wsplit, im ? im + w.o_out : nullptr), "unpool.out_proj+residual");
+                   w.wsplit, im ? im + w.o_out : nullptr, io16, 0), "unpool.out_proj+residual");
         // x += mlp(AdaGN(x))
         TRY(coeffs(w.stats_x, Tn, N, t, ctx, &L.mlp_norm, w.a2, w.o2, B, C, G, s), "adagn_coeffs(mlp_norm)");
         TRY(linear(x, L.mlp.w0, L.mlp.b0, w.a2, w.o2, L.mlp.alpha, nullptr, w.big, nullptr, B, N, C, Wd, act, s, pr, w.wsplit,
-                   im ? im + w.o_w0 : nullptr), "mlp.0");
+                   im ? im + w.o_w0 : nullptr, 0, io16), "mlp.0");
         float* so = (li + 1 < st->n_layers) ? w.stats_x : stats_out;
         TRY(linear(w.big, L.mlp.w2, L.mlp.b2, nullptr, nullptr, nullptr, x, x, so, B, N, Wd, C, 0, s, pr, w.wsplit,
-                   im ? im + w.o_w2 : nullptr), "mlp.2+residual");
+                   im ? im + w.o_w2 : nullptr, io16, 0), "mlp.2+residual");
         sx = w.stats_x;
         sT = Tn;
     }
@@ -313,7 +330,8 @@ int gecco_linear_ex_f32(const float* A, const float* W, const float* bias, const
                         int Nout, int act, int precision, void* wsplit, void* stream) {
     if (!A || !W || !C) return fail(-1, "linear: null argument");
     if ((pro_a == nullptr) != (pro_o == nullptr)) return fail(-1, "linear: pro_a/pro_o must both be set");
-    if (precision == 1 && !wsplit) return fail(-1, "linear: split-bf16 needs the wsplit scratch");
+    if (precision < 0 || precision > 2) return fail(-2, "linear: precision must be 0 (fp32), 1 (split-bf16) or 2 (fp16)");
+    if (precision >= 1 && !wsplit) return fail(-1, "linear: precision 1 / 2 need the wsplit scratch");
     TRY(linear(A, W, bias, pro_a, pro_o, alpha, residual, C, stats, B, rows, K, Nout, act, (hipStream_t)stream, precision,
                static_cast<float*>(wsplit)), "linear");
     return 0;
@@ -324,7 +342,8 @@ int gecco_linear_pair_f32(const float* A, const float* W1, const float* bias1, i
                           int rows, int K, int precision, void* wsplit, void* stream) {
     if (!A || !W1 || !W2 || !C1 || !C2) return fail(-1, "linear_pair: null argument");
     if ((pro_a == nullptr) != (pro_o == nullptr)) return fail(-1, "linear_pair: pro_a/pro_o must both be set");
-    if (precision == 1 && !wsplit) return fail(-1, "linear_pair: split-bf16 needs the wsplit scratch");
+    if (precision < 0 || precision > 2) return fail(-2, "linear_pair: precision must be 0 (fp32), 1 (split-bf16) or 2 (fp16)");
+    if (precision >= 1 && !wsplit) return fail(-1, "linear_pair: precision 1 / 2 need the wsplit scratch");
     hipStream_t s = (hipStream_t)stream;
     float* ws = static_cast<float*>(wsplit);
     int rc = linear_pair(A, W1, bias1, Nout1, C1, W2, bias2, Nout2, C2, pro_a, pro_o, B, rows, K, s, precision, ws);
@@ -390,7 +409,7 @@ size_t gecco_pool_attn_workspace_bytes(int B, int N, int C, int H, int I) {
 
 int gecco_pool_attn_ex_f32(const float* KV, const float* inducers, float* merged, int B, int N, int C, int H, int I,
                            int precision, void* ws, size_t ws_bytes, void* stream) {
-    if (precision != 0 && precision != 1) return fail(-2, "pool_attn: precision must be 0 (fp32) or 1 (split-bf16)");
+    if (precision < 0 || precision > 2) return fail(-2, "pool_attn: precision must be 0 (fp32), 1 (split-bf16) or 2 (fp16)");
     if (ws_bytes < gecco_pool_attn_workspace_bytes(B, N, C, H, I)) return fail(-7, "pool_attn: workspace too small");
     Carver c(ws);
     const int ns = pool_attn_nsplit(B, N, H);
@@ -407,7 +426,7 @@ int gecco_pool_attn_f32(const float* KV, const float* inducers, float* merged, i
 
 int gecco_unpool_attn_ex_f32(const float* q, const float* kvh, float* out, int B, int N, int C, int H, int I,
                              int precision, void* stream) {
-    if (precision != 0 && precision != 1) return fail(-2, "unpool_attn: precision must be 0 (fp32) or 1 (split-bf16)");
+    if (precision < 0 || precision > 2) return fail(-2, "unpool_attn: precision must be 0 (fp32), 1 (split-bf16) or 2 (fp16)");
     TRY(unpool_attn_launch(q, kvh, out, B, N, C, H, I, (hipStream_t)stream, precision), "unpool_attn");
     return 0;
 }

@@ -12,6 +12,8 @@
 //       pool   — the streamed value tile is stored row-major in 4-key x 32-column blocks of 256 B and read with
 //                ds_read_b64_tr_b16 (the hardware transpose), one conflict-free block per 32-lane half.
 // Head dims: multiples of 16 up to 64; anything else stays on the fp32 kernels.
+// The same kernels serve the fp16 mode (precision 2, template flag F16): one fp16 plane instead of hi | lo, one
+// v_mfma_f32_32x32x16_f16 per product, operands rounded to nearest even.
 #include "common.h"
 #include "kernels.h"
 
@@ -19,6 +21,8 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -29,7 +33,17 @@ constexpr float LOG2E = 1.4426950408889634f;
 __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // 4 fp32 -> 4 bf16 hi (top 16 bits) and 4 bf16 lo = rne(x - hi), each packed in two dwords
+// (F16: hi = the 4 values rounded to fp16, lo unused)
+template <bool F16>
 __device__ __forceinline__ void split4(const f32x4& x, u32x2& hi, u32x2& lo) {
+    if (F16) {
+        f16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (_Float16)x[e];
+        hi = __builtin_bit_cast(u32x2, v);
+        lo = hi;
+        return;
+    }
     bf16x4 l;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -41,8 +55,17 @@ __device__ __forceinline__ void split4(const f32x4& x, u32x2& hi, u32x2& lo) {
     lo = __builtin_bit_cast(u32x2, l);
 }
 
-// accumulator registers e0 .. e0+7 -> the hi / lo fragments of one 16-key chunk
-__device__ __forceinline__ void split_acc8(const f32x16& s, int e0, bf16x8& hi, bf16x8& lo) {
+// accumulator registers e0 .. e0+7 -> the hi / lo fragments of one 16-key chunk (F16: one fp16 fragment)
+template <bool F16>
+__device__ __forceinline__ void split_acc8(const f32x16& s, int e0, u32x4& hi, u32x4& lo) {
+    if (F16) {
+        f16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (_Float16)s[e0 + e];
+        hi = __builtin_bit_cast(u32x4, v);
+        lo = hi;
+        return;
+    }
     u32x4 hb;
     bf16x8 l;
 #pragma unroll
@@ -53,17 +76,22 @@ __device__ __forceinline__ void split_acc8(const f32x16& s, int e0, bf16x8& hi, 
         l[2 * p] = (__bf16)(a - __uint_as_float(ua & 0xFFFF0000u));
         l[2 * p + 1] = (__bf16)(c - __uint_as_float(uc & 0xFFFF0000u));
     }
-    hi = __builtin_bit_cast(bf16x8, hb);
-    lo = l;
+    hi = hb;
+    lo = __builtin_bit_cast(u32x4, l);
 }
 
-__device__ __forceinline__ bf16x8 frag(const u16* p) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p)); }
+__device__ __forceinline__ u32x4 frag(const u16* p) { return *reinterpret_cast<const u32x4*>(p); }
 
-__device__ __forceinline__ f32x16 mfma3(const bf16x8& ahi, const bf16x8& alo, const bf16x8& bhi, const bf16x8& blo,
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma3(const u32x4& ahi, const u32x4& alo, const u32x4& bhi, const u32x4& blo,
                                         f32x16 acc) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, acc, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc, 0, 0, 0);
+    if (F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ahi), __builtin_bit_cast(f16x8, bhi), acc, 0, 0, 0);
+    const bf16x8 ah = __builtin_bit_cast(bf16x8, ahi), al = __builtin_bit_cast(bf16x8, alo);
+    const bf16x8 bh = __builtin_bit_cast(bf16x8, bhi), bl = __builtin_bit_cast(bf16x8, blo);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
 }
 
 // ------------------------------------------------------------------------------------- pool
@@ -73,7 +101,8 @@ __device__ __forceinline__ int vt_off(int key, int d) {
     return ((key >> 2) * DT + (d >> 5)) * 128 + (key & 3) * 32 + (d & 31);
 }
 
-template <int HD>
+// IO16 (fp16 mode only): KV is an fp16 tensor (the kv_proj GEMM stored it that way) — tiles are copied to LDS as they are
+template <int HD, bool F16, bool IO16>
 __global__ __launch_bounds__(256, 2) void pool_attn_x3_kernel(const float* __restrict__ KV,
                                                            const float* __restrict__ Qind,
                                                            float* __restrict__ part_o, float* __restrict__ part_ml,
@@ -84,7 +113,8 @@ __global__ __launch_bounds__(256, 2) void pool_attn_x3_kernel(const float* __res
     constexpr int LD_IT = (32 * CH + 63) / 64;
     constexpr int NC = HD / 16;           // 16-wide k chunks of the head dim
     constexpr int VT = 8 * DT * 128;      // elements per value plane of one wave tile
-    constexpr int WAVE_E = 2 * 32 * KS + 2 * VT;
+    constexpr int NP = F16 ? 1 : 2;       // planes per operand
+    constexpr int WAVE_E = NP * (32 * KS + VT);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     u16* lds = reinterpret_cast<u16*>(smem);
 
@@ -94,11 +124,11 @@ __global__ __launch_bounds__(256, 2) void pool_attn_x3_kernel(const float* __res
     const int b = bh / H, hh = bh % H;
 
     u16* Qhi = lds;
-    u16* Qlo = lds + 64 * KS;
-    u16* Khi = lds + 2 * 64 * KS + wave * WAVE_E;
-    u16* Klo = Khi + 32 * KS;
-    u16* Vhi = Klo + 32 * KS;
-    u16* Vlo = Vhi + VT;
+    u16* Qlo = F16 ? Qhi : lds + 64 * KS;
+    u16* Khi = lds + NP * 64 * KS + wave * WAVE_E;
+    u16* Klo = F16 ? Khi : Khi + 32 * KS;
+    u16* Vhi = Khi + NP * 32 * KS;
+    u16* Vlo = F16 ? Vhi : Vhi + VT;
 
     const int ks = (((N + nsplit - 1) / nsplit) + 31) / 32 * 32;
     const int k_begin = split * ks;
@@ -111,18 +141,37 @@ __global__ __launch_bounds__(256, 2) void pool_attn_x3_kernel(const float* __res
         const int row = f / CH, ch = f % CH;
         const f32x4 v = *reinterpret_cast<const f32x4*>(Qind + ((size_t)hh * 64 + row) * HD + ch * 4) * scale;
         u32x2 hi, lo;
-        split4(v, hi, lo);
+        split4<F16>(v, hi, lo);
         *reinterpret_cast<u32x2*>(Qhi + row * KS + ch * 4) = hi;
-        *reinterpret_cast<u32x2*>(Qlo + row * KS + ch * 4) = lo;
+        if (!F16) *reinterpret_cast<u32x2*>(Qlo + row * KS + ch * 4) = lo;
     }
 
     const size_t ldkv = 2 * (size_t)C;
     const float* Kg = KV + (size_t)b * N * ldkv + hh * HD;
     const float* Vg = Kg + C;
 
-    f32x4 rk[LD_IT], rv[LD_IT];
+    static_assert(!IO16 || F16, "fp16 tensors exist in fp16 mode only");
+    constexpr int CH8 = HD / 8, LD8 = (32 * CH8 + 63) / 64;   // 16-byte chunks of 8 fp16
+    const _Float16* Kg16 = reinterpret_cast<const _Float16*>(KV) + (size_t)b * N * ldkv + hh * HD;
+    const _Float16* Vg16 = Kg16 + C;
+    f32x4 rk[IO16 ? 1 : LD_IT], rv[IO16 ? 1 : LD_IT];
+    u32x4 rk8[IO16 ? LD8 : 1], rv8[IO16 ? LD8 : 1];
     auto load_tile = [&](int tile) {
         const int base = k_begin + tile * 32;
+        if (IO16) {
+#pragma unroll
+            for (int it = 0; it < LD8; ++it) {
+                const int f = it * 64 + lane, row = f / CH8, c8 = f % CH8, key = base + row;
+                u32x4 zk = {0u, 0u, 0u, 0u}, zv = {0u, 0u, 0u, 0u};
+                if (f < 32 * CH8 && tile < ntiles && key < k_end) {
+                    zk = *reinterpret_cast<const u32x4*>(Kg16 + key * ldkv + c8 * 8);
+                    zv = *reinterpret_cast<const u32x4*>(Vg16 + key * ldkv + c8 * 8);
+                }
+                rk8[it] = zk;
+                rv8[it] = zv;
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < LD_IT; ++it) {
             const int f = it * 64 + lane, row = f / CH, ch = f % CH, key = base + row;
@@ -136,17 +185,28 @@ __global__ __launch_bounds__(256, 2) void pool_attn_x3_kernel(const float* __res
         }
     };
     auto store_tile = [&]() {
+        if (IO16) {
+#pragma unroll
+            for (int it = 0; it < LD8; ++it) {
+                const int f = it * 64 + lane, row = f / CH8, c8 = f % CH8;
+                if (f < 32 * CH8) {
+                    *reinterpret_cast<u32x4*>(Khi + row * KS + c8 * 8) = rk8[it];
+                    *reinterpret_cast<u32x4*>(Vhi + vt_off<DT>(row, c8 * 8)) = rv8[it];
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < LD_IT; ++it) {
             const int f = it * 64 + lane, row = f / CH, ch = f % CH;
             if (f < 32 * CH) {
                 u32x2 hi, lo;
-                split4(rk[it], hi, lo);
+                split4<F16>(rk[it], hi, lo);
                 *reinterpret_cast<u32x2*>(Khi + row * KS + ch * 4) = hi;
-                *reinterpret_cast<u32x2*>(Klo + row * KS + ch * 4) = lo;
-                split4(rv[it], hi, lo);
+                if (!F16) *reinterpret_cast<u32x2*>(Klo + row * KS + ch * 4) = lo;
+                split4<F16>(rv[it], hi, lo);
                 *reinterpret_cast<u32x2*>(Vhi + vt_off<DT>(row, ch * 4)) = hi;
-                *reinterpret_cast<u32x2*>(Vlo + vt_off<DT>(row, ch * 4)) = lo;
+                if (!F16) *reinterpret_cast<u32x2*>(Vlo + vt_off<DT>(row, ch * 4)) = lo;
             }
         }
     };
@@ -177,12 +237,13 @@ __global__ __launch_bounds__(256, 2) void pool_attn_x3_kernel(const float* __res
                 for (int e = 0; e < 16; ++e) s[j][e] = 0.f;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                const bf16x8 ah = frag(Khi + r * KS + c * 16 + 8 * h), al = frag(Klo + r * KS + c * 16 + 8 * h);
+                const u32x4 ah = frag(Khi + r * KS + c * 16 + 8 * h);
+                const u32x4 al = F16 ? ah : frag(Klo + r * KS + c * 16 + 8 * h);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const bf16x8 qh = frag(Qhi + (j * 32 + r) * KS + c * 16 + 8 * h);
-                    const bf16x8 ql = frag(Qlo + (j * 32 + r) * KS + c * 16 + 8 * h);
-                    s[j] = mfma3(ah, al, qh, ql, s[j]);
+                    const u32x4 qh = frag(Qhi + (j * 32 + r) * KS + c * 16 + 8 * h);
+                    const u32x4 ql = F16 ? qh : frag(Qlo + (j * 32 + r) * KS + c * 16 + 8 * h);
+                    s[j] = mfma3<F16>(ah, al, qh, ql, s[j]);
                 }
             }
             const int kbase = k_begin + tile * 32;
@@ -212,9 +273,9 @@ __global__ __launch_bounds__(256, 2) void pool_attn_x3_kernel(const float* __res
             }
 #pragma unroll
             for (int sg = 0; sg < 2; ++sg) {   // the tile's two 16-key chunks
-                bf16x8 ph[2], pl[2];
+                u32x4 ph[2], pl[2];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) split_acc8(s[j], 8 * sg, ph[j], pl[j]);
+                for (int j = 0; j < 2; ++j) split_acc8<F16>(s[j], 8 * sg, ph[j], pl[j]);
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
                     const int o0 = vt_off<DT>(16 * sg + 4 * h + tq, dt * 32 + tcol);
@@ -222,12 +283,15 @@ __global__ __launch_bounds__(256, 2) void pool_attn_x3_kernel(const float* __res
                     typedef __attribute__((address_space(3))) s16x4* lp;
                     const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(Vhi + o0));
                     const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(Vhi + o1));
-                    const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(Vlo + o0));
-                    const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(Vlo + o1));
-                    const bf16x8 vh = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
-                    const bf16x8 vl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    const u32x4 vh = __builtin_bit_cast(u32x4, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    u32x4 vl = vh;
+                    if (!F16) {
+                        const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(Vlo + o0));
+                        const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(Vlo + o1));
+                        vl = __builtin_bit_cast(u32x4, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    }
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) O[dt][j] = mfma3(vh, vl, ph[j], pl[j], O[dt][j]);
+                    for (int j = 0; j < 2; ++j) O[dt][j] = mfma3<F16>(vh, vl, ph[j], pl[j], O[dt][j]);
                 }
             }
         }
@@ -282,7 +346,8 @@ __global__ __launch_bounds__(256, 2) void pool_attn_x3_kernel(const float* __res
 }
 
 // ----------------------------------------------------------------------------------- unpool
-template <int HD>
+// IO16 (fp16 mode only): q and out are fp16 tensors (written by the q projection / read by out_proj in that form)
+template <int HD, bool F16, bool IO16>
 __global__ __launch_bounds__(256, 2) void unpool_attn_x3_kernel(const float* __restrict__ q,
                                                              const float* __restrict__ kvh, float* __restrict__ out,
                                                              int B, int N, int C, int H, int tiles_per_wave,
@@ -294,7 +359,8 @@ __global__ __launch_bounds__(256, 2) void unpool_attn_x3_kernel(const float* __r
     constexpr int LD_IT = (32 * CH + 63) / 64;
     constexpr int NC = HD / 16;
     constexpr int OP = HD + 4;            // fp32 row stride of the output transpose tile (aliases the Q planes)
-    static_assert(32 * OP * 4 <= 2 * 32 * KS * 2, "output tile must fit in the wave's Q planes");
+    constexpr int NP = F16 ? 1 : 2;       // planes per operand
+    constexpr int QW = 32 * OP * 2 > NP * 32 * KS ? 32 * OP * 2 : NP * 32 * KS;   // u16 per wave: Q planes, later the fp32 output tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
     u16* lds = reinterpret_cast<u16*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -303,41 +369,56 @@ __global__ __launch_bounds__(256, 2) void unpool_attn_x3_kernel(const float* __r
     const int b = bh / H, hh = bh % H;
 
     u16* Khi = lds;                        // [64][KS]
-    u16* Klo = Khi + 64 * KS;
-    u16* Vthi = Klo + 64 * KS;             // [DT * 32][VS]: row = head-dim index, keys permuted inside 16-chunks
-    u16* Vtlo = Vthi + DT * 32 * VS;
-    u16* Qhi = Vtlo + DT * 32 * VS + wave * 2 * 32 * KS;
-    u16* Qlo = Qhi + 32 * KS;
+    u16* Klo = F16 ? Khi : Khi + 64 * KS;
+    u16* Vthi = Khi + NP * 64 * KS;        // [DT * 32][VS]: row = head-dim index, keys permuted inside 16-chunks
+    u16* Vtlo = F16 ? Vthi : Vthi + DT * 32 * VS;
+    u16* Qhi = Vthi + NP * DT * 32 * VS + wave * QW;
+    u16* Qlo = F16 ? Qhi : Qhi + 32 * KS;
     float* Ot = reinterpret_cast<float*>(Qhi);   // [32][OP] fp32, after the Q fragments are consumed
 
     for (int f = tid; f < DT * 32 * VS / 2; f += 256) {   // zero the value planes: padded head-dim rows stay finite
         reinterpret_cast<unsigned*>(Vthi)[f] = 0u;
-        reinterpret_cast<unsigned*>(Vtlo)[f] = 0u;
+        if (!F16) reinterpret_cast<unsigned*>(Vtlo)[f] = 0u;
     }
     __syncthreads();
     for (int f = tid; f < 64 * CH; f += 256) {
         const int key = f / CH, ch = f % CH;
         const float* src = kvh + ((size_t)b * 64 + key) * 2 * C + hh * HD + ch * 4;
         u32x2 hi, lo;
-        split4(*reinterpret_cast<const f32x4*>(src), hi, lo);
+        split4<F16>(*reinterpret_cast<const f32x4*>(src), hi, lo);
         *reinterpret_cast<u32x2*>(Khi + key * KS + ch * 4) = hi;
-        *reinterpret_cast<u32x2*>(Klo + key * KS + ch * 4) = lo;
-        split4(*reinterpret_cast<const f32x4*>(src + C), hi, lo);
+        if (!F16) *reinterpret_cast<u32x2*>(Klo + key * KS + ch * 4) = lo;
+        split4<F16>(*reinterpret_cast<const f32x4*>(src + C), hi, lo);
         // key 16c + 8a + 4g + i sits at position 16c + 8g + 4a + i: lane half g reads its 8 keys contiguously
         const int pos = (key & ~15) + 8 * ((key >> 2) & 1) + 4 * ((key >> 3) & 1) + (key & 3);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             Vthi[(ch * 4 + e) * VS + pos] = (u16)(hi[e >> 1] >> (16 * (e & 1)));
-            Vtlo[(ch * 4 + e) * VS + pos] = (u16)(lo[e >> 1] >> (16 * (e & 1)));
+            if (!F16) Vtlo[(ch * 4 + e) * VS + pos] = (u16)(lo[e >> 1] >> (16 * (e & 1)));
         }
     }
     const float scale = LOG2E * rsqrtf((float)HD);
     const float* qb = q + (size_t)b * N * C + hh * HD;
     float* ob = out + (size_t)b * N * C + hh * HD;
 
-    f32x4 rq[LD_IT];
+    static_assert(!IO16 || F16, "fp16 tensors exist in fp16 mode only");
+    constexpr int CH8 = HD / 8, LD8 = (32 * CH8 + 63) / 64;
+    const _Float16* qb16 = reinterpret_cast<const _Float16*>(q) + (size_t)b * N * C + hh * HD;
+    _Float16* ob16 = reinterpret_cast<_Float16*>(out) + (size_t)b * N * C + hh * HD;
+    f32x4 rq[IO16 ? 1 : LD_IT];
+    u32x4 rq8[IO16 ? LD8 : 1];
     auto load_q = [&](int it) {
         const int q0 = (chunk * tiles_per_wave + it) * 128 + wave * 32;
+        if (IO16) {
+#pragma unroll
+            for (int ld = 0; ld < LD8; ++ld) {
+                const int f = ld * 64 + lane, row = f / CH8, c8 = f % CH8, n = q0 + row;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (f < 32 * CH8 && it < tiles_per_wave && n < N) v = *reinterpret_cast<const u32x4*>(qb16 + (size_t)n * C + c8 * 8);
+                rq8[ld] = v;
+            }
+            return;
+        }
 #pragma unroll
         for (int ld = 0; ld < LD_IT; ++ld) {
             const int f = ld * 64 + lane, row = f / CH, ch = f % CH, n = q0 + row;
@@ -349,14 +430,24 @@ __global__ __launch_bounds__(256, 2) void unpool_attn_x3_kernel(const float* __r
     load_q(0);
     for (int it = 0; it < tiles_per_wave; ++it) {
         const int q0 = (chunk * tiles_per_wave + it) * 128 + wave * 32;
+        // fp16 mode: the queries are rounded as they are and the softmax scale multiplies S in fp32 (so a q tensor
+        // already stored as fp16 gives the same bits); split-bf16 mode: scaled before the split
+        if (IO16) {
 #pragma unroll
-        for (int ld = 0; ld < LD_IT; ++ld) {
-            const int f = ld * 64 + lane, row = f / CH, ch = f % CH;
-            if (f < 32 * CH) {
-                u32x2 hi, lo;
-                split4(rq[ld] * scale, hi, lo);
-                *reinterpret_cast<u32x2*>(Qhi + row * KS + ch * 4) = hi;
-                *reinterpret_cast<u32x2*>(Qlo + row * KS + ch * 4) = lo;
+            for (int ld = 0; ld < LD8; ++ld) {
+                const int f = ld * 64 + lane, row = f / CH8, c8 = f % CH8;
+                if (f < 32 * CH8) *reinterpret_cast<u32x4*>(Qhi + row * KS + c8 * 8) = rq8[ld];
+            }
+        } else {
+#pragma unroll
+            for (int ld = 0; ld < LD_IT; ++ld) {
+                const int f = ld * 64 + lane, row = f / CH, ch = f % CH;
+                if (f < 32 * CH) {
+                    u32x2 hi, lo;
+                    split4<F16>(F16 ? rq[ld] : rq[ld] * scale, hi, lo);
+                    *reinterpret_cast<u32x2*>(Qhi + row * KS + ch * 4) = hi;
+                    if (!F16) *reinterpret_cast<u32x2*>(Qlo + row * KS + ch * 4) = lo;
+                }
             }
         }
         load_q(it + 1);
@@ -369,19 +460,23 @@ __global__ __launch_bounds__(256, 2) void unpool_attn_x3_kernel(const float* __r
             for (int e = 0; e < 16; ++e) s[kt][e] = 0.f;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const bf16x8 qh = frag(Qhi + r * KS + c * 16 + 8 * h), ql = frag(Qlo + r * KS + c * 16 + 8 * h);
+            const u32x4 qh = frag(Qhi + r * KS + c * 16 + 8 * h);
+            const u32x4 ql = F16 ? qh : frag(Qlo + r * KS + c * 16 + 8 * h);
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
-                const bf16x8 kh = frag(Khi + (kt * 32 + r) * KS + c * 16 + 8 * h);
-                const bf16x8 kl = frag(Klo + (kt * 32 + r) * KS + c * 16 + 8 * h);
-                s[kt] = mfma3(kh, kl, qh, ql, s[kt]);
+                const u32x4 kh = frag(Khi + (kt * 32 + r) * KS + c * 16 + 8 * h);
+                const u32x4 kl = F16 ? kh : frag(Klo + (kt * 32 + r) * KS + c * 16 + 8 * h);
+                s[kt] = mfma3<F16>(kh, kl, qh, ql, s[kt]);
             }
         }
         float mx = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[kt][e]);
+            for (int e = 0; e < 16; ++e) {
+                if (F16) s[kt][e] *= scale;
+                mx = fmaxf(mx, s[kt][e]);
+            }
         mx = fmaxf(mx, xor32(mx));
         float ls = 0.f;
 #pragma unroll
@@ -402,14 +497,14 @@ __global__ __launch_bounds__(256, 2) void unpool_attn_x3_kernel(const float* __r
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int sg = 0; sg < 2; ++sg) {
-                bf16x8 ph, pl;
-                split_acc8(s[kt], 8 * sg, ph, pl);
+                u32x4 ph, pl;
+                split_acc8<F16>(s[kt], 8 * sg, ph, pl);
                 const int c16 = 2 * kt + sg;   // 16-key chunk of the 64 inducers
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
-                    const bf16x8 vh = frag(Vthi + (dt * 32 + r) * VS + c16 * 16 + 8 * h);
-                    const bf16x8 vl = frag(Vtlo + (dt * 32 + r) * VS + c16 * 16 + 8 * h);
-                    O[dt] = mfma3(vh, vl, ph, pl, O[dt]);
+                    const u32x4 vh = frag(Vthi + (dt * 32 + r) * VS + c16 * 16 + 8 * h);
+                    const u32x4 vl = F16 ? vh : frag(Vtlo + (dt * 32 + r) * VS + c16 * 16 + 8 * h);
+                    O[dt] = mfma3<F16>(vh, vl, ph, pl, O[dt]);
                 }
             }
         wave_lds_sync();   // the Q fragments are consumed: their planes become the fp32 output tile
@@ -425,49 +520,68 @@ __global__ __launch_bounds__(256, 2) void unpool_attn_x3_kernel(const float* __r
                 }
             }
         wave_lds_sync();
+        if (IO16) {
 #pragma unroll
-        for (int ld = 0; ld < LD_IT; ++ld) {
-            const int f = ld * 64 + lane, row = f / CH, ch = f % CH, n = q0 + row;
-            if (f < 32 * CH && n < N)
-                *reinterpret_cast<f32x4*>(ob + (size_t)n * C + ch * 4) =
-                    *reinterpret_cast<const f32x4*>(Ot + row * OP + ch * 4);
+            for (int ld = 0; ld < LD8; ++ld) {
+                const int f = ld * 64 + lane, row = f / CH8, c8 = f % CH8, n = q0 + row;
+                if (f < 32 * CH8 && n < N) {
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(Ot + row * OP + c8 * 8);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(Ot + row * OP + c8 * 8 + 4);
+                    f16x8 hv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        hv[e] = (_Float16)v0[e];
+                        hv[4 + e] = (_Float16)v1[e];
+                    }
+                    *reinterpret_cast<u32x4*>(ob16 + (size_t)n * C + c8 * 8) = __builtin_bit_cast(u32x4, hv);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ld = 0; ld < LD_IT; ++ld) {
+                const int f = ld * 64 + lane, row = f / CH, ch = f % CH, n = q0 + row;
+                if (f < 32 * CH && n < N)
+                    *reinterpret_cast<f32x4*>(ob + (size_t)n * C + ch * 4) =
+                        *reinterpret_cast<const f32x4*>(Ot + row * OP + ch * 4);
+            }
         }
         wave_lds_sync();
     }
 }
 
-template <int HD>
+template <int HD, bool F16, bool IO16>
 int pool_x3_launch_t(const float* KV, const float* ind, float* po, float* pml, int B, int N, int C, int H, int nsplit,
                      hipStream_t st) {
-    constexpr int KS = HD + 8, DT = (HD + 31) / 32, VT = 8 * DT * 128;
-    const size_t a = ((size_t)2 * 64 * KS + 4 * (2 * 32 * KS + 2 * VT)) * 2, c = ((size_t)4 * HD * 64 + 512) * 4;
+    constexpr int KS = HD + 8, DT = (HD + 31) / 32, VT = 8 * DT * 128, NP = F16 ? 1 : 2;
+    const size_t a = ((size_t)NP * 64 * KS + 4 * NP * (32 * KS + VT)) * 2, c = ((size_t)4 * HD * 64 + 512) * 4;
     const size_t lds = a > c ? a : c;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pool_attn_x3_kernel<HD>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pool_attn_x3_kernel<HD, F16, IO16>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((pool_attn_x3_kernel<HD>), dim3(B * H * nsplit), dim3(256), lds, st, KV, ind, po, pml, B, N, C,
+    hipLaunchKernelGGL((pool_attn_x3_kernel<HD, F16, IO16>), dim3(B * H * nsplit), dim3(256), lds, st, KV, ind, po, pml, B, N, C,
                        H, nsplit);
     return (int)hipGetLastError();
 }
 
-template <int HD>
+template <int HD, bool F16, bool IO16>
 int unpool_x3_launch_t(const float* q, const float* kvh, float* out, int B, int N, int C, int H, hipStream_t st) {
-    constexpr int KS = HD + 8, VS = 72, DT = (HD + 31) / 32;
-    const size_t lds = ((size_t)2 * 64 * KS + 2 * DT * 32 * VS + 4 * 2 * 32 * KS) * 2;
+    constexpr int KS = HD + 8, VS = 72, DT = (HD + 31) / 32, NP = F16 ? 1 : 2, OP = HD + 4;
+    constexpr int QW = 32 * OP * 2 > NP * 32 * KS ? 32 * OP * 2 : NP * 32 * KS;
+    const size_t lds = ((size_t)NP * 64 * KS + NP * DT * 32 * VS + 4 * QW) * 2;
     const int tiles = (N + 127) / 128;
     int tpw = 1;
     while (tpw < 4 && (long)B * H * ((tiles + tpw * 2 - 1) / (tpw * 2)) >= 2048) tpw *= 2;
     const int nchunk = (tiles + tpw - 1) / tpw;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(unpool_attn_x3_kernel<HD>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(unpool_attn_x3_kernel<HD, F16, IO16>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((unpool_attn_x3_kernel<HD>), dim3(B * H * nchunk), dim3(256), lds, st, q, kvh, out, B, N, C, H,
+    hipLaunchKernelGGL((unpool_attn_x3_kernel<HD, F16, IO16>), dim3(B * H * nchunk), dim3(256), lds, st, q, kvh, out, B, N, C, H,
                        tpw, nchunk);
     return (int)hipGetLastError();
 }
@@ -477,22 +591,37 @@ int unpool_x3_launch_t(const float* q, const float* kvh, float* out, int B, int 
 bool attn_x3_supported(int HD) { return HD == 16 || HD == 32 || HD == 48 || HD == 64; }
 
 int pool_attn_x3_partials_launch(const float* KV, const float* inducers, float* part_o, float* part_ml, int B, int N,
-                                 int C, int H, int nsplit, hipStream_t st) {
+                                 int C, int H, int nsplit, hipStream_t st, int precision, int io16) {
+    if (io16 && precision != 2) return -9;
+#define POOL_CASE(HD)                                                                                                    \
+    case HD:                                                                                                             \
+        return io16 ? pool_x3_launch_t<HD, true, true>(KV, inducers, part_o, part_ml, B, N, C, H, nsplit, st)            \
+               : precision == 2 ? pool_x3_launch_t<HD, true, false>(KV, inducers, part_o, part_ml, B, N, C, H, nsplit, st) \
+                                : pool_x3_launch_t<HD, false, false>(KV, inducers, part_o, part_ml, B, N, C, H, nsplit, st)
     switch (C / H) {
-        case 16: return pool_x3_launch_t<16>(KV, inducers, part_o, part_ml, B, N, C, H, nsplit, st);
-        case 32: return pool_x3_launch_t<32>(KV, inducers, part_o, part_ml, B, N, C, H, nsplit, st);
-        case 48: return pool_x3_launch_t<48>(KV, inducers, part_o, part_ml, B, N, C, H, nsplit, st);
-        case 64: return pool_x3_launch_t<64>(KV, inducers, part_o, part_ml, B, N, C, H, nsplit, st);
+        POOL_CASE(16);
+        POOL_CASE(32);
+        POOL_CASE(48);
+        POOL_CASE(64);
         default: return -4;
     }
+#undef POOL_CASE
 }
 
-int unpool_attn_x3_launch(const float* q, const float* kvh, float* out, int B, int N, int C, int H, hipStream_t st) {
+int unpool_attn_x3_launch(const float* q, const float* kvh, float* out, int B, int N, int C, int H, hipStream_t st,
+                          int precision, int io16) {
+    if (io16 && precision != 2) return -9;
+#define UNPOOL_CASE(HD)                                                                                \
+    case HD:                                                                                           \
+        return io16 ? unpool_x3_launch_t<HD, true, true>(q, kvh, out, B, N, C, H, st)                  \
+               : precision == 2 ? unpool_x3_launch_t<HD, true, false>(q, kvh, out, B, N, C, H, st)     \
+                                : unpool_x3_launch_t<HD, false, false>(q, kvh, out, B, N, C, H, st)
     switch (C / H) {
-        case 16: return unpool_x3_launch_t<16>(q, kvh, out, B, N, C, H, st);
-        case 32: return unpool_x3_launch_t<32>(q, kvh, out, B, N, C, H, st);
-        case 48: return unpool_x3_launch_t<48>(q, kvh, out, B, N, C, H, st);
-        case 64: return unpool_x3_launch_t<64>(q, kvh, out, B, N, C, H, st);
+        UNPOOL_CASE(16);
+        UNPOOL_CASE(32);
+        UNPOOL_CASE(48);
+        UNPOOL_CASE(64);
         default: return -4;
     }
+#undef UNPOOL_CASE
 }

@@ -1,0 +1,177 @@
+// Shared pieces of the LDS-DMA GEMM kernels (gemm_f32_dma.hip: fp32 / split-bf16, gemm_f16_dma.hip: fp16): block ->
+// tile mapping with the optional second output segment, and the epilogue (bias, GaussianActivation, residual,
+// GroupNorm partials) through a wave-private LDS transpose with 16-byte nontemporal stores.
+#pragma once
+#include "common.h"
+#include "kernels.h"
+
+namespace dma {
+
+constexpr int DBN = 128, DNT = 256;
+constexpr int D_TP = 64 + 4;                        // epilogue transpose tile row stride
+constexpr int D_EPI = 4 * 32 * D_TP + 4 * 2 * DBN;  // 4 wave sub-tiles (32 x 64) + column partials = 38 KiB
+
+__device__ __forceinline__ void dma16(const void* gsrc, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N>
+__device__ __forceinline__ void wait_vm_lgkm0() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
+
+// Which tile this block computes.  Optional second output segment (two linears over the same A in one launch): whole
+// column tiles belong to one segment (n_split % 128 == 0); columns below are relative to the segment.
+struct Tile {
+    int tilesM, ct, rt, b, m0, n0;
+    int nseg0, nseg;          // first column of the tile inside its segment; columns of the segment
+    const float* Wseg;
+    const float* bias_seg;
+    float* Cseg;
+    int ldc_seg;
+};
+
+template <int BM>
+__device__ __forceinline__ Tile tile_of_block(const GemmArgs& g) {
+    Tile t;
+    t.tilesM = (g.rows + BM - 1) / BM;
+    const int tilesN = (g.Nout + DBN - 1) / DBN;
+    const int nblk = g.B * t.tilesM * tilesN;
+    const int v = xcd_remap(blockIdx.x, nblk);
+    t.ct = v % tilesN;
+    const int panel = v / tilesN;
+    t.rt = panel % t.tilesM;
+    t.b = panel / t.tilesM;
+    t.m0 = t.rt * BM;
+    t.n0 = t.ct * DBN;
+    const bool seg2 = g.C2 != nullptr && t.n0 >= g.n_split;
+    t.nseg0 = seg2 ? t.n0 - g.n_split : t.n0;
+    t.nseg = g.C2 ? (seg2 ? g.Nout - g.n_split : g.n_split) : g.Nout;
+    t.Wseg = seg2 ? g.W2 : g.W;
+    t.bias_seg = seg2 ? g.bias2 : g.bias;
+    t.Cseg = seg2 ? g.C2 : g.C;
+    t.ldc_seg = seg2 ? g.ldc2 : g.ldc;
+    return t;
+}
+
+// acc[i][j]: the wave's 32 x 32 accumulator tiles (C/D layout), wave (wm, wn) of a WMN x (4 / WMN) wave grid.
+// Must be entered by all 256 threads with the operand ring dead (it reuses the LDS from offset 0).
+// C16: the output is stored as fp16 (round to nearest even; an intermediate its consumer would round anyway) — no
+// residual, no statistics in that form; ldc counts fp16 elements.
+template <int TMW, int TNW, int WMN, bool C16 = false>
+__device__ __forceinline__ void epilogue(const GemmArgs& g, const Tile& t, f32x16 (&acc)[TMW][TNW], float* smem,
+                                         int wave, int lane, int wm, int wn) {
+    const int tid = threadIdx.x, r = lane & 31, h = lane >> 5;
+    const int b = t.b, rt = t.rt, m0 = t.m0, n0 = t.n0, nseg0 = t.nseg0, nseg = t.nseg, tilesM = t.tilesM;
+    const float* bias_seg = t.bias_seg;
+    float* Cseg = t.Cseg;
+    const int ldc_seg = t.ldc_seg;
+    const bool has_act = g.act != 0, act_norm = g.act == 1;
+    const float neg_inv_2a2 = has_act ? -1.0f / (2.0f * g.alpha[0] * g.alpha[0]) : 0.f;
+    float* Cb = Cseg + (size_t)b * g.rows * ldc_seg;
+    const float* Rb = g.residual ? g.residual + (size_t)b * g.rows * g.ldr : nullptr;
+    float* Tt = smem + wave * 32 * D_TP;
+    float* red = smem + 4 * 32 * D_TP;
+    const int lr = lane >> 4, c4 = lane & 15;   // 16 lanes per 64-float row, 4 rows per wave-instruction
+    constexpr int NJH = TNW / 2;                // 64-column halves of the wave tile
+    f32x4 s1[NJH], s2[NJH];
+#pragma unroll
+    for (int jh = 0; jh < NJH; ++jh) {
+        s1[jh] = f32x4{0.f, 0.f, 0.f, 0.f};
+        s2[jh] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // the wave's 32 x 64 sub-tiles, one after the other through the same wave-private LDS tile
+#pragma unroll
+    for (int i = 0; i < TMW; ++i) {
+#pragma unroll
+        for (int jh = 0; jh < NJH; ++jh) {
+            const int ncol0 = nseg0 + (wn * TNW + 2 * jh) * 32;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int nn = ncol0 + jj * 32 + r;
+                const float bias = bias_seg ? bias_seg[nn < nseg ? nn : nseg - 1] : 0.f;
+                f32x16 val = acc[i][2 * jh + jj];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) val[e] += bias;
+                if (has_act) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) val[e] = gauss_act(val[e], neg_inv_2a2, act_norm);
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) Tt[mfma_row(e, h) * D_TP + jj * 32 + r] = val[e];
+            }
+            __syncthreads();
+            const int n = ncol0 + c4 * 4;
+            const bool nok = n < nseg;
+            const int nc = nok ? n : 0;
+            const int mrow0 = m0 + (wm * TMW + i) * 32;
+#pragma unroll
+            for (int it0 = 0; it0 < 8; it0 += 4) {
+                f32x4 rres[4];
+                if (Rb) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int m = min(mrow0 + (it0 + c) * 4 + lr, g.rows - 1);
+                        rres[c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Rb + (size_t)m * g.ldr + nc));
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int it = it0 + c;
+                    const int m = mrow0 + it * 4 + lr;
+                    f32x4 v4 = *reinterpret_cast<const f32x4*>(Tt + (it * 4 + lr) * D_TP + c4 * 4);
+                    if (Rb) v4 += rres[c];
+                    const bool ok = nok && m < g.rows;
+                    if (C16) {
+                        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                        f16x4 hv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hv[e] = (_Float16)v4[e];
+                        if (ok)
+                            __builtin_nontemporal_store(__builtin_bit_cast(u32x2, hv),
+                                                        reinterpret_cast<u32x2*>(reinterpret_cast<_Float16*>(Cseg) +
+                                                                                 ((size_t)b * g.rows + m) * ldc_seg + n));
+                    } else if (ok) {
+                        __builtin_nontemporal_store(v4, reinterpret_cast<f32x4*>(Cb + (size_t)m * ldc_seg + n));
+                    }
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    const f32x4 vz = ok ? v4 : z;
+                    s1[jh] += vz;
+                    s2[jh] += vz * vz;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (g.stats) {
+#pragma unroll
+        for (int jh = 0; jh < NJH; ++jh) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                s1[jh][q] += __shfl_xor(s1[jh][q], 16, 64);
+                s1[jh][q] += __shfl_xor(s1[jh][q], 32, 64);
+                s2[jh][q] += __shfl_xor(s2[jh][q], 16, 64);
+                s2[jh][q] += __shfl_xor(s2[jh][q], 32, 64);
+            }
+            if (lane < 16) {
+                const int cl = (wn * TNW + 2 * jh) * 32 + c4 * 4;
+                *reinterpret_cast<f32x4*>(red + (wm * 2 + 0) * DBN + cl) = s1[jh];
+                *reinterpret_cast<f32x4*>(red + (wm * 2 + 1) * DBN + cl) = s2[jh];
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < 2 * DBN; c += DNT) {
+            const int which = c / DBN, cl = c % DBN, nn = n0 + cl;
+            if (nn < g.Nout) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < WMN; ++w) t += red[(w * 2 + which) * DBN + cl];
+                g.stats[(((size_t)b * tilesM + rt) * 2 + which) * g.Nout + nn] = t;
+            }
+        }
+    }
+}
+
+}  // namespace dma

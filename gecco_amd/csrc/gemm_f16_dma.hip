@@ -1,0 +1,327 @@
+// Fused linear layer, LDS-DMA kernel in fp16 arithmetic (precision 2): same contract as gemm_f32_dma.hip
+//
+//   C[b, m, n] = residual[b, m, n] + act( sum_k (A[b, m, k] * pa[b, k] + po[b, k]) * W[n, k] + bias[n] )  (+ GroupNorm partials)
+//
+// with both operands rounded to fp16 (round-to-nearest-even) and ONE v_mfma_f32_32x32x16_f16 per 16 k, fp32
+// accumulation.  fp16 keeps 11 significant bits: measured 3.0e-4 from the fp32 reference on the golden networks
+// (plain bf16: 2.3e-3, which misses the 1e-3 bar; split-bf16: 1.3e-5 at 3x the matrix work).  Every fp16 operand of
+// the path is range-safe by construction: the A operand is an AdaGN output, a GaussianActivation output, a softmax
+// average of projected inducer states or a point coordinate scaled by c_in; W are layer weights.
+//
+// With a third of the matrix work of the split-bf16 kernel the loop is bound by the tile fill, so it differs where
+// that matters (measured with tools/probe/dma_rate.hip):
+//   * K-steps of 32: the fp32 A tile is [BM][32] — a DMA wave-instruction moves 8 rows x 128 B, whole cache lines —
+//     and one barrier / wait / issue round covers 8 MFMAs per wave instead of 4;
+//   * W travels as a pre-tiled fp16 image (split_f16_tiled_kernel): one 8 KiB block per (128-column tile, K-step)
+//     that IS the LDS image, so its DMA pieces are 1 KiB of consecutive bytes and B costs 2 bytes per element;
+//   * k permutation: lane half h owns k = 16h .. 16h+15 of a K-step (64 consecutive bytes of its A row, four
+//     ds_read_b128); MFMA c of the step multiplies k = 16h + 8c .. 16h + 8c + 7 — the image stores W in that order.
+// Ring of DNS stages with the K-step being multiplied held in registers (two fragment sets), counted vmcnt waits and
+// one raw s_barrier per K-step as in the split-bf16 kernel.  Requires K % 32 == 0, Nout % 4 == 0, rows >= 64.
+#include "gemm_dma_common.h"
+
+#include <stdlib.h>
+
+namespace {
+
+using dma::DBN;
+using dma::DNT;
+using dma::D_EPI;
+using dma::dma16;
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int FBK = 32;                    // k per ring stage
+constexpr int FB_TILE = DBN * FBK / 2;     // floats of the fp16 W tile per stage (8 KiB)
+constexpr int fa_tile(int bm, bool a16) { return a16 ? bm * FBK / 2 : bm * FBK; }   // floats of the A tile per stage
+constexpr int f_stage(int bm, bool a16) { return fa_tile(bm, a16) + FB_TILE; }
+constexpr int f_main_floats(int ns, int bm, bool a16) {
+    return ns * f_stage(bm, a16) > D_EPI ? ns * f_stage(bm, a16) : D_EPI;
+}
+
+__device__ __forceinline__ f16x8 cvt8(const f32x4& x0, const f32x4& x1) {
+    f16x8 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[e] = (_Float16)x0[e];
+        v[4 + e] = (_Float16)x1[e];
+    }
+    return v;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_ahead(int ahead, bool lgkm) {
+    // N = DMA wave-instructions per wave per K-step; `ahead` K-steps may stay in flight
+    if (lgkm) {
+        if (ahead >= 2) dma::wait_vm_lgkm0<2 * N>();
+        else if (ahead == 1) dma::wait_vm_lgkm0<N>();
+        else dma::wait_vm_lgkm0<0>();
+    } else {
+        if (ahead >= 2) dma::wait_vm<2 * N>();
+        else if (ahead == 1) dma::wait_vm<N>();
+        else dma::wait_vm<0>();
+    }
+}
+
+#ifdef GEMM_STAMPS   // diagnostic build (tools/probe): per-block s_memtime stamps of the kernel's phases
+__device__ unsigned long long g_stamps[16384 * 8];
+#define STAMP(i)                                                                                     \
+    do {                                                                                             \
+        if (threadIdx.x == 0 && blockIdx.x < 16384) g_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define STAMP(i)
+#endif
+
+// A16: the A operand is already fp16 in memory (an intermediate a previous kernel stored that way): its tile is laid
+// out like the W tile (64-byte rows, 16 rows per DMA piece), fragments are read as they are, 16 KiB per stage and
+// three blocks per CU.  C16: the output is stored as fp16 (dma::epilogue).
+template <int DNS, bool HAS_PRO, int BM, bool A16, bool C16>
+__global__ __launch_bounds__(DNT, A16 ? 3 : 2) void gemm_f16_kernel(GemmArgs g) {
+    static_assert(DNS == 2 || DNS == 3, "ring of 2 or 3 stages");
+    static_assert(!(A16 && HAS_PRO), "the AdaGN prologue needs the fp32 operand");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int A_TILE = fa_tile(BM, A16), STAGE = f_stage(BM, A16);
+    float* pro_lds = smem + f_main_floats(DNS, BM, A16);   // pa[0..K) | po[0..K)
+
+    STAMP(0);
+    const dma::Tile T = dma::tile_of_block<BM>(g);
+    const int ct = T.ct, b = T.b, m0 = T.m0;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // 128-row tiles: 4 x 1 waves of 32 x 128 (A rows are wave-private); 64-row tiles: 2 x 2 waves of 32 x 64
+    constexpr int WMN = BM == 128 ? 4 : 2, WNN = 4 / WMN;
+    constexpr int TMW = 1, TNW = 4 / WNN;
+    constexpr int NAP = A16 ? BM / 64 : BM / 32;   // A pieces (8 rows x 128 B, or 16 rows x 64 B of fp16) per wave per K-step
+    constexpr int NPIECE = NAP + 2;    // + two 1 KiB pieces of the W image
+    const int wm = wave / WNN, wn = wave % WNN;
+    const int r = lane & 31, h = lane >> 5;
+
+    // ---- DMA sources.  A piece p = rows 8p .. 8p+7, lane l -> row 8p + (l >> 3), LDS chunk l & 7 holding global
+    // chunk (l & 7) ^ ((row >> 1) & 7) (the read-side swizzle, applied to the source address).
+    // fp16 A: piece p = rows 16p .. 16p+15, lane l -> row 16p + (l >> 2), LDS chunk l & 3 <- global chunk ^ ((row >> 2) & 3).
+    const float* asrc[NAP];   // advanced by one K-step = 32 k: 32 floats, or 16 floats' worth of fp16
+    constexpr int A_KSTEP = A16 ? FBK / 2 : FBK;
+#pragma unroll
+    for (int q = 0; q < NAP; ++q) {
+        if (A16) {
+            const _Float16* Ab = reinterpret_cast<const _Float16*>(g.A) + (size_t)b * g.rows * g.lda;
+            const int row = (NAP * wave + q) * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ ((row >> 2) & 3);
+            asrc[q] = reinterpret_cast<const float*>(Ab + (size_t)min(m0 + row, g.rows - 1) * g.lda + c * 8);
+        } else {
+            const float* Ab = g.A + (size_t)b * g.rows * g.lda;
+            const int row = (NAP * wave + q) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            asrc[q] = Ab + (size_t)min(m0 + row, g.rows - 1) * g.lda + c * 4;
+        }
+    }
+    const int nk = g.K / FBK;
+    const float* bsrc = static_cast<const float*>(g.w_img) + (size_t)ct * nk * FB_TILE + (2 * wave) * 256 + lane * 4;
+    auto issue = [&](int kt) {
+#ifdef GEMM_DIAG_NODMA
+        return;
+#endif
+        float* st = smem + (kt % DNS) * STAGE;
+#pragma unroll
+        for (int q = 0; q < NAP; ++q) dma16(asrc[q] + kt * A_KSTEP, st + (NAP * wave + q) * 256);
+        dma16(bsrc + (size_t)kt * FB_TILE, st + A_TILE + (2 * wave) * 256);
+        dma16(bsrc + (size_t)kt * FB_TILE + 256, st + A_TILE + (2 * wave + 1) * 256);
+    };
+
+    if (HAS_PRO) {  // park the AdaGN coefficients of this sample (ordinary loads, drained before the ring starts)
+        const float* pa = g.pro_a + (size_t)b * g.K;
+        const float* po = g.pro_o + (size_t)b * g.K;
+        for (int i = tid; i < g.K; i += DNT) {
+            pro_lds[i] = pa[i];
+            pro_lds[g.K + i] = po[i];
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    STAMP(1);
+#pragma unroll
+    for (int p = 0; p < DNS; ++p)
+        if (p < nk) issue(p);
+
+    f32x16 acc[TMW][TNW];
+#pragma unroll
+    for (int j = 0; j < TNW; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[0][j][e] = 0.f;
+
+    // fragment addressing (float offsets inside a stage)
+    const int ra = wm * 32 + r;
+    int aoff[4], boff[TNW][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        aoff[q] = A16 ? ra * 16 + (((2 * h + (q & 1)) ^ ((ra >> 2) & 3)) << 2)      // q = 0, 1: the two fp16 chunks
+                      : ra * FBK + (((4 * h + q) ^ ((ra >> 1) & 7)) << 2);
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) {
+        const int rb = (wn * TNW + j) * 32 + r;   // fp16 row = 64 B = 16 floats; chunk 2h + c ^ ((rb >> 2) & 3)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) boff[j][c] = A_TILE + rb * 16 + (((2 * h + c) ^ ((rb >> 2) & 3)) << 2);
+    }
+
+    f16x8 fa[2][2], fb[2][TNW][2];   // [set][chunk], [set][column tile][chunk]
+    auto load_frags = [&](const float* st, int kt, int f) {
+        if (A16) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                fa[f][c] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(st + aoff[c]));
+#pragma unroll
+            for (int j = 0; j < TNW; ++j)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    fb[f][j][c] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(st + boff[j][c]));
+            return;
+        }
+        f32x4 x[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x[q] = *reinterpret_cast<const f32x4*>(st + aoff[q]);
+#pragma unroll
+        for (int j = 0; j < TNW; ++j)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                fb[f][j][c] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(st + boff[j][c]));
+        if (HAS_PRO) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 pa4 = *reinterpret_cast<const f32x4*>(pro_lds + kt * FBK + 16 * h + 4 * q);
+                const f32x4 po4 = *reinterpret_cast<const f32x4*>(pro_lds + g.K + kt * FBK + 16 * h + 4 * q);
+                x[q] = x[q] * pa4 + po4;
+            }
+        }
+        fa[f][0] = cvt8(x[0], x[1]);
+        fa[f][1] = cvt8(x[2], x[3]);
+    };
+
+    wait_ahead<NPIECE>(min(nk, DNS) - 1, false);
+    __builtin_amdgcn_s_barrier();
+    STAMP(2);
+    load_frags(smem, 0, 0);   // K-step 0 into set 0
+    auto kstep = [&](int kt, int cur) {
+        // own reads of stage kt are complete (its slot may be refilled) and own pieces of stage kt + 1 landed
+        wait_ahead<NPIECE>(min(nk - 1, kt + DNS - 1) - (kt + 1), true);
+        __builtin_amdgcn_s_barrier();
+        if (kt + DNS < nk) issue(kt + DNS);
+        // next K-step's slot; past the end a landed slot is re-read and the values are never used
+        const int kn = min(kt + 1, nk - 1);
+        load_frags(smem + (kn % DNS) * STAGE, kn, cur ^ 1);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int j = 0; j < TNW; ++j)
+#ifdef GEMM_DIAG_NOMFMA
+                acc[0][j][0] += (float)fa[cur][c][0] + (float)fb[cur][j][c][0];
+#else
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][c], fb[cur][j][c], acc[0][j], 0, 0, 0);
+#endif
+    };
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        kstep(kt, 0);
+        kstep(kt + 1, 1);
+    }
+    if (kt < nk) kstep(kt, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // ring is dead: the epilogue reuses it
+    STAMP(3);
+    dma::epilogue<TMW, TNW, WMN, C16>(g, T, acc, smem, wave, lane, wm, wn);
+    STAMP(4);
+}
+
+// W (Nout, ldw) fp32 -> the tiled fp16 image: for column tile ct (128 rows of W) and K-step kt (32 k) the 8 KiB block
+// at float offset (ct * K/32 + kt) * 2048 holds row rb at rb * 16 floats (64 B = 32 fp16); its 16-byte chunk
+// s ^ ((rb >> 2) & 3) holds k = 16 (s >> 1) + 8 (s & 1) .. +7 (lane half s >> 1, MFMA s & 1 of the step).  Rows past
+// Nout repeat the last row (masked in the GEMM epilogue).  One thread per (block, row, chunk).
+__device__ __forceinline__ void f16_image_item(const float* __restrict__ W, float* __restrict__ img, int Nout, int K,
+                                               int ldw, size_t i) {
+    const int nk = K / FBK;
+    const int chp = (int)(i & 3), rb = (int)((i >> 2) & 127);
+    const size_t blk = i >> 9;
+    const int kt = (int)(blk % nk), ct = (int)(blk / nk);
+    const int s = chp ^ ((rb >> 2) & 3);
+    const float* src = W + (size_t)min(ct * DBN + rb, Nout - 1) * ldw + kt * FBK + 16 * (s >> 1) + 8 * (s & 1);
+    const f16x8 v = cvt8(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4));
+    *reinterpret_cast<u32x4*>(img + blk * FB_TILE + rb * 16 + chp * 4) = __builtin_bit_cast(u32x4, v);
+}
+
+__global__ void split_f16_tiled_kernel(const float* __restrict__ W, float* __restrict__ img, int Nout, int K, int ldw,
+                                       size_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        f16_image_item(W, img, Nout, K, ldw, i);
+}
+
+__global__ void split_f16_tiled_multi_kernel(SplitJobs jobs) {
+    const SplitJob j = jobs.job[blockIdx.y];
+    const size_t total = (size_t)((j.Nout + DBN - 1) / DBN) * (j.K / FBK) * 512;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        f16_image_item(j.W, j.img, j.Nout, j.K, j.ldw, i);
+}
+
+template <int DNS, int BM, bool A16, bool C16>
+int f16_launch_t(const GemmArgs& g, hipStream_t st) {
+    const int tilesM = (g.rows + BM - 1) / BM, tilesN = (g.Nout + DBN - 1) / DBN;
+    const size_t lds = (size_t)(f_main_floats(DNS, BM, A16) + (g.pro_a ? 2 * g.K : 0)) * sizeof(float);
+    static size_t attr = 0;
+    if (lds > attr) {
+        if (!A16)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<DNS, !A16, BM, A16, C16>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<DNS, false, BM, A16, C16>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = lds;
+    }
+    const dim3 grid(g.B * tilesM * tilesN);
+    if (g.pro_a) {
+        if (A16) return -9;
+        hipLaunchKernelGGL((gemm_f16_kernel<DNS, !A16, BM, A16, C16>), grid, dim3(DNT), lds, st, g);
+    } else {
+        hipLaunchKernelGGL((gemm_f16_kernel<DNS, false, BM, A16, C16>), grid, dim3(DNT), lds, st, g);
+    }
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+bool gemm_f16_dma_supported(const GemmArgs& g) {
+    if (g.C2 && ((g.n_split % DBN) || g.stats || g.residual || (g.ldc2 & 3) || g.n_split <= 0 || g.n_split >= g.Nout))
+        return false;
+    if (g.a_f16 && (g.pro_a || (g.lda & 7) || g.rows < 128)) return false;
+    if (g.c_f16 && (g.residual || g.stats || g.rows < 128)) return false;
+    return g.rows >= 64 && g.K % FBK == 0 && g.K <= 1024 && !(g.Nout & 3) && !(g.ldc & 3) && !(g.ldr & 3) &&
+           !(g.lda & 3) && !(g.ldw & 3);
+}
+
+int gemm_f16_dma_launch(const GemmArgs& g, hipStream_t st) {
+    if (!g.w_img) return -9;
+    static int ns = 0;
+    if (!ns) {
+        const char* e = getenv("GECCO_GEMM_F16_STAGES");
+        ns = (e && atoi(e) == 2) ? 2 : 3;
+    }
+    if (g.a_f16 && g.c_f16) return -9;   // not a combination the layer needs
+    if (g.a_f16) return f16_launch_t<3, 128, true, false>(g, st);
+    if (g.c_f16) return f16_launch_t<3, 128, false, true>(g, st);
+    if (g.rows < 128) return ns == 2 ? f16_launch_t<2, 64, false, false>(g, st) : f16_launch_t<3, 64, false, false>(g, st);
+    return ns == 2 ? f16_launch_t<2, 128, false, false>(g, st) : f16_launch_t<3, 128, false, false>(g, st);
+}
+
+size_t split_f16_image_bytes(int Nout, int K) { return (size_t)((Nout + DBN - 1) / DBN) * DBN * K * 2; }
+
+int split_f16_tiled_launch(const float* W, void* img, int Nout, int K, int ldw, hipStream_t st) {
+    const size_t total = (size_t)((Nout + DBN - 1) / DBN) * (K / FBK) * 512;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(split_f16_tiled_kernel, dim3(grid ? grid : 1), dim3(256), 0, st, W, static_cast<float*>(img), Nout,
+                       K, ldw, total);
+    return (int)hipGetLastError();
+}
+
+int split_f16_tiled_multi_launch(const SplitJobs& jobs, hipStream_t st) {
+    if (jobs.n <= 0) return 0;
+    hipLaunchKernelGGL(split_f16_tiled_multi_kernel, dim3(64, jobs.n), dim3(256), 0, st, jobs);
+    return (int)hipGetLastError();
+}

@@ -370,6 +370,7 @@ int gemm_row_tile(int rows) { return rows >= 128 ? 128 : 64; }
 
 int gemm_f32_launch(const GemmArgs& g, hipStream_t st) {
     if (g.K % 4 || g.lda % 4 || g.ldw % 4) return -2;  // 16-byte vector loads
+    if (g.precision == 2 && g.w_img && gemm_f16_dma_supported(g)) return gemm_f16_dma_launch(g, st);
     {
         static int use_dma = -1;  // GECCO_GEMM_DMA=0 forces the register-staged kernel (A/B runs)
         if (use_dma < 0) {

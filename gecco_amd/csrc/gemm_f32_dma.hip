@@ -23,8 +23,7 @@
 //               bf16 planes, tiled per (column tile, K-step) (split_bf16_tiled_kernel); A is split on the fragment,
 //               after the AdaGN affine.
 // Requires K % 16 == 0, Nout % 4 == 0, rows >= 128; everything else runs on gemm_f32.hip.
-#include "common.h"
-#include "kernels.h"
+#include "gemm_dma_common.h"
 
 #include <stdlib.h>
 
@@ -33,17 +32,14 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int DBN = 128, DBK = 16, DNT = 256;   // row tile BM: template parameter (128, or 64 in bf16x3 mode)
+using dma::DBN;
+using dma::DNT;
+using dma::D_EPI;
+using dma::dma16;
+constexpr int DBK = 16;                           // row tile BM: template parameter (128, or 64 in bf16x3 mode)
 constexpr int D_TILE = 128 * DBK;                 // floats per operand tile per stage (8 KiB)
 constexpr int D_STAGE = 2 * D_TILE;               // A then B (fp32 W tile, or bf16 hi | lo planes: same 8 KiB)
-constexpr int D_TP = 64 + 4;                      // epilogue transpose tile row stride
-constexpr int D_EPI = 4 * 32 * D_TP + 4 * 2 * DBN;  // 4 wave sub-tiles (32 x 64) + column partials = 38 KiB
 constexpr int d_main_floats(int ns) { return ns * D_STAGE > D_EPI ? ns * D_STAGE : D_EPI; }
-
-__device__ __forceinline__ void dma16(const void* gsrc, float* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
 
 // 8 fp32 -> bf16 hi (truncation: the top 16 bits) and bf16 lo = rne(x - hi); x - hi is exact in fp32
 __device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, bf16x8& hi, bf16x8& lo) {
@@ -69,21 +65,9 @@ __global__ __launch_bounds__(DNT, DNS <= 3 ? 3 : 2) void gemm_dma_kernel(GemmArg
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* pro_lds = smem + d_main_floats(DNS);   // pa[0..K) | po[0..K)
 
-    const int tilesM = (g.rows + BM - 1) / BM, tilesN = (g.Nout + DBN - 1) / DBN;
-    const int nblk = g.B * tilesM * tilesN;
-    const int v = xcd_remap(blockIdx.x, nblk);
-    const int ct = v % tilesN, panel = v / tilesN;
-    const int rt = panel % tilesM, b = panel / tilesM;
-    const int m0 = rt * BM, n0 = ct * DBN;
-    // optional second output segment (two linears over the same A in one launch): whole column tiles belong to one
-    // segment (n_split % 128 == 0); from here on columns are relative to the segment
-    const bool seg2 = g.C2 != nullptr && n0 >= g.n_split;
-    const int nseg0 = seg2 ? n0 - g.n_split : n0;                       // first column of the tile inside its segment
-    const int nseg = g.C2 ? (seg2 ? g.Nout - g.n_split : g.n_split) : g.Nout;   // columns of the segment
-    const float* Wseg = seg2 ? g.W2 : g.W;
-    const float* bias_seg = seg2 ? g.bias2 : g.bias;
-    float* Cseg = seg2 ? g.C2 : g.C;
-    const int ldc_seg = seg2 ? g.ldc2 : g.ldc;
+    const dma::Tile T = dma::tile_of_block<BM>(g);
+    const int ct = T.ct, b = T.b, m0 = T.m0, nseg0 = T.nseg0, nseg = T.nseg;
+    const float* Wseg = T.Wseg;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -310,100 +294,7 @@ __global__ __launch_bounds__(DNT, DNS <= 3 ? 3 : 2) void gemm_dma_kernel(GemmArg
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // ring is dead: the epilogue reuses it
 
-    // ---------------------------------------------------------------- epilogue (wide: through an LDS transpose)
-    const bool has_act = g.act != 0, act_norm = g.act == 1;
-    const float neg_inv_2a2 = has_act ? -1.0f / (2.0f * g.alpha[0] * g.alpha[0]) : 0.f;
-    float* Cb = Cseg + (size_t)b * g.rows * ldc_seg;
-    const float* Rb = g.residual ? g.residual + (size_t)b * g.rows * g.ldr : nullptr;
-    float* Tt = smem + wave * 32 * D_TP;
-    float* red = smem + 4 * 32 * D_TP;
-    const int lr = lane >> 4, c4 = lane & 15;   // 16 lanes per 64-float row, 4 rows per wave-instruction
-    constexpr int NJH = TNW / 2;                // 64-column halves of the wave tile
-    f32x4 s1[NJH], s2[NJH];
-#pragma unroll
-    for (int jh = 0; jh < NJH; ++jh) {
-        s1[jh] = f32x4{0.f, 0.f, 0.f, 0.f};
-        s2[jh] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    // the wave's 32 x 64 sub-tiles, one after the other through the same wave-private LDS tile
-#pragma unroll
-    for (int i = 0; i < TMW; ++i) {
-#pragma unroll
-        for (int jh = 0; jh < NJH; ++jh) {
-            const int ncol0 = nseg0 + (wn * TNW + 2 * jh) * 32;
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int nn = ncol0 + jj * 32 + r;
-                const float bias = bias_seg ? bias_seg[nn < nseg ? nn : nseg - 1] : 0.f;
-                f32x16 val = acc[i][2 * jh + jj];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) val[e] += bias;
-                if (has_act) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) val[e] = gauss_act(val[e], neg_inv_2a2, act_norm);
-                }
-#pragma unroll
-                for (int e = 0; e < 16; ++e) Tt[mfma_row(e, h) * D_TP + jj * 32 + r] = val[e];
-            }
-            __syncthreads();
-            const int n = ncol0 + c4 * 4;
-            const bool nok = n < nseg;
-            const int nc = nok ? n : 0;
-            const int mrow0 = m0 + (wm * TMW + i) * 32;
-#pragma unroll
-            for (int it0 = 0; it0 < 8; it0 += 4) {
-                f32x4 rres[4];
-                if (Rb) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int m = min(mrow0 + (it0 + c) * 4 + lr, g.rows - 1);
-                        rres[c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Rb + (size_t)m * g.ldr + nc));
-                    }
-                }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int it = it0 + c;
-                    const int m = mrow0 + it * 4 + lr;
-                    f32x4 v4 = *reinterpret_cast<const f32x4*>(Tt + (it * 4 + lr) * D_TP + c4 * 4);
-                    if (Rb) v4 += rres[c];
-                    const bool ok = nok && m < g.rows;
-                    if (ok) __builtin_nontemporal_store(v4, reinterpret_cast<f32x4*>(Cb + (size_t)m * ldc_seg + n));
-                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                    const f32x4 vz = ok ? v4 : z;
-                    s1[jh] += vz;
-                    s2[jh] += vz * vz;
-                }
-            }
-            __syncthreads();
-        }
-    }
-    if (g.stats) {
-#pragma unroll
-        for (int jh = 0; jh < NJH; ++jh) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                s1[jh][q] += __shfl_xor(s1[jh][q], 16, 64);
-                s1[jh][q] += __shfl_xor(s1[jh][q], 32, 64);
-                s2[jh][q] += __shfl_xor(s2[jh][q], 16, 64);
-                s2[jh][q] += __shfl_xor(s2[jh][q], 32, 64);
-            }
-            if (lane < 16) {
-                const int cl = (wn * TNW + 2 * jh) * 32 + c4 * 4;
-                *reinterpret_cast<f32x4*>(red + (wm * 2 + 0) * DBN + cl) = s1[jh];
-                *reinterpret_cast<f32x4*>(red + (wm * 2 + 1) * DBN + cl) = s2[jh];
-            }
-        }
-        __syncthreads();
-        for (int c = tid; c < 2 * DBN; c += DNT) {
-            const int which = c / DBN, cl = c % DBN, nn = n0 + cl;
-            if (nn < g.Nout) {
-                float t = 0.f;
-#pragma unroll
-                for (int w = 0; w < WMN; ++w) t += red[(w * 2 + which) * DBN + cl];
-                g.stats[(((size_t)b * tilesM + rt) * 2 + which) * g.Nout + nn] = t;
-            }
-        }
-    }
+    dma::epilogue<TMW, TNW, WMN>(g, T, acc, smem, wave, lane, wm, wn);
 }
 
 // W (Nout, ldw) fp32 -> the tiled split-bf16 image the X3 kernel streams: for column tile ct (128 rows of W) and

@@ -16,16 +16,21 @@ struct GemmArgs {
     int B, rows, K, Nout;
     int lda, ldw, ldc, ldr;
     int act;                // 0 none, 1 gaussian normalized, 2 gaussian raw
-    int precision;          // 0 exact fp32 MFMA, 1 split-bf16 (needs w_img)
-    const void* w_img;      // tiled bf16 hi | lo image of W (split_bf16_tiled_launch)
+    int precision;          // 0 exact fp32 MFMA, 1 split-bf16, 2 fp16 (1 and 2 need w_img)
+    const void* w_img;      // tiled image of W: bf16 hi | lo (split_bf16_tiled_launch) or fp16 (split_f16_tiled_launch)
     // optional second output segment, LDS-DMA kernel only: columns [n_split, Nout) are a second linear over the same
     // A (weights W2 (Nout - n_split, ldw), bias2) written to C2 (B, rows, ldc2); n_split % 128 == 0, no stats/residual
     float* C2;
     const float* W2;
     const float* bias2;
     int n_split, ldc2;
+    // fp16 kernel only: A is an fp16 tensor (lda in fp16 elements; no prologue) / C (and C2) are stored as fp16
+    // (ldc, ldc2 in fp16 elements; no residual, no stats).  Pointers are passed through the float* fields.
+    int a_f16, c_f16;
 };
 
+struct SplitJob { const float* W; float* img; int Nout, K, ldw, pad_; };
+struct SplitJobs { SplitJob job[32]; int n; };
 int gemm_row_tile(int rows);  // row-tile height the GEMM uses for `rows` rows per sample
 int gemm_f32_launch(const GemmArgs& g, hipStream_t st);
 // gemm_f32_dma.hip — LDS-DMA fast path of the same contract
@@ -33,9 +38,14 @@ bool gemm_f32_dma_supported(const GemmArgs& g, int precision = -1);   // -1: g.p
 int gemm_f32_dma_launch(const GemmArgs& g, hipStream_t st);
 size_t split_bf16_image_bytes(int Nout, int K);   // ceil(Nout / 128) * 128 * K * 4
 int split_bf16_tiled_launch(const float* W, void* img, int Nout, int K, int ldw, hipStream_t st);
-struct SplitJob { const float* W; float* img; int Nout, K, ldw, pad_; };
-struct SplitJobs { SplitJob job[32]; int n; };
 int split_bf16_tiled_multi_launch(const SplitJobs& jobs, hipStream_t st);   // K % 16 == 0, ldw % 4 == 0 per job
+
+// gemm_f16_dma.hip — the same contract in fp16 arithmetic (precision 2): K % 32 == 0, rows >= 64
+bool gemm_f16_dma_supported(const GemmArgs& g);
+int gemm_f16_dma_launch(const GemmArgs& g, hipStream_t st);
+size_t split_f16_image_bytes(int Nout, int K);   // ceil(Nout / 128) * 128 * K * 2
+int split_f16_tiled_launch(const float* W, void* img, int Nout, int K, int ldw, hipStream_t st);
+int split_f16_tiled_multi_launch(const SplitJobs& jobs, hipStream_t st);
 
 // gemm_general_f32.hip — C[z] = scale * op(A[z]) op(B[z]) (+ bias), per-operand layout flag, two-level batch strides
 struct GemmGeneralArgs {
@@ -73,17 +83,18 @@ int lower_bwd_launch(const float* feat, const float* dF, const float* W, float* 
                      int C, float eps, hipStream_t st);
 
 // attention_f32.hip
-// precision 1 = split-bf16 arithmetic (attention_x3.hip) when the head dim allows, else the exact fp32 kernels
+// precision 1 = split-bf16, 2 = fp16 arithmetic (attention_x3.hip) when the head dim allows, else the exact fp32 kernels
 int pool_attn_launch(const float* KV, const float* inducers, float* part_o, float* part_ml, float* merged,
-                     int B, int N, int C, int H, int I, int nsplit, hipStream_t st, int precision = 0);
+                     int B, int N, int C, int H, int I, int nsplit, hipStream_t st, int precision = 0, int io16 = 0);
 int pool_attn_nsplit(int B, int N, int H);
 int unpool_attn_launch(const float* q, const float* kvh, float* out, int B, int N, int C, int H, int I,
-                       hipStream_t st, int precision = 0);
+                       hipStream_t st, int precision = 0, int io16 = 0);
 // attention_x3.hip
 bool attn_x3_supported(int HD);
 int pool_attn_x3_partials_launch(const float* KV, const float* inducers, float* part_o, float* part_ml, int B, int N,
-                                 int C, int H, int nsplit, hipStream_t st);
-int unpool_attn_x3_launch(const float* q, const float* kvh, float* out, int B, int N, int C, int H, hipStream_t st);
+                                 int C, int H, int nsplit, hipStream_t st, int precision, int io16 = 0);   // 1 split-bf16, 2 fp16
+int unpool_attn_x3_launch(const float* q, const float* kvh, float* out, int B, int N, int C, int H, hipStream_t st,
+                          int precision, int io16 = 0);   // io16: KV / q / out are fp16 tensors (fp16 mode)
 
 // lookup.hip
 struct LookupArgs {

@@ -20,7 +20,7 @@ GN_EPS = 1e-5
 
 # Arithmetic of the N-token GEMMs: "fp32" = exact fp32 MFMA (~1e-6 against the fp32 reference), "bf16x3" = split-bf16
 # (hi + lo operands, three bf16 MFMAs per product, fp32 accumulate: ~2e-5, inside the 1e-3 parity bar, ~2x faster).
-PRECISIONS = {"fp32": 0, "bf16x3": 1}
+PRECISIONS = {"fp32": 0, "bf16x3": 1, "fp16": 2}
 _default_precision = os.environ.get("GECCO_PRECISION", "fp32")
 
 
@@ -70,7 +70,7 @@ def linear(A: Tensor, W: Tensor, bias: Tensor | None = None, pro: tuple[Tensor, 
     if want_stats:
         stats = torch.empty(B, lib.gecco_linear_row_tiles(rows), 2, Nout, device=A.device, dtype=torch.float32)
     act = 0 if act_alpha is None else (1 if normalized else 2)
-    wsplit = _ws((Nout + 127) // 128 * 128 * K * 4, A.device) if precision == "bf16x3" else None
+    wsplit = _ws((Nout + 127) // 128 * 128 * K * 4, A.device) if precision != "fp32" else None
     check(lib.gecco_linear_ex_f32(_ptr(A), _ptr(W), _ptr(bias), _ptr(pro[0]) if pro else None,
                                   _ptr(pro[1]) if pro else None, _ptr(act_alpha), _ptr(residual), _ptr(out), _ptr(stats),
                                   B, rows, K, Nout, act, PRECISIONS[precision],
@@ -139,7 +139,7 @@ def linear_pair(A: Tensor, W1: Tensor, b1: Tensor | None, W2: Tensor, b2: Tensor
     n1, n2 = W1.shape[0], W2.shape[0]
     c1, c2 = out if out is not None else (torch.empty(B, rows, n1, device=A.device, dtype=torch.float32),
                                           torch.empty(B, rows, n2, device=A.device, dtype=torch.float32))
-    wsplit = _ws(((n1 + 127) // 128 + (n2 + 127) // 128) * 128 * K * 4, A.device) if precision == "bf16x3" else None
+    wsplit = _ws(((n1 + 127) // 128 + (n2 + 127) // 128) * 128 * K * 4, A.device) if precision != "fp32" else None
     check(lib.gecco_linear_pair_f32(_ptr(A), _ptr(W1), _ptr(b1), n1, _ptr(c1), _ptr(W2), _ptr(b2), n2, _ptr(c2),
                                     _ptr(pro[0]) if pro else None, _ptr(pro[1]) if pro else None, B, rows, K,
                                     PRECISIONS[precision], C.c_void_p(wsplit.data_ptr()) if wsplit is not None else None,

@@ -123,6 +123,23 @@ def test_split_bf16_mode_golden(ops, golden_dir, name):
     assert torch.equal(den, net.forward(x.cuda(), sigma.cuda()))   # ... and still deterministic
 
 
+@pytest.mark.parametrize("name", list(cases.UNCOND_CASES))
+def test_fp16_mode_golden(ops, golden_dir, name):
+    """precision="fp16": operands rounded to fp16 (11 significant bits), one MFMA per product, fp32 accumulate.
+    Bar: the north-star 1e-3 relative against the fp32 reference's golden output; measured ~3e-4."""
+    g = _load(golden_dir, name)
+    p, x, sigma = cases.uncond_inputs(name)
+    net = ops.LinearLiftPlan(_cuda(p), cases.H, cases.I, precision="fp16")
+    den, raw = net.forward(x.cuda(), sigma.cuda(), return_raw=True)
+    e1 = cpu_ref.rel_err(den.cpu(), g["denoised"])
+    e2 = cpu_ref.rel_err(raw.cpu(), g["F_x"])
+    print(name, "fp16 denoised", e1, "F_x", e2)
+    assert e1[0] <= 1e-3 and e2[0] <= 1e-3, (e1, e2)
+    assert torch.equal(den, net.forward(x.cuda(), sigma.cuda()))   # deterministic
+    half = net.forward(x[:2].contiguous().cuda(), sigma[:2].contiguous().cuda())
+    assert torch.equal(half, den[:2])                               # bits do not depend on the batch
+
+
 def test_split_bf16_linear_accuracy(ops):
     """The split itself: products with operands spanning 8 orders of magnitude keep ~2^-16 relative accuracy."""
     import ctypes as C

@@ -79,7 +79,7 @@ def test_linear_split_bf16(ops, B, rows, K, Nout):
 
 
 @pytest.mark.parametrize("B,rows,K,n1,n2", [(2, 256, 128, 256, 128), (1, 2048, 384, 768, 384), (2, 200, 64, 96, 64), (3, 64, 384, 768, 384)])
-@pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16x3", 1e-4)])
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16x3", 1e-4), ("fp16", 2e-3)])
 def test_linear_pair(ops, B, rows, K, n1, n2, precision, tol):
     """kv_proj | q_proj in one launch: each half must equal its own linear (bit-for-bit in the same arithmetic)."""
     rs = _rs(rows + K + n1)
@@ -112,6 +112,32 @@ def test_adagn(ops, B, rows, C, G, ctx):
     _close(got, ref)
 
 
+@pytest.mark.parametrize("B,rows,K,Nout", [(2, 256, 128, 256), (1, 2048, 384, 768), (2, 300, 768, 384), (3, 64, 384, 768),
+                                           (2, 64, 768, 384), (2, 100, 128, 200), (1, 130, 32, 132)])
+def test_linear_fp16(ops, B, rows, K, Nout):
+    """precision="fp16": the fused contract with fp16-rounded operands; error ~2^-11 per operand."""
+    rs = _rs(rows + K + 7)
+    A, W, b = _t(rs.randn(B, rows, K) * 3), _t(rs.randn(Nout, K) / math.sqrt(K)), _t(rs.randn(Nout))
+    pa, po = _t(1 + 0.3 * rs.randn(B, K)), _t(0.3 * rs.randn(B, K))
+    R = _t(rs.randn(B, rows, Nout))
+    alpha = _t(np.array(1.1))
+    An = (A * pa[:, None] + po[:, None])
+    pre = F.linear(An.double(), W.double(), b.double())
+    ref = R.double() + cpu_ref.gaussian_activation(pre, alpha.double())
+    out, stats = ops.linear(A.cuda(), W.cuda(), b.cuda(), (pa.cuda(), po.cuda()), alpha.cuda(), R.cuda(), want_stats=True,
+                            precision="fp16")
+    e = cpu_ref.rel_err(out.cpu(), ref)
+    assert e[0] < 2e-3, e
+    _close(stats.cpu().double().sum(1)[:, 0], ref.sum(1), 5e-3)
+    # the arithmetic is exactly "round both operands to fp16, multiply exactly, accumulate in fp32"
+    # (the kernel's affine is one fma: emulate it as the correctly rounded fp32 of the exact a*x+o)
+    An16 = (A.double() * pa[:, None].double() + po[:, None].double()).float().half().double()
+    emu = F.linear(An16, W.half().double(), b.double())
+    plain = ops.linear(A.cuda(), W.cuda(), b.cuda(), (pa.cuda(), po.cuda()), precision="fp16")
+    e = cpu_ref.rel_err(plain.cpu(), emu)
+    assert e[1] <= 2e-6 and e[0] <= 2e-4, e   # rms at the fp32 accumulation floor; a rare fp16 tie may flip one operand
+
+
 def test_adagn_large_mean(ops):
     """E[x^2]-mean^2 cancellation: mean 50x the std must still be accurate (fp64 combine)."""
     rs = _rs(5)
@@ -120,7 +146,7 @@ def test_adagn_large_mean(ops):
 
 
 @pytest.mark.parametrize("B,N,C,H", [(2, 256, 128, 8), (2, 1000, 384, 8), (1, 64, 64, 8), (3, 33, 512, 8), (2, 2048, 256, 8)])
-@pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16x3", 1e-4)])
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16x3", 1e-4), ("fp16", 2e-3)])
 def test_pool_attn(ops, B, N, C, H, precision, tol):
     rs = _rs(N + C)
     y = _t(rs.randn(B, N, C))
@@ -132,7 +158,7 @@ def test_pool_attn(ops, B, N, C, H, precision, tol):
     _close(got, ref, tol)
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16x3", 1e-4)])
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16x3", 1e-4), ("fp16", 2e-3)])
 def test_pool_attn_online_softmax_rescale(ops, precision, tol):
     """Force the running max to jump late in the key stream (rule: a rare branch needs its own test)."""
     B, N, C, H = 1, 1024, 128, 8
@@ -153,7 +179,7 @@ def test_pool_attn_online_softmax_rescale(ops, precision, tol):
 
 
 @pytest.mark.parametrize("B,N,C,H", [(2, 256, 128, 8), (2, 1000, 384, 8), (1, 50, 64, 8), (2, 640, 512, 8), (2, 300, 256, 8)])
-@pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16x3", 1e-4)])
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16x3", 1e-4), ("fp16", 2e-3)])
 def test_unpool_attn(ops, B, N, C, H, precision, tol):
     rs = _rs(N + C + 1)
     y, h = _t(rs.randn(B, N, C)), _t(rs.randn(B, 64, C))

@@ -140,10 +140,11 @@ int linear(const float* A, const float* W, const float* bias, const float* pa, c
 // Returns 1 when the fused form does not apply (caller issues the two linears), 0 on success, <0 on error.
 int linear_pair(const float* A, const float* W1, const float* b1, int Nout1, float* C1, const float* W2,
                 const float* b2, int Nout2, float* C2, const float* pa, const float* po, int B, int rows, int K,
-                hipStream_t s, int precision, float* wsplit, const float* img_ready = nullptr, int c_f16 = 0) {
+                hipStream_t s, int precision, float* wsplit, const float* img_ready = nullptr, int c_f16 = 0, int a_f16 = 0) {
     GemmArgs g{};
     g.c_f16 = c_f16;
-    if (c_f16 && precision != 2) return -9;
+    g.a_f16 = a_f16;
+    if ((c_f16 || a_f16) && precision != 2) return -9;
     g.A = A; g.W = W1; g.bias = b1; g.pro_a = pa; g.pro_o = po; g.C = C1;
     g.B = B; g.rows = rows; g.K = K; g.Nout = Nout1 + Nout2;
     g.lda = K; g.ldw = K; g.ldc = Nout1; g.ldr = Nout1;
@@ -242,13 +243,18 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         if (!h) {
             // pool: KV projection, 64 inducer queries over the N points, out_proj
             // kv_proj and the unpool's q projection read the same AdaGN(x): one launch, x read once
-            int fused = linear_pair(x, L.kv_proj_w, nullptr, 2 * C, w.big, L.in_proj_w, L.in_proj_b, C, w.q, w.a1, w.o1, B,
-                                    N, C, s, pr, w.wsplit, (2 * C) % 128 == 0 ? im : nullptr, io16);
+            // fp16 mode: AdaGN(x) is formed once as the fp16 operand both projections read (in the attention-output
+            // buffer, idle until the unpool) instead of on every column tile's fragments
+            float* y16 = w.attn;
+            if (io16) TRY(affine_cast_f16_launch(x, w.a1, w.o1, y16, B, N, C, s), "broadcast_norm -> fp16");
+            int fused = linear_pair(io16 ? y16 : x, L.kv_proj_w, nullptr, 2 * C, w.big, L.in_proj_w, L.in_proj_b, C, w.q,
+                                    io16 ? nullptr : w.a1, io16 ? nullptr : w.o1, B, N, C, s, pr, w.wsplit,
+                                    (2 * C) % 128 == 0 ? im : nullptr, io16, io16);
             if (fused < 0) TRY(fused, "kv_proj|q_proj");
             q_done = fused == 0;
             if (!q_done)
-                TRY(linear(x, L.kv_proj_w, nullptr, w.a1, w.o1, nullptr, nullptr, w.big, nullptr, B, N, C, 2 * C, 0, s, pr,
-                           w.wsplit, im, 0, io16), "kv_proj");
+                TRY(linear(io16 ? y16 : x, L.kv_proj_w, nullptr, io16 ? nullptr : w.a1, io16 ? nullptr : w.o1, nullptr, nullptr,
+                           w.big, nullptr, B, N, C, 2 * C, 0, s, pr, w.wsplit, im, io16, io16), "kv_proj");
             TRY(pool_attn_launch(w.big, L.inducers, w.part_o, w.part_ml, w.merged, B, N, C, H, I, ns, s, pr, io16), "pool_attn");
             TRY(linear(w.merged, L.pool_out_w, nullptr, nullptr, nullptr, nullptr, nullptr, w.h0, w.stats_s, B, I, C, C,
                        0, s, pr, w.wsplit, im ? im + w.o_pout : nullptr), "pool.out_proj");
@@ -266,16 +272,20 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         // unpool: k|v of the 64 inducer states, q of the N points, attention, out_proj + residual
         TRY(linear(h, L.in_proj_w + (size_t)C * C, L.in_proj_b + C, nullptr, nullptr, nullptr, nullptr, w.kvh, nullptr,
                    B, I, C, 2 * C, 0, s, pr, w.wsplit, im ? im + w.o_ukv : nullptr), "unpool.in_proj(kv)");
-        if (!q_done)
-            TRY(linear(x, L.in_proj_w, L.in_proj_b, w.a1, w.o1, nullptr, nullptr, w.q, nullptr, B, N, C, C, 0, s, pr,
-                       w.wsplit, im ? im + w.o_q : nullptr, 0, io16), "unpool.in_proj(q)");
+        if (!q_done) {
+            if (io16 && h_in && h_in[li]) TRY(affine_cast_f16_launch(x, w.a1, w.o1, w.attn, B, N, C, s), "broadcast_norm -> fp16");
+            TRY(linear(io16 ? w.attn : x, L.in_proj_w, L.in_proj_b, io16 ? nullptr : w.a1, io16 ? nullptr : w.o1, nullptr,
+                       nullptr, w.q, nullptr, B, N, C, C, 0, s, pr, w.wsplit, im ? im + w.o_q : nullptr, io16, io16),
+                "unpool.in_proj(q)");
+        }
         TRY(unpool_attn_launch(w.q, w.kvh, w.attn, B, N, C, H, I, s, pr, io16), "unpool_attn");
         TRY(linear(w.attn, L.unpool_out_w, L.unpool_out_b, nullptr, nullptr, nullptr, x, x, w.stats_x, B, N, C, C, 0, s, pr,
                    w.wsplit, im ? im + w.o_out : nullptr, io16, 0), "unpool.out_proj+residual");
         // x += mlp(AdaGN(x))
         TRY(coeffs(w.stats_x, Tn, N, t, ctx, &L.mlp_norm, w.a2, w.o2, B, C, G, s), "adagn_coeffs(mlp_norm)");
-        TRY(linear(x, L.mlp.w0, L.mlp.b0, w.a2, w.o2, L.mlp.alpha, nullptr, w.big, nullptr, B, N, C, Wd, act, s, pr, w.wsplit,
-                   im ? im + w.o_w0 : nullptr, 0, io16), "mlp.0");
+        if (io16) TRY(affine_cast_f16_launch(x, w.a2, w.o2, w.attn, B, N, C, s), "mlp_norm -> fp16");
+        TRY(linear(io16 ? w.attn : x, L.mlp.w0, L.mlp.b0, io16 ? nullptr : w.a2, io16 ? nullptr : w.o2, L.mlp.alpha, nullptr,
+                   w.big, nullptr, B, N, C, Wd, act, s, pr, w.wsplit, im ? im + w.o_w0 : nullptr, io16, io16), "mlp.0");
         float* so = (li + 1 < st->n_layers) ? w.stats_x : stats_out;
         TRY(linear(w.big, L.mlp.w2, L.mlp.b2, nullptr, nullptr, nullptr, x, x, so, B, N, Wd, C, 0, s, pr, w.wsplit,
                    im ? im + w.o_w2 : nullptr, io16, 0), "mlp.2+residual");
@@ -352,6 +362,61 @@ int gecco_linear_pair_f32(const float* A, const float* W1, const float* bias1, i
         TRY(linear(A, W1, bias1, pro_a, pro_o, nullptr, nullptr, C1, nullptr, B, rows, K, Nout1, 0, s, precision, ws), "linear_pair[0]");
         TRY(linear(A, W2, bias2, pro_a, pro_o, nullptr, nullptr, C2, nullptr, B, rows, K, Nout2, 0, s, precision, ws), "linear_pair[1]");
     }
+    return 0;
+}
+
+int gecco_linear_f16io(const void* A, const float* W, const float* bias, const float* alpha, const float* residual,
+                       void* C, float* stats, int B, int rows, int K, int Nout, int act, int a_f16, int c_f16,
+                       void* wsplit, void* stream) {
+    if (!A || !W || !C || !wsplit) return fail(-1, "linear_f16io: null argument");
+    if (!a_f16 && !c_f16) return fail(-2, "linear_f16io: at least one of A / C must be an fp16 tensor (else gecco_linear_ex_f32)");
+    int rc = linear(static_cast<const float*>(A), W, bias, nullptr, nullptr, alpha, residual, static_cast<float*>(C),
+                    stats, B, rows, K, Nout, act, (hipStream_t)stream, 2, static_cast<float*>(wsplit), nullptr, a_f16,
+                    c_f16);
+    if (rc == -9) return fail(-2, "linear_f16io: needs rows >= 128, K %% 32 == 0, lda %% 8 == 0; fp16 C excludes residual / stats");
+    TRY(rc, "linear_f16io");
+    return 0;
+}
+
+int gecco_linear_pair_f16io(const void* A, const float* W1, const float* bias1, int Nout1, void* C1, const float* W2,
+                            const float* bias2, int Nout2, void* C2, int B, int rows, int K, void* wsplit,
+                            void* stream) {
+    if (!A || !W1 || !W2 || !C1 || !C2 || !wsplit) return fail(-1, "linear_pair_f16io: null argument");
+    int rc = linear_pair(static_cast<const float*>(A), W1, bias1, Nout1, static_cast<float*>(C1), W2, bias2, Nout2,
+                         static_cast<float*>(C2), nullptr, nullptr, B, rows, K, (hipStream_t)stream, 2,
+                         static_cast<float*>(wsplit), nullptr, 1, 1);
+    if (rc == 1 || rc == -9) return fail(-2, "linear_pair_f16io: needs rows >= 128, K %% 32 == 0, Nout1 %% 128 == 0");
+    TRY(rc, "linear_pair_f16io");
+    return 0;
+}
+
+int gecco_affine_cast_f16(const float* x, const float* a, const float* o, void* y16, int B, int rows, int C,
+                          void* stream) {
+    if (C % 8) return fail(-2, "affine_cast_f16: C must be a multiple of 8");
+    TRY(affine_cast_f16_launch(x, a, o, y16, B, rows, C, (hipStream_t)stream), "affine_cast_f16");
+    return 0;
+}
+
+int gecco_pool_attn_f16in(const void* KV16, const float* inducers, float* merged, int B, int N, int C, int H, int I,
+                          void* ws, size_t ws_bytes, void* stream) {
+    if (ws_bytes < gecco_pool_attn_workspace_bytes(B, N, C, H, I)) return fail(-7, "pool_attn: workspace too small");
+    Carver c(ws);
+    const int ns = pool_attn_nsplit(B, N, H);
+    float* po = c.f32((size_t)B * H * ns * 64 * (C / H));
+    float* pml = c.f32((size_t)B * H * ns * 64 * 2);
+    int rc = pool_attn_launch(static_cast<const float*>(KV16), inducers, po, pml, merged, B, N, C, H, I, ns,
+                              (hipStream_t)stream, 2, 1);
+    if (rc == -9) return fail(-2, "pool_attn_f16in: head dim must be 16, 32, 48 or 64");
+    TRY(rc, "pool_attn_f16in");
+    return 0;
+}
+
+int gecco_unpool_attn_f16io(const void* q16, const float* kvh, void* out16, int B, int N, int C, int H, int I,
+                            void* stream) {
+    int rc = unpool_attn_launch(static_cast<const float*>(q16), kvh, static_cast<float*>(out16), B, N, C, H, I,
+                                (hipStream_t)stream, 2, 1);
+    if (rc == -9) return fail(-2, "unpool_attn_f16io: head dim must be 16, 32, 48 or 64");
+    TRY(rc, "unpool_attn_f16io");
     return 0;
 }
 

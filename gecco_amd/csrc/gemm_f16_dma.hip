@@ -303,7 +303,7 @@ int gemm_f16_dma_launch(const GemmArgs& g, hipStream_t st) {
         const char* e = getenv("GECCO_GEMM_F16_STAGES");
         ns = (e && atoi(e) == 2) ? 2 : 3;
     }
-    if (g.a_f16 && g.c_f16) return -9;   // not a combination the layer needs
+    if (g.a_f16 && g.c_f16) return f16_launch_t<3, 128, true, true>(g, st);
     if (g.a_f16) return f16_launch_t<3, 128, true, false>(g, st);
     if (g.c_f16) return f16_launch_t<3, 128, false, true>(g, st);
     if (g.rows < 128) return ns == 2 ? f16_launch_t<2, 64, false, false>(g, st) : f16_launch_t<3, 64, false, false>(g, st);

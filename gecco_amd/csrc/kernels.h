@@ -137,6 +137,8 @@ int col_stats_launch(const float* x, float* stats, int B, int rows, int C, hipSt
 int adagn_coeffs_launch(const float* stats, int T, int rows, const float* t, int ctx_dim, const float* scale_w,
                         const float* scale_b, const float* bias_w, const float* bias_b, float* a, float* o, int B,
                         int C, int G, float eps, hipStream_t st);
+int affine_cast_f16_launch(const float* x, const float* a, const float* o, void* y16, int B, int rows, int C,
+                           hipStream_t st);   // y16 = fp16(a * x + o), C % 8 == 0
 int affine_apply_launch(const float* x, const float* a, const float* o, float* y, int B, int rows, int C,
                         hipStream_t st);
 int edm_coeffs_launch(const float* sigma, float sigma_data, float* coef, int B, hipStream_t st);

@@ -106,6 +106,29 @@ __global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restri
     }
 }
 
+// ---- y16[b,m,c] = fp16(a[b,c] * x[b,m,c] + o[b,c]): the AdaGN apply of the fp16 mode, one fma and one rounding per
+// element — the value the fp16 GEMM's prologue would have formed on the fragment, stored once as its fp16 A operand
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void affine_cast_f16_kernel(const float* __restrict__ x, const float* __restrict__ a,
+                                                              const float* __restrict__ o, _Float16* __restrict__ y,
+                                                              size_t total8, int rowsC8, int C8) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / rowsC8;
+        const int c8 = (int)(i % C8);
+        const f32x4 x0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x) + 2 * i);
+        const f32x4 x1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x) + 2 * i + 1);
+        const f32x4 a0 = reinterpret_cast<const f32x4*>(a)[(b * C8 + c8) * 2], a1 = reinterpret_cast<const f32x4*>(a)[(b * C8 + c8) * 2 + 1];
+        const f32x4 o0 = reinterpret_cast<const f32x4*>(o)[(b * C8 + c8) * 2], o1 = reinterpret_cast<const f32x4*>(o)[(b * C8 + c8) * 2 + 1];
+        f16x8_t v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = (_Float16)__builtin_fmaf(x0[e], a0[e], o0[e]);
+            v[4 + e] = (_Float16)__builtin_fmaf(x1[e], a1[e], o1[e]);
+        }
+        reinterpret_cast<f16x8_t*>(y)[i] = v;
+    }
+}
+
 // ---- EDM preconditioning coefficients (reference diffusion.py:46-51):
 // coef[4b .. 4b+3] = {c_skip, c_out, c_in, c_noise}; coef[4B + b] = c_noise again, packed (the AdaGN `t`).
 __global__ void edm_coeffs_kernel(const float* __restrict__ sigma, float sd, float* __restrict__ coef, int B) {
@@ -303,6 +326,16 @@ int affine_apply_launch(const float* x, const float* a, const float* o, float* y
     const unsigned grid = (unsigned)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
     hipLaunchKernelGGL(affine_apply_kernel, dim3(grid ? grid : 1), dim3(256), 0, st, x, a, o, y, total4, rows * C / 4,
                        C / 4);
+    return (int)hipGetLastError();
+}
+
+int affine_cast_f16_launch(const float* x, const float* a, const float* o, void* y16, int B, int rows, int C,
+                           hipStream_t st) {
+    if (C % 8) return -2;
+    const size_t total8 = (size_t)B * rows * C / 8;
+    const unsigned grid = (unsigned)((total8 + 255) / 256 < 8192 ? (total8 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(affine_cast_f16_kernel, dim3(grid ? grid : 1), dim3(256), 0, st, x, a, o,
+                       static_cast<_Float16*>(y16), total8, rows * C / 8, C / 8);
     return (int)hipGetLastError();
 }
 

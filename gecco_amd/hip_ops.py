@@ -130,6 +130,79 @@ def adagn(x: Tensor, t: Tensor | None, params: Sequence[Tensor] | None, G: int, 
     return y
 
 
+def _ptr16(t: Tensor) -> C.c_void_p:
+    if not t.is_cuda or t.dtype != torch.float16 or not t.is_contiguous():
+        raise _lib.GeccoHipError("expected a contiguous float16 HIP tensor")
+    return C.c_void_p(t.data_ptr())
+
+
+def _ptr_io(t: Tensor) -> C.c_void_p:
+    return _ptr16(t) if t.dtype == torch.float16 else _ptr(t)
+
+
+def linear_f16io(A: Tensor, W: Tensor, bias: Tensor | None = None, act_alpha: Tensor | None = None,
+                 residual: Tensor | None = None, want_stats: bool = False, out_f16: bool = False,
+                 normalized: bool = True, out: Tensor | None = None):
+    """fp16-mode linear whose A and / or C are fp16 TENSORS (the stored intermediates of precision "fp16")."""
+    lib = _lib.load()
+    B, rows, K = A.shape
+    Nout = W.shape[0]
+    a16 = A.dtype == torch.float16
+    if out is None:
+        out = torch.empty(B, rows, Nout, device=A.device, dtype=torch.float16 if out_f16 else torch.float32)
+    stats = torch.empty(B, lib.gecco_linear_row_tiles(rows), 2, Nout, device=A.device) if want_stats else None
+    act = 0 if act_alpha is None else (1 if normalized else 2)
+    wsplit = _ws((Nout + 127) // 128 * 128 * K * 4, A.device)
+    check(lib.gecco_linear_f16io(_ptr_io(A), _ptr(W), _ptr(bias), _ptr(act_alpha), _ptr(residual), _ptr_io(out), _ptr(stats),
+                                 B, rows, K, Nout, act, int(a16), int(out.dtype == torch.float16),
+                                 C.c_void_p(wsplit.data_ptr()), _stream()), "gecco_linear_f16io")
+    return (out, stats) if want_stats else out
+
+
+def linear_pair_f16io(A16: Tensor, W1: Tensor, b1: Tensor | None, W2: Tensor, b2: Tensor | None,
+                      out: tuple[Tensor, Tensor] | None = None) -> tuple[Tensor, Tensor]:
+    lib = _lib.load()
+    B, rows, K = A16.shape
+    n1, n2 = W1.shape[0], W2.shape[0]
+    c1, c2 = out if out is not None else (torch.empty(B, rows, n1, device=A16.device, dtype=torch.float16),
+                                          torch.empty(B, rows, n2, device=A16.device, dtype=torch.float16))
+    wsplit = _ws(((n1 + 127) // 128 + (n2 + 127) // 128) * 128 * K * 4, A16.device)
+    check(lib.gecco_linear_pair_f16io(_ptr16(A16), _ptr(W1), _ptr(b1), n1, _ptr16(c1), _ptr(W2), _ptr(b2), n2, _ptr16(c2),
+                                      B, rows, K, C.c_void_p(wsplit.data_ptr()), _stream()), "gecco_linear_pair_f16io")
+    return c1, c2
+
+
+def affine_cast_f16(x: Tensor, a: Tensor, o: Tensor, out: Tensor | None = None) -> Tensor:
+    """fp16(a[b, c] * x[b, m, c] + o[b, c]): the AdaGN apply stored as the fp16 GEMM operand."""
+    lib = _lib.load()
+    B, rows, Cc = x.shape
+    out = torch.empty(B, rows, Cc, device=x.device, dtype=torch.float16) if out is None else out
+    check(lib.gecco_affine_cast_f16(_ptr(x), _ptr(a), _ptr(o), _ptr16(out), B, rows, Cc, _stream()), "gecco_affine_cast_f16")
+    return out
+
+
+def pool_attn_f16in(KV16: Tensor, inducers: Tensor, H: int) -> Tensor:
+    lib = _lib.load()
+    B, N, C2 = KV16.shape
+    Cc = C2 // 2
+    I = inducers.shape[-2]
+    merged = torch.empty(B, I, Cc, device=KV16.device, dtype=torch.float32)
+    nb = lib.gecco_pool_attn_workspace_bytes(B, N, Cc, H, I)
+    ws = _ws(nb, KV16.device)
+    check(lib.gecco_pool_attn_f16in(_ptr16(KV16), _ptr(inducers), _ptr(merged), B, N, Cc, H, I, C.c_void_p(ws.data_ptr()), nb,
+                                    _stream()), "gecco_pool_attn_f16in")
+    return merged
+
+
+def unpool_attn_f16io(q16: Tensor, kvh: Tensor, H: int, out: Tensor | None = None) -> Tensor:
+    lib = _lib.load()
+    B, N, Cc = q16.shape
+    out = torch.empty_like(q16) if out is None else out
+    check(lib.gecco_unpool_attn_f16io(_ptr16(q16), _ptr(kvh), _ptr16(out), B, N, Cc, H, kvh.shape[1], _stream()),
+          "gecco_unpool_attn_f16io")
+    return out
+
+
 def linear_pair(A: Tensor, W1: Tensor, b1: Tensor | None, W2: Tensor, b2: Tensor | None,
                 pro: tuple[Tensor, Tensor] | None = None, out: tuple[Tensor, Tensor] | None = None,
                 precision: str = "fp32") -> tuple[Tensor, Tensor]:

@@ -63,8 +63,9 @@ typedef struct GeccoLayer {   /* BroadcastingLayer, models/set_transformer.py:12
 
 typedef struct GeccoSetTransformer {  /* SetTransformer, models/set_transformer.py:171-216 */
     int n_layers, C, H, I, ctx_dim, G, width, act;  /* act: 1 GaussianActivation(normalized) 2 raw */
-    int precision;  /* arithmetic of the N-token GEMMs: 0 exact fp32 MFMA (~1e-6 vs the fp32 reference),
-                     * 1 split-bf16 on bf16 MFMA, fp32 accumulate (a = hi + lo; 3 MFMAs; ~2e-5) */
+    int precision;  /* arithmetic of the linears and attention products: 0 exact fp32 MFMA (~1e-6 vs the fp32
+                     * reference), 1 split-bf16 on bf16 MFMA, fp32 accumulate (a = hi + lo; 3 MFMAs; ~2e-5),
+                     * 2 fp16 operands (round to nearest even), fp32 accumulate, fp16-stored intermediates (~3e-4) */
     const GeccoLayer* layers;                       /* HOST array of n_layers tables */
 } GeccoSetTransformer;
 
@@ -78,8 +79,8 @@ int gecco_linear_f32(const float* A, const float* W, const float* bias, const fl
                      const float* alpha, const float* residual, float* C, float* stats, int B, int rows, int K,
                      int Nout, int act, void* stream);
 int gecco_linear_row_tiles(int rows);
-/* The same with the arithmetic selectable: precision 0 = exact fp32 MFMA, 1 = split-bf16 (see GeccoSetTransformer);
- * wsplit: scratch of >= ceil(Nout/128)*128*K*4 bytes for the tiled bf16 hi | lo image of W (precision 1 only). */
+/* The same with the arithmetic selectable: precision 0 = exact fp32 MFMA, 1 = split-bf16, 2 = fp16 (see GeccoSetTransformer);
+ * wsplit: scratch of >= ceil(Nout/128)*128*K*4 bytes for the tiled image of W (bf16 hi | lo, or fp16; precision 1 / 2). */
 int gecco_linear_ex_f32(const float* A, const float* W, const float* bias, const float* pro_a, const float* pro_o,
                         const float* alpha, const float* residual, float* C, float* stats, int B, int rows, int K,
                         int Nout, int act, int precision, void* wsplit, void* stream);
@@ -106,6 +107,30 @@ int gecco_affine_apply_f32(const float* x, const float* a, const float* o, float
 int gecco_adagn_f32(const float* x, const float* t, int ctx_dim, const GeccoAdaGN* p, float* y, int B, int rows,
                     int C, int G, float eps, void* ws, size_t ws_bytes, void* stream);
 size_t gecco_adagn_workspace_bytes(int B, int rows, int C);
+
+/* ---- fp16-stored intermediates of the fp16 mode (precision 2) ------------------------------------------------
+ * In that mode every point-stream tensor whose only consumer rounds it to fp16 anyway (AdaGN(x) as a GEMM operand,
+ * K|V, q, the attention output, the MLP hidden layer) is STORED as fp16: the matrix pipe sees the same bits, a
+ * third of the layer's HBM bytes never move.  The residual stream and all statistics stay fp32.  These are the unit
+ * forms of the launches gecco_set_transformer_fwd_f32 makes; leading dimensions count elements of the tensor's type. */
+/* C = residual + act(A @ W^T + bias) with A and / or C an fp16 tensor (a_f16 / c_f16).  fp16 A: no AdaGN prologue
+ * (use gecco_affine_cast_f16 first); fp16 C: no residual, no stats.  rows >= 128, K % 32 == 0.  wsplit as above. */
+int gecco_linear_f16io(const void* A, const float* W, const float* bias, const float* alpha, const float* residual,
+                       void* C, float* stats, int B, int rows, int K, int Nout, int act, int a_f16, int c_f16,
+                       void* wsplit, void* stream);
+/* gecco_linear_pair_f32 with fp16 A and fp16 outputs (kv_proj | q_proj of the fp16 mode). */
+int gecco_linear_pair_f16io(const void* A, const float* W1, const float* bias1, int Nout1, void* C1, const float* W2,
+                            const float* bias2, int Nout2, void* C2, int B, int rows, int K, void* wsplit,
+                            void* stream);
+/* y16[b, m, c] = fp16(a[b, c] * x[b, m, c] + o[b, c]) — the AdaGN apply (models/normalization.py:44) rounded once,
+ * exactly the operand the fp16 GEMM's prologue would form.  C % 8 == 0. */
+int gecco_affine_cast_f16(const float* x, const float* a, const float* o, void* y16, int B, int rows, int C,
+                          void* stream);
+/* gecco_pool_attn_ex_f32 (precision 2) reading an fp16 KV; gecco_unpool_attn_ex_f32 (precision 2) with fp16 q / out. */
+int gecco_pool_attn_f16in(const void* KV16, const float* inducers, float* merged, int B, int N, int C, int H, int I,
+                          void* ws, size_t ws_bytes, void* stream);
+int gecco_unpool_attn_f16io(const void* q16, const float* kvh, void* out16, int B, int N, int C, int H, int I,
+                            void* stream);
 
 /* AttentionPool core (models/set_transformer.py:47-63, without out_proj): KV (B, N, 2C) -> merged (B, I, C). */
 int gecco_pool_attn_f32(const float* KV, const float* inducers, float* merged, int B, int N, int C, int H, int I,

@@ -138,6 +138,36 @@ def test_linear_fp16(ops, B, rows, K, Nout):
     assert e[1] <= 2e-6 and e[0] <= 2e-4, e   # rms at the fp32 accumulation floor; a rare fp16 tie may flip one operand
 
 
+def test_fp16_stored_intermediates(ops):
+    """The fp16-mode launches with fp16 TENSORS (what the network entry point issues) give the same bits as the unit
+    operators that take fp32 tensors and round on the fly."""
+    rs = _rs(77)
+    B, N, Cc, H = 2, 256, 128, 8
+    x = _t(rs.randn(B, N, Cc) * 2).cuda()
+    a, o = _t(1 + 0.3 * rs.randn(B, Cc)).cuda(), _t(0.3 * rs.randn(B, Cc)).cuda()
+    Wkv, Wq, bq = _t(rs.randn(2 * Cc, Cc) / 11).cuda(), _t(rs.randn(Cc, Cc) / 11).cuda(), _t(rs.randn(Cc) * .1).cuda()
+    y16 = ops.affine_cast_f16(x, a, o)
+    assert torch.equal(y16, torch.addcmul(o[:, None].double(), x.double(), a[:, None].double()).float().half())
+    kv16, q16 = ops.linear_pair_f16io(y16, Wkv, None, Wq, bq)
+    kv32, q32 = ops.linear_pair(x, Wkv, None, Wq, bq, (a, o), precision="fp16")
+    assert torch.equal(kv16, kv32.half()) and torch.equal(q16, q32.half())
+    ind = _t(rs.randn(1, H, 64, Cc // H)).cuda()
+    assert torch.equal(ops.pool_attn_f16in(kv16, ind, H), ops.pool_attn(kv16.float(), ind, H, precision="fp16"))
+    kvh = _t(rs.randn(B, 64, 2 * Cc)).cuda()
+    att16 = ops.unpool_attn_f16io(q16, kvh, H)
+    assert torch.equal(att16, ops.unpool_attn(q16.float(), kvh, H, precision="fp16").half())
+    Wo, bo = _t(rs.randn(Cc, Cc) / 11).cuda(), _t(rs.randn(Cc) * .1).cuda()
+    r1, r2 = x.clone(), x.clone()
+    _, s1 = ops.linear_f16io(att16, Wo, bo, residual=r1, want_stats=True, out=r1)
+    _, s2 = ops.linear(att16.float(), Wo, bo, residual=r2, want_stats=True, out=r2, precision="fp16")
+    assert torch.equal(r1, r2) and torch.equal(s1, s2)
+    alpha = _t(np.array(0.9)).cuda()
+    W0, b0 = _t(rs.randn(2 * Cc, Cc) / 11).cuda(), _t(rs.randn(2 * Cc) * .1).cuda()
+    h16 = ops.linear_f16io(y16, W0, b0, act_alpha=alpha, out_f16=True)
+    h32 = ops.linear(x, W0, b0, (a, o), act_alpha=alpha, precision="fp16")
+    assert torch.equal(h16, h32.half())
+
+
 def test_adagn_large_mean(ops):
     """E[x^2]-mean^2 cancellation: mean 50x the std must still be accurate (fp64 combine)."""
     rs = _rs(5)

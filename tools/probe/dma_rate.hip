@@ -17,6 +17,67 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
 }
 
+__device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, float* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
+// the same fill with buffer_load ... lds: per-lane 32-bit offsets computed once, the K-step advance in the scalar offset
+template <int NS>
+__global__ __launch_bounds__(256) void fill_buf_kernel(const float* A, const float* Wtiled, int rows, int K, int Nout, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tilesN = Nout / 128, nblk = (rows / 128) * tilesN;
+    const int v = xcd_remap(blockIdx.x, nblk);
+    const int ct = v % tilesN, rt = v / tilesN;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int BK = 32, STAGE = 128 * BK * 2;
+    const int nk = K / BK;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)rt * 128 * K), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(Wtiled + (size_t)ct * nk * 4096), 0, 0x7fffffff, 0x00020000);
+    unsigned aoff[4], boff[4];
+    for (int q = 0; q < 4; ++q) {
+        const int row = (4 * wave + q) * 8 + (lane >> 3);
+        aoff[q] = (unsigned)(row * K + (lane & 7) * 4) * 4u;
+        boff[q] = (unsigned)((4 * wave + q) * 256 + lane * 4) * 4u;
+    }
+    auto issue = [&](int kt) {
+        float* st = smem + (kt % NS) * STAGE;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dma16_buf(ra, aoff[q], (unsigned)kt * BK * 4u, st + (4 * wave + q) * 256);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dma16_buf(rb, boff[q], (unsigned)kt * 4096u * 4u, st + 4096 + (4 * wave + q) * 256);
+    };
+    for (int p = 0; p < NS - 1; ++p)
+        if (p < nk) issue(p);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int ahead = min(nk - 1 - kt, NS - 2);
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + NS - 1 < nk) issue(kt + NS - 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (sink && smem[threadIdx.x] == 123.456f) sink[0] = 1.f;
+}
+
+template <int NS>
+static void run_buf(const char* name, const float* A, const float* Wt, int rows, int K, int Nout, float* sink) {
+    const int nblk = (rows / 128) * (Nout / 128);
+    const size_t lds = (size_t)NS * 128 * 32 * 2 * 4;
+    (void)hipFuncSetAttribute((const void*)fill_buf_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    for (int i = 0; i < 2; ++i) fill_buf_kernel<NS><<<nblk, 256, lds, 0>>>(A, Wt, rows, K, Nout, sink);
+    (void)hipEventRecord(a, 0);
+    const int it = 8;
+    for (int i = 0; i < it; ++i) fill_buf_kernel<NS><<<nblk, 256, lds, 0>>>(A, Wt, rows, K, Nout, sink);
+    (void)hipEventRecord(b, 0); (void)hipEventSynchronize(b);
+    float ms; (void)hipEventElapsedTime(&ms, a, b); ms /= it;
+    const double bytes = (double)nblk * K * 128 * 8;
+    printf("%-34s K=%d Nout=%d stages=%d blocks/CU=%d: %.3f ms  %.2f TB/s into LDS  %.1f B/clk/CU\n", name, K, Nout, NS,
+           (int)(160 * 1024 / lds), ms, bytes / ms / 1e9, bytes / (ms * 1e-3) / 256 / 2.4e9);
+}
+
 template <int A_MODE, int B_MODE, int NS>
 __global__ __launch_bounds__(256) void fill_kernel(const float* A, const unsigned short* Whi, const unsigned short* Wlo,
                                                    const float* Wtiled, int rows, int K, int Nout, float* sink) {
@@ -108,6 +169,8 @@ int main() {
         run<0, 1, 2>("A 64B rows + B contiguous", A, hi, lo, Wt, rows, K, Nout, sink);
         run<1, 1, 2>("A 128B rows + B contiguous", A, hi, lo, Wt, rows, K, Nout, sink);
         run<1, 1, 3>("A 128B rows + B contiguous", A, hi, lo, Wt, rows, K, Nout, sink);
+        run_buf<2>("same, buffer_load lds", A, Wt, rows, K, Nout, sink);
+        run_buf<3>("same, buffer_load lds", A, Wt, rows, K, Nout, sink);
         run<1, 1, 4>("A 128B rows + B contiguous", A, hi, lo, Wt, rows, K, Nout, sink);
         run<0, 2, 2>("A 64B rows only", A, hi, lo, Wt, rows, K, Nout, sink);
         run<1, 2, 2>("A 128B rows only", A, hi, lo, Wt, rows, K, Nout, sink);

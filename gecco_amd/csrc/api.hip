@@ -6,6 +6,7 @@
 #include "kernels.h"
 
 #include <stdarg.h>
+#include <stdlib.h>
 #include <stdio.h>
 
 namespace {
@@ -170,6 +171,28 @@ int linear_pair(const float* A, const float* W1, const float* b1, int Nout1, flo
     return gemm_f32_dma_launch(g, s);
 }
 
+// fp16 mode: C16 (| C2_16) = fp16(act(fp16(x * pa + po) W^T + bias)) in one pass over x (gemm_f16_astat.hip).
+// Returns 1 when the shape is outside that kernel's reach (caller: cast pass + streaming GEMM), 0 on success.
+int astat_linear(const float* x, const float* pa, const float* po, const float* img, const float* bias1, int Nout1,
+                 float* C1, const float* bias2, int Nout2, float* C2, const float* alpha, int act, int B, int rows,
+                 int K, hipStream_t s) {
+    GemmArgs g{};
+    g.A = x; g.pro_a = pa; g.pro_o = po; g.bias = bias1; g.alpha = alpha; g.act = act; g.C = C1;
+    g.B = B; g.rows = rows; g.K = K; g.Nout = Nout1 + Nout2; g.lda = K; g.ldw = K; g.ldc = Nout1; g.ldr = Nout1;
+    g.precision = 2; g.w_img = img; g.c_f16 = 1;
+    if (C2) { g.C2 = C2; g.bias2 = bias2; g.n_split = Nout1; g.ldc2 = Nout2; }
+    // Opt-in (GECCO_ASTAT=1): as measured this round the one-pass kernel only ties the cast pass + streaming GEMM
+    // (its per-K-step barrier round costs ~300 cycles against 128 cycles of MFMA per wave, and every block's panel
+    // build hits HBM in lockstep); kept as the base for a deeper-K-step / overlapped-build version.
+    static int enabled = -1;
+    if (enabled < 0) {
+        const char* e = getenv("GECCO_ASTAT");
+        enabled = e ? atoi(e) : 0;
+    }
+    if (!enabled || !img || !gemm_f16_astat_supported(g)) return 1;
+    return gemm_f16_astat_launch(g, s);
+}
+
 int coeffs(const float* stats, int T, int rows, const float* t, int ctx, const GeccoAdaGN* p, float* a, float* o,
            int B, int C, int G, hipStream_t s) {
     return adagn_coeffs_launch(stats, T, rows, t, ctx, p ? p->scale_w : nullptr, p ? p->scale_b : nullptr,
@@ -246,8 +269,15 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
             // fp16 mode: AdaGN(x) is formed once as the fp16 operand both projections read (in the attention-output
             // buffer, idle until the unpool) instead of on every column tile's fragments
             float* y16 = w.attn;
+            int fused = io16 ? astat_linear(x, w.a1, w.o1, (2 * C) % 128 == 0 ? im : nullptr, nullptr, 2 * C, w.big,
+                                            L.in_proj_b, C, w.q, nullptr, 0, B, N, C, s)
+                             : 1;
+            if (fused < 0) TRY(fused, "kv_proj|q_proj (A-stationary)");
+            if (fused == 0) {
+                q_done = true;
+            } else {
             if (io16) TRY(affine_cast_f16_launch(x, w.a1, w.o1, y16, B, N, C, s), "broadcast_norm -> fp16");
-            int fused = linear_pair(io16 ? y16 : x, L.kv_proj_w, nullptr, 2 * C, w.big, L.in_proj_w, L.in_proj_b, C, w.q,
+            fused = linear_pair(io16 ? y16 : x, L.kv_proj_w, nullptr, 2 * C, w.big, L.in_proj_w, L.in_proj_b, C, w.q,
                                     io16 ? nullptr : w.a1, io16 ? nullptr : w.o1, B, N, C, s, pr, w.wsplit,
                                     (2 * C) % 128 == 0 ? im : nullptr, io16, io16);
             if (fused < 0) TRY(fused, "kv_proj|q_proj");
@@ -255,6 +285,7 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
             if (!q_done)
                 TRY(linear(io16 ? y16 : x, L.kv_proj_w, nullptr, io16 ? nullptr : w.a1, io16 ? nullptr : w.o1, nullptr, nullptr,
                            w.big, nullptr, B, N, C, 2 * C, 0, s, pr, w.wsplit, im, io16, io16), "kv_proj");
+            }
             TRY(pool_attn_launch(w.big, L.inducers, w.part_o, w.part_ml, w.merged, B, N, C, H, I, ns, s, pr, io16), "pool_attn");
             TRY(linear(w.merged, L.pool_out_w, nullptr, nullptr, nullptr, nullptr, nullptr, w.h0, w.stats_s, B, I, C, C,
                        0, s, pr, w.wsplit, im ? im + w.o_pout : nullptr), "pool.out_proj");
@@ -283,9 +314,15 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
                    w.wsplit, im ? im + w.o_out : nullptr, io16, 0), "unpool.out_proj+residual");
         // x += mlp(AdaGN(x))
         TRY(coeffs(w.stats_x, Tn, N, t, ctx, &L.mlp_norm, w.a2, w.o2, B, C, G, s), "adagn_coeffs(mlp_norm)");
+        int m0_done = io16 ? astat_linear(x, w.a2, w.o2, im ? im + w.o_w0 : nullptr, L.mlp.b0, Wd, w.big, nullptr, 0,
+                                          nullptr, L.mlp.alpha, act, B, N, C, s)
+                           : 1;
+        if (m0_done < 0) TRY(m0_done, "mlp.0 (A-stationary)");
+        if (m0_done == 1) {
         if (io16) TRY(affine_cast_f16_launch(x, w.a2, w.o2, w.attn, B, N, C, s), "mlp_norm -> fp16");
         TRY(linear(io16 ? w.attn : x, L.mlp.w0, L.mlp.b0, io16 ? nullptr : w.a2, io16 ? nullptr : w.o2, L.mlp.alpha, nullptr,
                    w.big, nullptr, B, N, C, Wd, act, s, pr, w.wsplit, im ? im + w.o_w0 : nullptr, io16, io16), "mlp.0");
+        }
         float* so = (li + 1 < st->n_layers) ? w.stats_x : stats_out;
         TRY(linear(w.big, L.mlp.w2, L.mlp.b2, nullptr, nullptr, nullptr, x, x, so, B, N, Wd, C, 0, s, pr, w.wsplit,
                    im ? im + w.o_w2 : nullptr, io16, 0), "mlp.2+residual");

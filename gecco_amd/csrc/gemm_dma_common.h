@@ -16,10 +16,16 @@ __device__ __forceinline__ void dma16(const void* gsrc, float* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Counted waits as the s_waitcnt BUILTIN, not inline asm: the compiler's own wait-count scoreboard understands the
+// builtin, so after wait_vm_lgkm0 it knows every earlier LDS read has returned and does not put a second
+// s_waitcnt lgkmcnt(0) in front of the first MFMA that uses last step's fragments — which would also wait for the
+// fragment reads just issued for the NEXT step and expose their whole latency every K-step (it did, with asm).
+// gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14.
+constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 0xF) | (0x7 << 4) | ((lgkm & 0xF) << 8) | ((vm >> 4) << 14); }
 template <int N>
-__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wait_vm() { __builtin_amdgcn_s_waitcnt(waitcnt_imm(N, 0xF)); }
 template <int N>
-__device__ __forceinline__ void wait_vm_lgkm0() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wait_vm_lgkm0() { __builtin_amdgcn_s_waitcnt(waitcnt_imm(N, 0)); }
 
 // Which tile this block computes.  Optional second output segment (two linears over the same A in one launch): whole
 // column tiles belong to one segment (n_split % 128 == 0); columns below are relative to the segment.

@@ -205,6 +205,15 @@ __global__ __launch_bounds__(DNT, A16 ? 3 : 2) void gemm_f16_kernel(GemmArgs g) 
     auto kstep = [&](int kt, int cur) {
         // own reads of stage kt are complete (its slot may be refilled) and own pieces of stage kt + 1 landed
         wait_ahead<NPIECE>(min(nk - 1, kt + DNS - 1) - (kt + 1), true);
+        // this step's fragments were read during the previous one and the wait above covered them: an empty asm
+        // "redefines" the registers so the compiler's wait-count pass does not park its own lgkmcnt(0) in front of
+        // the first MFMA — behind the NEXT step's reads issued below, which would expose their latency every step
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            asm volatile("" : "+v"(fa[cur][c]));
+#pragma unroll
+            for (int j = 0; j < TNW; ++j) asm volatile("" : "+v"(fb[cur][j][c]));
+        }
         __builtin_amdgcn_s_barrier();
         if (kt + DNS < nk) issue(kt + DNS);
         // next K-step's slot; past the end a landed slot is re-read and the values are never used

@@ -227,12 +227,21 @@ __global__ __launch_bounds__(DNT, DNS <= 3 ? 3 : 2) void gemm_dma_kernel(GemmArg
         auto kstep = [&](int kt, int cur) {
             // own reads of stage kt are complete (its slot may be refilled) and own pieces of stage kt + 1 landed
             const int ahead = min(nk - 1, kt + DNS - 1) - (kt + 1);   // K-steps in flight beyond kt + 1
-            if (DNS >= 4 && ahead >= 2) {
-                if (NPIECE == 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-            } else if (ahead >= 1) {
-                if (NPIECE == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (DNS >= 4 && ahead >= 2) dma::wait_vm_lgkm0<2 * NPIECE>();
+            else if (ahead >= 1) dma::wait_vm_lgkm0<NPIECE>();
+            else dma::wait_vm_lgkm0<0>();
+            // this step's fragments were read during the previous one and the wait above covered them: an empty asm
+            // "redefines" the registers so the compiler's wait-count pass does not park its own lgkmcnt(0) in front
+            // of the first MFMA — behind the NEXT step's reads issued below, exposing their latency every step
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) {
+                asm volatile("" : "+v"(ahi[cur][i]));
+                asm volatile("" : "+v"(alo[cur][i]));
+            }
+#pragma unroll
+            for (int j = 0; j < TNW; ++j) {
+                asm volatile("" : "+v"(bhi[cur][j]));
+                asm volatile("" : "+v"(blo[cur][j]));
             }
             __builtin_amdgcn_s_barrier();
             if (kt + DNS < nk) issue(kt + DNS);

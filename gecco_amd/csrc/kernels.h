@@ -47,6 +47,11 @@ size_t split_f16_image_bytes(int Nout, int K);   // ceil(Nout / 128) * 128 * K *
 int split_f16_tiled_launch(const float* W, void* img, int Nout, int K, int ldw, hipStream_t st);
 int split_f16_tiled_multi_launch(const SplitJobs& jobs, hipStream_t st);
 
+// gemm_f16_astat.hip — fp16 mode, A-stationary: AdaGN apply + fp16 rounding + all column tiles in one pass over x
+// (fp32 A with optional prologue, fp16 outputs, one or two segments; K <= 384, full 128-tiles)
+bool gemm_f16_astat_supported(const GemmArgs& g);
+int gemm_f16_astat_launch(const GemmArgs& g, hipStream_t st);
+
 // gemm_general_f32.hip — C[z] = scale * op(A[z]) op(B[z]) (+ bias), per-operand layout flag, two-level batch strides
 struct GemmGeneralArgs {
     const float* A;   // a_kmajor ? (K, lda>=M) : (M, lda>=K)

@@ -62,7 +62,8 @@ __device__ __forceinline__ Tile tile_of_block(const GemmArgs& g) {
 }
 
 // acc[i][j]: the wave's 32 x 32 accumulator tiles (C/D layout), wave (wm, wn) of a WMN x (4 / WMN) wave grid.
-// Must be entered by all 256 threads with the operand ring dead (it reuses the LDS from offset 0).
+// Must be entered by all 256 threads with the operand ring dead (it reuses the LDS from offset 0); the caller's
+// barrier before it is the only block-wide one the store phase needs (a second one guards the statistics reduce).
 // C16: the output is stored as fp16 (round to nearest even; an intermediate its consumer would round anyway) — no
 // residual, no statistics in that form; ldc counts fp16 elements.
 template <int TMW, int TNW, int WMN, bool C16 = false>
@@ -93,6 +94,20 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, const Tile& t, f32x1
 #pragma unroll
         for (int jh = 0; jh < NJH; ++jh) {
             const int ncol0 = nseg0 + (wn * TNW + 2 * jh) * 32;
+            const int n = ncol0 + c4 * 4;
+            const bool nok = n < nseg;
+            const int nc = nok ? n : 0;
+            const int mrow0 = m0 + (wm * TMW + i) * 32;
+            // the residual rows of this sub-tile: all eight 16-byte loads in flight at once, issued before the
+            // transpose below so their HBM latency is paid once per sub-tile and partly under it
+            f32x4 rres[8];
+            if (Rb) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int m = min(mrow0 + it * 4 + lr, g.rows - 1);
+                    rres[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Rb + (size_t)m * g.ldr + nc));
+                }
+            }
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const int nn = ncol0 + jj * 32 + r;
@@ -107,48 +122,31 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, const Tile& t, f32x1
 #pragma unroll
                 for (int e = 0; e < 16; ++e) Tt[mfma_row(e, h) * D_TP + jj * 32 + r] = val[e];
             }
-            __syncthreads();
-            const int n = ncol0 + c4 * 4;
-            const bool nok = n < nseg;
-            const int nc = nok ? n : 0;
-            const int mrow0 = m0 + (wm * TMW + i) * 32;
+            // the transpose tile is wave-private: the wave's own LDS operations execute in order, no barrier needed
 #pragma unroll
-            for (int it0 = 0; it0 < 8; it0 += 4) {
-                f32x4 rres[4];
-                if (Rb) {
+            for (int it = 0; it < 8; ++it) {
+                const int m = mrow0 + it * 4 + lr;
+                f32x4 v4 = *reinterpret_cast<const f32x4*>(Tt + (it * 4 + lr) * D_TP + c4 * 4);
+                if (Rb) v4 += rres[it];
+                const bool ok = nok && m < g.rows;
+                if (C16) {
+                    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                    f16x4 hv;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int m = min(mrow0 + (it0 + c) * 4 + lr, g.rows - 1);
-                        rres[c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Rb + (size_t)m * g.ldr + nc));
-                    }
+                    for (int e = 0; e < 4; ++e) hv[e] = (_Float16)v4[e];
+                    if (ok)
+                        __builtin_nontemporal_store(__builtin_bit_cast(u32x2, hv),
+                                                    reinterpret_cast<u32x2*>(reinterpret_cast<_Float16*>(Cseg) +
+                                                                             ((size_t)b * g.rows + m) * ldc_seg + n));
+                } else if (ok) {
+                    __builtin_nontemporal_store(v4, reinterpret_cast<f32x4*>(Cb + (size_t)m * ldc_seg + n));
                 }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int it = it0 + c;
-                    const int m = mrow0 + it * 4 + lr;
-                    f32x4 v4 = *reinterpret_cast<const f32x4*>(Tt + (it * 4 + lr) * D_TP + c4 * 4);
-                    if (Rb) v4 += rres[c];
-                    const bool ok = nok && m < g.rows;
-                    if (C16) {
-                        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-                        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-                        f16x4 hv;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) hv[e] = (_Float16)v4[e];
-                        if (ok)
-                            __builtin_nontemporal_store(__builtin_bit_cast(u32x2, hv),
-                                                        reinterpret_cast<u32x2*>(reinterpret_cast<_Float16*>(Cseg) +
-                                                                                 ((size_t)b * g.rows + m) * ldc_seg + n));
-                    } else if (ok) {
-                        __builtin_nontemporal_store(v4, reinterpret_cast<f32x4*>(Cb + (size_t)m * ldc_seg + n));
-                    }
-                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                    const f32x4 vz = ok ? v4 : z;
-                    s1[jh] += vz;
-                    s2[jh] += vz * vz;
-                }
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 vz = ok ? v4 : z;
+                s1[jh] += vz;
+                s2[jh] += vz * vz;
             }
-            __syncthreads();
         }
     }
     if (g.stats) {

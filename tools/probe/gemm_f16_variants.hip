@@ -40,6 +40,9 @@ int main() {
             g.alpha = alpha; g.residual = s.res ? R : nullptr; g.C = C; g.stats = s.stats ? stats : nullptr;
             g.B = B; g.rows = N; g.K = s.K; g.Nout = s.Nout; g.lda = s.K; g.ldw = s.K; g.ldc = s.Nout; g.ldr = s.Nout; g.act = s.act;
             g.precision = prec; g.w_img = img;
+#ifdef PROBE_A16
+            g.a_f16 = 1; g.pro_a = nullptr; g.pro_o = nullptr; if (!s.res) g.c_f16 = 1;
+#endif
             split_f16_tiled_launch(W, img, s.Nout, s.K, s.K, 0);
             const double fl = 2.0 * B * N * s.K * s.Nout;
             const float t0 = time_ms(g);

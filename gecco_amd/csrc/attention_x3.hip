@@ -247,29 +247,36 @@ __global__ __launch_bounds__(256, 2) void pool_attn_x3_kernel(const float* __res
                 }
             }
             const int kbase = k_begin + tile * 32;
+            const bool ragged = kbase + 32 > k_end;   // wave-uniform: only a split's last tile masks keys
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 float mx = -INFINITY;
+                if (ragged) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    if (kbase + mfma_row(e, h) >= k_end) s[j][e] = -INFINITY;
-                    mx = fmaxf(mx, s[j][e]);
+                    for (int e = 0; e < 16; ++e)
+                        if (kbase + mfma_row(e, h) >= k_end) s[j][e] = -INFINITY;
                 }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[j][e]);
                 mx = fmaxf(mx, xor32(mx));
                 const float mn = fmaxf(m[j], mx);  // finite: the tile holds >= 1 valid key
-                const float alpha = exp2f(m[j] - mn);
+                // v_exp_f32 directly: arguments are <= 0, results in (0, 1]; what it flushes is below 2^-126
+                const float alpha = __builtin_amdgcn_exp2f(m[j] - mn);
                 float ps = 0.f;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    s[j][e] = exp2f(s[j][e] - mn);
+                    s[j][e] = __builtin_amdgcn_exp2f(s[j][e] - mn);
                     ps += s[j][e];
                 }
                 l[j] = l[j] * alpha + ps;
                 m[j] = mn;
+                // the running maximum settles after a few tiles: rescale the accumulators only when some query's moved
+                if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
+                    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) O[dt][j][e] *= alpha;
+                        for (int e = 0; e < 16; ++e) O[dt][j][e] *= alpha;
+                }
             }
 #pragma unroll
             for (int sg = 0; sg < 2; ++sg) {   // the tile's two 16-key chunks
@@ -483,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void unpool_attn_x3_kernel(const float* __r
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                s[kt][e] = exp2f(s[kt][e] - mx);
+                s[kt][e] = __builtin_amdgcn_exp2f(s[kt][e] - mx);
                 ls += s[kt][e];
             }
         ls += xor32(ls);

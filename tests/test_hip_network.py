@@ -62,30 +62,37 @@ def test_uncond_golden(ops, golden_dir, name):
     assert torch.equal(den, den2)
 
 
-def test_cached_mode_golden(ops, golden_dir):
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16x3", 2e-4), ("fp16", 1e-3)])
+def test_cached_mode_golden(ops, golden_dir, precision, tol):
     g = _load(golden_dir, "cached_d128_L4")
     p, x, sigma, x_new = cases.cached_inputs()
-    net = ops.LinearLiftPlan(_cuda(p), cases.H, cases.I)
+    net = ops.LinearLiftPlan(_cuda(p), cases.H, cases.I, precision=precision)
     den, cache = net.forward(x.cuda(), sigma.cuda(), do_cache=True)
-    _close(torch.stack(cache), g["cache"])
+    # the cached inducer states are internal tensors (the 1e-3 bar is on the forward's output): 5x slack in the
+    # reduced-precision modes, where the max-norm is carried by a few inducers
+    e = _close(torch.stack(cache), g["cache"], tol if precision == "fp32" else 5 * tol)
     out = net.forward(x_new.cuda(), sigma.cuda(), cache=[c.cuda() for c in g["cache"]])
-    _close(out, g["out_new"])
+    e2 = _close(out, g["out_new"], tol)
+    print("cached", precision, "cache", e, "out_new", e2)
 
 
-@pytest.mark.parametrize("B,N,d,L", [(3, 333, 128, 2), (2, 2048, 384, 1), (1, 4096, 512, 1), (2, 100, 64, 3)])
-def test_uncond_vs_oracle_ragged(ops, B, N, d, L):
-    """Sizes the golden set does not hold (ragged N, d=512, N=4096), oracle computed on the fly."""
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16x3", 2e-4), ("fp16", 1e-3)])
+@pytest.mark.parametrize("B,N,d,L", [(3, 333, 128, 2), (2, 2048, 384, 1), (1, 4096, 512, 1), (2, 100, 64, 3), (2, 130, 256, 1)])
+def test_uncond_vs_oracle_ragged(ops, B, N, d, L, precision, tol):
+    """Sizes the golden set does not hold (ragged N, d=512, N=4096, head dim 8 that stays on the fp32 attention
+    kernels, rows < 128), oracle computed on the fly, every arithmetic mode."""
     from oracle import weights as W
     p = W.linear_lift_state_dict(77 + N, d, L, cases.I, cases.H)
     x, sigma = W.synthetic_cloud(N, B, N)
     with torch.no_grad():
         ref, raw_ref = cpu_ref.uncond_denoiser(p, "", cases.H)(x, sigma, return_raw=True)
-    den, raw = ops.LinearLiftPlan(_cuda(p), cases.H, cases.I).forward(x.cuda(), sigma.cuda(), return_raw=True)
-    _close(den, ref)
-    _close(raw, raw_ref)
+    den, raw = ops.LinearLiftPlan(_cuda(p), cases.H, cases.I, precision=precision).forward(x.cuda(), sigma.cuda(), return_raw=True)
+    _close(den, ref, tol)
+    _close(raw, raw_ref, tol)
 
 
-def test_full_size_properties(ops):
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "fp16"])
+def test_full_size_properties(ops, precision):
     """BASELINE config C2 (B=64, N=2048, d=384, L=6) is too slow for the CPU oracle inside a test, so
     check size-independent properties: (1) samples are independent — evaluating a batch equals
     evaluating its samples in two half batches, bit for bit; (2) permutation equivariance over the
@@ -95,7 +102,7 @@ def test_full_size_properties(ops):
     p = _cuda(W.linear_lift_state_dict(3, d, L, cases.I, cases.H))
     x, sigma = W.synthetic_cloud(0, B, N)
     x, sigma = x.cuda(), sigma.cuda()
-    net = ops.LinearLiftPlan(p, cases.H, cases.I)
+    net = ops.LinearLiftPlan(p, cases.H, cases.I, precision=precision)
     full = net.forward(x, sigma)
     assert torch.isfinite(full).all()
     lo = net.forward(x[:32].contiguous(), sigma[:32].contiguous())
@@ -103,7 +110,12 @@ def test_full_size_properties(ops):
     assert torch.equal(full, torch.cat([lo, hi]))
     perm = torch.randperm(N, device="cuda")
     full_p = net.forward(x[:4, perm].contiguous(), sigma[:4].contiguous())
-    _close(full_p, full[:4, perm].cpu(), 1e-4)
+    _close(full_p, full[:4, perm].cpu(), {"fp32": 1e-4, "bf16x3": 2e-4, "fp16": 2e-3}[precision])
+    if precision != "fp32":   # and the mode stays inside the parity bar at full size (against the exact-fp32 mode)
+        exact = ops.LinearLiftPlan(p, cases.H, cases.I, precision="fp32").forward(x[:8].contiguous(), sigma[:8].contiguous())
+        e = cpu_ref.rel_err(full[:8].cpu(), exact.cpu())
+        print("C2", precision, "vs exact fp32 mode", e)
+        assert e[0] < 1e-3, e
 
 
 @pytest.mark.parametrize("name", list(cases.UNCOND_CASES))

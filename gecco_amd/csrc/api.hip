@@ -632,7 +632,7 @@ int make_lookup_args(const GeccoReparam* rp, const GeccoPyramid* pyr, LookupArgs
 }
 
 struct RNWorkspace {
-    float *feat, *raw, *coef, *stats_raw, *stats_x, *stats_out, *a_raw, *o_raw, *a_out, *o_out;
+    float *feat, *raw, *coef, *stats_raw, *stats_x, *stats_out, *a_raw, *o_raw, *a_out, *o_out, *wsplit;
     void* st_ws;
     size_t st_bytes, bytes;
 };
@@ -651,6 +651,7 @@ RNWorkspace carve_rn(const GeccoRayNetwork* m, int c_total, int B, int N, void* 
     w.o_raw = c.f32((size_t)B * c_total);
     w.a_out = c.f32((size_t)B * C);
     w.o_out = c.f32((size_t)B * C);
+    w.wsplit = c.f32(((C + 127) / 128 * 128) * (size_t)c_total);   // tiled image of img_feature_proj (precision 1 / 2)
     c.off = (c.off + 255) & ~size_t(255);
     w.st_bytes = carve_st(&m->backbone, B, N, nullptr).bytes;
     w.st_ws = base ? static_cast<char*>(base) + c.off : nullptr;
@@ -700,7 +701,7 @@ int gecco_ray_network_fwd_f32(const GeccoRayNetwork* m, const float* x, const fl
     // point_features = xyz_features + Linear(GN16(lookup))  (models/ray.py:112-113): GN apply in the GEMM
     // prologue, the add as its residual, the first AdaGN's statistics in its epilogue
     TRY(linear(w.raw, m->img_w, m->img_b, w.a_raw, w.o_raw, nullptr, w.feat, w.feat, w.stats_x, B, N, a.c_total, C, 0,
-               s), "img_feature_proj");
+               s, m->backbone.precision, w.wsplit), "img_feature_proj");
     rc = st_forward(&m->backbone, w.feat, w.coef + 4 * (size_t)B, w.stats_x, row_tiles_gemm(N), h_in, h_out,
                     w.stats_out, B, N, w.st_ws, w.st_bytes, s);
     if (rc) return rc;

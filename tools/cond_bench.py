@@ -26,6 +26,8 @@ def ray_state_dict(p_ll, cdims=(96, 192, 384)):
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    ops.set_default_precision(os.environ.get("GECCO_PRECISION", "fp16"))
+    print("precision", ops.default_precision())
     N = 2048
     dev = torch.device("cuda", 0)
     p_ll = bench.random_state_dict(3)

@@ -8,6 +8,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define GECCO_WAVE 64
 
+// Streaming hints on the big once-per-kernel streams.  GECCO_PLAIN_MEMOPS builds the same kernels with default-policy
+// accesses (A/B of what the next kernel finds in the Infinity Cache; tools/README in DESIGN.md section 6).
+#ifdef GECCO_PLAIN_MEMOPS
+#define GECCO_NT_LOAD(p) (*(p))
+#define GECCO_NT_STORE(v, p) (*(p) = (v))
+#else
+#define GECCO_NT_LOAD(p) __builtin_nontemporal_load(p)
+#define GECCO_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
+#endif
+
 // Row of accumulator register `reg` (0..15) for lane-half `h` of a 32x32 MFMA tile
 // (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)).
 __device__ __forceinline__ int mfma_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }

@@ -105,7 +105,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, const Tile& t, f32x1
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
                     const int m = min(mrow0 + it * 4 + lr, g.rows - 1);
-                    rres[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Rb + (size_t)m * g.ldr + nc));
+                    rres[it] = GECCO_NT_LOAD(reinterpret_cast<const f32x4*>(Rb + (size_t)m * g.ldr + nc));
                 }
             }
 #pragma unroll
@@ -136,11 +136,11 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, const Tile& t, f32x1
 #pragma unroll
                     for (int e = 0; e < 4; ++e) hv[e] = (_Float16)v4[e];
                     if (ok)
-                        __builtin_nontemporal_store(__builtin_bit_cast(u32x2, hv),
+                        GECCO_NT_STORE(__builtin_bit_cast(u32x2, hv),
                                                     reinterpret_cast<u32x2*>(reinterpret_cast<_Float16*>(Cseg) +
                                                                              ((size_t)b * g.rows + m) * ldc_seg + n));
                 } else if (ok) {
-                    __builtin_nontemporal_store(v4, reinterpret_cast<f32x4*>(Cb + (size_t)m * ldc_seg + n));
+                    GECCO_NT_STORE(v4, reinterpret_cast<f32x4*>(Cb + (size_t)m * ldc_seg + n));
                 }
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
                 const f32x4 vz = ok ? v4 : z;

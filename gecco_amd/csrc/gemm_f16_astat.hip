@@ -119,8 +119,8 @@ __global__ __launch_bounds__(BM * 4, 1) void gemm_f16_astat_kernel(GemmArgs g) {
                 const int i = min(i0 + u * S_NT, nitems - 1);
                 const int row = i / c8n, c8 = i - row * c8n;
                 const float* src = xb + (size_t)row * g.lda + c8 * 8;
-                x0[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
-                x1[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + 4));
+                x0[u] = GECCO_NT_LOAD(reinterpret_cast<const f32x4*>(src));
+                x1[u] = GECCO_NT_LOAD(reinterpret_cast<const f32x4*>(src + 4));
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {

@@ -115,8 +115,8 @@ __global__ __launch_bounds__(256) void affine_cast_f16_kernel(const float* __res
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (size_t)gridDim.x * blockDim.x) {
         const size_t b = i / rowsC8;
         const int c8 = (int)(i % C8);
-        const f32x4 x0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x) + 2 * i);
-        const f32x4 x1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x) + 2 * i + 1);
+        const f32x4 x0 = GECCO_NT_LOAD(reinterpret_cast<const f32x4*>(x) + 2 * i);
+        const f32x4 x1 = GECCO_NT_LOAD(reinterpret_cast<const f32x4*>(x) + 2 * i + 1);
         const f32x4 a0 = reinterpret_cast<const f32x4*>(a)[(b * C8 + c8) * 2], a1 = reinterpret_cast<const f32x4*>(a)[(b * C8 + c8) * 2 + 1];
         const f32x4 o0 = reinterpret_cast<const f32x4*>(o)[(b * C8 + c8) * 2], o1 = reinterpret_cast<const f32x4*>(o)[(b * C8 + c8) * 2 + 1];
         f16x8_t v;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void lower_edm_v4_kernel(const float* __restri
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
         const int ch = sub + 16 * i;
-        v[i] = ch < nch ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(feat + row * C) + ch) : z;
+        v[i] = ch < nch ? GECCO_NT_LOAD(reinterpret_cast<const f32x4*>(feat + row * C) + ch) : z;
     }
     if (gn_a) {
 #pragma unroll

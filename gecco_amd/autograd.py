@@ -43,6 +43,13 @@ def _reduce(parts: Tensor, n: int, Z: int, stride: int) -> Tensor:
     return out
 
 
+def _train_precision() -> str:
+    """Arithmetic of the N-token linears in the training path: the module default, except that the fp16 mode is not used
+    for gradients (no loss scaling: small gradient values would flush) — split-bf16 has the fp32 exponent range."""
+    p = hip_ops.default_precision()
+    return "bf16x3" if p == "fp16" else p
+
+
 def _new(*shape, like: Tensor) -> Tensor:
     return torch.empty(*shape, device=like.device, dtype=torch.float32)
 
@@ -56,7 +63,7 @@ class LinearFn(torch.autograd.Function):
         x = _f(x)
         ctx.save_for_backward(x, W)
         ctx.has_bias = b is not None
-        return hip_ops.linear(x, W, b)
+        return hip_ops.linear(x, W, b, precision=_train_precision())
 
     @staticmethod
     def backward(ctx, dy):
@@ -65,8 +72,12 @@ class LinearFn(torch.autograd.Function):
         B, R, K = x.shape
         Nout = W.shape[0]
         dx = dW = db = None
-        if ctx.needs_input_grad[0]:  # dx = dy W : W read k-major (reduction over its rows)
-            dx = _gemm(dy, W, _new(B, R, K, like=x), Z=1, zdiv=1, M=B * R, N=K, K=Nout, lda=Nout, ldb=K, ldc=K, b_km=True)
+        if ctx.needs_input_grad[0]:
+            if R >= 128 and Nout % 16 == 0 and K % 4 == 0:
+                # dx = dy W = linear(dy, W^T): the fused LDS-DMA GEMM on a transposed copy of the (small) weight
+                dx = hip_ops.linear(dy, W.t().contiguous(), precision=_train_precision())
+            else:  # W read k-major (reduction over its rows)
+                dx = _gemm(dy, W, _new(B, R, K, like=x), Z=1, zdiv=1, M=B * R, N=K, K=Nout, lda=Nout, ldb=K, ldc=K, b_km=True)
         if ctx.needs_input_grad[1]:  # dW = dy^T x : both read k-major; one partial per sample, summed in order
             parts = _gemm(dy, x, _new(B, Nout, K, like=x), Z=B, zdiv=1, M=Nout, N=K, K=R, lda=Nout, ldb=K, ldc=K,
                           sA=(R * Nout, 0), sB=(R * K, 0), sC=(Nout * K, 0), a_km=True, b_km=True)

@@ -142,14 +142,31 @@ __global__ __launch_bounds__(GNT) void gemm_general_kernel(GemmGeneralArgs g) {
     }
 }
 
-// out[i] = sum_z parts[z * stride + i]   (fixed order: deterministic parameter gradients)
-__global__ void reduce_batch_kernel(const float* __restrict__ parts, float* __restrict__ out, size_t n, int Z,
-                                    size_t stride, int accumulate) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+// out[i] = sum_z parts[z * stride + i]   (fixed order z = 0, 1, ..: deterministic parameter gradients)
+// 16 bytes per thread, eight independent loads in flight per round; the additions stay strictly in z order.
+__global__ __launch_bounds__(256) void reduce_batch_kernel(const float* __restrict__ parts, float* __restrict__ out,
+                                                           size_t n, int Z, size_t stride, int accumulate) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= n) return;
-    float s = accumulate ? out[i] : 0.f;
-    for (int z = 0; z < Z; ++z) s += parts[(size_t)z * stride + i];
-    out[i] = s;
+    if (i + 4 <= n && !(stride & 3)) {
+        f32x4 s = accumulate ? *reinterpret_cast<const f32x4*>(out + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+        int z = 0;
+        for (; z + 8 <= Z; z += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(parts + (size_t)(z + u) * stride + i));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; z < Z; ++z) s += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(parts + (size_t)z * stride + i));
+        *reinterpret_cast<f32x4*>(out + i) = s;
+    } else {
+        for (size_t j = i; j < n && j < i + 4; ++j) {
+            float s = accumulate ? out[j] : 0.f;
+            for (int z = 0; z < Z; ++z) s += parts[(size_t)z * stride + j];
+            out[j] = s;
+        }
+    }
 }
 
 }  // namespace
@@ -169,7 +186,7 @@ int gemm_general_launch(const GemmGeneralArgs& g, hipStream_t st) {
 
 int reduce_batch_launch(const float* parts, float* out, size_t n, int Z, size_t stride, int accumulate,
                         hipStream_t st) {
-    hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, parts, out, n, Z,
+    hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, parts, out, n, Z,
                        stride, accumulate);
     return (int)hipGetLastError();
 }

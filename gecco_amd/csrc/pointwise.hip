@@ -17,9 +17,36 @@ __device__ __forceinline__ float wave_sum(float v) {
 // Used where no producer epilogue exists (unit-level AdaGN, cached-mode first touch).
 __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ x, float* __restrict__ stats,
                                                         int rows, int C, int T) {
+    // 16-byte column chunks; the 256 threads cover C/4 chunks x RL row lanes, lane rl sums rows m0 + rl, + RL, ..;
+    // the RL partials are combined through LDS in lane order (deterministic)
+    __shared__ f32x4 red[2][256];
     const int tile = blockIdx.x % T, b = blockIdx.x / T;
     const int m0 = tile * STATS_ROWS, m1 = min(rows, m0 + STATS_ROWS);
     const float* xb = x + (size_t)b * rows * C;
+    if (C % 4 == 0 && C / 4 <= 256) {
+        const int c4n = C / 4, RL = 256 / c4n;
+        const int c4 = threadIdx.x % c4n, rl = threadIdx.x / c4n;
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+        if (rl < RL) {
+            for (int m = m0 + rl; m < m1; m += RL) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (size_t)m * C + c4 * 4);
+                s1 += v;
+                s2 += v * v;
+            }
+            red[0][threadIdx.x] = s1;
+            red[1][threadIdx.x] = s2;
+        }
+        __syncthreads();
+        if (rl == 0) {
+            for (int q = 1; q < RL; ++q) {
+                s1 += red[0][q * c4n + c4];
+                s2 += red[1][q * c4n + c4];
+            }
+            *reinterpret_cast<f32x4*>(stats + (((size_t)b * T + tile) * 2 + 0) * C + c4 * 4) = s1;
+            *reinterpret_cast<f32x4*>(stats + (((size_t)b * T + tile) * 2 + 1) * C + c4 * 4) = s2;
+        }
+        return;
+    }
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float s1 = 0.f, s2 = 0.f;
         for (int m = m0; m < m1; ++m) {

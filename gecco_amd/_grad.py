@@ -1,7 +1,7 @@
 """Autograd routing.  The fused inference entry points keep no intermediates; when autograd would record a call
 (`needs_grad`) the modules switch to the unfused training path of gecco_amd/autograd.py (forward and backward both
-in HIP).  Modules without a backward yet (RayNetwork's projective lookup) refuse instead of silently returning
-tensors without a grad graph."""
+in HIP).  A module without a backward must refuse (`require_no_grad`) instead of silently returning tensors without a
+grad graph."""
 import torch
 
 

@@ -101,6 +101,7 @@ SIGNATURES = {
     "gecco_bilinear_taps_f32": (i, [vp, i, i, vp, vp, vp, vp, sz, vp]),
     "gecco_ray_lookup_f32": (i, [vp, vp, vp, C.POINTER(GeccoReparam), C.POINTER(GeccoPyramid), vp, vp, i, i, vp]),
     "gecco_lookup_row_tiles": (i, [i]),
+    "gecco_ray_lookup_bwd_f32": (i, [vp, vp, vp, C.POINTER(GeccoReparam), C.POINTER(GeccoPyramid), vp, PP, i, i, vp]),
     "gecco_ray_network_fwd_f32": (i, [C.POINTER(GeccoRayNetwork), vp, vp, vp, C.POINTER(GeccoPyramid), vp, vp, PP, PP,
                                       i, i, vp, sz, vp]),
     "gecco_ray_network_workspace_bytes": (sz, [C.POINTER(GeccoRayNetwork), C.POINTER(GeccoPyramid), i, i]),

@@ -312,6 +312,61 @@ class LowerFn(torch.autograd.Function):
         return dfeat, red[: 3 * Cc].reshape(3, Cc), red[3 * Cc: 3 * Cc + 3].contiguous(), None
 
 
+class Linear3Fn(torch.autograd.Function):
+    """F = Linear(C -> 3)(y) on (B, N, C) (RayNetwork.output_proj[1], reference models/ray.py:56-59)."""
+
+    @staticmethod
+    def forward(ctx, y, W, b):
+        y = _f(y)
+        ctx.save_for_backward(y, W)
+        B, _, Cc = y.shape
+        one, zero = torch.ones(B, Cc, device=y.device), torch.zeros(B, Cc, device=y.device)
+        return hip_ops.lower_edm(y, None, None, W, b, gn=(one, zero))
+
+    @staticmethod
+    def backward(ctx, dF):
+        y, W = ctx.saved_tensors
+        dF = _f(dF)
+        lib = _lib.load()
+        B, N, Cc = y.shape
+        # dy = dF W  (a Linear(3 -> C) with weight W^T: the lift kernel);  dW[o, c] = sum_n dF[n, o] y[n, c] is the
+        # lift's weight-gradient kernel with the roles of its two inputs exchanged
+        dy = hip_ops.lift(dF, None, W.t().contiguous(), None)
+        T = lib.gecco_stats_row_tiles(N)
+        part = _new(B, T, 4, Cc, like=y)
+        _lib.check(lib.gecco_lift_bwd_f32(_ptr(y), _ptr(dF), _ptr(part), B, N, Cc, _stream()), "lift_bwd")
+        red = _reduce(part, 4 * Cc, B * T, 4 * Cc).reshape(4, Cc)
+        return dy, red[:3].contiguous(), dF.sum(dim=(0, 1))
+
+
+class LookupFn(torch.autograd.Function):
+    """RayNetwork.extract_image_features with a gradient into the pyramid levels (reference models/ray.py:64-87;
+    the geometry is the noised data and carries no gradient)."""
+
+    @staticmethod
+    def forward(ctx, geom, K, reparam_spec, *features):
+        levels = hip_ops.to_channels_last_levels([f.detach() for f in features])
+        rp = hip_ops.make_reparam(*reparam_spec)
+        ctx.save_for_backward(geom, K, *levels)
+        ctx.spec = reparam_spec
+        return hip_ops.ray_lookup(geom, K, levels, rp)
+
+    @staticmethod
+    def backward(ctx, dout):
+        geom, K, *levels = ctx.saved_tensors
+        dout = _f(dout)
+        lib = _lib.load()
+        B, N, _ = geom.shape
+        rp = hip_ops.make_reparam(*ctx.spec)
+        pyr = hip_ops.make_pyramid(levels)
+        grads = [torch.zeros_like(f) for f in levels]   # (B, H, W, C)
+        arr = (C.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
+        _lib.check(lib.gecco_ray_lookup_bwd_f32(_ptr(geom), None, _ptr(K), C.byref(rp), C.byref(pyr), _ptr(dout), arr, B, N,
+                                                _stream()), "gecco_ray_lookup_bwd_f32")
+        # handed back NCHW-shaped (channels-last strides, no copy)
+        return (None, None, None, *[g.permute(0, 3, 1, 2) for g in grads])
+
+
 # ------------------------------------------------------------------------------------------- network composition
 def adagn(mod, x, t):
     return AdaGNFn.apply(x, t, mod.scale.weight, mod.scale.bias, mod.bias.weight, mod.bias.bias, mod.gn.num_groups, mod.gn.eps)
@@ -363,6 +418,35 @@ def set_transformer(st, feats, t, return_h=False, hs=None):
         feats, h = broadcasting_layer(layer, feats, t, h)
         stored.append(h)
     return feats, (stored if return_h else None)
+
+
+def group_norm(x, G, eps):
+    return AdaGNFn.apply(x, None, None, None, None, None, G, eps)
+
+
+def ray_network(net, geometry, t, K, features, do_cache=False, cache=None):
+    """RayNetwork.forward with autograd (reference models/ray.py:89-120)."""
+    g = _f(geometry.float())
+    xyz = LiftFn.apply(g, net.xyz_embed.weight, net.xyz_embed.bias)
+    raw = LookupFn.apply(g, _f(K.float()), net.reparam.lookup_spec(), *features)
+    gn, lin = net.img_feature_proj[0], net.img_feature_proj[1]
+    feats = xyz + LinearFn.apply(group_norm(raw, gn.num_groups, gn.eps), lin.weight, lin.bias)
+    feats, out_cache = set_transformer(net.backbone, feats, t, do_cache, cache)
+    gn2, lin2 = net.output_proj[0], net.output_proj[1]
+    return Linear3Fn.apply(group_norm(feats, gn2.num_groups, gn2.eps), lin2.weight, lin2.bias), out_cache
+
+
+def ray_network_edm(net, x, sigma, sigma_data, K, features, do_cache=False, cache=None):
+    """EDMPrecond(RayNetwork).forward with autograd (reference diffusion.py:46-57)."""
+    sigma = sigma.reshape(-1, 1, 1).float()
+    sd = float(sigma_data)
+    c_skip = sd ** 2 / (sigma ** 2 + sd ** 2)
+    c_out = sigma * sd / (sigma ** 2 + sd ** 2).sqrt()
+    c_in = 1 / (sd ** 2 + sigma ** 2).sqrt()
+    c_noise = sigma.log() / 4
+    F_x, out_cache = ray_network(net, c_in * x, c_noise, K, features, do_cache, cache)
+    den = c_skip * x + c_out * F_x
+    return (den, out_cache) if do_cache else den
 
 
 def linear_lift_edm(net, x, sigma, sigma_data, do_cache=False, cache=None):

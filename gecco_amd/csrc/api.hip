@@ -673,6 +673,19 @@ int gecco_ray_lookup_f32(const float* geom, const float* coef, const float* K, c
     return 0;
 }
 
+int gecco_ray_lookup_bwd_f32(const float* geom, const float* coef, const float* K, const GeccoReparam* rp,
+                             const GeccoPyramid* pyr, const float* dout, float* const* dfeat, int B, int N,
+                             void* stream) {
+    if (!geom || !K || !dout || !dfeat || !pyr) return fail(-1, "ray_lookup_bwd: null argument");
+    LookupArgs a;
+    int rc = make_lookup_args(rp, pyr, &a);
+    if (rc) return rc;
+    for (int l = 0; l < a.n_levels; ++l)
+        if (!dfeat[l]) return fail(-1, "ray_lookup_bwd: null gradient level");
+    TRY(ray_lookup_bwd_launch(geom, coef, K, a, dfeat, dout, B, N, (hipStream_t)stream), "ray_lookup_bwd");
+    return 0;
+}
+
 size_t gecco_ray_network_workspace_bytes(const GeccoRayNetwork* m, const GeccoPyramid* pyr, int B, int N) {
     int ct = 0;
     for (int l = 0; l < pyr->n_levels && l < 4; ++l) ct += pyr->C[l];

@@ -114,6 +114,8 @@ struct LookupArgs {
 int lookup_row_tile();
 int ray_lookup_launch(const float* geom, const float* coef, const float* K, const LookupArgs& a, float* out,
                       float* stats, int B, int N, hipStream_t st);
+int ray_lookup_bwd_launch(const float* geom, const float* coef, const float* K, const LookupArgs& a,
+                          float* const* dfeat, const float* dout, int B, int N, hipStream_t st);   // dfeat: zeroed, NHWC
 int bilinear_taps_launch(const float* uv, int Hh, int Ww, int* x0, int* y0, float* wx1, float* wy1, size_t n,
                          hipStream_t st);
 int nchw_to_nhwc_launch(const float* src, float* dst, int B, int C, int Hh, int Ww, hipStream_t st);

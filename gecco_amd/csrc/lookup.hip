@@ -156,6 +156,77 @@ __global__ __launch_bounds__(256) void ray_lookup_kernel(const float* __restrict
     }
 }
 
+// Backward of the lookup with respect to the pyramids (autograd of F.grid_sample w.r.t. its input, reference
+// models/ray.py:82-85 under loss.backward()): dfeat[l][b, y, x, c] += w_tap * dout[b, n, c] over the four taps of every
+// point.  Same projection and tap arithmetic as the forward; float atomics, like torch's own grid_sampler backward
+// (so, unlike every other gradient of the path, the summation order — the last bits — may differ run to run).
+struct LookupGrads {
+    float* d[4];   // channels-last (B, H, W, C) per level, zero-initialised by the caller
+};
+
+__global__ __launch_bounds__(256) void ray_lookup_bwd_kernel(const float* __restrict__ geom,
+                                                             const float* __restrict__ coef,
+                                                             const float* __restrict__ K, LookupArgs a, LookupGrads gr,
+                                                             const float* __restrict__ dout, int N, int T) {
+    const int tile = blockIdx.x % T, b = blockIdx.x / T;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int Ct = a.c_total, C4 = Ct / 4;
+    const float cin = coef ? coef[4 * b + 2] : 1.0f;
+    const float* Kb = K + (size_t)b * 9;
+    constexpr int MAXCH = 4;
+    int lvl[MAXCH], coff[MAXCH];
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) {
+        const int ch = (c * 64 + lane) * 4;
+        int l = 0, base = 0;
+        while (l + 1 < a.n_levels && ch >= base + a.C[l]) {
+            base += a.C[l];
+            ++l;
+        }
+        lvl[c] = l;
+        coff[c] = ch - base;
+    }
+    const int m0 = tile * LOOKUP_ROWS, m1 = min(N, m0 + LOOKUP_ROWS);
+    for (int m = m0 + wave; m < m1; m += 4) {
+        const float* gp = geom + ((size_t)b * N + m) * 3;
+        float u, v;
+        project_uv(cin * gp[0], cin * gp[1], cin * gp[2], Kb, a.reparam_kind, a.rp_mean, a.rp_std, a.logit_scale, u, v);
+        Taps tp[4];
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+            if (l < a.n_levels) tp[l] = bilinear_taps(u, v, a.H[l], a.W[l]);
+        const float* grow = dout + ((size_t)b * N + m) * Ct;
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) {
+            const int c4 = c * 64 + lane;
+            if (c4 >= C4) continue;
+            const int l = lvl[c];
+            Taps t = tp[0];
+#pragma unroll
+            for (int q = 1; q < 4; ++q)
+                if (l == q) t = tp[q];
+            const int Hh = a.H[l], Ww = a.W[l], Cl = a.C[l];
+            float* fb = gr.d[l] + (size_t)b * Hh * Ww * Cl + coff[c];
+            const int x1 = t.x0 + 1, y1 = t.y0 + 1;
+            const float wx0 = (float)x1 - t.ix, wy0 = (float)y1 - t.iy;
+            const float wx1 = t.ix - (float)t.x0, wy1 = t.iy - (float)t.y0;
+            const bool bx0 = t.x0 >= 0 && t.x0 <= Ww - 1, bx1 = x1 >= 0 && x1 <= Ww - 1;
+            const bool by0 = t.y0 >= 0 && t.y0 <= Hh - 1, by1 = y1 >= 0 && y1 <= Hh - 1;
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(grow + c4 * 4);
+            auto add = [&](bool ok, int yy, int xx, float w) {
+                if (!ok) return;
+                float* p = fb + ((size_t)yy * Ww + xx) * Cl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomicAdd(p + e, g4[e] * w);
+            };
+            add(bx0 && by0, t.y0, t.x0, wx0 * wy0);
+            add(bx1 && by0, t.y0, x1, wx1 * wy0);
+            add(bx0 && by1, y1, t.x0, wx0 * wy1);
+            add(bx1 && by1, y1, x1, wx1 * wy1);
+        }
+    }
+}
+
 // integer tap indices + fractional weights for given uv (the bit-exact part, testable in isolation)
 __global__ void bilinear_taps_kernel(const float* __restrict__ uv, int Hh, int Ww, int* __restrict__ x0,
                                      int* __restrict__ y0, float* __restrict__ wx1, float* __restrict__ wy1, size_t n) {
@@ -199,6 +270,16 @@ int ray_lookup_launch(const float* geom, const float* coef, const float* K, cons
     if (tot != a.c_total) return -8;
     const int T = (N + LOOKUP_ROWS - 1) / LOOKUP_ROWS;
     hipLaunchKernelGGL(ray_lookup_kernel, dim3(B * T), dim3(256), 0, st, geom, coef, K, a, out, stats, N, T);
+    return (int)hipGetLastError();
+}
+
+int ray_lookup_bwd_launch(const float* geom, const float* coef, const float* K, const LookupArgs& a,
+                          float* const* dfeat, const float* dout, int B, int N, hipStream_t st) {
+    if (a.n_levels < 1 || a.n_levels > 4 || a.c_total > 1024 || a.c_total % 4) return -8;
+    LookupGrads gr;
+    for (int l = 0; l < 4; ++l) gr.d[l] = l < a.n_levels ? dfeat[l] : nullptr;
+    const int T = (N + LOOKUP_ROWS - 1) / LOOKUP_ROWS;
+    hipLaunchKernelGGL(ray_lookup_bwd_kernel, dim3(B * T), dim3(256), 0, st, geom, coef, K, a, gr, dout, N, T);
     return (int)hipGetLastError();
 }
 

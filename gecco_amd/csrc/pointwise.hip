@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void lift_kernel(const float* __restrict__ x, 
     for (int i = threadIdx.x; i < (m1 - m0) * 3; i += blockDim.x) xs[i] = cin * x[((size_t)b * N + m0) * 3 + i];
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const float w0 = W[c * 3 + 0], w1 = W[c * 3 + 1], w2 = W[c * 3 + 2], bb = bias[c];
+        const float w0 = W[c * 3 + 0], w1 = W[c * 3 + 1], w2 = W[c * 3 + 2], bb = bias ? bias[c] : 0.f;
         float s1 = 0.f, s2 = 0.f;
         for (int m = 0; m < m1 - m0; ++m) {
             // same association as F.linear's dot product order: ((x0*w0 + x1*w1) + x2*w2) + b

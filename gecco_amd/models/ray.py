@@ -6,7 +6,7 @@ import torch
 from torch import Tensor, nn
 
 from .. import hip_ops
-from .._grad import require_no_grad
+from .._grad import needs_grad
 from ..reparam import Reparam
 from ..structs import Context3d
 from .feature_pyramid import FeaturePyramidContext
@@ -57,7 +57,9 @@ class RayNetwork(nn.Module):
 
     def forward(self, geometry: Tensor, t: Tensor, raw_ctx: Context3d, post_context: FeaturePyramidContext,
                 do_cache: bool = False, cache: list[Tensor] | None = None):
-        require_no_grad(self, geometry, t)
+        if needs_grad(self, geometry, t, *post_context.features):
+            from .. import autograd as ag
+            return ag.ray_network(self, geometry, t.float(), raw_ctx.K, post_context.features, do_cache, cache)
         g = geometry.float().contiguous()
         xyz = hip_ops.lift(g, None, self.xyz_embed.weight, self.xyz_embed.bias)
         raw, st_raw = hip_ops.ray_lookup(g, raw_ctx.K.float().contiguous(), _levels(post_context),
@@ -73,7 +75,9 @@ class RayNetwork(nn.Module):
 
     def fused_edm(self, x: Tensor, sigma: Tensor, raw_ctx: Context3d, post_context: FeaturePyramidContext,
                   do_cache: bool, cache, sigma_data: float, out: Tensor | None = None):
-        require_no_grad(self, x, sigma)
+        if needs_grad(self, x, sigma, *post_context.features):
+            from .. import autograd as ag
+            return ag.ray_network_edm(self, x.float(), sigma, sigma_data, raw_ctx.K, post_context.features, do_cache, cache)
 
         def build():
             st = self.backbone.plan()

@@ -218,6 +218,12 @@ int gecco_bilinear_taps_f32(const float* uv, int H, int W, int* x0, int* y0, flo
 int gecco_ray_lookup_f32(const float* geom, const float* coef, const float* K, const GeccoReparam* rp,
                          const GeccoPyramid* pyr, float* out, float* stats, int B, int N, void* stream);
 int gecco_lookup_row_tiles(int N);
+/* Its backward w.r.t. the pyramids (autograd of F.grid_sample's input under loss.backward(), models/ray.py:82-85):
+ * dfeat[l] (B, H_l, W_l, C_l) channels-last, ZEROED by the caller, += tap weight * dout (B, N, sum C).  pyr gives the
+ * level shapes (its feat pointers are not read).  Float atomics, like torch's grid_sampler backward. */
+int gecco_ray_lookup_bwd_f32(const float* geom, const float* coef, const float* K, const GeccoReparam* rp,
+                             const GeccoPyramid* pyr, const float* dout, float* const* dfeat, int B, int N,
+                             void* stream);
 
 typedef struct GeccoRayNetwork {  /* EDMPrecond(RayNetwork(SetTransformer, reparam)), models/ray.py:33-120 */
     GeccoSetTransformer backbone;

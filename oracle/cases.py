@@ -129,6 +129,23 @@ def upsample_draw_list():
     return out
 
 
+COND_LOSS_CASE = dict(name="cond_d128_L2_N96", seed=61, sigma_max=165.0)
+
+
+def cond_loss_inputs():
+    """Conditional training step: the conditional case's network and pyramid, examples given in DIFFUSION space
+    (the reference's loss converts data -> diffusion; the generator feeds it diffusion_to_data of these)."""
+    c = COND_LOSS_CASE
+    d, L, N, hw, cdims, seed = COND_CASES[c["name"]]
+    B = len(SIGMAS3)
+    p = W.ray_network_state_dict(seed, d, L, I, H, context_dims=cdims)
+    feats, K = W.synthetic_context(seed + 5, B, hw=hw, context_dims=cdims)
+    ex_diff = _randn(c["seed"] + 1, B, N, 3) * 0.7
+    u = torch.from_numpy(np.random.RandomState(c["seed"] + 2).uniform(size=B).astype(np.float32))
+    noise = _randn(c["seed"] + 3, B, N, 3)
+    return p, ex_diff, u, noise, K, feats
+
+
 def loss_inputs():
     c = LOSS_CASE
     p = W.linear_lift_state_dict(c["seed"], c["d"], c["L"], I, H)

@@ -11,7 +11,7 @@ import torch.nn.functional as F
 
 from oracle import cases, cpu_ref
 from oracle import weights as W
-from tests.test_modules_cpu import build_uncond, uncond_state_dict
+from tests.test_modules_cpu import build_cond, build_uncond, uncond_state_dict
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-4
@@ -189,6 +189,63 @@ def test_edm_loss_and_gradients_golden(golden_dir):
     D = m(exd + noise.cuda() * sigma, sigma, None)
     (100.0 * weight * (D - exd) ** 2).mean().backward()
     assert all(torch.equal(first[k], q.grad) for k, q in m.named_parameters())
+
+
+def test_lookup_fn_grads():
+    """Projective lookup backward (gradients into the pyramid levels) against torch autograd through the oracle."""
+    from gecco_amd.autograd import LookupFn
+    feats, K, geom, um, us = cases.lookup_inputs("lookup_small")
+    fr = [_leaf(f) for f in feats]
+    ref = cpu_ref.extract_image_features(geom, fr, K, um, us)
+    g = _t(np.random.RandomState(5).randn(*ref.shape))
+    ref.backward(g)
+    fg = [_leaf(f, "cuda") for f in feats]
+    out = LookupFn.apply(geom.cuda(), K.cuda(), (2, um.cuda(), us.cuda(), 1.1), *fg)
+    out.backward(g.cuda())
+    _close(out, ref.detach(), 1e-4)
+    for a, b in zip(fg, fr):
+        assert a.grad.shape == b.grad.shape
+        _close(a.grad, b.grad, 1e-4)
+
+
+def test_conditional_edm_loss_and_gradients_golden(golden_dir):
+    """The reference's EDMLoss through EDMPrecond(RayNetwork): loss value, parameter gradients and the gradients that
+    reach the conditioner's feature pyramid (tests/golden/cond_loss.npz, injected sigma draw and noise)."""
+    from gecco_amd.diffusion import Conditioner
+    from gecco_amd.models.feature_pyramid import FeaturePyramidContext
+    from gecco_amd.structs import Context3d
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(golden_dir, "cond_loss.npz")).items()}
+    c = cases.COND_LOSS_CASE
+    d, L, N, hw, cdims, seed = cases.COND_CASES[c["name"]]
+    p, ex_diff, u, noise, K, feats = cases.cond_loss_inputs()
+    fl = [_leaf(f, "cuda") for f in feats]
+
+    class FixedPyramid(Conditioner):
+        def forward(self, raw_ctx):
+            return FeaturePyramidContext(features=fl, K=raw_ctx.K)
+
+    m = build_cond(d, L, cdims, conditioner=FixedPyramid())
+    sd = {"backbone.model." + k: v for k, v in p.items()}
+    sd["reparam.uvl_mean"], sd["reparam.uvl_std"] = p["reparam.uvl_mean"], p["reparam.uvl_std"]
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    ctx = Context3d(image=torch.zeros(len(u), 3, hw, hw).cuda(), K=K.cuda())
+    sigma = cpu_ref.log_uniform_sigma(u, c["sigma_max"]).cuda()
+    with torch.no_grad():   # the loss works on the diffusion-space examples (reference diffusion.py:137)
+        exd = m.reparam.data_to_diffusion(g["ex_data"].cuda(), ctx)
+    _close(exd, ex_diff, 1e-4)
+    weight = (sigma ** 2 + 1.0) / (sigma ** 2)
+    D = m(exd + noise.cuda() * sigma, sigma, ctx)
+    loss = (100.0 * weight * (D - exd) ** 2).mean()
+    loss.backward()
+    _close(loss, g["loss"], 1e-4)
+    grads = dict(m.named_parameters())
+    for k, v in g.items():
+        if k.startswith("grad.features."):
+            _close(fl[int(k.rsplit(".", 1)[1])].grad, v, 1e-3)
+        elif k.startswith("grad."):
+            _close(grads["backbone.model." + k[5:]].grad, v, 1e-3)
+    assert all(q.grad is not None for q in m.parameters() if q.requires_grad)
 
 
 def test_training_step_decreases_loss():

@@ -94,7 +94,6 @@ def test_schedule_table_matches_oracle():
 
 def test_modules_refuse_cpu_and_autograd():
     from gecco_amd import _lib
-    from gecco_amd._grad import GeccoTrainingNotSupported
     m = build_uncond(64, 1)
     x, s = torch.randn(2, 64, 3), torch.tensor([1.0, 2.0])
     with torch.no_grad(), pytest.raises(_lib.GeccoHipError):
@@ -106,8 +105,8 @@ def test_modules_refuse_cpu_and_autograd():
     from gecco_amd.structs import Context3d
     ctx = Context3d(image=torch.zeros(2, 3, 8, 8), K=torch.eye(3).repeat(2, 1, 1))
     pyr = FeaturePyramidContext(features=[torch.zeros(2, c, 4, 4) for c in (8, 16, 24)], K=ctx.K)
-    with pytest.raises(GeccoTrainingNotSupported):
-        mc(x, s, ctx, pyr)  # RayNetwork has no backward yet: refuses rather than returning grad-less tensors
+    with pytest.raises(_lib.GeccoHipError):
+        mc(x, s, ctx, pyr)  # grad enabled: RayNetwork's HIP training path (lookup backward included) — no CPU fallback
     with pytest.raises(ValueError):
         m.upsample(x, new_latents=None, n_new=None)
 

@@ -227,6 +227,47 @@ def main():
         check("grad " + k, pg[k].grad, grads["backbone.model." + k], tol=2e-4)
         out["grad." + k] = grads["backbone.model." + k]
     save("loss", **out)
+
+    # ---- (10) conditional training step: EDMLoss through RayNetwork, gradients into parameters AND the pyramid
+    print("cond_loss")
+    c = cases.COND_LOSS_CASE
+    d, L, N, hw, cdims, seed = cases.COND_CASES[c["name"]]
+    p, ex_diff, u, noise, K, feats = cases.cond_loss_inputs()
+    feats_ref = [f.clone().requires_grad_(True) for f in feats]
+    model = ref_import.build_cond(ns, d, L, I, H, feats_ref, context_dims=cdims, sigma_max=c["sigma_max"])
+    sd = {"backbone.model." + k: v for k, v in p.items()}
+    sd["reparam.uvl_mean"], sd["reparam.uvl_std"] = p["reparam.uvl_mean"], p["reparam.uvl_std"]
+    model.load_state_dict(sd, strict=True)
+    ctx = ns.Context3d(image=torch.zeros(len(u), 3, hw, hw), K=K)
+    with torch.no_grad():
+        ex_data = model.reparam.diffusion_to_data(ex_diff, ctx)
+    D.torch = ref_import.TorchRandnProxy([])
+    D.torch.rand = lambda *a, **k: u.clone()
+    D.torch.randn_like = lambda t: noise.clone()
+    try:
+        loss_ref = model.loss(model, ex_data, ctx)
+    finally:
+        D.torch = torch
+    loss_ref.backward()
+    grads = {k: v.grad.clone() for k, v in model.named_parameters() if v.grad is not None}
+    pg = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "reparam" not in k else v) for k, v in p.items()}
+    fg = [f.clone().requires_grad_(True) for f in feats]
+    sigma = cpu_ref.log_uniform_sigma(u, c["sigma_max"])
+    with torch.no_grad():
+        ex_back = cpu_ref.uvl_data_to_diffusion(ex_data, K, p["reparam.uvl_mean"], p["reparam.uvl_std"])
+    loss = cpu_ref.edm_loss(cpu_ref.cond_denoiser(pg, "", H, K, fg), ex_back, sigma, noise)
+    loss.backward()
+    check("cond loss", loss.detach(), loss_ref.detach(), tol=5e-5)
+    sel = ["xyz_embed.weight", "img_feature_proj.1.weight", "img_feature_proj.1.bias", "output_proj.1.weight",
+           "output_proj.1.bias", "backbone.layers.0.mlp.2.bias", "backbone.layers.1.broadcast.pool.inducers"]
+    out = {"loss": loss_ref.detach(), "ex_data": ex_data}
+    for k in sel:
+        check("grad " + k, pg[k].grad, grads["backbone.model." + k], tol=5e-4)
+        out["grad." + k] = grads["backbone.model." + k]
+    for l, (a, b) in enumerate(zip(fg, feats_ref)):
+        check(f"grad features[{l}]", a.grad, b.grad, tol=5e-4)
+        out[f"grad.features.{l}"] = b.grad
+    save("cond_loss", **out)
     print("all golden vectors written")
 
 

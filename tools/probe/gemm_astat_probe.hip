@@ -37,10 +37,10 @@ int main() {
         (void)hipDeviceSynchronize();
         static unsigned long long hs[4096 * 8];
         (void)hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_astat_stamps), sizeof(hs));
-        const int nb = 2048;
-        double d[3] = {0, 0, 0};
-        for (int i = 0; i < nb; ++i) for (int k = 0; k < 3; ++k) d[k] += (double)(hs[i * 8 + k + 1] - hs[i * 8 + k]);
-        printf("   stamps (ticks, mean per block over %d blocks): panel build %.0f  sync+first stages %.0f  all rounds %.0f\n", nb, d[0] / nb, d[1] / nb, d[2] / nb);
+        const int nb = B * N / 128;
+        double d[2] = {0, 0};
+        for (int i = 0; i < nb; ++i) for (int k = 0; k < 2; ++k) d[k] += (double)(hs[i * 8 + k + 1] - hs[i * 8 + k]);
+        printf("   stamps (cycles, mean per block over %d blocks): A build %.0f  all column tiles %.0f\n", nb, d[0] / nb, d[1] / nb);
 #endif
     }
     return 0;

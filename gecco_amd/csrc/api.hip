@@ -181,13 +181,11 @@ int astat_linear(const float* x, const float* pa, const float* po, const float* 
     g.B = B; g.rows = rows; g.K = K; g.Nout = Nout1 + Nout2; g.lda = K; g.ldw = K; g.ldc = Nout1; g.ldr = Nout1;
     g.precision = 2; g.w_img = img; g.c_f16 = 1;
     if (C2) { g.C2 = C2; g.bias2 = bias2; g.n_split = Nout1; g.ldc2 = Nout2; }
-    // Opt-in (GECCO_ASTAT=1): as measured this round the one-pass kernel only ties the cast pass + streaming GEMM
-    // (its per-K-step barrier round costs ~300 cycles against 128 cycles of MFMA per wave, and every block's panel
-    // build hits HBM in lockstep); kept as the base for a deeper-K-step / overlapped-build version.
+    // GECCO_ASTAT=0 falls back to the cast pass + streaming GEMM (A/B runs; same bits)
     static int enabled = -1;
     if (enabled < 0) {
         const char* e = getenv("GECCO_ASTAT");
-        enabled = e ? atoi(e) : 0;
+        enabled = e ? atoi(e) : 1;
     }
     if (!enabled || !img || !gemm_f16_astat_supported(g)) return 1;
     return gemm_f16_astat_launch(g, s);
@@ -424,6 +422,28 @@ int gecco_linear_pair_f16io(const void* A, const float* W1, const float* bias1, 
                          static_cast<float*>(wsplit), nullptr, 1, 1);
     if (rc == 1 || rc == -9) return fail(-2, "linear_pair_f16io: needs rows >= 128, K %% 32 == 0, Nout1 %% 128 == 0");
     TRY(rc, "linear_pair_f16io");
+    return 0;
+}
+
+int gecco_linear_astat_f16(const float* x, const float* pro_a, const float* pro_o, const float* W1, const float* bias1,
+                           int Nout1, void* C1, const float* W2, const float* bias2, int Nout2, void* C2,
+                           const float* alpha, int act, int B, int rows, int K, void* wsplit, void* stream) {
+    if (!x || !W1 || !C1 || !wsplit) return fail(-1, "linear_astat: null argument");
+    if ((pro_a == nullptr) != (pro_o == nullptr)) return fail(-1, "linear_astat: pro_a/pro_o must both be set");
+    if ((W2 == nullptr) != (C2 == nullptr)) return fail(-1, "linear_astat: W2 and C2 go together");
+    hipStream_t s = (hipStream_t)stream;
+    float* img = static_cast<float*>(wsplit);
+    TRY(split_f16_tiled_launch(W1, img, Nout1, K, K, s), "linear_astat(split)");
+    if (W2) TRY(split_f16_tiled_launch(W2, img + split_f16_image_bytes(Nout1, K) / sizeof(float), Nout2, K, K, s), "linear_astat(split)");
+    GemmArgs g{};
+    g.A = x; g.pro_a = pro_a; g.pro_o = pro_o; g.bias = bias1; g.alpha = alpha; g.act = act; g.C = static_cast<float*>(C1);
+    g.B = B; g.rows = rows; g.K = K; g.Nout = Nout1 + (W2 ? Nout2 : 0); g.lda = K; g.ldw = K; g.ldc = Nout1; g.ldr = Nout1;
+    g.precision = 2; g.w_img = img; g.c_f16 = 1;
+    if (W2) { g.C2 = static_cast<float*>(C2); g.bias2 = bias2; g.n_split = Nout1; g.ldc2 = Nout2; }
+    if (act && !alpha) return fail(-6, "linear_astat: activation needs alpha");
+    if (!gemm_f16_astat_supported(g))
+        return fail(-2, "linear_astat: needs rows %% 128 == 0, Nout %% 128 == 0, K in {128, 256, 384, 512}");
+    TRY(gemm_f16_astat_launch(g, s), "linear_astat");
     return 0;
 }
 

@@ -26,6 +26,8 @@
 
 #include <stdlib.h>
 
+#include <utility>
+
 namespace {
 
 using dma::dma16;
@@ -36,35 +38,18 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SBK = 32;            // k per stage
 constexpr int S_TILE = 2048;       // floats of one [128][32] fp16 W tile (8 KiB)
-constexpr int S_NS = 6;            // ring slots
 constexpr int S_NT = 256;          // threads
 constexpr int S_PW = 2;            // 1 KiB pieces of a W stage per wave
 constexpr int S_STORES = 32;       // store instructions a wave's epilogue issues (32 x 128 wave tile)
 
-// s_waitcnt vmcnt(PW * n + STORES * e) lgkmcnt(0): n in [0, S_NS - 2] stages and e in [0, 1] epilogues may stay queued
-__device__ __forceinline__ void wait_stages(int n, bool stores) {
-    if (stores) {
-        switch (n) {
-            case 0: dma::wait_vm_lgkm0<S_STORES + 0 * S_PW>(); break;
-            case 1: dma::wait_vm_lgkm0<S_STORES + 1 * S_PW>(); break;
-            case 2: dma::wait_vm_lgkm0<S_STORES + 2 * S_PW>(); break;
-            case 3: dma::wait_vm_lgkm0<S_STORES + 3 * S_PW>(); break;
-            default: dma::wait_vm_lgkm0<S_STORES + 4 * S_PW>(); break;
-        }
-    } else {
-        switch (n) {
-            case 0: dma::wait_vm_lgkm0<0 * S_PW>(); break;
-            case 1: dma::wait_vm_lgkm0<1 * S_PW>(); break;
-            case 2: dma::wait_vm_lgkm0<2 * S_PW>(); break;
-            case 3: dma::wait_vm_lgkm0<3 * S_PW>(); break;
-            default: dma::wait_vm_lgkm0<4 * S_PW>(); break;
-        }
-    }
+// value of the neighbouring lane (lane ^ 1): one DPP move (quad_perm [1, 0, 3, 2])
+__device__ __forceinline__ unsigned swap_pair(unsigned v) {
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
 }
 
-// value of the neighbouring lane (lane ^ 1): one DPP move (quad_perm [1, 0, 3, 2])
-__device__ __forceinline__ float swap_pair(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+// W stage pieces by buffer_load ... lds: the per-lane offset is a register computed once, the stage offset a scalar
+__device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, float* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
 }
 
 #ifdef ASTAT_STAMPS   // diagnostic build (tools/probe): per-block s_memtime stamps
@@ -77,14 +62,20 @@ __device__ unsigned long long g_astat_stamps[4096 * 8];
 #define ASTAMP(i)
 #endif
 
-// NK = K / 32 K-steps, compile-time: the A fragments are indexed statically (they are registers)
-template <int NK>
+template <int... I, class F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+
+// NK = K / 32 K-steps (compile-time: the A fragments are registers, indexed statically); NS ring slots with
+// NK % NS == 0, so the ring slot of K-step kt of ANY column tile is kt % NS — every LDS address in the loop is static.
+template <int NK, int NS>
 __global__ __launch_bounds__(S_NT, 2) void gemm_f16_astat_kernel(GemmArgs g) {
-    static_assert(NK % 2 == 0 && NK >= S_NS - 1, "even K-step count, and at most one epilogue per ring depth");
+    static_assert(NK % 2 == 0 && NK % NS == 0 && NS >= 4, "static slots; the A build stages 4 K-steps in the ring");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     ASTAMP(0);
-    float* ring = smem;                                // [S_NS][S_TILE]
-    float* bias_lds = ring + S_NS * S_TILE;            // [Nout] (zeros where a segment has no bias)
+    float* ring = smem;                                // [NS][S_TILE]; first the staging area of the A build
+    float* bias_lds = ring + NS * S_TILE;              // [Nout] (zeros where a segment has no bias)
     float* pro_lds = bias_lds + g.Nout;                // pa[0..K) | po[0..K)
     constexpr int K = NK * SBK;
 
@@ -93,18 +84,6 @@ __global__ __launch_bounds__(S_NT, 2) void gemm_f16_astat_kernel(GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // rows 32 wave .. 32 wave + 31
     const int r = lane & 31, h = lane >> 5;
-
-    // ---- W image pieces: wave w moves pieces 2w, 2w+1 (1 KiB each) of every 8 KiB stage
-    const float* img = static_cast<const float*>(g.w_img) + (S_PW * wave) * 256 + lane * 4;
-    const int nsteps = tilesN * NK;                    // flattened step s = column tile * NK + kt
-    auto issue = [&](int s) {
-#pragma unroll
-        for (int q = 0; q < S_PW; ++q)
-            dma16(img + (size_t)s * S_TILE + q * 256, ring + (s % S_NS) * S_TILE + (S_PW * wave + q) * 256);
-    };
-#pragma unroll
-    for (int p = 0; p < S_NS; ++p)
-        if (p < nsteps) issue(p);
 
     for (int n = tid; n < g.Nout; n += S_NT) {
         const bool seg2 = g.C2 != nullptr && n >= g.n_split;
@@ -120,48 +99,82 @@ __global__ __launch_bounds__(S_NT, 2) void gemm_f16_astat_kernel(GemmArgs g) {
             pro_lds[K + i] = po[i];
         }
     }
-    __syncthreads();   // bias and AdaGN coefficients are in LDS (also drains vmcnt: the first S_NS stages have landed)
 
-    // ---- the A operand of this wave: fp16(x * pa + po) for its 32 rows, as the fragments of all NK K-steps.
-    // lane (r, h) holds row r, k = 32 kt + 16 h + 8 c .. + 7 in fragment [kt][c]: 64 consecutive bytes of x per K-step
+    // ---- the A operand: fp16(x * pa + po).  Built 4 K-steps (128 k) at a time: coalesced 32-byte reads of the 128
+    // rows (16 threads per row), affine + rounding, into the ring area laid out as four [128][32] fp16 stages (the
+    // A16 layout of gemm_f16_dma.hip), from where every wave takes the fragments of ITS 32 rows into registers:
+    // lane (r, h) holds row r, k = 32 kt + 16 h + 8 c .. + 7 in fa[kt][c].
     f16x8 fa[NK][2];
     {
-        const float* xr = g.A + ((size_t)b * g.rows + m0 + wave * 32 + r) * g.lda + 16 * h;
-        constexpr int KB = 4;   // K-steps per batch: 16 independent 16-byte loads in flight per lane
+        const float* xb = g.A + ((size_t)b * g.rows + m0) * g.lda;
+        const int ra = wave * 32 + r;
+        int aoff[2];
 #pragma unroll
-        for (int k0 = 0; k0 < NK; k0 += KB) {
-            f32x4 x[KB][4];
+        for (int c = 0; c < 2; ++c) aoff[c] = ra * 16 + (((2 * h + c) ^ ((ra >> 2) & 3)) << 2);
 #pragma unroll
-            for (int u = 0; u < KB; ++u)
+        for (int k0 = 0; k0 < NK; k0 += 4) {
+            constexpr int ITEMS = 128 * 16 / S_NT;   // (row, 8-k chunk) items per thread per 128-k slab
+            f32x4 x0[ITEMS], x1[ITEMS];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (k0 + u < NK) x[u][q] = GECCO_NT_LOAD(reinterpret_cast<const f32x4*>(xr + (k0 + u) * SBK + 4 * q));
+            for (int u = 0; u < ITEMS; ++u) {
+                const int i = tid + u * S_NT, row = i >> 4, c8 = i & 15;
+                const bool in = k0 * SBK + c8 * 8 < K;
+                const float* src = xb + (size_t)row * g.lda + k0 * SBK + (in ? c8 * 8 : 0);
+                x0[u] = GECCO_NT_LOAD(reinterpret_cast<const f32x4*>(src));
+                x1[u] = GECCO_NT_LOAD(reinterpret_cast<const f32x4*>(src + 4));
+            }
+            __syncthreads();   // coefficients in LDS (first slab) / every wave done reading the previous slab
 #pragma unroll
-            for (int u = 0; u < KB; ++u) {
-                if (k0 + u >= NK) break;
+            for (int u = 0; u < ITEMS; ++u) {
+                const int i = tid + u * S_NT, row = i >> 4, c8 = i & 15;
+                if (k0 * SBK + c8 * 8 >= K) continue;
                 if (has_pro) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 a4 = *reinterpret_cast<const f32x4*>(pro_lds + (k0 + u) * SBK + 16 * h + 4 * q);
-                        const f32x4 o4 = *reinterpret_cast<const f32x4*>(pro_lds + K + (k0 + u) * SBK + 16 * h + 4 * q);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) x[u][q][e] = __builtin_fmaf(x[u][q][e], a4[e], o4[e]);
-                    }
-                }
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
+                    const float* ap = pro_lds + k0 * SBK + c8 * 8;
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap), a1 = *reinterpret_cast<const f32x4*>(ap + 4);
+                    const f32x4 o0 = *reinterpret_cast<const f32x4*>(ap + K), o1 = *reinterpret_cast<const f32x4*>(ap + K + 4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        fa[k0 + u][c][e] = (_Float16)x[u][2 * c][e];
-                        fa[k0 + u][c][4 + e] = (_Float16)x[u][2 * c + 1][e];
+                        x0[u][e] = __builtin_fmaf(x0[u][e], a0[e], o0[e]);
+                        x1[u][e] = __builtin_fmaf(x1[u][e], a1[e], o1[e]);
                     }
+                }
+                f16x8 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = (_Float16)x0[u][e];
+                    v[4 + e] = (_Float16)x1[u][e];
+                }
+                const int sub = c8 >> 2, ch = (c8 & 3) ^ ((row >> 2) & 3);
+                *reinterpret_cast<u32x4*>(ring + sub * S_TILE + row * 16 + ch * 4) = __builtin_bit_cast(u32x4, v);
             }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (k0 + u < NK) {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+                        fa[k0 + u][c] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(ring + u * S_TILE + aoff[c]));
+                }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();   // the staging area becomes the W ring
     }
     ASTAMP(1);
+
+    // ---- W image: buffer_load ... lds, wave w moves pieces 2w, 2w+1 (1 KiB each) of every 8 KiB stage
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.w_img), 0, 0x7fffffff, 0x00020000);
+    const unsigned voff = (unsigned)((S_PW * wave) * 256 + lane * 4) * 4u;
+    unsigned soff = 0;                                 // byte offset of the next stage to issue in the image
+    auto issue = [&](int slot) {
+        dma16_buf(wrsrc, voff, soff, ring + slot * S_TILE + (S_PW * wave) * 256);
+        dma16_buf(wrsrc, voff + 1024u, soff, ring + slot * S_TILE + (S_PW * wave + 1) * 256);
+        soff += S_TILE * 4u;
+    };
+#pragma unroll
+    for (int p = 0; p < NS; ++p) issue(p);             // tilesN * NK >= NK >= NS stages exist
+
     const bool has_act = g.act != 0, act_norm = g.act == 1;
     const float neg_inv_2a2 = has_act ? -1.0f / (2.0f * g.alpha[0] * g.alpha[0]) : 0.f;
-
     f32x16 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -186,51 +199,64 @@ __global__ __launch_bounds__(S_NT, 2) void gemm_f16_astat_kernel(GemmArgs g) {
                 fb[f][j][c] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(st + boff[j][c]));
     };
 
-    // ---- epilogue of one column tile, from registers: bias, activation, fp16, packed-pair stores
+    // ---- epilogue of one column tile, from registers: bias, activation, a packed fp16 pair per lane.
+    // Lane (column n, rows in registers) converts registers e0, e0+1 (rows R, R+1 of its column) to one dword, swaps it
+    // with its neighbour (DPP) and permutes: the even lane ends up with row R of columns n, n+1, the odd lane with row
+    // R+1 of columns n-1, n — four bytes of one output row each.
+    const bool odd = lane & 1;
+    const unsigned psel = odd ? 0x03020706u : 0x05040100u;   // v_perm_b32 over {neighbour, own}
     auto epilogue = [&](int ct) {
         const int n0 = ct * 128;
         const bool seg2 = g.C2 != nullptr && n0 >= g.n_split;
         _Float16* Cb = reinterpret_cast<_Float16*>(seg2 ? g.C2 : g.C);
         const int ldc = seg2 ? g.ldc2 : g.ldc;
         const int nseg0 = seg2 ? n0 - g.n_split : n0;
-        _Float16* base = Cb + ((size_t)b * g.rows + m0 + wave * 32) * ldc + nseg0;
-        const bool odd = lane & 1;
+        _Float16* lanebase = Cb + ((size_t)b * g.rows + m0 + wave * 32 + 4 * h + (odd ? 1 : 0)) * ldc + nseg0 + (r & ~1);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float bias = bias_lds[n0 + j * 32 + r];
-            f32x16 v = acc[j];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                v[e] += bias;
-                if (has_act) v[e] = gauss_act(v[e], neg_inv_2a2, act_norm);
-                acc[j][e] = 0.f;
-            }
 #pragma unroll
             for (int e0 = 0; e0 < 16; e0 += 2) {
-                // even lane keeps register e0 (its column and the right neighbour's), odd lane register e0 + 1
-                const float recv = swap_pair(odd ? v[e0] : v[e0 + 1]);
+                float v0 = acc[j][e0] + bias, v1 = acc[j][e0 + 1] + bias;
+                acc[j][e0] = 0.f;
+                acc[j][e0 + 1] = 0.f;
+                if (has_act) {
+                    v0 = gauss_act(v0, neg_inv_2a2, act_norm);
+                    v1 = gauss_act(v1, neg_inv_2a2, act_norm);
+                }
                 f16x2 pk;
-                pk[0] = (_Float16)(odd ? recv : v[e0]);
-                pk[1] = (_Float16)(odd ? v[e0 + 1] : recv);
-                const int row = mfma_row(odd ? e0 + 1 : e0, h);
-                *reinterpret_cast<f16x2*>(base + (size_t)row * ldc + j * 32 + (r & ~1)) = pk;
+                pk[0] = (_Float16)v0;
+                pk[1] = (_Float16)v1;
+                const unsigned own = __builtin_bit_cast(unsigned, pk);
+                const unsigned out = __builtin_amdgcn_perm(swap_pair(own), own, psel);
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int rowoff = (e0 & 3) + 8 * (e0 >> 2);   // + 4h + odd in lanebase
+                *reinterpret_cast<unsigned*>(lanebase + (size_t)rowoff * ldc + j * 32) = out;
             }
         }
     };
 
-    // the plain loads of the build have returned (their values were consumed above); from here on the wave's vmcnt
-    // queue holds only DMA pieces and epilogue stores
+    // first stages landed
+    dma::wait_vm_lgkm0<(NS - 1) * S_PW>();
+    __builtin_amdgcn_s_barrier();
     load_b(0, 0);
-    int s = 0, slot_next = 1 % S_NS;   // flattened step; ring slot of stage s + 1
-    int since_epi = 1000;              // K-steps since this wave's last epilogue stores
     for (int ct = 0; ct < tilesN; ++ct) {
-#pragma unroll
-        for (int kt = 0; kt < NK; ++kt) {
-            const int cur = kt & 1;
-            // own pieces of stage s + 1 landed; younger stages may stay in flight, and so may the stores of an epilogue
-            // issued after the awaited piece (which was issued at the top of K-step s + 1 - S_NS)
-            const int rem = nsteps - 1 - s;
-            wait_stages(rem >= S_NS - 1 ? S_NS - 2 : (rem >= 1 ? rem - 1 : 0), since_epi <= S_NS - 1);
+        const bool first = ct == 0, last = ct == tilesN - 1;
+        static_for(std::make_integer_sequence<int, NK>{}, [&](auto KT) {
+            constexpr int kt = decltype(KT)::value;
+            constexpr int cur = kt & 1;
+            constexpr int rem_last = NK - 1 - kt;                                   // steps left after this one, last tile
+            constexpr int n_last = rem_last >= NS - 1 ? NS - 2 : (rem_last >= 1 ? rem_last - 1 : 0);
+            constexpr bool early = kt <= NS - 2;   // the previous tile's epilogue stores still queue behind the awaited piece
+            // own pieces of the next K-step's stage landed; younger stages (and those stores) may stay in flight
+            if (!last) {
+                if (early && !first) dma::wait_vm_lgkm0<(NS - 2) * S_PW + S_STORES>();
+                else dma::wait_vm_lgkm0<(NS - 2) * S_PW>();
+            } else {
+                if (early && !first) dma::wait_vm_lgkm0<n_last * S_PW + S_STORES>();
+                else dma::wait_vm_lgkm0<n_last * S_PW>();
+            }
             // this step's W fragments were read during the previous one and the wait above covered them: an empty asm
             // "redefines" the registers so the compiler's wait-count pass does not park its own lgkmcnt(0) in front of
             // the first MFMA, behind the NEXT step's reads issued below
@@ -239,35 +265,29 @@ __global__ __launch_bounds__(S_NT, 2) void gemm_f16_astat_kernel(GemmArgs g) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c) asm volatile("" : "+v"(fb[cur][j][c]));
             __builtin_amdgcn_s_barrier();
-            if (rem >= S_NS) issue(s + S_NS);
-            if (rem >= 1) load_b(slot_next, cur ^ 1);
+            if (!last || kt + NS < NK) issue(kt % NS);                 // the stage NS steps ahead reuses this step's slot
+            if (!last || kt + 1 < NK) load_b((kt + 1) % NS, cur ^ 1);
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kt][c], fb[cur][j][c], acc[j], 0, 0, 0);
-            ++since_epi;
-            if (kt == NK - 1) {
-                epilogue(ct);
-                since_epi = 1;
-            }
-            ++s;
-            slot_next = slot_next + 1 == S_NS ? 0 : slot_next + 1;
-        }
+            if (kt == NK - 1) epilogue(ct);
+        });
     }
     ASTAMP(2);
 }
 
-template <int NK>
+template <int NK, int NS>
 int astat_launch_t(const GemmArgs& g, hipStream_t st) {
-    const size_t lds = ((size_t)S_NS * S_TILE + g.Nout + 2 * g.K) * sizeof(float);
+    const size_t lds = ((size_t)NS * S_TILE + g.Nout + 2 * g.K) * sizeof(float);
     static size_t attr = 0;
     if (lds > attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_astat_kernel<NK>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_astat_kernel<NK, NS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = lds;
     }
-    hipLaunchKernelGGL((gemm_f16_astat_kernel<NK>), dim3(g.B * (g.rows / 128)), dim3(S_NT), lds, st, g);
+    hipLaunchKernelGGL((gemm_f16_astat_kernel<NK, NS>), dim3(g.B * (g.rows / 128)), dim3(S_NT), lds, st, g);
     return (int)hipGetLastError();
 }
 
@@ -276,16 +296,17 @@ int astat_launch_t(const GemmArgs& g, hipStream_t st) {
 bool gemm_f16_astat_supported(const GemmArgs& g) {
     const int nk = g.K / SBK;
     return g.c_f16 && !g.a_f16 && !g.residual && !g.stats && g.w_img && g.rows >= 128 && !(g.rows % 128) &&
-           !(g.Nout % 128) && !(g.K % SBK) && (nk == 6 || nk == 8 || nk == 12) && !(g.lda & 3) && !(g.ldc & 1) &&
+           !(g.Nout % 128) && !(g.K % SBK) && (nk == 4 || nk == 8 || nk == 12 || nk == 16) && !(g.lda & 3) && !(g.ldc & 1) &&
            (!g.C2 || (!(g.n_split % 128) && !(g.ldc2 & 1) && g.n_split > 0 && g.n_split < g.Nout)) &&
            ((g.pro_a == nullptr) == (g.pro_o == nullptr));
 }
 
 int gemm_f16_astat_launch(const GemmArgs& g, hipStream_t st) {
     switch (g.K / SBK) {
-        case 6: return astat_launch_t<6>(g, st);     // d = 192
-        case 8: return astat_launch_t<8>(g, st);     // d = 256
-        case 12: return astat_launch_t<12>(g, st);   // d = 384 (the shipped configs)
+        case 4: return astat_launch_t<4, 4>(g, st);     // d = 128
+        case 8: return astat_launch_t<8, 4>(g, st);     // d = 256
+        case 12: return astat_launch_t<12, 6>(g, st);   // d = 384 (the shipped configs)
+        case 16: return astat_launch_t<16, 4>(g, st);   // d = 512
         default: return -9;
     }
 }

@@ -149,8 +149,12 @@ __global__ __launch_bounds__(256) void affine_cast_f16_kernel(const float* __res
         f16x8_t v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            v[e] = (_Float16)__builtin_fmaf(x0[e], a0[e], o0[e]);
-            v[4 + e] = (_Float16)__builtin_fmaf(x1[e], a1[e], o1[e]);
+            // two roundings, as everywhere else on the path (fp32 fma, then fp32 -> fp16): the empty asm keeps the
+            // compiler from fusing them into v_fma_mixlo_f16, which rounds once and differs on double-rounding ties
+            float f0 = __builtin_fmaf(x0[e], a0[e], o0[e]), f1 = __builtin_fmaf(x1[e], a1[e], o1[e]);
+            asm volatile("" : "+v"(f0), "+v"(f1));
+            v[e] = (_Float16)f0;
+            v[4 + e] = (_Float16)f1;
         }
         reinterpret_cast<f16x8_t*>(y)[i] = v;
     }

@@ -122,6 +122,14 @@ int gecco_linear_f16io(const void* A, const float* W, const float* bias, const f
 int gecco_linear_pair_f16io(const void* A, const float* W1, const float* bias1, int Nout1, void* C1, const float* W2,
                             const float* bias2, int Nout2, void* C2, int B, int rows, int K, void* wsplit,
                             void* stream);
+/* The one-pass form the network uses for kv_proj | q_proj and mlp.0 in the fp16 mode: AdaGN apply + fp16 rounding +
+ * all output columns in one pass over x (the block keeps fp16(x*pro_a + pro_o) of its 128 rows in registers and walks
+ * every 128-column tile of W1 | W2).  C1 (B, rows, Nout1) and C2 (B, rows, Nout2; W2/bias2/C2 may be NULL) are fp16;
+ * act as in gecco_linear_f32.  Bit-identical to gecco_affine_cast_f16 + gecco_linear(_pair)_f16io.
+ * rows % 128 == 0, Nout1 % 128 == 0, Nout2 % 128 == 0, K in {128, 256, 384, 512}; wsplit as for the pair. */
+int gecco_linear_astat_f16(const float* x, const float* pro_a, const float* pro_o, const float* W1, const float* bias1,
+                           int Nout1, void* C1, const float* W2, const float* bias2, int Nout2, void* C2,
+                           const float* alpha, int act, int B, int rows, int K, void* wsplit, void* stream);
 /* y16[b, m, c] = fp16(a[b, c] * x[b, m, c] + o[b, c]) — the AdaGN apply (models/normalization.py:44) rounded once,
  * exactly the operand the fp16 GEMM's prologue would form.  C % 8 == 0. */
 int gecco_affine_cast_f16(const float* x, const float* a, const float* o, void* y16, int B, int rows, int C,

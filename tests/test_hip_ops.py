@@ -168,6 +168,24 @@ def test_fp16_stored_intermediates(ops):
     assert torch.equal(h16, h32.half())
 
 
+@pytest.mark.parametrize("B,N,Cc", [(2, 256, 128), (2, 128, 384), (1, 384, 256), (1, 128, 512)])
+def test_linear_astat_matches_two_launch_form(ops, B, N, Cc):
+    """The one-pass A-stationary kernel gives the bits of the cast pass + streaming fp16 GEMM (pair, and single + act)."""
+    rs = _rs(N + Cc)
+    x = _t(rs.randn(B, N, Cc) * 2).cuda()
+    a, o = _t(1 + 0.3 * rs.randn(B, Cc)).cuda(), _t(0.3 * rs.randn(B, Cc)).cuda()
+    Wkv, Wq, bq = _t(rs.randn(2 * Cc, Cc) / 11).cuda(), _t(rs.randn(Cc, Cc) / 11).cuda(), _t(rs.randn(Cc) * .1).cuda()
+    y16 = ops.affine_cast_f16(x, a, o)
+    kv_ref, q_ref = ops.linear_pair_f16io(y16, Wkv, None, Wq, bq)
+    kv, q = ops.linear_astat_f16(x, (a, o), Wkv, None, Wq, bq)
+    assert torch.equal(kv, kv_ref) and torch.equal(q, q_ref)
+    alpha = _t(np.array(0.9)).cuda()
+    W0, b0 = _t(rs.randn(2 * Cc, Cc) / 11).cuda(), _t(rs.randn(2 * Cc) * .1).cuda()
+    h_ref = ops.linear_f16io(y16, W0, b0, act_alpha=alpha, out_f16=True)
+    h = ops.linear_astat_f16(x, (a, o), W0, b0, act_alpha=alpha)
+    assert torch.equal(h, h_ref)
+
+
 def test_adagn_large_mean(ops):
     """E[x^2]-mean^2 cancellation: mean 50x the std must still be accurate (fp64 combine)."""
     rs = _rs(5)

@@ -121,15 +121,14 @@ def gemm_call_sites(ops, dev, precision="fp32"):
     S = B * N * D * 4  # bytes of one (B, N, d) fp32 stream
     if precision == "fp16":
         # fp16 mode: AdaGN(x), K|V, q, the attention output and the MLP hidden layer are fp16 TENSORS
-        y16 = ops.affine_cast_f16(x, pa, po)
         att16, big16 = rn(B, N, D).half(), rn(B, N, 2 * D).half()
         kv16, q16 = torch.empty(B, N, 2 * D, device=dev, dtype=torch.float16), torch.empty(B, N, D, device=dev, dtype=torch.float16)
         h16 = torch.empty(B, N, 2 * D, device=dev, dtype=torch.float16)
         H2 = S // 2   # bytes of one (B, N, d) fp16 stream
         return [
-            ("kv_proj|q_proj", 2 * B * N * D * 3 * D, H2 + 3 * H2, lambda: ops.linear_pair_f16io(y16, Wkv, None, Wq, bq, out=(kv16, q16))),
+            ("norm+kv_proj|q_proj", 2 * B * N * D * 3 * D, S + 3 * H2, lambda: ops.linear_astat_f16(x, (pa, po), Wkv, None, Wq, bq, out=(kv16, q16))),
             ("out_proj+res+stats", 2 * B * N * D * D, H2 + 2 * S, lambda: ops.linear_f16io(att16, Wo, bq, residual=res, want_stats=True, out=o384)),
-            ("mlp.0+act", 2 * B * N * D * 2 * D, H2 + 2 * H2, lambda: ops.linear_f16io(y16, W1, b1, act_alpha=alpha, out=h16)),
+            ("norm+mlp.0+act", 2 * B * N * D * 2 * D, S + 2 * H2, lambda: ops.linear_astat_f16(x, (pa, po), W1, b1, act_alpha=alpha, out=(h16, None))),
             ("mlp.2+res+stats", 2 * B * N * 2 * D * D, 2 * H2 + 2 * S, lambda: ops.linear_f16io(big16, W2, b2, residual=res, want_stats=True, out=o384)),
         ]
     pr = dict(precision=precision)
@@ -193,6 +192,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-sampler", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="time eager Diffusion.forward calls instead of the hipGraph replay")
     ap.add_argument("--precision", default=os.environ.get("GECCO_PRECISION", "fp16"), choices=["fp32", "bf16x3", "fp16"],
                     help="arithmetic of the linears and attention products: fp16 operands with fp32 accumulation (default; "
                          "~3e-4 from the fp32 reference, bar 1e-3), split-bf16 (3 MFMAs per product, ~1.5e-5) or exact fp32 MFMA (~1e-6)")
@@ -222,8 +222,17 @@ def main():
     out = torch.empty_like(x)
 
     @torch.no_grad()
-    def step():
+    def eager_step():
         model(x, sigma, None, out=out)             # Diffusion.forward (reference diffusion.py:233-247)
+
+    if args.eager:
+        step = eager_step
+    else:
+        # the same evaluation captured once as a hipGraph and replayed: every kernel still runs every step, the ~100
+        # launches cost one host call (the eager loop is host-launch-bound on a busy box: it is timed beside it below)
+        run = model.graphed_forward(x, sigma, None)
+        out = run()
+        step = run
 
     for _ in range(args.warmup):
         step()
@@ -249,6 +258,7 @@ def main():
                                "EDMPrecond(LinearLift(SetTransformer)), fp32 MFMA, random-init weights",
                    "parallelism": "replicas (batch-sharded, no data-path collective)" if world > 1 else "single GPU"},
         "forward_tflops": flops_per_sample() * B / (ms * 1e-3) / 1e12,
+        "launch": "eager" if args.eager else "hipgraph replay of one captured Diffusion.forward",
         "target_points_per_sec_per_gpu": 2.0e6,
     }
     mode = args.precision
@@ -273,14 +283,15 @@ def main():
         if os.path.exists(tj):
             traffic = json.load(open(tj)).get(mode, {}).get("bytes_per_launch")
         if mode == "fp16":
-            # One MFMA per product and fp16-stored operands: the four launches run at 190..380 FLOP/B against a ridge of
-            # 2500 TF / 8 TB/s = 312, and the counters show them waiting on memory (the tile fill and the C / residual
-            # streams), not on the matrix pipe.  Bound: hbm.
+            # One MFMA per product and fp16-stored operands: the four launches run at 150..250 FLOP/B against a ridge of
+            # 2500 TF / 8 TB/s = 312, and the counters show them waiting on memory (the W tile fill and the x / C /
+            # residual streams), not on the matrix pipe.  Bound: hbm.
             rec["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                                "traffic": traffic,
-                               "kernel": "gemm_f16_kernel<3,false,128,true,*> (LDS-DMA ring, v_mfma_f32_32x32x16_f16), mean over its 4 "
-                                         "per-layer launch shapes; achieved = algorithmic bytes (fp16 A, fp32 residual read; fp16 or "
-                                         "fp32 C written) / event-timed duration",
+                               "kernel": "gemm_f16_astat_kernel<12,6> (AdaGN + kv|q, AdaGN + mlp.0: x read once, A in registers) and "
+                                         "gemm_f16_kernel<3,false,128,true,false> (out_proj, mlp.2: fp16 A, LDS-DMA ring), v_mfma_f32_32x32x16_f16; "
+                                         "mean over the 4 per-layer launches; achieved = algorithmic bytes (fp32 x or fp16 A and fp32 residual "
+                                         "read; fp16 or fp32 C written) / event-timed duration",
                                "mfma": {"achieved_tflops": tf, "peak_tflops": PEAK_BF16_MFMA_TFLOPS, "frac": tf / PEAK_BF16_MFMA_TFLOPS},
                                "per_site": per}
         elif mode == "bf16x3":
@@ -306,17 +317,26 @@ def main():
                 continue
             ops.set_default_precision(other)
             for _ in range(2):
-                step()
+                eager_step()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(10):
-                step()
+                eager_step()
             torch.cuda.synchronize()
             ms_o = (time.perf_counter() - t0) / 10 * 1e3
             rec[{"bf16x3": "split_bf16_mode", "fp32": "exact_fp32_mode"}[other]] = {
                 "ms_per_step": ms_o, "points_per_sec": B * N / (ms_o * 1e-3),
                 "parity_vs_fp32_reference": {"bf16x3": "~2e-5", "fp32": "~1e-6"}[other]}
         ops.set_default_precision(mode)
+        if not args.eager:   # the eager loop of the headline mode, for the record
+            for _ in range(2):
+                eager_step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                eager_step()
+            torch.cuda.synchronize()
+            rec["eager_ms_per_step"] = (time.perf_counter() - t0) / 10 * 1e3
     if rank == 0 and world == 1 and not args.no_sampler:
         # Metric 2 (BASELINE.json): 128-step sample_stochastic wall-clock = 255 evaluations + fp64 sampler kernels,
         # one hipGraph per step replayed 127 times

@@ -173,14 +173,18 @@ def linear_pair_f16io(A16: Tensor, W1: Tensor, b1: Tensor | None, W2: Tensor, b2
 
 
 def linear_astat_f16(x: Tensor, pro: tuple[Tensor, Tensor] | None, W1: Tensor, b1: Tensor | None, W2: Tensor | None = None,
-                     b2: Tensor | None = None, act_alpha: Tensor | None = None, normalized: bool = True):
+                     b2: Tensor | None = None, act_alpha: Tensor | None = None, normalized: bool = True,
+                     out: tuple[Tensor, Tensor | None] | None = None):
     """fp16(act(fp16(x*pa + po) @ W^T + b)) for W = W1 (| W2), fp16 outputs, one pass over x (fp16 mode)."""
     lib = _lib.load()
     B, rows, K = x.shape
     n1 = W1.shape[0]
     n2 = W2.shape[0] if W2 is not None else 0
-    c1 = torch.empty(B, rows, n1, device=x.device, dtype=torch.float16)
-    c2 = torch.empty(B, rows, n2, device=x.device, dtype=torch.float16) if n2 else None
+    if out is not None:
+        c1, c2 = out
+    else:
+        c1 = torch.empty(B, rows, n1, device=x.device, dtype=torch.float16)
+        c2 = torch.empty(B, rows, n2, device=x.device, dtype=torch.float16) if n2 else None
     wsplit = _ws(((n1 + 127) // 128 + (n2 + 127) // 128) * 128 * K * 4, x.device)
     act = 0 if act_alpha is None else (1 if normalized else 2)
     check(lib.gecco_linear_astat_f16(_ptr(x), _ptr(pro[0]) if pro else None, _ptr(pro[1]) if pro else None, _ptr(W1), _ptr(b1),

@@ -225,6 +225,23 @@ def test_lookup_golden(golden_dir, name):
     assert torch.equal(got, got2)
 
 
+def test_graphed_forward_replays_the_eager_bits():
+    """Diffusion.graphed_forward: one captured evaluation replayed on new inputs equals the eager call bit for bit."""
+    name = "uncond_d128_L4_N256"
+    d, L, N, seed = cases.UNCOND_CASES[name]
+    p, x, sigma = cases.uncond_inputs(name)
+    m = build_uncond(d, L)
+    m.load_state_dict(uncond_state_dict(p))
+    m = m.cuda().eval()
+    run = m.graphed_forward(x.cuda(), sigma.cuda(), None)
+    with torch.no_grad():
+        ref = m(x.cuda(), sigma.cuda(), None)
+        assert torch.equal(run(), ref)
+        x2 = (x * 0.5 + 0.1).cuda()
+        s2 = (sigma * 1.7).cuda()
+        assert torch.equal(run(x2, s2), m(x2, s2, None))
+
+
 @pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16x3", 2e-4), ("fp16", 1e-3)])
 @pytest.mark.parametrize("name", list(cases.COND_CASES))
 def test_conditional_diffusion_golden(golden_dir, name, precision, tol):

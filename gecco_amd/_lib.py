@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GECCO_HIP_LIB") or os.path.join(_HERE, "libgecco_hip.so")   # override: A/B builds only
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_f = C.c_void_p  # device pointers travel as void*
 
@@ -76,6 +76,7 @@ SIGNATURES = {
     "gecco_linear_pair_f32": (i, [vp, vp, vp, i, vp, vp, vp, i, vp, vp, vp, i, i, i, i, vp, vp]),
     "gecco_linear_f16io": (i, [vp] * 7 + [i, i, i, i, i, i, i, vp, vp]),
     "gecco_linear_pair_f16io": (i, [vp, vp, vp, i, vp, vp, vp, i, vp, i, i, i, vp, vp]),
+    "gecco_set_option": (i, [C.c_char_p, i]),
     "gecco_linear_astat_f16": (i, [vp, vp, vp, vp, vp, i, vp, vp, vp, i, vp, vp, i, i, i, i, vp, vp]),
     "gecco_affine_cast_f16": (i, [vp, vp, vp, vp, i, i, i, vp]),
     "gecco_pool_attn_f16in": (i, [vp, vp, vp, i, i, i, i, i, vp, sz, vp]),

@@ -7,6 +7,7 @@
 
 #include <stdarg.h>
 #include <stdlib.h>
+#include <string.h>
 #include <stdio.h>
 
 namespace {
@@ -171,6 +172,19 @@ int linear_pair(const float* A, const float* W1, const float* b1, int Nout1, flo
     return gemm_f32_dma_launch(g, s);
 }
 
+// Path switches for A/B runs and tests: gecco_set_option, or the environment (GECCO_ASTAT, GECCO_CHAIN) on first use.
+enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_COUNT = 2 };
+int g_options[OPT_COUNT] = {-1, -1};
+const char* const g_option_names[OPT_COUNT] = {"astat", "chain"};
+const char* const g_option_env[OPT_COUNT] = {"GECCO_ASTAT", "GECCO_CHAIN"};
+int option(int which) {
+    if (g_options[which] < 0) {
+        const char* e = getenv(g_option_env[which]);
+        g_options[which] = e ? (atoi(e) != 0) : 1;
+    }
+    return g_options[which];
+}
+
 // fp16 mode: C16 (| C2_16) = fp16(act(fp16(x * pa + po) W^T + bias)) in one pass over x (gemm_f16_astat.hip).
 // Returns 1 when the shape is outside that kernel's reach (caller: cast pass + streaming GEMM), 0 on success.
 int astat_linear(const float* x, const float* pa, const float* po, const float* img, const float* bias1, int Nout1,
@@ -181,13 +195,8 @@ int astat_linear(const float* x, const float* pa, const float* po, const float* 
     g.B = B; g.rows = rows; g.K = K; g.Nout = Nout1 + Nout2; g.lda = K; g.ldw = K; g.ldc = Nout1; g.ldr = Nout1;
     g.precision = 2; g.w_img = img; g.c_f16 = 1;
     if (C2) { g.C2 = C2; g.bias2 = bias2; g.n_split = Nout1; g.ldc2 = Nout2; }
-    // GECCO_ASTAT=0 falls back to the cast pass + streaming GEMM (A/B runs; same bits)
-    static int enabled = -1;
-    if (enabled < 0) {
-        const char* e = getenv("GECCO_ASTAT");
-        enabled = e ? atoi(e) : 1;
-    }
-    if (!enabled || !img || !gemm_f16_astat_supported(g)) return 1;
+    // option "astat" = 0 falls back to the cast pass + streaming GEMM (A/B runs; same bits)
+    if (!option(OPT_ASTAT) || !img || !gemm_f16_astat_supported(g)) return 1;
     return gemm_f16_astat_launch(g, s);
 }
 
@@ -218,6 +227,9 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         sT = row_tiles_stats(N);
     }
     const int kmod = pr == 2 ? 32 : 16;   // K granularity of the fast kernels
+    // fp16 mode: everything on the 64 inducers between the two attentions is one launch (inducer_chain_f16.hip)
+    const bool chain_on = pr == 2 && w.wimg && option(OPT_CHAIN) && inducer_chain_f16_supported(C, Wd, H, G, I) &&
+                          (ns == 1 || ns == 2 || ns == 4 || ns == 8);
     if (pr >= 1 && w.wimg && !(C % kmod) && !(Wd % kmod)) {
         // split-bf16 mode: every N-token weight of every layer becomes its tiled hi | lo image in ONE launch per
         // 6 layers (weights may change between calls; nothing is cached across forwards)
@@ -239,7 +251,17 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
                 TRY(push(L.kv_proj_w, base, 2 * C, C), "split(kv_proj)");
                 TRY(push(L.pool_out_w, base + w.o_pout, C, C), "split(pool.out_proj)");
                 TRY(push(L.bmlp.w0, base + w.o_b0, Wd, C), "split(broadcast.mlp.0)");
-                TRY(push(L.bmlp.w2, base + w.o_b2, C, Wd), "split(broadcast.mlp.2)");
+                if (chain_on) {   // the one-launch chain walks mlp.2 K-half by K-half: one (C x C) image per half
+                    for (int hf = 0; hf < Wd / C; ++hf) {
+                        jobs.job[jobs.n] = SplitJob{L.bmlp.w2 + (size_t)hf * C, base + w.o_b2 + (size_t)hf * C * C / 2, C, C, Wd, 0};
+                        if (++jobs.n == 32) {
+                            TRY(split_f16_tiled_multi_launch(jobs, s), "split(weights)");
+                            jobs.n = 0;
+                        }
+                    }
+                } else {
+                    TRY(push(L.bmlp.w2, base + w.o_b2, C, Wd), "split(broadcast.mlp.2)");
+                }
             }
             TRY(push(L.in_proj_w + (size_t)C * C, base + w.o_ukv, 2 * C, C), "split(unpool.in_proj kv)");
             TRY(push(L.in_proj_w, base + w.o_q, C, C), "split(q_proj)");
@@ -260,7 +282,7 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         // y = AdaGN(x) is never materialised: (a1, o1) ride in the prologue of the two GEMMs that read x
         TRY(coeffs(sx, sT, N, t, ctx, &L.broadcast_norm, w.a1, w.o1, B, C, G, s), "adagn_coeffs(broadcast_norm)");
         const float* h = h_in ? h_in[li] : nullptr;
-        bool q_done = false;
+        bool q_done = false, kvh_done = false;
         if (!h) {
             // pool: KV projection, 64 inducer queries over the N points, out_proj
             // kv_proj and the unpool's q projection read the same AdaGN(x): one launch, x read once
@@ -284,7 +306,26 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
                 TRY(linear(io16 ? y16 : x, L.kv_proj_w, nullptr, io16 ? nullptr : w.a1, io16 ? nullptr : w.o1, nullptr, nullptr,
                            w.big, nullptr, B, N, C, 2 * C, 0, s, pr, w.wsplit, im, io16, io16), "kv_proj");
             }
-            TRY(pool_attn_launch(w.big, L.inducers, w.part_o, w.part_ml, w.merged, B, N, C, H, I, ns, s, pr, io16), "pool_attn");
+            const bool chain = chain_on && im;
+            TRY(pool_attn_launch(w.big, L.inducers, w.part_o, w.part_ml, chain ? nullptr : w.merged, B, N, C, H, I, ns, s,
+                                 pr, io16), "pool_attn");
+            if (chain) {
+                ChainArgs ca{};
+                ca.part_o = w.part_o; ca.part_ml = w.part_ml; ca.nsplit = ns; ca.H = H;
+                ca.w_stream = im + w.o_pout;   // o_pout, o_b0, o_b2, o_ukv are consecutive (carve_st)
+                ca.b0 = L.bmlp.b0; ca.b2 = L.bmlp.b2; ca.bkv = L.in_proj_b + C; ca.alpha = L.bmlp.alpha; ca.act = act;
+                ca.n1_scale_w = L.norm_1.scale_w; ca.n1_scale_b = L.norm_1.scale_b;
+                ca.n1_bias_w = L.norm_1.bias_w; ca.n1_bias_b = L.norm_1.bias_b;
+                ca.n2_scale_w = L.norm_2.scale_w; ca.n2_scale_b = L.norm_2.scale_b;
+                ca.n2_bias_w = L.norm_2.bias_w; ca.n2_bias_b = L.norm_2.bias_b;
+                ca.t = t; ca.ctx_dim = ctx; ca.G = G; ca.eps = 1e-5f;
+                float* hdst = (h_out && h_out[li]) ? h_out[li] : w.h;
+                ca.h_out = hdst; ca.kvh = w.kvh; ca.B = B;
+                if (act && !L.bmlp.alpha) return fail(-6, "inducer chain: activation needs alpha");
+                TRY(inducer_chain_f16_launch(ca, C, Wd, s), "inducer chain");
+                h = hdst;
+                kvh_done = true;
+            } else {
             TRY(linear(w.merged, L.pool_out_w, nullptr, nullptr, nullptr, nullptr, nullptr, w.h0, w.stats_s, B, I, C, C,
                        0, s, pr, w.wsplit, im ? im + w.o_pout : nullptr), "pool.out_proj");
             // h = norm_2(mlp(norm_1(h0)))
@@ -297,10 +338,12 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
             float* hdst = (h_out && h_out[li]) ? h_out[li] : w.h;
             TRY(affine_apply_launch(w.h2, w.as, w.os, hdst, B, I, C, s), "norm_2 apply");
             h = hdst;
+            }
         }
         // unpool: k|v of the 64 inducer states, q of the N points, attention, out_proj + residual
-        TRY(linear(h, L.in_proj_w + (size_t)C * C, L.in_proj_b + C, nullptr, nullptr, nullptr, nullptr, w.kvh, nullptr,
-                   B, I, C, 2 * C, 0, s, pr, w.wsplit, im ? im + w.o_ukv : nullptr), "unpool.in_proj(kv)");
+        if (!kvh_done)
+            TRY(linear(h, L.in_proj_w + (size_t)C * C, L.in_proj_b + C, nullptr, nullptr, nullptr, nullptr, w.kvh, nullptr,
+                       B, I, C, 2 * C, 0, s, pr, w.wsplit, im ? im + w.o_ukv : nullptr), "unpool.in_proj(kv)");
         if (!q_done) {
             if (io16 && h_in && h_in[li]) TRY(affine_cast_f16_launch(x, w.a1, w.o1, w.attn, B, N, C, s), "broadcast_norm -> fp16");
             TRY(linear(io16 ? w.attn : x, L.in_proj_w, L.in_proj_b, io16 ? nullptr : w.a1, io16 ? nullptr : w.o1, nullptr,
@@ -356,6 +399,16 @@ extern "C" {
 int gecco_abi_version(void) { return GECCO_ABI_VERSION; }
 const char* gecco_build_arch(void) { return "gfx950"; }
 const char* gecco_last_error(void) { return g_err; }
+
+int gecco_set_option(const char* name, int value) {
+    if (!name) return fail(-1, "set_option: null name");
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (!strcmp(name, g_option_names[i])) {
+            g_options[i] = value < 0 ? -1 : (value != 0);   // < 0: back to the environment / default
+            return 0;
+        }
+    return fail(-2, "set_option: unknown option '%s' (astat, chain)", name);
+}
 
 int gecco_linear_row_tiles(int rows) { return row_tiles_gemm(rows); }
 int gecco_stats_row_tiles(int rows) { return row_tiles_stats(rows); }

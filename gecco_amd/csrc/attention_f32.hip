@@ -410,6 +410,7 @@ int pool_attn_launch(const float* KV, const float* inducers, float* part_o, floa
         default: return -4;
     }
     if (rc) return rc;
+    if (!merged) return 0;   // the caller merges the partials itself (inducer_chain_f16.hip)
     const size_t total = (size_t)B * 64 * C;
     hipLaunchKernelGGL(pool_merge_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, part_o, part_ml,
                        merged, B, C, H, nsplit);

@@ -1,0 +1,546 @@
+// The 64-inducer chain of one BroadcastingLayer in ONE launch, fp16 mode (precision 2), gfx950.
+//
+// Between the pool attention and the unpool attention of a layer (reference models/set_transformer.py:99-117) the
+// 64 inducer states of every sample go through
+//
+//     merged = softmax-merge of the pool partials                     (pool_merge_kernel)
+//     h0     = merged @ Wpo^T                                          (pool.out_proj)
+//     u      = act(AdaGN_1(h0) @ W0^T + b0)                            (norm_1, broadcast.mlp.0 + GaussianActivation)
+//     h2     = u @ W2^T + b2                                           (broadcast.mlp.2)
+//     h      = AdaGN_2(h2)                                             (norm_2; the state a cached upsample re-uses)
+//     kvh    = h @ Wkv^T + bkv                                         (unpool.in_proj, rows C..3C)
+//
+// — eight launches of 5-14 us each on 64 rows per sample, every one of them latency-bound (a 4096 x 384 x 384 product
+// is 1.2 GFLOP).  Everything is per-sample (GroupNorm statistics included), so one block per sample runs the whole
+// chain with the activations in LDS / registers and ONE linear stream of weight tiles:
+//   * the four fp16 weight images (gemm_f16_dma.hip's 8 KiB blocks, one per 128-column tile and 32-k step) lie
+//     back to back in the layer's image in the order the chain consumes them; the block streams them through an
+//     11-slot global_load ... lds ring that keeps ~80 KiB in flight across GEMM boundaries and epilogues;
+//   * 8 waves (two per SIMD) as 2 x 4 of 32 x 32 per 128-column tile, 64-k steps (two weight blocks per barrier
+//     round); the A operand (64 rows x C, fp16, rows padded by 16 B) sits in LDS;
+//   * every GEMM's output stays in registers until its last column tile: GroupNorm column sums come from the
+//     accumulators (per-lane columns), the AdaGN apply and the fp16 rounding happen on them, neighbouring lanes
+//     exchange one DPP move so the next operand is written as packed pairs;
+//   * the 2C-wide hidden layer never exists as a whole in LDS: it is held as packed fp16 in 32 registers per column
+//     tile and enters the A buffer in K-halves of C; mlp.2 accumulates all its column tiles over half 0, then half 1
+//     (ascending k per output element, as in the stand-alone kernels).
+// Rounding points are those of the stand-alone chain (fp16 operands formed by one fma + one rounding, fp32
+// accumulation in the same k order, fp32 h and kvh); GroupNorm column sums are added in a different order (fp32).
+#include "gemm_dma_common.h"
+
+#include <stdlib.h>
+
+#include <type_traits>
+
+namespace {
+
+using dma::dma16;
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int CH_TILE = 2048;           // floats per 8 KiB weight block
+constexpr int CH_NT = 512;              // threads per block
+constexpr int CH_LDS_BYTES = 160 * 1024;
+
+constexpr int chain_par_floats(int C, int WD) { return WD + C + 2 * C + 4 * C + 2 * C + 128; }
+constexpr int chain_ns(int C, int WD) {
+    const int left = CH_LDS_BYTES - 64 * (2 * C + 16) - 4 * chain_par_floats(C, WD);
+    return left / (CH_TILE * 4) > 12 ? 12 : left / (CH_TILE * 4);
+}
+constexpr size_t chain_lds_bytes(int C, int WD) {
+    return (size_t)chain_ns(C, WD) * CH_TILE * 4 + 64 * (2 * C + 16) + 4 * chain_par_floats(C, WD);
+}
+
+__device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, float* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
+__device__ __forceinline__ unsigned swap_pair(unsigned v) {   // value of lane ^ 1 (DPP quad_perm [1, 0, 3, 2])
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
+}
+
+// LDS writes of this wave have landed, then the block barrier (no vmcnt wait: the weight ring stays in flight)
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// two fp32 -> one dword of two fp16, each rounded on its own (the asm keeps the compiler from folding a preceding
+// fma into v_fma_mixlo_f16, which would round once where every other kernel of the path rounds twice)
+__device__ __forceinline__ unsigned pack2(float v0, float v1) {
+    asm volatile("" : "+v"(v0), "+v"(v1));
+    f16x2 p;
+    p[0] = (_Float16)v0;
+    p[1] = (_Float16)v1;
+    return __builtin_bit_cast(unsigned, p);
+}
+
+#ifdef CHAIN_STAMPS   // diagnostic build (tools/probe): per-block s_memtime stamps of the phases
+__device__ unsigned long long g_chain_stamps[256 * 16];
+#define CSTAMP(i)                                                                                              \
+    do {                                                                                                       \
+        if (threadIdx.x == 0 && blockIdx.x < 256) g_chain_stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define CSTAMP(i)
+#endif
+
+template <int NT1, int NH>
+__global__ __launch_bounds__(CH_NT, 1) void inducer_chain_f16_kernel(ChainArgs g) {
+    constexpr int C = 128 * NT1, WD = C * NH, NTW = NT1 * NH, NT2 = 2 * NT1;
+    constexpr int NK = C / 32;                  // weight blocks (32 k) per column tile of a K = C operand
+    constexpr int RS = 2 * C + 16;              // bytes per A row: 16 B of padding -> conflict-free ds_read_b128
+    constexpr int S1 = NT1 * NK, S2 = NTW * NK, S3 = NTW * NK, S4 = NT2 * NK;
+    constexpr int S_TOTAL = S1 + S2 + S3 + S4;
+    constexpr int NS = chain_ns(C, WD);
+    constexpr int AHEAD = NS - 4;               // DMA pieces (one per block per wave) that may stay in flight at a wait
+    static_assert(NS >= 6 && S_TOTAL >= NS && NK % 4 == 0, "ring");
+    static_assert(C <= CH_NT, "one channel per thread in the coefficient passes");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* ring = smem;
+    char* abuf = reinterpret_cast<char*>(smem + NS * CH_TILE);
+    float* lb0 = reinterpret_cast<float*>(abuf + 64 * RS);   // mlp.0 bias
+    float* lb2 = lb0 + WD;                                     // mlp.2 bias
+    float* lbk = lb2 + C;                                      // unpool k|v bias
+    float* red = lbk + 2 * C;                                  // [2 row halves][sum, sum of squares][C]
+    float* coef = red + 4 * C;                                 // a[C] | o[C]
+    float* gm = coef + 2 * C;                                  // mean[G] | rstd[G]
+
+    // 8 waves = 2 per SIMD (one wave's issue stalls hide under the other's): 2 row halves x 4 column quarters of a
+    // 128-column tile, one 32 x 32 accumulator per wave and tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.x;
+    const bool odd = lane & 1;
+    const unsigned psel = odd ? 0x03020706u : 0x05040100u;   // v_perm_b32 over {neighbour, own}
+    CSTAMP(0);
+
+    // ---- the weight stream: consecutive 8 KiB blocks (api.hip writes the mlp.2 image K-half by K-half, so the
+    // order the chain consumes is the order in memory); buffer_load ... lds with the block offset in an SGPR, wave w
+    // moves piece w (1 KiB) of every block
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.w_stream), 0, 0x7fffffff, 0x00020000);
+    const unsigned voff = (unsigned)(wave * 256 + lane * 4) * 4u;
+    unsigned soff = 0;     // byte offset of the next block to issue
+    int islot = 0;         // its ring slot
+    int issued = 0;
+    auto issue = [&]() {
+#ifndef CHAIN_DIAG_NODMA
+        dma16_buf(wrsrc, voff, soff, ring + islot * CH_TILE + wave * 256);
+#endif
+        soff += CH_TILE * 4u;
+        islot = islot + 1 == NS ? 0 : islot + 1;
+        ++issued;
+    };
+    // ---- prologue.  Every global read of it is issued in batches of independent loads (one round trip per batch,
+    // not one per element): biases and AdaGN parameters first, then the weight ring's first NS - 2 blocks (younger in
+    // the in-order vmcnt, so waiting for the parameters does not wait for them), then the pool partials.
+    float sc[2], sh[2];   // AdaGN scale / shift of channel tid, norm_1 and norm_2
+    {
+        constexpr int NB0 = (WD + CH_NT - 1) / CH_NT, NBK = (2 * C + CH_NT - 1) / CH_NT;
+        float v0[NB0], vk[NBK];
+#pragma unroll
+        for (int q = 0; q < NB0; ++q) v0[q] = (g.b0 && tid + CH_NT * q < WD) ? g.b0[tid + CH_NT * q] : 0.f;
+        const float v2 = (g.b2 && tid < C) ? g.b2[tid] : 0.f;
+#pragma unroll
+        for (int q = 0; q < NBK; ++q) vk[q] = (g.bkv && tid + CH_NT * q < 2 * C) ? g.bkv[tid + CH_NT * q] : 0.f;
+#pragma unroll
+        for (int nrm = 0; nrm < 2; ++nrm) {
+            const float* sb = nrm ? g.n2_scale_b : g.n1_scale_b;
+            const float* bb = nrm ? g.n2_bias_b : g.n1_bias_b;
+            const bool on = sb && tid < C;
+            sc[nrm] = on ? sb[tid] : 1.f;
+            sh[nrm] = on ? bb[tid] : 0.f;
+        }
+        for (int j = 0; j < g.ctx_dim; ++j) {
+            const float tj = g.t[(size_t)b * g.ctx_dim + j];
+#pragma unroll
+            for (int nrm = 0; nrm < 2; ++nrm) {
+                const float* sw = nrm ? g.n2_scale_w : g.n1_scale_w;
+                const float* bw = nrm ? g.n2_bias_w : g.n1_bias_w;
+                if (sw && tid < C) {
+                    sc[nrm] += tj * sw[(size_t)tid * g.ctx_dim + j];
+                    sh[nrm] += tj * bw[(size_t)tid * g.ctx_dim + j];
+                }
+            }
+        }
+#pragma unroll 1
+        for (int p = 0; p < NS - 2; ++p) issue();
+        CSTAMP(1);
+#pragma unroll
+        for (int q = 0; q < NB0; ++q)
+            if (tid + CH_NT * q < WD) lb0[tid + CH_NT * q] = v0[q];
+        if (tid < C) lb2[tid] = v2;
+#pragma unroll
+        for (int q = 0; q < NBK; ++q)
+            if (tid + CH_NT * q < 2 * C) lbk[tid + CH_NT * q] = vk[q];
+    }
+
+    // ---- merged[i, hh*HD + d] = sum_s f_s O_s / sum_s f_s l_s (pool_merge_kernel's arithmetic), rounded to fp16 into
+    // the A buffer.  Batches of items per thread: all of a batch's loads are independent.
+    auto merge = [&](auto nsp_tag) {
+        constexpr int NSP = decltype(nsp_tag)::value;
+        constexpr int ITEMS = 64 * (C / 4) / CH_NT, BATCH = NSP <= 4 ? 4 : 2;
+        static_assert(64 * (C / 4) % CH_NT == 0 && ITEMS % BATCH == 0, "items per thread");
+        const int HD = C / g.H;
+        // c / HD for c < 512, HD >= 4 by multiply-shift: exact, the fractional part of c / HD is a multiple of 1 / HD
+        const unsigned hd_magic = (1u << 20) / (unsigned)HD + 1u;
+#pragma unroll 1
+        for (int k0 = 0; k0 < ITEMS; k0 += BATCH) {
+            float ml[BATCH][NSP][2];
+            f32x4 po[BATCH][NSP];
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) {
+                const int idx = tid + CH_NT * (k0 + k);
+                const int i = idx / (C / 4), c = (idx % (C / 4)) * 4;
+                const int hh = (int)(((unsigned)c * hd_magic) >> 20);
+                const size_t base = ((size_t)(b * g.H + hh) * NSP) * 64 + i;
+#pragma unroll
+                for (int s = 0; s < NSP; ++s) {
+                    const size_t p = base + (size_t)s * 64;
+                    ml[k][s][0] = g.part_ml[p * 2];
+                    ml[k][s][1] = g.part_ml[p * 2 + 1];
+                    po[k][s] = *reinterpret_cast<const f32x4*>(g.part_o + p * HD + (c - hh * HD));
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) {
+                const int idx = tid + CH_NT * (k0 + k);
+                const int i = idx / (C / 4), c = (idx % (C / 4)) * 4;
+                float M = -INFINITY;
+#pragma unroll
+                for (int s = 0; s < NSP; ++s) M = fmaxf(M, ml[k][s][0]);
+                f32x4 num = {0.f, 0.f, 0.f, 0.f};
+                float den = 0.f;
+#pragma unroll
+                for (int s = 0; s < NSP; ++s) {
+                    const float f = (ml[k][s][0] == -INFINITY) ? 0.f : exp2f(ml[k][s][0] - M);
+                    num += f * po[k][s];
+                    den += f * ml[k][s][1];
+                }
+                f16x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (_Float16)(num[e] / den);
+                *reinterpret_cast<u32x2*>(abuf + i * RS + 2 * c) = __builtin_bit_cast(u32x2, v);
+            }
+        }
+    };
+    switch (g.nsplit) {
+        case 1: merge(std::integral_constant<int, 1>{}); break;
+        case 2: merge(std::integral_constant<int, 2>{}); break;
+        case 4: merge(std::integral_constant<int, 4>{}); break;
+        default: merge(std::integral_constant<int, 8>{}); break;
+    }
+    CSTAMP(2);
+    lds_barrier();
+
+    // ---- the step machine.  One weight block = 8 KiB = 32 k of one 128-column tile; a STEP consumes two of them (64 k:
+    // 4 MFMAs per wave per barrier round).  The bookkeeping is increments and immediates: the fragments of the next
+    // step are read (second register set) before the MFMAs of this one are issued, ring slots and the stream offset
+    // advance by increments.
+    //   D = issued - s (blocks) is NS at a primed step: the wait for blocks s + 2, s + 3 leaves the NS - 4 younger
+    //   pieces in flight (in-order vmcnt; epilogue stores issued in between only make it wait for more), the barrier
+    //   frees the slots of blocks s, s + 1 (every wave's reads of them returned before it) and two blocks are issued
+    //   into them.  Where the A operand changes the pipeline drains (D = NS - 2) and is primed again: same wait, the
+    //   barrier frees blocks s - 2, s - 1, two issues.  Tiles that reach the end of the stream (TAIL) stop issuing
+    //   and wait for everything.
+    int s = 0;
+    int rslot = 0;             // ring slot of the next block to read fragments from
+    const char* arow = abuf + (wm * 32 + r) * RS + 32 * h;
+    int boff[2];
+    {
+        const int rb = wn * 32 + r;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) boff[c] = rb * 16 + (((2 * h + c) ^ ((rb >> 2) & 3)) << 2);
+    }
+    f16x8 fa[2][2][2], fb[2][2][2];   // [set][block][chunk]
+    auto load_frags = [&](auto set_tag, int kt) {   // blocks kt, kt + 1 of the tile
+        constexpr int set = decltype(set_tag)::value;
+#ifdef CHAIN_DIAG_NOFRAGS
+        if (kt >= 0) return;
+#endif
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float* st = ring + rslot * CH_TILE;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                fa[set][q][c] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(arow + (kt + q) * 64 + 16 * c));
+                fb[set][q][c] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(st + boff[c]));
+            }
+            rslot = rslot + 1 == NS ? 0 : rslot + 1;
+        }
+    };
+    auto wait_blocks = [&](auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        if (TAIL && issued >= S_TOTAL) dma::wait_vm_lgkm0<0>();
+        else dma::wait_vm_lgkm0<AHEAD>();
+    };
+    auto issue2 = [&](auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (!TAIL || issued < S_TOTAL) issue();
+    };
+    // one step: set `cur` holds its fragments; has_next: the following step reads the same A operand
+    auto kstep = [&](auto cur_tag, auto tail_tag, bool has_next, int kt_next, f32x16& a0) {
+        constexpr int cur = decltype(cur_tag)::value;
+        if (has_next) {
+            wait_blocks(tail_tag);
+            // this step's fragments were read during the previous one and the wait above covered them: "redefine"
+            // them so the compiler's wait-count pass does not put an lgkmcnt(0) — which would also wait for the
+            // reads issued below — in front of the first MFMA
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    asm volatile("" : "+v"(fa[cur][q][c]));
+                    asm volatile("" : "+v"(fb[cur][q][c]));
+                }
+#ifndef CHAIN_DIAG_NOBARRIER
+            __builtin_amdgcn_s_barrier();
+#endif
+            asm volatile("" ::: "memory");
+            issue2(tail_tag);
+            load_frags(std::integral_constant<int, cur ^ 1>{}, kt_next);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+#ifdef CHAIN_DIAG_NOMFMA
+                a0[0] += (float)fa[cur][q][c][0] + (float)fb[cur][q][c][0];
+#else
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][q][c], fb[cur][q][c], a0, 0, 0, 0);
+#endif
+            }
+    };
+    auto tile_steps = [&](auto tail_tag, bool first, bool more, f32x16& a0) {
+        constexpr std::integral_constant<int, 0> set0{};
+        constexpr std::integral_constant<int, 1> set1{};
+        if (first) {   // prime: the fragments of blocks s, s + 1
+            wait_blocks(tail_tag);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            issue2(tail_tag);
+            load_frags(set0, 0);
+        }
+#pragma unroll 1
+        for (int kt = 0; kt < NK - 4; kt += 4) {
+            kstep(set0, tail_tag, true, kt + 2, a0);
+            kstep(set1, tail_tag, true, kt + 4, a0);
+        }
+        kstep(set0, tail_tag, true, NK - 2, a0);
+        kstep(set1, tail_tag, more, 0, a0);
+        s += NK;
+    };
+    // the NK blocks of one column tile; first: the A operand is new (prime the pipeline); more: another tile over
+    // the same A operand follows
+    auto run_tile = [&](f32x16& a0, bool first, bool more) {
+        if (s + NK + NS > S_TOTAL) tile_steps(std::true_type{}, first, more, a0);
+        else tile_steps(std::false_type{}, first, more, a0);
+    };
+    auto zero = [](f32x16& a) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a[e] = 0.f;
+    };
+
+    // GroupNorm coefficients of the [64 x C] tensor whose per-lane columns are in acc (+ bias already added):
+    // column sums -> group mean / rstd (double, as adagn_coeffs_kernel) -> coef = a | o.  Three barriers.
+    auto norm_coeffs = [&](f32x16 (&acc)[NT1], int nrm) {
+#pragma unroll
+        for (int t = 0; t < NT1; ++t) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                s1 += acc[t][e];
+                s2 += acc[t][e] * acc[t][e];
+            }
+            s1 += xor32(s1);
+            s2 += xor32(s2);
+            if (h == 0) {
+                const int n = t * 128 + wn * 32 + r;
+                red[(wm * 2 + 0) * C + n] = s1;
+                red[(wm * 2 + 1) * C + n] = s2;
+            }
+        }
+        lds_barrier();
+        const int G = g.G, cpg = C / G;
+        if (tid < G) {
+            double d1 = 0.0, d2 = 0.0;
+            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+                d1 += (double)(red[c] + red[2 * C + c]);
+                d2 += (double)(red[C + c] + red[3 * C + c]);
+            }
+            const double n = 64.0 * cpg;
+            const double mean = d1 / n;
+            double var = d2 / n - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            gm[tid] = (float)mean;
+            gm[G + tid] = (float)(1.0 / sqrt(var + (double)g.eps));
+        }
+        lds_barrier();
+        if (tid < C) {
+            const float mean = gm[tid / cpg], rstd = gm[G + tid / cpg];
+            const float sv = nrm ? sc[1] : sc[0], zv = nrm ? sh[1] : sh[0];
+            coef[tid] = sv * rstd;
+            coef[C + tid] = zv - sv * mean * rstd;
+        }
+        lds_barrier();
+    };
+    // packed pair (rows of accumulator registers 2p, 2p+1 of this lane's column) -> (one row, this lane pair's two
+    // columns): even lanes keep row 2p, odd lanes row 2p + 1
+    auto pair_rows = [&](float v0, float v1) -> unsigned {
+        const unsigned own = pack2(v0, v1);
+        return __builtin_amdgcn_perm(swap_pair(own), own, psel);
+    };
+    // dword address of (accumulator pair p, column tile slot tl) in the A buffer
+    auto a_dst = [&](int tl, int p) -> unsigned* {
+        const int row = wm * 32 + ((2 * p) & 3) + 8 * ((2 * p) >> 2) + 4 * h + (odd ? 1 : 0);
+        const int col = tl * 128 + wn * 32 + (r & ~1);
+        return reinterpret_cast<unsigned*>(abuf + row * RS + 2 * col);
+    };
+
+    const bool has_act = g.act != 0, act_norm = g.act == 1;
+    const float neg_inv_2a2 = has_act ? -1.0f / (2.0f * g.alpha[0] * g.alpha[0]) : 0.f;
+
+    // ================= GEMM 1: h0 = merged16 Wpo^T; norm_1; y16 -> A buffer
+    f32x16 acc1[NT1];
+#pragma unroll
+    for (int t = 0; t < NT1; ++t) {
+        zero(acc1[t]);
+        run_tile(acc1[t], t == 0, t + 1 < NT1);
+    }
+    CSTAMP(3);
+    norm_coeffs(acc1, 0);   // its barriers also order every wave's last A reads before the writes below
+    CSTAMP(4);
+#pragma unroll
+    for (int t = 0; t < NT1; ++t) {
+        const int n = t * 128 + wn * 32 + r;
+        const float ca = coef[n], co = coef[C + n];
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+            *a_dst(t, p) = pair_rows(__builtin_fmaf(acc1[t][2 * p], ca, co), __builtin_fmaf(acc1[t][2 * p + 1], ca, co));
+    }
+    lds_barrier();
+
+    // ================= GEMM 2: u = act(y16 W0^T + b0), kept as packed fp16 pairs in registers
+    CSTAMP(5);
+    unsigned upk[NTW][8];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        f32x16 a0;
+        zero(a0);
+        run_tile(a0, t == 0, t + 1 < NTW);
+        const float bias = lb0[t * 128 + wn * 32 + r];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            float v0 = a0[2 * p] + bias, v1 = a0[2 * p + 1] + bias;
+            if (has_act) {
+                v0 = gauss_act(v0, neg_inv_2a2, act_norm);
+                v1 = gauss_act(v1, neg_inv_2a2, act_norm);
+            }
+            upk[t][p] = pair_rows(v0, v1);
+        }
+    }
+
+    // ================= GEMM 3: h2 = u16 W2^T + b2, K-half by K-half through the A buffer
+    CSTAMP(6);
+#pragma unroll
+    for (int t = 0; t < NT1; ++t) zero(acc1[t]);
+#pragma unroll
+    for (int hf = 0; hf < NH; ++hf) {
+        lds_barrier();   // every wave is done reading the previous operand
+#pragma unroll
+        for (int tl = 0; tl < NT1; ++tl)
+#pragma unroll
+            for (int p = 0; p < 8; ++p) *a_dst(tl, p) = upk[hf * NT1 + tl][p];
+        lds_barrier();
+#pragma unroll
+        for (int t = 0; t < NT1; ++t) run_tile(acc1[t], t == 0, t + 1 < NT1);
+    }
+#pragma unroll
+    for (int t = 0; t < NT1; ++t) {
+        const float bias = lb2[t * 128 + wn * 32 + r];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc1[t][e] += bias;
+    }
+    CSTAMP(7);
+    norm_coeffs(acc1, 1);
+    CSTAMP(8);
+    // h = AdaGN_2(h2): fp32 to memory (the cacheable inducer state), fp16 into the A buffer
+    {
+        float* hb = g.h_out + (size_t)b * 64 * C;
+#pragma unroll
+        for (int t = 0; t < NT1; ++t) {
+            const int n = t * 128 + wn * 32 + r;
+            const float ca = coef[n], co = coef[C + n];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const float v0 = __builtin_fmaf(acc1[t][2 * p], ca, co);
+                const float v1 = __builtin_fmaf(acc1[t][2 * p + 1], ca, co);
+                const int row0 = wm * 32 + mfma_row(2 * p, h);
+                hb[(size_t)row0 * C + n] = v0;
+                hb[(size_t)(row0 + 1) * C + n] = v1;
+                *a_dst(t, p) = pair_rows(v0, v1);
+            }
+        }
+    }
+    lds_barrier();
+
+    // ================= GEMM 4: kvh = h16 Wkv^T + bkv (fp32, read by the unpool attention)
+    CSTAMP(9);
+    {
+        float* kb = g.kvh + (size_t)b * 64 * 2 * C;
+#pragma unroll 1
+        for (int t = 0; t < NT2; ++t) {
+            f32x16 a0;
+            zero(a0);
+            run_tile(a0, t == 0, t + 1 < NT2);
+            const int n = t * 128 + wn * 32 + r;
+            const float bias = lbk[n];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) kb[(size_t)(wm * 32 + mfma_row(e, h)) * 2 * C + n] = a0[e] + bias;
+        }
+    }
+    CSTAMP(10);
+}
+
+template <int NT1, int NH>
+int chain_launch_t(const ChainArgs& g, hipStream_t st) {
+    constexpr int C = 128 * NT1, WD = C * NH;
+    constexpr size_t lds = chain_lds_bytes(C, WD);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(inducer_chain_f16_kernel<NT1, NH>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((inducer_chain_f16_kernel<NT1, NH>), dim3(g.B), dim3(CH_NT), lds, st, g);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+bool inducer_chain_f16_supported(int C, int Wd, int H, int G, int I) {
+    if (I != 64 || C % 128 || C > 512 || Wd != 2 * C || H <= 0 || C % H || (C / H) % 4) return false;
+    return G > 0 && G <= 64 && C % G == 0;
+}
+
+int inducer_chain_f16_launch(const ChainArgs& g, int C, int Wd, hipStream_t st) {
+    if (!inducer_chain_f16_supported(C, Wd, g.H, g.G, 64)) return -9;
+    if (g.nsplit != 1 && g.nsplit != 2 && g.nsplit != 4 && g.nsplit != 8) return -9;
+    switch (C / 128) {
+        case 1: return chain_launch_t<1, 2>(g, st);
+        case 2: return chain_launch_t<2, 2>(g, st);
+        case 3: return chain_launch_t<3, 2>(g, st);
+        default: return chain_launch_t<4, 2>(g, st);
+    }
+}

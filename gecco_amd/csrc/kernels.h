@@ -47,6 +47,27 @@ size_t split_f16_image_bytes(int Nout, int K);   // ceil(Nout / 128) * 128 * K *
 int split_f16_tiled_launch(const float* W, void* img, int Nout, int K, int ldw, hipStream_t st);
 int split_f16_tiled_multi_launch(const SplitJobs& jobs, hipStream_t st);
 
+// inducer_chain_f16.hip — fp16 mode: pool merge, pool.out_proj, norm_1, broadcast.mlp, norm_2 and the unpool k|v
+// projection of the 64 inducers of every sample in one launch (one block per sample)
+struct ChainArgs {
+    const float* part_o;      // pool partials (B, H, nsplit, 64, hd)
+    const float* part_ml;     // (B, H, nsplit, 64, 2)
+    int nsplit, H;
+    const float* w_stream;    // fp16 tiled images of pool.out_proj | mlp.0 | mlp.2 | unpool k|v, back to back
+    const float *b0, *b2, *bkv, *alpha;
+    int act;
+    const float *n1_scale_w, *n1_scale_b, *n1_bias_w, *n1_bias_b;
+    const float *n2_scale_w, *n2_scale_b, *n2_bias_w, *n2_bias_b;
+    const float* t;
+    int ctx_dim, G;
+    float eps;
+    float* h_out;             // (B, 64, C) fp32
+    float* kvh;               // (B, 64, 2C) fp32
+    int B;
+};
+bool inducer_chain_f16_supported(int C, int Wd, int H, int G, int I);
+int inducer_chain_f16_launch(const ChainArgs& g, int C, int Wd, hipStream_t st);
+
 // gemm_f16_astat.hip — fp16 mode, A-stationary: AdaGN apply + fp16 rounding + all column tiles in one pass over x
 // (fp32 A with optional prologue, fp16 outputs, one or two segments; K <= 384, full 128-tiles)
 bool gemm_f16_astat_supported(const GemmArgs& g);

@@ -32,6 +32,13 @@ def set_default_precision(name: str) -> None:
     _default_precision = name
 
 
+def set_option(name: str, value: int) -> None:
+    """Process-wide path switch of the library ("astat", "chain"; include/gecco_hip.h gecco_set_option): 0 / 1, or a
+    negative value to return to the default.  For A/B measurements and the tests that compare the fused launches with
+    the stand-alone kernels they replace."""
+    _lib.check(_lib.load().gecco_set_option(name.encode(), int(value)), "set_option")
+
+
 def default_precision() -> str:
     return _default_precision
 

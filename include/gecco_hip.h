@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GECCO_ABI_VERSION 3
+#define GECCO_ABI_VERSION 4
 
 int gecco_abi_version(void);
 const char* gecco_build_arch(void);   /* "gfx950" */
@@ -78,6 +78,12 @@ typedef struct GeccoSetTransformer {  /* SetTransformer, models/set_transformer.
 int gecco_linear_f32(const float* A, const float* W, const float* bias, const float* pro_a, const float* pro_o,
                      const float* alpha, const float* residual, float* C, float* stats, int B, int rows, int K,
                      int Nout, int act, void* stream);
+/* Path switches for A/B measurements and tests (the results agree to rounding):
+ *   "astat" (default 1): fp16 mode runs AdaGN + kv|q and AdaGN + mlp.0 as one A-stationary pass over x;
+ *   "chain" (default 1): fp16 mode runs the 64-inducer chain of a layer (pool merge .. unpool k|v) as one launch.
+ * value < 0 returns the option to its default / environment (GECCO_ASTAT, GECCO_CHAIN).  Process-wide. */
+int gecco_set_option(const char* name, int value);
+
 int gecco_linear_row_tiles(int rows);
 /* The same with the arithmetic selectable: precision 0 = exact fp32 MFMA, 1 = split-bf16, 2 = fp16 (see GeccoSetTransformer);
  * wsplit: scratch of >= ceil(Nout/128)*128*K*4 bytes for the tiled image of W (bf16 hi | lo, or fp16; precision 1 / 2). */

@@ -77,10 +77,10 @@ SIGNATURES = {
     "gecco_linear_f16io": (i, [vp] * 7 + [i, i, i, i, i, i, i, vp, vp]),
     "gecco_linear_pair_f16io": (i, [vp, vp, vp, i, vp, vp, vp, i, vp, i, i, i, vp, vp]),
     "gecco_set_option": (i, [C.c_char_p, i]),
-    "gecco_linear_astat_f16": (i, [vp, vp, vp, vp, vp, i, vp, vp, vp, i, vp, vp, i, i, i, i, vp, vp]),
+    "gecco_linear_astat_f16": (i, [vp, vp, vp, vp, vp, i, vp, vp, vp, i, vp, vp, i, i, i, i, i, vp, vp]),
     "gecco_affine_cast_f16": (i, [vp, vp, vp, vp, i, i, i, vp]),
-    "gecco_pool_attn_f16in": (i, [vp, vp, vp, i, i, i, i, i, vp, sz, vp]),
-    "gecco_unpool_attn_f16io": (i, [vp, vp, vp, i, i, i, i, i, vp]),
+    "gecco_pool_attn_f16in": (i, [vp, vp, vp, i, i, i, i, i, i, vp, sz, vp]),
+    "gecco_unpool_attn_f16io": (i, [vp, vp, vp, i, i, i, i, i, i, vp]),
     "gecco_col_stats_f32": (i, [vp, vp, i, i, i, vp]),
     "gecco_stats_row_tiles": (i, [i]),
     "gecco_adagn_coeffs_f32": (i, [vp, i, i, vp, i, C.POINTER(GeccoAdaGN), vp, vp, i, i, i, fl, vp]),

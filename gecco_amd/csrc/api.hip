@@ -173,10 +173,10 @@ int linear_pair(const float* A, const float* W1, const float* b1, int Nout1, flo
 }
 
 // Path switches for A/B runs and tests: gecco_set_option, or the environment (GECCO_ASTAT, GECCO_CHAIN) on first use.
-enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_COUNT = 2 };
-int g_options[OPT_COUNT] = {-1, -1};
-const char* const g_option_names[OPT_COUNT] = {"astat", "chain"};
-const char* const g_option_env[OPT_COUNT] = {"GECCO_ASTAT", "GECCO_CHAIN"};
+enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_HEADMAJOR = 2, OPT_COUNT = 3 };
+int g_options[OPT_COUNT] = {-1, -1, -1};
+const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor"};
+const char* const g_option_env[OPT_COUNT] = {"GECCO_ASTAT", "GECCO_CHAIN", "GECCO_HEADMAJOR"};
 int option(int which) {
     if (g_options[which] < 0) {
         const char* e = getenv(g_option_env[which]);
@@ -189,11 +189,11 @@ int option(int which) {
 // Returns 1 when the shape is outside that kernel's reach (caller: cast pass + streaming GEMM), 0 on success.
 int astat_linear(const float* x, const float* pa, const float* po, const float* img, const float* bias1, int Nout1,
                  float* C1, const float* bias2, int Nout2, float* C2, const float* alpha, int act, int B, int rows,
-                 int K, hipStream_t s) {
+                 int K, hipStream_t s, int hm_hd = 0) {
     GemmArgs g{};
     g.A = x; g.pro_a = pa; g.pro_o = po; g.bias = bias1; g.alpha = alpha; g.act = act; g.C = C1;
     g.B = B; g.rows = rows; g.K = K; g.Nout = Nout1 + Nout2; g.lda = K; g.ldw = K; g.ldc = Nout1; g.ldr = Nout1;
-    g.precision = 2; g.w_img = img; g.c_f16 = 1;
+    g.precision = 2; g.w_img = img; g.c_f16 = 1; g.hm_hd = hm_hd;
     if (C2) { g.C2 = C2; g.bias2 = bias2; g.n_split = Nout1; g.ldc2 = Nout2; }
     // option "astat" = 0 falls back to the cast pass + streaming GEMM (A/B runs; same bits)
     if (!option(OPT_ASTAT) || !img || !gemm_f16_astat_supported(g)) return 1;
@@ -283,15 +283,24 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         TRY(coeffs(sx, sT, N, t, ctx, &L.broadcast_norm, w.a1, w.o1, B, C, G, s), "adagn_coeffs(broadcast_norm)");
         const float* h = h_in ? h_in[li] : nullptr;
         bool q_done = false, kvh_done = false;
+        int hm = 0;   // K | V and q of this layer are head-major
         if (!h) {
             // pool: KV projection, 64 inducer queries over the N points, out_proj
             // kv_proj and the unpool's q projection read the same AdaGN(x): one launch, x read once
             // fp16 mode: AdaGN(x) is formed once as the fp16 operand both projections read (in the attention-output
             // buffer, idle until the unpool) instead of on every column tile's fragments
             float* y16 = w.attn;
+            // K | V and q leave the A-stationary kernel head-major: one contiguous (N, hd) slab per (sample, head),
+            // which is what a pool / unpool block streams (row-major: hd-wide pieces of rows shared by all heads)
+            const int hd_try = option(OPT_HEADMAJOR) ? C / H : 0;
             int fused = io16 ? astat_linear(x, w.a1, w.o1, (2 * C) % 128 == 0 ? im : nullptr, nullptr, 2 * C, w.big,
-                                            L.in_proj_b, C, w.q, nullptr, 0, B, N, C, s)
+                                            L.in_proj_b, C, w.q, nullptr, 0, B, N, C, s, hd_try)
                              : 1;
+            if (io16 && fused == 1 && hd_try)   // shape outside the head-major form: row-major
+                fused = astat_linear(x, w.a1, w.o1, (2 * C) % 128 == 0 ? im : nullptr, nullptr, 2 * C, w.big, L.in_proj_b,
+                                     C, w.q, nullptr, 0, B, N, C, s, 0);
+            else if (fused == 0 && hd_try)
+                hm = 1;
             if (fused < 0) TRY(fused, "kv_proj|q_proj (A-stationary)");
             if (fused == 0) {
                 q_done = true;
@@ -308,7 +317,7 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
             }
             const bool chain = chain_on && im;
             TRY(pool_attn_launch(w.big, L.inducers, w.part_o, w.part_ml, chain ? nullptr : w.merged, B, N, C, H, I, ns, s,
-                                 pr, io16), "pool_attn");
+                                 pr, io16, hm), "pool_attn");
             if (chain) {
                 ChainArgs ca{};
                 ca.part_o = w.part_o; ca.part_ml = w.part_ml; ca.nsplit = ns; ca.H = H;
@@ -350,7 +359,7 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
                        nullptr, w.q, nullptr, B, N, C, C, 0, s, pr, w.wsplit, im ? im + w.o_q : nullptr, io16, io16),
                 "unpool.in_proj(q)");
         }
-        TRY(unpool_attn_launch(w.q, w.kvh, w.attn, B, N, C, H, I, s, pr, io16), "unpool_attn");
+        TRY(unpool_attn_launch(w.q, w.kvh, w.attn, B, N, C, H, I, s, pr, io16, hm), "unpool_attn");
         TRY(linear(w.attn, L.unpool_out_w, L.unpool_out_b, nullptr, nullptr, nullptr, x, x, w.stats_x, B, N, C, C, 0, s, pr,
                    w.wsplit, im ? im + w.o_out : nullptr, io16, 0), "unpool.out_proj+residual");
         // x += mlp(AdaGN(x))
@@ -407,7 +416,7 @@ int gecco_set_option(const char* name, int value) {
             g_options[i] = value < 0 ? -1 : (value != 0);   // < 0: back to the environment / default
             return 0;
         }
-    return fail(-2, "set_option: unknown option '%s' (astat, chain)", name);
+    return fail(-2, "set_option: unknown option '%s' (astat, chain, headmajor)", name);
 }
 
 int gecco_linear_row_tiles(int rows) { return row_tiles_gemm(rows); }
@@ -480,7 +489,7 @@ int gecco_linear_pair_f16io(const void* A, const float* W1, const float* bias1, 
 
 int gecco_linear_astat_f16(const float* x, const float* pro_a, const float* pro_o, const float* W1, const float* bias1,
                            int Nout1, void* C1, const float* W2, const float* bias2, int Nout2, void* C2,
-                           const float* alpha, int act, int B, int rows, int K, void* wsplit, void* stream) {
+                           const float* alpha, int act, int B, int rows, int K, int head_dim, void* wsplit, void* stream) {
     if (!x || !W1 || !C1 || !wsplit) return fail(-1, "linear_astat: null argument");
     if ((pro_a == nullptr) != (pro_o == nullptr)) return fail(-1, "linear_astat: pro_a/pro_o must both be set");
     if ((W2 == nullptr) != (C2 == nullptr)) return fail(-1, "linear_astat: W2 and C2 go together");
@@ -491,11 +500,13 @@ int gecco_linear_astat_f16(const float* x, const float* pro_a, const float* pro_
     GemmArgs g{};
     g.A = x; g.pro_a = pro_a; g.pro_o = pro_o; g.bias = bias1; g.alpha = alpha; g.act = act; g.C = static_cast<float*>(C1);
     g.B = B; g.rows = rows; g.K = K; g.Nout = Nout1 + (W2 ? Nout2 : 0); g.lda = K; g.ldw = K; g.ldc = Nout1; g.ldr = Nout1;
-    g.precision = 2; g.w_img = img; g.c_f16 = 1;
+    g.precision = 2; g.w_img = img; g.c_f16 = 1; g.hm_hd = head_dim;
     if (W2) { g.C2 = static_cast<float*>(C2); g.bias2 = bias2; g.n_split = Nout1; g.ldc2 = Nout2; }
     if (act && !alpha) return fail(-6, "linear_astat: activation needs alpha");
+    if (head_dim < 0) return fail(-2, "linear_astat: head_dim < 0");
     if (!gemm_f16_astat_supported(g))
-        return fail(-2, "linear_astat: needs rows %% 128 == 0, Nout %% 128 == 0, K in {128, 256, 384, 512}");
+        return fail(-2, "linear_astat: needs rows %% 128 == 0, Nout %% 128 == 0, K in {128, 256, 384, 512}; head-major: "
+                        "even head_dim >= 8 dividing both segment widths");
     TRY(gemm_f16_astat_launch(g, s), "linear_astat");
     return 0;
 }
@@ -508,23 +519,23 @@ int gecco_affine_cast_f16(const float* x, const float* a, const float* o, void* 
 }
 
 int gecco_pool_attn_f16in(const void* KV16, const float* inducers, float* merged, int B, int N, int C, int H, int I,
-                          void* ws, size_t ws_bytes, void* stream) {
+                          int head_major, void* ws, size_t ws_bytes, void* stream) {
     if (ws_bytes < gecco_pool_attn_workspace_bytes(B, N, C, H, I)) return fail(-7, "pool_attn: workspace too small");
     Carver c(ws);
     const int ns = pool_attn_nsplit(B, N, H);
     float* po = c.f32((size_t)B * H * ns * 64 * (C / H));
     float* pml = c.f32((size_t)B * H * ns * 64 * 2);
     int rc = pool_attn_launch(static_cast<const float*>(KV16), inducers, po, pml, merged, B, N, C, H, I, ns,
-                              (hipStream_t)stream, 2, 1);
+                              (hipStream_t)stream, 2, 1, head_major != 0);
     if (rc == -9) return fail(-2, "pool_attn_f16in: head dim must be 16, 32, 48 or 64");
     TRY(rc, "pool_attn_f16in");
     return 0;
 }
 
 int gecco_unpool_attn_f16io(const void* q16, const float* kvh, void* out16, int B, int N, int C, int H, int I,
-                            void* stream) {
+                            int head_major, void* stream) {
     int rc = unpool_attn_launch(static_cast<const float*>(q16), kvh, static_cast<float*>(out16), B, N, C, H, I,
-                                (hipStream_t)stream, 2, 1);
+                                (hipStream_t)stream, 2, 1, head_major != 0);
     if (rc == -9) return fail(-2, "unpool_attn_f16io: head dim must be 16, 32, 48 or 64");
     TRY(rc, "unpool_attn_f16io");
     return 0;

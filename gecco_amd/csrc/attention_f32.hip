@@ -395,12 +395,13 @@ int pool_attn_nsplit(int B, int N, int H) {
 }
 
 int pool_attn_launch(const float* KV, const float* inducers, float* part_o, float* part_ml, float* merged, int B,
-                     int N, int C, int H, int I, int nsplit, hipStream_t st, int precision, int io16) {
+                     int N, int C, int H, int I, int nsplit, hipStream_t st, int precision, int io16, int hm) {
     if (I != 64 || C % H) return -3;
     if (io16 && !(precision == 2 && attn_x3_supported(C / H))) return -9;
+    if (hm && !io16) return -9;
     const int HD = C / H;
     int rc;
-    if (precision >= 1 && attn_x3_supported(HD)) rc = pool_attn_x3_partials_launch(KV, inducers, part_o, part_ml, B, N, C, H, nsplit, st, precision, io16);
+    if (precision >= 1 && attn_x3_supported(HD)) rc = pool_attn_x3_partials_launch(KV, inducers, part_o, part_ml, B, N, C, H, nsplit, st, precision, io16, hm);
     else switch (HD) {
         case 8: rc = pool_launch_t<8>(KV, inducers, part_o, part_ml, B, N, C, H, nsplit, st); break;
         case 16: rc = pool_launch_t<16>(KV, inducers, part_o, part_ml, B, N, C, H, nsplit, st); break;
@@ -418,10 +419,11 @@ int pool_attn_launch(const float* KV, const float* inducers, float* part_o, floa
 }
 
 int unpool_attn_launch(const float* q, const float* kvh, float* out, int B, int N, int C, int H, int I,
-                       hipStream_t st, int precision, int io16) {
+                       hipStream_t st, int precision, int io16, int hm) {
     if (I != 64 || C % H) return -3;
     if (io16 && !(precision == 2 && attn_x3_supported(C / H))) return -9;
-    if (precision >= 1 && attn_x3_supported(C / H)) return unpool_attn_x3_launch(q, kvh, out, B, N, C, H, st, precision, io16);
+    if (hm && !io16) return -9;
+    if (precision >= 1 && attn_x3_supported(C / H)) return unpool_attn_x3_launch(q, kvh, out, B, N, C, H, st, precision, io16, hm);
     switch (C / H) {
         case 8: return unpool_launch_t<8>(q, kvh, out, B, N, C, H, st);
         case 16: return unpool_launch_t<16>(q, kvh, out, B, N, C, H, st);

@@ -106,7 +106,7 @@ template <int HD, bool F16, bool IO16>
 __global__ __launch_bounds__(256, 2) void pool_attn_x3_kernel(const float* __restrict__ KV,
                                                            const float* __restrict__ Qind,
                                                            float* __restrict__ part_o, float* __restrict__ part_ml,
-                                                           int B, int N, int C, int H, int nsplit) {
+                                                           int B, int N, int C, int H, int nsplit, int hm) {
     constexpr int KS = HD + 8;            // bf16 elements per K / Q row: an odd number of 16-byte chunks
     constexpr int DT = (HD + 31) / 32;
     constexpr int CH = HD / 4;
@@ -152,8 +152,11 @@ __global__ __launch_bounds__(256, 2) void pool_attn_x3_kernel(const float* __res
 
     static_assert(!IO16 || F16, "fp16 tensors exist in fp16 mode only");
     constexpr int CH8 = HD / 8, LD8 = (32 * CH8 + 63) / 64;   // 16-byte chunks of 8 fp16
-    const _Float16* Kg16 = reinterpret_cast<const _Float16*>(KV) + (size_t)b * N * ldkv + hh * HD;
-    const _Float16* Vg16 = Kg16 + C;
+    // hm (IO16 only): head-major K | V, one contiguous (N, HD) slab per (sample, K or V, head) — gemm_f16_astat.hip
+    const size_t ld16 = hm ? (size_t)HD : ldkv;
+    const _Float16* Kg16 = reinterpret_cast<const _Float16*>(KV) +
+                           (hm ? ((size_t)b * 2 * H + hh) * N * HD : (size_t)b * N * ldkv + hh * HD);
+    const _Float16* Vg16 = Kg16 + (hm ? (size_t)H * N * HD : (size_t)C);
     f32x4 rk[IO16 ? 1 : LD_IT], rv[IO16 ? 1 : LD_IT];
     u32x4 rk8[IO16 ? LD8 : 1], rv8[IO16 ? LD8 : 1];
     auto load_tile = [&](int tile) {
@@ -164,8 +167,8 @@ __global__ __launch_bounds__(256, 2) void pool_attn_x3_kernel(const float* __res
                 const int f = it * 64 + lane, row = f / CH8, c8 = f % CH8, key = base + row;
                 u32x4 zk = {0u, 0u, 0u, 0u}, zv = {0u, 0u, 0u, 0u};
                 if (f < 32 * CH8 && tile < ntiles && key < k_end) {
-                    zk = *reinterpret_cast<const u32x4*>(Kg16 + key * ldkv + c8 * 8);
-                    zv = *reinterpret_cast<const u32x4*>(Vg16 + key * ldkv + c8 * 8);
+                    zk = *reinterpret_cast<const u32x4*>(Kg16 + key * ld16 + c8 * 8);
+                    zv = *reinterpret_cast<const u32x4*>(Vg16 + key * ld16 + c8 * 8);
                 }
                 rk8[it] = zk;
                 rv8[it] = zv;
@@ -358,7 +361,7 @@ template <int HD, bool F16, bool IO16>
 __global__ __launch_bounds__(256, 2) void unpool_attn_x3_kernel(const float* __restrict__ q,
                                                              const float* __restrict__ kvh, float* __restrict__ out,
                                                              int B, int N, int C, int H, int tiles_per_wave,
-                                                             int nchunk) {
+                                                             int nchunk, int hm) {
     constexpr int KS = HD + 8;            // bf16 elements per K / Q row
     constexpr int VS = 64 + 8;            // bf16 elements per V^T row (64 permuted keys + pad)
     constexpr int DT = (HD + 31) / 32;
@@ -410,7 +413,10 @@ __global__ __launch_bounds__(256, 2) void unpool_attn_x3_kernel(const float* __r
 
     static_assert(!IO16 || F16, "fp16 tensors exist in fp16 mode only");
     constexpr int CH8 = HD / 8, LD8 = (32 * CH8 + 63) / 64;
-    const _Float16* qb16 = reinterpret_cast<const _Float16*>(q) + (size_t)b * N * C + hh * HD;
+    // hm (IO16 only): head-major q, one contiguous (N, HD) slab per (sample, head)
+    const size_t ldq16 = hm ? (size_t)HD : (size_t)C;
+    const _Float16* qb16 = reinterpret_cast<const _Float16*>(q) +
+                           (hm ? ((size_t)b * H + hh) * N * HD : (size_t)b * N * C + hh * HD);
     _Float16* ob16 = reinterpret_cast<_Float16*>(out) + (size_t)b * N * C + hh * HD;
     f32x4 rq[IO16 ? 1 : LD_IT];
     u32x4 rq8[IO16 ? LD8 : 1];
@@ -421,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void unpool_attn_x3_kernel(const float* __r
             for (int ld = 0; ld < LD8; ++ld) {
                 const int f = ld * 64 + lane, row = f / CH8, c8 = f % CH8, n = q0 + row;
                 u32x4 v = {0u, 0u, 0u, 0u};
-                if (f < 32 * CH8 && it < tiles_per_wave && n < N) v = *reinterpret_cast<const u32x4*>(qb16 + (size_t)n * C + c8 * 8);
+                if (f < 32 * CH8 && it < tiles_per_wave && n < N) v = *reinterpret_cast<const u32x4*>(qb16 + (size_t)n * ldq16 + c8 * 8);
                 rq8[ld] = v;
             }
             return;
@@ -558,7 +564,7 @@ __global__ __launch_bounds__(256, 2) void unpool_attn_x3_kernel(const float* __r
 
 template <int HD, bool F16, bool IO16>
 int pool_x3_launch_t(const float* KV, const float* ind, float* po, float* pml, int B, int N, int C, int H, int nsplit,
-                     hipStream_t st) {
+                     hipStream_t st, int hm) {
     constexpr int KS = HD + 8, DT = (HD + 31) / 32, VT = 8 * DT * 128, NP = F16 ? 1 : 2;
     const size_t a = ((size_t)NP * 64 * KS + 4 * NP * (32 * KS + VT)) * 2, c = ((size_t)4 * HD * 64 + 512) * 4;
     const size_t lds = a > c ? a : c;
@@ -569,12 +575,12 @@ int pool_x3_launch_t(const float* KV, const float* ind, float* po, float* pml, i
         attr_set = true;
     }
     hipLaunchKernelGGL((pool_attn_x3_kernel<HD, F16, IO16>), dim3(B * H * nsplit), dim3(256), lds, st, KV, ind, po, pml, B, N, C,
-                       H, nsplit);
+                       H, nsplit, hm);
     return (int)hipGetLastError();
 }
 
 template <int HD, bool F16, bool IO16>
-int unpool_x3_launch_t(const float* q, const float* kvh, float* out, int B, int N, int C, int H, hipStream_t st) {
+int unpool_x3_launch_t(const float* q, const float* kvh, float* out, int B, int N, int C, int H, hipStream_t st, int hm) {
     constexpr int KS = HD + 8, VS = 72, DT = (HD + 31) / 32, NP = F16 ? 1 : 2, OP = HD + 4;
     constexpr int QW = 32 * OP * 2 > NP * 32 * KS ? 32 * OP * 2 : NP * 32 * KS;
     const size_t lds = ((size_t)NP * 64 * KS + NP * DT * 32 * VS + 4 * QW) * 2;
@@ -589,7 +595,7 @@ int unpool_x3_launch_t(const float* q, const float* kvh, float* out, int B, int 
         attr_set = true;
     }
     hipLaunchKernelGGL((unpool_attn_x3_kernel<HD, F16, IO16>), dim3(B * H * nchunk), dim3(256), lds, st, q, kvh, out, B, N, C, H,
-                       tpw, nchunk);
+                       tpw, nchunk, hm);
     return (int)hipGetLastError();
 }
 
@@ -598,13 +604,14 @@ int unpool_x3_launch_t(const float* q, const float* kvh, float* out, int B, int 
 bool attn_x3_supported(int HD) { return HD == 16 || HD == 32 || HD == 48 || HD == 64; }
 
 int pool_attn_x3_partials_launch(const float* KV, const float* inducers, float* part_o, float* part_ml, int B, int N,
-                                 int C, int H, int nsplit, hipStream_t st, int precision, int io16) {
+                                 int C, int H, int nsplit, hipStream_t st, int precision, int io16, int hm) {
     if (io16 && precision != 2) return -9;
+    if (hm && !io16) return -9;
 #define POOL_CASE(HD)                                                                                                    \
     case HD:                                                                                                             \
-        return io16 ? pool_x3_launch_t<HD, true, true>(KV, inducers, part_o, part_ml, B, N, C, H, nsplit, st)            \
-               : precision == 2 ? pool_x3_launch_t<HD, true, false>(KV, inducers, part_o, part_ml, B, N, C, H, nsplit, st) \
-                                : pool_x3_launch_t<HD, false, false>(KV, inducers, part_o, part_ml, B, N, C, H, nsplit, st)
+        return io16 ? pool_x3_launch_t<HD, true, true>(KV, inducers, part_o, part_ml, B, N, C, H, nsplit, st, hm)            \
+               : precision == 2 ? pool_x3_launch_t<HD, true, false>(KV, inducers, part_o, part_ml, B, N, C, H, nsplit, st, 0) \
+                                : pool_x3_launch_t<HD, false, false>(KV, inducers, part_o, part_ml, B, N, C, H, nsplit, st, 0)
     switch (C / H) {
         POOL_CASE(16);
         POOL_CASE(32);
@@ -616,13 +623,14 @@ int pool_attn_x3_partials_launch(const float* KV, const float* inducers, float* 
 }
 
 int unpool_attn_x3_launch(const float* q, const float* kvh, float* out, int B, int N, int C, int H, hipStream_t st,
-                          int precision, int io16) {
+                          int precision, int io16, int hm) {
     if (io16 && precision != 2) return -9;
+    if (hm && !io16) return -9;
 #define UNPOOL_CASE(HD)                                                                                \
     case HD:                                                                                           \
-        return io16 ? unpool_x3_launch_t<HD, true, true>(q, kvh, out, B, N, C, H, st)                  \
-               : precision == 2 ? unpool_x3_launch_t<HD, true, false>(q, kvh, out, B, N, C, H, st)     \
-                                : unpool_x3_launch_t<HD, false, false>(q, kvh, out, B, N, C, H, st)
+        return io16 ? unpool_x3_launch_t<HD, true, true>(q, kvh, out, B, N, C, H, st, hm)              \
+               : precision == 2 ? unpool_x3_launch_t<HD, true, false>(q, kvh, out, B, N, C, H, st, 0)  \
+                                : unpool_x3_launch_t<HD, false, false>(q, kvh, out, B, N, C, H, st, 0)
     switch (C / H) {
         UNPOOL_CASE(16);
         UNPOOL_CASE(32);

@@ -205,6 +205,7 @@ __global__ __launch_bounds__(S_NT, 2) void gemm_f16_astat_kernel(GemmArgs g) {
     // R+1 of columns n-1, n — four bytes of one output row each.
     const bool odd = lane & 1;
     const unsigned psel = odd ? 0x03020706u : 0x05040100u;   // v_perm_b32 over {neighbour, own}
+    const unsigned hm_magic = g.hm_hd ? (1u << 20) / (unsigned)g.hm_hd + 1u : 0u;
     auto epilogue = [&](int ct) {
         const int n0 = ct * 128;
         const bool seg2 = g.C2 != nullptr && n0 >= g.n_split;
@@ -212,9 +213,19 @@ __global__ __launch_bounds__(S_NT, 2) void gemm_f16_astat_kernel(GemmArgs g) {
         const int ldc = seg2 ? g.ldc2 : g.ldc;
         const int nseg0 = seg2 ? n0 - g.n_split : n0;
         _Float16* lanebase = Cb + ((size_t)b * g.rows + m0 + wave * 32 + 4 * h + (odd ? 1 : 0)) * ldc + nseg0 + (r & ~1);
+        // head-major output: row stride = head dim; the (sample, head) slab of this lane's column pair, per j
+        const int rstride = g.hm_hd ? g.hm_hd : ldc;
+        const int nseg = seg2 ? g.Nout - g.n_split : (g.C2 ? g.n_split : g.Nout);
+        const int hm_row = m0 + wave * 32 + 4 * h + (odd ? 1 : 0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float bias = bias_lds[n0 + j * 32 + r];
+            _Float16* jbase = lanebase + j * 32;
+            if (g.hm_hd) {
+                const int n = nseg0 + j * 32 + (r & ~1);
+                const int grp = (int)(((unsigned)n * hm_magic) >> 20);   // n / hd (exact: n < 2^20 / hd)
+                jbase = Cb + ((size_t)(b * (nseg / g.hm_hd) + grp) * g.rows + hm_row) * g.hm_hd + (n - grp * g.hm_hd);
+            }
 #pragma unroll
             for (int e0 = 0; e0 < 16; e0 += 2) {
                 float v0 = acc[j][e0] + bias, v1 = acc[j][e0 + 1] + bias;
@@ -232,7 +243,7 @@ __global__ __launch_bounds__(S_NT, 2) void gemm_f16_astat_kernel(GemmArgs g) {
                 constexpr int dummy = 0;
                 (void)dummy;
                 const int rowoff = (e0 & 3) + 8 * (e0 >> 2);   // + 4h + odd in lanebase
-                *reinterpret_cast<unsigned*>(lanebase + (size_t)rowoff * ldc + j * 32) = out;
+                *reinterpret_cast<unsigned*>(jbase + (size_t)rowoff * rstride) = out;
             }
         }
     };
@@ -298,7 +309,9 @@ bool gemm_f16_astat_supported(const GemmArgs& g) {
     return g.c_f16 && !g.a_f16 && !g.residual && !g.stats && g.w_img && g.rows >= 128 && !(g.rows % 128) &&
            !(g.Nout % 128) && !(g.K % SBK) && (nk == 4 || nk == 8 || nk == 12 || nk == 16) && !(g.lda & 3) && !(g.ldc & 1) &&
            (!g.C2 || (!(g.n_split % 128) && !(g.ldc2 & 1) && g.n_split > 0 && g.n_split < g.Nout)) &&
-           ((g.pro_a == nullptr) == (g.pro_o == nullptr));
+           ((g.pro_a == nullptr) == (g.pro_o == nullptr)) &&
+           (!g.hm_hd || (g.hm_hd >= 8 && !(g.hm_hd & 1) && g.Nout < (1 << 20) / g.hm_hd &&
+                         !((g.C2 ? g.n_split : g.Nout) % g.hm_hd) && !((g.C2 ? g.Nout - g.n_split : 0) % g.hm_hd)));
 }
 
 int gemm_f16_astat_launch(const GemmArgs& g, hipStream_t st) {

@@ -27,6 +27,10 @@ struct GemmArgs {
     // fp16 kernel only: A is an fp16 tensor (lda in fp16 elements; no prologue) / C (and C2) are stored as fp16
     // (ldc, ldc2 in fp16 elements; no residual, no stats).  Pointers are passed through the float* fields.
     int a_f16, c_f16;
+    // A-stationary fp16 kernel only: head-major output.  hm_hd = head dim (0: row-major).  Column n of a segment with
+    // nseg columns goes to element ((b * nseg / hd + n / hd) * rows + row) * hd + n % hd: one contiguous (rows, hd)
+    // slab per (sample, head) — what the attention kernels stream — instead of hd-wide pieces of (rows, nseg) rows.
+    int hm_hd;
 };
 
 struct SplitJob { const float* W; float* img; int Nout, K, ldw, pad_; };
@@ -111,16 +115,17 @@ int lower_bwd_launch(const float* feat, const float* dF, const float* W, float* 
 // attention_f32.hip
 // precision 1 = split-bf16, 2 = fp16 arithmetic (attention_x3.hip) when the head dim allows, else the exact fp32 kernels
 int pool_attn_launch(const float* KV, const float* inducers, float* part_o, float* part_ml, float* merged,
-                     int B, int N, int C, int H, int I, int nsplit, hipStream_t st, int precision = 0, int io16 = 0);
+                     int B, int N, int C, int H, int I, int nsplit, hipStream_t st, int precision = 0, int io16 = 0,
+                     int hm = 0);   // hm (with io16): K | V / q are head-major (GemmArgs::hm_hd)
 int pool_attn_nsplit(int B, int N, int H);
 int unpool_attn_launch(const float* q, const float* kvh, float* out, int B, int N, int C, int H, int I,
-                       hipStream_t st, int precision = 0, int io16 = 0);
+                       hipStream_t st, int precision = 0, int io16 = 0, int hm = 0);
 // attention_x3.hip
 bool attn_x3_supported(int HD);
 int pool_attn_x3_partials_launch(const float* KV, const float* inducers, float* part_o, float* part_ml, int B, int N,
-                                 int C, int H, int nsplit, hipStream_t st, int precision, int io16 = 0);   // 1 split-bf16, 2 fp16
+                                 int C, int H, int nsplit, hipStream_t st, int precision, int io16 = 0, int hm = 0);   // 1 split-bf16, 2 fp16
 int unpool_attn_x3_launch(const float* q, const float* kvh, float* out, int B, int N, int C, int H, hipStream_t st,
-                          int precision, int io16 = 0);   // io16: KV / q / out are fp16 tensors (fp16 mode)
+                          int precision, int io16 = 0, int hm = 0);   // io16: KV / q / out are fp16 tensors (fp16 mode)
 
 // lookup.hip
 struct LookupArgs {

@@ -181,8 +181,9 @@ def linear_pair_f16io(A16: Tensor, W1: Tensor, b1: Tensor | None, W2: Tensor, b2
 
 def linear_astat_f16(x: Tensor, pro: tuple[Tensor, Tensor] | None, W1: Tensor, b1: Tensor | None, W2: Tensor | None = None,
                      b2: Tensor | None = None, act_alpha: Tensor | None = None, normalized: bool = True,
-                     out: tuple[Tensor, Tensor | None] | None = None):
-    """fp16(act(fp16(x*pa + po) @ W^T + b)) for W = W1 (| W2), fp16 outputs, one pass over x (fp16 mode)."""
+                     out: tuple[Tensor, Tensor | None] | None = None, head_dim: int = 0):
+    """fp16(act(fp16(x*pa + po) @ W^T + b)) for W = W1 (| W2), fp16 outputs, one pass over x (fp16 mode).
+    head_dim > 0: head-major outputs (B, Nout / head_dim, rows, head_dim) — "b n (g d) -> b g n d"."""
     lib = _lib.load()
     B, rows, K = x.shape
     n1 = W1.shape[0]
@@ -190,13 +191,14 @@ def linear_astat_f16(x: Tensor, pro: tuple[Tensor, Tensor] | None, W1: Tensor, b
     if out is not None:
         c1, c2 = out
     else:
-        c1 = torch.empty(B, rows, n1, device=x.device, dtype=torch.float16)
-        c2 = torch.empty(B, rows, n2, device=x.device, dtype=torch.float16) if n2 else None
+        shape = lambda n: (B, n // head_dim, rows, head_dim) if head_dim else (B, rows, n)
+        c1 = torch.empty(*shape(n1), device=x.device, dtype=torch.float16)
+        c2 = torch.empty(*shape(n2), device=x.device, dtype=torch.float16) if n2 else None
     wsplit = _ws(((n1 + 127) // 128 + (n2 + 127) // 128) * 128 * K * 4, x.device)
     act = 0 if act_alpha is None else (1 if normalized else 2)
     check(lib.gecco_linear_astat_f16(_ptr(x), _ptr(pro[0]) if pro else None, _ptr(pro[1]) if pro else None, _ptr(W1), _ptr(b1),
                                      n1, _ptr16(c1), _ptr(W2), _ptr(b2), n2, _ptr16(c2) if c2 is not None else None,
-                                     _ptr(act_alpha), act, B, rows, K, C.c_void_p(wsplit.data_ptr()), _stream()),
+                                     _ptr(act_alpha), act, B, rows, K, head_dim, C.c_void_p(wsplit.data_ptr()), _stream()),
           "gecco_linear_astat_f16")
     return (c1, c2) if c2 is not None else c1
 
@@ -210,25 +212,35 @@ def affine_cast_f16(x: Tensor, a: Tensor, o: Tensor, out: Tensor | None = None) 
     return out
 
 
-def pool_attn_f16in(KV16: Tensor, inducers: Tensor, H: int) -> Tensor:
+def pool_attn_f16in(KV16: Tensor, inducers: Tensor, H: int, head_major: bool = False) -> Tensor:
+    """KV16: (B, N, 2C) fp16, or head-major (B, 2H, N, hd) = K heads then V heads."""
     lib = _lib.load()
-    B, N, C2 = KV16.shape
-    Cc = C2 // 2
+    if head_major:
+        B, _, N, hd = KV16.shape
+        Cc = H * hd
+    else:
+        B, N, C2 = KV16.shape
+        Cc = C2 // 2
     I = inducers.shape[-2]
     merged = torch.empty(B, I, Cc, device=KV16.device, dtype=torch.float32)
     nb = lib.gecco_pool_attn_workspace_bytes(B, N, Cc, H, I)
     ws = _ws(nb, KV16.device)
-    check(lib.gecco_pool_attn_f16in(_ptr16(KV16), _ptr(inducers), _ptr(merged), B, N, Cc, H, I, C.c_void_p(ws.data_ptr()), nb,
-                                    _stream()), "gecco_pool_attn_f16in")
+    check(lib.gecco_pool_attn_f16in(_ptr16(KV16), _ptr(inducers), _ptr(merged), B, N, Cc, H, I, int(head_major),
+                                    C.c_void_p(ws.data_ptr()), nb, _stream()), "gecco_pool_attn_f16in")
     return merged
 
 
-def unpool_attn_f16io(q16: Tensor, kvh: Tensor, H: int, out: Tensor | None = None) -> Tensor:
+def unpool_attn_f16io(q16: Tensor, kvh: Tensor, H: int, out: Tensor | None = None, head_major: bool = False) -> Tensor:
+    """q16: (B, N, C) fp16, or head-major (B, H, N, hd); out is (B, N, C) fp16 either way."""
     lib = _lib.load()
-    B, N, Cc = q16.shape
-    out = torch.empty_like(q16) if out is None else out
-    check(lib.gecco_unpool_attn_f16io(_ptr16(q16), _ptr(kvh), _ptr16(out), B, N, Cc, H, kvh.shape[1], _stream()),
-          "gecco_unpool_attn_f16io")
+    if head_major:
+        B, _, N, hd = q16.shape
+        Cc = H * hd
+    else:
+        B, N, Cc = q16.shape
+    out = torch.empty(B, N, Cc, device=q16.device, dtype=torch.float16) if out is None else out
+    check(lib.gecco_unpool_attn_f16io(_ptr16(q16), _ptr(kvh), _ptr16(out), B, N, Cc, H, kvh.shape[1], int(head_major),
+                                      _stream()), "gecco_unpool_attn_f16io")
     return out
 
 

@@ -80,8 +80,10 @@ int gecco_linear_f32(const float* A, const float* W, const float* bias, const fl
                      int Nout, int act, void* stream);
 /* Path switches for A/B measurements and tests (the results agree to rounding):
  *   "astat" (default 1): fp16 mode runs AdaGN + kv|q and AdaGN + mlp.0 as one A-stationary pass over x;
- *   "chain" (default 1): fp16 mode runs the 64-inducer chain of a layer (pool merge .. unpool k|v) as one launch.
- * value < 0 returns the option to its default / environment (GECCO_ASTAT, GECCO_CHAIN).  Process-wide. */
+ *   "chain" (default 1): fp16 mode runs the 64-inducer chain of a layer (pool merge .. unpool k|v) as one launch;
+ *   "headmajor" (default 1): fp16 mode stores K | V and q head-major (needs "astat").
+ * value < 0 returns the option to its default / environment (GECCO_ASTAT, GECCO_CHAIN, GECCO_HEADMAJOR).
+ * Process-wide. */
 int gecco_set_option(const char* name, int value);
 
 int gecco_linear_row_tiles(int rows);
@@ -132,19 +134,27 @@ int gecco_linear_pair_f16io(const void* A, const float* W1, const float* bias1, 
  * all output columns in one pass over x (the block keeps fp16(x*pro_a + pro_o) of its 128 rows in registers and walks
  * every 128-column tile of W1 | W2).  C1 (B, rows, Nout1) and C2 (B, rows, Nout2; W2/bias2/C2 may be NULL) are fp16;
  * act as in gecco_linear_f32.  Bit-identical to gecco_affine_cast_f16 + gecco_linear(_pair)_f16io.
- * rows % 128 == 0, Nout1 % 128 == 0, Nout2 % 128 == 0, K in {128, 256, 384, 512}; wsplit as for the pair. */
+ * rows % 128 == 0, Nout1 % 128 == 0, Nout2 % 128 == 0, K in {128, 256, 384, 512}; wsplit as for the pair.
+ * head_dim > 0: head-major outputs — C1 is (B, Nout1 / head_dim, rows, head_dim) and C2 (B, Nout2 / head_dim, rows,
+ * head_dim), i.e. "b n (g d) -> b g n d" applied to the row-major result: for kv_proj | q_proj that is one contiguous
+ * (rows, head_dim) slab per (sample, K or V, head), the unit a pool / unpool attention block streams (the einops
+ * rearranges of models/set_transformer.py:51-52,70 done by the store addressing).  head_dim even, >= 8, dividing
+ * Nout1 and Nout2.  0: row-major. */
 int gecco_linear_astat_f16(const float* x, const float* pro_a, const float* pro_o, const float* W1, const float* bias1,
                            int Nout1, void* C1, const float* W2, const float* bias2, int Nout2, void* C2,
-                           const float* alpha, int act, int B, int rows, int K, void* wsplit, void* stream);
+                           const float* alpha, int act, int B, int rows, int K, int head_dim, void* wsplit,
+                           void* stream);
 /* y16[b, m, c] = fp16(a[b, c] * x[b, m, c] + o[b, c]) — the AdaGN apply (models/normalization.py:44) rounded once,
  * exactly the operand the fp16 GEMM's prologue would form.  C % 8 == 0. */
 int gecco_affine_cast_f16(const float* x, const float* a, const float* o, void* y16, int B, int rows, int C,
                           void* stream);
-/* gecco_pool_attn_ex_f32 (precision 2) reading an fp16 KV; gecco_unpool_attn_ex_f32 (precision 2) with fp16 q / out. */
+/* gecco_pool_attn_ex_f32 (precision 2) reading an fp16 KV; gecco_unpool_attn_ex_f32 (precision 2) with fp16 q / out.
+ * head_major != 0: KV16 is (B, 2H, N, hd) = K heads then V heads, q16 is (B, H, N, hd) (gecco_linear_astat_f16 with
+ * head_dim = hd); out16 stays (B, N, C).  Same bits either way. */
 int gecco_pool_attn_f16in(const void* KV16, const float* inducers, float* merged, int B, int N, int C, int H, int I,
-                          void* ws, size_t ws_bytes, void* stream);
+                          int head_major, void* ws, size_t ws_bytes, void* stream);
 int gecco_unpool_attn_f16io(const void* q16, const float* kvh, void* out16, int B, int N, int C, int H, int I,
-                            void* stream);
+                            int head_major, void* stream);
 
 /* AttentionPool core (models/set_transformer.py:47-63, without out_proj): KV (B, N, 2C) -> merged (B, I, C). */
 int gecco_pool_attn_f32(const float* KV, const float* inducers, float* merged, int B, int N, int C, int H, int I,

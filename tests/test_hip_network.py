@@ -183,6 +183,21 @@ def test_fp16_inducer_chain_matches_standalone_kernels(ops, golden_dir, name):
     assert e_ab[0] <= 1e-3, e_ab
 
 
+@pytest.mark.parametrize("name", list(cases.UNCOND_CASES))
+def test_fp16_head_major_is_bit_identical(ops, golden_dir, name):
+    """K | V and q stored head-major (the default) against row-major: a layout, not an arithmetic — same bits."""
+    p, x, sigma = cases.uncond_inputs(name)
+    net = ops.LinearLiftPlan(_cuda(p), cases.H, cases.I, precision="fp16")
+    out = {}
+    try:
+        for hm in (0, 1):
+            ops.set_option("headmajor", hm)
+            out[hm] = net.forward(x.cuda(), sigma.cuda()).cpu()
+    finally:
+        ops.set_option("headmajor", -1)
+    assert torch.equal(out[0], out[1])
+
+
 def test_split_bf16_linear_accuracy(ops):
     """The split itself: products with operands spanning 8 orders of magnitude keep ~2^-16 relative accuracy."""
     import ctypes as C

@@ -186,6 +186,27 @@ def test_linear_astat_matches_two_launch_form(ops, B, N, Cc):
     assert torch.equal(h, h_ref)
 
 
+@pytest.mark.parametrize("B,N,Cc,H", [(2, 256, 128, 8), (3, 384, 384, 8), (2, 128, 256, 4)])
+def test_head_major_layout_is_a_pure_permutation(ops, B, N, Cc, H):
+    """head_dim > 0: the A-stationary kernel stores "b n (g d) -> b g n d" of the row-major result (same bits), and
+    the pool / unpool attention kernels give the same bits reading that layout (ragged N included: N = 384 has a last
+    key tile the split does not fill)."""
+    rs = _rs(N + Cc + H)
+    hd = Cc // H
+    x = _t(rs.randn(B, N, Cc) * 2).cuda()
+    a, o = _t(1 + 0.3 * rs.randn(B, Cc)).cuda(), _t(0.3 * rs.randn(B, Cc)).cuda()
+    Wkv, Wq, bq = _t(rs.randn(2 * Cc, Cc) / 11).cuda(), _t(rs.randn(Cc, Cc) / 11).cuda(), _t(rs.randn(Cc) * .1).cuda()
+    kv, q = ops.linear_astat_f16(x, (a, o), Wkv, None, Wq, bq)
+    kv_hm, q_hm = ops.linear_astat_f16(x, (a, o), Wkv, None, Wq, bq, head_dim=hd)
+    assert kv_hm.shape == (B, 2 * H, N, hd) and q_hm.shape == (B, H, N, hd)
+    assert torch.equal(kv_hm, kv.view(B, N, 2 * H, hd).permute(0, 2, 1, 3))
+    assert torch.equal(q_hm, q.view(B, N, H, hd).permute(0, 2, 1, 3))
+    ind = _t(rs.randn(1, H, 64, hd)).cuda()
+    assert torch.equal(ops.pool_attn_f16in(kv_hm, ind, H, head_major=True), ops.pool_attn_f16in(kv, ind, H))
+    kvh = _t(rs.randn(B, 64, 2 * Cc)).cuda()
+    assert torch.equal(ops.unpool_attn_f16io(q_hm, kvh, H, head_major=True), ops.unpool_attn_f16io(q, kvh, H))
+
+
 def test_adagn_large_mean(ops):
     """E[x^2]-mean^2 cancellation: mean 50x the std must still be accurate (fp64 combine)."""
     rs = _rs(5)

@@ -122,11 +122,13 @@ def gemm_call_sites(ops, dev, precision="fp32"):
     if precision == "fp16":
         # fp16 mode: AdaGN(x), K|V, q, the attention output and the MLP hidden layer are fp16 TENSORS
         att16, big16 = rn(B, N, D).half(), rn(B, N, 2 * D).half()
-        kv16, q16 = torch.empty(B, N, 2 * D, device=dev, dtype=torch.float16), torch.empty(B, N, D, device=dev, dtype=torch.float16)
+        # K | V and q head-major, as the network stores them: (B, 2H, N, hd) and (B, H, N, hd)
+        kv16 = torch.empty(B, 2 * H, N, D // H, device=dev, dtype=torch.float16)
+        q16 = torch.empty(B, H, N, D // H, device=dev, dtype=torch.float16)
         h16 = torch.empty(B, N, 2 * D, device=dev, dtype=torch.float16)
         H2 = S // 2   # bytes of one (B, N, d) fp16 stream
         return [
-            ("norm+kv_proj|q_proj", 2 * B * N * D * 3 * D, S + 3 * H2, lambda: ops.linear_astat_f16(x, (pa, po), Wkv, None, Wq, bq, out=(kv16, q16))),
+            ("norm+kv_proj|q_proj", 2 * B * N * D * 3 * D, S + 3 * H2, lambda: ops.linear_astat_f16(x, (pa, po), Wkv, None, Wq, bq, out=(kv16, q16), head_dim=D // H)),
             ("out_proj+res+stats", 2 * B * N * D * D, H2 + 2 * S, lambda: ops.linear_f16io(att16, Wo, bq, residual=res, want_stats=True, out=o384)),
             ("norm+mlp.0+act", 2 * B * N * D * 2 * D, S + 2 * H2, lambda: ops.linear_astat_f16(x, (pa, po), W1, b1, act_alpha=alpha, out=(h16, None))),
             ("mlp.2+res+stats", 2 * B * N * 2 * D * D, 2 * H2 + 2 * S, lambda: ops.linear_f16io(big16, W2, b2, residual=res, want_stats=True, out=o384)),

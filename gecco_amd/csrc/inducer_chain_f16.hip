@@ -188,7 +188,8 @@ __global__ __launch_bounds__(CH_NT, 1) void inducer_chain_f16_kernel(ChainArgs g
     // the A buffer.  Batches of items per thread: all of a batch's loads are independent.
     auto merge = [&](auto nsp_tag) {
         constexpr int NSP = decltype(nsp_tag)::value;
-        constexpr int ITEMS = 64 * (C / 4) / CH_NT, BATCH = NSP <= 4 ? 4 : 2;
+        // all of a thread's items in one round trip while the partials fit the register file (6 NSP registers per item)
+        constexpr int ITEMS = 64 * (C / 4) / CH_NT, BATCH = ITEMS * NSP <= 24 ? ITEMS : (NSP <= 4 ? 4 : 2);
         static_assert(64 * (C / 4) % CH_NT == 0 && ITEMS % BATCH == 0, "items per thread");
         const int HD = C / g.H;
         // c / HD for c < 512, HD >= 4 by multiply-shift: exact, the fractional part of c / HD is a multiple of 1 / HD

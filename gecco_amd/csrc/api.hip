@@ -353,6 +353,19 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         if (!kvh_done)
             TRY(linear(h, L.in_proj_w + (size_t)C * C, L.in_proj_b + C, nullptr, nullptr, nullptr, nullptr, w.kvh, nullptr,
                        B, I, C, 2 * C, 0, s, pr, w.wsplit, im ? im + w.o_ukv : nullptr), "unpool.in_proj(kv)");
+        if (!q_done && io16 && h_in && h_in[li]) {
+            // cached inducer states (upsampling): the layer only needs q — the same one-pass kernel, one segment
+            const int hd_try = option(OPT_HEADMAJOR) ? C / H : 0;
+            int one = astat_linear(x, w.a1, w.o1, im ? im + w.o_q : nullptr, L.in_proj_b, C, w.q, nullptr, 0, nullptr,
+                                   nullptr, 0, B, N, C, s, hd_try);
+            if (one == 1 && hd_try)
+                one = astat_linear(x, w.a1, w.o1, im ? im + w.o_q : nullptr, L.in_proj_b, C, w.q, nullptr, 0, nullptr, nullptr,
+                                   0, B, N, C, s, 0);
+            else if (one == 0 && hd_try)
+                hm = 1;
+            if (one < 0) TRY(one, "unpool.in_proj(q) (A-stationary)");
+            q_done = one == 0;
+        }
         if (!q_done) {
             if (io16 && h_in && h_in[li]) TRY(affine_cast_f16_launch(x, w.a1, w.o1, w.attn, B, N, C, s), "broadcast_norm -> fp16");
             TRY(linear(io16 ? w.attn : x, L.in_proj_w, L.in_proj_b, io16 ? nullptr : w.a1, io16 ? nullptr : w.o1, nullptr,

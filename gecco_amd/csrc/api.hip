@@ -56,6 +56,7 @@ struct STWorkspace {
     float* wimg;                       // images of every layer's N-token weights, built once per forward
     size_t wimg_layer, o_q, o_out, o_w0, o_w2;   // floats per layer and the per-weight offsets inside (kv at 0)
     size_t o_pout, o_b0, o_b2, o_ukv;            // the 64-inducer chain: pool.out_proj, broadcast mlp, unpool k|v
+    size_t o_mf;                                 // fused point MLP: W0 tile j | W2 K-slice j (two halves), j = 0 .. width/128
     size_t bytes;
 };
 
@@ -103,7 +104,8 @@ STWorkspace carve_st(const GeccoSetTransformer* st, int B, int N, void* base) {
         w.o_b0 = w.o_pout + pad(C) * C;
         w.o_b2 = w.o_b0 + pad(W) * C;
         w.o_ukv = w.o_b2 + pad(C) * W;
-        w.wimg_layer = w.o_ukv + pad(2 * C) * C;
+        w.o_mf = w.o_ukv + pad(2 * C) * C;
+        w.wimg_layer = w.o_mf + (st->precision == 2 ? pad(W) * C + pad(C) * W : 0);
         w.wimg = st->precision >= 1 ? c.f32(w.wimg_layer * st->n_layers) : nullptr;
     }
     w.bytes = (c.off + 255) & ~size_t(255);
@@ -173,10 +175,10 @@ int linear_pair(const float* A, const float* W1, const float* b1, int Nout1, flo
 }
 
 // Path switches for A/B runs and tests: gecco_set_option, or the environment (GECCO_ASTAT, GECCO_CHAIN) on first use.
-enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_HEADMAJOR = 2, OPT_COUNT = 3 };
-int g_options[OPT_COUNT] = {-1, -1, -1};
-const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor"};
-const char* const g_option_env[OPT_COUNT] = {"GECCO_ASTAT", "GECCO_CHAIN", "GECCO_HEADMAJOR"};
+enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_HEADMAJOR = 2, OPT_MLPFUSED = 3, OPT_COUNT = 4 };
+int g_options[OPT_COUNT] = {-1, -1, -1, -1};
+const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor", "mlpfused"};
+const char* const g_option_env[OPT_COUNT] = {"GECCO_ASTAT", "GECCO_CHAIN", "GECCO_HEADMAJOR", "GECCO_MLPFUSED"};
 int option(int which) {
     if (g_options[which] < 0) {
         const char* e = getenv(g_option_env[which]);
@@ -228,6 +230,8 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
     }
     const int kmod = pr == 2 ? 32 : 16;   // K granularity of the fast kernels
     // fp16 mode: everything on the 64 inducers between the two attentions is one launch (inducer_chain_f16.hip)
+    // fp16 mode: the point-stream MLP of a layer (AdaGN, mlp.0, activation, mlp.2, residual, statistics) is one launch
+    const bool mlpf_on = pr == 2 && w.wimg && option(OPT_MLPFUSED) && mlp_fused_f16_supported(C, Wd, N);
     const bool chain_on = pr == 2 && w.wimg && option(OPT_CHAIN) && inducer_chain_f16_supported(C, Wd, H, G, I) &&
                           (ns == 1 || ns == 2 || ns == 4 || ns == 8);
     if (pr >= 1 && w.wimg && !(C % kmod) && !(Wd % kmod)) {
@@ -237,7 +241,7 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         jobs.n = 0;
         auto push = [&](const float* Wp, float* img, int Nout, int K) -> int {
             jobs.job[jobs.n++] = SplitJob{Wp, img, Nout, K, K, 0};
-            if (jobs.n == 32) {
+            if (jobs.n == 96) {
                 int rc = pr == 2 ? split_f16_tiled_multi_launch(jobs, s) : split_bf16_tiled_multi_launch(jobs, s);
                 jobs.n = 0;
                 return rc;
@@ -254,7 +258,7 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
                 if (chain_on) {   // the one-launch chain walks mlp.2 K-half by K-half: one (C x C) image per half
                     for (int hf = 0; hf < Wd / C; ++hf) {
                         jobs.job[jobs.n] = SplitJob{L.bmlp.w2 + (size_t)hf * C, base + w.o_b2 + (size_t)hf * C * C / 2, C, C, Wd, 0};
-                        if (++jobs.n == 32) {
+                        if (++jobs.n == 96) {
                             TRY(split_f16_tiled_multi_launch(jobs, s), "split(weights)");
                             jobs.n = 0;
                         }
@@ -266,8 +270,23 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
             TRY(push(L.in_proj_w + (size_t)C * C, base + w.o_ukv, 2 * C, C), "split(unpool.in_proj kv)");
             TRY(push(L.in_proj_w, base + w.o_q, C, C), "split(q_proj)");
             TRY(push(L.unpool_out_w, base + w.o_out, C, C), "split(out_proj)");
-            TRY(push(L.mlp.w0, base + w.o_w0, Wd, C), "split(mlp.0)");
-            TRY(push(L.mlp.w2, base + w.o_w2, C, Wd), "split(mlp.2)");
+            if (mlpf_on) {   // one stream in consumption order: per hidden chunk j, W0 tile j, then W2[:, chunk j] in two K-halves
+                const int nkb = C / 32;
+                for (int jc = 0; jc < Wd / 128; ++jc) {
+                    float* cb = base + w.o_mf + (size_t)jc * 2 * nkb * 2048;
+                    jobs.job[jobs.n++] = SplitJob{L.mlp.w0 + (size_t)jc * 128 * C, cb, 128, C, C, 0};
+                    for (int hf = 0; hf < 2; ++hf)
+                        jobs.job[jobs.n++] = SplitJob{L.mlp.w2 + (size_t)jc * 128 + hf * 64,
+                                                      cb + (size_t)(nkb + hf * (nkb / 2)) * 2048, C, 64, Wd, 0};
+                    if (jobs.n + 3 > 96) {
+                        TRY(split_f16_tiled_multi_launch(jobs, s), "split(weights)");
+                        jobs.n = 0;
+                    }
+                }
+            } else {
+                TRY(push(L.mlp.w0, base + w.o_w0, Wd, C), "split(mlp.0)");
+                TRY(push(L.mlp.w2, base + w.o_w2, C, Wd), "split(mlp.2)");
+            }
         }
         TRY(pr == 2 ? split_f16_tiled_multi_launch(jobs, s) : split_bf16_tiled_multi_launch(jobs, s), "split(weights)");
     }
@@ -377,6 +396,17 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
                    w.wsplit, im ? im + w.o_out : nullptr, io16, 0), "unpool.out_proj+residual");
         // x += mlp(AdaGN(x))
         TRY(coeffs(w.stats_x, Tn, N, t, ctx, &L.mlp_norm, w.a2, w.o2, B, C, G, s), "adagn_coeffs(mlp_norm)");
+        float* so = (li + 1 < st->n_layers) ? w.stats_x : stats_out;
+        if (mlpf_on && im) {
+            MlpArgs ma{};
+            ma.x = x; ma.pro_a = w.a2; ma.pro_o = w.o2; ma.w_stream = im + w.o_mf;
+            ma.b0 = L.mlp.b0; ma.b2 = L.mlp.b2; ma.alpha = L.mlp.alpha; ma.act = act; ma.stats = so; ma.B = B; ma.rows = N;
+            if (act && !L.mlp.alpha) return fail(-6, "mlp: activation needs alpha");
+            TRY(mlp_fused_f16_launch(ma, C, Wd, s), "mlp (fused)");
+            sx = w.stats_x;
+            sT = Tn;
+            continue;
+        }
         int m0_done = io16 ? astat_linear(x, w.a2, w.o2, im ? im + w.o_w0 : nullptr, L.mlp.b0, Wd, w.big, nullptr, 0,
                                           nullptr, L.mlp.alpha, act, B, N, C, s)
                            : 1;
@@ -386,7 +416,6 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         TRY(linear(io16 ? w.attn : x, L.mlp.w0, L.mlp.b0, io16 ? nullptr : w.a2, io16 ? nullptr : w.o2, L.mlp.alpha, nullptr,
                    w.big, nullptr, B, N, C, Wd, act, s, pr, w.wsplit, im ? im + w.o_w0 : nullptr, io16, io16), "mlp.0");
         }
-        float* so = (li + 1 < st->n_layers) ? w.stats_x : stats_out;
         TRY(linear(w.big, L.mlp.w2, L.mlp.b2, nullptr, nullptr, nullptr, x, x, so, B, N, Wd, C, 0, s, pr, w.wsplit,
                    im ? im + w.o_w2 : nullptr, io16, 0), "mlp.2+residual");
         sx = w.stats_x;
@@ -429,7 +458,7 @@ int gecco_set_option(const char* name, int value) {
             g_options[i] = value < 0 ? -1 : (value != 0);   // < 0: back to the environment / default
             return 0;
         }
-    return fail(-2, "set_option: unknown option '%s' (astat, chain, headmajor)", name);
+    return fail(-2, "set_option: unknown option '%s' (astat, chain, headmajor, mlpfused)", name);
 }
 
 int gecco_linear_row_tiles(int rows) { return row_tiles_gemm(rows); }
@@ -521,6 +550,32 @@ int gecco_linear_astat_f16(const float* x, const float* pro_a, const float* pro_
         return fail(-2, "linear_astat: needs rows %% 128 == 0, Nout %% 128 == 0, K in {128, 256, 384, 512}; head-major: "
                         "even head_dim >= 8 dividing both segment widths");
     TRY(gemm_f16_astat_launch(g, s), "linear_astat");
+    return 0;
+}
+
+int gecco_mlp_fused_f16(float* x, const float* pro_a, const float* pro_o, const float* W0, const float* b0, const float* W2,
+                        const float* b2, const float* alpha, int act, float* stats, int B, int rows, int C, int width,
+                        void* wsplit, void* stream) {
+    if (!x || !pro_a || !pro_o || !W0 || !W2 || !wsplit) return fail(-1, "mlp_fused: null argument");
+    if (act && !alpha) return fail(-6, "mlp_fused: activation needs alpha");
+    if (!mlp_fused_f16_supported(C, width, rows))
+        return fail(-2, "mlp_fused: needs C in {128, 256, 384}, width == 2 C, rows %% 128 == 0");
+    hipStream_t s = (hipStream_t)stream;
+    float* img = static_cast<float*>(wsplit);
+    SplitJobs jobs;
+    jobs.n = 0;
+    const int nkb = C / 32;
+    for (int jc = 0; jc < width / 128; ++jc) {   // the stream order of mlp_fused_f16.hip
+        float* cb = img + (size_t)jc * 2 * nkb * 2048;
+        jobs.job[jobs.n++] = SplitJob{W0 + (size_t)jc * 128 * C, cb, 128, C, C, 0};
+        for (int hf = 0; hf < 2; ++hf)
+            jobs.job[jobs.n++] = SplitJob{W2 + (size_t)jc * 128 + hf * 64, cb + (size_t)(nkb + hf * (nkb / 2)) * 2048, C, 64, width, 0};
+    }
+    TRY(split_f16_tiled_multi_launch(jobs, s), "mlp_fused(split)");
+    MlpArgs ma{};
+    ma.x = x; ma.pro_a = pro_a; ma.pro_o = pro_o; ma.w_stream = img; ma.b0 = b0; ma.b2 = b2; ma.alpha = alpha; ma.act = act;
+    ma.stats = stats; ma.B = B; ma.rows = rows;
+    TRY(mlp_fused_f16_launch(ma, C, width, s), "mlp_fused");
     return 0;
 }
 

@@ -34,7 +34,7 @@ struct GemmArgs {
 };
 
 struct SplitJob { const float* W; float* img; int Nout, K, ldw, pad_; };
-struct SplitJobs { SplitJob job[32]; int n; };
+struct SplitJobs { SplitJob job[96]; int n; };   // 3 KiB of kernel arguments
 int gemm_row_tile(int rows);  // row-tile height the GEMM uses for `rows` rows per sample
 int gemm_f32_launch(const GemmArgs& g, hipStream_t st);
 // gemm_f32_dma.hip — LDS-DMA fast path of the same contract
@@ -71,6 +71,20 @@ struct ChainArgs {
 };
 bool inducer_chain_f16_supported(int C, int Wd, int H, int G, int I);
 int inducer_chain_f16_launch(const ChainArgs& g, int C, int Wd, hipStream_t st);
+
+// mlp_fused_f16.hip — fp16 mode: x += mlp.2(act(mlp.0(AdaGN(x)))) + GroupNorm partials in one launch (128 rows per block)
+struct MlpArgs {
+    float* x;                 // (B, rows, C) fp32, updated in place
+    const float *pro_a, *pro_o;   // (B, C) AdaGN coefficients of mlp_norm
+    const float* w_stream;    // per hidden chunk j of 128: fp16 image of W0 tile j | W2[:, chunk j] K-half 0 | K-half 1
+    const float *b0, *b2, *alpha;
+    int act;
+    float* stats;             // (B, rows / 128, 2, C) or null
+    int B, rows;
+    int stagger;              // cycles between the start offsets of the first blocks (see mlp_fused_f16.hip)
+};
+bool mlp_fused_f16_supported(int C, int Wd, int rows);
+int mlp_fused_f16_launch(const MlpArgs& g, int C, int Wd, hipStream_t st);
 
 // gemm_f16_astat.hip — fp16 mode, A-stationary: AdaGN apply + fp16 rounding + all column tiles in one pass over x
 // (fp32 A with optional prologue, fp16 outputs, one or two segments; K <= 384, full 128-tiles)

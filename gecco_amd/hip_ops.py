@@ -203,6 +203,21 @@ def linear_astat_f16(x: Tensor, pro: tuple[Tensor, Tensor] | None, W1: Tensor, b
     return (c1, c2) if c2 is not None else c1
 
 
+def mlp_fused_f16(x: Tensor, pro: tuple[Tensor, Tensor], W0: Tensor, b0: Tensor | None, W2: Tensor, b2: Tensor | None,
+                  act_alpha: Tensor | None = None, normalized: bool = True, want_stats: bool = False):
+    """x += mlp.2(act(mlp.0(x*pa + po))) in place (fp16 mode, one launch); returns (x, stats | None)."""
+    lib = _lib.load()
+    B, rows, Cc = x.shape
+    width = W0.shape[0]
+    stats = torch.empty(B, rows // 128, 2, Cc, device=x.device, dtype=torch.float32) if want_stats else None
+    wsplit = _ws(4 * Cc * width, x.device)
+    act = 0 if act_alpha is None else (1 if normalized else 2)
+    check(lib.gecco_mlp_fused_f16(_ptr(x), _ptr(pro[0]), _ptr(pro[1]), _ptr(W0), _ptr(b0), _ptr(W2), _ptr(b2), _ptr(act_alpha),
+                                  act, _ptr(stats), B, rows, Cc, width, C.c_void_p(wsplit.data_ptr()), _stream()),
+          "gecco_mlp_fused_f16")
+    return x, stats
+
+
 def affine_cast_f16(x: Tensor, a: Tensor, o: Tensor, out: Tensor | None = None) -> Tensor:
     """fp16(a[b, c] * x[b, m, c] + o[b, c]): the AdaGN apply stored as the fp16 GEMM operand."""
     lib = _lib.load()

@@ -81,8 +81,9 @@ int gecco_linear_f32(const float* A, const float* W, const float* bias, const fl
 /* Path switches for A/B measurements and tests (the results agree to rounding):
  *   "astat" (default 1): fp16 mode runs AdaGN + kv|q and AdaGN + mlp.0 as one A-stationary pass over x;
  *   "chain" (default 1): fp16 mode runs the 64-inducer chain of a layer (pool merge .. unpool k|v) as one launch;
- *   "headmajor" (default 1): fp16 mode stores K | V and q head-major (needs "astat").
- * value < 0 returns the option to its default / environment (GECCO_ASTAT, GECCO_CHAIN, GECCO_HEADMAJOR).
+ *   "headmajor" (default 1): fp16 mode stores K | V and q head-major (needs "astat");
+ *   "mlpfused" (default 1): fp16 mode runs AdaGN + mlp.0 + activation + mlp.2 + residual + statistics as one launch.
+ * value < 0 returns the option to its default / environment (GECCO_ASTAT, GECCO_CHAIN, GECCO_HEADMAJOR, GECCO_MLPFUSED).
  * Process-wide. */
 int gecco_set_option(const char* name, int value);
 
@@ -144,6 +145,14 @@ int gecco_linear_astat_f16(const float* x, const float* pro_a, const float* pro_
                            int Nout1, void* C1, const float* W2, const float* bias2, int Nout2, void* C2,
                            const float* alpha, int act, int B, int rows, int K, int head_dim, void* wsplit,
                            void* stream);
+/* The point-stream MLP of a BroadcastingLayer in one launch (fp16 mode; models/set_transformer.py:165-166 with the
+ * AdaGN apply of :164 folded in): x += (GaussianActivation(fp16(x*pro_a + pro_o) @ W0^T + b0)) @ W2^T + b2, in place on
+ * the fp32 x (B, rows, C); the 2C-wide hidden layer never leaves the CU.  stats (B, rows / 128, 2, C) or NULL: GroupNorm
+ * partials of the updated x.  Bit-identical x and stats to gecco_linear_astat_f16 (act) followed by gecco_linear_f16io
+ * (fp16 A, residual, stats).  C in {128, 256, 384}, width == 2 C, rows % 128 == 0; wsplit: 4 * C * width bytes. */
+int gecco_mlp_fused_f16(float* x, const float* pro_a, const float* pro_o, const float* W0, const float* b0, const float* W2,
+                        const float* b2, const float* alpha, int act, float* stats, int B, int rows, int C, int width,
+                        void* wsplit, void* stream);
 /* y16[b, m, c] = fp16(a[b, c] * x[b, m, c] + o[b, c]) — the AdaGN apply (models/normalization.py:44) rounded once,
  * exactly the operand the fp16 GEMM's prologue would form.  C % 8 == 0. */
 int gecco_affine_cast_f16(const float* x, const float* a, const float* o, void* y16, int B, int rows, int C,

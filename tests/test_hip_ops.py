@@ -207,6 +207,24 @@ def test_head_major_layout_is_a_pure_permutation(ops, B, N, Cc, H):
     assert torch.equal(ops.unpool_attn_f16io(q_hm, kvh, H, head_major=True), ops.unpool_attn_f16io(q, kvh, H))
 
 
+@pytest.mark.parametrize("B,N,Cc", [(2, 256, 128), (3, 384, 384), (2, 128, 256)])
+def test_mlp_fused_matches_the_two_launch_form(ops, B, N, Cc):
+    """x += mlp.2(act(mlp.0(AdaGN(x)))) in one launch against the A-stationary mlp.0 kernel followed by the fp16-A mlp.2
+    kernel with residual: same rounding points, same k order, same order of the GroupNorm partial sums — the same bits."""
+    rs = _rs(N + Cc)
+    x = _t(rs.randn(B, N, Cc) * 2).cuda()
+    a, o = _t(1 + 0.3 * rs.randn(B, Cc)).cuda(), _t(0.3 * rs.randn(B, Cc)).cuda()
+    W0, b0 = _t(rs.randn(2 * Cc, Cc) / 11).cuda(), _t(rs.randn(2 * Cc) * .1).cuda()
+    W2, b2 = _t(rs.randn(Cc, 2 * Cc) / 15).cuda(), _t(rs.randn(Cc) * .1).cuda()
+    alpha = _t(np.array(0.9)).cuda()
+    h16 = ops.linear_astat_f16(x, (a, o), W0, b0, act_alpha=alpha)
+    ref, st_ref = ops.linear_f16io(h16, W2, b2, residual=x, want_stats=True)
+    got, st = ops.mlp_fused_f16(x.clone(), (a, o), W0, b0, W2, b2, act_alpha=alpha, want_stats=True)
+    assert torch.equal(got, ref)
+    assert st_ref.shape == st.shape and torch.equal(st, st_ref)
+    assert torch.equal(ops.mlp_fused_f16(x.clone(), (a, o), W0, b0, W2, b2, act_alpha=alpha)[0], ref)   # stats optional
+
+
 def test_adagn_large_mean(ops):
     """E[x^2]-mean^2 cancellation: mean 50x the std must still be accurate (fp64 combine)."""
     rs = _rs(5)

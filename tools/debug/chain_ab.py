@@ -1,4 +1,5 @@
-"""A/B of the one-launch inducer chain against the stand-alone kernels: per-layer cached inducer states."""
+"""A/B of a fused launch (option "chain", "mlpfused", ...) against the kernels it replaces: per-layer cached inducer
+states and the denoised output.  python tools/debug/chain_ab.py [case] [option]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -6,12 +7,13 @@ from gecco_amd import hip_ops as ops
 from oracle import cases
 
 name = sys.argv[1] if len(sys.argv) > 1 else "uncond_d128_L4_N256"
+opt = sys.argv[2] if len(sys.argv) > 2 else "chain"
 p, x, sigma = cases.uncond_inputs(name)
 pc = {k: v.cuda() for k, v in p.items()}
 net = ops.LinearLiftPlan(pc, cases.H, cases.I, precision="fp16")
 out = {}
 for chain in (0, 1):
-    ops.set_option("chain", chain)
+    ops.set_option(opt, chain)
     den, hs = net.forward(x.cuda(), sigma.cuda(), do_cache=True)
     out[chain] = (den.cpu(), [c.cpu() for c in hs])
 for li, (a, b) in enumerate(zip(out[1][1], out[0][1])):

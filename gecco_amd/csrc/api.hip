@@ -175,10 +175,10 @@ int linear_pair(const float* A, const float* W1, const float* b1, int Nout1, flo
 }
 
 // Path switches for A/B runs and tests: gecco_set_option, or the environment (GECCO_ASTAT, GECCO_CHAIN) on first use.
-enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_HEADMAJOR = 2, OPT_MLPFUSED = 3, OPT_COUNT = 4 };
-int g_options[OPT_COUNT] = {-1, -1, -1, -1};
-const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor", "mlpfused"};
-const char* const g_option_env[OPT_COUNT] = {"GECCO_ASTAT", "GECCO_CHAIN", "GECCO_HEADMAJOR", "GECCO_MLPFUSED"};
+enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_HEADMAJOR = 2, OPT_MLPFUSED = 3, OPT_UNPOOLFUSED = 4, OPT_COUNT = 5 };
+int g_options[OPT_COUNT] = {-1, -1, -1, -1, -1};
+const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor", "mlpfused", "unpoolfused"};
+const char* const g_option_env[OPT_COUNT] = {"GECCO_ASTAT", "GECCO_CHAIN", "GECCO_HEADMAJOR", "GECCO_MLPFUSED", "GECCO_UNPOOLFUSED"};
 int option(int which) {
     if (g_options[which] < 0) {
         const char* e = getenv(g_option_env[which]);
@@ -391,9 +391,18 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
                        nullptr, w.q, nullptr, B, N, C, C, 0, s, pr, w.wsplit, im ? im + w.o_q : nullptr, io16, io16),
                 "unpool.in_proj(q)");
         }
-        TRY(unpool_attn_launch(w.q, w.kvh, w.attn, B, N, C, H, I, s, pr, io16, hm), "unpool_attn");
-        TRY(linear(w.attn, L.unpool_out_w, L.unpool_out_b, nullptr, nullptr, nullptr, x, x, w.stats_x, B, N, C, C, 0, s, pr,
-                   w.wsplit, im ? im + w.o_out : nullptr, io16, 0), "unpool.out_proj+residual");
+        if (hm && im && I == 64 && option(OPT_UNPOOLFUSED) && unpool_outproj_f16_supported(C, H, N)) {
+            // fp16 mode, head-major q: attention, out_proj, residual and statistics in one launch (the attention output
+            // of a row block is the A operand of out_proj for the same rows and never leaves the CU)
+            UnpoolProjArgs ua{};
+            ua.x = x; ua.q16 = w.q; ua.kvh = w.kvh; ua.w_stream = im + w.o_out; ua.bias = L.unpool_out_b; ua.stats = w.stats_x;
+            ua.B = B; ua.rows = N; ua.H = H;
+            TRY(unpool_outproj_f16_launch(ua, C, s), "unpool attention + out_proj");
+        } else {
+            TRY(unpool_attn_launch(w.q, w.kvh, w.attn, B, N, C, H, I, s, pr, io16, hm), "unpool_attn");
+            TRY(linear(w.attn, L.unpool_out_w, L.unpool_out_b, nullptr, nullptr, nullptr, x, x, w.stats_x, B, N, C, C, 0, s, pr,
+                       w.wsplit, im ? im + w.o_out : nullptr, io16, 0), "unpool.out_proj+residual");
+        }
         // x += mlp(AdaGN(x))
         TRY(coeffs(w.stats_x, Tn, N, t, ctx, &L.mlp_norm, w.a2, w.o2, B, C, G, s), "adagn_coeffs(mlp_norm)");
         float* so = (li + 1 < st->n_layers) ? w.stats_x : stats_out;
@@ -458,7 +467,7 @@ int gecco_set_option(const char* name, int value) {
             g_options[i] = value < 0 ? -1 : (value != 0);   // < 0: back to the environment / default
             return 0;
         }
-    return fail(-2, "set_option: unknown option '%s' (astat, chain, headmajor, mlpfused)", name);
+    return fail(-2, "set_option: unknown option '%s' (astat, chain, headmajor, mlpfused, unpoolfused)", name);
 }
 
 int gecco_linear_row_tiles(int rows) { return row_tiles_gemm(rows); }
@@ -576,6 +585,20 @@ int gecco_mlp_fused_f16(float* x, const float* pro_a, const float* pro_o, const 
     ma.x = x; ma.pro_a = pro_a; ma.pro_o = pro_o; ma.w_stream = img; ma.b0 = b0; ma.b2 = b2; ma.alpha = alpha; ma.act = act;
     ma.stats = stats; ma.B = B; ma.rows = rows;
     TRY(mlp_fused_f16_launch(ma, C, width, s), "mlp_fused");
+    return 0;
+}
+
+int gecco_unpool_outproj_f16(float* x, const void* q16, const float* kvh, const float* W, const float* bias, float* stats,
+                             int B, int rows, int C, int H, void* wsplit, void* stream) {
+    if (!x || !q16 || !kvh || !W || !wsplit) return fail(-1, "unpool_outproj: null argument");
+    if (!unpool_outproj_f16_supported(C, H, rows))
+        return fail(-2, "unpool_outproj: needs (C, head dim) in {(128, 16), (256, 32), (384, 48)}, rows %% 128 == 0");
+    hipStream_t s = (hipStream_t)stream;
+    TRY(split_f16_tiled_launch(W, wsplit, C, C, C, s), "unpool_outproj(split)");
+    UnpoolProjArgs ua{};
+    ua.x = x; ua.q16 = q16; ua.kvh = kvh; ua.w_stream = static_cast<const float*>(wsplit); ua.bias = bias; ua.stats = stats;
+    ua.B = B; ua.rows = rows; ua.H = H;
+    TRY(unpool_outproj_f16_launch(ua, C, s), "unpool_outproj");
     return 0;
 }
 

@@ -86,6 +86,20 @@ struct MlpArgs {
 bool mlp_fused_f16_supported(int C, int Wd, int rows);
 int mlp_fused_f16_launch(const MlpArgs& g, int C, int Wd, hipStream_t st);
 
+// unpool_outproj_f16.hip — fp16 mode: unpool attention + out_proj + residual + GroupNorm partials in one launch
+struct UnpoolProjArgs {
+    float* x;                 // (B, rows, C) fp32 residual stream, updated in place
+    const void* q16;          // head-major fp16 q (B, H, rows, hd)
+    const float* kvh;         // (B, 64, 2C) fp32: k | v of the inducer states
+    const float* w_stream;    // fp16 tiled image of out_proj.weight (C, C)
+    const float* bias;        // (C) or null
+    float* stats;             // (B, rows / 128, 2, C) or null
+    int B, rows, H;
+    int stagger;
+};
+bool unpool_outproj_f16_supported(int C, int H, int rows);
+int unpool_outproj_f16_launch(const UnpoolProjArgs& g, int C, hipStream_t st);
+
 // gemm_f16_astat.hip — fp16 mode, A-stationary: AdaGN apply + fp16 rounding + all column tiles in one pass over x
 // (fp32 A with optional prologue, fp16 outputs, one or two segments; K <= 384, full 128-tiles)
 bool gemm_f16_astat_supported(const GemmArgs& g);

@@ -218,6 +218,18 @@ def mlp_fused_f16(x: Tensor, pro: tuple[Tensor, Tensor], W0: Tensor, b0: Tensor 
     return x, stats
 
 
+def unpool_outproj_f16(x: Tensor, q16: Tensor, kvh: Tensor, W: Tensor, bias: Tensor | None, H: int, want_stats: bool = False):
+    """x += MHA(q, inducer k | v) @ W^T + bias in place (fp16 mode, one launch); q16 head-major (B, H, N, hd).
+    Returns (x, stats | None)."""
+    lib = _lib.load()
+    B, rows, Cc = x.shape
+    stats = torch.empty(B, rows // 128, 2, Cc, device=x.device, dtype=torch.float32) if want_stats else None
+    wsplit = _ws(2 * Cc * Cc, x.device)
+    check(lib.gecco_unpool_outproj_f16(_ptr(x), _ptr16(q16), _ptr(kvh), _ptr(W), _ptr(bias), _ptr(stats), B, rows, Cc, H,
+                                       C.c_void_p(wsplit.data_ptr()), _stream()), "gecco_unpool_outproj_f16")
+    return x, stats
+
+
 def affine_cast_f16(x: Tensor, a: Tensor, o: Tensor, out: Tensor | None = None) -> Tensor:
     """fp16(a[b, c] * x[b, m, c] + o[b, c]): the AdaGN apply stored as the fp16 GEMM operand."""
     lib = _lib.load()

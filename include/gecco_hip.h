@@ -82,8 +82,11 @@ int gecco_linear_f32(const float* A, const float* W, const float* bias, const fl
  *   "astat" (default 1): fp16 mode runs AdaGN + kv|q and AdaGN + mlp.0 as one A-stationary pass over x;
  *   "chain" (default 1): fp16 mode runs the 64-inducer chain of a layer (pool merge .. unpool k|v) as one launch;
  *   "headmajor" (default 1): fp16 mode stores K | V and q head-major (needs "astat");
- *   "mlpfused" (default 1): fp16 mode runs AdaGN + mlp.0 + activation + mlp.2 + residual + statistics as one launch.
- * value < 0 returns the option to its default / environment (GECCO_ASTAT, GECCO_CHAIN, GECCO_HEADMAJOR, GECCO_MLPFUSED).
+ *   "mlpfused" (default 1): fp16 mode runs AdaGN + mlp.0 + activation + mlp.2 + residual + statistics as one launch;
+ *   "unpoolfused" (default 1): fp16 mode runs unpool attention + out_proj + residual + statistics as one launch
+ *   (needs "headmajor").
+ * value < 0 returns the option to its default / environment (GECCO_ASTAT, GECCO_CHAIN, GECCO_HEADMAJOR, GECCO_MLPFUSED,
+ * GECCO_UNPOOLFUSED).
  * Process-wide. */
 int gecco_set_option(const char* name, int value);
 
@@ -153,6 +156,14 @@ int gecco_linear_astat_f16(const float* x, const float* pro_a, const float* pro_
 int gecco_mlp_fused_f16(float* x, const float* pro_a, const float* pro_o, const float* W0, const float* b0, const float* W2,
                         const float* b2, const float* alpha, int act, float* stats, int B, int rows, int C, int width,
                         void* wsplit, void* stream);
+/* The unpool half of a BroadcastingLayer in one launch (fp16 mode; models/set_transformer.py:112 = nn.MultiheadAttention
+ * with the 64 inducer states as keys / values, its out_proj, and the residual of :164): x += softmax(q k^T / sqrt(hd)) v @
+ * W^T + bias, in place on the fp32 x (B, rows, C).  q16: head-major fp16 (B, H, rows, hd) as gecco_linear_astat_f16
+ * (head_dim = hd) writes it; kvh (B, 64, 2C) fp32; stats (B, rows / 128, 2, C) or NULL.  Bit-identical x and stats to
+ * gecco_unpool_attn_f16io (head_major) followed by gecco_linear_f16io (fp16 A, residual, stats).
+ * (C, hd) in {(128, 16), (256, 32), (384, 48)}, rows % 128 == 0; wsplit: 2 * C * C bytes. */
+int gecco_unpool_outproj_f16(float* x, const void* q16, const float* kvh, const float* W, const float* bias, float* stats,
+                             int B, int rows, int C, int H, void* wsplit, void* stream);
 /* y16[b, m, c] = fp16(a[b, c] * x[b, m, c] + o[b, c]) — the AdaGN apply (models/normalization.py:44) rounded once,
  * exactly the operand the fp16 GEMM's prologue would form.  C % 8 == 0. */
 int gecco_affine_cast_f16(const float* x, const float* a, const float* o, void* y16, int B, int rows, int C,

@@ -215,6 +215,22 @@ def test_fp16_fused_mlp_matches_two_launch_form(ops, golden_dir, name):
     assert torch.equal(out[0], out[1])
 
 
+@pytest.mark.parametrize("name", list(cases.UNCOND_CASES))
+def test_fp16_fused_unpool_matches_two_launch_form(ops, golden_dir, name):
+    """The one-launch unpool attention + out_proj (unpool_outproj_f16.hip) against the two kernels it replaces: the
+    whole network output is the same bit for bit."""
+    p, x, sigma = cases.uncond_inputs(name)
+    net = ops.LinearLiftPlan(_cuda(p), cases.H, cases.I, precision="fp16")
+    out = {}
+    try:
+        for on in (0, 1):
+            ops.set_option("unpoolfused", on)
+            out[on] = net.forward(x.cuda(), sigma.cuda()).cpu()
+    finally:
+        ops.set_option("unpoolfused", -1)
+    assert torch.equal(out[0], out[1])
+
+
 def test_split_bf16_linear_accuracy(ops):
     """The split itself: products with operands spanning 8 orders of magnitude keep ~2^-16 relative accuracy."""
     import ctypes as C

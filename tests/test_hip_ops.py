@@ -225,6 +225,25 @@ def test_mlp_fused_matches_the_two_launch_form(ops, B, N, Cc):
     assert torch.equal(ops.mlp_fused_f16(x.clone(), (a, o), W0, b0, W2, b2, act_alpha=alpha)[0], ref)   # stats optional
 
 
+@pytest.mark.parametrize("B,N,Cc,H", [(2, 256, 128, 8), (3, 384, 384, 8), (2, 128, 256, 8)])
+def test_unpool_outproj_fused_gives_the_bits_of_the_two_launch_form(ops, B, N, Cc, H):
+    """Unpool attention + out_proj + residual + GroupNorm partials in one launch against unpool_attn_f16io (head-major
+    q) followed by the fp16-A out_proj GEMM: same fragments, same softmax, same roundings, same epilogue — same bits."""
+    rs = _rs(N + Cc + 1)
+    hd = Cc // H
+    x = _t(rs.randn(B, N, Cc) * 2).cuda()
+    q = (_t(rs.randn(B, H, N, hd)).cuda()).half()
+    kvh = _t(rs.randn(B, 64, 2 * Cc)).cuda()
+    W, bias = _t(rs.randn(Cc, Cc) / 13).cuda(), _t(rs.randn(Cc) * .1).cuda()
+    att = ops.unpool_attn_f16io(q, kvh, H, head_major=True)
+    ref, st_ref = ops.linear_f16io(att, W, bias, residual=x, want_stats=True)
+    got, st = ops.unpool_outproj_f16(x.clone(), q, kvh, W, bias, H, want_stats=True)
+    assert torch.equal(got, ref)
+    assert st.shape == st_ref.shape and torch.equal(st, st_ref)
+    assert torch.equal(ops.unpool_outproj_f16(x.clone(), q, kvh, W, None, H)[0],
+                       ops.linear_f16io(att, W, None, residual=x))   # bias and stats optional
+
+
 def test_adagn_large_mean(ops):
     """E[x^2]-mean^2 cancellation: mean 50x the std must still be accurate (fp64 combine)."""
     rs = _rs(5)

@@ -117,7 +117,9 @@ __global__ __launch_bounds__(MF_NT, 1) void mlp_fused_f16_kernel(MlpArgs g) {
     unsigned soff = 0;
     int islot = 0, issued = 0;
     auto issue = [&]() {
+#ifndef MLPF_DIAG_NODMA
         mf_dma16(wrsrc, voff, soff, ring + islot * MF_TILE + wave * 256);
+#endif
         soff += MF_TILE * 4u;
         islot = islot + 1 == NS ? 0 : islot + 1;
         ++issued;
@@ -182,16 +184,22 @@ __global__ __launch_bounds__(MF_NT, 1) void mlp_fused_f16_kernel(MlpArgs g) {
         for (int c = 0; c < 2; ++c) boff[j][c] = rb * 16 + (((2 * h + c) ^ ((rb >> 2) & 3)) << 2);
     }
     f16x8 fa[2][2], fb[2][2][2];   // [set][chunk], [set][n-block][chunk]
+    f16x8 fh[2][2];                // GEMM b: the A fragments of the hidden K-half (blocks 0, 1), read once per half and
+                                   // reused by every output tile (LDS reads are the pace-setter: 128 B/clk per CU)
     // A fragment addresses of block kt: GEMM a reads y16 (swizzled), GEMM b the hidden K-half buffer
     auto a_addr = [&](bool gemm_b, int kt, int c) -> const char* {
         return gemm_b ? hrow + kt * 64 + 16 * c : yrow + (((kt * 4 + 2 * h + c) ^ ysw) << 4);
     };
-    auto load_frags = [&](auto set_tag, bool gemm_b, int kt) {
+    auto load_frags = [&](auto set_tag, auto gb_tag, int kt) {
         constexpr int set = decltype(set_tag)::value;
+        constexpr bool gemm_b = decltype(gb_tag)::value;
         const float* st = ring + rslot * MF_TILE;
+#ifdef MLPF_DIAG_NOFRAGS
+        if (kt >= 0) return;
+#endif
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            fa[set][c] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(a_addr(gemm_b, kt, c)));
+            if (!gemm_b) fa[set][c] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(a_addr(false, kt, c)));
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 fb[set][j][c] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(st + boff[j][c]));
@@ -202,31 +210,39 @@ __global__ __launch_bounds__(MF_NT, 1) void mlp_fused_f16_kernel(MlpArgs g) {
         if (decltype(tail_tag)::value && issued >= S_TOTAL) dma::wait_vm_lgkm0<0>();
         else dma::wait_vm_lgkm0<AHEAD>();
     };
-    auto kstep = [&](auto cur_tag, auto tail_tag, bool has_next, bool gemm_b, int kt_next, f32x16& a0, f32x16& a1) {
+    auto kstep = [&](auto cur_tag, auto tail_tag, bool has_next, auto gb_tag, int kt_next, f32x16& a0, f32x16& a1) {
         constexpr int cur = decltype(cur_tag)::value;
+        constexpr bool gemm_b = decltype(gb_tag)::value;
         if (has_next) {
             wait_block(tail_tag);
             // this step's fragments were read during the previous one and the wait above covered them: "redefine" them
             // so the compiler's wait-count pass does not put an lgkmcnt(0) in front of the first MFMA
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                asm volatile("" : "+v"(fa[cur][c]));
+                if (!gemm_b) asm volatile("" : "+v"(fa[cur][c]));
 #pragma unroll
                 for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(fb[cur][j][c]));
             }
+#ifndef MLPF_DIAG_NOBARRIER
             __builtin_amdgcn_s_barrier();
+#endif
             asm volatile("" ::: "memory");
             if (!decltype(tail_tag)::value || issued < S_TOTAL) issue();
-            load_frags(std::integral_constant<int, cur ^ 1>{}, gemm_b, kt_next);
+            load_frags(std::integral_constant<int, cur ^ 1>{}, gb_tag, kt_next);
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][c], fb[cur][0][c], a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][c], fb[cur][1][c], a1, 0, 0, 0);
+#ifdef MLPF_DIAG_NOMFMA
+            a0[0] += (float)fa[cur][c][0] + (float)fb[cur][0][c][0];
+            a1[0] += (float)fa[cur][c][1] + (float)fb[cur][1][c][0];
+#else
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(gemm_b ? fh[cur][c] : fa[cur][c], fb[cur][0][c], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(gemm_b ? fh[cur][c] : fa[cur][c], fb[cur][1][c], a1, 0, 0, 0);
+#endif
         }
     };
     // n (even) blocks of one 128-column tile; first: prime the pipeline; more: another tile over the same A follows
-    auto tile_steps = [&](auto tail_tag, int n, bool gemm_b, bool first, bool more, f32x16& a0, f32x16& a1) {
+    auto tile_steps = [&](auto tail_tag, int n, auto gb_tag, bool first, bool more, f32x16& a0, f32x16& a1) {
         constexpr std::integral_constant<int, 0> set0{};
         constexpr std::integral_constant<int, 1> set1{};
         if (first) {
@@ -234,20 +250,20 @@ __global__ __launch_bounds__(MF_NT, 1) void mlp_fused_f16_kernel(MlpArgs g) {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (!decltype(tail_tag)::value || issued < S_TOTAL) issue();
-            load_frags(set0, gemm_b, 0);
+            load_frags(set0, gb_tag, 0);
         }
 #pragma unroll 1
         for (int kt = 0; kt < n - 2; kt += 2) {
-            kstep(set0, tail_tag, true, gemm_b, kt + 1, a0, a1);
-            kstep(set1, tail_tag, true, gemm_b, kt + 2, a0, a1);
+            kstep(set0, tail_tag, true, gb_tag, kt + 1, a0, a1);
+            kstep(set1, tail_tag, true, gb_tag, kt + 2, a0, a1);
         }
-        kstep(set0, tail_tag, true, gemm_b, n - 1, a0, a1);
-        kstep(set1, tail_tag, more, gemm_b, 0, a0, a1);
+        kstep(set0, tail_tag, true, gb_tag, n - 1, a0, a1);
+        kstep(set1, tail_tag, more, gb_tag, 0, a0, a1);
         s += n;
     };
-    auto run_tile = [&](int n, bool gemm_b, bool first, bool more, f32x16& a0, f32x16& a1) {
-        if (s + n + NS > S_TOTAL) tile_steps(std::true_type{}, n, gemm_b, first, more, a0, a1);
-        else tile_steps(std::false_type{}, n, gemm_b, first, more, a0, a1);
+    auto run_tile = [&](int n, auto gb_tag, bool first, bool more, f32x16& a0, f32x16& a1) {
+        if (s + n + NS > S_TOTAL) tile_steps(std::true_type{}, n, gb_tag, first, more, a0, a1);
+        else tile_steps(std::false_type{}, n, gb_tag, first, more, a0, a1);
     };
     auto zero = [](f32x16& a) {
 #pragma unroll
@@ -269,7 +285,7 @@ __global__ __launch_bounds__(MF_NT, 1) void mlp_fused_f16_kernel(MlpArgs g) {
         f32x16 a0, a1;
         zero(a0);
         zero(a1);
-        run_tile(NK, false, true, false, a0, a1);
+        run_tile(NK, std::false_type{}, true, false, a0, a1);
         unsigned hp[2][8];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -302,7 +318,12 @@ __global__ __launch_bounds__(MF_NT, 1) void mlp_fused_f16_kernel(MlpArgs g) {
             }
             mf_lds_barrier();
 #pragma unroll
-            for (int t = 0; t < NT1; ++t) run_tile(2, true, t == 0, t + 1 < NT1, acc2[t][0], acc2[t][1]);
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    fh[q][c] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(a_addr(true, q, c)));
+#pragma unroll
+            for (int t = 0; t < NT1; ++t) run_tile(2, std::true_type{}, t == 0, t + 1 < NT1, acc2[t][0], acc2[t][1]);
         }
     }
     MSTAMP(2);

@@ -115,13 +115,15 @@ __global__ __launch_bounds__(MF_NT, 1) void mlp_fused_f16_kernel(MlpArgs g) {
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.w_stream), 0, 0x7fffffff, 0x00020000);
     const unsigned voff = (unsigned)(wave * 256 + lane * 4) * 4u;
     unsigned soff = 0;
-    int islot = 0, issued = 0;
+    int ioff = 0, issued = 0;   // float offset of the ring slot the next block goes to
     auto issue = [&]() {
 #ifndef MLPF_DIAG_NODMA
-        mf_dma16(wrsrc, voff, soff, ring + islot * MF_TILE + wave * 256);
+        mf_dma16(wrsrc, voff, soff, ring + ioff + wave * 256);
 #endif
         soff += MF_TILE * 4u;
-        islot = islot + 1 == NS ? 0 : islot + 1;
+#ifndef MLPF_DIAG_NOADDR
+        ioff = ioff + MF_TILE == NS * MF_TILE ? 0 : ioff + MF_TILE;
+#endif
         ++issued;
     };
 #pragma unroll 1
@@ -171,10 +173,12 @@ __global__ __launch_bounds__(MF_NT, 1) void mlp_fused_f16_kernel(MlpArgs g) {
     // one block is issued into it; where the A operand changes the pipeline drains (D = NS - 1) and is primed again:
     // same wait, the barrier frees block s - 1's slot, one issue.  Tiles that reach the end of the stream (TAIL) stop
     // issuing and wait for everything.
-    int s = 0, rslot = 0;
+    int s = 0, roff = 0;   // float offset of the ring slot of the next block to read fragments from
     const int row = wm * 32 + r;
-    const char* yrow = ybuf + row * RSY;
-    const int ysw = row & 15;
+    // y16 fragment of block kt, chunk c: chunk index (kt * 4 + 2 h + c) ^ (row & 15) = ((kt ^ (row >> 2 & 3)) * 4) | ((2 h + c)
+    // ^ (row & 3)): a per-lane base per c, plus (kt ^ ym) * 64 bytes
+    const int ym = (row >> 2) & 3;
+    const char* ybase[2] = {ybuf + row * RSY + (((2 * h) ^ (row & 3)) << 4), ybuf + row * RSY + (((2 * h + 1) ^ (row & 3)) << 4)};
     const char* hrow = hbuf + row * MF_RSH + 32 * h;
     int boff[2][2];
 #pragma unroll
@@ -188,12 +192,15 @@ __global__ __launch_bounds__(MF_NT, 1) void mlp_fused_f16_kernel(MlpArgs g) {
                                    // reused by every output tile (LDS reads are the pace-setter: 128 B/clk per CU)
     // A fragment addresses of block kt: GEMM a reads y16 (swizzled), GEMM b the hidden K-half buffer
     auto a_addr = [&](bool gemm_b, int kt, int c) -> const char* {
-        return gemm_b ? hrow + kt * 64 + 16 * c : yrow + (((kt * 4 + 2 * h + c) ^ ysw) << 4);
+#ifdef MLPF_DIAG_NOADDR   // timing only: no swizzle, fixed ring slot (wrong results)
+        return gemm_b ? hrow + kt * 64 + 16 * c : ybase[c] + kt * 64;
+#endif
+        return gemm_b ? hrow + kt * 64 + 16 * c : ybase[c] + ((kt ^ ym) << 6);
     };
     auto load_frags = [&](auto set_tag, auto gb_tag, int kt) {
         constexpr int set = decltype(set_tag)::value;
         constexpr bool gemm_b = decltype(gb_tag)::value;
-        const float* st = ring + rslot * MF_TILE;
+        const float* st = ring + roff;
 #ifdef MLPF_DIAG_NOFRAGS
         if (kt >= 0) return;
 #endif
@@ -204,7 +211,9 @@ __global__ __launch_bounds__(MF_NT, 1) void mlp_fused_f16_kernel(MlpArgs g) {
             for (int j = 0; j < 2; ++j)
                 fb[set][j][c] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(st + boff[j][c]));
         }
-        rslot = rslot + 1 == NS ? 0 : rslot + 1;
+#ifndef MLPF_DIAG_NOADDR
+        roff = roff + MF_TILE == NS * MF_TILE ? 0 : roff + MF_TILE;
+#endif
     };
     auto wait_block = [&](auto tail_tag) {
         if (decltype(tail_tag)::value && issued >= S_TOTAL) dma::wait_vm_lgkm0<0>();

@@ -78,10 +78,22 @@ class LinearFn(torch.autograd.Function):
                 dx = hip_ops.linear(dy, W.t().contiguous(), precision=_train_precision())
             else:  # W read k-major (reduction over its rows)
                 dx = _gemm(dy, W, _new(B, R, K, like=x), Z=1, zdiv=1, M=B * R, N=K, K=Nout, lda=Nout, ldb=K, ldc=K, b_km=True)
-        if ctx.needs_input_grad[1]:  # dW = dy^T x : both read k-major; one partial per sample, summed in order
-            parts = _gemm(dy, x, _new(B, Nout, K, like=x), Z=B, zdiv=1, M=Nout, N=K, K=R, lda=Nout, ldb=K, ldc=K,
-                          sA=(R * Nout, 0), sB=(R * K, 0), sC=(Nout * K, 0), a_km=True, b_km=True)
-            dW = _reduce(parts, Nout * K, B, Nout * K).reshape(Nout, K)
+        if ctx.needs_input_grad[1]:  # dW = dy^T x : both read k-major; partials summed in a fixed order
+            if _train_precision() == "bf16x3" and R % 32 == 0 and Nout % 128 == 0 and K % 128 == 0:
+                # split-bf16 MFMA with transposed LDS reads (gemm_tn_x3.hip); one partial per group of samples, groups
+                # sized so that ~1000 blocks fill the chip
+                tiles = (Nout // 128) * (K // 128)
+                G = min(B, max(1, -(-1024 // tiles)))
+                group = -(-B // G)
+                G = -(-B // group)
+                parts = _new(G, Nout, K, like=x)
+                _lib.check(_lib.load().gecco_gemm_tn_x3_f32(_ptr(dy), _ptr(x), _ptr(parts), B, R, Nout, K, group, _stream()),
+                           "gecco_gemm_tn_x3_f32")
+                dW = _reduce(parts, Nout * K, G, Nout * K).reshape(Nout, K)
+            else:
+                parts = _gemm(dy, x, _new(B, Nout, K, like=x), Z=B, zdiv=1, M=Nout, N=K, K=R, lda=Nout, ldb=K, ldc=K,
+                              sA=(R * Nout, 0), sB=(R * K, 0), sC=(Nout * K, 0), a_km=True, b_km=True)
+                dW = _reduce(parts, Nout * K, B, Nout * K).reshape(Nout, K)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             st = hip_ops.col_stats(dy)  # (B, T, 2, Nout): [..., 0, :] = column sums
             db = _reduce(st, Nout, B * st.shape[1], 2 * Nout)

@@ -1,0 +1,158 @@
+// Weight gradients of the training path in split-bf16 arithmetic, gfx950:
+//
+//     C[g, n, k] = sum over the samples z of group g, sum over rows m:  A[z, m, n] * B[z, m, k]
+//
+// with A = dY (Z, R, N) and B = X (Z, R, K) both row-major — dW = dY^T X of every nn.Linear (autograd of
+// reference models/set_transformer.py / mlp.py under Lightning's loss.backward(), diffusion.py:213-222).  The
+// contraction runs over the ROWS of both operands, so both MFMA fragments are transposed reads: a (32 rows x 128
+// columns) fp32 tile of each operand is split into bf16 hi | lo planes (a = hi + lo, gemm_f32_dma.hip) stored in the
+// 4-row x 32-column blocks of attention_x3.hip's value tile and read with ds_read_b64_tr_b16 (the hardware transpose);
+// the same k permutation applies to both fragments, so products pair up.  Three v_mfma_f32_32x32x16_bf16 per product
+// (a_lo b_hi + a_hi b_lo + a_hi b_hi), fp32 accumulation: ~2^-16 per product at 16x the fp32 matrix rate / 3.
+// 128 x 128 output tile per block, 2 x 2 waves of 64 x 64, 32 rows per step, next step's tiles in registers while this
+// one multiplies, two LDS stages (one barrier per step).  One partial per GROUP of samples, summed afterwards in a
+// fixed order (reduce_batch_kernel): bit-reproducible gradients, 1/8 of the partial traffic of one per sample.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16;
+
+// 4 fp32 -> 4 bf16 hi (top 16 bits) and 4 bf16 lo = rne(x - hi), each packed in two dwords
+__device__ __forceinline__ void tn_split4(const f32x4& x, u32x2& hi, u32x2& lo) {
+    bf16x4 l;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const unsigned ua = __float_as_uint(x[2 * p]), uc = __float_as_uint(x[2 * p + 1]);
+        hi[p] = __builtin_amdgcn_perm(uc, ua, 0x07060302u);
+        l[2 * p] = (__bf16)(x[2 * p] - __uint_as_float(ua & 0xFFFF0000u));
+        l[2 * p + 1] = (__bf16)(x[2 * p + 1] - __uint_as_float(uc & 0xFFFF0000u));
+    }
+    lo = __builtin_bit_cast(u32x2, l);
+}
+
+// element offset of (row, col) in a [32][128] plane: 4-row x 32-column blocks of 128 elements (256 B)
+__device__ __forceinline__ int tn_off(int row, int col) {
+    return ((row >> 2) * 4 + (col >> 5)) * 128 + (row & 3) * 32 + (col & 31);
+}
+
+constexpr int TN_PLANE = 32 * 128;   // u16 per plane
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(TnArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    u16* lds = reinterpret_cast<u16*>(smem);   // [2 stages][A hi | A lo | B hi | B lo]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int tilesK = g.K / 128;
+    const int n0 = (blockIdx.x / tilesK) * 128, k0 = (blockIdx.x % tilesK) * 128;
+    const int z0 = blockIdx.y * g.group, z1 = min(g.Z, z0 + g.group);
+    const int msteps = g.R / 32, nsteps = (z1 - z0) * msteps;
+
+    // global tile loads: thread -> 4 x (row, 4 columns) of each operand
+    f32x4 ra[4], rb[4];
+    auto load = [&](int s) {
+        const int z = z0 + s / msteps, m0 = (s % msteps) * 32;
+        const float* Ab = g.A + (size_t)z * g.sA + (size_t)m0 * g.lda + n0;
+        const float* Bb = g.Bm + (size_t)z * g.sB + (size_t)m0 * g.ldb + k0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + i * 256, row = f >> 5, c4 = f & 31;
+            ra[i] = *reinterpret_cast<const f32x4*>(Ab + (size_t)row * g.lda + c4 * 4);
+            rb[i] = *reinterpret_cast<const f32x4*>(Bb + (size_t)row * g.ldb + c4 * 4);
+        }
+    };
+    auto store = [&](int stage) {
+        u16* st = lds + stage * 4 * TN_PLANE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + i * 256, row = f >> 5, c4 = f & 31, o = tn_off(row, c4 * 4);
+            u32x2 hi, lo;
+            tn_split4(ra[i], hi, lo);
+            *reinterpret_cast<u32x2*>(st + o) = hi;
+            *reinterpret_cast<u32x2*>(st + TN_PLANE + o) = lo;
+            tn_split4(rb[i], hi, lo);
+            *reinterpret_cast<u32x2*>(st + 2 * TN_PLANE + o) = hi;
+            *reinterpret_cast<u32x2*>(st + 3 * TN_PLANE + o) = lo;
+        }
+    };
+    // transposed-read addressing (attention_x3.hip): lane 4q+p of a 16-lane group points at row q, columns 4p .. 4p+3
+    const int tq = (lane & 15) >> 2, tp = lane & 3, tcol = 16 * ((lane >> 4) & 1) + 4 * tp;
+    auto frag = [&](const u16* plane, int sg, int blk) -> bf16x8 {
+        typedef __attribute__((address_space(3))) s16x4* lp;
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(plane + tn_off(16 * sg + 4 * h + tq, blk * 32 + tcol)));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(plane + tn_off(16 * sg + 8 + 4 * h + tq, blk * 32 + tcol)));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (nsteps > 0) load(0);
+    for (int s = 0; s < nsteps; ++s) {
+        const int stage = s & 1;
+        store(stage);
+        __syncthreads();   // stage complete; every wave is past its reads of the other stage's previous contents
+        if (s + 1 < nsteps) load(s + 1);
+        const u16* st = lds + stage * 4 * TN_PLANE;
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg) {
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = frag(st, sg, wn * 2 + i);
+                al[i] = frag(st + TN_PLANE, sg, wn * 2 + i);
+                bh[i] = frag(st + 2 * TN_PLANE, sg, wk * 2 + i);
+                bl[i] = frag(st + 3 * TN_PLANE, sg, wk * 2 + i);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+    float* Cb = g.C + (size_t)blockIdx.y * g.N * g.K;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                Cb[(size_t)(n0 + wn * 64 + i * 32 + mfma_row(e, h)) * g.K + k0 + wk * 64 + j * 32 + r] = acc[i][j][e];
+}
+
+}  // namespace
+
+bool gemm_tn_x3_supported(const TnArgs& g) {
+    return g.Z > 0 && g.group > 0 && g.R >= 32 && g.R % 32 == 0 && g.N % 128 == 0 && g.K % 128 == 0 && !(g.lda & 3) &&
+           !(g.ldb & 3);
+}
+
+int gemm_tn_x3_launch(const TnArgs& g, hipStream_t st) {
+    if (!gemm_tn_x3_supported(g)) return -9;
+    const int G = (g.Z + g.group - 1) / g.group;
+    const size_t lds = (size_t)2 * 4 * TN_PLANE * 2;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_x3_kernel, dim3((g.N / 128) * (g.K / 128), G), dim3(256), lds, st, g);
+    return (int)hipGetLastError();
+}

@@ -100,6 +100,18 @@ struct UnpoolProjArgs {
 bool unpool_outproj_f16_supported(int C, int H, int rows);
 int unpool_outproj_f16_launch(const UnpoolProjArgs& g, int C, hipStream_t st);
 
+// gemm_tn_x3.hip — split-bf16 weight gradients: C[g] = sum over the samples of group g of A[z]^T B[z]
+struct TnArgs {
+    const float* A;    // (Z, R, lda): dY, columns n
+    const float* Bm;   // (Z, R, ldb): X, columns k
+    float* C;          // (ceil(Z / group), N, K) partials
+    int Z, R, N, K, lda, ldb;
+    size_t sA, sB;     // sample strides (elements)
+    int group;
+};
+bool gemm_tn_x3_supported(const TnArgs& g);
+int gemm_tn_x3_launch(const TnArgs& g, hipStream_t st);
+
 // gemm_f16_astat.hip — fp16 mode, A-stationary: AdaGN apply + fp16 rounding + all column tiles in one pass over x
 // (fp32 A with optional prologue, fp16 outputs, one or two segments; K <= 384, full 128-tiles)
 bool gemm_f16_astat_supported(const GemmArgs& g);

@@ -329,6 +329,11 @@ typedef struct GeccoGemm {
 } GeccoGemm;
 int gecco_gemm_f32(const GeccoGemm* g, void* stream);
 /* out[i] (+)= sum_z parts[z*stride + i], fixed order (deterministic parameter gradients). */
+/* Weight gradient of a linear in split-bf16 arithmetic (training path; autograd of every nn.Linear on the point stream):
+ * parts[g] = sum over the samples z of group g of A[z]^T @ B[z], A (Z, R, N) = dY, B (Z, R, K) = X, parts
+ * (ceil(Z / group), N, K); dW = gecco_reduce_batch_f32 over the groups (fixed order: bit-reproducible).
+ * R % 32 == 0, N % 128 == 0, K % 128 == 0. */
+int gecco_gemm_tn_x3_f32(const float* A, const float* Bm, float* parts, int Z, int R, int N, int K, int group, void* stream);
 int gecco_reduce_batch_f32(const float* parts, float* out, size_t n, int Z, size_t stride, int accumulate, void* stream);
 
 /* Row softmax of the materialised attention scores: P = softmax(scale*S) over the last dim n; and its backward

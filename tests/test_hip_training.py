@@ -71,6 +71,41 @@ def test_linear_fn_grads():
     _close(bg.grad, br.grad)
 
 
+def test_split_bf16_weight_gradient_kernel():
+    """dW = dY^T X with transposed LDS reads and 3 bf16 MFMAs per product (gemm_tn_x3.hip) against fp64, operands
+    spanning orders of magnitude; and through LinearFn in the split-bf16 training mode (grouped partials, fixed order)."""
+    import ctypes as C
+    from gecco_amd import _lib, autograd as ag, hip_ops
+    rs = np.random.RandomState(7)
+    Z, R, N, K = 5, 256, 256, 384
+    dy = _t(rs.randn(Z, R, N) * np.exp(rs.uniform(-6, 2, size=(Z, R, 1))))
+    x = _t(rs.randn(Z, R, K))
+    ref = torch.einsum("zrn,zrk->nk", dy.double(), x.double())
+    lib = _lib.load()
+    dyc, xc = dy.cuda(), x.cuda()
+    for group in (1, 2, 5):
+        G = -(-Z // group)
+        parts = torch.empty(G, N, K, device="cuda")
+        _lib.check(lib.gecco_gemm_tn_x3_f32(C.c_void_p(dyc.data_ptr()), C.c_void_p(xc.data_ptr()),
+                                            C.c_void_p(parts.data_ptr()), Z, R, N, K, group, None), "gemm_tn_x3")
+        got = parts.double().sum(0).cpu()
+        e = cpu_ref.rel_err(got, ref)
+        assert e[0] <= 1e-4, (group, e)
+    prev = hip_ops.default_precision()
+    try:
+        hip_ops.set_default_precision("bf16x3")
+        xg, Wg = _leaf(x, "cuda"), _leaf(_t(rs.randn(N, K) / 20), "cuda")
+        y = ag.LinearFn.apply(xg, Wg, None)
+        y.backward(dy.cuda())
+        _close(Wg.grad, ref.float(), 1e-4)
+        g1 = Wg.grad.clone()
+        Wg.grad = None
+        ag.LinearFn.apply(xg, Wg, None).backward(dy.cuda())
+        assert torch.equal(g1, Wg.grad)   # bit-reproducible
+    finally:
+        hip_ops.set_default_precision(prev)
+
+
 @pytest.mark.parametrize("affine", [True, False])
 def test_adagn_fn_grads(affine):
     from gecco_amd.autograd import AdaGNFn

@@ -293,7 +293,9 @@ __global__ __launch_bounds__(256) void lower_edm_v4_kernel(const float* __restri
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
         const int ch = sub + 16 * i;
-        v[i] = ch < nch ? GECCO_NT_LOAD(reinterpret_cast<const f32x4*>(feat + row * C) + ch) : z;
+        // default-policy loads: the rows were written by the previous kernel and part of them is still in the Infinity
+        // Cache (nontemporal loads measured 0.5 % slower end to end)
+        v[i] = ch < nch ? *(reinterpret_cast<const f32x4*>(feat + row * C) + ch) : z;
     }
     if (gn_a) {
 #pragma unroll

@@ -120,8 +120,8 @@ __global__ __launch_bounds__(S_NT, 2) void gemm_f16_astat_kernel(GemmArgs g) {
                 const int i = tid + u * S_NT, row = i >> 4, c8 = i & 15;
                 const bool in = k0 * SBK + c8 * 8 < K;
                 const float* src = xb + (size_t)row * g.lda + k0 * SBK + (in ? c8 * 8 : 0);
-                x0[u] = GECCO_NT_LOAD(reinterpret_cast<const f32x4*>(src));
-                x1[u] = GECCO_NT_LOAD(reinterpret_cast<const f32x4*>(src + 4));
+                x0[u] = *reinterpret_cast<const f32x4*>(src);   // default policy: x was written by the previous kernel
+                x1[u] = *reinterpret_cast<const f32x4*>(src + 4);
             }
             __syncthreads();   // coefficients in LDS (first slab) / every wave done reading the previous slab
 #pragma unroll

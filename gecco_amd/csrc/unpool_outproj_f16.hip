@@ -353,7 +353,7 @@ __global__ __launch_bounds__(MF_NT, 1) void unpool_outproj_f16_kernel(UnpoolProj
         auto fetch = [&](int t, int set) {
 #pragma unroll
             for (int it = 0; it < 8; ++it)
-                rres[set][it] = GECCO_NT_LOAD(reinterpret_cast<const f32x4*>(xw + (size_t)(it * 4 + lr) * C + t * 128));
+                rres[set][it] = *reinterpret_cast<const f32x4*>(xw + (size_t)(it * 4 + lr) * C + t * 128);
         };
         fetch(0, 0);
         mf_lds_barrier();   // every wave is done with the ring and the attention-output buffer
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(MF_NT, 1) void unpool_outproj_f16_kernel(UnpoolProj
             for (int it = 0; it < 8; ++it) {
                 f32x4 v4 = *reinterpret_cast<const f32x4*>(Tt + (it * 4 + lr) * TP + c4 * 4);
                 v4 += rres[set][it];
-                GECCO_NT_STORE(v4, reinterpret_cast<f32x4*>(xw + (size_t)(it * 4 + lr) * C + t * 128));
+                *reinterpret_cast<f32x4*>(xw + (size_t)(it * 4 + lr) * C + t * 128) = v4;   // default policy: the next kernel re-reads x (201 MB: Infinity Cache)
                 s1 += v4;
                 s2 += v4 * v4;
             }

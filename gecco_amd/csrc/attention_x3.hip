@@ -120,7 +120,10 @@ __global__ __launch_bounds__(256, 2) void pool_attn_x3_kernel(const float* __res
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int bh = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
+    // newest data first: K | V were written in ascending (sample, row) order by a kernel whose output (300 MB) exceeds the
+    // 256 MB Infinity Cache — walking them backwards meets what is still cached instead of chasing the eviction front
+    const int bid = gridDim.x - 1 - blockIdx.x;
+    const int bh = bid / nsplit, split = bid % nsplit;
     const int b = bh / H, hh = bh % H;
 
     u16* Qhi = lds;

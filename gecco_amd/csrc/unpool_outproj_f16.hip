@@ -82,7 +82,8 @@ __global__ __launch_bounds__(MF_NT, 1) void unpool_outproj_f16_kernel(UnpoolProj
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
     const int tilesM = g.rows / 128;
-    const int b = blockIdx.x / tilesM, rt = blockIdx.x % tilesM, m0 = rt * 128;
+    const int bid = gridDim.x - 1 - blockIdx.x;   // newest q / x first (see pool_attn_x3_kernel)
+    const int b = bid / tilesM, rt = bid % tilesM, m0 = rt * 128;
 
     // start-up stagger (mlp_fused_f16.hip): spread the HBM-bound phases of the rounds of blocks over 8 offsets
     if (g.stagger > 0 && blockIdx.x < 256) {

@@ -10,10 +10,15 @@ are independent, there is no data-path collective ("replicas only", weak scaling
 the max over ranks.  Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
-  roofline     — the dominant kernel (fp32-MFMA fused GEMM, 42 launches per forward): algorithmic
-                 FLOPs of its five call-site shapes / their event-timed durations, vs the 157.3 TF
-                 dense fp32 MFMA peak (MI355X_MICROARCH.md).  The rocprofv3 summary of this same
-                 command lives in profiles/.
+  roofline     — the dominant kernel of the measured mode.  fp16 (default): the fused point MLP
+                 (mlp_fused_f16_kernel, 35 % of device time), bound "mfma": 4 B N d 2d FLOP / its
+                 duration, where the duration is timed with HIP events around hipGraph replays of the
+                 layer's three point-stream launches (kernel launches only) as "round - round without
+                 that launch", so the kernel meets the cache state of the forward and no host launch
+                 gap is inside the timed region; the other two launches are priced against HBM in
+                 "hbm_side"; "traffic" = FETCH_SIZE x 2 + WRITE_SIZE of that kernel from the committed
+                 --pmc passes (profiles/).  bf16x3 / fp32: the LDS-DMA GEMM at its four call-site shapes.
+                 The rocprofv3 --kernel-trace --stats summary of this same command lives in profiles/.
   cpu_baseline — the oracle (plain PyTorch CPU restatement of the reference) on a bounded sample.
 """
 from __future__ import annotations
@@ -130,15 +135,23 @@ def gemm_call_sites(ops, dev, precision="fp32"):
         # the three point-stream launches of a layer as the network runs them: AdaGN + kv|q
         # (A-stationary), unpool attention + out_proj + residual + statistics, AdaGN + mlp.0 + activation + mlp.2 +
         # residual + statistics.  Bytes: what has to cross HBM once (x in / x out counted once each).
-        qhm = rn(B, H, N, D // H).half()
+        # The three closures work on shared buffers (kv|q reads the x the MLP wrote and writes the q the unpool launch
+        # reads, which writes the x the MLP reads); no allocation inside, so they can be captured (time_graphed).
         kvh = rn(B, I, 2 * D)
         xw = x.clone()   # updated in place by the fused launches (bounded: the coefficients and weights are fixed)
+        # weight images made once (as the network does once per forward): the timed calls launch the kernels alone
+        ws = [torch.empty(n, dtype=torch.uint8, device=dev) for n in (3 * D * D * 4, 2 * D * D, 4 * D * 2 * D)]
+        st1, st2 = (torch.empty(B, N // 128, 2, D, device=dev) for _ in range(2))
+        ops.linear_astat_f16(xw, (pa, po), Wkv, None, Wq, bq, out=(kv16, q16), head_dim=D // H, wsplit=ws[0])
+        ops.unpool_outproj_f16(xw, q16, kvh, Wo, bq, H, wsplit=ws[1], stats=st1)
+        ops.mlp_fused_f16(xw, (pa, po), W1, b1, W2, b2, act_alpha=alpha, wsplit=ws[2], stats=st2)
         return [
-            ("norm+kv_proj|q_proj", 2 * B * N * D * 3 * D, S + 3 * H2, lambda: ops.linear_astat_f16(x, (pa, po), Wkv, None, Wq, bq, out=(kv16, q16), head_dim=D // H)),
+            ("norm+kv_proj|q_proj", 2 * B * N * D * 3 * D, S + 3 * H2,
+             lambda: ops.linear_astat_f16(xw, (pa, po), Wkv, None, Wq, bq, out=(kv16, q16), head_dim=D // H, wsplit=ws[0], image_ready=True)),
             ("unpool_attn+out_proj+res+stats", 2 * B * N * D * D + 4 * B * N * I * D, H2 + 2 * S,
-             lambda: ops.unpool_outproj_f16(xw, qhm, kvh, Wo, bq, H, want_stats=True)),
+             lambda: ops.unpool_outproj_f16(xw, q16, kvh, Wo, bq, H, wsplit=ws[1], image_ready=True, stats=st1)),
             ("norm+mlp.0+act+mlp.2+res+stats", 4 * B * N * D * 2 * D, 2 * S,
-             lambda: ops.mlp_fused_f16(xw, (pa, po), W1, b1, W2, b2, act_alpha=alpha, want_stats=True)),
+             lambda: ops.mlp_fused_f16(xw, (pa, po), W1, b1, W2, b2, act_alpha=alpha, wsplit=ws[2], image_ready=True, stats=st2)),
         ]
     pr = dict(precision=precision)
     sites = [
@@ -160,6 +173,35 @@ def time_events(fn, iters, warmup=2):
     e.record()
     e.synchronize()
     return s.elapsed_time(e) / iters  # ms
+
+
+def time_graph_of(fns, reps=8, iters=4):
+    """ms per replayed round of the launch sequence `fns` inside a hipGraph of `reps` rounds (HIP events around the
+    replays, on the stream the graph is replayed on): no host launch gap inside the timed region — an event pair around
+    eager launches adds ~20 us per launch here — i.e. the condition the kernels have in the captured forward."""
+    for fn in fns:
+        fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            for fn in fns:
+                fn()
+    g.replay()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        g.replay()
+    e.record()
+    e.synchronize()
+    return s.elapsed_time(e) / (iters * reps)
+
+
+def time_in_sequence(fns):
+    """Duration of each launch of the sequence `fns` IN the sequence (so that it meets the cache state its predecessor
+    leaves, as in the forward): the plain round minus the round without launch k."""
+    base = time_graph_of(fns)
+    return [base - time_graph_of(fns[:k] + fns[k + 1:]) for k in range(len(fns))], base
 
 
 def cpu_baseline(p, x, sigma, budget_s=15.0):
@@ -279,8 +321,13 @@ def main():
     if rank == 0 and not args.no_roofline:
         sites = gemm_call_sites(ops, dev, mode)
         tot_f, tot_b, tot_ms, per = 0.0, 0.0, 0.0, {}
-        for name, fl, by, fn in sites:
-            t = time_events(fn, 10)
+        # fp16 mode: kernel-only launches (images prepared) timed inside hipGraphs of the three-launch round
+        seq_ms = None
+        if mode == "fp16":
+            times, seq_ms = time_in_sequence([fn for _, _, _, fn in sites])
+        else:
+            times = [time_events(fn, 10) for _, _, _, fn in sites]
+        for (name, fl, by, fn), t in zip(sites, times):
             per[name] = {"ms": round(t, 4), "tflops": round(fl / (t * 1e-3) / 1e12, 2), "gbs": round(by / (t * 1e-3) / 1e9, 1)}
             tot_f += fl
             tot_b += by
@@ -310,7 +357,10 @@ def main():
                                                        "unpool_outproj_f16_kernel<3,48> (unpool attention + out_proj + residual + partials)",
                                             "achieved_gbs_algorithmic": o_b / (o_ms * 1e-3) / 1e9, "peak_gbs": PEAK_HBM_GBS,
                                             "frac": o_b / (o_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
-                               "all_three": {"achieved_tflops": tf, "achieved_gbs_algorithmic": gbs},
+                               "all_three": {"achieved_tflops": tot_f / (seq_ms * 1e-3) / 1e12,
+                                             "achieved_gbs_algorithmic": tot_b / (seq_ms * 1e-3) / 1e9, "ms_per_round": seq_ms},
+                               "timing": "HIP events around hipGraph replays of the three-launch round (kernel launches only, weight "
+                                         "images prepared); a launch's duration = plain round - round without that launch",
                                "per_site": per}
         elif mode == "bf16x3":
             # The split-bf16 algorithm issues 3 MFMAs per product, so its matrix roof is the dense bf16 peak / 3 =

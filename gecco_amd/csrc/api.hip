@@ -541,18 +541,21 @@ int gecco_linear_pair_f16io(const void* A, const float* W1, const float* bias1, 
 int gecco_linear_astat_f16(const float* x, const float* pro_a, const float* pro_o, const float* W1, const float* bias1,
                            int Nout1, void* C1, const float* W2, const float* bias2, int Nout2, void* C2,
                            const float* alpha, int act, int B, int rows, int K, int head_dim, void* wsplit, void* stream) {
-    if (!x || !W1 || !C1 || !wsplit) return fail(-1, "linear_astat: null argument");
+    if (!x || !C1 || !wsplit) return fail(-1, "linear_astat: null argument");
+    const bool image_ready = W1 == nullptr;   // wsplit holds the images a previous call made from the same weights
     if ((pro_a == nullptr) != (pro_o == nullptr)) return fail(-1, "linear_astat: pro_a/pro_o must both be set");
-    if ((W2 == nullptr) != (C2 == nullptr)) return fail(-1, "linear_astat: W2 and C2 go together");
+    if (!image_ready && (W2 == nullptr) != (C2 == nullptr)) return fail(-1, "linear_astat: W2 and C2 go together");
     hipStream_t s = (hipStream_t)stream;
     float* img = static_cast<float*>(wsplit);
-    TRY(split_f16_tiled_launch(W1, img, Nout1, K, K, s), "linear_astat(split)");
-    if (W2) TRY(split_f16_tiled_launch(W2, img + split_f16_image_bytes(Nout1, K) / sizeof(float), Nout2, K, K, s), "linear_astat(split)");
+    if (!image_ready) {
+        TRY(split_f16_tiled_launch(W1, img, Nout1, K, K, s), "linear_astat(split)");
+        if (W2) TRY(split_f16_tiled_launch(W2, img + split_f16_image_bytes(Nout1, K) / sizeof(float), Nout2, K, K, s), "linear_astat(split)");
+    }
     GemmArgs g{};
     g.A = x; g.pro_a = pro_a; g.pro_o = pro_o; g.bias = bias1; g.alpha = alpha; g.act = act; g.C = static_cast<float*>(C1);
-    g.B = B; g.rows = rows; g.K = K; g.Nout = Nout1 + (W2 ? Nout2 : 0); g.lda = K; g.ldw = K; g.ldc = Nout1; g.ldr = Nout1;
+    g.B = B; g.rows = rows; g.K = K; g.Nout = Nout1 + (C2 ? Nout2 : 0); g.lda = K; g.ldw = K; g.ldc = Nout1; g.ldr = Nout1;
     g.precision = 2; g.w_img = img; g.c_f16 = 1; g.hm_hd = head_dim;
-    if (W2) { g.C2 = static_cast<float*>(C2); g.bias2 = bias2; g.n_split = Nout1; g.ldc2 = Nout2; }
+    if (C2) { g.C2 = static_cast<float*>(C2); g.bias2 = bias2; g.n_split = Nout1; g.ldc2 = Nout2; }
     if (act && !alpha) return fail(-6, "linear_astat: activation needs alpha");
     if (head_dim < 0) return fail(-2, "linear_astat: head_dim < 0");
     if (!gemm_f16_astat_supported(g))
@@ -565,7 +568,7 @@ int gecco_linear_astat_f16(const float* x, const float* pro_a, const float* pro_
 int gecco_mlp_fused_f16(float* x, const float* pro_a, const float* pro_o, const float* W0, const float* b0, const float* W2,
                         const float* b2, const float* alpha, int act, float* stats, int B, int rows, int C, int width,
                         void* wsplit, void* stream) {
-    if (!x || !pro_a || !pro_o || !W0 || !W2 || !wsplit) return fail(-1, "mlp_fused: null argument");
+    if (!x || !pro_a || !pro_o || !wsplit || ((W0 == nullptr) != (W2 == nullptr))) return fail(-1, "mlp_fused: null argument");
     if (act && !alpha) return fail(-6, "mlp_fused: activation needs alpha");
     if (!mlp_fused_f16_supported(C, width, rows))
         return fail(-2, "mlp_fused: needs C in {128, 256, 384}, width == 2 C, rows %% 128 == 0");
@@ -580,7 +583,7 @@ int gecco_mlp_fused_f16(float* x, const float* pro_a, const float* pro_o, const 
         for (int hf = 0; hf < 2; ++hf)
             jobs.job[jobs.n++] = SplitJob{W2 + (size_t)jc * 128 + hf * 64, cb + (size_t)(nkb + hf * (nkb / 2)) * 2048, C, 64, width, 0};
     }
-    TRY(split_f16_tiled_multi_launch(jobs, s), "mlp_fused(split)");
+    if (W0) TRY(split_f16_tiled_multi_launch(jobs, s), "mlp_fused(split)");   // W0 == W2 == NULL: wsplit holds the image already
     MlpArgs ma{};
     ma.x = x; ma.pro_a = pro_a; ma.pro_o = pro_o; ma.w_stream = img; ma.b0 = b0; ma.b2 = b2; ma.alpha = alpha; ma.act = act;
     ma.stats = stats; ma.B = B; ma.rows = rows;
@@ -590,11 +593,11 @@ int gecco_mlp_fused_f16(float* x, const float* pro_a, const float* pro_o, const 
 
 int gecco_unpool_outproj_f16(float* x, const void* q16, const float* kvh, const float* W, const float* bias, float* stats,
                              int B, int rows, int C, int H, void* wsplit, void* stream) {
-    if (!x || !q16 || !kvh || !W || !wsplit) return fail(-1, "unpool_outproj: null argument");
+    if (!x || !q16 || !kvh || !wsplit) return fail(-1, "unpool_outproj: null argument");
     if (!unpool_outproj_f16_supported(C, H, rows))
         return fail(-2, "unpool_outproj: needs (C, head dim) in {(128, 16), (256, 32), (384, 48)}, rows %% 128 == 0");
     hipStream_t s = (hipStream_t)stream;
-    TRY(split_f16_tiled_launch(W, wsplit, C, C, C, s), "unpool_outproj(split)");
+    if (W) TRY(split_f16_tiled_launch(W, wsplit, C, C, C, s), "unpool_outproj(split)");   // W == NULL: image ready
     UnpoolProjArgs ua{};
     ua.x = x; ua.q16 = q16; ua.kvh = kvh; ua.w_stream = static_cast<const float*>(wsplit); ua.bias = bias; ua.stats = stats;
     ua.B = B; ua.rows = rows; ua.H = H;

@@ -181,9 +181,11 @@ def linear_pair_f16io(A16: Tensor, W1: Tensor, b1: Tensor | None, W2: Tensor, b2
 
 def linear_astat_f16(x: Tensor, pro: tuple[Tensor, Tensor] | None, W1: Tensor, b1: Tensor | None, W2: Tensor | None = None,
                      b2: Tensor | None = None, act_alpha: Tensor | None = None, normalized: bool = True,
-                     out: tuple[Tensor, Tensor | None] | None = None, head_dim: int = 0):
+                     out: tuple[Tensor, Tensor | None] | None = None, head_dim: int = 0, wsplit: Tensor | None = None,
+                     image_ready: bool = False):
     """fp16(act(fp16(x*pa + po) @ W^T + b)) for W = W1 (| W2), fp16 outputs, one pass over x (fp16 mode).
-    head_dim > 0: head-major outputs (B, Nout / head_dim, rows, head_dim) — "b n (g d) -> b g n d"."""
+    head_dim > 0: head-major outputs (B, Nout / head_dim, rows, head_dim) — "b n (g d) -> b g n d".
+    wsplit / image_ready: caller-owned scratch holding the weight image of a previous call (kernel launch only)."""
     lib = _lib.load()
     B, rows, K = x.shape
     n1 = W1.shape[0]
@@ -194,38 +196,48 @@ def linear_astat_f16(x: Tensor, pro: tuple[Tensor, Tensor] | None, W1: Tensor, b
         shape = lambda n: (B, n // head_dim, rows, head_dim) if head_dim else (B, rows, n)
         c1 = torch.empty(*shape(n1), device=x.device, dtype=torch.float16)
         c2 = torch.empty(*shape(n2), device=x.device, dtype=torch.float16) if n2 else None
-    wsplit = _ws(((n1 + 127) // 128 + (n2 + 127) // 128) * 128 * K * 4, x.device)
+    if wsplit is None:
+        wsplit = _ws(((n1 + 127) // 128 + (n2 + 127) // 128) * 128 * K * 4, x.device)
     act = 0 if act_alpha is None else (1 if normalized else 2)
-    check(lib.gecco_linear_astat_f16(_ptr(x), _ptr(pro[0]) if pro else None, _ptr(pro[1]) if pro else None, _ptr(W1), _ptr(b1),
-                                     n1, _ptr16(c1), _ptr(W2), _ptr(b2), n2, _ptr16(c2) if c2 is not None else None,
+    check(lib.gecco_linear_astat_f16(_ptr(x), _ptr(pro[0]) if pro else None, _ptr(pro[1]) if pro else None,
+                                     None if image_ready else _ptr(W1), _ptr(b1),
+                                     n1, _ptr16(c1), None if image_ready else _ptr(W2), _ptr(b2), n2, _ptr16(c2) if c2 is not None else None,
                                      _ptr(act_alpha), act, B, rows, K, head_dim, C.c_void_p(wsplit.data_ptr()), _stream()),
           "gecco_linear_astat_f16")
     return (c1, c2) if c2 is not None else c1
 
 
 def mlp_fused_f16(x: Tensor, pro: tuple[Tensor, Tensor], W0: Tensor, b0: Tensor | None, W2: Tensor, b2: Tensor | None,
-                  act_alpha: Tensor | None = None, normalized: bool = True, want_stats: bool = False):
-    """x += mlp.2(act(mlp.0(x*pa + po))) in place (fp16 mode, one launch); returns (x, stats | None)."""
+                  act_alpha: Tensor | None = None, normalized: bool = True, want_stats: bool = False,
+                  wsplit: Tensor | None = None, image_ready: bool = False, stats: Tensor | None = None):
+    """x += mlp.2(act(mlp.0(x*pa + po))) in place (fp16 mode, one launch); returns (x, stats | None).
+    wsplit / image_ready: caller-owned scratch holding the weight image of a previous call (kernel launch only)."""
     lib = _lib.load()
     B, rows, Cc = x.shape
     width = W0.shape[0]
-    stats = torch.empty(B, rows // 128, 2, Cc, device=x.device, dtype=torch.float32) if want_stats else None
-    wsplit = _ws(4 * Cc * width, x.device)
+    if stats is None and want_stats:
+        stats = torch.empty(B, rows // 128, 2, Cc, device=x.device, dtype=torch.float32)
+    if wsplit is None:
+        wsplit = _ws(4 * Cc * width, x.device)
     act = 0 if act_alpha is None else (1 if normalized else 2)
-    check(lib.gecco_mlp_fused_f16(_ptr(x), _ptr(pro[0]), _ptr(pro[1]), _ptr(W0), _ptr(b0), _ptr(W2), _ptr(b2), _ptr(act_alpha),
+    check(lib.gecco_mlp_fused_f16(_ptr(x), _ptr(pro[0]), _ptr(pro[1]), None if image_ready else _ptr(W0), _ptr(b0),
+                                  None if image_ready else _ptr(W2), _ptr(b2), _ptr(act_alpha),
                                   act, _ptr(stats), B, rows, Cc, width, C.c_void_p(wsplit.data_ptr()), _stream()),
           "gecco_mlp_fused_f16")
     return x, stats
 
 
-def unpool_outproj_f16(x: Tensor, q16: Tensor, kvh: Tensor, W: Tensor, bias: Tensor | None, H: int, want_stats: bool = False):
+def unpool_outproj_f16(x: Tensor, q16: Tensor, kvh: Tensor, W: Tensor, bias: Tensor | None, H: int, want_stats: bool = False,
+                       wsplit: Tensor | None = None, image_ready: bool = False, stats: Tensor | None = None):
     """x += MHA(q, inducer k | v) @ W^T + bias in place (fp16 mode, one launch); q16 head-major (B, H, N, hd).
-    Returns (x, stats | None)."""
+    Returns (x, stats | None).  wsplit / image_ready: scratch holding the weight image of a previous call."""
     lib = _lib.load()
     B, rows, Cc = x.shape
-    stats = torch.empty(B, rows // 128, 2, Cc, device=x.device, dtype=torch.float32) if want_stats else None
-    wsplit = _ws(2 * Cc * Cc, x.device)
-    check(lib.gecco_unpool_outproj_f16(_ptr(x), _ptr16(q16), _ptr(kvh), _ptr(W), _ptr(bias), _ptr(stats), B, rows, Cc, H,
+    if stats is None and want_stats:
+        stats = torch.empty(B, rows // 128, 2, Cc, device=x.device, dtype=torch.float32)
+    if wsplit is None:
+        wsplit = _ws(2 * Cc * Cc, x.device)
+    check(lib.gecco_unpool_outproj_f16(_ptr(x), _ptr16(q16), _ptr(kvh), None if image_ready else _ptr(W), _ptr(bias), _ptr(stats), B, rows, Cc, H,
                                        C.c_void_p(wsplit.data_ptr()), _stream()), "gecco_unpool_outproj_f16")
     return x, stats
 

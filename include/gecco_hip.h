@@ -134,7 +134,12 @@ int gecco_linear_f16io(const void* A, const float* W, const float* bias, const f
 int gecco_linear_pair_f16io(const void* A, const float* W1, const float* bias1, int Nout1, void* C1, const float* W2,
                             const float* bias2, int Nout2, void* C2, int B, int rows, int K, void* wsplit,
                             void* stream);
-/* The one-pass form the network uses for kv_proj | q_proj and mlp.0 in the fp16 mode: AdaGN apply + fp16 rounding +
+/* Image-ready calls (gecco_linear_astat_f16, gecco_mlp_fused_f16, gecco_unpool_outproj_f16): a NULL weight pointer
+ * (W1 / W0 and W2 / W) means "wsplit still holds the fp16 weight image a previous call of the same function made from
+ * the same weights" — the call then launches the kernel alone (what the network entry points do once per forward, and
+ * what bench.py times).
+ *
+The one-pass form the network uses for kv_proj | q_proj and mlp.0 in the fp16 mode: AdaGN apply + fp16 rounding +
  * all output columns in one pass over x (the block keeps fp16(x*pro_a + pro_o) of its 128 rows in registers and walks
  * every 128-column tile of W1 | W2).  C1 (B, rows, Nout1) and C2 (B, rows, Nout2; W2/bias2/C2 may be NULL) are fp16;
  * act as in gecco_linear_f32.  Bit-identical to gecco_affine_cast_f16 + gecco_linear(_pair)_f16io.

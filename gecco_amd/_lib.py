@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GECCO_HIP_LIB") or os.path.join(_HERE, "libgecco_hip.so")   # override: A/B builds only
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_f = C.c_void_p  # device pointers travel as void*
 
@@ -60,6 +60,12 @@ class GeccoGemm(C.Structure):
                 ("sA1", C.c_longlong), ("sA2", C.c_longlong), ("sB1", C.c_longlong), ("sB2", C.c_longlong),
                 ("sC1", C.c_longlong), ("sC2", C.c_longlong), ("a_kmajor", C.c_int), ("b_kmajor", C.c_int),
                 ("scale", C.c_float)]
+
+
+class GeccoAdamEma(C.Structure):
+    _fields_ = [("p", c_f), ("g", c_f), ("m", c_f), ("v", c_f), ("ema", c_f), ("n", C.c_size_t), ("lr", C.c_float),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float),
+                ("step", C.c_int), ("grad_scale", C.c_float), ("ema_decay", C.c_float), ("do_ema", C.c_int)]
 
 
 i, sz, vp, fl, db = C.c_int, C.c_size_t, C.c_void_p, C.c_float, C.c_double
@@ -132,6 +138,8 @@ SIGNATURES = {
     "gecco_lift_bwd_f32": (i, [vp, vp, vp, i, i, i, vp]),
     "gecco_lower_bwd_f32": (i, [vp, vp, vp, vp, vp, sz, i, fl, vp]),
     "gecco_lower_bwd_blocks": (i, [sz]),
+    "gecco_adam_ema_step_f32": (i, [C.POINTER(GeccoAdamEma), vp]),
+    "gecco_ema_update_f32": (i, [vp, vp, sz, fl, vp]),
 }
 
 _lib = None

@@ -5,7 +5,9 @@
 #include "../../include/gecco_hip.h"
 #include "kernels.h"
 
+#include <math.h>
 #include <stdarg.h>
+#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 #include <stdio.h>
@@ -239,15 +241,18 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         // 6 layers (weights may change between calls; nothing is cached across forwards)
         SplitJobs jobs;
         jobs.n = 0;
-        auto push = [&](const float* Wp, float* img, int Nout, int K) -> int {
-            jobs.job[jobs.n++] = SplitJob{Wp, img, Nout, K, K, 0};
-            if (jobs.n == 96) {
+        // every insertion goes through here: the table is flushed BEFORE a write that would not fit
+        constexpr int kJobCap = (int)(sizeof(jobs.job) / sizeof(jobs.job[0]));
+        auto push_ld = [&](const float* Wp, float* img, int Nout, int K, int ldw) -> int {
+            if (jobs.n >= kJobCap) {
                 int rc = pr == 2 ? split_f16_tiled_multi_launch(jobs, s) : split_bf16_tiled_multi_launch(jobs, s);
                 jobs.n = 0;
-                return rc;
+                if (rc) return rc;
             }
+            jobs.job[jobs.n++] = SplitJob{Wp, img, Nout, K, ldw, 0};
             return 0;
         };
+        auto push = [&](const float* Wp, float* img, int Nout, int K) -> int { return push_ld(Wp, img, Nout, K, K); };
         for (int li = 0; li < st->n_layers; ++li) {
             const GeccoLayer& L = st->layers[li];
             float* base = w.wimg + (size_t)li * w.wimg_layer;
@@ -256,13 +261,9 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
                 TRY(push(L.pool_out_w, base + w.o_pout, C, C), "split(pool.out_proj)");
                 TRY(push(L.bmlp.w0, base + w.o_b0, Wd, C), "split(broadcast.mlp.0)");
                 if (chain_on) {   // the one-launch chain walks mlp.2 K-half by K-half: one (C x C) image per half
-                    for (int hf = 0; hf < Wd / C; ++hf) {
-                        jobs.job[jobs.n] = SplitJob{L.bmlp.w2 + (size_t)hf * C, base + w.o_b2 + (size_t)hf * C * C / 2, C, C, Wd, 0};
-                        if (++jobs.n == 96) {
-                            TRY(split_f16_tiled_multi_launch(jobs, s), "split(weights)");
-                            jobs.n = 0;
-                        }
-                    }
+                    for (int hf = 0; hf < Wd / C; ++hf)
+                        TRY(push_ld(L.bmlp.w2 + (size_t)hf * C, base + w.o_b2 + (size_t)hf * C * C / 2, C, C, Wd),
+                            "split(broadcast.mlp.2 K-half)");
                 } else {
                     TRY(push(L.bmlp.w2, base + w.o_b2, C, Wd), "split(broadcast.mlp.2)");
                 }
@@ -274,14 +275,10 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
                 const int nkb = C / 32;
                 for (int jc = 0; jc < Wd / 128; ++jc) {
                     float* cb = base + w.o_mf + (size_t)jc * 2 * nkb * 2048;
-                    jobs.job[jobs.n++] = SplitJob{L.mlp.w0 + (size_t)jc * 128 * C, cb, 128, C, C, 0};
+                    TRY(push_ld(L.mlp.w0 + (size_t)jc * 128 * C, cb, 128, C, C), "split(mlp.0 tile)");
                     for (int hf = 0; hf < 2; ++hf)
-                        jobs.job[jobs.n++] = SplitJob{L.mlp.w2 + (size_t)jc * 128 + hf * 64,
-                                                      cb + (size_t)(nkb + hf * (nkb / 2)) * 2048, C, 64, Wd, 0};
-                    if (jobs.n + 3 > 96) {
-                        TRY(split_f16_tiled_multi_launch(jobs, s), "split(weights)");
-                        jobs.n = 0;
-                    }
+                        TRY(push_ld(L.mlp.w2 + (size_t)jc * 128 + hf * 64, cb + (size_t)(nkb + hf * (nkb / 2)) * 2048, C, 64, Wd),
+                            "split(mlp.2 K-slice)");
                 }
             } else {
                 TRY(push(L.mlp.w0, base + w.o_w0, Wd, C), "split(mlp.0)");
@@ -1024,6 +1021,32 @@ int gecco_lower_bwd_blocks(size_t rows) { return lower_bwd_blocks(rows); }
 int gecco_lower_bwd_f32(const float* feat, const float* dF, const float* W, float* dfeat, float* partial, size_t rows,
                         int C, float eps, void* stream) {
     TRY(lower_bwd_launch(feat, dF, W, dfeat, partial, rows, C, eps, (hipStream_t)stream), "lower_bwd");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------- optimizer
+int gecco_adam_ema_step_f32(const GeccoAdamEma* a, void* stream) {
+    if (!a || !a->p || !a->g || !a->m || !a->v) return fail(-1, "adam_ema: null argument");
+    if (a->do_ema && !a->ema) return fail(-1, "adam_ema: do_ema needs the ema buffer");
+    if (a->n % 4) return fail(-2, "adam_ema: n must be a multiple of 4 (pad the flat buffers)");
+    if (a->step < 1) return fail(-2, "adam_ema: step is 1-based");
+    const uintptr_t al = (uintptr_t)a->p | (uintptr_t)a->g | (uintptr_t)a->m | (uintptr_t)a->v | (uintptr_t)a->ema;
+    if (al & 15) return fail(-2, "adam_ema: buffers must be 16-byte aligned");
+    AdamEmaArgs k{};
+    k.p = a->p; k.g = a->g; k.m = a->m; k.v = a->v; k.ema = a->ema; k.n = a->n;
+    k.beta1 = a->beta1; k.beta2 = a->beta2; k.eps = a->eps; k.weight_decay = a->weight_decay;
+    // bias corrections in double, like torch's Python scalars (torch/optim/adam.py _single_tensor_adam)
+    const double bc1 = 1.0 - pow((double)a->beta1, (double)a->step), bc2 = 1.0 - pow((double)a->beta2, (double)a->step);
+    k.step_size = (float)((double)a->lr / bc1);
+    k.bc2_sqrt = (float)sqrt(bc2);
+    k.grad_scale = a->grad_scale; k.ema_decay = a->ema_decay; k.do_ema = a->do_ema;
+    TRY(adam_ema_launch(k, (hipStream_t)stream), "adam_ema");
+    return 0;
+}
+int gecco_ema_update_f32(const float* p, float* ema, size_t n, float decay, void* stream) {
+    if (!p || !ema) return fail(-1, "ema_update: null argument");
+    if ((n % 4) || (((uintptr_t)p | (uintptr_t)ema) & 15)) return fail(-2, "ema_update: n %% 4 == 0 and 16-byte aligned buffers");
+    TRY(ema_update_launch(p, ema, n, decay, (hipStream_t)stream), "ema_update");
     return 0;
 }
 

@@ -220,3 +220,20 @@ int lift_launch(const float* x, const float* coef, const float* W, const float* 
 int lower_edm_launch(const float* feat, const float* x, const float* coef, const float* W, const float* bias,
                      const float* gn_a, const float* gn_o, float* out, float* raw, int B, int N, int C, float eps,
                      hipStream_t st);
+
+// optim.hip — Adam + EMA shadow weights in one pass over flat fp32 buffers (n % 4 == 0, 16-byte aligned)
+struct AdamEmaArgs {
+    float* p;          // parameters
+    const float* g;    // gradients (summed over ranks when grad_scale = 1 / world)
+    float* m;          // exp_avg
+    float* v;          // exp_avg_sq
+    float* ema;        // EMA shadow weights (read / written only when do_ema)
+    size_t n;
+    float beta1, beta2, eps, weight_decay;
+    float step_size;   // lr / (1 - beta1^step)
+    float bc2_sqrt;    // sqrt(1 - beta2^step)
+    float grad_scale, ema_decay;
+    int do_ema;
+};
+int adam_ema_launch(const AdamEmaArgs& a, hipStream_t st);
+int ema_update_launch(const float* p, float* ema, size_t n, float decay, hipStream_t st);

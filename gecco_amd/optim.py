@@ -1,0 +1,275 @@
+"""Optimizer of the training path: Adam fused with the EMA shadow weights, one HIP launch per step.
+
+Reference: `Diffusion.configure_optimizers` returns `torch.optim.Adam(lr=1e-4)` (diffusion.py:210-211); `EMACallback`
+wraps it in `EMAOptimizer` (ema.py:61-75), whose `step()` runs the inner optimizer and then `ema_update`
+(ema.py:187-194, 273-325).  `FusedAdamEMA` is both at once:
+
+* every parameter, its gradient, `exp_avg`, `exp_avg_sq` and its EMA shadow live as views of five flat, 16-byte aligned
+  fp32 buffers; a step is ONE `gecco_adam_ema_step_f32` launch over them (36 bytes per parameter, HBM-bound);
+* `p.grad` is a view of the flat gradient buffer, so autograd accumulates in place, a data-parallel all-reduce works
+  on slices of that buffer (`gecco_amd.distributed.BucketedGradAllReducer`) and the 1 / world_size of the gradient
+  mean folds into the kernel's read of g — no gather / scatter of gradients anywhere;
+* the state-dict wire format is the reference's: `state_dict()` returns `EMAOptimizer.state_dict()`'s dict
+  ({"opt": <torch.optim.Adam state_dict>, "ema": tuple of tensors, "current_step", "decay", "every_n_steps"},
+  ema.py:369-388) and `load_state_dict` accepts it (or a bare Adam state dict), so Lightning checkpoints written by the
+  reference resume here and vice versa (`gecco_amd/checkpoint.py`).
+
+There is no CPU fallback: parameters must live on the HIP device when `step()` runs.
+"""
+from __future__ import annotations
+
+import contextlib
+import ctypes as C
+from typing import Any, Iterable
+
+import torch
+from torch import Tensor
+
+from . import _lib
+
+
+def _align4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+class FusedAdamEMA(torch.optim.Optimizer):
+    """torch.optim.Adam (single param-group hyper-parameters, no amsgrad / maximize) + EMA of the parameters.
+
+    `ema_decay=None` disables the shadow weights (plain fused Adam).  The EMA is updated on steps where
+    `current_step % every_n_steps == 0`, counted like `EMAOptimizer` (ema.py:296-299)."""
+
+    def __init__(self, params: Iterable[Tensor] | Iterable[dict], lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.0, ema_decay: float | None = 0.9999, every_n_steps: int = 1,
+                 current_step: int = 0):
+        if ema_decay is not None and not 0.0 <= ema_decay <= 1.0:
+            raise ValueError("EMA decay value must be between 0 and 1")
+        defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
+                        foreach=None, capturable=False, differentiable=False, fused=None, decoupled_weight_decay=False)
+        super().__init__(params, defaults)
+        self.decay = ema_decay
+        self.every_n_steps = every_n_steps
+        self.current_step = current_step          # EMAOptimizer's counter (ema.py:288)
+        self.in_saving_ema_model_context = False  # ema.py:378-383
+        self.save_original_optimizer_state = False
+        self._flat: dict[str, Tensor] | None = None
+        self._spans: list[tuple[Tensor, int, int]] = []   # (param, offset, numel) in param-group order
+        self._adam_step = 0
+        self.grad_scale = 1.0                     # set by a summing gradient all-reduce to 1 / world_size
+
+    # ------------------------------------------------------------------------------------------ flat storage
+    def all_parameters(self) -> list[Tensor]:
+        return [p for g in self.param_groups for p in g["params"]]
+
+    def _build(self) -> None:
+        ps = self.all_parameters()
+        if not ps:
+            raise ValueError("FusedAdamEMA: no parameters")
+        dev = ps[0].device
+        if dev.type != "cuda":
+            raise _lib.GeccoHipError("FusedAdamEMA needs parameters on the HIP device (no CPU fallback)")
+        if any(p.dtype != torch.float32 or p.device != dev for p in ps):
+            raise _lib.GeccoHipError("FusedAdamEMA: all parameters must be fp32 on one device")
+        off, spans = 0, []
+        for p in ps:
+            spans.append((p, off, p.numel()))
+            off += _align4(p.numel())             # every view starts 16-byte aligned
+        n = off
+        old = self._flat
+        flat = {k: torch.zeros(n, dtype=torch.float32, device=dev) for k in ("p", "g", "m", "v")}
+        flat["ema"] = torch.zeros(n, dtype=torch.float32, device=dev) if self.decay is not None else None
+        with torch.no_grad():
+            for i, (p, o, k) in enumerate(spans):
+                flat["p"][o:o + k].copy_(p.detach().reshape(-1))
+                if p.grad is not None:
+                    flat["g"][o:o + k].copy_(p.grad.reshape(-1))
+                if old is not None and i < len(self._spans) and self._spans[i][0] is p:   # keep state across a rebuild
+                    oo = self._spans[i][1]
+                    for key in ("m", "v", "ema"):
+                        if flat[key] is not None and old.get(key) is not None:
+                            flat[key][o:o + k].copy_(old[key][oo:oo + k])
+                elif flat["ema"] is not None:
+                    flat["ema"][o:o + k].copy_(p.detach().reshape(-1))   # EMA starts as a copy (ema.py:283-291)
+                p.data = flat["p"][o:o + k].view(p.shape)
+                p.grad = flat["g"][o:o + k].view(p.shape)
+        self._flat, self._spans = flat, spans
+
+    def _ensure(self) -> None:
+        """(Re)build the flat views when parameters were added, moved or re-allocated since the last step."""
+        ps = self.all_parameters()
+        ok = self._flat is not None and len(ps) == len(self._spans)
+        if ok:
+            base = self._flat["p"].data_ptr()
+            for (p, o, k), q in zip(self._spans, ps):
+                if p is not q or q.data_ptr() != base + 4 * o:
+                    ok = False
+                    break
+        if not ok:
+            self._build()
+
+    def flat_grad(self) -> Tensor:
+        """The flat gradient buffer every p.grad is a view of (what a data-parallel all-reduce operates on)."""
+        self._ensure()
+        return self._flat["g"]
+
+    def spans(self) -> list[tuple[Tensor, int, int]]:
+        self._ensure()
+        return list(self._spans)
+
+    def view_of(self, key: str, i: int) -> Tensor:
+        p, o, k = self._spans[i]
+        return self._flat[key][o:o + k].view(p.shape)
+
+    @property
+    def ema_params(self) -> tuple[Tensor, ...]:
+        self._ensure()
+        if self._flat["ema"] is None:
+            return ()
+        return tuple(self.view_of("ema", i) for i in range(len(self._spans)))
+
+    # ------------------------------------------------------------------------------------------ step
+    def zero_grad(self, set_to_none: bool = False) -> None:   # noqa: ARG002 — the views stay, the buffer is cleared
+        self._ensure()
+        self._flat["g"].zero_()
+        for p, o, k in self._spans:
+            if p.grad is None or p.grad.data_ptr() != self._flat["g"].data_ptr() + 4 * o:
+                p.grad = self._flat["g"][o:o + k].view(p.shape)
+
+    def _gather_foreign_grads(self) -> None:
+        """A caller that reset p.grad (zero_grad(set_to_none=True) on the module, then backward) left gradients in
+        tensors of their own: copy them into the flat buffer and restore the views."""
+        gb = self._flat["g"].data_ptr()
+        src, dst = [], []
+        for p, o, k in self._spans:
+            v = self._flat["g"][o:o + k].view(p.shape)
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != gb + 4 * o:
+                src.append(p.grad)
+                dst.append(v)
+            else:
+                continue
+            p.grad = v
+        if src:
+            torch._foreach_copy_(dst, src)
+
+    def _should_update_at_step(self) -> bool:
+        return self.decay is not None and self.current_step % self.every_n_steps == 0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        self._ensure()
+        self._gather_foreign_grads()
+        g = self.param_groups[0]
+        if len(self.param_groups) > 1 and any(
+                (h["lr"], h["betas"], h["eps"], h["weight_decay"]) != (g["lr"], g["betas"], g["eps"], g["weight_decay"])
+                for h in self.param_groups[1:]):
+            raise NotImplementedError("FusedAdamEMA: one set of hyper-parameters for all param groups")
+        if g.get("amsgrad") or g.get("maximize"):
+            raise NotImplementedError("FusedAdamEMA: amsgrad / maximize are not supported")
+        self._adam_step += 1
+        f = self._flat
+        do_ema = self._should_update_at_step()
+        a = _lib.GeccoAdamEma(f["p"].data_ptr(), f["g"].data_ptr(), f["m"].data_ptr(), f["v"].data_ptr(),
+                              f["ema"].data_ptr() if f["ema"] is not None else None, f["p"].numel(), float(g["lr"]),
+                              float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
+                              self._adam_step, float(self.grad_scale), float(self.decay if self.decay is not None else 0.0),
+                              int(do_ema))
+        _lib.check(_lib.load().gecco_adam_ema_step_f32(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                   "gecco_adam_ema_step_f32")
+        self.current_step += 1
+        return loss
+
+    # ------------------------------------------------------------------------------------------ EMA weight swap
+    def join(self) -> None:   # EMAOptimizer API (its update runs on a side stream / thread; ours is in-stream)
+        pass
+
+    def switch_main_parameter_weights(self, saving_ema_model: bool = False) -> None:
+        """In-place swap of the parameters with their EMA shadows (ema.py:335-339)."""
+        self._ensure()
+        if self._flat["ema"] is None:
+            raise RuntimeError("EMA is disabled (ema_decay=None)")
+        self.in_saving_ema_model_context = saving_ema_model
+        tmp = self._flat["p"].clone()
+        self._flat["p"].copy_(self._flat["ema"])
+        self._flat["ema"].copy_(tmp)
+
+    @contextlib.contextmanager
+    def swap_ema_weights(self, enabled: bool = True):
+        if enabled:
+            self.switch_main_parameter_weights()
+        try:
+            yield
+        finally:
+            if enabled:
+                self.switch_main_parameter_weights()
+
+    # ------------------------------------------------------------------------------------------ wire format
+    def _adam_state_dict(self) -> dict[str, Any]:
+        """What torch.optim.Adam.state_dict() returns for the same parameters (packed ids, per-parameter state)."""
+        self._ensure()
+        state, idx, groups = {}, 0, []
+        for g in self.param_groups:
+            ids = []
+            for _ in g["params"]:
+                if self._adam_step > 0:
+                    state[idx] = {"step": torch.tensor(float(self._adam_step)),
+                                  "exp_avg": self.view_of("m", idx).clone(), "exp_avg_sq": self.view_of("v", idx).clone()}
+                ids.append(idx)
+                idx += 1
+            groups.append({**{k: v for k, v in g.items() if k != "params"}, "params": ids})
+        return {"state": state, "param_groups": groups}
+
+    def state_dict(self) -> dict[str, Any]:
+        opt = self._adam_state_dict()
+        if self.decay is None or self.save_original_optimizer_state:
+            return opt
+        # in the context of saving an EMA model the EMA weights sit in the modules' own weights (ema.py:378-383)
+        ema = tuple(p.detach().clone() for p in self.all_parameters()) if self.in_saving_ema_model_context \
+            else tuple(t.clone() for t in self.ema_params)
+        return {"opt": opt, "ema": ema, "current_step": self.current_step, "decay": self.decay,
+                "every_n_steps": self.every_n_steps}
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict: dict[str, Any]) -> None:
+        self._ensure()
+        opt = state_dict["opt"] if "opt" in state_dict else state_dict
+        n = len(self._spans)
+        ids = [i for g in opt["param_groups"] for i in g["params"]]
+        if len(ids) != n:
+            raise ValueError(f"loaded state dict has {len(ids)} parameters, the optimizer {n}")
+        for g, sg in zip(self.param_groups, opt["param_groups"]):
+            for k in ("lr", "betas", "eps", "weight_decay"):
+                if k in sg:
+                    g[k] = tuple(sg[k]) if k == "betas" else sg[k]
+        steps = set()
+        self._flat["m"].zero_()
+        self._flat["v"].zero_()
+        for pos, i in enumerate(ids):
+            st = opt["state"].get(i)
+            if st is None:
+                continue
+            self.view_of("m", pos).copy_(st["exp_avg"])
+            self.view_of("v", pos).copy_(st["exp_avg_sq"])
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise NotImplementedError("FusedAdamEMA: parameters with different Adam step counts")
+        self._adam_step = steps.pop() if steps else 0
+        if "opt" in state_dict:
+            if self._flat["ema"] is None:
+                self.decay = state_dict["decay"]
+                self._build_ema_buffer()
+            ema = state_dict["ema"]
+            if len(ema) != n:
+                raise ValueError(f"loaded EMA has {len(ema)} tensors, the optimizer {n} parameters")
+            for pos, t in enumerate(ema):
+                self.view_of("ema", pos).copy_(t)
+            self.current_step = state_dict["current_step"]
+            self.decay = state_dict["decay"]
+            self.every_n_steps = state_dict["every_n_steps"]
+
+    def _build_ema_buffer(self) -> None:
+        self._flat["ema"] = self._flat["p"].clone()

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GECCO_ABI_VERSION 4
+#define GECCO_ABI_VERSION 5
 
 int gecco_abi_version(void);
 const char* gecco_build_arch(void);   /* "gfx950" */
@@ -368,6 +368,28 @@ int gecco_lift_bwd_f32(const float* dY, const float* xin, float* partial, int B,
 int gecco_lower_bwd_f32(const float* feat, const float* dF, const float* W, float* dfeat, float* partial, size_t rows,
                         int C, float eps, void* stream);
 int gecco_lower_bwd_blocks(size_t rows);
+
+/* ---- optimizer step -------------------------------------------------------------------
+ * torch.optim.Adam(lr=1e-4) of Diffusion.configure_optimizers (diffusion.py:210-211) fused with the EMA shadow-weight
+ * update the reference runs after every step (EMAOptimizer.step / update, ema.py:273-325; ema_update, ema.py:187-194:
+ * ema = ema * decay + (1 - decay) * param): ONE pass over flat, 16-byte aligned fp32 buffers of n elements (n % 4 == 0),
+ * 36 bytes per parameter.  Same operation order as torch's single-tensor Adam, in fp32:
+ *   g' = g * grad_scale (+ weight_decay * p);  m += (1 - beta1) (g' - m);  v = beta2 v + (1 - beta2) g'^2;
+ *   p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps);  ema = decay * ema + (1 - decay) * p.
+ * `step` is the 1-based count of this update (Adam's state["step"] after it).  `grad_scale` folds the 1 / world_size of
+ * a summing gradient all-reduce into the read of g.  ema may be NULL when do_ema == 0. */
+typedef struct GeccoAdamEma {
+    float* p; const float* g; float* m; float* v; float* ema;
+    size_t n;
+    float lr, beta1, beta2, eps, weight_decay;
+    int step;
+    float grad_scale;
+    float ema_decay;
+    int do_ema;
+} GeccoAdamEma;
+int gecco_adam_ema_step_f32(const GeccoAdamEma* a, void* stream);
+/* ema = ema * decay + (1 - decay) * p alone (ema_update, ema.py:187-194), for optimizers other than the fused Adam. */
+int gecco_ema_update_f32(const float* p, float* ema, size_t n, float decay, void* stream);
 
 #ifdef __cplusplus
 }

@@ -63,9 +63,9 @@ class GeccoGemm(C.Structure):
 
 
 class GeccoAdamEma(C.Structure):
-    _fields_ = [("p", c_f), ("g", c_f), ("m", c_f), ("v", c_f), ("ema", c_f), ("n", C.c_size_t), ("lr", C.c_float),
-                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float),
-                ("step", C.c_int), ("grad_scale", C.c_float), ("ema_decay", C.c_float), ("do_ema", C.c_int)]
+    _fields_ = [("p", c_f), ("g", c_f), ("m", c_f), ("v", c_f), ("ema", c_f), ("n", C.c_size_t), ("lr", C.c_double),
+                ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("weight_decay", C.c_double),
+                ("ema_decay", C.c_double), ("grad_scale", C.c_float), ("step", C.c_int), ("do_ema", C.c_int)]
 
 
 i, sz, vp, fl, db = C.c_int, C.c_size_t, C.c_void_p, C.c_float, C.c_double
@@ -119,6 +119,8 @@ SIGNATURES = {
     "gecco_gaussian_reparam": (i, [vp, vp, vp, vp, sz, i, i, i, vp]),
     "gecco_uvl_reparam": (i, [vp, vp, vp, vp, db, vp, i, i, i, i, vp]),
     "gecco_gaussian_act_f32": (i, [vp, vp, vp, sz, i, vp]),
+    "gecco_relu_f32": (i, [vp, vp, sz, vp]),
+    "gecco_relu_bwd_f32": (i, [vp, vp, vp, sz, vp]),
     "gecco_sampler_add_noise_f64": (i, [vp, vp, sz, vp, vp, i, i, vp, vp, vp, sz, i, vp]),
     "gecco_sampler_add_noise_f32": (i, [vp, vp, sz, vp, vp, i, vp, vp, sz, i, vp]),
     "gecco_sampler_euler_f64": (i, [vp, vp, vp, vp, vp, vp, vp, vp, sz, i, vp]),
@@ -139,7 +141,7 @@ SIGNATURES = {
     "gecco_lower_bwd_f32": (i, [vp, vp, vp, vp, vp, sz, i, fl, vp]),
     "gecco_lower_bwd_blocks": (i, [sz]),
     "gecco_adam_ema_step_f32": (i, [C.POINTER(GeccoAdamEma), vp]),
-    "gecco_ema_update_f32": (i, [vp, vp, sz, fl, vp]),
+    "gecco_ema_update_f32": (i, [vp, vp, sz, db, vp]),
 }
 
 _lib = None

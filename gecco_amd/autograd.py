@@ -166,6 +166,19 @@ class GaussActFn(torch.autograd.Function):
         return du, dalpha, None
 
 
+class ReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u):
+        y = hip_ops.relu(_f(u))
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return hip_ops.relu_bwd(y, _f(dy))
+
+
 # ------------------------------------------------------------------------------------------- attention
 def _softmax(S: Tensor, scale: float) -> Tensor:
     lib = _lib.load()
@@ -393,9 +406,12 @@ def mlp(mod, x):
         x = LinearFn.apply(x, lin.weight, lin.bias)
         if i + 1 < len(mods):
             act = mods[i + 1]
-            if not isinstance(act, GaussianActivation):
-                raise NotImplementedError(f"training on HIP needs GaussianActivation (got {type(act).__name__})")
-            x = GaussActFn.apply(x, act.alpha, act.normalized)
+            if isinstance(act, GaussianActivation):
+                x = GaussActFn.apply(x, act.alpha, act.normalized)
+            elif isinstance(act, torch.nn.ReLU):
+                x = ReluFn.apply(x)
+            elif not isinstance(act, torch.nn.Identity):
+                raise NotImplementedError(f"training on HIP: no backward for activation {type(act).__name__}")
         i += 2
     return x
 

@@ -124,7 +124,8 @@ int linear(const float* A, const float* W, const float* bias, const float* pa, c
     g.stats = stats; g.B = B; g.rows = rows; g.K = K; g.Nout = Nout;
     g.lda = K; g.ldw = K; g.ldc = Nout; g.ldr = Nout; g.act = act;
     g.precision = 0; g.w_img = nullptr;
-    if (act && !alpha) return -6;
+    if (act < 0 || act > 3) return -6;
+    if ((act == 1 || act == 2) && !alpha) return -6;
     g.a_f16 = a_f16; g.c_f16 = c_f16;   // fp16 tensors exist only between the fp16 kernels (st_forward checks support)
     const bool fast = precision == 1 ? gemm_f32_dma_supported(g, 1) : precision == 2 ? gemm_f16_dma_supported(g) : false;
     if ((a_f16 || c_f16) && !(fast && precision == 2 && (wsplit || img_ready))) return -9;
@@ -216,6 +217,7 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
     if (!st || !x || !t) return fail(-1, "set_transformer: null argument");
     if (st->I != 64) return fail(-3, "set_transformer: num_inducers must be 64 (got %d)", st->I);
     if (st->C % st->H || st->C % st->G || st->C % 4) return fail(-3, "set_transformer: bad feature_dim %d", st->C);
+    if (st->act < 0 || st->act > 3) return fail(-3, "set_transformer: act must be 0 (identity), 1 / 2 (GaussianActivation normalized / raw) or 3 (ReLU)");
     STWorkspace w = carve_st(st, B, N, ws);
     if (ws_bytes < w.bytes) return fail(-7, "set_transformer: workspace too small (%zu < %zu)", ws_bytes, w.bytes);
     const int C = st->C, I = st->I, H = st->H, G = st->G, Wd = st->width, ctx = st->ctx_dim, act = st->act;
@@ -346,7 +348,7 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
                 ca.t = t; ca.ctx_dim = ctx; ca.G = G; ca.eps = 1e-5f;
                 float* hdst = (h_out && h_out[li]) ? h_out[li] : w.h;
                 ca.h_out = hdst; ca.kvh = w.kvh; ca.B = B;
-                if (act && !L.bmlp.alpha) return fail(-6, "inducer chain: activation needs alpha");
+                if ((act == 1 || act == 2) && !L.bmlp.alpha) return fail(-6, "inducer chain: GaussianActivation needs alpha");
                 TRY(inducer_chain_f16_launch(ca, C, Wd, s), "inducer chain");
                 h = hdst;
                 kvh_done = true;
@@ -407,7 +409,7 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
             MlpArgs ma{};
             ma.x = x; ma.pro_a = w.a2; ma.pro_o = w.o2; ma.w_stream = im + w.o_mf;
             ma.b0 = L.mlp.b0; ma.b2 = L.mlp.b2; ma.alpha = L.mlp.alpha; ma.act = act; ma.stats = so; ma.B = B; ma.rows = N;
-            if (act && !L.mlp.alpha) return fail(-6, "mlp: activation needs alpha");
+            if ((act == 1 || act == 2) && !L.mlp.alpha) return fail(-6, "mlp: GaussianActivation needs alpha");
             TRY(mlp_fused_f16_launch(ma, C, Wd, s), "mlp (fused)");
             sx = w.stats_x;
             sT = Tn;
@@ -553,7 +555,7 @@ int gecco_linear_astat_f16(const float* x, const float* pro_a, const float* pro_
     g.B = B; g.rows = rows; g.K = K; g.Nout = Nout1 + (C2 ? Nout2 : 0); g.lda = K; g.ldw = K; g.ldc = Nout1; g.ldr = Nout1;
     g.precision = 2; g.w_img = img; g.c_f16 = 1; g.hm_hd = head_dim;
     if (C2) { g.C2 = static_cast<float*>(C2); g.bias2 = bias2; g.n_split = Nout1; g.ldc2 = Nout2; }
-    if (act && !alpha) return fail(-6, "linear_astat: activation needs alpha");
+    if ((act == 1 || act == 2) && !alpha) return fail(-6, "linear_astat: GaussianActivation needs alpha");
     if (head_dim < 0) return fail(-2, "linear_astat: head_dim < 0");
     if (!gemm_f16_astat_supported(g))
         return fail(-2, "linear_astat: needs rows %% 128 == 0, Nout %% 128 == 0, K in {128, 256, 384, 512}; head-major: "
@@ -566,7 +568,7 @@ int gecco_mlp_fused_f16(float* x, const float* pro_a, const float* pro_o, const 
                         const float* b2, const float* alpha, int act, float* stats, int B, int rows, int C, int width,
                         void* wsplit, void* stream) {
     if (!x || !pro_a || !pro_o || !wsplit || ((W0 == nullptr) != (W2 == nullptr))) return fail(-1, "mlp_fused: null argument");
-    if (act && !alpha) return fail(-6, "mlp_fused: activation needs alpha");
+    if ((act == 1 || act == 2) && !alpha) return fail(-6, "mlp_fused: GaussianActivation needs alpha");
     if (!mlp_fused_f16_supported(C, width, rows))
         return fail(-2, "mlp_fused: needs C in {128, 256, 384}, width == 2 C, rows %% 128 == 0");
     hipStream_t s = (hipStream_t)stream;
@@ -924,6 +926,14 @@ int gecco_uvl_reparam(const void* x, const float* K, const float* uvl_mean, cons
         "uvl_reparam");
     return 0;
 }
+int gecco_relu_f32(const float* x, float* y, size_t n, void* stream) {
+    TRY(relu_launch(x, y, n, (hipStream_t)stream), "relu");
+    return 0;
+}
+int gecco_relu_bwd_f32(const float* y, const float* dy, float* du, size_t n, void* stream) {
+    TRY(relu_bwd_launch(y, dy, du, n, (hipStream_t)stream), "relu_bwd");
+    return 0;
+}
 int gecco_gaussian_act_f32(const float* x, const float* alpha, float* y, size_t n, int normalized, void* stream) {
     TRY(gaussian_act_launch(x, alpha, y, n, normalized, (hipStream_t)stream), "gaussian_act");
     return 0;
@@ -1034,16 +1044,18 @@ int gecco_adam_ema_step_f32(const GeccoAdamEma* a, void* stream) {
     if (al & 15) return fail(-2, "adam_ema: buffers must be 16-byte aligned");
     AdamEmaArgs k{};
     k.p = a->p; k.g = a->g; k.m = a->m; k.v = a->v; k.ema = a->ema; k.n = a->n;
-    k.beta1 = a->beta1; k.beta2 = a->beta2; k.eps = a->eps; k.weight_decay = a->weight_decay;
-    // bias corrections in double, like torch's Python scalars (torch/optim/adam.py _single_tensor_adam)
-    const double bc1 = 1.0 - pow((double)a->beta1, (double)a->step), bc2 = 1.0 - pow((double)a->beta2, (double)a->step);
-    k.step_size = (float)((double)a->lr / bc1);
+    // every derived scalar in double first, like torch's Python scalars (torch/optim/adam.py _single_tensor_adam:
+    // 1 - beta1, 1 - beta2, bias corrections, lr / bc1; ema.py:187-194: 1 - decay), then one rounding to fp32
+    k.beta2 = (float)a->beta2; k.eps = (float)a->eps; k.weight_decay = (float)a->weight_decay;
+    k.w1 = (float)(1.0 - a->beta1); k.w2 = (float)(1.0 - a->beta2);
+    const double bc1 = 1.0 - pow(a->beta1, (double)a->step), bc2 = 1.0 - pow(a->beta2, (double)a->step);
+    k.step_size = (float)(a->lr / bc1);
     k.bc2_sqrt = (float)sqrt(bc2);
-    k.grad_scale = a->grad_scale; k.ema_decay = a->ema_decay; k.do_ema = a->do_ema;
+    k.grad_scale = a->grad_scale; k.ema_decay = (float)a->ema_decay; k.ema_w = (float)(1.0 - a->ema_decay); k.do_ema = a->do_ema;
     TRY(adam_ema_launch(k, (hipStream_t)stream), "adam_ema");
     return 0;
 }
-int gecco_ema_update_f32(const float* p, float* ema, size_t n, float decay, void* stream) {
+int gecco_ema_update_f32(const float* p, float* ema, size_t n, double decay, void* stream) {
     if (!p || !ema) return fail(-1, "ema_update: null argument");
     if ((n % 4) || (((uintptr_t)p | (uintptr_t)ema) & 15)) return fail(-2, "ema_update: n %% 4 == 0 and 16-byte aligned buffers");
     TRY(ema_update_launch(p, ema, n, decay, (hipStream_t)stream), "ema_update");

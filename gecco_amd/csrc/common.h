@@ -42,3 +42,10 @@ __device__ __forceinline__ float gauss_act(float u, float neg_inv_2a2, bool norm
     // (y - 0.7) / 0.28 as a multiply by the rounded reciprocal: <= 1 ulp from the IEEE division, ~9 VALU fewer
     return normalized ? (y - 0.7f) * (1.0f / 0.28f) : y;
 }
+// Epilogue activation by code (GemmArgs::act): 1 / 2 = GaussianActivation normalized / raw, 3 = ReLU (the reference's
+// default `activation=nn.ReLU`, models/mlp.py:12, set_transformer.py:81,133).  The code is wave-uniform.
+__device__ __forceinline__ float act_apply(float u, float neg_inv_2a2, int act) {
+    if (act == 3) return fmaxf(u, 0.f);
+    return gauss_act(u, neg_inv_2a2, act == 1);
+}
+__device__ __forceinline__ bool act_is_gauss(int act) { return act == 1 || act == 2; }

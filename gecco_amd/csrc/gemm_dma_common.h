@@ -74,8 +74,9 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, const Tile& t, f32x1
     const float* bias_seg = t.bias_seg;
     float* Cseg = t.Cseg;
     const int ldc_seg = t.ldc_seg;
-    const bool has_act = g.act != 0, act_norm = g.act == 1;
-    const float neg_inv_2a2 = has_act ? -1.0f / (2.0f * g.alpha[0] * g.alpha[0]) : 0.f;
+    const bool has_act = g.act != 0;
+    const int act_mode = g.act;
+    const float neg_inv_2a2 = act_is_gauss(g.act) ? -1.0f / (2.0f * g.alpha[0] * g.alpha[0]) : 0.f;
     float* Cb = Cseg + (size_t)b * g.rows * ldc_seg;
     const float* Rb = g.residual ? g.residual + (size_t)b * g.rows * g.ldr : nullptr;
     float* Tt = smem + wave * 32 * D_TP;
@@ -117,7 +118,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, const Tile& t, f32x1
                 for (int e = 0; e < 16; ++e) val[e] += bias;
                 if (has_act) {
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) val[e] = gauss_act(val[e], neg_inv_2a2, act_norm);
+                    for (int e = 0; e < 16; ++e) val[e] = act_apply(val[e], neg_inv_2a2, act_mode);
                 }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) Tt[mfma_row(e, h) * D_TP + jj * 32 + r] = val[e];

@@ -173,8 +173,9 @@ __global__ __launch_bounds__(S_NT, 2) void gemm_f16_astat_kernel(GemmArgs g) {
 #pragma unroll
     for (int p = 0; p < NS; ++p) issue(p);             // tilesN * NK >= NK >= NS stages exist
 
-    const bool has_act = g.act != 0, act_norm = g.act == 1;
-    const float neg_inv_2a2 = has_act ? -1.0f / (2.0f * g.alpha[0] * g.alpha[0]) : 0.f;
+    const bool has_act = g.act != 0;
+    const int act_mode = g.act;
+    const float neg_inv_2a2 = act_is_gauss(g.act) ? -1.0f / (2.0f * g.alpha[0] * g.alpha[0]) : 0.f;
     f32x16 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -232,8 +233,8 @@ __global__ __launch_bounds__(S_NT, 2) void gemm_f16_astat_kernel(GemmArgs g) {
                 acc[j][e0] = 0.f;
                 acc[j][e0 + 1] = 0.f;
                 if (has_act) {
-                    v0 = gauss_act(v0, neg_inv_2a2, act_norm);
-                    v1 = gauss_act(v1, neg_inv_2a2, act_norm);
+                    v0 = act_apply(v0, neg_inv_2a2, act_mode);
+                    v1 = act_apply(v1, neg_inv_2a2, act_mode);
                 }
                 f16x2 pk;
                 pk[0] = (_Float16)v0;

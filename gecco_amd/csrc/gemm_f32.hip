@@ -157,8 +157,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_f32_kernel(GemmArgs g) {
 #endif
     };
 
-    const float neg_inv_2a2 = g.act ? -1.0f / (2.0f * g.alpha[0] * g.alpha[0]) : 0.f;
-    const bool has_act = g.act != 0, act_norm = g.act == 1;
+    const float neg_inv_2a2 = act_is_gauss(g.act) ? -1.0f / (2.0f * g.alpha[0] * g.alpha[0]) : 0.f;
+    const bool has_act = g.act != 0;
+    const int act_mode = g.act;
     constexpr int WR = TM * 32, WC = TN * 32;       // this wave's output tile
     constexpr int TP = WC + 4;                      // padded row stride of the transpose tile
     constexpr int LPR = WC / 4;                     // lanes per row (16-byte chunks)
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         float val = acc[i][j][e] + bias;
-                        if (has_act) val = gauss_act(val, neg_inv_2a2, act_norm);
+                        if (has_act) val = act_apply(val, neg_inv_2a2, act_mode);
                         Tt[(i * 32 + mfma_row(e, h)) * TP + j * 32 + r] = val;
                     }
                 }
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_f32_kernel(GemmArgs g) {
                 for (int e = 0; e < 16; ++e) val[e] += bias;
                 if (has_act) {
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) val[e] = gauss_act(val[e], neg_inv_2a2, act_norm);
+                    for (int e = 0; e < 16; ++e) val[e] = act_apply(val[e], neg_inv_2a2, act_mode);
                 }
                 if (Rb) {  // 16 independent loads in flight, then one add pass
                     f32x16 rr;

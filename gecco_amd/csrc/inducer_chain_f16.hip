@@ -409,8 +409,9 @@ __global__ __launch_bounds__(CH_NT, 1) void inducer_chain_f16_kernel(ChainArgs g
         return reinterpret_cast<unsigned*>(abuf + row * RS + 2 * col);
     };
 
-    const bool has_act = g.act != 0, act_norm = g.act == 1;
-    const float neg_inv_2a2 = has_act ? -1.0f / (2.0f * g.alpha[0] * g.alpha[0]) : 0.f;
+    const bool has_act = g.act != 0;
+    const int act_mode = g.act;
+    const float neg_inv_2a2 = act_is_gauss(g.act) ? -1.0f / (2.0f * g.alpha[0] * g.alpha[0]) : 0.f;
 
     // ================= GEMM 1: h0 = merged16 Wpo^T; norm_1; y16 -> A buffer
     f32x16 acc1[NT1];
@@ -445,8 +446,8 @@ __global__ __launch_bounds__(CH_NT, 1) void inducer_chain_f16_kernel(ChainArgs g
         for (int p = 0; p < 8; ++p) {
             float v0 = a0[2 * p] + bias, v1 = a0[2 * p + 1] + bias;
             if (has_act) {
-                v0 = gauss_act(v0, neg_inv_2a2, act_norm);
-                v1 = gauss_act(v1, neg_inv_2a2, act_norm);
+                v0 = act_apply(v0, neg_inv_2a2, act_mode);
+                v1 = act_apply(v1, neg_inv_2a2, act_mode);
             }
             upk[t][p] = pair_rows(v0, v1);
         }

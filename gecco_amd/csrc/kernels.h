@@ -15,7 +15,7 @@ struct GemmArgs {
     float* stats;           // (B, tilesM, 2, Nout) or null
     int B, rows, K, Nout;
     int lda, ldw, ldc, ldr;
-    int act;                // 0 none, 1 gaussian normalized, 2 gaussian raw
+    int act;                // 0 none, 1 gaussian normalized, 2 gaussian raw, 3 ReLU
     int precision;          // 0 exact fp32 MFMA, 1 split-bf16, 2 fp16 (1 and 2 need w_img)
     const void* w_img;      // tiled image of W: bf16 hi | lo (split_bf16_tiled_launch) or fp16 (split_f16_tiled_launch)
     // optional second output segment, LDS-DMA kernel only: columns [n_split, Nout) are a second linear over the same
@@ -203,6 +203,8 @@ int gaussian_reparam_launch(const void* x, const float* mean, const float* sigma
 int uvl_reparam_launch(const void* x, const float* K, const float* mean, const float* std_, double logit_scale, void* y,
                        int B, int N, int inverse, int is_f64, hipStream_t st);
 int gaussian_act_launch(const float* x, const float* alpha, float* y, size_t n, int normalized, hipStream_t st);
+int relu_launch(const float* x, float* y, size_t n, hipStream_t st);
+int relu_bwd_launch(const float* y, const float* dy, float* du, size_t n, hipStream_t st);   // du = dy * (y > 0)
 
 // pointwise.hip
 int stats_row_tile(int rows);
@@ -229,11 +231,12 @@ struct AdamEmaArgs {
     float* v;          // exp_avg_sq
     float* ema;        // EMA shadow weights (read / written only when do_ema)
     size_t n;
-    float beta1, beta2, eps, weight_decay;
+    float beta2, eps, weight_decay;
+    float w1, w2;      // 1 - beta1, 1 - beta2 (formed in double like torch's Python scalars, then rounded)
     float step_size;   // lr / (1 - beta1^step)
     float bc2_sqrt;    // sqrt(1 - beta2^step)
-    float grad_scale, ema_decay;
+    float grad_scale, ema_decay, ema_w;   // ema_w = 1 - decay
     int do_ema;
 };
 int adam_ema_launch(const AdamEmaArgs& a, hipStream_t st);
-int ema_update_launch(const float* p, float* ema, size_t n, float decay, hipStream_t st);
+int ema_update_launch(const float* p, float* ema, size_t n, double decay, hipStream_t st);

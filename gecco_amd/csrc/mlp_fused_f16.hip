@@ -279,8 +279,9 @@ __global__ __launch_bounds__(MF_NT, 1) void mlp_fused_f16_kernel(MlpArgs g) {
         for (int e = 0; e < 16; ++e) a[e] = 0.f;
     };
 
-    const bool has_act = g.act != 0, act_norm = g.act == 1;
-    const float neg_inv_2a2 = has_act ? -1.0f / (2.0f * g.alpha[0] * g.alpha[0]) : 0.f;
+    const bool has_act = g.act != 0;
+    const int act_mode = g.act;
+    const float neg_inv_2a2 = act_is_gauss(g.act) ? -1.0f / (2.0f * g.alpha[0] * g.alpha[0]) : 0.f;
 
     f32x16 acc2[NT1][2];   // the 128 x C result: this wave's 32 rows x (64 columns of every output tile)
 #pragma unroll
@@ -304,8 +305,8 @@ __global__ __launch_bounds__(MF_NT, 1) void mlp_fused_f16_kernel(MlpArgs g) {
             for (int p = 0; p < 8; ++p) {
                 float v0 = a[2 * p] + bias, v1 = a[2 * p + 1] + bias;
                 if (has_act) {
-                    v0 = gauss_act(v0, neg_inv_2a2, act_norm);
-                    v1 = gauss_act(v1, neg_inv_2a2, act_norm);
+                    v0 = act_apply(v0, neg_inv_2a2, act_mode);
+                    v1 = act_apply(v1, neg_inv_2a2, act_mode);
                 }
                 const unsigned own = mf_pack2(v0, v1);
                 // even lanes keep row 2p of columns (n, n + 1), odd lanes row 2p + 1 of (n - 1, n)

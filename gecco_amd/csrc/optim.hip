@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(AdamEmaArgs a) {
     f32x4* __restrict__ m4 = reinterpret_cast<f32x4*>(a.m);
     f32x4* __restrict__ v4 = reinterpret_cast<f32x4*>(a.v);
     f32x4* __restrict__ e4 = reinterpret_cast<f32x4*>(a.ema);
-    const float w1 = 1.0f - a.beta1, w2 = 1.0f - a.beta2, we = 1.0f - a.ema_decay;
+    const float w1 = a.w1, w2 = a.w2, we = a.ema_w;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         f32x4 p = p4[i], g = GECCO_NT_LOAD(g4 + i), m = m4[i], v = v4[i];
 #pragma unroll
@@ -53,9 +53,8 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(AdamEmaArgs a) {
 }
 
 __global__ __launch_bounds__(256) void ema_only_kernel(const float* __restrict__ p, float* __restrict__ ema, size_t n,
-                                                       float decay) {
+                                                       float decay, float we) {
     const size_t n4 = n / 4;
-    const float we = 1.0f - decay;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const f32x4 x = reinterpret_cast<const f32x4*>(p)[i];
         f32x4 s = reinterpret_cast<f32x4*>(ema)[i];
@@ -79,9 +78,9 @@ int adam_ema_launch(const AdamEmaArgs& a, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-int ema_update_launch(const float* p, float* ema, size_t n, float decay, hipStream_t st) {
+int ema_update_launch(const float* p, float* ema, size_t n, double decay, hipStream_t st) {
     if (n % 4) return -2;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(ema_only_kernel, dim3(grid_for4(n)), dim3(256), 0, st, p, ema, n, decay);
+    hipLaunchKernelGGL(ema_only_kernel, dim3(grid_for4(n)), dim3(256), 0, st, p, ema, n, (float)decay, (float)(1.0 - decay));
     return (int)hipGetLastError();
 }

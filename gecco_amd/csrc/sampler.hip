@@ -214,6 +214,22 @@ int uvl_reparam_launch(const void* x, const float* K, const float* mean, const f
                            logit_scale, (float*)y, B, N, inverse);
     return (int)hipGetLastError();
 }
+namespace {
+__global__ void relu_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n) {
+    for (size_t i = gid(); i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = fmaxf(x[i], 0.f);
+}
+__global__ void relu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ du, size_t n) {
+    for (size_t i = gid(); i < n; i += (size_t)gridDim.x * blockDim.x) du[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+}  // namespace
+int relu_launch(const float* x, float* y, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(relu_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, y, n);
+    return (int)hipGetLastError();
+}
+int relu_bwd_launch(const float* y, const float* dy, float* du, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, y, dy, du, n);
+    return (int)hipGetLastError();
+}
 int gaussian_act_launch(const float* x, const float* alpha, float* y, size_t n, int normalized, hipStream_t st) {
     hipLaunchKernelGGL(gaussian_act_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, alpha, y, n, normalized);
     return (int)hipGetLastError();

@@ -43,6 +43,32 @@ def default_precision() -> str:
     return _default_precision
 
 
+ACT_NONE, ACT_GAUSS, ACT_GAUSS_RAW, ACT_RELU = 0, 1, 2, 3
+
+
+def act_code(act_alpha: Tensor | None, normalized: bool = True, act: str | int | None = None) -> int:
+    """Epilogue activation code of the C ABI: GaussianActivation (alpha given) 1 / 2, "relu" 3, none 0."""
+    if act in ("relu", ACT_RELU):
+        return ACT_RELU
+    if act not in (None, "gauss", "none", ACT_NONE, ACT_GAUSS, ACT_GAUSS_RAW):
+        raise ValueError(f"unknown activation {act!r}")
+    if act_alpha is None:
+        return ACT_NONE
+    return ACT_GAUSS if normalized else ACT_GAUSS_RAW
+
+
+def module_act(m) -> tuple[int, Tensor | None]:
+    """(code, alpha) of an activation module: GaussianActivation, nn.ReLU (the reference's default) or nn.Identity."""
+    from .models.activation import GaussianActivation
+    if isinstance(m, GaussianActivation):
+        return (ACT_GAUSS if m.normalized else ACT_GAUSS_RAW), m.alpha
+    if isinstance(m, torch.nn.ReLU):
+        return ACT_RELU, None
+    if isinstance(m, torch.nn.Identity):
+        return ACT_NONE, None
+    raise NotImplementedError(f"activation {type(m).__name__} has no HIP epilogue (GaussianActivation, nn.ReLU, nn.Identity do)")
+
+
 def _stream() -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -66,8 +92,9 @@ def _ws(nbytes: int, device) -> Tensor:
 # ------------------------------------------------------------------------------- unit operators
 def linear(A: Tensor, W: Tensor, bias: Tensor | None = None, pro: tuple[Tensor, Tensor] | None = None,
            act_alpha: Tensor | None = None, residual: Tensor | None = None, want_stats: bool = False,
-           normalized: bool = True, out: Tensor | None = None, precision: str = "fp32"):
-    """C = residual + act((A*pro_a + pro_o) @ W^T + bias) on (B, rows, K) x (Nout, K)."""
+           normalized: bool = True, out: Tensor | None = None, precision: str = "fp32", act: str | int | None = None):
+    """C = residual + act((A*pro_a + pro_o) @ W^T + bias) on (B, rows, K) x (Nout, K).
+    act: GaussianActivation when act_alpha is given (normalized or raw), "relu", or none."""
     lib = _lib.load()
     B, rows, K = A.shape
     Nout = W.shape[0]
@@ -76,7 +103,7 @@ def linear(A: Tensor, W: Tensor, bias: Tensor | None = None, pro: tuple[Tensor, 
     stats = None
     if want_stats:
         stats = torch.empty(B, lib.gecco_linear_row_tiles(rows), 2, Nout, device=A.device, dtype=torch.float32)
-    act = 0 if act_alpha is None else (1 if normalized else 2)
+    act = act_code(act_alpha, normalized, act)
     wsplit = _ws((Nout + 127) // 128 * 128 * K * 4, A.device) if precision != "fp32" else None
     check(lib.gecco_linear_ex_f32(_ptr(A), _ptr(W), _ptr(bias), _ptr(pro[0]) if pro else None,
                                   _ptr(pro[1]) if pro else None, _ptr(act_alpha), _ptr(residual), _ptr(out), _ptr(stats),
@@ -364,7 +391,8 @@ def _adagn_from(p: Mapping[str, Tensor], pre: str) -> GeccoAdaGN:
 
 
 def _mlp_from(p: Mapping[str, Tensor], pre: str) -> GeccoMLP:
-    return GeccoMLP(_ptr(p[pre + "0.weight"]), _ptr(p[pre + "0.bias"]), _ptr(p[pre + "1.alpha"]),
+    # "1.alpha" exists only with GaussianActivation (nn.ReLU / nn.Identity have no parameters)
+    return GeccoMLP(_ptr(p[pre + "0.weight"]), _ptr(p[pre + "0.bias"]), _ptr(p.get(pre + "1.alpha")),
                     _ptr(p[pre + "2.weight"]), _ptr(p[pre + "2.bias"]))
 
 
@@ -384,7 +412,7 @@ class SetTransformerPlan:
     parameter tensors so the raw pointers stay valid; rebuild it if parameters are re-allocated."""
 
     def __init__(self, p: Mapping[str, Tensor], pre: str, H: int, I: int = 64, G: int = 32, normalized: bool = True,
-                 precision: str | None = None):
+                 precision: str | None = None, act: int | None = None):
         self.lib = _lib.load()
         self.precision = precision or _default_precision
         if self.precision not in PRECISIONS:
@@ -401,7 +429,10 @@ class SetTransformerPlan:
         self.ctx_dim = p[f"{pre}layers.0.mlp_norm.scale.weight"].shape[1]
         self.device = w0.device
         self._layers = (GeccoLayer * L)(*[layer_table(p, f"{pre}layers.{i}.") for i in range(L)])
-        self.table = GeccoSetTransformer(L, self.C, H, I, self.ctx_dim, G, self.width, 1 if normalized else 2,
+        if act is None:   # GaussianActivation when the state dict carries its alpha, else the reference's default ReLU
+            act = (ACT_GAUSS if normalized else ACT_GAUSS_RAW) if f"{pre}layers.0.mlp.1.alpha" in p else ACT_RELU
+        self.act = act
+        self.table = GeccoSetTransformer(L, self.C, H, I, self.ctx_dim, G, self.width, act,
                                          PRECISIONS[self.precision], self._layers)
         self._ws: dict[tuple[int, int], Tensor] = {}
 
@@ -441,8 +472,8 @@ class LinearLiftPlan:
     """EDMPrecond(LinearLift(SetTransformer)) = the unconditional Diffusion.forward, one C call."""
 
     def __init__(self, p: Mapping[str, Tensor], H: int, I: int = 64, pre: str = "", sigma_data: float = 1.0,
-                 precision: str | None = None):
-        self.st = SetTransformerPlan(p, pre + "inner.", H, I, precision=precision)
+                 precision: str | None = None, act: int | None = None):
+        self.st = SetTransformerPlan(p, pre + "inner.", H, I, precision=precision, act=act)
         self.p = p
         self.lib = self.st.lib
         self.table = GeccoLinearLift(self.st.table, _ptr(p[pre + "lift.weight"]), _ptr(p[pre + "lift.bias"]),
@@ -548,8 +579,8 @@ class RayNetworkPlan:
 
     def __init__(self, p: Mapping[str, Tensor], H: int, I: int = 64, pre: str = "", reparam_kind: int = 2,
                  rp_mean: Tensor | None = None, rp_std: Tensor | None = None, logit_scale: float = 1.1,
-                 sigma_data: float = 1.0, precision: str | None = None):
-        self.st = SetTransformerPlan(p, pre + "backbone.", H, I, precision=precision)
+                 sigma_data: float = 1.0, precision: str | None = None, act: int | None = None):
+        self.st = SetTransformerPlan(p, pre + "backbone.", H, I, precision=precision, act=act)
         self.p = p
         self.lib = self.st.lib
         if reparam_kind == 2 and rp_mean is None:
@@ -605,6 +636,20 @@ def uvl_reparam(x: Tensor, K: Tensor, mean: Tensor, std: Tensor, logit_scale: fl
     check(lib.gecco_uvl_reparam(_ptr_any(x), _ptr(K), _ptr(mean), _ptr(std), logit_scale, _ptr_any(y), B, N,
                                 int(inverse), int(x.dtype == torch.float64), _stream()), "gecco_uvl_reparam")
     return y
+
+
+def relu(x: Tensor) -> Tensor:
+    lib = _lib.load()
+    y = torch.empty_like(x)
+    check(lib.gecco_relu_f32(_ptr(x), _ptr(y), x.numel(), _stream()), "gecco_relu_f32")
+    return y
+
+
+def relu_bwd(y: Tensor, dy: Tensor) -> Tensor:
+    lib = _lib.load()
+    du = torch.empty_like(y)
+    check(lib.gecco_relu_bwd_f32(_ptr(y), _ptr(dy), _ptr(du), y.numel(), _stream()), "gecco_relu_bwd_f32")
+    return du
 
 
 def gaussian_act(x: Tensor, alpha: Tensor, normalized: bool = True) -> Tensor:

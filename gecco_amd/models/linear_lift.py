@@ -53,6 +53,6 @@ class LinearLift(nn.Module):
         def build():
             st = self.inner.plan()
             p = dict(self.named_parameters())
-            return hip_ops.LinearLiftPlan(p, st.H, st.I, sigma_data=sigma_data)
+            return hip_ops.LinearLiftPlan(p, st.H, st.I, sigma_data=sigma_data, act=st.act)
         plan = self._cache.get(self, build)
         return plan.forward(x.float().contiguous(), sigma.float().contiguous(), cache=cache, do_cache=do_cache, out=out)

@@ -36,11 +36,8 @@ class MLP(nn.Sequential):
             if act is None:
                 h = hip_ops.linear(h, lin.weight, lin.bias)
                 i += 1
-            elif isinstance(act, GaussianActivation):
-                h = hip_ops.linear(h, lin.weight, lin.bias, act_alpha=act.alpha, normalized=act.normalized)
+            else:   # bias + activation in the GEMM epilogue: GaussianActivation, nn.ReLU (the reference's default), nn.Identity
+                code, alpha = hip_ops.module_act(act)
+                h = hip_ops.linear(h, lin.weight, lin.bias, act_alpha=alpha, act=code)
                 i += 2
-            else:
-                raise NotImplementedError(
-                    f"MLP activation {type(act).__name__} has no HIP epilogue (GaussianActivation is what every shipped "
-                    "GECCO config uses)")
         return h.reshape(*shape[:-1], h.shape[-1])

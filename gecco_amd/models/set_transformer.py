@@ -14,7 +14,8 @@ from .normalization import AdaGN
 
 
 def _param_sig(module: nn.Module):
-    return (hip_ops.default_precision(),) + tuple(p.data_ptr() for p in module.parameters())
+    return (hip_ops.default_precision(),) + tuple(p.data_ptr() for p in module.parameters()) + \
+        tuple(b.data_ptr() for b in module.buffers())
 
 
 class _PlanCache:
@@ -22,6 +23,18 @@ class _PlanCache:
     (.to(), .cuda(), load of a differently-placed state dict).  In-place updates keep it valid."""
 
     def __init__(self):
+        self.sig = None
+        self.plan = None
+
+    # plans hold ctypes structures with raw pointers: a copied / pickled module starts with an empty cache and
+    # rebuilds its plan on first use (copy.deepcopy(model), torch.save(model), spawn-based DDP, swa_utils.AveragedModel)
+    def __deepcopy__(self, memo):
+        return _PlanCache()
+
+    def __getstate__(self):
+        return {}
+
+    def __setstate__(self, state):
         self.sig = None
         self.plan = None
 
@@ -33,13 +46,10 @@ class _PlanCache:
         return self.plan
 
 
-def _gaussian_or_raise(mlp: MLP) -> GaussianActivation:
-    act = mlp[1]
-    if not isinstance(act, GaussianActivation):
-        raise NotImplementedError(
-            f"the fused HIP set transformer needs activation=GaussianActivation (got {type(act).__name__}); "
-            "every shipped GECCO config uses it")
-    return act
+def _act_of(mlp: MLP) -> int:
+    """Epilogue code of the MLPs' activation: GaussianActivation (every shipped config), nn.ReLU (the reference's
+    default, set_transformer.py:81,133) or nn.Identity; anything else has no HIP epilogue and raises."""
+    return hip_ops.module_act(mlp[1])[0]
 
 
 class AttentionPool(nn.Module):
@@ -123,11 +133,10 @@ class BroadcastingLayer(nn.Module):
 
     def _plan(self):
         def build():
-            act = _gaussian_or_raise(self.mlp)
             p = {"layers.0." + k: v for k, v in self.named_parameters()}
             return hip_ops.SetTransformerPlan(p, "", self.broadcast.pool.num_heads,
                                               self.broadcast.pool.inducers.shape[2], self.broadcast_norm.gn.num_groups,
-                                              act.normalized)
+                                              act=_act_of(self.mlp))
         return self._cache.get(self, build)
 
     def forward(self, x: Tensor, t_embed: Tensor, return_h: bool = False, h: Tensor | None = None):
@@ -155,10 +164,9 @@ class SetTransformer(nn.Module):
     def plan(self) -> hip_ops.SetTransformerPlan:
         def build():
             l0 = self.layers[0]
-            act = _gaussian_or_raise(l0.mlp)
             return hip_ops.SetTransformerPlan(dict(self.named_parameters()), "", l0.broadcast.pool.num_heads,
                                               l0.broadcast.pool.inducers.shape[2], l0.broadcast_norm.gn.num_groups,
-                                              act.normalized)
+                                              act=_act_of(l0.mlp))
         return self._cache.get(self, build)
 
     def forward(self, features: Tensor, t_embed: Tensor, return_h: bool = False, hs: list[Tensor] | None = None):

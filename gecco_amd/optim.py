@@ -140,14 +140,15 @@ class FusedAdamEMA(torch.optim.Optimizer):
         gb = self._flat["g"].data_ptr()
         src, dst = [], []
         for p, o, k in self._spans:
+            gr = p.grad
+            if gr is not None and gr.data_ptr() == gb + 4 * o:
+                continue                       # the usual case: still our view
             v = self._flat["g"][o:o + k].view(p.shape)
-            if p.grad is None:
+            if gr is None:
                 v.zero_()
-            elif p.grad.data_ptr() != gb + 4 * o:
-                src.append(p.grad)
-                dst.append(v)
             else:
-                continue
+                src.append(gr)
+                dst.append(v)
             p.grad = v
         if src:
             torch._foreach_copy_(dst, src)
@@ -171,17 +172,20 @@ class FusedAdamEMA(torch.optim.Optimizer):
         if g.get("amsgrad") or g.get("maximize"):
             raise NotImplementedError("FusedAdamEMA: amsgrad / maximize are not supported")
         self._adam_step += 1
-        f = self._flat
-        do_ema = self._should_update_at_step()
+        self.launch(self._adam_step, self._should_update_at_step())
+        self.current_step += 1
+        return loss
+
+    def launch(self, adam_step: int, do_ema: bool) -> None:
+        """The one kernel of a step (gecco_adam_ema_step_f32) on the current stream, no bookkeeping."""
+        f, g = self._flat, self.param_groups[0]
         a = _lib.GeccoAdamEma(f["p"].data_ptr(), f["g"].data_ptr(), f["m"].data_ptr(), f["v"].data_ptr(),
                               f["ema"].data_ptr() if f["ema"] is not None else None, f["p"].numel(), float(g["lr"]),
                               float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
-                              self._adam_step, float(self.grad_scale), float(self.decay if self.decay is not None else 0.0),
+                              float(self.decay if self.decay is not None else 0.0), float(self.grad_scale), adam_step,
                               int(do_ema))
         _lib.check(_lib.load().gecco_adam_ema_step_f32(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
                    "gecco_adam_ema_step_f32")
-        self.current_step += 1
-        return loss
 
     # ------------------------------------------------------------------------------------------ EMA weight swap
     def join(self) -> None:   # EMAOptimizer API (its update runs on a side stream / thread; ours is in-stream)

@@ -62,7 +62,7 @@ typedef struct GeccoLayer {   /* BroadcastingLayer, models/set_transformer.py:12
 } GeccoLayer;
 
 typedef struct GeccoSetTransformer {  /* SetTransformer, models/set_transformer.py:171-216 */
-    int n_layers, C, H, I, ctx_dim, G, width, act;  /* act: 1 GaussianActivation(normalized) 2 raw */
+    int n_layers, C, H, I, ctx_dim, G, width, act;  /* act of the MLPs: 0 identity, 1 GaussianActivation(normalized), 2 raw, 3 nn.ReLU */
     int precision;  /* arithmetic of the linears and attention products: 0 exact fp32 MFMA (~1e-6 vs the fp32
                      * reference), 1 split-bf16 on bf16 MFMA, fp32 accumulate (a = hi + lo; 3 MFMAs; ~2e-5),
                      * 2 fp16 operands (round to nearest even), fp32 accumulate, fp16-stored intermediates (~3e-4) */
@@ -74,7 +74,8 @@ typedef struct GeccoSetTransformer {  /* SetTransformer, models/set_transformer.
 /* C = residual + act((A*pro_a + pro_o) @ W^T + bias); optional GroupNorm partial statistics of C.
  * Replaces nn.Linear call sites of models/set_transformer.py:49,65,112,165-166 and models/mlp.py.
  * stats: (B, T, 2, Nout) with T = gecco_linear_row_tiles(rows).  Any of bias/pro/alpha/residual/stats
- * may be NULL. */
+ * may be NULL.  act: 0 none, 1 / 2 GaussianActivation normalized / raw (alpha required), 3 ReLU (the reference's
+ * default activation, models/mlp.py:12). */
 int gecco_linear_f32(const float* A, const float* W, const float* bias, const float* pro_a, const float* pro_o,
                      const float* alpha, const float* residual, float* C, float* stats, int B, int rows, int K,
                      int Nout, int act, void* stream);
@@ -296,6 +297,10 @@ int gecco_gaussian_reparam(const void* x, const float* mean, const float* sigma,
                            int inverse, int is_f64, void* stream);
 int gecco_uvl_reparam(const void* x, const float* K, const float* uvl_mean, const float* uvl_std, double logit_scale,
                       void* y, int B, int N, int inverse, int is_f64, void* stream);
+/* nn.ReLU, the reference's default `activation` (models/mlp.py:12, set_transformer.py:81,133), stand-alone and its
+ * backward du = dy * (y > 0) (training path).  In the fused kernels ReLU is epilogue code act = 3. */
+int gecco_relu_f32(const float* x, float* y, size_t n, void* stream);
+int gecco_relu_bwd_f32(const float* y, const float* dy, float* du, size_t n, void* stream);
 int gecco_gaussian_act_f32(const float* x, const float* alpha, float* y, size_t n, int normalized, void* stream);
 
 /* ---- sampler state kernels (diffusion.py:271-352, 354-470) ------------------------------------- */
@@ -381,15 +386,15 @@ int gecco_lower_bwd_blocks(size_t rows);
 typedef struct GeccoAdamEma {
     float* p; const float* g; float* m; float* v; float* ema;
     size_t n;
-    float lr, beta1, beta2, eps, weight_decay;
-    int step;
+    double lr, beta1, beta2, eps, weight_decay;   /* doubles: torch derives 1 - beta, lr / bc1, 1 - decay in double, then rounds */
+    double ema_decay;
     float grad_scale;
-    float ema_decay;
+    int step;
     int do_ema;
 } GeccoAdamEma;
 int gecco_adam_ema_step_f32(const GeccoAdamEma* a, void* stream);
 /* ema = ema * decay + (1 - decay) * p alone (ema_update, ema.py:187-194), for optimizers other than the fused Adam. */
-int gecco_ema_update_f32(const float* p, float* ema, size_t n, float decay, void* stream);
+int gecco_ema_update_f32(const float* p, float* ema, size_t n, double decay, void* stream);
 
 #ifdef __cplusplus
 }

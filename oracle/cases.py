@@ -153,3 +153,40 @@ def loss_inputs():
     u = torch.from_numpy(np.random.RandomState(c["seed"] + 2).uniform(size=c["B"]).astype(np.float32))
     noise = _randn(c["seed"] + 3, c["B"], c["N"], 3)
     return p, ex, u, noise
+
+
+OPTIM_CASE = dict(d=64, L=1, seed=71, decay=0.99, steps_before=3, steps_after=2)
+
+
+def optim_grads(step: int, shapes):
+    """Injected gradients of optimizer step `step` (seeded; the same on the reference and the HIP side): magnitudes
+    spread over four decades across parameters so that Adam's normalisation and eps both matter."""
+    rs = np.random.RandomState(OPTIM_CASE["seed"] * 100 + step)
+    out = []
+    for j, shp in enumerate(shapes):
+        scale = 10.0 ** (-(j % 5))
+        out.append(torch.from_numpy(np.asarray(rs.randn(*shp) * scale, dtype=np.float32)).reshape(shp))
+    return out
+
+
+def ema_update_ref(ema, params, decay):
+    """ema_update, ema.py:187-194: ema = ema * decay + (1 - decay) * param (fp32, per tensor)."""
+    return [e * decay + p * (1.0 - decay) for e, p in zip(ema, params)]
+
+
+# the reference's DEFAULT activation (nn.ReLU: models/mlp.py:12, set_transformer.py:81,133) — no shipped config uses it
+RELU_CASE = dict(d=128, L=2, N=256, B=2, seed=81)
+
+
+def drop_alpha(p):
+    """The state dict of the same network built with activation=nn.ReLU: no `*.1.alpha` entries."""
+    return {k: v for k, v in p.items() if not k.endswith(".1.alpha")}
+
+
+def relu_inputs():
+    c = RELU_CASE
+    p = drop_alpha(W.linear_lift_state_dict(c["seed"], c["d"], c["L"], I, H))
+    sigma = torch.tensor([0.05, 30.0][: c["B"]], dtype=torch.float32)
+    data = _randn(c["seed"] + 1, c["B"], c["N"], 3)
+    x = data + sigma.reshape(-1, 1, 1) * _randn(c["seed"] + 2, c["B"], c["N"], 3)
+    return p, x, sigma

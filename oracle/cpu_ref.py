@@ -53,7 +53,8 @@ def mlp(x: Tensor, p: dict, pre: str) -> Tensor:
     """MLP(depth=1, activation=GaussianActivation), models/mlp.py:5-39:
     Linear -> act -> Linear, children indexed 0,1,2."""
     h = F.linear(x, p[pre + "0.weight"], p[pre + "0.bias"])
-    h = gaussian_activation(h, p[pre + "1.alpha"])
+    # GaussianActivation carries a parameter ("1.alpha"); without it the MLP has the reference's default nn.ReLU
+    h = gaussian_activation(h, p[pre + "1.alpha"]) if (pre + "1.alpha") in p else F.relu(h)
     return F.linear(h, p[pre + "2.weight"], p[pre + "2.bias"])
 
 

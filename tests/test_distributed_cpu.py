@@ -37,7 +37,7 @@ def _worker(rank, world, port, B, q):
     assert torch.equal(full[lo:hi], local)
     t = gd.max_over_ranks(1.0 + rank)
     gd.barrier()
-    q.put((rank, full, t))
+    q.put((rank, full.numpy(), t))   # by value: a tensor travels as a shared-memory handle the exiting child may unlink
     dist.destroy_process_group()
 
 
@@ -55,7 +55,7 @@ def test_two_rank_sharded_sampling_equals_single_process(B):
         assert p.exitcode == 0
     single = _toy_sampler((B, 16, 3), gd.sample_noise((16, 3), 5, 7, 0, B, "cpu"), 4)
     for rank, full, t in got:
-        assert torch.equal(full, single)      # union of the shards == the single-process batch, bit for bit
+        assert torch.equal(torch.from_numpy(full), single)      # union of the shards == the single-process batch, bit for bit
         assert t == 2.0                       # max over ranks
 
 
@@ -91,7 +91,8 @@ def _dp_worker(rank, world, port, q):
     loss = ((net(x[lo:hi]) - y[lo:hi]) ** 2).mean()
     loss.backward()
     red.all_reduce_()
-    q.put((rank, [p.detach().clone() for p in net.parameters()], [p.grad.clone() for p in net.parameters() if p.requires_grad]))
+    q.put((rank, [p.detach().numpy().copy() for p in net.parameters()],
+           [p.grad.numpy().copy() for p in net.parameters() if p.requires_grad]))   # by value (see _worker)
     dist.destroy_process_group()
 
 
@@ -106,6 +107,7 @@ def test_two_rank_gradient_all_reduce_matches_full_batch():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    got = [(r, [torch.from_numpy(a) for a in w], [torch.from_numpy(a) for a in g]) for r, w, g in got]
     (_, w0, g0), (_, w1, g1) = got
     assert all(torch.equal(a, b) for a, b in zip(w0, w1))
     assert all(torch.equal(a, b) for a, b in zip(g0, g1))
@@ -119,3 +121,72 @@ def test_two_rank_gradient_all_reduce_matches_full_batch():
     ((net(x) - y) ** 2).mean().backward()           # equal shards: mean of shard means == full-batch mean
     ref = [p.grad for p in net.parameters() if p.requires_grad]
     assert all(torch.allclose(a, b, atol=1e-6) for a, b in zip(g0, ref))
+
+
+def _bucket_worker(rank, world, port, q):
+    """The overlapped, bucketed reducer (hooks fire during backward, async all-reduce per bucket, scale folded into the
+    optimizer's read of g) against the single-process full-batch gradient; one parameter never receives a gradient."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    gd.init("gloo")
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 32), torch.nn.Tanh(), torch.nn.Linear(32, 32), torch.nn.Tanh(),
+                              torch.nn.Linear(32, 3))
+    unused = torch.nn.Parameter(torch.ones(5))
+    params = list(net.parameters()) + [unused]
+    buf = gd.FlatGradBuffer(params)
+    red = gd.BucketedGradAllReducer(buf, bucket_bytes=512)   # several buckets
+    assert len(red.buckets) >= 3
+    g = torch.Generator().manual_seed(0)
+    x, y = torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)
+    lo, hi = gd.shard_range(8, rank, world)
+    outs = []
+    for step in range(2):                                      # two steps: the bucket bookkeeping resets
+        buf.zero_grad()
+        ((net(x[lo:hi]) - y[lo:hi]) ** 2).mean().backward()
+        red.finish()
+        outs.append([(p.grad * buf.grad_scale).numpy().copy() for p in params])
+    q.put((rank, outs))
+    dist.destroy_process_group()
+
+
+def test_two_rank_bucketed_overlapped_all_reduce():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 32), torch.nn.Tanh(), torch.nn.Linear(32, 32), torch.nn.Tanh(),
+                              torch.nn.Linear(32, 3))
+    g = torch.Generator().manual_seed(0)
+    x, y = torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)
+    ((net(x) - y) ** 2).mean().backward()
+    ref = [p.grad for p in net.parameters()] + [torch.zeros(5)]
+    for rank, outs in got:
+        for grads in outs:
+            assert all(torch.allclose(torch.from_numpy(a), b, atol=1e-6) for a, b in zip(grads, ref))
+
+
+def test_bench_self_launcher_two_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: the script spawns its own ranks (fresh processes, env
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), they rendezvous, and rank 0 prints the one JSON line.  Exercised on gloo
+    with the stand-in step (`--selftest-launcher`): the compute path needs the GPU, the plumbing does not."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-launcher", "--steps", "3"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                      # ONE line, from rank 0
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3
+    assert rec["ms_per_step"] >= 2.0                      # max over ranks: rank 1 sleeps 2 ms per step

@@ -279,3 +279,46 @@ def test_conditional_diffusion_golden(golden_dir, name, precision, tol):
         assert out.shape == (len(sigma), N, 3) and torch.isfinite(out).all()
     finally:
         hip_ops.set_default_precision(old)
+
+
+# ------------------------------------------------------------------------------------------- nn.ReLU (reference default)
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16x3", 2e-4), ("fp16", 1e-3)])
+def test_default_relu_activation_golden(golden_dir, precision, tol):
+    """The reference's DEFAULT `activation=nn.ReLU` (models/mlp.py:12, set_transformer.py:81,133): module API with the
+    argument left out, state dict without alpha entries, fused path (epilogue code 3) in every arithmetic mode, against
+    the reference's own output; and the training path's gradient through ReLU against torch autograd on the oracle."""
+    from gecco_amd import hip_ops
+    from gecco_amd.diffusion import Diffusion, EDMLoss, EDMPrecond, IdleConditioner, LogUniformSchedule
+    from gecco_amd.models.linear_lift import LinearLift
+    from gecco_amd.models.set_transformer import SetTransformer
+    from gecco_amd.reparam import GaussianReparam
+    g = _load(golden_dir, "relu_d128_L2_N256")
+    c = cases.RELU_CASE
+    p, x, sigma = cases.relu_inputs()
+    net = LinearLift(inner=SetTransformer(n_layers=c["L"], num_inducers=cases.I, feature_dim=c["d"], t_embed_dim=1,
+                                          num_heads=cases.H), feature_dim=c["d"])
+    assert isinstance(net.inner.layers[0].mlp[1], torch.nn.ReLU)
+    m = Diffusion(backbone=EDMPrecond(model=net), conditioner=IdleConditioner(),
+                  reparam=GaussianReparam(torch.tensor(cases.GAUSS_MEAN), torch.tensor(cases.GAUSS_SIGMA)),
+                  loss=EDMLoss(schedule=LogUniformSchedule(max=165.0)))
+    m.load_state_dict(uncond_state_dict(p), strict=True)
+    m = m.cuda().eval()
+    old = hip_ops.default_precision()
+    hip_ops.set_default_precision(precision)
+    try:
+        with torch.no_grad():
+            den = m(x.cuda(), sigma.cuda(), None)
+        e = _close(den, g["denoised"], tol)
+        print("relu", precision, e)
+        if precision == "fp32":   # gradient of a scalar of the output w.r.t. two weights that sit before / after a ReLU
+            pg = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+            ref = cpu_ref.uncond_denoiser(pg, "", cases.H)(x, sigma)
+            (ref ** 2).mean().backward()
+            m.train()
+            out = m(x.cuda(), sigma.cuda(), None)
+            (out ** 2).mean().backward()
+            for k in ("inner.layers.0.mlp.0.weight", "inner.layers.1.broadcast.mlp.2.weight", "lift.weight"):
+                got = dict(m.backbone.model.named_parameters())[k].grad
+                _close(got, pg[k].grad, 5e-4)
+    finally:
+        hip_ops.set_default_precision(old)

@@ -268,6 +268,26 @@ def main():
         check(f"grad features[{l}]", a.grad, b.grad, tol=5e-4)
         out[f"grad.features.{l}"] = b.grad
     save("cond_loss", **out)
+
+    # ---- the reference's default activation, nn.ReLU
+    print("relu")
+    with torch.no_grad():
+        c = cases.RELU_CASE
+        p, x, sigma = cases.relu_inputs()
+        net = ns.LinearLift(inner=ns.SetTransformer(n_layers=c["L"], num_inducers=I, feature_dim=c["d"], t_embed_dim=1,
+                                                    num_heads=H),   # activation left at its default
+                            feature_dim=c["d"])
+        model = D.Diffusion(backbone=D.EDMPrecond(model=net), conditioner=D.IdleConditioner(),
+                            reparam=ns.reparam_mod.GaussianReparam(torch.tensor(cases.GAUSS_MEAN), torch.tensor(cases.GAUSS_SIGMA)),
+                            loss=D.EDMLoss(schedule=D.LogUniformSchedule(max=165.0)))
+        assert isinstance(net.inner.layers[0].mlp[1], torch.nn.ReLU)
+        sd = {"backbone.model." + k: v for k, v in p.items()}
+        sd["reparam.mean"], sd["reparam.sigma"] = torch.tensor(cases.GAUSS_MEAN), torch.tensor(cases.GAUSS_SIGMA)
+        model.load_state_dict(sd, strict=True)
+        den_ref = model(x, sigma, None)
+        den, raw = cpu_ref.uncond_denoiser(p, "", H)(x, sigma, return_raw=True)
+        check("relu denoised", den, den_ref)
+        save("relu_d128_L2_N256", denoised=den_ref)
     print("all golden vectors written")
 
 

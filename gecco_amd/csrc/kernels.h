@@ -240,3 +240,29 @@ struct AdamEmaArgs {
 };
 int adam_ema_launch(const AdamEmaArgs& a, hipStream_t st);
 int ema_update_launch(const float* p, float* ema, size_t n, double decay, hipStream_t st);
+
+// gemm_x3_planes.hip — split-bf16 linear on PRE-SPLIT operands ("planes": per row K/32 blocks of [32 bf16 hi | 32 bf16 lo]),
+// 8-wave / 8-phase LDS-DMA schedule.  Rows are flat (rows_total = B * rows_per_sample).
+struct X3Args {
+    const void* Y;          // activation planes (rows_total, K/32, 2, 32) bf16
+    const void* Wimg;       // weight planes image (split_planes_image_launch), rows in the kernel's channel order
+    const float* bias;      // (Nout) or null
+    const float* alpha;     // GaussianActivation alpha (act 1 / 2)
+    const float* residual;  // (rows_total, ldr) fp32 or null
+    float* C;               // fp32 (rows_total, ldc); or, with c_planes, the output planes (rows_total, Nout/32, 2, 32)
+    float* stats;           // (rows_total / gemm_x3_planes_row_tile(), 2, Nout) column sums / sums of squares, or null
+    int rows_total, rows_per_sample, K, Nout, ldc, ldr, act, c_planes;
+    float* C2;              // optional second output segment: channels [n_split, Nout) -> C2 (rows_total, ldc2), bias2
+    const float* bias2;
+    int n_split, ldc2;
+    int skew;               // start-up skew per XCD index in s_sleep(127) units; < 0: the launcher's default
+};
+bool gemm_x3_planes_supported(const X3Args& g);
+int gemm_x3_planes_row_tile(int Nout, int n_split);   // rows per statistics partial of the configuration picked (0: unsupported)
+int gemm_x3_planes_launch(const X3Args& g, hipStream_t st);
+size_t planes_image_bytes(int Nout, int K);           // ceil(Nout / 32) * 32 * K * 4
+int split_planes_image_launch(const float* W, void* img, int Nout, int K, int ldw, hipStream_t st);
+int split_planes_image_multi_launch(const SplitJobs& jobs, hipStream_t st);
+// y planes = a[b, c] * x + o[b, c] (a == null: x itself), C % 32 == 0
+int affine_split_planes_launch(const float* x, const float* a, const float* o, void* y, size_t rows_total, int rows_per_sample,
+                               int C, hipStream_t st);

@@ -266,3 +266,20 @@ int split_planes_image_multi_launch(const SplitJobs& jobs, hipStream_t st);
 // y planes = a[b, c] * x + o[b, c] (a == null: x itself), C % 32 == 0
 int affine_split_planes_launch(const float* x, const float* a, const float* o, void* y, size_t rows_total, int rows_per_sample,
                                int C, hipStream_t st);
+
+// mlp_x3_fused.hip — split-bf16 mode: x += mlp.2(act(mlp.0(a * x + o))) + GroupNorm partials in one launch; activations
+// in registers (transposed products), only the weight stream image (mlp_x3_stream_launch) passes through LDS
+struct MlpX3Args {
+    float* x;                    // (rows_total, C) fp32, updated in place
+    const float *pro_a, *pro_o;  // (B, C) AdaGN coefficients
+    const void* w_stream;        // mlp_x3_stream_launch image of (W0, W2), mlp_x3_stream_bytes(C) bytes
+    const float *b0, *b2, *alpha;
+    int act;
+    float* stats;                // (rows_total / mlp_x3_fused_row_tile(C), 2, C) or null
+    int rows_total, rows_per_sample;
+};
+int mlp_x3_fused_row_tile(int C);
+bool mlp_x3_fused_supported(int C, int Wd, int rows_per_sample);
+size_t mlp_x3_stream_bytes(int C);
+int mlp_x3_stream_launch(const float* W0, const float* W2, void* img, int C, hipStream_t st);
+int mlp_x3_fused_launch(const MlpX3Args& g, int C, hipStream_t st);

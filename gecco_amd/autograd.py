@@ -47,7 +47,7 @@ def _train_precision() -> str:
     """Arithmetic of the N-token linears in the training path: the module default, except that the fp16 mode is not used
     for gradients (no loss scaling: small gradient values would flush) — split-bf16 has the fp32 exponent range."""
     p = hip_ops.default_precision()
-    return "bf16x3" if p == "fp16" else p
+    return "bf16x3" if p in ("fp16", "mixed") else p
 
 
 def _new(*shape, like: Tensor) -> Tensor:

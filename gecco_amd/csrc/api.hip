@@ -194,11 +194,12 @@ int option(int which) {
 // Returns 1 when the shape is outside that kernel's reach (caller: cast pass + streaming GEMM), 0 on success.
 int astat_linear(const float* x, const float* pa, const float* po, const float* img, const float* bias1, int Nout1,
                  float* C1, const float* bias2, int Nout2, float* C2, const float* alpha, int act, int B, int rows,
-                 int K, hipStream_t s, int hm_hd = 0) {
+                 int K, hipStream_t s, int hm_hd = 0, const float* img_lo = nullptr) {
     GemmArgs g{};
     g.A = x; g.pro_a = pa; g.pro_o = po; g.bias = bias1; g.alpha = alpha; g.act = act; g.C = C1;
     g.B = B; g.rows = rows; g.K = K; g.Nout = Nout1 + Nout2; g.lda = K; g.ldw = K; g.ldc = Nout1; g.ldr = Nout1;
-    g.precision = 2; g.w_img = img; g.c_f16 = 1; g.hm_hd = hm_hd;
+    g.precision = 2; g.w_img = img; g.c_f16 = 1; g.hm_hd = hm_hd; g.w_img2 = img_lo;   // img_lo: two-term weights (mixed mode)
+    if (img_lo && C2) g.lo_tiles = Nout1 / 128;   // kv_proj | q_proj: the q segment's weights stay one-term
     if (C2) { g.C2 = C2; g.bias2 = bias2; g.n_split = Nout1; g.ldc2 = Nout2; }
     // option "astat" = 0 falls back to the cast pass + streaming GEMM (A/B runs; same bits)
     if (!option(OPT_ASTAT) || !img || !gemm_f16_astat_supported(g)) return 1;
@@ -221,7 +222,12 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
     STWorkspace w = carve_st(st, B, N, ws);
     if (ws_bytes < w.bytes) return fail(-7, "set_transformer: workspace too small (%zu < %zu)", ws_bytes, w.bytes);
     const int C = st->C, I = st->I, H = st->H, G = st->G, Wd = st->width, ctx = st->ctx_dim, act = st->act;
-    const int pr = st->precision;
+    // precision 3 ("mixed"): kv_proj | q_proj with fp16 activations and TWO-TERM fp16 weights (A-stationary kernel), fp16
+    // K | V / q and fp16 attention products; everything that feeds the residual stream or the shared inducer states
+    // (pool.out_proj .. unpool k|v on the 64 inducers, unpool.out_proj, the point MLP) in split-bf16 arithmetic.
+    // tools/experiments/fp16_site_sensitivity.py: those are the products whose operand rounding reaches the output.
+    const bool mixed = st->precision == 3;
+    const int pr = mixed ? 1 : st->precision;       // arithmetic of the generic linears
     const int Tn = row_tiles_gemm(N), Ti = row_tiles_gemm(I);
     const int ns = pool_attn_nsplit(B, N, H);
 
@@ -232,7 +238,7 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         sx = w.stats_x;
         sT = row_tiles_stats(N);
     }
-    const int kmod = pr == 2 ? 32 : 16;   // K granularity of the fast kernels
+    const int kmod = (pr == 2 || mixed) ? 32 : 16;   // K granularity of the fast kernels
     // fp16 mode: everything on the 64 inducers between the two attentions is one launch (inducer_chain_f16.hip)
     // fp16 mode: the point-stream MLP of a layer (AdaGN, mlp.0, activation, mlp.2, residual, statistics) is one launch
     const bool mlpf_on = pr == 2 && w.wimg && option(OPT_MLPFUSED) && mlp_fused_f16_supported(C, Wd, N);
@@ -241,8 +247,9 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
     if (pr >= 1 && w.wimg && !(C % kmod) && !(Wd % kmod)) {
         // split-bf16 mode: every N-token weight of every layer becomes its tiled hi | lo image in ONE launch per
         // 6 layers (weights may change between calls; nothing is cached across forwards)
-        SplitJobs jobs;
+        SplitJobs jobs, jobs16;   // jobs16: the fp16 images of the mixed mode (kv_proj | q_proj, hi and lo)
         jobs.n = 0;
+        jobs16.n = 0;
         // every insertion goes through here: the table is flushed BEFORE a write that would not fit
         constexpr int kJobCap = (int)(sizeof(jobs.job) / sizeof(jobs.job[0]));
         auto push_ld = [&](const float* Wp, float* img, int Nout, int K, int ldw) -> int {
@@ -258,8 +265,21 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         for (int li = 0; li < st->n_layers; ++li) {
             const GeccoLayer& L = st->layers[li];
             float* base = w.wimg + (size_t)li * w.wimg_layer;
+            if (mixed) {
+                // fp16 hi images of kv_proj | q_proj back to back (one stream for the A-stationary kernel), then their lo images
+                const size_t hkv = (size_t)(2 * C + 127) / 128 * 128 * C / 2, hq = (size_t)(C + 127) / 128 * 128 * C / 2;
+                for (int lo = 0; lo < 2; ++lo) {
+                    float* dst = base + lo * (hkv + hq);
+                    if (!(h_in && h_in[li])) {
+                        if (jobs16.n >= kJobCap) { TRY(split_f16_tiled_multi_launch(jobs16, s), "split(weights)"); jobs16.n = 0; }
+                        jobs16.job[jobs16.n++] = SplitJob{L.kv_proj_w, dst, 2 * C, C, C, lo};
+                    }
+                    if (jobs16.n >= kJobCap) { TRY(split_f16_tiled_multi_launch(jobs16, s), "split(weights)"); jobs16.n = 0; }
+                    jobs16.job[jobs16.n++] = SplitJob{L.in_proj_w, dst + hkv, C, C, C, lo};
+                }
+            }
             if (!(h_in && h_in[li])) {
-                TRY(push(L.kv_proj_w, base, 2 * C, C), "split(kv_proj)");
+                if (!mixed) TRY(push(L.kv_proj_w, base, 2 * C, C), "split(kv_proj)");
                 TRY(push(L.pool_out_w, base + w.o_pout, C, C), "split(pool.out_proj)");
                 TRY(push(L.bmlp.w0, base + w.o_b0, Wd, C), "split(broadcast.mlp.0)");
                 if (chain_on) {   // the one-launch chain walks mlp.2 K-half by K-half: one (C x C) image per half
@@ -271,7 +291,7 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
                 }
             }
             TRY(push(L.in_proj_w + (size_t)C * C, base + w.o_ukv, 2 * C, C), "split(unpool.in_proj kv)");
-            TRY(push(L.in_proj_w, base + w.o_q, C, C), "split(q_proj)");
+            if (!mixed) TRY(push(L.in_proj_w, base + w.o_q, C, C), "split(q_proj)");
             TRY(push(L.unpool_out_w, base + w.o_out, C, C), "split(out_proj)");
             if (mlpf_on) {   // one stream in consumption order: per hidden chunk j, W0 tile j, then W2[:, chunk j] in two K-halves
                 const int nkb = C / 32;
@@ -288,12 +308,17 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
             }
         }
         TRY(pr == 2 ? split_f16_tiled_multi_launch(jobs, s) : split_bf16_tiled_multi_launch(jobs, s), "split(weights)");
+        if (mixed) TRY(split_f16_tiled_multi_launch(jobs16, s), "split(weights, fp16)");
     }
     const bool imgs = pr >= 1 && w.wimg && !(C % kmod) && !(Wd % kmod);
     // fp16 mode: the point-stream intermediates every consumer rounds to fp16 anyway (K|V, q, the attention output,
     // the MLP hidden layer) are STORED as fp16 — the same bits reach the matrix pipe, a third of the layer's HBM
     // bytes never move.  x (the residual stream) and everything on the 64 inducers stay fp32.
-    const bool io16 = pr == 2 && imgs && N >= 128 && attn_x3_supported(C / H) && !(C % 8) && !(Wd % 8);
+    const bool io16 = (pr == 2 || mixed) && imgs && N >= 128 && attn_x3_supported(C / H) && !(C % 8) && !(Wd % 8);
+    if (mixed && !(io16 && !(N % 128) && !(C % 128)))
+        return fail(-3, "set_transformer: the mixed mode needs rows %% 128 == 0, feature_dim %% 128 == 0 and a head dim of 16 / 32 / 48 / 64");
+    const int apr = mixed ? 2 : pr;                  // arithmetic of the attention products
+    const size_t kvq_lo = ((size_t)(2 * C + 127) / 128 * 128 + (size_t)(C + 127) / 128 * 128) * C / 2;   // floats: mixed mode's lo images
     for (int li = 0; li < st->n_layers; ++li) {
         const GeccoLayer& L = st->layers[li];
         const float* im = imgs ? w.wimg + (size_t)li * w.wimg_layer : nullptr;
@@ -311,12 +336,14 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
             // K | V and q leave the A-stationary kernel head-major: one contiguous (N, hd) slab per (sample, head),
             // which is what a pool / unpool block streams (row-major: hd-wide pieces of rows shared by all heads)
             const int hd_try = option(OPT_HEADMAJOR) ? C / H : 0;
+            const float* im_lo = mixed && im ? im + kvq_lo : nullptr;
             int fused = io16 ? astat_linear(x, w.a1, w.o1, (2 * C) % 128 == 0 ? im : nullptr, nullptr, 2 * C, w.big,
-                                            L.in_proj_b, C, w.q, nullptr, 0, B, N, C, s, hd_try)
+                                            L.in_proj_b, C, w.q, nullptr, 0, B, N, C, s, hd_try, im_lo)
                              : 1;
             if (io16 && fused == 1 && hd_try)   // shape outside the head-major form: row-major
                 fused = astat_linear(x, w.a1, w.o1, (2 * C) % 128 == 0 ? im : nullptr, nullptr, 2 * C, w.big, L.in_proj_b,
-                                     C, w.q, nullptr, 0, B, N, C, s, 0);
+                                     C, w.q, nullptr, 0, B, N, C, s, 0, im_lo);
+            if (mixed && fused != 0) return fail(fused < 0 ? fused : -3, "set_transformer: mixed mode: kv_proj | q_proj outside the A-stationary kernel's reach");
             else if (fused == 0 && hd_try)
                 hm = 1;
             if (fused < 0) TRY(fused, "kv_proj|q_proj (A-stationary)");
@@ -335,7 +362,7 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
             }
             const bool chain = chain_on && im;
             TRY(pool_attn_launch(w.big, L.inducers, w.part_o, w.part_ml, chain ? nullptr : w.merged, B, N, C, H, I, ns, s,
-                                 pr, io16, hm), "pool_attn");
+                                 apr, io16, hm), "pool_attn");
             if (chain) {
                 ChainArgs ca{};
                 ca.part_o = w.part_o; ca.part_ml = w.part_ml; ca.nsplit = ns; ca.H = H;
@@ -374,11 +401,15 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         if (!q_done && io16 && h_in && h_in[li]) {
             // cached inducer states (upsampling): the layer only needs q — the same one-pass kernel, one segment
             const int hd_try = option(OPT_HEADMAJOR) ? C / H : 0;
-            int one = astat_linear(x, w.a1, w.o1, im ? im + w.o_q : nullptr, L.in_proj_b, C, w.q, nullptr, 0, nullptr,
-                                   nullptr, 0, B, N, C, s, hd_try);
+            // q's image: after kv_proj's (fp16 mode: o_q floats in; mixed mode: fp16 images inside the 4-byte layout)
+            const float* qim = !im ? nullptr : mixed ? im + (size_t)(2 * C + 127) / 128 * 128 * C / 2 : im + w.o_q;
+            const float* qim_lo = mixed && qim ? qim + kvq_lo : nullptr;
+            int one = astat_linear(x, w.a1, w.o1, qim, L.in_proj_b, C, w.q, nullptr, 0, nullptr,
+                                   nullptr, 0, B, N, C, s, hd_try, qim_lo);
             if (one == 1 && hd_try)
-                one = astat_linear(x, w.a1, w.o1, im ? im + w.o_q : nullptr, L.in_proj_b, C, w.q, nullptr, 0, nullptr, nullptr,
-                                   0, B, N, C, s, 0);
+                one = astat_linear(x, w.a1, w.o1, qim, L.in_proj_b, C, w.q, nullptr, 0, nullptr, nullptr,
+                                   0, B, N, C, s, 0, qim_lo);
+            if (mixed && one != 0) return fail(one < 0 ? one : -3, "set_transformer: mixed mode: q projection outside the A-stationary kernel's reach");
             else if (one == 0 && hd_try)
                 hm = 1;
             if (one < 0) TRY(one, "unpool.in_proj(q) (A-stationary)");
@@ -390,7 +421,8 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
                        nullptr, w.q, nullptr, B, N, C, C, 0, s, pr, w.wsplit, im ? im + w.o_q : nullptr, io16, io16),
                 "unpool.in_proj(q)");
         }
-        if (hm && im && I == 64 && option(OPT_UNPOOLFUSED) && unpool_outproj_f16_supported(C, H, N)) {
+        const bool a16 = io16 && !mixed;   // fp16-stored operands of the generic linears (fp16 mode only)
+        if (!mixed && hm && im && I == 64 && option(OPT_UNPOOLFUSED) && unpool_outproj_f16_supported(C, H, N)) {
             // fp16 mode, head-major q: attention, out_proj, residual and statistics in one launch (the attention output
             // of a row block is the A operand of out_proj for the same rows and never leaves the CU)
             UnpoolProjArgs ua{};
@@ -398,9 +430,10 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
             ua.B = B; ua.rows = N; ua.H = H;
             TRY(unpool_outproj_f16_launch(ua, C, s), "unpool attention + out_proj");
         } else {
-            TRY(unpool_attn_launch(w.q, w.kvh, w.attn, B, N, C, H, I, s, pr, io16, hm), "unpool_attn");
+            // mixed mode: fp16 q in, fp32 attention output (io16 = 2) = the operand of the split-bf16 out_proj
+            TRY(unpool_attn_launch(w.q, w.kvh, w.attn, B, N, C, H, I, s, apr, mixed ? 2 : (int)io16, hm), "unpool_attn");
             TRY(linear(w.attn, L.unpool_out_w, L.unpool_out_b, nullptr, nullptr, nullptr, x, x, w.stats_x, B, N, C, C, 0, s, pr,
-                       w.wsplit, im ? im + w.o_out : nullptr, io16, 0), "unpool.out_proj+residual");
+                       w.wsplit, im ? im + w.o_out : nullptr, a16, 0), "unpool.out_proj+residual");
         }
         // x += mlp(AdaGN(x))
         TRY(coeffs(w.stats_x, Tn, N, t, ctx, &L.mlp_norm, w.a2, w.o2, B, C, G, s), "adagn_coeffs(mlp_norm)");
@@ -415,17 +448,17 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
             sT = Tn;
             continue;
         }
-        int m0_done = io16 ? astat_linear(x, w.a2, w.o2, im ? im + w.o_w0 : nullptr, L.mlp.b0, Wd, w.big, nullptr, 0,
-                                          nullptr, L.mlp.alpha, act, B, N, C, s)
-                           : 1;
+        int m0_done = a16 ? astat_linear(x, w.a2, w.o2, im ? im + w.o_w0 : nullptr, L.mlp.b0, Wd, w.big, nullptr, 0,
+                                         nullptr, L.mlp.alpha, act, B, N, C, s)
+                          : 1;
         if (m0_done < 0) TRY(m0_done, "mlp.0 (A-stationary)");
         if (m0_done == 1) {
-        if (io16) TRY(affine_cast_f16_launch(x, w.a2, w.o2, w.attn, B, N, C, s), "mlp_norm -> fp16");
-        TRY(linear(io16 ? w.attn : x, L.mlp.w0, L.mlp.b0, io16 ? nullptr : w.a2, io16 ? nullptr : w.o2, L.mlp.alpha, nullptr,
-                   w.big, nullptr, B, N, C, Wd, act, s, pr, w.wsplit, im ? im + w.o_w0 : nullptr, io16, io16), "mlp.0");
+        if (a16) TRY(affine_cast_f16_launch(x, w.a2, w.o2, w.attn, B, N, C, s), "mlp_norm -> fp16");
+        TRY(linear(a16 ? w.attn : x, L.mlp.w0, L.mlp.b0, a16 ? nullptr : w.a2, a16 ? nullptr : w.o2, L.mlp.alpha, nullptr,
+                   w.big, nullptr, B, N, C, Wd, act, s, pr, w.wsplit, im ? im + w.o_w0 : nullptr, a16, a16), "mlp.0");
         }
         TRY(linear(w.big, L.mlp.w2, L.mlp.b2, nullptr, nullptr, nullptr, x, x, so, B, N, Wd, C, 0, s, pr, w.wsplit,
-                   im ? im + w.o_w2 : nullptr, io16, 0), "mlp.2+residual");
+                   im ? im + w.o_w2 : nullptr, a16, 0), "mlp.2+residual");
         sx = w.stats_x;
         sT = Tn;
     }
@@ -901,7 +934,7 @@ int gecco_ray_network_fwd_f32(const GeccoRayNetwork* m, const float* x, const fl
     // point_features = xyz_features + Linear(GN16(lookup))  (models/ray.py:112-113): GN apply in the GEMM
     // prologue, the add as its residual, the first AdaGN's statistics in its epilogue
     TRY(linear(w.raw, m->img_w, m->img_b, w.a_raw, w.o_raw, nullptr, w.feat, w.feat, w.stats_x, B, N, a.c_total, C, 0,
-               s, m->backbone.precision, w.wsplit), "img_feature_proj");
+               s, m->backbone.precision == 3 ? 1 : m->backbone.precision, w.wsplit), "img_feature_proj");   // mixed mode: split-bf16
     rc = st_forward(&m->backbone, w.feat, w.coef + 4 * (size_t)B, w.stats_x, row_tiles_gemm(N), h_in, h_out,
                     w.stats_out, B, N, w.st_ws, w.st_bytes, s);
     if (rc) return rc;

@@ -364,7 +364,7 @@ template <int HD, bool F16, bool IO16>
 __global__ __launch_bounds__(256, 2) void unpool_attn_x3_kernel(const float* __restrict__ q,
                                                              const float* __restrict__ kvh, float* __restrict__ out,
                                                              int B, int N, int C, int H, int tiles_per_wave,
-                                                             int nchunk, int hm) {
+                                                             int nchunk, int hm, int out32) {   // out32 (IO16): fp32 output
     constexpr int KS = HD + 8;            // bf16 elements per K / Q row
     constexpr int VS = 64 + 8;            // bf16 elements per V^T row (64 permuted keys + pad)
     constexpr int DT = (HD + 31) / 32;
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256, 2) void unpool_attn_x3_kernel(const float* __r
                 }
             }
         wave_lds_sync();
-        if (IO16) {
+        if (IO16 && !out32) {
 #pragma unroll
             for (int ld = 0; ld < LD8; ++ld) {
                 const int f = ld * 64 + lane, row = f / CH8, c8 = f % CH8, n = q0 + row;
@@ -583,7 +583,7 @@ int pool_x3_launch_t(const float* KV, const float* ind, float* po, float* pml, i
 }
 
 template <int HD, bool F16, bool IO16>
-int unpool_x3_launch_t(const float* q, const float* kvh, float* out, int B, int N, int C, int H, hipStream_t st, int hm) {
+int unpool_x3_launch_t(const float* q, const float* kvh, float* out, int B, int N, int C, int H, hipStream_t st, int hm, int out32 = 0) {
     constexpr int KS = HD + 8, VS = 72, DT = (HD + 31) / 32, NP = F16 ? 1 : 2, OP = HD + 4;
     constexpr int QW = 32 * OP * 2 > NP * 32 * KS ? 32 * OP * 2 : NP * 32 * KS;
     const size_t lds = ((size_t)NP * 64 * KS + NP * DT * 32 * VS + 4 * QW) * 2;
@@ -598,7 +598,7 @@ int unpool_x3_launch_t(const float* q, const float* kvh, float* out, int B, int 
         attr_set = true;
     }
     hipLaunchKernelGGL((unpool_attn_x3_kernel<HD, F16, IO16>), dim3(B * H * nchunk), dim3(256), lds, st, q, kvh, out, B, N, C, H,
-                       tpw, nchunk, hm);
+                       tpw, nchunk, hm, out32);
     return (int)hipGetLastError();
 }
 
@@ -629,9 +629,10 @@ int unpool_attn_x3_launch(const float* q, const float* kvh, float* out, int B, i
                           int precision, int io16, int hm) {
     if (io16 && precision != 2) return -9;
     if (hm && !io16) return -9;
+    const int out32 = io16 == 2;   // io16 = 2: q is an fp16 tensor, the output stays fp32 (operand of a split-bf16 out_proj)
 #define UNPOOL_CASE(HD)                                                                                \
     case HD:                                                                                           \
-        return io16 ? unpool_x3_launch_t<HD, true, true>(q, kvh, out, B, N, C, H, st, hm)              \
+        return io16 ? unpool_x3_launch_t<HD, true, true>(q, kvh, out, B, N, C, H, st, hm, out32)       \
                : precision == 2 ? unpool_x3_launch_t<HD, true, false>(q, kvh, out, B, N, C, H, st, 0)  \
                                 : unpool_x3_launch_t<HD, false, false>(q, kvh, out, B, N, C, H, st, 0)
     switch (C / H) {

@@ -66,12 +66,22 @@ template <int... I, class F>
 __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) {
     (f(std::integral_constant<int, I>{}), ...);
 }
+// the same with a second compile-time tag handed through (no wrapper lambda around f: the accumulators stay in registers)
+template <int TAG, int... I, class F>
+__device__ __forceinline__ void static_for_tag(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}, std::integral_constant<int, TAG>{}), ...);
+}
 
 // NK = K / 32 K-steps (compile-time: the A fragments are registers, indexed statically); NS ring slots with
 // NK % NS == 0, so the ring slot of K-step kt of ANY column tile is kt % NS — every LDS address in the loop is static.
-template <int NK, int NS>
+// WS = 2 ("mixed" mode): two-term fp16 weights W = W_hi + W_lo.  The lo image (g.w_img2) is streamed as NK further
+// K-steps of every column tile, multiplied with the SAME register-resident A fragments: x . W_hi + x . W_lo in one
+// accumulator.  The rounding of the weights — coherent over all points of a cloud, the dominant error of the fp16
+// mode (tools/experiments/fp16_site_sensitivity.py) — drops from 2^-12 to 2^-23; the A side is unchanged.
+template <int NK, int NS, int WS = 1>
 __global__ __launch_bounds__(S_NT, 2) void gemm_f16_astat_kernel(GemmArgs g) {
     static_assert(NK % 2 == 0 && NK % NS == 0 && NS >= 4, "static slots; the A build stages 4 K-steps in the ring");
+    constexpr int NKW = NK * WS;   // W stages per column tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
     ASTAMP(0);
     float* ring = smem;                                // [NS][S_TILE]; first the staging area of the A build
@@ -163,12 +173,34 @@ __global__ __launch_bounds__(S_NT, 2) void gemm_f16_astat_kernel(GemmArgs g) {
 
     // ---- W image: buffer_load ... lds, wave w moves pieces 2w, 2w+1 (1 KiB each) of every 8 KiB stage
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.w_img), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(WS == 2 ? g.w_img2 : g.w_img), 0, 0x7fffffff, 0x00020000);
     const unsigned voff = (unsigned)((S_PW * wave) * 256 + lane * 4) * 4u;
     unsigned soff = 0;                                 // byte offset of the next stage to issue in the image
+    int part_left = NK;                                // WS == 2: stages left in the current part (hi, then lo) of the column tile
+    bool lo_part = false;
+    int it_tile = 0;                                   // column tile of the next stage to issue
+    // WS == 2: column tiles [0, lo_tiles) carry a lo part, the rest (the q projection: its weights' rounding does not reach
+    // the output, tools/experiments/fp16_site_sensitivity.py) are streamed hi only
+    const int lo_tiles = WS == 2 ? (g.lo_tiles > 0 ? g.lo_tiles : tilesN) : 0;
     auto issue = [&](int slot) {
-        dma16_buf(wrsrc, voff, soff, ring + slot * S_TILE + (S_PW * wave) * 256);
-        dma16_buf(wrsrc, voff + 1024u, soff, ring + slot * S_TILE + (S_PW * wave + 1) * 256);
+        if (WS == 2 && lo_part) {
+            dma16_buf(wrsrc2, voff, soff, ring + slot * S_TILE + (S_PW * wave) * 256);
+            dma16_buf(wrsrc2, voff + 1024u, soff, ring + slot * S_TILE + (S_PW * wave + 1) * 256);
+        } else {
+            dma16_buf(wrsrc, voff, soff, ring + slot * S_TILE + (S_PW * wave) * 256);
+            dma16_buf(wrsrc, voff + 1024u, soff, ring + slot * S_TILE + (S_PW * wave + 1) * 256);
+        }
         soff += S_TILE * 4u;
+        if (WS == 2 && --part_left == 0) {             // hi part done: the same stages of the lo image; lo done: next tile's hi
+            part_left = NK;
+            if (!lo_part && it_tile < lo_tiles) {
+                soff -= NK * S_TILE * 4u;
+                lo_part = true;
+            } else {
+                lo_part = false;
+                ++it_tile;
+            }
+        }
     };
 #pragma unroll
     for (int p = 0; p < NS; ++p) issue(p);             // tilesN * NK >= NK >= NS stages exist
@@ -255,19 +287,26 @@ __global__ __launch_bounds__(S_NT, 2) void gemm_f16_astat_kernel(GemmArgs g) {
     load_b(0, 0);
     for (int ct = 0; ct < tilesN; ++ct) {
         const bool first = ct == 0, last = ct == tilesN - 1;
-        static_for(std::make_integer_sequence<int, NK>{}, [&](auto KT) {
+        const bool has_lo = WS == 2 && ct < lo_tiles;   // this column tile runs 2 NK stages (hi, lo), else NK
+        static_for(std::make_integer_sequence<int, NKW>{}, [&](auto KT) {
             constexpr int kt = decltype(KT)::value;
             constexpr int cur = kt & 1;
-            constexpr int rem_last = NK - 1 - kt;                                   // steps left after this one, last tile
-            constexpr int n_last = rem_last >= NS - 1 ? NS - 2 : (rem_last >= 1 ? rem_last - 1 : 0);
+            if (WS == 2 && kt >= NK && !has_lo) return;   // wave-uniform: a tile without a lo part ends after NK stages
             constexpr bool early = kt <= NS - 2;   // the previous tile's epilogue stores still queue behind the awaited piece
+            // steps left after this one in the last tile, for either length
+            constexpr int rem_l = NKW - 1 - kt, rem_s = NK - 1 - kt;
+            constexpr int n_l = rem_l >= NS - 1 ? NS - 2 : (rem_l >= 1 ? rem_l - 1 : 0);
+            constexpr int n_s = rem_s >= NS - 1 ? NS - 2 : (rem_s >= 1 ? rem_s - 1 : 0);
             // own pieces of the next K-step's stage landed; younger stages (and those stores) may stay in flight
             if (!last) {
                 if (early && !first) dma::wait_vm_lgkm0<(NS - 2) * S_PW + S_STORES>();
                 else dma::wait_vm_lgkm0<(NS - 2) * S_PW>();
+            } else if (WS == 1 || has_lo) {
+                if (early && !first) dma::wait_vm_lgkm0<n_l * S_PW + S_STORES>();
+                else dma::wait_vm_lgkm0<n_l * S_PW>();
             } else {
-                if (early && !first) dma::wait_vm_lgkm0<n_last * S_PW + S_STORES>();
-                else dma::wait_vm_lgkm0<n_last * S_PW>();
+                if (early && !first) dma::wait_vm_lgkm0<n_s * S_PW + S_STORES>();
+                else dma::wait_vm_lgkm0<n_s * S_PW>();
             }
             // this step's W fragments were read during the previous one and the wait above covered them: an empty asm
             // "redefines" the registers so the compiler's wait-count pass does not park its own lgkmcnt(0) in front of
@@ -277,30 +316,35 @@ __global__ __launch_bounds__(S_NT, 2) void gemm_f16_astat_kernel(GemmArgs g) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c) asm volatile("" : "+v"(fb[cur][j][c]));
             __builtin_amdgcn_s_barrier();
-            if (!last || kt + NS < NK) issue(kt % NS);                 // the stage NS steps ahead reuses this step's slot
-            if (!last || kt + 1 < NK) load_b((kt + 1) % NS, cur ^ 1);
+            const int len = (WS == 1 || has_lo) ? NKW : NK;
+            if (!last || kt + NS < len) issue(kt % NS);                 // the stage NS steps ahead reuses this step's slot
+            if (!last || kt + 1 < len) load_b((kt + 1) % NS, cur ^ 1);
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kt][c], fb[cur][j][c], acc[j], 0, 0, 0);
-            if (kt == NK - 1) epilogue(ct);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kt % NK][c], fb[cur][j][c], acc[j], 0, 0, 0);
         });
+        epilogue(ct);
     }
     ASTAMP(2);
 }
 
-template <int NK, int NS>
-int astat_launch_t(const GemmArgs& g, hipStream_t st) {
+template <int NK, int NS, int WS>
+int astat_launch_ws(const GemmArgs& g, hipStream_t st) {
     const size_t lds = ((size_t)NS * S_TILE + g.Nout + 2 * g.K) * sizeof(float);
     static size_t attr = 0;
     if (lds > attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_astat_kernel<NK, NS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_astat_kernel<NK, NS, WS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = lds;
     }
-    hipLaunchKernelGGL((gemm_f16_astat_kernel<NK, NS>), dim3(g.B * (g.rows / 128)), dim3(S_NT), lds, st, g);
+    hipLaunchKernelGGL((gemm_f16_astat_kernel<NK, NS, WS>), dim3(g.B * (g.rows / 128)), dim3(S_NT), lds, st, g);
     return (int)hipGetLastError();
+}
+template <int NK, int NS>
+int astat_launch_t(const GemmArgs& g, hipStream_t st) {
+    return g.w_img2 ? astat_launch_ws<NK, NS, 2>(g, st) : astat_launch_ws<NK, NS, 1>(g, st);
 }
 
 }  // namespace

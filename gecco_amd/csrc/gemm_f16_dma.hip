@@ -246,15 +246,25 @@ __global__ __launch_bounds__(DNT, A16 ? 3 : 2) void gemm_f16_kernel(GemmArgs g) 
 // at float offset (ct * K/32 + kt) * 2048 holds row rb at rb * 16 floats (64 B = 32 fp16); its 16-byte chunk
 // s ^ ((rb >> 2) & 3) holds k = 16 (s >> 1) + 8 (s & 1) .. +7 (lane half s >> 1, MFMA s & 1 of the step).  Rows past
 // Nout repeat the last row (masked in the GEMM epilogue).  One thread per (block, row, chunk).
+// lo != 0: the image of the LOW part, fp16(W - float(fp16(W))) — the second term of a two-term fp16 weight (mixed mode)
 __device__ __forceinline__ void f16_image_item(const float* __restrict__ W, float* __restrict__ img, int Nout, int K,
-                                               int ldw, size_t i) {
+                                               int ldw, size_t i, int lo = 0) {
     const int nk = K / FBK;
     const int chp = (int)(i & 3), rb = (int)((i >> 2) & 127);
     const size_t blk = i >> 9;
     const int kt = (int)(blk % nk), ct = (int)(blk / nk);
     const int s = chp ^ ((rb >> 2) & 3);
     const float* src = W + (size_t)min(ct * DBN + rb, Nout - 1) * ldw + kt * FBK + 16 * (s >> 1) + 8 * (s & 1);
-    const f16x8 v = cvt8(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4));
+    f32x4 w0 = *reinterpret_cast<const f32x4*>(src), w1 = *reinterpret_cast<const f32x4*>(src + 4);
+    f16x8 v = cvt8(w0, w1);
+    if (lo) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            w0[e] -= (float)v[e];
+            w1[e] -= (float)v[4 + e];
+        }
+        v = cvt8(w0, w1);
+    }
     *reinterpret_cast<u32x4*>(img + blk * FB_TILE + rb * 16 + chp * 4) = __builtin_bit_cast(u32x4, v);
 }
 
@@ -268,7 +278,7 @@ __global__ void split_f16_tiled_multi_kernel(SplitJobs jobs) {
     const SplitJob j = jobs.job[blockIdx.y];
     const size_t total = (size_t)((j.Nout + DBN - 1) / DBN) * (j.K / FBK) * 512;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
-        f16_image_item(j.W, j.img, j.Nout, j.K, j.ldw, i);
+        f16_image_item(j.W, j.img, j.Nout, j.K, j.ldw, i, j.pad_);
 }
 
 template <int DNS, int BM, bool A16, bool C16>

@@ -31,9 +31,13 @@ struct GemmArgs {
     // nseg columns goes to element ((b * nseg / hd + n / hd) * rows + row) * hd + n % hd: one contiguous (rows, hd)
     // slab per (sample, head) — what the attention kernels stream — instead of hd-wide pieces of (rows, nseg) rows.
     int hm_hd;
+    // A-stationary fp16 kernel only: image of the weights' LOW part fp16(W - fp16(W)) (same layout as w_img; split jobs with
+    // pad_ = 1): two-term fp16 weights, 2 MFMAs per product ("mixed" mode).  Null: one-term weights.
+    const void* w_img2;
+    int lo_tiles;           // with w_img2: only the first lo_tiles 128-column tiles have a lo part (0: all)
 };
 
-struct SplitJob { const float* W; float* img; int Nout, K, ldw, pad_; };
+struct SplitJob { const float* W; float* img; int Nout, K, ldw, pad_; };   // pad_ = 1 (fp16 images): the LOW part fp16(W - fp16(W))
 struct SplitJobs { SplitJob job[96]; int n; };   // 3 KiB of kernel arguments
 int gemm_row_tile(int rows);  // row-tile height the GEMM uses for `rows` rows per sample
 int gemm_f32_launch(const GemmArgs& g, hipStream_t st);

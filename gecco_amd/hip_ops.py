@@ -20,7 +20,7 @@ GN_EPS = 1e-5
 
 # Arithmetic of the N-token GEMMs: "fp32" = exact fp32 MFMA (~1e-6 against the fp32 reference), "bf16x3" = split-bf16
 # (hi + lo operands, three bf16 MFMAs per product, fp32 accumulate: ~2e-5, inside the 1e-3 parity bar, ~2x faster).
-PRECISIONS = {"fp32": 0, "bf16x3": 1, "fp16": 2}
+PRECISIONS = {"fp32": 0, "bf16x3": 1, "fp16": 2, "mixed": 3}
 _default_precision = os.environ.get("GECCO_PRECISION", "fp32")
 
 

@@ -65,7 +65,10 @@ typedef struct GeccoSetTransformer {  /* SetTransformer, models/set_transformer.
     int n_layers, C, H, I, ctx_dim, G, width, act;  /* act of the MLPs: 0 identity, 1 GaussianActivation(normalized), 2 raw, 3 nn.ReLU */
     int precision;  /* arithmetic of the linears and attention products: 0 exact fp32 MFMA (~1e-6 vs the fp32
                      * reference), 1 split-bf16 on bf16 MFMA, fp32 accumulate (a = hi + lo; 3 MFMAs; ~2e-5),
-                     * 2 fp16 operands (round to nearest even), fp32 accumulate, fp16-stored intermediates (~3e-4) */
+                     * 2 fp16 operands (round to nearest even), fp32 accumulate, fp16-stored intermediates (D ~4e-4, F_x ~1e-3),
+                     * 3 "mixed": kv_proj | q_proj with fp16 activations and two-term fp16 weights, fp16 K | V / q and attention
+                     *   products; every product that feeds the residual stream or the shared inducer states (the 64-inducer
+                     *   chain, unpool.out_proj, the point MLP) in split-bf16 (~6e-5 on both outputs) */
     const GeccoLayer* layers;                       /* HOST array of n_layers tables */
 } GeccoSetTransformer;
 

@@ -21,9 +21,12 @@ pytestmark = pytest.mark.gpu
 # here and reproduced by the CPU emulation tools/experiments/fp16_site_sensitivity.py: ~70 % of that variance is the
 # static rounding of the WEIGHTS to fp16, which does not average out over the points of a cloud).  That is why fp16 is
 # not the headline mode; its F_x is asserted against 2e-3 and printed.
-BARS = {"fp32": 5e-5, "bf16x3": 2e-4, "fp16": 1e-3}
-BARS_FX = {"fp32": 5e-5, "bf16x3": 2e-4, "fp16": 2e-3}
-MODES = ["fp32", "bf16x3", "fp16"]
+# "mixed" = fp16 where the sensitivity analysis (tools/experiments/fp16_site_sensitivity.py) shows operand rounding does not
+# reach the output (kv_proj | q_proj activations, K | V, q, both attention products — with two-term fp16 weights for
+# kv_proj | q_proj), split-bf16 everywhere else: held to the split-bf16 bars.
+BARS = {"fp32": 5e-5, "bf16x3": 2e-4, "fp16": 1e-3, "mixed": 2e-4}
+BARS_FX = {"fp32": 5e-5, "bf16x3": 2e-4, "fp16": 2e-3, "mixed": 2e-4}
+MODES = ["fp32", "bf16x3", "mixed", "fp16"]
 
 
 @pytest.fixture(scope="module")
@@ -171,7 +174,7 @@ def test_fp16_deep_network_weight_staging(ops, d, L):
     x, sigma = _noisy(7, B, N, (0.2, 4.0))
     with torch.no_grad():
         ref, raw_ref = cpu_ref.uncond_denoiser(p, "", cases.H)(x, sigma, return_raw=True)
-    for precision in ("fp16", "bf16x3"):
+    for precision in ("fp16", "bf16x3", "mixed"):
         den, raw = ops.LinearLiftPlan(_cuda(p), cases.H, cases.I, precision=precision).forward(x.cuda(), sigma.cuda(), return_raw=True)
         # error grows with depth (each layer adds its own rounding); the bar stays the north star's
         _report(f"d={d} L={L} {precision} D", den, ref, 1e-3 if precision == "fp16" else 3e-4)

@@ -140,6 +140,10 @@ SIGNATURES = {
     "gecco_lift_bwd_f32": (i, [vp, vp, vp, i, i, i, vp]),
     "gecco_lower_bwd_f32": (i, [vp, vp, vp, vp, vp, sz, i, fl, vp]),
     "gecco_lower_bwd_blocks": (i, [sz]),
+    "gecco_sampler_refresh_known_f64": (i, [vp, vp, vp, vp, vp, i, i, i, i, vp]),
+    "gecco_distance_matrix_f32": (i, [vp, vp, vp, i, i, i, i, vp]),
+    "gecco_chamfer_f32": (i, [vp, vp, vp, vp, i, i, i, i, vp]),
+    "gecco_sinkhorn_f32": (i, [vp, vp, vp, vp, vp, i, i, i, fl, i, vp]),
     "gecco_adam_ema_step_f32": (i, [C.POINTER(GeccoAdamEma), vp]),
     "gecco_ema_update_f32": (i, [vp, vp, sz, db, vp]),
 }

@@ -1095,4 +1095,38 @@ int gecco_ema_update_f32(const float* p, float* ema, size_t n, double decay, voi
     return 0;
 }
 
+// ---------------------------------------------------------------------------- samplers / metrics of the "next" rows
+int gecco_sampler_refresh_known_f64(double* x, const float* known, const float* noise, const double* sched, const int* step,
+                                    int col, int m, int n_known, int B, void* stream) {
+    if (!x || !known || !noise || !sched || !step) return fail(-1, "sampler_refresh_known: null argument");
+    TRY(sampler_refresh_known_launch(x, known, noise, sched, step, col, m, n_known, B, (hipStream_t)stream), "sampler_refresh_known");
+    return 0;
+}
+int gecco_distance_matrix_f32(const float* a, const float* b, float* D, int B, int N, int M, int squared, void* stream) {
+    if (!a || !b || !D) return fail(-1, "distance_matrix: null argument");
+    TRY(dist_matrix_launch(a, b, D, B, N, M, squared, (hipStream_t)stream), "distance_matrix");
+    return 0;
+}
+int gecco_chamfer_f32(const float* a, const float* b, float* out, float* ws, int B, int N, int M, int squared, void* stream) {
+    if (!a || !b || !out || !ws) return fail(-1, "chamfer: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    float* min_ab = ws;                       // (B, N): nearest b of every a
+    float* min_ba = ws + (size_t)B * N;       // (B, M): nearest a of every b
+    TRY(nearest_dist_launch(a, b, min_ab, B, N, M, squared, s), "chamfer(a -> b)");
+    TRY(nearest_dist_launch(b, a, min_ba, B, M, N, squared, s), "chamfer(b -> a)");
+    TRY(row_mean_launch(min_ab, out, B, N, 0.5f, 0, s), "chamfer(mean a)");
+    TRY(row_mean_launch(min_ba, out, B, M, 0.5f, 1, s), "chamfer(mean b)");
+    return 0;
+}
+int gecco_sinkhorn_f32(const float* C, float* f, float* g, float* rowcost, float* out, int B, int N, int M, float epsilon,
+                       int iterations, void* stream) {
+    if (!C || !f || !g || !rowcost || !out) return fail(-1, "sinkhorn: null argument");
+    if (epsilon <= 0.f || iterations < 1) return fail(-2, "sinkhorn: epsilon > 0 and iterations >= 1");
+    hipStream_t s = (hipStream_t)stream;
+    TRY((int)hipMemsetAsync(g, 0, (size_t)B * M * sizeof(float), s), "sinkhorn(g = 0)");
+    for (int it = 0; it < iterations; ++it) TRY(sinkhorn_step_launch(C, f, g, B, N, M, epsilon, s), "sinkhorn(step)");
+    TRY(sinkhorn_cost_launch(C, f, g, rowcost, out, B, N, M, epsilon, s), "sinkhorn(cost)");
+    return 0;
+}
+
 }  // extern "C"

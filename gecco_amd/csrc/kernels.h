@@ -287,3 +287,14 @@ bool mlp_x3_fused_supported(int C, int Wd, int rows_per_sample);
 size_t mlp_x3_stream_bytes(int C);
 int mlp_x3_stream_launch(const float* W0, const float* W2, void* img, int C, hipStream_t st);
 int mlp_x3_fused_launch(const MlpX3Args& g, int C, hipStream_t st);
+
+// metrics.hip — evaluation metrics on (B, N, 3) clouds (gecco-jax metrics.py:92-156, geometry.py:8-24)
+int dist_matrix_launch(const float* A, const float* Bp, float* D, int B, int N, int M, int squared, hipStream_t st);
+int nearest_dist_launch(const float* A, const float* Bp, float* mins, int B, int N, int M, int squared, hipStream_t st);
+int row_mean_launch(const float* v, float* out, int B, int n, float scale, int accumulate, hipStream_t st);
+int sinkhorn_step_launch(const float* C, float* f, float* g, int B, int N, int M, float eps, hipStream_t st);
+int sinkhorn_cost_launch(const float* C, const float* f, const float* g, float* rowcost, float* out, int B, int N, int M, float eps,
+                         hipStream_t st);
+// sampler.hip — inpainting: re-draw the known points of the fp64 state at the current noise level
+int sampler_refresh_known_launch(double* x, const float* known, const float* noise, const double* sched, const int* step, int col,
+                                 int m, int n_known, int B, hipStream_t st);

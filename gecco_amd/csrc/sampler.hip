@@ -32,6 +32,19 @@ __global__ void add_noise_f64_kernel(const double* __restrict__ x_cur, const flo
     if (sigma && gid() < (size_t)B) sigma[gid()] = (float)sched[(size_t)s * SCHED_COLS + sigma_col];
 }
 
+// Inpainting sampler (gecco-jax models/stochastic.py:136-143): the KNOWN points of the state are re-drawn at the current
+// noise level every sub-step: x[b, m + j] = known[b, j] + noise[b, j] * sigma_cur.  x is (B, m + n_known, 3) fp64.
+__global__ void refresh_known_f64_kernel(double* __restrict__ x, const float* __restrict__ known, const float* __restrict__ noise,
+                                         const double* __restrict__ sched, const int* __restrict__ step, int col, int m,
+                                         int n_known, int B) {
+    const float c = (float)sched[(size_t)(*step) * SCHED_COLS + col];
+    const size_t per = (size_t)n_known * 3, total = (size_t)B * per;
+    for (size_t i = gid(); i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / per, r = i % per;
+        x[(b * (size_t)(m + n_known) + m) * 3 + r] = (double)known[i] + (double)(c * noise[i]);
+    }
+}
+
 // data_ctx = data + noise * (float)t_cur, all fp32 (diffusion.py:430)
 __global__ void add_noise_f32_kernel(const float* __restrict__ x, const float* __restrict__ noise,
                                      size_t noise_step_stride, const double* __restrict__ sched,
@@ -192,6 +205,13 @@ int sampler_scale_launch(const float* latents, double t, double* x, size_t n, hi
     hipLaunchKernelGGL(scale_f64_kernel, dim3(grid_for(n)), dim3(256), 0, st, latents, t, x, n);
     return (int)hipGetLastError();
 }
+int sampler_refresh_known_launch(double* x, const float* known, const float* noise, const double* sched, const int* step, int col,
+                                 int m, int n_known, int B, hipStream_t st) {
+    hipLaunchKernelGGL(refresh_known_f64_kernel, dim3(grid_for((size_t)B * n_known * 3)), dim3(256), 0, st, x, known, noise, sched, step,
+                       col, m, n_known, B);
+    return (int)hipGetLastError();
+}
+
 int gaussian_reparam_launch(const void* x, const float* mean, const float* sigma, void* y, size_t n, int dim,
                             int inverse, int is_f64, hipStream_t st) {
     if (is_f64)

@@ -290,7 +290,11 @@ class Diffusion(_Base):
         if noise is None:
             if rng is None:
                 rng = torch.Generator(device).manual_seed(42)
-            noise = torch.randn((num_steps + 1, *shape), device=device, generator=rng, dtype=dtype)
+            # the reference's draw order on the same generator: the latents, then one draw per step (diffusion.py:300,324)
+            # — so a seed / generator gives the clouds it gives there and is left in the same state — into one buffer
+            noise = torch.empty((num_steps + 1, *shape), device=device, dtype=dtype)
+            for i in range(num_steps + 1):
+                torch.randn(shape, device=device, generator=rng, dtype=dtype, out=noise[i])
         elif not torch.is_tensor(noise):
             noise = torch.stack([n.to(device=device, dtype=dtype) for n in noise])
         noise = noise.to(device=device, dtype=dtype).contiguous()
@@ -346,6 +350,89 @@ class Diffusion(_Base):
             pbar.update(1)
             pbar.close()
         return self.reparam.diffusion_to_data(st.x_next, context)
+
+    @torch.no_grad()
+    def sample_ode(self, shape: Sequence[int], context: Context3d | None, rng: torch.Generator = None,
+                   latents: Tensor | None = None, use_graph: bool = True, **kwargs) -> Tensor:
+        """Deterministic (probability-flow ODE) Heun sampler: the EDM sampler without churn, what gecco-jax's
+        `Diffusion.solve_sample_ode` integrates with diffrax's Heun solver on the schedule's time grid
+        (gecco-jax models/diffusion.py:333-374); the torch package does not ship it (gecco-torch/README.md:49-52).  Same
+        device loop as `sample_stochastic` with S_churn = 0: num_steps steps = 2 num_steps - 1 evaluations, fp64 state,
+        one captured hipGraph per step.  `latents` (optional, (B, N, 3)): the starting noise instead of a generator draw."""
+        kw = {**self.sampler_kwargs, **kwargs, "S_churn": 0.0}
+        num_steps = kw["num_steps"]
+        device, dtype = self.example_param.device, self.example_param.dtype
+        shape = tuple(shape)
+        if latents is None:
+            if rng is None:
+                rng = torch.Generator(device).manual_seed(42)
+            latents = torch.randn(shape, device=device, generator=rng, dtype=dtype)
+        noise = torch.zeros((num_steps + 1, *shape), device=device, dtype=dtype)   # churn noise is multiplied by 0
+        noise[0] = latents.to(device=device, dtype=dtype)
+        return self.sample_stochastic(shape, context, noise=noise, use_graph=use_graph, **kw)
+
+    @torch.no_grad()
+    def sample_inpaint(self, known: Tensor, m_to_inpaint: int, context: Context3d | None = None, num_substeps: int = 1,
+                       seed: int | None = 42, noise: Sequence[Tensor] | None = None, **kwargs) -> Tensor:
+        """Completion of partial clouds (gecco-jax models/stochastic.py:101-231, `sample_inpaint`): `known` (B, n, 3) data-space
+        points are kept — re-noised to the current level at every sub-step — while `m_to_inpaint` new points are sampled
+        jointly with them; returns the (B, m, 3) new points in data space (fp64).  Per step i, sub-step j: refresh the
+        known part at sigma_i, churn, Euler step to sigma_{i+1}, 2nd-order correction when i < steps - 1, and between
+        sub-steps noise back up from sigma_{i+1} to sigma_i.  The JAX package draws per-step keys; here a generator
+        (`seed`) or the injected `noise` list supplies the draws in call order: [initial (B, m + n, 3)], then per
+        (i, j): known-part noise (B, n, 3), churn noise (B, m + n, 3) [, redo noise (B, m + n, 3) when j < num_substeps - 1]."""
+        kw = {**self.sampler_kwargs, **kwargs}
+        num_steps = kw["num_steps"]
+        device, dtype = self.example_param.device, self.example_param.dtype
+        if dtype != torch.float32:
+            raise NotImplementedError("the HIP denoiser computes in float32")
+        rng = torch.Generator(device=device)
+        if seed is not None:
+            rng = rng.manual_seed(seed)
+        it = iter(noise) if noise is not None else None
+
+        def randn(shape):
+            if it is not None:
+                t = next(it).to(device=device, dtype=dtype).contiguous()
+                assert tuple(t.shape) == tuple(shape), (t.shape, shape)
+                return t
+            return torch.randn(tuple(shape), device=device, dtype=dtype, generator=rng)
+
+        known = known.to(device=device, dtype=dtype).contiguous()
+        B, n, _ = known.shape
+        m = int(m_to_inpaint)
+        known_diff = self.reparam.data_to_diffusion(known, context).contiguous()
+        post_context = self.conditioner(context)
+        ts = karras_t_steps(num_steps, kw["sigma_max"], kw["sigma_min"], kw["rho"])
+        sched = build_schedule_table(ts, num_steps, kw["S_churn"], kw["S_min"], kw["S_max"], kw["S_noise"])
+        st = _SamplerState((B, m + n, 3), device, sched)
+        lib = st.lib
+
+        def refresh():   # x_cur[:, m:] = known_diff + randn * sigma_cur
+            nz = randn(known.shape)
+            _lib.check(lib.gecco_sampler_refresh_known_f64(_vp(st.x_cur), _vp(known_diff), _vp(nz), _vp(st.sched), _vp(st.step),
+                                                           0, m, n, B, st._s()), "sampler_refresh_known")
+
+        # x_init = [0 | known_diff] + randn * sigma_0  (stochastic.py:189-197)
+        init = randn((B, m + n, 3))
+        base = torch.zeros(B, m + n, 3, device=device, dtype=dtype)
+        base[:, m:] = known_diff
+        st.x_cur.copy_(base.double() + (init * float(ts[0])).double())
+        for i in range(num_steps):
+            for j in range(num_substeps):
+                refresh()
+                st.churn(randn((B, m + n, 3)), 0)
+                self(st.x_in, st.sigma, context, post_context, out=st.den)
+                st.euler()
+                if i < num_steps - 1:
+                    self(st.x_in, st.sigma, context, post_context, out=st.den)
+                    st.heun()
+                else:
+                    st.x_cur.copy_(st.x_next)
+                if j < num_substeps - 1:
+                    st.redo(randn((B, m + n, 3)))
+            st.advance()
+        return self.reparam.diffusion_to_data(st.x_cur, context)[:, :m]
 
     @torch.no_grad()
     def upsample(self, data: Tensor, new_latents: Tensor | None = None, n_new: int | None = None,

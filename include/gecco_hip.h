@@ -399,6 +399,26 @@ int gecco_adam_ema_step_f32(const GeccoAdamEma* a, void* stream);
 /* ema = ema * decay + (1 - decay) * p alone (ema_update, ema.py:187-194), for optimizers other than the fused Adam. */
 int gecco_ema_update_f32(const float* p, float* ema, size_t n, double decay, void* stream);
 
+/* ---- samplers and metrics behind the hot path (gecco-torch/README.md:49-52 lists them as absent
+ * from the torch package, the JAX package has them) ------------------------------------------------------------------ */
+
+/* Inpainting sampler (gecco-jax models/stochastic.py:101-187): every sub-step re-draws the KNOWN points of the state at
+ * the current noise level: x[b, m + j, :] = known[b, j, :] + noise[b, j, :] * sched[step][col]; x (B, m + n_known, 3)
+ * fp64, known / noise (B, n_known, 3) fp32 (diffusion space). */
+int gecco_sampler_refresh_known_f64(double* x, const float* known, const float* noise, const double* sched, const int* step,
+                                    int col, int m, int n_known, int B, void* stream);
+/* D[b, i, j] = |a[b, i] - b[b, j]| formed as sqrt(max(|a|^2 + |b|^2 - 2 a.b, 0)) (gecco-jax geometry.py:8-24); squared != 0:
+ * no square root.  a (B, N, 3), b (B, M, 3), D (B, N, M). */
+int gecco_distance_matrix_f32(const float* a, const float* b, float* D, int B, int N, int M, int squared, void* stream);
+/* Chamfer distance per sample (gecco-jax metrics.py:92-103): out[b] = (mean_i min_j d(a_i, b_j) + mean_j min_i d) / 2.
+ * ws: B * (N + M) floats. */
+int gecco_chamfer_f32(const float* a, const float* b, float* out, float* ws, int B, int N, int M, int squared, void* stream);
+/* Entropic optimal transport between uniform marginals on a cost matrix C (B, N, M) (gecco-jax metrics.py:141-156:
+ * `sinkhorn_emd` through ott): `iterations` log-domain Sinkhorn sweeps, then out[b] = <P, C> with
+ * P_ij = exp((f_i + g_j - C_ij) / epsilon) / (N M).  f (B, N), g (B, M), rowcost (B, N) are caller scratch / outputs. */
+int gecco_sinkhorn_f32(const float* C, float* f, float* g, float* rowcost, float* out, int B, int N, int M, float epsilon,
+                       int iterations, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -405,3 +405,65 @@ def rel_err(y: Tensor, ref: Tensor):
     y, ref = y.double(), ref.double()
     return ((y - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item(), \
            ((y - ref).norm() / ref.norm().clamp_min(1e-30)).item()
+
+
+# --------------------------------------------------------------------------- gecco-jax samplers / metrics (f4 rows)
+def sample_inpaint(D: Callable, known_diff: Tensor, m: int, draws: Sequence[Tensor], num_steps: int, num_substeps: int,
+                   sigma_max: float, sigma_min: float = 0.002, rho: float = 7, S_churn: float = 0.5, S_noise: float = 1.0):
+    """gecco-jax models/stochastic.py:101-199 (`_sample_inpaint`) restated on the torch schedule (`t_steps`, fp64 state like
+    the torch samplers): x = [m new points | known points]; per step i, sub-step j: re-draw the known part at sigma_i,
+    churn, Euler to sigma_{i+1}, Heun correction when i < steps - 1, noise back up to sigma_i between sub-steps.
+    `draws` in call order: initial (B, m + n, 3); per (i, j): known noise (B, n, 3), churn noise (B, m + n, 3) [, redo noise].
+    gecco-jax itself cannot be imported here (jax is not installed): parity unpinned for this function."""
+    ts = t_steps(num_steps, sigma_max, sigma_min, rho)
+    it = iter(draws)
+    B, n, _ = known_diff.shape
+    x = torch.zeros(B, m + n, 3, dtype=torch.float64)
+    x[:, m:] = known_diff.double()
+    x = x + (next(it) * float(ts[0])).double()
+    for i in range(num_steps):
+        s_cur, s_next = ts[i], ts[i + 1]
+        for j in range(num_substeps):
+            x = x.clone()
+            x[:, m:] = known_diff.double() + (next(it) * s_cur.float()).double()
+            gamma = min(S_churn / num_steps, math.sqrt(2.0) - 1)
+            s_hat = s_cur + gamma * s_cur
+            x_hat = x + (((s_hat ** 2 - s_cur ** 2).sqrt() * S_noise).float() * next(it)).double()
+            den = D(x_hat.float(), s_hat.repeat(B).float()).double()
+            d_cur = (x_hat - den) / s_hat
+            x_next = x_hat + (s_next - s_hat) * d_cur
+            if i < num_steps - 1:
+                den2 = D(x_next.float(), s_next.repeat(B).float()).double()
+                d_prime = (x_next - den2) / s_next
+                x_next = x_hat + (s_next - s_hat) * (0.5 * d_cur + 0.5 * d_prime)
+            if j < num_substeps - 1:
+                x_next = x_next + ((s_cur ** 2 - s_next ** 2).sqrt().float() * next(it)).double()
+            x = x_next
+    return x[:, :m]
+
+
+def distance_matrix(a: Tensor, b: Tensor, squared: bool = False) -> Tensor:
+    """gecco-jax geometry.py:8-24."""
+    aa, bb = (a * a).sum(-1), (b * b).sum(-1)
+    d2 = (aa[..., :, None] + bb[..., None, :] - 2 * a @ b.transpose(-1, -2)).clamp_min(0.0)
+    return d2 if squared else d2.sqrt()
+
+
+def chamfer_distance(a: Tensor, b: Tensor, squared: bool = False) -> Tensor:
+    """gecco-jax metrics.py:92-103, batched over the leading dim."""
+    d = distance_matrix(a, b, squared)
+    return (d.min(dim=-2).values.mean(-1) + d.min(dim=-1).values.mean(-1)) / 2
+
+
+def sinkhorn_cost(Cm: Tensor, epsilon: float, iterations: int) -> Tensor:
+    """Log-domain Sinkhorn between uniform marginals on cost matrices (B, N, M), then <P, C>: the arithmetic of
+    gecco_sinkhorn_f32 (what ott's Sinkhorn solver iterates, gecco-jax metrics.py:141-156), in fp64."""
+    Cm = Cm.double()
+    B, N, M = Cm.shape
+    f = torch.zeros(B, N, dtype=torch.float64)
+    g = torch.zeros(B, M, dtype=torch.float64)
+    for _ in range(iterations):
+        f = -epsilon * torch.logsumexp((g[:, None, :] - Cm) / epsilon - math.log(M), dim=2)
+        g = -epsilon * torch.logsumexp((f[:, :, None] - Cm) / epsilon - math.log(N), dim=1)
+    P = torch.exp((f[:, :, None] + g[:, None, :] - Cm) / epsilon - math.log(N) - math.log(M))
+    return (P * Cm).sum((1, 2))

@@ -144,6 +144,10 @@ SIGNATURES = {
     "gecco_distance_matrix_f32": (i, [vp, vp, vp, i, i, i, i, vp]),
     "gecco_chamfer_f32": (i, [vp, vp, vp, vp, i, i, i, i, vp]),
     "gecco_sinkhorn_f32": (i, [vp, vp, vp, vp, vp, i, i, i, fl, i, vp]),
+    "gecco_convnext_stem_f32": (i, [vp] * 6 + [i, i, i, i, fl, vp]),
+    "gecco_convnext_dwconv_ln_f32": (i, [vp] * 6 + [i, i, i, i, fl, vp]),
+    "gecco_convnext_ln_patch2_f32": (i, [vp] * 4 + [i, i, i, i, fl, vp]),
+    "gecco_convnext_fold_scale_f32": (i, [vp] * 5 + [i, i, vp]),
     "gecco_adam_ema_step_f32": (i, [C.POINTER(GeccoAdamEma), vp]),
     "gecco_ema_update_f32": (i, [vp, vp, sz, db, vp]),
 }

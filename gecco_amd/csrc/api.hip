@@ -124,7 +124,7 @@ int linear(const float* A, const float* W, const float* bias, const float* pa, c
     g.stats = stats; g.B = B; g.rows = rows; g.K = K; g.Nout = Nout;
     g.lda = K; g.ldw = K; g.ldc = Nout; g.ldr = Nout; g.act = act;
     g.precision = 0; g.w_img = nullptr;
-    if (act < 0 || act > 3) return -6;
+    if (act < 0 || act > 4) return -6;
     if ((act == 1 || act == 2) && !alpha) return -6;
     g.a_f16 = a_f16; g.c_f16 = c_f16;   // fp16 tensors exist only between the fp16 kernels (st_forward checks support)
     const bool fast = precision == 1 ? gemm_f32_dma_supported(g, 1) : precision == 2 ? gemm_f16_dma_supported(g) : false;
@@ -1126,6 +1126,37 @@ int gecco_sinkhorn_f32(const float* C, float* f, float* g, float* rowcost, float
     TRY((int)hipMemsetAsync(g, 0, (size_t)B * M * sizeof(float), s), "sinkhorn(g = 0)");
     for (int it = 0; it < iterations; ++it) TRY(sinkhorn_step_launch(C, f, g, B, N, M, epsilon, s), "sinkhorn(step)");
     TRY(sinkhorn_cost_launch(C, f, g, rowcost, out, B, N, M, epsilon, s), "sinkhorn(cost)");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------- ConvNeXt conditioner (channels-last)
+int gecco_convnext_stem_f32(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b, float* out,
+                            int B, int H, int W, int C, float eps, void* stream) {
+    if (!x || !w || !bias || !ln_w || !ln_b || !out) return fail(-1, "convnext_stem: null argument");
+    int rc = cnx_stem_launch(x, w, bias, ln_w, ln_b, out, B, H, W, C, eps, (hipStream_t)stream);
+    if (rc == -9) return fail(-2, "convnext_stem: needs C == 96 and H, W multiples of 4");
+    TRY(rc, "convnext_stem");
+    return 0;
+}
+int gecco_convnext_dwconv_ln_f32(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b, float* out,
+                                 int B, int H, int W, int C, float eps, void* stream) {
+    if (!x || !w || !bias || !ln_w || !ln_b || !out) return fail(-1, "convnext_dwconv_ln: null argument");
+    int rc = cnx_dwconv_ln_launch(x, w, bias, ln_w, ln_b, out, B, H, W, C, eps, (hipStream_t)stream);
+    if (rc == -9) return fail(-2, "convnext_dwconv_ln: C must be 96, 192 or 384");
+    TRY(rc, "convnext_dwconv_ln");
+    return 0;
+}
+int gecco_convnext_ln_patch2_f32(const float* x, const float* ln_w, const float* ln_b, float* out, int B, int H, int W, int C,
+                                 float eps, void* stream) {
+    if (!x || !ln_w || !ln_b || !out) return fail(-1, "convnext_ln_patch2: null argument");
+    int rc = cnx_ln_patch2_launch(x, ln_w, ln_b, out, B, H, W, C, eps, (hipStream_t)stream);
+    if (rc == -9) return fail(-2, "convnext_ln_patch2: C must be 96, 192 or 384 and H, W even");
+    TRY(rc, "convnext_ln_patch2");
+    return 0;
+}
+int gecco_convnext_fold_scale_f32(const float* W, const float* b, const float* s, float* Wo, float* bo, int N, int K, void* stream) {
+    if (!W || !b || !s || !Wo || !bo) return fail(-1, "convnext_fold_scale: null argument");
+    TRY(cnx_fold_scale_launch(W, b, s, Wo, bo, N, K, (hipStream_t)stream), "convnext_fold_scale");
     return 0;
 }
 

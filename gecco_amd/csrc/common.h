@@ -43,9 +43,11 @@ __device__ __forceinline__ float gauss_act(float u, float neg_inv_2a2, bool norm
     return normalized ? (y - 0.7f) * (1.0f / 0.28f) : y;
 }
 // Epilogue activation by code (GemmArgs::act): 1 / 2 = GaussianActivation normalized / raw, 3 = ReLU (the reference's
-// default `activation=nn.ReLU`, models/mlp.py:12, set_transformer.py:81,133).  The code is wave-uniform.
+// default `activation=nn.ReLU`, models/mlp.py:12, set_transformer.py:81,133), 4 = GELU (erf form; the conditioner's
+// CNBlocks, models/feature_pyramid.py:28-73 through torchvision).  The code is wave-uniform.
 __device__ __forceinline__ float act_apply(float u, float neg_inv_2a2, int act) {
     if (act == 3) return fmaxf(u, 0.f);
+    if (act == 4) return 0.5f * u * (1.0f + erff(u * 0.70710678118654752f));   // nn.GELU() (exact erf form): ConvNeXt blocks
     return gauss_act(u, neg_inv_2a2, act == 1);
 }
 __device__ __forceinline__ bool act_is_gauss(int act) { return act == 1 || act == 2; }

@@ -1,0 +1,214 @@
+// ConvNeXt conditioner on the device, channels-last end to end (gfx950) — SURVEY.md 8(f) row 2.
+//
+// Reference: `ConvNeXtExtractor` (models/feature_pyramid.py:28-73) wraps torchvision's ConvNeXt-T/S stages
+//   stem      Conv2d(3, 96, k4, s4) + LayerNorm2d(eps 1e-6)
+//   CNBlock   x + layer_scale * Linear(4C -> C)(GELU(Linear(C -> 4C)(LayerNorm(dwconv7x7(x)))))      (stochastic depth off)
+//   downsample LayerNorm2d + Conv2d(C, 2C, k2, s2)
+// and hands NCHW maps to the lookup, which the reference re-runs per `upsample` evaluation (diffusion.py:415-421).  Here
+// every activation lives as (B, H, W, C) fp32 — one texel's channels contiguous, what ray_lookup_kernel gathers — so the
+// pyramid needs no NCHW -> NHWC transpose; the two pointwise linears of a block (96 % of its FLOPs) are the fused GEMM
+// of gemm_f32*.hip on rows = B H W (bias + GELU, or bias + residual with layer_scale folded into the weights), and
+// this file holds the HBM-bound rest: patchify stem, depthwise 7x7 + LayerNorm, LayerNorm + 2x2 patch gather, the
+// layer_scale fold.  LayerNorm statistics are per texel over its channels (fp32 sums over <= 384 values).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+__device__ __forceinline__ float group_sum(float v, int width) {   // sum over `width` consecutive lanes (power of two <= 64)
+    for (int o = 1; o < width; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- stem: out[b, h, w, :] = LN(W x_patch + bias), x NCHW (B, 3, H, W), patch 4 x 4 stride 4, weight (C, 3, 4, 4).
+// 8 lanes per output texel, lane q computes channels q, q + 8, ...; the 48 patch values sit in LDS.
+template <int C>
+__global__ __launch_bounds__(256) void stem_conv_ln_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, const float* __restrict__ ln_w,
+                                                           const float* __restrict__ ln_b, float* __restrict__ out, int B, int H,
+                                                           int W, float eps) {
+    constexpr int CPL = C / 8;                 // channels per lane
+    __shared__ float sw[48 * C];               // [k][c]: lanes of a texel read consecutive c
+    __shared__ float sp[32][48];
+    const int Ho = H / 4, Wo = W / 4;
+    for (int i = threadIdx.x; i < 48 * C; i += 256) sw[(i % 48) * C + i / 48] = w[i];   // w[c][k] -> sw[k][c]
+    const size_t npix = (size_t)B * Ho * Wo;
+    const size_t p0 = (size_t)blockIdx.x * 32;
+    for (int i = threadIdx.x; i < 32 * 48; i += 256) {
+        const int pl = i / 48, k = i % 48;
+        const size_t p = p0 + pl;
+        float v = 0.f;
+        if (p < npix) {
+            const int wo = (int)(p % Wo), ho = (int)((p / Wo) % Ho), b = (int)(p / ((size_t)Wo * Ho));
+            const int ci = k / 16, dy = (k / 4) & 3, dx = k & 3;
+            v = x[(((size_t)b * 3 + ci) * H + 4 * ho + dy) * W + 4 * wo + dx];
+        }
+        sp[pl][k] = v;
+    }
+    __syncthreads();
+    const int pl = threadIdx.x >> 3, q = threadIdx.x & 7;
+    const size_t p = p0 + pl;
+    float acc[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) acc[j] = bias[q + 8 * j];
+    for (int k = 0; k < 48; ++k) {
+        const float v = sp[pl][k];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) acc[j] += v * sw[k * C + q + 8 * j];
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) s1 += acc[j];
+    s1 = group_sum(s1, 8);
+    const float mean = s1 / C;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) s2 += (acc[j] - mean) * (acc[j] - mean);
+    s2 = group_sum(s2, 8);
+    const float rstd = rsqrtf(s2 / C + eps);
+    if (p < npix) {
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            const int c = q + 8 * j;
+            out[p * C + c] = (acc[j] - mean) * rstd * ln_w[c] + ln_b[c];
+        }
+    }
+}
+
+// ---- depthwise 7 x 7 (padding 3) + bias + LayerNorm over channels, channels-last.  TPP = C / 4 threads per texel (one
+// 16-byte channel chunk each), weight (C, 1, 7, 7) read as w[c][tap].
+template <int C>
+__global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, const float* __restrict__ ln_w,
+                                                         const float* __restrict__ ln_b, float* __restrict__ out, int B, int H,
+                                                         int W, float eps) {
+    constexpr int TPP = C / 4, PIX = 256 / TPP;
+    __shared__ float red[2][256];
+    const int pl = threadIdx.x / TPP, t = threadIdx.x % TPP;
+    const size_t npix = (size_t)B * H * W;
+    const size_t p = (size_t)blockIdx.x * PIX + pl;
+    const bool live = pl < PIX && p < npix;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int c = 4 * t;
+    if (live) {
+        const int wx = (int)(p % W), hy = (int)((p / W) % H), b = (int)(p / ((size_t)W * H));
+        acc = *reinterpret_cast<const f32x4*>(bias + c);
+        const float* xb = x + (size_t)b * H * W * C;
+#pragma unroll 1
+        for (int dy = -3; dy <= 3; ++dy) {
+            const int yy = hy + dy;
+            if (yy < 0 || yy >= H) continue;
+#pragma unroll
+            for (int dx = -3; dx <= 3; ++dx) {
+                const int xx = wx + dx;
+                if (xx < 0 || xx >= W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(xb + ((size_t)yy * W + xx) * C + c);
+                const int tap = (dy + 3) * 7 + dx + 3;
+                acc[0] += v[0] * w[(c + 0) * 49 + tap];
+                acc[1] += v[1] * w[(c + 1) * 49 + tap];
+                acc[2] += v[2] * w[(c + 2) * 49 + tap];
+                acc[3] += v[3] * w[(c + 3) * 49 + tap];
+            }
+        }
+    }
+    // LayerNorm over the texel's C channels: two passes through LDS partials (mean, then centred variance)
+    red[0][threadIdx.x] = acc[0] + acc[1] + acc[2] + acc[3];
+    __syncthreads();
+    float s1 = 0.f;
+    if (pl < PIX)
+        for (int i = 0; i < TPP; ++i) s1 += red[0][pl * TPP + i];
+    const float mean = s1 / C;
+    f32x4 d = acc - mean;
+    red[1][threadIdx.x] = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+    __syncthreads();
+    float s2 = 0.f;
+    if (pl < PIX)
+        for (int i = 0; i < TPP; ++i) s2 += red[1][pl * TPP + i];
+    const float rstd = rsqrtf(s2 / C + eps);
+    if (live) {
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(ln_w + c), b4 = *reinterpret_cast<const f32x4*>(ln_b + c);
+        *reinterpret_cast<f32x4*>(out + p * C + c) = d * rstd * g4 + b4;
+    }
+}
+
+// ---- downsample front half: LayerNorm over channels of every input texel, written where the 2 x 2 stride-2 conv's
+// GEMM reads it: out[b, h/2, w/2, (dy, dx, c)] (K = 4 C contiguous per output texel).
+template <int C>
+__global__ __launch_bounds__(256) void ln_patch2_kernel(const float* __restrict__ x, const float* __restrict__ ln_w,
+                                                        const float* __restrict__ ln_b, float* __restrict__ out, int B, int H,
+                                                        int W, float eps) {
+    constexpr int TPP = C / 4, PIX = 256 / TPP;
+    __shared__ float red[2][256];
+    const int pl = threadIdx.x / TPP, t = threadIdx.x % TPP;
+    const size_t npix = (size_t)B * H * W;
+    const size_t p = (size_t)blockIdx.x * PIX + pl;
+    const bool live = pl < PIX && p < npix;
+    const int c = 4 * t;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (live) v = *reinterpret_cast<const f32x4*>(x + p * C + c);
+    red[0][threadIdx.x] = v[0] + v[1] + v[2] + v[3];
+    __syncthreads();
+    float s1 = 0.f;
+    if (pl < PIX)
+        for (int i = 0; i < TPP; ++i) s1 += red[0][pl * TPP + i];
+    const float mean = s1 / C;
+    const f32x4 d = v - mean;
+    red[1][threadIdx.x] = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+    __syncthreads();
+    float s2 = 0.f;
+    if (pl < PIX)
+        for (int i = 0; i < TPP; ++i) s2 += red[1][pl * TPP + i];
+    const float rstd = rsqrtf(s2 / C + eps);
+    if (live) {
+        const int wx = (int)(p % W), hy = (int)((p / W) % H), b = (int)(p / ((size_t)W * H));
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(ln_w + c), b4 = *reinterpret_cast<const f32x4*>(ln_b + c);
+        const size_t op = ((size_t)b * (H / 2) + hy / 2) * (W / 2) + wx / 2;
+        *reinterpret_cast<f32x4*>(out + op * 4 * C + ((hy & 1) * 2 + (wx & 1)) * C + c) = d * rstd * g4 + b4;
+    }
+}
+
+// W'[n, k] = s[n] W[n, k], b'[n] = s[n] b[n]   (layer_scale folded into pwconv2: x + ls * (W h + b) = x + W' h + b')
+__global__ void fold_scale_kernel(const float* __restrict__ Wm, const float* __restrict__ b, const float* __restrict__ s,
+                                  float* __restrict__ Wo, float* __restrict__ bo, int N, int K) {
+    const size_t total = (size_t)N * K;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) Wo[i] = Wm[i] * s[i / K];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)N; i += (size_t)gridDim.x * blockDim.x) bo[i] = b[i] * s[i];
+}
+
+}  // namespace
+
+#define CNX_DISPATCH(KERNEL, C, grid, ...)                                                                      \
+    switch (C) {                                                                                                \
+        case 96: hipLaunchKernelGGL((KERNEL<96>), grid, dim3(256), 0, st, __VA_ARGS__); break;                  \
+        case 192: hipLaunchKernelGGL((KERNEL<192>), grid, dim3(256), 0, st, __VA_ARGS__); break;                \
+        case 384: hipLaunchKernelGGL((KERNEL<384>), grid, dim3(256), 0, st, __VA_ARGS__); break;                \
+        case 768: return -9; /* the fourth stage is not part of the pyramid (n_stages <= 3 in every config) */  \
+        default: return -9;                                                                                     \
+    }
+
+int cnx_stem_launch(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b, float* out, int B,
+                    int H, int W, int C, float eps, hipStream_t st) {
+    if (C != 96 || (H & 3) || (W & 3)) return -9;
+    const size_t npix = (size_t)B * (H / 4) * (W / 4);
+    hipLaunchKernelGGL((stem_conv_ln_kernel<96>), dim3((unsigned)((npix + 31) / 32)), dim3(256), 0, st, x, w, bias, ln_w, ln_b, out, B, H,
+                       W, eps);
+    return (int)hipGetLastError();
+}
+int cnx_dwconv_ln_launch(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b, float* out, int B,
+                         int H, int W, int C, float eps, hipStream_t st) {
+    const int pix = 256 / (C / 4);
+    const dim3 grid((unsigned)(((size_t)B * H * W + pix - 1) / pix));
+    CNX_DISPATCH(dwconv7_ln_kernel, C, grid, x, w, bias, ln_w, ln_b, out, B, H, W, eps);
+    return (int)hipGetLastError();
+}
+int cnx_ln_patch2_launch(const float* x, const float* ln_w, const float* ln_b, float* out, int B, int H, int W, int C, float eps,
+                         hipStream_t st) {
+    if ((H & 1) || (W & 1)) return -9;
+    const int pix = 256 / (C / 4);
+    const dim3 grid((unsigned)(((size_t)B * H * W + pix - 1) / pix));
+    CNX_DISPATCH(ln_patch2_kernel, C, grid, x, ln_w, ln_b, out, B, H, W, eps);
+    return (int)hipGetLastError();
+}
+int cnx_fold_scale_launch(const float* Wm, const float* b, const float* s, float* Wo, float* bo, int N, int K, hipStream_t st) {
+    hipLaunchKernelGGL(fold_scale_kernel, dim3(512), dim3(256), 0, st, Wm, b, s, Wo, bo, N, K);
+    return (int)hipGetLastError();
+}

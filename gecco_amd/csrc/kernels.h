@@ -15,7 +15,7 @@ struct GemmArgs {
     float* stats;           // (B, tilesM, 2, Nout) or null
     int B, rows, K, Nout;
     int lda, ldw, ldc, ldr;
-    int act;                // 0 none, 1 gaussian normalized, 2 gaussian raw, 3 ReLU
+    int act;                // 0 none, 1 gaussian normalized, 2 gaussian raw, 3 ReLU, 4 GELU (erf)
     int precision;          // 0 exact fp32 MFMA, 1 split-bf16, 2 fp16 (1 and 2 need w_img)
     const void* w_img;      // tiled image of W: bf16 hi | lo (split_bf16_tiled_launch) or fp16 (split_f16_tiled_launch)
     // optional second output segment, LDS-DMA kernel only: columns [n_split, Nout) are a second linear over the same
@@ -298,3 +298,12 @@ int sinkhorn_cost_launch(const float* C, const float* f, const float* g, float* 
 // sampler.hip — inpainting: re-draw the known points of the fp64 state at the current noise level
 int sampler_refresh_known_launch(double* x, const float* known, const float* noise, const double* sched, const int* step, int col,
                                  int m, int n_known, int B, hipStream_t st);
+
+// convnext.hip — channels-last ConvNeXt conditioner pieces (the pointwise linears run on the fused GEMM)
+int cnx_stem_launch(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b, float* out, int B,
+                    int H, int W, int C, float eps, hipStream_t st);
+int cnx_dwconv_ln_launch(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b, float* out, int B,
+                         int H, int W, int C, float eps, hipStream_t st);
+int cnx_ln_patch2_launch(const float* x, const float* ln_w, const float* ln_b, float* out, int B, int H, int W, int C, float eps,
+                         hipStream_t st);
+int cnx_fold_scale_launch(const float* Wm, const float* b, const float* s, float* Wo, float* bo, int N, int K, hipStream_t st);

@@ -43,13 +43,15 @@ def default_precision() -> str:
     return _default_precision
 
 
-ACT_NONE, ACT_GAUSS, ACT_GAUSS_RAW, ACT_RELU = 0, 1, 2, 3
+ACT_NONE, ACT_GAUSS, ACT_GAUSS_RAW, ACT_RELU, ACT_GELU = 0, 1, 2, 3, 4
 
 
 def act_code(act_alpha: Tensor | None, normalized: bool = True, act: str | int | None = None) -> int:
     """Epilogue activation code of the C ABI: GaussianActivation (alpha given) 1 / 2, "relu" 3, none 0."""
     if act in ("relu", ACT_RELU):
         return ACT_RELU
+    if act in ("gelu", ACT_GELU):
+        return ACT_GELU
     if act not in (None, "gauss", "none", ACT_NONE, ACT_GAUSS, ACT_GAUSS_RAW):
         raise ValueError(f"unknown activation {act!r}")
     if act_alpha is None:
@@ -66,6 +68,8 @@ def module_act(m) -> tuple[int, Tensor | None]:
         return ACT_RELU, None
     if isinstance(m, torch.nn.Identity):
         return ACT_NONE, None
+    if isinstance(m, torch.nn.GELU) and getattr(m, "approximate", "none") == "none":
+        return ACT_GELU, None
     raise NotImplementedError(f"activation {type(m).__name__} has no HIP epilogue (GaussianActivation, nn.ReLU, nn.Identity do)")
 
 

@@ -78,7 +78,7 @@ typedef struct GeccoSetTransformer {  /* SetTransformer, models/set_transformer.
  * Replaces nn.Linear call sites of models/set_transformer.py:49,65,112,165-166 and models/mlp.py.
  * stats: (B, T, 2, Nout) with T = gecco_linear_row_tiles(rows).  Any of bias/pro/alpha/residual/stats
  * may be NULL.  act: 0 none, 1 / 2 GaussianActivation normalized / raw (alpha required), 3 ReLU (the reference's
- * default activation, models/mlp.py:12). */
+ * default activation, models/mlp.py:12), 4 GELU in its exact erf form (the conditioner's CNBlocks). */
 int gecco_linear_f32(const float* A, const float* W, const float* bias, const float* pro_a, const float* pro_o,
                      const float* alpha, const float* residual, float* C, float* stats, int B, int rows, int K,
                      int Nout, int act, void* stream);
@@ -418,6 +418,22 @@ int gecco_chamfer_f32(const float* a, const float* b, float* out, float* ws, int
  * P_ij = exp((f_i + g_j - C_ij) / epsilon) / (N M).  f (B, N), g (B, M), rowcost (B, N) are caller scratch / outputs. */
 int gecco_sinkhorn_f32(const float* C, float* f, float* g, float* rowcost, float* out, int B, int N, int M, float epsilon,
                        int iterations, void* stream);
+
+/* ---- ConvNeXt conditioner, channels-last on the device (ConvNeXtExtractor, models/feature_pyramid.py:28-73,
+ * = torchvision's ConvNeXt stages).  Activations are (B, H, W, C) fp32.  The pointwise linears of a CNBlock run through
+ * gecco_linear_ex_f32 on rows = B H W (act = 4: exact-erf GELU; the second one with the block input as residual and
+ * layer_scale folded into its weights by gecco_convnext_fold_scale_f32); these are the rest of a block. */
+/* stem: out = LayerNorm_C(Conv2d(3 -> C, k4, s4)(x) + bias); x NCHW (B, 3, H, W), w (C, 3, 4, 4), out (B, H/4, W/4, C); C == 96 */
+int gecco_convnext_stem_f32(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b, float* out,
+                            int B, int H, int W, int C, float eps, void* stream);
+/* CNBlock front half: out = LayerNorm_C(dwconv7x7(x, padding 3) + bias); w (C, 1, 7, 7); C in {96, 192, 384} */
+int gecco_convnext_dwconv_ln_f32(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b, float* out,
+                                 int B, int H, int W, int C, float eps, void* stream);
+/* downsample front half: LayerNorm_C per texel, written as the 2 x 2 stride-2 conv's GEMM operand (B, H/2, W/2, (dy, dx, c)) */
+int gecco_convnext_ln_patch2_f32(const float* x, const float* ln_w, const float* ln_b, float* out, int B, int H, int W, int C,
+                                 float eps, void* stream);
+/* Wo[n, k] = s[n] W[n, k], bo[n] = s[n] b[n] (CNBlock.layer_scale folded into its second linear) */
+int gecco_convnext_fold_scale_f32(const float* W, const float* b, const float* s, float* Wo, float* bo, int N, int K, void* stream);
 
 #ifdef __cplusplus
 }

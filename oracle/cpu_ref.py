@@ -467,3 +467,33 @@ def sinkhorn_cost(Cm: Tensor, epsilon: float, iterations: int) -> Tensor:
         g = -epsilon * torch.logsumexp((f[:, :, None] - Cm) / epsilon - math.log(N), dim=1)
     P = torch.exp((f[:, :, None] + g[:, None, :] - Cm) / epsilon - math.log(N) - math.log(M))
     return (P * Cm).sum((1, 2))
+
+
+# --------------------------------------------------------------------------- ConvNeXt conditioner (a15 / f2)
+def convnext_features(image: Tensor, p: dict, pre: str = "stages.", n_stages: int = 3):
+    """ConvNeXtExtractor.forward (models/feature_pyramid.py:62-73) on torchvision's ConvNeXt stages restated with plain
+    torch ops (torchvision itself is absent from the image: parity unpinned for this function).  torchvision
+    `convnext.py`: stem Conv2d(3, C, k4, s4) + LayerNorm2d(eps 1e-6); CNBlock: x + layer_scale * (Linear(GELU(Linear(
+    LayerNorm(dwconv7x7(x), eps 1e-6))))) in NHWC; downsample LayerNorm2d + Conv2d(C, 2C, k2, s2).  `p` is keyed like the
+    reference's extractor: stages.{s}.0.* the stem / downsample, stages.{s}.1.{i}.block.{0,2,3,5}.*, .layer_scale."""
+    def ln2d(x, w, b):
+        return F.layer_norm(x.permute(0, 2, 3, 1), (x.shape[1],), w, b, 1e-6).permute(0, 3, 1, 2)
+
+    x, feats = image, []
+    for s in range(n_stages):
+        h = f"{pre}{s}.0."
+        if s == 0:
+            x = ln2d(F.conv2d(x, p[h + "0.weight"], p[h + "0.bias"], stride=4), p[h + "1.weight"], p[h + "1.bias"])
+        else:
+            x = F.conv2d(ln2d(x, p[h + "0.weight"], p[h + "0.bias"]), p[h + "1.weight"], p[h + "1.bias"], stride=2)
+        i = 0
+        while f"{pre}{s}.1.{i}.layer_scale" in p:
+            b = f"{pre}{s}.1.{i}."
+            C = x.shape[1]
+            y = F.conv2d(x, p[b + "block.0.weight"], p[b + "block.0.bias"], padding=3, groups=C).permute(0, 2, 3, 1)
+            y = F.layer_norm(y, (C,), p[b + "block.2.weight"], p[b + "block.2.bias"], 1e-6)
+            y = F.linear(F.gelu(F.linear(y, p[b + "block.3.weight"], p[b + "block.3.bias"])), p[b + "block.5.weight"], p[b + "block.5.bias"])
+            x = x + p[b + "layer_scale"] * y.permute(0, 3, 1, 2)
+            i += 1
+        feats.append(x)
+    return feats

@@ -60,8 +60,8 @@ def flops_per_sample():
     return L * per_layer + 2 * (2 * N * 3 * D)
 
 
-def random_state_dict(seed):
-    """Random-init weights of the C2 architecture, keyed like the reference state dict
+def random_state_dict(seed, D=D, L=L):
+    """Random-init weights of the C2 architecture (or another width / depth), keyed like the reference state dict
     (LinearLift: lift / inner.layers.i.* / lower.1); AdaGN and alpha deliberately non-default."""
     g = torch.Generator().manual_seed(seed)
     u = lambda o, i_: (torch.rand(o, i_, generator=g) * 2 - 1) / i_ ** 0.5
@@ -368,6 +368,120 @@ def train_bench(args, rank, world, dev):
         dist.destroy_process_group()
 
 
+def other_config_bench(args, rank, world, dev):
+    """`--config C3 | C4 | C5`: the other BASELINE.json shapes, same metric (denoiser forward points/s/GPU), same timing
+    contract; random-init weights (tests/test_hip_fullsize.py checks these very shapes against the oracle).  The conditioner is outside the timed step (it runs once per batch); its own time
+    on the channels-last HIP path is reported beside it for C3 / C4."""
+    from gecco_amd import distributed as gd
+    from gecco_amd import hip_ops as ops
+    ops.set_default_precision(args.precision)
+    cfg = args.config
+    Hh, Ii, Ll = H, I, 6
+    g0 = torch.Generator().manual_seed(1000 + rank)
+
+    def cloud(Bc, Nc):
+        import math
+        data = torch.randn(Bc, Nc, 3, generator=g0)
+        u = (torch.arange(Bc) + torch.rand(Bc, generator=g0)) / Bc
+        sig = torch.exp(math.log(0.002) + u * (math.log(165.0) - math.log(0.002)))
+        return (data + sig[:, None, None] * torch.randn(Bc, Nc, 3, generator=g0)).contiguous(), sig.float().contiguous()
+
+    def ray_weights(dc):
+        p_ll = random_state_dict(31, dc, Ll)
+        uu = lambda o, i_: (torch.rand(o, i_, generator=g0) * 2 - 1) / i_ ** 0.5
+        pr = {k.replace("inner.", "backbone."): v for k, v in p_ll.items() if k.startswith("inner.")}
+        pr["xyz_embed.weight"], pr["xyz_embed.bias"] = uu(dc, 3), uu(1, dc)[0]
+        pr["img_feature_proj.1.weight"], pr["img_feature_proj.1.bias"] = uu(dc, 672), uu(1, dc)[0]
+        pr["output_proj.1.weight"], pr["output_proj.1.bias"] = uu(3, dc), uu(1, 3)[0]
+        pr["reparam.uvl_mean"], pr["reparam.uvl_std"] = torch.tensor([0.0, 0.0, 1.38]), torch.tensor([0.56, 0.60, 0.49])
+        return {k: v.float().contiguous() for k, v in pr.items()}
+    if cfg == "C3":
+        Bc, Nc, dc, hw = 64, 2048, 384, 224
+    elif cfg == "C4":
+        Bc, Nc, dc, hw = 32, 4096, 512, 256
+    else:
+        Bc, Nc, dc, hw = 8, 2048, 384, 0
+        n_new = 16384
+    rec_extra = {}
+    per_layer = lambda n, d_: 16 * n * d_ * d_ + 8 * n * Ii * d_ + 14 * Ii * d_ * d_
+    if cfg in ("C3", "C4"):
+        p = {k: v.to(dev) for k, v in ray_weights(dc).items()}
+        feats = [torch.randn(Bc, c, hw // st_, hw // st_, generator=g0) for c, st_ in ((96, 4), (192, 8), (384, 16))]
+        K = torch.zeros(Bc, 3, 3)
+        K[:, 0, 0] = K[:, 1, 1] = 1.1
+        K[:, 0, 2] = K[:, 1, 2] = 0.5
+        K[:, 2, 2] = 1.0
+        net = ops.RayNetworkPlan(p, Hh, Ii)
+        levels = ops.to_channels_last_levels([f.to(dev) for f in feats])
+        x, sigma = cloud(Bc, Nc)
+        x, sigma, K = x.to(dev), sigma.to(dev), K.to(dev)
+        out = torch.empty_like(x)
+        step = lambda: net.forward(x, sigma, K, levels, out=out)
+        points = Bc * Nc
+        flops = Bc * (Ll * per_layer(Nc, dc) + 2 * Nc * 672 * dc + 2 * 2 * Nc * 3 * dc)
+        what = (f"{cfg} image-conditional denoiser forward: B={Bc}/GPU, N={Nc}, d={dc}, L={Ll}, {hw}x{hw} image -> pyramids "
+                f"{hw // 4}/{hw // 8}/{hw // 16} (96/192/384 ch), projective lookup + RayNetwork; conditioner outside the step")
+        # the conditioner itself, once per batch
+        from gecco_amd.models.feature_pyramid import ConvNeXtExtractor
+        from gecco_amd.structs import Context3d
+        cn = ConvNeXtExtractor(pretrained=False).to(dev).eval()
+        img = torch.rand(Bc, 3, hw, hw, device=dev)
+        ctx = Context3d(image=img, K=K)
+        cn(ctx)
+        rec_extra["conditioner_ms"] = time_events(lambda: cn(ctx), 3, warmup=1)
+    else:
+        p = {k: v.to(dev) for k, v in random_state_dict(9, dc, Ll).items()}
+        net = ops.LinearLiftPlan(p, Hh, Ii)
+        xk, sk = cloud(Bc, Nc)
+        xk, sk = xk.to(dev), sk.to(dev)
+        _, cache = net.forward(xk, sk, do_cache=True)
+        g = torch.Generator().manual_seed(7 + rank)
+        x = torch.randn(Bc, n_new, 3, generator=g).to(dev)
+        out = torch.empty_like(x)
+        step = lambda: net.forward(x, sk, cache=cache, out=out)
+        points = Bc * n_new
+        flops = Bc * Ll * (12 * n_new * dc * dc + 4 * n_new * Ii * dc)
+        what = (f"C5 cached-inducer (upsampling) evaluation: B={Bc}/GPU, n_new={n_new} points against the inducer states of "
+                f"N={Nc} known points, d={dc}, L={Ll} (diffusion.py:433-447: every sub-step of `upsample`)")
+    step()
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        step()
+    run = gr.replay
+    for _ in range(args.warmup):
+        run()
+    torch.cuda.synchronize()
+    gd.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    gd.barrier()
+    torch.cuda.synchronize()
+    dt = gd.max_over_ranks(time.perf_counter() - t0, dev)
+    assert torch.isfinite(out).all()
+    ms = dt / args.steps * 1e3
+    tf = flops / (ms * 1e-3) / 1e12
+    rec = {"metric": "denoiser_fwd_points_per_sec", "value": world * points * args.steps / dt, "unit": "points/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+           "config": {"workload": what + f"; arithmetic mode {args.precision}, seeded random weights",
+                      "parallelism": "replicas (batch-sharded, no data-path collective)" if world > 1 else "single GPU"},
+           "forward_tflops": tf, "launch": "hipgraph replay of one captured evaluation",
+           "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_BF16_MFMA_TFLOPS,
+                        "traffic": None,
+                        "kernel": "whole evaluation: algorithmic FLOPs (SURVEY.md Appendix B) / step time against the dense 16-bit MFMA "
+                                  "peak; the split-bf16 products of the mixed / bf16x3 modes execute 3 MFMAs per algorithmic product"},
+           **rec_extra}
+    if rank == 0:
+        print(json.dumps(rec))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -382,6 +496,8 @@ def main():
                          "output, split-bf16 elsewhere: D and F_x ~6e-5), split-bf16 (3 MFMAs per product, D and F_x "
                          "~2e-5 .. 5e-5 from the fp32 reference), fp16 operands with fp32 accumulation (faster; D ~4e-4, F_x ~1e-3: "
                          "at the 1e-3 bar) or exact fp32 MFMA (~1e-6)")
+    ap.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "C5"],
+                    help="BASELINE.json configuration: C2 (default, the headline), C3 / C4 image-conditional, C5 cached upsampling evaluation")
     ap.add_argument("--train", action="store_true", help="time the data-parallel training step instead of the forward")
     ap.add_argument("--train-batch", type=int, default=48, help="per-GPU batch of --train (shipped config: 48)")
     ap.add_argument("--bucket-mb", type=int, default=8, help="gradient all-reduce bucket size of --train")
@@ -414,6 +530,8 @@ def main():
     from gecco_amd import hip_ops as ops
     if args.train:
         return train_bench(args, rank, world, dev)
+    if args.config != "C2":
+        return other_config_bench(args, rank, world, dev)
     ops.set_default_precision(args.precision)
 
     p_cpu = random_state_dict(seed=3)

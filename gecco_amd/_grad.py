@@ -22,5 +22,5 @@ def require_no_grad(module, *tensors) -> None:
     needs = any(torch.is_tensor(t) and t.requires_grad for t in tensors) or any(p.requires_grad for p in module.parameters())
     if needs:
         raise GeccoTrainingNotSupported(
-            f"{type(module).__name__}: the MI355X HIP path has no backward kernels yet; run under torch.no_grad() "
-            "(sampling, upsampling, evaluation). Training support is the next scope row (SURVEY.md 8(f)).")
+            f"{type(module).__name__} has no backward on the MI355X HIP path (the denoiser, loss and optimizer do: "
+            "gecco_amd/autograd.py, gecco_amd/optim.py); run this module under torch.no_grad() or keep its parameters frozen.")

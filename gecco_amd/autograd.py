@@ -50,6 +50,16 @@ def _train_precision() -> str:
     return "bf16x3" if p in ("fp16", "mixed") else p
 
 
+def _no_input_grad(ctx, idx: int, what: str) -> None:
+    """The training path differentiates with respect to PARAMETERS (and the conditioner's pyramid); a caller asking for the
+    gradient of the denoiser with respect to the geometry or the noise level (guidance, score Jacobians) must hear about it
+    instead of receiving a silently missing gradient."""
+    if ctx.needs_input_grad[idx]:
+        from ._grad import GeccoTrainingNotSupported
+        raise GeccoTrainingNotSupported(f"the HIP training path has no gradient with respect to {what} (parameters and feature "
+                                        "pyramids only): detach it, or differentiate through the reference modules")
+
+
 def _new(*shape, like: Tensor) -> Tensor:
     return torch.empty(*shape, device=like.device, dtype=torch.float32)
 
@@ -119,6 +129,7 @@ class AdaGNFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _no_input_grad(ctx, 1, "the noise-level embedding t")
         x, stats, t2, sw, sb = ctx.saved_tensors
         dy = _f(dy)
         lib = _lib.load()
@@ -300,6 +311,7 @@ class LiftFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _no_input_grad(ctx, 0, "the geometry")
         (x,) = ctx.saved_tensors
         dy = _f(dy)
         lib = _lib.load()
@@ -361,7 +373,9 @@ class Linear3Fn(torch.autograd.Function):
         part = _new(B, T, 4, Cc, like=y)
         _lib.check(lib.gecco_lift_bwd_f32(_ptr(y), _ptr(dF), _ptr(part), B, N, Cc, _stream()), "lift_bwd")
         red = _reduce(part, 4 * Cc, B * T, 4 * Cc).reshape(4, Cc)
-        return dy, red[:3].contiguous(), dF.sum(dim=(0, 1))
+        st = hip_ops.col_stats(dF)   # (B, T, 2, 3): [..., 0, :] = column sums -> the bias gradient, summed in a fixed order
+        db = _reduce(st, 3, B * st.shape[1], 2 * 3)
+        return dy, red[:3].contiguous(), db
 
 
 class LookupFn(torch.autograd.Function):
@@ -378,6 +392,8 @@ class LookupFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        _no_input_grad(ctx, 0, "the geometry")
+        _no_input_grad(ctx, 1, "the camera matrix")
         geom, K, *levels = ctx.saved_tensors
         dout = _f(dout)
         lib = _lib.load()

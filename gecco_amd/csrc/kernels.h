@@ -245,49 +245,6 @@ struct AdamEmaArgs {
 int adam_ema_launch(const AdamEmaArgs& a, hipStream_t st);
 int ema_update_launch(const float* p, float* ema, size_t n, double decay, hipStream_t st);
 
-// gemm_x3_planes.hip — split-bf16 linear on PRE-SPLIT operands ("planes": per row K/32 blocks of [32 bf16 hi | 32 bf16 lo]),
-// 8-wave / 8-phase LDS-DMA schedule.  Rows are flat (rows_total = B * rows_per_sample).
-struct X3Args {
-    const void* Y;          // activation planes (rows_total, K/32, 2, 32) bf16
-    const void* Wimg;       // weight planes image (split_planes_image_launch), rows in the kernel's channel order
-    const float* bias;      // (Nout) or null
-    const float* alpha;     // GaussianActivation alpha (act 1 / 2)
-    const float* residual;  // (rows_total, ldr) fp32 or null
-    float* C;               // fp32 (rows_total, ldc); or, with c_planes, the output planes (rows_total, Nout/32, 2, 32)
-    float* stats;           // (rows_total / gemm_x3_planes_row_tile(), 2, Nout) column sums / sums of squares, or null
-    int rows_total, rows_per_sample, K, Nout, ldc, ldr, act, c_planes;
-    float* C2;              // optional second output segment: channels [n_split, Nout) -> C2 (rows_total, ldc2), bias2
-    const float* bias2;
-    int n_split, ldc2;
-    int skew;               // start-up skew per XCD index in s_sleep(127) units; < 0: the launcher's default
-};
-bool gemm_x3_planes_supported(const X3Args& g);
-int gemm_x3_planes_row_tile(int Nout, int n_split);   // rows per statistics partial of the configuration picked (0: unsupported)
-int gemm_x3_planes_launch(const X3Args& g, hipStream_t st);
-size_t planes_image_bytes(int Nout, int K);           // ceil(Nout / 32) * 32 * K * 4
-int split_planes_image_launch(const float* W, void* img, int Nout, int K, int ldw, hipStream_t st);
-int split_planes_image_multi_launch(const SplitJobs& jobs, hipStream_t st);
-// y planes = a[b, c] * x + o[b, c] (a == null: x itself), C % 32 == 0
-int affine_split_planes_launch(const float* x, const float* a, const float* o, void* y, size_t rows_total, int rows_per_sample,
-                               int C, hipStream_t st);
-
-// mlp_x3_fused.hip — split-bf16 mode: x += mlp.2(act(mlp.0(a * x + o))) + GroupNorm partials in one launch; activations
-// in registers (transposed products), only the weight stream image (mlp_x3_stream_launch) passes through LDS
-struct MlpX3Args {
-    float* x;                    // (rows_total, C) fp32, updated in place
-    const float *pro_a, *pro_o;  // (B, C) AdaGN coefficients
-    const void* w_stream;        // mlp_x3_stream_launch image of (W0, W2), mlp_x3_stream_bytes(C) bytes
-    const float *b0, *b2, *alpha;
-    int act;
-    float* stats;                // (rows_total / mlp_x3_fused_row_tile(C), 2, C) or null
-    int rows_total, rows_per_sample;
-};
-int mlp_x3_fused_row_tile(int C);
-bool mlp_x3_fused_supported(int C, int Wd, int rows_per_sample);
-size_t mlp_x3_stream_bytes(int C);
-int mlp_x3_stream_launch(const float* W0, const float* W2, void* img, int C, hipStream_t st);
-int mlp_x3_fused_launch(const MlpX3Args& g, int C, hipStream_t st);
-
 // metrics.hip — evaluation metrics on (B, N, 3) clouds (gecco-jax metrics.py:92-156, geometry.py:8-24)
 int dist_matrix_launch(const float* A, const float* Bp, float* D, int B, int N, int M, int squared, hipStream_t st);
 int nearest_dist_launch(const float* A, const float* Bp, float* mins, int B, int N, int M, int squared, hipStream_t st);

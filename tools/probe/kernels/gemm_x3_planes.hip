@@ -31,8 +31,8 @@
 // Other widths (d = 128's 128-wide outputs) stay on gemm_f32_dma.hip.
 // Requires K % 64 == 0, rows % BM == 0 (a row tile never straddles samples when the per-sample row count is a multiple
 // of BM), Nout % BN == 0 (per segment).
-#include "common.h"
-#include "kernels.h"
+#include "../../../gecco_amd/csrc/common.h"
+#include "x3_experimental.h"
 
 // Epilogue traffic is streamed (nontemporal): the tile walk lives on W and the Y row tiles staying in the XCD's L2
 #ifdef X3_PLAIN_EPILOGUE

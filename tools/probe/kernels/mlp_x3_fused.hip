@@ -24,8 +24,8 @@
 // Epilogue from the accumulators: + b2 + x (fp32 residual rows re-read), 16-byte stores, per-column sums and sums of
 // squares of the new x reduced over the block's points in a fixed order (deterministic).
 // Template <NC = C / 128, P>: C = 384 with P = 2 (128 points per block), C = 512 with P = 1.  Hidden width 2 C.
-#include "common.h"
-#include "kernels.h"
+#include "../../../gecco_amd/csrc/common.h"
+#include "x3_experimental.h"
 
 #ifdef MX_DIAG_NOMFMA
 #define MX_MFMA(a, b, c) ((c) + f32x4{(float)(a)[0] + (float)(b)[0], 0.f, 0.f, 0.f})
@@ -43,15 +43,16 @@ __device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 0xF) | (0x7 << 4) | ((lgkm & 0xF) << 8) | ((vm >> 4) << 14); }
-__device__ __forceinline__ void wait_vm_slots(int slots) {   // s_waitcnt vmcnt(4 * slots), wave-uniform, 0..6
+template <int PER>   // s_waitcnt vmcnt(PER * slots): PER DMA instructions per wave per slot; wave-uniform slots 0..6
+__device__ __forceinline__ void wait_vm_slots(int slots) {
     switch (slots) {
         case 0: __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0xF)); break;
-        case 1: __builtin_amdgcn_s_waitcnt(waitcnt_imm(4, 0xF)); break;
-        case 2: __builtin_amdgcn_s_waitcnt(waitcnt_imm(8, 0xF)); break;
-        case 3: __builtin_amdgcn_s_waitcnt(waitcnt_imm(12, 0xF)); break;
-        case 4: __builtin_amdgcn_s_waitcnt(waitcnt_imm(16, 0xF)); break;
-        case 5: __builtin_amdgcn_s_waitcnt(waitcnt_imm(20, 0xF)); break;
-        default: __builtin_amdgcn_s_waitcnt(waitcnt_imm(24, 0xF)); break;
+        case 1: __builtin_amdgcn_s_waitcnt(waitcnt_imm(PER, 0xF)); break;
+        case 2: __builtin_amdgcn_s_waitcnt(waitcnt_imm(2 * PER, 0xF)); break;
+        case 3: __builtin_amdgcn_s_waitcnt(waitcnt_imm(3 * PER, 0xF)); break;
+        case 4: __builtin_amdgcn_s_waitcnt(waitcnt_imm(4 * PER, 0xF)); break;
+        case 5: __builtin_amdgcn_s_waitcnt(waitcnt_imm(5 * PER, 0xF)); break;
+        default: __builtin_amdgcn_s_waitcnt(waitcnt_imm(6 * PER, 0xF)); break;
     }
 }
 // chunk swizzle of a 128-byte LDS row (gemm_x3_planes.hip): conflict-free ds_read_b128 fragment reads
@@ -80,12 +81,14 @@ __device__ unsigned long long g_mx_stamps[1024 * 8];
 #define MX_STAMP(i)
 #endif
 
-template <int NC, int P, int YL, int RING>
-__global__ __launch_bounds__(256, 1) void mlp_x3_fused_kernel(MlpX3Args g) {
-    constexpr int AHEAD = RING - 1;
+// NW waves per block (4: one per SIMD, up to 512 registers each; 8: two per SIMD, 256 registers each — the second wave
+// fills the issue slots and latencies the first leaves open), each owning 16 P points.
+template <int NC, int P, int YL, int RING, int NW>
+__global__ __launch_bounds__(64 * NW) void mlp_x3_fused_kernel(MlpX3Args g) {
+    constexpr int AHEAD = RING - 1, NT = 64 * NW, DPW = 16 / NW;   // threads; DMA wave-instructions per wave per 16 KiB slot
     constexpr int C = 128 * NC, WD = 2 * C, NK = C / 32, NCT = C / 16, NCH = WD / 32;
     constexpr int S1 = NC, S2 = NC, NS = S1 + S2;    // slots per hidden chunk: W0 pieces of 4 K-steps, W2 pieces of 8 channel tiles
-    constexpr int PTS = 16 * P, BM = 4 * PTS;
+    constexpr int PTS = 16 * P, BM = NW * PTS;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     float* lb0 = reinterpret_cast<float*>(lds + RING * SLOT);   // b0 (WD) | b2 (C)
     float* lb2 = lb0 + WD;
@@ -103,17 +106,17 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_fused_kernel(MlpX3Args g) {
     MX_STAMP(0);
     // ---- weight ring: each wave copies its quarter (4 KiB = 4 wave-instructions) of every slot, linearly
     auto issue = [&](int sigma) {
-        const unsigned char* src = stream + (size_t)sigma * SLOT + wave * 4096 + lane * 16;
-        unsigned char* dst = lds + (sigma % RING) * SLOT + wave * 4096;
+        const unsigned char* src = stream + (size_t)sigma * SLOT + wave * (DPW * 1024) + lane * 16;
+        unsigned char* dst = lds + (sigma % RING) * SLOT + wave * (DPW * 1024);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dma16(src + q * 1024, dst + q * 1024);
+        for (int q = 0; q < DPW; ++q) dma16(src + q * 1024, dst + q * 1024);
     };
 #pragma unroll
     for (int s = 0; s < AHEAD; ++s) issue(s);        // total >= 24 slots
 
     // ---- biases into LDS (ordinary loads; the wait below also covers the ring's first slots: in-order completion)
-    for (int i = tid; i < WD; i += 256) lb0[i] = g.b0 ? g.b0[i] : 0.f;
-    for (int i = tid; i < C; i += 256) lb2[i] = g.b2 ? g.b2[i] : 0.f;
+    for (int i = tid; i < WD; i += NT) lb0[i] = g.b0 ? g.b0[i] : 0.f;
+    for (int i = tid; i < C; i += NT) lb2[i] = g.b2 ? g.b2[i] : 0.f;
     __builtin_amdgcn_s_waitcnt(waitcnt_imm(0x3F, 0));   // the LDS writes are done before this wave reaches the first barrier
 
     // ---- y = a * x + o of this wave's 16 P points, split into B-operand fragments (lane (fr, fq): point fr of the
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_fused_kernel(MlpX3Args g) {
     auto enter_slot = [&](int sigma) -> const unsigned char* {
         const int after = total - 1 - sigma;         // slots issued after sigma and still allowed in flight (<= 6)
 #ifndef MX_DIAG_NODMA
-        wait_vm_slots(after < AHEAD - 1 ? after : AHEAD - 1);
+        wait_vm_slots<DPW>(after < AHEAD - 1 ? after : AHEAD - 1);
 #endif
 #ifndef MX_DIAG_NOBARRIER
         __builtin_amdgcn_s_barrier();
@@ -210,7 +213,28 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_fused_kernel(MlpX3Args g) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const int f = kk & 1, kt = 4 * s1 + kk;
-                if (kk + 1 < 4) load1(kk + 1, f ^ 1);
+                const bool ylo_now = kt >= NK - YL, ylo_next = kt + 1 >= NK - YL;
+                // explicit software pipeline (hipcc would sink the reads to just before their use and wait lgkmcnt(0) every
+                // few MFMAs): issue the next sub-step's reads, wait only for THIS sub-step's (LDS returns in order), and
+                // "redefine" the fragments so that the compiler's own wait-count pass adds nothing in front of the MFMAs
+                if (kk + 1 < 4) {
+                    load1(kk + 1, f ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ylo_next) __builtin_amdgcn_s_waitcnt(waitcnt_imm(0x3F, 4 + P));
+                    else __builtin_amdgcn_s_waitcnt(waitcnt_imm(0x3F, 4));
+                } else {
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_waitcnt(waitcnt_imm(0x3F, 0));
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    asm volatile("" : "+v"(wh[f][j]));
+                    asm volatile("" : "+v"(wl[f][j]));
+                }
+                if (ylo_now) {
+#pragma unroll
+                    for (int pt = 0; pt < P; ++pt) asm volatile("" : "+v"(ylk[f][pt]));
+                }
                 // three terms, accumulators interleaved (consecutive MFMAs never share one)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
@@ -225,6 +249,7 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_fused_kernel(MlpX3Args g) {
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int pt = 0; pt < P; ++pt) X[j][pt] = MX_MFMA(wh[f][j], yh[kt][pt], X[j][pt]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         // ---- bias, activation, hi | lo split on the accumulator registers: lane (point fr, fq) holds units
@@ -269,7 +294,19 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_fused_kernel(MlpX3Args g) {
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
                 const int f = qq & 1;
-                if (qq + 1 < 4) load2(qq + 1, f ^ 1);
+                if (qq + 1 < 4) {
+                    load2(qq + 1, f ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_waitcnt(waitcnt_imm(0x3F, 4));
+                } else {
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_waitcnt(waitcnt_imm(0x3F, 0));
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    asm volatile("" : "+v"(wh[f][q]));
+                    asm volatile("" : "+v"(wl[f][q]));
+                }
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -291,6 +328,7 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_fused_kernel(MlpX3Args g) {
                         f32x4& a = acc[8 * s2 + 2 * qq + q][pt];
                         a = MX_MFMA(wh[f][q], xh[pt], a);
                     }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
@@ -346,10 +384,12 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_fused_kernel(MlpX3Args g) {
     MX_STAMP(5);
     if (g.stats) {
         __syncthreads();
-        for (int i = tid; i < 2 * C; i += 256) {
+        for (int i = tid; i < 2 * C; i += NT) {
             const int which = i / C, c = i % C;
-            g.stats[((size_t)blockIdx.x * 2 + which) * C + c] =
-                ((red[(0 * 2 + which) * C + c] + red[(1 * 2 + which) * C + c]) + red[(2 * 2 + which) * C + c]) + red[(3 * 2 + which) * C + c];
+            float t = red[(0 * 2 + which) * C + c];
+#pragma unroll
+            for (int wv = 1; wv < NW; ++wv) t += red[(wv * 2 + which) * C + c];   // fixed order: deterministic
+            g.stats[((size_t)blockIdx.x * 2 + which) * C + c] = t;
         }
     }
 }
@@ -388,17 +428,17 @@ __global__ void mlp_x3_stream_kernel(const float* __restrict__ W0, const float* 
     }
 }
 
-template <int NC, int P, int YL, int RING>
+template <int NC, int P, int YL, int RING, int NW>
 int launch_t(const MlpX3Args& g, hipStream_t st) {
     constexpr int C = 128 * NC;
-    constexpr int lds = RING * SLOT + (2 * C + C) * 4 + 4 * YL * P * 1024;
-    static_assert(lds <= 160 * 1024 && 4 * 2 * C * 4 <= RING * SLOT, "LDS budget");
+    constexpr int lds = RING * SLOT + (2 * C + C) * 4 + NW * YL * P * 1024;
+    static_assert(lds <= 160 * 1024 && NW * 2 * C * 4 <= RING * SLOT, "LDS budget");
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_x3_fused_kernel<NC, P, YL, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_x3_fused_kernel<NC, P, YL, RING, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr = true;
     }
-    hipLaunchKernelGGL((mlp_x3_fused_kernel<NC, P, YL, RING>), dim3(g.rows_total / (64 * P)), dim3(256), lds, st, g);
+    hipLaunchKernelGGL((mlp_x3_fused_kernel<NC, P, YL, RING, NW>), dim3(g.rows_total / (16 * P * NW)), dim3(64 * NW), lds, st, g);
     return (int)hipGetLastError();
 }
 
@@ -425,8 +465,12 @@ int mlp_x3_stream_launch(const float* W0, const float* W2, void* img, int C, hip
 int mlp_x3_fused_launch(const MlpX3Args& g, int C, hipStream_t st) {
     if (!mlp_x3_fused_supported(C, 2 * C, g.rows_per_sample) || g.rows_total % mlp_x3_fused_row_tile(C)) return -9;
     switch (C) {
-        case 256: return launch_t<2, 2, 0, 8>(g, st);
-        case 384: return launch_t<3, 2, 8, 5>(g, st);
-        default: return launch_t<4, 1, 2, 8>(g, st);
+        case 256: return launch_t<2, 2, 0, 8, 4>(g, st);
+#ifdef MX_P1
+        case 384: return launch_t<3, 1, MX_YL, MX_RING, 8>(g, st);
+#else
+        case 384: return launch_t<3, 2, 8, 5, 4>(g, st);
+#endif
+        default: return launch_t<4, 1, 2, 8, 4>(g, st);
     }
 }

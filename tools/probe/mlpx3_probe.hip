@@ -1,6 +1,6 @@
 // Correctness + timing probe of mlp_x3_fused.hip (standalone).
 #include <hip/hip_runtime.h>
-#include "../../gecco_amd/csrc/mlp_x3_fused.hip"
+#include "kernels/mlp_x3_fused.hip"
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>

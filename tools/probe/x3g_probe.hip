@@ -1,7 +1,7 @@
 // Correctness + timing probe of gemm_x3_planes.hip (standalone: hipcc, no torch).
 //   ./x3g_probe            correctness on small shapes vs a host fp64 reference, then timing at the C2 call sites
 #include <hip/hip_runtime.h>
-#include "../../gecco_amd/csrc/gemm_x3_planes.hip"
+#include "kernels/gemm_x3_planes.hip"
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>

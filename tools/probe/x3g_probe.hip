@@ -101,10 +101,11 @@ int main(int argc, char** argv) {
     (void)hipMalloc(&bias, 1152 * 4); (void)hipMalloc(&st, (size_t)(rows / 64) * 2 * 1152 * 4); (void)hipMalloc(&alpha, 4);
     (void)hipMalloc(&Y, rows * 768 * 4); (void)hipMalloc(&img, 1152 * 768 * 4);
     std::vector<float> h(rows * 768);
-    for (auto& v : h) v = (float)gauss();
+    const bool zero = getenv("ZERO") != nullptr;
+    for (auto& v : h) v = zero ? 0.f : (float)gauss();
     (void)hipMemcpy(x, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(R, h.data(), rows * 384 * 4, hipMemcpyHostToDevice);
-    for (size_t i = 0; i < 1152 * 768; ++i) h[i] = (float)(rnd() / 20);
+    for (size_t i = 0; i < 1152 * 768; ++i) h[i] = zero ? 0.f : (float)(rnd() / 20);
     (void)hipMemcpy(W, h.data(), 1152 * 768 * 4, hipMemcpyHostToDevice); (void)hipMemcpy(bias, h.data(), 1152 * 4, hipMemcpyHostToDevice);
     float one = 1.f; (void)hipMemcpy(alpha, &one, 4, hipMemcpyHostToDevice);
     struct Site { const char* name; int K, Nout, split; bool res, stats, planes; int act; } sites[] = {

@@ -333,7 +333,8 @@ def train_bench(args, rank, world, dev):
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None,
            "dtype": {"bf16x3": "bf16 (split hi+lo operands, 3 MFMAs per product, fp32 accumulate)", "fp32": "f32",
-                     "fp16": "bf16 (split; the fp16 mode is not used for gradients)"}[args.precision],
+                     "fp16": "bf16 (split; the fp16 mode is not used for gradients)",
+                     "mixed": "bf16 (split; the mixed mode trains in split-bf16)"}[args.precision],
            "data": "synthetic",
            "config": {"workload": f"C2 unconditional training step: batch {Bt}/GPU, N={N}, d={D}, L={L}: EDMLoss forward + backward "
                                   "(HIP autograd Functions), bucketed gradient all-reduce overlapped with backward, fused Adam+EMA",

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GECCO_HIP_LIB") or os.path.join(_HERE, "libgecco_hip.so")   # override: A/B builds only
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_f = C.c_void_p  # device pointers travel as void*
 
@@ -101,6 +101,11 @@ SIGNATURES = {
     "gecco_pool_attn_workspace_bytes": (sz, [i, i, i, i, i]),
     "gecco_unpool_attn_f32": (i, [vp, vp, vp, i, i, i, i, i, vp]),
     "gecco_unpool_attn_ex_f32": (i, [vp, vp, vp, i, i, i, i, i, i, vp]),
+    "gecco_pool_attn_lse_f32": (i, [vp, sz, vp, i, i, i, i, i, vp]),
+    "gecco_pool_attn_bwd_partials": (i, [i, i, i]),
+    "gecco_pool_attn_bwd_f32": (i, [vp] * 7 + [i, i, i, i, i, vp]),
+    "gecco_unpool_attn_bwd_partials": (i, [i, i, i]),
+    "gecco_unpool_attn_bwd_f32": (i, [vp] * 5 + [i, i, i, i, i, vp]),
     "gecco_edm_coeffs_f32": (i, [vp, fl, vp, i, vp]),
     "gecco_lift_f32": (i, [vp, vp, vp, vp, vp, vp, i, i, i, vp]),
     "gecco_lower_edm_f32": (i, [vp] * 9 + [i, i, i, fl, vp]),

@@ -2,8 +2,9 @@
 
 The inference path fuses a whole evaluation into one C call and keeps nothing; training needs the intermediates, so
 it runs the reference's op sequence unfused (models/set_transformer.py:155-168) with every op a Function:
-Linear / AdaGN / GaussianActivation / pool & unpool attention (scores materialised, products on the general
-strided-batched GEMM with per-operand layout flags, so no tensor is transposed for a backward product) / lift /
+Linear / AdaGN / GaussianActivation / pool & unpool attention (fused flash-style forward and backward kernels,
+csrc/attention_bwd_f32.hip: no (B, H, N, I) tensor exists; shapes they do not take run with materialised scores on the
+general strided-batched GEMM with per-operand layout flags, so no tensor is transposed for a backward product) / lift /
 lower.  Cross-workgroup reductions use per-block partials summed in a fixed order: gradients are bitwise
 reproducible.  EDM preconditioning and the loss are (B, N, 3) elementwise torch ops.
 """
@@ -11,6 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import torch
 from torch import Tensor
@@ -206,6 +208,12 @@ def _softmax_bwd(P: Tensor, dP: Tensor, scale: float) -> Tensor:
     return dS
 
 
+def _fused_attn_ok(I: int, hd: int) -> bool:
+    """Shapes the fused attention kernels take (every shipped config: 64 inducers, head dim d / 8); others run the
+    strided-batched GEMM form below."""
+    return I == 64 and hd in (8, 16, 32, 48, 64) and os.environ.get("GECCO_TRAIN_ATTN", "fused") != "gemm"
+
+
 class PoolAttnFn(torch.autograd.Function):
     """AttentionPool core: KV (B, N, 2C), inducers (1, H, I, hd) -> merged heads (B, I, C)."""
 
@@ -214,6 +222,22 @@ class PoolAttnFn(torch.autograd.Function):
         KV, ind = _f(KV), _f(ind)
         B, N, C2 = KV.shape
         Cc, I, hd = C2 // 2, ind.shape[2], ind.shape[3]
+        ctx.H = H
+        ctx.fused = _fused_attn_ok(I, hd)
+        if ctx.fused:
+            # flash-style forward (no (B, H, I, N) tensor) + the log-sum-exp the fused backward recomputes P from
+            lib = _lib.load()
+            nb = lib.gecco_pool_attn_workspace_bytes(B, N, Cc, H, I)
+            ws = torch.empty(nb, dtype=torch.uint8, device=KV.device)
+            O = _new(B, I, Cc, like=KV)
+            pr = hip_ops.PRECISIONS[_train_precision()]
+            _lib.check(lib.gecco_pool_attn_ex_f32(_ptr(KV), _ptr(ind), _ptr(O), B, N, Cc, H, I, pr, C.c_void_p(ws.data_ptr()), nb,
+                                                  _stream()), "gecco_pool_attn_ex_f32")
+            lse = _new(B, H, I, like=KV)
+            _lib.check(lib.gecco_pool_attn_lse_f32(C.c_void_p(ws.data_ptr()), nb, _ptr(lse), B, N, Cc, H, I, _stream()),
+                       "gecco_pool_attn_lse_f32")
+            ctx.save_for_backward(KV, ind, O, lse)
+            return O
         sc = 1.0 / math.sqrt(hd)
         S = _new(B, H, I, N, like=KV)
         _gemm(ind, KV, S, Z=B * H, zdiv=H, M=I, N=N, K=hd, lda=hd, ldb=C2, ldc=N, sA=(0, I * hd), sB=(N * C2, hd),
@@ -223,14 +247,23 @@ class PoolAttnFn(torch.autograd.Function):
         _gemm(P, KV, O, Z=B * H, zdiv=H, M=I, N=hd, K=N, lda=N, ldb=C2, ldc=Cc, sA=(H * I * N, I * N), sB=(N * C2, hd),
               sC=(I * Cc, hd), b_km=True, b_off=Cc)
         ctx.save_for_backward(KV, ind, P)
-        ctx.H = H
         return O
 
     @staticmethod
     def backward(ctx, dO):
-        KV, ind, P = ctx.saved_tensors
         dO = _f(dO)
         H = ctx.H
+        if ctx.fused:
+            KV, ind, O, lse = ctx.saved_tensors
+            B, N, C2 = KV.shape
+            Cc, I, hd = C2 // 2, ind.shape[2], ind.shape[3]
+            lib = _lib.load()
+            P = B * lib.gecco_pool_attn_bwd_partials(B, N, H)
+            dKV, dQp = torch.empty_like(KV), _new(P, H, I, hd, like=KV)
+            _lib.check(lib.gecco_pool_attn_bwd_f32(_ptr(KV), _ptr(ind), _ptr(O), _ptr(lse), _ptr(dO), _ptr(dKV), _ptr(dQp), B, N, Cc,
+                                                   H, I, _stream()), "gecco_pool_attn_bwd_f32")
+            return dKV, _reduce(dQp, H * I * hd, P, H * I * hd).reshape(ind.shape), None
+        KV, ind, P = ctx.saved_tensors
         B, N, C2 = KV.shape
         Cc, I, hd = C2 // 2, ind.shape[2], ind.shape[3]
         sc = 1.0 / math.sqrt(hd)
@@ -262,6 +295,11 @@ class UnpoolAttnFn(torch.autograd.Function):
         q, kvh = _f(q), _f(kvh)
         B, N, Cc = q.shape
         I, hd = kvh.shape[1], Cc // H
+        ctx.H = H
+        ctx.fused = _fused_attn_ok(I, hd)
+        if ctx.fused:
+            ctx.save_for_backward(q, kvh)
+            return hip_ops.unpool_attn(q, kvh, H, precision=_train_precision())
         sc = 1.0 / math.sqrt(hd)
         S = _new(B, H, N, I, like=q)
         zq, zk, zS = (N * Cc, hd), (I * 2 * Cc, hd), (H * N * I, N * I)
@@ -270,14 +308,24 @@ class UnpoolAttnFn(torch.autograd.Function):
         O = torch.empty_like(q)
         _gemm(P, kvh, O, Z=B * H, zdiv=H, M=N, N=hd, K=I, lda=I, ldb=2 * Cc, ldc=Cc, sA=zS, sB=zk, sC=zq, b_km=True, b_off=Cc)
         ctx.save_for_backward(q, kvh, P)
-        ctx.H = H
         return O
 
     @staticmethod
     def backward(ctx, dO):
-        q, kvh, P = ctx.saved_tensors
         dO = _f(dO)
         H = ctx.H
+        if ctx.fused:
+            q, kvh = ctx.saved_tensors
+            B, N, Cc = q.shape
+            I = kvh.shape[1]
+            lib = _lib.load()
+            P = lib.gecco_unpool_attn_bwd_partials(B, N, H)
+            dq, parts = torch.empty_like(q), _new(P, B, I, 2 * Cc, like=q)
+            _lib.check(lib.gecco_unpool_attn_bwd_f32(_ptr(q), _ptr(kvh), _ptr(dO), _ptr(dq), _ptr(parts), B, N, Cc, H, I, _stream()),
+                       "gecco_unpool_attn_bwd_f32")
+            n = B * I * 2 * Cc
+            return dq, (parts[0] if P == 1 else _reduce(parts, n, P, n).reshape(B, I, 2 * Cc)), None
+        q, kvh, P = ctx.saved_tensors
         B, N, Cc = q.shape
         I, hd = kvh.shape[1], Cc // H
         sc = 1.0 / math.sqrt(hd)

@@ -741,6 +741,38 @@ int gecco_pool_attn_ex_f32(const float* KV, const float* inducers, float* merged
     return 0;
 }
 
+int gecco_pool_attn_lse_f32(const void* ws, size_t ws_bytes, float* lse, int B, int N, int C, int H, int I, void* stream) {
+    if (ws_bytes < gecco_pool_attn_workspace_bytes(B, N, C, H, I)) return fail(-7, "pool_attn_lse: workspace too small");
+    Carver c(const_cast<void*>(ws));
+    const int ns = pool_attn_nsplit(B, N, H);
+    c.f32((size_t)B * H * ns * 64 * (C / H));
+    const float* pml = c.f32((size_t)B * H * ns * 64 * 2);
+    TRY(pool_attn_lse_launch(pml, lse, B, H, ns, (hipStream_t)stream), "pool_attn_lse");
+    return 0;
+}
+
+int gecco_pool_attn_bwd_partials(int B, int N, int H) { return pool_attn_bwd_nsplit(B, N, H); }
+int gecco_unpool_attn_bwd_partials(int B, int N, int H) { return unpool_attn_bwd_chunks(B, N, H, nullptr); }
+
+int gecco_pool_attn_bwd_f32(const float* KV, const float* inducers, const float* merged, const float* lse, const float* dO,
+                            float* dKV, float* dQ_partials, int B, int N, int C, int H, int I, void* stream) {
+    if (B <= 0 || N <= 0) return fail(-2, "pool_attn_bwd: empty batch");
+    const int rc = pool_attn_bwd_launch(KV, inducers, merged, lse, dO, dKV, dQ_partials, B, N, C, H, I, pool_attn_bwd_nsplit(B, N, H),
+                                        (hipStream_t)stream);
+    if (rc == -3 || rc == -4) return fail(-2, "pool_attn_bwd: needs I == 64 and a head dim of 8, 16, 32, 48 or 64");
+    TRY(rc, "pool_attn_bwd");
+    return 0;
+}
+
+int gecco_unpool_attn_bwd_f32(const float* q, const float* kvh, const float* dO, float* dq, float* dkv_partials, int B, int N,
+                              int C, int H, int I, void* stream) {
+    if (B <= 0 || N <= 0) return fail(-2, "unpool_attn_bwd: empty batch");
+    const int rc = unpool_attn_bwd_launch(q, kvh, dO, dq, dkv_partials, B, N, C, H, I, (hipStream_t)stream);
+    if (rc == -3 || rc == -4) return fail(-2, "unpool_attn_bwd: needs I == 64 and a head dim of 8, 16, 32, 48 or 64");
+    TRY(rc, "unpool_attn_bwd");
+    return 0;
+}
+
 int gecco_pool_attn_f32(const float* KV, const float* inducers, float* merged, int B, int N, int C, int H, int I,
                         void* ws, size_t ws_bytes, void* stream) {
     return gecco_pool_attn_ex_f32(KV, inducers, merged, B, N, C, H, I, 0, ws, ws_bytes, stream);

@@ -169,6 +169,39 @@ __global__ __launch_bounds__(256) void reduce_batch_kernel(const float* __restri
     }
 }
 
+// The same sum for FEW outputs and MANY partials (bias / activation-parameter gradients: n <= a few hundred, Z in the
+// thousands): one thread per output would walk Z loads serially.  A block owns COLS outputs; its 256 / COLS z-lanes sum
+// interleaved partials (z = lane, lane + ZL, ..) in z order, and a fixed-shape LDS tree combines the lanes: the result
+// depends on (Z, COLS) only — deterministic — though not on the strict z order of the kernel above.
+template <int COLS>
+__global__ __launch_bounds__(256) void reduce_batch_wide_kernel(const float* __restrict__ parts, float* __restrict__ out,
+                                                                size_t n, int Z, size_t stride, int accumulate) {
+    constexpr int ZL = 256 / COLS;
+    __shared__ float red[256];
+    const int c = threadIdx.x % COLS, zl = threadIdx.x / COLS;
+    const size_t i = (size_t)blockIdx.x * COLS + c;
+    float s = 0.f;
+    if (i < n) {
+        int z = zl;
+        for (; z + 7 * ZL < Z; z += 8 * ZL) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = parts[(size_t)(z + u * ZL) * stride + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; z < Z; z += ZL) s += parts[(size_t)z * stride + i];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+#pragma unroll
+    for (int o = ZL / 2; o > 0; o >>= 1) {
+        if (zl < o) red[threadIdx.x] += red[threadIdx.x + o * COLS];
+        __syncthreads();
+    }
+    if (zl == 0 && i < n) out[i] = accumulate ? out[i] + red[c] : red[c];
+}
+
 }  // namespace
 
 int gemm_general_launch(const GemmGeneralArgs& g, hipStream_t st) {
@@ -186,6 +219,15 @@ int gemm_general_launch(const GemmGeneralArgs& g, hipStream_t st) {
 
 int reduce_batch_launch(const float* parts, float* out, size_t n, int Z, size_t stride, int accumulate,
                         hipStream_t st) {
+    if (Z >= 64 && n <= 16384) {   // few outputs, many partials: spread the partials over the lanes
+        if (n >= 16)
+            hipLaunchKernelGGL(reduce_batch_wide_kernel<16>, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, parts, out, n, Z,
+                               stride, accumulate);
+        else
+            hipLaunchKernelGGL(reduce_batch_wide_kernel<1>, dim3((unsigned)n), dim3(256), 0, st, parts, out, n, Z, stride,
+                               accumulate);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, parts, out, n, Z,
                        stride, accumulate);
     return (int)hipGetLastError();

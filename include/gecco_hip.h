@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GECCO_ABI_VERSION 5
+#define GECCO_ABI_VERSION 6
 
 int gecco_abi_version(void);
 const char* gecco_build_arch(void);   /* "gfx950" */
@@ -193,6 +193,23 @@ int gecco_pool_attn_f32(const float* KV, const float* inducers, float* merged, i
 int gecco_pool_attn_ex_f32(const float* KV, const float* inducers, float* merged, int B, int N, int C, int H, int I,
                            int precision, void* ws, size_t ws_bytes, void* stream);
 size_t gecco_pool_attn_workspace_bytes(int B, int N, int C, int H, int I);
+
+/* Training path: backward of the two attention cores (autograd through F.scaled_dot_product_attention,
+ * models/set_transformer.py:55-63, and through nn.MultiheadAttention, :112, under loss.backward(), diffusion.py:213-222),
+ * fused: probabilities are recomputed per tile, nothing of shape (B, H, N, I) touches HBM.
+ *   gecco_pool_attn_lse_f32: after gecco_pool_attn_ex_f32 on the same workspace, lse (B, H, I) = log2-domain
+ *     log-sum-exp of the scaled scores (what the backward needs to recompute P).
+ *   gecco_pool_attn_bwd_f32: dO (B, I, C) -> dKV (B, N, 2C) and dQ_partials (P, H, I, hd) with
+ *     P = B * gecco_pool_attn_bwd_partials(B, N, H); the caller sums the P partials in order (gecco_reduce_batch_f32).
+ *   gecco_unpool_attn_bwd_f32: dO (B, N, C) -> dq (B, N, C) and dkv_partials (P, B, I, 2C) with
+ *     P = gecco_unpool_attn_bwd_partials(B, N, H); summed over P by the caller. */
+int gecco_pool_attn_lse_f32(const void* ws, size_t ws_bytes, float* lse, int B, int N, int C, int H, int I, void* stream);
+int gecco_pool_attn_bwd_partials(int B, int N, int H);
+int gecco_pool_attn_bwd_f32(const float* KV, const float* inducers, const float* merged, const float* lse, const float* dO,
+                            float* dKV, float* dQ_partials, int B, int N, int C, int H, int I, void* stream);
+int gecco_unpool_attn_bwd_partials(int B, int N, int H);
+int gecco_unpool_attn_bwd_f32(const float* q, const float* kvh, const float* dO, float* dq, float* dkv_partials, int B, int N,
+                              int C, int H, int I, void* stream);
 
 /* nn.MultiheadAttention core (models/set_transformer.py:112, between in_proj and out_proj):
  * q (B, N, C) projected queries, kvh (B, I, 2C) projected inducer keys|values -> out (B, N, C). */

@@ -141,9 +141,17 @@ def test_gauss_act_fn_grads():
     _close(agd.grad, ar.grad)
 
 
-@pytest.mark.parametrize("B,N,C,H", [(2, 300, 128, 8), (1, 128, 384, 8)])
-def test_attention_fn_grads(B, N, C, H):
+@pytest.mark.parametrize("path", ["fused", "gemm"])
+@pytest.mark.parametrize("B,N,C,H", [(2, 300, 128, 8), (1, 128, 384, 8), (3, 2048, 256, 8), (2, 1000, 512, 8), (2, 333, 64, 8),
+                                     (5, 4096, 384, 8)])
+def test_attention_fn_grads(B, N, C, H, path, monkeypatch):
+    """Both training forms of the two attention cores against torch autograd: the fused flash-style kernels
+    (csrc/attention_bwd_f32.hip; head dims 8 ... 64, ragged N, key splits and query chunks > 1) and the strided-batched
+    GEMM form kept for shapes the fused kernels do not take."""
     from gecco_amd.autograd import PoolAttnFn, UnpoolAttnFn
+    if path == "gemm" and (N > 1000 or N % 4):
+        pytest.skip("the materialised-score form is covered at the small shapes (and reads N in 16-byte pieces)")
+    monkeypatch.setenv("GECCO_TRAIN_ATTN", path)
     rs = np.random.RandomState(N)
     hd = C // H
     KV, ind, g = _t(rs.randn(B, N, 2 * C)), _t(rs.randn(1, H, 64, hd)), _t(rs.randn(B, 64, C))
@@ -172,6 +180,30 @@ def test_attention_fn_grads(B, N, C, H):
     _close(o2g, o2, 2e-5)
     _close(qg.grad, qr.grad)
     _close(kvg.grad, kvr.grad)
+
+
+def test_attention_fn_grads_split_bf16(monkeypatch):
+    """The training precision of the shipped configs: split-bf16 forward kernels, fp32 fused backward recomputing P from
+    the forward's log-sum-exp."""
+    from gecco_amd import hip_ops
+    from gecco_amd.autograd import PoolAttnFn, UnpoolAttnFn
+    B, N, C, H = 2, 1024, 384, 8
+    hd = C // H
+    rs = np.random.RandomState(7)
+    KV, ind, g = _t(rs.randn(B, N, 2 * C)), _t(rs.randn(1, H, 64, hd)), _t(rs.randn(B, 64, C))
+    q, kvh, g2 = _t(rs.randn(B, N, C)), _t(rs.randn(B, 64, 2 * C)), _t(rs.randn(B, N, C))
+    out = {}
+    for pr in ("fp32", "bf16x3"):
+        hip_ops.set_default_precision(pr)
+        try:
+            KVg, indg, qg, kvg = _leaf(KV, "cuda"), _leaf(ind, "cuda"), _leaf(q, "cuda"), _leaf(kvh, "cuda")
+            PoolAttnFn.apply(KVg, indg, H).backward(g.cuda())
+            UnpoolAttnFn.apply(qg, kvg, H).backward(g2.cuda())
+            out[pr] = [t.grad.cpu() for t in (KVg, indg, qg, kvg)]
+        finally:
+            hip_ops.set_default_precision("fp32")
+    for a, b in zip(out["bf16x3"], out["fp32"]):
+        _close(a, b, 1e-4)
 
 
 def test_lift_lower_fn_grads():

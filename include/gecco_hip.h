@@ -384,6 +384,10 @@ int gecco_adagn_bwd_coeffs_f32(const float* xstats, int Tx, const float* gstats,
                                int B, int C, int G, float eps, void* stream);
 int gecco_affine2_apply_f32(const float* dy, const float* x, const float* cA, const float* cB, const float* cC,
                             float* dx, int B, int rows, int C, void* stream);
+/* the same with the gradient that reaches x through the residual connection added in the same pass
+ * (x = x + f(norm(x)), models/set_transformer.py:164-166): dx = dy*cA + x*cB + cC + add; add may be NULL */
+int gecco_affine2_apply_add_f32(const float* dy, const float* x, const float* cA, const float* cB, const float* cC,
+                                const float* add, float* dx, int B, int rows, int C, void* stream);
 int gecco_adagn_param_grads_f32(const float* ds, const float* dz, const float* t, int B, int C, int ctx_dim,
                                 float* d_scale_w, float* d_scale_b, float* d_bias_w, float* d_bias_b, void* stream);
 

@@ -71,6 +71,41 @@ def test_linear_fn_grads():
     _close(bg.grad, br.grad)
 
 
+@pytest.mark.parametrize("rows", [64, 192])
+def test_linear_fn_residual_and_pair_grads(rows):
+    """The fused forms of the training path: the skip connection in the GEMM epilogue (its gradient is dy), the two
+    projections of one normalised tensor in one launch (dx accumulated in the second product's epilogue), and AdaGN's
+    skip pass-through (the skip's gradient added inside the backward kernel) — against torch autograd of the plain ops."""
+    from gecco_amd.autograd import AdaGNFn, LinearFn, LinearPairFn
+    rs = np.random.RandomState(rows)
+    B, K, N1, N2, G, ctx = 3, 128, 256, 128, 32, 1
+    x, W1, b1, W2, b2 = _t(rs.randn(B, rows, K)), _t(rs.randn(N1, K) * .1), _t(rs.randn(N1)), _t(rs.randn(N2, K) * .1), _t(rs.randn(N2))
+    Wr, br = _t(rs.randn(K, N1) * .1), _t(rs.randn(K))
+    t = _t(rs.randn(B, ctx))
+    sw, sb, bw, bb = _t(rs.randn(K, ctx) * .3), _t(1 + rs.randn(K) * .1), _t(rs.randn(K, ctx) * .3), _t(rs.randn(K) * .1)
+    g1, g2, g3 = _t(rs.randn(B, rows, N1)), _t(rs.randn(B, rows, N2)), _t(rs.randn(B, rows, K))
+
+    def net(dev, fused):
+        L = [_leaf(v, dev) for v in (x, W1, b1, W2, b2, Wr, br, sw, sb, bw, bb)]
+        xx, w1, bb1, w2, bb2, wr, bbr, s_w, s_b, b_w, b_b = L
+        td = t.to(dev)
+        if fused:
+            y, skip = AdaGNFn.apply(xx, td, s_w, s_b, b_w, b_b, G, 1e-5, True)
+            o1, o2 = LinearPairFn.apply(y, w1, bb1, w2, bb2)
+            out = LinearFn.apply(o1, wr, bbr, skip)
+        else:
+            sc, sh = td @ s_w.T + s_b, td @ b_w.T + b_b
+            y = F.group_norm(xx.transpose(1, 2), G, eps=1e-5).transpose(1, 2) * sc[:, None] + sh[:, None]
+            o1, o2 = F.linear(y, w1, bb1), F.linear(y, w2, bb2)
+            out = xx + F.linear(o1, wr, bbr)
+        (out * g3.to(dev)).sum().add((o2 * g2.to(dev)).sum()).add((o1 * g1.to(dev)).sum()).backward()
+        return [out, o2] + [v.grad for v in L]
+
+    ref, got = net("cpu", False), net("cuda", True)
+    for a, b in zip(got, ref):
+        _close(a, b)
+
+
 def test_split_bf16_weight_gradient_kernel():
     """dW = dY^T X with transposed LDS reads and 3 bf16 MFMAs per product (gemm_tn_x3.hip) against fp64, operands
     spanning orders of magnitude; and through LinearFn in the split-bf16 training mode (grouped partials, fixed order)."""

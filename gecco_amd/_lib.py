@@ -85,6 +85,7 @@ SIGNATURES = {
     "gecco_mlp_fused_f16": (i, [vp, vp, vp, vp, vp, vp, vp, vp, i, vp, i, i, i, i, vp, vp]),
     "gecco_unpool_outproj_f16": (i, [vp, vp, vp, vp, vp, vp, i, i, i, i, vp, vp]),
     "gecco_gemm_tn_x3_f32": (i, [vp, vp, vp, i, i, i, i, i, vp]),
+    "gecco_gemm_tn_x3_bias_f32": (i, [vp, vp, vp, vp, i, i, i, i, i, vp]),
     "gecco_set_option": (i, [C.c_char_p, i]),
     "gecco_linear_astat_f16": (i, [vp, vp, vp, vp, vp, i, vp, vp, vp, i, vp, vp, i, i, i, i, i, vp, vp]),
     "gecco_affine_cast_f16": (i, [vp, vp, vp, vp, i, i, i, vp]),

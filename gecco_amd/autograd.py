@@ -78,10 +78,23 @@ def _linear_dx(dy: Tensor, W: Tensor, residual: Tensor | None = None) -> Tensor:
     return dx if residual is None else dx + residual
 
 
-def _linear_dw(dy: Tensor, x: Tensor) -> Tensor:
-    """dW = dy^T x: both operands read k-major (contraction over their rows); partials summed in a fixed order."""
+def _linear_dw(dy: Tensor, x: Tensor, want_db: bool = False):
+    """dW = dy^T x: both operands read k-major (contraction over their rows); partials summed in a fixed order.
+    want_db: also the bias gradient db = column sums of dy -> (dW, db); the split-bf16 kernel forms it from the dy tiles
+    it stages anyway."""
     B, R, K = x.shape
     Nout = dy.shape[2]
+    if want_db:
+        if not (_train_precision() == "bf16x3" and R % 32 == 0 and Nout % 128 == 0 and K % 128 == 0):
+            return _linear_dw(dy, x), _linear_db(dy)
+        tiles = (Nout // 128) * (K // 128)
+        G = min(B, max(1, -(-1024 // tiles)))
+        group = -(-B // G)
+        G = -(-B // group)
+        parts, cparts = _new(G, Nout, K, like=x), _new(G, Nout, like=x)
+        _lib.check(_lib.load().gecco_gemm_tn_x3_bias_f32(_ptr(dy), _ptr(x), _ptr(parts), _ptr(cparts), B, R, Nout, K, group,
+                                                         _stream()), "gecco_gemm_tn_x3_bias_f32")
+        return _reduce(parts, Nout * K, G, Nout * K).reshape(Nout, K), _reduce(cparts, Nout, G, Nout)
     if _train_precision() == "bf16x3" and R % 32 == 0 and Nout % 128 == 0 and K % 128 == 0:
         # split-bf16 MFMA with transposed LDS reads (gemm_tn_x3.hip); one partial per group of samples, groups
         # sized so that ~1000 blocks fill the chip
@@ -120,8 +133,13 @@ class LinearFn(torch.autograd.Function):
         x, W = ctx.saved_tensors
         dy = _f(dy)
         dx = _linear_dx(dy, W) if ctx.needs_input_grad[0] else None
-        dW = _linear_dw(dy, x) if ctx.needs_input_grad[1] else None
-        db = _linear_db(dy) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        dW = db = None
+        if ctx.has_bias and ctx.needs_input_grad[2] and ctx.needs_input_grad[1]:
+            dW, db = _linear_dw(dy, x, want_db=True)
+        elif ctx.needs_input_grad[1]:
+            dW = _linear_dw(dy, x)
+        elif ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _linear_db(dy)
         if len(ctx.needs_input_grad) == 3:   # called without a residual
             return dx, dW, db
         return dx, dW, db, (dy if ctx.needs_input_grad[3] else None)
@@ -145,8 +163,13 @@ class LinearPairFn(torch.autograd.Function):
         d1, d2 = _f(d1), _f(d2)
         need = ctx.needs_input_grad
         dx = _linear_dx(d2, W2, residual=_linear_dx(d1, W1)) if need[0] else None
-        return (dx, _linear_dw(d1, x) if need[1] else None, _linear_db(d1) if ctx.bias[0] and need[2] else None,
-                _linear_dw(d2, x) if need[3] else None, _linear_db(d2) if ctx.bias[1] and need[4] else None)
+        out = [dx]
+        for d, has_b, iw in ((d1, ctx.bias[0], 1), (d2, ctx.bias[1], 3)):
+            if need[iw] and has_b and need[iw + 1]:
+                out += list(_linear_dw(d, x, want_db=True))
+            else:
+                out += [_linear_dw(d, x) if need[iw] else None, _linear_db(d) if has_b and need[iw + 1] else None]
+        return tuple(out)
 
 
 # ------------------------------------------------------------------------------------------- AdaGN / GroupNorm

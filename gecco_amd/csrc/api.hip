@@ -638,10 +638,15 @@ int gecco_unpool_outproj_f16(float* x, const void* q16, const float* kvh, const 
 }
 
 int gecco_gemm_tn_x3_f32(const float* A, const float* Bm, float* parts, int Z, int R, int N, int K, int group, void* stream) {
+    return gecco_gemm_tn_x3_bias_f32(A, Bm, parts, nullptr, Z, R, N, K, group, stream);
+}
+
+int gecco_gemm_tn_x3_bias_f32(const float* A, const float* Bm, float* parts, float* colsum_parts, int Z, int R, int N, int K,
+                              int group, void* stream) {
     if (!A || !Bm || !parts) return fail(-1, "gemm_tn_x3: null argument");
     TnArgs g{};
     g.A = A; g.Bm = Bm; g.C = parts; g.Z = Z; g.R = R; g.N = N; g.K = K; g.lda = N; g.ldb = K;
-    g.sA = (size_t)R * N; g.sB = (size_t)R * K; g.group = group;
+    g.sA = (size_t)R * N; g.sB = (size_t)R * K; g.group = group; g.colsum = colsum_parts;
     if (!gemm_tn_x3_supported(g)) return fail(-2, "gemm_tn_x3: needs R %% 32 == 0, N %% 128 == 0, K %% 128 == 0, group > 0");
     TRY(gemm_tn_x3_launch(g, (hipStream_t)stream), "gemm_tn_x3");
     return 0;

@@ -68,12 +68,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(TnArgs g) {
             rb[i] = *reinterpret_cast<const f32x4*>(Bb + (size_t)row * g.ldb + c4 * 4);
         }
     };
+    // bias gradient = column sums of dY: the blocks of the first K tile add up the rows they stage anyway
+    const bool want_cs = g.colsum != nullptr && k0 == 0;
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f};
     auto store = [&](int stage) {
         u16* st = lds + stage * 4 * TN_PLANE;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int f = tid + i * 256, row = f >> 5, c4 = f & 31, o = tn_off(row, c4 * 4);
             u32x2 hi, lo;
+            if (want_cs) cs += ra[i];
             tn_split4(ra[i], hi, lo);
             *reinterpret_cast<u32x2*>(st + o) = hi;
             *reinterpret_cast<u32x2*>(st + TN_PLANE + o) = lo;
@@ -124,6 +128,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(TnArgs g) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
+        }
+    }
+    if (want_cs) {   // (block-uniform) the 8 threads of a column group, summed in thread order
+        __syncthreads();
+        f32x4* red = reinterpret_cast<f32x4*>(smem);
+        red[tid] = cs;
+        __syncthreads();
+        if (tid < 32) {
+            f32x4 s = red[tid];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) s += red[tid + 32 * j];
+            *reinterpret_cast<f32x4*>(g.colsum + (size_t)blockIdx.y * g.N + n0 + tid * 4) = s;
         }
     }
     float* Cb = g.C + (size_t)blockIdx.y * g.N * g.K;

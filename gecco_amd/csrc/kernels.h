@@ -112,6 +112,7 @@ struct TnArgs {
     int Z, R, N, K, lda, ldb;
     size_t sA, sB;     // sample strides (elements)
     int group;
+    float* colsum;     // optional (ceil(Z / group), N): column sums of A per group (the bias gradient), or null
 };
 bool gemm_tn_x3_supported(const TnArgs& g);
 int gemm_tn_x3_launch(const TnArgs& g, hipStream_t st);

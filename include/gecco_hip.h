@@ -364,6 +364,10 @@ int gecco_gemm_f32(const GeccoGemm* g, void* stream);
  * (ceil(Z / group), N, K); dW = gecco_reduce_batch_f32 over the groups (fixed order: bit-reproducible).
  * R % 32 == 0, N % 128 == 0, K % 128 == 0. */
 int gecco_gemm_tn_x3_f32(const float* A, const float* Bm, float* parts, int Z, int R, int N, int K, int group, void* stream);
+/* the same, also leaving colsum_parts[g] (ceil(Z / group), N) = column sums of A over the group's rows: the bias gradient
+ * db = sum_rows dY comes out of the pass that reads dY for dW (colsum_parts may be NULL) */
+int gecco_gemm_tn_x3_bias_f32(const float* A, const float* Bm, float* parts, float* colsum_parts, int Z, int R, int N, int K,
+                              int group, void* stream);
 int gecco_reduce_batch_f32(const float* parts, float* out, size_t n, int Z, size_t stride, int accumulate, void* stream);
 
 /* Row softmax of the materialised attention scores: P = softmax(scale*S) over the last dim n; and its backward

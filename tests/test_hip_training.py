@@ -71,8 +71,9 @@ def test_linear_fn_grads():
     _close(bg.grad, br.grad)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("rows", [64, 192])
-def test_linear_fn_residual_and_pair_grads(rows):
+def test_linear_fn_residual_and_pair_grads(rows, precision):
     """The fused forms of the training path: the skip connection in the GEMM epilogue (its gradient is dy), the two
     projections of one normalised tensor in one launch (dx accumulated in the second product's epilogue), and AdaGN's
     skip pass-through (the skip's gradient added inside the backward kernel) — against torch autograd of the plain ops."""
@@ -101,7 +102,12 @@ def test_linear_fn_residual_and_pair_grads(rows):
         (out * g3.to(dev)).sum().add((o2 * g2.to(dev)).sum()).add((o1 * g1.to(dev)).sum()).backward()
         return [out, o2] + [v.grad for v in L]
 
-    ref, got = net("cpu", False), net("cuda", True)
+    from gecco_amd import hip_ops
+    hip_ops.set_default_precision(precision)   # bf16x3: dW and the bias gradient come from gemm_tn_x3.hip in one pass
+    try:
+        ref, got = net("cpu", False), net("cuda", True)
+    finally:
+        hip_ops.set_default_precision("fp32")
     for a, b in zip(got, ref):
         _close(a, b)
 

@@ -199,7 +199,10 @@ int astat_linear(const float* x, const float* pa, const float* po, const float* 
     g.A = x; g.pro_a = pa; g.pro_o = po; g.bias = bias1; g.alpha = alpha; g.act = act; g.C = C1;
     g.B = B; g.rows = rows; g.K = K; g.Nout = Nout1 + Nout2; g.lda = K; g.ldw = K; g.ldc = Nout1; g.ldr = Nout1;
     g.precision = 2; g.w_img = img; g.c_f16 = 1; g.hm_hd = hm_hd; g.w_img2 = img_lo;   // img_lo: two-term weights (mixed mode)
-    if (img_lo && C2) g.lo_tiles = Nout1 / 128;   // kv_proj | q_proj: the q segment's weights stay one-term
+    if (img_lo && C2) {   // kv_proj | q_proj: two-term weights for the V half only; the K half and the q segment stay one-term
+        g.lo_begin = Nout1 / 256;
+        g.lo_tiles = Nout1 / 128;
+    }
     if (C2) { g.C2 = C2; g.bias2 = bias2; g.n_split = Nout1; g.ldc2 = Nout2; }
     // option "astat" = 0 falls back to the cast pass + streaming GEMM (A/B runs; same bits)
     if (!option(OPT_ASTAT) || !img || !gemm_f16_astat_supported(g)) return 1;

@@ -78,9 +78,48 @@ __global__ __launch_bounds__(256) void gauss_act_bwd_kernel(const float* __restr
 __global__ __launch_bounds__(256) void col_dot_stats_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             float* __restrict__ stats, int rows, int C, int T,
                                                             int tile_rows) {
+    __shared__ f32x4 red[2][256];
     const int tile = blockIdx.x % T, b = blockIdx.x / T;
     const int m0 = tile * tile_rows, m1 = min(rows, m0 + tile_rows);
     const size_t base = (size_t)b * rows * C;
+    if (C % 4 == 0 && C / 4 <= 256) {
+        // 16-byte column chunks x RL row lanes (pointwise.hip's col_stats_kernel); lane partials combined in lane order
+        const int c4n = C / 4, RL = 256 / c4n;
+        const int c4 = threadIdx.x % c4n, rl = threadIdx.x / c4n;
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+        if (rl < RL) {
+            const float* gp = dy + base + c4 * 4;
+            const float* xp = x + base + c4 * 4;
+            int m = m0 + rl;
+            for (; m + 3 * RL < m1; m += 4 * RL) {
+                f32x4 g[4], v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    g[u] = *reinterpret_cast<const f32x4*>(gp + (size_t)(m + u * RL) * C);
+                    v[u] = *reinterpret_cast<const f32x4*>(xp + (size_t)(m + u * RL) * C);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { s1 += g[u]; s2 += g[u] * v[u]; }
+            }
+            for (; m < m1; m += RL) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(gp + (size_t)m * C);
+                s1 += g;
+                s2 += g * *reinterpret_cast<const f32x4*>(xp + (size_t)m * C);
+            }
+            red[0][threadIdx.x] = s1;
+            red[1][threadIdx.x] = s2;
+        }
+        __syncthreads();
+        if (rl == 0) {
+            for (int q = 1; q < RL; ++q) {
+                s1 += red[0][q * c4n + c4];
+                s2 += red[1][q * c4n + c4];
+            }
+            *reinterpret_cast<f32x4*>(stats + (((size_t)b * T + tile) * 2 + 0) * C + c4 * 4) = s1;
+            *reinterpret_cast<f32x4*>(stats + (((size_t)b * T + tile) * 2 + 1) * C + c4 * 4) = s2;
+        }
+        return;
+    }
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float s1 = 0.f, s2 = 0.f;
         for (int m = m0; m < m1; ++m) {

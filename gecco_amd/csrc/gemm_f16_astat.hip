@@ -179,9 +179,10 @@ __global__ __launch_bounds__(S_NT, 2) void gemm_f16_astat_kernel(GemmArgs g) {
     int part_left = NK;                                // WS == 2: stages left in the current part (hi, then lo) of the column tile
     bool lo_part = false;
     int it_tile = 0;                                   // column tile of the next stage to issue
-    // WS == 2: column tiles [0, lo_tiles) carry a lo part, the rest (the q projection: its weights' rounding does not reach
-    // the output, tools/experiments/fp16_site_sensitivity.py) are streamed hi only
+    // WS == 2: column tiles [lo_begin, lo_tiles) carry a lo part — the V projection; the rounding of the K and q
+    // projections' weights does not reach the output (tools/experiments/fp16_site_sensitivity.py): streamed hi only
     const int lo_tiles = WS == 2 ? (g.lo_tiles > 0 ? g.lo_tiles : tilesN) : 0;
+    const int lo_begin = WS == 2 ? g.lo_begin : 0;
     auto issue = [&](int slot) {
         if (WS == 2 && lo_part) {
             dma16_buf(wrsrc2, voff, soff, ring + slot * S_TILE + (S_PW * wave) * 256);
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(S_NT, 2) void gemm_f16_astat_kernel(GemmArgs g) {
         soff += S_TILE * 4u;
         if (WS == 2 && --part_left == 0) {             // hi part done: the same stages of the lo image; lo done: next tile's hi
             part_left = NK;
-            if (!lo_part && it_tile < lo_tiles) {
+            if (!lo_part && it_tile >= lo_begin && it_tile < lo_tiles) {
                 soff -= NK * S_TILE * 4u;
                 lo_part = true;
             } else {
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(S_NT, 2) void gemm_f16_astat_kernel(GemmArgs g) {
     load_b(0, 0);
     for (int ct = 0; ct < tilesN; ++ct) {
         const bool first = ct == 0, last = ct == tilesN - 1;
-        const bool has_lo = WS == 2 && ct < lo_tiles;   // this column tile runs 2 NK stages (hi, lo), else NK
+        const bool has_lo = WS == 2 && ct >= lo_begin && ct < lo_tiles;   // this column tile runs 2 NK stages (hi, lo), else NK
         static_for(std::make_integer_sequence<int, NKW>{}, [&](auto KT) {
             constexpr int kt = decltype(KT)::value;
             constexpr int cur = kt & 1;

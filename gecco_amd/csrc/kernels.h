@@ -34,7 +34,8 @@ struct GemmArgs {
     // A-stationary fp16 kernel only: image of the weights' LOW part fp16(W - fp16(W)) (same layout as w_img; split jobs with
     // pad_ = 1): two-term fp16 weights, 2 MFMAs per product ("mixed" mode).  Null: one-term weights.
     const void* w_img2;
-    int lo_tiles;           // with w_img2: only the first lo_tiles 128-column tiles have a lo part (0: all)
+    int lo_tiles;           // with w_img2: only the 128-column tiles [lo_begin, lo_tiles) have a lo part (lo_tiles 0: all)
+    int lo_begin;
 };
 
 struct SplitJob { const float* W; float* img; int Nout, K, ldw, pad_; };   // pad_ = 1 (fp16 images): the LOW part fp16(W - fp16(W))

@@ -53,6 +53,12 @@ def product(a, b_t, scheme, mm):
     if scheme == "x2a":    # W split, A rounded once
         bh = r16(b_t)
         return mm(r16(a), bh) + mm(r16(a), r16(b_t - bh))
+    if scheme in ("x2a_v", "x2a_k"):   # linear sites only: two-term weights for the second (V) / first (K) half of the outputs
+        bh = r16(b_t)
+        lo = r16(b_t - bh)
+        half = b_t.shape[0] // 2
+        lo = torch.cat([torch.zeros_like(lo[:half]), lo[half:]]) if scheme == "x2a_v" else torch.cat([lo[:half], torch.zeros_like(lo[half:])])
+        return mm(r16(a), bh) + mm(r16(a), lo)
     if scheme == "x3":
         ah, bh = r16(a), r16(b_t)
         return mm(ah, bh) + mm(r16(a - ah), bh) + mm(ah, r16(b_t - bh))

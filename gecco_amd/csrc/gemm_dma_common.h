@@ -167,6 +167,18 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, const Tile& t, f32x1
             }
         }
         __syncthreads();
+        if (TMW * WMN == 8) {
+            // 256-row tile: the statistics keep their 128-row granularity (consumers count partials per 128 rows): waves
+            // {0, 1} own the first half, {2, 3} the second
+            const int T128 = (g.rows + 127) / 128;
+            for (int c = tid; c < 4 * DBN; c += DNT) {
+                const int half = c / (2 * DBN), which = (c / DBN) & 1, cl = c % DBN, nn = n0 + cl;
+                if (nn < g.Nout && 2 * rt + half < T128)
+                    g.stats[(((size_t)b * T128 + 2 * rt + half) * 2 + which) * g.Nout + nn] =
+                        red[((2 * half) * 2 + which) * DBN + cl] + red[((2 * half + 1) * 2 + which) * DBN + cl];
+            }
+            return;
+        }
         for (int c = tid; c < 2 * DBN; c += DNT) {
             const int which = c / DBN, cl = c % DBN, nn = n0 + cl;
             if (nn < g.Nout) {

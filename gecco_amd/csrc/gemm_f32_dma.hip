@@ -39,7 +39,10 @@ using dma::dma16;
 constexpr int DBK = 16;                           // row tile BM: template parameter (128, or 64 in bf16x3 mode)
 constexpr int D_TILE = 128 * DBK;                 // floats per operand tile per stage (8 KiB)
 constexpr int D_STAGE = 2 * D_TILE;               // A then B (fp32 W tile, or bf16 hi | lo planes: same 8 KiB)
-constexpr int d_main_floats(int ns) { return ns * D_STAGE > D_EPI ? ns * D_STAGE : D_EPI; }
+// 256-row tiles (bf16x3): the A tile is [256][16] = 16 KiB, the W block stays 8 KiB
+constexpr int a_tile_floats(int bm) { return bm == 256 ? 256 * DBK : D_TILE; }
+constexpr int stage_floats(int bm) { return a_tile_floats(bm) + D_TILE; }
+constexpr int d_main_floats(int ns, int bm = 128) { return ns * stage_floats(bm) > D_EPI ? ns * stage_floats(bm) : D_EPI; }
 
 // 8 fp32 -> bf16 hi (truncation: the top 16 bits) and bf16 lo = rne(x - hi); x - hi is exact in fp32
 __device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, bf16x8& hi, bf16x8& lo) {
@@ -58,12 +61,18 @@ __device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, bf16x8&
     for (int e = 0; e < 8; ++e) lo[e] = (__bf16)l[e];
 }
 
-// BM = 128 rows per block; BM = 64 (bf16x3 only) serves the 64-inducer GEMMs (rows per sample < 128)
+// BM = 128 rows per block; BM = 64 (bf16x3 only) serves the 64-inducer GEMMs (rows per sample < 128);
+// BM = 256 (bf16x3 only): 4 x 1 waves of 64 x 128 — the split-bf16 loop is bound by LDS bandwidth (per K-step the four
+// 32 x 128 wave tiles of a 128-row block read 40 KiB of fragments and the DMA writes 16 KiB for 48 MFMAs: 146 B/clk/CU
+// at the full matrix rate against the LDS's 128), and a wave tile twice as tall re-uses every W fragment for two row
+// tiles: 0.75 KiB of LDS traffic per MFMA instead of 1.17; 72 KiB of ring = two blocks per CU, so one block's epilogue
+// still runs under the other's K loop.
 template <int DNS, bool HAS_PRO, bool X3, int BM = 128>
-__global__ __launch_bounds__(DNT, DNS <= 3 ? 3 : 2) void gemm_dma_kernel(GemmArgs g) {
-    static_assert(BM == 128 || (BM == 64 && X3), "64-row tiles exist in split-bf16 mode only");
+__global__ __launch_bounds__(DNT, BM == 256 ? 2 : (DNS <= 3 ? 3 : 2)) void gemm_dma_kernel(GemmArgs g) {
+    static_assert(BM == 128 || ((BM == 64 || BM == 256) && X3), "64- and 256-row tiles exist in split-bf16 mode only");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* pro_lds = smem + d_main_floats(DNS);   // pa[0..K) | po[0..K)
+    constexpr int A_TILE = a_tile_floats(BM), STAGE = stage_floats(BM);
+    float* pro_lds = smem + d_main_floats(DNS, BM);   // pa[0..K) | po[0..K)
 
     const dma::Tile T = dma::tile_of_block<BM>(g);
     const int ct = T.ct, b = T.b, m0 = T.m0, nseg0 = T.nseg0, nseg = T.nseg;
@@ -75,7 +84,7 @@ __global__ __launch_bounds__(DNT, DNS <= 3 ? 3 : 2) void gemm_dma_kernel(GemmArg
     // ~28 VALU per 32-row tile per K-step to split into hi / lo, the (pre-split) B fragment nothing, so the
     // wave tile is made wide in N: half the split work per MFMA of the square layout.
     // (64-row tiles: 2 x 2 waves of 32 x 64)
-    constexpr int WMN = (X3 && BM == 128) ? 4 : 2, WNN = 4 / WMN;
+    constexpr int WMN = (X3 && BM >= 128) ? 4 : 2, WNN = 4 / WMN;
     constexpr int TMW = (BM / 32) / WMN, TNW = 4 / WNN;   // 32 x 32 MFMA tiles per wave in M / N
     constexpr int NAP = BM / 64;                  // A pieces (16 rows x 64 B) per wave per K-step
     constexpr int NPIECE = NAP + 2;               // DMA wave-instructions per wave per K-step
@@ -87,14 +96,15 @@ __global__ __launch_bounds__(DNT, DNS <= 3 ? 3 : 2) void gemm_dma_kernel(GemmArg
     // fp32 W tile: the same.  bf16 planes [128][16] bf16: 4 pieces of 32 rows x 32 B each; wave w moves piece w of
     // the hi plane and of the lo plane; chunk ^= (row >> 3) & 1.
     const float* __restrict__ Ab = g.A + (size_t)b * g.rows * g.lda;
-    const float* asrc[2];
+    constexpr int NQ = NAP > 2 ? NAP : 2;
+    const float* asrc[NQ];
     const void* bsrc[2];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         const int row = (NAP * wave + (q < NAP ? q : 0)) * 16 + (lane >> 2);
         const int c = (lane & 3) ^ ((row >> 2) & 3);
         asrc[q] = Ab + (size_t)min(m0 + row, g.rows - 1) * g.lda + c * 4;
-        if (!X3) bsrc[q] = Wseg + (size_t)min(nseg0 + row, nseg - 1) * g.ldw + c * 4;
+        if (!X3 && q < 2) bsrc[q] = Wseg + (size_t)min(nseg0 + row, nseg - 1) * g.ldw + c * 4;
     }
     const int nk = g.K / DBK;
     if (X3) {
@@ -109,16 +119,16 @@ __global__ __launch_bounds__(DNT, DNS <= 3 ? 3 : 2) void gemm_dma_kernel(GemmArg
 #ifdef GEMM_DIAG_NODMA
         return;
 #endif
-        float* st = smem + (kt % DNS) * D_STAGE;
+        float* st = smem + (kt % DNS) * STAGE;
 #pragma unroll
         for (int q = 0; q < NAP; ++q) dma16(asrc[q] + kt * DBK, st + (NAP * wave + q) * 256);
         if (X3) {
-            dma16(static_cast<const float*>(bsrc[0]) + (size_t)kt * D_TILE, st + D_TILE + wave * 256);
-            dma16(static_cast<const float*>(bsrc[1]) + (size_t)kt * D_TILE, st + D_TILE + 1024 + wave * 256);
+            dma16(static_cast<const float*>(bsrc[0]) + (size_t)kt * D_TILE, st + A_TILE + wave * 256);
+            dma16(static_cast<const float*>(bsrc[1]) + (size_t)kt * D_TILE, st + A_TILE + 1024 + wave * 256);
         } else {
 #pragma unroll
             for (int q = 0; q < 2; ++q)
-                dma16(static_cast<const float*>(bsrc[q]) + kt * DBK, st + D_TILE + (2 * wave + q) * 256);
+                dma16(static_cast<const float*>(bsrc[q]) + kt * DBK, st + A_TILE + (2 * wave + q) * 256);
         }
     };
 
@@ -164,11 +174,11 @@ __global__ __launch_bounds__(DNT, DNS <= 3 ? 3 : 2) void gemm_dma_kernel(GemmArg
         const int rb = (wn * TNW + j) * 32 + r;
         if (X3) {  // bf16 plane row = 32 B = 8 floats; this lane's 8 k-values = chunk h ^ ((row >> 3) & 1)
             const int ch = h ^ ((rb >> 3) & 1);
-            boff[j][0] = D_TILE + rb * 8 + ch * 4;          // hi plane
-            boff[j][1] = D_TILE + 1024 + rb * 8 + ch * 4;   // lo plane
+            boff[j][0] = A_TILE + rb * 8 + ch * 4;          // hi plane
+            boff[j][1] = A_TILE + 1024 + rb * 8 + ch * 4;   // lo plane
         } else {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) boff[j][q] = D_TILE + rb * DBK + (((2 * q + h) ^ ((rb >> 2) & 3)) << 2);
+            for (int q = 0; q < 2; ++q) boff[j][q] = A_TILE + rb * DBK + (((2 * q + h) ^ ((rb >> 2) & 3)) << 2);
         }
     }
 
@@ -212,16 +222,11 @@ __global__ __launch_bounds__(DNT, DNS <= 3 ? 3 : 2) void gemm_dma_kernel(GemmArg
 #endif
             }
         };
-        // counted waits: NPIECE wave-instructions per K-step in flight (4, or 3 with 64-row tiles)
-        if (DNS >= 4 && nk >= 4) {
-            if (NPIECE == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-        } else if (nk >= 3) {
-            if (NPIECE == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        } else if (nk == 2) {
-            if (NPIECE == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        // counted waits: NPIECE wave-instructions per K-step in flight (4; 3 with 64-row, 6 with 256-row tiles)
+        if (DNS >= 4 && nk >= 4) dma::wait_vm<3 * NPIECE>();
+        else if (nk >= 3) dma::wait_vm<2 * NPIECE>();
+        else if (nk == 2) dma::wait_vm<NPIECE>();
+        else dma::wait_vm<0>();
         __builtin_amdgcn_s_barrier();
         load_frags(smem, 0, 0);   // K-step 0 into set 0
         auto kstep = [&](int kt, int cur) {
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(DNT, DNS <= 3 ? 3 : 2) void gemm_dma_kernel(GemmArg
             if (kt + DNS < nk) issue(kt + DNS);
             // next K-step's slot; past the end a landed slot is re-read and the values are never used
             const int kn = min(kt + 1, nk - 1);
-            load_frags(smem + (kn % DNS) * D_STAGE, kn, cur ^ 1);
+            load_frags(smem + (kn % DNS) * STAGE, kn, cur ^ 1);
 #pragma unroll
             for (int j = 0; j < TNW; ++j)
 #pragma unroll
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(DNT, DNS <= 3 ? 3 : 2) void gemm_dma_kernel(GemmArg
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();   // everyone's pieces of kt are in; everyone is done reading stage (kt-1) % DNS
             if (kt + DNS - 1 < nk) issue(kt + DNS - 1);
-            const float* st = smem + (kt % DNS) * D_STAGE;
+            const float* st = smem + (kt % DNS) * STAGE;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 // lane half h holds k = 8*kk + 4*h + e: the same k permutation on both operands
@@ -331,7 +336,7 @@ __global__ void split_bf16_tiled_kernel(const float* __restrict__ W, float* __re
 template <int DNS, bool X3, int BM = 128>
 int dma_launch_t(const GemmArgs& g, hipStream_t st) {
     const int tilesM = (g.rows + BM - 1) / BM, tilesN = (g.Nout + DBN - 1) / DBN;
-    const size_t lds = (size_t)(d_main_floats(DNS) + 2 * g.K) * sizeof(float);
+    const size_t lds = (size_t)(d_main_floats(DNS, BM) + 2 * g.K) * sizeof(float);
     static size_t attr = 0;
     if (lds > attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma_kernel<DNS, true, X3, BM>),
@@ -364,6 +369,14 @@ int gemm_f32_dma_launch(const GemmArgs& g, hipStream_t st) {
     }
     if (g.precision == 1 && g.w_img) {
         if (g.rows < 128) return dma_launch_t<3, true, 64>(g, st);
+        static int bm256 = -1;
+        if (bm256 < 0) {
+            const char* e = getenv("GECCO_GEMM_BM256");   // 0: keep the 128-row tiles (A/B runs)
+            bm256 = (e && atoi(e) == 0) ? 0 : 1;
+        }
+        // measured at C2 (B = 64, N = 2048): 768 -> 384 with residual 0.321 -> 0.288 ms; 384 -> 384 and the prologue
+        // form 384 -> 768 are 3-8 % slower with the tall tile (fewer, longer blocks; the prologue form spills): long K only
+        if (bm256 && g.rows >= 256 && g.rows % 128 == 0 && !g.pro_a && g.K >= 512) return dma_launch_t<3, true, 256>(g, st);
         return ns3 ? dma_launch_t<3, true>(g, st) : dma_launch_t<4, true>(g, st);
     }
     return ns3 ? dma_launch_t<3, false>(g, st) : dma_launch_t<4, false>(g, st);

@@ -107,6 +107,8 @@ SIGNATURES = {
     "gecco_pool_attn_bwd_f32": (i, [vp] * 7 + [i, i, i, i, i, vp]),
     "gecco_unpool_attn_bwd_partials": (i, [i, i, i]),
     "gecco_unpool_attn_bwd_f32": (i, [vp] * 5 + [i, i, i, i, i, vp]),
+    "gecco_pool_attn_bwd_ex_f32": (i, [vp] * 7 + [i, i, i, i, i, i, vp]),
+    "gecco_unpool_attn_bwd_ex_f32": (i, [vp] * 5 + [i, i, i, i, i, i, vp]),
     "gecco_edm_coeffs_f32": (i, [vp, fl, vp, i, vp]),
     "gecco_lift_f32": (i, [vp, vp, vp, vp, vp, vp, i, i, i, vp]),
     "gecco_lower_edm_f32": (i, [vp] * 9 + [i, i, i, fl, vp]),

@@ -299,7 +299,7 @@ class PoolAttnFn(torch.autograd.Function):
             nb = lib.gecco_pool_attn_workspace_bytes(B, N, Cc, H, I)
             ws = torch.empty(nb, dtype=torch.uint8, device=KV.device)
             O = _new(B, I, Cc, like=KV)
-            pr = hip_ops.PRECISIONS[_train_precision()]
+            pr = ctx.pr = min(hip_ops.PRECISIONS[_train_precision()], 1)
             _lib.check(lib.gecco_pool_attn_ex_f32(_ptr(KV), _ptr(ind), _ptr(O), B, N, Cc, H, I, pr, C.c_void_p(ws.data_ptr()), nb,
                                                   _stream()), "gecco_pool_attn_ex_f32")
             lse = _new(B, H, I, like=KV)
@@ -329,8 +329,8 @@ class PoolAttnFn(torch.autograd.Function):
             lib = _lib.load()
             P = B * lib.gecco_pool_attn_bwd_partials(B, N, H)
             dKV, dQp = torch.empty_like(KV), _new(P, H, I, hd, like=KV)
-            _lib.check(lib.gecco_pool_attn_bwd_f32(_ptr(KV), _ptr(ind), _ptr(O), _ptr(lse), _ptr(dO), _ptr(dKV), _ptr(dQp), B, N, Cc,
-                                                   H, I, _stream()), "gecco_pool_attn_bwd_f32")
+            _lib.check(lib.gecco_pool_attn_bwd_ex_f32(_ptr(KV), _ptr(ind), _ptr(O), _ptr(lse), _ptr(dO), _ptr(dKV), _ptr(dQp), B, N, Cc,
+                                                      H, I, ctx.pr, _stream()), "gecco_pool_attn_bwd_ex_f32")
             return dKV, _reduce(dQp, H * I * hd, P, H * I * hd).reshape(ind.shape), None
         KV, ind, P = ctx.saved_tensors
         B, N, C2 = KV.shape
@@ -368,6 +368,7 @@ class UnpoolAttnFn(torch.autograd.Function):
         ctx.fused = _fused_attn_ok(I, hd)
         if ctx.fused:
             ctx.save_for_backward(q, kvh)
+            ctx.pr = min(hip_ops.PRECISIONS[_train_precision()], 1)
             return hip_ops.unpool_attn(q, kvh, H, precision=_train_precision())
         sc = 1.0 / math.sqrt(hd)
         S = _new(B, H, N, I, like=q)
@@ -390,8 +391,8 @@ class UnpoolAttnFn(torch.autograd.Function):
             lib = _lib.load()
             P = lib.gecco_unpool_attn_bwd_partials(B, N, H)
             dq, parts = torch.empty_like(q), _new(P, B, I, 2 * Cc, like=q)
-            _lib.check(lib.gecco_unpool_attn_bwd_f32(_ptr(q), _ptr(kvh), _ptr(dO), _ptr(dq), _ptr(parts), B, N, Cc, H, I, _stream()),
-                       "gecco_unpool_attn_bwd_f32")
+            _lib.check(lib.gecco_unpool_attn_bwd_ex_f32(_ptr(q), _ptr(kvh), _ptr(dO), _ptr(dq), _ptr(parts), B, N, Cc, H, I, ctx.pr,
+                                                        _stream()), "gecco_unpool_attn_bwd_ex_f32")
             n = B * I * 2 * Cc
             return dq, (parts[0] if P == 1 else _reduce(parts, n, P, n).reshape(B, I, 2 * Cc)), None
         q, kvh, P = ctx.saved_tensors

@@ -764,18 +764,29 @@ int gecco_unpool_attn_bwd_partials(int B, int N, int H) { return unpool_attn_bwd
 
 int gecco_pool_attn_bwd_f32(const float* KV, const float* inducers, const float* merged, const float* lse, const float* dO,
                             float* dKV, float* dQ_partials, int B, int N, int C, int H, int I, void* stream) {
+    return gecco_pool_attn_bwd_ex_f32(KV, inducers, merged, lse, dO, dKV, dQ_partials, B, N, C, H, I, 0, stream);
+}
+int gecco_unpool_attn_bwd_f32(const float* q, const float* kvh, const float* dO, float* dq, float* dkv_partials, int B, int N,
+                              int C, int H, int I, void* stream) {
+    return gecco_unpool_attn_bwd_ex_f32(q, kvh, dO, dq, dkv_partials, B, N, C, H, I, 0, stream);
+}
+
+int gecco_pool_attn_bwd_ex_f32(const float* KV, const float* inducers, const float* merged, const float* lse, const float* dO,
+                               float* dKV, float* dQ_partials, int B, int N, int C, int H, int I, int precision, void* stream) {
     if (B <= 0 || N <= 0) return fail(-2, "pool_attn_bwd: empty batch");
+    if (precision < 0 || precision > 1) return fail(-2, "pool_attn_bwd: precision must be 0 (fp32) or 1 (split-bf16)");
     const int rc = pool_attn_bwd_launch(KV, inducers, merged, lse, dO, dKV, dQ_partials, B, N, C, H, I, pool_attn_bwd_nsplit(B, N, H),
-                                        (hipStream_t)stream);
+                                        (hipStream_t)stream, precision);
     if (rc == -3 || rc == -4) return fail(-2, "pool_attn_bwd: needs I == 64 and a head dim of 8, 16, 32, 48 or 64");
     TRY(rc, "pool_attn_bwd");
     return 0;
 }
 
-int gecco_unpool_attn_bwd_f32(const float* q, const float* kvh, const float* dO, float* dq, float* dkv_partials, int B, int N,
-                              int C, int H, int I, void* stream) {
+int gecco_unpool_attn_bwd_ex_f32(const float* q, const float* kvh, const float* dO, float* dq, float* dkv_partials, int B, int N,
+                                 int C, int H, int I, int precision, void* stream) {
     if (B <= 0 || N <= 0) return fail(-2, "unpool_attn_bwd: empty batch");
-    const int rc = unpool_attn_bwd_launch(q, kvh, dO, dq, dkv_partials, B, N, C, H, I, (hipStream_t)stream);
+    if (precision < 0 || precision > 1) return fail(-2, "unpool_attn_bwd: precision must be 0 (fp32) or 1 (split-bf16)");
+    const int rc = unpool_attn_bwd_launch(q, kvh, dO, dq, dkv_partials, B, N, C, H, I, (hipStream_t)stream, precision);
     if (rc == -3 || rc == -4) return fail(-2, "unpool_attn_bwd: needs I == 64 and a head dim of 8, 16, 32, 48 or 64");
     TRY(rc, "unpool_attn_bwd");
     return 0;

@@ -210,6 +210,12 @@ int gecco_pool_attn_bwd_f32(const float* KV, const float* inducers, const float*
 int gecco_unpool_attn_bwd_partials(int B, int N, int H);
 int gecco_unpool_attn_bwd_f32(const float* q, const float* kvh, const float* dO, float* dq, float* dkv_partials, int B, int N,
                               int C, int H, int I, void* stream);
+/* the same with the arithmetic selected: precision 0 = exact fp32 MFMA, 1 = split-bf16 (head dims 16 / 32 / 48 / 64; other head
+ * dims run the fp32 kernels) */
+int gecco_pool_attn_bwd_ex_f32(const float* KV, const float* inducers, const float* merged, const float* lse, const float* dO,
+                               float* dKV, float* dQ_partials, int B, int N, int C, int H, int I, int precision, void* stream);
+int gecco_unpool_attn_bwd_ex_f32(const float* q, const float* kvh, const float* dO, float* dq, float* dkv_partials, int B, int N,
+                                 int C, int H, int I, int precision, void* stream);
 
 /* nn.MultiheadAttention core (models/set_transformer.py:112, between in_proj and out_proj):
  * q (B, N, C) projected queries, kvh (B, I, 2C) projected inducer keys|values -> out (B, N, C). */

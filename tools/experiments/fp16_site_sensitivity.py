@@ -68,6 +68,8 @@ def product(a, b_t, scheme, mm):
     if scheme == "h8w":    # A rounded once (fp16), W = fp16 hi + fp8 lo: 1.5 MFMA units
         bh = r16(b_t)
         return mm(r16(a), bh) + mm(r8(a), r8(b_t - bh))
+    if scheme == "f8":     # both operands fp8 e4m3 behind power-of-two tensor scales (what an "fp8 mode" would compute)
+        return mm(r8(a), r8(b_t))
     if scheme == "bf16":
         return mm(a.bfloat16().float(), b_t.bfloat16().float())
     raise ValueError(scheme)

@@ -178,10 +178,10 @@ int linear_pair(const float* A, const float* W1, const float* b1, int Nout1, flo
 }
 
 // Path switches for A/B runs and tests: gecco_set_option, or the environment (GECCO_ASTAT, GECCO_CHAIN) on first use.
-enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_HEADMAJOR = 2, OPT_MLPFUSED = 3, OPT_UNPOOLFUSED = 4, OPT_COUNT = 5 };
-int g_options[OPT_COUNT] = {-1, -1, -1, -1, -1};
-const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor", "mlpfused", "unpoolfused"};
-const char* const g_option_env[OPT_COUNT] = {"GECCO_ASTAT", "GECCO_CHAIN", "GECCO_HEADMAJOR", "GECCO_MLPFUSED", "GECCO_UNPOOLFUSED"};
+enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_HEADMAJOR = 2, OPT_MLPFUSED = 3, OPT_UNPOOLFUSED = 4, OPT_LO8 = 5, OPT_COUNT = 6 };
+int g_options[OPT_COUNT] = {-1, -1, -1, -1, -1, -1};
+const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor", "mlpfused", "unpoolfused", "lo8"};
+const char* const g_option_env[OPT_COUNT] = {"GECCO_ASTAT", "GECCO_CHAIN", "GECCO_HEADMAJOR", "GECCO_MLPFUSED", "GECCO_UNPOOLFUSED", "GECCO_LO8"};
 int option(int which) {
     if (g_options[which] < 0) {
         const char* e = getenv(g_option_env[which]);
@@ -203,6 +203,7 @@ int astat_linear(const float* x, const float* pa, const float* po, const float* 
         g.lo_begin = Nout1 / 256;
         g.lo_tiles = Nout1 / 128;
     }
+    g.lo_fp8 = img_lo && option(OPT_LO8) && gemm_f16_astat_lo8_supported(K);   // the caller built the lo image by the same rule
     if (C2) { g.C2 = C2; g.bias2 = bias2; g.n_split = Nout1; g.ldc2 = Nout2; }
     // option "astat" = 0 falls back to the cast pass + streaming GEMM (A/B runs; same bits)
     if (!option(OPT_ASTAT) || !img || !gemm_f16_astat_supported(g)) return 1;
@@ -275,10 +276,13 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
                     float* dst = base + lo * (hkv + hq);
                     if (!(h_in && h_in[li])) {
                         if (jobs16.n >= kJobCap) { TRY(split_f16_tiled_multi_launch(jobs16, s), "split(weights)"); jobs16.n = 0; }
-                        jobs16.job[jobs16.n++] = SplitJob{L.kv_proj_w, dst, 2 * C, C, C, lo};
+                        // lo image: fp8 x 2^19 in 64-k blocks where the A-stationary kernel has that form (astat_linear decides alike)
+                        const int lo_kind = lo && option(OPT_LO8) && gemm_f16_astat_lo8_supported(C) ? 2 : lo;
+                        jobs16.job[jobs16.n++] = SplitJob{L.kv_proj_w, dst, 2 * C, C, C, lo_kind};
                     }
+                    if (lo) continue;   // q_proj is one-term: no lo image
                     if (jobs16.n >= kJobCap) { TRY(split_f16_tiled_multi_launch(jobs16, s), "split(weights)"); jobs16.n = 0; }
-                    jobs16.job[jobs16.n++] = SplitJob{L.in_proj_w, dst + hkv, C, C, C, lo};
+                    jobs16.job[jobs16.n++] = SplitJob{L.in_proj_w, dst + hkv, C, C, C, 0};
                 }
             }
             if (!(h_in && h_in[li])) {
@@ -406,7 +410,7 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
             const int hd_try = option(OPT_HEADMAJOR) ? C / H : 0;
             // q's image: after kv_proj's (fp16 mode: o_q floats in; mixed mode: fp16 images inside the 4-byte layout)
             const float* qim = !im ? nullptr : mixed ? im + (size_t)(2 * C + 127) / 128 * 128 * C / 2 : im + w.o_q;
-            const float* qim_lo = mixed && qim ? qim + kvq_lo : nullptr;
+            const float* qim_lo = nullptr;   // q_proj's weights stay one-term (their rounding does not reach the output)
             int one = astat_linear(x, w.a1, w.o1, qim, L.in_proj_b, C, w.q, nullptr, 0, nullptr,
                                    nullptr, 0, B, N, C, s, hd_try, qim_lo);
             if (one == 1 && hd_try)

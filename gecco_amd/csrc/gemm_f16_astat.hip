@@ -35,6 +35,9 @@ using dma::dma16;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int SBK = 32;            // k per stage
 constexpr int S_TILE = 2048;       // floats of one [128][32] fp16 W tile (8 KiB)
@@ -78,10 +81,17 @@ __device__ __forceinline__ void static_for_tag(std::integer_sequence<int, I...>,
 // K-steps of every column tile, multiplied with the SAME register-resident A fragments: x . W_hi + x . W_lo in one
 // accumulator.  The rounding of the weights — coherent over all points of a cloud, the dominant error of the fp16
 // mode (tools/experiments/fp16_site_sensitivity.py) — drops from 2^-12 to 2^-23; the A side is unchanged.
+// WS = 3: the lo term on the fp8 matrix instruction.  The lo image holds fp8(2^19 (W - fp16(W))) in 64-k stages
+// (f8lo_image_item): NK / 2 further stages per column tile, each ONE v_mfma_scale_f32_32x32x64_f8f6f4 per 32-column block
+// (scale_b = 2^-19) on the A fragments of two K-steps converted to fp8 on the fly — half the LDS bytes and half the
+// matrix cycles of the fp16 lo term for the same result (the lo term is 2^-12 of the product: 3 mantissa bits of it suffice;
+// tools/experiments/fp16_site_sensitivity.py scheme x2a_v8).
 template <int NK, int NS, int WS = 1>
 __global__ __launch_bounds__(S_NT, 2) void gemm_f16_astat_kernel(GemmArgs g) {
     static_assert(NK % 2 == 0 && NK % NS == 0 && NS >= 4, "static slots; the A build stages 4 K-steps in the ring");
-    constexpr int NKW = NK * WS;   // W stages per column tile
+    static_assert(WS != 3 || (NK / 2) % NS == 0, "fp8 lo stages keep the static slot arithmetic");
+    constexpr int NL = WS == 3 ? NK / 2 : (WS == 2 ? NK : 0);   // lo stages per column tile
+    constexpr int NKW = NK + NL;   // W stages per column tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
     ASTAMP(0);
     float* ring = smem;                                // [NS][S_TILE]; first the staging area of the A build
@@ -173,18 +183,19 @@ __global__ __launch_bounds__(S_NT, 2) void gemm_f16_astat_kernel(GemmArgs g) {
 
     // ---- W image: buffer_load ... lds, wave w moves pieces 2w, 2w+1 (1 KiB each) of every 8 KiB stage
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.w_img), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wrsrc2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(WS == 2 ? g.w_img2 : g.w_img), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(WS >= 2 ? g.w_img2 : g.w_img), 0, 0x7fffffff, 0x00020000);
     const unsigned voff = (unsigned)((S_PW * wave) * 256 + lane * 4) * 4u;
-    unsigned soff = 0;                                 // byte offset of the next stage to issue in the image
-    int part_left = NK;                                // WS == 2: stages left in the current part (hi, then lo) of the column tile
+    unsigned soff = 0;                                 // byte offset of the next stage to issue in its image (hi or lo)
+    unsigned soff_hi = 0;                              // WS >= 2: where the hi image continues after a lo part
+    int part_left = NK;                                // WS >= 2: stages left in the current part (hi, then lo) of the column tile
     bool lo_part = false;
     int it_tile = 0;                                   // column tile of the next stage to issue
     // WS == 2: column tiles [lo_begin, lo_tiles) carry a lo part — the V projection; the rounding of the K and q
     // projections' weights does not reach the output (tools/experiments/fp16_site_sensitivity.py): streamed hi only
-    const int lo_tiles = WS == 2 ? (g.lo_tiles > 0 ? g.lo_tiles : tilesN) : 0;
-    const int lo_begin = WS == 2 ? g.lo_begin : 0;
+    const int lo_tiles = WS >= 2 ? (g.lo_tiles > 0 ? g.lo_tiles : tilesN) : 0;
+    const int lo_begin = WS >= 2 ? g.lo_begin : 0;
     auto issue = [&](int slot) {
-        if (WS == 2 && lo_part) {
+        if (WS >= 2 && lo_part) {
             dma16_buf(wrsrc2, voff, soff, ring + slot * S_TILE + (S_PW * wave) * 256);
             dma16_buf(wrsrc2, voff + 1024u, soff, ring + slot * S_TILE + (S_PW * wave + 1) * 256);
         } else {
@@ -192,12 +203,15 @@ __global__ __launch_bounds__(S_NT, 2) void gemm_f16_astat_kernel(GemmArgs g) {
             dma16_buf(wrsrc, voff + 1024u, soff, ring + slot * S_TILE + (S_PW * wave + 1) * 256);
         }
         soff += S_TILE * 4u;
-        if (WS == 2 && --part_left == 0) {             // hi part done: the same stages of the lo image; lo done: next tile's hi
-            part_left = NK;
+        if (WS >= 2 && --part_left == 0) {             // hi part done: this tile's stages of the lo image; lo done: next tile's hi
             if (!lo_part && it_tile >= lo_begin && it_tile < lo_tiles) {
-                soff -= NK * S_TILE * 4u;
+                soff_hi = soff;
+                soff = (unsigned)it_tile * (unsigned)(NL * S_TILE * 4);
+                part_left = NL;
                 lo_part = true;
             } else {
+                if (lo_part) soff = soff_hi;
+                part_left = NK;
                 lo_part = false;
                 ++it_tile;
             }
@@ -223,14 +237,20 @@ __global__ __launch_bounds__(S_NT, 2) void gemm_f16_astat_kernel(GemmArgs g) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) boff[j][c] = rb * 16 + (((2 * h + c) ^ ((rb >> 2) & 3)) << 2);
     }
-    f16x8 fb[2][4][2];
+    // the two 16-byte chunks of a 32-column block as ONE 8-register tuple: the fp16 MFMAs take its halves (sub-registers),
+    // the fp8 lo stage (WS = 3) the whole tuple as its 32-byte B operand — no copies either way
+    i32x8 fb[2][4];
     auto load_b = [&](int slot, int f) {
         const float* st = ring + slot * S_TILE;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int c = 0; c < 2; ++c)
-                fb[f][j][c] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(st + boff[j][c]));
+            {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(st + boff[j][c]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) fb[f][j][4 * c + e] = (int)v[e];
+            }
     };
 
     // ---- epilogue of one column tile, from registers: bias, activation, a packed fp16 pair per lane.
@@ -286,13 +306,15 @@ __global__ __launch_bounds__(S_NT, 2) void gemm_f16_astat_kernel(GemmArgs g) {
     dma::wait_vm_lgkm0<(NS - 1) * S_PW>();
     __builtin_amdgcn_s_barrier();
     load_b(0, 0);
+    float one = 1.0f;   // the fp8 conversions' scale operand (see the lo stage)
     for (int ct = 0; ct < tilesN; ++ct) {
         const bool first = ct == 0, last = ct == tilesN - 1;
-        const bool has_lo = WS == 2 && ct >= lo_begin && ct < lo_tiles;   // this column tile runs 2 NK stages (hi, lo), else NK
+        const bool has_lo = WS >= 2 && ct >= lo_begin && ct < lo_tiles;   // this column tile runs NK + NL stages (hi, lo), else NK
+        if (WS == 3) asm volatile("" : "+s"(one));
         static_for(std::make_integer_sequence<int, NKW>{}, [&](auto KT) {
             constexpr int kt = decltype(KT)::value;
             constexpr int cur = kt & 1;
-            if (WS == 2 && kt >= NK && !has_lo) return;   // wave-uniform: a tile without a lo part ends after NK stages
+            if (WS >= 2 && kt >= NK && !has_lo) return;   // wave-uniform: a tile without a lo part ends after NK stages
             constexpr bool early = kt <= NS - 2;   // the previous tile's epilogue stores still queue behind the awaited piece
             // steps left after this one in the last tile, for either length
             constexpr int rem_l = NKW - 1 - kt, rem_s = NK - 1 - kt;
@@ -313,18 +335,50 @@ __global__ __launch_bounds__(S_NT, 2) void gemm_f16_astat_kernel(GemmArgs g) {
             // "redefines" the registers so the compiler's wait-count pass does not park its own lgkmcnt(0) in front of
             // the first MFMA, behind the NEXT step's reads issued below
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) asm volatile("" : "+v"(fb[cur][j][c]));
+            for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(fb[cur][j]));
             __builtin_amdgcn_s_barrier();
             const int len = (WS == 1 || has_lo) ? NKW : NK;
             if (!last || kt + NS < len) issue(kt % NS);                 // the stage NS steps ahead reuses this step's slot
-            if (!last || kt + 1 < len) load_b((kt + 1) % NS, cur ^ 1);
+            constexpr bool lo8 = WS == 3 && kt >= NK;
+            // fp8 lo stage: its A operand is built in the registers of the idle fragment set, so the next stage's fragments
+            // are read right AFTER the four matrix instructions are issued (256 cycles of pipe cover the LDS latency)
+            if (!lo8 && (!last || kt + 1 < len)) load_b((kt + 1) % NS, cur ^ 1);
+            if constexpr (lo8) {
+                // fp8 lo stage S = kt - NK: k = 64 S .. 64 S + 63; lane half h holds k = 64 S + 32 c + 16 h .. + 15 of
+                // its row in fa[2 S + c] — converted to 16 fp8 each, bytes in k order, matching the image's chunks
+                constexpr int S = kt - NK;
+                i32x8 a8;
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        // f16 -> fp8 directly, two values per instruction (v_cvt_scalef32_pk_fp8_f16, scale 1)
+                        // (`one` is 1.0 behind an opaque per-tile asm: it keeps these loop-invariant conversions from being
+                        // hoisted out of the column-tile loop, where 48 more live registers would spill)
+                        const f16x8 v = fa[2 * S + c][q];
+                        s16x2 p0 = {0, 0}, p1 = {0, 0};
+                        p0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(p0, f16x2{v[0], v[1]}, one, false);
+                        p0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(p0, f16x2{v[2], v[3]}, one, true);
+                        p1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(p1, f16x2{v[4], v[5]}, one, false);
+                        p1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(p1, f16x2{v[6], v[7]}, one, true);
+                        const int w0 = __builtin_bit_cast(int, p0), w1 = __builtin_bit_cast(int, p1);
+                        a8[4 * c + 2 * q] = w0;
+                        a8[4 * c + 2 * q + 1] = w1;
+                    }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kt % NK][c], fb[cur][j][c], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, fb[cur][j], acc[j], 0, 0, 0, 127, 0, 127 - 19);
+                if (!last || kt + 1 < len) load_b((kt + 1) % NS, cur ^ 1);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const i32x4 bc = c == 0 ? __builtin_shufflevector(fb[cur][j], fb[cur][j], 0, 1, 2, 3)
+                                                : __builtin_shufflevector(fb[cur][j], fb[cur][j], 4, 5, 6, 7);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kt % NK][c], __builtin_bit_cast(f16x8, bc), acc[j], 0, 0, 0);
+                    }
+            }
         });
         epilogue(ct);
     }
@@ -345,10 +399,16 @@ int astat_launch_ws(const GemmArgs& g, hipStream_t st) {
 }
 template <int NK, int NS>
 int astat_launch_t(const GemmArgs& g, hipStream_t st) {
+    if (g.w_img2 && g.lo_fp8) {
+        if constexpr ((NK / 2) % NS == 0) return astat_launch_ws<NK, NS, 3>(g, st);
+        else return -9;
+    }
     return g.w_img2 ? astat_launch_ws<NK, NS, 2>(g, st) : astat_launch_ws<NK, NS, 1>(g, st);
 }
 
 }  // namespace
+
+bool gemm_f16_astat_lo8_supported(int K) { return K == 256 || K == 384; }   // (K / 64) stages in whole ring rounds: <8, 4>, <12, 6>
 
 bool gemm_f16_astat_supported(const GemmArgs& g) {
     const int nk = g.K / SBK;

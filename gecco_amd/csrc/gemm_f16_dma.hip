@@ -268,6 +268,36 @@ __device__ __forceinline__ void f16_image_item(const float* __restrict__ W, floa
     *reinterpret_cast<u32x4*>(img + blk * FB_TILE + rb * 16 + chp * 4) = __builtin_bit_cast(u32x4, v);
 }
 
+// The LOW part of a two-term fp16 weight as fp8 (e4m3), scaled by 2^19, for v_mfma_scale_f32_32x32x64_f8f6f4: for column
+// tile ct and 64-k step S the 8 KiB block at float offset (ct * K/64 + S) * 2048 holds row rb at rb * 16 floats (64 B =
+// 64 fp8); its 16-byte chunk s ^ ((rb >> 2) & 3) holds k = 64 S + 32 (s & 1) + 16 (s >> 1) .. + 15 — lane half s >> 1,
+// bytes 16 (s & 1) .. of the 32-byte B operand: the same (lane half, chunk) addressing as the fp16 stages, and the k
+// order in which gemm_f16_astat.hip packs its fp16 A fragments into the fp8 A operand.  |w_lo| <= 2^-12 |w|: the scale
+// keeps weights up to |w| = 1 inside e4m3's range (448); larger ones saturate (their hi term is unaffected).
+constexpr float LO8_SCALE = 524288.f;   // 2^19; the kernel's scale_b is 2^-19
+__device__ __forceinline__ void f8lo_image_item(const float* __restrict__ W, float* __restrict__ img, int Nout, int K,
+                                                int ldw, size_t i) {
+    const int nk = K / 64;
+    const int chp = (int)(i & 3), rb = (int)((i >> 2) & 127);
+    const size_t blk = i >> 9;
+    const int S = (int)(blk % nk), ct = (int)(blk / nk);
+    const int s = chp ^ ((rb >> 2) & 3);
+    const float* src = W + (size_t)min(ct * DBN + rb, Nout - 1) * ldw + S * 64 + 32 * (s & 1) + 16 * (s >> 1);
+    u32x4 out;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(src + 4 * q);
+        float lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lo[e] = (w[e] - (float)(_Float16)w[e]) * LO8_SCALE;
+        int pk = 0;
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(lo[0], lo[1], pk, false);
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(lo[2], lo[3], pk, true);
+        out[q] = (unsigned)pk;
+    }
+    *reinterpret_cast<u32x4*>(img + blk * FB_TILE + rb * 16 + chp * 4) = out;
+}
+
 __global__ void split_f16_tiled_kernel(const float* __restrict__ W, float* __restrict__ img, int Nout, int K, int ldw,
                                        size_t total) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
@@ -276,6 +306,12 @@ __global__ void split_f16_tiled_kernel(const float* __restrict__ W, float* __res
 
 __global__ void split_f16_tiled_multi_kernel(SplitJobs jobs) {
     const SplitJob j = jobs.job[blockIdx.y];
+    if (j.pad_ == 2) {
+        const size_t total8 = (size_t)((j.Nout + DBN - 1) / DBN) * (j.K / 64) * 512;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (size_t)gridDim.x * blockDim.x)
+            f8lo_image_item(j.W, j.img, j.Nout, j.K, j.ldw, i);
+        return;
+    }
     const size_t total = (size_t)((j.Nout + DBN - 1) / DBN) * (j.K / FBK) * 512;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
         f16_image_item(j.W, j.img, j.Nout, j.K, j.ldw, i, j.pad_);

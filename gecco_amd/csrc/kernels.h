@@ -36,9 +36,10 @@ struct GemmArgs {
     const void* w_img2;
     int lo_tiles;           // with w_img2: only the 128-column tiles [lo_begin, lo_tiles) have a lo part (lo_tiles 0: all)
     int lo_begin;
+    int lo_fp8;             // with w_img2: the lo image holds fp8 (e4m3) values scaled by 2^19 in 64-k stages (gemm_f16_astat.hip WS = 3)
 };
 
-struct SplitJob { const float* W; float* img; int Nout, K, ldw, pad_; };   // pad_ = 1 (fp16 images): the LOW part fp16(W - fp16(W))
+struct SplitJob { const float* W; float* img; int Nout, K, ldw, pad_; };   // pad_ = 1 (fp16 images): the LOW part fp16(W - fp16(W)); 2: the same as fp8 x 2^19 in 64-k blocks
 struct SplitJobs { SplitJob job[96]; int n; };   // 3 KiB of kernel arguments
 int gemm_row_tile(int rows);  // row-tile height the GEMM uses for `rows` rows per sample
 int gemm_f32_launch(const GemmArgs& g, hipStream_t st);
@@ -120,6 +121,7 @@ int gemm_tn_x3_launch(const TnArgs& g, hipStream_t st);
 
 // gemm_f16_astat.hip — fp16 mode, A-stationary: AdaGN apply + fp16 rounding + all column tiles in one pass over x
 // (fp32 A with optional prologue, fp16 outputs, one or two segments; K <= 384, full 128-tiles)
+bool gemm_f16_astat_lo8_supported(int K);   // the fp8 form of the lo image exists for this K
 bool gemm_f16_astat_supported(const GemmArgs& g);
 int gemm_f16_astat_launch(const GemmArgs& g, hipStream_t st);
 

@@ -89,8 +89,10 @@ int gecco_linear_f32(const float* A, const float* W, const float* bias, const fl
  *   "mlpfused" (default 1): fp16 mode runs AdaGN + mlp.0 + activation + mlp.2 + residual + statistics as one launch;
  *   "unpoolfused" (default 1): fp16 mode runs unpool attention + out_proj + residual + statistics as one launch
  *   (needs "headmajor").
+ *   "lo8" (default 1): mixed mode streams the second term of the V projection's two-term weights as fp8 (e4m3, x 2^19) on
+ *   v_mfma_scale_f32_32x32x64_f8f6f4 (d = 256, 384) instead of as fp16: same result to ~1e-6 of the output.
  * value < 0 returns the option to its default / environment (GECCO_ASTAT, GECCO_CHAIN, GECCO_HEADMAJOR, GECCO_MLPFUSED,
- * GECCO_UNPOOLFUSED).
+ * GECCO_UNPOOLFUSED, GECCO_LO8).
  * Process-wide. */
 int gecco_set_option(const char* name, int value);
 

@@ -231,6 +231,31 @@ def test_fp16_fused_unpool_matches_two_launch_form(ops, golden_dir, name):
     assert torch.equal(out[0], out[1])
 
 
+@pytest.mark.parametrize("name", list(cases.UNCOND_CASES))
+def test_mixed_fp8_lo_term_matches_fp16_lo_term(ops, golden_dir, name):
+    """Mixed mode: the second term of the V projection's two-term weights on the fp8 matrix instruction (option "lo8",
+    v_mfma_scale_f32_32x32x64_f8f6f4 with scale 2^-19; d = 256 / 384) against the same term as fp16 — the lo term is 2^-12 of
+    the product, so 3 mantissa bits of it move the output by ~2^-16 — and both against the golden reference output."""
+    p, x, sigma = cases.uncond_inputs(name)
+    g = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    net = ops.LinearLiftPlan(_cuda(p), cases.H, cases.I, precision="mixed")
+    out = {}
+    try:
+        for on in (0, 1):
+            ops.set_option("lo8", on)
+            out[on] = net.forward(x.cuda(), sigma.cuda()).cpu()
+    finally:
+        ops.set_option("lo8", -1)
+    e = cpu_ref.rel_err(out[1], out[0])
+    assert e[0] <= 3e-5, e
+    for on in (0, 1):
+        eg = cpu_ref.rel_err(out[on], torch.from_numpy(g["denoised"]))
+        assert eg[0] <= 2e-4, (on, eg)
+    d = p["lift.weight"].shape[0]
+    if d in (256, 384):
+        assert not torch.equal(out[0], out[1]), "the fp8 form did not run"
+
+
 def test_split_bf16_linear_accuracy(ops):
     """The split itself: products with operands spanning 8 orders of magnitude keep ~2^-16 relative accuracy."""
     import ctypes as C

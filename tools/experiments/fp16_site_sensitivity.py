@@ -59,6 +59,12 @@ def product(a, b_t, scheme, mm):
         half = b_t.shape[0] // 2
         lo = torch.cat([torch.zeros_like(lo[:half]), lo[half:]]) if scheme == "x2a_v" else torch.cat([lo[:half], torch.zeros_like(lo[half:])])
         return mm(r16(a), bh) + mm(r16(a), lo)
+    if scheme == "x2a_v8":   # V half: fp16 a x (fp16 w_hi) + fp8 a x fp8 w_lo (the lo term on the fp8 matrix instruction)
+        bh = r16(b_t)
+        lo = b_t - bh
+        half = b_t.shape[0] // 2
+        lo = torch.cat([torch.zeros_like(lo[:half]), lo[half:]])
+        return mm(r16(a), bh) + mm(r8(a), r8(lo))
     if scheme == "x3":
         ah, bh = r16(a), r16(b_t)
         return mm(ah, bh) + mm(r16(a - ah), bh) + mm(ah, r16(b_t - bh))

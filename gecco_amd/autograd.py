@@ -122,14 +122,21 @@ class LinearFn(torch.autograd.Function):
     `x = x + f(...)` (models/set_transformer.py:164-166) folded into the GEMM's epilogue; its gradient is dy itself."""
 
     @staticmethod
-    def forward(ctx, x, W, b, residual=None):
+    def forward(ctx, x, W, b, residual=None, want_stats=False):
+        """want_stats: also return the GroupNorm partial sums of the output, (B, T, 2, Nout), from the GEMM's epilogue — the
+        next AdaGN takes them instead of a pass over the tensor (not differentiable: AdaGNFn's backward owns that path)."""
         x = _f(x)
         ctx.save_for_backward(x, W)
         ctx.has_bias = b is not None
-        return hip_ops.linear(x, W, b, residual=None if residual is None else _f(residual), precision=_train_precision())
+        res = None if residual is None else _f(residual)
+        if want_stats:
+            y, st = hip_ops.linear(x, W, b, residual=res, want_stats=True, precision=_train_precision())
+            ctx.mark_non_differentiable(st)
+            return y, st
+        return hip_ops.linear(x, W, b, residual=res, precision=_train_precision())
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dstats=None):
         x, W = ctx.saved_tensors
         dy = _f(dy)
         dx = _linear_dx(dy, W) if ctx.needs_input_grad[0] else None
@@ -140,9 +147,9 @@ class LinearFn(torch.autograd.Function):
             dW = _linear_dw(dy, x)
         elif ctx.has_bias and ctx.needs_input_grad[2]:
             db = _linear_db(dy)
-        if len(ctx.needs_input_grad) == 3:   # called without a residual
-            return dx, dW, db
-        return dx, dW, db, (dy if ctx.needs_input_grad[3] else None)
+        n = len(ctx.needs_input_grad)        # 3 .. 5: called without / with a residual (and the statistics flag)
+        dres = dy if n > 3 and ctx.needs_input_grad[3] else None
+        return (dx, dW, db, dres, None)[:n]
 
 
 class LinearPairFn(torch.autograd.Function):
@@ -177,15 +184,17 @@ class AdaGNFn(torch.autograd.Function):
     """y = scale(t) * GroupNorm(x) + bias(t) on (B, R, C); params None -> plain GroupNorm."""
 
     @staticmethod
-    def forward(ctx, x, t, sw, sb, bw, bb, G, eps, passthrough=False):
+    def forward(ctx, x, t, sw, sb, bw, bb, G, eps, passthrough=False, stats=None):
         """passthrough: also return x itself, for the residual connection around the normalised branch — the gradient
-        that comes back through it is added inside this Function's backward kernel instead of by an autograd pass."""
+        that comes back through it is added inside this Function's backward kernel instead of by an autograd pass.
+        stats: the partial sums {sum x, sum x^2} per (sample, row tile, channel) when the producer of x already formed them
+        (LinearFn(..., want_stats=True)); otherwise one pass over x here."""
         x = _f(x)
         lib = _lib.load()
         ctx.set_materialize_grads(False)
         ctx.passthrough = passthrough
         B, R, Cc = x.shape
-        stats = hip_ops.col_stats(x)
+        stats = hip_ops.col_stats(x) if stats is None else stats
         params = None if sw is None else (sw, sb, bw, bb)
         t2 = None if t is None else _f(t.reshape(B, -1).float())
         a, o = hip_ops.adagn_coeffs(stats, R, t2, params, G, eps)
@@ -198,13 +207,15 @@ class AdaGNFn(torch.autograd.Function):
     def backward(ctx, dy, dskip=None):
         _no_input_grad(ctx, 1, "the noise-level embedding t")
         x, stats, t2, sw, sb = ctx.saved_tensors
-        none = (None,) * 8
+        none = (None,) * 9
         if dy is None:   # only the skip connection carried a gradient
             return (dskip, *none)
         dy = _f(dy)
         lib = _lib.load()
         B, R, Cc = x.shape
-        gst = torch.empty_like(stats)
+        # {sum dy, sum dy x} partials in col_dot_stats' own row tiling (the forward statistics may come from a GEMM epilogue
+        # with another one)
+        gst = _new(B, lib.gecco_stats_row_tiles(R), 2, Cc, like=x)
         _lib.check(lib.gecco_col_dot_stats_f32(_ptr(dy), _ptr(x), _ptr(gst), B, R, Cc, _stream()), "col_dot_stats")
         cA, cB, cC, ds, dz = (_new(B, Cc, like=x) for _ in range(5))
         p = _lib.GeccoAdaGN(_ptr(sw), _ptr(sb), None, None) if ctx.affine else None
@@ -222,7 +233,7 @@ class AdaGNFn(torch.autograd.Function):
         dsb, dbb = _new(Cc, like=x), _new(Cc, like=x)
         _lib.check(lib.gecco_adagn_param_grads_f32(_ptr(ds), _ptr(dz), _ptr(t2), B, Cc, ctxd, _ptr(dsw), _ptr(dsb),
                                                    _ptr(dbw), _ptr(dbb), _stream()), "adagn_param_grads")
-        return dx, None, dsw, dsb, dbw, dbb, None, None, None
+        return dx, None, dsw, dsb, dbw, dbb, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------- activation
@@ -527,19 +538,23 @@ class LookupFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------- network composition
-def adagn(mod, x, t, passthrough=False):
+def adagn(mod, x, t, passthrough=False, stats=None):
     return AdaGNFn.apply(x, t, mod.scale.weight, mod.scale.bias, mod.bias.weight, mod.bias.bias, mod.gn.num_groups, mod.gn.eps,
-                         passthrough)
+                         passthrough, stats)
 
 
-def mlp(mod, x, residual=None):
-    """nn.Sequential(Linear, act, Linear, ...) (reference models/mlp.py); `residual` is added by the last Linear's epilogue."""
+def mlp(mod, x, residual=None, want_stats=False):
+    """nn.Sequential(Linear, act, Linear, ...) (reference models/mlp.py); `residual` is added by the last Linear's epilogue,
+    which with `want_stats` also leaves the next norm's partial sums: returns (y, stats)."""
     from .models.activation import GaussianActivation
     mods = list(mod)
     i = 0
     while i < len(mods):
         lin = mods[i]
-        x = LinearFn.apply(x, lin.weight, lin.bias, residual if i + 2 >= len(mods) else None)
+        last = i + 2 >= len(mods)
+        x = LinearFn.apply(x, lin.weight, lin.bias, residual if last else None, want_stats and last)
+        if want_stats and last:
+            return x   # (y, stats)
         if i + 1 < len(mods):
             act = mods[i + 1]
             if isinstance(act, GaussianActivation):
@@ -552,12 +567,14 @@ def mlp(mod, x, residual=None):
     return x
 
 
-def broadcasting_layer(layer, x, t, h=None):
-    """BroadcastingLayer.forward with autograd (reference models/set_transformer.py:155-168, 92-117, 47-65)."""
+def broadcasting_layer(layer, x, t, h=None, stats=None, want_stats=False):
+    """BroadcastingLayer.forward with autograd (reference models/set_transformer.py:155-168, 92-117, 47-65).
+    stats / want_stats: the GroupNorm partial sums of x handed from layer to layer (formed by the GEMM that wrote x);
+    with want_stats the return value is (x, h, stats of x)."""
     bc = layer.broadcast
     H = bc.pool.num_heads
     Cc = x.shape[-1]
-    y, x = adagn(layer.broadcast_norm, x, t, passthrough=True)
+    y, x = adagn(layer.broadcast_norm, x, t, passthrough=True, stats=stats)
     W, b = bc.unpool.in_proj_weight, bc.unpool.in_proj_bias
     if h is None:
         KV, q = LinearPairFn.apply(y, bc.pool.kv_proj.weight, None, W[:Cc], b[:Cc])
@@ -570,17 +587,20 @@ def broadcasting_layer(layer, x, t, h=None):
         q = LinearFn.apply(y, W[:Cc], b[:Cc])
     kvh = LinearFn.apply(h, W[Cc:], b[Cc:])
     attn = UnpoolAttnFn.apply(q, kvh, H)
-    x = LinearFn.apply(attn, bc.unpool.out_proj.weight, bc.unpool.out_proj.bias, x)      # x + out_proj(attn)
-    y, x = adagn(layer.mlp_norm, x, t, passthrough=True)
-    x = mlp(layer.mlp, y, residual=x)                                                     # x + mlp(mlp_norm(x))
-    return x, h
+    x, st = LinearFn.apply(attn, bc.unpool.out_proj.weight, bc.unpool.out_proj.bias, x, True)   # x + out_proj(attn)
+    y, x = adagn(layer.mlp_norm, x, t, passthrough=True, stats=st)
+    if want_stats:
+        x, st = mlp(layer.mlp, y, residual=x, want_stats=True)                            # x + mlp(mlp_norm(x))
+        return x, h, st
+    return mlp(layer.mlp, y, residual=x), h
 
 
 def set_transformer(st, feats, t, return_h=False, hs=None):
     hs = [None] * len(st.layers) if hs is None else hs
     stored = []
+    stats = None
     for layer, h in zip(st.layers, hs):
-        feats, h = broadcasting_layer(layer, feats, t, h)
+        feats, h, stats = broadcasting_layer(layer, feats, t, h, stats, True)
         stored.append(h)
     return feats, (stored if return_h else None)
 

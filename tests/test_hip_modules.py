@@ -106,6 +106,28 @@ def test_diffusion_forward_golden(golden_dir, name):
         _close(out_new, gc["out_new"])
 
 
+def test_forward_and_sampler_under_autocast_and_half_inputs(golden_dir):
+    """Callers of the reference wrap sampling in `torch.autocast` (its notebooks) and train under fp16 autocast:
+    the HIP path computes in its own arithmetic whatever the autocast state or the input dtype — same bits as the plain call."""
+    name = "uncond_d128_L4_N256"
+    d, L, N, seed = cases.UNCOND_CASES[name]
+    p, x, sigma = cases.uncond_inputs(name)
+    m = build_uncond(d, L)
+    m.load_state_dict(uncond_state_dict(p), strict=True)
+    m = m.cuda().eval()
+    with torch.no_grad():
+        ref = m(x.cuda(), sigma.cuda(), None)
+        with torch.autocast(device_type="cuda", dtype=torch.float16):
+            got = m(x.cuda(), sigma.cuda(), None)
+        assert got.dtype == torch.float32 and torch.equal(got, ref)
+        got16 = m(x.cuda().half(), sigma.cuda(), None)      # a half input is widened, not computed on in fp16
+        _close(got16, m(x.half().float().cuda(), sigma.cuda(), None).cpu(), 1e-6)
+        s0 = m.sample_stochastic((2, 64, 3), None, num_steps=4, rng=torch.Generator("cuda").manual_seed(7))
+        with torch.autocast(device_type="cuda", dtype=torch.float16):
+            s1 = m.sample_stochastic((2, 64, 3), None, num_steps=4, rng=torch.Generator("cuda").manual_seed(7))
+        assert torch.equal(s0, s1)
+
+
 def test_plan_follows_parameter_moves_and_updates():
     d, L = 64, 2
     p, x, sigma = W.linear_lift_state_dict(5, d, L, cases.I, cases.H), *W.synthetic_cloud(5, 2, 96)

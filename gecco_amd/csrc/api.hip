@@ -118,8 +118,10 @@ STWorkspace carve_st(const GeccoSetTransformer* st, int B, int N, void* base) {
 // hi | lo image of W first (a ~3 us pass over <= 1.2 MB: weights may change between calls, nothing is cached).
 int linear(const float* A, const float* W, const float* bias, const float* pa, const float* po, const float* alpha,
            const float* res, float* C, float* stats, int B, int rows, int K, int Nout, int act, hipStream_t s,
-           int precision = 0, float* wsplit = nullptr, const float* img_ready = nullptr, int a_f16 = 0, int c_f16 = 0) {
+           int precision = 0, float* wsplit = nullptr, const float* img_ready = nullptr, int a_f16 = 0, int c_f16 = 0,
+           int a_img = 0, int c_img = 0) {
     GemmArgs g{};
+    g.a_img = a_img; g.c_img = c_img;   // activation handed over as a tiled split image (kernels.h); callers check act_image_ok
     g.A = A; g.W = W; g.bias = bias; g.pro_a = pa; g.pro_o = po; g.alpha = alpha; g.residual = res; g.C = C;
     g.stats = stats; g.B = B; g.rows = rows; g.K = K; g.Nout = Nout;
     g.lda = K; g.ldw = K; g.ldc = Nout; g.ldr = Nout; g.act = act;
@@ -129,6 +131,7 @@ int linear(const float* A, const float* W, const float* bias, const float* pa, c
     g.a_f16 = a_f16; g.c_f16 = c_f16;   // fp16 tensors exist only between the fp16 kernels (st_forward checks support)
     const bool fast = precision == 1 ? gemm_f32_dma_supported(g, 1) : precision == 2 ? gemm_f16_dma_supported(g) : false;
     if ((a_f16 || c_f16) && !(fast && precision == 2 && (wsplit || img_ready))) return -9;
+    if ((a_img || c_img) && !(fast && precision == 1 && (wsplit || img_ready))) return -9;
     if (fast && (wsplit || img_ready)) {
         if (img_ready) {
             g.w_img = img_ready;   // already converted this forward
@@ -178,10 +181,11 @@ int linear_pair(const float* A, const float* W1, const float* b1, int Nout1, flo
 }
 
 // Path switches for A/B runs and tests: gecco_set_option, or the environment (GECCO_ASTAT, GECCO_CHAIN) on first use.
-enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_HEADMAJOR = 2, OPT_MLPFUSED = 3, OPT_UNPOOLFUSED = 4, OPT_LO8 = 5, OPT_COUNT = 6 };
-int g_options[OPT_COUNT] = {-1, -1, -1, -1, -1, -1};
-const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor", "mlpfused", "unpoolfused", "lo8"};
-const char* const g_option_env[OPT_COUNT] = {"GECCO_ASTAT", "GECCO_CHAIN", "GECCO_HEADMAJOR", "GECCO_MLPFUSED", "GECCO_UNPOOLFUSED", "GECCO_LO8"};
+enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_HEADMAJOR = 2, OPT_MLPFUSED = 3, OPT_UNPOOLFUSED = 4, OPT_LO8 = 5, OPT_ACTIMG = 6, OPT_COUNT = 7 };
+int g_options[OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1};
+const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor", "mlpfused", "unpoolfused", "lo8", "actimg"};
+const char* const g_option_env[OPT_COUNT] = {"GECCO_ASTAT", "GECCO_CHAIN", "GECCO_HEADMAJOR", "GECCO_MLPFUSED", "GECCO_UNPOOLFUSED", "GECCO_LO8",
+                                             "GECCO_ACTIMG"};
 int option(int which) {
     if (g_options[which] < 0) {
         const char* e = getenv(g_option_env[which]);
@@ -459,13 +463,16 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
                                          nullptr, L.mlp.alpha, act, B, N, C, s)
                           : 1;
         if (m0_done < 0) TRY(m0_done, "mlp.0 (A-stationary)");
+        // split-bf16 products: the hidden layer goes from mlp.0 to mlp.2 as a tiled split image (same bytes as the fp32 tensor
+        // it replaces, in the same buffer): contiguous DMA pieces and no hi / lo split in mlp.2's K loop
+        const int himg = pr == 1 && !a16 && im && option(OPT_ACTIMG) && N >= 128 && N % 128 == 0 && Wd % 16 == 0 && C % 16 == 0;
         if (m0_done == 1) {
         if (a16) TRY(affine_cast_f16_launch(x, w.a2, w.o2, w.attn, B, N, C, s), "mlp_norm -> fp16");
         TRY(linear(a16 ? w.attn : x, L.mlp.w0, L.mlp.b0, a16 ? nullptr : w.a2, a16 ? nullptr : w.o2, L.mlp.alpha, nullptr,
-                   w.big, nullptr, B, N, C, Wd, act, s, pr, w.wsplit, im ? im + w.o_w0 : nullptr, a16, a16), "mlp.0");
+                   w.big, nullptr, B, N, C, Wd, act, s, pr, w.wsplit, im ? im + w.o_w0 : nullptr, a16, a16, 0, himg), "mlp.0");
         }
         TRY(linear(w.big, L.mlp.w2, L.mlp.b2, nullptr, nullptr, nullptr, x, x, so, B, N, Wd, C, 0, s, pr, w.wsplit,
-                   im ? im + w.o_w2 : nullptr, a16, 0), "mlp.2+residual");
+                   im ? im + w.o_w2 : nullptr, a16, 0, himg, 0), "mlp.2+residual");
         sx = w.stats_x;
         sT = Tn;
     }

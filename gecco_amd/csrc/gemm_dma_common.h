@@ -124,6 +124,39 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, const Tile& t, f32x1
                 for (int e = 0; e < 16; ++e) Tt[mfma_row(e, h) * D_TP + jj * 32 + r] = val[e];
             }
             // the transpose tile is wave-private: the wave's own LDS operations execute in order, no barrier needed
+            if (!C16 && g.c_img) {
+                // tiled split image (GemmArgs::c_img): 8 lanes per 64-column row of the sub-tile, 8 rows per instruction; a lane's 8
+                // consecutive k are 16 bytes of the hi plane and 16 of the lo plane of one 8 KiB block
+                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+                const int lr8 = lane >> 3, c8 = lane & 7;
+                const int n8 = ncol0 + c8 * 8;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int m = mrow0 + it * 8 + lr8;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(Tt + (it * 8 + lr8) * D_TP + c8 * 8);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(Tt + (it * 8 + lr8) * D_TP + c8 * 8 + 4);
+                    u32x4 hi;
+                    bf16x8 lo;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const float a = p < 2 ? v0[2 * p] : v1[2 * p - 4], c = p < 2 ? v0[2 * p + 1] : v1[2 * p - 3];
+                        const unsigned ua = __float_as_uint(a), uc = __float_as_uint(c);
+                        hi[p] = __builtin_amdgcn_perm(uc, ua, 0x07060302u);
+                        lo[2 * p] = (__bf16)(a - __uint_as_float(ua & 0xFFFF0000u));
+                        lo[2 * p + 1] = (__bf16)(c - __uint_as_float(uc & 0xFFFF0000u));
+                    }
+                    if (n8 < nseg && m < g.rows) {
+                        const int kt = n8 >> 4, ml = m & 127;
+                        const size_t blk = ((size_t)b * ((g.rows + 127) >> 7) + (m >> 7)) * (g.Nout >> 4) + kt;
+                        unsigned short* dst = reinterpret_cast<unsigned short*>(Cseg) + blk * 4096 + ml * 16 +
+                                              ((((n8 & 15) >> 3) ^ ((ml >> 3) & 1)) << 3);
+                        GECCO_NT_STORE(hi, reinterpret_cast<u32x4*>(dst));
+                        GECCO_NT_STORE(__builtin_bit_cast(u32x4, lo), reinterpret_cast<u32x4*>(dst + 2048));
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int m = mrow0 + it * 4 + lr;
@@ -146,7 +179,10 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, const Tile& t, f32x1
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
                 const f32x4 vz = ok ? v4 : z;
                 s1[jh] += vz;
-                s2[jh] += vz * vz;
+                // an explicit fma: left to -ffp-contract the compiler fuses this in some instantiations of the template and
+                // not in others, and the kernels that share this epilogue stop agreeing to the bit on the statistics
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s2[jh][q] = __builtin_fmaf(vz[q], vz[q], s2[jh][q]);
             }
         }
     }

@@ -67,9 +67,13 @@ __device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, bf16x8&
 // at the full matrix rate against the LDS's 128), and a wave tile twice as tall re-uses every W fragment for two row
 // tiles: 0.75 KiB of LDS traffic per MFMA instead of 1.17; 72 KiB of ring = two blocks per CU, so one block's epilogue
 // still runs under the other's K loop.
-template <int DNS, bool HAS_PRO, bool X3, int BM = 128>
+// AIMG: A arrives as the tiled split image of GemmArgs::a_img (written by the producing GEMM's epilogue): its blocks are DMA'd
+// as they are — 1 KiB contiguous per wave-instruction like the W image, where fp32 rows give 64-byte pieces — and the
+// fragments are read as bf16 hi / lo planes: no split, no VALU in the K loop.
+template <int DNS, bool HAS_PRO, bool X3, int BM = 128, bool AIMG = false>
 __global__ __launch_bounds__(DNT, BM == 256 ? 2 : (DNS <= 3 ? 3 : 2)) void gemm_dma_kernel(GemmArgs g) {
     static_assert(BM == 128 || ((BM == 64 || BM == 256) && X3), "64- and 256-row tiles exist in split-bf16 mode only");
+    static_assert(!AIMG || (X3 && !HAS_PRO && BM >= 128), "the activation image feeds the split-bf16 kernel without prologue");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int A_TILE = a_tile_floats(BM), STAGE = stage_floats(BM);
     float* pro_lds = smem + d_main_floats(DNS, BM);   // pa[0..K) | po[0..K)
@@ -99,14 +103,20 @@ __global__ __launch_bounds__(DNT, BM == 256 ? 2 : (DNS <= 3 ? 3 : 2)) void gemm_
     constexpr int NQ = NAP > 2 ? NAP : 2;
     const float* asrc[NQ];
     const void* bsrc[2];
+    const int nk = g.K / DBK;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int row = (NAP * wave + (q < NAP ? q : 0)) * 16 + (lane >> 2);
         const int c = (lane & 3) ^ ((row >> 2) & 3);
         asrc[q] = Ab + (size_t)min(m0 + row, g.rows - 1) * g.lda + c * 4;
+        if (AIMG) {
+            // piece p of the block tile's image: 8 pieces (hi plane 4, lo plane 4) per 128-row image tile
+            const int p = NAP * wave + (q < NAP ? q : 0), t128 = (g.rows + 127) >> 7;
+            const int tile = min((m0 >> 7) + (p >> 3), t128 - 1);
+            asrc[q] = g.A + ((size_t)b * t128 + tile) * nk * D_TILE + (p & 7) * 256 + lane * 4;
+        }
         if (!X3 && q < 2) bsrc[q] = Wseg + (size_t)min(nseg0 + row, nseg - 1) * g.ldw + c * 4;
     }
-    const int nk = g.K / DBK;
     if (X3) {
         // pre-tiled W image (split_bf16_tiled_kernel): one 8 KiB block per (column tile, K-step) that IS the LDS
         // image (hi plane | lo plane, swizzle baked in), so a wave-instruction reads 1 KiB of consecutive bytes —
@@ -121,7 +131,7 @@ __global__ __launch_bounds__(DNT, BM == 256 ? 2 : (DNS <= 3 ? 3 : 2)) void gemm_
 #endif
         float* st = smem + (kt % DNS) * STAGE;
 #pragma unroll
-        for (int q = 0; q < NAP; ++q) dma16(asrc[q] + kt * DBK, st + (NAP * wave + q) * 256);
+        for (int q = 0; q < NAP; ++q) dma16(asrc[q] + (AIMG ? (size_t)kt * D_TILE : (size_t)kt * DBK), st + (NAP * wave + q) * 256);
         if (X3) {
             dma16(static_cast<const float*>(bsrc[0]) + (size_t)kt * D_TILE, st + A_TILE + wave * 256);
             dma16(static_cast<const float*>(bsrc[1]) + (size_t)kt * D_TILE, st + A_TILE + 1024 + wave * 256);
@@ -168,6 +178,11 @@ __global__ __launch_bounds__(DNT, BM == 256 ? 2 : (DNS <= 3 ? 3 : 2)) void gemm_
             const int c = X3 ? (2 * h + q) : (2 * q + h);
             aoff[i][q] = ra * DBK + ((c ^ ((ra >> 2) & 3)) << 2);
         }
+        if (AIMG) {   // image tile ra >> 7 of the block tile; bf16 plane row = 8 floats, this lane's chunk = h ^ ((row >> 3) & 1)
+            const int rl = ra & 127;
+            aoff[i][0] = (ra >> 7) * D_TILE + rl * 8 + ((h ^ ((rl >> 3) & 1)) << 2);   // hi plane
+            aoff[i][1] = aoff[i][0] + 1024;                                             // lo plane
+        }
     }
 #pragma unroll
     for (int j = 0; j < TNW; ++j) {
@@ -202,6 +217,10 @@ __global__ __launch_bounds__(DNT, BM == 256 ? 2 : (DNS <= 3 ? 3 : 2)) void gemm_
             for (int i = 0; i < TMW; ++i) {
                 x0[i] = *reinterpret_cast<const f32x4*>(st + aoff[i][0]);
                 x1[i] = *reinterpret_cast<const f32x4*>(st + aoff[i][1]);
+                if (AIMG) {   // already hi / lo planes
+                    ahi[f][i] = __builtin_bit_cast(bf16x8, x0[i]);
+                    alo[f][i] = __builtin_bit_cast(bf16x8, x1[i]);
+                }
             }
 #pragma unroll
             for (int j = 0; j < TNW; ++j) {
@@ -210,6 +229,7 @@ __global__ __launch_bounds__(DNT, BM == 256 ? 2 : (DNS <= 3 ? 3 : 2)) void gemm_
             }
 #pragma unroll
             for (int i = 0; i < TMW; ++i) {
+                if (AIMG) continue;
                 if (HAS_PRO) {
                     x0[i] = x0[i] * pa0 + po0;
                     x1[i] = x1[i] * pa1 + po1;
@@ -248,7 +268,9 @@ __global__ __launch_bounds__(DNT, BM == 256 ? 2 : (DNS <= 3 ? 3 : 2)) void gemm_
                 asm volatile("" : "+v"(bhi[cur][j]));
                 asm volatile("" : "+v"(blo[cur][j]));
             }
+#ifndef GEMM_DIAG_NOBARRIER   // diagnostic build: wrong results, the cost of the per-K-step lock-step
             __builtin_amdgcn_s_barrier();
+#endif
             if (kt + DNS < nk) issue(kt + DNS);
             // next K-step's slot; past the end a landed slot is re-read and the values are never used
             const int kn = min(kt + 1, nk - 1);
@@ -333,6 +355,20 @@ __global__ void split_bf16_tiled_kernel(const float* __restrict__ W, float* __re
     }
 }
 
+template <int BM>
+int dma_launch_aimg(const GemmArgs& g, hipStream_t st) {
+    const int tilesM = (g.rows + BM - 1) / BM, tilesN = (g.Nout + DBN - 1) / DBN;
+    const size_t lds = (size_t)(d_main_floats(3, BM) + 2 * g.K) * sizeof(float);
+    static size_t attr = 0;
+    if (lds > attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma_kernel<3, false, true, BM, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = lds;
+    }
+    hipLaunchKernelGGL((gemm_dma_kernel<3, false, true, BM, true>), dim3(g.B * tilesM * tilesN), dim3(DNT), lds, st, g);
+    return (int)hipGetLastError();
+}
+
 template <int DNS, bool X3, int BM = 128>
 int dma_launch_t(const GemmArgs& g, hipStream_t st) {
     const int tilesM = (g.rows + BM - 1) / BM, tilesN = (g.Nout + DBN - 1) / DBN;
@@ -367,6 +403,19 @@ int gemm_f32_dma_launch(const GemmArgs& g, hipStream_t st) {
         const char* e = getenv("GECCO_GEMM_STAGES");   // 3 stages = 51 KB LDS = three blocks per CU (measured best)
         ns3 = (e && atoi(e) == 4) ? 0 : 1;
     }
+    if (g.a_img) {
+        if (!(g.precision == 1 && g.w_img && !g.pro_a && g.rows >= 128 && g.rows % 128 == 0)) return -9;
+        static int areg = -1;
+        if (areg < 0) {
+            const char* e = getenv("GECCO_AREG");   // 0: the image through the LDS ring (A/B runs)
+            areg = (e && atoi(e) == 0) ? 0 : 1;
+        }
+        if (areg && gemm_x3_areg_supported(g)) return gemm_x3_areg_launch(g, st);
+        return (g.rows >= 256 && g.K >= 512) ? dma_launch_aimg<256>(g, st) : dma_launch_aimg<128>(g, st);
+    }
+    if (g.c_img && !(g.precision == 1 && g.w_img && !g.residual && !g.stats && !g.C2 && g.rows >= 128 && g.rows % 128 == 0 &&
+                     g.Nout % 16 == 0))
+        return -9;
     if (g.precision == 1 && g.w_img) {
         if (g.rows < 128) return dma_launch_t<3, true, 64>(g, st);
         static int bm256 = -1;

@@ -37,6 +37,12 @@ struct GemmArgs {
     int lo_tiles;           // with w_img2: only the 128-column tiles [lo_begin, lo_tiles) have a lo part (lo_tiles 0: all)
     int lo_begin;
     int lo_fp8;             // with w_img2: the lo image holds fp8 (e4m3) values scaled by 2^19 in 64-k stages (gemm_f16_astat.hip WS = 3)
+    // split-bf16 LDS-DMA kernel only: an activation handed from one GEMM to the next as a TILED SPLIT IMAGE instead of an
+    // fp32 tensor — per (sample, 128-row tile, 16-k step) one 8 KiB block that IS the consumer's LDS A tile: bf16 hi plane
+    // [128][16] then lo plane, the 16-byte chunk of a row swapped when (row >> 3) & 1 (the W image's layout, gemm_f32_dma.hip).
+    // c_img: C is written that way (no residual, no statistics, rows % 128 == 0, Nout % 16 == 0);  a_img: A is read that way
+    // (no prologue; K % 16 == 0): contiguous 1 KiB DMA pieces instead of 64-byte row pieces, and no hi / lo split in the K loop.
+    int a_img, c_img;
 };
 
 struct SplitJob { const float* W; float* img; int Nout, K, ldw, pad_; };   // pad_ = 1 (fp16 images): the LOW part fp16(W - fp16(W)); 2: the same as fp8 x 2^19 in 64-k blocks
@@ -116,6 +122,9 @@ struct TnArgs {
     int group;
     float* colsum;     // optional (ceil(Z / group), N): column sums of A per group (the bias gradient), or null
 };
+// gemm_x3_areg.hip: split-bf16 GEMM whose A operand is a tiled split image loaded global -> registers (GemmArgs::a_img)
+bool gemm_x3_areg_supported(const GemmArgs& g);
+int gemm_x3_areg_launch(const GemmArgs& g, hipStream_t st);
 bool gemm_tn_x3_supported(const TnArgs& g);
 int gemm_tn_x3_launch(const TnArgs& g, hipStream_t st);
 

@@ -376,7 +376,9 @@ __global__ __launch_bounds__(MF_NT, 1) void unpool_outproj_f16_kernel(UnpoolProj
                 v4 += rres[set][it];
                 *reinterpret_cast<f32x4*>(xw + (size_t)(it * 4 + lr) * C + t * 128) = v4;   // default policy: the next kernel re-reads x (201 MB: Infinity Cache)
                 s1 += v4;
-                s2 += v4 * v4;
+                // explicit fma, as in dma::epilogue: the kernels sharing this store phase must agree to the bit on the statistics
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s2[q] = __builtin_fmaf(v4[q], v4[q], s2[q]);
             }
             if (g.stats) {
 #pragma unroll

@@ -441,10 +441,13 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
             ua.B = B; ua.rows = N; ua.H = H;
             TRY(unpool_outproj_f16_launch(ua, C, s), "unpool attention + out_proj");
         } else {
-            // mixed mode: fp16 q in, fp32 attention output (io16 = 2) = the operand of the split-bf16 out_proj
-            TRY(unpool_attn_launch(w.q, w.kvh, w.attn, B, N, C, H, I, s, apr, mixed ? 2 : (int)io16, hm), "unpool_attn");
+            // mixed mode: fp16 q in, fp32 attention output (io16 = 2) = the operand of the split-bf16 out_proj — handed over as
+            // a tiled split image where out_proj can load it straight into registers (gemm_x3_areg.hip)
+            const int aimg = pr == 1 && !a16 && im && option(OPT_ACTIMG) && I == 64 && attn_x3_supported(C / H) && N >= 128 &&
+                             N % 128 == 0 && C % 64 == 0;
+            TRY(unpool_attn_launch(w.q, w.kvh, w.attn, B, N, C, H, I, s, apr, mixed ? 2 : (int)io16, hm, aimg), "unpool_attn");
             TRY(linear(w.attn, L.unpool_out_w, L.unpool_out_b, nullptr, nullptr, nullptr, x, x, w.stats_x, B, N, C, C, 0, s, pr,
-                       w.wsplit, im ? im + w.o_out : nullptr, a16, 0), "unpool.out_proj+residual");
+                       w.wsplit, im ? im + w.o_out : nullptr, a16, 0, aimg, 0), "unpool.out_proj+residual");
         }
         // x += mlp(AdaGN(x))
         TRY(coeffs(w.stats_x, Tn, N, t, ctx, &L.mlp_norm, w.a2, w.o2, B, C, G, s), "adagn_coeffs(mlp_norm)");

@@ -419,11 +419,12 @@ int pool_attn_launch(const float* KV, const float* inducers, float* part_o, floa
 }
 
 int unpool_attn_launch(const float* q, const float* kvh, float* out, int B, int N, int C, int H, int I,
-                       hipStream_t st, int precision, int io16, int hm) {
+                       hipStream_t st, int precision, int io16, int hm, int out_img) {
     if (I != 64 || C % H) return -3;
     if (io16 && !(precision == 2 && attn_x3_supported(C / H))) return -9;
     if (hm && !io16) return -9;
-    if (precision >= 1 && attn_x3_supported(C / H)) return unpool_attn_x3_launch(q, kvh, out, B, N, C, H, st, precision, io16, hm);
+    if (out_img && !(precision >= 1 && attn_x3_supported(C / H))) return -9;
+    if (precision >= 1 && attn_x3_supported(C / H)) return unpool_attn_x3_launch(q, kvh, out, B, N, C, H, st, precision, io16, hm, out_img);
     switch (C / H) {
         case 8: return unpool_launch_t<8>(q, kvh, out, B, N, C, H, st);
         case 16: return unpool_launch_t<16>(q, kvh, out, B, N, C, H, st);

@@ -364,7 +364,7 @@ template <int HD, bool F16, bool IO16>
 __global__ __launch_bounds__(256, 2) void unpool_attn_x3_kernel(const float* __restrict__ q,
                                                              const float* __restrict__ kvh, float* __restrict__ out,
                                                              int B, int N, int C, int H, int tiles_per_wave,
-                                                             int nchunk, int hm, int out32) {   // out32 (IO16): fp32 output
+                                                             int nchunk, int hm, int out32) {   // out32: 1 (IO16) fp32 output; 2: tiled split image
     constexpr int KS = HD + 8;            // bf16 elements per K / Q row
     constexpr int VS = 64 + 8;            // bf16 elements per V^T row (64 permuted keys + pad)
     constexpr int DT = (HD + 31) / 32;
@@ -536,7 +536,27 @@ __global__ __launch_bounds__(256, 2) void unpool_attn_x3_kernel(const float* __r
                 }
             }
         wave_lds_sync();
-        if (IO16 && !out32) {
+        if (out32 == 2) {
+            // the output as the tiled split image a split-bf16 out_proj loads straight into registers (GemmArgs::a_img,
+            // gemm_x3_areg.hip): per (sample, 128-row tile, 16-k step) an 8 KiB block of bf16 hi | lo planes [128][16]
+            const int t128 = (N + 127) >> 7, nkc = C >> 4;
+            unsigned short* img = reinterpret_cast<unsigned short*>(out);
+#pragma unroll
+            for (int ld = 0; ld < LD8; ++ld) {
+                const int f = ld * 64 + lane, row = f / CH8, c8 = f % CH8, n = q0 + row;
+                if (f < 32 * CH8 && n < N) {
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(Ot + row * OP + c8 * 8);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(Ot + row * OP + c8 * 8 + 4);
+                    u32x4 hi, lo;
+                    split_acc8<false>(f32x16{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3], 0, 0, 0, 0, 0, 0, 0, 0}, 0, hi, lo);
+                    const int col = hh * HD + c8 * 8, ml = n & 127;
+                    unsigned short* dst = img + (((size_t)b * t128 + (n >> 7)) * nkc + (col >> 4)) * 4096 + ml * 16 +
+                                          ((((col & 15) >> 3) ^ ((ml >> 3) & 1)) << 3);
+                    *reinterpret_cast<u32x4*>(dst) = hi;
+                    *reinterpret_cast<u32x4*>(dst + 2048) = lo;
+                }
+            }
+        } else if (IO16 && !out32) {
 #pragma unroll
             for (int ld = 0; ld < LD8; ++ld) {
                 const int f = ld * 64 + lane, row = f / CH8, c8 = f % CH8, n = q0 + row;
@@ -626,15 +646,17 @@ int pool_attn_x3_partials_launch(const float* KV, const float* inducers, float* 
 }
 
 int unpool_attn_x3_launch(const float* q, const float* kvh, float* out, int B, int N, int C, int H, hipStream_t st,
-                          int precision, int io16, int hm) {
+                          int precision, int io16, int hm, int out_img) {
     if (io16 && precision != 2) return -9;
     if (hm && !io16) return -9;
-    const int out32 = io16 == 2;   // io16 = 2: q is an fp16 tensor, the output stays fp32 (operand of a split-bf16 out_proj)
+    if (out_img && (C % 16 || (io16 && io16 != 2))) return -9;
+    // io16 = 2: q is an fp16 tensor, the output stays fp32 (operand of a split-bf16 out_proj); out_img: as a tiled split image
+    const int out32 = out_img ? 2 : io16 == 2;
 #define UNPOOL_CASE(HD)                                                                                \
     case HD:                                                                                           \
         return io16 ? unpool_x3_launch_t<HD, true, true>(q, kvh, out, B, N, C, H, st, hm, out32)       \
                : precision == 2 ? unpool_x3_launch_t<HD, true, false>(q, kvh, out, B, N, C, H, st, 0)  \
-                                : unpool_x3_launch_t<HD, false, false>(q, kvh, out, B, N, C, H, st, 0)
+                                : unpool_x3_launch_t<HD, false, false>(q, kvh, out, B, N, C, H, st, 0, out_img ? 2 : 0)
     switch (C / H) {
         UNPOOL_CASE(16);
         UNPOOL_CASE(32);

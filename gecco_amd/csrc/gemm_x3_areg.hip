@@ -168,14 +168,17 @@ int areg_launch_t(const GemmArgs& g, hipStream_t st) {
 
 bool gemm_x3_areg_supported(const GemmArgs& g) {
     return g.a_img && g.precision == 1 && g.w_img && !g.pro_a && !g.C2 && !g.c_img && g.rows >= 128 && g.rows % 128 == 0 &&
-           (g.K == 256 || g.K == 512 || g.K == 768 || g.K == 1024) && !(g.Nout & 3) && !(g.ldc & 3) && !(g.ldr & 3);   // mlp.2: K = 2 d
+           (g.K == 128 || g.K == 256 || g.K == 384 || g.K == 512 || g.K == 768 || g.K == 1024) && !(g.Nout & 3) &&
+           !(g.ldc & 3) && !(g.ldr & 3);   // out_proj: K = d; mlp.2: K = 2 d
 }
 
 int gemm_x3_areg_launch(const GemmArgs& g, hipStream_t st) {
     if (!gemm_x3_areg_supported(g)) return -9;
     const bool tall = g.rows >= 256;
     switch (g.K) {
+        case 128: return areg_launch_t<128, 4, 8>(g, st);
         case 256: return areg_launch_t<128, 4, 16>(g, st);
+        case 384: return areg_launch_t<128, 4, 24>(g, st);
         case 512: return tall ? areg_launch_t<256, 4, 32>(g, st) : areg_launch_t<128, 4, 32>(g, st);
         case 768: return tall ? areg_launch_t<256, 4, 48>(g, st) : areg_launch_t<128, 4, 48>(g, st);
         case 1024: return tall ? areg_launch_t<256, 4, 64>(g, st) : areg_launch_t<128, 4, 64>(g, st);

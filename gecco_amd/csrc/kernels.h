@@ -176,7 +176,7 @@ int pool_attn_launch(const float* KV, const float* inducers, float* part_o, floa
                      int hm = 0);   // hm (with io16): K | V / q are head-major (GemmArgs::hm_hd)
 int pool_attn_nsplit(int B, int N, int H);
 int unpool_attn_launch(const float* q, const float* kvh, float* out, int B, int N, int C, int H, int I,
-                       hipStream_t st, int precision = 0, int io16 = 0, int hm = 0);
+                       hipStream_t st, int precision = 0, int io16 = 0, int hm = 0, int out_img = 0);   // out_img: GemmArgs::a_img layout
 // attention_bwd_f32.hip (training path)
 int pool_attn_lse_launch(const float* part_ml, float* lse, int B, int H, int nsplit, hipStream_t st);
 int pool_attn_bwd_nsplit(int B, int N, int H);
@@ -197,7 +197,7 @@ bool attn_x3_supported(int HD);
 int pool_attn_x3_partials_launch(const float* KV, const float* inducers, float* part_o, float* part_ml, int B, int N,
                                  int C, int H, int nsplit, hipStream_t st, int precision, int io16 = 0, int hm = 0);   // 1 split-bf16, 2 fp16
 int unpool_attn_x3_launch(const float* q, const float* kvh, float* out, int B, int N, int C, int H, hipStream_t st,
-                          int precision, int io16 = 0, int hm = 0);   // io16: KV / q / out are fp16 tensors (fp16 mode)
+                          int precision, int io16 = 0, int hm = 0, int out_img = 0);   // io16: KV / q / out are fp16 tensors (fp16 mode)
 
 // lookup.hip
 struct LookupArgs {

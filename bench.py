@@ -636,7 +636,27 @@ def main():
                                "timing": "HIP events around hipGraph replays of the three-launch round (kernel launches only, weight "
                                          "images prepared); a launch's duration = plain round - round without that launch",
                                "per_site": per}
-        elif mode in ("bf16x3", "mixed"):
+        elif mode == "mixed":
+            # The dominant kernel of the mixed mode is mlp.0 (AdaGN prologue + split-bf16 product + GaussianActivation, 27 % of
+            # the device time): 3 MFMAs per product -> matrix roof 2500 / 3 TFLOP/s of 2MNK; 77.3 GFLOP over 604 MB = 128 FLOP/B,
+            # above that roof's ridge of 104.  out_proj and mlp.2 run on the register-fed kernel (gemm_x3_areg.hip) whose A
+            # operand is an image only a producer epilogue writes: they cannot be launched stand-alone from here — their
+            # durations are in profiles/*_kernel_stats.csv; the stand-alone LDS-DMA forms are listed in per_site for scale.
+            mk = "mlp.0+act"
+            mtf = per[mk]["tflops"]
+            mb = [by for name, fl, by, fn in sites if name == mk][0]
+            traffic = json.load(open(tj)).get("mixed", {}).get("bytes_per_launch") if os.path.exists(tj) else None
+            rec["roofline"] = {"bound": "mfma", "achieved": mtf, "peak": PEAK_BF16_MFMA_TFLOPS / 3, "unit": "TFLOP/s",
+                               "frac": 3 * mtf / PEAK_BF16_MFMA_TFLOPS, "traffic": traffic,
+                               "kernel": "gemm_dma_kernel<3,true,true,128> = mlp.0 (LDS-DMA ring, AdaGN prologue on the A fragment, "
+                                         "3 x v_mfma_f32_32x32x16_bf16 per product, GaussianActivation epilogue); achieved = 2MNK / "
+                                         "event-timed duration of the stand-alone launch, peak = dense bf16 MFMA peak (2500 TFLOP/s) "
+                                         "/ 3 MFMAs per product; traffic = FETCH_SIZE x 2 + WRITE_SIZE of that kernel in the forward "
+                                         "(profiles/r02m_forward_pmc_summary.txt: a committed constant, not measured in this run)",
+                               "hbm": {"achieved_gbs_algorithmic": mb / (per[mk]["ms"] * 1e-3) / 1e9, "peak_gbs": PEAK_HBM_GBS,
+                                       "frac": mb / (per[mk]["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS},
+                               "per_site": per}
+        elif mode == "bf16x3":
             # The split-bf16 algorithm issues 3 MFMAs per product, so its matrix roof is the dense bf16 peak / 3 =
             # 833 TFLOP/s of 2MNK work.  The launches run at 96..192 FLOP/B (2MNK over fp32 A/residual/C bytes): at or
             # above the ridge of that roof (833 TF / 8 TB/s = 104 FLOP/B), and the PMC counters agree — the matrix

@@ -91,8 +91,11 @@ int gecco_linear_f32(const float* A, const float* W, const float* bias, const fl
  *   (needs "headmajor").
  *   "lo8" (default 1): mixed mode streams the second term of the V projection's two-term weights as fp8 (e4m3, x 2^19) on
  *   v_mfma_scale_f32_32x32x64_f8f6f4 (d = 256, 384) instead of as fp16: same result to ~1e-6 of the output.
+ *   "actimg" (default 1): split-bf16 / mixed modes hand the MLP hidden layer and the unpool attention output to the next
+ *   GEMM as tiled split images (bf16 hi | lo planes in 8 KiB blocks, same bytes as the fp32 tensor) which that GEMM loads
+ *   global -> registers (gemm_x3_areg.hip): same bits as the fp32 hand-over.
  * value < 0 returns the option to its default / environment (GECCO_ASTAT, GECCO_CHAIN, GECCO_HEADMAJOR, GECCO_MLPFUSED,
- * GECCO_UNPOOLFUSED, GECCO_LO8).
+ * GECCO_UNPOOLFUSED, GECCO_LO8, GECCO_ACTIMG).
  * Process-wide. */
 int gecco_set_option(const char* name, int value);
 

@@ -256,6 +256,24 @@ def test_mixed_fp8_lo_term_matches_fp16_lo_term(ops, golden_dir, name):
         assert not torch.equal(out[0], out[1]), "the fp8 form did not run"
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "mixed"])
+@pytest.mark.parametrize("name", list(cases.UNCOND_CASES))
+def test_activation_images_are_bit_identical(ops, golden_dir, name, precision):
+    """Split-bf16 / mixed modes: the MLP hidden layer and the unpool attention output handed to the next GEMM as tiled split
+    images and loaded global -> registers there (option "actimg", gemm_x3_areg.hip) against the fp32 hand-over through the LDS
+    ring: the same hi / lo values reach the same matrix instructions in the same order — same bits."""
+    p, x, sigma = cases.uncond_inputs(name)
+    net = ops.LinearLiftPlan(_cuda(p), cases.H, cases.I, precision=precision)
+    out = {}
+    try:
+        for on in (0, 1):
+            ops.set_option("actimg", on)
+            out[on] = net.forward(x.cuda(), sigma.cuda()).cpu()
+    finally:
+        ops.set_option("actimg", -1)
+    assert torch.equal(out[0], out[1])
+
+
 def test_split_bf16_linear_accuracy(ops):
     """The split itself: products with operands spanning 8 orders of magnitude keep ~2^-16 relative accuracy."""
     import ctypes as C

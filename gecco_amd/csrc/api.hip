@@ -234,8 +234,12 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
     // K | V / q and fp16 attention products; everything that feeds the residual stream or the shared inducer states
     // (pool.out_proj .. unpool k|v on the 64 inducers, unpool.out_proj, the point MLP) in split-bf16 arithmetic.
     // tools/experiments/fp16_site_sensitivity.py: those are the products whose operand rounding reaches the output.
-    const bool mixed = st->precision == 3;
-    const int pr = mixed ? 1 : st->precision;       // arithmetic of the generic linears
+    // Shapes the A-stationary kv_proj | q_proj kernel does not take (rows not a multiple of 128, C outside 128 .. 512 in steps
+    // of 128, head dims the fp16 attention kernels do not have) run the whole evaluation in split-bf16 — at least as
+    // accurate, slower — instead of failing: a drop-in caller's N need not be a multiple of 128.
+    const bool mixed = st->precision == 3 && N >= 128 && N % 128 == 0 && C % 128 == 0 && C <= 512 && !(C % H) &&
+                       attn_x3_supported(C / H) && st->I == 64 && option(OPT_ASTAT);
+    const int pr = mixed ? 1 : (st->precision == 3 ? 1 : st->precision);       // arithmetic of the generic linears
     const int Tn = row_tiles_gemm(N), Ti = row_tiles_gemm(I);
     const int ns = pool_attn_nsplit(B, N, H);
 

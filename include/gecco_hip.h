@@ -68,7 +68,8 @@ typedef struct GeccoSetTransformer {  /* SetTransformer, models/set_transformer.
                      * 2 fp16 operands (round to nearest even), fp32 accumulate, fp16-stored intermediates (D ~4e-4, F_x ~1e-3),
                      * 3 "mixed": kv_proj | q_proj with fp16 activations and two-term fp16 weights, fp16 K | V / q and attention
                      *   products; every product that feeds the residual stream or the shared inducer states (the 64-inducer
-                     *   chain, unpool.out_proj, the point MLP) in split-bf16 (~6e-5 on both outputs) */
+                     *   chain, unpool.out_proj, the point MLP) in split-bf16 (~6e-5 on both outputs); point counts that are
+                     *   not a multiple of 128 (and widths / head dims outside the fp16 kernels' set) run as mode 1 */
     const GeccoLayer* layers;                       /* HOST array of n_layers tables */
 } GeccoSetTransformer;
 

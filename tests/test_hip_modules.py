@@ -264,7 +264,7 @@ def test_graphed_forward_replays_the_eager_bits():
         assert torch.equal(run(x2, s2), m(x2, s2, None))
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16x3", 2e-4), ("fp16", 1e-3)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16x3", 2e-4), ("mixed", 2e-4), ("fp16", 1e-3)])
 @pytest.mark.parametrize("name", list(cases.COND_CASES))
 def test_conditional_diffusion_golden(golden_dir, name, precision, tol):
     from gecco_amd import hip_ops
@@ -304,7 +304,7 @@ def test_conditional_diffusion_golden(golden_dir, name, precision, tol):
 
 
 # ------------------------------------------------------------------------------------------- nn.ReLU (reference default)
-@pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16x3", 2e-4), ("fp16", 1e-3)])
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16x3", 2e-4), ("mixed", 2e-4), ("fp16", 1e-3)])
 def test_default_relu_activation_golden(golden_dir, precision, tol):
     """The reference's DEFAULT `activation=nn.ReLU` (models/mlp.py:12, set_transformer.py:81,133): module API with the
     argument left out, state dict without alpha entries, fused path (epilogue code 3) in every arithmetic mode, against

@@ -76,11 +76,13 @@ def test_cached_mode_golden(ops, golden_dir, precision, tol):
     print("cached", precision, "cache", e, "out_new", e2)
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16x3", 2e-4), ("fp16", 1e-3)])
-@pytest.mark.parametrize("B,N,d,L", [(3, 333, 128, 2), (2, 2048, 384, 1), (1, 4096, 512, 1), (2, 100, 64, 3), (2, 130, 256, 1)])
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16x3", 2e-4), ("mixed", 2e-4), ("fp16", 1e-3)])
+@pytest.mark.parametrize("B,N,d,L", [(3, 333, 128, 2), (2, 2048, 384, 1), (1, 4096, 512, 1), (2, 100, 64, 3), (2, 130, 256, 1),
+                                     (2, 384, 384, 2), (1, 640, 512, 1), (3, 128, 256, 2)])
 def test_uncond_vs_oracle_ragged(ops, B, N, d, L, precision, tol):
     """Sizes the golden set does not hold (ragged N, d=512, N=4096, head dim 8 that stays on the fp32 attention
-    kernels, rows < 128), oracle computed on the fly, every arithmetic mode."""
+    kernels, rows < 128; N = 128, 384, 640: an odd number of 128-row tiles under the 256-row tiles and the activation
+    images), oracle computed on the fly, every arithmetic mode."""
     from oracle import weights as W
     p = W.linear_lift_state_dict(77 + N, d, L, cases.I, cases.H)
     x, sigma = W.synthetic_cloud(N, B, N)
@@ -91,7 +93,7 @@ def test_uncond_vs_oracle_ragged(ops, B, N, d, L, precision, tol):
     _close(raw, raw_ref, tol)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "fp16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "mixed", "fp16"])
 def test_full_size_properties(ops, precision):
     """BASELINE config C2 (B=64, N=2048, d=384, L=6) is too slow for the CPU oracle inside a test, so
     check size-independent properties: (1) samples are independent — evaluating a batch equals
@@ -110,7 +112,7 @@ def test_full_size_properties(ops, precision):
     assert torch.equal(full, torch.cat([lo, hi]))
     perm = torch.randperm(N, device="cuda")
     full_p = net.forward(x[:4, perm].contiguous(), sigma[:4].contiguous())
-    _close(full_p, full[:4, perm].cpu(), {"fp32": 1e-4, "bf16x3": 2e-4, "fp16": 2e-3}[precision])
+    _close(full_p, full[:4, perm].cpu(), {"fp32": 1e-4, "bf16x3": 2e-4, "mixed": 4e-4, "fp16": 2e-3}[precision])
     if precision != "fp32":   # and the mode stays inside the parity bar at full size (against the exact-fp32 mode)
         exact = ops.LinearLiftPlan(p, cases.H, cases.I, precision="fp32").forward(x[:8].contiguous(), sigma[:8].contiguous())
         e = cpu_ref.rel_err(full[:8].cpu(), exact.cpu())

@@ -74,59 +74,102 @@ __global__ __launch_bounds__(256) void stem_conv_ln_kernel(const float* __restri
     }
 }
 
-// ---- depthwise 7 x 7 (padding 3) + bias + LayerNorm over channels, channels-last.  TPP = C / 4 threads per texel (one
-// 16-byte channel chunk each), weight (C, 1, 7, 7) read as w[c][tap].
+// ---- depthwise 7 x 7 (padding 3) + bias + LayerNorm over channels, channels-last.
+// A thread owns one 16-byte channel chunk of a GROUP of TX = 4 texels adjacent in W: a row of the window needs 10 texel
+// loads for the four outputs instead of 28, and one weight read per tap serves four texels.  The weights (C, 1, 7, 7) are
+// given TAP-MAJOR, (49, C) = weight.reshape(C, 49).T, and staged once per block in LDS (a tap's 4 channels are one 16-byte
+// read, the same address for every group of the block — a broadcast); a block walks `iters` batches of 256 / (C / 4) groups
+// to amortise that.  (The first form read w[c][tap] — four strided scalar loads per tap and texel — and ran 40x off the HBM
+// floor of the layer.)
 template <int C>
 __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, const float* __restrict__ ln_w,
                                                          const float* __restrict__ ln_b, float* __restrict__ out, int B, int H,
-                                                         int W, float eps) {
-    constexpr int TPP = C / 4, PIX = 256 / TPP;
-    __shared__ float red[2][256];
-    const int pl = threadIdx.x / TPP, t = threadIdx.x % TPP;
-    const size_t npix = (size_t)B * H * W;
-    const size_t p = (size_t)blockIdx.x * PIX + pl;
-    const bool live = pl < PIX && p < npix;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const int c = 4 * t;
-    if (live) {
-        const int wx = (int)(p % W), hy = (int)((p / W) % H), b = (int)(p / ((size_t)W * H));
-        acc = *reinterpret_cast<const f32x4*>(bias + c);
-        const float* xb = x + (size_t)b * H * W * C;
-#pragma unroll 1
-        for (int dy = -3; dy <= 3; ++dy) {
-            const int yy = hy + dy;
-            if (yy < 0 || yy >= H) continue;
+                                                         int W, float eps, int iters) {
+    constexpr int TPP = C / 4, PG = 256 / TPP, TX = 4, NPART = 4;
+    static_assert(TPP % NPART == 0, "the LayerNorm partial sums split a group's threads in four");
+    extern __shared__ __attribute__((aligned(16))) float cs[];
+    float* wl = cs;                       // [49][C]
+    float* red = wl + 49 * C;             // [TX][256] per-thread partials
+    float* part = red + TX * 256;         // [PG][TX][NPART]
+    const int pg = threadIdx.x / TPP, t = threadIdx.x % TPP, c = 4 * t;
+    for (int i = threadIdx.x; i < 49 * C / 4; i += 256)   // w arrives tap-major (49, C): a coalesced copy
+        reinterpret_cast<f32x4*>(wl)[i] = reinterpret_cast<const f32x4*>(w)[i];
+    const f32x4 bias4 = pg < PG ? *reinterpret_cast<const f32x4*>(bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 g4 = pg < PG ? *reinterpret_cast<const f32x4*>(ln_w + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 b4 = pg < PG ? *reinterpret_cast<const f32x4*>(ln_b + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int GR = (W + TX - 1) / TX;     // groups per image row
+    const size_t ngroups = (size_t)B * H * GR;
+    __syncthreads();
+    for (int it = 0; it < iters; ++it) {
+        const size_t gid = ((size_t)blockIdx.x * iters + it) * PG + pg;
+        const bool live = pg < PG && gid < ngroups;
+        f32x4 acc[TX];
 #pragma unroll
-            for (int dx = -3; dx <= 3; ++dx) {
-                const int xx = wx + dx;
-                if (xx < 0 || xx >= W) continue;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(xb + ((size_t)yy * W + xx) * C + c);
-                const int tap = (dy + 3) * 7 + dx + 3;
-                acc[0] += v[0] * w[(c + 0) * 49 + tap];
-                acc[1] += v[1] * w[(c + 1) * 49 + tap];
-                acc[2] += v[2] * w[(c + 2) * 49 + tap];
-                acc[3] += v[3] * w[(c + 3) * 49 + tap];
+        for (int tx = 0; tx < TX; ++tx) acc[tx] = bias4;
+        int wx0 = 0, hy = 0, b = 0;
+        if (live) {
+            wx0 = (int)(gid % GR) * TX;
+            hy = (int)((gid / GR) % H);
+            b = (int)(gid / ((size_t)GR * H));
+            const float* xb = x + (size_t)b * H * W * C + c;
+#pragma unroll 1
+            for (int dy = -3; dy <= 3; ++dy) {
+                const int yy = hy + dy;
+                if (yy < 0 || yy >= H) continue;
+                const float* xr = xb + (size_t)yy * W * C;
+                f32x4 xv[TX + 6];
+#pragma unroll
+                for (int j = 0; j < TX + 6; ++j) {
+                    const int xx = wx0 - 3 + j;
+                    xv[j] = (xx >= 0 && xx < W) ? *reinterpret_cast<const f32x4*>(xr + (size_t)xx * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                const float* wr = wl + (dy + 3) * 7 * C + c;
+#pragma unroll
+                for (int dx = 0; dx < 7; ++dx) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + dx * C);
+#pragma unroll
+                    for (int tx = 0; tx < TX; ++tx) acc[tx] += xv[tx + dx] * wv;
+                }
             }
         }
-    }
-    // LayerNorm over the texel's C channels: two passes through LDS partials (mean, then centred variance)
-    red[0][threadIdx.x] = acc[0] + acc[1] + acc[2] + acc[3];
-    __syncthreads();
-    float s1 = 0.f;
-    if (pl < PIX)
-        for (int i = 0; i < TPP; ++i) s1 += red[0][pl * TPP + i];
-    const float mean = s1 / C;
-    f32x4 d = acc - mean;
-    red[1][threadIdx.x] = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
-    __syncthreads();
-    float s2 = 0.f;
-    if (pl < PIX)
-        for (int i = 0; i < TPP; ++i) s2 += red[1][pl * TPP + i];
-    const float rstd = rsqrtf(s2 / C + eps);
-    if (live) {
-        const f32x4 g4 = *reinterpret_cast<const f32x4*>(ln_w + c), b4 = *reinterpret_cast<const f32x4*>(ln_b + c);
-        *reinterpret_cast<f32x4*>(out + p * C + c) = d * rstd * g4 + b4;
+        // LayerNorm over each texel's C channels, two passes (mean, centred variance): per-thread partials in LDS, four
+        // threads per (group, texel) add a quarter of them each, everyone combines the four quarters
+        float mean[TX], rstd[TX];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int tx = 0; tx < TX; ++tx) {
+                f32x4 d = acc[tx];
+                if (pass == 1) { d = d - mean[tx]; d = d * d; }
+                red[tx * 256 + threadIdx.x] = d[0] + d[1] + d[2] + d[3];
+            }
+            __syncthreads();
+            if (pg < PG && t < TX * NPART) {
+                const int tx = t % TX, pt = t / TX;
+                float s = 0.f;
+                const float* rp = red + tx * 256 + pg * TPP + pt * (TPP / NPART);
+#pragma unroll 4
+                for (int i = 0; i < TPP / NPART; ++i) s += rp[i];
+                part[(pg * TX + tx) * NPART + pt] = s;
+            }
+            __syncthreads();
+            if (pg < PG) {
+#pragma unroll
+                for (int tx = 0; tx < TX; ++tx) {
+                    const f32x4 q = *reinterpret_cast<const f32x4*>(part + (pg * TX + tx) * NPART);
+                    const float s = ((q[0] + q[1]) + q[2]) + q[3];
+                    if (pass == 0) mean[tx] = s / C;
+                    else rstd[tx] = rsqrtf(s / C + eps);
+                }
+            }
+        }
+        if (live) {
+            float* op = out + (((size_t)b * H + hy) * W + wx0) * C + c;
+#pragma unroll
+            for (int tx = 0; tx < TX; ++tx)
+                if (wx0 + tx < W) *reinterpret_cast<f32x4*>(op + (size_t)tx * C) = (acc[tx] - mean[tx]) * rstd[tx] * g4 + b4;
+        }
     }
 }
 
@@ -195,9 +238,31 @@ int cnx_stem_launch(const float* x, const float* w, const float* bias, const flo
 }
 int cnx_dwconv_ln_launch(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b, float* out, int B,
                          int H, int W, int C, float eps, hipStream_t st) {
-    const int pix = 256 / (C / 4);
-    const dim3 grid((unsigned)(((size_t)B * H * W + pix - 1) / pix));
-    CNX_DISPATCH(dwconv7_ln_kernel, C, grid, x, w, bias, ln_w, ln_b, out, B, H, W, eps);
+    if (C != 96 && C != 192 && C != 384) return -9;
+    const int pg = 256 / (C / 4);
+    const size_t ngroups = (size_t)B * H * ((W + 3) / 4), batches = (ngroups + pg - 1) / pg;
+    // a block stages 49 C weights: enough batches per block to amortise that, enough blocks to fill the chip
+    int iters = 1;
+    while (iters < 16 && batches / (iters * 2) >= 512) iters *= 2;
+    const unsigned grid = (unsigned)((batches + iters - 1) / iters);
+    const size_t lds = (size_t)(49 * C + 4 * 256 + pg * 4 * 4) * sizeof(float);
+#define CNX_DW(CV)                                                                                                          \
+    case CV: {                                                                                                              \
+        static bool attr = false;                                                                                           \
+        if (!attr) {                                                                                                        \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv7_ln_kernel<CV>),                                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
+            attr = true;                                                                                                    \
+        }                                                                                                                   \
+        hipLaunchKernelGGL((dwconv7_ln_kernel<CV>), dim3(grid), dim3(256), lds, st, x, w, bias, ln_w, ln_b, out, B, H, W, eps, iters); \
+        break;                                                                                                              \
+    }
+    switch (C) {
+        CNX_DW(96)
+        CNX_DW(192)
+        CNX_DW(384)
+    }
+#undef CNX_DW
     return (int)hipGetLastError();
 }
 int cnx_ln_patch2_launch(const float* x, const float* ln_w, const float* ln_b, float* out, int B, int H, int W, int C, float eps,

@@ -122,7 +122,8 @@ class ConvNeXtExtractor(FeaturePyramidExtractor):
             for blk in blocks:
                 dw, ln, pw1, pw2 = blk.block[0], blk.block[2], blk.block[3], blk.block[5]
                 y = torch.empty_like(x)
-                _lib.check(lib.gecco_convnext_dwconv_ln_f32(_ptr(x), _ptr(dw.weight), _ptr(dw.bias), _ptr(ln.weight), _ptr(ln.bias),
+                w_tap = dw.weight.reshape(C, 49).t().contiguous()   # tap-major (49, C): what the kernel stages in LDS
+                _lib.check(lib.gecco_convnext_dwconv_ln_f32(_ptr(x), _ptr(w_tap), _ptr(dw.bias), _ptr(ln.weight), _ptr(ln.bias),
                                                             _ptr(y), B, h, w, C, LN_EPS, _stream()), "gecco_convnext_dwconv_ln_f32")
                 hid = hip_ops.linear(y.view(1, rows, C), pw1.weight, pw1.bias, act="gelu", precision=self._precision())
                 w2 = torch.empty_like(pw2.weight)

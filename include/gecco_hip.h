@@ -463,7 +463,9 @@ int gecco_sinkhorn_f32(const float* C, float* f, float* g, float* rowcost, float
 /* stem: out = LayerNorm_C(Conv2d(3 -> C, k4, s4)(x) + bias); x NCHW (B, 3, H, W), w (C, 3, 4, 4), out (B, H/4, W/4, C); C == 96 */
 int gecco_convnext_stem_f32(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b, float* out,
                             int B, int H, int W, int C, float eps, void* stream);
-/* CNBlock front half: out = LayerNorm_C(dwconv7x7(x, padding 3) + bias); w (C, 1, 7, 7); C in {96, 192, 384} */
+/* CNBlock front half: out = LayerNorm_C(dwconv7x7(x, padding 3) + bias); w TAP-MAJOR (49, C) = the module's weight
+ * (C, 1, 7, 7) reshaped to (C, 49) and transposed (a re-layout of 19 .. 75 KB of parameters, like the 2 x 2 downsample
+ * weight's); C in {96, 192, 384} */
 int gecco_convnext_dwconv_ln_f32(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b, float* out,
                                  int B, int H, int W, int C, float eps, void* stream);
 /* downsample front half: LayerNorm_C per texel, written as the 2 x 2 stride-2 conv's GEMM operand (B, H/2, W/2, (dy, dx, c)) */

@@ -372,7 +372,7 @@ int dma_launch_aimg(const GemmArgs& g, hipStream_t st) {
 template <int DNS, bool X3, int BM = 128>
 int dma_launch_t(const GemmArgs& g, hipStream_t st) {
     const int tilesM = (g.rows + BM - 1) / BM, tilesN = (g.Nout + DBN - 1) / DBN;
-    const size_t lds = (size_t)(d_main_floats(DNS, BM) + 2 * g.K) * sizeof(float);
+    const size_t lds = (size_t)(d_main_floats(DNS, BM) + (g.pro_a ? 2 * g.K : 0)) * sizeof(float);
     static size_t attr = 0;
     if (lds > attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma_kernel<DNS, true, X3, BM>),
@@ -393,7 +393,9 @@ bool gemm_f32_dma_supported(const GemmArgs& g, int precision) {
     if (precision < 0) precision = g.precision;
     if (g.C2 && ((g.n_split % DBN) || g.stats || g.residual || (g.ldc2 & 3) || g.n_split <= 0 || g.n_split >= g.Nout))
         return false;
-    return g.rows >= (precision == 1 ? 64 : 128) && g.K % DBK == 0 && g.K <= 1024 && !(g.Nout & 3) && !(g.ldc & 3) && !(g.ldr & 3) &&
+    // K <= 1024 with the AdaGN prologue (its coefficients are parked in LDS: 8 K bytes); without it up to 2048 (the ConvNeXt
+    // conditioner's 4 C -> C linears at C = 384: K = 1536)
+    return g.rows >= (precision == 1 ? 64 : 128) && g.K % DBK == 0 && g.K <= (g.pro_a ? 1024 : 2048) && !(g.Nout & 3) && !(g.ldc & 3) && !(g.ldr & 3) &&
            !(g.lda & 3) && !(g.ldw & 7);
 }
 

@@ -20,26 +20,27 @@ __device__ __forceinline__ float pair_dist(float ax, float ay, float az, float a
     return squared ? d2 : sqrtf(d2);
 }
 
-// D[b, i, j] = dist(a[b, i], b[b, j])
+// D[b, i, j] = dist(a[b, i], b[b, j]): a 256 x 256 tile per block, the thread owns COLUMN j (its b point in registers) and walks
+// the tile's a points in LDS (a broadcast read): every store instruction writes 256 consecutive floats of a row
 __global__ __launch_bounds__(256) void dist_matrix_kernel(const float* __restrict__ A, const float* __restrict__ Bp,
                                                           float* __restrict__ D, int N, int M, int squared) {
-    __shared__ float sb[256 * 4];
-    const int b = blockIdx.z, i = blockIdx.y * 256 + threadIdx.x;
-    const float* a = A + ((size_t)b * N + min(i, N - 1)) * 3;
-    const float ax = a[0], ay = a[1], az = a[2], aa = ax * ax + ay * ay + az * az;
-    const int j0 = blockIdx.x * 256;
+    __shared__ float sa[256 * 4];
+    const int b = blockIdx.z, i0 = blockIdx.y * 256, j = blockIdx.x * 256 + threadIdx.x;
     {
-        const int j = j0 + threadIdx.x;
-        const float* q = Bp + ((size_t)b * M + min(j, M - 1)) * 3;
-        const float bx = q[0], by = q[1], bz = q[2];
-        sb[threadIdx.x * 4 + 0] = bx; sb[threadIdx.x * 4 + 1] = by; sb[threadIdx.x * 4 + 2] = bz;
-        sb[threadIdx.x * 4 + 3] = bx * bx + by * by + bz * bz;
+        const int i = i0 + threadIdx.x;
+        const float* a = A + ((size_t)b * N + min(i, N - 1)) * 3;
+        const float ax = a[0], ay = a[1], az = a[2];
+        sa[threadIdx.x * 4 + 0] = ax; sa[threadIdx.x * 4 + 1] = ay; sa[threadIdx.x * 4 + 2] = az;
+        sa[threadIdx.x * 4 + 3] = ax * ax + ay * ay + az * az;
     }
+    const float* q = Bp + ((size_t)b * M + min(j, M - 1)) * 3;
+    const float bx = q[0], by = q[1], bz = q[2], bb = bx * bx + by * by + bz * bz;
     __syncthreads();
-    if (i >= N) return;
-    float* drow = D + ((size_t)b * N + i) * M + j0;
-    const int jn = min(256, M - j0);
-    for (int j = 0; j < jn; ++j) drow[j] = pair_dist(ax, ay, az, aa, sb[j * 4], sb[j * 4 + 1], sb[j * 4 + 2], sb[j * 4 + 3], squared != 0);
+    if (j >= M) return;
+    float* dcol = D + ((size_t)b * N + i0) * M + j;
+    const int in = min(256, N - i0);
+    for (int i = 0; i < in; ++i)
+        dcol[(size_t)i * M] = pair_dist(sa[i * 4], sa[i * 4 + 1], sa[i * 4 + 2], sa[i * 4 + 3], bx, by, bz, bb, squared != 0);
 }
 
 // mins[b, i] = min_j dist(a[b, i], b[b, j]) — one thread per a-point, the b cloud streamed through LDS in tiles
@@ -96,12 +97,18 @@ __global__ __launch_bounds__(256) void sinkhorn_rows_kernel(const float* __restr
     const float* c = C + ((size_t)b * N + i) * M;
     const float* gb = g + (size_t)b * M;
     const float inv = 1.f / eps;
-    float mx = -3.0e38f;
-    for (int j = lane; j < M; j += 64) mx = fmaxf(mx, (gb[j] - c[j]) * inv);
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    float s = 0.f;
-    for (int j = lane; j < M; j += 64) s += __expf((gb[j] - c[j]) * inv - mx);
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    // one pass over the row: per-lane running (max, sum), merged across the wave in a fixed butterfly
+    float mx = -3.0e38f, s = 0.f;
+    for (int j = lane; j < M; j += 64) {
+        const float v = (gb[j] - c[j]) * inv, mn = fmaxf(mx, v);
+        s = s * __expf(mx - mn) + __expf(v - mn);
+        mx = mn;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(mx, o, 64), os = __shfl_xor(s, o, 64), mn = fmaxf(mx, om);
+        s = s * __expf(mx - mn) + os * __expf(om - mn);
+        mx = mn;
+    }
     if (lane == 0) f[(size_t)b * N + i] = -eps * (mx + __logf(s) + logw);
 }
 __global__ __launch_bounds__(256) void sinkhorn_cols_kernel(const float* __restrict__ C, const float* __restrict__ f, float* __restrict__ g,
@@ -111,11 +118,29 @@ __global__ __launch_bounds__(256) void sinkhorn_cols_kernel(const float* __restr
     const float* c = C + (size_t)b * N * M + j;
     const float* fb = f + (size_t)b * N;
     const float inv = 1.f / eps;
-    float mx = -3.0e38f;
-    for (int i = 0; i < N; ++i) mx = fmaxf(mx, (fb[i] - c[(size_t)i * M]) * inv);
-    float s = 0.f;
-    for (int i = 0; i < N; ++i) s += __expf((fb[i] - c[(size_t)i * M]) * inv - mx);
-    g[(size_t)b * M + j] = -eps * (mx + __logf(s) + logw);
+    // one pass down the column, four independent (max, sum) chains so that loads of consecutive rows are in flight together
+    float mx[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f}, s[4] = {0.f, 0.f, 0.f, 0.f};
+    int i = 0;
+    for (; i + 4 <= N; i += 4) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (fb[i + u] - c[(size_t)(i + u) * M]) * inv;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float mn = fmaxf(mx[u], v[u]);
+            s[u] = s[u] * __expf(mx[u] - mn) + __expf(v[u] - mn);
+            mx[u] = mn;
+        }
+    }
+    for (; i < N; ++i) {
+        const float v = (fb[i] - c[(size_t)i * M]) * inv, mn = fmaxf(mx[0], v);
+        s[0] = s[0] * __expf(mx[0] - mn) + __expf(v - mn);
+        mx[0] = mn;
+    }
+    float M4 = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3])), S4 = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) S4 += s[u] * __expf(mx[u] - M4);
+    g[(size_t)b * M + j] = -eps * (M4 + __logf(S4) + logw);
 }
 // rowcost[b, i] = sum_j P_ij C_ij with P_ij = exp((f_i + g_j - C_ij) / eps) / (N M)
 __global__ __launch_bounds__(256) void sinkhorn_cost_kernel(const float* __restrict__ C, const float* __restrict__ f, const float* __restrict__ g,

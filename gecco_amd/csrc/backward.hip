@@ -217,26 +217,42 @@ __global__ __launch_bounds__(256) void affine2_apply_kernel(const float* __restr
     }
 }
 
-// AdaGN parameter gradients from ds, dz (B, C) and t (B, ctx): one thread per channel
-__global__ void adagn_param_grads_kernel(const float* __restrict__ ds, const float* __restrict__ dz,
-                                         const float* __restrict__ t, int B, int C, int ctx_dim,
-                                         float* __restrict__ d_scale_w, float* __restrict__ d_scale_b,
-                                         float* __restrict__ d_bias_w, float* __restrict__ d_bias_b) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float sb = 0.f, zb = 0.f;
-    for (int b = 0; b < B; ++b) { sb += ds[(size_t)b * C + c]; zb += dz[(size_t)b * C + c]; }
-    d_scale_b[c] = sb;
-    d_bias_b[c] = zb;
-    for (int j = 0; j < ctx_dim; ++j) {
-        float sw = 0.f, zw = 0.f;
-        for (int b = 0; b < B; ++b) {
-            const float tj = t[(size_t)b * ctx_dim + j];
-            sw += ds[(size_t)b * C + c] * tj;
-            zw += dz[(size_t)b * C + c] * tj;
+// AdaGN parameter gradients from ds, dz (B, C) and t (B, ctx).
+// 32 channels x 8 sample lanes per block: lane bl sums samples bl, bl + 8, ..; the lanes are combined in lane order (fixed
+// summation order).  One pass per quantity (the biases, then each column of the scale / bias weights).
+__global__ __launch_bounds__(256) void adagn_param_grads_kernel(const float* __restrict__ ds, const float* __restrict__ dz,
+                                                                const float* __restrict__ t, int B, int C, int ctx_dim,
+                                                                float* __restrict__ d_scale_w, float* __restrict__ d_scale_b,
+                                                                float* __restrict__ d_bias_w, float* __restrict__ d_bias_b) {
+    __shared__ float red[8][32][2];
+    const int cl = threadIdx.x & 31, bl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    for (int q = 0; q <= ctx_dim; ++q) {
+        float s = 0.f, z = 0.f;
+        if (c < C) {
+#pragma unroll 4
+            for (int b = bl; b < B; b += 8) {
+                const float wq = q == 0 ? 1.f : t[(size_t)b * ctx_dim + q - 1];
+                s += ds[(size_t)b * C + c] * wq;
+                z += dz[(size_t)b * C + c] * wq;
+            }
         }
-        d_scale_w[(size_t)c * ctx_dim + j] = sw;
-        d_bias_w[(size_t)c * ctx_dim + j] = zw;
+        red[bl][cl][0] = s;
+        red[bl][cl][1] = z;
+        __syncthreads();
+        if (bl == 0 && c < C) {
+            float ss = red[0][cl][0], zz = red[0][cl][1];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) { ss += red[k][cl][0]; zz += red[k][cl][1]; }
+            if (q == 0) {
+                d_scale_b[c] = ss;
+                d_bias_b[c] = zz;
+            } else {
+                d_scale_w[(size_t)c * ctx_dim + q - 1] = ss;
+                d_bias_w[(size_t)c * ctx_dim + q - 1] = zz;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -357,7 +373,7 @@ int affine2_apply_launch(const float* dy, const float* x, const float* cA, const
 }
 int adagn_param_grads_launch(const float* ds, const float* dz, const float* t, int B, int C, int ctx_dim,
                              float* d_scale_w, float* d_scale_b, float* d_bias_w, float* d_bias_b, hipStream_t st) {
-    hipLaunchKernelGGL(adagn_param_grads_kernel, dim3((C + 127) / 128), dim3(128), 0, st, ds, dz, t, B, C, ctx_dim,
+    hipLaunchKernelGGL(adagn_param_grads_kernel, dim3((C + 31) / 32), dim3(256), 0, st, ds, dz, t, B, C, ctx_dim,
                        d_scale_w, d_scale_b, d_bias_w, d_bias_b);
     return (int)hipGetLastError();
 }

@@ -320,16 +320,47 @@ def train_bench(args, rank, world, dev):
     from gecco_amd.structs import Example
     ops.set_default_precision(args.precision)
     Bt = args.train_batch
-    model = build_model(random_state_dict(seed=3)).to(dev).train()
-    gd.broadcast_parameters(model)
-    opt = FusedAdamEMA(model.parameters(), lr=1e-4, ema_decay=0.99)
-    red = gd.BucketedGradAllReducer(opt, bucket_bytes=args.bucket_mb << 20)
     g = torch.Generator().manual_seed(100 + rank)      # every rank: its own shard of the global batch
-    data = (torch.randn(Bt, N, 3, generator=g) * model.reparam.sigma.cpu() + model.reparam.mean.cpu()).to(dev)
+    Nt, Dt, Lt, cond = N, D, L, args.config in ("C3", "C4")
+    if cond:
+        # image-conditional training (BASELINE config C4: Taskonomy 256 x 256, N = 4096, d = 512, DDP; C3: 224 x 224, N = 2048,
+        # d = 384): RayNetwork + projective lookup trained through the HIP autograd path, the channels-last ConvNeXt
+        # conditioner frozen (it has no HIP backward) and evaluated inside every step like the reference's training_step
+        from gecco_amd.diffusion import Diffusion, EDMLoss, EDMPrecond, LogUniformSchedule
+        from gecco_amd.models.activation import GaussianActivation
+        from gecco_amd.models.feature_pyramid import ConvNeXtExtractor
+        from gecco_amd.models.ray import RayNetwork
+        from gecco_amd.models.set_transformer import SetTransformer
+        from gecco_amd.reparam import UVLReparam
+        from gecco_amd.structs import Context3d
+        Nt, Dt, hw = (2048, 384, 224) if args.config == "C3" else (4096, 512, 256)
+        torch.manual_seed(3)
+        rp = UVLReparam(torch.tensor([0.0, 0.0, 1.38]), torch.tensor([0.56, 0.60, 0.49]))
+        net = RayNetwork(backbone=SetTransformer(n_layers=Lt, num_inducers=I, feature_dim=Dt, t_embed_dim=1, num_heads=H,
+                                                 activation=GaussianActivation), reparam=rp, context_dims=(96, 192, 384))
+        model = Diffusion(backbone=EDMPrecond(model=net), conditioner=ConvNeXtExtractor(pretrained=False), reparam=rp,
+                          loss=EDMLoss(schedule=LogUniformSchedule(max=180.0))).to(dev).train()
+        model.conditioner.requires_grad_(False)
+        K = torch.zeros(Bt, 3, 3)
+        K[:, 0, 0] = K[:, 1, 1] = 1.1
+        K[:, 0, 2] = K[:, 1, 2] = 0.5
+        K[:, 2, 2] = 1.0
+        ctx = Context3d(image=torch.rand(Bt, 3, hw, hw, generator=g).to(dev), K=K.to(dev))
+        data = model.reparam.diffusion_to_data(torch.randn(Bt, Nt, 3, generator=g).to(dev), ctx)   # clouds in front of the camera
+        example = Example(data, ctx)
+        params = [q for q in model.parameters() if q.requires_grad]
+    else:
+        model = build_model(random_state_dict(seed=3)).to(dev).train()
+        data = (torch.randn(Bt, N, 3, generator=g) * model.reparam.sigma.cpu() + model.reparam.mean.cpu()).to(dev)
+        example = Example(data, None)
+        params = list(model.parameters())
+    gd.broadcast_parameters(model)
+    opt = FusedAdamEMA(params, lr=1e-4, ema_decay=0.99)
+    red = gd.BucketedGradAllReducer(opt, bucket_bytes=args.bucket_mb << 20)
 
     def step(i):
         opt.zero_grad()
-        loss = model.training_step(Example(data, None), i)
+        loss = model.training_step(example, i)
         loss.backward()
         red.finish()
         opt.step()
@@ -349,18 +380,23 @@ def train_bench(args, rank, world, dev):
     dt = gd.max_over_ranks(time.perf_counter() - t0, dev)
     assert torch.isfinite(loss.detach()).all()
     ms = dt / args.steps * 1e3
-    rec = {"metric": "train_points_per_sec", "value": world * Bt * N * args.steps / dt, "unit": "points/s", "n_gpus": world,
+    per_layer = 16 * Nt * Dt * Dt + 8 * Nt * I * Dt + 14 * I * Dt * Dt
+    fwd_flops = Lt * per_layer + (2 * Nt * 672 * Dt + 12 * Nt * Dt if cond else 12 * Nt * Dt)   # per sample
+    rec = {"metric": "train_points_per_sec", "value": world * Bt * Nt * args.steps / dt, "unit": "points/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None,
            "dtype": {"bf16x3": "bf16 (split hi+lo operands, 3 MFMAs per product, fp32 accumulate)", "fp32": "f32",
                      "fp16": "bf16 (split; the fp16 mode is not used for gradients)",
                      "mixed": "bf16 (split; the mixed mode trains in split-bf16)"}[args.precision],
            "data": "synthetic",
-           "config": {"workload": f"C2 unconditional training step: batch {Bt}/GPU, N={N}, d={D}, L={L}: EDMLoss forward + backward "
-                                  "(HIP autograd Functions), bucketed gradient all-reduce overlapped with backward, fused Adam+EMA",
+           "config": {"workload": (f"{args.config} image-conditional training step (frozen channels-last ConvNeXt conditioner inside the step, "
+                                   f"projective lookup, RayNetwork): batch {Bt}/GPU, N={Nt}, d={Dt}, L={Lt}" if cond else
+                                   f"C2 unconditional training step: batch {Bt}/GPU, N={N}, d={D}, L={L}") +
+                                  ": EDMLoss forward + backward (HIP autograd Functions), bucketed gradient all-reduce overlapped with "
+                                  "backward, fused Adam+EMA",
                       "parallelism": f"dp{world}"},
            "loss": float(loss.detach()), "peak_mem_gib": torch.cuda.max_memory_allocated() / 2 ** 30,
-           "train_tflops_algorithmic": 3 * flops_per_sample() * Bt / (ms * 1e-3) / 1e12}
+           "train_tflops_algorithmic": 3 * fwd_flops * Bt / (ms * 1e-3) / 1e12}
     # the optimizer step alone, and the collective alone (bus bandwidth = 2 (n-1)/n bytes / t for an all-reduce)
     flat = opt.flat_grad()
     rec["adam_ema_ms"] = time_events(lambda: opt.launch(opt._adam_step, True), 10)   # the kernel alone (state kept: same step)

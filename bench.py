@@ -22,10 +22,16 @@ every BASELINE shape (tests/test_hip_fullsize.py: F_x 3e-5 .. 9e-5).  `--precisi
 `--train` times the data-parallel TRAINING step instead: per rank batch 48 (the shipped
 config), forward + backward on the HIP training path, gradient all-reduce overlapped with the backward
 (one RCCL all-reduce per ~8 MB bucket of the flat gradient buffer, issued as the bucket completes), fused
-Adam + EMA step (one launch); it reports step ms, the stand-alone all-reduce time and bus bandwidth.
+Adam + EMA step (one launch); it reports step ms, the stand-alone all-reduce time and bus bandwidth.  `--train --config
+C3 | C4` is the image-conditional step (frozen channels-last ConvNeXt conditioner inside the step, projective lookup,
+RayNetwork; C4 = BASELINE's data-parallel configuration: N = 4096, d = 512).  `--config C3 | C4 | C5` without `--train`
+times one evaluation of the other BASELINE shapes (C5: the cached upsampling evaluation of 16 384 new points).
 
 Extra objects on that line:
-  roofline     — the dominant kernel of the measured mode.  fp16 (default): the fused point MLP
+  roofline     — the dominant kernel of the measured mode.  mixed (default): mlp.0 (gemm_dma_kernel<3,true,true,128>: AdaGN
+                 prologue + split-bf16 product + GaussianActivation, 27 % of device time), bound "mfma" against 2500 / 3
+                 TFLOP/s of 2MNK, timed with HIP events inside hipGraph replays of the round out_proj -> mlp.0 -> mlp.2 on
+                 shared buffers ("round - round without that launch").  fp16 (opt-in): the fused point MLP
                  (mlp_fused_f16_kernel, 35 % of device time), bound "mfma": 4 B N d 2d FLOP / its
                  duration, where the duration is timed with HIP events around hipGraph replays of the
                  layer's three point-stream launches (kernel launches only) as "round - round without

@@ -291,7 +291,7 @@ def _softmax_bwd(P: Tensor, dP: Tensor, scale: float) -> Tensor:
 def _fused_attn_ok(I: int, hd: int) -> bool:
     """Shapes the fused attention kernels take (every shipped config: 64 inducers, head dim d / 8); others run the
     strided-batched GEMM form below."""
-    return I == 64 and hd in (8, 16, 32, 48, 64) and os.environ.get("GECCO_TRAIN_ATTN", "fused") != "gemm"
+    return I == 64 and hd % 8 == 0 and 8 <= hd <= 64 and os.environ.get("GECCO_TRAIN_ATTN", "fused") != "gemm"
 
 
 class PoolAttnFn(torch.autograd.Function):

@@ -795,7 +795,7 @@ int gecco_pool_attn_bwd_ex_f32(const float* KV, const float* inducers, const flo
     if (precision < 0 || precision > 1) return fail(-2, "pool_attn_bwd: precision must be 0 (fp32) or 1 (split-bf16)");
     const int rc = pool_attn_bwd_launch(KV, inducers, merged, lse, dO, dKV, dQ_partials, B, N, C, H, I, pool_attn_bwd_nsplit(B, N, H),
                                         (hipStream_t)stream, precision);
-    if (rc == -3 || rc == -4) return fail(-2, "pool_attn_bwd: needs I == 64 and a head dim of 8, 16, 32, 48 or 64");
+    if (rc == -3 || rc == -4) return fail(-2, "pool_attn_bwd: needs I == 64 and a head dim that is a multiple of 8 up to 64");
     TRY(rc, "pool_attn_bwd");
     return 0;
 }
@@ -805,7 +805,7 @@ int gecco_unpool_attn_bwd_ex_f32(const float* q, const float* kvh, const float* 
     if (B <= 0 || N <= 0) return fail(-2, "unpool_attn_bwd: empty batch");
     if (precision < 0 || precision > 1) return fail(-2, "unpool_attn_bwd: precision must be 0 (fp32) or 1 (split-bf16)");
     const int rc = unpool_attn_bwd_launch(q, kvh, dO, dq, dkv_partials, B, N, C, H, I, (hipStream_t)stream, precision);
-    if (rc == -3 || rc == -4) return fail(-2, "unpool_attn_bwd: needs I == 64 and a head dim of 8, 16, 32, 48 or 64");
+    if (rc == -3 || rc == -4) return fail(-2, "unpool_attn_bwd: needs I == 64 and a head dim that is a multiple of 8 up to 64");
     TRY(rc, "unpool_attn_bwd");
     return 0;
 }

@@ -515,8 +515,11 @@ int pool_attn_bwd_launch(const float* KV, const float* inducers, const float* me
     switch (C / H) {
         case 8: return pool_bwd_t<8>(KV, inducers, merged, lse, dO, dKV, dQpart, B, N, C, H, nsplit, st);
         case 16: return pool_bwd_t<16>(KV, inducers, merged, lse, dO, dKV, dQpart, B, N, C, H, nsplit, st);
+        case 24: return pool_bwd_t<24>(KV, inducers, merged, lse, dO, dKV, dQpart, B, N, C, H, nsplit, st);
         case 32: return pool_bwd_t<32>(KV, inducers, merged, lse, dO, dKV, dQpart, B, N, C, H, nsplit, st);
+        case 40: return pool_bwd_t<40>(KV, inducers, merged, lse, dO, dKV, dQpart, B, N, C, H, nsplit, st);
         case 48: return pool_bwd_t<48>(KV, inducers, merged, lse, dO, dKV, dQpart, B, N, C, H, nsplit, st);
+        case 56: return pool_bwd_t<56>(KV, inducers, merged, lse, dO, dKV, dQpart, B, N, C, H, nsplit, st);
         case 64: return pool_bwd_t<64>(KV, inducers, merged, lse, dO, dKV, dQpart, B, N, C, H, nsplit, st);
         default: return -4;
     }
@@ -532,8 +535,11 @@ int unpool_attn_bwd_launch(const float* q, const float* kvh, const float* dO, fl
     switch (C / H) {
         case 8: return unpool_bwd_t<8>(q, kvh, dO, dq, dkv_part, B, N, C, H, tpw, nchunk, st);
         case 16: return unpool_bwd_t<16>(q, kvh, dO, dq, dkv_part, B, N, C, H, tpw, nchunk, st);
+        case 24: return unpool_bwd_t<24>(q, kvh, dO, dq, dkv_part, B, N, C, H, tpw, nchunk, st);
         case 32: return unpool_bwd_t<32>(q, kvh, dO, dq, dkv_part, B, N, C, H, tpw, nchunk, st);
+        case 40: return unpool_bwd_t<40>(q, kvh, dO, dq, dkv_part, B, N, C, H, tpw, nchunk, st);
         case 48: return unpool_bwd_t<48>(q, kvh, dO, dq, dkv_part, B, N, C, H, tpw, nchunk, st);
+        case 56: return unpool_bwd_t<56>(q, kvh, dO, dq, dkv_part, B, N, C, H, tpw, nchunk, st);
         case 64: return unpool_bwd_t<64>(q, kvh, dO, dq, dkv_part, B, N, C, H, tpw, nchunk, st);
         default: return -4;
     }

@@ -405,8 +405,11 @@ int pool_attn_launch(const float* KV, const float* inducers, float* part_o, floa
     else switch (HD) {
         case 8: rc = pool_launch_t<8>(KV, inducers, part_o, part_ml, B, N, C, H, nsplit, st); break;
         case 16: rc = pool_launch_t<16>(KV, inducers, part_o, part_ml, B, N, C, H, nsplit, st); break;
+        case 24: rc = pool_launch_t<24>(KV, inducers, part_o, part_ml, B, N, C, H, nsplit, st); break;
         case 32: rc = pool_launch_t<32>(KV, inducers, part_o, part_ml, B, N, C, H, nsplit, st); break;
+        case 40: rc = pool_launch_t<40>(KV, inducers, part_o, part_ml, B, N, C, H, nsplit, st); break;
         case 48: rc = pool_launch_t<48>(KV, inducers, part_o, part_ml, B, N, C, H, nsplit, st); break;
+        case 56: rc = pool_launch_t<56>(KV, inducers, part_o, part_ml, B, N, C, H, nsplit, st); break;
         case 64: rc = pool_launch_t<64>(KV, inducers, part_o, part_ml, B, N, C, H, nsplit, st); break;
         default: return -4;
     }
@@ -428,8 +431,11 @@ int unpool_attn_launch(const float* q, const float* kvh, float* out, int B, int 
     switch (C / H) {
         case 8: return unpool_launch_t<8>(q, kvh, out, B, N, C, H, st);
         case 16: return unpool_launch_t<16>(q, kvh, out, B, N, C, H, st);
+        case 24: return unpool_launch_t<24>(q, kvh, out, B, N, C, H, st);
         case 32: return unpool_launch_t<32>(q, kvh, out, B, N, C, H, st);
+        case 40: return unpool_launch_t<40>(q, kvh, out, B, N, C, H, st);
         case 48: return unpool_launch_t<48>(q, kvh, out, B, N, C, H, st);
+        case 56: return unpool_launch_t<56>(q, kvh, out, B, N, C, H, st);
         case 64: return unpool_launch_t<64>(q, kvh, out, B, N, C, H, st);
         default: return -4;
     }

@@ -184,7 +184,7 @@ def test_gauss_act_fn_grads():
 
 @pytest.mark.parametrize("path", ["fused", "gemm"])
 @pytest.mark.parametrize("B,N,C,H", [(2, 300, 128, 8), (1, 128, 384, 8), (3, 2048, 256, 8), (2, 1000, 512, 8), (2, 333, 64, 8),
-                                     (5, 4096, 384, 8)])
+                                     (5, 4096, 384, 8), (2, 500, 192, 8), (1, 256, 448, 8)])
 def test_attention_fn_grads(B, N, C, H, path, monkeypatch):
     """Both training forms of the two attention cores against torch autograd: the fused flash-style kernels
     (csrc/attention_bwd_f32.hip; head dims 8 ... 64, ragged N, key splits and query chunks > 1) and the strided-batched

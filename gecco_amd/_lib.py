@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GECCO_HIP_LIB") or os.path.join(_HERE, "libgecco_hip.so")   # override: A/B builds only
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_f = C.c_void_p  # device pointers travel as void*
 
@@ -157,6 +157,16 @@ SIGNATURES = {
     "gecco_convnext_dwconv_ln_f32": (i, [vp] * 6 + [i, i, i, i, fl, vp]),
     "gecco_convnext_ln_patch2_f32": (i, [vp] * 4 + [i, i, i, i, fl, vp]),
     "gecco_convnext_fold_scale_f32": (i, [vp] * 5 + [i, i, vp]),
+    "gecco_convnext_stem_train_f32": (i, [vp] * 7 + [i, i, i, i, fl, vp]),
+    "gecco_convnext_dwconv_ln_train_f32": (i, [vp] * 7 + [i, i, i, i, fl, vp]),
+    "gecco_convnext_dwconv_f32": (i, [vp] * 4 + [i, i, i, i, vp]),
+    "gecco_convnext_ln_bwd_blocks": (i, [i, i, i, i]),
+    "gecco_convnext_ln_bwd_f32": (i, [vp] * 5 + [i, i, i, i, fl, i, vp]),
+    "gecco_convnext_dwconv_dw_blocks": (i, [i, i, i, i]),
+    "gecco_convnext_dwconv_dw_f32": (i, [vp] * 3 + [i, i, i, i, vp]),
+    "gecco_gelu_f32": (i, [vp, vp, C.c_size_t, vp]),
+    "gecco_gelu_bwd_f32": (i, [vp, vp, vp, C.c_size_t, vp]),
+    "gecco_convnext_im2col4_f32": (i, [vp, vp, i, i, i, vp]),
     "gecco_adam_ema_step_f32": (i, [C.POINTER(GeccoAdamEma), vp]),
     "gecco_ema_update_f32": (i, [vp, vp, sz, db, vp]),
 }

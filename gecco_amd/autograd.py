@@ -84,6 +84,12 @@ def _linear_dw(dy: Tensor, x: Tensor, want_db: bool = False):
     it stages anyway."""
     B, R, K = x.shape
     Nout = dy.shape[2]
+    if B == 1 and R >= 4096:
+        # one long row block (the conditioner's texel matrix): cut it into groups for the per-group partials below
+        g = max((d for d in range(1, 65) if R % (32 * d) == 0), default=1)
+        if g > 1:
+            dy, x = dy.view(g, R // g, Nout), x.view(g, R // g, K)
+            B, R = g, R // g
     if want_db:
         if not (_train_precision() == "bf16x3" and R % 32 == 0 and Nout % 128 == 0 and K % 128 == 0):
             return _linear_dw(dy, x), _linear_db(dy)
@@ -535,6 +541,157 @@ class LookupFn(torch.autograd.Function):
                                                 _stream()), "gecco_ray_lookup_bwd_f32")
         # handed back NCHW-shaped (channels-last strides, no copy)
         return (None, None, None, *[g.permute(0, 3, 1, 2) for g in grads])
+
+
+# ------------------------------------------------------------------------------------------- ConvNeXt conditioner
+class GeluFn(torch.autograd.Function):
+    """nn.GELU() (erf form) between the pointwise linears of a CNBlock."""
+
+    @staticmethod
+    def forward(ctx, u):
+        u = _f(u)
+        ctx.save_for_backward(u)
+        y = torch.empty_like(u)
+        _lib.check(_lib.load().gecco_gelu_f32(_ptr(u), _ptr(y), u.numel(), _stream()), "gecco_gelu_f32")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (u,) = ctx.saved_tensors
+        dy = _f(dy)
+        du = torch.empty_like(u)
+        _lib.check(_lib.load().gecco_gelu_bwd_f32(_ptr(u), _ptr(dy), _ptr(du), u.numel(), _stream()), "gecco_gelu_bwd_f32")
+        return du
+
+
+def _cnx_ln_bwd(z: Tensor, dy: Tensor, ln_w: Tensor, eps: float, patch2: bool):
+    """LayerNorm over C backward from its input z (B, H, W, C) -> dz, (d ln_w, d ln_b, column sums of dz)."""
+    lib = _lib.load()
+    B, H, W, Cc = z.shape
+    nb = lib.gecco_convnext_ln_bwd_blocks(B, H, W, Cc)
+    if nb <= 0:
+        raise _lib.GeccoHipError("convnext LayerNorm backward: C must be 96, 192 or 384")
+    dz, parts = torch.empty_like(z), _new(nb, 3 * Cc, like=z)
+    _lib.check(lib.gecco_convnext_ln_bwd_f32(_ptr(z), _ptr(dy), _ptr(ln_w), _ptr(dz), _ptr(parts), B, H, W, Cc, eps, int(patch2),
+                                             _stream()), "gecco_convnext_ln_bwd_f32")
+    red = _reduce(parts, 3 * Cc, nb, 3 * Cc)
+    return dz, red[:Cc], red[Cc:2 * Cc], red[2 * Cc:]
+
+
+class CnxStemFn(torch.autograd.Function):
+    """LayerNorm2d(Conv2d(3, C, k4, s4)(image)) -> (B, H/4, W/4, C)   (torchvision ConvNeXt features[0])."""
+
+    @staticmethod
+    def forward(ctx, img, w, b, ln_w, ln_b, eps):
+        img = _f(img.float())
+        B, _, H, W = img.shape
+        Cc = w.shape[0]
+        out = _new(B, H // 4, W // 4, Cc, like=img)
+        z = torch.empty_like(out)
+        _lib.check(_lib.load().gecco_convnext_stem_train_f32(_ptr(img), _ptr(_f(w)), _ptr(b), _ptr(ln_w), _ptr(ln_b), _ptr(out), _ptr(z),
+                                                             B, H, W, Cc, eps, _stream()), "gecco_convnext_stem_train_f32")
+        ctx.save_for_backward(img, z, ln_w)
+        ctx.eps = eps
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        _no_input_grad(ctx, 0, "the image")
+        img, z, ln_w = ctx.saved_tensors
+        B, h, w_, Cc = z.shape
+        dz, dg, dbl, dbias = _cnx_ln_bwd(z, _f(dy), ln_w, ctx.eps, False)
+        patches = _new(B, h * w_, 48, like=z)
+        _lib.check(_lib.load().gecco_convnext_im2col4_f32(_ptr(img), _ptr(patches), B, img.shape[2], img.shape[3], _stream()),
+                   "gecco_convnext_im2col4_f32")
+        dW = _linear_dw(dz.view(B, h * w_, Cc), patches).reshape(Cc, 3, 4, 4)
+        return None, dW, dbias, dg, dbl, None
+
+
+class CnxDwLnFn(torch.autograd.Function):
+    """LayerNorm(dwconv7x7(x) + b) on (B, H, W, C): the front half of a CNBlock (block.0 .. block.2)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, ln_w, ln_b, eps):
+        x = _f(x)
+        B, H, W, Cc = x.shape
+        w_tap = w.reshape(Cc, 49).t().contiguous()   # tap-major (49, C)
+        out, z = torch.empty_like(x), torch.empty_like(x)
+        _lib.check(_lib.load().gecco_convnext_dwconv_ln_train_f32(_ptr(x), _ptr(w_tap), _ptr(b), _ptr(ln_w), _ptr(ln_b), _ptr(out),
+                                                                  _ptr(z), B, H, W, Cc, eps, _stream()),
+                   "gecco_convnext_dwconv_ln_train_f32")
+        ctx.save_for_backward(x, z, w_tap, ln_w)
+        ctx.eps = eps
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, z, w_tap, ln_w = ctx.saved_tensors
+        lib = _lib.load()
+        B, H, W, Cc = x.shape
+        dz, dg, dbl, dbias = _cnx_ln_bwd(z, _f(dy), ln_w, ctx.eps, False)
+        dx = None
+        if ctx.needs_input_grad[0]:   # the same convolution on the reversed taps
+            dx = torch.empty_like(x)
+            _lib.check(lib.gecco_convnext_dwconv_f32(_ptr(dz), _ptr(w_tap.flip(0).contiguous()), None, _ptr(dx), B, H, W, Cc, _stream()),
+                       "gecco_convnext_dwconv_f32")
+        nb = lib.gecco_convnext_dwconv_dw_blocks(B, H, W, Cc)
+        parts = _new(nb, 49 * Cc, like=x)
+        _lib.check(lib.gecco_convnext_dwconv_dw_f32(_ptr(x), _ptr(dz), _ptr(parts), B, H, W, Cc, _stream()), "gecco_convnext_dwconv_dw_f32")
+        dW = _reduce(parts, 49 * Cc, nb, 49 * Cc).reshape(49, Cc).t().reshape(Cc, 1, 7, 7)
+        return dx, dW, dbias, dg, dbl, None
+
+
+class CnxLnPatchFn(torch.autograd.Function):
+    """LayerNorm2d(x) gathered into the 2 x 2 stride-2 convolution's GEMM operand (B, H/2, W/2, (dy, dx, c))."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, eps):
+        x = _f(x)
+        B, H, W, Cc = x.shape
+        out = _new(B, H // 2, W // 2, 4 * Cc, like=x)
+        _lib.check(_lib.load().gecco_convnext_ln_patch2_f32(_ptr(x), _ptr(ln_w), _ptr(ln_b), _ptr(out), B, H, W, Cc, eps, _stream()),
+                   "gecco_convnext_ln_patch2_f32")
+        ctx.save_for_backward(x, ln_w)
+        ctx.eps = eps
+        return out
+
+    @staticmethod
+    def backward(ctx, dp):
+        x, ln_w = ctx.saved_tensors
+        dx, dg, dbl, _ = _cnx_ln_bwd(x, _f(dp), ln_w, ctx.eps, True)
+        return dx, dg, dbl, None
+
+
+def convnext_pyramid(ext, image: Tensor) -> list[Tensor]:
+    """ConvNeXtExtractor.forward WITH autograd (reference models/feature_pyramid.py:62-73 over torchvision's stages; the
+    reference optimises the conditioner's parameters with the denoiser's, diffusion.py:210-211).  Channels-last like the
+    inference path; returns NCHW-shaped views.  layer_scale and the 2 x 2 convolution's weight reach the GEMM as small
+    re-laid-out parameter tensors (torch ops on parameters, differentiated by autograd)."""
+    from .models.feature_pyramid import LN_EPS
+    feats = []
+    x = None
+    for s, stage in enumerate(ext.stages):
+        head, blocks = stage[0], stage[1]
+        if s == 0:
+            conv, ln = head[0], head[1]
+            x = CnxStemFn.apply(image, conv.weight, conv.bias, ln.weight, ln.bias, LN_EPS)
+        else:
+            ln, conv = head[0], head[1]
+            Cin, Cout = conv.in_channels, conv.out_channels
+            patches = CnxLnPatchFn.apply(x, ln.weight, ln.bias, LN_EPS)
+            Bq, hq, wq, _ = patches.shape
+            wmat = conv.weight.permute(0, 2, 3, 1).reshape(Cout, 4 * Cin)
+            x = LinearFn.apply(patches.view(1, Bq * hq * wq, 4 * Cin), wmat, conv.bias).view(Bq, hq, wq, Cout)
+        Bq, hq, wq, Cc = x.shape
+        rows = Bq * hq * wq
+        for blk in blocks:
+            dw, ln, pw1, pw2 = blk.block[0], blk.block[2], blk.block[3], blk.block[5]
+            y = CnxDwLnFn.apply(x, dw.weight, dw.bias, ln.weight, ln.bias, LN_EPS)
+            hid = GeluFn.apply(LinearFn.apply(y.view(1, rows, Cc), pw1.weight, pw1.bias))
+            ls = blk.layer_scale.reshape(-1)
+            x = LinearFn.apply(hid, pw2.weight * ls[:, None], pw2.bias * ls, x.view(1, rows, Cc)).view(Bq, hq, wq, Cc)
+        feats.append(x.permute(0, 3, 1, 2))
+    return feats
 
 
 # ------------------------------------------------------------------------------------------- network composition

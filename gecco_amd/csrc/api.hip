@@ -1207,7 +1207,7 @@ int gecco_sinkhorn_f32(const float* C, float* f, float* g, float* rowcost, float
 int gecco_convnext_stem_f32(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b, float* out,
                             int B, int H, int W, int C, float eps, void* stream) {
     if (!x || !w || !bias || !ln_w || !ln_b || !out) return fail(-1, "convnext_stem: null argument");
-    int rc = cnx_stem_launch(x, w, bias, ln_w, ln_b, out, B, H, W, C, eps, (hipStream_t)stream);
+    int rc = cnx_stem_launch(x, w, bias, ln_w, ln_b, out, nullptr, B, H, W, C, eps, (hipStream_t)stream);
     if (rc == -9) return fail(-2, "convnext_stem: needs C == 96 and H, W multiples of 4");
     TRY(rc, "convnext_stem");
     return 0;
@@ -1215,7 +1215,7 @@ int gecco_convnext_stem_f32(const float* x, const float* w, const float* bias, c
 int gecco_convnext_dwconv_ln_f32(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b, float* out,
                                  int B, int H, int W, int C, float eps, void* stream) {
     if (!x || !w || !bias || !ln_w || !ln_b || !out) return fail(-1, "convnext_dwconv_ln: null argument");
-    int rc = cnx_dwconv_ln_launch(x, w, bias, ln_w, ln_b, out, B, H, W, C, eps, (hipStream_t)stream);
+    int rc = cnx_dwconv_ln_launch(x, w, bias, ln_w, ln_b, out, nullptr, B, H, W, C, eps, (hipStream_t)stream);
     if (rc == -9) return fail(-2, "convnext_dwconv_ln: C must be 96, 192 or 384");
     TRY(rc, "convnext_dwconv_ln");
     return 0;
@@ -1231,6 +1231,69 @@ int gecco_convnext_ln_patch2_f32(const float* x, const float* ln_w, const float*
 int gecco_convnext_fold_scale_f32(const float* W, const float* b, const float* s, float* Wo, float* bo, int N, int K, void* stream) {
     if (!W || !b || !s || !Wo || !bo) return fail(-1, "convnext_fold_scale: null argument");
     TRY(cnx_fold_scale_launch(W, b, s, Wo, bo, N, K, (hipStream_t)stream), "convnext_fold_scale");
+    return 0;
+}
+
+// ---- the conditioner's training path
+int gecco_convnext_stem_train_f32(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b, float* out,
+                                  float* z, int B, int H, int W, int C, float eps, void* stream) {
+    if (!x || !w || !bias || !ln_w || !ln_b || !out || !z) return fail(-1, "convnext_stem_train: null argument");
+    int rc = cnx_stem_launch(x, w, bias, ln_w, ln_b, out, z, B, H, W, C, eps, (hipStream_t)stream);
+    if (rc == -9) return fail(-2, "convnext_stem_train: needs C == 96 and H, W multiples of 4");
+    TRY(rc, "convnext_stem_train");
+    return 0;
+}
+int gecco_convnext_dwconv_ln_train_f32(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b,
+                                       float* out, float* z, int B, int H, int W, int C, float eps, void* stream) {
+    if (!x || !w || !bias || !ln_w || !ln_b || !out || !z) return fail(-1, "convnext_dwconv_ln_train: null argument");
+    int rc = cnx_dwconv_ln_launch(x, w, bias, ln_w, ln_b, out, z, B, H, W, C, eps, (hipStream_t)stream);
+    if (rc == -9) return fail(-2, "convnext_dwconv_ln_train: C must be 96, 192 or 384");
+    TRY(rc, "convnext_dwconv_ln_train");
+    return 0;
+}
+int gecco_convnext_dwconv_f32(const float* x, const float* w, const float* bias, float* out, int B, int H, int W, int C, void* stream) {
+    if (!x || !w || !out) return fail(-1, "convnext_dwconv: null argument");
+    int rc = cnx_dwconv_ln_launch(x, w, bias, nullptr, nullptr, out, nullptr, B, H, W, C, 0.f, (hipStream_t)stream);
+    if (rc == -9) return fail(-2, "convnext_dwconv: C must be 96, 192 or 384");
+    TRY(rc, "convnext_dwconv");
+    return 0;
+}
+int gecco_convnext_ln_bwd_blocks(int B, int H, int W, int C) { return cnx_ln_bwd_blocks(B, H, W, C); }
+int gecco_convnext_ln_bwd_f32(const float* z, const float* dy, const float* ln_w, float* dz, float* parts, int B, int H, int W, int C,
+                              float eps, int patch2, void* stream) {
+    if (!z || !dy || !ln_w || !dz || !parts) return fail(-1, "convnext_ln_bwd: null argument");
+    int rc = cnx_ln_bwd_launch(z, dy, ln_w, dz, parts, B, H, W, C, eps, patch2, (hipStream_t)stream);
+    if (rc == -9) return fail(-2, "convnext_ln_bwd: C must be 96, 192 or 384 (and H, W even for the patch layout)");
+    TRY(rc, "convnext_ln_bwd");
+    return 0;
+}
+int gecco_convnext_dwconv_dw_blocks(int B, int H, int W, int C) { return cnx_dwconv_dw_blocks(B, H, W, C); }
+int gecco_convnext_dwconv_dw_f32(const float* x, const float* dz, float* parts, int B, int H, int W, int C, void* stream) {
+    if (!x || !dz || !parts) return fail(-1, "convnext_dwconv_dw: null argument");
+    int rc = cnx_dwconv_dw_launch(x, dz, parts, B, H, W, C, (hipStream_t)stream);
+    if (rc == -9) return fail(-2, "convnext_dwconv_dw: C must be 96, 192 or 384");
+    TRY(rc, "convnext_dwconv_dw");
+    return 0;
+}
+int gecco_gelu_f32(const float* u, float* y, size_t n, void* stream) {
+    if (!u || !y) return fail(-1, "gelu: null argument");
+    int rc = gelu_launch(u, y, n, (hipStream_t)stream);
+    if (rc == -9) return fail(-2, "gelu: n must be a multiple of 4");
+    TRY(rc, "gelu");
+    return 0;
+}
+int gecco_gelu_bwd_f32(const float* u, const float* dy, float* du, size_t n, void* stream) {
+    if (!u || !dy || !du) return fail(-1, "gelu_bwd: null argument");
+    int rc = gelu_bwd_launch(u, dy, du, n, (hipStream_t)stream);
+    if (rc == -9) return fail(-2, "gelu_bwd: n must be a multiple of 4");
+    TRY(rc, "gelu_bwd");
+    return 0;
+}
+int gecco_convnext_im2col4_f32(const float* x, float* out, int B, int H, int W, void* stream) {
+    if (!x || !out) return fail(-1, "convnext_im2col4: null argument");
+    int rc = cnx_im2col4_launch(x, out, B, H, W, (hipStream_t)stream);
+    if (rc == -9) return fail(-2, "convnext_im2col4: H, W must be multiples of 4");
+    TRY(rc, "convnext_im2col4");
     return 0;
 }
 

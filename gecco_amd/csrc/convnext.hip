@@ -25,8 +25,8 @@ __device__ __forceinline__ float group_sum(float v, int width) {   // sum over `
 template <int C>
 __global__ __launch_bounds__(256) void stem_conv_ln_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, const float* __restrict__ ln_w,
-                                                           const float* __restrict__ ln_b, float* __restrict__ out, int B, int H,
-                                                           int W, float eps) {
+                                                           const float* __restrict__ ln_b, float* __restrict__ out,
+                                                           float* __restrict__ zout, int B, int H, int W, float eps) {
     constexpr int CPL = C / 8;                 // channels per lane
     __shared__ float sw[48 * C];               // [k][c]: lanes of a texel read consecutive c
     __shared__ float sp[32][48];
@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256) void stem_conv_ln_kernel(const float* __restri
         for (int j = 0; j < CPL; ++j) {
             const int c = q + 8 * j;
             out[p * C + c] = (acc[j] - mean) * rstd * ln_w[c] + ln_b[c];
+            if (zout) zout[p * C + c] = acc[j];   // training: the LayerNorm's input, what its backward starts from
         }
     }
 }
@@ -84,8 +85,10 @@ __global__ __launch_bounds__(256) void stem_conv_ln_kernel(const float* __restri
 template <int C>
 __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, const float* __restrict__ ln_w,
-                                                         const float* __restrict__ ln_b, float* __restrict__ out, int B, int H,
-                                                         int W, float eps, int iters) {
+                                                         const float* __restrict__ ln_b, float* __restrict__ out,
+                                                         float* __restrict__ zout, int B, int H, int W, float eps, int iters) {
+    // zout: also the convolution's own output (training: the LayerNorm's input).  ln_w == null: no LayerNorm — out is the
+    // convolution (bias may be null too): with the taps reversed this is the convolution's input gradient.
     constexpr int TPP = C / 4, PG = 256 / TPP, TX = 4, NPART = 4;
     static_assert(TPP % NPART == 0, "the LayerNorm partial sums split a group's threads in four");
     extern __shared__ __attribute__((aligned(16))) float cs[];
@@ -95,9 +98,9 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
     const int pg = threadIdx.x / TPP, t = threadIdx.x % TPP, c = 4 * t;
     for (int i = threadIdx.x; i < 49 * C / 4; i += 256)   // w arrives tap-major (49, C): a coalesced copy
         reinterpret_cast<f32x4*>(wl)[i] = reinterpret_cast<const f32x4*>(w)[i];
-    const f32x4 bias4 = pg < PG ? *reinterpret_cast<const f32x4*>(bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-    const f32x4 g4 = pg < PG ? *reinterpret_cast<const f32x4*>(ln_w + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-    const f32x4 b4 = pg < PG ? *reinterpret_cast<const f32x4*>(ln_b + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 bias4 = pg < PG && bias ? *reinterpret_cast<const f32x4*>(bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 g4 = pg < PG && ln_w ? *reinterpret_cast<const f32x4*>(ln_w + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 b4 = pg < PG && ln_w ? *reinterpret_cast<const f32x4*>(ln_b + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     const int GR = (W + TX - 1) / TX;     // groups per image row
     const size_t ngroups = (size_t)B * H * GR;
     __syncthreads();
@@ -132,6 +135,21 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
                     for (int tx = 0; tx < TX; ++tx) acc[tx] += xv[tx + dx] * wv;
                 }
             }
+        }
+        if (!ln_w) {   // grid-uniform
+            if (live) {
+                float* op = out + (((size_t)b * H + hy) * W + wx0) * C + c;
+#pragma unroll
+                for (int tx = 0; tx < TX; ++tx)
+                    if (wx0 + tx < W) *reinterpret_cast<f32x4*>(op + (size_t)tx * C) = acc[tx];
+            }
+            continue;
+        }
+        if (zout && live) {
+            float* zp = zout + (((size_t)b * H + hy) * W + wx0) * C + c;
+#pragma unroll
+            for (int tx = 0; tx < TX; ++tx)
+                if (wx0 + tx < W) *reinterpret_cast<f32x4*>(zp + (size_t)tx * C) = acc[tx];
         }
         // LayerNorm over each texel's C channels, two passes (mean, centred variance): per-thread partials in LDS, four
         // threads per (group, texel) add a quarter of them each, everyone combines the four quarters
@@ -228,16 +246,16 @@ __global__ void fold_scale_kernel(const float* __restrict__ Wm, const float* __r
         default: return -9;                                                                                     \
     }
 
-int cnx_stem_launch(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b, float* out, int B,
-                    int H, int W, int C, float eps, hipStream_t st) {
+int cnx_stem_launch(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b, float* out, float* zout,
+                    int B, int H, int W, int C, float eps, hipStream_t st) {
     if (C != 96 || (H & 3) || (W & 3)) return -9;
     const size_t npix = (size_t)B * (H / 4) * (W / 4);
-    hipLaunchKernelGGL((stem_conv_ln_kernel<96>), dim3((unsigned)((npix + 31) / 32)), dim3(256), 0, st, x, w, bias, ln_w, ln_b, out, B, H,
-                       W, eps);
+    hipLaunchKernelGGL((stem_conv_ln_kernel<96>), dim3((unsigned)((npix + 31) / 32)), dim3(256), 0, st, x, w, bias, ln_w, ln_b, out, zout, B,
+                       H, W, eps);
     return (int)hipGetLastError();
 }
-int cnx_dwconv_ln_launch(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b, float* out, int B,
-                         int H, int W, int C, float eps, hipStream_t st) {
+int cnx_dwconv_ln_launch(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b, float* out,
+                         float* zout, int B, int H, int W, int C, float eps, hipStream_t st) {
     if (C != 96 && C != 192 && C != 384) return -9;
     const int pg = 256 / (C / 4);
     const size_t ngroups = (size_t)B * H * ((W + 3) / 4), batches = (ngroups + pg - 1) / pg;
@@ -254,7 +272,7 @@ int cnx_dwconv_ln_launch(const float* x, const float* w, const float* bias, cons
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
             attr = true;                                                                                                    \
         }                                                                                                                   \
-        hipLaunchKernelGGL((dwconv7_ln_kernel<CV>), dim3(grid), dim3(256), lds, st, x, w, bias, ln_w, ln_b, out, B, H, W, eps, iters); \
+        hipLaunchKernelGGL((dwconv7_ln_kernel<CV>), dim3(grid), dim3(256), lds, st, x, w, bias, ln_w, ln_b, out, zout, B, H, W, eps, iters); \
         break;                                                                                                              \
     }
     switch (C) {

@@ -285,10 +285,20 @@ int sampler_refresh_known_launch(double* x, const float* known, const float* noi
                                  int m, int n_known, int B, hipStream_t st);
 
 // convnext.hip — channels-last ConvNeXt conditioner pieces (the pointwise linears run on the fused GEMM)
-int cnx_stem_launch(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b, float* out, int B,
-                    int H, int W, int C, float eps, hipStream_t st);
-int cnx_dwconv_ln_launch(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b, float* out, int B,
-                         int H, int W, int C, float eps, hipStream_t st);
+// zout (optional): the LayerNorm's input as well (training).  dwconv: ln_w == null -> out is the plain convolution (bias optional)
+int cnx_stem_launch(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b, float* out, float* zout,
+                    int B, int H, int W, int C, float eps, hipStream_t st);
+int cnx_dwconv_ln_launch(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b, float* out,
+                         float* zout, int B, int H, int W, int C, float eps, hipStream_t st);
 int cnx_ln_patch2_launch(const float* x, const float* ln_w, const float* ln_b, float* out, int B, int H, int W, int C, float eps,
                          hipStream_t st);
 int cnx_fold_scale_launch(const float* Wm, const float* b, const float* s, float* Wo, float* bo, int N, int K, hipStream_t st);
+// convnext_bwd.hip — the conditioner's backward (HBM-bound pieces; partial sums per block, reduced by reduce_batch)
+int cnx_ln_bwd_blocks(int B, int H, int W, int C);   // rows of the (blocks, 3, C) partial buffer
+int cnx_ln_bwd_launch(const float* z, const float* dy, const float* ln_w, float* dz, float* parts, int B, int H, int W, int C,
+                      float eps, int patch2, hipStream_t st);
+int cnx_dwconv_dw_blocks(int B, int H, int W, int C);   // rows of the (blocks, 49, C) partial buffer
+int cnx_dwconv_dw_launch(const float* x, const float* dz, float* parts, int B, int H, int W, int C, hipStream_t st);
+int gelu_launch(const float* u, float* y, size_t n, hipStream_t st);
+int gelu_bwd_launch(const float* u, const float* dy, float* du, size_t n, hipStream_t st);
+int cnx_im2col4_launch(const float* x, float* out, int B, int H, int W, hipStream_t st);

@@ -90,10 +90,17 @@ class ConvNeXtExtractor(FeaturePyramidExtractor):
                     sd[f"stages.{int(i) // 2}.{int(i) % 2}.{rest}"] = v
             self.load_state_dict(sd, strict=True)
 
-    @torch.no_grad()
     def forward(self, raw_ctx: Context3d) -> FeaturePyramidContext:
-        """Channels-last forward on the HIP path.  (Inference / sampling only: the conditioner has no HIP backward; train it
-        through a torchvision module, or freeze it.)"""
+        """Channels-last forward on the HIP path.  With gradients enabled and trainable parameters it runs as autograd
+        Functions (autograd.convnext_pyramid: the reference trains the conditioner with the denoiser); otherwise the fused
+        inference sequence below."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from ..autograd import convnext_pyramid
+            return FeaturePyramidContext(features=convnext_pyramid(self, raw_ctx.image), K=raw_ctx.K)
+        with torch.no_grad():
+            return self._forward_inference(raw_ctx)
+
+    def _forward_inference(self, raw_ctx: Context3d) -> FeaturePyramidContext:
         lib = _lib.load()
         img = raw_ctx.image.float().contiguous()
         B, _, H, W = img.shape

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GECCO_ABI_VERSION 6
+#define GECCO_ABI_VERSION 7
 
 int gecco_abi_version(void);
 const char* gecco_build_arch(void);   /* "gfx950" */
@@ -473,6 +473,35 @@ int gecco_convnext_ln_patch2_f32(const float* x, const float* ln_w, const float*
                                  float eps, void* stream);
 /* Wo[n, k] = s[n] W[n, k], bo[n] = s[n] b[n] (CNBlock.layer_scale folded into its second linear) */
 int gecco_convnext_fold_scale_f32(const float* W, const float* b, const float* s, float* Wo, float* bo, int N, int K, void* stream);
+
+/* ---- the conditioner's TRAINING path.  The reference trains ConvNeXtExtractor with the denoiser (it is a sub-module of
+ * Diffusion: diffusion.py:203-222 optimises self.parameters(); feature_pyramid.py:55-59 only removes stochastic depth), so
+ * the pyramid gradient of gecco_ray_lookup_bwd_f32 continues through these.  The pointwise linears' dX / dW / db are the
+ * GEMM entries of the denoiser's training path (gecco_linear_ex_f32 on W^T, gecco_gemm_tn_x3_bias_f32, gecco_gemm_f32). */
+/* the two forward entries above that also keep z, the LayerNorm's input (same shape as out) */
+int gecco_convnext_stem_train_f32(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b, float* out,
+                                  float* z, int B, int H, int W, int C, float eps, void* stream);
+int gecco_convnext_dwconv_ln_train_f32(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b,
+                                       float* out, float* z, int B, int H, int W, int C, float eps, void* stream);
+/* out = dwconv7x7(x, padding 3) (+ bias when non-null), w tap-major (49, C).  With the taps reversed (w[48 - tap]) and dz as
+ * x this is the depthwise convolution's input gradient. */
+int gecco_convnext_dwconv_f32(const float* x, const float* w, const float* bias, float* out, int B, int H, int W, int C, void* stream);
+/* LayerNorm_C backward per texel from its input z (B, H, W, C) (statistics recomputed): dz, and per-block column partials
+ * parts (gecco_convnext_ln_bwd_blocks(B, H, W, C), 3, C) = [d ln_w | d ln_b | column sums of dz] (the last is the bias
+ * gradient of the convolution that produced z); reduce with gecco_reduce_batch_f32.  patch2 != 0: dy is laid out as the
+ * downsample GEMM's operand (B, H/2, W/2, (dy, dx, c)) — the backward of gecco_convnext_ln_patch2_f32. */
+int gecco_convnext_ln_bwd_blocks(int B, int H, int W, int C);
+int gecco_convnext_ln_bwd_f32(const float* z, const float* dy, const float* ln_w, float* dz, float* parts, int B, int H, int W, int C,
+                              float eps, int patch2, void* stream);
+/* depthwise 7 x 7 weight gradient, tap-major: parts (gecco_convnext_dwconv_dw_blocks(B, H, W, C), 49, C) per-block partials of
+ * dW[tap][c] = sum_texels dz[b, y, x, c] x[b, y + dy - 3, x + dx - 3, c] */
+int gecco_convnext_dwconv_dw_blocks(int B, int H, int W, int C);
+int gecco_convnext_dwconv_dw_f32(const float* x, const float* dz, float* parts, int B, int H, int W, int C, void* stream);
+/* y = GELU(u) (exact erf form, nn.GELU()) and du = dy GELU'(u) on n values (n % 4 == 0) */
+int gecco_gelu_f32(const float* u, float* y, size_t n, void* stream);
+int gecco_gelu_bwd_f32(const float* u, const float* dy, float* du, size_t n, void* stream);
+/* the stem's patch matrix (B H/4 W/4, 48), k = (ci, dy, dx) as in conv.weight.reshape(C, 48): its weight gradient is dz^T @ patches */
+int gecco_convnext_im2col4_f32(const float* x, float* out, int B, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

@@ -111,3 +111,104 @@ def test_conditional_diffusion_with_the_device_conditioner():
     print("image -> ConvNeXt -> lookup -> RayNetwork vs oracle:", e)
     assert e[0] < 1e-4, e
     assert torch.isfinite(smp).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw,B", [(64, 2), (96, 3), (224, 11)])
+def test_convnext_parameter_gradients_vs_oracle(hw, B):
+    """The conditioner's TRAINING path (the reference optimises it with the denoiser: diffusion.py:210-211 over
+    self.parameters()): gradients of sum_levels <features, R> with respect to every parameter, HIP autograd Functions
+    (autograd.convnext_pyramid) against torch autograd through the oracle's restatement.  224 x 224 x 11 images exercises the
+    multi-batch-per-block loops of the reduction kernels and ragged tails."""
+    import __graft_entry__ as ge
+    ge.build()
+    from gecco_amd import hip_ops
+    from gecco_amd.models.feature_pyramid import ConvNeXtExtractor
+    from gecco_amd.structs import Context3d
+    m = ConvNeXtExtractor(n_stages=3, model="tiny", pretrained=False)
+    sd = _seeded_state(m, 21)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    rs = np.random.RandomState(22)
+    img = torch.from_numpy(rs.rand(B, 3, hw, hw).astype(np.float32))
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = cpu_ref.convnext_features(img, p)
+    R = [torch.from_numpy(rs.randn(*f.shape).astype(np.float32)) for f in ref]
+    sum((f * r).sum() for f, r in zip(ref, R)).backward()
+    K = torch.eye(3).repeat(B, 1, 1)
+    old = hip_ops.default_precision()
+    try:
+        for precision, tol in (("fp32", 1e-4), ("bf16x3", 1e-3)):
+            hip_ops.set_default_precision(precision)
+            m.zero_grad(set_to_none=True)
+            out = m(Context3d(image=img.cuda(), K=K.cuda()))
+            for f, r in zip(out.features, ref):
+                assert f.shape == r.shape and f.requires_grad
+                assert cpu_ref.rel_err(f.detach().cpu(), r.detach())[0] < (2e-5 if precision == "fp32" else 2e-4)
+            sum((f * r.cuda()).sum() for f, r in zip(out.features, R)).backward()
+            worst = ("", 0.0)
+            for k, prm in m.named_parameters():
+                assert prm.grad is not None, k
+                e = cpu_ref.rel_err(prm.grad.cpu(), p[k].grad)[0]
+                if e > worst[1]:
+                    worst = (k, e)
+                assert e < tol, (precision, k, e)
+            print(f"convnext gradients {hw}x{hw} B={B} [{precision}]: worst {worst[0]} {worst[1]:.2e}")
+    finally:
+        hip_ops.set_default_precision(old)
+
+
+@pytest.mark.gpu
+def test_conditional_training_step_reaches_the_conditioner():
+    """training_step of the image-conditional model with a trainable conditioner: the loss and the conditioner's parameter
+    gradients against torch autograd through the oracle chain convnext_features -> cond_denoiser -> EDM loss."""
+    import __graft_entry__ as ge
+    ge.build()
+    from oracle import cases
+    from oracle import weights as Wt
+    from gecco_amd import hip_ops
+    from gecco_amd.models.feature_pyramid import ConvNeXtExtractor
+    from gecco_amd.structs import Context3d
+    from tests.test_modules_cpu import build_cond
+    d, L, N, hw, B = 128, 2, 128, 64, 2
+    cn = ConvNeXtExtractor(n_stages=3, model="tiny", pretrained=False)
+    csd = _seeded_state(cn, 9)
+    cn.load_state_dict(csd, strict=True)
+    m = build_cond(d, L, conditioner=cn)
+    p = Wt.ray_network_state_dict(17, d, L, cases.I, cases.H)
+    sd = {"backbone.model." + k: v for k, v in p.items()}
+    sd["reparam.uvl_mean"], sd["reparam.uvl_std"] = p["reparam.uvl_mean"], p["reparam.uvl_std"]
+    sd.update({"conditioner." + k: v for k, v in csd.items()})
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    rs = np.random.RandomState(3)
+    img = torch.from_numpy(rs.rand(B, 3, hw, hw).astype(np.float32))
+    _, K = Wt.synthetic_context(4, B, hw=hw)
+    data = torch.from_numpy((0.5 * rs.randn(B, N, 3)).astype(np.float32))
+    noise = torch.from_numpy(rs.randn(B, N, 3).astype(np.float32))
+    sigma = torch.tensor([0.3, 2.0])
+    cp = {k: v.clone().requires_grad_(True) for k, v in csd.items()}
+    feats = cpu_ref.convnext_features(img, cp)
+    D = cpu_ref.cond_denoiser(p, "", cases.H, K, feats)
+    s3 = sigma.reshape(-1, 1, 1)
+    ref_loss = (100.0 * (s3 ** 2 + 1.0) / s3 ** 2 * (D(data + noise * s3, sigma) - data) ** 2).mean()
+    ref_loss.backward()
+    old = hip_ops.default_precision()
+    try:
+        for precision, tol in (("fp32", 2e-4), ("bf16x3", 2e-3)):
+            hip_ops.set_default_precision(precision)
+            m.zero_grad(set_to_none=True)
+            s3c = s3.cuda()
+            den = m(data.cuda() + noise.cuda() * s3c, sigma.cuda(), Context3d(image=img.cuda(), K=K.cuda()))
+            loss = (100.0 * (s3c ** 2 + 1.0) / s3c ** 2 * (den - data.cuda()) ** 2).mean()
+            loss.backward()
+            lv, rv = float(loss.detach()), float(ref_loss.detach())
+            assert abs(lv - rv) / abs(rv) < 1e-4, (lv, rv)
+            worst = ("", 0.0)
+            for k, prm in m.conditioner.named_parameters():
+                e = cpu_ref.rel_err(prm.grad.cpu(), cp[k].grad)[0]
+                worst = max(worst, (k, e), key=lambda t: t[1])
+                assert e < tol, (precision, k, e)
+            print(f"conditional training step [{precision}]: loss {lv:.6f} (oracle {rv:.6f}), worst conditioner gradient {worst[0]} {worst[1]:.2e}")
+    finally:
+        hip_ops.set_default_precision(old)

@@ -330,8 +330,9 @@ def train_bench(args, rank, world, dev):
     Nt, Dt, Lt, cond = N, D, L, args.config in ("C3", "C4")
     if cond:
         # image-conditional training (BASELINE config C4: Taskonomy 256 x 256, N = 4096, d = 512, DDP; C3: 224 x 224, N = 2048,
-        # d = 384): RayNetwork + projective lookup trained through the HIP autograd path, the channels-last ConvNeXt
-        # conditioner frozen (it has no HIP backward) and evaluated inside every step like the reference's training_step
+        # d = 384): channels-last ConvNeXt conditioner + projective lookup + RayNetwork, ALL trained through the HIP autograd
+        # path like the reference's training_step (the conditioner is a sub-module of Diffusion: diffusion.py:210-211
+        # optimises self.parameters()); --freeze-conditioner evaluates it without gradients instead
         from gecco_amd.diffusion import Diffusion, EDMLoss, EDMPrecond, LogUniformSchedule
         from gecco_amd.models.activation import GaussianActivation
         from gecco_amd.models.feature_pyramid import ConvNeXtExtractor
@@ -346,7 +347,8 @@ def train_bench(args, rank, world, dev):
                                                  activation=GaussianActivation), reparam=rp, context_dims=(96, 192, 384))
         model = Diffusion(backbone=EDMPrecond(model=net), conditioner=ConvNeXtExtractor(pretrained=False), reparam=rp,
                           loss=EDMLoss(schedule=LogUniformSchedule(max=180.0))).to(dev).train()
-        model.conditioner.requires_grad_(False)
+        if args.freeze_conditioner:
+            model.conditioner.requires_grad_(False)
         K = torch.zeros(Bt, 3, 3)
         K[:, 0, 0] = K[:, 1, 1] = 1.1
         K[:, 0, 2] = K[:, 1, 2] = 0.5
@@ -395,7 +397,7 @@ def train_bench(args, rank, world, dev):
                      "fp16": "bf16 (split; the fp16 mode is not used for gradients)",
                      "mixed": "bf16 (split; the mixed mode trains in split-bf16)"}[args.precision],
            "data": "synthetic",
-           "config": {"workload": (f"{args.config} image-conditional training step (frozen channels-last ConvNeXt conditioner inside the step, "
+           "config": {"workload": (f"{args.config} image-conditional training step ({'frozen' if args.freeze_conditioner else 'trained'} channels-last ConvNeXt-T conditioner inside the step, "
                                    f"projective lookup, RayNetwork): batch {Bt}/GPU, N={Nt}, d={Dt}, L={Lt}" if cond else
                                    f"C2 unconditional training step: batch {Bt}/GPU, N={N}, d={D}, L={L}") +
                                   ": EDMLoss forward + backward (HIP autograd Functions), bucketed gradient all-reduce overlapped with "
@@ -564,6 +566,8 @@ def main():
     ap.add_argument("--train", action="store_true", help="time the data-parallel training step instead of the forward")
     ap.add_argument("--train-batch", type=int, default=48, help="per-GPU batch of --train (shipped config: 48)")
     ap.add_argument("--bucket-mb", type=int, default=8, help="gradient all-reduce bucket size of --train")
+    ap.add_argument("--freeze-conditioner", action="store_true",
+                    help="--train --config C3|C4: evaluate the ConvNeXt conditioner without gradients (the reference trains it)")
     ap.add_argument("--selftest-launcher", action="store_true", help="N-rank plumbing on gloo with a stand-in step (no GPU)")
     args = ap.parse_args()
 

@@ -91,9 +91,9 @@ def _linear_dw(dy: Tensor, x: Tensor, want_db: bool = False):
             dy, x = dy.view(g, R // g, Nout), x.view(g, R // g, K)
             B, R = g, R // g
     if want_db:
-        if not (_train_precision() == "bf16x3" and R % 32 == 0 and Nout % 128 == 0 and K % 128 == 0):
+        if not (_train_precision() == "bf16x3" and R % 32 == 0 and Nout % 4 == 0 and K % 4 == 0):
             return _linear_dw(dy, x), _linear_db(dy)
-        tiles = (Nout // 128) * (K // 128)
+        tiles = -(-Nout // 128) * -(-K // 128)
         G = min(B, max(1, -(-1024 // tiles)))
         group = -(-B // G)
         G = -(-B // group)
@@ -101,10 +101,10 @@ def _linear_dw(dy: Tensor, x: Tensor, want_db: bool = False):
         _lib.check(_lib.load().gecco_gemm_tn_x3_bias_f32(_ptr(dy), _ptr(x), _ptr(parts), _ptr(cparts), B, R, Nout, K, group,
                                                          _stream()), "gecco_gemm_tn_x3_bias_f32")
         return _reduce(parts, Nout * K, G, Nout * K).reshape(Nout, K), _reduce(cparts, Nout, G, Nout)
-    if _train_precision() == "bf16x3" and R % 32 == 0 and Nout % 128 == 0 and K % 128 == 0:
+    if _train_precision() == "bf16x3" and R % 32 == 0 and Nout % 4 == 0 and K % 4 == 0:
         # split-bf16 MFMA with transposed LDS reads (gemm_tn_x3.hip); one partial per group of samples, groups
         # sized so that ~1000 blocks fill the chip
-        tiles = (Nout // 128) * (K // 128)
+        tiles = -(-Nout // 128) * -(-K // 128)
         G = min(B, max(1, -(-1024 // tiles)))
         group = -(-B // G)
         G = -(-B // group)
@@ -530,15 +530,25 @@ class LookupFn(torch.autograd.Function):
         _no_input_grad(ctx, 0, "the geometry")
         _no_input_grad(ctx, 1, "the camera matrix")
         geom, K, *levels = ctx.saved_tensors
+        if not any(ctx.needs_input_grad[3:]):
+            return (None,) * (3 + len(levels))   # a frozen (or foreign, detached) conditioner: nothing to compute
         dout = _f(dout)
         lib = _lib.load()
         B, N, _ = geom.shape
         rp = hip_ops.make_reparam(*ctx.spec)
         pyr = hip_ops.make_pyramid(levels)
-        grads = [torch.zeros_like(f) for f in levels]   # (B, H, W, C)
-        arr = (C.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
-        _lib.check(lib.gecco_ray_lookup_bwd_f32(_ptr(geom), None, _ptr(K), C.byref(rp), C.byref(pyr), _ptr(dout), arr, B, N,
-                                                _stream()), "gecco_ray_lookup_bwd_f32")
+        nb = lib.gecco_ray_lookup_bwd_sorted_workspace_bytes(C.byref(pyr), B, N) if os.environ.get("GECCO_LOOKUP_BWD", "sorted") == "sorted" else 0
+        if nb:   # sort + gather: no atomics, fixed summation order, every texel written
+            grads = [torch.empty_like(f) for f in levels]   # (B, H, W, C)
+            arr = (C.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
+            ws = hip_ops._ws(nb, geom.device)
+            _lib.check(lib.gecco_ray_lookup_bwd_sorted_f32(_ptr(geom), None, _ptr(K), C.byref(rp), C.byref(pyr), _ptr(dout), arr, B, N,
+                                                           C.c_void_p(ws.data_ptr()), nb, _stream()), "gecco_ray_lookup_bwd_sorted_f32")
+        else:    # more than 4096 points per cloud: float atomics, like torch's grid_sampler backward
+            grads = [torch.zeros_like(f) for f in levels]
+            arr = (C.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
+            _lib.check(lib.gecco_ray_lookup_bwd_f32(_ptr(geom), None, _ptr(K), C.byref(rp), C.byref(pyr), _ptr(dout), arr, B, N,
+                                                    _stream()), "gecco_ray_lookup_bwd_f32")
         # handed back NCHW-shaped (channels-last strides, no copy)
         return (None, None, None, *[g.permute(0, 3, 1, 2) for g in grads])
 

@@ -668,7 +668,7 @@ int gecco_gemm_tn_x3_bias_f32(const float* A, const float* Bm, float* parts, flo
     TnArgs g{};
     g.A = A; g.Bm = Bm; g.C = parts; g.Z = Z; g.R = R; g.N = N; g.K = K; g.lda = N; g.ldb = K;
     g.sA = (size_t)R * N; g.sB = (size_t)R * K; g.group = group; g.colsum = colsum_parts;
-    if (!gemm_tn_x3_supported(g)) return fail(-2, "gemm_tn_x3: needs R %% 32 == 0, N %% 128 == 0, K %% 128 == 0, group > 0");
+    if (!gemm_tn_x3_supported(g)) return fail(-2, "gemm_tn_x3: needs R %% 32 == 0, N %% 4 == 0, K %% 4 == 0, group > 0");
     TRY(gemm_tn_x3_launch(g, (hipStream_t)stream), "gemm_tn_x3");
     return 0;
 }
@@ -972,6 +972,26 @@ int gecco_ray_lookup_bwd_f32(const float* geom, const float* coef, const float* 
     for (int l = 0; l < a.n_levels; ++l)
         if (!dfeat[l]) return fail(-1, "ray_lookup_bwd: null gradient level");
     TRY(ray_lookup_bwd_launch(geom, coef, K, a, dfeat, dout, B, N, (hipStream_t)stream), "ray_lookup_bwd");
+    return 0;
+}
+
+size_t gecco_ray_lookup_bwd_sorted_workspace_bytes(const GeccoPyramid* pyr, int B, int N) {
+    LookupArgs a;
+    if (!pyr || make_lookup_args(nullptr, pyr, &a) || !ray_lookup_bwd_sorted_supported(a, N)) return 0;
+    return ray_lookup_bwd_sorted_ws_bytes(a, B, N);
+}
+int gecco_ray_lookup_bwd_sorted_f32(const float* geom, const float* coef, const float* K, const GeccoReparam* rp,
+                                    const GeccoPyramid* pyr, const float* dout, float* const* dfeat, int B, int N, void* ws,
+                                    size_t ws_bytes, void* stream) {
+    if (!geom || !K || !dout || !dfeat || !pyr || !ws) return fail(-1, "ray_lookup_bwd_sorted: null argument");
+    LookupArgs a;
+    int rc = make_lookup_args(rp, pyr, &a);
+    if (rc) return rc;
+    for (int l = 0; l < a.n_levels; ++l)
+        if (!dfeat[l]) return fail(-1, "ray_lookup_bwd_sorted: null gradient level");
+    if (!ray_lookup_bwd_sorted_supported(a, N)) return fail(-2, "ray_lookup_bwd_sorted: needs N <= 4096 and H W <= 2^17 per level");
+    if (ws_bytes < ray_lookup_bwd_sorted_ws_bytes(a, B, N)) return fail(-3, "ray_lookup_bwd_sorted: workspace too small");
+    TRY(ray_lookup_bwd_sorted_launch(geom, coef, K, a, dfeat, dout, B, N, ws, (hipStream_t)stream), "ray_lookup_bwd_sorted");
     return 0;
 }
 

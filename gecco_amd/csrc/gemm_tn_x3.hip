@@ -50,8 +50,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(TnArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wk = wave & 1;
     const int r = lane & 31, h = lane >> 5;
-    const int tilesK = g.K / 128;
+    const int tilesK = (g.K + 127) / 128;
     const int n0 = (blockIdx.x / tilesK) * 128, k0 = (blockIdx.x % tilesK) * 128;
+    // N, K need not fill the last tile (the conditioner's 96 / 192 / 48 / 672-wide layers): a thread's four columns are the
+    // same in every step, so one predicate per operand zero-fills what lies beyond the matrix
+    const bool aok = n0 + (tid & 31) * 4 < g.N, bok = k0 + (tid & 31) * 4 < g.K;
     const int z0 = blockIdx.y * g.group, z1 = min(g.Z, z0 + g.group);
     const int msteps = g.R / 32, nsteps = (z1 - z0) * msteps;
 
@@ -64,8 +67,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(TnArgs g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int f = tid + i * 256, row = f >> 5, c4 = f & 31;
-            ra[i] = *reinterpret_cast<const f32x4*>(Ab + (size_t)row * g.lda + c4 * 4);
-            rb[i] = *reinterpret_cast<const f32x4*>(Bb + (size_t)row * g.ldb + c4 * 4);
+            ra[i] = aok ? *reinterpret_cast<const f32x4*>(Ab + (size_t)row * g.lda + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            rb[i] = bok ? *reinterpret_cast<const f32x4*>(Bb + (size_t)row * g.ldb + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     // bias gradient = column sums of dY: the blocks of the first K tile add up the rows they stage anyway
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(TnArgs g) {
         f32x4* red = reinterpret_cast<f32x4*>(smem);
         red[tid] = cs;
         __syncthreads();
-        if (tid < 32) {
+        if (tid < 32 && n0 + tid * 4 < g.N) {
             f32x4 s = red[tid];
 #pragma unroll
             for (int j = 1; j < 8; ++j) s += red[tid + 32 * j];
@@ -148,14 +151,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(TnArgs g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
-                Cb[(size_t)(n0 + wn * 64 + i * 32 + mfma_row(e, h)) * g.K + k0 + wk * 64 + j * 32 + r] = acc[i][j][e];
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + wn * 64 + i * 32 + mfma_row(e, h), k = k0 + wk * 64 + j * 32 + r;
+                if (n < g.N && k < g.K) Cb[(size_t)n * g.K + k] = acc[i][j][e];
+            }
 }
 
 }  // namespace
 
 bool gemm_tn_x3_supported(const TnArgs& g) {
-    return g.Z > 0 && g.group > 0 && g.R >= 32 && g.R % 32 == 0 && g.N % 128 == 0 && g.K % 128 == 0 && !(g.lda & 3) &&
+    return g.Z > 0 && g.group > 0 && g.R >= 32 && g.R % 32 == 0 && g.N > 0 && g.K > 0 && !(g.N & 3) && !(g.K & 3) && !(g.lda & 3) &&
            !(g.ldb & 3);
 }
 
@@ -169,6 +174,6 @@ int gemm_tn_x3_launch(const TnArgs& g, hipStream_t st) {
                                   (int)lds);
         attr = true;
     }
-    hipLaunchKernelGGL(gemm_tn_x3_kernel, dim3((g.N / 128) * (g.K / 128), G), dim3(256), lds, st, g);
+    hipLaunchKernelGGL(gemm_tn_x3_kernel, dim3(((g.N + 127) / 128) * ((g.K + 127) / 128), G), dim3(256), lds, st, g);
     return (int)hipGetLastError();
 }

@@ -214,6 +214,11 @@ int ray_lookup_launch(const float* geom, const float* coef, const float* K, cons
                       float* stats, int B, int N, hipStream_t st);
 int ray_lookup_bwd_launch(const float* geom, const float* coef, const float* K, const LookupArgs& a,
                           float* const* dfeat, const float* dout, int B, int N, hipStream_t st);   // dfeat: zeroed, NHWC
+// the same gradient by sort + gather (no atomics, fixed summation order, dfeat fully written: no zero fill needed)
+bool ray_lookup_bwd_sorted_supported(const LookupArgs& a, int N);
+size_t ray_lookup_bwd_sorted_ws_bytes(const LookupArgs& a, int B, int N);
+int ray_lookup_bwd_sorted_launch(const float* geom, const float* coef, const float* K, const LookupArgs& a, float* const* dfeat,
+                                 const float* dout, int B, int N, void* ws, hipStream_t st);
 int bilinear_taps_launch(const float* uv, int Hh, int Ww, int* x0, int* y0, float* wx1, float* wy1, size_t n,
                          hipStream_t st);
 int nchw_to_nhwc_launch(const float* src, float* dst, int B, int C, int Hh, int Ww, hipStream_t st);

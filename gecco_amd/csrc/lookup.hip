@@ -227,6 +227,133 @@ __global__ __launch_bounds__(256) void ray_lookup_bwd_kernel(const float* __rest
     }
 }
 
+// ---- the same gradient WITHOUT float atomics: sort, then gather.
+// The atomic form issues 4 taps x sum(C_l) device-scope float atomics per point (264 M at B = 48, N = 2048, 672 channels:
+// 3.3 ms, 80 G atomics/s — the rate of the memory-side atomic units, since the blocks of one image run on all XCDs).  Here
+// one block per (image, level) builds the 4 N (texel, point, tap) entries, sorts them by texel in LDS (bitonic, key =
+// texel << 14 | entry: ties keep point order, so the summation order is FIXED — this gradient is bit-reproducible too), and
+// writes the entry list, the tap weights and the per-texel list starts; a second kernel gives every texel C_l / 4 threads
+// that walk the texel's list and gather w * dout rows: every texel is written exactly once (no zero fill, no atomics).
+constexpr int SORT_NT = 512;
+constexpr unsigned SORT_INVALID = 0xffffffffu;
+
+struct LookupSortWs {
+    int* ent;      // (B, L, P) sorted entry ids (4 m + tap); the first start[HW] are valid
+    float* wts;    // (B, L, P) tap weight per entry id
+    int* start;    // (B, L, SW) list start per texel (HW_l + 1 used)
+    int P, SW;
+};
+
+__global__ __launch_bounds__(SORT_NT) void lookup_sort_kernel(const float* __restrict__ geom, const float* __restrict__ coef,
+                                                               const float* __restrict__ K, LookupArgs a, LookupSortWs ws,
+                                                               int N) {
+    extern __shared__ unsigned skeys[];   // P
+    const int l = blockIdx.x % a.n_levels, b = blockIdx.x / a.n_levels;
+    const int P = ws.P, Hh = a.H[l], Ww = a.W[l], HW = Hh * Ww;
+    const float cin = coef ? coef[4 * b + 2] : 1.0f;
+    const float* Kb = K + (size_t)b * 9;
+    float* wts = ws.wts + ((size_t)b * a.n_levels + l) * P;
+    int* ent = ws.ent + ((size_t)b * a.n_levels + l) * P;
+    int* start = ws.start + ((size_t)b * a.n_levels + l) * ws.SW;
+    for (int m = threadIdx.x; m < P / 4; m += SORT_NT) {
+        unsigned key[4] = {SORT_INVALID, SORT_INVALID, SORT_INVALID, SORT_INVALID};
+        float w[4] = {0.f, 0.f, 0.f, 0.f};
+        if (m < N) {
+            const float* gp = geom + ((size_t)b * N + m) * 3;
+            float u, v;
+            project_uv(cin * gp[0], cin * gp[1], cin * gp[2], Kb, a.reparam_kind, a.rp_mean, a.rp_std, a.logit_scale, u, v);
+            const Taps t = bilinear_taps(u, v, Hh, Ww);
+            const int x1 = t.x0 + 1, y1 = t.y0 + 1;
+            const float wx0 = (float)x1 - t.ix, wy0 = (float)y1 - t.iy;
+            const float wx1 = t.ix - (float)t.x0, wy1 = t.iy - (float)t.y0;
+            const bool bx0 = t.x0 >= 0 && t.x0 <= Ww - 1, bx1 = x1 >= 0 && x1 <= Ww - 1;
+            const bool by0 = t.y0 >= 0 && t.y0 <= Hh - 1, by1 = y1 >= 0 && y1 <= Hh - 1;
+            const bool ok[4] = {bx0 && by0, bx1 && by0, bx0 && by1, bx1 && by1};
+            const int tx[4] = {t.x0, x1, t.x0, x1}, ty[4] = {t.y0, t.y0, y1, y1};
+            const float ww[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (ok[q]) {
+                    key[q] = ((unsigned)(ty[q] * Ww + tx[q]) << 14) | (unsigned)(4 * m + q);
+                    w[q] = ww[q];
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            skeys[4 * m + q] = key[q];
+            wts[4 * m + q] = w[q];
+        }
+    }
+    __syncthreads();
+    for (unsigned k = 2; k <= (unsigned)P; k <<= 1)
+        for (unsigned j = k >> 1; j > 0; j >>= 1) {
+            for (unsigned i = threadIdx.x; i < (unsigned)P; i += SORT_NT) {
+                const unsigned o = i ^ j;
+                if (o > i) {
+                    const unsigned x = skeys[i], y = skeys[o];
+                    if ((x > y) == ((i & k) == 0)) {
+                        skeys[i] = y;
+                        skeys[o] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    // entry list + list starts: position i opens the lists of the texels (t_prev, t_i] (empty ones included)
+    for (int i = threadIdx.x; i < P; i += SORT_NT) {
+        const unsigned key = skeys[i];
+        const int ti = key == SORT_INVALID ? HW : (int)(key >> 14);
+        int tp = -1;
+        if (i > 0) {
+            const unsigned kp = skeys[i - 1];
+            tp = kp == SORT_INVALID ? HW : (int)(kp >> 14);
+        }
+        if (key != SORT_INVALID) ent[i] = (int)(key & 0x3fffu);
+        for (int t = tp + 1; t <= ti; ++t) start[t] = i;
+        if (i == P - 1 && key != SORT_INVALID)
+            for (int t = ti + 1; t <= HW; ++t) start[t] = P;
+    }
+}
+
+// dfeat[l][b, t, :] = sum over the texel's entries of w * dout[b, m, off_l : off_l + C_l];  C_l / 4 threads per texel
+__global__ __launch_bounds__(256) void lookup_gather_bwd_kernel(const float* __restrict__ dout, LookupSortWs ws, float* __restrict__ dfeat,
+                                                                int l, int n_levels, int HW, int Cl, int coff, int Ct, int N,
+                                                                size_t ntasks) {
+    const int tpt = Cl / 4, per = 256 / tpt;
+    const int tk = threadIdx.x / tpt, c = (threadIdx.x % tpt) * 4;
+    const size_t task = (size_t)blockIdx.x * per + tk;
+    if (tk >= per || task >= ntasks) return;
+    const int t = (int)(task % HW);
+    const size_t b = task / HW;
+    const size_t wb = (b * n_levels + l) * ws.P;
+    const int* ent = ws.ent + wb;
+    const float* wts = ws.wts + wb;
+    const int* start = ws.start + (b * n_levels + l) * ws.SW;
+    const int s = start[t], e = start[t + 1];
+    const float* gb = dout + b * N * (size_t)Ct + coff + c;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int i = s;
+    for (; i + 4 <= e; i += 4) {   // four independent gathers in flight, added in list order
+        int en[4];
+        f32x4 g[4];
+        float w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) en[q] = ent[i + q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            w[q] = wts[en[q]];
+            g[q] = *reinterpret_cast<const f32x4*>(gb + (size_t)(en[q] >> 2) * Ct);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc += g[q] * w[q];
+    }
+    for (; i < e; ++i) {
+        const int en = ent[i];
+        acc += *reinterpret_cast<const f32x4*>(gb + (size_t)(en >> 2) * Ct) * wts[en];
+    }
+    *reinterpret_cast<f32x4*>(dfeat + task * Cl + c) = acc;
+}
+
 // integer tap indices + fractional weights for given uv (the bit-exact part, testable in isolation)
 __global__ void bilinear_taps_kernel(const float* __restrict__ uv, int Hh, int Ww, int* __restrict__ x0,
                                      int* __restrict__ y0, float* __restrict__ wx1, float* __restrict__ wy1, size_t n) {
@@ -280,6 +407,55 @@ int ray_lookup_bwd_launch(const float* geom, const float* coef, const float* K, 
     for (int l = 0; l < 4; ++l) gr.d[l] = l < a.n_levels ? dfeat[l] : nullptr;
     const int T = (N + LOOKUP_ROWS - 1) / LOOKUP_ROWS;
     hipLaunchKernelGGL(ray_lookup_bwd_kernel, dim3(B * T), dim3(256), 0, st, geom, coef, K, a, gr, dout, N, T);
+    return (int)hipGetLastError();
+}
+
+// sorted form: N <= 4096 points, H W <= 2^17 texels per level, C_l % 4 == 0 and C_l <= 1024
+static int sort_P(int N) {
+    int P = 1024;
+    while (P < 4 * N) P <<= 1;
+    return P;
+}
+static int sort_SW(const LookupArgs& a) {
+    int m = 0;
+    for (int l = 0; l < a.n_levels; ++l) m = std::max(m, a.H[l] * a.W[l]);
+    return (m + 1 + 3) & ~3;
+}
+bool ray_lookup_bwd_sorted_supported(const LookupArgs& a, int N) {
+    if (N < 1 || N > 4096 || a.n_levels < 1 || a.n_levels > 4) return false;
+    for (int l = 0; l < a.n_levels; ++l)
+        if ((size_t)a.H[l] * a.W[l] > (1u << 17) || (a.C[l] & 3) || a.C[l] > 1024) return false;
+    return true;
+}
+size_t ray_lookup_bwd_sorted_ws_bytes(const LookupArgs& a, int B, int N) {
+    const size_t per = (size_t)B * a.n_levels;
+    return per * sort_P(N) * 8 + per * sort_SW(a) * 4;
+}
+int ray_lookup_bwd_sorted_launch(const float* geom, const float* coef, const float* K, const LookupArgs& a, float* const* dfeat,
+                                 const float* dout, int B, int N, void* wsp, hipStream_t st) {
+    if (!ray_lookup_bwd_sorted_supported(a, N)) return -8;
+    LookupSortWs ws;
+    ws.P = sort_P(N);
+    ws.SW = sort_SW(a);
+    const size_t per = (size_t)B * a.n_levels;
+    ws.ent = static_cast<int*>(wsp);
+    ws.wts = reinterpret_cast<float*>(ws.ent + per * ws.P);
+    ws.start = reinterpret_cast<int*>(ws.wts + per * ws.P);
+    const size_t lds = (size_t)ws.P * sizeof(unsigned);
+    static size_t attr = 0;
+    if (lds > attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lookup_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = lds;
+    }
+    hipLaunchKernelGGL(lookup_sort_kernel, dim3(B * a.n_levels), dim3(SORT_NT), lds, st, geom, coef, K, a, ws, N);
+    int coff = 0;
+    for (int l = 0; l < a.n_levels; ++l) {
+        const int HW = a.H[l] * a.W[l], per_blk = 256 / (a.C[l] / 4);
+        const size_t ntasks = (size_t)B * HW;
+        hipLaunchKernelGGL(lookup_gather_bwd_kernel, dim3((unsigned)((ntasks + per_blk - 1) / per_blk)), dim3(256), 0, st, dout, ws, dfeat[l],
+                           l, a.n_levels, HW, a.C[l], coff, a.c_total, N, ntasks);
+        coff += a.C[l];
+    }
     return (int)hipGetLastError();
 }
 

@@ -306,6 +306,14 @@ int gecco_lookup_row_tiles(int N);
 int gecco_ray_lookup_bwd_f32(const float* geom, const float* coef, const float* K, const GeccoReparam* rp,
                              const GeccoPyramid* pyr, const float* dout, float* const* dfeat, int B, int N,
                              void* stream);
+/* The same gradient by SORT + GATHER: per (image, level) the 4 N (texel, point, tap) entries are sorted by texel in LDS, then
+ * every texel's threads walk its list — no atomics, a fixed summation order (bit-reproducible), and every texel of dfeat is
+ * WRITTEN (no zero fill).  Needs N <= 4096 and H_l W_l <= 2^17 (gecco_ray_lookup_bwd_sorted_workspace_bytes returns 0
+ * otherwise: use the atomic form); ws: that many bytes of scratch. */
+size_t gecco_ray_lookup_bwd_sorted_workspace_bytes(const GeccoPyramid* pyr, int B, int N);
+int gecco_ray_lookup_bwd_sorted_f32(const float* geom, const float* coef, const float* K, const GeccoReparam* rp,
+                                    const GeccoPyramid* pyr, const float* dout, float* const* dfeat, int B, int N, void* ws,
+                                    size_t ws_bytes, void* stream);
 
 typedef struct GeccoRayNetwork {  /* EDMPrecond(RayNetwork(SetTransformer, reparam)), models/ray.py:33-120 */
     GeccoSetTransformer backbone;
@@ -374,7 +382,7 @@ int gecco_gemm_f32(const GeccoGemm* g, void* stream);
 /* Weight gradient of a linear in split-bf16 arithmetic (training path; autograd of every nn.Linear on the point stream):
  * parts[g] = sum over the samples z of group g of A[z]^T @ B[z], A (Z, R, N) = dY, B (Z, R, K) = X, parts
  * (ceil(Z / group), N, K); dW = gecco_reduce_batch_f32 over the groups (fixed order: bit-reproducible).
- * R % 32 == 0, N % 128 == 0, K % 128 == 0. */
+ * R % 32 == 0, N % 4 == 0, K % 4 == 0 (128 x 128 output tiles; the last tile of a dimension may be partial). */
 int gecco_gemm_tn_x3_f32(const float* A, const float* Bm, float* parts, int Z, int R, int N, int K, int group, void* stream);
 /* the same, also leaving colsum_parts[g] (ceil(Z / group), N) = column sums of A over the group's rows: the bias gradient
  * db = sum_rows dY comes out of the pass that reads dY for dW (colsum_parts may be NULL) */

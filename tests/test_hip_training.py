@@ -112,13 +112,15 @@ def test_linear_fn_residual_and_pair_grads(rows, precision):
         _close(a, b)
 
 
-def test_split_bf16_weight_gradient_kernel():
+@pytest.mark.parametrize("N,K", [(256, 384), (96, 384), (384, 96), (192, 768), (96, 48), (384, 672), (4, 132)])
+def test_split_bf16_weight_gradient_kernel(N, K):
     """dW = dY^T X with transposed LDS reads and 3 bf16 MFMAs per product (gemm_tn_x3.hip) against fp64, operands
-    spanning orders of magnitude; and through LinearFn in the split-bf16 training mode (grouped partials, fixed order)."""
+    spanning orders of magnitude; and through LinearFn in the split-bf16 training mode (grouped partials, fixed order).
+    Shapes: the denoiser's (multiples of 128) and the conditioner's 96 / 192 / 48 / 672-wide layers (partial edge tiles)."""
     import ctypes as C
     from gecco_amd import _lib, autograd as ag, hip_ops
     rs = np.random.RandomState(7)
-    Z, R, N, K = 5, 256, 256, 384
+    Z, R = 5, 256
     dy = _t(rs.randn(Z, R, N) * np.exp(rs.uniform(-6, 2, size=(Z, R, 1))))
     x = _t(rs.randn(Z, R, K))
     ref = torch.einsum("zrn,zrk->nk", dy.double(), x.double())
@@ -126,7 +128,7 @@ def test_split_bf16_weight_gradient_kernel():
     dyc, xc = dy.cuda(), x.cuda()
     for group in (1, 2, 5):
         G = -(-Z // group)
-        parts = torch.empty(G, N, K, device="cuda")
+        parts = torch.full((G, N, K), float("nan"), device="cuda")
         _lib.check(lib.gecco_gemm_tn_x3_f32(C.c_void_p(dyc.data_ptr()), C.c_void_p(xc.data_ptr()),
                                             C.c_void_p(parts.data_ptr()), Z, R, N, K, group, None), "gemm_tn_x3")
         got = parts.double().sum(0).cpu()
@@ -135,13 +137,14 @@ def test_split_bf16_weight_gradient_kernel():
     prev = hip_ops.default_precision()
     try:
         hip_ops.set_default_precision("bf16x3")
-        xg, Wg = _leaf(x, "cuda"), _leaf(_t(rs.randn(N, K) / 20), "cuda")
-        y = ag.LinearFn.apply(xg, Wg, None)
+        xg, Wg, bg = _leaf(x, "cuda"), _leaf(_t(rs.randn(N, K) / 20), "cuda"), _leaf(_t(rs.randn(N)), "cuda")
+        y = ag.LinearFn.apply(xg, Wg, bg)
         y.backward(dy.cuda())
         _close(Wg.grad, ref.float(), 1e-4)
+        _close(bg.grad, dy.double().sum((0, 1)).float(), 1e-5)   # the bias gradient out of the same pass
         g1 = Wg.grad.clone()
         Wg.grad = None
-        ag.LinearFn.apply(xg, Wg, None).backward(dy.cuda())
+        ag.LinearFn.apply(xg, Wg, bg).backward(dy.cuda())
         assert torch.equal(g1, Wg.grad)   # bit-reproducible
     finally:
         hip_ops.set_default_precision(prev)
@@ -315,6 +318,47 @@ def test_lookup_fn_grads():
     for a, b in zip(fg, fr):
         assert a.grad.shape == b.grad.shape
         _close(a.grad, b.grad, 1e-4)
+
+
+@pytest.mark.parametrize("N,hw", [(1000, 24), (2048, 56), (4096, 64), (5000, 16)])
+def test_lookup_backward_sort_gather_form(N, hw, monkeypatch):
+    """The pyramid gradient by sort + gather (csrc/lookup.hip: no atomics) against torch autograd through the oracle's
+    grid_sample restatement and against the atomic form: clustered clouds (long per-texel lists), points projecting outside the
+    image (dropped taps), texels nobody touches (must be written as zero: the buffers are not pre-filled), N that is not a
+    power of two; two runs agree bit for bit.  N = 5000 is beyond the sorted form's bound: the atomic form takes over."""
+    from gecco_amd.autograd import LookupFn
+    rs = np.random.RandomState(N)
+    B, dims = 3, (96, 192, 384)
+    feats = [_t(rs.randn(B, c, hw >> i, hw >> i)) for i, c in enumerate(dims)]
+    geom = rs.randn(B, N, 3).astype(np.float32)
+    geom[0] *= 0.05                                   # sample 0: everything lands on a few texels
+    geom[1, : N // 4, :2] *= 4.0                      # sample 1: a quarter of the points outside the image
+    geom = _t(geom)
+    K = torch.tensor([[1.1, 0.0, 0.5], [0.0, 1.1, 0.5], [0.0, 0.0, 1.0]]).repeat(B, 1, 1)
+    um, us = torch.tensor([0.0, 0.0, 1.38]), torch.tensor([0.56, 0.60, 0.49])
+    fr = [_leaf(f) for f in feats]
+    ref = cpu_ref.extract_image_features(geom, fr, K, um, us)
+    g = _t(rs.randn(*ref.shape))
+    ref.backward(g)
+
+    def run():
+        fg = [_leaf(f.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2), "cuda") for f in feats]   # channels-last leaves
+        out = LookupFn.apply(geom.cuda(), K.cuda(), (2, um.cuda(), us.cuda(), 1.1), *fg)
+        torch.full((1 << 24,), float("nan"), device="cuda")          # poison freed memory the next allocations may reuse
+        out.backward(g.cuda())
+        return [a.grad.clone() for a in fg]
+
+    first, second = run(), run()
+    monkeypatch.setenv("GECCO_LOOKUP_BWD", "atomic")
+    atomic = run()
+    for a, a2, at, b in zip(first, second, atomic, fr):
+        assert a.shape == b.grad.shape and torch.isfinite(a).all()
+        _close(a, b.grad, 1e-4)
+        _close(a, at.cpu(), 1e-5)
+        if N <= 4096:
+            assert torch.equal(a, a2)
+        assert (b.grad == 0).any()                    # the case really has untouched texels
+        assert torch.equal(a.cpu() == 0, b.grad == 0) or cpu_ref.rel_err(a.cpu(), b.grad)[0] < 1e-5
 
 
 def test_conditional_edm_loss_and_gradients_golden(golden_dir):

@@ -85,8 +85,10 @@ def _linear_dw(dy: Tensor, x: Tensor, want_db: bool = False):
     B, R, K = x.shape
     Nout = dy.shape[2]
     if B == 1 and R >= 4096:
-        # one long row block (the conditioner's texel matrix): cut it into groups for the per-group partials below
-        g = max((d for d in range(1, 65) if R % (32 * d) == 0), default=1)
+        # one long row block (the conditioner's texel matrix): cut it into groups for the per-group partials below — enough of
+        # them that groups x output tiles fill the chip (a 96 x 384 gradient has three tiles)
+        cap = max(64, 768 // (-(-Nout // 128) * -(-K // 128)))
+        g = max((d for d in range(1, cap + 1) if R % (32 * d) == 0), default=1)
         if g > 1:
             dy, x = dy.view(g, R // g, Nout), x.view(g, R // g, K)
             B, R = g, R // g
@@ -613,7 +615,7 @@ class CnxStemFn(torch.autograd.Function):
         patches = _new(B, h * w_, 48, like=z)
         _lib.check(_lib.load().gecco_convnext_im2col4_f32(_ptr(img), _ptr(patches), B, img.shape[2], img.shape[3], _stream()),
                    "gecco_convnext_im2col4_f32")
-        dW = _linear_dw(dz.view(B, h * w_, Cc), patches).reshape(Cc, 3, 4, 4)
+        dW = _linear_dw(dz.view(1, B * h * w_, Cc), patches.view(1, B * h * w_, 48)).reshape(Cc, 3, 4, 4)
         return None, dW, dbias, dg, dbl, None
 
 

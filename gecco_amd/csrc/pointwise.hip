@@ -65,21 +65,41 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict_
 //   a[b,c] = s * rstd,  o[b,c] = z - s * mean * rstd
 // With null scale/bias weights: plain GroupNorm(affine=False) (GroupNormBNC, models/ray.py:20-30).
 // Partial sums are fp32 per tile, combined in fp64 (E[x^2] - mean^2 cancellation stays < 1e-7).
-__global__ __launch_bounds__(256) void adagn_coeffs_kernel(const float* __restrict__ stats, int T, int rows,
-                                                           const float* __restrict__ t, int ctx_dim,
-                                                           const float* __restrict__ scale_w,
-                                                           const float* __restrict__ scale_b,
-                                                           const float* __restrict__ bias_w,
-                                                           const float* __restrict__ bias_b, float* __restrict__ a,
-                                                           float* __restrict__ o, int C, int G, float eps) {
-    extern __shared__ double dsm[];  // [2][C] column sums, then [2][G] mean / rstd
+__global__ __launch_bounds__(1024) void adagn_coeffs_kernel(const float* __restrict__ stats, int T, int rows,
+                                                            const float* __restrict__ t, int ctx_dim,
+                                                            const float* __restrict__ scale_w,
+                                                            const float* __restrict__ scale_b,
+                                                            const float* __restrict__ bias_w,
+                                                            const float* __restrict__ bias_b, float* __restrict__ a,
+                                                            float* __restrict__ o, int C, int G, float eps, int nsl) {
+    extern __shared__ double dsm[];  // [2][C] column sums, [2][G] mean / rstd, [nsl][2][C] slice sums
     double* cs = dsm;
     double* gm = dsm + 2 * C;
+    double* ps = gm + 2 * G;
     const int b = blockIdx.x;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    // the T tile partials of a column are cut into nsl slices summed by different threads (a cached upsample has 128 tiles per
+    // sample and 8 samples: one thread per column walked them in 16 dependent round trips), 16 loads in flight per round
+    // trip; slices are combined in slice order: a fixed summation order for a given (T, nsl)
+    const int per = (T + nsl - 1) / nsl;
+    for (int i = threadIdx.x; i < nsl * C; i += blockDim.x) {
+        const int sl = i / C, c = i % C;
+        const int k0 = sl * per, k1 = min(T, k0 + per);
         double s1 = 0.0, s2 = 0.0;
-        int k = 0;
-        for (; k + 8 <= T; k += 8) {   // eight partials' loads in flight per round trip; same summation order
+        int k = k0;
+        for (; k + 16 <= k1; k += 16) {
+            float p1[16], p2[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                p1[u] = stats[(((size_t)b * T + k + u) * 2 + 0) * C + c];
+                p2[u] = stats[(((size_t)b * T + k + u) * 2 + 1) * C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                s1 += (double)p1[u];
+                s2 += (double)p2[u];
+            }
+        }
+        for (; k + 8 <= k1; k += 8) {
             float p1[8], p2[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -92,9 +112,19 @@ __global__ __launch_bounds__(256) void adagn_coeffs_kernel(const float* __restri
                 s2 += (double)p2[u];
             }
         }
-        for (; k < T; ++k) {
+        for (; k < k1; ++k) {
             s1 += (double)stats[(((size_t)b * T + k) * 2 + 0) * C + c];
             s2 += (double)stats[(((size_t)b * T + k) * 2 + 1) * C + c];
+        }
+        ps[(sl * 2 + 0) * C + c] = s1;
+        ps[(sl * 2 + 1) * C + c] = s2;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int sl = 0; sl < nsl; ++sl) {
+            s1 += ps[(sl * 2 + 0) * C + c];
+            s2 += ps[(sl * 2 + 1) * C + c];
         }
         cs[c] = s1;
         cs[C + c] = s2;
@@ -360,9 +390,18 @@ int adagn_coeffs_launch(const float* stats, int T, int rows, const float* t, int
                         const float* scale_b, const float* bias_w, const float* bias_b, float* a, float* o, int B,
                         int C, int G, float eps, hipStream_t st) {
     if (C % G) return -5;
-    const size_t lds = (size_t)(2 * C + 2 * G) * sizeof(double);
-    hipLaunchKernelGGL(adagn_coeffs_kernel, dim3(B), dim3(256), lds, st, stats, T, rows, t, ctx_dim, scale_w, scale_b,
-                       bias_w, bias_b, a, o, C, G, eps);
+    // slices of the tile partials per column: as many as 1024 threads give, while a slice keeps >= 8 tiles
+    int nsl = 1;
+    while (nsl < 8 && (nsl * 2) * C <= 1024 && T / (nsl * 2) >= 8) nsl *= 2;
+    const int nt = nsl * C >= 1024 ? 1024 : (nsl * C <= 256 ? 256 : ((nsl * C + 63) / 64) * 64);
+    const size_t lds = (size_t)(2 * C + 2 * G + 2 * nsl * C) * sizeof(double);
+    static size_t attr = 0;
+    if (lds > 48 * 1024 && lds > attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(adagn_coeffs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = lds;
+    }
+    hipLaunchKernelGGL(adagn_coeffs_kernel, dim3(B), dim3(nt), lds, st, stats, T, rows, t, ctx_dim, scale_w, scale_b,
+                       bias_w, bias_b, a, o, C, G, eps, nsl);
     return (int)hipGetLastError();
 }
 

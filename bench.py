@@ -367,7 +367,7 @@ def train_bench(args, rank, world, dev):
     red = gd.BucketedGradAllReducer(opt, bucket_bytes=args.bucket_mb << 20)
 
     def step(i):
-        opt.zero_grad()
+        opt.zero_grad(set_to_none=not args.grad_views)   # autograd hands the gradients over; gathered per bucket / at step()
         loss = model.training_step(example, i)
         loss.backward()
         red.finish()
@@ -566,6 +566,8 @@ def main():
     ap.add_argument("--train", action="store_true", help="time the data-parallel training step instead of the forward")
     ap.add_argument("--train-batch", type=int, default=48, help="per-GPU batch of --train (shipped config: 48)")
     ap.add_argument("--bucket-mb", type=int, default=8, help="gradient all-reduce bucket size of --train")
+    ap.add_argument("--grad-views", action="store_true",
+                    help="--train: keep p.grad as views of the flat buffer (autograd adds into zeros: one small kernel per parameter)")
     ap.add_argument("--freeze-conditioner", action="store_true",
                     help="--train --config C3|C4: evaluate the ConvNeXt conditioner without gradients (the reference trains it)")
     ap.add_argument("--selftest-launcher", action="store_true", help="N-rank plumbing on gloo with a stand-in step (no GPU)")

@@ -128,7 +128,7 @@ class GradAllReducer:
 class FlatGradBuffer:
     """The gradient-storage half of `gecco_amd.optim.FusedAdamEMA` on its own: one flat fp32 buffer with every
     `p.grad` a 16-byte aligned view of it, for optimizers that are not the fused one (and for the gloo tests).
-    Offers what `BucketedGradAllReducer` needs: `flat_grad()`, `spans()`, `grad_scale`, `zero_grad()`."""
+    Offers what `BucketedGradAllReducer` needs: `flat_grad()`, `spans()`, `grad_scale`, `zero_grad()`, `gather_grads()`."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
@@ -147,11 +147,36 @@ class FlatGradBuffer:
     def spans(self):
         return list(self._spans)
 
-    def zero_grad(self, set_to_none: bool = False) -> None:   # noqa: ARG002
+    def zero_grad(self, set_to_none: bool = False) -> None:
+        """set_to_none: p.grad = None — autograd hands its gradient tensors over instead of adding them to zeros, and
+        `gather_grads` (called by the reducer per bucket) copies them into the flat buffer (FusedAdamEMA.zero_grad)."""
+        if set_to_none:
+            for p, _, _ in self._spans:
+                p.grad = None
+            return
         self._g.zero_()
         for p, o, k in self._spans:
             if p.grad is None or p.grad.data_ptr() != self._g.data_ptr() + 4 * o:
                 p.grad = self._g[o:o + k].view(p.shape)
+
+    @torch.no_grad()
+    def gather_grads(self, params=None) -> None:
+        span_of = {id(p): (o, k) for p, o, k in self._spans}
+        src, dst = [], []
+        for p in (params if params is not None else self.params):
+            o, k = span_of[id(p)]
+            gr = p.grad
+            if gr is not None and gr.data_ptr() == self._g.data_ptr() + 4 * o:
+                continue
+            v = self._g[o:o + k].view(p.shape)
+            if gr is None:
+                v.zero_()
+            else:
+                src.append(gr)
+                dst.append(v)
+            p.grad = v
+        if src:
+            torch._foreach_copy_(dst, src)
 
 
 class BucketedGradAllReducer:
@@ -195,6 +220,7 @@ class BucketedGradAllReducer:
         for b in self.buckets:
             b["pending"] = len(b["params"])
             b["launched"] = False
+            b["seen"] = set()
             for p in b["params"]:
                 self._bucket_of[id(p)] = b
         self._handles: list = []
@@ -207,7 +233,8 @@ class BucketedGradAllReducer:
     def _launch(self, b: dict) -> None:
         b["launched"] = True
         if self.world() == 1:
-            return
+            return                                 # optimizer.step() gathers whatever is not in the flat buffer yet
+        self.opt.gather_grads(b["params"])        # zero_grad(set_to_none=True): the bucket's gradients into their slice
         view = self.flat[b["lo"]:b["hi"]]
         self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
@@ -215,6 +242,9 @@ class BucketedGradAllReducer:
         if not self.enabled:
             return
         b = self._bucket_of[id(p)]
+        if id(p) in b["seen"]:
+            return                                 # a second contribution to the same parameter (it is used twice)
+        b["seen"].add(id(p))
         b["pending"] -= 1
         if b["pending"] == 0 and not b["launched"]:
             if self.flat.data_ptr() != self.opt.flat_grad().data_ptr():
@@ -229,8 +259,10 @@ class BucketedGradAllReducer:
         for h in self._handles:
             h.wait()
         self._handles.clear()
+        self.opt.gather_grads()                    # single process: nothing was gathered bucket by bucket
         for b in self.buckets:
             b["pending"], b["launched"] = len(b["params"]), False
+            b["seen"].clear()
         self.opt.grad_scale = 1.0 / self.world()
 
     def remove(self) -> None:

@@ -53,6 +53,7 @@ class FusedAdamEMA(torch.optim.Optimizer):
         self.save_original_optimizer_state = False
         self._flat: dict[str, Tensor] | None = None
         self._spans: list[tuple[Tensor, int, int]] = []   # (param, offset, numel) in param-group order
+        self._span_of: dict[int, tuple[int, int]] | None = None
         self._adam_step = 0
         self.grad_scale = 1.0                     # set by a summing gradient all-reduce to 1 / world_size
 
@@ -92,6 +93,7 @@ class FusedAdamEMA(torch.optim.Optimizer):
                 p.data = flat["p"][o:o + k].view(p.shape)
                 p.grad = flat["g"][o:o + k].view(p.shape)
         self._flat, self._spans = flat, spans
+        self._span_of = None
 
     def _ensure(self) -> None:
         """(Re)build the flat views when parameters were added, moved or re-allocated since the last step."""
@@ -127,22 +129,36 @@ class FusedAdamEMA(torch.optim.Optimizer):
         return tuple(self.view_of("ema", i) for i in range(len(self._spans)))
 
     # ------------------------------------------------------------------------------------------ step
-    def zero_grad(self, set_to_none: bool = False) -> None:   # noqa: ARG002 — the views stay, the buffer is cleared
+    def zero_grad(self, set_to_none: bool = False) -> None:
+        """set_to_none=False (default): the flat gradient buffer is cleared and every p.grad stays a view of it — autograd
+        accumulates in place (one small add per parameter per backward).
+        set_to_none=True: p.grad = None, so autograd HANDS OVER the gradient tensors its backward functions produced instead
+        of adding them to zeros (no per-parameter kernel); `step()` — or the data-parallel reducer, bucket by bucket as the
+        backward completes them — gathers them into the flat buffer with one multi-tensor copy.  Same values either way."""
         self._ensure()
+        if set_to_none:
+            for p, _, _ in self._spans:
+                p.grad = None
+            return
         self._flat["g"].zero_()
         for p, o, k in self._spans:
             if p.grad is None or p.grad.data_ptr() != self._flat["g"].data_ptr() + 4 * o:
                 p.grad = self._flat["g"][o:o + k].view(p.shape)
 
-    def _gather_foreign_grads(self) -> None:
-        """A caller that reset p.grad (zero_grad(set_to_none=True) on the module, then backward) left gradients in
-        tensors of their own: copy them into the flat buffer and restore the views."""
+    @torch.no_grad()
+    def gather_grads(self, params: Iterable[Tensor] | None = None) -> None:
+        """Gradients that live in tensors of their own (zero_grad(set_to_none=True), or a caller that reset p.grad) are copied
+        into their slices of the flat buffer — one multi-tensor copy — and p.grad becomes the view again; a parameter without a
+        gradient gets zeros.  `params`: a subset (a reducer bucket); default all."""
+        if self._span_of is None or len(self._span_of) != len(self._spans):
+            self._span_of = {id(p): (o, k) for p, o, k in self._spans}
         gb = self._flat["g"].data_ptr()
         src, dst = [], []
-        for p, o, k in self._spans:
+        for p in (params if params is not None else (q for q, _, _ in self._spans)):
+            o, k = self._span_of[id(p)]
             gr = p.grad
             if gr is not None and gr.data_ptr() == gb + 4 * o:
-                continue                       # the usual case: still our view
+                continue                       # still (or already) our view
             v = self._flat["g"][o:o + k].view(p.shape)
             if gr is None:
                 v.zero_()
@@ -152,6 +168,9 @@ class FusedAdamEMA(torch.optim.Optimizer):
             p.grad = v
         if src:
             torch._foreach_copy_(dst, src)
+
+    def _gather_foreign_grads(self) -> None:
+        self.gather_grads()
 
     def _should_update_at_step(self) -> bool:
         return self.decay is not None and self.current_step % self.every_n_steps == 0

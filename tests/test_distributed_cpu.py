@@ -141,8 +141,8 @@ def _bucket_worker(rank, world, port, q):
     x, y = torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)
     lo, hi = gd.shard_range(8, rank, world)
     outs = []
-    for step in range(2):                                      # two steps: the bucket bookkeeping resets
-        buf.zero_grad()
+    for step in range(3):                                      # several steps: the bucket bookkeeping resets
+        buf.zero_grad(set_to_none=step == 1)                   # step 1: gradients handed over by autograd, gathered per bucket
         ((net(x[lo:hi]) - y[lo:hi]) ** 2).mean().backward()
         red.finish()
         outs.append([(p.grad * buf.grad_scale).numpy().copy() for p in params])

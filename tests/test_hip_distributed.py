@@ -64,8 +64,10 @@ def _run(rank, world, port, q):
     data, noise, sigma = (t.cuda() for t in _batch())
     lo, hi = gd.shard_range(B, rank, world)
     grads, losses = [], []
-    for _ in range(2):   # two steps: bucket bookkeeping and optimizer state carry over
-        opt.zero_grad()
+    for it in range(2):   # two steps: bucket bookkeeping and optimizer state carry over
+        # step 0: p.grad are views of the flat buffer (autograd adds in place); step 1: p.grad = None, autograd hands the
+        # gradient tensors over and the reducer gathers them bucket by bucket as the backward completes them
+        opt.zero_grad(set_to_none=it == 1)
         loss = _loss(model, data[lo:hi], noise[lo:hi], sigma[lo:hi])
         loss.backward()
         if red is not None:

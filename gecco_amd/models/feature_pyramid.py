@@ -19,7 +19,6 @@ import torch
 from torch import Tensor, nn
 
 from .. import _lib, hip_ops
-from .._grad import require_no_grad
 from ..hip_ops import _ptr, _stream
 from ..structs import Context3d
 

@@ -302,7 +302,8 @@ int gecco_ray_lookup_f32(const float* geom, const float* coef, const float* K, c
 int gecco_lookup_row_tiles(int N);
 /* Its backward w.r.t. the pyramids (autograd of F.grid_sample's input under loss.backward(), models/ray.py:82-85):
  * dfeat[l] (B, H_l, W_l, C_l) channels-last, ZEROED by the caller, += tap weight * dout (B, N, sum C).  pyr gives the
- * level shapes (its feat pointers are not read).  Float atomics, like torch's grid_sampler backward. */
+ * level shapes (its feat pointers are not read).  Float atomics, like torch's grid_sampler backward: any N; the sorted form
+ * below is the one the training path uses for N <= 4096. */
 int gecco_ray_lookup_bwd_f32(const float* geom, const float* coef, const float* K, const GeccoReparam* rp,
                              const GeccoPyramid* pyr, const float* dout, float* const* dfeat, int B, int N,
                              void* stream);

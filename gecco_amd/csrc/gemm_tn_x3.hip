@@ -15,6 +15,8 @@
 #include "common.h"
 #include "kernels.h"
 
+#include <stdlib.h>
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -51,11 +53,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(TnArgs g) {
     const int wn = wave >> 1, wk = wave & 1;
     const int r = lane & 31, h = lane >> 5;
     const int tilesK = (g.K + 127) / 128;
-    const int n0 = (blockIdx.x / tilesK) * 128, k0 = (blockIdx.x % tilesK) * 128;
+    // the output tiles of one sample group read the same rows of dY / X: the XCD-aware virtual grid puts them on ONE XCD, so its
+    // L2 serves the re-reads (dispatch order deals consecutive blocks to different XCDs, each with its own L2)
+    const int ntile = (int)gridDim.x;
+    const int vb = g.xcd ? xcd_remap((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y)) : (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    const int bx = vb % ntile, by = vb / ntile;
+    const int n0 = (bx / tilesK) * 128, k0 = (bx % tilesK) * 128;
     // N, K need not fill the last tile (the conditioner's 96 / 192 / 48 / 672-wide layers): a thread's four columns are the
     // same in every step, so one predicate per operand zero-fills what lies beyond the matrix
     const bool aok = n0 + (tid & 31) * 4 < g.N, bok = k0 + (tid & 31) * 4 < g.K;
-    const int z0 = blockIdx.y * g.group, z1 = min(g.Z, z0 + g.group);
+    const int z0 = by * g.group, z1 = min(g.Z, z0 + g.group);
     const int msteps = g.R / 32, nsteps = (z1 - z0) * msteps;
 
     // global tile loads: thread -> 4 x (row, 4 columns) of each operand
@@ -142,10 +149,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(TnArgs g) {
             f32x4 s = red[tid];
 #pragma unroll
             for (int j = 1; j < 8; ++j) s += red[tid + 32 * j];
-            *reinterpret_cast<f32x4*>(g.colsum + (size_t)blockIdx.y * g.N + n0 + tid * 4) = s;
+            *reinterpret_cast<f32x4*>(g.colsum + (size_t)by * g.N + n0 + tid * 4) = s;
         }
     }
-    float* Cb = g.C + (size_t)blockIdx.y * g.N * g.K;
+    float* Cb = g.C + (size_t)by * g.N * g.K;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -174,6 +181,13 @@ int gemm_tn_x3_launch(const TnArgs& g, hipStream_t st) {
                                   (int)lds);
         attr = true;
     }
-    hipLaunchKernelGGL(gemm_tn_x3_kernel, dim3(((g.N + 127) / 128) * ((g.K + 127) / 128), G), dim3(256), lds, st, g);
+    static int xcd = -1;
+    if (xcd < 0) {
+        const char* e = getenv("GECCO_TN_XCD");   // 0: plain dispatch order (A/B runs)
+        xcd = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    TnArgs ga = g;
+    ga.xcd = xcd;
+    hipLaunchKernelGGL(gemm_tn_x3_kernel, dim3(((g.N + 127) / 128) * ((g.K + 127) / 128), G), dim3(256), lds, st, ga);
     return (int)hipGetLastError();
 }

@@ -121,6 +121,7 @@ struct TnArgs {
     size_t sA, sB;     // sample strides (elements)
     int group;
     float* colsum;     // optional (ceil(Z / group), N): column sums of A per group (the bias gradient), or null
+    int xcd;           // set by the launcher: XCD-aware block -> (tile, group) mapping
 };
 // gemm_x3_areg.hip: split-bf16 GEMM whose A operand is a tiled split image loaded global -> registers (GemmArgs::a_img)
 bool gemm_x3_areg_supported(const GemmArgs& g);

@@ -103,9 +103,11 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
     const f32x4 b4 = pg < PG && ln_w ? *reinterpret_cast<const f32x4*>(ln_b + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     const int GR = (W + TX - 1) / TX;     // groups per image row
     const size_t ngroups = (size_t)B * H * GR;
+    // neighbouring strips share their halo rows (a window is 7 rows high): consecutive strips on one XCD, its L2 serves them
+    const int vbx = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     __syncthreads();
     for (int it = 0; it < iters; ++it) {
-        const size_t gid = ((size_t)blockIdx.x * iters + it) * PG + pg;
+        const size_t gid = ((size_t)vbx * iters + it) * PG + pg;
         const bool live = pg < PG && gid < ngroups;
         f32x4 acc[TX];
 #pragma unroll

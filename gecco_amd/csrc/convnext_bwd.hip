@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ z
 
 // ---- depthwise 7 x 7 weight gradient: dW[tap = (dy, dx)][c] = sum over texels dz[b, y, x, c] x[b, y + dy - 3, x + dx - 3, c].
 // Same thread layout as the forward kernel (a 16-byte channel chunk of four texels adjacent in W; a window row is ten texel
-// loads), blockIdx.y = dy: 7 four-channel accumulators per thread, carried over the block's `iters` batches of groups, then
+// loads), one block per (strip, tap row dy): 7 four-channel accumulators per thread, carried over the block's `iters` batches of groups, then
 // summed over the block's groups through LDS.  parts: (gridDim.x, 49, C).
 template <int C>
 __global__ __launch_bounds__(256) void dwconv7_dw_kernel(const float* __restrict__ x, const float* __restrict__ dz,
@@ -116,14 +116,17 @@ __global__ __launch_bounds__(256) void dwconv7_dw_kernel(const float* __restrict
     constexpr int TPP = C / 4, PG = 256 / TPP, TX = 4;
     __shared__ float red[PG * 7 * C];
     const int pg = threadIdx.x / TPP, t = threadIdx.x % TPP, c = 4 * t;
-    const int dy = (int)blockIdx.y - 3;
+    // the seven tap-row blocks of a texel strip read the same dz and neighbouring rows of x: consecutive virtual ids, one XCD
+    const int vb = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int bx = vb / 7, tr = vb % 7;
+    const int dy = tr - 3;
     const int GR = (W + TX - 1) / TX;
     const size_t ngroups = (size_t)B * H * GR;
     f32x4 acc[7];
 #pragma unroll
     for (int d = 0; d < 7; ++d) acc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int it = 0; it < iters; ++it) {
-        const size_t gid = ((size_t)blockIdx.x * iters + it) * PG + pg;
+        const size_t gid = ((size_t)bx * iters + it) * PG + pg;
         if (pg >= PG || gid >= ngroups) continue;
         const int wx0 = (int)(gid % GR) * TX, hy = (int)((gid / GR) % H);
         const size_t b = gid / ((size_t)GR * H);
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256) void dwconv7_dw_kernel(const float* __restrict
         float s = 0.f;
 #pragma unroll
         for (int g = 0; g < PG; ++g) s += red[g * 7 * C + i];
-        parts[((size_t)blockIdx.x * 49 + blockIdx.y * 7) * C + i] = s;
+        parts[((size_t)bx * 49 + tr * 7) * C + i] = s;
     }
 }
 
@@ -244,7 +247,7 @@ int cnx_dwconv_dw_launch(const float* x, const float* dz, float* parts, int B, i
     if (C != 96 && C != 192 && C != 384) return -9;
     int iters;
     const int gx = dw_plan(B, H, W, C, &iters);
-    const dim3 grid(gx, 7);
+    const dim3 grid(gx * 7);
     switch (C) {
         case 96: hipLaunchKernelGGL((dwconv7_dw_kernel<96>), grid, dim3(256), 0, st, x, dz, parts, B, H, W, iters); break;
         case 192: hipLaunchKernelGGL((dwconv7_dw_kernel<192>), grid, dim3(256), 0, st, x, dz, parts, B, H, W, iters); break;

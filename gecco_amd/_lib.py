@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GECCO_HIP_LIB") or os.path.join(_HERE, "libgecco_hip.so")   # override: A/B builds only
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_f = C.c_void_p  # device pointers travel as void*
 
@@ -62,6 +62,10 @@ class GeccoGemm(C.Structure):
                 ("scale", C.c_float)]
 
 
+class GeccoSplitJob(C.Structure):
+    _fields_ = [("W", c_f), ("img", C.c_void_p), ("Nout", C.c_int), ("K", C.c_int), ("ldw", C.c_int), ("transposed", C.c_int)]
+
+
 class GeccoAdamEma(C.Structure):
     _fields_ = [("p", c_f), ("g", c_f), ("m", c_f), ("v", c_f), ("ema", c_f), ("n", C.c_size_t), ("lr", C.c_double),
                 ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("weight_decay", C.c_double),
@@ -80,6 +84,9 @@ SIGNATURES = {
     "gecco_linear_row_tiles": (i, [i]),
     "gecco_linear_ex_f32": (i, [vp] * 9 + [i, i, i, i, i, i, vp, vp]),
     "gecco_linear_pair_f32": (i, [vp, vp, vp, i, vp, vp, vp, i, vp, vp, vp, i, i, i, i, vp, vp]),
+    "gecco_split_bf16_images_f32": (i, [C.POINTER(GeccoSplitJob), i, vp]),
+    "gecco_split_bf16_image_bytes": (sz, [i, i]),
+    "gecco_linear_image_ok": (i, [i, i, i, i]),
     "gecco_linear_f16io": (i, [vp] * 7 + [i, i, i, i, i, i, i, vp, vp]),
     "gecco_linear_pair_f16io": (i, [vp, vp, vp, i, vp, vp, vp, i, vp, i, i, i, vp, vp]),
     "gecco_mlp_fused_f16": (i, [vp, vp, vp, vp, vp, vp, vp, vp, i, vp, i, i, i, i, vp, vp]),

@@ -66,13 +66,98 @@ def _new(*shape, like: Tensor) -> Tensor:
     return torch.empty(*shape, device=like.device, dtype=torch.float32)
 
 
+# ------------------------------------------------------------------------------------------- weight images
+class WeightImages:
+    """The split-bf16 weight images of a training step, made AHEAD in batched launches.
+
+    Every linear of the split-bf16 path streams a tiled bf16 hi | lo image of its weight (csrc/gemm_f32_dma.hip); made per
+    call that is one small launch per linear in the forward and, in the backward, a transposed copy of W plus the image of
+    that copy for the dX product: ~260 launches of ~5 us per step for the shipped model.  The first step RECORDS which
+    (weight view, orientation) pairs its linears asked for; from then on `prepare()` — called by `Diffusion.training_step`
+    — writes all of them with `gecco_split_bf16_images_f32` (<= 96 weights per launch; the W^T images straight from W) and
+    the linears only look their image up.  An image is valid for the weight values `prepare()` saw: the key carries the
+    tensor's version counter (in-place torch updates miss), and `FusedAdamEMA.step()` — which updates through raw pointers
+    — calls `invalidate()`.  A miss falls back to the per-call image, always correct."""
+
+    def __init__(self):
+        self.plan: dict[tuple, tuple] = {}     # key -> (tensors kept alive, job descriptions)
+        self.images: dict[tuple, Tensor] = {}  # key -> image (a view of self.pool), valid while self.armed
+        self.versions: dict[tuple, tuple] = {}
+        self.pool: Tensor | None = None
+        self.armed = False
+        self.recording = False
+
+    @staticmethod
+    def _key(kind: str, *ws: Tensor) -> tuple:
+        return (kind,) + tuple((w.data_ptr(), tuple(w.shape), tuple(w.stride())) for w in ws)
+
+    def lookup(self, kind: str, *ws: Tensor) -> Tensor | None:
+        """The ready image for this weight (pair), or None.  kind: "n" image of W, "t" image of W^T, "pair" W1 | W2."""
+        if _train_precision() != "bf16x3":
+            return None
+        key = self._key(kind, *ws)
+        if self.armed:
+            img = self.images.get(key)
+            if img is not None and self.versions[key] == tuple(w._version for w in ws):
+                return img
+        if self.recording and key not in self.plan and all(w.stride(-1) == 1 for w in ws):
+            self.plan[key] = tuple(ws)
+        return None
+
+    def invalidate(self) -> None:
+        self.armed = False
+
+    @torch.no_grad()
+    def prepare(self) -> None:
+        """(Re)build every recorded image from the current weight values; arms the lookups."""
+        if os.environ.get("GECCO_WEIGHT_IMAGES", "1") == "0":   # per-call images only (A/B runs, tests)
+            self.armed = self.recording = False
+            return
+        self.recording = True
+        if not self.plan:
+            return
+        lib = _lib.load()
+        jobs, offs, total = [], {}, 0
+        for key, ws in self.plan.items():
+            kind = key[0]
+            nbytes = 0
+            for w in ws:
+                nout, k = (w.shape[1], w.shape[0]) if kind == "t" else (w.shape[0], w.shape[1])
+                jobs.append((key, w, nout, k, kind == "t", total + nbytes))
+                nbytes += lib.gecco_split_bf16_image_bytes(nout, k)
+            offs[key] = (total, nbytes)
+            total += (nbytes + 255) // 256 * 256
+        dev = jobs[0][1].device
+        if self.pool is None or self.pool.numel() < total or self.pool.device != dev:
+            self.pool = torch.empty(total, dtype=torch.uint8, device=dev)
+        arr = (_lib.GeccoSplitJob * len(jobs))()
+        base = self.pool.data_ptr()
+        for j, (key, w, nout, k, tr, off) in enumerate(jobs):
+            arr[j] = _lib.GeccoSplitJob(w.data_ptr(), base + off, nout, k, w.stride(0), int(tr))
+        _lib.check(lib.gecco_split_bf16_images_f32(arr, len(jobs), _stream()), "gecco_split_bf16_images_f32")
+        self.images = {key: self.pool[o:o + n] for key, (o, n) in offs.items()}
+        self.versions = {key: tuple(w._version for w in ws) for key, ws in self.plan.items()}
+        self.armed = True
+
+
+WEIGHT_IMAGES = WeightImages()
+
+
+def _image_ok(rows: int, K: int, Nout: int) -> bool:
+    return bool(_lib.load().gecco_linear_image_ok(rows, K, Nout, 0))
+
+
 # ------------------------------------------------------------------------------------------- Linear
 def _linear_dx(dy: Tensor, W: Tensor, residual: Tensor | None = None) -> Tensor:
     """dx = dy W (+ residual: another gradient contribution to the same tensor, added in the GEMM's epilogue)."""
     B, R, Nout = dy.shape
     K = W.shape[1]
     if R >= 64 and Nout % 16 == 0 and K % 4 == 0:
-        # linear(dy, W^T): the fused LDS-DMA GEMM on a transposed copy of the (small) weight
+        # linear(dy, W^T): the fused LDS-DMA GEMM; the image of W^T comes ready from the step's batched launch when it is
+        # there (WeightImages), else from a transposed copy of the (small) weight
+        img = WEIGHT_IMAGES.lookup("t", W) if _image_ok(R, Nout, K) else None
+        if img is not None:
+            return hip_ops.linear(dy, None, residual=residual, precision="bf16x3", w_image=img, w_shape=(K, Nout))
         return hip_ops.linear(dy, W.t().contiguous(), residual=residual, precision=_train_precision())
     dx = _gemm(dy, W, _new(B, R, K, like=dy), Z=1, zdiv=1, M=B * R, N=K, K=Nout, lda=Nout, ldb=K, ldc=K, b_km=True)  # W read k-major
     return dx if residual is None else dx + residual
@@ -137,11 +222,13 @@ class LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, W)
         ctx.has_bias = b is not None
         res = None if residual is None else _f(residual)
+        img = WEIGHT_IMAGES.lookup("n", W) if _image_ok(x.shape[1], W.shape[1], W.shape[0]) else None
+        kw = dict(precision="bf16x3", w_image=img, w_shape=tuple(W.shape)) if img is not None else dict(precision=_train_precision())
         if want_stats:
-            y, st = hip_ops.linear(x, W, b, residual=res, want_stats=True, precision=_train_precision())
+            y, st = hip_ops.linear(x, None if img is not None else W, b, residual=res, want_stats=True, **kw)
             ctx.mark_non_differentiable(st)
             return y, st
-        return hip_ops.linear(x, W, b, residual=res, precision=_train_precision())
+        return hip_ops.linear(x, None if img is not None else W, b, residual=res, **kw)
 
     @staticmethod
     def backward(ctx, dy, _dstats=None):
@@ -170,6 +257,11 @@ class LinearPairFn(torch.autograd.Function):
         x = _f(x)
         ctx.save_for_backward(x, W1, W2)
         ctx.bias = (b1 is not None, b2 is not None)
+        img = None
+        if W1.shape[0] % 128 == 0 and W2.shape[0] % 128 == 0 and _image_ok(x.shape[1], W1.shape[1], W1.shape[0] + W2.shape[0]):
+            img = WEIGHT_IMAGES.lookup("pair", W1, W2)
+        if img is not None:
+            return hip_ops.linear_pair(x, W1, b1, W2, b2, precision="bf16x3", w_image=img)
         return hip_ops.linear_pair(x, W1, b1, _f(W2), b2, precision=_train_precision())
 
     @staticmethod

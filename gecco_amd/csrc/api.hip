@@ -539,10 +539,17 @@ int gecco_linear_f32(const float* A, const float* W, const float* bias, const fl
 int gecco_linear_ex_f32(const float* A, const float* W, const float* bias, const float* pro_a, const float* pro_o,
                         const float* alpha, const float* residual, float* C, float* stats, int B, int rows, int K,
                         int Nout, int act, int precision, void* wsplit, void* stream) {
-    if (!A || !W || !C) return fail(-1, "linear: null argument");
+    if (!A || !C) return fail(-1, "linear: null argument");
     if ((pro_a == nullptr) != (pro_o == nullptr)) return fail(-1, "linear: pro_a/pro_o must both be set");
     if (precision < 0 || precision > 2) return fail(-2, "linear: precision must be 0 (fp32), 1 (split-bf16) or 2 (fp16)");
     if (precision >= 1 && !wsplit) return fail(-1, "linear: precision 1 / 2 need the wsplit scratch");
+    if (!W) {   // wsplit already holds the image of W (gecco_split_bf16_images_f32): kernel launch only
+        if (precision != 1 || !gecco_linear_image_ok(rows, K, Nout, pro_a != nullptr))
+            return fail(-2, "linear: W == NULL (image ready) needs precision 1 and a shape gecco_linear_image_ok accepts");
+        TRY(linear(A, nullptr, bias, pro_a, pro_o, alpha, residual, C, stats, B, rows, K, Nout, act, (hipStream_t)stream, 1, nullptr,
+                   static_cast<const float*>(wsplit)), "linear");
+        return 0;
+    }
     TRY(linear(A, W, bias, pro_a, pro_o, alpha, residual, C, stats, B, rows, K, Nout, act, (hipStream_t)stream, precision,
                static_cast<float*>(wsplit)), "linear");
     return 0;
@@ -551,18 +558,51 @@ int gecco_linear_ex_f32(const float* A, const float* W, const float* bias, const
 int gecco_linear_pair_f32(const float* A, const float* W1, const float* bias1, int Nout1, float* C1, const float* W2,
                           const float* bias2, int Nout2, float* C2, const float* pro_a, const float* pro_o, int B,
                           int rows, int K, int precision, void* wsplit, void* stream) {
-    if (!A || !W1 || !W2 || !C1 || !C2) return fail(-1, "linear_pair: null argument");
+    if (!A || !C1 || !C2 || (!W1) != (!W2)) return fail(-1, "linear_pair: null argument");
     if ((pro_a == nullptr) != (pro_o == nullptr)) return fail(-1, "linear_pair: pro_a/pro_o must both be set");
     if (precision < 0 || precision > 2) return fail(-2, "linear_pair: precision must be 0 (fp32), 1 (split-bf16) or 2 (fp16)");
     if (precision >= 1 && !wsplit) return fail(-1, "linear_pair: precision 1 / 2 need the wsplit scratch");
     hipStream_t s = (hipStream_t)stream;
     float* ws = static_cast<float*>(wsplit);
+    if (!W1) {   // wsplit holds the images of W1 and, from the next 128-column tile boundary, W2
+        if (precision != 1) return fail(-2, "linear_pair: W == NULL (images ready) needs precision 1");
+        int rc = linear_pair(A, nullptr, bias1, Nout1, C1, nullptr, bias2, Nout2, C2, pro_a, pro_o, B, rows, K, s, 1, nullptr, ws);
+        if (rc == 1) return fail(-2, "linear_pair: images ready, but the shape is outside the fused kernel's reach");
+        TRY(rc, "linear_pair");
+        return 0;
+    }
     int rc = linear_pair(A, W1, bias1, Nout1, C1, W2, bias2, Nout2, C2, pro_a, pro_o, B, rows, K, s, precision, ws);
     if (rc < 0) TRY(rc, "linear_pair");
     if (rc == 1) {   // shape outside the fused kernel's reach: the two linears, same results
         TRY(linear(A, W1, bias1, pro_a, pro_o, nullptr, nullptr, C1, nullptr, B, rows, K, Nout1, 0, s, precision, ws), "linear_pair[0]");
         TRY(linear(A, W2, bias2, pro_a, pro_o, nullptr, nullptr, C2, nullptr, B, rows, K, Nout2, 0, s, precision, ws), "linear_pair[1]");
     }
+    return 0;
+}
+
+int gecco_linear_image_ok(int rows, int K, int Nout, int with_prologue) {
+    GemmArgs g{};
+    float dummy = 0.f;
+    g.A = &dummy; g.W = &dummy; g.C = &dummy; g.pro_a = with_prologue ? &dummy : nullptr; g.pro_o = g.pro_a;
+    g.B = 1; g.rows = rows; g.K = K; g.Nout = Nout; g.lda = K; g.ldw = K; g.ldc = Nout; g.ldr = Nout;
+    return gemm_f32_dma_supported(g, 1) ? 1 : 0;
+}
+size_t gecco_split_bf16_image_bytes(int Nout, int K) { return split_bf16_image_bytes(Nout, K); }
+int gecco_split_bf16_images_f32(const GeccoSplitJob* jobs, int n, void* stream) {
+    if (n < 0 || (n > 0 && !jobs)) return fail(-1, "split_bf16_images: null argument");
+    SplitJobs sj;
+    sj.n = 0;
+    for (int i = 0; i < n; ++i) {
+        const GeccoSplitJob& j = jobs[i];
+        if (!j.W || !j.img || j.Nout <= 0 || j.K <= 0 || (j.K % 16) || (!j.transposed && (j.ldw & 3)))
+            return fail(-2, "split_bf16_images: job %d needs K %% 16 == 0 (and ldw %% 4 == 0 unless transposed)", i);
+        sj.job[sj.n++] = SplitJob{j.W, static_cast<float*>(j.img), j.Nout, j.K, j.ldw, j.transposed ? 4 : 0};
+        if (sj.n == 96) {
+            TRY(split_bf16_tiled_multi_launch(sj, (hipStream_t)stream), "split_bf16_images");
+            sj.n = 0;
+        }
+    }
+    TRY(split_bf16_tiled_multi_launch(sj, (hipStream_t)stream), "split_bf16_images");
     return 0;
 }
 

@@ -380,6 +380,7 @@ int gemm_f32_launch(const GemmArgs& g, hipStream_t st) {
         }
         if (use_dma && gemm_f32_dma_supported(g)) return gemm_f32_dma_launch(g, st);
     }
+    if (!g.W) return -9;   // a ready weight image without the matrix itself: only the LDS-DMA kernel reads images
     if (g.C2) return -8;   // the two-segment form exists on the LDS-DMA kernel only (callers check dma_supported)
     const bool pro = g.pro_a != nullptr;
     // 128x128x16: 41 KB LDS and <= 256 VGPR -> two persistent blocks per CU (BK = 32 would spill once the next

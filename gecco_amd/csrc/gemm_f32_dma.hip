@@ -445,8 +445,21 @@ __global__ void split_bf16_tiled_multi_kernel(SplitJobs jobs) {
         const size_t blk = i >> 8;
         const int kt = (int)(blk % nk), ct = (int)(blk / nk);
         const int c = ch ^ ((rb >> 3) & 1);
-        const float* src = j.W + (size_t)min(ct * DBN + rb, j.Nout - 1) * j.ldw + kt * DBK + c * 8;
-        const f32x4 x0 = *reinterpret_cast<const f32x4*>(src), x1 = *reinterpret_cast<const f32x4*>(src + 4);
+        f32x4 x0, x1;
+        if (j.pad_ == 4) {
+            // the image of W^T from W (K, ldw) itself (the dX product of a linear is linear(dY, W^T)): row n of the image is
+            // column n of W — eight strided reads, consecutive n in consecutive threads
+            const float* src = j.W + (size_t)(kt * DBK + c * 8) * j.ldw + min(ct * DBN + rb, j.Nout - 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                x0[e] = src[(size_t)e * j.ldw];
+                x1[e] = src[(size_t)(4 + e) * j.ldw];
+            }
+        } else {
+            const float* src = j.W + (size_t)min(ct * DBN + rb, j.Nout - 1) * j.ldw + kt * DBK + c * 8;
+            x0 = *reinterpret_cast<const f32x4*>(src);
+            x1 = *reinterpret_cast<const f32x4*>(src + 4);
+        }
         bf16x8 hi, lo;
         split8(x0, x1, hi, lo);
         float* dst = j.img + blk * D_TILE + rb * 8 + ch * 4;

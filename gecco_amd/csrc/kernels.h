@@ -45,7 +45,7 @@ struct GemmArgs {
     int a_img, c_img;
 };
 
-struct SplitJob { const float* W; float* img; int Nout, K, ldw, pad_; };   // pad_ = 1 (fp16 images): the LOW part fp16(W - fp16(W)); 2: the same as fp8 x 2^19 in 64-k blocks
+struct SplitJob { const float* W; float* img; int Nout, K, ldw, pad_; };   // pad_ = 1 (fp16 images): the LOW part fp16(W - fp16(W)); 2: the same as fp8 x 2^19 in 64-k blocks; 4 (bf16 images): W is (K, ldw) and the image is of W^T
 struct SplitJobs { SplitJob job[96]; int n; };   // 3 KiB of kernel arguments
 int gemm_row_tile(int rows);  // row-tile height the GEMM uses for `rows` rows per sample
 int gemm_f32_launch(const GemmArgs& g, hipStream_t st);

@@ -225,6 +225,9 @@ class Diffusion(_Base):
 
     def training_step(self, batch: Example, batch_idx):
         x, ctx = batch
+        if torch.is_grad_enabled() and x.is_cuda:
+            from .autograd import WEIGHT_IMAGES
+            WEIGHT_IMAGES.prepare()   # the step's split-bf16 weight images in batched launches (recorded by the first step)
         loss = self.loss(self, x, ctx)
         self.log("train_loss", loss)
         return loss

@@ -96,19 +96,25 @@ def _ws(nbytes: int, device) -> Tensor:
 # ------------------------------------------------------------------------------- unit operators
 def linear(A: Tensor, W: Tensor, bias: Tensor | None = None, pro: tuple[Tensor, Tensor] | None = None,
            act_alpha: Tensor | None = None, residual: Tensor | None = None, want_stats: bool = False,
-           normalized: bool = True, out: Tensor | None = None, precision: str = "fp32", act: str | int | None = None):
+           normalized: bool = True, out: Tensor | None = None, precision: str = "fp32", act: str | int | None = None,
+           w_image: Tensor | None = None, w_shape: tuple[int, int] | None = None):
     """C = residual + act((A*pro_a + pro_o) @ W^T + bias) on (B, rows, K) x (Nout, K).
-    act: GaussianActivation when act_alpha is given (normalized or raw), "relu", or none."""
+    act: GaussianActivation when act_alpha is given (normalized or raw), "relu", or none.
+    w_image (precision "bf16x3"): the READY tiled image of W (autograd.WeightImages) — W may then be None, w_shape = (Nout, K)."""
     lib = _lib.load()
     B, rows, K = A.shape
-    Nout = W.shape[0]
-    assert W.shape[1] == K
+    Nout = W.shape[0] if W is not None else w_shape[0]
+    assert (W.shape[1] if W is not None else w_shape[1]) == K
     out = torch.empty(B, rows, Nout, device=A.device, dtype=torch.float32) if out is None else out
     stats = None
     if want_stats:
         stats = torch.empty(B, lib.gecco_linear_row_tiles(rows), 2, Nout, device=A.device, dtype=torch.float32)
     act = act_code(act_alpha, normalized, act)
-    wsplit = _ws((Nout + 127) // 128 * 128 * K * 4, A.device) if precision != "fp32" else None
+    if w_image is not None:
+        assert precision == "bf16x3"
+        wsplit, W = w_image, None
+    else:
+        wsplit = _ws((Nout + 127) // 128 * 128 * K * 4, A.device) if precision != "fp32" else None
     check(lib.gecco_linear_ex_f32(_ptr(A), _ptr(W), _ptr(bias), _ptr(pro[0]) if pro else None,
                                   _ptr(pro[1]) if pro else None, _ptr(act_alpha), _ptr(residual), _ptr(out), _ptr(stats),
                                   B, rows, K, Nout, act, PRECISIONS[precision],
@@ -316,14 +322,19 @@ def unpool_attn_f16io(q16: Tensor, kvh: Tensor, H: int, out: Tensor | None = Non
 
 def linear_pair(A: Tensor, W1: Tensor, b1: Tensor | None, W2: Tensor, b2: Tensor | None,
                 pro: tuple[Tensor, Tensor] | None = None, out: tuple[Tensor, Tensor] | None = None,
-                precision: str = "fp32") -> tuple[Tensor, Tensor]:
-    """(A' @ W1^T + b1, A' @ W2^T + b2) with A' = A*pro_a + pro_o, one launch (A read once)."""
+                precision: str = "fp32", w_image: Tensor | None = None) -> tuple[Tensor, Tensor]:
+    """(A' @ W1^T + b1, A' @ W2^T + b2) with A' = A*pro_a + pro_o, one launch (A read once).
+    w_image (precision "bf16x3"): the READY images of W1 | W2 (autograd.WeightImages): launch only."""
     lib = _lib.load()
     B, rows, K = A.shape
     n1, n2 = W1.shape[0], W2.shape[0]
     c1, c2 = out if out is not None else (torch.empty(B, rows, n1, device=A.device, dtype=torch.float32),
                                           torch.empty(B, rows, n2, device=A.device, dtype=torch.float32))
-    wsplit = _ws(((n1 + 127) // 128 + (n2 + 127) // 128) * 128 * K * 4, A.device) if precision != "fp32" else None
+    if w_image is not None:
+        assert precision == "bf16x3"
+        wsplit, W1, W2 = w_image, None, None
+    else:
+        wsplit = _ws(((n1 + 127) // 128 + (n2 + 127) // 128) * 128 * K * 4, A.device) if precision != "fp32" else None
     check(lib.gecco_linear_pair_f32(_ptr(A), _ptr(W1), _ptr(b1), n1, _ptr(c1), _ptr(W2), _ptr(b2), n2, _ptr(c2),
                                     _ptr(pro[0]) if pro else None, _ptr(pro[1]) if pro else None, B, rows, K,
                                     PRECISIONS[precision], C.c_void_p(wsplit.data_ptr()) if wsplit is not None else None,

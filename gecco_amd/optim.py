@@ -192,6 +192,8 @@ class FusedAdamEMA(torch.optim.Optimizer):
             raise NotImplementedError("FusedAdamEMA: amsgrad / maximize are not supported")
         self._adam_step += 1
         self.launch(self._adam_step, self._should_update_at_step())
+        from .autograd import WEIGHT_IMAGES
+        WEIGHT_IMAGES.invalidate()   # the kernel updates the weights through raw pointers: no version counter moves
         self.current_step += 1
         return loss
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GECCO_ABI_VERSION 7
+#define GECCO_ABI_VERSION 8
 
 int gecco_abi_version(void);
 const char* gecco_build_arch(void);   /* "gfx950" */
@@ -114,6 +114,16 @@ int gecco_linear_ex_f32(const float* A, const float* W, const float* bias, const
 int gecco_linear_pair_f32(const float* A, const float* W1, const float* bias1, int Nout1, float* C1, const float* W2,
                           const float* bias2, int Nout2, float* C2, const float* pro_a, const float* pro_o, int B,
                           int rows, int K, int precision, void* wsplit, void* stream);
+/* Weight images prepared AHEAD of the linears that use them (the training step: one launch per <= 96 weights at its start
+ * instead of one per linear call, and the dX products' W^T images straight from W — no transposed copy).  A job writes the
+ * tiled split-bf16 image (gecco_split_bf16_image_bytes(Nout, K) bytes) of the (Nout, K) matrix W (row stride ldw), or, with
+ * transposed != 0, of W^T where W is (K, ldw >= Nout).  gecco_linear_ex_f32 / gecco_linear_pair_f32 with W == NULL (W1 ==
+ * W2 == NULL) and precision 1 take `wsplit` as that READY image (pair: the image of W1, then from the next 128-row tile
+ * boundary that of W2) and only launch the GEMM; the shape must satisfy gecco_linear_image_ok(rows, K, Nout, prologue?). */
+typedef struct GeccoSplitJob { const float* W; void* img; int Nout, K, ldw, transposed; } GeccoSplitJob;
+int gecco_split_bf16_images_f32(const GeccoSplitJob* jobs, int n, void* stream);
+size_t gecco_split_bf16_image_bytes(int Nout, int K);
+int gecco_linear_image_ok(int rows, int K, int Nout, int with_prologue);
 
 /* GroupNorm partial statistics of x (B, rows, C): stats (B, T, 2, C), T = gecco_stats_row_tiles(rows). */
 int gecco_col_stats_f32(const float* x, float* stats, int B, int rows, int C, void* stream);

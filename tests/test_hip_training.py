@@ -421,3 +421,73 @@ def test_training_step_decreases_loss():
         losses.append(float(loss.detach()))
     assert all(b < a for a, b in zip(losses, losses[1:])), losses   # same draws every step: strictly decreasing
     assert losses[-1] < 0.97 * losses[0], losses
+
+
+def test_transposed_weight_image_equals_the_image_of_the_transposed_copy():
+    """gecco_split_bf16_images_f32: a transposed job writes, from W itself, the bytes the plain job writes from
+    W.t().contiguous() (what the dX product of a linear streams); several shapes incl. partial 128-row tiles and a view."""
+    import ctypes as C
+    from gecco_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(4)
+    big = _t(rs.randn(3 * 384, 384)).cuda()
+    cases_ = [_t(rs.randn(768, 384)).cuda(), _t(rs.randn(96, 384)).cuda(), _t(rs.randn(384, 96)).cuda(), _t(rs.randn(48, 672)).cuda(),
+              big[384:]]                                           # in_proj_weight[C:]: a row-offset view
+    for W in cases_:
+        K_img, N_img = W.shape                                     # image of W^T: (N_img, K_img)
+        nb = lib.gecco_split_bf16_image_bytes(N_img, K_img)
+        a = torch.full((nb,), 7, dtype=torch.uint8, device="cuda")
+        b = torch.full((nb,), 9, dtype=torch.uint8, device="cuda")
+        Wt = W.t().contiguous()
+        jobs = (_lib.GeccoSplitJob * 2)(_lib.GeccoSplitJob(W.data_ptr(), a.data_ptr(), N_img, K_img, W.stride(0), 1),
+                                        _lib.GeccoSplitJob(Wt.data_ptr(), b.data_ptr(), N_img, K_img, Wt.stride(0), 0))
+        _lib.check(lib.gecco_split_bf16_images_f32(jobs, 2, None), "split images")
+        assert torch.equal(a, b), tuple(W.shape)
+
+
+def test_batched_weight_images_leave_the_training_step_unchanged(monkeypatch):
+    """WeightImages (autograd.py): steps whose linears look their split-bf16 weight images up in the step's batched launch
+    produce bit for bit the losses, gradients and weights of steps that build an image per call — across optimizer steps
+    (raw-pointer updates: explicit invalidation) and an in-place torch update between prepare() and use (version counter)."""
+    from gecco_amd import autograd as ag
+    from gecco_amd import hip_ops
+    from gecco_amd.optim import FusedAdamEMA
+    from gecco_amd.structs import Example
+    prev = hip_ops.default_precision()
+    hip_ops.set_default_precision("bf16x3")
+    try:
+        def run(cached):
+            monkeypatch.setenv("GECCO_WEIGHT_IMAGES", "1" if cached else "0")
+            ag.WEIGHT_IMAGES.__init__()
+            torch.manual_seed(0)
+            m = build_uncond(128, 2)
+            m.load_state_dict(uncond_state_dict(W.linear_lift_state_dict(11, 128, 2, 64, 8)), strict=True)
+            m = m.cuda().train()
+            opt = FusedAdamEMA(m.parameters(), lr=1e-3, ema_decay=0.9)
+            g = torch.Generator().manual_seed(5)
+            data = torch.randn(4, 256, 3, generator=g).cuda()
+            out = []
+            for it in range(4):
+                opt.zero_grad()
+                torch.manual_seed(100 + it)                      # the loss draws sigma and the noise
+                loss = m.training_step(Example(data, None), it)
+                if it == 2:                                      # weights move behind prepare()'s back, by a torch op
+                    with torch.no_grad():
+                        next(p for n, p in m.named_parameters() if n.endswith("mlp.0.weight")).mul_(1.01)
+                    torch.manual_seed(100 + it)
+                    loss = m.loss(m, data, None)                  # not training_step: no prepare(), the stale image must be refused
+                loss.backward()
+                out.append((float(loss.detach()), opt.flat_grad().clone()))
+                opt.step()
+            used = len(ag.WEIGHT_IMAGES.plan)
+            return out, torch.cat([p.detach().reshape(-1) for p in m.parameters()]).clone(), used
+        ref, wref, n0 = run(False)
+        got, wgot, n1 = run(True)
+        assert n0 == 0 and n1 >= 10, (n0, n1)                    # the cached run really recorded and used images
+        for (l0, g0), (l1, g1) in zip(ref, got):
+            assert l0 == l1
+            assert torch.equal(g0, g1)
+        assert torch.equal(wref, wgot)
+    finally:
+        hip_ops.set_default_precision(prev)
+        ag.WEIGHT_IMAGES.__init__()

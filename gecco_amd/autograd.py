@@ -21,6 +21,7 @@ from . import _lib, hip_ops
 from .hip_ops import _ptr, _stream
 
 GN_EPS = 1e-5
+_DW_BLOCKS = int(os.environ.get("GECCO_DW_BLOCKS", "768"))   # blocks a weight-gradient launch aims for (groups x output tiles)
 
 
 def _f(t: Tensor) -> Tensor:
@@ -181,7 +182,7 @@ def _linear_dw(dy: Tensor, x: Tensor, want_db: bool = False):
         if not (_train_precision() == "bf16x3" and R % 32 == 0 and Nout % 4 == 0 and K % 4 == 0):
             return _linear_dw(dy, x), _linear_db(dy)
         tiles = -(-Nout // 128) * -(-K // 128)
-        G = min(B, max(1, -(-1024 // tiles)))
+        G = min(B, max(1, -(-_DW_BLOCKS // tiles)))
         group = -(-B // G)
         G = -(-B // group)
         parts, cparts = _new(G, Nout, K, like=x), _new(G, Nout, like=x)
@@ -192,7 +193,7 @@ def _linear_dw(dy: Tensor, x: Tensor, want_db: bool = False):
         # split-bf16 MFMA with transposed LDS reads (gemm_tn_x3.hip); one partial per group of samples, groups
         # sized so that ~1000 blocks fill the chip
         tiles = -(-Nout // 128) * -(-K // 128)
-        G = min(B, max(1, -(-1024 // tiles)))
+        G = min(B, max(1, -(-_DW_BLOCKS // tiles)))
         group = -(-B // G)
         G = -(-B // group)
         parts = _new(G, Nout, K, like=x)

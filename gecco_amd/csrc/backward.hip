@@ -328,6 +328,88 @@ __global__ __launch_bounds__(256) void lower_bwd_kernel(const float* __restrict_
     if (threadIdx.x < 3) p[3 * C + threadIdx.x] = bsm[threadIdx.x] + bsm[3 + threadIdx.x] + bsm[6 + threadIdx.x] + bsm[9 + threadIdx.x];
 }
 
+// The same for C = 128 CPL (CPL = 1 .. 4): 32 lanes per point, CPL 16-byte channel chunks per lane (chunk q + 32 j), the row,
+// the three weight rows and the 3 x C weight-gradient accumulators in registers — one read of feat, one write of dfeat, no LDS
+// in the loop (the generic kernel above re-reads every feat element four times and keeps its accumulators in LDS: 317 us
+// against ~60 for the 151 + 151 MB of the C2 step).  Same partial layout: (blocks, 3 C + 4).
+template <int CPL>
+__global__ __launch_bounds__(256) void lower_bwd_v4_kernel(const float* __restrict__ feat, const float* __restrict__ dF,
+                                                           const float* __restrict__ W, float* __restrict__ dfeat,
+                                                           float* __restrict__ partial, size_t rows, float eps, int rows_per_block) {
+    constexpr int C = 128 * CPL;
+    __shared__ float red[8][3 * C + 4];
+    const int q = threadIdx.x & 31, slot = threadIdx.x >> 5;
+    f32x4 w[3][CPL], acc[3][CPL];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            w[k][j] = *reinterpret_cast<const f32x4*>(W + (size_t)k * C + 4 * (q + 32 * j));
+            acc[k][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+    const size_t r0 = (size_t)blockIdx.x * rows_per_block;
+    auto lsum = [](float v) {
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    };
+    for (size_t row = r0 + slot; row < r0 + rows_per_block; row += 8) {
+        const bool live = row < rows;
+        f32x4 f[CPL];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j)
+            f[j] = live ? *reinterpret_cast<const f32x4*>(feat + row * C + 4 * (q + 32 * j)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const float g0 = live ? dF[row * 3 + 0] : 0.f, g1 = live ? dF[row * 3 + 1] : 0.f, g2 = live ? dF[row * 3 + 2] : 0.f;
+        float s1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) s1 += (f[j][0] + f[j][1]) + (f[j][2] + f[j][3]);
+        const float mean = lsum(s1) / C;
+        float s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            f[j] = f[j] - mean;
+            const f32x4 d = f[j] * f[j];
+            s2 += (d[0] + d[1]) + (d[2] + d[3]);
+        }
+        const float rstd = rsqrtf(lsum(s2) / C + eps);
+        float m1 = 0.f, m2 = 0.f;
+        f32x4 dyh[CPL];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            f[j] = f[j] * rstd;   // yhat
+            dyh[j] = w[0][j] * g0 + w[1][j] * g1 + w[2][j] * g2;
+            const f32x4 e = dyh[j] * f[j];
+            m1 += (dyh[j][0] + dyh[j][1]) + (dyh[j][2] + dyh[j][3]);
+            m2 += (e[0] + e[1]) + (e[2] + e[3]);
+            acc[0][j] += f[j] * g0;
+            acc[1][j] += f[j] * g1;
+            acc[2][j] += f[j] * g2;
+        }
+        m1 = lsum(m1) / C;
+        m2 = lsum(m2) / C;
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < CPL; ++j)
+                *reinterpret_cast<f32x4*>(dfeat + row * C + 4 * (q + 32 * j)) = (dyh[j] - m1 - f[j] * m2) * rstd;
+        }
+        b0 += g0; b1 += g1; b2 += g2;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) *reinterpret_cast<f32x4*>(&red[slot][k * C + 4 * (q + 32 * j)]) = acc[k][j];
+    if (q == 0) { red[slot][3 * C] = b0; red[slot][3 * C + 1] = b1; red[slot][3 * C + 2] = b2; red[slot][3 * C + 3] = 0.f; }
+    __syncthreads();
+    float* p = partial + (size_t)blockIdx.x * (3 * C + 4);
+    for (int c = threadIdx.x; c < 3 * C + 4; c += 256) {
+        float t = 0.f;
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) t += red[s_][c];
+        p[c] = t;
+    }
+}
+
 unsigned grid_for(size_t n) {
     size_t g = (n + 255) / 256;
     return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -386,6 +468,14 @@ int lift_bwd_launch(const float* dY, const float* xin, float* partial, int B, in
 int lower_bwd_blocks(size_t rows) { return (int)((rows + 127) / 128); }
 int lower_bwd_launch(const float* feat, const float* dF, const float* W, float* dfeat, float* partial, size_t rows,
                      int C, float eps, hipStream_t st) {
+    const unsigned nblk = (unsigned)lower_bwd_blocks(rows);
+    switch (C) {
+        case 128: hipLaunchKernelGGL((lower_bwd_v4_kernel<1>), dim3(nblk), dim3(256), 0, st, feat, dF, W, dfeat, partial, rows, eps, 128); return (int)hipGetLastError();
+        case 256: hipLaunchKernelGGL((lower_bwd_v4_kernel<2>), dim3(nblk), dim3(256), 0, st, feat, dF, W, dfeat, partial, rows, eps, 128); return (int)hipGetLastError();
+        case 384: hipLaunchKernelGGL((lower_bwd_v4_kernel<3>), dim3(nblk), dim3(256), 0, st, feat, dF, W, dfeat, partial, rows, eps, 128); return (int)hipGetLastError();
+        case 512: hipLaunchKernelGGL((lower_bwd_v4_kernel<4>), dim3(nblk), dim3(256), 0, st, feat, dF, W, dfeat, partial, rows, eps, 128); return (int)hipGetLastError();
+        default: break;
+    }
     const size_t lds = (size_t)(12 * C + 12) * sizeof(float);
     static size_t attr = 0;
     if (lds > attr) {

@@ -74,7 +74,14 @@ __device__ __forceinline__ f32x16 mfma3(const u32x4& ahi, const u32x4& alo, cons
 // element offset of (row, col) in a plane of 4-row x 32-column blocks, NB column blocks per row group
 template <int NB>
 __device__ __forceinline__ int blk_off(int row, int col) {
-    return ((row >> 2) * NB + (col >> 5)) * 128 + (row & 3) * 32 + (col & 31);
+    // inside a 256-byte block (= all 64 banks) a row takes one of four 64-byte slots and an 8-column piece one of its four
+    // 16-byte chunks.  Both are permuted: the slot rotates with the column block (the column blocks one row of a store
+    // instruction touches land on different bank groups) and the chunk is XORed with the 4-row group index — a row fragment
+    // read (32 lanes = 32 rows = 8 row groups, the same 16 bytes of each) hit 4 banks 8-fold in the plain layout
+    // (SQ_LDS_BANK_CONFLICT 74 % / 63 % of the LDS-active cycles of the two kernels); now groups g and g + 4 share a chunk,
+    // 2-fold.  A transposed read (16 lanes: 4 rows of one group x 32 bytes) still covers whole slots.
+    const int slot = (row + (col >> 5)) & 3, chunk = ((col & 31) >> 3) ^ ((row >> 2) & 3);
+    return ((row >> 2) * NB + (col >> 5)) * 128 + slot * 32 + chunk * 8 + (col & 7);
 }
 
 // columns 16c + 8h .. + 7 of `row`: the fragment of a product that contracts over the columns

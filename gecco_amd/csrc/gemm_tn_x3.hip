@@ -39,9 +39,12 @@ __device__ __forceinline__ void tn_split4(const f32x4& x, u32x2& hi, u32x2& lo) 
     lo = __builtin_bit_cast(u32x2, l);
 }
 
-// element offset of (row, col) in a [32][128] plane: 4-row x 32-column blocks of 128 elements (256 B)
+// element offset of (row, col) in a [32][128] plane: 4-row x 32-column blocks of 128 elements (256 B = all 64 banks); the
+// row's 64-byte slot inside its block is rotated by the column block, so the four column blocks a store instruction touches
+// for one row land on four different bank groups (unrotated they share one: SQ_LDS_BANK_CONFLICT was 33 % of the LDS-active
+// cycles); a transposed read still covers whole blocks (its four rows take the four slots in another order)
 __device__ __forceinline__ int tn_off(int row, int col) {
-    return ((row >> 2) * 4 + (col >> 5)) * 128 + (row & 3) * 32 + (col & 31);
+    return ((row >> 2) * 4 + (col >> 5)) * 128 + ((row + (col >> 5)) & 3) * 32 + (col & 31);
 }
 
 constexpr int TN_PLANE = 32 * 128;   // u16 per plane

@@ -94,6 +94,8 @@ class FusedAdamEMA(torch.optim.Optimizer):
                 p.grad = flat["g"][o:o + k].view(p.shape)
         self._flat, self._spans = flat, spans
         self._span_of = None
+        from .autograd import WEIGHT_IMAGES
+        WEIGHT_IMAGES.invalidate()   # the parameters moved into the flat buffer
 
     def _ensure(self) -> None:
         """(Re)build the flat views when parameters were added, moved or re-allocated since the last step."""
@@ -221,6 +223,8 @@ class FusedAdamEMA(torch.optim.Optimizer):
         tmp = self._flat["p"].clone()
         self._flat["p"].copy_(self._flat["ema"])
         self._flat["ema"].copy_(tmp)
+        from .autograd import WEIGHT_IMAGES
+        WEIGHT_IMAGES.invalidate()   # the parameters are views of the flat buffer: their version counters did not move
 
     @contextlib.contextmanager
     def swap_ema_weights(self, enabled: bool = True):

@@ -179,3 +179,110 @@ def test_fp16_deep_network_weight_staging(ops, d, L):
         # error grows with depth (each layer adds its own rounding); the bar stays the north star's
         _report(f"d={d} L={L} {precision} D", den, ref, 1e-3 if precision == "fp16" else 3e-4)
         _report(f"d={d} L={L} {precision} F_x", raw, raw_ref, 2e-3 if precision == "fp16" else 3e-4)
+
+
+# ------------------------------------------------------------------------------------------------- training path at full size
+def _edm_loss(D, data, noise, sigma):
+    """EDMLoss with injected draws (reference diffusion.py:136-143): 100 (s^2 + 1) / s^2 |D(x + s n) - x|^2, mean."""
+    s = sigma.reshape(-1, 1, 1)
+    return (100.0 * (s ** 2 + 1.0) / s ** 2 * (D(data + noise * s, sigma) - data) ** 2).mean()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_c2_full_size_gradients_vs_oracle(ops, precision):
+    """The TRAINING path at the headline size (N = 2048, d = 384, L = 6): EDM loss and the gradient of every parameter,
+    HIP autograd Functions (gecco_amd/autograd.py) against torch autograd through the oracle on the host cores.  The mixed /
+    fp16 modes train in split-bf16 (no loss scaling), so "bf16x3" is what `bench.py --train` runs."""
+    from tests.test_modules_cpu import build_uncond, uncond_state_dict
+    d, L, N, B = 384, 6, 2048, 2
+    p = W.linear_lift_state_dict(3, d, L, cases.I, cases.H)
+    rs = np.random.RandomState(11)
+    data = torch.from_numpy(rs.randn(B, N, 3).astype(np.float32))
+    noise = torch.from_numpy(rs.randn(B, N, 3).astype(np.float32))
+    sigma = torch.tensor([0.1, 5.0])
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    ref_loss = _edm_loss(cpu_ref.uncond_denoiser(pr, "", cases.H), data, noise, sigma)
+    ref_loss.backward()
+    m = build_uncond(d, L)
+    m.load_state_dict(uncond_state_dict(p), strict=True)
+    m = m.cuda().train()
+    old = ops.default_precision()
+    ops.set_default_precision(precision)
+    try:
+        loss = _edm_loss(lambda x, s: m(x, s, None), data.cuda(), noise.cuda(), sigma.cuda())
+        loss.backward()
+    finally:
+        ops.set_default_precision(old)
+    lv, rv = float(loss.detach()), float(ref_loss.detach())
+    print(f"C2 training [{precision}]: loss {lv:.6f} (oracle {rv:.6f})")
+    assert abs(lv - rv) / abs(rv) < (1e-5 if precision == "fp32" else 1e-4)
+    bar = 2e-4 if precision == "fp32" else 2e-3
+    worst = ("", 0.0)
+    grads = {k[len("backbone.model."):]: q.grad for k, q in m.named_parameters() if k.startswith("backbone.model.")}
+    assert set(grads) == set(p)
+    for k in p:
+        assert grads[k] is not None and pr[k].grad is not None, k
+        e = cpu_ref.rel_err(grads[k].cpu(), pr[k].grad)[0]
+        worst = max(worst, (k, e), key=lambda t: t[1])
+        assert e < bar, (precision, k, e)
+    print(f"C2 training [{precision}]: worst parameter gradient {worst[0]} {worst[1]:.2e} (bar {bar:.0e})")
+    assert worst[1] > 0.0   # gradients were really compared
+
+
+def test_c3_full_size_training_step_vs_oracle(ops):
+    """The image-conditional training step at the C3 size (224 x 224 images -> ConvNeXt-T pyramids 96 / 192 / 384 channels ->
+    projective lookup -> RayNetwork, N = 2048, d = 384, L = 6), conditioner TRAINED as in the reference: the loss and the
+    gradient of every parameter — conditioner and denoiser — against torch autograd through the oracle chain
+    convnext_features -> cond_denoiser -> EDM loss (split-bf16, what `bench.py --train --config C3` runs)."""
+    from gecco_amd.models.feature_pyramid import ConvNeXtExtractor
+    from gecco_amd.structs import Context3d
+    from tests.test_hip_convnext import _seeded_state
+    from tests.test_modules_cpu import build_cond
+    d, L, N, hw, B = 384, 6, 2048, 224, 2
+    cn = ConvNeXtExtractor(n_stages=3, model="tiny", pretrained=False)
+    csd = _seeded_state(cn, 9)
+    cn.load_state_dict(csd, strict=True)
+    m = build_cond(d, L, conditioner=cn)
+    p = W.ray_network_state_dict(17, d, L, cases.I, cases.H)
+    sd = {"backbone.model." + k: v for k, v in p.items()}
+    sd["reparam.uvl_mean"], sd["reparam.uvl_std"] = p["reparam.uvl_mean"], p["reparam.uvl_std"]
+    sd.update({"conditioner." + k: v for k, v in csd.items()})
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    rs = np.random.RandomState(3)
+    img = torch.from_numpy(rs.rand(B, 3, hw, hw).astype(np.float32))
+    _, K = W.synthetic_context(4, B, hw=hw)
+    data = torch.from_numpy((0.5 * rs.randn(B, N, 3)).astype(np.float32))
+    noise = torch.from_numpy(rs.randn(B, N, 3).astype(np.float32))
+    sigma = torch.tensor([0.3, 2.0])
+    cp = {k: v.clone().requires_grad_(True) for k, v in csd.items()}
+    pr = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not k.startswith("reparam.") else v) for k, v in p.items()}
+    feats = cpu_ref.convnext_features(img, cp)
+    ref_loss = _edm_loss(cpu_ref.cond_denoiser(pr, "", cases.H, K, feats), data, noise, sigma)
+    ref_loss.backward()
+    old = ops.default_precision()
+    ops.set_default_precision("bf16x3")
+    try:
+        ctx = Context3d(image=img.cuda(), K=K.cuda())
+        loss = _edm_loss(lambda x, s: m(x, s, ctx), data.cuda(), noise.cuda(), sigma.cuda())
+        loss.backward()
+    finally:
+        ops.set_default_precision(old)
+    lv, rv = float(loss.detach()), float(ref_loss.detach())
+    print(f"C3 training: loss {lv:.6f} (oracle {rv:.6f})")
+    assert abs(lv - rv) / abs(rv) < 1e-4
+    worst = {"conditioner": ("", 0.0), "denoiser": ("", 0.0)}
+    for k, q in m.named_parameters():
+        if k.startswith("conditioner."):
+            r, part = cp[k[len("conditioner."):]].grad, "conditioner"
+        elif k.startswith("backbone.model."):
+            r, part = pr[k[len("backbone.model."):]].grad, "denoiser"
+        else:
+            continue
+        assert q.grad is not None and r is not None, k
+        e = cpu_ref.rel_err(q.grad.cpu(), r)[0]
+        worst[part] = max(worst[part], (k, e), key=lambda t: t[1])
+        assert e < 3e-3, (k, e)
+    for part, (k, e) in worst.items():
+        print(f"C3 training: worst {part} gradient {k} {e:.2e} (bar 3e-03)")
+        assert e > 0.0

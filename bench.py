@@ -508,6 +508,27 @@ def other_config_bench(args, rank, world, dev):
         flops = Bc * Ll * (12 * n_new * dc * dc + 4 * n_new * Ii * dc)
         what = (f"C5 cached-inducer (upsampling) evaluation: B={Bc}/GPU, n_new={n_new} points against the inducer states of "
                 f"N={Nc} known points, d={dc}, L={Ll} (diffusion.py:433-447: every sub-step of `upsample`)")
+        if rank == 0 and world == 1 and not args.no_sampler and (dc, Ll) == (D, L):
+            # Diffusion.upsample end to end (reference diffusion.py:354-470) on a SHORT schedule (8 of the 128 steps: the
+            # per-step cost is what scales): per outer step one full evaluation of the known clouds + 5 x 2 cached
+            # evaluations of the new points + the sampler kernels, one captured hipGraph per step; and the same eagerly
+            ups = build_model(random_state_dict(9, dc, Ll)).to(dev).eval()
+            known = (torch.randn(Bc, Nc, 3, generator=g) * ups.reparam.sigma.cpu() + ups.reparam.mean.cpu()).to(dev)
+            nst, nsub = 8, 5
+            res = {}
+            for name, ug in (("hipgraph", True), ("eager", False)):
+                ups.upsample(known, n_new=n_new, num_steps=3, num_substeps=nsub, use_graph=ug)   # warm-up
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                o = ups.upsample(known, n_new=n_new, num_steps=nst, num_substeps=nsub, use_graph=ug)
+                torch.cuda.synchronize()
+                res[name] = time.perf_counter() - t0
+                assert torch.isfinite(o).all()
+            rec_extra["upsample"] = {"outer_steps": nst, "num_substeps": nsub, "evaluations_per_step": "1 full + 10 cached",
+                                     "seconds": res["hipgraph"], "ms_per_outer_step": res["hipgraph"] / nst * 1e3,
+                                     "eager_ms_per_outer_step": res["eager"] / nst * 1e3,
+                                     "projected_128_steps_s": res["hipgraph"] / nst * 128,
+                                     "new_points_per_sec_128_steps": Bc * n_new / (res["hipgraph"] / nst * 128)}
     step()
     torch.cuda.synchronize()
     gr = torch.cuda.CUDAGraph()

@@ -440,10 +440,15 @@ class Diffusion(_Base):
     @torch.no_grad()
     def upsample(self, data: Tensor, new_latents: Tensor | None = None, n_new: int | None = None,
                  context: Context3d | None = None, seed: int | None = 42, num_substeps=5,
-                 noise: Sequence[Tensor] | None = None, **kwargs):
+                 noise: Sequence[Tensor] | None = None, use_graph: bool = True, **kwargs):
         """Generates `n_new` extra points conditionally independent given the per-layer inducer states of the known
         cloud (reference diffusion.py:354-470).  `noise` (optional): the randn draws in the reference's call order
-        ([new_latents,] then per outer step: data noise, per sub-step churn noise [, redo noise])."""
+        ([new_latents,] then per outer step: data noise, per sub-step churn noise [, redo noise]).
+
+        One outer step — re-noise the known cloud, one full evaluation that builds the inducer cache, `num_substeps` x
+        (churn, cached evaluation, Euler, cached evaluation, Heun[, redo]) on the new points, advance — is captured as ONE
+        hipGraph (`use_graph`) and replayed per step; the step's noise is drawn before each replay, in the reference's
+        order, into the buffers the graph reads (BASELINE config C5: "hipGraph, 128 steps")."""
         kw = {**self.sampler_kwargs, **kwargs}
         num_steps = kw["num_steps"]
         device, dtype = self.example_param.device, self.example_param.dtype
@@ -454,11 +459,13 @@ class Diffusion(_Base):
             rng = rng.manual_seed(seed)
         it = iter(noise) if noise is not None else None
 
-        def randn(shape):
+        def randn(shape, out=None):
             if it is not None:
                 t = next(it).to(device=device, dtype=dtype).contiguous()
                 assert tuple(t.shape) == tuple(shape), (t.shape, shape)
-                return t
+                return t if out is None else out.copy_(t)
+            if out is not None:
+                return torch.randn(tuple(shape), device=device, dtype=dtype, generator=rng, out=out)
             return torch.randn(tuple(shape), device=device, dtype=dtype, generator=rng)
 
         if (new_latents is None) == (n_new is None):
@@ -478,26 +485,61 @@ class Diffusion(_Base):
         data_ctx = torch.empty_like(data)
         sigma_d = torch.empty(B, device=device, dtype=torch.float32)
         st.init_from_latents(new_latents, float(ts[0]))
+        # the draws of one outer step, in the buffers its kernels (and the captured graph) read
+        nz_data = torch.empty_like(data)
+        nz_churn = [torch.empty_like(new_latents) for _ in range(num_substeps)]
+        nz_redo = [torch.empty_like(new_latents) for _ in range(max(num_substeps - 1, 0))]
 
-        steps = range(num_steps)
-        if kw["with_pbar"]:
-            from tqdm.auto import tqdm
-            steps = tqdm(steps, total=num_steps)
-        for i in steps:
-            nz = randn(data.shape)
-            _lib.check(lib.gecco_sampler_add_noise_f32(_vp(data), _vp(nz), 0, _vp(st.sched), _vp(st.step), 0, _vp(data_ctx),
+        def draw(last: bool) -> None:   # the reference's call order: data noise, then per sub-step churn [, redo]
+            randn(data.shape, out=nz_data)
+            for u in range(num_substeps):
+                randn(new_latents.shape, out=nz_churn[u])
+                if u < num_substeps - 1 and not last:
+                    randn(new_latents.shape, out=nz_redo[u])
+
+        def outer(last: bool) -> None:
+            _lib.check(lib.gecco_sampler_add_noise_f32(_vp(data), _vp(nz_data), 0, _vp(st.sched), _vp(st.step), 0, _vp(data_ctx),
                                                        _vp(sigma_d), data.numel(), B, st._s()), "sampler_add_noise_f32")
             _, cache = self(data_ctx, sigma_d, context, post_context, do_cache=True, cache=None)
             for u in range(num_substeps):
-                st.churn(randn(new_latents.shape), 0)
+                st.churn(nz_churn[u], 0)
                 self(st.x_in, st.sigma, context, post_context, cache=cache, out=st.den)
                 st.euler()
-                if i < num_steps - 1:
+                if not last:
                     self(st.x_in, st.sigma, context, post_context, cache=cache, out=st.den)
                     st.heun()
                 else:
                     st.x_cur.copy_(st.x_next)
-                if u < num_substeps - 1 and i < num_steps - 1:
-                    st.redo(randn(new_latents.shape))
+                if u < num_substeps - 1 and not last:
+                    st.redo(nz_redo[u])
             st.advance()
+
+        pbar = None
+        if kw["with_pbar"]:
+            from tqdm.auto import tqdm
+            pbar = tqdm(total=num_steps, unit="step")
+        graph = None
+        if use_graph and num_steps > 2:
+            # warm-up outside the capture: plans / workspaces of the full and of the cached evaluation (state untouched)
+            data_ctx.copy_(data)
+            sigma_d.fill_(1.0)
+            st.x_in.zero_()
+            st.sigma.fill_(1.0)
+            _, wc = self(data_ctx, sigma_d, context, post_context, do_cache=True, cache=None)
+            self(st.x_in, st.sigma, context, post_context, cache=wc, out=st.den)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                outer(False)
+        for i in range(num_steps):
+            last = i == num_steps - 1
+            draw(last)
+            if graph is not None and not last:
+                graph.replay()
+            else:
+                outer(last)
+            if pbar:
+                pbar.update(1)
+        if pbar:
+            pbar.close()
         return self.reparam.diffusion_to_data(st.x_cur, context)

@@ -184,8 +184,14 @@ def test_upsample_golden(golden_dir):
                      noise=cases.upsample_draw_list())
     assert out.dtype == torch.float64
     _close(out, g["upsampled"], 2e-4)
-    out2 = m.upsample(data.cuda(), n_new=500, num_steps=3, num_substeps=2)  # generator path, many new points
+    # the captured outer-step graph (default) and the eager loop are the same launches: bit-identical clouds
+    eager = m.upsample(data.cuda(), n_new=c["n_new"], num_steps=c["num_steps"], num_substeps=c["num_substeps"],
+                       noise=cases.upsample_draw_list(), use_graph=False)
+    assert torch.equal(out, eager)
+    out2 = m.upsample(data.cuda(), n_new=500, num_steps=4, num_substeps=2)  # generator path, many new points
     assert out2.shape == (c["B"], 500, 3) and torch.isfinite(out2).all()
+    out3 = m.upsample(data.cuda(), n_new=500, num_steps=4, num_substeps=2, use_graph=False)   # same seed, same draw order
+    assert torch.equal(out2, out3)
 
 
 # ------------------------------------------------------------------------------------------- conditional

@@ -360,6 +360,86 @@ class GaussActFn(torch.autograd.Function):
         return du, dalpha, None
 
 
+class ActLinearFn(torch.autograd.Function):
+    """y = act(u) @ W^T + b (+ residual): the activation and the linear that follows it (models/mlp.py: Linear -> act ->
+    Linear; a CNBlock's Linear -> GELU -> Linear) as ONE Function, so that the backward can run the activation's derivative
+    as the EPILOGUE of the dX product (`gecco_linear_actbwd_f32`): dh = dy W never exists, du leaves the GEMM, and for
+    GaussianActivation the alpha gradient's partial sums come out of the same epilogue.  kind: 1 / 2 GaussianActivation
+    normalized / raw, 3 ReLU, 4 GELU.  Shapes the LDS-DMA kernels do not take fall back to the two-kernel backward."""
+
+    @staticmethod
+    def forward(ctx, u, alpha, W, b, residual, kind, want_stats=False):
+        u = _f(u)
+        if kind in (1, 2):
+            h = hip_ops.gaussian_act(u, alpha, kind == 1)
+        elif kind == 3:
+            h = hip_ops.relu(u)
+        else:
+            h = torch.empty_like(u)
+            _lib.check(_lib.load().gecco_gelu_f32(_ptr(u), _ptr(h), u.numel(), _stream()), "gecco_gelu_f32")
+        ctx.save_for_backward(u, h, alpha if alpha is not None else u.new_empty(0), W)
+        ctx.kind, ctx.has_bias = kind, b is not None
+        res = None if residual is None else _f(residual)
+        img = WEIGHT_IMAGES.lookup("n", W) if _image_ok(h.shape[1], W.shape[1], W.shape[0]) else None
+        kw = dict(precision="bf16x3", w_image=img, w_shape=tuple(W.shape)) if img is not None else dict(precision=_train_precision())
+        if want_stats:
+            y, st = hip_ops.linear(h, None if img is not None else W, b, residual=res, want_stats=True, **kw)
+            ctx.mark_non_differentiable(st)
+            return y, st
+        return hip_ops.linear(h, None if img is not None else W, b, residual=res, **kw)
+
+    @staticmethod
+    def backward(ctx, dy, _dstats=None):
+        u, h, alpha, W = ctx.saved_tensors
+        kind = ctx.kind
+        dy = _f(dy)
+        lib = _lib.load()
+        B, R, Nout = dy.shape
+        K = W.shape[1]
+        prec = _train_precision()
+        dalpha = None
+        fused = (os.environ.get("GECCO_TRAIN_ACTBWD", "1") != "0" and prec in ("fp32", "bf16x3")
+                 and lib.gecco_linear_actbwd_ok(R, Nout, K, hip_ops.PRECISIONS[prec]))
+        if fused:
+            du = torch.empty_like(u)
+            nt = lib.gecco_linear_actbwd_tiles(B, R, K)
+            parts = torch.zeros(nt, device=u.device, dtype=torch.float32) if kind in (1, 2) else None
+            img = WEIGHT_IMAGES.lookup("t", W) if prec == "bf16x3" else None
+            if img is not None:
+                Wt, ws = None, img
+            else:
+                Wt = W.t().contiguous()
+                ws = hip_ops._ws((K + 127) // 128 * 128 * Nout * 4, u.device) if prec != "fp32" else None
+            _lib.check(lib.gecco_linear_actbwd_f32(_ptr(dy), _ptr(Wt), _ptr(u), _ptr(alpha) if kind in (1, 2) else None, kind, None,
+                                                   _ptr(du), _ptr(parts), B, R, Nout, K, hip_ops.PRECISIONS[prec],
+                                                   C.c_void_p(ws.data_ptr()) if ws is not None else None, _stream()),
+                       "gecco_linear_actbwd_f32")
+            if kind in (1, 2) and ctx.needs_input_grad[1]:
+                dalpha = _reduce(parts, 1, nt, 1).reshape(alpha.shape)
+        else:
+            dh = _linear_dx(dy, W)
+            if kind in (1, 2):
+                nb = lib.gecco_gauss_act_bwd_blocks(u.numel())
+                du, part = torch.empty_like(u), _new(nb, like=u)
+                _lib.check(lib.gecco_gauss_act_bwd_f32(_ptr(u), _ptr(dh), _ptr(alpha), _ptr(du), _ptr(part), u.numel(), int(kind == 1),
+                                                       _stream()), "gauss_act_bwd")
+                dalpha = _reduce(part, 1, nb, 1).reshape(alpha.shape)
+            elif kind == 3:
+                du = hip_ops.relu_bwd(h, dh)
+            else:
+                du = torch.empty_like(u)
+                _lib.check(lib.gecco_gelu_bwd_f32(_ptr(u), _ptr(dh), _ptr(du), u.numel(), _stream()), "gecco_gelu_bwd_f32")
+        dW = db = None
+        if ctx.has_bias and ctx.needs_input_grad[3] and ctx.needs_input_grad[2]:
+            dW, db = _linear_dw(dy, h, want_db=True)
+        elif ctx.needs_input_grad[2]:
+            dW = _linear_dw(dy, h)
+        elif ctx.has_bias and ctx.needs_input_grad[3]:
+            db = _linear_db(dy)
+        dres = dy if ctx.needs_input_grad[4] else None
+        return du, dalpha, dW, db, dres, None, None
+
+
 class ReluFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, u):
@@ -792,9 +872,9 @@ def convnext_pyramid(ext, image: Tensor) -> list[Tensor]:
         for blk in blocks:
             dw, ln, pw1, pw2 = blk.block[0], blk.block[2], blk.block[3], blk.block[5]
             y = CnxDwLnFn.apply(x, dw.weight, dw.bias, ln.weight, ln.bias, LN_EPS)
-            hid = GeluFn.apply(LinearFn.apply(y.view(1, rows, Cc), pw1.weight, pw1.bias))
+            u = LinearFn.apply(y.view(1, rows, Cc), pw1.weight, pw1.bias)
             ls = blk.layer_scale.reshape(-1)
-            x = LinearFn.apply(hid, pw2.weight * ls[:, None], pw2.bias * ls, x.view(1, rows, Cc)).view(Bq, hq, wq, Cc)
+            x = ActLinearFn.apply(u, None, pw2.weight * ls[:, None], pw2.bias * ls, x.view(1, rows, Cc), 4).view(Bq, hq, wq, Cc)
         feats.append(x.permute(0, 3, 1, 2))
     return feats
 
@@ -809,24 +889,27 @@ def mlp(mod, x, residual=None, want_stats=False):
     """nn.Sequential(Linear, act, Linear, ...) (reference models/mlp.py); `residual` is added by the last Linear's epilogue,
     which with `want_stats` also leaves the next norm's partial sums: returns (y, stats)."""
     from .models.activation import GaussianActivation
-    mods = list(mod)
-    i = 0
-    while i < len(mods):
-        lin = mods[i]
-        last = i + 2 >= len(mods)
-        x = LinearFn.apply(x, lin.weight, lin.bias, residual if last else None, want_stats and last)
-        if want_stats and last:
-            return x   # (y, stats)
-        if i + 1 < len(mods):
-            act = mods[i + 1]
-            if isinstance(act, GaussianActivation):
-                x = GaussActFn.apply(x, act.alpha, act.normalized)
-            elif isinstance(act, torch.nn.ReLU):
-                x = ReluFn.apply(x)
-            elif not isinstance(act, torch.nn.Identity):
-                raise NotImplementedError(f"training on HIP: no backward for activation {type(act).__name__}")
+    mods = list(mod)   # Linear, act, Linear[, act, Linear ...] (models/mlp.py)
+    n = len(mods)
+    x = LinearFn.apply(x, mods[0].weight, mods[0].bias, residual if n == 1 else None, want_stats and n == 1)
+    i = 1
+    while i + 1 < n:
+        act, lin = mods[i], mods[i + 1]
+        last = i + 2 >= n
+        if isinstance(act, GaussianActivation):
+            kind, alpha = (1 if act.normalized else 2), act.alpha
+        elif isinstance(act, torch.nn.ReLU):
+            kind, alpha = 3, None
+        elif isinstance(act, torch.nn.Identity):
+            kind, alpha = 0, None
+        else:
+            raise NotImplementedError(f"training on HIP: no backward for activation {type(act).__name__}")
+        if kind:   # activation + the linear after it: one Function whose backward runs act' as the dX product's epilogue
+            x = ActLinearFn.apply(x, alpha, lin.weight, lin.bias, residual if last else None, kind, want_stats and last)
+        else:
+            x = LinearFn.apply(x, lin.weight, lin.bias, residual if last else None, want_stats and last)
         i += 2
-    return x
+    return x   # (y, stats) with want_stats
 
 
 def broadcasting_layer(layer, x, t, h=None, stats=None, want_stats=False):

@@ -51,3 +51,16 @@ __device__ __forceinline__ float act_apply(float u, float neg_inv_2a2, int act) 
     return gauss_act(u, neg_inv_2a2, act == 1);
 }
 __device__ __forceinline__ bool act_is_gauss(int act) { return act == 1 || act == 2; }
+// d act / d u, and for GaussianActivation d act / d alpha (gauss_act_bwd_kernel's expressions, backward.hip)
+__device__ __forceinline__ float act_prime(float u, float neg_inv_2a2, float inv_a2, int kind, float& dalpha) {
+    dalpha = 0.f;
+    if (kind == 3) return u > 0.f ? 1.f : 0.f;
+    if (kind == 4) {
+        const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752f));
+        const float pdf = 0.3989422804014327f * __expf(-0.5f * u * u);
+        return cdf + u * pdf;
+    }
+    const float E = __expf(u * u * neg_inv_2a2) * (kind == 1 ? 1.0f / 0.28f : 1.0f);
+    dalpha = E * (u * u * inv_a2);   // x (1 / alpha) by the caller: E u^2 / alpha^3
+    return E * (-u * inv_a2);
+}

@@ -66,9 +66,9 @@ __device__ __forceinline__ Tile tile_of_block(const GemmArgs& g) {
 // barrier before it is the only block-wide one the store phase needs (a second one guards the statistics reduce).
 // C16: the output is stored as fp16 (round to nearest even; an intermediate its consumer would round anyway) — no
 // residual, no statistics in that form; ldc counts fp16 elements.
-template <int TMW, int TNW, int WMN, bool C16 = false>
-__device__ __forceinline__ void epilogue(const GemmArgs& g, const Tile& t, f32x16 (&acc)[TMW][TNW], float* smem,
-                                         int wave, int lane, int wm, int wn) {
+template <int TMW, int TNW, int WMN, bool C16, bool ACTBWD>
+__device__ __forceinline__ void epilogue_t(const GemmArgs& g, const Tile& t, f32x16 (&acc)[TMW][TNW], float* smem,
+                                           int wave, int lane, int wm, int wn) {
     const int tid = threadIdx.x, r = lane & 31, h = lane >> 5;
     const int b = t.b, rt = t.rt, m0 = t.m0, n0 = t.n0, nseg0 = t.nseg0, nseg = t.nseg, tilesM = t.tilesM;
     const float* bias_seg = t.bias_seg;
@@ -76,7 +76,12 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, const Tile& t, f32x1
     const int ldc_seg = t.ldc_seg;
     const bool has_act = g.act != 0;
     const int act_mode = g.act;
-    const float neg_inv_2a2 = act_is_gauss(g.act) ? -1.0f / (2.0f * g.alpha[0] * g.alpha[0]) : 0.f;
+    const bool mulg = ACTBWD && g.mul_u != nullptr && act_is_gauss(g.mul_kind);
+    const float alpha0 = (act_is_gauss(g.act) || mulg) ? g.alpha[0] : 1.f;
+    const float neg_inv_2a2 = (act_is_gauss(g.act) || mulg) ? -1.0f / (2.0f * alpha0 * alpha0) : 0.f;
+    const float inv_a2 = 1.0f / (alpha0 * alpha0);
+    const float* Ub = (ACTBWD && g.mul_u) ? g.mul_u + (size_t)b * g.rows * ldc_seg : nullptr;   // the pre-activation, laid out like C
+    float ga = 0.f;   // this thread's share of sum (A W^T) d act / d alpha
     float* Cb = Cseg + (size_t)b * g.rows * ldc_seg;
     const float* Rb = g.residual ? g.residual + (size_t)b * g.rows * g.ldr : nullptr;
     float* Tt = smem + wave * 32 * D_TP;
@@ -107,6 +112,12 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, const Tile& t, f32x1
                 for (int it = 0; it < 8; ++it) {
                     const int m = min(mrow0 + it * 4 + lr, g.rows - 1);
                     rres[it] = GECCO_NT_LOAD(reinterpret_cast<const f32x4*>(Rb + (size_t)m * g.ldr + nc));
+                }
+            } else if (ACTBWD && Ub) {   // the same eight loads in flight serve the pre-activation rows of the backward epilogue
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int m = min(mrow0 + it * 4 + lr, g.rows - 1);
+                    rres[it] = GECCO_NT_LOAD(reinterpret_cast<const f32x4*>(Ub + (size_t)m * ldc_seg + nc));
                 }
             }
 #pragma unroll
@@ -161,8 +172,17 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, const Tile& t, f32x1
             for (int it = 0; it < 8; ++it) {
                 const int m = mrow0 + it * 4 + lr;
                 f32x4 v4 = *reinterpret_cast<const f32x4*>(Tt + (it * 4 + lr) * D_TP + c4 * 4);
-                if (Rb) v4 += rres[it];
                 const bool ok = nok && m < g.rows;
+                if (Rb) v4 += rres[it];
+                else if (ACTBWD && Ub) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float da;
+                        const float f = act_prime(rres[it][q], neg_inv_2a2, inv_a2, g.mul_kind, da);
+                        if (ok) ga += v4[q] * da;
+                        v4[q] *= f;
+                    }
+                }
                 if (C16) {
                     typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
                     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -184,6 +204,17 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, const Tile& t, f32x1
 #pragma unroll
                 for (int q = 0; q < 4; ++q) s2[jh][q] = __builtin_fmaf(vz[q], vz[q], s2[jh][q]);
             }
+        }
+    }
+    if (ACTBWD && g.agrad && mulg) {   // (block-uniform) lanes, then the four waves, in a fixed order
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) ga += __shfl_xor(ga, o, 64);
+        __syncthreads();                       // every wave is done with its transpose tile: red is free
+        if (lane == 0) red[wave] = ga;
+        __syncthreads();
+        if (tid == 0) {
+            const int T128 = (g.rows + 127) / 128, tn = (g.Nout + DBN - 1) / DBN;
+            g.agrad[((size_t)b * T128 + (m0 >> 7)) * tn + (n0 / DBN)] = (((red[0] + red[1]) + red[2]) + red[3]) / alpha0;
         }
     }
     if (g.stats) {
@@ -225,6 +256,14 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, const Tile& t, f32x1
             }
         }
     }
+}
+
+// The forward epilogue; the training path's activation-backward products (GemmArgs::mul_u) run a separate KERNEL
+// instantiation (gemm_f32_dma.hip: ACTBWD) with the second form, so the inference kernels are the code they were.
+template <int TMW, int TNW, int WMN, bool C16 = false>
+__device__ __forceinline__ void epilogue(const GemmArgs& g, const Tile& t, f32x16 (&acc)[TMW][TNW], float* smem,
+                                         int wave, int lane, int wm, int wn) {
+    epilogue_t<TMW, TNW, WMN, C16, false>(g, t, acc, smem, wave, lane, wm, wn);
 }
 
 }  // namespace dma

@@ -70,8 +70,9 @@ __device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, bf16x8&
 // AIMG: A arrives as the tiled split image of GemmArgs::a_img (written by the producing GEMM's epilogue): its blocks are DMA'd
 // as they are — 1 KiB contiguous per wave-instruction like the W image, where fp32 rows give 64-byte pieces — and the
 // fragments are read as bf16 hi / lo planes: no split, no VALU in the K loop.
-template <int DNS, bool HAS_PRO, bool X3, int BM = 128, bool AIMG = false>
+template <int DNS, bool HAS_PRO, bool X3, int BM = 128, bool AIMG = false, bool ACTBWD = false>
 __global__ __launch_bounds__(DNT, BM == 256 ? 2 : (DNS <= 3 ? 3 : 2)) void gemm_dma_kernel(GemmArgs g) {
+    // ACTBWD: the epilogue multiplies by act'(u) (GemmArgs::mul_u) — the training path's dX product after an activation
     static_assert(BM == 128 || ((BM == 64 || BM == 256) && X3), "64- and 256-row tiles exist in split-bf16 mode only");
     static_assert(!AIMG || (X3 && !HAS_PRO && BM >= 128), "the activation image feeds the split-bf16 kernel without prologue");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(DNT, BM == 256 ? 2 : (DNS <= 3 ? 3 : 2)) void gemm_
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // ring is dead: the epilogue reuses it
 
-    dma::epilogue<TMW, TNW, WMN>(g, T, acc, smem, wave, lane, wm, wn);
+    dma::epilogue_t<TMW, TNW, WMN, false, ACTBWD>(g, T, acc, smem, wave, lane, wm, wn);
 }
 
 // W (Nout, ldw) fp32 -> the tiled split-bf16 image the X3 kernel streams: for column tile ct (128 rows of W) and
@@ -382,7 +383,16 @@ int dma_launch_t(const GemmArgs& g, hipStream_t st) {
         attr = lds;
     }
     const dim3 grid(g.B * tilesM * tilesN);
-    if (g.pro_a) hipLaunchKernelGGL((gemm_dma_kernel<DNS, true, X3, BM>), grid, dim3(DNT), lds, st, g);
+    if (g.mul_u) {
+        if (g.pro_a) return -9;
+        static size_t attr2 = 0;
+        if (lds > attr2) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma_kernel<DNS, false, X3, BM, false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr2 = lds;
+        }
+        hipLaunchKernelGGL((gemm_dma_kernel<DNS, false, X3, BM, false, true>), grid, dim3(DNT), lds, st, g);
+    } else if (g.pro_a) hipLaunchKernelGGL((gemm_dma_kernel<DNS, true, X3, BM>), grid, dim3(DNT), lds, st, g);
     else hipLaunchKernelGGL((gemm_dma_kernel<DNS, false, X3, BM>), grid, dim3(DNT), lds, st, g);
     return (int)hipGetLastError();
 }

@@ -43,6 +43,15 @@ struct GemmArgs {
     // c_img: C is written that way (no residual, no statistics, rows % 128 == 0, Nout % 16 == 0);  a_img: A is read that way
     // (no prologue; K % 16 == 0): contiguous 1 KiB DMA pieces instead of 64-byte row pieces, and no hi / lo split in the K loop.
     int a_img, c_img;
+    // Activation BACKWARD as an epilogue (training: the dX product of the linear that FOLLOWS an activation).  C = (A W^T) *
+    // act'(u) with u (B, rows, ldc) the pre-activation the forward kept: dh = dy W2 never exists, du leaves directly.
+    // mul_kind: 1 / 2 GaussianActivation normalized / raw (alpha in `alpha`), 3 ReLU, 4 GELU.  agrad (Gaussian only):
+    // one float per 128-row x 128-column output tile, (b * ceil(rows / 128) + m0 / 128) * ceil(Nout / 128) + n0 / 128,
+    // = sum over the tile of (A W^T) * d act / d alpha (u) — the alpha gradient's partials (zero-initialised by the caller:
+    // 256-row tiles write every other row slot).  LDS-DMA kernels only; no bias, no forward activation, no statistics.
+    const float* mul_u;
+    int mul_kind;
+    float* agrad;
 };
 
 struct SplitJob { const float* W; float* img; int Nout, K, ldw, pad_; };   // pad_ = 1 (fp16 images): the LOW part fp16(W - fp16(W)); 2: the same as fp8 x 2^19 in 64-k blocks; 4 (bf16 images): W is (K, ldw) and the image is of W^T

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GECCO_ABI_VERSION 8
+#define GECCO_ABI_VERSION 9
 
 int gecco_abi_version(void);
 const char* gecco_build_arch(void);   /* "gfx950" */
@@ -124,6 +124,17 @@ typedef struct GeccoSplitJob { const float* W; void* img; int Nout, K, ldw, tran
 int gecco_split_bf16_images_f32(const GeccoSplitJob* jobs, int n, void* stream);
 size_t gecco_split_bf16_image_bytes(int Nout, int K);
 int gecco_linear_image_ok(int rows, int K, int Nout, int with_prologue);
+/* The dX product of the linear that FOLLOWS an activation, with the activation's backward as its epilogue (training:
+ * autograd of models/mlp.py's Linear -> act -> Linear, and of a CNBlock's Linear -> GELU -> Linear):
+ *   C = residual + (A W^T) * act'(u),   A = dY (B, rows, K), W (Nout, K) = W2^T (or NULL: its ready image in wsplit),
+ *   u (B, rows, Nout) the pre-activation the forward kept; dh = dY W2 is never written.
+ * kind: 1 / 2 GaussianActivation normalized / raw, 3 ReLU, 4 GELU.  GaussianActivation: alpha (device scalar), and agrad —
+ * gecco_linear_actbwd_tiles(B, rows, Nout) floats, ZEROED by the caller — receives per output tile
+ * sum (A W^T) * d act / d alpha (u): d alpha = their sum (gecco_reduce_batch_f32).  Shapes: gecco_linear_actbwd_ok. */
+int gecco_linear_actbwd_ok(int rows, int K, int Nout, int precision);
+size_t gecco_linear_actbwd_tiles(int B, int rows, int Nout);
+int gecco_linear_actbwd_f32(const float* A, const float* W, const float* u, const float* alpha, int kind, const float* residual,
+                            float* C, float* agrad, int B, int rows, int K, int Nout, int precision, void* wsplit, void* stream);
 
 /* GroupNorm partial statistics of x (B, rows, C): stats (B, T, 2, C), T = gecco_stats_row_tiles(rows). */
 int gecco_col_stats_f32(const float* x, float* stats, int B, int rows, int C, void* stream);

@@ -491,3 +491,49 @@ def test_batched_weight_images_leave_the_training_step_unchanged(monkeypatch):
     finally:
         hip_ops.set_default_precision(prev)
         ag.WEIGHT_IMAGES.__init__()
+
+
+@pytest.mark.parametrize("kind", [1, 2, 3, 4])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_activation_backward_as_gemm_epilogue(kind, precision, monkeypatch):
+    """ActLinearFn: act(u) @ W^T + b (+ residual) whose backward runs act' as the epilogue of the dX product
+    (gecco_linear_actbwd_f32: dh = dy W never written, the alpha-gradient partials from the same epilogue), against the
+    two-kernel backward (GECCO_TRAIN_ACTBWD=0) and against torch autograd in fp64; 128- and 256-row tiles, a ragged
+    last row tile."""
+    from gecco_amd import autograd as ag
+    from gecco_amd import hip_ops
+    rs = np.random.RandomState(10 * kind + len(precision))
+    prev = hip_ops.default_precision()
+    hip_ops.set_default_precision(precision)
+    try:
+        for (B, R, K, Nout) in ((2, 384, 768, 384), (3, 200, 256, 128), (1, 512, 384, 96)):
+            u = _t(rs.randn(B, R, K) * 1.5)
+            Wm, b = _t(rs.randn(Nout, K) / np.sqrt(K)), _t(rs.randn(Nout) * 0.1)
+            res, dy = _t(rs.randn(B, R, Nout)), _t(rs.randn(B, R, Nout))
+            alpha = torch.tensor(0.8)
+
+            def act64(x, a):
+                if kind in (1, 2):
+                    y = torch.exp(-x ** 2 / (2 * a ** 2))
+                    return (y - 0.7) / 0.28 if kind == 1 else y
+                return torch.relu(x) if kind == 3 else torch.nn.functional.gelu(x)
+            u64, a64, W64, r64 = (t.double().requires_grad_(True) for t in (u, alpha, Wm, res))
+            (((act64(u64, a64) @ W64.t() + b.double() + r64) * dy.double()).sum()).backward()
+
+            def run(fused):
+                monkeypatch.setenv("GECCO_TRAIN_ACTBWD", "1" if fused else "0")
+                ug, ag_, Wg, bg, rg = (_leaf(t, "cuda") for t in (u, alpha, Wm, b, res))
+                y = ag.ActLinearFn.apply(ug, ag_ if kind < 3 else None, Wg, bg, rg, kind)
+                y.backward(dy.cuda())
+                return y.detach(), ug.grad, (ag_.grad if kind < 3 else None), Wg.grad, bg.grad, rg.grad
+            yf, duf, daf, dWf, dbf, drf = run(True)
+            y0, du0, da0, dW0, db0, dr0 = run(False)
+            tol = 2e-5 if precision == "fp32" else 3e-4
+            assert torch.equal(yf, y0) and torch.equal(dWf, dW0) and torch.equal(dbf, db0) and torch.equal(drf, dr0)
+            _close(duf, u64.grad.float(), tol)
+            _close(duf, du0.cpu(), tol)
+            if kind < 3:
+                _close(daf.reshape(()), a64.grad.float().reshape(()), 10 * tol)
+                _close(daf.reshape(()), da0.cpu().reshape(()), 10 * tol)
+    finally:
+        hip_ops.set_default_precision(prev)

@@ -229,16 +229,18 @@ def test_c2_full_size_gradients_vs_oracle(ops, precision):
     assert worst[1] > 0.0   # gradients were really compared
 
 
-def test_c3_full_size_training_step_vs_oracle(ops):
+@pytest.mark.parametrize("cfg", ["C3", "C4"])
+def test_conditional_full_size_training_step_vs_oracle(ops, cfg):
     """The image-conditional training step at the C3 size (224 x 224 images -> ConvNeXt-T pyramids 96 / 192 / 384 channels ->
-    projective lookup -> RayNetwork, N = 2048, d = 384, L = 6), conditioner TRAINED as in the reference: the loss and the
-    gradient of every parameter — conditioner and denoiser — against torch autograd through the oracle chain
-    convnext_features -> cond_denoiser -> EDM loss (split-bf16, what `bench.py --train --config C3` runs)."""
+    projective lookup -> RayNetwork, N = 2048, d = 384, L = 6) and at the C4 size — BASELINE's data-parallel training
+    configuration: 256 x 256 images, N = 4096, d = 512 — conditioner TRAINED as in the reference: the loss and the gradient of
+    every parameter — conditioner and denoiser — against torch autograd through the oracle chain convnext_features ->
+    cond_denoiser -> EDM loss (split-bf16, what `bench.py --train --config C3 | C4` runs)."""
     from gecco_amd.models.feature_pyramid import ConvNeXtExtractor
     from gecco_amd.structs import Context3d
     from tests.test_hip_convnext import _seeded_state
     from tests.test_modules_cpu import build_cond
-    d, L, N, hw, B = 384, 6, 2048, 224, 2
+    d, L, N, hw, B = (384, 6, 2048, 224, 2) if cfg == "C3" else (512, 6, 4096, 256, 2)
     cn = ConvNeXtExtractor(n_stages=3, model="tiny", pretrained=False)
     csd = _seeded_state(cn, 9)
     cn.load_state_dict(csd, strict=True)
@@ -269,7 +271,7 @@ def test_c3_full_size_training_step_vs_oracle(ops):
     finally:
         ops.set_default_precision(old)
     lv, rv = float(loss.detach()), float(ref_loss.detach())
-    print(f"C3 training: loss {lv:.6f} (oracle {rv:.6f})")
+    print(f"{cfg} training: loss {lv:.6f} (oracle {rv:.6f})")
     assert abs(lv - rv) / abs(rv) < 1e-4
     worst = {"conditioner": ("", 0.0), "denoiser": ("", 0.0)}
     for k, q in m.named_parameters():
@@ -284,5 +286,5 @@ def test_c3_full_size_training_step_vs_oracle(ops):
         worst[part] = max(worst[part], (k, e), key=lambda t: t[1])
         assert e < 3e-3, (k, e)
     for part, (k, e) in worst.items():
-        print(f"C3 training: worst {part} gradient {k} {e:.2e} (bar 3e-03)")
+        print(f"{cfg} training: worst {part} gradient {k} {e:.2e} (bar 3e-03)")
         assert e > 0.0

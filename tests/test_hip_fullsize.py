@@ -273,12 +273,15 @@ def test_conditional_full_size_training_step_vs_oracle(ops, cfg):
     lv, rv = float(loss.detach()), float(ref_loss.detach())
     print(f"{cfg} training: loss {lv:.6f} (oracle {rv:.6f})")
     assert abs(lv - rv) / abs(rv) < 1e-4
-    worst = {"conditioner": ("", 0.0), "denoiser": ("", 0.0)}
+    worst = {"conditioner": ("", 0.0), "denoiser": ("", 0.0), "denoiser matrices": ("", 0.0)}
     for k, q in m.named_parameters():
         if k.startswith("conditioner."):
             r, part = cp[k[len("conditioner."):]].grad, "conditioner"
         elif k.startswith("backbone.model."):
             r, part = pr[k[len("backbone.model."):]].grad, "denoiser"
+            if q.dim() == 2 and min(q.shape) > 1:
+                e2 = cpu_ref.rel_err(q.grad.cpu(), r)[0]
+                worst["denoiser matrices"] = max(worst["denoiser matrices"], (k, e2), key=lambda t: t[1])
         else:
             continue
         assert q.grad is not None and r is not None, k

@@ -9,8 +9,26 @@ class GeccoTrainingNotSupported(NotImplementedError):
     pass
 
 
+def outside_fused_reach(module) -> bool:
+    """True when the module tree holds a configuration the fused inference entry points do not take — today: a number of
+    inducers other than 64 (the attention kernels are built around 64 = two 32-row matrix tiles; every shipped config uses
+    64, the reference's constructor takes any).  Such models run the general composition of gecco_amd/autograd.py (every op
+    still in libgecco_hip.so: attention with materialised scores on the strided-batched GEMM) instead of raising.
+    Decided once per module object."""
+    hit = module.__dict__.get("_gecco_general")
+    if hit is None:
+        hit = any(getattr(m, "inducers", None) is not None and m.inducers.dim() == 4 and m.inducers.shape[2] != 64
+                  for m in module.modules())
+        module.__dict__["_gecco_general"] = hit
+    return hit
+
+
 def needs_grad(module, *tensors) -> bool:
-    """True when autograd would record this call: grad mode on and a trainable parameter or input involved."""
+    """True when the call has to take the unfused path of gecco_amd/autograd.py: autograd would record it (grad mode on and a
+    trainable parameter or input involved), or the configuration is outside the fused kernels' reach (`outside_fused_reach`:
+    then also under no_grad — the Functions' forwards alone)."""
+    if outside_fused_reach(module):
+        return True
     if not torch.is_grad_enabled():
         return False
     return any(torch.is_tensor(t) and t.requires_grad for t in tensors) or any(p.requires_grad for p in module.parameters())
@@ -24,3 +42,13 @@ def require_no_grad(module, *tensors) -> None:
         raise GeccoTrainingNotSupported(
             f"{type(module).__name__} has no backward on the MI355X HIP path (the denoiser, loss and optimizer do: "
             "gecco_amd/autograd.py, gecco_amd/optim.py); run this module under torch.no_grad() or keep its parameters frozen.")
+
+
+def result_into(out, res, do_cache: bool):
+    """The unfused path returns fresh tensors; a caller that passed `out=` (the samplers' state buffers) gets the denoised
+    cloud written there, as the fused entry points do."""
+    if out is None:
+        return res
+    den = res[0] if do_cache else res
+    out.copy_(den)
+    return (out, res[1]) if do_cache else out

@@ -6,7 +6,7 @@ from typing import Any
 from torch import Tensor, nn
 
 from .. import hip_ops
-from .._grad import needs_grad
+from .._grad import needs_grad, result_into as _into
 from .set_transformer import SetTransformer, _PlanCache
 
 
@@ -48,7 +48,7 @@ class LinearLift(nn.Module):
         self._check()
         if needs_grad(self, x, sigma):
             from .. import autograd as ag
-            return ag.linear_lift_edm(self, x.float(), sigma, sigma_data, do_cache, cache)
+            return _into(out, ag.linear_lift_edm(self, x.float(), sigma, sigma_data, do_cache, cache), do_cache)
 
         def build():
             st = self.inner.plan()

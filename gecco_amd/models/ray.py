@@ -6,7 +6,7 @@ import torch
 from torch import Tensor, nn
 
 from .. import hip_ops
-from .._grad import needs_grad
+from .._grad import needs_grad, result_into as _into
 from ..reparam import Reparam
 from ..structs import Context3d
 from .feature_pyramid import FeaturePyramidContext
@@ -77,7 +77,8 @@ class RayNetwork(nn.Module):
                   do_cache: bool, cache, sigma_data: float, out: Tensor | None = None):
         if needs_grad(self, x, sigma, *post_context.features):
             from .. import autograd as ag
-            return ag.ray_network_edm(self, x.float(), sigma, sigma_data, raw_ctx.K, post_context.features, do_cache, cache)
+            return _into(out, ag.ray_network_edm(self, x.float(), sigma, sigma_data, raw_ctx.K, post_context.features, do_cache,
+                                                 cache), do_cache)
 
         def build():
             st = self.backbone.plan()

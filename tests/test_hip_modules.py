@@ -350,3 +350,43 @@ def test_default_relu_activation_golden(golden_dir, precision, tol):
                 _close(got, pg[k].grad, 5e-4)
     finally:
         hip_ops.set_default_precision(old)
+
+
+@pytest.mark.parametrize("I", [32, 96])
+def test_num_inducers_other_than_64_runs_the_general_path(I):
+    """The reference's `SetTransformer(num_inducers=...)` takes any count; the fused kernels are built around 64.  Other
+    counts run the general composition (every op still in libgecco_hip.so) instead of raising: forward and cached
+    evaluation against the oracle, the sampler, and the training gradients against the oracle's autograd."""
+    d, L, N, B = 128, 2, 256, 3
+    p = W.linear_lift_state_dict(23, d, L, I, cases.H)
+    m = build_uncond(d, L, num_inducers=I)
+    m.load_state_dict(uncond_state_dict(p), strict=True)
+    m = m.cuda().eval()
+    rs = np.random.RandomState(I)
+    x = torch.from_numpy(rs.randn(B, N, 3).astype(np.float32))
+    sigma = torch.tensor([0.05, 1.0, 40.0])
+    D = cpu_ref.uncond_denoiser(p, "", cases.H)
+    with torch.no_grad():
+        ref, ref_cache = D(x, sigma, do_cache=True)
+        out, cache = m(x.cuda(), sigma.cuda(), None, do_cache=True)
+        _close(out, ref, 2e-5)
+        assert len(cache) == L and cache[0].shape == (B, I, d)
+        x2 = torch.from_numpy(rs.randn(B, 2 * N, 3).astype(np.float32))
+        _close(m(x2.cuda(), sigma.cuda(), None, cache=cache), D(x2, sigma, cache=ref_cache), 2e-5)
+        smp = m.sample_stochastic((B, N, 3), None, num_steps=4)
+        assert smp.shape == (B, N, 3) and torch.isfinite(smp).all()
+    # training: loss and every gradient
+    m.train()
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    data = torch.from_numpy(rs.randn(B, N, 3).astype(np.float32))
+    noise = torch.from_numpy(rs.randn(B, N, 3).astype(np.float32))
+    s3 = sigma.reshape(-1, 1, 1)
+    ref_loss = (100.0 * (s3 ** 2 + 1) / s3 ** 2 * (cpu_ref.uncond_denoiser(pr, "", cases.H)(data + noise * s3, sigma) - data) ** 2).mean()
+    ref_loss.backward()
+    s3c = s3.cuda()
+    loss = (100.0 * (s3c ** 2 + 1) / s3c ** 2 * (m(data.cuda() + noise.cuda() * s3c, sigma.cuda(), None) - data.cuda()) ** 2).mean()
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) / abs(float(ref_loss.detach())) < 1e-5
+    for k, q in m.named_parameters():
+        if k.startswith("backbone.model."):
+            _close(q.grad, pr[k[len("backbone.model."):]].grad, 2e-4)

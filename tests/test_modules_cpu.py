@@ -10,13 +10,13 @@ from oracle import cases, cpu_ref
 from oracle import weights as W
 
 
-def build_uncond(d, L, sigma_max=165.0):
+def build_uncond(d, L, sigma_max=165.0, num_inducers=None):
     from gecco_amd.diffusion import Diffusion, EDMLoss, EDMPrecond, IdleConditioner, LogUniformSchedule
     from gecco_amd.models.activation import GaussianActivation
     from gecco_amd.models.linear_lift import LinearLift
     from gecco_amd.models.set_transformer import SetTransformer
     from gecco_amd.reparam import GaussianReparam
-    net = LinearLift(inner=SetTransformer(n_layers=L, num_inducers=cases.I, feature_dim=d, t_embed_dim=1,
+    net = LinearLift(inner=SetTransformer(n_layers=L, num_inducers=num_inducers or cases.I, feature_dim=d, t_embed_dim=1,
                                           num_heads=cases.H, activation=GaussianActivation), feature_dim=d)
     return Diffusion(backbone=EDMPrecond(model=net), conditioner=IdleConditioner(),
                      reparam=GaussianReparam(torch.tensor(cases.GAUSS_MEAN), torch.tensor(cases.GAUSS_SIGMA)),

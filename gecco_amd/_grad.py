@@ -12,13 +12,19 @@ class GeccoTrainingNotSupported(NotImplementedError):
 def outside_fused_reach(module) -> bool:
     """True when the module tree holds a configuration the fused inference entry points do not take — today: a number of
     inducers other than 64 (the attention kernels are built around 64 = two 32-row matrix tiles; every shipped config uses
-    64, the reference's constructor takes any).  Such models run the general composition of gecco_amd/autograd.py (every op
+    64, the reference's constructor takes any), or a head dimension that is not a multiple of 8 up to 64 (multiples of 4 run
+    here; anything else is rejected by the strided-batched GEMM's 16-byte loads).  Such models run the general composition of gecco_amd/autograd.py (every op
     still in libgecco_hip.so: attention with materialised scores on the strided-batched GEMM) instead of raising.
     Decided once per module object."""
     hit = module.__dict__.get("_gecco_general")
     if hit is None:
-        hit = any(getattr(m, "inducers", None) is not None and m.inducers.dim() == 4 and m.inducers.shape[2] != 64
-                  for m in module.modules())
+        def general(m):
+            ind = getattr(m, "inducers", None)
+            if ind is None or ind.dim() != 4:
+                return False
+            hd = ind.shape[3]                       # (1, H, I, head dim)
+            return ind.shape[2] != 64 or hd % 8 != 0 or hd > 64
+        hit = any(general(m) for m in module.modules())
         module.__dict__["_gecco_general"] = hit
     return hit
 

@@ -352,12 +352,13 @@ def test_default_relu_activation_golden(golden_dir, precision, tol):
         hip_ops.set_default_precision(old)
 
 
-@pytest.mark.parametrize("I", [32, 96])
-def test_num_inducers_other_than_64_runs_the_general_path(I):
+@pytest.mark.parametrize("I,d", [(32, 128), (96, 128), (64, 96), (64, 640)])
+def test_num_inducers_other_than_64_runs_the_general_path(I, d):
     """The reference's `SetTransformer(num_inducers=...)` takes any count; the fused kernels are built around 64.  Other
     counts run the general composition (every op still in libgecco_hip.so) instead of raising: forward and cached
-    evaluation against the oracle, the sampler, and the training gradients against the oracle's autograd."""
-    d, L, N, B = 128, 2, 256, 3
+    evaluation against the oracle, the sampler, and the training gradients against the oracle's autograd.  Likewise head
+    dimensions outside the fused attention kernels' set (d = 96: 12, d = 640: 80 with the 8 heads of every config)."""
+    L, N, B = 2, 256, 3
     p = W.linear_lift_state_dict(23, d, L, I, cases.H)
     m = build_uncond(d, L, num_inducers=I)
     m.load_state_dict(uncond_state_dict(p), strict=True)

@@ -360,6 +360,121 @@ class GaussActFn(torch.autograd.Function):
         return du, dalpha, None
 
 
+def _act_linear_dx(dy: Tensor, u: Tensor, h: Tensor, alpha: Tensor, W: Tensor, kind: int, want_alpha: bool):
+    """du = (dy W) * act'(u) and, for GaussianActivation, d alpha: the activation's backward as the epilogue of the dX product
+    (`gecco_linear_actbwd_f32`) where the LDS-DMA kernels take the shape, else the product followed by the activation's
+    backward kernel."""
+    lib = _lib.load()
+    B, R, Nout = dy.shape
+    K = W.shape[1]
+    prec = _train_precision()
+    dalpha = None
+    fused = (os.environ.get("GECCO_TRAIN_ACTBWD", "1") != "0" and prec in ("fp32", "bf16x3")
+             and lib.gecco_linear_actbwd_ok(R, Nout, K, hip_ops.PRECISIONS[prec]))
+    if fused:
+        du = torch.empty_like(u)
+        nt = lib.gecco_linear_actbwd_tiles(B, R, K)
+        parts = torch.zeros(nt, device=u.device, dtype=torch.float32) if kind in (1, 2) else None
+        img = WEIGHT_IMAGES.lookup("t", W) if prec == "bf16x3" else None
+        if img is not None:
+            Wt, ws = None, img
+        else:
+            Wt = W.t().contiguous()
+            ws = hip_ops._ws((K + 127) // 128 * 128 * Nout * 4, u.device) if prec != "fp32" else None
+        _lib.check(lib.gecco_linear_actbwd_f32(_ptr(dy), _ptr(Wt), _ptr(u), _ptr(alpha) if kind in (1, 2) else None, kind, None,
+                                               _ptr(du), _ptr(parts), B, R, Nout, K, hip_ops.PRECISIONS[prec],
+                                               C.c_void_p(ws.data_ptr()) if ws is not None else None, _stream()),
+                   "gecco_linear_actbwd_f32")
+        if kind in (1, 2) and want_alpha:
+            dalpha = _reduce(parts, 1, nt, 1).reshape(alpha.shape)
+        return du, dalpha
+    dh = _linear_dx(dy, W)
+    if kind in (1, 2):
+        nb = lib.gecco_gauss_act_bwd_blocks(u.numel())
+        du, part = torch.empty_like(u), _new(nb, like=u)
+        _lib.check(lib.gecco_gauss_act_bwd_f32(_ptr(u), _ptr(dh), _ptr(alpha), _ptr(du), _ptr(part), u.numel(), int(kind == 1),
+                                               _stream()), "gauss_act_bwd")
+        dalpha = _reduce(part, 1, nb, 1).reshape(alpha.shape)
+    elif kind == 3:
+        du = hip_ops.relu_bwd(h, dh)
+    else:
+        du = torch.empty_like(u)
+        _lib.check(lib.gecco_gelu_bwd_f32(_ptr(u), _ptr(dh), _ptr(du), u.numel(), _stream()), "gecco_gelu_bwd_f32")
+    return du, dalpha
+
+
+def _act_forward(u: Tensor, alpha: Tensor | None, kind: int) -> Tensor:
+    if kind in (1, 2):
+        return hip_ops.gaussian_act(u, alpha, kind == 1)
+    if kind == 3:
+        return hip_ops.relu(u)
+    h = torch.empty_like(u)
+    _lib.check(_lib.load().gecco_gelu_f32(_ptr(u), _ptr(h), u.numel(), _stream()), "gecco_gelu_f32")
+    return h
+
+
+def _linear_fwd(x: Tensor, W: Tensor, b, res, want_stats: bool):
+    """hip_ops.linear in the training precision, with the step's ready weight image when there is one."""
+    img = WEIGHT_IMAGES.lookup("n", W) if _image_ok(x.shape[1], W.shape[1], W.shape[0]) else None
+    kw = dict(precision="bf16x3", w_image=img, w_shape=tuple(W.shape)) if img is not None else dict(precision=_train_precision())
+    return hip_ops.linear(x, None if img is not None else W, b, residual=res, want_stats=want_stats, **kw)
+
+
+class LinearActLinearFn(torch.autograd.Function):
+    """y = act(x @ W0^T + b0) @ W2^T + b2 (+ residual): an MLP of the reference (models/mlp.py: Linear -> act -> Linear; a
+    CNBlock's pointwise pair) as ONE Function.  Forward: the first GEMM's epilogue leaves both u = x W0^T + b0 and act(u)
+    (`gecco_linear_act_keep_f32`: no activation pass); backward: act' is the epilogue of the second linear's dX product
+    (`_act_linear_dx`).  kind: 1 / 2 GaussianActivation normalized / raw, 3 ReLU, 4 GELU."""
+
+    @staticmethod
+    def forward(ctx, x, W0, b0, alpha, W2, b2, residual, kind, want_stats=False):
+        x = _f(x)
+        lib = _lib.load()
+        B, R, K0 = x.shape
+        N0 = W0.shape[0]
+        prec = _train_precision()
+        keep = (os.environ.get("GECCO_TRAIN_ACTKEEP", "1") != "0" and prec in ("fp32", "bf16x3")
+                and lib.gecco_linear_actbwd_ok(R, K0, N0, hip_ops.PRECISIONS[prec]))
+        if keep:
+            u, h = _new(B, R, N0, like=x), _new(B, R, N0, like=x)
+            img = WEIGHT_IMAGES.lookup("n", W0) if prec == "bf16x3" and _image_ok(R, K0, N0) else None
+            if img is not None:
+                Wp, ws = None, img
+            else:
+                Wp = _f(W0)
+                ws = hip_ops._ws((N0 + 127) // 128 * 128 * K0 * 4, x.device) if prec != "fp32" else None
+            _lib.check(lib.gecco_linear_act_keep_f32(_ptr(x), _ptr(Wp), _ptr(b0), _ptr(alpha) if kind in (1, 2) else None, kind,
+                                                     _ptr(u), _ptr(h), B, R, K0, N0, hip_ops.PRECISIONS[prec],
+                                                     C.c_void_p(ws.data_ptr()) if ws is not None else None, _stream()),
+                       "gecco_linear_act_keep_f32")
+        else:
+            u = _linear_fwd(x, W0, b0, None, False)
+            h = _act_forward(u, alpha, kind)
+        ctx.save_for_backward(x, u, h, alpha if alpha is not None else x.new_empty(0), W0, W2)
+        ctx.kind, ctx.bias = kind, (b0 is not None, b2 is not None)
+        res = None if residual is None else _f(residual)
+        out = _linear_fwd(h, W2, b2, res, want_stats)
+        if want_stats:
+            ctx.mark_non_differentiable(out[1])
+        return out
+
+    @staticmethod
+    def backward(ctx, dy, _dstats=None):
+        x, u, h, alpha, W0, W2 = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        dy = _f(dy)
+        du, dalpha = _act_linear_dx(dy, u, h, alpha, W2, ctx.kind, need[3])
+
+        def wgrads(g, a, has_b, iw, ib):
+            if has_b and need[ib] and need[iw]:
+                return _linear_dw(g, a, want_db=True)
+            return (_linear_dw(g, a) if need[iw] else None), (_linear_db(g) if has_b and need[ib] else None)
+        dW2, db2 = wgrads(dy, h, ctx.bias[1], 4, 5)
+        dW0, db0 = wgrads(du, x, ctx.bias[0], 1, 2)
+        dx = _linear_dx(du, W0) if need[0] else None
+        return dx, dW0, db0, dalpha, dW2, db2, (dy if need[6] else None), None, None
+
+
 class ActLinearFn(torch.autograd.Function):
     """y = act(u) @ W^T + b (+ residual): the activation and the linear that follows it (models/mlp.py: Linear -> act ->
     Linear; a CNBlock's Linear -> GELU -> Linear) as ONE Function, so that the backward can run the activation's derivative
@@ -370,65 +485,20 @@ class ActLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, u, alpha, W, b, residual, kind, want_stats=False):
         u = _f(u)
-        if kind in (1, 2):
-            h = hip_ops.gaussian_act(u, alpha, kind == 1)
-        elif kind == 3:
-            h = hip_ops.relu(u)
-        else:
-            h = torch.empty_like(u)
-            _lib.check(_lib.load().gecco_gelu_f32(_ptr(u), _ptr(h), u.numel(), _stream()), "gecco_gelu_f32")
+        h = _act_forward(u, alpha, kind)
         ctx.save_for_backward(u, h, alpha if alpha is not None else u.new_empty(0), W)
         ctx.kind, ctx.has_bias = kind, b is not None
         res = None if residual is None else _f(residual)
-        img = WEIGHT_IMAGES.lookup("n", W) if _image_ok(h.shape[1], W.shape[1], W.shape[0]) else None
-        kw = dict(precision="bf16x3", w_image=img, w_shape=tuple(W.shape)) if img is not None else dict(precision=_train_precision())
+        out = _linear_fwd(h, W, b, res, want_stats)
         if want_stats:
-            y, st = hip_ops.linear(h, None if img is not None else W, b, residual=res, want_stats=True, **kw)
-            ctx.mark_non_differentiable(st)
-            return y, st
-        return hip_ops.linear(h, None if img is not None else W, b, residual=res, **kw)
+            ctx.mark_non_differentiable(out[1])
+        return out
 
     @staticmethod
     def backward(ctx, dy, _dstats=None):
         u, h, alpha, W = ctx.saved_tensors
-        kind = ctx.kind
         dy = _f(dy)
-        lib = _lib.load()
-        B, R, Nout = dy.shape
-        K = W.shape[1]
-        prec = _train_precision()
-        dalpha = None
-        fused = (os.environ.get("GECCO_TRAIN_ACTBWD", "1") != "0" and prec in ("fp32", "bf16x3")
-                 and lib.gecco_linear_actbwd_ok(R, Nout, K, hip_ops.PRECISIONS[prec]))
-        if fused:
-            du = torch.empty_like(u)
-            nt = lib.gecco_linear_actbwd_tiles(B, R, K)
-            parts = torch.zeros(nt, device=u.device, dtype=torch.float32) if kind in (1, 2) else None
-            img = WEIGHT_IMAGES.lookup("t", W) if prec == "bf16x3" else None
-            if img is not None:
-                Wt, ws = None, img
-            else:
-                Wt = W.t().contiguous()
-                ws = hip_ops._ws((K + 127) // 128 * 128 * Nout * 4, u.device) if prec != "fp32" else None
-            _lib.check(lib.gecco_linear_actbwd_f32(_ptr(dy), _ptr(Wt), _ptr(u), _ptr(alpha) if kind in (1, 2) else None, kind, None,
-                                                   _ptr(du), _ptr(parts), B, R, Nout, K, hip_ops.PRECISIONS[prec],
-                                                   C.c_void_p(ws.data_ptr()) if ws is not None else None, _stream()),
-                       "gecco_linear_actbwd_f32")
-            if kind in (1, 2) and ctx.needs_input_grad[1]:
-                dalpha = _reduce(parts, 1, nt, 1).reshape(alpha.shape)
-        else:
-            dh = _linear_dx(dy, W)
-            if kind in (1, 2):
-                nb = lib.gecco_gauss_act_bwd_blocks(u.numel())
-                du, part = torch.empty_like(u), _new(nb, like=u)
-                _lib.check(lib.gecco_gauss_act_bwd_f32(_ptr(u), _ptr(dh), _ptr(alpha), _ptr(du), _ptr(part), u.numel(), int(kind == 1),
-                                                       _stream()), "gauss_act_bwd")
-                dalpha = _reduce(part, 1, nb, 1).reshape(alpha.shape)
-            elif kind == 3:
-                du = hip_ops.relu_bwd(h, dh)
-            else:
-                du = torch.empty_like(u)
-                _lib.check(lib.gecco_gelu_bwd_f32(_ptr(u), _ptr(dh), _ptr(du), u.numel(), _stream()), "gecco_gelu_bwd_f32")
+        du, dalpha = _act_linear_dx(dy, u, h, alpha, W, ctx.kind, ctx.needs_input_grad[1])
         dW = db = None
         if ctx.has_bias and ctx.needs_input_grad[3] and ctx.needs_input_grad[2]:
             dW, db = _linear_dw(dy, h, want_db=True)
@@ -872,9 +942,9 @@ def convnext_pyramid(ext, image: Tensor) -> list[Tensor]:
         for blk in blocks:
             dw, ln, pw1, pw2 = blk.block[0], blk.block[2], blk.block[3], blk.block[5]
             y = CnxDwLnFn.apply(x, dw.weight, dw.bias, ln.weight, ln.bias, LN_EPS)
-            u = LinearFn.apply(y.view(1, rows, Cc), pw1.weight, pw1.bias)
             ls = blk.layer_scale.reshape(-1)
-            x = ActLinearFn.apply(u, None, pw2.weight * ls[:, None], pw2.bias * ls, x.view(1, rows, Cc), 4).view(Bq, hq, wq, Cc)
+            x = LinearActLinearFn.apply(y.view(1, rows, Cc), pw1.weight, pw1.bias, None, pw2.weight * ls[:, None], pw2.bias * ls,
+                                        x.view(1, rows, Cc), 4).view(Bq, hq, wq, Cc)
         feats.append(x.permute(0, 3, 1, 2))
     return feats
 
@@ -891,19 +961,27 @@ def mlp(mod, x, residual=None, want_stats=False):
     from .models.activation import GaussianActivation
     mods = list(mod)   # Linear, act, Linear[, act, Linear ...] (models/mlp.py)
     n = len(mods)
-    x = LinearFn.apply(x, mods[0].weight, mods[0].bias, residual if n == 1 else None, want_stats and n == 1)
-    i = 1
+    def kind_of(act):
+        if isinstance(act, GaussianActivation):
+            return (1 if act.normalized else 2), act.alpha
+        if isinstance(act, torch.nn.ReLU):
+            return 3, None
+        if isinstance(act, torch.nn.Identity):
+            return 0, None
+        raise NotImplementedError(f"training on HIP: no backward for activation {type(act).__name__}")
+    k0, a0 = kind_of(mods[1]) if n >= 3 else (0, None)
+    if k0:   # Linear -> act -> Linear: one Function (the forward keeps u from the first GEMM's epilogue, the backward runs act'
+        # as the epilogue of the second linear's dX product)
+        x = LinearActLinearFn.apply(x, mods[0].weight, mods[0].bias, a0, mods[2].weight, mods[2].bias, residual if n == 3 else None,
+                                    k0, want_stats and n == 3)
+        i = 3
+    else:
+        x = LinearFn.apply(x, mods[0].weight, mods[0].bias, residual if n == 1 else None, want_stats and n == 1)
+        i = 1
     while i + 1 < n:
         act, lin = mods[i], mods[i + 1]
         last = i + 2 >= n
-        if isinstance(act, GaussianActivation):
-            kind, alpha = (1 if act.normalized else 2), act.alpha
-        elif isinstance(act, torch.nn.ReLU):
-            kind, alpha = 3, None
-        elif isinstance(act, torch.nn.Identity):
-            kind, alpha = 0, None
-        else:
-            raise NotImplementedError(f"training on HIP: no backward for activation {type(act).__name__}")
+        kind, alpha = kind_of(act)
         if kind:   # activation + the linear after it: one Function whose backward runs act' as the dX product's epilogue
             x = ActLinearFn.apply(x, alpha, lin.weight, lin.bias, residual if last else None, kind, want_stats and last)
         else:

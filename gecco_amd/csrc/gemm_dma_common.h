@@ -127,7 +127,7 @@ __device__ __forceinline__ void epilogue_t(const GemmArgs& g, const Tile& t, f32
                 f32x16 val = acc[i][2 * jh + jj];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) val[e] += bias;
-                if (has_act) {
+                if (has_act && !(ACTBWD && g.pre_out)) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) val[e] = act_apply(val[e], neg_inv_2a2, act_mode);
                 }
@@ -173,6 +173,13 @@ __device__ __forceinline__ void epilogue_t(const GemmArgs& g, const Tile& t, f32
                 const int m = mrow0 + it * 4 + lr;
                 f32x4 v4 = *reinterpret_cast<const f32x4*>(Tt + (it * 4 + lr) * D_TP + c4 * 4);
                 const bool ok = nok && m < g.rows;
+                if (ACTBWD && g.pre_out) {   // keep u = A W^T + bias, then activate the row piece
+                    if (ok) GECCO_NT_STORE(v4, reinterpret_cast<f32x4*>(g.pre_out + ((size_t)b * g.rows + m) * ldc_seg + n));
+                    if (has_act) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v4[q] = act_apply(v4[q], neg_inv_2a2, act_mode);
+                    }
+                }
                 if (Rb) v4 += rres[it];
                 else if (ACTBWD && Ub) {
 #pragma unroll

@@ -52,6 +52,9 @@ struct GemmArgs {
     const float* mul_u;
     int mul_kind;
     float* agrad;
+    // Activation FORWARD that keeps its input (training: the backward needs u): C = act(A W^T + bias) as with `act`, and
+    // pre_out (B, rows, ldc) = A W^T + bias.  Same kernel instantiation as mul_u (the training path's); not with c_img.
+    float* pre_out;
 };
 
 struct SplitJob { const float* W; float* img; int Nout, K, ldw, pad_; };   // pad_ = 1 (fp16 images): the LOW part fp16(W - fp16(W)); 2: the same as fp8 x 2^19 in 64-k blocks; 4 (bf16 images): W is (K, ldw) and the image is of W^T

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GECCO_ABI_VERSION 9
+#define GECCO_ABI_VERSION 10
 
 int gecco_abi_version(void);
 const char* gecco_build_arch(void);   /* "gfx950" */
@@ -135,6 +135,10 @@ int gecco_linear_actbwd_ok(int rows, int K, int Nout, int precision);
 size_t gecco_linear_actbwd_tiles(int B, int rows, int Nout);
 int gecco_linear_actbwd_f32(const float* A, const float* W, const float* u, const float* alpha, int kind, const float* residual,
                             float* C, float* agrad, int B, int rows, int K, int Nout, int precision, void* wsplit, void* stream);
+/* Its forward companion: C = act(A W^T + bias) AND pre_out = A W^T + bias (the u the backward needs) from one epilogue — the
+ * training forward of Linear -> act without a separate activation pass.  act 1 / 2 / 3 / 4 as above; W == NULL: image ready. */
+int gecco_linear_act_keep_f32(const float* A, const float* W, const float* bias, const float* alpha, int act, float* pre_out,
+                              float* C, int B, int rows, int K, int Nout, int precision, void* wsplit, void* stream);
 
 /* GroupNorm partial statistics of x (B, rows, C): stats (B, T, 2, C), T = gecco_stats_row_tiles(rows). */
 int gecco_col_stats_f32(const float* x, float* stats, int B, int rows, int C, void* stream);

@@ -537,3 +537,55 @@ def test_activation_backward_as_gemm_epilogue(kind, precision, monkeypatch):
                 _close(daf.reshape(()), da0.cpu().reshape(()), 10 * tol)
     finally:
         hip_ops.set_default_precision(prev)
+
+
+@pytest.mark.parametrize("kind", [1, 3, 4])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_mlp_as_one_function(kind, precision, monkeypatch):
+    """LinearActLinearFn: Linear -> act -> Linear (+ residual) with the pre-activation kept by the first GEMM's epilogue
+    (gecco_linear_act_keep_f32) and act' as the epilogue of the second linear's dX product — against the same Function with
+    both epilogue forms switched off (separate activation kernels) and against torch autograd in fp64."""
+    from gecco_amd import autograd as ag
+    from gecco_amd import hip_ops
+    rs = np.random.RandomState(100 * kind + len(precision))
+    prev = hip_ops.default_precision()
+    hip_ops.set_default_precision(precision)
+    try:
+        for (B, R, C0, Wd) in ((2, 256, 128, 256), (1, 200, 96, 384)):
+            x = _t(rs.randn(B, R, C0))
+            W0, b0 = _t(rs.randn(Wd, C0) / np.sqrt(C0)), _t(rs.randn(Wd) * 0.1)
+            W2, b2 = _t(rs.randn(C0, Wd) / np.sqrt(Wd)), _t(rs.randn(C0) * 0.1)
+            res, dy = _t(rs.randn(B, R, C0)), _t(rs.randn(B, R, C0))
+            alpha = torch.tensor(0.9)
+
+            def act64(v, a):
+                if kind == 1:
+                    return (torch.exp(-v ** 2 / (2 * a ** 2)) - 0.7) / 0.28
+                return torch.relu(v) if kind == 3 else torch.nn.functional.gelu(v)
+            leaves = [t.double().requires_grad_(True) for t in (x, W0, b0, alpha, W2, b2, res)]
+            x6, W06, b06, a6, W26, b26, r6 = leaves
+            (((act64(x6 @ W06.t() + b06, a6) @ W26.t() + b26 + r6) * dy.double()).sum()).backward()
+
+            def run(fused):
+                monkeypatch.setenv("GECCO_TRAIN_ACTBWD", "1" if fused else "0")
+                monkeypatch.setenv("GECCO_TRAIN_ACTKEEP", "1" if fused else "0")
+                ls = [_leaf(t, "cuda") for t in (x, W0, b0, alpha, W2, b2, res)]
+                y = ag.LinearActLinearFn.apply(ls[0], ls[1], ls[2], ls[3] if kind < 3 else None, ls[4], ls[5], ls[6], kind)
+                y.backward(dy.cuda())
+                return y.detach(), [t.grad for t in ls]
+            yf, gf = run(True)
+            y0, g0 = run(False)
+            tol = 3e-5 if precision == "fp32" else 4e-4
+            _close(yf, y0.cpu(), 1e-6)
+            for i, (a, b, r) in enumerate(zip(gf, g0, leaves)):
+                if i == 3 and kind >= 3:
+                    assert a is None
+                    continue
+                if kind == 3:   # ReLU' flips where |u| is below the arithmetic's rounding: judge the rel-L2 error, not the max
+                    e = cpu_ref.rel_err(a.reshape(r.shape).cpu(), r.grad.float())
+                    assert e[1] < 2e-2, e
+                else:
+                    _close(a.reshape(r.shape), r.grad.float(), tol * (10 if i == 3 else 1))
+                _close(a, b.cpu(), tol * (10 if i == 3 else 1))   # the two HIP forms see the same u
+    finally:
+        hip_ops.set_default_precision(prev)

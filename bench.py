@@ -739,9 +739,14 @@ def main():
             per["round_ms"] = round(round_ms, 4)
             mtf = per[mk]["tflops"]
             mb = [by for name, fl, by, fn in rsites if name == mk][0]
-            traffic = json.load(open(tj)).get("mixed", {}).get("bytes_per_launch") if os.path.exists(tj) else None
+            tjd = json.load(open(tj)).get("mixed", {}) if os.path.exists(tj) else {}
+            traffic = tjd.get("bytes_per_launch")
             rec["roofline"] = {"bound": "mfma", "achieved": mtf, "peak": PEAK_BF16_MFMA_TFLOPS / 3, "unit": "TFLOP/s",
                                "frac": 3 * mtf / PEAK_BF16_MFMA_TFLOPS, "traffic": traffic,
+                               # cycle-based view of the same kernel (committed PMC constant, not measured in this run): the share
+                               # of SIMD cycles the matrix pipe is busy — above `frac`, which prices wall time against the
+                               # 2.4 GHz peak: the chip clocks down under sustained MFMA load
+                               "mfma_busy_pmc": tjd.get("mfma_busy"),
                                "kernel": "gemm_dma_kernel<3,true,true,128> = mlp.0 (LDS-DMA ring, AdaGN prologue on the A fragment, "
                                          "3 x v_mfma_f32_32x32x16_bf16 per product, GaussianActivation epilogue); achieved = 2MNK / "
                                          "its duration inside hipGraph replays of the round out_proj -> mlp.0 -> mlp.2 on shared "

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GECCO_HIP_LIB") or os.path.join(_HERE, "libgecco_hip.so")   # override: A/B builds only
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 c_f = C.c_void_p  # device pointers travel as void*
 
@@ -91,12 +91,14 @@ SIGNATURES = {
     "gecco_linear_actbwd_tiles": (sz, [i, i, i]),
     "gecco_linear_actbwd_f32": (i, [vp, vp, vp, vp, i, vp, vp, vp, i, i, i, i, i, vp, vp]),
     "gecco_linear_act_keep_f32": (i, [vp, vp, vp, vp, i, vp, vp, i, i, i, i, i, vp, vp]),
+    "gecco_linear_act_keep_pro_f32": (i, [vp, vp, vp, vp, vp, vp, i, vp, vp, i, i, i, i, i, vp, vp]),
     "gecco_linear_f16io": (i, [vp] * 7 + [i, i, i, i, i, i, i, vp, vp]),
     "gecco_linear_pair_f16io": (i, [vp, vp, vp, i, vp, vp, vp, i, vp, i, i, i, vp, vp]),
     "gecco_mlp_fused_f16": (i, [vp, vp, vp, vp, vp, vp, vp, vp, i, vp, i, i, i, i, vp, vp]),
     "gecco_unpool_outproj_f16": (i, [vp, vp, vp, vp, vp, vp, i, i, i, i, vp, vp]),
     "gecco_gemm_tn_x3_f32": (i, [vp, vp, vp, i, i, i, i, i, vp]),
     "gecco_gemm_tn_x3_bias_f32": (i, [vp, vp, vp, vp, i, i, i, i, i, vp]),
+    "gecco_gemm_tn_x3_pro_f32": (i, [vp, vp, vp, vp, vp, vp, i, i, i, i, i, vp]),
     "gecco_set_option": (i, [C.c_char_p, i]),
     "gecco_linear_astat_f16": (i, [vp, vp, vp, vp, vp, i, vp, vp, vp, i, vp, vp, i, i, i, i, i, vp, vp]),
     "gecco_affine_cast_f16": (i, [vp, vp, vp, vp, i, i, i, vp]),

@@ -164,12 +164,27 @@ def _linear_dx(dy: Tensor, W: Tensor, residual: Tensor | None = None) -> Tensor:
     return dx if residual is None else dx + residual
 
 
-def _linear_dw(dy: Tensor, x: Tensor, want_db: bool = False):
+def _linear_dw(dy: Tensor, x: Tensor, want_db: bool = False, pro=None):
     """dW = dy^T x: both operands read k-major (contraction over their rows); partials summed in a fixed order.
     want_db: also the bias gradient db = column sums of dy -> (dW, db); the split-bf16 kernel forms it from the dy tiles
-    it stages anyway."""
+    it stages anyway.  pro = (a, o): the linear's input was AdaGN(x) = a x + o (per sample and column) — the split-bf16 kernel
+    applies it while it stages x; elsewhere the normalised tensor is formed first."""
     B, R, K = x.shape
     Nout = dy.shape[2]
+    tn_ok = _train_precision() == "bf16x3" and R % 32 == 0 and Nout % 4 == 0 and K % 4 == 0
+    if pro is not None and not tn_ok:
+        x, pro = hip_ops.affine_apply(x, pro[0], pro[1]), None
+    if pro is not None:
+        tiles = -(-Nout // 128) * -(-K // 128)
+        G = min(B, max(1, -(-_DW_BLOCKS // tiles)))
+        group = -(-B // G)
+        G = -(-B // group)
+        parts = _new(G, Nout, K, like=x)
+        cparts = _new(G, Nout, like=x) if want_db else None
+        _lib.check(_lib.load().gecco_gemm_tn_x3_pro_f32(_ptr(dy), _ptr(x), _ptr(pro[0]), _ptr(pro[1]), _ptr(parts), _ptr(cparts), B, R,
+                                                        Nout, K, group, _stream()), "gecco_gemm_tn_x3_pro_f32")
+        dW = _reduce(parts, Nout * K, G, Nout * K).reshape(Nout, K)
+        return (dW, _reduce(cparts, Nout, G, Nout)) if want_db else dW
     if B == 1 and R >= 4096:
         # one long row block (the conditioner's texel matrix): cut it into groups for the per-group partials below — enough of
         # them that groups x output tiles fill the chip (a 96 x 384 gradient has three tiles)
@@ -291,14 +306,9 @@ class AdaGNFn(torch.autograd.Function):
         stats: the partial sums {sum x, sum x^2} per (sample, row tile, channel) when the producer of x already formed them
         (LinearFn(..., want_stats=True)); otherwise one pass over x here."""
         x = _f(x)
-        lib = _lib.load()
         ctx.set_materialize_grads(False)
         ctx.passthrough = passthrough
-        B, R, Cc = x.shape
-        stats = hip_ops.col_stats(x) if stats is None else stats
-        params = None if sw is None else (sw, sb, bw, bb)
-        t2 = None if t is None else _f(t.reshape(B, -1).float())
-        a, o = hip_ops.adagn_coeffs(stats, R, t2, params, G, eps)
+        a, o, stats, t2 = _adagn_coeffs(x, t, sw, sb, bw, bb, G, eps, stats)
         ctx.save_for_backward(x, stats, t2, sw, sb)
         ctx.G, ctx.eps, ctx.affine = G, eps, sw is not None
         y = hip_ops.affine_apply(x, a, o)
@@ -311,30 +321,142 @@ class AdaGNFn(torch.autograd.Function):
         none = (None,) * 9
         if dy is None:   # only the skip connection carried a gradient
             return (dskip, *none)
-        dy = _f(dy)
-        lib = _lib.load()
-        B, R, Cc = x.shape
-        # {sum dy, sum dy x} partials in col_dot_stats' own row tiling (the forward statistics may come from a GEMM epilogue
-        # with another one)
-        gst = _new(B, lib.gecco_stats_row_tiles(R), 2, Cc, like=x)
-        _lib.check(lib.gecco_col_dot_stats_f32(_ptr(dy), _ptr(x), _ptr(gst), B, R, Cc, _stream()), "col_dot_stats")
-        cA, cB, cC, ds, dz = (_new(B, Cc, like=x) for _ in range(5))
-        p = _lib.GeccoAdaGN(_ptr(sw), _ptr(sb), None, None) if ctx.affine else None
-        ctxd = 0 if t2 is None else t2.shape[1]
-        _lib.check(lib.gecco_adagn_bwd_coeffs_f32(_ptr(stats), stats.shape[1], _ptr(gst), gst.shape[1], R, _ptr(t2), ctxd,
-                                                  C.byref(p) if p is not None else None, _ptr(cA), _ptr(cB), _ptr(cC),
-                                                  _ptr(ds), _ptr(dz), B, Cc, ctx.G, ctx.eps, _stream()), "adagn_bwd_coeffs")
-        dx = torch.empty_like(x)
-        _lib.check(lib.gecco_affine2_apply_add_f32(_ptr(dy), _ptr(x), _ptr(cA), _ptr(cB), _ptr(cC),
-                                                   None if dskip is None else _ptr(_f(dskip)), _ptr(dx), B, R, Cc, _stream()),
-                   "affine2_apply_add")
+        dx, dsw, dsb, dbw, dbb = _adagn_backward(x, stats, t2, sw, sb, _f(dy), dskip, ctx.G, ctx.eps, ctx.affine)
         if not ctx.affine:
             return (dx, *none)
-        dsw, dbw = _new(Cc, ctxd, like=x), _new(Cc, ctxd, like=x)
-        dsb, dbb = _new(Cc, like=x), _new(Cc, like=x)
-        _lib.check(lib.gecco_adagn_param_grads_f32(_ptr(ds), _ptr(dz), _ptr(t2), B, Cc, ctxd, _ptr(dsw), _ptr(dsb),
-                                                   _ptr(dbw), _ptr(dbb), _stream()), "adagn_param_grads")
         return dx, None, dsw, dsb, dbw, dbb, None, None, None, None
+
+
+def _adagn_backward(x, stats, t2, sw, sb, dy, dskip, G, eps, affine):
+    """Backward of y = scale(t) GroupNorm(x) + bias(t) given dy (and the gradient `dskip` that reached x through a skip
+    connection, added in the same pass): dx and the gradients of the scale / bias linears."""
+    lib = _lib.load()
+    B, R, Cc = x.shape
+    # {sum dy, sum dy x} partials in col_dot_stats' own row tiling (the forward statistics may come from a GEMM epilogue
+    # with another one)
+    gst = _new(B, lib.gecco_stats_row_tiles(R), 2, Cc, like=x)
+    _lib.check(lib.gecco_col_dot_stats_f32(_ptr(dy), _ptr(x), _ptr(gst), B, R, Cc, _stream()), "col_dot_stats")
+    cA, cB, cC, ds, dz = (_new(B, Cc, like=x) for _ in range(5))
+    p = _lib.GeccoAdaGN(_ptr(sw), _ptr(sb), None, None) if affine else None
+    ctxd = 0 if t2 is None else t2.shape[1]
+    _lib.check(lib.gecco_adagn_bwd_coeffs_f32(_ptr(stats), stats.shape[1], _ptr(gst), gst.shape[1], R, _ptr(t2), ctxd,
+                                              C.byref(p) if p is not None else None, _ptr(cA), _ptr(cB), _ptr(cC),
+                                              _ptr(ds), _ptr(dz), B, Cc, G, eps, _stream()), "adagn_bwd_coeffs")
+    dx = torch.empty_like(x)
+    _lib.check(lib.gecco_affine2_apply_add_f32(_ptr(dy), _ptr(x), _ptr(cA), _ptr(cB), _ptr(cC),
+                                               None if dskip is None else _ptr(_f(dskip)), _ptr(dx), B, R, Cc, _stream()),
+               "affine2_apply_add")
+    if not affine:
+        return dx, None, None, None, None
+    dsw, dbw = _new(Cc, ctxd, like=x), _new(Cc, ctxd, like=x)
+    dsb, dbb = _new(Cc, like=x), _new(Cc, like=x)
+    _lib.check(lib.gecco_adagn_param_grads_f32(_ptr(ds), _ptr(dz), _ptr(t2), B, Cc, ctxd, _ptr(dsw), _ptr(dsb),
+                                               _ptr(dbw), _ptr(dbb), _stream()), "adagn_param_grads")
+    return dx, dsw, dsb, dbw, dbb
+
+
+def _adagn_coeffs(x, t, sw, sb, bw, bb, G, eps, stats):
+    """(a, o, stats, t2) with AdaGN(x) = a x + o: the forward half every AdaGN Function shares."""
+    B, R, _ = x.shape
+    stats = hip_ops.col_stats(x) if stats is None else stats
+    params = None if sw is None else (sw, sb, bw, bb)
+    t2 = None if t is None else _f(t.reshape(B, -1).float())
+    a, o = hip_ops.adagn_coeffs(stats, R, t2, params, G, eps)
+    return a, o, stats, t2
+
+
+def _pro_ok(R: int, K: int, Nout: int) -> bool:
+    """The AdaGN-as-prologue Functions: split-bf16 training precision, shapes the LDS-DMA kernels take with a prologue."""
+    return (os.environ.get("GECCO_TRAIN_ADAGNPRO", "1") != "0" and _train_precision() == "bf16x3" and K <= 1024 and R % 32 == 0
+            and bool(_lib.load().gecco_linear_image_ok(R, K, Nout, 1)))
+
+
+class AdaGNPairFn(torch.autograd.Function):
+    """(KV, q, x) = (AdaGN(x) Wkv^T, AdaGN(x) Wq^T + bq, x): broadcast_norm and the two projections of its output
+    (models/set_transformer.py:161-162 -> :49, :112) as ONE Function.  AdaGN(x) is never materialised: the pair GEMM applies
+    a x + o on its A fragments (as the inference path does), the weight-gradient kernel applies it while staging x
+    (`gecco_gemm_tn_x3_pro_f32`), and the backward continues into the AdaGN backward with the two dX products' sum.  The third
+    output hands x to the skip connection; the gradient returning through it is added inside the AdaGN backward kernel."""
+
+    @staticmethod
+    def forward(ctx, x, t, sw, sb, bw, bb, G, eps, stats, W1, W2, b2):
+        x = _f(x)
+        ctx.set_materialize_grads(False)
+        a, o, stats, t2 = _adagn_coeffs(x, t, sw, sb, bw, bb, G, eps, stats)
+        img = WEIGHT_IMAGES.lookup("pair", W1, W2)
+        if img is not None:
+            KV, q = hip_ops.linear_pair(x, W1, None, W2, b2, pro=(a, o), precision="bf16x3", w_image=img)
+        else:
+            KV, q = hip_ops.linear_pair(x, W1, None, _f(W2), b2, pro=(a, o), precision="bf16x3")
+        ctx.save_for_backward(x, stats, t2, sw, sb, a, o, W1, W2)
+        ctx.G, ctx.eps, ctx.has_b2 = G, eps, b2 is not None
+        return KV, q, x
+
+    @staticmethod
+    def backward(ctx, dKV, dq, dskip):
+        _no_input_grad(ctx, 1, "the noise-level embedding t")
+        x, stats, t2, sw, sb, a, o, W1, W2 = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        B, R, Cc = x.shape
+        dKV = _f(dKV) if dKV is not None else x.new_zeros(B, R, W1.shape[0])
+        dq = _f(dq) if dq is not None else x.new_zeros(B, R, W2.shape[0])
+        dY = _linear_dx(dq, W2, residual=_linear_dx(dKV, W1))
+        dW1 = _linear_dw(dKV, x, pro=(a, o)) if need[9] else None
+        dW2 = db2 = None
+        if need[10] and ctx.has_b2 and need[11]:
+            dW2, db2 = _linear_dw(dq, x, want_db=True, pro=(a, o))
+        elif need[10]:
+            dW2 = _linear_dw(dq, x, pro=(a, o))
+        elif ctx.has_b2 and need[11]:
+            db2 = _linear_db(dq)
+        dx, dsw, dsb, dbw, dbb = _adagn_backward(x, stats, t2, sw, sb, dY, dskip, ctx.G, ctx.eps, True)
+        return dx, None, dsw, dsb, dbw, dbb, None, None, None, dW1, dW2, db2
+
+
+class AdaGNMlpFn(torch.autograd.Function):
+    """x + MLP(AdaGN(x)) (models/set_transformer.py:165-166: mlp_norm, Linear -> act -> Linear, the skip) as ONE Function:
+    AdaGN as the prologue of the first GEMM (whose epilogue keeps the pre-activation), the skip as the epilogue of the
+    second (which with want_stats also leaves the next norm's partial sums); backward: act' as the epilogue of the second
+    linear's dX product, the first linear's weight gradient from x through the prologue, then the AdaGN backward with the
+    skip's gradient added in its kernel."""
+
+    @staticmethod
+    def forward(ctx, x, t, sw, sb, bw, bb, G, eps, stats, W0, b0, alpha, W2, b2, kind, want_stats):
+        x = _f(x)
+        lib = _lib.load()
+        B, R, K0 = x.shape
+        N0 = W0.shape[0]
+        a, o, stats, t2 = _adagn_coeffs(x, t, sw, sb, bw, bb, G, eps, stats)
+        u, h = _new(B, R, N0, like=x), _new(B, R, N0, like=x)
+        img = WEIGHT_IMAGES.lookup("n", W0)
+        Wp, ws = (None, img) if img is not None else (_f(W0), hip_ops._ws((N0 + 127) // 128 * 128 * K0 * 4, x.device))
+        _lib.check(lib.gecco_linear_act_keep_pro_f32(_ptr(x), _ptr(Wp), _ptr(b0), _ptr(a), _ptr(o), _ptr(alpha) if kind in (1, 2) else None,
+                                                     kind, _ptr(u), _ptr(h), B, R, K0, N0, 1, C.c_void_p(ws.data_ptr()), _stream()),
+                   "gecco_linear_act_keep_pro_f32")
+        ctx.save_for_backward(x, stats, t2, sw, sb, a, o, u, h, alpha if alpha is not None else x.new_empty(0), W0, W2)
+        ctx.G, ctx.eps, ctx.kind, ctx.bias = G, eps, kind, (b0 is not None, b2 is not None)
+        out = _linear_fwd(h, W2, b2, x, want_stats)
+        if want_stats:
+            ctx.mark_non_differentiable(out[1])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout, _dstats=None):
+        _no_input_grad(ctx, 1, "the noise-level embedding t")
+        x, stats, t2, sw, sb, a, o, u, h, alpha, W0, W2 = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        dout = _f(dout)
+        du, dalpha = _act_linear_dx(dout, u, h, alpha, W2, ctx.kind, need[11])
+
+        def wgrads(g, act_in, has_b, iw, ib, pro=None):
+            if has_b and need[ib] and need[iw]:
+                return _linear_dw(g, act_in, want_db=True, pro=pro)
+            return (_linear_dw(g, act_in, pro=pro) if need[iw] else None), (_linear_db(g) if has_b and need[ib] else None)
+        dW2, db2 = wgrads(dout, h, ctx.bias[1], 12, 13)
+        dW0, db0 = wgrads(du, x, ctx.bias[0], 9, 10, pro=(a, o))
+        dY = _linear_dx(du, W0)
+        dx, dsw, dsb, dbw, dbb = _adagn_backward(x, stats, t2, sw, sb, dY, dout, ctx.G, ctx.eps, True)
+        return dx, None, dsw, dsb, dbw, dbb, None, None, None, dW0, db0, dalpha, dW2, db2, None, None
 
 
 # ------------------------------------------------------------------------------------------- activation
@@ -994,13 +1116,22 @@ def broadcasting_layer(layer, x, t, h=None, stats=None, want_stats=False):
     """BroadcastingLayer.forward with autograd (reference models/set_transformer.py:155-168, 92-117, 47-65).
     stats / want_stats: the GroupNorm partial sums of x handed from layer to layer (formed by the GEMM that wrote x);
     with want_stats the return value is (x, h, stats of x)."""
+    from .models.activation import GaussianActivation
     bc = layer.broadcast
     H = bc.pool.num_heads
     Cc = x.shape[-1]
-    y, x = adagn(layer.broadcast_norm, x, t, passthrough=True, stats=stats)
+    R = x.shape[1]
     W, b = bc.unpool.in_proj_weight, bc.unpool.in_proj_bias
+    n1 = layer.broadcast_norm
+    fused_pair = h is None and _pro_ok(R, Cc, 3 * Cc) and Cc % 128 == 0
+    if fused_pair:   # broadcast_norm as the prologue of kv_proj | q_proj: AdaGN(x) is never written
+        KV, q, x = AdaGNPairFn.apply(x, t, n1.scale.weight, n1.scale.bias, n1.bias.weight, n1.bias.bias, n1.gn.num_groups, n1.gn.eps,
+                                     stats, bc.pool.kv_proj.weight, W[:Cc], b[:Cc])
+    else:
+        y, x = adagn(n1, x, t, passthrough=True, stats=stats)
     if h is None:
-        KV, q = LinearPairFn.apply(y, bc.pool.kv_proj.weight, None, W[:Cc], b[:Cc])
+        if not fused_pair:
+            KV, q = LinearPairFn.apply(y, bc.pool.kv_proj.weight, None, W[:Cc], b[:Cc])
         merged = PoolAttnFn.apply(KV, bc.pool.inducers, H)
         h = LinearFn.apply(merged, bc.pool.out_proj.weight, None)
         h = adagn(bc.norm_1, h, t)
@@ -1011,7 +1142,15 @@ def broadcasting_layer(layer, x, t, h=None, stats=None, want_stats=False):
     kvh = LinearFn.apply(h, W[Cc:], b[Cc:])
     attn = UnpoolAttnFn.apply(q, kvh, H)
     x, st = LinearFn.apply(attn, bc.unpool.out_proj.weight, bc.unpool.out_proj.bias, x, True)   # x + out_proj(attn)
-    y, x = adagn(layer.mlp_norm, x, t, passthrough=True, stats=st)
+    n2, mods = layer.mlp_norm, list(layer.mlp)
+    if len(mods) == 3 and isinstance(mods[1], (GaussianActivation, torch.nn.ReLU)) and _pro_ok(R, Cc, mods[0].weight.shape[0]):
+        # x + mlp(mlp_norm(x)) as one Function: the norm is the first GEMM's prologue, the skip the second's epilogue
+        act = mods[1]
+        kind, alpha = ((1 if act.normalized else 2), act.alpha) if isinstance(act, GaussianActivation) else (3, None)
+        out = AdaGNMlpFn.apply(x, t, n2.scale.weight, n2.scale.bias, n2.bias.weight, n2.bias.bias, n2.gn.num_groups, n2.gn.eps, st,
+                               mods[0].weight, mods[0].bias, alpha, mods[2].weight, mods[2].bias, kind, want_stats)
+        return (out[0], h, out[1]) if want_stats else (out, h)
+    y, x = adagn(n2, x, t, passthrough=True, stats=st)
     if want_stats:
         x, st = mlp(layer.mlp, y, residual=x, want_stats=True)                            # x + mlp(mlp_norm(x))
         return x, h, st

@@ -635,13 +635,21 @@ int gecco_linear_actbwd_f32(const float* A, const float* W, const float* u, cons
 
 int gecco_linear_act_keep_f32(const float* A, const float* W, const float* bias, const float* alpha, int act, float* pre_out,
                               float* C, int B, int rows, int K, int Nout, int precision, void* wsplit, void* stream) {
+    return gecco_linear_act_keep_pro_f32(A, W, bias, nullptr, nullptr, alpha, act, pre_out, C, B, rows, K, Nout, precision, wsplit, stream);
+}
+
+int gecco_linear_act_keep_pro_f32(const float* A, const float* W, const float* bias, const float* pro_a, const float* pro_o,
+                                  const float* alpha, int act, float* pre_out, float* C, int B, int rows, int K, int Nout,
+                                  int precision, void* wsplit, void* stream) {
     if (!A || !pre_out || !C) return fail(-1, "linear_act_keep: null argument");
+    if ((pro_a == nullptr) != (pro_o == nullptr)) return fail(-1, "linear_act_keep: pro_a / pro_o must both be set");
+    if (pro_a && K > 1024) return fail(-2, "linear_act_keep: the AdaGN prologue needs K <= 1024");
     if (act < 1 || act > 4) return fail(-2, "linear_act_keep: act must be 1 / 2 (GaussianActivation), 3 (ReLU) or 4 (GELU)");
     if ((act == 1 || act == 2) && !alpha) return fail(-1, "linear_act_keep: GaussianActivation needs alpha");
     if (!gecco_linear_actbwd_ok(rows, K, Nout, precision)) return fail(-2, "linear_act_keep: shape / precision outside the LDS-DMA kernels' reach");
     if (precision == 1 && !wsplit) return fail(-1, "linear_act_keep: precision 1 needs wsplit");
     if (!W && precision != 1) return fail(-2, "linear_act_keep: W == NULL (image ready) needs precision 1");
-    TRY(linear(A, W, bias, nullptr, nullptr, alpha, nullptr, C, nullptr, B, rows, K, Nout, act, (hipStream_t)stream, precision,
+    TRY(linear(A, W, bias, pro_a, pro_o, alpha, nullptr, C, nullptr, B, rows, K, Nout, act, (hipStream_t)stream, precision,
                W ? static_cast<float*>(wsplit) : nullptr, W ? nullptr : static_cast<const float*>(wsplit), 0, 0, 0, 0, nullptr, 0,
                nullptr, pre_out), "linear_act_keep");
     return 0;
@@ -745,8 +753,15 @@ int gecco_gemm_tn_x3_f32(const float* A, const float* Bm, float* parts, int Z, i
 
 int gecco_gemm_tn_x3_bias_f32(const float* A, const float* Bm, float* parts, float* colsum_parts, int Z, int R, int N, int K,
                               int group, void* stream) {
+    return gecco_gemm_tn_x3_pro_f32(A, Bm, nullptr, nullptr, parts, colsum_parts, Z, R, N, K, group, stream);
+}
+
+int gecco_gemm_tn_x3_pro_f32(const float* A, const float* Bm, const float* pro_a, const float* pro_o, float* parts,
+                             float* colsum_parts, int Z, int R, int N, int K, int group, void* stream) {
     if (!A || !Bm || !parts) return fail(-1, "gemm_tn_x3: null argument");
+    if ((pro_a == nullptr) != (pro_o == nullptr)) return fail(-1, "gemm_tn_x3: pro_a / pro_o must both be set");
     TnArgs g{};
+    g.pro_a = pro_a; g.pro_o = pro_o;
     g.A = A; g.Bm = Bm; g.C = parts; g.Z = Z; g.R = R; g.N = N; g.K = K; g.lda = N; g.ldb = K;
     g.sA = (size_t)R * N; g.sB = (size_t)R * K; g.group = group; g.colsum = colsum_parts;
     if (!gemm_tn_x3_supported(g)) return fail(-2, "gemm_tn_x3: needs R %% 32 == 0, N %% 4 == 0, K %% 4 == 0, group > 0");

@@ -383,15 +383,18 @@ int dma_launch_t(const GemmArgs& g, hipStream_t st) {
         attr = lds;
     }
     const dim3 grid(g.B * tilesM * tilesN);
-    if (g.mul_u || g.pre_out) {   // the training path's epilogue forms: their own kernel instantiation
-        if (g.pro_a || (g.pre_out && g.c_img)) return -9;
+    if (g.mul_u || g.pre_out) {   // the training path's epilogue forms: their own kernel instantiations
+        if ((g.mul_u && g.pro_a) || (g.pre_out && g.c_img)) return -9;
         static size_t attr2 = 0;
         if (lds > attr2) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma_kernel<DNS, false, X3, BM, false, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma_kernel<DNS, true, X3, BM, false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr2 = lds;
         }
-        hipLaunchKernelGGL((gemm_dma_kernel<DNS, false, X3, BM, false, true>), grid, dim3(DNT), lds, st, g);
+        if (g.pro_a) hipLaunchKernelGGL((gemm_dma_kernel<DNS, true, X3, BM, false, true>), grid, dim3(DNT), lds, st, g);
+        else hipLaunchKernelGGL((gemm_dma_kernel<DNS, false, X3, BM, false, true>), grid, dim3(DNT), lds, st, g);
     } else if (g.pro_a) hipLaunchKernelGGL((gemm_dma_kernel<DNS, true, X3, BM>), grid, dim3(DNT), lds, st, g);
     else hipLaunchKernelGGL((gemm_dma_kernel<DNS, false, X3, BM>), grid, dim3(DNT), lds, st, g);
     return (int)hipGetLastError();

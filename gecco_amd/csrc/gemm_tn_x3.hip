@@ -49,6 +49,9 @@ __device__ __forceinline__ int tn_off(int row, int col) {
 
 constexpr int TN_PLANE = 32 * 128;   // u16 per plane
 
+// PRO: the AdaGN apply on the B operand (TnArgs::pro_a) — its own instantiation, so the plain weight gradients run the code
+// they ran before it existed
+template <bool PRO>
 __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(TnArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     u16* lds = reinterpret_cast<u16*>(smem);   // [2 stages][A hi | A lo | B hi | B lo]
@@ -70,8 +73,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(TnArgs g) {
 
     // global tile loads: thread -> 4 x (row, 4 columns) of each operand
     f32x4 ra[4], rb[4];
+    f32x4 pa4 = {1.f, 1.f, 1.f, 1.f}, po4 = {0.f, 0.f, 0.f, 0.f};   // AdaGN coefficients of the thread's four X columns, sample zc
+    int zc = -1;
     auto load = [&](int s) {
         const int z = z0 + s / msteps, m0 = (s % msteps) * 32;
+        if (PRO && z != zc && bok) {
+            pa4 = *reinterpret_cast<const f32x4*>(g.pro_a + (size_t)z * g.K + k0 + (tid & 31) * 4);
+            po4 = *reinterpret_cast<const f32x4*>(g.pro_o + (size_t)z * g.K + k0 + (tid & 31) * 4);
+        }
+        zc = z;
         const float* Ab = g.A + (size_t)z * g.sA + (size_t)m0 * g.lda + n0;
         const float* Bb = g.Bm + (size_t)z * g.sB + (size_t)m0 * g.ldb + k0;
 #pragma unroll
@@ -94,7 +104,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(TnArgs g) {
             tn_split4(ra[i], hi, lo);
             *reinterpret_cast<u32x2*>(st + o) = hi;
             *reinterpret_cast<u32x2*>(st + TN_PLANE + o) = lo;
-            tn_split4(rb[i], hi, lo);
+            // the AdaGN apply, if any, here — where the loaded values are consumed a step after their loads were issued (applied
+            // at the load it would make every step wait for its own global loads)
+            tn_split4(PRO ? (bok ? rb[i] * pa4 + po4 : rb[i]) : rb[i], hi, lo);
             *reinterpret_cast<u32x2*>(st + 2 * TN_PLANE + o) = hi;
             *reinterpret_cast<u32x2*>(st + 3 * TN_PLANE + o) = lo;
         }
@@ -180,7 +192,9 @@ int gemm_tn_x3_launch(const TnArgs& g, hipStream_t st) {
     const size_t lds = (size_t)2 * 4 * TN_PLANE * 2;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
         attr = true;
     }
@@ -191,6 +205,8 @@ int gemm_tn_x3_launch(const TnArgs& g, hipStream_t st) {
     }
     TnArgs ga = g;
     ga.xcd = xcd;
-    hipLaunchKernelGGL(gemm_tn_x3_kernel, dim3(((g.N + 127) / 128) * ((g.K + 127) / 128), G), dim3(256), lds, st, ga);
+    const dim3 grid(((g.N + 127) / 128) * ((g.K + 127) / 128), G);
+    if (g.pro_a) hipLaunchKernelGGL(gemm_tn_x3_kernel<true>, grid, dim3(256), lds, st, ga);
+    else hipLaunchKernelGGL(gemm_tn_x3_kernel<false>, grid, dim3(256), lds, st, ga);
     return (int)hipGetLastError();
 }

@@ -134,6 +134,10 @@ struct TnArgs {
     int group;
     float* colsum;     // optional (ceil(Z / group), N): column sums of A per group (the bias gradient), or null
     int xcd;           // set by the launcher: XCD-aware block -> (tile, group) mapping
+    // optional AdaGN apply on the B operand: B'[z, m, k] = B[z, m, k] * pro_a[z, k] + pro_o[z, k] (the weight gradient of a linear
+    // whose input was AdaGN(x), from x itself: the normalised tensor is never materialised)
+    const float* pro_a;
+    const float* pro_o;
 };
 // gemm_x3_areg.hip: split-bf16 GEMM whose A operand is a tiled split image loaded global -> registers (GemmArgs::a_img)
 bool gemm_x3_areg_supported(const GemmArgs& g);

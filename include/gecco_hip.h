@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GECCO_ABI_VERSION 10
+#define GECCO_ABI_VERSION 11
 
 int gecco_abi_version(void);
 const char* gecco_build_arch(void);   /* "gfx950" */
@@ -139,6 +139,10 @@ int gecco_linear_actbwd_f32(const float* A, const float* W, const float* u, cons
  * training forward of Linear -> act without a separate activation pass.  act 1 / 2 / 3 / 4 as above; W == NULL: image ready. */
 int gecco_linear_act_keep_f32(const float* A, const float* W, const float* bias, const float* alpha, int act, float* pre_out,
                               float* C, int B, int rows, int K, int Nout, int precision, void* wsplit, void* stream);
+/* the same with the AdaGN apply as the prologue of the product: A' = A * pro_a[b, k] + pro_o[b, k] (K <= 1024) */
+int gecco_linear_act_keep_pro_f32(const float* A, const float* W, const float* bias, const float* pro_a, const float* pro_o,
+                                  const float* alpha, int act, float* pre_out, float* C, int B, int rows, int K, int Nout,
+                                  int precision, void* wsplit, void* stream);
 
 /* GroupNorm partial statistics of x (B, rows, C): stats (B, T, 2, C), T = gecco_stats_row_tiles(rows). */
 int gecco_col_stats_f32(const float* x, float* stats, int B, int rows, int C, void* stream);
@@ -414,6 +418,10 @@ int gecco_gemm_tn_x3_f32(const float* A, const float* Bm, float* parts, int Z, i
  * db = sum_rows dY comes out of the pass that reads dY for dW (colsum_parts may be NULL) */
 int gecco_gemm_tn_x3_bias_f32(const float* A, const float* Bm, float* parts, float* colsum_parts, int Z, int R, int N, int K,
                               int group, void* stream);
+/* the same with B read through an AdaGN apply, B'[z, m, k] = B[z, m, k] * pro_a[z, k] + pro_o[z, k] (pro_a / pro_o (Z, K) or
+ * both NULL): the weight gradient of a linear whose input was AdaGN(x), formed from x — AdaGN(x) is never materialised */
+int gecco_gemm_tn_x3_pro_f32(const float* A, const float* Bm, const float* pro_a, const float* pro_o, float* parts,
+                             float* colsum_parts, int Z, int R, int N, int K, int group, void* stream);
 int gecco_reduce_batch_f32(const float* parts, float* out, size_t n, int Z, size_t stride, int accumulate, void* stream);
 
 /* Row softmax of the materialised attention scores: P = softmax(scale*S) over the last dim n; and its backward

@@ -87,6 +87,8 @@ class WeightImages:
         self.pool: Tensor | None = None
         self.armed = False
         self.recording = False
+        self.step = 0                           # prepare() calls so far
+        self.used: dict[tuple, int] = {}        # key -> the step it was last asked for (stale keys are dropped)
 
     @staticmethod
     def _key(kind: str, *ws: Tensor) -> tuple:
@@ -97,6 +99,7 @@ class WeightImages:
         if _train_precision() != "bf16x3":
             return None
         key = self._key(kind, *ws)
+        self.used[key] = self.step
         if self.armed:
             img = self.images.get(key)
             if img is not None and self.versions[key] == tuple(w._version for w in ws):
@@ -115,7 +118,16 @@ class WeightImages:
             self.armed = self.recording = False
             return
         self.recording = True
+        self.step += 1
+        # weights nobody asked for during the last two steps (a model that is gone, a branch no longer taken) leave the plan
+        stale = [k for k in self.plan if self.used.get(k, 0) < self.step - 2]
+        for k in stale:
+            self.plan.pop(k, None)
+            self.images.pop(k, None)
+            self.versions.pop(k, None)
+            self.used.pop(k, None)
         if not self.plan:
+            self.armed = False
             return
         lib = _lib.load()
         jobs, offs, total = [], {}, 0

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GECCO_HIP_LIB") or os.path.join(_HERE, "libgecco_hip.so")   # override: A/B builds only
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 c_f = C.c_void_p  # device pointers travel as void*
 
@@ -176,6 +176,8 @@ SIGNATURES = {
     "gecco_convnext_stem_train_f32": (i, [vp] * 7 + [i, i, i, i, fl, vp]),
     "gecco_convnext_dwconv_ln_train_f32": (i, [vp] * 7 + [i, i, i, i, fl, vp]),
     "gecco_convnext_dwconv_f32": (i, [vp] * 4 + [i, i, i, i, vp]),
+    "gecco_convnext_dwconv_bwd_f32": (i, [vp] * 4 + [i, i, i, i, vp]),
+    "gecco_convnext_fold_scale_bwd_f32": (i, [vp] * 8 + [i, i, vp]),
     "gecco_convnext_ln_bwd_blocks": (i, [i, i, i, i]),
     "gecco_convnext_ln_bwd_f32": (i, [vp] * 5 + [i, i, i, i, fl, i, vp]),
     "gecco_convnext_dwconv_dw_blocks": (i, [i, i, i, i]),

@@ -1030,6 +1030,76 @@ class CnxDwLnFn(torch.autograd.Function):
         return dx, dW, dbias, dg, dbl, None
 
 
+class CnxBlockFn(torch.autograd.Function):
+    """A whole CNBlock, x + layer_scale * Linear(4C -> C)(GELU(Linear(C -> 4C)(LayerNorm(dwconv7x7(x))))) (torchvision's CNBlock,
+    stochastic depth off: models/feature_pyramid.py:55-59), as ONE Function.  Forward: tap-major re-layout, depthwise conv +
+    LayerNorm (keeping the LayerNorm input), layer_scale folded into the second linear by one kernel, the first linear with
+    GELU in its epilogue (pre-activation kept), the second with the skip as its epilogue.  Backward: GELU' as the epilogue of
+    the second linear's dX product, the fold's backward in one kernel (dW2, db2, d layer_scale), LayerNorm backward, and the
+    depthwise input gradient on reversed taps WITH the skip's gradient added in the same kernel — no autograd additions, no
+    flipped or scaled copies made by torch."""
+
+    @staticmethod
+    def forward(ctx, x, dw_w, dw_b, ln_w, ln_b, W1, b1, W2, b2, ls, eps):
+        x = _f(x)
+        lib = _lib.load()
+        B, H, W, Cc = x.shape
+        rows = B * H * W
+        w_tap = dw_w.reshape(Cc, 49).t().contiguous()   # tap-major (49, C)
+        y, z = torch.empty_like(x), torch.empty_like(x)
+        _lib.check(lib.gecco_convnext_dwconv_ln_train_f32(_ptr(x), _ptr(w_tap), _ptr(dw_b), _ptr(ln_w), _ptr(ln_b), _ptr(y), _ptr(z),
+                                                          B, H, W, Cc, eps, _stream()), "gecco_convnext_dwconv_ln_train_f32")
+        lsv = _f(ls.reshape(-1))
+        w2f, b2f = torch.empty_like(W2), torch.empty_like(b2)
+        _lib.check(lib.gecco_convnext_fold_scale_f32(_ptr(W2), _ptr(b2), _ptr(lsv), _ptr(w2f), _ptr(b2f), Cc, W2.shape[1], _stream()),
+                   "gecco_convnext_fold_scale_f32")
+        y3 = y.view(1, rows, Cc)
+        N1 = W1.shape[0]
+        prec = _train_precision()
+        if prec in ("fp32", "bf16x3") and lib.gecco_linear_actbwd_ok(rows, Cc, N1, hip_ops.PRECISIONS[prec]):
+            u, h = _new(1, rows, N1, like=x), _new(1, rows, N1, like=x)
+            img = WEIGHT_IMAGES.lookup("n", W1) if prec == "bf16x3" and _image_ok(rows, Cc, N1) else None
+            Wp, ws = (None, img) if img is not None else (
+                _f(W1), hip_ops._ws((N1 + 127) // 128 * 128 * Cc * 4, x.device) if prec != "fp32" else None)
+            _lib.check(lib.gecco_linear_act_keep_f32(_ptr(y3), _ptr(Wp), _ptr(b1), None, 4, _ptr(u), _ptr(h), 1, rows, Cc, N1,
+                                                     hip_ops.PRECISIONS[prec], C.c_void_p(ws.data_ptr()) if ws is not None else None,
+                                                     _stream()), "gecco_linear_act_keep_f32")
+        else:
+            u = _linear_fwd(y3, W1, b1, None, False)
+            h = _act_forward(u, None, 4)
+        out = _linear_fwd(h, w2f, b2f, x.view(1, rows, Cc), False)
+        ctx.save_for_backward(x, z, w_tap, ln_w, y, u, h, W1, W2, b2, lsv, w2f)
+        ctx.eps, ctx.ls_shape = eps, ls.shape
+        return out.view(B, H, W, Cc)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, z, w_tap, ln_w, y, u, h, W1, W2, b2, lsv, w2f = ctx.saved_tensors
+        lib = _lib.load()
+        B, H, W, Cc = x.shape
+        rows = B * H * W
+        dout = _f(dout)
+        d3 = dout.view(1, rows, Cc)
+        du, _ = _act_linear_dx(d3, u, h, None, w2f, 4, False)
+        dWp, dbp = _linear_dw(d3, h, want_db=True)
+        dW2, db2, dls = torch.empty_like(W2), torch.empty_like(b2), torch.empty_like(lsv)
+        _lib.check(lib.gecco_convnext_fold_scale_bwd_f32(_ptr(dWp), _ptr(dbp), _ptr(W2), _ptr(b2), _ptr(lsv), _ptr(dW2), _ptr(db2),
+                                                         _ptr(dls), Cc, W2.shape[1], _stream()), "gecco_convnext_fold_scale_bwd_f32")
+        dW1, db1 = _linear_dw(du, y.view(1, rows, Cc), want_db=True)
+        dy = _linear_dx(du, W1).view(B, H, W, Cc)
+        dz, dg, dbl, dbias = _cnx_ln_bwd(z, dy, ln_w, ctx.eps, False)
+        dx = None
+        if ctx.needs_input_grad[0]:   # reversed taps, + the gradient that came through the skip, one launch
+            dx = torch.empty_like(x)
+            _lib.check(lib.gecco_convnext_dwconv_bwd_f32(_ptr(dz), _ptr(w_tap), _ptr(dout), _ptr(dx), B, H, W, Cc, _stream()),
+                       "gecco_convnext_dwconv_bwd_f32")
+        nb = lib.gecco_convnext_dwconv_dw_blocks(B, H, W, Cc)
+        parts = _new(nb, 49 * Cc, like=x)
+        _lib.check(lib.gecco_convnext_dwconv_dw_f32(_ptr(x), _ptr(dz), _ptr(parts), B, H, W, Cc, _stream()), "gecco_convnext_dwconv_dw_f32")
+        dWd = _reduce(parts, 49 * Cc, nb, 49 * Cc).reshape(49, Cc).t().reshape(Cc, 1, 7, 7)
+        return dx, dWd, dbias, dg, dbl, dW1, db1, dW2, db2, dls.reshape(ctx.ls_shape), None
+
+
 class CnxLnPatchFn(torch.autograd.Function):
     """LayerNorm2d(x) gathered into the 2 x 2 stride-2 convolution's GEMM operand (B, H/2, W/2, (dy, dx, c))."""
 
@@ -1073,8 +1143,13 @@ def convnext_pyramid(ext, image: Tensor) -> list[Tensor]:
             x = LinearFn.apply(patches.view(1, Bq * hq * wq, 4 * Cin), wmat, conv.bias).view(Bq, hq, wq, Cout)
         Bq, hq, wq, Cc = x.shape
         rows = Bq * hq * wq
+        fused = os.environ.get("GECCO_TRAIN_CNBLOCK", "1") != "0"
         for blk in blocks:
             dw, ln, pw1, pw2 = blk.block[0], blk.block[2], blk.block[3], blk.block[5]
+            if fused:   # the whole block as one Function
+                x = CnxBlockFn.apply(x, dw.weight, dw.bias, ln.weight, ln.bias, pw1.weight, pw1.bias, pw2.weight, pw2.bias,
+                                     blk.layer_scale, LN_EPS)
+                continue
             y = CnxDwLnFn.apply(x, dw.weight, dw.bias, ln.weight, ln.bias, LN_EPS)
             ls = blk.layer_scale.reshape(-1)
             x = LinearActLinearFn.apply(y.view(1, rows, Cc), pw1.weight, pw1.bias, None, pw2.weight * ls[:, None], pw2.bias * ls,

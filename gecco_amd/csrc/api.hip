@@ -1374,6 +1374,19 @@ int gecco_convnext_dwconv_f32(const float* x, const float* w, const float* bias,
     TRY(rc, "convnext_dwconv");
     return 0;
 }
+int gecco_convnext_dwconv_bwd_f32(const float* dz, const float* w, const float* add, float* dx, int B, int H, int W, int C, void* stream) {
+    if (!dz || !w || !dx) return fail(-1, "convnext_dwconv_bwd: null argument");
+    int rc = cnx_dwconv_ln_launch(dz, w, nullptr, nullptr, nullptr, dx, nullptr, B, H, W, C, 0.f, (hipStream_t)stream, add, 1);
+    if (rc == -9) return fail(-2, "convnext_dwconv_bwd: C must be 96, 192 or 384");
+    TRY(rc, "convnext_dwconv_bwd");
+    return 0;
+}
+int gecco_convnext_fold_scale_bwd_f32(const float* dWp, const float* dbp, const float* W, const float* b, const float* s, float* dW,
+                                      float* db, float* ds, int N, int K, void* stream) {
+    if (!dWp || !dbp || !W || !b || !s || !dW || !db || !ds) return fail(-1, "convnext_fold_scale_bwd: null argument");
+    TRY(cnx_fold_scale_bwd_launch(dWp, dbp, W, b, s, dW, db, ds, N, K, (hipStream_t)stream), "convnext_fold_scale_bwd");
+    return 0;
+}
 int gecco_convnext_ln_bwd_blocks(int B, int H, int W, int C) { return cnx_ln_bwd_blocks(B, H, W, C); }
 int gecco_convnext_ln_bwd_f32(const float* z, const float* dy, const float* ln_w, float* dz, float* parts, int B, int H, int W, int C,
                               float eps, int patch2, void* stream) {

@@ -86,7 +86,10 @@ template <int C>
 __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, const float* __restrict__ ln_w,
                                                          const float* __restrict__ ln_b, float* __restrict__ out,
-                                                         float* __restrict__ zout, int B, int H, int W, float eps, int iters) {
+                                                         float* __restrict__ zout, int B, int H, int W, float eps, int iters,
+                                                         const float* __restrict__ addp, int flip) {
+    // raw mode extras: flip — the taps are staged reversed (w[48 - tap]: the convolution's input gradient from dz without a
+    // flipped copy of the weights); addp — a tensor added to the result (the skip connection's gradient of a CNBlock)
     // zout: also the convolution's own output (training: the LayerNorm's input).  ln_w == null: no LayerNorm — out is the
     // convolution (bias may be null too): with the taps reversed this is the convolution's input gradient.
     constexpr int TPP = C / 4, PG = 256 / TPP, TX = 4, NPART = 4;
@@ -96,8 +99,10 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
     float* red = wl + 49 * C;             // [TX][256] per-thread partials
     float* part = red + TX * 256;         // [PG][TX][NPART]
     const int pg = threadIdx.x / TPP, t = threadIdx.x % TPP, c = 4 * t;
-    for (int i = threadIdx.x; i < 49 * C / 4; i += 256)   // w arrives tap-major (49, C): a coalesced copy
-        reinterpret_cast<f32x4*>(wl)[i] = reinterpret_cast<const f32x4*>(w)[i];
+    for (int i = threadIdx.x; i < 49 * C / 4; i += 256) {   // w arrives tap-major (49, C): a coalesced copy
+        const int tap = i / (C / 4), c4 = i % (C / 4);
+        reinterpret_cast<f32x4*>(wl)[i] = reinterpret_cast<const f32x4*>(w)[flip ? (48 - tap) * (C / 4) + c4 : i];
+    }
     const f32x4 bias4 = pg < PG && bias ? *reinterpret_cast<const f32x4*>(bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     const f32x4 g4 = pg < PG && ln_w ? *reinterpret_cast<const f32x4*>(ln_w + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     const f32x4 b4 = pg < PG && ln_w ? *reinterpret_cast<const f32x4*>(ln_b + c) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -143,7 +148,11 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
                 float* op = out + (((size_t)b * H + hy) * W + wx0) * C + c;
 #pragma unroll
                 for (int tx = 0; tx < TX; ++tx)
-                    if (wx0 + tx < W) *reinterpret_cast<f32x4*>(op + (size_t)tx * C) = acc[tx];
+                    if (wx0 + tx < W) {
+                        f32x4 r = acc[tx];
+                        if (addp) r += *reinterpret_cast<const f32x4*>(addp + (op - out) + (size_t)tx * C);
+                        *reinterpret_cast<f32x4*>(op + (size_t)tx * C) = r;
+                    }
             }
             continue;
         }
@@ -237,6 +246,30 @@ __global__ void fold_scale_kernel(const float* __restrict__ Wm, const float* __r
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)N; i += (size_t)gridDim.x * blockDim.x) bo[i] = b[i] * s[i];
 }
 
+// backward of the layer_scale fold: given dW' (N, K), db' (N) of the folded weights W' = s W, b' = s b:
+//   dW[n, k] = s[n] dW'[n, k],  db[n] = s[n] db'[n],  ds[n] = sum_k dW'[n, k] W[n, k] + db'[n] b[n]     (one block per row n)
+__global__ __launch_bounds__(256) void fold_scale_bwd_kernel(const float* __restrict__ dWp, const float* __restrict__ dbp,
+                                                             const float* __restrict__ Wm, const float* __restrict__ b,
+                                                             const float* __restrict__ s, float* __restrict__ dW,
+                                                             float* __restrict__ db, float* __restrict__ ds, int K) {
+    __shared__ float red[4];
+    const int n = blockIdx.x;
+    const float sn = s[n];
+    float acc = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float g = dWp[(size_t)n * K + k];
+        dW[(size_t)n * K + k] = sn * g;
+        acc += g * Wm[(size_t)n * K + k];
+    }
+    for (int o = 1; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ds[n] = ((red[0] + red[1]) + red[2]) + red[3] + dbp[n] * b[n];
+        db[n] = sn * dbp[n];
+    }
+}
+
 }  // namespace
 
 #define CNX_DISPATCH(KERNEL, C, grid, ...)                                                                      \
@@ -257,7 +290,7 @@ int cnx_stem_launch(const float* x, const float* w, const float* bias, const flo
     return (int)hipGetLastError();
 }
 int cnx_dwconv_ln_launch(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b, float* out,
-                         float* zout, int B, int H, int W, int C, float eps, hipStream_t st) {
+                         float* zout, int B, int H, int W, int C, float eps, hipStream_t st, const float* addp, int flip) {
     if (C != 96 && C != 192 && C != 384) return -9;
     const int pg = 256 / (C / 4);
     const size_t ngroups = (size_t)B * H * ((W + 3) / 4), batches = (ngroups + pg - 1) / pg;
@@ -274,7 +307,7 @@ int cnx_dwconv_ln_launch(const float* x, const float* w, const float* bias, cons
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
             attr = true;                                                                                                    \
         }                                                                                                                   \
-        hipLaunchKernelGGL((dwconv7_ln_kernel<CV>), dim3(grid), dim3(256), lds, st, x, w, bias, ln_w, ln_b, out, zout, B, H, W, eps, iters); \
+        hipLaunchKernelGGL((dwconv7_ln_kernel<CV>), dim3(grid), dim3(256), lds, st, x, w, bias, ln_w, ln_b, out, zout, B, H, W, eps, iters, addp, flip); \
         break;                                                                                                              \
     }
     switch (C) {
@@ -295,5 +328,10 @@ int cnx_ln_patch2_launch(const float* x, const float* ln_w, const float* ln_b, f
 }
 int cnx_fold_scale_launch(const float* Wm, const float* b, const float* s, float* Wo, float* bo, int N, int K, hipStream_t st) {
     hipLaunchKernelGGL(fold_scale_kernel, dim3(512), dim3(256), 0, st, Wm, b, s, Wo, bo, N, K);
+    return (int)hipGetLastError();
+}
+int cnx_fold_scale_bwd_launch(const float* dWp, const float* dbp, const float* Wm, const float* b, const float* s, float* dW, float* db,
+                              float* ds, int N, int K, hipStream_t st) {
+    hipLaunchKernelGGL(fold_scale_bwd_kernel, dim3(N), dim3(256), 0, st, dWp, dbp, Wm, b, s, dW, db, ds, K);
     return (int)hipGetLastError();
 }

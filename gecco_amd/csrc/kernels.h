@@ -311,7 +311,9 @@ int sampler_refresh_known_launch(double* x, const float* known, const float* noi
 int cnx_stem_launch(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b, float* out, float* zout,
                     int B, int H, int W, int C, float eps, hipStream_t st);
 int cnx_dwconv_ln_launch(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b, float* out,
-                         float* zout, int B, int H, int W, int C, float eps, hipStream_t st);
+                         float* zout, int B, int H, int W, int C, float eps, hipStream_t st, const float* addp = nullptr, int flip = 0);
+int cnx_fold_scale_bwd_launch(const float* dWp, const float* dbp, const float* Wm, const float* b, const float* s, float* dW, float* db,
+                              float* ds, int N, int K, hipStream_t st);
 int cnx_ln_patch2_launch(const float* x, const float* ln_w, const float* ln_b, float* out, int B, int H, int W, int C, float eps,
                          hipStream_t st);
 int cnx_fold_scale_launch(const float* Wm, const float* b, const float* s, float* Wo, float* bo, int N, int K, hipStream_t st);

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GECCO_ABI_VERSION 11
+#define GECCO_ABI_VERSION 12
 
 int gecco_abi_version(void);
 const char* gecco_build_arch(void);   /* "gfx950" */
@@ -528,6 +528,12 @@ int gecco_convnext_dwconv_ln_train_f32(const float* x, const float* w, const flo
 /* out = dwconv7x7(x, padding 3) (+ bias when non-null), w tap-major (49, C).  With the taps reversed (w[48 - tap]) and dz as
  * x this is the depthwise convolution's input gradient. */
 int gecco_convnext_dwconv_f32(const float* x, const float* w, const float* bias, float* out, int B, int H, int W, int C, void* stream);
+/* the depthwise convolution's input gradient in one launch: dx = dwconv7x7(dz, taps reversed) (+ add: the gradient that reached
+ * the block input through its skip connection); w is the FORWARD tap-major weight (the kernel stages it reversed) */
+int gecco_convnext_dwconv_bwd_f32(const float* dz, const float* w, const float* add, float* dx, int B, int H, int W, int C, void* stream);
+/* backward of gecco_convnext_fold_scale_f32: dW = s dW', db = s db', ds[n] = sum_k dW'[n, k] W[n, k] + db'[n] b[n] */
+int gecco_convnext_fold_scale_bwd_f32(const float* dWp, const float* dbp, const float* W, const float* b, const float* s, float* dW,
+                                      float* db, float* ds, int N, int K, void* stream);
 /* LayerNorm_C backward per texel from its input z (B, H, W, C) (statistics recomputed): dz, and per-block column partials
  * parts (gecco_convnext_ln_bwd_blocks(B, H, W, C), 3, C) = [d ln_w | d ln_b | column sums of dz] (the last is the bias
  * gradient of the convolution that produced z); reduce with gecco_reduce_batch_f32.  patch2 != 0: dy is laid out as the

@@ -34,7 +34,7 @@ def test_header_symbols_exported_and_bound(lib):
 
 
 def test_identity(lib):
-    assert lib.gecco_abi_version() == 11
+    assert lib.gecco_abi_version() == 12
     assert lib.gecco_build_arch() == b"gfx950"
     assert lib.gecco_linear_row_tiles(2048) == 16 and lib.gecco_linear_row_tiles(64) == 1
 

@@ -176,7 +176,55 @@ def _linear_dx(dy: Tensor, W: Tensor, residual: Tensor | None = None) -> Tensor:
     return dx if residual is None else dx + residual
 
 
-def _linear_dw(dy: Tensor, x: Tensor, want_db: bool = False, pro=None):
+# Weight gradients on a SIDE stream.  The dX products form the backward's critical path (each feeds the next backward op); the
+# weight gradients feed nothing until the optimizer.  Both families of kernels keep the matrix pipe 28 - 40 % busy on their own
+# (profiles/r02za_train_pmc_summary.txt), so the dW kernel of a linear is issued on a second stream and shares the CUs with the
+# dX chain running ahead on the main one.  Ordering: the side stream waits for the main stream's work issued so far (dy and x
+# exist), the caching allocator is told about the cross-stream uses (record_stream), and ONE engine callback per backward pass
+# makes the main stream wait for the side stream when the pass ends — after loss.backward() returns, every gradient is
+# ordered on the main stream as before.  Mid-pass consumers on the main stream (a gradient that is ACCUMULATED into an
+# existing .grad, the data-parallel reducer's bucket launch) synchronise explicitly.
+_SIDE = {"stream": None, "pending": False}
+
+
+def _side_enabled() -> bool:
+    return os.environ.get("GECCO_TRAIN_DW_STREAM", "1") != "0" and torch.cuda.is_available() and \
+        not torch.cuda.is_current_stream_capturing()
+
+
+def sync_side_stream() -> None:
+    """The main (current) stream waits for the weight-gradient work issued on the side stream so far."""
+    if _SIDE["pending"] and _SIDE["stream"] is not None:
+        torch.cuda.current_stream().wait_stream(_SIDE["stream"])
+        _SIDE["pending"] = False
+
+
+def _linear_dw(dy: Tensor, x: Tensor, want_db: bool = False, pro=None, leaf: Tensor | None = None):
+    """leaf: the parameter this gradient is FOR, when the caller knows that nothing will read the result before the pass ends —
+    a leaf that is not a view (a view's gradient is scattered into its base by autograd, on the main stream, right away) and
+    has no .grad yet (autograd then keeps the tensor instead of adding it into an existing one).  Only then the side stream."""
+    if leaf is None or not (leaf.is_leaf and leaf._base is None and leaf.grad is None) or not _side_enabled():
+        return _linear_dw_main(dy, x, want_db, pro)
+    if _SIDE["stream"] is None:
+        _SIDE["stream"] = torch.cuda.Stream()
+    side, main = _SIDE["stream"], torch.cuda.current_stream()
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        res = _linear_dw_main(dy, x, want_db, pro)
+    for t in (dy, x) + (tuple(pro) if pro is not None else ()):
+        t.record_stream(side)
+    for t in (res if isinstance(res, tuple) else (res,)):
+        t.record_stream(main)
+    _SIDE["pending"] = True
+    try:   # one callback per call (the first to run does the wait, the rest find nothing pending): no state to go stale if a
+        # backward pass is abandoned half way
+        torch.autograd.Variable._execution_engine.queue_callback(sync_side_stream)
+    except RuntimeError:   # not inside a backward pass: order it right away
+        sync_side_stream()
+    return res
+
+
+def _linear_dw_main(dy: Tensor, x: Tensor, want_db: bool = False, pro=None):
     """dW = dy^T x: both operands read k-major (contraction over their rows); partials summed in a fixed order.
     want_db: also the bias gradient db = column sums of dy -> (dW, db); the split-bf16 kernel forms it from the dy tiles
     it stages anyway.  pro = (a, o): the linear's input was AdaGN(x) = a x + o (per sample and column) — the split-bf16 kernel
@@ -207,7 +255,7 @@ def _linear_dw(dy: Tensor, x: Tensor, want_db: bool = False, pro=None):
             B, R = g, R // g
     if want_db:
         if not (_train_precision() == "bf16x3" and R % 32 == 0 and Nout % 4 == 0 and K % 4 == 0):
-            return _linear_dw(dy, x), _linear_db(dy)
+            return _linear_dw_main(dy, x), _linear_db(dy)
         tiles = -(-Nout // 128) * -(-K // 128)
         G = min(B, max(1, -(-_DW_BLOCKS // tiles)))
         group = -(-B // G)
@@ -265,9 +313,9 @@ class LinearFn(torch.autograd.Function):
         dx = _linear_dx(dy, W) if ctx.needs_input_grad[0] else None
         dW = db = None
         if ctx.has_bias and ctx.needs_input_grad[2] and ctx.needs_input_grad[1]:
-            dW, db = _linear_dw(dy, x, want_db=True)
+            dW, db = _linear_dw(dy, x, want_db=True, leaf=W)
         elif ctx.needs_input_grad[1]:
-            dW = _linear_dw(dy, x)
+            dW = _linear_dw(dy, x, leaf=W)
         elif ctx.has_bias and ctx.needs_input_grad[2]:
             db = _linear_db(dy)
         n = len(ctx.needs_input_grad)        # 3 .. 5: called without / with a residual (and the statistics flag)
@@ -299,11 +347,11 @@ class LinearPairFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         dx = _linear_dx(d2, W2, residual=_linear_dx(d1, W1)) if need[0] else None
         out = [dx]
-        for d, has_b, iw in ((d1, ctx.bias[0], 1), (d2, ctx.bias[1], 3)):
+        for d, has_b, iw, Wl in ((d1, ctx.bias[0], 1, W1), (d2, ctx.bias[1], 3, W2)):
             if need[iw] and has_b and need[iw + 1]:
-                out += list(_linear_dw(d, x, want_db=True))
+                out += list(_linear_dw(d, x, want_db=True, leaf=Wl))
             else:
-                out += [_linear_dw(d, x) if need[iw] else None, _linear_db(d) if has_b and need[iw + 1] else None]
+                out += [_linear_dw(d, x, leaf=Wl) if need[iw] else None, _linear_db(d) if has_b and need[iw + 1] else None]
         return tuple(out)
 
 
@@ -413,12 +461,12 @@ class AdaGNPairFn(torch.autograd.Function):
         dKV = _f(dKV) if dKV is not None else x.new_zeros(B, R, W1.shape[0])
         dq = _f(dq) if dq is not None else x.new_zeros(B, R, W2.shape[0])
         dY = _linear_dx(dq, W2, residual=_linear_dx(dKV, W1))
-        dW1 = _linear_dw(dKV, x, pro=(a, o)) if need[9] else None
+        dW1 = _linear_dw(dKV, x, pro=(a, o), leaf=W1) if need[9] else None
         dW2 = db2 = None
         if need[10] and ctx.has_b2 and need[11]:
-            dW2, db2 = _linear_dw(dq, x, want_db=True, pro=(a, o))
+            dW2, db2 = _linear_dw(dq, x, want_db=True, pro=(a, o), leaf=W2)
         elif need[10]:
-            dW2 = _linear_dw(dq, x, pro=(a, o))
+            dW2 = _linear_dw(dq, x, pro=(a, o), leaf=W2)
         elif ctx.has_b2 and need[11]:
             db2 = _linear_db(dq)
         dx, dsw, dsb, dbw, dbb = _adagn_backward(x, stats, t2, sw, sb, dY, dskip, ctx.G, ctx.eps, True)
@@ -460,12 +508,12 @@ class AdaGNMlpFn(torch.autograd.Function):
         dout = _f(dout)
         du, dalpha = _act_linear_dx(dout, u, h, alpha, W2, ctx.kind, need[11])
 
-        def wgrads(g, act_in, has_b, iw, ib, pro=None):
+        def wgrads(g, act_in, has_b, iw, ib, Wl, pro=None):
             if has_b and need[ib] and need[iw]:
-                return _linear_dw(g, act_in, want_db=True, pro=pro)
-            return (_linear_dw(g, act_in, pro=pro) if need[iw] else None), (_linear_db(g) if has_b and need[ib] else None)
-        dW2, db2 = wgrads(dout, h, ctx.bias[1], 12, 13)
-        dW0, db0 = wgrads(du, x, ctx.bias[0], 9, 10, pro=(a, o))
+                return _linear_dw(g, act_in, want_db=True, pro=pro, leaf=Wl)
+            return (_linear_dw(g, act_in, pro=pro, leaf=Wl) if need[iw] else None), (_linear_db(g) if has_b and need[ib] else None)
+        dW2, db2 = wgrads(dout, h, ctx.bias[1], 12, 13, W2)
+        dW0, db0 = wgrads(du, x, ctx.bias[0], 9, 10, W0, pro=(a, o))
         dY = _linear_dx(du, W0)
         dx, dsw, dsb, dbw, dbb = _adagn_backward(x, stats, t2, sw, sb, dY, dout, ctx.G, ctx.eps, True)
         return dx, None, dsw, dsb, dbw, dbb, None, None, None, dW0, db0, dalpha, dW2, db2, None, None
@@ -599,12 +647,12 @@ class LinearActLinearFn(torch.autograd.Function):
         dy = _f(dy)
         du, dalpha = _act_linear_dx(dy, u, h, alpha, W2, ctx.kind, need[3])
 
-        def wgrads(g, a, has_b, iw, ib):
+        def wgrads(g, a, has_b, iw, ib, Wl):
             if has_b and need[ib] and need[iw]:
-                return _linear_dw(g, a, want_db=True)
-            return (_linear_dw(g, a) if need[iw] else None), (_linear_db(g) if has_b and need[ib] else None)
-        dW2, db2 = wgrads(dy, h, ctx.bias[1], 4, 5)
-        dW0, db0 = wgrads(du, x, ctx.bias[0], 1, 2)
+                return _linear_dw(g, a, want_db=True, leaf=Wl)
+            return (_linear_dw(g, a, leaf=Wl) if need[iw] else None), (_linear_db(g) if has_b and need[ib] else None)
+        dW2, db2 = wgrads(dy, h, ctx.bias[1], 4, 5, W2)
+        dW0, db0 = wgrads(du, x, ctx.bias[0], 1, 2, W0)
         dx = _linear_dx(du, W0) if need[0] else None
         return dx, dW0, db0, dalpha, dW2, db2, (dy if need[6] else None), None, None
 
@@ -635,9 +683,9 @@ class ActLinearFn(torch.autograd.Function):
         du, dalpha = _act_linear_dx(dy, u, h, alpha, W, ctx.kind, ctx.needs_input_grad[1])
         dW = db = None
         if ctx.has_bias and ctx.needs_input_grad[3] and ctx.needs_input_grad[2]:
-            dW, db = _linear_dw(dy, h, want_db=True)
+            dW, db = _linear_dw(dy, h, want_db=True, leaf=W)
         elif ctx.needs_input_grad[2]:
-            dW = _linear_dw(dy, h)
+            dW = _linear_dw(dy, h, leaf=W)
         elif ctx.has_bias and ctx.needs_input_grad[3]:
             db = _linear_db(dy)
         dres = dy if ctx.needs_input_grad[4] else None
@@ -1085,7 +1133,7 @@ class CnxBlockFn(torch.autograd.Function):
         dW2, db2, dls = torch.empty_like(W2), torch.empty_like(b2), torch.empty_like(lsv)
         _lib.check(lib.gecco_convnext_fold_scale_bwd_f32(_ptr(dWp), _ptr(dbp), _ptr(W2), _ptr(b2), _ptr(lsv), _ptr(dW2), _ptr(db2),
                                                          _ptr(dls), Cc, W2.shape[1], _stream()), "gecco_convnext_fold_scale_bwd_f32")
-        dW1, db1 = _linear_dw(du, y.view(1, rows, Cc), want_db=True)
+        dW1, db1 = _linear_dw(du, y.view(1, rows, Cc), want_db=True, leaf=W1)
         dy = _linear_dx(du, W1).view(B, H, W, Cc)
         dz, dg, dbl, dbias = _cnx_ln_bwd(z, dy, ln_w, ctx.eps, False)
         dx = None

@@ -234,6 +234,8 @@ class BucketedGradAllReducer:
         b["launched"] = True
         if self.world() == 1:
             return                                 # optimizer.step() gathers whatever is not in the flat buffer yet
+        from .autograd import sync_side_stream
+        sync_side_stream()                         # weight gradients issued on the side stream (autograd._linear_dw)
         self.opt.gather_grads(b["params"])        # zero_grad(set_to_none=True): the bucket's gradients into their slice
         view = self.flat[b["lo"]:b["hi"]]
         self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))

@@ -152,6 +152,8 @@ class FusedAdamEMA(torch.optim.Optimizer):
         """Gradients that live in tensors of their own (zero_grad(set_to_none=True), or a caller that reset p.grad) are copied
         into their slices of the flat buffer — one multi-tensor copy — and p.grad becomes the view again; a parameter without a
         gradient gets zeros.  `params`: a subset (a reducer bucket); default all."""
+        from .autograd import sync_side_stream
+        sync_side_stream()   # weight gradients issued on the side stream (autograd._linear_dw), if any are still unordered
         if self._span_of is None or len(self._span_of) != len(self._spans):
             self._span_of = {id(p): (o, k) for p, o, k in self._spans}
         gb = self._flat["g"].data_ptr()

@@ -483,6 +483,40 @@ class SetTransformerPlan:
         return x, h_out, so
 
 
+# ------------------------------------------------------------------------------- two streams per evaluation
+# Every kernel of an evaluation keeps the matrix pipe 33 - 50 % busy on its own (profiles/r02za_forward_pmc_summary.txt): the
+# latency of one barrier per K-step.  The samples of a batch are independent (the forward is bit-identical for a sample
+# whatever batch it sits in), so an evaluation runs as TWO half batches on two HIP streams — two C calls, each with its own
+# workspace — whose kernels share the CUs: one half's latency-bound stretches (the 64-inducer chain, a kernel's tail) sit
+# under the other's GEMMs.  C2: 6.64 -> 6.38 ms per evaluation, outputs identical to the bit.  Inside a hipGraph capture the
+# fork / join (event waits) is captured with it.  GECCO_FWD_STREAMS=1 keeps one stream.
+_FWD_SIDE = {"stream": None}
+
+
+def _fwd_parts(B: int, N: int) -> int:
+    if os.environ.get("GECCO_FWD_STREAMS", "2") == "1" or B < 2 or B % 2 or B * N < 32768:
+        return 1
+    return 2
+
+
+def _two_stream_halves(B: int, call, tensors) -> None:
+    """call(lo, hi, idx) issues the evaluation of samples [lo, hi) on the current stream; half 0 runs on the caller's stream,
+    half 1 on the side stream.  `tensors`: what the side stream touches (allocated on the caller's stream)."""
+    if _FWD_SIDE["stream"] is None:
+        _FWD_SIDE["stream"] = torch.cuda.Stream()
+    side, main = _FWD_SIDE["stream"], torch.cuda.current_stream()
+    hb = B // 2
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        call(hb, B, 1)
+    call(0, hb, 0)
+    main.wait_stream(side)
+    if not torch.cuda.is_current_stream_capturing():   # (a captured graph owns its memory: nothing to tell the allocator)
+        for t in tensors:
+            if t is not None:
+                t.record_stream(side)
+
+
 class LinearLiftPlan:
     """EDMPrecond(LinearLift(SetTransformer)) = the unconditional Diffusion.forward, one C call."""
 
@@ -495,8 +529,8 @@ class LinearLiftPlan:
                                      _ptr(p[pre + "lower.1.weight"]), _ptr(p[pre + "lower.1.bias"]), sigma_data)
         self._ws: dict[tuple[int, int], Tensor] = {}
 
-    def workspace(self, B: int, N: int) -> Tensor:
-        key = (B, N)
+    def workspace(self, B: int, N: int, idx: int = 0) -> Tensor:
+        key = (B, N, idx)
         if key not in self._ws:
             self._ws[key] = _ws(self.lib.gecco_linear_lift_workspace_bytes(C.byref(self.table), B, N), self.st.device)
         return self._ws[key]
@@ -504,15 +538,22 @@ class LinearLiftPlan:
     def forward(self, x: Tensor, sigma: Tensor, return_raw: bool = False, cache: Sequence[Tensor] | None = None,
                 do_cache: bool = False, out: Tensor | None = None):
         B, N, _ = x.shape
-        ws = self.workspace(B, N)
         den = torch.empty_like(x) if out is None else out
         raw = torch.empty_like(x) if return_raw else None
         L = self.st.L
         h_out = [torch.empty(B, self.st.I, self.st.C, device=x.device, dtype=torch.float32) for _ in range(L)] if do_cache else None
-        check(self.lib.gecco_linear_lift_fwd_f32(
-            C.byref(self.table), _ptr(x), _ptr(sigma), _ptr(den), _ptr(raw), self.st._ptr_array(cache, L),
-            self.st._ptr_array(h_out, L), B, N, C.c_void_p(ws.data_ptr()), ws.numel(), _stream()),
-            "gecco_linear_lift_fwd_f32")
+
+        def call(lo, hi, idx):
+            ws = self.workspace(hi - lo, N, idx)
+            cut = (lambda ts: None if ts is None else [None if t is None else t[lo:hi] for t in ts])
+            check(self.lib.gecco_linear_lift_fwd_f32(
+                C.byref(self.table), _ptr(x[lo:hi]), _ptr(sigma[lo:hi]), _ptr(den[lo:hi]), _ptr(None if raw is None else raw[lo:hi]),
+                self.st._ptr_array(cut(cache), L), self.st._ptr_array(cut(h_out), L), hi - lo, N, C.c_void_p(ws.data_ptr()),
+                ws.numel(), _stream()), "gecco_linear_lift_fwd_f32")
+        if _fwd_parts(B, N) == 2:
+            _two_stream_halves(B, call, [x, sigma, den, raw, *(cache or []), *(h_out or [])])
+        else:
+            call(0, B, 0)
         res = (den, raw) if return_raw else den
         return (res, h_out) if do_cache else res
 
@@ -611,20 +652,28 @@ class RayNetworkPlan:
     def forward(self, x: Tensor, sigma: Tensor, K: Tensor, levels_nhwc: Sequence[Tensor], return_raw: bool = False,
                 cache: Sequence[Tensor] | None = None, do_cache: bool = False, out: Tensor | None = None):
         B, N, _ = x.shape
-        pyr = make_pyramid(levels_nhwc)
-        key = (B, N, tuple(f.shape[1:] for f in levels_nhwc))
-        if key not in self._ws:
-            self._ws[key] = _ws(self.lib.gecco_ray_network_workspace_bytes(C.byref(self.table), C.byref(pyr), B, N),
-                                self.st.device)
-        ws = self._ws[key]
         den = torch.empty_like(x) if out is None else out
         raw = torch.empty_like(x) if return_raw else None
         L = self.st.L
         h_out = [torch.empty(B, self.st.I, self.st.C, device=x.device, dtype=torch.float32) for _ in range(L)] if do_cache else None
-        check(self.lib.gecco_ray_network_fwd_f32(
-            C.byref(self.table), _ptr(x), _ptr(sigma), _ptr(K), C.byref(pyr), _ptr(den), _ptr(raw),
-            self.st._ptr_array(cache, L), self.st._ptr_array(h_out, L), B, N, C.c_void_p(ws.data_ptr()), ws.numel(),
-            _stream()), "gecco_ray_network_fwd_f32")
+
+        def call(lo, hi, idx):
+            lv = [f[lo:hi] for f in levels_nhwc]               # a sample's pyramid: its slice of every level
+            pyr = make_pyramid(lv)
+            key = (hi - lo, N, tuple(f.shape[1:] for f in levels_nhwc), idx)
+            if key not in self._ws:
+                self._ws[key] = _ws(self.lib.gecco_ray_network_workspace_bytes(C.byref(self.table), C.byref(pyr), hi - lo, N),
+                                    self.st.device)
+            ws = self._ws[key]
+            cut = (lambda ts: None if ts is None else [None if t is None else t[lo:hi] for t in ts])
+            check(self.lib.gecco_ray_network_fwd_f32(
+                C.byref(self.table), _ptr(x[lo:hi]), _ptr(sigma[lo:hi]), _ptr(K[lo:hi]), C.byref(pyr), _ptr(den[lo:hi]),
+                _ptr(None if raw is None else raw[lo:hi]), self.st._ptr_array(cut(cache), L), self.st._ptr_array(cut(h_out), L),
+                hi - lo, N, C.c_void_p(ws.data_ptr()), ws.numel(), _stream()), "gecco_ray_network_fwd_f32")
+        if _fwd_parts(B, N) == 2:
+            _two_stream_halves(B, call, [x, sigma, K, den, raw, *levels_nhwc, *(cache or []), *(h_out or [])])
+        else:
+            call(0, B, 0)
         res = (den, raw) if return_raw else den
         return (res, h_out) if do_cache else res
 

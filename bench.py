@@ -187,7 +187,10 @@ def gemm_call_sites(ops, dev, precision="fp32"):
 def split_bf16_round(ops, dev):
     """out_proj -> mlp.0 -> mlp.2 of one layer as the split-bf16 unit operator on SHARED buffers (x updated in place, the
     hidden layer handed from mlp.0 to mlp.2), so that inside a replayed round each launch meets the cache state its
-    predecessor leaves, as in the forward.  Entries as gemm_call_sites: (name, FLOPs, algorithmic HBM bytes, closure)."""
+    predecessor leaves, as in the forward.  Entries as gemm_call_sites: (name, FLOPs, algorithmic HBM bytes, closure).
+    Launches of the whole batch on ONE stream — the kernel on its own, as `GECCO_FWD_STREAMS=1 bench.py` runs it and as
+    profiles/r02zc_bench_kernel_stats.csv shows it; the default evaluation issues the same kernels for two half batches on two
+    streams (hip_ops._two_stream_halves), where their durations overlap and no per-kernel time exists."""
     g = torch.Generator(device="cpu").manual_seed(2)
     rn = lambda *s: torch.randn(*s, generator=g).to(dev)
     xw, att, hid = rn(B, N, D), rn(B, N, D), torch.empty(B, N, 2 * D, device=dev)
@@ -748,7 +751,9 @@ def main():
                                # 2.4 GHz peak: the chip clocks down under sustained MFMA load
                                "mfma_busy_pmc": tjd.get("mfma_busy"),
                                "kernel": "gemm_dma_kernel<3,true,true,128> = mlp.0 (LDS-DMA ring, AdaGN prologue on the A fragment, "
-                                         "3 x v_mfma_f32_32x32x16_bf16 per product, GaussianActivation epilogue); achieved = 2MNK / "
+                                         "3 x v_mfma_f32_32x32x16_bf16 per product, GaussianActivation epilogue), one launch over the whole batch on one "
+                                         "stream (what GECCO_FWD_STREAMS=1 runs and profiles/r02zc_bench_kernel_stats.csv shows; the default evaluation "
+                                         "issues it for two half batches on two streams, where kernel durations overlap); achieved = 2MNK / "
                                          "its duration inside hipGraph replays of the round out_proj -> mlp.0 -> mlp.2 on shared "
                                          "buffers (HIP events; round - round without it), peak = dense bf16 MFMA peak (2500 TFLOP/s) "
                                          "/ 3 MFMAs per product; traffic = FETCH_SIZE x 2 + WRITE_SIZE of that kernel in the forward "

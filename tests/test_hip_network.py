@@ -297,3 +297,41 @@ def test_split_bf16_linear_accuracy(ops):
     y16, _, _ = plan16.forward_(x.clone(), t)
     e = cpu_ref.rel_err(y16.cpu(), y32.cpu())
     assert 0 < e[0] < 1e-4, e
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["mixed", "fp32"])
+def test_two_stream_evaluation_is_bit_identical(precision, monkeypatch):
+    """hip_ops._two_stream_halves: an evaluation as two half batches on two HIP streams (the default for even batches of
+    >= 32 K points) returns, to the bit, what one launch sequence over the whole batch returns — denoised cloud, raw output,
+    the inducer cache, a cached evaluation of other points, and a hipGraph capture of the forked / joined sequence."""
+    import __graft_entry__ as ge
+    ge.build()
+    from gecco_amd import hip_ops
+    from oracle import weights as W
+    d, L, N, B = 128, 2, 2048, 16
+    p = {k: v.cuda() for k, v in W.linear_lift_state_dict(31, d, L, cases.I, cases.H).items()}
+    rs = np.random.RandomState(8)
+    x = torch.from_numpy(rs.randn(B, N, 3).astype(np.float32)).cuda()
+    x2 = torch.from_numpy(rs.randn(B, 2 * N, 3).astype(np.float32)).cuda()
+    sigma = torch.from_numpy(np.exp(rs.uniform(np.log(0.002), np.log(165.0), size=B)).astype(np.float32)).cuda()
+
+    def run(streams):
+        monkeypatch.setenv("GECCO_FWD_STREAMS", streams)
+        plan = hip_ops.LinearLiftPlan(p, cases.H, cases.I, precision=precision)
+        (den, raw), cache = plan.forward(x, sigma, return_raw=True, do_cache=True)
+        den2 = plan.forward(x2, sigma, cache=cache)
+        out = torch.empty_like(x)
+        plan.forward(x, sigma, out=out)           # warm-up outside the capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            plan.forward(x, sigma, out=out)
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        return den, raw, cache, den2, out.clone()
+    a, b = run("2"), run("1")
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+    assert all(torch.equal(u, v) for u, v in zip(a[2], b[2]))
+    assert torch.equal(a[4], a[0])

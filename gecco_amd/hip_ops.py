@@ -490,31 +490,35 @@ class SetTransformerPlan:
 # workspace — whose kernels share the CUs: one half's latency-bound stretches (the 64-inducer chain, a kernel's tail) sit
 # under the other's GEMMs.  C2: 6.64 -> 6.38 ms per evaluation, outputs identical to the bit.  Inside a hipGraph capture the
 # fork / join (event waits) is captured with it.  GECCO_FWD_STREAMS=1 keeps one stream.
-_FWD_SIDE = {"stream": None}
+_FWD_SIDE = {"streams": []}
 
 
 def _fwd_parts(B: int, N: int) -> int:
-    if os.environ.get("GECCO_FWD_STREAMS", "2") == "1" or B < 2 or B % 2 or B * N < 32768:
+    n = int(os.environ.get("GECCO_FWD_STREAMS", "2"))
+    if n <= 1 or B < 2 * n or B * N < 32768:
         return 1
-    return 2
+    return n
 
 
-def _two_stream_halves(B: int, call, tensors) -> None:
-    """call(lo, hi, idx) issues the evaluation of samples [lo, hi) on the current stream; half 0 runs on the caller's stream,
-    half 1 on the side stream.  `tensors`: what the side stream touches (allocated on the caller's stream)."""
-    if _FWD_SIDE["stream"] is None:
-        _FWD_SIDE["stream"] = torch.cuda.Stream()
-    side, main = _FWD_SIDE["stream"], torch.cuda.current_stream()
-    hb = B // 2
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        call(hb, B, 1)
-    call(0, hb, 0)
-    main.wait_stream(side)
+def _two_stream_halves(B: int, call, tensors, parts: int = 2) -> None:
+    """call(lo, hi, idx) issues the evaluation of samples [lo, hi) on the current stream; part 0 runs on the caller's stream,
+    the others on side streams.  `tensors`: what the side streams touch (allocated on the caller's stream)."""
+    while len(_FWD_SIDE["streams"]) < parts - 1:
+        _FWD_SIDE["streams"].append(torch.cuda.Stream())
+    sides, main = _FWD_SIDE["streams"][:parts - 1], torch.cuda.current_stream()
+    cuts = [B * i // parts for i in range(parts + 1)]
+    for i, side in enumerate(sides, start=1):
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            call(cuts[i], cuts[i + 1], i)
+    call(cuts[0], cuts[1], 0)
+    for side in sides:
+        main.wait_stream(side)
     if not torch.cuda.is_current_stream_capturing():   # (a captured graph owns its memory: nothing to tell the allocator)
         for t in tensors:
             if t is not None:
-                t.record_stream(side)
+                for side in sides:
+                    t.record_stream(side)
 
 
 class LinearLiftPlan:
@@ -550,8 +554,8 @@ class LinearLiftPlan:
                 C.byref(self.table), _ptr(x[lo:hi]), _ptr(sigma[lo:hi]), _ptr(den[lo:hi]), _ptr(None if raw is None else raw[lo:hi]),
                 self.st._ptr_array(cut(cache), L), self.st._ptr_array(cut(h_out), L), hi - lo, N, C.c_void_p(ws.data_ptr()),
                 ws.numel(), _stream()), "gecco_linear_lift_fwd_f32")
-        if _fwd_parts(B, N) == 2:
-            _two_stream_halves(B, call, [x, sigma, den, raw, *(cache or []), *(h_out or [])])
+        if _fwd_parts(B, N) > 1:
+            _two_stream_halves(B, call, [x, sigma, den, raw, *(cache or []), *(h_out or [])], _fwd_parts(B, N))
         else:
             call(0, B, 0)
         res = (den, raw) if return_raw else den
@@ -670,8 +674,8 @@ class RayNetworkPlan:
                 C.byref(self.table), _ptr(x[lo:hi]), _ptr(sigma[lo:hi]), _ptr(K[lo:hi]), C.byref(pyr), _ptr(den[lo:hi]),
                 _ptr(None if raw is None else raw[lo:hi]), self.st._ptr_array(cut(cache), L), self.st._ptr_array(cut(h_out), L),
                 hi - lo, N, C.c_void_p(ws.data_ptr()), ws.numel(), _stream()), "gecco_ray_network_fwd_f32")
-        if _fwd_parts(B, N) == 2:
-            _two_stream_halves(B, call, [x, sigma, K, den, raw, *levels_nhwc, *(cache or []), *(h_out or [])])
+        if _fwd_parts(B, N) > 1:
+            _two_stream_halves(B, call, [x, sigma, K, den, raw, *levels_nhwc, *(cache or []), *(h_out or [])], _fwd_parts(B, N))
         else:
             call(0, B, 0)
         res = (den, raw) if return_raw else den

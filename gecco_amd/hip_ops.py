@@ -554,7 +554,9 @@ class LinearLiftPlan:
                 C.byref(self.table), _ptr(x[lo:hi]), _ptr(sigma[lo:hi]), _ptr(den[lo:hi]), _ptr(None if raw is None else raw[lo:hi]),
                 self.st._ptr_array(cut(cache), L), self.st._ptr_array(cut(h_out), L), hi - lo, N, C.c_void_p(ws.data_ptr()),
                 ws.numel(), _stream()), "gecco_linear_lift_fwd_f32")
-        if _fwd_parts(B, N) > 1:
+        if B == 0:
+            pass   # an empty batch (a rank that owns no cloud): empty results, nothing to launch
+        elif _fwd_parts(B, N) > 1:
             _two_stream_halves(B, call, [x, sigma, den, raw, *(cache or []), *(h_out or [])], _fwd_parts(B, N))
         else:
             call(0, B, 0)
@@ -674,7 +676,9 @@ class RayNetworkPlan:
                 C.byref(self.table), _ptr(x[lo:hi]), _ptr(sigma[lo:hi]), _ptr(K[lo:hi]), C.byref(pyr), _ptr(den[lo:hi]),
                 _ptr(None if raw is None else raw[lo:hi]), self.st._ptr_array(cut(cache), L), self.st._ptr_array(cut(h_out), L),
                 hi - lo, N, C.c_void_p(ws.data_ptr()), ws.numel(), _stream()), "gecco_ray_network_fwd_f32")
-        if _fwd_parts(B, N) > 1:
+        if B == 0:
+            pass   # an empty batch: empty results, nothing to launch
+        elif _fwd_parts(B, N) > 1:
             _two_stream_halves(B, call, [x, sigma, K, den, raw, *levels_nhwc, *(cache or []), *(h_out or [])], _fwd_parts(B, N))
         else:
             call(0, B, 0)

@@ -335,3 +335,22 @@ def test_two_stream_evaluation_is_bit_identical(precision, monkeypatch):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
     assert all(torch.equal(u, v) for u, v in zip(a[2], b[2]))
     assert torch.equal(a[4], a[0])
+
+
+@pytest.mark.gpu
+def test_empty_batch_returns_empty_results():
+    """B = 0 (a data-parallel rank that owns no cloud; the reference's torch modules return empty tensors for it): empty
+    denoised / raw clouds and an empty inducer cache, nothing launched, no error."""
+    import __graft_entry__ as ge
+    ge.build()
+    from gecco_amd import hip_ops
+    from oracle import weights as W
+    d, L, N = 128, 2, 256
+    p = {k: v.cuda() for k, v in W.linear_lift_state_dict(31, d, L, cases.I, cases.H).items()}
+    plan = hip_ops.LinearLiftPlan(p, cases.H, cases.I, precision="mixed")
+    x = torch.empty(0, N, 3, device="cuda")
+    sigma = torch.empty(0, device="cuda")
+    (den, raw), cache = plan.forward(x, sigma, return_raw=True, do_cache=True)
+    assert den.shape == (0, N, 3) and raw.shape == (0, N, 3)
+    assert len(cache) == L and all(h.shape == (0, cases.I, d) for h in cache)
+    torch.cuda.synchronize()

@@ -14,6 +14,7 @@
 // stage), and the fragment reads of A disappear from the LDS pipe.
 #include "gemm_dma_common.h"
 
+#include <cstdlib>
 #include <utility>
 
 namespace {
@@ -178,7 +179,12 @@ int gemm_x3_areg_launch(const GemmArgs& g, hipStream_t st) {
     switch (g.K) {
         case 128: return areg_launch_t<128, 4, 8>(g, st);
         case 256: return areg_launch_t<128, 4, 16>(g, st);
-        case 384: return areg_launch_t<128, 4, 24>(g, st);
+        case 384: {
+            // out_proj at d = 384 (K = 384): 64 x 128 wave tiles measured 0.2 % of the evaluation faster than 32 x 128
+            // (6.650 vs 6.665 ms, three pairs on one box); GECCO_AREG_TALL384=0 keeps the 128-row tile (A/B runs)
+            static const int tall384 = [] { const char* e = getenv("GECCO_AREG_TALL384"); return e ? atoi(e) : 1; }();
+            return (tall && tall384) ? areg_launch_t<256, 4, 24>(g, st) : areg_launch_t<128, 4, 24>(g, st);
+        }
         case 512: return tall ? areg_launch_t<256, 4, 32>(g, st) : areg_launch_t<128, 4, 32>(g, st);
         case 768: return tall ? areg_launch_t<256, 4, 48>(g, st) : areg_launch_t<128, 4, 48>(g, st);
         case 1024: return tall ? areg_launch_t<256, 4, 64>(g, st) : areg_launch_t<128, 4, 64>(g, st);

@@ -120,7 +120,12 @@ __global__ __launch_bounds__(256) void pool_attn_bwd_x3_kernel(const float* __re
     constexpr int P64 = 16 * DT * 128;   // elements of a 64-row plane with DT column blocks
     constexpr int P32 = 8 * DT * 128;    // 32-row plane
     constexpr int PT = 16 * 128;         // the P / dS plane: 64 rows (queries) x 32 columns (keys)
-    constexpr int WAVE_E = 4 * P32 + 2 * PT;
+    // head dims 48 / 64 (DT = 2): the P / dS planes lie over the wave's V planes — V is dead once dP^T is formed, the planes
+    // have the same size, and the next tile's V is stored after the last read of T.  96.5 KB instead of 128.5 KB per block: a
+    // 64 KB block of the weight-gradient kernel (side stream) fits next to it on the CU
+    constexpr bool T_OVER_V = DT == 2;
+    static_assert(!T_OVER_V || PT == P32, "the aliased planes have one size");
+    constexpr int WAVE_E = 4 * P32 + (T_OVER_V ? 0 : 2 * PT);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     u16* lds = reinterpret_cast<u16*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -137,8 +142,8 @@ __global__ __launch_bounds__(256) void pool_attn_bwd_x3_kernel(const float* __re
     u16* Klo = Khi + P32;
     u16* Vhi = Klo + P32;
     u16* Vlo = Vhi + P32;
-    u16* Thi = Vlo + P32;           // P, then dS, as [query][key]
-    u16* Tlo = Thi + PT;
+    u16* Thi = T_OVER_V ? Vhi : Vlo + P32;   // P, then dS, as [query][key]
+    u16* Tlo = T_OVER_V ? Vlo : Thi + PT;
 
     const int ks = (((N + nsplit - 1) / nsplit) + 31) / 32 * 32;
     const int k_begin = split * ks, k_end = min(N, k_begin + ks);
@@ -547,7 +552,7 @@ template <int HD>
 int pool_bwd_x3_t(const float* KV, const float* ind, const float* O, const float* lse, const float* dO, float* dKV, float* dQp,
                   int B, int N, int C, int H, int nsplit, hipStream_t st) {
     constexpr int DT = (HD + 31) / 32;
-    const size_t a = (size_t)(4 * 16 * DT * 128 + 4 * (4 * 8 * DT * 128 + 2 * 16 * 128)) * 2 + 128 * 4, c = (size_t)4 * HD * 64 * 4;
+    const size_t a = (size_t)(4 * 16 * DT * 128 + 4 * (4 * 8 * DT * 128 + (DT == 2 ? 0 : 2 * 16 * 128))) * 2 + 128 * 4, c = (size_t)4 * HD * 64 * 4;
     const size_t lds = a > c ? a : c;
     static bool attr_set = false;
     if (!attr_set) {

@@ -367,7 +367,7 @@ def train_bench(args, rank, world, dev):
         params = list(model.parameters())
     gd.broadcast_parameters(model)
     opt = FusedAdamEMA(params, lr=1e-4, ema_decay=0.99)
-    red = gd.BucketedGradAllReducer(opt, bucket_bytes=args.bucket_mb << 20)
+    red = gd.BucketedGradAllReducer(opt, bucket_bytes=args.bucket_mb << 20, force_collective=args.force_collective)
 
     def step(i):
         opt.zero_grad(set_to_none=not args.grad_views)   # autograd hands the gradients over; gathered per bucket / at step()
@@ -413,11 +413,15 @@ def train_bench(args, rank, world, dev):
     rec["adam_ema_ms"] = time_events(lambda: opt.launch(opt._adam_step, True), 10)   # the kernel alone (state kept: same step)
     rec["grad_bytes"] = flat.numel() * 4
     rec["buckets"] = len(red.buckets)
-    if world > 1:
+    if world > 1 or args.force_collective:
+        # --force-collective at one rank: the RCCL all-reduce of every bucket really executes (a group of one: no bytes
+        # cross a link, so no bus bandwidth is claimed) — the collective path of the step runs before an 8-GPU box has to
         ar = time_events(lambda: dist.all_reduce(flat), 10)
         rec["allreduce_ms_standalone"] = ar
-        rec["allreduce_busbw_gbs"] = 2 * (world - 1) / world * flat.numel() * 4 / (ar * 1e-3) / 1e9
-        red.enabled = False      # same step without the collective: the difference is what the overlap leaves exposed
+        rec["allreduce_busbw_gbs"] = 2 * (world - 1) / world * flat.numel() * 4 / (ar * 1e-3) / 1e9 if world > 1 else None
+        rec["collective"] = {"backend": dist.get_backend(), "world": world, "forced": bool(args.force_collective),
+                             "all_reduces_issued": red.collectives_issued}
+        red.enabled = False      # same step with NO collective anywhere (hooks and finish()): the difference is what the overlap leaves exposed
         for i in range(2):
             step(i)
         torch.cuda.synchronize()
@@ -432,7 +436,7 @@ def train_bench(args, rank, world, dev):
         rec["allreduce_ms_exposed"] = ms - ms0
     if rank == 0:
         print(json.dumps(rec))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
@@ -594,6 +598,8 @@ def main():
                     help="--train: keep p.grad as views of the flat buffer (autograd adds into zeros: one small kernel per parameter)")
     ap.add_argument("--freeze-conditioner", action="store_true",
                     help="--train --config C3|C4: evaluate the ConvNeXt conditioner without gradients (the reference trains it)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="--train: create the (RCCL) process group even for one rank and issue the per-bucket all-reduces in it")
     ap.add_argument("--selftest-launcher", action="store_true", help="N-rank plumbing on gloo with a stand-in step (no GPU)")
     args = ap.parse_args()
 
@@ -614,7 +620,13 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     from gecco_amd import distributed as gd   # rendezvous / barrier / max-over-ranks (covered on gloo in tests/)
-    gd.init("nccl", dev)
+    if args.force_collective and "MASTER_PORT" not in os.environ:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local))
+    gd.init("nccl", dev, force=args.force_collective)
 
     import __graft_entry__ as ge
     if rank == 0 and not os.path.exists(ge.LIB):

@@ -25,10 +25,11 @@ def env_rank_world() -> tuple[int, int, int]:
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def init(backend: str = "nccl", device: torch.device | None = None) -> tuple[int, int]:
-    """Initialise the default process group from the environment; no-op for world_size 1."""
+def init(backend: str = "nccl", device: torch.device | None = None, force: bool = False) -> tuple[int, int]:
+    """Initialise the default process group from the environment; no-op for world_size 1 unless `force` (a group of one
+    rank: the collectives of the training step then execute on RCCL on a 1-GPU box too; needs MASTER_PORT)."""
     rank, world, _ = env_rank_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
         dist.init_process_group(backend, **kw)
@@ -78,51 +79,6 @@ def all_gather_batch(local: Tensor, total: int) -> Tensor:
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad)
     return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0)
-
-
-class GradAllReducer:
-    """Data-parallel training step support: mean all-reduce of every parameter gradient as ONE flat fp32 buffer
-    (13.5 M parameters = 53.9 MB for the shipped unconditional model) — the only collective of the whole path
-    (reference: Lightning's implicit DDP, example_configs/*.py; JAX `lax.pmean`, gecco-jax models/diffusion.py:571-573).
-
-    One large message instead of DDP's 25 MB buckets: the 8 MI355X of a node are fully connected by xGMI, a ring is
-    per-link bound, and a 54 MB all-reduce (~0.6 ms) is small next to the backward pass, so it is issued once after
-    `loss.backward()` on the current stream.  Persistent flat buffer: no per-step allocation.
-
-        reducer = GradAllReducer(model)
-        loss.backward(); reducer.all_reduce_(); optimizer.step()
-    """
-
-    def __init__(self, module: torch.nn.Module):
-        self.params = [p for p in module.parameters() if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
-        dev = self.params[0].device if self.params else torch.device("cpu")
-        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.views, off = [], 0
-        for p in self.params:
-            self.views.append(self.flat[off: off + p.numel()].view_as(p))
-            off += p.numel()
-
-    def all_reduce_(self) -> None:
-        """Average gradients over ranks in place (no-op for world_size 1).  Parameters without a gradient this step
-        contribute zeros, as DDP does."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-            return
-        for p, v in zip(self.params, self.views):
-            if p.grad is None:
-                v.zero_()
-            else:
-                v.copy_(p.grad)
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        self.flat.div_(dist.get_world_size())
-        # a parameter that had no gradient on THIS rank receives the mean of the others' (zero when no rank had one:
-        # then it stays None, so the optimizer skips it exactly as a single-process run would)
-        for p, v in zip(self.params, self.views):
-            if p.grad is None:
-                if bool((v != 0).any()):
-                    p.grad = v.clone()
-            else:
-                p.grad.copy_(v)
 
 
 class FlatGradBuffer:
@@ -183,26 +139,37 @@ class BucketedGradAllReducer:
     """Gradient all-reduce of the data-parallel training step, overlapped with the backward pass.
 
     The gradients live in ONE flat fp32 buffer (`FusedAdamEMA.flat_grad()`: every `p.grad` is a view of it, autograd
-    accumulates in place).  The buffer is cut into buckets of whole parameters — by default one per top-level layer
-    group, ~9 MB each for the shipped model — and a post-accumulate hook counts a bucket's parameters as their
-    gradients land; the moment a bucket is complete its slice is all-reduced (SUM) asynchronously: on RCCL the
-    collective runs on the communicator's own stream behind an event recorded on the compute stream, so it overlaps
-    the rest of the backward (the layers are differentiated last to first, the buckets complete in that order).
-    `finish()` reduces what never completed (parameters without a gradient this step), waits for every handle and sets
-    `optimizer.grad_scale = 1 / world`, which the fused Adam kernel applies while reading g: no averaging pass, no
-    copy in, no copy out.  xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce of 54 MB is
-    per-link bound at ~0.6 ms, so a handful of ~9 MB messages is the right granularity here (DDP's 25 MB buckets
-    would leave the last bucket exposed; per-tensor messages would be latency-bound).
+    accumulates in place).  The buffer is cut into buckets of whole parameters (~8 MB each, 7 for the shipped model)
+    and a post-accumulate hook counts a bucket's parameters as their gradients land.  Collectives are issued in ONE
+    FIXED ORDER on every rank — last bucket first, the order in which the backward completes them (layers are
+    differentiated last to first): a complete bucket is all-reduced (SUM, asynchronously) as soon as every bucket
+    after it has been, so ranks whose hooks fire in different orders (or on which a parameter receives no gradient)
+    still issue the same sequence of same-sized messages, as DDP guarantees with its bucket order.  On RCCL the
+    collective runs on the communicator's own stream behind the compute stream's work so far and overlaps the rest of
+    the backward.  `finish()` reduces what never completed (parameters without a gradient this step), waits for every
+    handle and sets `optimizer.grad_scale = 1 / world`, which the fused Adam kernel applies while reading g: no
+    averaging pass, no copy in, no copy out.  xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce
+    of 54 MB is per-link bound at ~0.6 ms, so a handful of ~8 MB messages is the right granularity here (DDP's 25 MB
+    buckets would leave the last bucket exposed; per-tensor messages would be latency-bound).
+
+    ONE backward per `finish()`: a second `backward()` before `finish()` (gradient accumulation) would add local
+    gradients onto slices that are already summed over ranks — the hook raises when that happens.
+
+    `enabled = False`: no collective is issued anywhere (hooks, `finish()`); gradients are still gathered into the flat
+    buffer and `grad_scale` is 1 — a step "without the all-reduce" for measuring what the overlap leaves exposed.
+    `force_collective = True`: the collectives are issued even in a group of one rank (the RCCL path executes on a
+    1-GPU box: tests/test_hip_nccl.py, `bench.py --train --force-collective`).
 
     Reference: Lightning's implicit DDP (example_configs/shapenet_airplane_unconditional.py:59-77), JAX `lax.pmean`
     (gecco-jax models/diffusion.py:571-573).  Works on any backend (gloo in the CPU tests).
     """
 
-    def __init__(self, optimizer, bucket_bytes: int = 8 << 20, group=None):
+    def __init__(self, optimizer, bucket_bytes: int = 8 << 20, group=None, force_collective: bool = False):
         self.opt = optimizer
         self.group = group
+        self.force_collective = force_collective
         self.flat = optimizer.flat_grad()
-        spans = optimizer.spans()                      # (param, offset, numel) in parameter order
+        spans = [(p, off, n) for p, off, n in optimizer.spans()]   # (param, offset, numel) in parameter order
         # buckets are contiguous slices of the flat buffer, closed whenever they reach bucket_bytes
         self.buckets: list[dict] = []
         cur = None
@@ -218,54 +185,78 @@ class BucketedGradAllReducer:
             self.buckets.append(cur)
         self._bucket_of = {}
         for b in self.buckets:
-            b["pending"] = len(b["params"])
+            b["hooked"] = [p for p in b["params"] if p.requires_grad]   # only these can ever report
+            b["pending"] = len(b["hooked"])
             b["launched"] = False
             b["seen"] = set()
             for p in b["params"]:
                 self._bucket_of[id(p)] = b
+        self._next = len(self.buckets) - 1            # the next bucket to all-reduce (fixed order: last to first)
         self._handles: list = []
         self._hooks = [p.register_post_accumulate_grad_hook(self._ready) for p, _, _ in spans if p.requires_grad]
         self.enabled = True
+        self.collectives_issued = 0                   # lifetime count (tests; the bench's report)
 
     def world(self) -> int:
         return dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
 
+    def _collective(self) -> bool:
+        if not self.enabled:
+            return False
+        if self.force_collective:
+            if not (dist.is_available() and dist.is_initialized()):
+                raise RuntimeError("force_collective needs an initialised process group (distributed.init(..., force=True))")
+            return True
+        return self.world() > 1
+
     def _launch(self, b: dict) -> None:
         b["launched"] = True
-        if self.world() == 1:
-            return                                 # optimizer.step() gathers whatever is not in the flat buffer yet
+        if not self._collective():
+            return                                 # finish() / optimizer.step() gather whatever is not in the flat buffer yet
         from .autograd import sync_side_stream
         sync_side_stream()                         # weight gradients issued on the side stream (autograd._linear_dw)
         self.opt.gather_grads(b["params"])        # zero_grad(set_to_none=True): the bucket's gradients into their slice
         view = self.flat[b["lo"]:b["hi"]]
         self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.collectives_issued += 1
+
+    def _flush(self, everything: bool = False) -> None:
+        """Issue, in the fixed order, every bucket that is complete (or, from finish(), every bucket left)."""
+        while self._next >= 0:
+            b = self.buckets[self._next]
+            if not (everything or b["pending"] == 0):
+                return
+            self._launch(b)
+            self._next -= 1
 
     def _ready(self, p) -> None:
         if not self.enabled:
             return
         b = self._bucket_of[id(p)]
+        if b["launched"] and self._collective():
+            raise RuntimeError("a gradient arrived for a bucket that was already all-reduced: call finish() after every "
+                               "backward() (gradient accumulation over several backward passes is not supported)")
         if id(p) in b["seen"]:
             return                                 # a second contribution to the same parameter (it is used twice)
         b["seen"].add(id(p))
         b["pending"] -= 1
-        if b["pending"] == 0 and not b["launched"]:
+        if b["pending"] == 0:
             if self.flat.data_ptr() != self.opt.flat_grad().data_ptr():
                 raise RuntimeError("gradient storage moved: rebuild the BucketedGradAllReducer after the optimizer")
-            self._launch(b)
+            self._flush()
 
     def finish(self) -> None:
         """Call after `loss.backward()`, before `optimizer.step()`."""
-        for b in self.buckets:
-            if not b["launched"]:
-                self._launch(b)
+        self._flush(everything=True)
         for h in self._handles:
             h.wait()
         self._handles.clear()
-        self.opt.gather_grads()                    # single process: nothing was gathered bucket by bucket
+        self.opt.gather_grads()                    # single process / disabled: nothing was gathered bucket by bucket
         for b in self.buckets:
-            b["pending"], b["launched"] = len(b["params"]), False
+            b["pending"], b["launched"] = len(b["hooked"]), False
             b["seen"].clear()
-        self.opt.grad_scale = 1.0 / self.world()
+        self._next = len(self.buckets) - 1
+        self.opt.grad_scale = 1.0 / self.world() if self.enabled else 1.0
 
     def remove(self) -> None:
         for h in self._hooks:

@@ -1,0 +1,67 @@
+"""Child process of tests/test_hip_nccl.py: a fresh interpreter (nothing has touched the GPU before the process group
+exists) that runs two data-parallel training steps of a small unconditional model on the HIP path in a ONE-RANK `nccl`
+(= RCCL) process group and writes the gradients / parameters / EMA weights it ends with.
+
+  python tests/_nccl_child.py <out.npz> <force_collective 0|1>
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+D, L, N, B = 128, 2, 256, 4
+
+
+def main():
+    out, force = sys.argv[1], sys.argv[2] == "1"
+    import __graft_entry__ as ge
+    ge.build()
+    from gecco_amd import distributed as gd
+    from gecco_amd import hip_ops
+    from gecco_amd.optim import FusedAdamEMA
+    from oracle import weights as W   # test infrastructure: seeded weights only
+    from tests.test_modules_cpu import build_uncond, uncond_state_dict
+    hip_ops.set_default_precision("bf16x3")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    if force:
+        gd.init("nccl", dev, force=True)      # RANK=0 WORLD_SIZE=1 from the environment
+        import torch.distributed as dist
+        assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == 1
+    m = build_uncond(D, L)
+    m.load_state_dict(uncond_state_dict(W.linear_lift_state_dict(11, D, L, 64, 8)), strict=True)
+    model = m.cuda().train()
+    gd.broadcast_parameters(model)
+    opt = FusedAdamEMA(model.parameters(), lr=1e-3, ema_decay=0.9)
+    red = gd.BucketedGradAllReducer(opt, bucket_bytes=64 << 10, force_collective=force)   # several buckets
+    g = torch.Generator().manual_seed(5)
+    data = torch.randn(B, N, 3, generator=g).cuda()
+    noise = torch.randn(B, N, 3, generator=g).cuda()
+    sigma = torch.tensor([0.05, 0.4, 2.0, 30.0]).cuda()
+    s = sigma.reshape(-1, 1, 1)
+    weight = (s ** 2 + 1.0) / (s ** 2)
+    grads = []
+    for it in range(2):
+        # step 1 with p.grad = None: the reducer gathers per bucket after sync_side_stream() — the side-stream weight
+        # gradients (autograd._linear_dw) are in play exactly as in bench.py --train
+        opt.zero_grad(set_to_none=it == 1)
+        den = model(data + noise * s, sigma, None)
+        loss = (100.0 * weight * (den - data) ** 2).mean()
+        loss.backward()
+        red.finish()
+        grads.append((opt.flat_grad() * opt.grad_scale).cpu().numpy().copy())
+        opt.step()
+    torch.cuda.synchronize()
+    params = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu().numpy()
+    ema = torch.cat([e.reshape(-1) for e in opt.ema_params]).cpu().numpy()
+    np.savez(out, g0=grads[0], g1=grads[1], params=params, ema=ema, issued=red.collectives_issued, buckets=len(red.buckets))
+    if force:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -3,6 +3,7 @@ sharded sampler use on RCCL (no data-path collective: replicas only)."""
 import os
 import socket
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
@@ -87,12 +88,22 @@ def _dp_worker(rank, world, port, q):
     g = torch.Generator().manual_seed(0)
     x, y = torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)
     lo, hi = gd.shard_range(8, rank, world)
-    red = gd.GradAllReducer(net)
+    buf = gd.FlatGradBuffer(net.parameters())        # the frozen bias has no span: it can never report a gradient
+    red = gd.BucketedGradAllReducer(buf, bucket_bytes=1 << 30)   # one bucket = one message
+    assert len(red.buckets) == 1
     loss = ((net(x[lo:hi]) - y[lo:hi]) ** 2).mean()
     loss.backward()
-    red.all_reduce_()
-    q.put((rank, [p.detach().numpy().copy() for p in net.parameters()],
-           [p.grad.numpy().copy() for p in net.parameters() if p.requires_grad]))   # by value (see _worker)
+    red.finish()
+    assert red.collectives_issued == 1
+    grads = [(p.grad * buf.grad_scale).numpy().copy() for p in net.parameters() if p.requires_grad]
+    # the same step with the reducer disabled: NO collective anywhere (hooks, finish), local gradients, scale 1
+    buf.zero_grad()
+    red.enabled = False
+    ((net(x[lo:hi]) - y[lo:hi]) ** 2).mean().backward()
+    red.finish()
+    assert red.collectives_issued == 1 and buf.grad_scale == 1.0
+    local = [p.grad.numpy().copy() for p in net.parameters() if p.requires_grad]
+    q.put((rank, [p.detach().numpy().copy() for p in net.parameters()], grads, local))   # by value (see _worker)
     dist.destroy_process_group()
 
 
@@ -107,10 +118,13 @@ def test_two_rank_gradient_all_reduce_matches_full_batch():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    got = [(r, [torch.from_numpy(a) for a in w], [torch.from_numpy(a) for a in g]) for r, w, g in got]
-    (_, w0, g0), (_, w1, g1) = got
+    got = [(r, [torch.from_numpy(a) for a in w], [torch.from_numpy(a) for a in g], [torch.from_numpy(a) for a in l])
+           for r, w, g, l in got]
+    (_, w0, g0, l0), (_, w1, g1, l1) = got
     assert all(torch.equal(a, b) for a, b in zip(w0, w1))
     assert all(torch.equal(a, b) for a, b in zip(g0, g1))
+    assert not all(torch.equal(a, b) for a, b in zip(l0, l1))       # disabled: each rank kept its own shard's gradient
+    assert all(torch.allclose(0.5 * (a + b), g, atol=1e-6) for a, b, g in zip(l0, l1, g0))
     net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 3))
     net[2].bias.requires_grad_(False)
     with torch.no_grad():
@@ -171,6 +185,64 @@ def test_two_rank_bucketed_overlapped_all_reduce():
     for rank, outs in got:
         for grads in outs:
             assert all(torch.allclose(torch.from_numpy(a), b, atol=1e-6) for a, b in zip(grads, ref))
+
+
+def _order_worker(rank, world, port, q):
+    """Ranks whose hooks fire in DIFFERENT orders (rank 1 differentiates the branches in the opposite order; its last
+    parameter gets no gradient at all) must still issue the same sequence of same-sized messages: fixed bucket order."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    gd.init("gloo")
+    torch.manual_seed(1)
+    ws = [torch.nn.Parameter(torch.randn(40 + 8 * i)) for i in range(5)]   # different sizes: a mispaired message would fail
+    buf = gd.FlatGradBuffer(ws)
+    red = gd.BucketedGradAllReducer(buf, bucket_bytes=64)
+    assert len(red.buckets) == 5
+    order = []
+    launch = red._launch
+    red._launch = lambda b: (order.append(red.buckets.index(b)), launch(b))[1]
+    # independent scalar losses, backward one at a time in a rank-dependent order; all five backward passes belong to ONE
+    # step, so the test drives the hooks directly through .backward() on detached graphs before finish()
+    idx = [0, 1, 2, 3, 4] if rank == 0 else [3, 1, 4, 0]       # rank 1: parameter 2 never receives a gradient
+    torch.autograd.backward([(w * (i + 1 + rank)).sum() for i, w in enumerate(ws) if i in idx])
+    red.finish()
+    q.put((rank, order, [(w.grad * buf.grad_scale).numpy().copy() for w in ws]))
+    dist.destroy_process_group()
+
+
+def test_bucket_collectives_are_issued_in_one_fixed_order():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_order_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, order, grads in got:
+        assert order == [4, 3, 2, 1, 0]
+        for i, g in enumerate(grads):
+            want = ((i + 1) + (i + 2 if i != 2 else 0)) / 2.0      # mean over the two ranks of d/dw sum(w * c) = c
+            assert np.allclose(g, want), (rank, i, g[:3], want)
+
+
+def test_second_backward_before_finish_is_refused():
+    """Gradient accumulation across backward passes would add local gradients onto an already reduced slice."""
+    w = [torch.nn.Parameter(torch.ones(8)), torch.nn.Parameter(torch.ones(8))]
+    buf = gd.FlatGradBuffer(w)
+    red = gd.BucketedGradAllReducer(buf, bucket_bytes=16)
+    (w[0].sum() + w[1].sum()).backward()
+    (w[0].sum() + w[1].sum()).backward()          # world 1: nothing was reduced, accumulation is harmless and allowed
+    red.finish()
+    assert float(w[0].grad[0]) == 2.0
+    red._collective = lambda: True                # as if in a group: the buckets of the first pass count as reduced
+    red._launch = lambda b: b.__setitem__("launched", True)
+    buf.zero_grad()
+    (w[0].sum() + w[1].sum()).backward()
+    with pytest.raises(RuntimeError, match="already all-reduced"):
+        (w[0].sum() + w[1].sum()).backward()
 
 
 def test_bench_self_launcher_two_ranks():

@@ -413,6 +413,21 @@ def train_bench(args, rank, world, dev):
     rec["adam_ema_ms"] = time_events(lambda: opt.launch(opt._adam_step, True), 10)   # the kernel alone (state kept: same step)
     rec["grad_bytes"] = flat.numel() * 4
     rec["buckets"] = len(red.buckets)
+    if rank == 0 and not cond and args.precision in ("mixed", "bf16x3", "fp16"):
+        # dominant kernel of the step: the weight-gradient product dW = dY^T X (gemm_tn_x3_kernel, split-bf16: 3 MFMAs per product)
+        # at its largest call site — mlp.2: dY (Bt N, d), X = the hidden layer (Bt N, 2d) — timed with HIP events on the stream it
+        # is launched on (+ the ~5 us fixed-order reduction of its per-group partials)
+        from gecco_amd import autograd as ga
+        gg = torch.Generator().manual_seed(5)
+        dy = torch.randn(Bt, N, D, generator=gg).to(dev)
+        xh = torch.randn(Bt, N, 2 * D, generator=gg).to(dev)
+        with torch.no_grad():
+            t_dw = time_events(lambda: ga._linear_dw_main(dy, xh, want_db=True), 10)
+        fl = 2.0 * Bt * N * D * 2 * D
+        rec["dominant_kernel"] = {"kernel": "gemm_tn_x3_kernel (dW = dY^T X of mlp.2: 2 M N K with M = Bt N rows contracted, split-bf16 = 3 MFMAs "
+                                            "per product; incl. the fixed-order reduction of the per-group partials)",
+                                  "ms": t_dw, "achieved_tflops": fl / (t_dw * 1e-3) / 1e12, "peak_tflops": PEAK_BF16_MFMA_TFLOPS / 3,
+                                  "frac": 3 * fl / (t_dw * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, "bound": "mfma"}
     if world > 1 or args.force_collective:
         # --force-collective at one rank: the RCCL all-reduce of every bucket really executes (a group of one: no bytes
         # cross a link, so no bus bandwidth is claimed) — the collective path of the step runs before an 8-GPU box has to
@@ -438,6 +453,38 @@ def train_bench(args, rank, world, dev):
         print(json.dumps(rec))
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def executed_mfma_flops(mode, Bc=B, Nc=N, d=D, Ll=L):
+    """MFMA FLOPs the evaluation EXECUTES in 16-bit-equivalent matrix-pipe units (an fp8 64-k instruction counts half the
+    cycles per FLOP of a 16-bit one, so its FLOPs count half; split-bf16 executes 3 instructions per product): what
+    `roofline.whole` prices against the 2500 TFLOP/s dense 16-bit peak.  Per sample and layer, SURVEY.md Appendix B terms."""
+    kv, q, outp, m0, m2 = 4 * Nc * d * d, 2 * Nc * d * d, 2 * Nc * d * d, 4 * Nc * d * d, 4 * Nc * d * d
+    attn = 2 * (4 * Nc * I * d)                       # pool + unpool: two products each
+    chain = 2 * I * d * d + 4 * I * d * d + 4 * I * d * d + 4 * I * d * d   # pool.out_proj, broadcast.mlp.0 / .2, unpool k|v
+    if mode == "fp32":
+        return None
+    if mode == "fp16":
+        u = kv + q + outp + m0 + m2 + attn + chain
+    elif mode == "bf16x3":
+        u = 3 * (kv + q + outp + m0 + m2 + attn + chain)
+    else:   # mixed: K, q one fp16 term; V fp16 + fp8 lo term (1.5); attention fp16; chain, out_proj, mlp.2 split-bf16; mlp.0 h8 (2)
+        u = 0.5 * kv * (1 + 1.5) + q + attn + 3 * chain + 3 * outp + 2 * m0 + 3 * m2
+    return Bc * Ll * u
+
+
+def run_child(extra, timeout=420):
+    """One more measurement in a fresh process (own GPU context; started as a child — never exec'd over this one)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), *extra, "--no-extras"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": f"rc {r.returncode}: {r.stderr[-300:]}"}
+        return json.loads(lines[-1])
+    except Exception as e:   # a failed extra must not cost the headline line
+        return {"error": repr(e)[:300]}
 
 
 def other_config_bench(args, rank, world, dev):
@@ -583,6 +630,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-sampler", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra blocks of the default run (train / configs / upsample: child processes, ~6 s of timed work each)")
     ap.add_argument("--eager", action="store_true", help="time eager Diffusion.forward calls instead of the hipGraph replay")
     ap.add_argument("--precision", default=os.environ.get("GECCO_PRECISION", "mixed"), choices=["fp32", "bf16x3", "mixed", "fp16"],
                     help="arithmetic of the linears and attention products: mixed (fp16 where operand rounding does not reach the "
@@ -831,6 +880,42 @@ def main():
                                    "ms_per_evaluation": ts / 255 * 1e3, "hipgraph": True}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         rec["cpu_baseline"] = cpu_baseline(p_cpu, x_cpu, sigma_cpu)
+    if rank == 0 and "roofline" in rec:
+        # whole evaluation against both roofs: executed matrix-pipe work / time / 2500 TFLOP/s, and HBM bytes from the counters
+        # (profiles/gemm_hbm_traffic.json: FETCH_SIZE / WRITE_SIZE passes over whole evaluations of this tree) / time / 8 TB/s
+        ex = executed_mfma_flops(mode)
+        tjw = {}
+        try:
+            tjw = json.load(open(os.path.join(ROOT, "profiles", "gemm_hbm_traffic.json"))).get(mode, {})
+        except Exception:
+            pass
+        cb = tjw.get("bytes_per_evaluation")
+        rec["roofline"]["whole"] = {
+            "executed_mfma_tflops": ex / (ms * 1e-3) / 1e12 if ex else None,
+            "mfma_frac": ex / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS if ex else None,
+            "counter_bytes_per_evaluation": cb, "counter_source": tjw.get("source"),
+            "hbm_gbs": cb / (ms * 1e-3) / 1e9 if cb else None, "hbm_frac": cb / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS if cb else None,
+            "algorithmic_bytes_fp32_stream": 6.04e9}
+    if rank == 0 and world == 1 and not args.no_extras and not args.eager:
+        # what else the tree does, in front of the driver (compact; each a child process with ~10 timed steps)
+        tr = run_child(["--train", "--steps", "10", "--warmup", "3", "--precision", args.precision])
+        rec["train"] = tr if "error" in tr else {
+            "config": "C2 training step, batch 48/GPU (forward + backward + fused Adam/EMA, HIP autograd path, split-bf16)",
+            "ms_per_step": tr["ms_per_step"], "points_per_sec": tr["value"], "tflops_algorithmic": tr["train_tflops_algorithmic"],
+            "adam_ema_ms": tr.get("adam_ema_ms"), "dominant_kernel": tr.get("dominant_kernel")}
+        cfgs = {}
+        for c in ("C3", "C4", "C5"):
+            rc_ = run_child(["--config", c, "--steps", "10", "--warmup", "3", "--precision", args.precision] + (["--no-sampler"] if c != "C5" else []))
+            if "error" in rc_:
+                cfgs[c] = rc_
+                continue
+            cfgs[c] = {"ms_per_step": rc_["ms_per_step"], "points_per_sec": rc_["value"], "forward_tflops": rc_["forward_tflops"],
+                       "workload": rc_["config"]["workload"][:160]}
+            if "conditioner_ms" in rc_:
+                cfgs[c]["conditioner_ms_per_batch"] = rc_["conditioner_ms"]
+            if "upsample" in rc_:
+                rec["upsample"] = rc_["upsample"]
+        rec["configs"] = cfgs
     if rank == 0:
         print(json.dumps(rec))
     if world > 1:

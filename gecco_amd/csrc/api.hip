@@ -186,11 +186,11 @@ int linear_pair(const float* A, const float* W1, const float* b1, int Nout1, flo
 }
 
 // Path switches for A/B runs and tests: gecco_set_option, or the environment (GECCO_ASTAT, GECCO_CHAIN) on first use.
-enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_HEADMAJOR = 2, OPT_MLPFUSED = 3, OPT_UNPOOLFUSED = 4, OPT_LO8 = 5, OPT_ACTIMG = 6, OPT_COUNT = 7 };
-int g_options[OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1};
-const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor", "mlpfused", "unpoolfused", "lo8", "actimg"};
+enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_HEADMAJOR = 2, OPT_MLPFUSED = 3, OPT_UNPOOLFUSED = 4, OPT_LO8 = 5, OPT_ACTIMG = 6, OPT_H8 = 7, OPT_COUNT = 8 };
+int g_options[OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1};
+const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor", "mlpfused", "unpoolfused", "lo8", "actimg", "h8"};
 const char* const g_option_env[OPT_COUNT] = {"GECCO_ASTAT", "GECCO_CHAIN", "GECCO_HEADMAJOR", "GECCO_MLPFUSED", "GECCO_UNPOOLFUSED", "GECCO_LO8",
-                                             "GECCO_ACTIMG"};
+                                             "GECCO_ACTIMG", "GECCO_H8"};
 int option(int which) {
     if (g_options[which] < 0) {
         const char* e = getenv(g_option_env[which]);
@@ -259,14 +259,23 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
     // fp16 mode: everything on the 64 inducers between the two attentions is one launch (inducer_chain_f16.hip)
     // fp16 mode: the point-stream MLP of a layer (AdaGN, mlp.0, activation, mlp.2, residual, statistics) is one launch
     const bool mlpf_on = pr == 2 && w.wimg && option(OPT_MLPFUSED) && mlp_fused_f16_supported(C, Wd, N);
+    // mixed mode: mlp.0 as fp16 main product + two fp8 cross terms, A-stationary over 256-row blocks (gemm_h8_astat.hip); its
+    // output is the tiled split image mlp.2 loads into registers (option "actimg")
+    bool h8_on = false;
+    if (mixed && w.wimg && option(OPT_H8) && option(OPT_ACTIMG) && (act == 0 || (act >= 1 && act <= 3))) {
+        GemmArgs hg{};
+        hg.c_img = 1; hg.w_img = w.wimg; hg.rows = N; hg.Nout = Wd; hg.K = C; hg.lda = C; hg.act = act;
+        h8_on = gemm_h8_astat_supported(hg) && Wd % 16 == 0 && C % 16 == 0;
+    }
     const bool chain_on = pr == 2 && w.wimg && option(OPT_CHAIN) && inducer_chain_f16_supported(C, Wd, H, G, I) &&
                           (ns == 1 || ns == 2 || ns == 4 || ns == 8);
     if (pr >= 1 && w.wimg && !(C % kmod) && !(Wd % kmod)) {
         // split-bf16 mode: every N-token weight of every layer becomes its tiled hi | lo image in ONE launch per
         // 6 layers (weights may change between calls; nothing is cached across forwards)
-        SplitJobs jobs, jobs16;   // jobs16: the fp16 images of the mixed mode (kv_proj | q_proj, hi and lo)
+        SplitJobs jobs, jobs16, jobs8;   // jobs16: the fp16 images of the mixed mode (kv_proj | q_proj, hi and lo); jobs8: mlp.0's h8 image
         jobs.n = 0;
         jobs16.n = 0;
+        jobs8.n = 0;
         // every insertion goes through here: the table is flushed BEFORE a write that would not fit
         constexpr int kJobCap = (int)(sizeof(jobs.job) / sizeof(jobs.job[0]));
         auto push_ld = [&](const float* Wp, float* img, int Nout, int K, int ldw) -> int {
@@ -323,12 +332,18 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
                             "split(mlp.2 K-slice)");
                 }
             } else {
-                TRY(push(L.mlp.w0, base + w.o_w0, Wd, C), "split(mlp.0)");
+                if (h8_on) {   // same bytes as the split-bf16 image it replaces: fp16 hi + fp8 lo + fp8 W per element
+                    if (jobs8.n >= kJobCap) { TRY(h8_image_multi_launch(jobs8, s), "split(mlp.0, h8)"); jobs8.n = 0; }
+                    jobs8.job[jobs8.n++] = SplitJob{L.mlp.w0, base + w.o_w0, Wd, C, C, 0};
+                } else {
+                    TRY(push(L.mlp.w0, base + w.o_w0, Wd, C), "split(mlp.0)");
+                }
                 TRY(push(L.mlp.w2, base + w.o_w2, C, Wd), "split(mlp.2)");
             }
         }
         TRY(pr == 2 ? split_f16_tiled_multi_launch(jobs, s) : split_bf16_tiled_multi_launch(jobs, s), "split(weights)");
         if (mixed) TRY(split_f16_tiled_multi_launch(jobs16, s), "split(weights, fp16)");
+        TRY(h8_image_multi_launch(jobs8, s), "split(mlp.0, h8)");
     }
     const bool imgs = pr >= 1 && w.wimg && !(C % kmod) && !(Wd % kmod);
     // fp16 mode: the point-stream intermediates every consumer rounds to fp16 anyway (K|V, q, the attention output,
@@ -478,6 +493,14 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         // split-bf16 products: the hidden layer goes from mlp.0 to mlp.2 as a tiled split image (same bytes as the fp32 tensor
         // it replaces, in the same buffer): contiguous DMA pieces and no hi / lo split in mlp.2's K loop
         const int himg = pr == 1 && !a16 && im && option(OPT_ACTIMG) && N >= 128 && N % 128 == 0 && Wd % 16 == 0 && C % 16 == 0;
+        if (m0_done == 1 && h8_on && himg && im) {
+            GemmArgs hg{};
+            hg.A = x; hg.pro_a = w.a2; hg.pro_o = w.o2; hg.bias = L.mlp.b0; hg.alpha = L.mlp.alpha; hg.act = act; hg.C = w.big;
+            hg.B = B; hg.rows = N; hg.K = C; hg.Nout = Wd; hg.lda = C; hg.ldw = C; hg.ldc = Wd; hg.c_img = 1; hg.w_img = im + w.o_w0;
+            if ((act == 1 || act == 2) && !L.mlp.alpha) return fail(-6, "mlp.0: GaussianActivation needs alpha");
+            TRY(gemm_h8_astat_launch(hg, s), "mlp.0 (h8)");
+            m0_done = 0;
+        }
         if (m0_done == 1) {
         if (a16) TRY(affine_cast_f16_launch(x, w.a2, w.o2, w.attn, B, N, C, s), "mlp_norm -> fp16");
         TRY(linear(a16 ? w.attn : x, L.mlp.w0, L.mlp.b0, a16 ? nullptr : w.a2, a16 ? nullptr : w.o2, L.mlp.alpha, nullptr,
@@ -525,7 +548,7 @@ int gecco_set_option(const char* name, int value) {
             g_options[i] = value < 0 ? -1 : (value != 0);   // < 0: back to the environment / default
             return 0;
         }
-    return fail(-2, "set_option: unknown option '%s' (astat, chain, headmajor, mlpfused, unpoolfused)", name);
+    return fail(-2, "set_option: unknown option '%s' (astat, chain, headmajor, mlpfused, unpoolfused, lo8, actimg, h8)", name);
 }
 
 int gecco_linear_row_tiles(int rows) { return row_tiles_gemm(rows); }
@@ -704,6 +727,27 @@ int gecco_linear_astat_f16(const float* x, const float* pro_a, const float* pro_
         return fail(-2, "linear_astat: needs rows %% 128 == 0, Nout %% 128 == 0, K in {128, 256, 384, 512}; head-major: "
                         "even head_dim >= 8 dividing both segment widths");
     TRY(gemm_f16_astat_launch(g, s), "linear_astat");
+    return 0;
+}
+
+int gecco_linear_h8_img_f32(const float* x, const float* pro_a, const float* pro_o, const float* W, const float* bias,
+                            const float* alpha, int act, void* c_img, int B, int rows, int K, int Nout, void* wsplit, void* stream) {
+    if (!x || !c_img || !wsplit) return fail(-1, "linear_h8_img: null argument");
+    if ((pro_a == nullptr) != (pro_o == nullptr)) return fail(-1, "linear_h8_img: pro_a/pro_o must both be set");
+    if ((act == 1 || act == 2) && !alpha) return fail(-6, "linear_h8_img: GaussianActivation needs alpha");
+    hipStream_t s = (hipStream_t)stream;
+    GemmArgs g{};
+    g.A = x; g.pro_a = pro_a; g.pro_o = pro_o; g.bias = bias; g.alpha = alpha; g.act = act; g.C = static_cast<float*>(c_img);
+    g.B = B; g.rows = rows; g.K = K; g.Nout = Nout; g.lda = K; g.ldw = K; g.ldc = Nout; g.c_img = 1; g.w_img = wsplit;
+    if (!gemm_h8_astat_supported(g))
+        return fail(-2, "linear_h8_img: needs rows %% 256 == 0, Nout %% 64 == 0, Nout >= 128, K in {128, 256, 384}, act in 0 .. 3");
+    if (W) {   // NULL: wsplit still holds the image a previous call made from the same weights
+        SplitJobs jobs;
+        jobs.n = 1;
+        jobs.job[0] = SplitJob{W, static_cast<float*>(wsplit), Nout, K, K, 0};
+        TRY(h8_image_multi_launch(jobs, s), "linear_h8_img(image)");
+    }
+    TRY(gemm_h8_astat_launch(g, s), "linear_h8_img");
     return 0;
 }
 

@@ -1,0 +1,536 @@
+// A-stationary first linear of the point MLP in "fp16 + fp8 cross terms" arithmetic (h8), gfx950:
+//
+//   u[b, m, n] = act( sum_k y[b, m, k] W[n, k] + bias[n] ),   y = x * pa[b] + po[b]   (AdaGN apply, never materialised)
+//
+// written as the TILED SPLIT IMAGE (GemmArgs::c_img layout: bf16 hi | lo planes) that mlp.2's register-fed kernel
+// (gemm_x3_areg.hip) consumes.  Reference: x + mlp(mlp_norm(x)), models/set_transformer.py:164-166; models/mlp.py:5-39;
+// models/activation.py:17-24; models/normalization.py:36-44.
+//
+// Arithmetic.  Both operands of this product have to carry more than fp16's 11 significant bits (the product feeds the
+// residual stream: tools/experiments/fp16_site_sensitivity.py — one-term fp16 on either side leaves 3e-4 .. 4.5e-4 on F_x,
+// two terms on both 6e-5).  With y = yh + yl (yh = fp16(y)) and W = Wh + Wl:
+//
+//       y W  =  yh Wh          fp16 MFMA            (v_mfma_f32_32x32x16_f16, 32 cycles per 16 k)
+//            +  yh Wl          fp8 scaled MFMA      (v_mfma_scale_f32_32x32x64_f8f6f4, 64 cycles per 64 k: fp8(yh) x fp8(2^19 Wl))
+//            +  yl W           fp8 scaled MFMA      (fp8(2^14 yl) x fp8(2^8 W))
+//            +  yl Wl          dropped (2^-24)
+//
+// — the cross terms are 2^-12 of the product, so 4 significant bits of them suffice: 2 matrix-pipe units per product
+// instead of the 3 of split-bf16, at the same accuracy (emulated 6.0e-5 vs 6.7e-5 on the C2 network).
+//
+// Structure.  A block (8 waves) owns 256 rows of x; every wave keeps ITS 32 rows in registers for the whole kernel — yh as
+// the fp16 fragments of all K / 32 k-steps (96 VGPRs at K = 384), fp8(2^14 yl) as 48 more — built once from coalesced
+// reads through a wave-private staging tile.  All 8 waves then walk the output columns 64 at a time: every wave
+// multiplies its rows with the SAME 64-column W tile, so a byte of W brought into the LDS serves 256 rows (128 in
+// gemm_f16_astat.hip, whose pace the global -> LDS fill sets).  W streams from a pre-tiled image in consumption
+// order — per (64-column tile, 64-k group) one 8 KiB stage of fp16 Wh (two 32-k sub-tiles) and one of fp8 (Wl | W) —
+// through a ring of 2 K / 64 stages by buffer_load ... lds, one 1 KiB piece per wave and stage; a stage is two
+// sub-steps of 128 matrix-pipe cycles per wave, the fragments of the next sub-step are read while one runs.
+// The MFMAs take W as the row operand and y as the column operand: the accumulator then holds, per lane, ONE point and
+// 16 output columns, so the epilogue (bias, activation, hi / lo split) needs no LDS transpose — one
+// v_permlane32_swap per register pair gives every lane 8 consecutive columns = 16 bytes of the hi plane and 16 of the
+// lo plane of the image, a wave-instruction writes 1 KiB of consecutive bytes.
+#include "gemm_dma_common.h"
+
+#include <stdlib.h>
+
+#include <utility>
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int H_NT = 512;          // 8 waves
+constexpr int H_ROWS = 256;        // rows of x per block
+constexpr int H_BN = 64;           // columns per W tile
+constexpr int H_STAGE = 2048;      // floats per 8 KiB ring stage (two 4 KiB sub-tiles)
+constexpr int H_STG = 1536;        // floats of a wave's staging tile: [32][64] fp16 (4 KiB) + [32][64] fp8 (2 KiB)
+constexpr int H_STORES = 8;        // store instructions of a wave's epilogue per column tile
+constexpr float YL_SCALE = 16384.f;    // 2^14: |yl| <= 2^-11 |y| -> fp8 range (448) up to |y| = 56, saturating beyond
+constexpr float W8_SCALE = 256.f;      // 2^8: weights up to |w| = 1.75 (the bound the 2^19 lo image has as well)
+constexpr float WL_SCALE = 524288.f;   // 2^19
+
+__device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, float* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
+template <int... I, class F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+
+// Diagnostic builds (tools/probe/h8_probe.hip): -DH8_STAMPS per-block s_memtime stamps; -DH8_DIAG_NOMFMA / _NODMA / _NOACT /
+// _NOSTORE / _NOEPI remove one ingredient each (results are then garbage; only the time is of interest)
+#ifdef H8_DIAG_NOACT
+#define H8_ACT_ON false
+#else
+#define H8_ACT_ON true
+#endif
+#ifdef H8_STAMPS
+__device__ unsigned long long g_h8_stamps[1024 * 4];
+#define HSTAMP(i)                                                                                              \
+    do {                                                                                                       \
+        if (threadIdx.x == 0 && blockIdx.x < 1024) g_h8_stamps[blockIdx.x * 4 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define HSTAMP(i)
+#endif
+
+#ifdef H8_DIAG_NOMFMA
+__device__ __forceinline__ f32x16 h8_keep16(f16x8 a, f16x8 b, f32x16 c) {
+    asm volatile("" ::"v"(a), "v"(b));
+    return c;
+}
+__device__ __forceinline__ f32x16 h8_keep8(i32x8 a, i32x8 b, f32x16 c) {
+    asm volatile("" ::"v"(a), "v"(b));
+    return c;
+}
+#define H8_MFMA16(a, b, c) h8_keep16(a, b, c)
+#define H8_MFMA8(a, b, c, sa, sb) h8_keep8(a, b, c)
+#else
+#define H8_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define H8_MFMA8(a, b, c, sa, sb) __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, sa, 0, sb)
+#endif
+
+__device__ __forceinline__ float clamp448(float v) { return __builtin_fminf(__builtin_fmaxf(v, -448.f), 448.f); }
+
+// four floats -> four fp8 (e4m3) bytes, k order
+__device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d) {
+    int pk = 0;
+    pk = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, pk, false);
+    pk = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, pk, true);
+    return (unsigned)pk;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// W image.  Stage s = (ct * NG + g) * 2 + kind of 8 KiB each, ct = 64-column tile, g = 64-k group:
+//   kind 0 (H): sub-tile a = fp16(W[n, 64 g + 0 .. 31]), sub-tile b = fp16(W[n, 64 g + 32 .. 63]); a row n (0 .. 63) is 64 bytes =
+//               four 16-byte chunks, logical chunk q = k / 8 stored at physical chunk q ^ ((n >> 2) & 3)
+//               (the [128][32] fp16 tile layout of gemm_f16_dma.hip, 64 rows of it);
+//   kind 1 (L): sub-tile a = fp8(2^19 (W - fp16(W))), sub-tile b = fp8(2^8 W), both [64 n][64 k] bytes: logical chunk q = 2 h + t
+//               holds k = 64 g + 32 t + 16 h + 0 .. 15 — the order in which a lane half h packs its fp16 fragments of two
+//               k-steps (t) into the fp8 operand; physical chunk as above.
+// One thread per 16-byte chunk: 1024 chunks per (ct, g).
+__device__ __forceinline__ void h8_image_item(const float* __restrict__ W, float* __restrict__ img, int Nout, int K, int ldw, size_t i) {
+    const int NG = K / 64;
+    const int pc = (int)(i & 3), n = (int)((i >> 2) & 63), sub = (int)((i >> 8) & 1), kind = (int)((i >> 9) & 1);
+    const size_t cg = i >> 10;
+    const int g = (int)(cg % NG), ct = (int)(cg / NG);
+    const int q = pc ^ ((n >> 2) & 3);
+    const int nn = min(ct * H_BN + n, Nout - 1);
+    u32x4 out;
+    if (kind == 0) {
+        const float* src = W + (size_t)nn * ldw + 64 * g + 32 * sub + 8 * q;
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(src), w1 = *reinterpret_cast<const f32x4*>(src + 4);
+        f16x8 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = (_Float16)w0[e];
+            v[4 + e] = (_Float16)w1[e];
+        }
+        out = __builtin_bit_cast(u32x4, v);
+    } else {
+        const int h = q >> 1, t = q & 1;
+        const float* src = W + (size_t)nn * ldw + 64 * g + 32 * t + 16 * h;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(src + 4 * c);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                v[e] = clamp448(sub == 0 ? (w[e] - (float)(_Float16)w[e]) * WL_SCALE : w[e] * W8_SCALE);
+            out[c] = pack_fp8x4(v[0], v[1], v[2], v[3]);
+        }
+    }
+    // stage base: ((ct * NG + g) * 2 + kind) * 2048 floats; sub-tile: + 1024 floats; row n: 16 floats; chunk: 4 floats
+    *reinterpret_cast<u32x4*>(img + ((cg * 2 + kind) * H_STAGE) + sub * 1024 + n * 16 + pc * 4) = out;
+}
+
+__global__ void h8_image_multi_kernel(SplitJobs jobs) {
+    const SplitJob j = jobs.job[blockIdx.y];
+    const size_t total = (size_t)(j.Nout / H_BN) * (j.K / 64) * 1024;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        h8_image_item(j.W, j.img, j.Nout, j.K, j.ldw, i);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// NG = K / 64; NW = waves per block (rows = 32 NW); NS ring slots with (2 NG) % NS == 0, so the slot of a stage is its position
+// in the column tile mod NS — static.  ACT: the epilogue's activation is a template parameter (a runtime code costs a scalar
+// branch per VALUE here: the compiler does not hoist it out of the unrolled epilogue).
+template <int NG, int NW, int NS, int ACT>
+__global__ __launch_bounds__(64 * NW, 2) void gemm_h8_astat_kernel(GemmArgs g) {
+    constexpr int NKT = 2 * NG, K = 64 * NG, NT = 64 * NW, ROWS = 32 * NW, PW = 8 / NW;
+    static_assert(NS >= 4 && NKT % NS == 0 && (NW == 4 || NW == 8), "static slots; lookahead NS - 1 >= 3 stages");
+    static_assert(NS * H_STAGE * 4 <= 65536 || NS % 2 == 0, "ring addressed from two bases");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* ring = smem;                                // [NS][H_STAGE]
+    float* stg = ring + NS * H_STAGE;                  // [NW][H_STG] wave-private staging of the A build
+    float* bias_lds = stg + NW * H_STG;                // [Nout]
+    float* pro_lds = bias_lds + g.Nout;                // pa[0 .. K) | po[0 .. K)
+
+    const int tilesM = g.rows / ROWS, tilesN = g.Nout / H_BN;
+    const int b = blockIdx.x / tilesM, rt = blockIdx.x % tilesM, m0 = rt * ROWS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // rows m0 + 32 wave .. + 31
+    const int r = lane & 31, h = lane >> 5;
+
+    HSTAMP(0);
+    for (int n = tid; n < g.Nout; n += NT) bias_lds[n] = g.bias ? g.bias[n] : 0.f;
+    {
+        const bool has_pro = g.pro_a != nullptr;
+        const float* pa = has_pro ? g.pro_a + (size_t)b * K : nullptr;
+        const float* po = has_pro ? g.pro_o + (size_t)b * K : nullptr;
+        for (int i = tid; i < K; i += NT) {
+            pro_lds[i] = has_pro ? pa[i] : 1.f;
+            pro_lds[K + i] = has_pro ? po[i] : 0.f;
+        }
+    }
+    // two blocks per CU: the second of a pair starts late, so that one's epilogue (vector work) meets the other's matrix work
+    if (g.h8_stagger > 0 && (((blockIdx.x >> 3) / g.h8_pair) & 1)) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)g.h8_stagger) __builtin_amdgcn_s_sleep(8);
+    }
+    __syncthreads();   // before the first DMA: a block barrier drains the vector-memory queue
+
+    // ---- W stream: PW 1 KiB pieces per wave and stage; the image is consumed front to back.  Past its end the last stage is
+    // fetched again (into slots nobody reads any more): every step issues, so every wait below is the same count
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.w_img), 0, 0x7fffffff, 0x00020000);
+    const unsigned voff = (unsigned)(wave * PW * 256 + lane * 4) * 4u;
+    const unsigned soff_last = (unsigned)(tilesN * NKT - 1) * (H_STAGE * 4u);
+    unsigned soff = 0;
+    auto issue = [&](int slot) {
+#ifndef H8_DIAG_NODMA
+#pragma unroll
+        for (int p = 0; p < PW; ++p)
+            dma16_buf(wrsrc, voff + p * 1024u, soff, ring + slot * H_STAGE + (wave * PW + p) * 256);
+#endif
+        soff = soff < soff_last ? soff + H_STAGE * 4u : soff_last;
+    };
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p) issue(p);
+
+    // ---- the A operand, wave-private: yh = fp16(x pa + po) as the fragments fa[kt][c] (lane (r, h): row r, k = 32 kt + 16 h +
+    // 8 c .. + 7) and fp8(2^14 (y - yh)) as alo[g] (byte 16 t + e of the lane's 32: k = 64 g + 32 t + 16 h + e).  Per 64-k slab:
+    // eight coalesced 16-byte loads per lane (4 rows x 256 bytes per wave-instruction), affine, rounding, into the staging
+    // tile (16-byte chunks XOR-swizzled by row), from where the lane takes its fragments.
+    f16x8 fa[2 * NG][2];
+    i32x8 alo[NG];
+    {
+        const float* xw = g.A + ((size_t)b * g.rows + m0 + wave * 32) * g.lda;
+        char* sw = reinterpret_cast<char*>(stg + wave * H_STG);
+        const int lrow = lane >> 4, c16 = lane & 15;
+        f32x4 xs[2][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xs[0][i] = *reinterpret_cast<const f32x4*>(xw + (size_t)(4 * i + lrow) * g.lda + 4 * c16);
+        static_for(std::make_integer_sequence<int, NG>{}, [&](auto S) {
+            constexpr int s = decltype(S)::value;
+            if constexpr (s + 1 < NG) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    xs[(s + 1) & 1][i] = *reinterpret_cast<const f32x4*>(xw + (size_t)(4 * i + lrow) * g.lda + 64 * (s + 1) + 4 * c16);
+            }
+            const f32x4 pa4 = *reinterpret_cast<const f32x4*>(pro_lds + 64 * s + 4 * c16);
+            const f32x4 po4 = *reinterpret_cast<const f32x4*>(pro_lds + K + 64 * s + 4 * c16);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = 4 * i + lrow;
+                f16x4 hv;
+                float lo[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float y = __builtin_fmaf(xs[s & 1][i][e], pa4[e], po4[e]);
+                    hv[e] = (_Float16)y;
+                    lo[e] = clamp448((y - (float)hv[e]) * YL_SCALE);
+                }
+                *reinterpret_cast<u32x2*>(sw + row * 128 + (((c16 >> 1) ^ (row & 7)) << 4) + (c16 & 1) * 8) = __builtin_bit_cast(u32x2, hv);
+                *reinterpret_cast<unsigned*>(sw + 4096 + row * 64 + (((c16 >> 2) ^ ((row >> 1) & 3)) << 4) + (c16 & 3) * 4) =
+                    pack_fp8x4(lo[0], lo[1], lo[2], lo[3]);
+            }
+            __builtin_amdgcn_wave_barrier();   // a wave's LDS operations execute in order: its reads below see these writes
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int cq = 4 * t + 2 * h + c;
+                    fa[2 * s + t][c] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(sw + r * 128 + ((cq ^ (r & 7)) << 4)));
+                }
+                const int nc = 2 * t + h;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(sw + 4096 + r * 64 + ((nc ^ ((r >> 1) & 3)) << 4));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) alo[s][4 * t + e] = (int)v[e];
+            }
+            __builtin_amdgcn_wave_barrier();
+        });
+    }
+
+    // ---- per-lane addressing of the W fragments and of the output image.  ds_read offsets are 16-bit: a ring of more than
+    // 64 KiB is addressed from two bases, slots [0, NS / 2) and [NS / 2, NS)
+    constexpr bool TWO = NS * H_STAGE * 4 > 65536;
+    constexpr int HALF = TWO ? NS / 2 : NS;
+    const float* bptr[2][2][2];   // [ring half][j][c]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = j * 32 + r;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            bptr[0][j][c] = ring + n * 16 + (((2 * h + c) ^ ((n >> 2) & 3)) << 2);
+            bptr[1][j][c] = bptr[0][j][c] + HALF * H_STAGE;
+        }
+    }
+    i32x8 fbA[2], fbB[2];
+    // fragments of sub-tile `sub` (0 / 1) of ring slot `slot` (compile-time): base register + immediate offset
+    auto load_f = [&](auto SLOT, auto SUB, i32x8(&f)[2]) {
+        constexpr int slot = decltype(SLOT)::value, sub = decltype(SUB)::value;
+        constexpr int hf = slot >= HALF ? 1 : 0;
+        constexpr int off = (slot - hf * HALF) * H_STAGE + sub * 1024;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(bptr[hf][j][c] + off);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f[j][4 * c + e] = (int)v[e];
+            }
+    };
+    const int T128 = g.rows >> 7;
+    const int mrow = m0 + wave * 32 + r, ml = mrow & 127;
+    unsigned short* lane_dst = reinterpret_cast<unsigned short*>(g.C) +
+                               ((size_t)b * T128 + (mrow >> 7)) * (size_t)(g.Nout >> 4) * 4096 + ml * 16 + ((h ^ ((ml >> 3) & 1)) << 3);
+
+    // exp(-u^2 / (2 a^2)) = exp2(u^2 c2): log2(e) folded into the constant (one multiply less per value than gauss_act)
+    const float c2 = (ACT == 1 || ACT == 2) ? -1.4426950408889634f / (2.0f * g.alpha[0] * g.alpha[0]) : 0.f;
+    f32x16 acc[2];
+
+    // ---- epilogue of one 64-column tile, from registers.  acc[j][4 q + e] = u[row r][n0 + 32 j + 8 q + 4 h + e].
+    auto epilogue = [&](int ct) {
+        const int n0 = ct * H_BN;
+        unsigned short* tdst = lane_dst + (size_t)(n0 >> 4) * 4096;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x4 bs[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bs[q] = *reinterpret_cast<const f32x4*>(bias_lds + n0 + 32 * j + 8 * q + 4 * h);
+            unsigned hq[4][2], lq[4][2];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v[4];
+                unsigned u[4];
+                float lo[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[j][4 * q + e] + bs[q][e];
+                    if (H8_ACT_ON && ACT == 3) v[e] = fmaxf(v[e], 0.f);
+                    if (H8_ACT_ON && (ACT == 1 || ACT == 2)) {
+                        const float y = __builtin_amdgcn_exp2f(v[e] * v[e] * c2);
+                        v[e] = ACT == 1 ? (y - 0.7f) * (1.0f / 0.28f) : y;
+                    }
+                    u[e] = __float_as_uint(v[e]);
+                    lo[e] = v[e] - __uint_as_float(u[e] & 0xFFFF0000u);
+                }
+                hq[q][0] = __builtin_amdgcn_perm(u[1], u[0], 0x07060302u);
+                hq[q][1] = __builtin_amdgcn_perm(u[3], u[2], 0x07060302u);
+                bf16x2 l0, l1;
+                l0[0] = (__bf16)lo[0];
+                l0[1] = (__bf16)lo[1];
+                l1[0] = (__bf16)lo[2];
+                l1[1] = (__bf16)lo[3];
+                lq[q][0] = __builtin_bit_cast(unsigned, l0);
+                lq[q][1] = __builtin_bit_cast(unsigned, l1);
+            }
+            // quads (2 p, 2 p + 1): after the swap the lower lane half holds columns 16 p + 0 .. 7 of its row, the upper half
+            // 16 p + 8 .. 15 — chunk h of k-step (n0 + 32 j) / 16 + p of the image
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                u32x4 H, Lo;
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const auto sh = __builtin_amdgcn_permlane32_swap(hq[2 * p][d], hq[2 * p + 1][d], false, false);
+                    const auto sl = __builtin_amdgcn_permlane32_swap(lq[2 * p][d], lq[2 * p + 1][d], false, false);
+                    H[d] = sh[0];
+                    H[2 + d] = sh[1];
+                    Lo[d] = sl[0];
+                    Lo[2 + d] = sl[1];
+                }
+                unsigned short* dst = tdst + (size_t)(2 * j + p) * 4096;
+#ifdef H8_DIAG_NOSTORE
+                asm volatile("" ::"v"(H), "v"(Lo), "v"(dst));
+#else
+                GECCO_NT_STORE(H, reinterpret_cast<u32x4*>(dst));
+                GECCO_NT_STORE(Lo, reinterpret_cast<u32x4*>(dst + 2048));
+#endif
+            }
+        }
+    };
+
+    HSTAMP(1);
+    // every wave's pieces of the first NS - 1 stages (older than the x loads, long landed) are in the ring
+    dma::wait_vm_lgkm0<0>();
+    __builtin_amdgcn_s_barrier();
+    load_f(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, fbA);
+    float one = 1.0f;   // the fp8 conversions' scale operand behind an opaque asm: keeps them inside the column-tile loop
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int ct = 0; ct < tilesN; ++ct) {
+        const bool first = ct == 0;
+        asm volatile("" : "+s"(one));
+#ifdef H8_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
+        static_for(std::make_integer_sequence<int, NKT>{}, [&](auto KT) {
+            constexpr int kt = decltype(KT)::value;
+            constexpr bool lstage = (kt & 1) != 0;
+            constexpr int gq = kt >> 1;
+            // own pieces of stage kt + 1 landed.  Younger vector-memory operations that may stay in flight: the pieces of the
+            // NS - 3 stages after it (every step issues one stage, the stream's end included) and, while the awaited pieces
+            // are older than them (kt <= NS - 3), the 8 stores of the previous tile's epilogue
+            constexpr int young = (NS - 3) * PW;
+            constexpr bool st_young = kt <= NS - 3;
+            if (st_young && !first) dma::wait_vm_lgkm0<young + H_STORES>();
+            else dma::wait_vm_lgkm0<young>();
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(fbA[j]));
+            __builtin_amdgcn_s_barrier();
+            // stage kt + NS - 1 goes to the slot of stage kt - 1, whose last fragment reads (this step's sub-step a set, read
+            // during the previous step) every wave has completed before the barrier
+            issue((kt + NS - 1) % NS);
+            // sub-step a: fragments of sub-step b are read while it runs
+            load_f(std::integral_constant<int, kt % NS>{}, std::integral_constant<int, 1>{}, fbB);
+            if constexpr (!lstage) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const i32x4 wc = c == 0 ? __builtin_shufflevector(fbA[j], fbA[j], 0, 1, 2, 3) : __builtin_shufflevector(fbA[j], fbA[j], 4, 5, 6, 7);
+                        // the first product of a column tile starts from zero: no accumulator clearing pass
+                        acc[j] = H8_MFMA16(__builtin_bit_cast(f16x8, wc), fa[2 * gq][c], (kt == 0 && c == 0) ? zero16 : acc[j]);
+                    }
+            } else {
+                // yh Wl: fp8(yh) of the group's two k-steps, bytes in the image's k order (16 t + 8 c + e)
+                i32x8 a8;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const f16x8 v = fa[2 * gq + t][c];
+                        s16x2 p0 = {0, 0}, p1 = {0, 0};
+                        p0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(p0, f16x2{v[0], v[1]}, one, false);
+                        p0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(p0, f16x2{v[2], v[3]}, one, true);
+                        p1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(p1, f16x2{v[4], v[5]}, one, false);
+                        p1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(p1, f16x2{v[6], v[7]}, one, true);
+                        a8[4 * t + 2 * c] = __builtin_bit_cast(int, p0);
+                        a8[4 * t + 2 * c + 1] = __builtin_bit_cast(int, p1);
+                    }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[j] = H8_MFMA8(fbA[j], a8, acc[j], 127 - 19, 127);
+            }
+            // sub-step b: the first fragments of the next stage are read while it runs
+            load_f(std::integral_constant<int, (kt + 1) % NS>{}, std::integral_constant<int, 0>{}, fbA);
+            if constexpr (!lstage) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const i32x4 wc = c == 0 ? __builtin_shufflevector(fbB[j], fbB[j], 0, 1, 2, 3) : __builtin_shufflevector(fbB[j], fbB[j], 4, 5, 6, 7);
+                        acc[j] = H8_MFMA16(__builtin_bit_cast(f16x8, wc), fa[2 * gq + 1][c], acc[j]);
+                    }
+            } else {
+                // yl W
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[j] = H8_MFMA8(fbB[j], alo[gq], acc[j], 127 - 8, 127 - 14);
+            }
+        });
+#ifdef H8_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+#ifndef H8_DIAG_NOEPI
+        epilogue(ct);
+#endif
+    }
+    HSTAMP(2);
+#ifdef H8_DIAG_NOEPI
+    if (acc[0][0] == 123.456f) epilogue(0);
+#endif
+    dma::wait_vm_lgkm0<0>();   // the re-fetched tail stages still target this block's LDS: land them before it is released
+}
+
+constexpr int h8_ns(int NG, int NW) { return NW == 8 ? 2 * NG : (NG % 3 == 0 ? 6 : 4); }   // NW = 4: 48 / 32 KiB rings, two blocks per CU
+
+template <int NG, int NW, int ACT>
+int h8_launch_a(const GemmArgs& g, hipStream_t st) {
+    constexpr int NS = h8_ns(NG, NW);
+    const size_t lds = ((size_t)NS * H_STAGE + NW * H_STG + g.Nout + 2 * g.K) * sizeof(float);
+    static size_t attr = 0;
+    if (lds > attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h8_astat_kernel<NG, NW, NS, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = lds;
+    }
+    hipLaunchKernelGGL((gemm_h8_astat_kernel<NG, NW, NS, ACT>), dim3(g.B * (g.rows / (32 * NW))), dim3(64 * NW), lds, st, g);
+    return (int)hipGetLastError();
+}
+template <int NG, int NW>
+int h8_launch_t(const GemmArgs& g, hipStream_t st) {
+    switch (g.act) {
+        case 0: return h8_launch_a<NG, NW, 0>(g, st);
+        case 1: return h8_launch_a<NG, NW, 1>(g, st);
+        case 2: return h8_launch_a<NG, NW, 2>(g, st);
+        case 3: return h8_launch_a<NG, NW, 3>(g, st);
+        default: return -9;
+    }
+}
+
+int h8_env(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+}  // namespace
+
+size_t h8_image_bytes(int Nout, int K) { return (size_t)((Nout + H_BN - 1) / H_BN) * H_BN * K * 4; }
+
+int h8_image_multi_launch(const SplitJobs& jobs, hipStream_t st) {
+    if (jobs.n <= 0) return 0;
+    for (int i = 0; i < jobs.n; ++i)
+        if (jobs.job[i].K % 64 || jobs.job[i].Nout % H_BN || (jobs.job[i].ldw & 3)) return -9;
+    hipLaunchKernelGGL(h8_image_multi_kernel, dim3(48, jobs.n), dim3(256), 0, st, jobs);
+    return (int)hipGetLastError();
+}
+
+// c_img output only: whole 128-row blocks of one sample, 64-column tiles, K = 128 / 256 / 384 (the stationary operand is
+// 3 K / 8 registers per lane)
+bool gemm_h8_astat_supported(const GemmArgs& g) {
+    return g.c_img && !g.a_img && !g.a_f16 && !g.c_f16 && !g.residual && !g.stats && !g.C2 && g.w_img && g.rows >= 128 &&
+           !(g.rows % 128) && !(g.Nout % H_BN) && g.Nout >= 2 * H_BN && g.Nout <= 4096 && (g.K == 128 || g.K == 256 || g.K == 384) &&
+           !(g.lda & 3) && ((g.pro_a == nullptr) == (g.pro_o == nullptr)) && !g.mul_u && !g.pre_out && g.act >= 0 && g.act <= 3;
+}
+
+// GECCO_H8_WAVES = 8: one 256-row block of 8 waves per CU (rows % 256 == 0) instead of two 128-row blocks of 4;
+// GECCO_H8_STAGGER: start offset (s_memtime ticks) of every second block of a CU, GECCO_H8_PAIR: blocks per XCD between partners
+int gemm_h8_astat_launch(const GemmArgs& g0, hipStream_t st) {
+    if (!gemm_h8_astat_supported(g0)) return -9;
+    static const int waves = h8_env("GECCO_H8_WAVES", 4), stagger = h8_env("GECCO_H8_STAGGER", 0), pair = h8_env("GECCO_H8_PAIR", 32);
+    GemmArgs g = g0;
+    g.h8_stagger = stagger;
+    g.h8_pair = pair > 0 ? pair : 32;
+    if (waves == 8 && g.rows % 256 == 0) {
+        g.h8_stagger = 0;
+        switch (g.K) {
+            case 128: return h8_launch_t<2, 8>(g, st);
+            case 256: return h8_launch_t<4, 8>(g, st);
+            case 384: return h8_launch_t<6, 8>(g, st);
+            default: return -9;
+        }
+    }
+    switch (g.K) {
+        case 128: return h8_launch_t<2, 4>(g, st);
+        case 256: return h8_launch_t<4, 4>(g, st);
+        case 384: return h8_launch_t<6, 4>(g, st);
+        default: return -9;
+    }
+}

@@ -55,6 +55,7 @@ struct GemmArgs {
     // Activation FORWARD that keeps its input (training: the backward needs u): C = act(A W^T + bias) as with `act`, and
     // pre_out (B, rows, ldc) = A W^T + bias.  Same kernel instantiation as mul_u (the training path's); not with c_img.
     float* pre_out;
+    int h8_stagger, h8_pair;   // gemm_h8_astat.hip: start offset of every second block of a CU (set by its launcher)
 };
 
 struct SplitJob { const float* W; float* img; int Nout, K, ldw, pad_; };   // pad_ = 1 (fp16 images): the LOW part fp16(W - fp16(W)); 2: the same as fp8 x 2^19 in 64-k blocks; 4 (bf16 images): W is (K, ldw) and the image is of W^T
@@ -150,6 +151,13 @@ int gemm_tn_x3_launch(const TnArgs& g, hipStream_t st);
 bool gemm_f16_astat_lo8_supported(int K);   // the fp8 form of the lo image exists for this K
 bool gemm_f16_astat_supported(const GemmArgs& g);
 int gemm_f16_astat_launch(const GemmArgs& g, hipStream_t st);
+
+// gemm_h8_astat.hip — mixed mode's mlp.0: AdaGN apply + fp16 main product + two fp8 cross terms (2 matrix-pipe units per
+// product at split-bf16 accuracy), A-stationary over 256-row blocks, output as the tiled split image (c_img)
+size_t h8_image_bytes(int Nout, int K);   // Nout * K * 4 (Nout % 64 == 0)
+int h8_image_multi_launch(const SplitJobs& jobs, hipStream_t st);   // K % 64 == 0, Nout % 64 == 0, ldw % 4 == 0 per job
+bool gemm_h8_astat_supported(const GemmArgs& g);
+int gemm_h8_astat_launch(const GemmArgs& g, hipStream_t st);
 
 // gemm_general_f32.hip — C[z] = scale * op(A[z]) op(B[z]) (+ bias), per-operand layout flag, two-level batch strides
 struct GemmGeneralArgs {

@@ -244,6 +244,37 @@ def linear_astat_f16(x: Tensor, pro: tuple[Tensor, Tensor] | None, W1: Tensor, b
     return (c1, c2) if c2 is not None else c1
 
 
+def linear_h8_img(x: Tensor, pro: tuple[Tensor, Tensor] | None, W: Tensor, b: Tensor | None, act_alpha: Tensor | None = None,
+                  normalized: bool = True, act: str | int | None = None, wsplit: Tensor | None = None,
+                  image_ready: bool = False, out: Tensor | None = None) -> Tensor:
+    """act((x*pa + po) @ W^T + b) in fp16 + fp8-cross-term arithmetic (mixed mode's mlp.0), returned as the tiled split image
+    (B, rows / 128, Nout / 16, 2, 128, 16) of bf16 bit patterns (int16): hi plane, lo plane; see `decode_split_image`."""
+    lib = _lib.load()
+    B, rows, K = x.shape
+    n = W.shape[0]
+    if out is None:
+        out = torch.empty(B, rows // 128, n // 16, 2, 128, 16, device=x.device, dtype=torch.int16)
+    if wsplit is None:
+        wsplit = _ws(n * K * 4, x.device)
+    check(lib.gecco_linear_h8_img_f32(_ptr(x), _ptr(pro[0]) if pro else None, _ptr(pro[1]) if pro else None,
+                                      None if image_ready else _ptr(W), _ptr(b), _ptr(act_alpha),
+                                      act_code(act_alpha, normalized, act), C.c_void_p(out.data_ptr()), B, rows, K, n,
+                                      C.c_void_p(wsplit.data_ptr()), _stream()), "gecco_linear_h8_img_f32")
+    return out
+
+
+def decode_split_image(img: Tensor) -> Tensor:
+    """(B, rows / 128, Nout / 16, 2, 128, 16) int16 tiled split image -> the (B, rows, Nout) fp32 tensor it represents
+    (hi + lo; GemmArgs::c_img layout: the 8-element half of a row is swapped when (row >> 3) & 1)."""
+    Bn, T, KT = img.shape[:3]
+    f = (img.to(torch.int32) << 16).view(torch.float32)             # bf16 bits -> fp32
+    v = f[:, :, :, 0] + f[:, :, :, 1]                                # (B, T, KT, 128, 16)
+    rows = torch.arange(128, device=img.device)
+    swap = ((rows >> 3) & 1).bool()
+    v = torch.where(swap[None, None, None, :, None], torch.cat([v[..., 8:], v[..., :8]], dim=-1), v)
+    return v.permute(0, 1, 3, 2, 4).reshape(Bn, T * 128, KT * 16)
+
+
 def mlp_fused_f16(x: Tensor, pro: tuple[Tensor, Tensor], W0: Tensor, b0: Tensor | None, W2: Tensor, b2: Tensor | None,
                   act_alpha: Tensor | None = None, normalized: bool = True, want_stats: bool = False,
                   wsplit: Tensor | None = None, image_ready: bool = False, stats: Tensor | None = None):

@@ -95,8 +95,11 @@ int gecco_linear_f32(const float* A, const float* W, const float* bias, const fl
  *   "actimg" (default 1): split-bf16 / mixed modes hand the MLP hidden layer and the unpool attention output to the next
  *   GEMM as tiled split images (bf16 hi | lo planes in 8 KiB blocks, same bytes as the fp32 tensor) which that GEMM loads
  *   global -> registers (gemm_x3_areg.hip): same bits as the fp32 hand-over.
+ *   "h8" (default 1): mixed mode runs mlp.0 as an fp16 main product plus two fp8 cross terms (v_mfma_scale_f32_32x32x64_f8f6f4)
+ *   on the A-stationary 256-row kernel (gemm_h8_astat.hip; needs "actimg", rows % 256 == 0, feature_dim <= 384) instead of as a
+ *   split-bf16 product: 2 instead of 3 matrix-pipe units per product, same accuracy (~6e-5 on F_x).
  * value < 0 returns the option to its default / environment (GECCO_ASTAT, GECCO_CHAIN, GECCO_HEADMAJOR, GECCO_MLPFUSED,
- * GECCO_UNPOOLFUSED, GECCO_LO8, GECCO_ACTIMG).
+ * GECCO_UNPOOLFUSED, GECCO_LO8, GECCO_ACTIMG, GECCO_H8).
  * Process-wide. */
 int gecco_set_option(const char* name, int value);
 
@@ -192,6 +195,15 @@ int gecco_linear_astat_f16(const float* x, const float* pro_a, const float* pro_
                            int Nout1, void* C1, const float* W2, const float* bias2, int Nout2, void* C2,
                            const float* alpha, int act, int B, int rows, int K, int head_dim, void* wsplit,
                            void* stream);
+/* mlp.0 of a BroadcastingLayer's point MLP in the mixed mode (models/set_transformer.py:164-166: the first linear of
+ * `x + mlp(mlp_norm(x))` with the AdaGN apply of models/normalization.py:44 folded in; models/mlp.py:5-39; activation.py:17-24):
+ *   u = act((x*pro_a + pro_o) @ W^T + bias),   product = fp16(y) fp16(W) + fp8(y) fp8(W - fp16(W)) + fp8(y - fp16(y)) fp8(W)
+ * (fp32 accumulate; the cross terms on v_mfma_scale_f32_32x32x64_f8f6f4), written as the TILED SPLIT IMAGE the next linear
+ * (gecco_linear_ex_f32 with a_img) loads into registers: per (sample, 128-row tile, 16-column step) one 8 KiB block — bf16 hi
+ * plane [128][16] (the 16-byte half of a row swapped when (row >> 3) & 1), then the lo plane; c_img: B * rows * Nout * 4 bytes.
+ * rows % 256 == 0, Nout % 64 == 0, K in {128, 256, 384}, act 0 .. 3.  wsplit: Nout * K * 4 bytes; W == NULL: image-ready call. */
+int gecco_linear_h8_img_f32(const float* x, const float* pro_a, const float* pro_o, const float* W, const float* bias,
+                            const float* alpha, int act, void* c_img, int B, int rows, int K, int Nout, void* wsplit, void* stream);
 /* The point-stream MLP of a BroadcastingLayer in one launch (fp16 mode; models/set_transformer.py:165-166 with the
  * AdaGN apply of :164 folded in): x += (GaussianActivation(fp16(x*pro_a + pro_o) @ W0^T + b0)) @ W2^T + b2, in place on
  * the fp32 x (B, rows, C); the 2C-wide hidden layer never leaves the CU.  stats (B, rows / 128, 2, C) or NULL: GroupNorm

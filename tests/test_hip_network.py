@@ -269,12 +269,39 @@ def test_activation_images_are_bit_identical(ops, golden_dir, name, precision):
     net = ops.LinearLiftPlan(_cuda(p), cases.H, cases.I, precision=precision)
     out = {}
     try:
+        ops.set_option("h8", 0)   # mlp.0's h8 form exists only with the image hand-over: compare like with like
         for on in (0, 1):
             ops.set_option("actimg", on)
             out[on] = net.forward(x.cuda(), sigma.cuda()).cpu()
     finally:
         ops.set_option("actimg", -1)
+        ops.set_option("h8", -1)
     assert torch.equal(out[0], out[1])
+
+
+@pytest.mark.parametrize("name", list(cases.UNCOND_CASES))
+def test_mixed_h8_mlp0_matches_split_bf16_mlp0(ops, golden_dir, name):
+    """Mixed mode: mlp.0 as fp16 main product + two fp8 cross terms on the A-stationary kernel (option "h8", gemm_h8_astat.hip)
+    against the split-bf16 product it replaces: both within the bar of the reference's golden output, and close to each other
+    (the two arithmetics differ at ~2^-16 per product); the h8 form must actually have run."""
+    p, x, sigma = cases.uncond_inputs(name)
+    g = np.load(golden_dir / f"{name}.npz")
+    net = ops.LinearLiftPlan(_cuda(p), cases.H, cases.I, precision="mixed")
+    out, raw = {}, {}
+    try:
+        for on in (0, 1):
+            ops.set_option("h8", on)
+            d, r = net.forward(x.cuda(), sigma.cuda(), return_raw=True)
+            out[on], raw[on] = d.cpu(), r.cpu()
+    finally:
+        ops.set_option("h8", -1)
+    for on in (0, 1):
+        eg = cpu_ref.rel_err(out[on], torch.from_numpy(g["denoised"]))
+        assert eg[0] <= 2e-4, (on, eg)
+    e = cpu_ref.rel_err(raw[1], raw[0])
+    assert e[0] <= 2e-4, e
+    if x.shape[1] % 128 == 0 and p["lift.weight"].shape[0] in (128, 256, 384):
+        assert not torch.equal(raw[0], raw[1]), "the h8 form did not run"
 
 
 def test_split_bf16_linear_accuracy(ops):

@@ -321,3 +321,36 @@ def test_lift_lower_edm(ops, B, N, C):
     a, o = ops.adagn_coeffs(st, N, None, None, 16)
     F2 = F.linear(cpu_ref.group_norm_bnc(feat_ref, 16), Wo, bo)
     _close(ops.lower_edm(feat, None, None, Wo.cuda(), bo.cuda(), gn=(a, o)), F2)
+
+
+@pytest.mark.parametrize("B,rows,K,Nout,act", [(2, 512, 384, 768, "gauss"), (1, 256, 256, 512, "relu"), (3, 256, 128, 256, "none"),
+                                               (1, 2048, 384, 768, "gauss")])
+def test_linear_h8_image(ops, B, rows, K, Nout, act):
+    """mlp.0 of the mixed mode (gemm_h8_astat.hip): fp16 main product + the two cross terms on the fp8 matrix instruction,
+    AdaGN prologue, activation, output as the tiled split image — against float64 (models/set_transformer.py:164-166,
+    models/mlp.py).  One-term fp16 operands would sit at ~3e-4 here; the cross terms bring the product to split-bf16 accuracy."""
+    rs = _rs(B * 7 + rows + K + Nout)
+    x, W, b = _t(rs.randn(B, rows, K)), _t(rs.randn(Nout, K) / math.sqrt(K)), _t(rs.randn(Nout) / math.sqrt(K))
+    pa, po = _t(1 + 0.3 * rs.randn(B, K)), _t(0.3 * rs.randn(B, K))
+    alpha = _t(np.array(0.9))
+    u = F.linear((x.double() * pa[:, None].double() + po[:, None].double()), W.double(), b.double())
+    if act == "gauss":
+        ref = (torch.exp(-u * u / (2 * 0.9 ** 2)) - 0.7) / 0.28
+    elif act == "relu":
+        ref = torch.relu(u)
+    else:
+        ref = u
+    kw = dict(act_alpha=alpha.cuda()) if act == "gauss" else dict(act="relu") if act == "relu" else {}
+    img = ops.linear_h8_img(x.cuda(), (pa.cuda(), po.cuda()), W.cuda(), b.cuda(), **kw)
+    got = ops.decode_split_image(img).cpu().double()
+    e = cpu_ref.rel_err(got, ref)
+    assert e[0] < (1e-4 if act == "gauss" else 3e-5), e   # the Gaussian epilogue uses the fast exp (as every kernel here): ~6e-5 max
+    # the pre-activation itself, without prologue / bias: the product's own error
+    img0 = ops.linear_h8_img(x.cuda(), None, W.cuda(), None)
+    e0 = cpu_ref.rel_err(ops.decode_split_image(img0).cpu().double(), F.linear(x.double(), W.double()))
+    assert e0[0] < 2e-5, e0
+    # image-ready call: the same bits from the weight image the first call left in the scratch
+    ws = torch.empty(Nout * K * 4, dtype=torch.uint8, device="cuda")
+    a = ops.linear_h8_img(x.cuda(), (pa.cuda(), po.cuda()), W.cuda(), b.cuda(), wsplit=ws, **kw)
+    c = ops.linear_h8_img(x.cuda(), (pa.cuda(), po.cuda()), W.cuda(), b.cuda(), wsplit=ws, image_ready=True, **kw)
+    assert torch.equal(a, c) and torch.equal(a, img)

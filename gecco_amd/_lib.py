@@ -101,6 +101,7 @@ SIGNATURES = {
     "gecco_gemm_tn_x3_pro_f32": (i, [vp, vp, vp, vp, vp, vp, i, i, i, i, i, vp]),
     "gecco_set_option": (i, [C.c_char_p, i]),
     "gecco_linear_astat_f16": (i, [vp, vp, vp, vp, vp, i, vp, vp, vp, i, vp, vp, i, i, i, i, i, vp, vp]),
+    "gecco_linear_kvq_f16": (i, [vp, vp, vp, vp, vp, i, vp, vp, vp, i, vp, i, i, i, i, i, i, vp, vp]),
     "gecco_linear_h8_img_f32": (i, [vp, vp, vp, vp, vp, vp, i, vp, i, i, i, i, vp, vp]),
     "gecco_affine_cast_f16": (i, [vp, vp, vp, vp, i, i, i, vp]),
     "gecco_pool_attn_f16in": (i, [vp, vp, vp, i, i, i, i, i, i, vp, sz, vp]),

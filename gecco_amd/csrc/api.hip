@@ -186,11 +186,11 @@ int linear_pair(const float* A, const float* W1, const float* b1, int Nout1, flo
 }
 
 // Path switches for A/B runs and tests: gecco_set_option, or the environment (GECCO_ASTAT, GECCO_CHAIN) on first use.
-enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_HEADMAJOR = 2, OPT_MLPFUSED = 3, OPT_UNPOOLFUSED = 4, OPT_LO8 = 5, OPT_ACTIMG = 6, OPT_H8 = 7, OPT_COUNT = 8 };
-int g_options[OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1};
-const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor", "mlpfused", "unpoolfused", "lo8", "actimg", "h8"};
+enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_HEADMAJOR = 2, OPT_MLPFUSED = 3, OPT_UNPOOLFUSED = 4, OPT_LO8 = 5, OPT_ACTIMG = 6, OPT_H8 = 7, OPT_KVQ64 = 8, OPT_COUNT = 9 };
+int g_options[OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};
+const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor", "mlpfused", "unpoolfused", "lo8", "actimg", "h8", "kvq64"};
 const char* const g_option_env[OPT_COUNT] = {"GECCO_ASTAT", "GECCO_CHAIN", "GECCO_HEADMAJOR", "GECCO_MLPFUSED", "GECCO_UNPOOLFUSED", "GECCO_LO8",
-                                             "GECCO_ACTIMG", "GECCO_H8"};
+                                             "GECCO_ACTIMG", "GECCO_H8", "GECCO_KVQ64"};
 int option(int which) {
     if (g_options[which] < 0) {
         const char* e = getenv(g_option_env[which]);
@@ -203,7 +203,19 @@ int option(int which) {
 // Returns 1 when the shape is outside that kernel's reach (caller: cast pass + streaming GEMM), 0 on success.
 int astat_linear(const float* x, const float* pa, const float* po, const float* img, const float* bias1, int Nout1,
                  float* C1, const float* bias2, int Nout2, float* C2, const float* alpha, int act, int B, int rows,
-                 int K, hipStream_t s, int hm_hd = 0, const float* img_lo = nullptr) {
+                 int K, hipStream_t s, int hm_hd = 0, const float* img_lo = nullptr, int use64 = 0) {
+    if (use64) {
+        // mixed mode on the 64-column-tile kernel (gemm_h8_astat.hip: gemm_kvq_astat_kernel): `img` is the kvq stream — Nout1's
+        // tiles, the V half of a K | V pair with its fp8 second weight term (use64 == 2), then Nout2's
+        GemmArgs g{};
+        g.A = x; g.pro_a = pa; g.pro_o = po; g.bias = bias1; g.C = C1;
+        g.B = B; g.rows = rows; g.K = K; g.Nout = Nout1 + Nout2; g.lda = K; g.ldw = K; g.ldc = Nout1; g.ldr = Nout1;
+        g.precision = 2; g.w_img = img; g.c_f16 = 1; g.hm_hd = hm_hd;
+        if (use64 == 2) { g.lo_begin = Nout1 / 128; g.lo_tiles = Nout1 / 64; }
+        if (C2) { g.C2 = C2; g.bias2 = bias2; g.n_split = Nout1; g.ldc2 = Nout2; }
+        if (!img || act || !gemm_kvq_astat_supported(g)) return 1;
+        return gemm_kvq_astat_launch(g, s);
+    }
     GemmArgs g{};
     g.A = x; g.pro_a = pa; g.pro_o = po; g.bias = bias1; g.alpha = alpha; g.act = act; g.C = C1;
     g.B = B; g.rows = rows; g.K = K; g.Nout = Nout1 + Nout2; g.lda = K; g.ldw = K; g.ldc = Nout1; g.ldr = Nout1;
@@ -267,6 +279,10 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         hg.c_img = 1; hg.w_img = w.wimg; hg.rows = N; hg.Nout = Wd; hg.K = C; hg.lda = C; hg.act = act;
         h8_on = gemm_h8_astat_supported(hg) && Wd % 16 == 0 && C % 16 == 0;
     }
+    // mixed mode: kv_proj | q_proj on the 64-column-tile A-stationary kernel (option "kvq64"; two 128-row blocks per CU, W bytes
+    // shared by 128 rows, 16-byte head-major stores); falls back to the 128-column-tile kernel where it does not apply
+    bool kvq_on = false;
+    if (mixed && w.wimg && option(OPT_KVQ64) && option(OPT_HEADMAJOR) && (C == 128 || C == 256 || C == 384 || C == 512) && !((C / H) & 7)) kvq_on = true;
     const bool chain_on = pr == 2 && w.wimg && option(OPT_CHAIN) && inducer_chain_f16_supported(C, Wd, H, G, I) &&
                           (ns == 1 || ns == 2 || ns == 4 || ns == 8);
     if (pr >= 1 && w.wimg && !(C % kmod) && !(Wd % kmod)) {
@@ -291,7 +307,15 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         for (int li = 0; li < st->n_layers; ++li) {
             const GeccoLayer& L = st->layers[li];
             float* base = w.wimg + (size_t)li * w.wimg_layer;
-            if (mixed) {
+            if (mixed && kvq_on) {
+                // the kvq stream: K | V tiles (the V half with L stages), then the q tiles
+                if (!(h_in && h_in[li])) {
+                    if (jobs8.n >= kJobCap) { TRY(h8_image_multi_launch(jobs8, s), "split(kv_proj, kvq)"); jobs8.n = 0; }
+                    jobs8.job[jobs8.n++] = SplitJob{L.kv_proj_w, base, 2 * C, C, C, 1 | ((C / 64) << 8) | ((2 * C / 64) << 20)};
+                }
+                if (jobs8.n >= kJobCap) { TRY(h8_image_multi_launch(jobs8, s), "split(q_proj, kvq)"); jobs8.n = 0; }
+                jobs8.job[jobs8.n++] = SplitJob{L.in_proj_w, base + kvq_image_bytes(2 * C, C, C) / sizeof(float), C, C, C, 1};
+            } else if (mixed) {
                 // fp16 hi images of kv_proj | q_proj back to back (one stream for the A-stationary kernel), then their lo images
                 const size_t hkv = (size_t)(2 * C + 127) / 128 * 128 * C / 2, hq = (size_t)(C + 127) / 128 * 128 * C / 2;
                 for (int lo = 0; lo < 2; ++lo) {
@@ -373,11 +397,11 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
             const int hd_try = option(OPT_HEADMAJOR) ? C / H : 0;
             const float* im_lo = mixed && im ? im + kvq_lo : nullptr;
             int fused = io16 ? astat_linear(x, w.a1, w.o1, (2 * C) % 128 == 0 ? im : nullptr, nullptr, 2 * C, w.big,
-                                            L.in_proj_b, C, w.q, nullptr, 0, B, N, C, s, hd_try, im_lo)
+                                            L.in_proj_b, C, w.q, nullptr, 0, B, N, C, s, hd_try, im_lo, kvq_on ? 2 : 0)
                              : 1;
             if (io16 && fused == 1 && hd_try)   // shape outside the head-major form: row-major
                 fused = astat_linear(x, w.a1, w.o1, (2 * C) % 128 == 0 ? im : nullptr, nullptr, 2 * C, w.big, L.in_proj_b,
-                                     C, w.q, nullptr, 0, B, N, C, s, 0, im_lo);
+                                     C, w.q, nullptr, 0, B, N, C, s, 0, im_lo, kvq_on ? 2 : 0);
             if (mixed && fused != 0) return fail(fused < 0 ? fused : -3, "set_transformer: mixed mode: kv_proj | q_proj outside the A-stationary kernel's reach");
             else if (fused == 0 && hd_try)
                 hm = 1;
@@ -437,13 +461,14 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
             // cached inducer states (upsampling): the layer only needs q — the same one-pass kernel, one segment
             const int hd_try = option(OPT_HEADMAJOR) ? C / H : 0;
             // q's image: after kv_proj's (fp16 mode: o_q floats in; mixed mode: fp16 images inside the 4-byte layout)
-            const float* qim = !im ? nullptr : mixed ? im + (size_t)(2 * C + 127) / 128 * 128 * C / 2 : im + w.o_q;
+            const float* qim = !im ? nullptr : kvq_on ? im + kvq_image_bytes(2 * C, C, C) / sizeof(float)
+                                                      : mixed ? im + (size_t)(2 * C + 127) / 128 * 128 * C / 2 : im + w.o_q;
             const float* qim_lo = nullptr;   // q_proj's weights stay one-term (their rounding does not reach the output)
             int one = astat_linear(x, w.a1, w.o1, qim, L.in_proj_b, C, w.q, nullptr, 0, nullptr,
-                                   nullptr, 0, B, N, C, s, hd_try, qim_lo);
+                                   nullptr, 0, B, N, C, s, hd_try, qim_lo, kvq_on ? 1 : 0);
             if (one == 1 && hd_try)
                 one = astat_linear(x, w.a1, w.o1, qim, L.in_proj_b, C, w.q, nullptr, 0, nullptr, nullptr,
-                                   0, B, N, C, s, 0, qim_lo);
+                                   0, B, N, C, s, 0, qim_lo, kvq_on ? 1 : 0);
             if (mixed && one != 0) return fail(one < 0 ? one : -3, "set_transformer: mixed mode: q projection outside the A-stationary kernel's reach");
             else if (one == 0 && hd_try)
                 hm = 1;
@@ -548,7 +573,7 @@ int gecco_set_option(const char* name, int value) {
             g_options[i] = value < 0 ? -1 : (value != 0);   // < 0: back to the environment / default
             return 0;
         }
-    return fail(-2, "set_option: unknown option '%s' (astat, chain, headmajor, mlpfused, unpoolfused, lo8, actimg, h8)", name);
+    return fail(-2, "set_option: unknown option '%s' (astat, chain, headmajor, mlpfused, unpoolfused, lo8, actimg, h8, kvq64)", name);
 }
 
 int gecco_linear_row_tiles(int rows) { return row_tiles_gemm(rows); }
@@ -727,6 +752,37 @@ int gecco_linear_astat_f16(const float* x, const float* pro_a, const float* pro_
         return fail(-2, "linear_astat: needs rows %% 128 == 0, Nout %% 128 == 0, K in {128, 256, 384, 512}; head-major: "
                         "even head_dim >= 8 dividing both segment widths");
     TRY(gemm_f16_astat_launch(g, s), "linear_astat");
+    return 0;
+}
+
+int gecco_linear_kvq_f16(const float* x, const float* pro_a, const float* pro_o, const float* W1, const float* bias1, int Nout1,
+                         void* C1, const float* W2, const float* bias2, int Nout2, void* C2, int B, int rows, int K, int head_dim,
+                         int lo_begin, int lo_end, void* wsplit, void* stream) {
+    if (!x || !C1 || !wsplit) return fail(-1, "linear_kvq: null argument");
+    if ((pro_a == nullptr) != (pro_o == nullptr)) return fail(-1, "linear_kvq: pro_a/pro_o must both be set");
+    if ((Nout2 > 0) != (C2 != nullptr)) return fail(-1, "linear_kvq: Nout2 and C2 go together");
+    if (head_dim < 0 || lo_begin < 0 || lo_end < lo_begin || lo_end > Nout1 || (lo_begin & 63) || (lo_end & 63) || (Nout1 & 63) || (Nout2 & 63) ||
+        K <= 0 || (K & 127))
+        return fail(-2, "linear_kvq: head_dim >= 0; lo range inside the first segment, multiples of 64; Nout %% 64 == 0; K %% 128 == 0");
+    hipStream_t s = (hipStream_t)stream;
+    float* img = static_cast<float*>(wsplit);
+    GemmArgs g{};
+    g.A = x; g.pro_a = pro_a; g.pro_o = pro_o; g.bias = bias1; g.C = static_cast<float*>(C1);
+    g.B = B; g.rows = rows; g.K = K; g.Nout = Nout1 + Nout2; g.lda = K; g.ldw = K; g.ldc = Nout1; g.ldr = Nout1;
+    g.precision = 2; g.w_img = img; g.c_f16 = 1; g.hm_hd = head_dim; g.lo_begin = lo_begin / 64; g.lo_tiles = lo_end / 64;
+    if (C2) { g.C2 = static_cast<float*>(C2); g.bias2 = bias2; g.n_split = Nout1; g.ldc2 = Nout2; }
+    if (!gemm_kvq_astat_supported(g))
+        return fail(-2, "linear_kvq: needs rows %% 128 == 0, Nout1 + Nout2 >= 128, K in {128, 256, 384, 512}; head-major: head_dim %% 8 == 0 "
+                        "dividing both segment widths");
+    if (W1) {   // NULL: wsplit still holds the stream a previous call made from the same weights
+        if (Nout2 > 0 && !W2) return fail(-1, "linear_kvq: W2 missing");
+        SplitJobs jobs;
+        jobs.n = 0;
+        jobs.job[jobs.n++] = SplitJob{W1, img, Nout1, K, K, 1 | ((lo_begin / 64) << 8) | ((lo_end / 64) << 20)};
+        if (Nout2 > 0) jobs.job[jobs.n++] = SplitJob{W2, img + kvq_image_bytes(Nout1, K, lo_end - lo_begin) / sizeof(float), Nout2, K, K, 1};
+        TRY(h8_image_multi_launch(jobs, s), "linear_kvq(image)");
+    }
+    TRY(gemm_kvq_astat_launch(g, s), "linear_kvq");
     return 0;
 }
 

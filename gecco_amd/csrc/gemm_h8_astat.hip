@@ -154,8 +154,61 @@ __device__ __forceinline__ void h8_image_item(const float* __restrict__ W, float
     *reinterpret_cast<u32x4*>(img + ((cg * 2 + kind) * H_STAGE) + sub * 1024 + n * 16 + pc * 4) = out;
 }
 
+// kv_proj | q_proj stream (gemm_kvq_astat_kernel).  Per 64-column tile ct: the H stages of all NG groups; a tile inside
+// [lo_begin, lo_end) (the V projection) is followed by NG / 2 L stages, each [fp8(2^19 Wl) of group 2 i | of group 2 i + 1] — the
+// two-term weights of the mixed mode where their rounding reaches the output, one-term elsewhere.
+// Stage index of tile ct: ct * NG + (NG / 2) * clamp(ct - lo_begin, 0, lo_end - lo_begin).  1024 chunks per (ct, pair of H stages
+// or L stage): item i -> (tile, stage-in-tile, sub-tile, row, physical chunk).
+__device__ __forceinline__ void kvq_image_item(const float* __restrict__ W, float* __restrict__ img, int Nout, int K, int ldw, int lo_begin,
+                                               int lo_end, size_t i) {
+    const int NG = K / 64;
+    const int pc = (int)(i & 3), n = (int)((i >> 2) & 63), sub = (int)((i >> 8) & 1);
+    const size_t st = i >> 9;                          // stage index in the stream
+    // invert the stage index: tiles before lo_begin have NG stages, inside 3 NG / 2, after NG
+    const int per_lo = NG + NG / 2;
+    const size_t s_lo0 = (size_t)lo_begin * NG, s_lo1 = s_lo0 + (size_t)(lo_end - lo_begin) * per_lo;
+    int ct, kt;
+    if (st < s_lo0) { ct = (int)(st / NG); kt = (int)(st % NG); }
+    else if (st < s_lo1) { ct = lo_begin + (int)((st - s_lo0) / per_lo); kt = (int)((st - s_lo0) % per_lo); }
+    else { ct = lo_end + (int)((st - s_lo1) / NG); kt = (int)((st - s_lo1) % NG); }
+    const int q = pc ^ ((n >> 2) & 3);
+    const int nn = min(ct * H_BN + n, Nout - 1);
+    u32x4 out;
+    if (kt < NG) {
+        const float* src = W + (size_t)nn * ldw + 64 * kt + 32 * sub + 8 * q;
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(src), w1 = *reinterpret_cast<const f32x4*>(src + 4);
+        f16x8 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = (_Float16)w0[e];
+            v[4 + e] = (_Float16)w1[e];
+        }
+        out = __builtin_bit_cast(u32x4, v);
+    } else {
+        const int g = 2 * (kt - NG) + sub, h = q >> 1, t = q & 1;
+        const float* src = W + (size_t)nn * ldw + 64 * g + 32 * t + 16 * h;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(src + 4 * c);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = clamp448((w[e] - (float)(_Float16)w[e]) * WL_SCALE);
+            out[c] = pack_fp8x4(v[0], v[1], v[2], v[3]);
+        }
+    }
+    *reinterpret_cast<u32x4*>(img + st * H_STAGE + sub * 1024 + n * 16 + pc * 4) = out;
+}
+
+// SplitJob::pad_ = 0: the h8 stream of mlp.0; pad_ = 1 | lo_begin << 8 | lo_end << 20 (64-column tiles): the kv | q stream
 __global__ void h8_image_multi_kernel(SplitJobs jobs) {
     const SplitJob j = jobs.job[blockIdx.y];
+    if (j.pad_ & 1) {
+        const int lb = (j.pad_ >> 8) & 0xFFF, le = (j.pad_ >> 20) & 0xFFF, NG = j.K / 64;
+        const size_t total = ((size_t)(j.Nout / H_BN) * NG + (size_t)(le - lb) * (NG / 2)) * 512;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+            kvq_image_item(j.W, j.img, j.Nout, j.K, j.ldw, lb, le, i);
+        return;
+    }
     const size_t total = (size_t)(j.Nout / H_BN) * (j.K / 64) * 1024;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
         h8_image_item(j.W, j.img, j.Nout, j.K, j.ldw, i);
@@ -460,6 +513,289 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_h8_astat_kernel(GemmArgs g) {
     dma::wait_vm_lgkm0<0>();   // the re-fetched tail stages still target this block's LDS: land them before it is released
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// kv_proj | q_proj of the mixed mode on the same structure (reference: models/set_transformer.py:49-52, 65-70 — `kv_proj`, the
+// `q` rows of nn.MultiheadAttention's in_proj — over y = AdaGN(x), normalization.py:36-44):
+//   C1 (K | V) and C2 (q) = fp16( fp16(y) Wh^T [+ fp8(y) Wl^T for the V columns] + bias ),  head-major or row-major fp16 outputs.
+// The A operand is yh alone (96 registers at K = 384; its rounding does not reach the output, section 5 of DESIGN.md), the W
+// stream is kvq_image_item's.  Tiles have NG stages (K, q) or 3 NG / 2 (V), so the ring slot is a running counter (scalar
+// arithmetic; the fragment addresses take one vector add per sub-step).  Epilogue: fp16 pairs, one v_permlane32_swap per
+// register pair, 16-byte stores (8 consecutive columns of one row = one piece of a head's (rows, hd) slab).
+template <int NG, int NS>
+__global__ __launch_bounds__(256, 2) void gemm_kvq_astat_kernel(GemmArgs g) {
+    constexpr int K = 64 * NG, NT = 256, NW = 4, ROWS = 128, PW = 2, KV_STORES = 4;
+    static_assert(NS >= 4 && NG % 2 == 0 && NS - 2 <= NG, "lookahead NS - 1 >= 3 stages; L stages hold two groups; one epilogue's stores in flight");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* ring = smem;                                // [NS][H_STAGE]
+    float* stg = ring + NS * H_STAGE;                  // [NW][1024] wave-private staging: [32][64] fp16
+    float* bias_lds = stg + NW * 1024;                 // [Nout] (zeros where a segment has no bias)
+    float* pro_lds = bias_lds + g.Nout;                // pa | po
+
+    const int tilesM = g.rows / ROWS, tilesN = g.Nout / H_BN;
+    const int b = blockIdx.x / tilesM, rt = blockIdx.x % tilesM, m0 = rt * ROWS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int lo_begin = g.lo_begin, lo_end = g.lo_tiles;   // 64-column tiles with L stages
+    HSTAMP(0);
+
+    for (int n = tid; n < g.Nout; n += NT) {
+        const bool seg2 = g.C2 != nullptr && n >= g.n_split;
+        const float* bp = seg2 ? g.bias2 : g.bias;
+        bias_lds[n] = bp ? bp[seg2 ? n - g.n_split : n] : 0.f;
+    }
+    {
+        const bool has_pro = g.pro_a != nullptr;
+        const float* pa = has_pro ? g.pro_a + (size_t)b * K : nullptr;
+        const float* po = has_pro ? g.pro_o + (size_t)b * K : nullptr;
+        for (int i = tid; i < K; i += NT) {
+            pro_lds[i] = has_pro ? pa[i] : 1.f;
+            pro_lds[K + i] = has_pro ? po[i] : 0.f;
+        }
+    }
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.w_img), 0, 0x7fffffff, 0x00020000);
+    const unsigned voff = (unsigned)(wave * PW * 256 + lane * 4) * 4u;
+    const int n_stages = tilesN * NG + (lo_end - lo_begin) * (NG / 2);
+    const unsigned soff_last = (unsigned)(n_stages - 1) * (H_STAGE * 4u);
+    unsigned soff = 0;
+    int islot = 0;                                     // slot of the next stage to issue
+    auto issue = [&]() {
+#ifndef H8_DIAG_NODMA
+#pragma unroll
+        for (int p = 0; p < PW; ++p)
+            dma16_buf(wrsrc, voff + p * 1024u, soff, ring + islot * H_STAGE + (wave * PW + p) * 256);
+#endif
+        soff = soff < soff_last ? soff + H_STAGE * 4u : soff_last;
+        islot = islot + 1 == NS ? 0 : islot + 1;
+    };
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p) issue();
+
+    f16x8 fa[2 * NG][2];
+    {
+        const float* xw = g.A + ((size_t)b * g.rows + m0 + wave * 32) * g.lda;
+        char* sw = reinterpret_cast<char*>(stg + wave * 1024);
+        const int lrow = lane >> 4, c16 = lane & 15;
+        f32x4 xs[2][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xs[0][i] = *reinterpret_cast<const f32x4*>(xw + (size_t)(4 * i + lrow) * g.lda + 4 * c16);
+        static_for(std::make_integer_sequence<int, NG>{}, [&](auto S) {
+            constexpr int s = decltype(S)::value;
+            if constexpr (s + 1 < NG) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    xs[(s + 1) & 1][i] = *reinterpret_cast<const f32x4*>(xw + (size_t)(4 * i + lrow) * g.lda + 64 * (s + 1) + 4 * c16);
+            }
+            const f32x4 pa4 = *reinterpret_cast<const f32x4*>(pro_lds + 64 * s + 4 * c16);
+            const f32x4 po4 = *reinterpret_cast<const f32x4*>(pro_lds + K + 64 * s + 4 * c16);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = 4 * i + lrow;
+                f16x4 hv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hv[e] = (_Float16)__builtin_fmaf(xs[s & 1][i][e], pa4[e], po4[e]);
+                *reinterpret_cast<u32x2*>(sw + row * 128 + (((c16 >> 1) ^ (row & 7)) << 4) + (c16 & 1) * 8) = __builtin_bit_cast(u32x2, hv);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int cq = 4 * t + 2 * h + c;
+                    fa[2 * s + t][c] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(sw + r * 128 + ((cq ^ (r & 7)) << 4)));
+                }
+            __builtin_amdgcn_wave_barrier();
+        });
+    }
+
+    // fragment addressing: rows r and 32 + r of a sub-tile share the swizzle ((32 + r) >> 2 & 3 == r >> 2 & 3): two lane offsets
+    // (c = 0, 1), the second 32-column block 2 KiB further
+    int boffc[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) boffc[c] = r * 16 + (((2 * h + c) ^ ((r >> 2) & 3)) << 2);
+    i32x8 fbA[2], fbB[2];
+    auto load_f = [&](const float* sub, i32x8(&f)[2]) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float* pc = sub + boffc[c];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(pc + j * 512);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f[j][4 * c + e] = (int)v[e];
+            }
+        }
+    };
+
+    const int mrow = m0 + wave * 32 + r;
+    const unsigned hm_magic = g.hm_hd ? (1u << 20) / (unsigned)g.hm_hd + 1u : 0u;
+    f32x16 acc[2];
+    auto epilogue = [&](int ct) {
+        const int n0 = ct * H_BN;
+        const bool seg2 = g.C2 != nullptr && n0 >= g.n_split;
+        _Float16* Cb = reinterpret_cast<_Float16*>(seg2 ? g.C2 : g.C);
+        const int ldc = seg2 ? g.ldc2 : g.ldc;
+        const int nseg0 = seg2 ? n0 - g.n_split : n0;
+        const int nseg = seg2 ? g.Nout - g.n_split : (g.C2 ? g.n_split : g.Nout);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            unsigned pk[4][2];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bs = *reinterpret_cast<const f32x4*>(bias_lds + n0 + 32 * j + 8 * q + 4 * h);
+                f16x2 a, c;
+                a[0] = (_Float16)(acc[j][4 * q + 0] + bs[0]);
+                a[1] = (_Float16)(acc[j][4 * q + 1] + bs[1]);
+                c[0] = (_Float16)(acc[j][4 * q + 2] + bs[2]);
+                c[1] = (_Float16)(acc[j][4 * q + 3] + bs[3]);
+                pk[q][0] = __builtin_bit_cast(unsigned, a);
+                pk[q][1] = __builtin_bit_cast(unsigned, c);
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                u32x4 O;
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const auto sh = __builtin_amdgcn_permlane32_swap(pk[2 * p][d], pk[2 * p + 1][d], false, false);
+                    O[d] = sh[0];
+                    O[2 + d] = sh[1];
+                }
+                const int nb = nseg0 + 32 * j + 16 * p + 8 * h;   // first of this lane's 8 columns, inside its segment
+                _Float16* dst;
+                if (g.hm_hd) {
+                    const int grp = (int)(((unsigned)nb * hm_magic) >> 20);   // nb / hd (exact: nb < 2^20 / hd)
+                    dst = Cb + ((size_t)(b * (nseg / g.hm_hd) + grp) * g.rows + mrow) * g.hm_hd + (nb - grp * g.hm_hd);
+                } else {
+                    dst = Cb + ((size_t)b * g.rows + mrow) * ldc + nb;
+                }
+#ifdef H8_DIAG_NOSTORE
+                asm volatile("" ::"v"(O), "v"(dst));
+#else
+#ifdef KVQ_NT_STORE
+                GECCO_NT_STORE(O, reinterpret_cast<u32x4*>(dst));
+#else
+                *reinterpret_cast<u32x4*>(dst) = O;   // default policy: the attention kernels read K | V and q next
+#endif
+#endif
+            }
+        }
+    };
+
+    HSTAMP(1);
+    dma::wait_vm_lgkm0<0>();
+    __builtin_amdgcn_s_barrier();
+    int slot = 0;                                      // slot of the current stage
+    load_f(ring, fbA);
+    float one = 1.0f;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // one stage: wait / barrier / issue, two sub-steps.  LST: an L stage (two groups' Wl); G2: its first group (L) or the group (H)
+    auto stage = [&](auto KT, auto LST, auto G2, bool first) {
+        constexpr int kt = decltype(KT)::value, gq = decltype(G2)::value;
+        constexpr bool lst = decltype(LST)::value;
+        constexpr int young = (NS - 3) * PW;
+        constexpr bool st_young = kt <= NS - 3;
+        if (st_young && !first) dma::wait_vm_lgkm0<young + KV_STORES>();
+        else dma::wait_vm_lgkm0<young>();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(fbA[j]));
+        __builtin_amdgcn_s_barrier();
+        issue();
+        const float* cur = ring + slot * H_STAGE;
+        slot = slot + 1 == NS ? 0 : slot + 1;
+        const float* nxt = ring + slot * H_STAGE;
+        load_f(cur + 1024, fbB);
+        if constexpr (!lst) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const i32x4 wc = c == 0 ? __builtin_shufflevector(fbA[j], fbA[j], 0, 1, 2, 3) : __builtin_shufflevector(fbA[j], fbA[j], 4, 5, 6, 7);
+                    acc[j] = H8_MFMA16(__builtin_bit_cast(f16x8, wc), fa[2 * gq][c], (kt == 0 && c == 0) ? zero16 : acc[j]);
+                }
+        } else {
+            i32x8 a8;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const f16x8 v = fa[2 * gq + t][c];
+                    s16x2 p0 = {0, 0}, p1 = {0, 0};
+                    p0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(p0, f16x2{v[0], v[1]}, one, false);
+                    p0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(p0, f16x2{v[2], v[3]}, one, true);
+                    p1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(p1, f16x2{v[4], v[5]}, one, false);
+                    p1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(p1, f16x2{v[6], v[7]}, one, true);
+                    a8[4 * t + 2 * c] = __builtin_bit_cast(int, p0);
+                    a8[4 * t + 2 * c + 1] = __builtin_bit_cast(int, p1);
+                }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[j] = H8_MFMA8(fbA[j], a8, acc[j], 127 - 19, 127);
+        }
+        load_f(nxt, fbA);
+        if constexpr (!lst) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const i32x4 wc = c == 0 ? __builtin_shufflevector(fbB[j], fbB[j], 0, 1, 2, 3) : __builtin_shufflevector(fbB[j], fbB[j], 4, 5, 6, 7);
+                    acc[j] = H8_MFMA16(__builtin_bit_cast(f16x8, wc), fa[2 * gq + 1][c], acc[j]);
+                }
+        } else {
+            i32x8 a8;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const f16x8 v = fa[2 * (gq + 1) + t][c];
+                    s16x2 p0 = {0, 0}, p1 = {0, 0};
+                    p0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(p0, f16x2{v[0], v[1]}, one, false);
+                    p0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(p0, f16x2{v[2], v[3]}, one, true);
+                    p1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(p1, f16x2{v[4], v[5]}, one, false);
+                    p1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(p1, f16x2{v[6], v[7]}, one, true);
+                    a8[4 * t + 2 * c] = __builtin_bit_cast(int, p0);
+                    a8[4 * t + 2 * c + 1] = __builtin_bit_cast(int, p1);
+                }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[j] = H8_MFMA8(fbB[j], a8, acc[j], 127 - 19, 127);
+        }
+    };
+    for (int ct = 0; ct < tilesN; ++ct) {
+        const bool first = ct == 0;
+        const bool has_lo = ct >= lo_begin && ct < lo_end;
+        asm volatile("" : "+s"(one));
+        static_for(std::make_integer_sequence<int, NG>{}, [&](auto KT) {
+            stage(KT, std::false_type{}, KT, first);
+        });
+        if (has_lo) {
+            static_for(std::make_integer_sequence<int, NG / 2>{}, [&](auto LT) {
+                constexpr int lt = decltype(LT)::value;
+                stage(std::integral_constant<int, NG + lt>{}, std::true_type{}, std::integral_constant<int, 2 * lt>{}, first);
+            });
+        }
+#ifndef H8_DIAG_NOEPI
+        epilogue(ct);
+#endif
+    }
+    HSTAMP(2);
+#ifdef H8_DIAG_NOEPI
+    if (acc[0][0] == 123.456f) epilogue(0);
+#endif
+    dma::wait_vm_lgkm0<0>();
+}
+
+template <int NG, int NS>
+int kvq_launch_t(const GemmArgs& g, hipStream_t st) {
+    const size_t lds = ((size_t)NS * H_STAGE + 4 * 1024 + g.Nout + 2 * g.K) * sizeof(float);
+    static size_t attr = 0;
+    if (lds > attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kvq_astat_kernel<NG, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = lds;
+    }
+    hipLaunchKernelGGL((gemm_kvq_astat_kernel<NG, NS>), dim3(g.B * (g.rows / 128)), dim3(256), lds, st, g);
+    return (int)hipGetLastError();
+}
+
 constexpr int h8_ns(int NG, int NW) { return NW == 8 ? 2 * NG : (NG % 3 == 0 ? 6 : 4); }   // NW = 4: 48 / 32 KiB rings, two blocks per CU
 
 template <int NG, int NW, int ACT>
@@ -508,6 +844,34 @@ bool gemm_h8_astat_supported(const GemmArgs& g) {
     return g.c_img && !g.a_img && !g.a_f16 && !g.c_f16 && !g.residual && !g.stats && !g.C2 && g.w_img && g.rows >= 128 &&
            !(g.rows % 128) && !(g.Nout % H_BN) && g.Nout >= 2 * H_BN && g.Nout <= 4096 && (g.K == 128 || g.K == 256 || g.K == 384) &&
            !(g.lda & 3) && ((g.pro_a == nullptr) == (g.pro_o == nullptr)) && !g.mul_u && !g.pre_out && g.act >= 0 && g.act <= 3;
+}
+
+// kv_proj | q_proj stream: bytes of the image of one job (Nout columns, `lo_cols` of them with L stages)
+size_t kvq_image_bytes(int Nout, int K, int lo_cols) { return ((size_t)(Nout / H_BN) * (K / 64) + (size_t)(lo_cols / H_BN) * (K / 128)) * H_STAGE * 4; }
+
+// fp16 outputs (one or two segments, row- or head-major), 128-row blocks, 64-column tiles; lo_begin / lo_tiles in 64-column tiles
+bool gemm_kvq_astat_supported(const GemmArgs& g) {
+    return g.c_f16 && !g.a_f16 && !g.a_img && !g.c_img && !g.residual && !g.stats && g.w_img && !g.act && g.rows >= 128 && !(g.rows % 128) &&
+           !(g.Nout % H_BN) && g.Nout >= 2 * H_BN && g.Nout <= 4096 && (g.K == 128 || g.K == 256 || g.K == 384 || g.K == 512) && !(g.lda & 3) && !(g.ldc & 7) &&
+           (!g.C2 || (!(g.n_split % H_BN) && !(g.ldc2 & 7) && g.n_split > 0 && g.n_split < g.Nout)) &&
+           ((g.pro_a == nullptr) == (g.pro_o == nullptr)) && g.lo_begin >= 0 && g.lo_tiles >= g.lo_begin && g.lo_tiles <= g.Nout / H_BN &&
+           (!g.hm_hd || (g.hm_hd >= 8 && !(g.hm_hd & 7) && g.Nout < (1 << 20) / g.hm_hd && !((g.C2 ? g.n_split : g.Nout) % g.hm_hd) &&
+                         !((g.C2 ? g.Nout - g.n_split : 0) % g.hm_hd)));
+}
+
+int gemm_kvq_astat_launch(const GemmArgs& g, hipStream_t st) {
+    if (!gemm_kvq_astat_supported(g)) return -9;
+    switch (g.K) {
+        case 128: return kvq_launch_t<2, 4>(g, st);   // NS - 2 <= stages of the shortest tile: the wait counts assume one epilogue in flight
+        case 256: return kvq_launch_t<4, 6>(g, st);
+#ifdef KVQ_NS
+        case 384: return kvq_launch_t<6, KVQ_NS>(g, st);
+#else
+        case 384: return kvq_launch_t<6, 6>(g, st);
+#endif
+        case 512: return kvq_launch_t<8, 6>(g, st);   // d = 512: 128 registers of A fragments, no scratch
+        default: return -9;
+    }
 }
 
 // GECCO_H8_WAVES = 8: one 256-row block of 8 waves per CU (rows % 256 == 0) instead of two 128-row blocks of 4;

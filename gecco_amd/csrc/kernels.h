@@ -157,6 +157,11 @@ int gemm_f16_astat_launch(const GemmArgs& g, hipStream_t st);
 size_t h8_image_bytes(int Nout, int K);   // Nout * K * 4 (Nout % 64 == 0)
 int h8_image_multi_launch(const SplitJobs& jobs, hipStream_t st);   // K % 64 == 0, Nout % 64 == 0, ldw % 4 == 0 per job
 bool gemm_h8_astat_supported(const GemmArgs& g);
+// kv_proj | q_proj of the mixed mode on the same structure: fp16 outputs, w_img = the stream of kvq image jobs (SplitJob::pad_ =
+// 1 | lo_begin << 8 | lo_end << 20, 64-column tiles with a second fp8 weight term); GemmArgs::lo_begin / lo_tiles in 64-column tiles
+size_t kvq_image_bytes(int Nout, int K, int lo_cols);
+bool gemm_kvq_astat_supported(const GemmArgs& g);
+int gemm_kvq_astat_launch(const GemmArgs& g, hipStream_t st);
 int gemm_h8_astat_launch(const GemmArgs& g, hipStream_t st);
 
 // gemm_general_f32.hip — C[z] = scale * op(A[z]) op(B[z]) (+ bias), per-operand layout flag, two-level batch strides

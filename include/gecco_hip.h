@@ -98,8 +98,10 @@ int gecco_linear_f32(const float* A, const float* W, const float* bias, const fl
  *   "h8" (default 1): mixed mode runs mlp.0 as an fp16 main product plus two fp8 cross terms (v_mfma_scale_f32_32x32x64_f8f6f4)
  *   on the A-stationary 256-row kernel (gemm_h8_astat.hip; needs "actimg", rows % 256 == 0, feature_dim <= 384) instead of as a
  *   split-bf16 product: 2 instead of 3 matrix-pipe units per product, same accuracy (~6e-5 on F_x).
+ *   "kvq64" (default 1): mixed mode runs kv_proj | q_proj on the 64-column-tile A-stationary kernel (gecco_linear_kvq_f16; needs
+ *   "headmajor") instead of the 128-column-tile one (gecco_linear_astat_f16 + lo image): same arithmetic, also at feature_dim 512.
  * value < 0 returns the option to its default / environment (GECCO_ASTAT, GECCO_CHAIN, GECCO_HEADMAJOR, GECCO_MLPFUSED,
- * GECCO_UNPOOLFUSED, GECCO_LO8, GECCO_ACTIMG, GECCO_H8).
+ * GECCO_UNPOOLFUSED, GECCO_LO8, GECCO_ACTIMG, GECCO_H8, GECCO_KVQ64).
  * Process-wide. */
 int gecco_set_option(const char* name, int value);
 
@@ -195,6 +197,17 @@ int gecco_linear_astat_f16(const float* x, const float* pro_a, const float* pro_
                            int Nout1, void* C1, const float* W2, const float* bias2, int Nout2, void* C2,
                            const float* alpha, int act, int B, int rows, int K, int head_dim, void* wsplit,
                            void* stream);
+/* kv_proj | q_proj of the mixed mode (models/set_transformer.py:49-52 `kv_proj`, :65-70 the q rows of nn.MultiheadAttention's
+ * in_proj, both over AdaGN(x), models/normalization.py:36-44) on the 64-column-tile A-stationary kernel:
+ *   C1 (B, rows, Nout1) | C2 (B, rows, Nout2) = fp16( fp16(x*pro_a + pro_o) @ fp16(W)^T + bias ),  fp32 accumulate,
+ * where the columns [lo_begin, lo_end) of the first segment (the V projection) add the second weight term
+ * fp8(y) @ fp8(2^19 (W - fp16(W)))^T on v_mfma_scale_f32_32x32x64_f8f6f4 (two-term weights: their rounding is the part of this
+ * product's error that reaches the output).  head_dim > 0: head-major outputs as gecco_linear_astat_f16.
+ * rows % 128 == 0, Nout1, Nout2, lo_begin, lo_end % 64 == 0, K in {128, 256, 384, 512}, head_dim % 8 == 0.
+ * wsplit: (Nout1 + Nout2) * K * 2 + (lo_end - lo_begin) * K bytes; W1 == NULL: image-ready call.  Option "kvq64". */
+int gecco_linear_kvq_f16(const float* x, const float* pro_a, const float* pro_o, const float* W1, const float* bias1, int Nout1,
+                         void* C1, const float* W2, const float* bias2, int Nout2, void* C2, int B, int rows, int K, int head_dim,
+                         int lo_begin, int lo_end, void* wsplit, void* stream);
 /* mlp.0 of a BroadcastingLayer's point MLP in the mixed mode (models/set_transformer.py:164-166: the first linear of
  * `x + mlp(mlp_norm(x))` with the AdaGN apply of models/normalization.py:44 folded in; models/mlp.py:5-39; activation.py:17-24):
  *   u = act((x*pro_a + pro_o) @ W^T + bias),   product = fp16(y) fp16(W) + fp8(y) fp8(W - fp16(W)) + fp8(y - fp16(y)) fp8(W)

@@ -244,13 +244,20 @@ def test_mixed_fp8_lo_term_matches_fp16_lo_term(ops, golden_dir, name):
     net = ops.LinearLiftPlan(_cuda(p), cases.H, cases.I, precision="mixed")
     out = {}
     try:
+        ops.set_option("kvq64", 0)   # "lo8" chooses the form of the lo term of the 128-column-tile kernel
         for on in (0, 1):
             ops.set_option("lo8", on)
             out[on] = net.forward(x.cuda(), sigma.cuda()).cpu()
+        ops.set_option("kvq64", 1)   # the 64-column-tile kernel (default): fp8 lo term as well
+        out[2] = net.forward(x.cuda(), sigma.cuda()).cpu()
     finally:
         ops.set_option("lo8", -1)
+        ops.set_option("kvq64", -1)
     e = cpu_ref.rel_err(out[1], out[0])
     assert e[0] <= 3e-5, e
+    e2 = cpu_ref.rel_err(out[2], out[0])
+    assert e2[0] <= 3e-5, e2
+    assert cpu_ref.rel_err(out[2], torch.from_numpy(g["denoised"]))[0] <= 2e-4
     for on in (0, 1):
         eg = cpu_ref.rel_err(out[on], torch.from_numpy(g["denoised"]))
         assert eg[0] <= 2e-4, (on, eg)

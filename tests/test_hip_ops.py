@@ -354,3 +354,39 @@ def test_linear_h8_image(ops, B, rows, K, Nout, act):
     a = ops.linear_h8_img(x.cuda(), (pa.cuda(), po.cuda()), W.cuda(), b.cuda(), wsplit=ws, **kw)
     c = ops.linear_h8_img(x.cuda(), (pa.cuda(), po.cuda()), W.cuda(), b.cuda(), wsplit=ws, image_ready=True, **kw)
     assert torch.equal(a, c) and torch.equal(a, img)
+
+
+@pytest.mark.parametrize("B,rows,K,hd", [(2, 256, 384, 48), (1, 128, 128, 16), (2, 384, 256, 32), (1, 256, 512, 64), (2, 256, 384, 0)])
+def test_linear_kvq_f16(ops, B, rows, K, hd):
+    """kv_proj | q_proj of the mixed mode on the 64-column-tile kernel (gemm_kvq_astat_kernel): fp16(y) x fp16(W) everywhere, the V
+    columns with the fp8 second weight term; head-major and row-major outputs; against float64 on the SAME rounded operands
+    (so the bar is fp32 accumulation + the fp16 rounding of the result), and the V columns measurably closer to the
+    unrounded-weight product than one-term weights are (models/set_transformer.py:49-52, 65-70)."""
+    rs = _rs(B + rows + K + hd)
+    C = K
+    x = _t(rs.randn(B, rows, K))
+    pa, po = _t(1 + 0.3 * rs.randn(B, K)), _t(0.3 * rs.randn(B, K))
+    Wkv, Wq, bq = _t(rs.randn(2 * C, K) / math.sqrt(K)), _t(rs.randn(C, K) / math.sqrt(K)), _t(rs.randn(C) / math.sqrt(K))
+    y16 = (x * pa[:, None] + po[:, None]).half().double()          # the kernel's A operand: one fma, one rounding
+    kv, q = ops.linear_kvq_f16(x.cuda(), (pa.cuda(), po.cuda()), Wkv.cuda(), None, Wq.cuda(), bq.cuda(), lo=(C, 2 * C), head_dim=hd)
+    if hd:
+        kv = kv.permute(0, 2, 1, 3).reshape(B, rows, 2 * C)        # "b g n d -> b n (g d)"
+        q = q.permute(0, 2, 1, 3).reshape(B, rows, C)
+    kv, q = kv.cpu().double(), q.cpu().double()
+    Wh = Wkv.half().double()
+    ref_k = y16 @ Wh[:C].T
+    ref_q = y16 @ Wq.half().double().T + bq.double()
+    ref_v2 = y16 @ Wkv[C:].double().T                              # two-term weights ~ the unrounded weights
+    ref_v1 = y16 @ Wh[C:].T
+    tol = 2.0 ** -10                                               # fp16 result rounding (relative to the value) + accumulation
+    assert cpu_ref.rel_err(kv[..., :C], ref_k)[0] < tol
+    assert cpu_ref.rel_err(q, ref_q)[0] < tol
+    # compare before the output rounding hides it: mean absolute distance to the two candidates
+    d2, d1 = (kv[..., C:] - ref_v2).abs().mean(), (kv[..., C:] - ref_v1).abs().mean()
+    assert cpu_ref.rel_err(kv[..., C:], ref_v2)[0] < tol and d2 <= d1, (d2, d1)
+    # one segment only (the cached evaluation's q projection), image-ready second call: same bits
+    ws = torch.empty(C * K * 2, dtype=torch.uint8, device="cuda")
+    a = ops.linear_kvq_f16(x.cuda(), (pa.cuda(), po.cuda()), Wq.cuda(), bq.cuda(), head_dim=hd, wsplit=ws)
+    c = ops.linear_kvq_f16(x.cuda(), (pa.cuda(), po.cuda()), Wq.cuda(), bq.cuda(), head_dim=hd, wsplit=ws, image_ready=True)
+    qq = a.permute(0, 2, 1, 3).reshape(B, rows, C) if hd else a
+    assert torch.equal(a, c) and cpu_ref.rel_err(qq.cpu().double(), ref_q)[0] < tol

@@ -52,3 +52,19 @@ t_x3 = timed(lambda: ops.linear(x, W1, b1, (pa, po), act_alpha=alpha, out=hid, p
 fl = 2 * B * N * D * 2 * D
 print(f"h8  mlp.0: {t_h8:7.1f} us  {fl / t_h8 / 1e6:6.1f} TFLOP/s of 2MNK")
 print(f"x3  mlp.0: {t_x3:7.1f} us  {fl / t_x3 / 1e6:6.1f} TFLOP/s of 2MNK (LDS-DMA kernel, fp32 output, weight split included)")
+
+# kv_proj | q_proj: the 64-column-tile kernel against the 128-column-tile A-stationary kernel (one-term form; the mixed mode's
+# lo image is built inside the network entry point only)
+H = 8
+Wkv, Wq, bq = rn(2 * D, D) / 20, rn(D, D) / 20, rn(D) / 20
+ws2 = torch.empty(3 * D * D * 2 + D * D, dtype=torch.uint8, device=dev)
+ops.linear_kvq_f16(x, (pa, po), Wkv, None, Wq, bq, lo=(D, 2 * D), head_dim=D // H, wsplit=ws2)
+t_kvq = timed(lambda: ops.linear_kvq_f16(x, (pa, po), Wkv, None, Wq, bq, lo=(D, 2 * D), head_dim=D // H, wsplit=ws2, image_ready=True))
+t_kvq1 = timed(lambda: ops.linear_kvq_f16(x, (pa, po), Wkv, None, Wq, bq, lo=(0, 0), head_dim=D // H, wsplit=ws2, image_ready=False))
+ws3 = torch.empty(3 * D * D * 4, dtype=torch.uint8, device=dev)
+kv16 = torch.empty(B, 2 * H, N, D // H, device=dev, dtype=torch.float16)
+q16 = torch.empty(B, H, N, D // H, device=dev, dtype=torch.float16)
+ops.linear_astat_f16(x, (pa, po), Wkv, None, Wq, bq, out=(kv16, q16), head_dim=D // H, wsplit=ws3)
+t_as = timed(lambda: ops.linear_astat_f16(x, (pa, po), Wkv, None, Wq, bq, out=(kv16, q16), head_dim=D // H, wsplit=ws3, image_ready=True))
+fl = 2 * B * N * D * 3 * D
+print(f"kvq64 (V two-term): {t_kvq:7.1f} us   kvq64 one-term (+ image build): {t_kvq1:7.1f} us   astat128 one-term: {t_as:7.1f} us   ({fl / t_kvq / 1e6:.0f} TFLOP/s of 2MNK; 502 MB -> {502e6 / t_kvq / 1e6:.2f} TB/s)")

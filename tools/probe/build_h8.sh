@@ -1,9 +1,15 @@
 #!/bin/bash
-# builds the diagnostic variants of the h8 kernel probe (cross-compiles without a GPU)
+# builds the diagnostic variants of the h8 / kvq kernel probes (cross-compiles without a GPU)
 cd "$(dirname "$0")"
 F="--offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-function -Wno-unused-result"
-/opt/rocm/bin/hipcc $F -DH8_STAMPS h8_probe.hip -o h8_BASE &
-/opt/rocm/bin/hipcc $F -DH8_STAMPS -DH8_PRIO h8_probe.hip -o h8_PRIO &
-for v in NOMFMA NODMA NOACT NOSTORE NOEPI; do /opt/rocm/bin/hipcc $F -DH8_STAMPS -DH8_DIAG_$v h8_probe.hip -o h8_$v & done
+for P in h8 kvq; do
+/opt/rocm/bin/hipcc $F -DH8_STAMPS ${P}_probe.hip -o ${P}_BASE &
+for v in NOMFMA NODMA NOSTORE NOEPI; do /opt/rocm/bin/hipcc $F -DH8_STAMPS -DH8_DIAG_$v ${P}_probe.hip -o ${P}_$v & done
+done
+/opt/rocm/bin/hipcc $F -DH8_STAMPS -DH8_DIAG_NOACT h8_probe.hip -o h8_NOACT &
+/opt/rocm/bin/hipcc $F -DH8_STAMPS -DKVQ_NS=4 kvq_probe.hip -o kvq_NS4 &
+/opt/rocm/bin/hipcc $F -DH8_STAMPS -DKVQ_NS=8 kvq_probe.hip -o kvq_NS8 &
+/opt/rocm/bin/hipcc $F -DH8_STAMPS -DKVQ_NS=4 -DH8_DIAG_NOSTORE kvq_probe.hip -o kvq_NS4_NOSTORE &
+/opt/rocm/bin/hipcc $F -DH8_STAMPS -DKVQ_NS=8 -DH8_DIAG_NOSTORE kvq_probe.hip -o kvq_NS8_NOSTORE &
 wait
-ls -la h8_*
+ls h8_* kvq_*

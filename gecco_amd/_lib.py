@@ -102,7 +102,8 @@ SIGNATURES = {
     "gecco_set_option": (i, [C.c_char_p, i]),
     "gecco_linear_astat_f16": (i, [vp, vp, vp, vp, vp, i, vp, vp, vp, i, vp, vp, i, i, i, i, i, vp, vp]),
     "gecco_linear_kvq_f16": (i, [vp, vp, vp, vp, vp, i, vp, vp, vp, i, vp, i, i, i, i, i, i, vp, vp]),
-    "gecco_linear_h8_img_f32": (i, [vp, vp, vp, vp, vp, vp, i, vp, i, i, i, i, vp, vp]),
+    "gecco_linear_h8_img_f32": (i, [vp, vp, vp, vp, vp, vp, i, vp, i, i, i, i, i, vp, vp]),
+    "gecco_linear_h8_areg_f32": (i, [vp, vp, vp, vp, vp, vp, i, i, i, i, vp, vp]),
     "gecco_affine_cast_f16": (i, [vp, vp, vp, vp, i, i, i, vp]),
     "gecco_pool_attn_f16in": (i, [vp, vp, vp, i, i, i, i, i, i, vp, sz, vp]),
     "gecco_unpool_attn_f16io": (i, [vp, vp, vp, i, i, i, i, i, i, vp]),

@@ -186,11 +186,11 @@ int linear_pair(const float* A, const float* W1, const float* b1, int Nout1, flo
 }
 
 // Path switches for A/B runs and tests: gecco_set_option, or the environment (GECCO_ASTAT, GECCO_CHAIN) on first use.
-enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_HEADMAJOR = 2, OPT_MLPFUSED = 3, OPT_UNPOOLFUSED = 4, OPT_LO8 = 5, OPT_ACTIMG = 6, OPT_H8 = 7, OPT_KVQ64 = 8, OPT_COUNT = 9 };
-int g_options[OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};
-const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor", "mlpfused", "unpoolfused", "lo8", "actimg", "h8", "kvq64"};
+enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_HEADMAJOR = 2, OPT_MLPFUSED = 3, OPT_UNPOOLFUSED = 4, OPT_LO8 = 5, OPT_ACTIMG = 6, OPT_H8 = 7, OPT_KVQ64 = 8, OPT_H8AREG = 9, OPT_COUNT = 10 };
+int g_options[OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor", "mlpfused", "unpoolfused", "lo8", "actimg", "h8", "kvq64", "h8areg"};
 const char* const g_option_env[OPT_COUNT] = {"GECCO_ASTAT", "GECCO_CHAIN", "GECCO_HEADMAJOR", "GECCO_MLPFUSED", "GECCO_UNPOOLFUSED", "GECCO_LO8",
-                                             "GECCO_ACTIMG", "GECCO_H8", "GECCO_KVQ64"};
+                                             "GECCO_ACTIMG", "GECCO_H8", "GECCO_KVQ64", "GECCO_H8AREG"};
 int option(int which) {
     if (g_options[which] < 0) {
         const char* e = getenv(g_option_env[which]);
@@ -229,6 +229,16 @@ int astat_linear(const float* x, const float* pa, const float* po, const float* 
     // option "astat" = 0 falls back to the cast pass + streaming GEMM (A/B runs; same bits)
     if (!option(OPT_ASTAT) || !img || !gemm_f16_astat_supported(g)) return 1;
     return gemm_f16_astat_launch(g, s);
+}
+
+// mixed mode: C = residual + A W^T + bias (+ statistics) with A an h8 activation image and W the 128-column-tile h8 stream
+// (gemm_h8_areg.hip): mlp.2 and out_proj
+int h8_linear(const float* a_img, const float* w_img, const float* bias, const float* res, float* C, float* stats, int B, int rows,
+              int K, int Nout, hipStream_t s) {
+    GemmArgs g{};
+    g.A = a_img; g.bias = bias; g.residual = res; g.C = C; g.stats = stats; g.B = B; g.rows = rows; g.K = K; g.Nout = Nout;
+    g.lda = K; g.ldw = K; g.ldc = Nout; g.ldr = Nout; g.a_img = 2; g.w_img = w_img; g.precision = 1;
+    return gemm_h8_areg_launch(g, s);
 }
 
 int coeffs(const float* stats, int T, int rows, const float* t, int ctx, const GeccoAdaGN* p, float* a, float* o,
@@ -283,6 +293,18 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
     // shared by 128 rows, 16-byte head-major stores); falls back to the 128-column-tile kernel where it does not apply
     bool kvq_on = false;
     if (mixed && w.wimg && option(OPT_KVQ64) && option(OPT_HEADMAJOR) && (C == 128 || C == 256 || C == 384 || C == 512) && !((C / H) & 7)) kvq_on = true;
+    // ... and mlp.2 / out_proj as h8 products fed from h8 activation images (gemm_h8_areg.hip; option "h8areg")
+    bool h8x = false, h8o = false;
+    if (h8_on && option(OPT_H8AREG) && Wd % 64 == 0) {
+        GemmArgs hg{};
+        hg.a_img = 2; hg.w_img = w.wimg; hg.rows = N; hg.Nout = C; hg.K = Wd; hg.lda = Wd; hg.ldc = C; hg.ldr = C;
+        h8x = gemm_h8_areg_supported(hg);
+    }
+    if (mixed && w.wimg && option(OPT_H8AREG) && option(OPT_ACTIMG) && I == 64 && C % 64 == 0 && attn_x3_supported(C / H)) {
+        GemmArgs hg{};
+        hg.a_img = 2; hg.w_img = w.wimg; hg.rows = N; hg.Nout = C; hg.K = C; hg.lda = C; hg.ldc = C; hg.ldr = C;
+        h8o = gemm_h8_areg_supported(hg);
+    }
     const bool chain_on = pr == 2 && w.wimg && option(OPT_CHAIN) && inducer_chain_f16_supported(C, Wd, H, G, I) &&
                           (ns == 1 || ns == 2 || ns == 4 || ns == 8);
     if (pr >= 1 && w.wimg && !(C % kmod) && !(Wd % kmod)) {
@@ -345,7 +367,12 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
             }
             TRY(push(L.in_proj_w + (size_t)C * C, base + w.o_ukv, 2 * C, C), "split(unpool.in_proj kv)");
             if (!mixed) TRY(push(L.in_proj_w, base + w.o_q, C, C), "split(q_proj)");
-            TRY(push(L.unpool_out_w, base + w.o_out, C, C), "split(out_proj)");
+            if (h8o) {
+                if (jobs8.n >= kJobCap) { TRY(h8_image_multi_launch(jobs8, s), "split(out_proj, h8)"); jobs8.n = 0; }
+                jobs8.job[jobs8.n++] = SplitJob{L.unpool_out_w, base + w.o_out, C, C, C, 2};
+            } else {
+                TRY(push(L.unpool_out_w, base + w.o_out, C, C), "split(out_proj)");
+            }
             if (mlpf_on) {   // one stream in consumption order: per hidden chunk j, W0 tile j, then W2[:, chunk j] in two K-halves
                 const int nkb = C / 32;
                 for (int jc = 0; jc < Wd / 128; ++jc) {
@@ -362,7 +389,12 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
                 } else {
                     TRY(push(L.mlp.w0, base + w.o_w0, Wd, C), "split(mlp.0)");
                 }
-                TRY(push(L.mlp.w2, base + w.o_w2, C, Wd), "split(mlp.2)");
+                if (h8x) {
+                    if (jobs8.n >= kJobCap) { TRY(h8_image_multi_launch(jobs8, s), "split(mlp.2, h8)"); jobs8.n = 0; }
+                    jobs8.job[jobs8.n++] = SplitJob{L.mlp.w2, base + w.o_w2, C, Wd, Wd, 2};
+                } else {
+                    TRY(push(L.mlp.w2, base + w.o_w2, C, Wd), "split(mlp.2)");
+                }
             }
         }
         TRY(pr == 2 ? split_f16_tiled_multi_launch(jobs, s) : split_bf16_tiled_multi_launch(jobs, s), "split(weights)");
@@ -494,7 +526,11 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
             // a tiled split image where out_proj can load it straight into registers (gemm_x3_areg.hip)
             const int aimg = pr == 1 && !a16 && im && option(OPT_ACTIMG) && I == 64 && attn_x3_supported(C / H) && N >= 128 &&
                              N % 128 == 0 && C % 64 == 0;
-            TRY(unpool_attn_launch(w.q, w.kvh, w.attn, B, N, C, H, I, s, apr, mixed ? 2 : (int)io16, hm, aimg), "unpool_attn");
+            const bool o8 = h8o && aimg && im && N % 128 == 0;
+            TRY(unpool_attn_launch(w.q, w.kvh, w.attn, B, N, C, H, I, s, apr, mixed ? 2 : (int)io16, hm, o8 ? 2 : aimg), "unpool_attn");
+            if (o8)
+                TRY(h8_linear(w.attn, im + w.o_out, L.unpool_out_b, x, x, w.stats_x, B, N, C, C, s), "unpool.out_proj+residual (h8)");
+            else
             TRY(linear(w.attn, L.unpool_out_w, L.unpool_out_b, nullptr, nullptr, nullptr, x, x, w.stats_x, B, N, C, C, 0, s, pr,
                        w.wsplit, im ? im + w.o_out : nullptr, a16, 0, aimg, 0), "unpool.out_proj+residual");
         }
@@ -521,10 +557,16 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         if (m0_done == 1 && h8_on && himg && im) {
             GemmArgs hg{};
             hg.A = x; hg.pro_a = w.a2; hg.pro_o = w.o2; hg.bias = L.mlp.b0; hg.alpha = L.mlp.alpha; hg.act = act; hg.C = w.big;
-            hg.B = B; hg.rows = N; hg.K = C; hg.Nout = Wd; hg.lda = C; hg.ldw = C; hg.ldc = Wd; hg.c_img = 1; hg.w_img = im + w.o_w0;
+            hg.B = B; hg.rows = N; hg.K = C; hg.Nout = Wd; hg.lda = C; hg.ldw = C; hg.ldc = Wd; hg.c_img = h8x ? 2 : 1; hg.w_img = im + w.o_w0;
             if ((act == 1 || act == 2) && !L.mlp.alpha) return fail(-6, "mlp.0: GaussianActivation needs alpha");
             TRY(gemm_h8_astat_launch(hg, s), "mlp.0 (h8)");
             m0_done = 0;
+            if (h8x) {
+                TRY(h8_linear(w.big, im + w.o_w2, L.mlp.b2, x, x, so, B, N, Wd, C, s), "mlp.2+residual (h8)");
+                sx = w.stats_x;
+                sT = Tn;
+                continue;
+            }
         }
         if (m0_done == 1) {
         if (a16) TRY(affine_cast_f16_launch(x, w.a2, w.o2, w.attn, B, N, C, s), "mlp_norm -> fp16");
@@ -573,7 +615,7 @@ int gecco_set_option(const char* name, int value) {
             g_options[i] = value < 0 ? -1 : (value != 0);   // < 0: back to the environment / default
             return 0;
         }
-    return fail(-2, "set_option: unknown option '%s' (astat, chain, headmajor, mlpfused, unpoolfused, lo8, actimg, h8, kvq64)", name);
+    return fail(-2, "set_option: unknown option '%s' (astat, chain, headmajor, mlpfused, unpoolfused, lo8, actimg, h8, kvq64, h8areg)", name);
 }
 
 int gecco_linear_row_tiles(int rows) { return row_tiles_gemm(rows); }
@@ -787,14 +829,16 @@ int gecco_linear_kvq_f16(const float* x, const float* pro_a, const float* pro_o,
 }
 
 int gecco_linear_h8_img_f32(const float* x, const float* pro_a, const float* pro_o, const float* W, const float* bias,
-                            const float* alpha, int act, void* c_img, int B, int rows, int K, int Nout, void* wsplit, void* stream) {
+                            const float* alpha, int act, void* c_img, int image_kind, int B, int rows, int K, int Nout, void* wsplit,
+                            void* stream) {
     if (!x || !c_img || !wsplit) return fail(-1, "linear_h8_img: null argument");
+    if (image_kind != 1 && image_kind != 2) return fail(-2, "linear_h8_img: image_kind must be 1 (tiled split image) or 2 (h8 activation image)");
     if ((pro_a == nullptr) != (pro_o == nullptr)) return fail(-1, "linear_h8_img: pro_a/pro_o must both be set");
     if ((act == 1 || act == 2) && !alpha) return fail(-6, "linear_h8_img: GaussianActivation needs alpha");
     hipStream_t s = (hipStream_t)stream;
     GemmArgs g{};
     g.A = x; g.pro_a = pro_a; g.pro_o = pro_o; g.bias = bias; g.alpha = alpha; g.act = act; g.C = static_cast<float*>(c_img);
-    g.B = B; g.rows = rows; g.K = K; g.Nout = Nout; g.lda = K; g.ldw = K; g.ldc = Nout; g.c_img = 1; g.w_img = wsplit;
+    g.B = B; g.rows = rows; g.K = K; g.Nout = Nout; g.lda = K; g.ldw = K; g.ldc = Nout; g.c_img = image_kind; g.w_img = wsplit;
     if (!gemm_h8_astat_supported(g))
         return fail(-2, "linear_h8_img: needs rows %% 256 == 0, Nout %% 64 == 0, Nout >= 128, K in {128, 256, 384}, act in 0 .. 3");
     if (W) {   // NULL: wsplit still holds the image a previous call made from the same weights
@@ -804,6 +848,25 @@ int gecco_linear_h8_img_f32(const float* x, const float* pro_a, const float* pro
         TRY(h8_image_multi_launch(jobs, s), "linear_h8_img(image)");
     }
     TRY(gemm_h8_astat_launch(g, s), "linear_h8_img");
+    return 0;
+}
+
+int gecco_linear_h8_areg_f32(const void* a_img, const float* W, const float* bias, const float* residual, float* C, float* stats,
+                             int B, int rows, int K, int Nout, void* wsplit, void* stream) {
+    if (!a_img || !C || !wsplit) return fail(-1, "linear_h8_areg: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    GemmArgs g{};
+    g.A = static_cast<const float*>(a_img); g.bias = bias; g.residual = residual; g.C = C; g.stats = stats;
+    g.B = B; g.rows = rows; g.K = K; g.Nout = Nout; g.lda = K; g.ldw = K; g.ldc = Nout; g.ldr = Nout; g.a_img = 2; g.w_img = wsplit; g.precision = 1;
+    if (!gemm_h8_areg_supported(g))
+        return fail(-2, "linear_h8_areg: needs rows %% 128 == 0, K in {128, 256, 384, 512, 768, 1024}, Nout %% 4 == 0");
+    if (W) {   // NULL: wsplit still holds the image a previous call made from the same weights
+        SplitJobs jobs;
+        jobs.n = 1;
+        jobs.job[0] = SplitJob{W, static_cast<float*>(wsplit), Nout, K, K, 2};
+        TRY(h8_image_multi_launch(jobs, s), "linear_h8_areg(image)");
+    }
+    TRY(gemm_h8_areg_launch(g, s), "linear_h8_areg");
     return 0;
 }
 

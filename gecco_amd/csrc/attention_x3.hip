@@ -556,6 +556,39 @@ __global__ __launch_bounds__(256, 2) void unpool_attn_x3_kernel(const float* __r
                     *reinterpret_cast<u32x4*>(dst + 2048) = lo;
                 }
             }
+        } else if (out32 == 3) {
+            // the output as the h8 activation image an h8 out_proj loads straight into registers (GemmArgs::a_img == 2,
+            // gemm_h8_areg.hip): per (sample, 128-row tile, 64-k group) 6144 floats — fp16 hi fragments [32-row tile][sub][c][lane],
+            // then fp8(2^14 lo) halves [32-row tile][t][lane]; a row's 8 columns are one 16-byte hi chunk and 8 lo bytes
+            const int t128 = (N + 127) >> 7, ngk = C >> 6;
+#pragma unroll
+            for (int ld = 0; ld < LD8; ++ld) {
+                const int f = ld * 64 + lane, row = f / CH8, c8 = f % CH8, n = q0 + row;
+                if (f < 32 * CH8 && n < N) {
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(Ot + row * OP + c8 * 8);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(Ot + row * OP + c8 * 8 + 4);
+                    f16x8 hv;
+                    float lo[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        hv[e] = (_Float16)v0[e];       // v0 / v1 come from LDS: one fp32 value for the hi rounding and the lo difference
+                        hv[4 + e] = (_Float16)v1[e];
+                        lo[e] = __builtin_fminf(__builtin_fmaxf((v0[e] - (float)hv[e]) * 16384.f, -448.f), 448.f);
+                        lo[4 + e] = __builtin_fminf(__builtin_fmaxf((v1[e] - (float)hv[4 + e]) * 16384.f, -448.f), 448.f);
+                    }
+                    int p0 = 0, p1 = 0;
+                    p0 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[0], lo[1], p0, false);
+                    p0 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[2], lo[3], p0, true);
+                    p1 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[4], lo[5], p1, false);
+                    p1 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[6], lo[7], p1, true);
+                    const int col = hh * HD + c8 * 8, kk = col & 63, ml = n & 127, rt = ml >> 5, rr = ml & 31;
+                    const int sub = kk >> 5, hhalf = (kk >> 4) & 1, cc = (kk >> 3) & 1;
+                    float* blk = out + (((size_t)b * t128 + (n >> 7)) * ngk + (col >> 6)) * 6144;
+                    *reinterpret_cast<u32x4*>(blk + rt * 1024 + (2 * sub + cc) * 256 + (32 * hhalf + rr) * 4) = __builtin_bit_cast(u32x4, hv);
+                    typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+                    *reinterpret_cast<u32x2_*>(blk + 4096 + rt * 512 + sub * 256 + (32 * hhalf + rr) * 4 + 2 * cc) = u32x2_{(unsigned)p0, (unsigned)p1};
+                }
+            }
         } else if (IO16 && !out32) {
 #pragma unroll
             for (int ld = 0; ld < LD8; ++ld) {
@@ -649,14 +682,14 @@ int unpool_attn_x3_launch(const float* q, const float* kvh, float* out, int B, i
                           int precision, int io16, int hm, int out_img) {
     if (io16 && precision != 2) return -9;
     if (hm && !io16) return -9;
-    if (out_img && (C % 16 || (io16 && io16 != 2))) return -9;
+    if (out_img && (C % 16 || (out_img == 2 && C % 64) || (io16 && io16 != 2))) return -9;
     // io16 = 2: q is an fp16 tensor, the output stays fp32 (operand of a split-bf16 out_proj); out_img: as a tiled split image
-    const int out32 = out_img ? 2 : io16 == 2;
+    const int out32 = out_img == 2 ? 3 : out_img ? 2 : io16 == 2;   // out_img 2: h8 activation image (gemm_h8_areg.hip)
 #define UNPOOL_CASE(HD)                                                                                \
     case HD:                                                                                           \
         return io16 ? unpool_x3_launch_t<HD, true, true>(q, kvh, out, B, N, C, H, st, hm, out32)       \
                : precision == 2 ? unpool_x3_launch_t<HD, true, false>(q, kvh, out, B, N, C, H, st, 0)  \
-                                : unpool_x3_launch_t<HD, false, false>(q, kvh, out, B, N, C, H, st, 0, out_img ? 2 : 0)
+                                : unpool_x3_launch_t<HD, false, false>(q, kvh, out, B, N, C, H, st, 0, out_img == 2 ? 3 : out_img ? 2 : 0)
     switch (C / H) {
         UNPOOL_CASE(16);
         UNPOOL_CASE(32);

@@ -1,0 +1,235 @@
+// Linear layer in "fp16 + fp8 cross terms" arithmetic (h8) whose A operand arrives as an h8 ACTIVATION IMAGE written by its
+// producer's epilogue and goes global -> REGISTERS, gfx950:
+//
+//   C[b, m, n] = residual[b, m, n] + sum_k A[b, m, k] * W[n, k] + bias[n]          (+ GroupNorm partials of C)
+//
+// the second linear of the point MLP and the unpool attention's out_proj in the mixed mode (reference:
+// models/set_transformer.py:112,164-166; models/mlp.py:5-39).  Same contract, block tile (128 x 128, 4 x 1 waves of 32 x 128)
+// and epilogue as gemm_x3_areg.hip, whose split-bf16 product (3 matrix instructions per 16 k, 4 bytes per operand element) it
+// replaces by
+//
+//       A W = Ah Wh (v_mfma_f32_32x32x16_f16) + fp8(Ah) fp8(2^19 Wl) + fp8(2^14 Al) fp8(2^8 W)   (v_mfma_scale_f32_32x32x64_f8f6f4)
+//
+// — 2 matrix-pipe units per product and 3 bytes per element, at split-bf16 accuracy (tools/experiments/fp16_site_sensitivity.py,
+// scheme h8: 6.0e-5 on F_x against 6.7e-5).  A = Ah + Al with Ah = fp16(A), Al kept as fp8(2^14 (A - Ah)).
+//
+// Activation image (GemmArgs::a_img == 2; written by gemm_h8_astat.hip's epilogue and by the unpool attention kernel): per
+// (sample, 128-row tile, 64-k group) one 24 KiB block:
+//   hi, 16 KiB: [32-row tile rt][sub][c][lane] x 16 bytes = the 8 fp16 of row 32 rt + (lane & 31), k = 32 sub + 16 (lane >> 5) + 8 c + 0 .. 7
+//               — the MFMA A fragment of k-step (sub, c), 1 KiB of consecutive bytes per wave-instruction;
+//   lo,  8 KiB: [rt][t][lane] x 16 bytes = the 16 fp8 of the same row, k = 32 t + 16 (lane >> 5) + 0 .. 15 — one half of the scaled
+//               MFMA's 32-byte A operand.
+// W image: h8_image_item<128> (gemm_h8_astat.hip): per (128-column tile, 64-k group) a 16 KiB H stage (two [128][32] fp16
+// sub-tiles) and a 16 KiB L stage (fp8 Wl | fp8 W), streamed through a ring of NS stages by global_load_lds; the A fragments
+// of group g + D are loaded when group g's registers are free.  The K loop is fully unrolled: every wait is a compile-time
+// count (young_at below).
+#include "gemm_dma_common.h"
+
+#include <utility>
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+using dma::DBN;
+using dma::DNT;
+using dma::D_EPI;
+using dma::dma16;
+
+constexpr int G_STAGE = 4096;   // floats per 16 KiB W stage: two [128][16 floats] sub-tiles
+constexpr int A_BLK = 6144;     // floats per (128-row tile, 64-k group) block of the activation image
+constexpr int PW = 4;           // 1 KiB W pieces per wave and stage
+constexpr int AL = 6;           // A loads per lane and group: 4 hi + 2 lo
+
+template <int... I, class F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+
+// Vector-memory operations issued after the youngest one step t needs, up to (not including) step t's own issues — what
+// s_waitcnt vmcnt may leave in flight.  Steps t = 2 g (H stage of group g) and 2 g + 1 (L stage).  Issue order: prologue
+// P_0 .. P_{NS-2}, A_0 .. A_{D-1}; step u: P_{u+NS-1} (while it exists), and at the end of an L step A_{g+D} (while it exists).
+// Step t needs P_{t+1} (the barrier then makes every wave's pieces of the next stage visible) and, at an H step, A_{t/2}.
+constexpr int young_at(int t, int NGK, int NS, int D) {
+    const int nst = 2 * NGK;
+    int total = 0, need_end = 0;
+    auto mark_p = [&](int s) { if (s == t + 1) need_end = total; };
+    auto mark_a = [&](int gq) { if ((t & 1) == 0 && gq == t / 2) need_end = total; };
+    for (int s = 0; s < NS - 1 && s < nst; ++s) { total += PW; mark_p(s); }
+    for (int gq = 0; gq < D && gq < NGK; ++gq) { total += AL; mark_a(gq); }
+    for (int u = 0; u < t; ++u) {
+        if (u + NS - 1 < nst) { total += PW; mark_p(u + NS - 1); }
+        if ((u & 1) && (u - 1) / 2 + D < NGK) { total += AL; mark_a((u - 1) / 2 + D); }
+    }
+    return total - need_end;
+}
+
+template <int NGK, int NS, int D>
+__global__ __launch_bounds__(DNT, 2) void gemm_h8_areg_kernel(GemmArgs g) {
+    static_assert(NS >= 3 && D >= 1 && D <= NGK, "ring / lookahead");
+    constexpr int NST = 2 * NGK;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const dma::Tile T = dma::tile_of_block<128>(g);
+    const int ct = T.ct, b = T.b, m0 = T.m0;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+
+    const float* wimg = static_cast<const float*>(g.w_img) + (size_t)ct * NST * G_STAGE + wave * 256 + lane * 4;
+    auto issue_w = [&](int s) {
+        float* st = smem + (s % NS) * G_STAGE + wave * 256;
+#pragma unroll
+        for (int p = 0; p < PW; ++p) dma16(wimg + (size_t)s * G_STAGE + p * 1024, st + p * 1024);
+    };
+    // this wave's 32 rows = 32-row tile `wave` of the 128-row tile: its lane's 16 bytes of fragment (sub, c) of group 0
+    const int t128 = g.rows >> 7;
+    const u32x4* asrc = reinterpret_cast<const u32x4*>(g.A + ((size_t)b * t128 + (m0 >> 7)) * NGK * A_BLK + wave * 1024 + lane * 4);
+    const u32x4* asrc_lo = reinterpret_cast<const u32x4*>(g.A + ((size_t)b * t128 + (m0 >> 7)) * NGK * A_BLK + 4096 + wave * 512 + lane * 4);
+    u32x4 ahi[D][4], alo[D][2];
+    auto load_a = [&](int gq, int set) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ahi[set][i] = asrc[(size_t)gq * (A_BLK / 4) + i * 64];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) alo[set][i] = asrc_lo[(size_t)gq * (A_BLK / 4) + i * 64];
+    };
+
+    static_for(std::make_integer_sequence<int, (NS - 1 < NST ? NS - 1 : NST)>{}, [&](auto P) { issue_w(decltype(P)::value); });
+    static_for(std::make_integer_sequence<int, D>{}, [&](auto P) { load_a(decltype(P)::value, decltype(P)::value); });
+
+    f32x16 acc[1][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[0][j][e] = 0.f;
+
+    // W fragments: rows r, 32 + r, .. of a sub-tile share the swizzle — two lane offsets (c = 0, 1), column block j 2 KiB further
+    int boffc[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) boffc[c] = r * 16 + (((2 * h + c) ^ ((r >> 2) & 3)) << 2);
+    i32x8 fbA[4], fbB[4];
+    auto load_f = [&](const float* sub, i32x8(&f)[4]) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(sub + boffc[c] + j * 512);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f[j][4 * c + e] = (int)v[e];
+            }
+    };
+
+    dma::wait_vm<young_at(0, NGK, NS, D) + AL * 0>();   // stage 0 (own pieces) and the younger ones' allowance: see young_at
+    // step 0 needs P_1 and A_0; the fragments of stage 0 itself need P_0 of every wave: older than both
+    __builtin_amdgcn_s_barrier();
+    load_f(smem, fbA);
+    float one = 1.0f;
+    asm volatile("" : "+s"(one));
+
+    static_for(std::make_integer_sequence<int, NST>{}, [&](auto TT) {
+        constexpr int t = decltype(TT)::value, gq = t >> 1, set = gq % D;
+        constexpr bool lst = (t & 1) != 0;
+        dma::wait_vm_lgkm0<young_at(t, NGK, NS, D)>();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(fbA[j]));
+        __builtin_amdgcn_s_barrier();
+        // stage t + NS - 1 reuses the slot of stage t - 1, whose last fragment reads (this step's first set) are complete
+        if constexpr (t + NS - 1 < NST) issue_w(t + NS - 1);
+        const float* cur = smem + (t % NS) * G_STAGE;
+        load_f(cur + 2048, fbB);
+        if constexpr (!lst) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const i32x4 wc = c == 0 ? __builtin_shufflevector(fbA[j], fbA[j], 0, 1, 2, 3) : __builtin_shufflevector(fbA[j], fbA[j], 4, 5, 6, 7);
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ahi[set][c]), __builtin_bit_cast(f16x8, wc), acc[0][j], 0, 0, 0);
+                }
+        } else {
+            // Ah Wl: fp8(Ah) of the group, bytes in the image's k order (16 t + 8 c + e)
+            i32x8 a8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f16x8 v = __builtin_bit_cast(f16x8, ahi[set][i]);
+                s16x2 p0 = {0, 0}, p1 = {0, 0};
+                p0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(p0, f16x2{v[0], v[1]}, one, false);
+                p0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(p0, f16x2{v[2], v[3]}, one, true);
+                p1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(p1, f16x2{v[4], v[5]}, one, false);
+                p1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(p1, f16x2{v[6], v[7]}, one, true);
+                a8[2 * i] = __builtin_bit_cast(int, p0);
+                a8[2 * i + 1] = __builtin_bit_cast(int, p1);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[0][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, fbA[j], acc[0][j], 0, 0, 0, 127, 0, 127 - 19);
+        }
+        if constexpr (t + 1 < NST) load_f(smem + ((t + 1) % NS) * G_STAGE, fbA);
+        if constexpr (!lst) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const i32x4 wc = c == 0 ? __builtin_shufflevector(fbB[j], fbB[j], 0, 1, 2, 3) : __builtin_shufflevector(fbB[j], fbB[j], 4, 5, 6, 7);
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ahi[set][2 + c]), __builtin_bit_cast(f16x8, wc), acc[0][j], 0, 0, 0);
+                }
+        } else {
+            // Al W
+            i32x8 al8;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                al8[e] = (int)alo[set][0][e];
+                al8[4 + e] = (int)alo[set][1][e];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[0][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(al8, fbB[j], acc[0][j], 0, 0, 0, 127 - 14, 0, 127 - 8);
+            // this group's A registers are free once its matrix instructions are issued: the loads of group gq + D
+            if constexpr (gq + D < NGK) load_a(gq + D, set);
+        }
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // ring is dead: the epilogue reuses it
+    dma::epilogue<1, 4, 4>(g, T, acc, smem, wave, lane, wave, 0);
+}
+
+template <int NGK>
+int h8_areg_launch_t(const GemmArgs& g, hipStream_t st) {
+    constexpr int NS = 4, D = NGK >= 3 ? 3 : NGK;
+    const int tilesM = g.rows / 128, tilesN = (g.Nout + DBN - 1) / DBN;
+    constexpr size_t ring = (size_t)NS * G_STAGE, epi = (size_t)D_EPI;
+    const size_t lds = (ring > epi ? ring : epi) * sizeof(float);
+    static size_t attr = 0;
+    if (lds > attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h8_areg_kernel<NGK, NS, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = lds;
+    }
+    hipLaunchKernelGGL((gemm_h8_areg_kernel<NGK, NS, D>), dim3(g.B * tilesM * tilesN), dim3(DNT), lds, st, g);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+size_t h8_w128_image_bytes(int Nout, int K) { return (size_t)((Nout + 127) / 128) * 128 * K * 4; }
+
+bool gemm_h8_areg_supported(const GemmArgs& g) {
+    return g.a_img == 2 && g.w_img && !g.pro_a && !g.C2 && !g.c_img && !g.a_f16 && !g.c_f16 && !g.mul_u && !g.pre_out && g.rows >= 128 &&
+           g.rows % 128 == 0 && (g.K == 128 || g.K == 256 || g.K == 384 || g.K == 512 || g.K == 768 || g.K == 1024) && !(g.Nout & 3) &&
+           !(g.ldc & 3) && !(g.ldr & 3);
+}
+
+int gemm_h8_areg_launch(const GemmArgs& g, hipStream_t st) {
+    if (!gemm_h8_areg_supported(g)) return -9;
+    switch (g.K) {
+        case 128: return h8_areg_launch_t<2>(g, st);
+        case 256: return h8_areg_launch_t<4>(g, st);
+        case 384: return h8_areg_launch_t<6>(g, st);
+        case 512: return h8_areg_launch_t<8>(g, st);
+        case 768: return h8_areg_launch_t<12>(g, st);
+        case 1024: return h8_areg_launch_t<16>(g, st);
+        default: return -9;
+    }
+}

@@ -119,13 +119,15 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
 //               holds k = 64 g + 32 t + 16 h + 0 .. 15 — the order in which a lane half h packs its fp16 fragments of two
 //               k-steps (t) into the fp8 operand; physical chunk as above.
 // One thread per 16-byte chunk: 1024 chunks per (ct, g).
+template <int BN>
 __device__ __forceinline__ void h8_image_item(const float* __restrict__ W, float* __restrict__ img, int Nout, int K, int ldw, size_t i) {
+    constexpr int LB = BN == 64 ? 6 : 7;               // log2(BN); a stage is 2 sub-tiles of [BN][16 floats]
     const int NG = K / 64;
-    const int pc = (int)(i & 3), n = (int)((i >> 2) & 63), sub = (int)((i >> 8) & 1), kind = (int)((i >> 9) & 1);
-    const size_t cg = i >> 10;
+    const int pc = (int)(i & 3), n = (int)((i >> 2) & (BN - 1)), sub = (int)((i >> (2 + LB)) & 1), kind = (int)((i >> (3 + LB)) & 1);
+    const size_t cg = i >> (4 + LB);
     const int g = (int)(cg % NG), ct = (int)(cg / NG);
     const int q = pc ^ ((n >> 2) & 3);
-    const int nn = min(ct * H_BN + n, Nout - 1);
+    const int nn = min(ct * BN + n, Nout - 1);
     u32x4 out;
     if (kind == 0) {
         const float* src = W + (size_t)nn * ldw + 64 * g + 32 * sub + 8 * q;
@@ -150,8 +152,8 @@ __device__ __forceinline__ void h8_image_item(const float* __restrict__ W, float
             out[c] = pack_fp8x4(v[0], v[1], v[2], v[3]);
         }
     }
-    // stage base: ((ct * NG + g) * 2 + kind) * 2048 floats; sub-tile: + 1024 floats; row n: 16 floats; chunk: 4 floats
-    *reinterpret_cast<u32x4*>(img + ((cg * 2 + kind) * H_STAGE) + sub * 1024 + n * 16 + pc * 4) = out;
+    // stage base: ((ct * NG + g) * 2 + kind) * 2 BN * 16 floats; sub-tile: + BN * 16 floats; row n: 16 floats; chunk: 4 floats
+    *reinterpret_cast<u32x4*>(img + ((cg * 2 + kind) * (2 * BN * 16)) + sub * (BN * 16) + n * 16 + pc * 4) = out;
 }
 
 // kv_proj | q_proj stream (gemm_kvq_astat_kernel).  Per 64-column tile ct: the H stages of all NG groups; a tile inside
@@ -199,7 +201,8 @@ __device__ __forceinline__ void kvq_image_item(const float* __restrict__ W, floa
     *reinterpret_cast<u32x4*>(img + st * H_STAGE + sub * 1024 + n * 16 + pc * 4) = out;
 }
 
-// SplitJob::pad_ = 0: the h8 stream of mlp.0; pad_ = 1 | lo_begin << 8 | lo_end << 20 (64-column tiles): the kv | q stream
+// SplitJob::pad_ = 0: the h8 stream of mlp.0 (64-column tiles); 2: the same in 128-column tiles (gemm_h8_areg.hip);
+// pad_ = 1 | lo_begin << 8 | lo_end << 20 (64-column tiles): the kv | q stream
 __global__ void h8_image_multi_kernel(SplitJobs jobs) {
     const SplitJob j = jobs.job[blockIdx.y];
     if (j.pad_ & 1) {
@@ -209,18 +212,26 @@ __global__ void h8_image_multi_kernel(SplitJobs jobs) {
             kvq_image_item(j.W, j.img, j.Nout, j.K, j.ldw, lb, le, i);
         return;
     }
+    if (j.pad_ & 2) {   // 128-column tiles (gemm_h8_areg.hip); Nout padded up to whole tiles (the pad rows repeat the last row)
+        const size_t total = (size_t)((j.Nout + 127) / 128) * (j.K / 64) * 2048;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+            h8_image_item<128>(j.W, j.img, j.Nout, j.K, j.ldw, i);
+        return;
+    }
     const size_t total = (size_t)(j.Nout / H_BN) * (j.K / 64) * 1024;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
-        h8_image_item(j.W, j.img, j.Nout, j.K, j.ldw, i);
+        h8_image_item<64>(j.W, j.img, j.Nout, j.K, j.ldw, i);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // NG = K / 64; NW = waves per block (rows = 32 NW); NS ring slots with (2 NG) % NS == 0, so the slot of a stage is its position
 // in the column tile mod NS — static.  ACT: the epilogue's activation is a template parameter (a runtime code costs a scalar
 // branch per VALUE here: the compiler does not hoist it out of the unrolled epilogue).
-template <int NG, int NW, int NS, int ACT>
+// IMG2: the output is the h8 activation image (GemmArgs::c_img == 2, gemm_h8_areg.hip: fp16 hi + fp8 lo, 3 bytes per element)
+// instead of the tiled split image (bf16 hi | lo planes, 4 bytes) of gemm_x3_areg.hip.
+template <int NG, int NW, int NS, int ACT, bool IMG2>
 __global__ __launch_bounds__(64 * NW, 2) void gemm_h8_astat_kernel(GemmArgs g) {
-    constexpr int NKT = 2 * NG, K = 64 * NG, NT = 64 * NW, ROWS = 32 * NW, PW = 8 / NW;
+    constexpr int NKT = 2 * NG, K = 64 * NG, NT = 64 * NW, ROWS = 32 * NW, PW = 8 / NW, STORES = IMG2 ? 6 : H_STORES;
     static_assert(NS >= 4 && NKT % NS == 0 && (NW == 4 || NW == 8), "static slots; lookahead NS - 1 >= 3 stages");
     static_assert(NS * H_STAGE * 4 <= 65536 || NS % 2 == 0, "ring addressed from two bases");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -299,7 +310,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_h8_astat_kernel(GemmArgs g) {
                 float lo[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float y = __builtin_fmaf(xs[s & 1][i][e], pa4[e], po4[e]);
+                    float y = __builtin_fmaf(xs[s & 1][i][e], pa4[e], po4[e]);
+                    asm volatile("" : "+v"(y));   // one rounded fp32 value for the hi rounding and the lo difference (see the epilogue)
                     hv[e] = (_Float16)y;
                     lo[e] = clamp448((y - (float)hv[e]) * YL_SCALE);
                 }
@@ -363,8 +375,77 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_h8_astat_kernel(GemmArgs g) {
     f32x16 acc[2];
 
     // ---- epilogue of one 64-column tile, from registers.  acc[j][4 q + e] = u[row r][n0 + 32 j + 8 q + 4 h + e].
+    // h8 activation image: this tile is 64-k group ct of the consumer; block (sample, 128-row tile, ct) of 6144 floats
+    float* img2_base = g.C + (((size_t)b * T128 + (mrow >> 7)) * (size_t)(g.Nout >> 6)) * 6144 + ((mrow & 127) >> 5) * 1024;
     auto epilogue = [&](int ct) {
         const int n0 = ct * H_BN;
+        if constexpr (IMG2) {
+            float* blk = img2_base + (size_t)ct * 6144;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x4 bs[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bs[q] = *reinterpret_cast<const f32x4*>(bias_lds + n0 + 32 * j + 8 * q + 4 * h);
+                unsigned hq[4][2], lq[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v[4], lo[4];
+                    f16x2 a, c;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[j][4 * q + e] + bs[q][e];
+                        if (H8_ACT_ON && ACT == 3) v[e] = fmaxf(v[e], 0.f);
+                        if (H8_ACT_ON && (ACT == 1 || ACT == 2)) {
+                            const float y = __builtin_amdgcn_exp2f(v[e] * v[e] * c2);
+                            v[e] = ACT == 1 ? (y - 0.7f) * (1.0f / 0.28f) : y;
+                        }
+                        // ONE fp32 value feeds both the hi rounding and the lo difference: left to itself the compiler forms the
+                        // lo path from the unrounded product (v_fma_mixlo_f16 / v_fma_mix_f32) and the stored hi from the rounded
+                        // one — near a tie the two hi differ by an fp16 ulp and hi + lo is off by that ulp
+                        asm volatile("" : "+v"(v[e]));
+                    }
+                    a[0] = (_Float16)v[0];
+                    a[1] = (_Float16)v[1];
+                    c[0] = (_Float16)v[2];
+                    c[1] = (_Float16)v[3];
+                    lo[0] = clamp448((v[0] - (float)a[0]) * YL_SCALE);
+                    lo[1] = clamp448((v[1] - (float)a[1]) * YL_SCALE);
+                    lo[2] = clamp448((v[2] - (float)c[0]) * YL_SCALE);
+                    lo[3] = clamp448((v[3] - (float)c[1]) * YL_SCALE);
+                    hq[q][0] = __builtin_bit_cast(unsigned, a);
+                    hq[q][1] = __builtin_bit_cast(unsigned, c);
+                    lq[q] = pack_fp8x4(lo[0], lo[1], lo[2], lo[3]);
+                }
+                // hi: quads (2 p, 2 p + 1) -> the lane half h holds columns 16 p + 8 h + 0 .. 7 of block j = fragment (sub j, c h) of
+                // image lane (r, p)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    u32x4 H;
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        const auto sh = __builtin_amdgcn_permlane32_swap(hq[2 * p][d], hq[2 * p + 1][d], false, false);
+                        H[d] = sh[0];
+                        H[2 + d] = sh[1];
+                    }
+#ifdef H8_DIAG_NOSTORE
+                    asm volatile("" ::"v"(H));
+#else
+                    GECCO_NT_STORE(H, reinterpret_cast<u32x4*>(blk + (2 * j + h) * 256 + (32 * p + r) * 4));
+#endif
+                }
+                // lo: quads (0, 2) and (1, 3) swapped -> the lane half h holds the 16 fp8 of columns 16 h + 0 .. 15 of block j =
+                // half t = j of image lane (r, h)
+                const auto s02 = __builtin_amdgcn_permlane32_swap(lq[0], lq[2], false, false);
+                const auto s13 = __builtin_amdgcn_permlane32_swap(lq[1], lq[3], false, false);
+                const u32x4 Lo = {s02[0], s02[1], s13[0], s13[1]};
+#ifdef H8_DIAG_NOSTORE
+                asm volatile("" ::"v"(Lo));
+#else
+                GECCO_NT_STORE(Lo, reinterpret_cast<u32x4*>(blk + 4096 - ((mrow & 127) >> 5) * 512 + j * 256 + lane * 4));
+#endif
+            }
+            return;
+        }
         unsigned short* tdst = lane_dst + (size_t)(n0 >> 4) * 4096;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -445,7 +526,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_h8_astat_kernel(GemmArgs g) {
             // are older than them (kt <= NS - 3), the 8 stores of the previous tile's epilogue
             constexpr int young = (NS - 3) * PW;
             constexpr bool st_young = kt <= NS - 3;
-            if (st_young && !first) dma::wait_vm_lgkm0<young + H_STORES>();
+            if (st_young && !first) dma::wait_vm_lgkm0<young + STORES>();
             else dma::wait_vm_lgkm0<young>();
 #pragma unroll
             for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(fbA[j]));
@@ -798,17 +879,21 @@ int kvq_launch_t(const GemmArgs& g, hipStream_t st) {
 
 constexpr int h8_ns(int NG, int NW) { return NW == 8 ? 2 * NG : (NG % 3 == 0 ? 6 : 4); }   // NW = 4: 48 / 32 KiB rings, two blocks per CU
 
-template <int NG, int NW, int ACT>
-int h8_launch_a(const GemmArgs& g, hipStream_t st) {
+template <int NG, int NW, int ACT, bool IMG2>
+int h8_launch_i(const GemmArgs& g, hipStream_t st) {
     constexpr int NS = h8_ns(NG, NW);
     const size_t lds = ((size_t)NS * H_STAGE + NW * H_STG + g.Nout + 2 * g.K) * sizeof(float);
     static size_t attr = 0;
     if (lds > attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h8_astat_kernel<NG, NW, NS, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h8_astat_kernel<NG, NW, NS, ACT, IMG2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = lds;
     }
-    hipLaunchKernelGGL((gemm_h8_astat_kernel<NG, NW, NS, ACT>), dim3(g.B * (g.rows / (32 * NW))), dim3(64 * NW), lds, st, g);
+    hipLaunchKernelGGL((gemm_h8_astat_kernel<NG, NW, NS, ACT, IMG2>), dim3(g.B * (g.rows / (32 * NW))), dim3(64 * NW), lds, st, g);
     return (int)hipGetLastError();
+}
+template <int NG, int NW, int ACT>
+int h8_launch_a(const GemmArgs& g, hipStream_t st) {
+    return g.c_img == 2 ? h8_launch_i<NG, NW, ACT, true>(g, st) : h8_launch_i<NG, NW, ACT, false>(g, st);
 }
 template <int NG, int NW>
 int h8_launch_t(const GemmArgs& g, hipStream_t st) {
@@ -833,13 +918,13 @@ size_t h8_image_bytes(int Nout, int K) { return (size_t)((Nout + H_BN - 1) / H_B
 int h8_image_multi_launch(const SplitJobs& jobs, hipStream_t st) {
     if (jobs.n <= 0) return 0;
     for (int i = 0; i < jobs.n; ++i)
-        if (jobs.job[i].K % 64 || jobs.job[i].Nout % H_BN || (jobs.job[i].ldw & 3)) return -9;
+        if (jobs.job[i].K % 64 || (!(jobs.job[i].pad_ & 2) && jobs.job[i].Nout % H_BN) || (jobs.job[i].ldw & 3)) return -9;
     hipLaunchKernelGGL(h8_image_multi_kernel, dim3(48, jobs.n), dim3(256), 0, st, jobs);
     return (int)hipGetLastError();
 }
 
-// c_img output only: whole 128-row blocks of one sample, 64-column tiles, K = 128 / 256 / 384 (the stationary operand is
-// 3 K / 8 registers per lane)
+// c_img output only (1: tiled split image, 2: h8 activation image): whole 128-row blocks of one sample, 64-column tiles,
+// K = 128 / 256 / 384 (the stationary operand is 3 K / 8 registers per lane)
 bool gemm_h8_astat_supported(const GemmArgs& g) {
     return g.c_img && !g.a_img && !g.a_f16 && !g.c_f16 && !g.residual && !g.stats && !g.C2 && g.w_img && g.rows >= 128 &&
            !(g.rows % 128) && !(g.Nout % H_BN) && g.Nout >= 2 * H_BN && g.Nout <= 4096 && (g.K == 128 || g.K == 256 || g.K == 384) &&
@@ -874,23 +959,15 @@ int gemm_kvq_astat_launch(const GemmArgs& g, hipStream_t st) {
     }
 }
 
-// GECCO_H8_WAVES = 8: one 256-row block of 8 waves per CU (rows % 256 == 0) instead of two 128-row blocks of 4;
+// Two 128-row blocks of 4 waves per CU (one 256-row block of 8 waves measured the same, 192 vs 194 us, and is not instantiated).
 // GECCO_H8_STAGGER: start offset (s_memtime ticks) of every second block of a CU, GECCO_H8_PAIR: blocks per XCD between partners
+// (measured: no gain, default 0)
 int gemm_h8_astat_launch(const GemmArgs& g0, hipStream_t st) {
     if (!gemm_h8_astat_supported(g0)) return -9;
-    static const int waves = h8_env("GECCO_H8_WAVES", 4), stagger = h8_env("GECCO_H8_STAGGER", 0), pair = h8_env("GECCO_H8_PAIR", 32);
+    static const int stagger = h8_env("GECCO_H8_STAGGER", 0), pair = h8_env("GECCO_H8_PAIR", 32);
     GemmArgs g = g0;
     g.h8_stagger = stagger;
     g.h8_pair = pair > 0 ? pair : 32;
-    if (waves == 8 && g.rows % 256 == 0) {
-        g.h8_stagger = 0;
-        switch (g.K) {
-            case 128: return h8_launch_t<2, 8>(g, st);
-            case 256: return h8_launch_t<4, 8>(g, st);
-            case 384: return h8_launch_t<6, 8>(g, st);
-            default: return -9;
-        }
-    }
     switch (g.K) {
         case 128: return h8_launch_t<2, 4>(g, st);
         case 256: return h8_launch_t<4, 4>(g, st);

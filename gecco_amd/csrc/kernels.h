@@ -42,7 +42,7 @@ struct GemmArgs {
     // [128][16] then lo plane, the 16-byte chunk of a row swapped when (row >> 3) & 1 (the W image's layout, gemm_f32_dma.hip).
     // c_img: C is written that way (no residual, no statistics, rows % 128 == 0, Nout % 16 == 0);  a_img: A is read that way
     // (no prologue; K % 16 == 0): contiguous 1 KiB DMA pieces instead of 64-byte row pieces, and no hi / lo split in the K loop.
-    int a_img, c_img;
+    int a_img, c_img;       // 1: tiled split image (bf16 hi | lo planes); 2: h8 activation image (gemm_h8_areg.hip: fp16 hi + fp8 lo)
     // Activation BACKWARD as an epilogue (training: the dX product of the linear that FOLLOWS an activation).  C = (A W^T) *
     // act'(u) with u (B, rows, ldc) the pre-activation the forward kept: dh = dy W2 never exists, du leaves directly.
     // mul_kind: 1 / 2 GaussianActivation normalized / raw (alpha in `alpha`), 3 ReLU, 4 GELU.  agrad (Gaussian only):
@@ -163,6 +163,13 @@ size_t kvq_image_bytes(int Nout, int K, int lo_cols);
 bool gemm_kvq_astat_supported(const GemmArgs& g);
 int gemm_kvq_astat_launch(const GemmArgs& g, hipStream_t st);
 int gemm_h8_astat_launch(const GemmArgs& g, hipStream_t st);
+
+// gemm_h8_areg.hip — mixed mode's mlp.2 / out_proj in h8 arithmetic: A is an h8 activation image (a_img == 2: fp16 hi + fp8 lo,
+// written by gemm_h8_astat.hip with c_img == 2 or by the unpool attention with out_img == 2), W the 128-column-tile h8 stream
+// (SplitJob::pad_ = 2); residual / bias / statistics epilogue of the LDS-DMA kernels
+size_t h8_w128_image_bytes(int Nout, int K);
+bool gemm_h8_areg_supported(const GemmArgs& g);
+int gemm_h8_areg_launch(const GemmArgs& g, hipStream_t st);
 
 // gemm_general_f32.hip — C[z] = scale * op(A[z]) op(B[z]) (+ bias), per-operand layout flag, two-level batch strides
 struct GemmGeneralArgs {

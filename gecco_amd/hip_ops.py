@@ -267,21 +267,39 @@ def linear_kvq_f16(x: Tensor, pro: tuple[Tensor, Tensor] | None, W1: Tensor, b1:
 
 def linear_h8_img(x: Tensor, pro: tuple[Tensor, Tensor] | None, W: Tensor, b: Tensor | None, act_alpha: Tensor | None = None,
                   normalized: bool = True, act: str | int | None = None, wsplit: Tensor | None = None,
-                  image_ready: bool = False, out: Tensor | None = None) -> Tensor:
-    """act((x*pa + po) @ W^T + b) in fp16 + fp8-cross-term arithmetic (mixed mode's mlp.0), returned as the tiled split image
-    (B, rows / 128, Nout / 16, 2, 128, 16) of bf16 bit patterns (int16): hi plane, lo plane; see `decode_split_image`."""
+                  image_ready: bool = False, out: Tensor | None = None, kind: int = 1) -> Tensor:
+    """act((x*pa + po) @ W^T + b) in fp16 + fp8-cross-term arithmetic (mixed mode's mlp.0), returned as an image the next linear
+    loads into registers.  kind 1: tiled split image (B, rows / 128, Nout / 16, 2, 128, 16) of bf16 bit patterns (int16) — hi plane,
+    lo plane (`decode_split_image`); kind 2: h8 activation image (B, rows / 128, Nout / 64, 24576) bytes (`decode_h8_image`)."""
     lib = _lib.load()
     B, rows, K = x.shape
     n = W.shape[0]
     if out is None:
-        out = torch.empty(B, rows // 128, n // 16, 2, 128, 16, device=x.device, dtype=torch.int16)
+        out = (torch.empty(B, rows // 128, n // 16, 2, 128, 16, device=x.device, dtype=torch.int16) if kind == 1 else
+               torch.empty(B, rows // 128, n // 64, 24576, device=x.device, dtype=torch.uint8))
     if wsplit is None:
         wsplit = _ws(n * K * 4, x.device)
     check(lib.gecco_linear_h8_img_f32(_ptr(x), _ptr(pro[0]) if pro else None, _ptr(pro[1]) if pro else None,
                                       None if image_ready else _ptr(W), _ptr(b), _ptr(act_alpha),
-                                      act_code(act_alpha, normalized, act), C.c_void_p(out.data_ptr()), B, rows, K, n,
+                                      act_code(act_alpha, normalized, act), C.c_void_p(out.data_ptr()), kind, B, rows, K, n,
                                       C.c_void_p(wsplit.data_ptr()), _stream()), "gecco_linear_h8_img_f32")
     return out
+
+
+def linear_h8_areg(a_img: Tensor, W: Tensor, b: Tensor | None = None, residual: Tensor | None = None, want_stats: bool = False,
+                   out: Tensor | None = None, wsplit: Tensor | None = None, image_ready: bool = False):
+    """residual + A @ W^T + b with A an h8 activation image (B, rows / 128, K / 64, 24576) bytes: mlp.2 / out_proj of the mixed mode."""
+    lib = _lib.load()
+    B, T, G = a_img.shape[:3]
+    rows, K, n = T * 128, G * 64, W.shape[0]
+    if out is None:
+        out = torch.empty(B, rows, n, device=a_img.device, dtype=torch.float32)
+    stats = torch.empty(B, rows // 128, 2, n, device=a_img.device, dtype=torch.float32) if want_stats else None
+    if wsplit is None:
+        wsplit = _ws((n + 127) // 128 * 128 * K * 4, a_img.device)
+    check(lib.gecco_linear_h8_areg_f32(C.c_void_p(a_img.data_ptr()), None if image_ready else _ptr(W), _ptr(b), _ptr(residual), _ptr(out),
+                                       _ptr(stats), B, rows, K, n, C.c_void_p(wsplit.data_ptr()), _stream()), "gecco_linear_h8_areg_f32")
+    return (out, stats) if want_stats else out
 
 
 def decode_split_image(img: Tensor) -> Tensor:
@@ -294,6 +312,18 @@ def decode_split_image(img: Tensor) -> Tensor:
     swap = ((rows >> 3) & 1).bool()
     v = torch.where(swap[None, None, None, :, None], torch.cat([v[..., 8:], v[..., :8]], dim=-1), v)
     return v.permute(0, 1, 3, 2, 4).reshape(Bn, T * 128, KT * 16)
+
+
+def decode_h8_image(img: Tensor) -> Tensor:
+    """(B, rows / 128, K / 64, 24576) uint8 h8 activation image -> the (B, rows, K) float64 tensor hi + 2^-14 lo it represents.
+    hi: [rt 4][sub 2][c 2][lane 64][8 fp16], column 32 sub + 16 (lane >> 5) + 8 c + e; lo: [rt 4][t 2][lane 64][16 fp8 e4m3],
+    column 32 t + 16 (lane >> 5) + e; row 32 rt + (lane & 31)."""
+    Bn, T, G = img.shape[:3]
+    hi = img[..., :16384].contiguous().view(torch.float16).reshape(Bn, T, G, 4, 2, 2, 2, 32, 8).double()   # rt sub c h r e
+    lo = img[..., 16384:].contiguous().view(torch.float8_e4m3fn).reshape(Bn, T, G, 4, 2, 2, 32, 16).double()   # rt t h r e
+    hi = hi.permute(0, 1, 3, 7, 2, 4, 6, 5, 8)        # B T rt r G sub h c e
+    lo = lo.permute(0, 1, 3, 6, 2, 4, 5, 7)           # B T rt r G t h e
+    return hi.reshape(Bn, T * 128, G * 64) + lo.reshape(Bn, T * 128, G * 64) * 2.0 ** -14
 
 
 def mlp_fused_f16(x: Tensor, pro: tuple[Tensor, Tensor], W0: Tensor, b0: Tensor | None, W2: Tensor, b2: Tensor | None,

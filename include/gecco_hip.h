@@ -98,10 +98,13 @@ int gecco_linear_f32(const float* A, const float* W, const float* bias, const fl
  *   "h8" (default 1): mixed mode runs mlp.0 as an fp16 main product plus two fp8 cross terms (v_mfma_scale_f32_32x32x64_f8f6f4)
  *   on the A-stationary 256-row kernel (gemm_h8_astat.hip; needs "actimg", rows % 256 == 0, feature_dim <= 384) instead of as a
  *   split-bf16 product: 2 instead of 3 matrix-pipe units per product, same accuracy (~6e-5 on F_x).
+ *   "h8areg" (default 1): mixed mode hands the MLP hidden layer and the unpool attention output on as h8 activation images
+ *   (fp16 hi + fp8 lo, 3 bytes per element) and runs mlp.2 / out_proj as h8 products (gecco_linear_h8_areg_f32) instead of
+ *   split-bf16 products on tiled split images: 2 instead of 3 matrix-pipe units per product, same accuracy (needs "h8").
  *   "kvq64" (default 1): mixed mode runs kv_proj | q_proj on the 64-column-tile A-stationary kernel (gecco_linear_kvq_f16; needs
  *   "headmajor") instead of the 128-column-tile one (gecco_linear_astat_f16 + lo image): same arithmetic, also at feature_dim 512.
  * value < 0 returns the option to its default / environment (GECCO_ASTAT, GECCO_CHAIN, GECCO_HEADMAJOR, GECCO_MLPFUSED,
- * GECCO_UNPOOLFUSED, GECCO_LO8, GECCO_ACTIMG, GECCO_H8, GECCO_KVQ64).
+ * GECCO_UNPOOLFUSED, GECCO_LO8, GECCO_ACTIMG, GECCO_H8, GECCO_KVQ64, GECCO_H8AREG).
  * Process-wide. */
 int gecco_set_option(const char* name, int value);
 
@@ -212,11 +215,23 @@ int gecco_linear_kvq_f16(const float* x, const float* pro_a, const float* pro_o,
  * `x + mlp(mlp_norm(x))` with the AdaGN apply of models/normalization.py:44 folded in; models/mlp.py:5-39; activation.py:17-24):
  *   u = act((x*pro_a + pro_o) @ W^T + bias),   product = fp16(y) fp16(W) + fp8(y) fp8(W - fp16(W)) + fp8(y - fp16(y)) fp8(W)
  * (fp32 accumulate; the cross terms on v_mfma_scale_f32_32x32x64_f8f6f4), written as the TILED SPLIT IMAGE the next linear
- * (gecco_linear_ex_f32 with a_img) loads into registers: per (sample, 128-row tile, 16-column step) one 8 KiB block — bf16 hi
- * plane [128][16] (the 16-byte half of a row swapped when (row >> 3) & 1), then the lo plane; c_img: B * rows * Nout * 4 bytes.
- * rows % 256 == 0, Nout % 64 == 0, K in {128, 256, 384}, act 0 .. 3.  wsplit: Nout * K * 4 bytes; W == NULL: image-ready call. */
+ * loads into registers.  image_kind 1 — the tiled split image of the split-bf16 consumer: per (sample, 128-row tile, 16-column
+ * step) one 8 KiB block, bf16 hi plane [128][16] (the 16-byte half of a row swapped when (row >> 3) & 1), then the lo plane;
+ * B * rows * Nout * 4 bytes.  image_kind 2 — the h8 activation image of gecco_linear_h8_areg_f32: per (sample, 128-row tile,
+ * 64-column group) one 24 KiB block: 16 KiB of fp16 MFMA fragments [32-row tile][sub][c][lane] (row 32 rt + (lane & 31), columns
+ * 32 sub + 16 (lane >> 5) + 8 c + 0 .. 7), then 8 KiB of fp8(2^14 (u - fp16(u))) halves [32-row tile][t][lane] (columns 32 t +
+ * 16 (lane >> 5) + 0 .. 15); B * rows * Nout * 3 bytes.
+ * rows % 128 == 0, Nout % 64 == 0, K in {128, 256, 384}, act 0 .. 3.  wsplit: Nout * K * 4 bytes; W == NULL: image-ready call. */
 int gecco_linear_h8_img_f32(const float* x, const float* pro_a, const float* pro_o, const float* W, const float* bias,
-                            const float* alpha, int act, void* c_img, int B, int rows, int K, int Nout, void* wsplit, void* stream);
+                            const float* alpha, int act, void* c_img, int image_kind, int B, int rows, int K, int Nout,
+                            void* wsplit, void* stream);
+/* The linear that consumes an h8 activation image (mixed mode: mlp.2 of the point MLP and the unpool attention's out_proj;
+ * models/set_transformer.py:112,164-166, models/mlp.py:5-39):  C = residual + A @ W^T + bias  (+ GroupNorm partials `stats`
+ * (B, rows / 128, 2, Nout) of C), A = hi + 2^-14 lo read from the image, product = fp16 main term + two fp8 cross terms as in
+ * gecco_linear_h8_img_f32, fp32 accumulate.  C may alias residual.  rows % 128 == 0, K in {128, 256, 384, 512, 768, 1024},
+ * Nout % 4 == 0.  wsplit: ceil(Nout / 128) * 128 * K * 4 bytes; W == NULL: image-ready call.  Option "h8areg". */
+int gecco_linear_h8_areg_f32(const void* a_img, const float* W, const float* bias, const float* residual, float* C, float* stats,
+                             int B, int rows, int K, int Nout, void* wsplit, void* stream);
 /* The point-stream MLP of a BroadcastingLayer in one launch (fp16 mode; models/set_transformer.py:165-166 with the
  * AdaGN apply of :164 folded in): x += (GaussianActivation(fp16(x*pro_a + pro_o) @ W0^T + b0)) @ W2^T + b2, in place on
  * the fp32 x (B, rows, C); the 2C-wide hidden layer never leaves the CU.  stats (B, rows / 128, 2, C) or NULL: GroupNorm

@@ -276,13 +276,15 @@ def test_activation_images_are_bit_identical(ops, golden_dir, name, precision):
     net = ops.LinearLiftPlan(_cuda(p), cases.H, cases.I, precision=precision)
     out = {}
     try:
-        ops.set_option("h8", 0)   # mlp.0's h8 form exists only with the image hand-over: compare like with like
+        ops.set_option("h8", 0)   # the h8 products exist only with the image hand-over: compare like with like
+        ops.set_option("h8areg", 0)
         for on in (0, 1):
             ops.set_option("actimg", on)
             out[on] = net.forward(x.cuda(), sigma.cuda()).cpu()
     finally:
         ops.set_option("actimg", -1)
         ops.set_option("h8", -1)
+        ops.set_option("h8areg", -1)
     assert torch.equal(out[0], out[1])
 
 
@@ -292,16 +294,24 @@ def test_mixed_h8_mlp0_matches_split_bf16_mlp0(ops, golden_dir, name):
     against the split-bf16 product it replaces: both within the bar of the reference's golden output, and close to each other
     (the two arithmetics differ at ~2^-16 per product); the h8 form must actually have run."""
     p, x, sigma = cases.uncond_inputs(name)
-    g = np.load(golden_dir / f"{name}.npz")
+    g = np.load(os.path.join(golden_dir, f"{name}.npz"))
     net = ops.LinearLiftPlan(_cuda(p), cases.H, cases.I, precision="mixed")
     out, raw = {}, {}
     try:
         for on in (0, 1):
             ops.set_option("h8", on)
+            ops.set_option("h8areg", 0)
             d, r = net.forward(x.cuda(), sigma.cuda(), return_raw=True)
             out[on], raw[on] = d.cpu(), r.cpu()
+        ops.set_option("h8areg", 1)   # + mlp.2 and out_proj as h8 products on h8 activation images (gemm_h8_areg.hip)
+        d, r = net.forward(x.cuda(), sigma.cuda(), return_raw=True)
+        out[2], raw[2] = d.cpu(), r.cpu()
     finally:
         ops.set_option("h8", -1)
+        ops.set_option("h8areg", -1)
+    assert cpu_ref.rel_err(out[2], torch.from_numpy(g["denoised"]))[0] <= 2e-4
+    assert cpu_ref.rel_err(raw[2], raw[0])[0] <= 2e-4
+    assert not torch.equal(raw[2], raw[1]), "the h8 mlp.2 / out_proj did not run"
     for on in (0, 1):
         eg = cpu_ref.rel_err(out[on], torch.from_numpy(g["denoised"]))
         assert eg[0] <= 2e-4, (on, eg)

@@ -390,3 +390,39 @@ def test_linear_kvq_f16(ops, B, rows, K, hd):
     c = ops.linear_kvq_f16(x.cuda(), (pa.cuda(), po.cuda()), Wq.cuda(), bq.cuda(), head_dim=hd, wsplit=ws, image_ready=True)
     qq = a.permute(0, 2, 1, 3).reshape(B, rows, C) if hd else a
     assert torch.equal(a, c) and cpu_ref.rel_err(qq.cpu().double(), ref_q)[0] < tol
+
+
+@pytest.mark.parametrize("B,rows,K,Wd", [(2, 256, 384, 768), (1, 128, 128, 256), (2, 384, 256, 512)])
+def test_linear_h8_areg_chain(ops, B, rows, K, Wd):
+    """The point MLP of the mixed mode as its two h8 launches (models/set_transformer.py:164-166, models/mlp.py): mlp.0 writes the
+    h8 activation image (fp16 hi + fp8 lo), mlp.2 (gemm_h8_areg.hip) loads it into registers.  The image against float64 of
+    mlp.0; mlp.2 against float64 on the image's own values (its product alone) and the whole chain against float64."""
+    rs = _rs(B + rows + K)
+    x, W0, b0 = _t(rs.randn(B, rows, K)), _t(rs.randn(Wd, K) / math.sqrt(K)), _t(rs.randn(Wd) / math.sqrt(K))
+    W2, b2 = _t(rs.randn(K, Wd) / math.sqrt(Wd)), _t(rs.randn(K) / math.sqrt(Wd))
+    pa, po = _t(1 + 0.3 * rs.randn(B, K)), _t(0.3 * rs.randn(B, K))
+    alpha = _t(np.array(0.9))
+    u = F.linear((x.double() * pa[:, None].double() + po[:, None].double()), W0.double(), b0.double())
+    hid = (torch.exp(-u * u / (2 * 0.9 ** 2)) - 0.7) / 0.28
+    img = ops.linear_h8_img(x.cuda(), (pa.cuda(), po.cuda()), W0.cuda(), b0.cuda(), act_alpha=alpha.cuda(), kind=2)
+    dec = ops.decode_h8_image(img).cpu()
+    e = cpu_ref.rel_err(dec, hid)
+    assert e[0] < 1e-4, e                                        # fast exp in the epilogue, as for the split image
+    out, stats = ops.linear_h8_areg(img, W2.cuda(), b2.cuda(), residual=x.cuda(), want_stats=True)
+    ref2 = x.double() + F.linear(dec, W2.double(), b2.double())  # the consumer's own product on exactly the operand it read
+    e2 = cpu_ref.rel_err(out.cpu().double(), ref2)
+    assert e2[0] < 1e-5, e2
+    ref = x.double() + F.linear(hid, W2.double(), b2.double())
+    e3 = cpu_ref.rel_err(out.cpu().double(), ref)
+    assert e3[0] < 5e-5, e3
+    s = stats.cpu().double().sum(1)
+    _close(s[:, 0], ref2.sum(1), 1e-4)
+    _close(s[:, 1], (ref2 ** 2).sum(1), 1e-5)
+    # in place on the residual stream, no bias, image-ready call
+    ws = torch.empty(K * Wd * 4, dtype=torch.uint8, device="cuda")
+    xc = x.cuda().clone()
+    ops.linear_h8_areg(img, W2.cuda(), None, residual=xc, out=xc, wsplit=ws)
+    xd = x.cuda().clone()
+    ops.linear_h8_areg(img, W2.cuda(), None, residual=xd, out=xd, wsplit=ws, image_ready=True)
+    assert torch.equal(xc, xd)
+    assert cpu_ref.rel_err(xc.cpu().double(), x.double() + F.linear(dec, W2.double()))[0] < 1e-5

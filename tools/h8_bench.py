@@ -68,3 +68,20 @@ ops.linear_astat_f16(x, (pa, po), Wkv, None, Wq, bq, out=(kv16, q16), head_dim=D
 t_as = timed(lambda: ops.linear_astat_f16(x, (pa, po), Wkv, None, Wq, bq, out=(kv16, q16), head_dim=D // H, wsplit=ws3, image_ready=True))
 fl = 2 * B * N * D * 3 * D
 print(f"kvq64 (V two-term): {t_kvq:7.1f} us   kvq64 one-term (+ image build): {t_kvq1:7.1f} us   astat128 one-term: {t_as:7.1f} us   ({fl / t_kvq / 1e6:.0f} TFLOP/s of 2MNK; 502 MB -> {502e6 / t_kvq / 1e6:.2f} TB/s)")
+
+# mlp.2 and out_proj: the h8 register-fed kernel against the split-bf16 register-fed kernel is only reachable inside the network;
+# here the h8 pair mlp.0 -> mlp.2 on shared buffers
+W2, b2 = rn(D, 2 * D) / 28, rn(D) / 20
+img2 = ops.linear_h8_img(x, (pa, po), W1, b1, act_alpha=alpha, wsplit=ws, kind=2)
+wsb = torch.empty(D * 2 * D * 4, dtype=torch.uint8, device=dev)
+xo = x.clone()
+ops.linear_h8_areg(img2, W2, b2, residual=xo, out=xo, wsplit=wsb)
+t_m0 = timed(lambda: ops.linear_h8_img(x, (pa, po), W1, b1, act_alpha=alpha, wsplit=ws, image_ready=True, out=img2, kind=2))
+t_pair = timed(lambda: (ops.linear_h8_img(x, (pa, po), W1, b1, act_alpha=alpha, wsplit=ws, image_ready=True, out=img2, kind=2),
+                        ops.linear_h8_areg(img2, W2, b2, residual=xo, out=xo, wsplit=wsb, image_ready=True)))
+Wo = rn(D, D) / 20
+wsc = torch.empty(D * D * 4, dtype=torch.uint8, device=dev)
+att = img2[:, :, :D // 64].contiguous()
+ops.linear_h8_areg(att, Wo, b2, residual=xo, out=xo, wsplit=wsc)
+t_op = timed(lambda: ops.linear_h8_areg(att, Wo, b2, residual=xo, out=xo, wsplit=wsc, image_ready=True))
+print(f"h8 mlp.0 (h8 image): {t_m0:7.1f} us   mlp.0 + mlp.2 pair: {t_pair:7.1f} us  -> mlp.2 {t_pair - t_m0:7.1f} us   out_proj (K = {D}): {t_op:7.1f} us")

@@ -241,7 +241,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_h8_astat_kernel(GemmArgs g) {
     float* pro_lds = bias_lds + g.Nout;                // pa[0 .. K) | po[0 .. K)
 
     const int tilesM = g.rows / ROWS, tilesN = g.Nout / H_BN;
-    const int b = blockIdx.x / tilesM, rt = blockIdx.x % tilesM, m0 = rt * ROWS;
+    const int bid = g.h8_rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    const int b = bid / tilesM, rt = bid % tilesM, m0 = rt * ROWS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // rows m0 + 32 wave .. + 31
     const int r = lane & 31, h = lane >> 5;
@@ -613,7 +614,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kvq_astat_kernel(GemmArgs g) {
     float* pro_lds = bias_lds + g.Nout;                // pa | po
 
     const int tilesM = g.rows / ROWS, tilesN = g.Nout / H_BN;
-    const int b = blockIdx.x / tilesM, rt = blockIdx.x % tilesM, m0 = rt * ROWS;
+    const int bid = g.h8_rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    const int b = bid / tilesM, rt = bid % tilesM, m0 = rt * ROWS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -944,8 +946,11 @@ bool gemm_kvq_astat_supported(const GemmArgs& g) {
                          !((g.C2 ? g.Nout - g.n_split : 0) % g.hm_hd)));
 }
 
-int gemm_kvq_astat_launch(const GemmArgs& g, hipStream_t st) {
-    if (!gemm_kvq_astat_supported(g)) return -9;
+int gemm_kvq_astat_launch(const GemmArgs& g0, hipStream_t st) {
+    if (!gemm_kvq_astat_supported(g0)) return -9;
+    static const int rev = h8_env("GECCO_H8_REV", 0);
+    GemmArgs g = g0;
+    g.h8_rev = rev;
     switch (g.K) {
         case 128: return kvq_launch_t<2, 4>(g, st);   // NS - 2 <= stages of the shortest tile: the wait counts assume one epilogue in flight
         case 256: return kvq_launch_t<4, 6>(g, st);
@@ -966,6 +971,7 @@ int gemm_h8_astat_launch(const GemmArgs& g0, hipStream_t st) {
     if (!gemm_h8_astat_supported(g0)) return -9;
     static const int stagger = h8_env("GECCO_H8_STAGGER", 0), pair = h8_env("GECCO_H8_PAIR", 32);
     GemmArgs g = g0;
+    g.h8_rev = h8_env("GECCO_H8_REV", 0);
     g.h8_stagger = stagger;
     g.h8_pair = pair > 0 ? pair : 32;
     switch (g.K) {

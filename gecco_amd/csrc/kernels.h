@@ -55,6 +55,7 @@ struct GemmArgs {
     // Activation FORWARD that keeps its input (training: the backward needs u): C = act(A W^T + bias) as with `act`, and
     // pre_out (B, rows, ldc) = A W^T + bias.  Same kernel instantiation as mul_u (the training path's); not with c_img.
     float* pre_out;
+    int h8_rev;                // gemm_h8_astat.hip: blocks walk the row panels last to first (the producer wrote them first to last)
     int h8_stagger, h8_pair;   // gemm_h8_astat.hip: start offset of every second block of a CU (set by its launcher)
 };
 

@@ -295,7 +295,7 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
     if (mixed && w.wimg && option(OPT_KVQ64) && option(OPT_HEADMAJOR) && (C == 128 || C == 256 || C == 384 || C == 512) && !((C / H) & 7)) kvq_on = true;
     // ... and mlp.2 / out_proj as h8 products fed from h8 activation images (gemm_h8_areg.hip; option "h8areg")
     bool h8x = false, h8o = false;
-    if (h8_on && option(OPT_H8AREG) && Wd % 64 == 0) {
+    if (mixed && w.wimg && option(OPT_H8AREG) && option(OPT_ACTIMG) && Wd % 64 == 0 && N % 128 == 0) {
         GemmArgs hg{};
         hg.a_img = 2; hg.w_img = w.wimg; hg.rows = N; hg.Nout = C; hg.K = Wd; hg.lda = Wd; hg.ldc = C; hg.ldr = C;
         h8x = gemm_h8_areg_supported(hg);
@@ -571,7 +571,13 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         if (m0_done == 1) {
         if (a16) TRY(affine_cast_f16_launch(x, w.a2, w.o2, w.attn, B, N, C, s), "mlp_norm -> fp16");
         TRY(linear(a16 ? w.attn : x, L.mlp.w0, L.mlp.b0, a16 ? nullptr : w.a2, a16 ? nullptr : w.o2, L.mlp.alpha, nullptr,
-                   w.big, nullptr, B, N, C, Wd, act, s, pr, w.wsplit, im ? im + w.o_w0 : nullptr, a16, a16, 0, himg), "mlp.0");
+                   w.big, nullptr, B, N, C, Wd, act, s, pr, w.wsplit, im ? im + w.o_w0 : nullptr, a16, a16, 0, (himg && h8x) ? 2 : himg), "mlp.0");
+        if (himg && h8x && im) {   // feature_dim 512: mlp.0 on the split-bf16 kernel writing the h8 activation image, mlp.2 as the h8 product
+            TRY(h8_linear(w.big, im + w.o_w2, L.mlp.b2, x, x, so, B, N, Wd, C, s), "mlp.2+residual (h8)");
+            sx = w.stats_x;
+            sT = Tn;
+            continue;
+        }
         }
         TRY(linear(w.big, L.mlp.w2, L.mlp.b2, nullptr, nullptr, nullptr, x, x, so, B, N, Wd, C, 0, s, pr, w.wsplit,
                    im ? im + w.o_w2 : nullptr, a16, 0, himg, 0), "mlp.2+residual");

@@ -142,6 +142,41 @@ __device__ __forceinline__ void epilogue_t(const GemmArgs& g, const Tile& t, f32
                 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
                 const int lr8 = lane >> 3, c8 = lane & 7;
                 const int n8 = ncol0 + c8 * 8;
+                if (g.c_img == 2) {
+                    // h8 activation image (gemm_h8_areg.hip): per (sample, 128-row tile, 64-column group) 6144 floats — fp16 hi
+                    // fragments [32-row tile][sub][c][lane], then fp8(2^14 lo) halves [32-row tile][t][lane]; a lane's 8
+                    // consecutive columns are one 16-byte hi chunk and 8 lo bytes (Nout % 64 == 0)
+                    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+                    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int m = mrow0 + it * 8 + lr8;
+                        const f32x4 v0 = *reinterpret_cast<const f32x4*>(Tt + (it * 8 + lr8) * D_TP + c8 * 8);
+                        const f32x4 v1 = *reinterpret_cast<const f32x4*>(Tt + (it * 8 + lr8) * D_TP + c8 * 8 + 4);
+                        f16x8 hv;
+                        float lo[8];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            hv[e] = (_Float16)v0[e];       // v0 / v1 come from LDS: one fp32 value for the hi rounding and the lo difference
+                            hv[4 + e] = (_Float16)v1[e];
+                            lo[e] = __builtin_fminf(__builtin_fmaxf((v0[e] - (float)hv[e]) * 16384.f, -448.f), 448.f);
+                            lo[4 + e] = __builtin_fminf(__builtin_fmaxf((v1[e] - (float)hv[4 + e]) * 16384.f, -448.f), 448.f);
+                        }
+                        int p0 = 0, p1 = 0;
+                        p0 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[0], lo[1], p0, false);
+                        p0 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[2], lo[3], p0, true);
+                        p1 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[4], lo[5], p1, false);
+                        p1 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[6], lo[7], p1, true);
+                        if (n8 < nseg && m < g.rows) {
+                            const int kk = n8 & 63, ml = m & 127, rt = ml >> 5, rr = ml & 31;
+                            const int sub = kk >> 5, hh = (kk >> 4) & 1, cc = (kk >> 3) & 1;
+                            float* blk = Cseg + (((size_t)b * ((g.rows + 127) >> 7) + (m >> 7)) * (g.Nout >> 6) + (n8 >> 6)) * 6144;
+                            GECCO_NT_STORE(__builtin_bit_cast(u32x4, hv), reinterpret_cast<u32x4*>(blk + rt * 1024 + (2 * sub + cc) * 256 + (32 * hh + rr) * 4));
+                            GECCO_NT_STORE((u32x2{(unsigned)p0, (unsigned)p1}), reinterpret_cast<u32x2*>(blk + 4096 + rt * 512 + sub * 256 + (32 * hh + rr) * 4 + 2 * cc));
+                        }
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int m = mrow0 + it * 8 + lr8;

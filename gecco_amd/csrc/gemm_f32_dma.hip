@@ -429,7 +429,7 @@ int gemm_f32_dma_launch(const GemmArgs& g, hipStream_t st) {
         return (g.rows >= 256 && g.K >= 512) ? dma_launch_aimg<256>(g, st) : dma_launch_aimg<128>(g, st);
     }
     if (g.c_img && !(g.precision == 1 && g.w_img && !g.residual && !g.stats && !g.C2 && g.rows >= 128 && g.rows % 128 == 0 &&
-                     g.Nout % 16 == 0))
+                     g.Nout % 16 == 0 && (g.c_img != 2 || g.Nout % 64 == 0)))
         return -9;
     if (g.precision == 1 && g.w_img) {
         if (g.rows < 128) return dma_launch_t<3, true, 64>(g, st);

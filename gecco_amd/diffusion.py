@@ -440,15 +440,19 @@ class Diffusion(_Base):
     @torch.no_grad()
     def upsample(self, data: Tensor, new_latents: Tensor | None = None, n_new: int | None = None,
                  context: Context3d | None = None, seed: int | None = 42, num_substeps=5,
-                 noise: Sequence[Tensor] | None = None, use_graph: bool = True, **kwargs):
+                 noise: Sequence[Tensor] | None = None, use_graph: bool = False, **kwargs):
         """Generates `n_new` extra points conditionally independent given the per-layer inducer states of the known
         cloud (reference diffusion.py:354-470).  `noise` (optional): the randn draws in the reference's call order
         ([new_latents,] then per outer step: data noise, per sub-step churn noise [, redo noise]).
 
         One outer step — re-noise the known cloud, one full evaluation that builds the inducer cache, `num_substeps` x
         (churn, cached evaluation, Euler, cached evaluation, Heun[, redo]) on the new points, advance — is captured as ONE
-        hipGraph (`use_graph`) and replayed per step; the step's noise is drawn before each replay, in the reference's
-        order, into the buffers the graph reads (BASELINE config C5: "hipGraph, 128 steps")."""
+        hipGraph (`use_graph=True`) and replayed per step; the step's noise is drawn before each replay, in the reference's
+        order, into the buffers the graph reads (BASELINE config C5: "hipGraph, 128 steps").  Default: eager.  An outer step is
+        ~1100 kernel nodes of 10 - 40 us each and the step is device-bound either way (the host issues it in half the time);
+        measured on MI355X at C5 (8 clouds, 16 384 new points): 44.5 ms per outer step replayed against 42.6 ms eager, with one
+        or two streams inside the capture alike (profiles/r03i_upsample_graph_vs_eager.txt) — the replay pays ~1.5 us per node
+        that in-stream launches do not.  `sample_stochastic` (2 evaluations per graph at B = 64) gains from its graph."""
         kw = {**self.sampler_kwargs, **kwargs}
         num_steps = kw["num_steps"]
         device, dtype = self.example_param.device, self.example_param.dtype

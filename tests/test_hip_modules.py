@@ -181,14 +181,14 @@ def test_upsample_golden(golden_dir):
     m.load_state_dict(uncond_state_dict(p))
     m = m.cuda().eval()
     out = m.upsample(data.cuda(), n_new=c["n_new"], num_steps=c["num_steps"], num_substeps=c["num_substeps"],
-                     noise=cases.upsample_draw_list())
+                     noise=cases.upsample_draw_list(), use_graph=True)
     assert out.dtype == torch.float64
     _close(out, g["upsampled"], 2e-4)
-    # the captured outer-step graph (default) and the eager loop are the same launches: bit-identical clouds
+    # the captured outer-step graph and the eager loop (default) are the same launches: bit-identical clouds
     eager = m.upsample(data.cuda(), n_new=c["n_new"], num_steps=c["num_steps"], num_substeps=c["num_substeps"],
                        noise=cases.upsample_draw_list(), use_graph=False)
     assert torch.equal(out, eager)
-    out2 = m.upsample(data.cuda(), n_new=500, num_steps=4, num_substeps=2)  # generator path, many new points
+    out2 = m.upsample(data.cuda(), n_new=500, num_steps=4, num_substeps=2, use_graph=True)  # generator path, many new points
     assert out2.shape == (c["B"], 500, 3) and torch.isfinite(out2).all()
     out3 = m.upsample(data.cuda(), n_new=500, num_steps=4, num_substeps=2, use_graph=False)   # same seed, same draw order
     assert torch.equal(out2, out3)

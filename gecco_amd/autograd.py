@@ -86,6 +86,7 @@ class WeightImages:
         self.versions: dict[tuple, tuple] = {}
         self.pool: Tensor | None = None
         self.armed = False
+        self.fresh = False                      # prepare() ran and no grad-enabled forward has used its images yet
         self.recording = False
         self.step = 0                           # prepare() calls so far
         self.used: dict[tuple, int] = {}        # key -> the step it was last asked for (stale keys are dropped)
@@ -110,6 +111,16 @@ class WeightImages:
 
     def invalidate(self) -> None:
         self.armed = False
+
+    def begin_forward(self) -> None:
+        """Called at the start of every grad-enabled `Diffusion.forward`.  The images are valid for the weight values
+        `prepare()` saw, and writes through `param.data` (EMA weight swaps, hand-written updates) do not move the version
+        counter the lookups compare — so the images serve exactly ONE forward (and its backward): the first one after
+        `prepare()`.  Any other grad-enabled forward (a `model.loss(...)` outside `training_step`, a second model, a validation
+        loss computed with grad) disarms them and its linears make their images per call — always correct."""
+        if not self.fresh:
+            self.armed = False
+        self.fresh = False
 
     @torch.no_grad()
     def prepare(self) -> None:
@@ -151,6 +162,7 @@ class WeightImages:
         self.images = {key: self.pool[o:o + n] for key, (o, n) in offs.items()}
         self.versions = {key: tuple(w._version for w in ws) for key, ws in self.plan.items()}
         self.armed = True
+        self.fresh = True
 
 
 WEIGHT_IMAGES = WeightImages()

@@ -265,6 +265,9 @@ class Diffusion(_Base):
 
     def forward(self, data: Tensor, sigma: Tensor, raw_context: Any | None, post_context: Any | None = None,
                 do_cache: bool = False, cache: Any | None = None, out: Tensor | None = None) -> Tensor:
+        if torch.is_grad_enabled() and data.is_cuda:
+            from .autograd import WEIGHT_IMAGES
+            WEIGHT_IMAGES.begin_forward()   # batched weight images serve the one forward that follows prepare() (training_step)
         if post_context is None:
             post_context = self.conditioner(raw_context)
         return self.backbone(data, sigma, raw_context, post_context, do_cache, cache, out=out)

@@ -256,6 +256,8 @@ class BucketedGradAllReducer:
             b["pending"], b["launched"] = len(b["hooked"]), False
             b["seen"].clear()
         self._next = len(self.buckets) - 1
+        if self._collective() and hasattr(self.opt, "_missing_grad"):
+            self.opt._missing_grad = 0             # a gradient missing on this rank arrived with the sum over the ranks
         self.opt.grad_scale = 1.0 / self.world() if self.enabled else 1.0
 
     def remove(self) -> None:

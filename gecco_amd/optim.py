@@ -40,7 +40,7 @@ class FusedAdamEMA(torch.optim.Optimizer):
 
     def __init__(self, params: Iterable[Tensor] | Iterable[dict], lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, ema_decay: float | None = 0.9999, every_n_steps: int = 1,
-                 current_step: int = 0):
+                 current_step: int = 0, missing_grad: str = "raise"):
         if ema_decay is not None and not 0.0 <= ema_decay <= 1.0:
             raise ValueError("EMA decay value must be between 0 and 1")
         defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
@@ -56,6 +56,13 @@ class FusedAdamEMA(torch.optim.Optimizer):
         self._span_of: dict[int, tuple[int, int]] | None = None
         self._adam_step = 0
         self.grad_scale = 1.0                     # set by a summing gradient all-reduce to 1 / world_size
+        # A parameter whose .grad is None at step() (zero_grad(set_to_none=True) and no gradient arrived): torch.optim.Adam skips it;
+        # the one-launch update cannot.  "raise" (default) refuses the step, "zero" updates it with a zero gradient (moments decay,
+        # the step count advances).  With zero_grad() (views of the flat buffer) a missing gradient is indistinguishable from zeros.
+        if missing_grad not in ("raise", "zero"):
+            raise ValueError("missing_grad must be 'raise' or 'zero'")
+        self.missing_grad = missing_grad
+        self._missing_grad = 0
 
     # ------------------------------------------------------------------------------------------ flat storage
     def all_parameters(self) -> list[Tensor]:
@@ -166,6 +173,7 @@ class FusedAdamEMA(torch.optim.Optimizer):
             v = self._flat["g"][o:o + k].view(p.shape)
             if gr is None:
                 v.zero_()
+                self._missing_grad += 1
             else:
                 src.append(gr)
                 dst.append(v)
@@ -187,6 +195,14 @@ class FusedAdamEMA(torch.optim.Optimizer):
                 loss = closure()
         self._ensure()
         self._gather_foreign_grads()
+        if self._missing_grad and self.missing_grad != "zero":
+            n, self._missing_grad = self._missing_grad, 0
+            raise RuntimeError(
+                f"FusedAdamEMA.step(): {n} parameter(s) received no gradient this step.  torch.optim.Adam (and the reference's "
+                "EMAOptimizer around it) SKIPS such parameters; this optimizer's one-launch update over the flat buffers would "
+                "instead decay their moments, move them by stale momentum and advance their step count.  Freeze them "
+                "(requires_grad_(False)) before building the optimizer, or pass missing_grad='zero' to accept a zero gradient.")
+        self._missing_grad = 0
         g = self.param_groups[0]
         if len(self.param_groups) > 1 and any(
                 (h["lr"], h["betas"], h["eps"], h["weight_decay"]) != (g["lr"], g["betas"], g["eps"], g["weight_decay"])

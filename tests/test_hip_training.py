@@ -493,6 +493,70 @@ def test_batched_weight_images_leave_the_training_step_unchanged(monkeypatch):
         ag.WEIGHT_IMAGES.__init__()
 
 
+def test_weight_images_refuse_a_forward_after_a_data_write(monkeypatch):
+    """A write through `param.data` (the reference's EMA swap, ema.py:250-255, writes that way) does not move the version counter
+    the image lookups compare.  The batched images therefore serve only the forward that follows `prepare()`; a later grad-enabled
+    forward — here `model.loss` called directly after a `.data` update — must build its images per call: same loss and gradients as
+    a run without batched images."""
+    from gecco_amd import autograd as ag
+    from gecco_amd import hip_ops
+    from gecco_amd.optim import FusedAdamEMA
+    from gecco_amd.structs import Example
+    prev = hip_ops.default_precision()
+    hip_ops.set_default_precision("bf16x3")
+    try:
+        def run(cached):
+            monkeypatch.setenv("GECCO_WEIGHT_IMAGES", "1" if cached else "0")
+            ag.WEIGHT_IMAGES.__init__()
+            m = build_uncond(128, 2)
+            m.load_state_dict(uncond_state_dict(W.linear_lift_state_dict(11, 128, 2, 64, 8)), strict=True)
+            m = m.cuda().train()
+            opt = FusedAdamEMA(m.parameters(), lr=1e-3, ema_decay=0.9)
+            data = torch.randn(4, 256, 3, generator=torch.Generator().manual_seed(5)).cuda()
+            for it in range(2):                                  # the first step records the plan, the second one uses it
+                opt.zero_grad()
+                torch.manual_seed(100 + it)
+                m.training_step(Example(data, None), it).backward()
+                opt.step()
+            opt.zero_grad()
+            torch.manual_seed(7)
+            m.training_step(Example(data, None), 2).backward()   # arms the images for these weight values ...
+            w = next(p for n, p in m.named_parameters() if n.endswith("mlp.2.weight"))
+            w.data.mul_(1.02)                                    # ... which a .data write then changes: no version bump
+            opt.zero_grad()
+            torch.manual_seed(8)
+            loss = m.loss(m, data, None)                         # grad-enabled forward without prepare()
+            loss.backward()
+            return float(loss.detach()), opt.flat_grad().clone()
+        l0, g0 = run(False)
+        l1, g1 = run(True)
+        assert l0 == l1 and torch.equal(g0, g1)
+    finally:
+        hip_ops.set_default_precision(prev)
+        ag.WEIGHT_IMAGES.__init__()
+
+
+def test_fused_adam_refuses_a_parameter_without_gradient():
+    """torch.optim.Adam skips a parameter whose .grad is None; the one-launch update cannot, so it refuses (or, asked to,
+    takes a zero gradient) instead of silently decaying that parameter's moments."""
+    from gecco_amd.optim import FusedAdamEMA
+    a = torch.nn.Parameter(torch.ones(64, device="cuda"))
+    b = torch.nn.Parameter(torch.ones(64, device="cuda"))
+    opt = FusedAdamEMA([a, b], lr=1e-2, ema_decay=None)
+    opt.zero_grad(set_to_none=True)
+    (a * 2).sum().backward()
+    with pytest.raises(RuntimeError, match="no gradient"):
+        opt.step()
+    opt2 = FusedAdamEMA([torch.nn.Parameter(torch.ones(64, device="cuda")), torch.nn.Parameter(torch.ones(64, device="cuda"))],
+                        lr=1e-2, ema_decay=None, missing_grad="zero")
+    p0, p1 = opt2.all_parameters()
+    opt2.zero_grad(set_to_none=True)
+    (p0 * 2).sum().backward()
+    opt2.step()
+    torch.cuda.synchronize()
+    assert float(p0[0]) < 1.0 and float(p1[0]) == 1.0            # zero gradient, zero moments: the parameter does not move
+
+
 @pytest.mark.parametrize("kind", [1, 2, 3, 4])
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 def test_activation_backward_as_gemm_epilogue(kind, precision, monkeypatch):

@@ -51,6 +51,32 @@ __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&&
     (f(std::integral_constant<int, I>{}), ...);
 }
 
+// Diagnostic builds (tools/probe/h8areg_probe.hip): -DH8_STAMPS per-block s_memtime stamps; -DH8_DIAG_NOMFMA / _NOEPI
+#ifdef H8_STAMPS
+__device__ unsigned long long g_h8a_stamps[4096 * 4];
+#define ASTAMP(i)                                                                                               \
+    do {                                                                                                        \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) g_h8a_stamps[blockIdx.x * 4 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define ASTAMP(i)
+#endif
+#ifdef H8_DIAG_NOMFMA
+__device__ __forceinline__ f32x16 keep16(f16x8 a, f16x8 b, f32x16 c) {
+    asm volatile("" ::"v"(a), "v"(b));
+    return c;
+}
+__device__ __forceinline__ f32x16 keep8(i32x8 a, i32x8 b, f32x16 c) {
+    asm volatile("" ::"v"(a), "v"(b));
+    return c;
+}
+#define A_MFMA16(a, b, c) keep16(a, b, c)
+#define A_MFMA8(a, b, c, sa, sb) keep8(a, b, c)
+#else
+#define A_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define A_MFMA8(a, b, c, sa, sb) __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, sa, 0, sb)
+#endif
+
 // Vector-memory operations issued after the youngest one step t needs, up to (not including) step t's own issues — what
 // s_waitcnt vmcnt may leave in flight.  Steps t = 2 g (H stage of group g) and 2 g + 1 (L stage).  Issue order: prologue
 // P_0 .. P_{NS-2}, A_0 .. A_{D-1}; step u: P_{u+NS-1} (while it exists), and at the end of an L step A_{g+D} (while it exists).
@@ -74,6 +100,7 @@ __global__ __launch_bounds__(DNT, 2) void gemm_h8_areg_kernel(GemmArgs g) {
     static_assert(NS >= 3 && D >= 1 && D <= NGK, "ring / lookahead");
     constexpr int NST = 2 * NGK;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    ASTAMP(0);
     const dma::Tile T = dma::tile_of_block<128>(g);
     const int ct = T.ct, b = T.b, m0 = T.m0;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -123,7 +150,8 @@ __global__ __launch_bounds__(DNT, 2) void gemm_h8_areg_kernel(GemmArgs g) {
             }
     };
 
-    dma::wait_vm<young_at(0, NGK, NS, D) + AL * 0>();   // stage 0 (own pieces) and the younger ones' allowance: see young_at
+    dma::wait_vm<young_at(0, NGK, NS, D)>();
+    ASTAMP(1);   // stage 0 (own pieces) and the younger ones' allowance: see young_at
     // step 0 needs P_1 and A_0; the fragments of stage 0 itself need P_0 of every wave: older than both
     __builtin_amdgcn_s_barrier();
     load_f(smem, fbA);
@@ -133,7 +161,8 @@ __global__ __launch_bounds__(DNT, 2) void gemm_h8_areg_kernel(GemmArgs g) {
     static_for(std::make_integer_sequence<int, NST>{}, [&](auto TT) {
         constexpr int t = decltype(TT)::value, gq = t >> 1, set = gq % D;
         constexpr bool lst = (t & 1) != 0;
-        dma::wait_vm_lgkm0<young_at(t, NGK, NS, D)>();
+        constexpr int yv = young_at(t, NGK, NS, D);
+        dma::wait_vm_lgkm0<(yv > 63 ? 63 : yv)>();   // 6-bit field; the last step needs nothing: everything may stay in flight
 #pragma unroll
         for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(fbA[j]));
         __builtin_amdgcn_s_barrier();
@@ -147,7 +176,7 @@ __global__ __launch_bounds__(DNT, 2) void gemm_h8_areg_kernel(GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const i32x4 wc = c == 0 ? __builtin_shufflevector(fbA[j], fbA[j], 0, 1, 2, 3) : __builtin_shufflevector(fbA[j], fbA[j], 4, 5, 6, 7);
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ahi[set][c]), __builtin_bit_cast(f16x8, wc), acc[0][j], 0, 0, 0);
+                    acc[0][j] = A_MFMA16(__builtin_bit_cast(f16x8, ahi[set][c]), __builtin_bit_cast(f16x8, wc), acc[0][j]);
                 }
         } else {
             // Ah Wl: fp8(Ah) of the group, bytes in the image's k order (16 t + 8 c + e)
@@ -165,7 +194,7 @@ __global__ __launch_bounds__(DNT, 2) void gemm_h8_areg_kernel(GemmArgs g) {
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[0][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, fbA[j], acc[0][j], 0, 0, 0, 127, 0, 127 - 19);
+                acc[0][j] = A_MFMA8(a8, fbA[j], acc[0][j], 127, 127 - 19);
         }
         if constexpr (t + 1 < NST) load_f(smem + ((t + 1) % NS) * G_STAGE, fbA);
         if constexpr (!lst) {
@@ -174,7 +203,7 @@ __global__ __launch_bounds__(DNT, 2) void gemm_h8_areg_kernel(GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const i32x4 wc = c == 0 ? __builtin_shufflevector(fbB[j], fbB[j], 0, 1, 2, 3) : __builtin_shufflevector(fbB[j], fbB[j], 4, 5, 6, 7);
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ahi[set][2 + c]), __builtin_bit_cast(f16x8, wc), acc[0][j], 0, 0, 0);
+                    acc[0][j] = A_MFMA16(__builtin_bit_cast(f16x8, ahi[set][2 + c]), __builtin_bit_cast(f16x8, wc), acc[0][j]);
                 }
         } else {
             // Al W
@@ -186,14 +215,19 @@ __global__ __launch_bounds__(DNT, 2) void gemm_h8_areg_kernel(GemmArgs g) {
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[0][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(al8, fbB[j], acc[0][j], 0, 0, 0, 127 - 14, 0, 127 - 8);
+                acc[0][j] = A_MFMA8(al8, fbB[j], acc[0][j], 127 - 14, 127 - 8);
             // this group's A registers are free once its matrix instructions are issued: the loads of group gq + D
             if constexpr (gq + D < NGK) load_a(gq + D, set);
         }
     });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // ring is dead: the epilogue reuses it
+    ASTAMP(2);
+#ifdef H8_DIAG_NOEPI
+    if (acc[0][0][0] == 123.456f)
+#endif
     dma::epilogue<1, 4, 4>(g, T, acc, smem, wave, lane, wave, 0);
+    ASTAMP(3);
 }
 
 template <int NGK>

@@ -13,3 +13,9 @@ done
 /opt/rocm/bin/hipcc $F -DH8_STAMPS -DKVQ_NS=8 -DH8_DIAG_NOSTORE kvq_probe.hip -o kvq_NS8_NOSTORE &
 wait
 ls h8_* kvq_*
+F="--offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-function -Wno-unused-result"
+/opt/rocm/bin/hipcc $F -DH8_STAMPS h8areg_probe.hip -o h8areg_BASE &
+/opt/rocm/bin/hipcc $F -DH8_STAMPS -DH8_DIAG_NOMFMA h8areg_probe.hip -o h8areg_NOMFMA &
+/opt/rocm/bin/hipcc $F -DH8_STAMPS -DH8_DIAG_NOEPI h8areg_probe.hip -o h8areg_NOEPI &
+wait
+ls h8areg_*

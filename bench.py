@@ -12,10 +12,12 @@ torch.distributed.run around it) the script spawns the N ranks itself, as fresh 
 touches the GPU.
 
 Default arithmetic: `--precision mixed` — fp16 operands where their rounding does not reach the output (the
-kv_proj | q_proj activations with two-term fp16 weights, K | V, q, both attention products), split-bf16 (3 bf16
-MFMAs per product) for every product that feeds the residual stream or the shared inducer states — the fastest mode
-that holds BOTH outputs of the network (denoised D and raw F_x) within the 1e-3 parity bar with a >= 15x margin at
-every BASELINE shape (tests/test_hip_fullsize.py: F_x 3e-5 .. 9e-5).  `--precision bf16x3` is split-bf16 everywhere
+kv_proj | q_proj activations, K | V, q, both attention products; the V projection's weights carry an fp8 second term), and
+two terms on BOTH operands for every product that feeds the residual stream or the shared inducer states: out_proj and the
+point MLP as an fp16 main product plus two fp8 cross terms ("h8": 2 matrix-pipe units per product at split-bf16 accuracy,
+round 3), the 64-inducer chain in split-bf16 — the cheapest recipe of the per-site search (profiles/r03_precision_search.txt)
+that holds BOTH outputs of the network (denoised D and raw F_x) within the 1e-3 parity bar with a >= 10x margin at every
+BASELINE shape (tests/test_hip_fullsize.py: F_x 3e-5 .. 7e-5).  `--precision bf16x3` is split-bf16 everywhere
 (F_x 3e-5 .. 5e-5); `--precision fp16` is the faster opt-in mode: D within 1e-3 (2.5x margin) but F_x AT the bar
 (0.9e-3 .. 1.2e-3 at L=6, N=2048), so it is not the headline.
 
@@ -28,18 +30,19 @@ RayNetwork; C4 = BASELINE's data-parallel configuration: N = 4096, d = 512).  `-
 times one evaluation of the other BASELINE shapes (C5: the cached upsampling evaluation of 16 384 new points).
 
 Extra objects on that line:
-  roofline     — the dominant kernel of the measured mode.  mixed (default): mlp.0 (gemm_dma_kernel<3,true,true,128>: AdaGN
-                 prologue + split-bf16 product + GaussianActivation, 27 % of device time), bound "mfma" against 2500 / 3
-                 TFLOP/s of 2MNK, timed with HIP events inside hipGraph replays of the round out_proj -> mlp.0 -> mlp.2 on
-                 shared buffers ("round - round without that launch").  fp16 (opt-in): the fused point MLP
-                 (mlp_fused_f16_kernel, 35 % of device time), bound "mfma": 4 B N d 2d FLOP / its
-                 duration, where the duration is timed with HIP events around hipGraph replays of the
-                 layer's three point-stream launches (kernel launches only) as "round - round without
-                 that launch", so the kernel meets the cache state of the forward and no host launch
-                 gap is inside the timed region; the other two launches are priced against HBM in
-                 "hbm_side"; "traffic" = FETCH_SIZE x 2 + WRITE_SIZE of that kernel from the committed
-                 --pmc passes (profiles/).  bf16x3 / fp32: the LDS-DMA GEMM at its four call-site shapes.
-                 The rocprofv3 --kernel-trace --stats summary of this same command lives in profiles/.
+  roofline     — the dominant kernel of the measured mode.  mixed (default): mlp.0 on the A-stationary h8 kernel
+                 (gemm_h8_astat_kernel: AdaGN apply + fp16 main product + two fp8 cross terms + GaussianActivation, 20 % of device
+                 time), bound "mfma" against 2500 / 2 TFLOP/s of 2MNK (2 matrix-pipe units per product), its HBM side beside it
+                 ("hbm": the kernel sits at the ridge), timed with HIP events inside hipGraph replays of the round out_proj ->
+                 mlp.0 -> mlp.2 on shared buffers ("round - round without that launch"); "traffic" / "mfma_busy_pmc" = that
+                 kernel's FETCH_SIZE x 2 + WRITE_SIZE and matrix-pipe busy fraction from the committed --pmc passes
+                 (profiles/gemm_hbm_traffic.json <- profiles/r03h_forward_pmc_summary.txt); "whole" = the whole evaluation:
+                 executed matrix-pipe work / time / 2500 TFLOP/s and counter bytes / time / 8 TB/s.  fp16 (opt-in): the fused
+                 point MLP (mlp_fused_f16_kernel), same method.  bf16x3 / fp32: the LDS-DMA GEMM at its four call-site shapes.
+                 The rocprofv3 --kernel-trace --stats summary of the same model lives in profiles/.
+  train, configs, upsample — what else the tree does, measured by child processes of the default run (`--no-extras` skips
+                 them): the C2 training step with its dominant kernel's own roofline fraction, the C3 / C4 / C5 forward shapes,
+                 Diffusion.upsample per outer step (eager and captured).
   cpu_baseline — the oracle (plain PyTorch CPU restatement of the reference) on a bounded sample.
 """
 from __future__ import annotations
@@ -204,6 +207,34 @@ def split_bf16_round(ops, dev):
         ("out_proj+res", 2 * B * N * D * D, 3 * S, lambda: ops.linear(att, Wo, bo, residual=xw, out=xw, **pr)),
         ("mlp.0+act", 2 * B * N * D * 2 * D, S + 2 * S, lambda: ops.linear(xw, W1, b1, (pa, po), act_alpha=alpha, out=hid, **pr)),
         ("mlp.2+res", 2 * B * N * 2 * D * D, 2 * S + 2 * S, lambda: ops.linear(hid, W2, b2, residual=xw, out=xw, **pr)),
+    ]
+
+
+def h8_round(ops, dev):
+    """out_proj -> mlp.0 -> mlp.2 of one layer as the mixed mode runs them since round 3 (h8 arithmetic: fp16 main product + two fp8
+    cross terms): out_proj and mlp.2 on the register-fed kernel (gemm_h8_areg.hip) reading h8 activation images, mlp.0 on the
+    A-stationary kernel (gemm_h8_astat.hip) writing one — on SHARED buffers (x updated in place, the hidden image handed from
+    mlp.0 to mlp.2), image-ready calls = kernel launches only, so that inside a replayed round each launch meets the cache
+    state its predecessor leaves.  Entries: (name, 2MNK FLOPs, algorithmic HBM bytes, closure)."""
+    g = torch.Generator(device="cpu").manual_seed(2)
+    rn = lambda *s: torch.randn(*s, generator=g).to(dev)
+    xw = rn(B, N, D)
+    pa, po = 1 + 0.1 * rn(B, D), 0.1 * rn(B, D)
+    Wo, W1, W2 = rn(D, D) / 40, rn(2 * D, D) / 20, rn(D, 2 * D) / 56
+    bo, b1, b2 = rn(D) / 20, rn(2 * D) / 20, rn(D) / 20
+    alpha = torch.tensor(1.0, device=dev)
+    ws0, ws1, ws2 = (torch.empty(n, dtype=torch.uint8, device=dev) for n in (D * D * 4, 2 * D * D * 4, D * 2 * D * 4))
+    hid = ops.linear_h8_img(xw, (pa, po), W1, b1, act_alpha=alpha, wsplit=ws1, kind=2)          # (B, N / 128, 2D / 64, 24576) bytes
+    att = ops.linear_h8_img(xw, None, Wo, None, wsplit=ws0, kind=2)                              # stands in for the attention output image
+    st = torch.empty(B, N // 128, 2, D, device=dev)
+    ops.linear_h8_areg(att, Wo, bo, residual=xw, out=xw, wsplit=ws0)
+    ops.linear_h8_areg(hid, W2, b2, residual=xw, out=xw, wsplit=ws2)
+    S, S16 = B * N * D * 4, B * N * D * 3    # bytes of an fp32 (B, N, d) stream / of a d-wide h8 image
+    return [
+        ("out_proj+res (h8)", 2 * B * N * D * D, S16 + 2 * S, lambda: ops.linear_h8_areg(att, Wo, bo, residual=xw, out=xw, wsplit=ws0, image_ready=True)),
+        ("mlp.0+act (h8)", 2 * B * N * D * 2 * D, S + 2 * S16,
+         lambda: ops.linear_h8_img(xw, (pa, po), W1, b1, act_alpha=alpha, wsplit=ws1, image_ready=True, out=hid, kind=2)),
+        ("mlp.2+res (h8)", 2 * B * N * 2 * D * D, 2 * S16 + 2 * S, lambda: ops.linear_h8_areg(hid, W2, b2, residual=xw, out=xw, wsplit=ws2, image_ready=True)),
     ]
 
 
@@ -750,22 +781,21 @@ def main():
         "target_points_per_sec_per_gpu": 2.0e6,
     }
     mode = args.precision
-    rec["dtype"] = {"mixed": "bf16/f16 mixed (kv_proj|q_proj: fp16 activations x two-term fp16 weights, fp16 K|V, q and attention products; "
-                             "inducer chain, out_proj and the point MLP: split-bf16, 3 MFMAs per product; fp32 accumulate, residual stream and statistics)",
+    rec["dtype"] = {"mixed": "f16/fp8/bf16 mixed (kv_proj|q_proj: fp16 activations x fp16 weights, the V columns + an fp8 second weight term; fp16 K|V, q "
+                             "and attention products; out_proj and the point MLP: fp16 main product + two fp8 cross terms (h8, split-bf16 accuracy); "
+                             "inducer chain: split-bf16; fp32 accumulate, residual stream and statistics)",
                     "fp16": "f16 (fp16 operands, fp32 accumulate; fp16-stored intermediates, fp32 residual stream and statistics)",
                     "bf16x3": "bf16 (split hi+lo operands, 3 MFMAs per product, fp32 accumulate; fp32 activations in HBM)",
                     "fp32": "f32"}[mode]
     rec["config"]["workload"] = rec["config"]["workload"].replace(
-        "fp32 MFMA", {"fp16": "fp16 MFMA", "bf16x3": "split-bf16 MFMA", "fp32": "fp32 MFMA", "mixed": "mixed fp16 / split-bf16 MFMA"}[mode])
+        "fp32 MFMA", {"fp16": "fp16 MFMA", "bf16x3": "split-bf16 MFMA", "fp32": "fp32 MFMA", "mixed": "mixed fp16 / fp8-cross-term / split-bf16 MFMA"}[mode])
     if rank == 0 and not args.no_roofline:
-        site_mode = "bf16x3" if mode == "mixed" else mode   # mixed: the split-bf16 GEMM (out_proj, mlp.0, mlp.2) dominates
-        sites = gemm_call_sites(ops, dev, site_mode)
-        if mode == "mixed":
-            sites = sites[1:]                                # kv_proj | q_proj runs on the A-stationary fp16 kernel there
+        site_mode = "bf16x3" if mode == "mixed" else mode
+        sites = gemm_call_sites(ops, dev, site_mode) if mode != "mixed" else []   # mixed: its own round of h8 launches (h8_round)
         tot_f, tot_b, tot_ms, per = 0.0, 0.0, 0.0, {}
         # fp16 mode: kernel-only launches (images prepared) timed inside hipGraphs of the three-launch round
         seq_ms = None
-        if site_mode == "fp16":
+        if site_mode == "fp16" and mode != "mixed":
             times, seq_ms = time_in_sequence([fn for _, _, _, fn in sites])
         else:
             times = [time_events(fn, 10) for _, _, _, fn in sites]
@@ -774,8 +804,8 @@ def main():
             tot_f += fl
             tot_b += by
             tot_ms += t
-        tf = tot_f / (tot_ms * 1e-3) / 1e12
-        gbs = tot_b / (tot_ms * 1e-3) / 1e9
+        tf = tot_f / (tot_ms * 1e-3) / 1e12 if tot_ms else 0.0
+        gbs = tot_b / (tot_ms * 1e-3) / 1e9 if tot_ms else 0.0
         traffic = None
         tj = os.path.join(ROOT, "profiles", "gemm_hbm_traffic.json")
         if os.path.exists(tj):
@@ -805,13 +835,15 @@ def main():
                                          "images prepared); a launch's duration = plain round - round without that launch",
                                "per_site": per}
         elif mode == "mixed":
-            # The dominant kernel of the mixed mode is mlp.0 (AdaGN prologue + split-bf16 product + GaussianActivation, 27 % of
-            # the device time): 3 MFMAs per product -> matrix roof 2500 / 3 TFLOP/s of 2MNK; 77.3 GFLOP over 604 MB = 128 FLOP/B,
-            # above that roof's ridge of 104.  out_proj and mlp.2 run on the register-fed kernel (gemm_x3_areg.hip) whose A
-            # operand is an image only a producer epilogue writes: they cannot be launched stand-alone from here — their
-            # durations are in profiles/*_kernel_stats.csv; the stand-alone LDS-DMA forms are listed in per_site for scale.
-            mk = "mlp.0+act"
-            rsites = split_bf16_round(ops, dev)
+            # The dominant kernel of the mixed mode since round 3 is mlp.0 on the A-stationary h8 kernel (gemm_h8_astat_kernel: AdaGN
+            # apply + fp16 main product + two fp8 cross terms + GaussianActivation, writes the h8 activation image; 20 % of the device
+            # time, profiles/r03g_fwd_kernel_stats_one_stream.csv).  Its product executes 2 matrix-pipe units (one 16-bit instruction
+            # stream + two fp8 streams at twice the rate), so its matrix roof is 2500 / 2 TFLOP/s of 2MNK; 77.3 GFLOP x 2 over 503 MB
+            # = 307 unit-FLOP/B, at the ridge of 2500 TF / 8 TB/s = 312: both roofs are reported, `bound` names the matrix side the
+            # counters show busier (0.36 of the cycles against 0.33 of 8 TB/s).  Timed live with HIP events inside hipGraph replays of
+            # the round out_proj -> mlp.0 -> mlp.2 (all three on their h8 kernels, shared buffers): round - round without it.
+            mk = "mlp.0+act (h8)"
+            rsites = h8_round(ops, dev)
             rtimes, round_ms = time_in_sequence([fn for _, _, _, fn in rsites])
             per = {name: {"ms": round(t, 4), "tflops": round(fl / (t * 1e-3) / 1e12, 2), "gbs": round(by / (t * 1e-3) / 1e9, 1)}
                    for (name, fl, by, fn), t in zip(rsites, rtimes)}
@@ -819,21 +851,19 @@ def main():
             mtf = per[mk]["tflops"]
             mb = [by for name, fl, by, fn in rsites if name == mk][0]
             tjd = json.load(open(tj)).get("mixed", {}) if os.path.exists(tj) else {}
-            traffic = tjd.get("bytes_per_launch")
-            rec["roofline"] = {"bound": "mfma", "achieved": mtf, "peak": PEAK_BF16_MFMA_TFLOPS / 3, "unit": "TFLOP/s",
-                               "frac": 3 * mtf / PEAK_BF16_MFMA_TFLOPS, "traffic": traffic,
-                               # cycle-based view of the same kernel (committed PMC constant, not measured in this run): the share
-                               # of SIMD cycles the matrix pipe is busy — above `frac`, which prices wall time against the
-                               # 2.4 GHz peak: the chip clocks down under sustained MFMA load
-                               "mfma_busy_pmc": tjd.get("mfma_busy"),
-                               "kernel": "gemm_dma_kernel<3,true,true,128> = mlp.0 (LDS-DMA ring, AdaGN prologue on the A fragment, "
-                                         "3 x v_mfma_f32_32x32x16_bf16 per product, GaussianActivation epilogue), one launch over the whole batch on one "
-                                         "stream (what GECCO_FWD_STREAMS=1 runs and profiles/r02zc_bench_kernel_stats.csv shows; the default evaluation "
-                                         "issues it for two half batches on two streams, where kernel durations overlap); achieved = 2MNK / "
-                                         "its duration inside hipGraph replays of the round out_proj -> mlp.0 -> mlp.2 on shared "
-                                         "buffers (HIP events; round - round without it), peak = dense bf16 MFMA peak (2500 TFLOP/s) "
-                                         "/ 3 MFMAs per product; traffic = FETCH_SIZE x 2 + WRITE_SIZE of that kernel in the forward "
-                                         "(profiles/r02m_forward_pmc_summary.txt: a committed constant, not measured in this run)",
+            pk = tjd.get("per_kernel", {})
+            kk = next((v for k, v in pk.items() if k.startswith("gemm_h8_astat_kernel")), {})
+            rec["roofline"] = {"bound": "mfma", "achieved": mtf, "peak": PEAK_BF16_MFMA_TFLOPS / 2, "unit": "TFLOP/s",
+                               "frac": 2 * mtf / PEAK_BF16_MFMA_TFLOPS, "traffic": kk.get("bytes_per_launch"),
+                               # cycle-based view of the same kernel (committed PMC constant, not measured in this run)
+                               "mfma_busy_pmc": kk.get("mfma_busy"),
+                               "kernel": "gemm_h8_astat_kernel<6,4,6,1,true> = mlp.0 of the mixed mode (A-stationary over 128-row blocks, AdaGN apply, "
+                                         "v_mfma_f32_32x32x16_f16 + 2 x v_mfma_scale_f32_32x32x64_f8f6f4 per 64 k, GaussianActivation, h8 activation image "
+                                         "out), one launch over the whole batch on one stream; achieved = 2MNK / its duration inside hipGraph replays of "
+                                         "the round out_proj -> mlp.0 -> mlp.2 on shared buffers (HIP events; round - round without it); peak = dense "
+                                         "16-bit MFMA peak (2500 TFLOP/s) / 2 matrix-pipe units per product; traffic / mfma_busy_pmc = FETCH_SIZE x 2 + "
+                                         "WRITE_SIZE and SQ_VALU_MFMA_BUSY_CYCLES of that kernel in the forward (" + str(tjd.get("source")) + ": committed "
+                                         "constants, not measured in this run)",
                                "hbm": {"achieved_gbs_algorithmic": mb / (per[mk]["ms"] * 1e-3) / 1e9, "peak_gbs": PEAK_HBM_GBS,
                                        "frac": mb / (per[mk]["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS},
                                "per_site": per}
@@ -871,6 +901,8 @@ def main():
                 "ms_per_step": ms_o, "points_per_sec": B * N / (ms_o * 1e-3), "launch": "eager",
                 "parity_vs_fp32_reference": {"fp16": "D ~4e-4, F_x ~1e-3 (at the bar; tests/test_hip_fullsize.py)",
                                              "mixed": "D ~2e-5, F_x ~6e-5", "bf16x3": "D ~2e-5, F_x ~5e-5", "fp32": "~1e-6"}[other]}
+        rec["parity_vs_fp32_reference"] = {"mixed": "D ~2e-5, F_x 3e-5 .. 7e-5 on C2 - C5 and the L = 8 / 10 / 14 networks (tests/test_hip_fullsize.py; bar 1e-3)",
+                                           "fp16": "D ~4e-4, F_x ~1e-3", "bf16x3": "D ~2e-5, F_x ~5e-5", "fp32": "~1e-6"}[mode]
         ops.set_default_precision(mode)
         if not args.eager:   # the eager loop of the headline mode, for the record
             for _ in range(2):

@@ -304,8 +304,25 @@ __global__ void split_f16_tiled_kernel(const float* __restrict__ W, float* __res
         f16_image_item(W, img, Nout, K, ldw, i);
 }
 
+// Two-term fp16 weights for a kernel that walks ONE stream (inducer_chain_f16.hip with TWO): per 128-column tile the NK blocks of
+// fp16(W), then the NK blocks of fp16(W - fp16(W)) — block (2 ct + lo) nk + kt of the stream is block ct nk + kt of that image
+__device__ __forceinline__ void f16_image_item_hilo(const float* __restrict__ W, float* __restrict__ img, int Nout, int K, int ldw, size_t i) {
+    const int nk = K / FBK;
+    const size_t blk2 = i >> 9;
+    const int idx = (int)(blk2 % (2 * nk)), ct = (int)(blk2 / (2 * nk)), lo = idx >= nk, kt = idx % nk;
+    const size_t src_item = (((size_t)ct * nk + kt) << 9) | (i & 511);
+    // the plain item writes to img + (ct nk + kt) FB_TILE: shift the base so that it lands on block blk2
+    f16_image_item(W, img + ((ptrdiff_t)blk2 - (ptrdiff_t)((size_t)ct * nk + kt)) * FB_TILE, Nout, K, ldw, src_item, lo);
+}
+
 __global__ void split_f16_tiled_multi_kernel(SplitJobs jobs) {
     const SplitJob j = jobs.job[blockIdx.y];
+    if (j.pad_ == 8) {
+        const size_t total2 = (size_t)((j.Nout + DBN - 1) / DBN) * (j.K / FBK) * 1024;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total2; i += (size_t)gridDim.x * blockDim.x)
+            f16_image_item_hilo(j.W, j.img, j.Nout, j.K, j.ldw, i);
+        return;
+    }
     if (j.pad_ == 2) {
         const size_t total8 = (size_t)((j.Nout + DBN - 1) / DBN) * (j.K / 64) * 512;
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (size_t)gridDim.x * blockDim.x)

@@ -90,12 +90,18 @@ __device__ unsigned long long g_chain_stamps[256 * 16];
 #define CSTAMP(i)
 #endif
 
-template <int NT1, int NH>
+// TWO (the mixed mode, option "chain2"): two-term fp16 weights W = fp16(W) + fp16(W - fp16(W)).  The stream carries, per column
+// tile, the NK blocks of the hi image and then the NK blocks of the lo image (f16_image_item_hilo); a tile's K pass simply runs
+// twice over the same A operand, into the same accumulator: x . W_hi + x . W_lo.  The rounding of the WEIGHTS — the same for
+// every point of a cloud, the part of this chain's fp16 error that reaches the output (tools/experiments/precision_search.py:
+// chain = x2a holds F_x at 1.0e-4 .. 1.3e-4, chain = fp16 at 5e-4) — drops from 2^-12 to 2^-23; the activations stay one-term.
+template <int NT1, int NH, bool TWO>
 __global__ __launch_bounds__(CH_NT, 1) void inducer_chain_f16_kernel(ChainArgs g) {
     constexpr int C = 128 * NT1, WD = C * NH, NTW = NT1 * NH, NT2 = 2 * NT1;
     constexpr int NK = C / 32;                  // weight blocks (32 k) per column tile of a K = C operand
     constexpr int RS = 2 * C + 16;              // bytes per A row: 16 B of padding -> conflict-free ds_read_b128
-    constexpr int S1 = NT1 * NK, S2 = NTW * NK, S3 = NTW * NK, S4 = NT2 * NK;
+    constexpr int WT = TWO ? 2 : 1;             // K passes (weight terms) per column tile
+    constexpr int S1 = WT * NT1 * NK, S2 = WT * NTW * NK, S3 = WT * NTW * NK, S4 = WT * NT2 * NK;
     constexpr int S_TOTAL = S1 + S2 + S3 + S4;
     constexpr int NS = chain_ns(C, WD);
     constexpr int AHEAD = NS - 4;               // DMA pieces (one per block per wave) that may stay in flight at a wait
@@ -344,9 +350,17 @@ __global__ __launch_bounds__(CH_NT, 1) void inducer_chain_f16_kernel(ChainArgs g
     };
     // the NK blocks of one column tile; first: the A operand is new (prime the pipeline); more: another tile over
     // the same A operand follows
-    auto run_tile = [&](f32x16& a0, bool first, bool more) {
+    auto run_pass = [&](f32x16& a0, bool first, bool more) {
         if (s + NK + NS > S_TOTAL) tile_steps(std::true_type{}, first, more, a0);
         else tile_steps(std::false_type{}, first, more, a0);
+    };
+    auto run_tile = [&](f32x16& a0, bool first, bool more) {
+        if (TWO) {   // hi pass, then the lo pass over the same A operand
+            run_pass(a0, first, true);
+            run_pass(a0, false, more);
+        } else {
+            run_pass(a0, first, more);
+        }
     };
     auto zero = [](f32x16& a) {
 #pragma unroll
@@ -515,18 +529,22 @@ __global__ __launch_bounds__(CH_NT, 1) void inducer_chain_f16_kernel(ChainArgs g
     CSTAMP(10);
 }
 
-template <int NT1, int NH>
-int chain_launch_t(const ChainArgs& g, hipStream_t st) {
+template <int NT1, int NH, bool TWO>
+int chain_launch_w(const ChainArgs& g, hipStream_t st) {
     constexpr int C = 128 * NT1, WD = C * NH;
     constexpr size_t lds = chain_lds_bytes(C, WD);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(inducer_chain_f16_kernel<NT1, NH>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(inducer_chain_f16_kernel<NT1, NH, TWO>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    hipLaunchKernelGGL((inducer_chain_f16_kernel<NT1, NH>), dim3(g.B), dim3(CH_NT), lds, st, g);
+    hipLaunchKernelGGL((inducer_chain_f16_kernel<NT1, NH, TWO>), dim3(g.B), dim3(CH_NT), lds, st, g);
     return (int)hipGetLastError();
+}
+template <int NT1, int NH>
+int chain_launch_t(const ChainArgs& g, hipStream_t st) {
+    return g.two_term ? chain_launch_w<NT1, NH, true>(g, st) : chain_launch_w<NT1, NH, false>(g, st);
 }
 
 }  // namespace

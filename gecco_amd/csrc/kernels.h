@@ -59,7 +59,7 @@ struct GemmArgs {
     int h8_stagger, h8_pair;   // gemm_h8_astat.hip: start offset of every second block of a CU (set by its launcher)
 };
 
-struct SplitJob { const float* W; float* img; int Nout, K, ldw, pad_; };   // pad_ = 1 (fp16 images): the LOW part fp16(W - fp16(W)); 2: the same as fp8 x 2^19 in 64-k blocks; 4 (bf16 images): W is (K, ldw) and the image is of W^T
+struct SplitJob { const float* W; float* img; int Nout, K, ldw, pad_; };   // pad_ = 1 (fp16 images): the LOW part fp16(W - fp16(W)); 2: the same as fp8 x 2^19 in 64-k blocks; 8: hi | lo blocks interleaved per column tile; 4 (bf16 images): W is (K, ldw) and the image is of W^T
 struct SplitJobs { SplitJob job[96]; int n; };   // 3 KiB of kernel arguments
 int gemm_row_tile(int rows);  // row-tile height the GEMM uses for `rows` rows per sample
 int gemm_f32_launch(const GemmArgs& g, hipStream_t st);
@@ -84,6 +84,7 @@ struct ChainArgs {
     const float* part_ml;     // (B, H, nsplit, 64, 2)
     int nsplit, H;
     const float* w_stream;    // fp16 tiled images of pool.out_proj | mlp.0 | mlp.2 | unpool k|v, back to back
+    int two_term;             // the images carry hi | lo blocks per column tile (SplitJob::pad_ = 8): two-term weights (mixed mode)
     const float *b0, *b2, *bkv, *alpha;
     int act;
     const float *n1_scale_w, *n1_scale_b, *n1_bias_w, *n1_bias_b;

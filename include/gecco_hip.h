@@ -101,10 +101,13 @@ int gecco_linear_f32(const float* A, const float* W, const float* bias, const fl
  *   "h8areg" (default 1): mixed mode hands the MLP hidden layer and the unpool attention output on as h8 activation images
  *   (fp16 hi + fp8 lo, 3 bytes per element) and runs mlp.2 / out_proj as h8 products (gecco_linear_h8_areg_f32) instead of
  *   split-bf16 products on tiled split images: 2 instead of 3 matrix-pipe units per product, same accuracy (needs "h8").
+ *   "chain2" (default 1): mixed mode runs the 64-inducer chain of a layer (pool merge .. unpool k|v) as the ONE launch of the fp16
+ *   mode with two-term fp16 weights (hi | lo blocks per column tile) instead of five 64-row split-bf16 GEMMs + their AdaGN
+ *   coefficient launches: 16 -> 9 launches per layer; F_x 6e-5 -> ~1e-4 (its activations are rounded to fp16 once).
  *   "kvq64" (default 1): mixed mode runs kv_proj | q_proj on the 64-column-tile A-stationary kernel (gecco_linear_kvq_f16; needs
  *   "headmajor") instead of the 128-column-tile one (gecco_linear_astat_f16 + lo image): same arithmetic, also at feature_dim 512.
  * value < 0 returns the option to its default / environment (GECCO_ASTAT, GECCO_CHAIN, GECCO_HEADMAJOR, GECCO_MLPFUSED,
- * GECCO_UNPOOLFUSED, GECCO_LO8, GECCO_ACTIMG, GECCO_H8, GECCO_KVQ64, GECCO_H8AREG).
+ * GECCO_UNPOOLFUSED, GECCO_LO8, GECCO_ACTIMG, GECCO_H8, GECCO_KVQ64, GECCO_H8AREG, GECCO_CHAIN2).
  * Process-wide. */
 int gecco_set_option(const char* name, int value);
 

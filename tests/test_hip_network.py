@@ -321,6 +321,33 @@ def test_mixed_h8_mlp0_matches_split_bf16_mlp0(ops, golden_dir, name):
         assert not torch.equal(raw[0], raw[1]), "the h8 form did not run"
 
 
+@pytest.mark.parametrize("name", list(cases.UNCOND_CASES))
+def test_mixed_two_term_chain_matches_split_bf16_chain(ops, golden_dir, name):
+    """Mixed mode: the 64-inducer chain of a layer as ONE launch with two-term fp16 weights (option "chain2",
+    inducer_chain_f16_kernel<.., TWO>: pool merge, pool.out_proj, norm_1, broadcast.mlp, norm_2, unpool k|v —
+    models/set_transformer.py:99-117) against five 64-row split-bf16 GEMMs: both within the bar of the reference's golden
+    output, close to each other (the chain's activations are rounded to fp16 once: ~1e-4 on F_x), and a cached evaluation
+    (which skips the chain and reads the split-bf16 k|v image) still works beside it."""
+    p, x, sigma = cases.uncond_inputs(name)
+    g = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    net = ops.LinearLiftPlan(_cuda(p), cases.H, cases.I, precision="mixed")
+    out, raw = {}, {}
+    try:
+        for on in (0, 1):
+            ops.set_option("chain2", on)
+            d, r = net.forward(x.cuda(), sigma.cuda(), return_raw=True)
+            out[on], raw[on] = d.cpu(), r.cpu()
+        _, cache = net.forward(x.cuda(), sigma.cuda(), do_cache=True)          # chain2 on: the cache it produces ...
+        again = net.forward(x.cuda(), sigma.cuda(), cache=cache).cpu()         # ... and a cached evaluation of the same points
+    finally:
+        ops.set_option("chain2", -1)
+    for on in (0, 1):
+        assert cpu_ref.rel_err(out[on], torch.from_numpy(g["denoised"]))[0] <= 2e-4, on
+    e = cpu_ref.rel_err(raw[1], raw[0])
+    assert 0 < e[0] <= 3e-4, e
+    assert cpu_ref.rel_err(again, out[1])[0] <= 2e-4
+
+
 def test_split_bf16_linear_accuracy(ops):
     """The split itself: products with operands spanning 8 orders of magnitude keep ~2^-16 relative accuracy."""
     import ctypes as C

@@ -15,9 +15,9 @@ Default arithmetic: `--precision mixed` — fp16 operands where their rounding d
 kv_proj | q_proj activations, K | V, q, both attention products; the V projection's weights carry an fp8 second term), and
 two terms on BOTH operands for every product that feeds the residual stream or the shared inducer states: out_proj and the
 point MLP as an fp16 main product plus two fp8 cross terms ("h8": 2 matrix-pipe units per product at split-bf16 accuracy,
-round 3), the 64-inducer chain in split-bf16 — the cheapest recipe of the per-site search (profiles/r03_precision_search.txt)
+round 3), the 64-inducer chain with two-term fp16 weights — the cheapest recipe of the per-site search (profiles/r03_precision_search.txt)
 that holds BOTH outputs of the network (denoised D and raw F_x) within the 1e-3 parity bar with a >= 10x margin at every
-BASELINE shape (tests/test_hip_fullsize.py: F_x 3e-5 .. 7e-5).  `--precision bf16x3` is split-bf16 everywhere
+BASELINE shape (tests/test_hip_fullsize.py: F_x 5e-5 .. 8e-5; <= 1.6e-4 on 14-layer networks).  `--precision bf16x3` is split-bf16 everywhere
 (F_x 3e-5 .. 5e-5); `--precision fp16` is the faster opt-in mode: D within 1e-3 (2.5x margin) but F_x AT the bar
 (0.9e-3 .. 1.2e-3 at L=6, N=2048), so it is not the headline.
 
@@ -36,7 +36,7 @@ Extra objects on that line:
                  ("hbm": the kernel sits at the ridge), timed with HIP events inside hipGraph replays of the round out_proj ->
                  mlp.0 -> mlp.2 on shared buffers ("round - round without that launch"); "traffic" / "mfma_busy_pmc" = that
                  kernel's FETCH_SIZE x 2 + WRITE_SIZE and matrix-pipe busy fraction from the committed --pmc passes
-                 (profiles/gemm_hbm_traffic.json <- profiles/r03h_forward_pmc_summary.txt); "whole" = the whole evaluation:
+                 (profiles/gemm_hbm_traffic.json <- profiles/r03p_forward_pmc_summary.txt); "whole" = the whole evaluation:
                  executed matrix-pipe work / time / 2500 TFLOP/s and counter bytes / time / 8 TB/s.  fp16 (opt-in): the fused
                  point MLP (mlp_fused_f16_kernel), same method.  bf16x3 / fp32: the LDS-DMA GEMM at its four call-site shapes.
                  The rocprofv3 --kernel-trace --stats summary of the same model lives in profiles/.
@@ -511,8 +511,8 @@ def executed_mfma_flops(mode, Bc=B, Nc=N, d=D, Ll=L):
         u = kv + q + outp + m0 + m2 + attn + chain
     elif mode == "bf16x3":
         u = 3 * (kv + q + outp + m0 + m2 + attn + chain)
-    else:   # mixed: K, q one fp16 term; V fp16 + fp8 lo term (1.5); attention fp16; chain, out_proj, mlp.2 split-bf16; mlp.0 h8 (2)
-        u = 0.5 * kv * (1 + 1.5) + q + attn + 3 * chain + 3 * outp + 2 * m0 + 3 * m2
+    else:   # mixed: K, q one fp16 term; V fp16 + fp8 lo term (1.5); attention fp16; chain two-term fp16 weights (2); out_proj, mlp.0, mlp.2 h8 (2)
+        u = 0.5 * kv * (1 + 1.5) + q + attn + 2 * chain + 2 * outp + 2 * m0 + 2 * m2
     return Bc * Ll * u
 
 
@@ -783,7 +783,7 @@ def main():
     mode = args.precision
     rec["dtype"] = {"mixed": "f16/fp8/bf16 mixed (kv_proj|q_proj: fp16 activations x fp16 weights, the V columns + an fp8 second weight term; fp16 K|V, q "
                              "and attention products; out_proj and the point MLP: fp16 main product + two fp8 cross terms (h8, split-bf16 accuracy); "
-                             "inducer chain: split-bf16; fp32 accumulate, residual stream and statistics)",
+                             "inducer chain: fp16 activations x two-term fp16 weights; fp32 accumulate, residual stream and statistics)",
                     "fp16": "f16 (fp16 operands, fp32 accumulate; fp16-stored intermediates, fp32 residual stream and statistics)",
                     "bf16x3": "bf16 (split hi+lo operands, 3 MFMAs per product, fp32 accumulate; fp32 activations in HBM)",
                     "fp32": "f32"}[mode]
@@ -837,7 +837,7 @@ def main():
         elif mode == "mixed":
             # The dominant kernel of the mixed mode since round 3 is mlp.0 on the A-stationary h8 kernel (gemm_h8_astat_kernel: AdaGN
             # apply + fp16 main product + two fp8 cross terms + GaussianActivation, writes the h8 activation image; 20 % of the device
-            # time, profiles/r03g_fwd_kernel_stats_one_stream.csv).  Its product executes 2 matrix-pipe units (one 16-bit instruction
+            # time, profiles/r03p_fwd_kernel_stats_one_stream.csv).  Its product executes 2 matrix-pipe units (one 16-bit instruction
             # stream + two fp8 streams at twice the rate), so its matrix roof is 2500 / 2 TFLOP/s of 2MNK; 77.3 GFLOP x 2 over 503 MB
             # = 307 unit-FLOP/B, at the ridge of 2500 TF / 8 TB/s = 312: both roofs are reported, `bound` names the matrix side the
             # counters show busier (0.36 of the cycles against 0.33 of 8 TB/s).  Timed live with HIP events inside hipGraph replays of
@@ -901,7 +901,7 @@ def main():
                 "ms_per_step": ms_o, "points_per_sec": B * N / (ms_o * 1e-3), "launch": "eager",
                 "parity_vs_fp32_reference": {"fp16": "D ~4e-4, F_x ~1e-3 (at the bar; tests/test_hip_fullsize.py)",
                                              "mixed": "D ~2e-5, F_x ~6e-5", "bf16x3": "D ~2e-5, F_x ~5e-5", "fp32": "~1e-6"}[other]}
-        rec["parity_vs_fp32_reference"] = {"mixed": "D ~2e-5, F_x 3e-5 .. 7e-5 on C2 - C5 and the L = 8 / 10 / 14 networks (tests/test_hip_fullsize.py; bar 1e-3)",
+        rec["parity_vs_fp32_reference"] = {"mixed": "D ~3e-5, F_x 5e-5 .. 8e-5 on C2 - C5, <= 1.6e-4 on the L = 8 / 10 / 14 networks (tests/test_hip_fullsize.py; bar 1e-3)",
                                            "fp16": "D ~4e-4, F_x ~1e-3", "bf16x3": "D ~2e-5, F_x ~5e-5", "fp32": "~1e-6"}[mode]
         ops.set_default_precision(mode)
         if not args.eager:   # the eager loop of the headline mode, for the record

@@ -310,7 +310,9 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
     // mixed mode: the same one-launch chain with TWO-TERM fp16 weights (option "chain2") instead of five 64-row split-bf16 GEMMs
     // and their coefficient launches: the chain's activation rounding does not reach the output, its weight rounding does
     // (tools/experiments/precision_search.py: chain = x2a keeps F_x at 1.0e-4 .. 1.3e-4)
-    const bool chain2_on = mixed && w.wimg && option(OPT_CHAIN2) && inducer_chain_f16_supported(C, Wd, H, G, I) &&
+    // feature_dim <= 384: at 512 one block per sample streams 7 MB of weights through one CU and loses to the five launches
+    // (C4, B = 32: 10.25 vs 10.03 ms per evaluation)
+    const bool chain2_on = mixed && w.wimg && option(OPT_CHAIN2) && C <= 384 && inducer_chain_f16_supported(C, Wd, H, G, I) &&
                            (ns == 1 || ns == 2 || ns == 4 || ns == 8) && (act >= 0 && act <= 3);
     if (pr >= 1 && w.wimg && !(C % kmod) && !(Wd % kmod)) {
         // split-bf16 mode: every N-token weight of every layer becomes its tiled hi | lo image in ONE launch per

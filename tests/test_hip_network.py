@@ -254,7 +254,7 @@ def test_mixed_fp8_lo_term_matches_fp16_lo_term(ops, golden_dir, name):
         ops.set_option("lo8", -1)
         ops.set_option("kvq64", -1)
     e = cpu_ref.rel_err(out[1], out[0])
-    assert e[0] <= 3e-5, e
+    assert e[0] <= 6e-5, e
     e2 = cpu_ref.rel_err(out[2], out[0])
     assert e2[0] <= 6e-5, e2   # the fp8 second term moves the output by ~2^-15; through the fp16-activation chain ~4e-5
     assert cpu_ref.rel_err(out[2], torch.from_numpy(g["denoised"]))[0] <= 2e-4

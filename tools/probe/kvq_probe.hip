@@ -3,11 +3,13 @@
 #include <hip/hip_runtime.h>
 #include "../../gecco_amd/csrc/gemm_h8_astat.hip"
 #include <stdio.h>
+#include <algorithm>
 #include <vector>
 
 int main(int argc, char** argv) {
     const int B = 64, N = 2048, K = 384, N1 = 768, N2 = 384, hd = 48;
     const int lo = argc > 1 ? atoi(argv[1]) : 1;
+    const int zero = argc > 2 ? atoi(argv[2]) : 0;   // 1: all-zero x and weights (the clock a kernel reaches depends on operand toggling)
     float *A, *W, *pa, *po, *bias, *img; _Float16 *C1, *C2;
     (void)hipMalloc(&A, (size_t)B * N * K * 4); (void)hipMalloc(&W, (size_t)(N1 + N2) * K * 4); (void)hipMalloc(&img, (size_t)(N1 + N2) * K * 4);
     (void)hipMalloc(&C1, (size_t)B * N * N1 * 2); (void)hipMalloc(&C2, (size_t)B * N * N2 * 2);
@@ -15,6 +17,7 @@ int main(int argc, char** argv) {
     std::vector<float> h((size_t)B * N * K);
     unsigned long long s = 88172645463325252ull;
     for (size_t i = 0; i < h.size(); ++i) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; h[i] = (float)((double)(s >> 11) / 9007199254740992.0 * 4.0 - 2.0); }
+    if (zero) std::fill(h.begin(), h.end(), 0.f);
     (void)hipMemcpy(A, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     for (size_t i = 0; i < (size_t)(N1 + N2) * K; ++i) h[i] *= 0.05f;
     (void)hipMemcpy(W, h.data(), (size_t)(N1 + N2) * K * 4, hipMemcpyHostToDevice);

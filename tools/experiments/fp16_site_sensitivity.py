@@ -37,6 +37,26 @@ def r8(x):
     return (x * sc).to(torch.float8_e4m3fn).float() / sc
 
 
+def rmx(x, mant_bits, emax, block=32):
+    """block-scaled low-precision rounding (OCP MX style): along the last dim in blocks of `block`, a power-of-two scale puts the
+    block's max at the format's top binade; elements keep `mant_bits` mantissa bits (implicit one) over an exponent range of
+    2^emax .. 2^0 (below: fixed-point steps of 2^-mant_bits).  mant_bits 1, emax 2 = fp4 e2m1; 3, 2 = fp6 e2m3; 2, 4 = fp6 e3m2."""
+    shp = x.shape
+    K = shp[-1]
+    pad = (-K) % block
+    xp = torch.nn.functional.pad(x, (0, pad)) if pad else x
+    xb = xp.reshape(*xp.shape[:-1], -1, block)
+    m = xb.abs().amax(-1, keepdim=True).clamp_min(1e-30)
+    sc = 2.0 ** (torch.floor(torch.log2(m)) - emax)
+    y = xb / sc
+    e = torch.floor(torch.log2(y.abs().clamp_min(2.0 ** -20))).clamp_min(0.0)       # binade (>= 0: below 1 the step is fixed)
+    step = 2.0 ** (e - mant_bits)
+    y = torch.round(y / step) * step
+    top = (2.0 - 2.0 ** -mant_bits) * 2.0 ** emax
+    y = y.clamp(-top, top) * sc
+    return y.reshape(xp.shape)[..., :K].reshape(shp)
+
+
 def product(a, b_t, scheme, mm):
     """a @ b_t-ish product through `mm(a, b)` with operands per `scheme`."""
     if scheme == "exact":
@@ -71,6 +91,11 @@ def product(a, b_t, scheme, mm):
     if scheme == "h8":     # fp16 main product + both cross terms on fp8 (e4m3) operands, power-of-two tensor scales
         ah, bh = r16(a), r16(b_t)
         return mm(ah, bh) + mm(r8(a - ah), r8(b_t)) + mm(r8(a), r8(b_t - bh))
+    if scheme in ("h4", "h6", "h6b"):   # fp16 main product + both cross terms on block-scaled fp4 (e2m1) / fp6 (e2m3 / e3m2) operands
+        mb, em = {"h4": (1, 2), "h6": (3, 2), "h6b": (2, 4)}[scheme]
+        ah, bh = r16(a), r16(b_t)
+        q = lambda t: rmx(t, mb, em)
+        return mm(ah, bh) + mm(q(a - ah), q(b_t)) + mm(q(a), q(b_t - bh))
     if scheme == "h8w":    # A rounded once (fp16), W = fp16 hi + fp8 lo: 1.5 MFMA units
         bh = r16(b_t)
         return mm(r16(a), bh) + mm(r8(a), r8(b_t - bh))

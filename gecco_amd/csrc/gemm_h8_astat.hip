@@ -18,13 +18,13 @@
 // — the cross terms are 2^-12 of the product, so 4 significant bits of them suffice: 2 matrix-pipe units per product
 // instead of the 3 of split-bf16, at the same accuracy (emulated 6.0e-5 vs 6.7e-5 on the C2 network).
 //
-// Structure.  A block (8 waves) owns 256 rows of x; every wave keeps ITS 32 rows in registers for the whole kernel — yh as
+// Structure.  A block (4 waves; two blocks per CU) owns 128 rows of x; every wave keeps ITS 32 rows in registers for the whole kernel — yh as
 // the fp16 fragments of all K / 32 k-steps (96 VGPRs at K = 384), fp8(2^14 yl) as 48 more — built once from coalesced
-// reads through a wave-private staging tile.  All 8 waves then walk the output columns 64 at a time: every wave
-// multiplies its rows with the SAME 64-column W tile, so a byte of W brought into the LDS serves 256 rows (128 in
-// gemm_f16_astat.hip, whose pace the global -> LDS fill sets).  W streams from a pre-tiled image in consumption
+// reads through a wave-private staging tile.  The waves then walk the output columns 64 at a time: every wave
+// multiplies its rows with the SAME 64-column W tile (a byte of W brought into the LDS serves 128 rows; one 256-row block of
+// 8 waves per CU measured the same and is not instantiated).  W streams from a pre-tiled image in consumption
 // order — per (64-column tile, 64-k group) one 8 KiB stage of fp16 Wh (two 32-k sub-tiles) and one of fp8 (Wl | W) —
-// through a ring of 2 K / 64 stages by buffer_load ... lds, one 1 KiB piece per wave and stage; a stage is two
+// through a ring of 4 - 6 stages by buffer_load ... lds, two 1 KiB pieces per wave and stage; a stage is two
 // sub-steps of 128 matrix-pipe cycles per wave, the fragments of the next sub-step are read while one runs.
 // The MFMAs take W as the row operand and y as the column operand: the accumulator then holds, per lane, ONE point and
 // 16 output columns, so the epilogue (bias, activation, hi / lo split) needs no LDS transpose — one
@@ -48,8 +48,6 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int H_NT = 512;          // 8 waves
-constexpr int H_ROWS = 256;        // rows of x per block
 constexpr int H_BN = 64;           // columns per W tile
 constexpr int H_STAGE = 2048;      // floats per 8 KiB ring stage (two 4 KiB sub-tiles)
 constexpr int H_STG = 1536;        // floats of a wave's staging tile: [32][64] fp16 (4 KiB) + [32][64] fp8 (2 KiB)

@@ -186,11 +186,11 @@ int linear_pair(const float* A, const float* W1, const float* b1, int Nout1, flo
 }
 
 // Path switches for A/B runs and tests: gecco_set_option, or the environment (GECCO_ASTAT, GECCO_CHAIN) on first use.
-enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_HEADMAJOR = 2, OPT_MLPFUSED = 3, OPT_UNPOOLFUSED = 4, OPT_LO8 = 5, OPT_ACTIMG = 6, OPT_H8 = 7, OPT_KVQ64 = 8, OPT_H8AREG = 9, OPT_CHAIN2 = 10, OPT_COUNT = 11 };
-int g_options[OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
-const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor", "mlpfused", "unpoolfused", "lo8", "actimg", "h8", "kvq64", "h8areg", "chain2"};
+enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_HEADMAJOR = 2, OPT_MLPFUSED = 3, OPT_UNPOOLFUSED = 4, OPT_LO8 = 5, OPT_ACTIMG = 6, OPT_H8 = 7, OPT_KVQ64 = 8, OPT_H8AREG = 9, OPT_CHAIN2 = 10, OPT_UNPOOLH8 = 11, OPT_COUNT = 12 };
+int g_options[OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor", "mlpfused", "unpoolfused", "lo8", "actimg", "h8", "kvq64", "h8areg", "chain2", "unpoolh8"};
 const char* const g_option_env[OPT_COUNT] = {"GECCO_ASTAT", "GECCO_CHAIN", "GECCO_HEADMAJOR", "GECCO_MLPFUSED", "GECCO_UNPOOLFUSED", "GECCO_LO8",
-                                             "GECCO_ACTIMG", "GECCO_H8", "GECCO_KVQ64", "GECCO_H8AREG", "GECCO_CHAIN2"};
+                                             "GECCO_ACTIMG", "GECCO_H8", "GECCO_KVQ64", "GECCO_H8AREG", "GECCO_CHAIN2", "GECCO_UNPOOLH8"};
 int option(int which) {
     if (g_options[which] < 0) {
         const char* e = getenv(g_option_env[which]);
@@ -305,6 +305,11 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         hg.a_img = 2; hg.w_img = w.wimg; hg.rows = N; hg.Nout = C; hg.K = C; hg.lda = C; hg.ldc = C; hg.ldr = C;
         h8o = gemm_h8_areg_supported(hg);
     }
+    // mixed mode: unpool attention + out_proj (h8) + residual + statistics in ONE launch (unpool_outproj_h8.hip; option "unpoolh8"):
+    // the attention output of a row block is the stationary operand of out_proj and never leaves the CU.  Needs the head-major
+    // fp16 q of the kvq kernel; the k | v image of the inducers lives in the (then idle) attention-output buffer
+    const bool uo8_on = h8o && kvq_on && option(OPT_UNPOOLH8) && I == 64 && unpool_outproj_h8_supported(C, H, N) &&
+                        unpool_outproj_h8_kv_bytes(B, C, H) <= (size_t)B * N * C * sizeof(float);
     const bool chain_on = pr == 2 && w.wimg && option(OPT_CHAIN) && inducer_chain_f16_supported(C, Wd, H, G, I) &&
                           (ns == 1 || ns == 2 || ns == 4 || ns == 8);
     // mixed mode: the same one-launch chain with TWO-TERM fp16 weights (option "chain2") instead of five 64-row split-bf16 GEMMs
@@ -392,7 +397,7 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
             if (!mixed) TRY(push(L.in_proj_w, base + w.o_q, C, C), "split(q_proj)");
             if (h8o) {
                 if (jobs8.n >= kJobCap) { TRY(h8_image_multi_launch(jobs8, s), "split(out_proj, h8)"); jobs8.n = 0; }
-                jobs8.job[jobs8.n++] = SplitJob{L.unpool_out_w, base + w.o_out, C, C, C, 2};
+                jobs8.job[jobs8.n++] = SplitJob{L.unpool_out_w, base + w.o_out, C, C, C, uo8_on ? 16 : 2};   // 16: 64-column tiles, attention k order
             } else {
                 TRY(push(L.unpool_out_w, base + w.o_out, C, C), "split(out_proj)");
             }
@@ -538,7 +543,14 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
                 "unpool.in_proj(q)");
         }
         const bool a16 = io16 && !mixed;   // fp16-stored operands of the generic linears (fp16 mode only)
-        if (!mixed && hm && im && I == 64 && option(OPT_UNPOOLFUSED) && unpool_outproj_f16_supported(C, H, N)) {
+        if (uo8_on) {
+            if (!hm || !im) return fail(-3, "set_transformer: unpool + out_proj (h8) needs the head-major fp16 q");
+            TRY(kvh_image_launch(w.kvh, w.attn, B, C, H, s), "unpool k | v image");
+            UnpoolH8Args ua{};
+            ua.x = x; ua.q16 = w.q; ua.kv_img = w.attn; ua.w_img = im + w.o_out; ua.bias = L.unpool_out_b; ua.stats = w.stats_x;
+            ua.B = B; ua.rows = N; ua.H = H;
+            TRY(unpool_outproj_h8_launch(ua, C, s), "unpool attention + out_proj (h8)");
+        } else if (!mixed && hm && im && I == 64 && option(OPT_UNPOOLFUSED) && unpool_outproj_f16_supported(C, H, N)) {
             // fp16 mode, head-major q: attention, out_proj, residual and statistics in one launch (the attention output
             // of a row block is the A operand of out_proj for the same rows and never leaves the CU)
             UnpoolProjArgs ua{};
@@ -645,7 +657,7 @@ int gecco_set_option(const char* name, int value) {
             g_options[i] = value < 0 ? -1 : (value != 0);   // < 0: back to the environment / default
             return 0;
         }
-    return fail(-2, "set_option: unknown option '%s' (astat, chain, headmajor, mlpfused, unpoolfused, lo8, actimg, h8, kvq64, h8areg, chain2)", name);
+    return fail(-2, "set_option: unknown option '%s' (astat, chain, headmajor, mlpfused, unpoolfused, lo8, actimg, h8, kvq64, h8areg, chain2, unpoolh8)", name);
 }
 
 int gecco_linear_row_tiles(int rows) { return row_tiles_gemm(rows); }
@@ -937,6 +949,39 @@ int gecco_unpool_outproj_f16(float* x, const void* q16, const float* kvh, const 
     ua.x = x; ua.q16 = q16; ua.kvh = kvh; ua.w_stream = static_cast<const float*>(wsplit); ua.bias = bias; ua.stats = stats;
     ua.B = B; ua.rows = rows; ua.H = H;
     TRY(unpool_outproj_f16_launch(ua, C, s), "unpool_outproj");
+    return 0;
+}
+
+int gecco_unpool_outproj_h8(float* x, const void* q16, const float* kvh, const float* W, const float* bias, float* stats,
+                            int B, int rows, int C, int H, void* wsplit, void* stream) {
+    if (!x || !q16 || !kvh || !wsplit) return fail(-1, "unpool_outproj_h8: null argument");
+    if (!unpool_outproj_h8_supported(C, H, rows))
+        return fail(-2, "unpool_outproj_h8: needs (C, head dim) in {(128, 16), (256, 32), (384, 48)}, rows %% 128 == 0");
+    hipStream_t s = (hipStream_t)stream;
+    if (W) {   // W == NULL: image ready
+        SplitJobs jobs;
+        jobs.n = 1;
+        jobs.job[0] = SplitJob{W, static_cast<float*>(wsplit), C, C, C, 16};
+        TRY(h8_image_multi_launch(jobs, s), "unpool_outproj_h8(split)");
+    }
+    void* kvimg = static_cast<char*>(wsplit) + h8_image_bytes(C, C);
+    TRY(kvh_image_launch(kvh, kvimg, B, C, H, s), "unpool_outproj_h8(k | v image)");
+    UnpoolH8Args ua{};
+    ua.x = x; ua.q16 = q16; ua.kv_img = kvimg; ua.w_img = wsplit; ua.bias = bias; ua.stats = stats; ua.B = B; ua.rows = rows; ua.H = H;
+    TRY(unpool_outproj_h8_launch(ua, C, s), "unpool_outproj_h8");
+    return 0;
+}
+
+size_t gecco_unpool_outproj_h8_wsplit_bytes(int B, int C, int H) {
+    if (H <= 0 || C % H) return 0;
+    return h8_image_bytes(C, C) + unpool_outproj_h8_kv_bytes(B, C, H);
+}
+
+int gecco_unpool_attn_h8img(const void* q16, const float* kvh, void* out_img, int B, int N, int C, int H, void* stream) {
+    if (!q16 || !kvh || !out_img) return fail(-1, "unpool_attn_h8img: null argument");
+    if (N % 128 || C % 64 || H <= 0 || C % H || !attn_x3_supported(C / H)) return fail(-2, "unpool_attn_h8img: needs N %% 128 == 0, C %% 64 == 0, head dim 16 / 32 / 48 / 64");
+    TRY(unpool_attn_launch(static_cast<const float*>(q16), kvh, static_cast<float*>(out_img), B, N, C, H, 64, (hipStream_t)stream, 2, 2, 1, 2),
+        "unpool_attn_h8img");
     return 0;
 }
 

@@ -117,7 +117,9 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
 //               holds k = 64 g + 32 t + 16 h + 0 .. 15 — the order in which a lane half h packs its fp16 fragments of two
 //               k-steps (t) into the fp8 operand; physical chunk as above.
 // One thread per 16-byte chunk: 1024 chunks per (ct, g).
-template <int BN>
+// PERM (unpool_outproj_h8.hip: the stationary operand comes out of an attention accumulator): the k order inside a 32-k
+// sub-tile is 16 c + 8 (e >> 2) + 4 h + (e & 3) for element e of the fragment (c, lane half h) instead of 16 h + 8 c + e.
+template <int BN, bool PERM = false>
 __device__ __forceinline__ void h8_image_item(const float* __restrict__ W, float* __restrict__ img, int Nout, int K, int ldw, size_t i) {
     constexpr int LB = BN == 64 ? 6 : 7;               // log2(BN); a stage is 2 sub-tiles of [BN][16 floats]
     const int NG = K / 64;
@@ -128,8 +130,9 @@ __device__ __forceinline__ void h8_image_item(const float* __restrict__ W, float
     const int nn = min(ct * BN + n, Nout - 1);
     u32x4 out;
     if (kind == 0) {
-        const float* src = W + (size_t)nn * ldw + 64 * g + 32 * sub + 8 * q;
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(src), w1 = *reinterpret_cast<const f32x4*>(src + 4);
+        // chunk q = 2 h + c of the sub-tile
+        const float* src = W + (size_t)nn * ldw + 64 * g + 32 * sub + (PERM ? 16 * (q & 1) + 4 * (q >> 1) : 8 * q);
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(src), w1 = *reinterpret_cast<const f32x4*>(src + (PERM ? 8 : 4));
         f16x8 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -139,10 +142,11 @@ __device__ __forceinline__ void h8_image_item(const float* __restrict__ W, float
         out = __builtin_bit_cast(u32x4, v);
     } else {
         const int h = q >> 1, t = q & 1;
-        const float* src = W + (size_t)nn * ldw + 64 * g + 32 * t + 16 * h;
+        const float* src = W + (size_t)nn * ldw + 64 * g + 32 * t + (PERM ? 4 * h : 16 * h);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(src + 4 * c);
+            // byte 4 c + e of the chunk (h, t): k = 32 t + 16 h + 4 c + e, PERM: 32 t + 16 (c >> 1) + 8 (c & 1) + 4 h + e
+            const f32x4 w = *reinterpret_cast<const f32x4*>(src + (PERM ? 16 * (c >> 1) + 8 * (c & 1) : 4 * c));
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -199,7 +203,8 @@ __device__ __forceinline__ void kvq_image_item(const float* __restrict__ W, floa
     *reinterpret_cast<u32x4*>(img + st * H_STAGE + sub * 1024 + n * 16 + pc * 4) = out;
 }
 
-// SplitJob::pad_ = 0: the h8 stream of mlp.0 (64-column tiles); 2: the same in 128-column tiles (gemm_h8_areg.hip);
+// SplitJob::pad_ = 0: the h8 stream of mlp.0 (64-column tiles); 2: the same in 128-column tiles (gemm_h8_areg.hip); 16: 64-column
+// tiles in the attention accumulator's k order (unpool_outproj_h8.hip);
 // pad_ = 1 | lo_begin << 8 | lo_end << 20 (64-column tiles): the kv | q stream
 __global__ void h8_image_multi_kernel(SplitJobs jobs) {
     const SplitJob j = jobs.job[blockIdx.y];
@@ -208,6 +213,12 @@ __global__ void h8_image_multi_kernel(SplitJobs jobs) {
         const size_t total = ((size_t)(j.Nout / H_BN) * NG + (size_t)(le - lb) * (NG / 2)) * 512;
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
             kvq_image_item(j.W, j.img, j.Nout, j.K, j.ldw, lb, le, i);
+        return;
+    }
+    if (j.pad_ & 16) {   // 64-column tiles in the attention accumulator's k order (unpool_outproj_h8.hip)
+        const size_t total = (size_t)(j.Nout / H_BN) * (j.K / 64) * 1024;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+            h8_image_item<64, true>(j.W, j.img, j.Nout, j.K, j.ldw, i);
         return;
     }
     if (j.pad_ & 2) {   // 128-column tiles (gemm_h8_areg.hip); Nout padded up to whole tiles (the pad rows repeat the last row)

@@ -59,7 +59,7 @@ struct GemmArgs {
     int h8_stagger, h8_pair;   // gemm_h8_astat.hip: start offset of every second block of a CU (set by its launcher)
 };
 
-struct SplitJob { const float* W; float* img; int Nout, K, ldw, pad_; };   // pad_ = 1 (fp16 images): the LOW part fp16(W - fp16(W)); 2: the same as fp8 x 2^19 in 64-k blocks; 8: hi | lo blocks interleaved per column tile; 4 (bf16 images): W is (K, ldw) and the image is of W^T
+struct SplitJob { const float* W; float* img; int Nout, K, ldw, pad_; };   // pad_ = 1 (fp16 images): the LOW part fp16(W - fp16(W)); 2: the same as fp8 x 2^19 in 64-k blocks; 8: hi | lo blocks interleaved per column tile; 4 (bf16 images): W is (K, ldw) and the image is of W^T; h8 images (h8_image_multi_launch): see gemm_h8_astat.hip
 struct SplitJobs { SplitJob job[96]; int n; };   // 3 KiB of kernel arguments
 int gemm_row_tile(int rows);  // row-tile height the GEMM uses for `rows` rows per sample
 int gemm_f32_launch(const GemmArgs& g, hipStream_t st);
@@ -126,6 +126,22 @@ struct UnpoolProjArgs {
 };
 bool unpool_outproj_f16_supported(int C, int H, int rows);
 int unpool_outproj_f16_launch(const UnpoolProjArgs& g, int C, hipStream_t st);
+
+// unpool_outproj_h8.hip — mixed mode: unpool attention + out_proj (h8 arithmetic) + residual + GroupNorm partials in one launch
+struct UnpoolH8Args {
+    float* x;                 // (B, rows, C) fp32 residual stream, updated in place
+    const void* q16;          // head-major fp16 q (B, H, rows, hd)
+    const void* kv_img;       // kvh_image_launch: per (sample, head) the fp16 LDS image of the inducers' k | v
+    const void* w_img;        // h8 stream of out_proj.weight, 64-column tiles, attention k order (SplitJob::pad_ = 16)
+    const float* bias;        // (C) or null
+    float* stats;             // (B, rows / 128, 2, C) or null
+    int B, rows, H;
+    int rev;                  // set by the launcher: blocks walk the row panels last to first
+};
+bool unpool_outproj_h8_supported(int C, int H, int rows);
+size_t unpool_outproj_h8_kv_bytes(int B, int C, int H);
+int kvh_image_launch(const float* kvh, void* img, int B, int C, int H, hipStream_t st);   // kvh (B, 64, 2C) fp32
+int unpool_outproj_h8_launch(const UnpoolH8Args& g, int C, hipStream_t st);
 
 // gemm_tn_x3.hip — split-bf16 weight gradients: C[g] = sum over the samples of group g of A[z]^T B[z]
 struct TnArgs {

@@ -361,6 +361,32 @@ def unpool_outproj_f16(x: Tensor, q16: Tensor, kvh: Tensor, W: Tensor, bias: Ten
     return x, stats
 
 
+def unpool_outproj_h8(x: Tensor, q16: Tensor, kvh: Tensor, W: Tensor, bias: Tensor | None, H: int, want_stats: bool = False,
+                      wsplit: Tensor | None = None, image_ready: bool = False, stats: Tensor | None = None):
+    """x += MHA(q, inducer k | v) @ W^T + bias in place (mixed mode, one launch: fp16 attention, h8 out_proj); q16 head-major
+    (B, H, N, hd).  Returns (x, stats | None).  wsplit / image_ready: scratch holding the weight image of a previous call."""
+    lib = _lib.load()
+    B, rows, Cc = x.shape
+    if stats is None and want_stats:
+        stats = torch.empty(B, rows // 128, 2, Cc, device=x.device, dtype=torch.float32)
+    if wsplit is None:
+        wsplit = _ws(lib.gecco_unpool_outproj_h8_wsplit_bytes(B, Cc, H), x.device)
+    check(lib.gecco_unpool_outproj_h8(_ptr(x), _ptr16(q16), _ptr(kvh), None if image_ready else _ptr(W), _ptr(bias), _ptr(stats), B, rows, Cc, H,
+                                      C.c_void_p(wsplit.data_ptr()), _stream()), "gecco_unpool_outproj_h8")
+    return x, stats
+
+
+def unpool_attn_h8img(q16: Tensor, kvh: Tensor, H: int) -> Tensor:
+    """The mixed mode's unpool attention: head-major fp16 q16 (B, H, N, hd) -> the h8 activation image (B, N / 128, C / 64, 24576) bytes
+    that `linear_h8_areg` consumes (`decode_h8_image` turns it back into (B, N, C) fp32)."""
+    lib = _lib.load()
+    B, _, N, hd = q16.shape
+    Cc = H * hd
+    out = torch.empty(B, N // 128, Cc // 64, 24576, device=q16.device, dtype=torch.uint8)
+    check(lib.gecco_unpool_attn_h8img(_ptr16(q16), _ptr(kvh), C.c_void_p(out.data_ptr()), B, N, Cc, H, _stream()), "gecco_unpool_attn_h8img")
+    return out
+
+
 def affine_cast_f16(x: Tensor, a: Tensor, o: Tensor, out: Tensor | None = None) -> Tensor:
     """fp16(a[b, c] * x[b, m, c] + o[b, c]): the AdaGN apply stored as the fp16 GEMM operand."""
     lib = _lib.load()

@@ -101,6 +101,9 @@ int gecco_linear_f32(const float* A, const float* W, const float* bias, const fl
  *   "h8areg" (default 1): mixed mode hands the MLP hidden layer and the unpool attention output on as h8 activation images
  *   (fp16 hi + fp8 lo, 3 bytes per element) and runs mlp.2 / out_proj as h8 products (gecco_linear_h8_areg_f32) instead of
  *   split-bf16 products on tiled split images: 2 instead of 3 matrix-pipe units per product, same accuracy (needs "h8").
+ *   "unpoolh8" (default 1): mixed mode runs unpool attention + out_proj (h8) + residual + statistics as one launch
+ *   (gecco_unpool_outproj_h8) instead of the attention writing an h8 activation image for gecco_linear_h8_areg_f32; needs
+ *   "kvq64" (head-major fp16 q), "h8areg", feature_dim in {128, 256, 384}.
  *   "chain2" (default 1): mixed mode runs the 64-inducer chain of a layer (pool merge .. unpool k|v) as the ONE launch of the fp16
  *   mode with two-term fp16 weights (hi | lo blocks per column tile) instead of five 64-row split-bf16 GEMMs + their AdaGN
  *   coefficient launches: 16 -> 9 launches per layer; F_x 6e-5 -> ~1e-4 (its activations are rounded to fp16 once).
@@ -251,6 +254,20 @@ int gecco_mlp_fused_f16(float* x, const float* pro_a, const float* pro_o, const 
  * (C, hd) in {(128, 16), (256, 32), (384, 48)}, rows % 128 == 0; wsplit: 2 * C * C bytes. */
 int gecco_unpool_outproj_f16(float* x, const void* q16, const float* kvh, const float* W, const float* bias, float* stats,
                              int B, int rows, int C, int H, void* wsplit, void* stream);
+/* The same half of the layer in the MIXED mode, one launch (unpool_outproj_h8.hip; option "unpoolh8", default 1): attention in
+ * fp16 (the bits of gecco_unpool_attn_h8img), out_proj as the h8 product (fp16 main product + two fp8 cross terms, as
+ * gecco_linear_h8_areg_f32), + bias + residual, in place on x, + GroupNorm partials; the attention output stays in registers as
+ * the stationary operand.  Replaces models/set_transformer.py:70-75, 112 and the residual of :164.  Equal to
+ * gecco_unpool_attn_h8img followed by gecco_linear_h8_areg_f32 up to fp32 summation order (~1e-6).  (C, hd) in {(128, 16),
+ * (256, 32), (384, 48)}, rows % 128 == 0; wsplit: gecco_unpool_outproj_h8_wsplit_bytes(B, C, H) (weight image, then the fp16
+ * k | v image of the inducers); W == NULL: the weight image is ready. */
+int gecco_unpool_outproj_h8(float* x, const void* q16, const float* kvh, const float* W, const float* bias, float* stats,
+                            int B, int rows, int C, int H, void* wsplit, void* stream);
+size_t gecco_unpool_outproj_h8_wsplit_bytes(int B, int C, int H);
+/* The mixed mode's unpool attention alone (nn.MultiheadAttention core, models/set_transformer.py:112): head-major fp16 q16
+ * (B, H, N, hd), kvh (B, 64, 2C) fp32 -> the h8 activation image (image_kind 2 of gecco_linear_h8_img_f32: B * N * C * 3 bytes)
+ * that gecco_linear_h8_areg_f32 consumes.  N % 128 == 0, C % 64 == 0, hd in {16, 32, 48, 64}. */
+int gecco_unpool_attn_h8img(const void* q16, const float* kvh, void* out_img, int B, int N, int C, int H, void* stream);
 /* y16[b, m, c] = fp16(a[b, c] * x[b, m, c] + o[b, c]) — the AdaGN apply (models/normalization.py:44) rounded once,
  * exactly the operand the fp16 GEMM's prologue would form.  C % 8 == 0. */
 int gecco_affine_cast_f16(const float* x, const float* a, const float* o, void* y16, int B, int rows, int C,

@@ -322,6 +322,33 @@ def test_mixed_h8_mlp0_matches_split_bf16_mlp0(ops, golden_dir, name):
 
 
 @pytest.mark.parametrize("name", list(cases.UNCOND_CASES))
+def test_mixed_unpool_outproj_fused_matches_the_two_launch_form(ops, golden_dir, name):
+    """Mixed mode: unpool attention + out_proj (h8) + residual + statistics as ONE launch (option "unpoolh8",
+    unpool_outproj_h8.hip; models/set_transformer.py:70-75, 112, 164) against the attention writing an h8 activation image for
+    gemm_h8_areg.hip: same attention bits and operand split, so the whole network agrees to fp32 summation order; both within the
+    bar of the reference's golden output; the fused form must actually have run; a cached evaluation takes the same path."""
+    p, x, sigma = cases.uncond_inputs(name)
+    g = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    net = ops.LinearLiftPlan(_cuda(p), cases.H, cases.I, precision="mixed")
+    out, raw = {}, {}
+    try:
+        for on in (0, 1):
+            ops.set_option("unpoolh8", on)
+            d, r = net.forward(x.cuda(), sigma.cuda(), return_raw=True)
+            out[on], raw[on] = d.cpu(), r.cpu()
+    finally:
+        ops.set_option("unpoolh8", -1)
+    for on in (0, 1):
+        eg = cpu_ref.rel_err(out[on], torch.from_numpy(g["denoised"]))
+        assert eg[0] <= 2e-4, (on, eg)
+    e = cpu_ref.rel_err(raw[1], raw[0])
+    assert e[0] <= 1e-4, e   # per layer the two forms differ by <= 4e-6 of the stream's scale (tests/test_hip_ops.py); the network amplifies it
+    assert not torch.equal(raw[0], raw[1]), "the fused unpool + out_proj did not run"
+    d2 = net.forward(x.cuda(), sigma.cuda())
+    assert torch.equal(d2.cpu(), out[1])   # reproducible run to run
+
+
+@pytest.mark.parametrize("name", list(cases.UNCOND_CASES))
 def test_mixed_two_term_chain_matches_split_bf16_chain(ops, golden_dir, name):
     """Mixed mode: the 64-inducer chain of a layer as ONE launch with two-term fp16 weights (option "chain2",
     inducer_chain_f16_kernel<.., TWO>: pool merge, pool.out_proj, norm_1, broadcast.mlp, norm_2, unpool k|v —

@@ -244,6 +244,41 @@ def test_unpool_outproj_fused_gives_the_bits_of_the_two_launch_form(ops, B, N, C
                        ops.linear_f16io(att, W, None, residual=x))   # bias and stats optional
 
 
+@pytest.mark.parametrize("B,N,Cc,H", [(2, 256, 128, 8), (3, 384, 384, 8), (2, 128, 256, 8), (5, 2048, 384, 8)])
+def test_unpool_outproj_h8_fused_matches_the_two_launch_form(ops, B, N, Cc, H):
+    """Mixed mode: unpool attention + h8 out_proj + residual + GroupNorm partials in ONE launch (unpool_outproj_h8.hip; reference
+    models/set_transformer.py:70-75, 112, 164) against the two launches it replaces — the fp16 attention writing the h8 activation
+    image, then gemm_h8_areg.hip: the same attention bits and the same hi / lo split of its output, so the results differ by the
+    fp32 summation order of the product alone; and against float64 of what the image decodes to."""
+    rs = _rs(N + Cc + 2)
+    hd = Cc // H
+    x = _t(rs.randn(B, N, Cc) * 2).cuda()
+    q = (_t(rs.randn(B, H, N, hd)).cuda()).half()
+    kvh = _t(rs.randn(B, 64, 2 * Cc)).cuda()
+    W, bias = _t(rs.randn(Cc, Cc) / 13).cuda(), _t(rs.randn(Cc) * .1).cuda()
+    img = ops.unpool_attn_h8img(q, kvh, H)
+    ref, st_ref = ops.linear_h8_areg(img, W, bias, residual=x, want_stats=True)
+    got, st = ops.unpool_outproj_h8(x.clone(), q, kvh, W, bias, H, want_stats=True)
+    torch.cuda.synchronize()
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() <= 4e-6 * scale, (got - ref).abs().max().item() / scale
+    att = ops.decode_h8_image(img).double()
+    ref64 = x.double() + att @ W.double().t() + bias.double()
+    assert (got.double() - ref64).abs().max().item() <= 3e-5 * scale
+    assert st.shape == st_ref.shape
+    g4 = got.double().reshape(B, N // 128, 128, Cc)
+    assert (st[:, :, 0].double() - g4.sum(2)).abs().max().item() <= 1e-3
+    assert (st[:, :, 1].double() - (g4 * g4).sum(2)).abs().max().item() <= 1e-5 * (g4 * g4).sum(2).max().item()
+    # bias and statistics optional; a ready weight image gives the same bits; run to run reproducible
+    lib = ops._lib.load()
+    ws = torch.empty(lib.gecco_unpool_outproj_h8_wsplit_bytes(B, Cc, H), dtype=torch.uint8, device="cuda")
+    a = ops.unpool_outproj_h8(x.clone(), q, kvh, W, None, H, wsplit=ws)[0]
+    c = ops.unpool_outproj_h8(x.clone(), q, kvh, W, None, H, wsplit=ws, image_ready=True)[0]
+    assert torch.equal(a, c)
+    assert (a - ops.linear_h8_areg(img, W, None, residual=x)).abs().max().item() <= 4e-6 * scale
+    assert torch.equal(ops.unpool_outproj_h8(x.clone(), q, kvh, W, bias, H)[0], got)
+
+
 def test_adagn_large_mean(ops):
     """E[x^2]-mean^2 cancellation: mean 50x the std must still be accurate (fp64 combine)."""
     rs = _rs(5)

@@ -137,6 +137,7 @@ struct UnpoolH8Args {
     float* stats;             // (B, rows / 128, 2, C) or null
     int B, rows, H;
     int rev;                  // set by the launcher: blocks walk the row panels last to first
+    int stagger, pair;        // set by the launcher: start offset (s_memtime ticks) of every second block of a CU
 };
 bool unpool_outproj_h8_supported(int C, int H, int rows);
 size_t unpool_outproj_h8_kv_bytes(int B, int C, int H);

@@ -18,12 +18,12 @@
 //     hi)) in place — no transpose: the k order of the stationary operand is whatever the accumulator gives (element e of
 //     fragment (k-step s, lane half h) is k = 16 s + 8 (e >> 2) + 4 h + (e & 3)), and the W image is written in the same order
 //     (h8_image_item<64, true>, SplitJob::pad_ = 16).
-//   * out_proj = gemm_h8_astat.hip's main loop (A W = Ah Wh + fp8(Ah) fp8(2^19 Wl) + fp8(2^14 Al) fp8(2^8 W); W as the MFMA's row
-//     operand, 64-column tiles, W streamed through an LDS ring in consumption order).
-//   * epilogue per 64-column tile: the residual rows of the tile were fetched by LDS-DMA into the wave's transpose tile when the
-//     tile's K loop started (16-byte chunks XOR-swizzled by row: the DMA writes lanes contiguously, so the swizzle sits in the
-//     global address); a lane adds accumulator + bias onto its row of it (the accumulator holds one point per lane), the wave
-//     reads the tile back as rows and stores 4 x 256 contiguous bytes per instruction; column sums for the next GroupNorm.
+//   * out_proj = gemm_h8_astat.hip's main loop (A W = Ah Wh + fp8(Ah) fp8(2^19 Wl) + fp8(2^14 Al) fp8(2^8 W); 64-column tiles, W
+//     streamed through an LDS ring in consumption order).
+//   * epilogue per 64-column tile: the residual rows of the tile were fetched by LDS-DMA into a wave-private tile when the tile's
+//     K loop started; with the stationary operand as the MFMA's ROW operand an accumulator register holds 32 consecutive columns
+//     of one row, so there is no transpose: register by register (A W^T + bias) + residual, a store of 2 x 128 contiguous bytes,
+//     and — a lane owning one column — the column sums for the next GroupNorm as 16 adds and one lane-half exchange.
 //
 // HBM per launch at C2: q 100 MB + x in 201 MB + x out 201 MB (the 151 MB image written + read before never leaves the CU).
 #include "gemm_dma_common.h"
@@ -37,6 +37,7 @@ namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -44,9 +45,19 @@ typedef unsigned short u16;
 
 constexpr int U_STAGE = 2048;          // floats per 8 KiB ring stage (two 4 KiB sub-tiles)
 constexpr int U_PW = 2;                // 1 KiB W pieces per wave and stage
+// Diagnostic builds (tools/probe/uo8_probe.hip): -DUO8_STAMPS per-block s_memtime stamps; -DUO8_DIAG_NOATT / _NOMFMA / _NOEPI /
+// _NORES remove one ingredient each (results are then garbage; only the time is of interest)
+#if defined(UO8_DIAG_NORES) || defined(UO8_DIAG_NOEPI)
+constexpr int U_RES = 0;
+#else
 constexpr int U_RES = 8;               // residual DMA pieces per wave and column tile
-constexpr int U_STORES = 8;            // x stores per wave and column tile
-constexpr int U_TT = 2048;             // floats of a wave's transpose tile: [32 rows][64 columns]
+#endif
+#ifdef UO8_DIAG_NOEPI
+constexpr int U_STORES = 0;
+#else
+constexpr int U_STORES = 32;           // x stores per wave and column tile (one per accumulator register)
+#endif
+constexpr int U_TT = 2048;             // floats of a wave's residual tile: [32 rows][64 columns]
 constexpr float U_LOG2E = 1.4426950408889634f;
 constexpr float U_YL_SCALE = 16384.f;  // 2^14 (gemm_h8_astat.hip)
 
@@ -62,9 +73,10 @@ __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&&
     (f(std::integral_constant<int, I>{}), ...);
 }
 
-// Diagnostic builds (tools/probe/uo8_probe.hip): -DUO8_STAMPS per-block s_memtime stamps
 #ifdef UO8_STAMPS
 __device__ unsigned long long g_uo8_stamps[2048 * 4];
+__device__ unsigned long long g_uo8_epi[2048 * 4];   // per block: ticks inside the epilogues: transposed phase | row phase | first K step of a tile
+#define UTICK() __builtin_amdgcn_s_memtime()
 #define USTAMP(i)                                                                                                \
     do {                                                                                                         \
         if (threadIdx.x == 0 && blockIdx.x < 2048) g_uo8_stamps[blockIdx.x * 4 + (i)] = __builtin_amdgcn_s_memtime(); \
@@ -74,7 +86,32 @@ __device__ unsigned long long g_uo8_stamps[2048 * 4];
 #endif
 
 #define U_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
-#define U_MFMA8(a, b, c, sa, sb) __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, sa, 0, sb)
+#ifdef UO8_DIAG_NOMFMA
+__device__ __forceinline__ f32x16 u_keep16(f16x8 a, f16x8 b, f32x16 c) {
+    asm volatile("" ::"v"(a), "v"(b));
+    return c;
+}
+__device__ __forceinline__ f32x16 u_keep8(i32x8 a, i32x8 b, f32x16 c) {
+    asm volatile("" ::"v"(a), "v"(b));
+    return c;
+}
+#define UG_MFMA16(a, b, c) u_keep16(a, b, c)
+#define UG_MFMA8(a, b, c, sa, sb) u_keep8(a, b, c)
+#else
+#define UG_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define UG_MFMA8(a, b, c, sa, sb) __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, sa, 0, sb)
+#endif
+
+// the value of the other lane half (lane ^ 32) without the LDS round trip of ds_bpermute: v_permlane32_swap of a register with
+// itself leaves {lower half's value, upper half's value} on every lane
+__device__ __forceinline__ float max_halves(float v) {
+    const auto a = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    return fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+}
+__device__ __forceinline__ float sum_halves(float v) {
+    const auto a = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+}
 
 __device__ __forceinline__ float clamp448(float v) { return __builtin_fminf(__builtin_fmaxf(v, -448.f), 448.f); }
 
@@ -90,26 +127,30 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
 //   K  [64 keys][hd + 8]: row = key, the head's hd values (pad columns zero);
 //   V^T [ceil(hd / 32) * 32][72]: row = head-dim index d (rows >= hd zero), key 16 c + 8 a + 4 g + i at position 16 c + 8 g + 4 a + i
 //       (lane half g reads its 8 keys of a 16-key chunk contiguously: attention_x3.hip).
-// One block per (sample, head); same roundings (fp32 -> fp16, nearest even) as the staging code of unpool_attn_x3_kernel.
-__global__ void kvh_image_kernel(const float* __restrict__ kvh, u16* __restrict__ img, int C, int H, int HD, int kvb) {
+// One block per (sample, head); same roundings (fp32 -> fp16, nearest even) as the staging code of unpool_attn_x3_kernel.  The
+// image is assembled in LDS (coalesced 16-byte reads of the key rows, 2-byte transposed writes) and leaves as 16-byte chunks.
+__global__ __launch_bounds__(256) void kvh_image_kernel(const float* __restrict__ kvh, u16* __restrict__ img, int C, int H, int HD, int kvb) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    u16* buf = reinterpret_cast<u16*>(smem);
     const int b = blockIdx.x / H, hh = blockIdx.x % H;
-    const int KS = HD + 8, nk = 64 * KS, total = kvb / 2;
-    u16* dst = img + (size_t)blockIdx.x * total;
+    const int KS = HD + 8, nk = 64 * KS, CH = HD / 4;
+    for (int i = threadIdx.x; i < kvb / 16; i += 256) reinterpret_cast<u32x4*>(buf)[i] = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
     const float* src = kvh + (size_t)b * 64 * 2 * C + hh * HD;
-    for (int i = threadIdx.x; i < total; i += blockDim.x) {
-        _Float16 v = (_Float16)0.f;
-        if (i < nk) {
-            const int key = i / KS, d = i % KS;
-            if (d < HD) v = (_Float16)src[(size_t)key * 2 * C + d];
-        } else {
-            const int jv = i - nk, d = jv / 72, pos = jv % 72;
-            if (d < HD && pos < 64) {
-                const int key = (pos & ~15) + 8 * ((pos >> 2) & 1) + 4 * ((pos >> 3) & 1) + (pos & 3);
-                v = (_Float16)src[(size_t)key * 2 * C + C + d];
-            }
+    for (int i = threadIdx.x; i < 64 * CH; i += 256) {
+        const int key = i / CH, ch = i % CH;
+        const f32x4 kf = *reinterpret_cast<const f32x4*>(src + (size_t)key * 2 * C + ch * 4);
+        const f32x4 vf = *reinterpret_cast<const f32x4*>(src + (size_t)key * 2 * C + C + ch * 4);
+        const int pos = (key & ~15) + 8 * ((key >> 2) & 1) + 4 * ((key >> 3) & 1) + (key & 3);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            buf[key * KS + ch * 4 + e] = __builtin_bit_cast(u16, (_Float16)kf[e]);
+            buf[nk + (ch * 4 + e) * 72 + pos] = __builtin_bit_cast(u16, (_Float16)vf[e]);
         }
-        dst[i] = __builtin_bit_cast(u16, v);
     }
+    __syncthreads();
+    u32x4* dst = reinterpret_cast<u32x4*>(img + (size_t)blockIdx.x * (kvb / 2));
+    for (int i = threadIdx.x; i < kvb / 16; i += 256) dst[i] = reinterpret_cast<const u32x4*>(buf)[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -120,10 +161,10 @@ __global__ __launch_bounds__(256, 2) void unpool_outproj_h8_kernel(UnpoolH8Args 
     constexpr int KS = HD + 8, VS = 72, KVB = u_kv_bytes(HD), PK = KVB / 4096;
     static_assert(C % HD == 0 && HD % 16 == 0 && HD <= 64, "head dims 16 .. 64");
     static_assert(2 * KVB <= 4 * U_TT * 4, "two staged heads alias the four transpose tiles");
-    static_assert(NS >= 4 && NS - 2 <= NKT, "lookahead NS - 1 >= 3 stages; one epilogue's memory operations in flight");
+    static_assert(NS >= 4 && NS <= NKT, "lookahead NS - 1 >= 3 stages; the residual pieces land inside their tile");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* ring = smem;                        // [NS][U_STAGE]
-    float* tts = ring + NS * U_STAGE;          // [4][U_TT] residual / transpose tiles; during the attention: two staged heads
+    float* tts = ring + NS * U_STAGE;          // [4][U_TT] residual tiles; during the attention: two staged heads
     float* bias_lds = tts + 4 * U_TT;          // [C]
     float* red = bias_lds + C;                 // [4 waves][2][64] column sums of one tile
 
@@ -136,6 +177,11 @@ __global__ __launch_bounds__(256, 2) void unpool_outproj_h8_kernel(UnpoolH8Args 
 
     USTAMP(0);
     for (int n = tid; n < C; n += 256) bias_lds[n] = g.bias ? g.bias[n] : 0.f;
+    // two blocks per CU run the same phases (vector-heavy attention, then the matrix loop): the second of a pair may start late
+    if (g.stagger > 0 && (((blockIdx.x >> 3) / g.pair) & 1)) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)g.stagger) __builtin_amdgcn_s_sleep(8);
+    }
     __syncthreads();   // before the first DMA: a block barrier drains the vector-memory queue
 
     // ---- W stream: U_PW 1 KiB pieces per wave and stage, consumed front to back; past its end the last stage is fetched again
@@ -157,6 +203,18 @@ __global__ __launch_bounds__(256, 2) void unpool_outproj_h8_kernel(UnpoolH8Args 
     // ================= attention: this wave's 32 queries against the 64 inducer keys / values, head by head
     f16x8 fa[2 * NG][2];   // fa[s >> 1][s & 1]: k-step s (16 k) of the stationary operand, element e: k = 16 s + 8 (e >> 2) + 4 h + (e & 3)
     i32x8 alo[NG];         // dword 4 t + 2 c + (e >> 2) of group gq: fp8(2^14 lo) of fa[2 gq + t][c]
+#ifdef UO8_DIAG_NOATT
+#pragma unroll
+    for (int i = 0; i < 2 * NG; ++i)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fa[i][c][e] = (_Float16)(0.01f * (float)((lane + i + c + e) & 63));
+#pragma unroll
+    for (int i = 0; i < NG; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) alo[i][e] = 0x20202020 + lane + e;
+#else
     {
         const __amdgpu_buffer_rsrc_t kvrsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<char*>(static_cast<const char*>(g.kv_img) + (size_t)b * H * KVB), 0, 0x7fffffff, 0x00020000);
@@ -205,24 +263,33 @@ __global__ __launch_bounds__(256, 2) void unpool_outproj_h8_kernel(UnpoolH8Args 
                     const u32x4 kf = *reinterpret_cast<const u32x4*>(Kh + (kt * 32 + r) * KS + c * 16 + 8 * h);
                     sc[kt] = U_MFMA16(__builtin_bit_cast(f16x8, kf), __builtin_bit_cast(f16x8, qf[set][c]), sc[kt]);
                 }
+            // element-wise steps on pairs (v_pk_mul_f32 / v_pk_add_f32: the same IEEE results per element as the scalar forms of
+            // unpool_attn_x3_kernel at half the vector instructions); the sum over the keys keeps that kernel's serial order
+            const f32x2 scale2 = {scale, scale};
             float mx = -INFINITY;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    sc[kt][e] *= scale;
-                    mx = fmaxf(mx, sc[kt][e]);
+                for (int e = 0; e < 16; e += 2) {
+                    const f32x2 t = f32x2{sc[kt][e], sc[kt][e + 1]} * scale2;
+                    sc[kt][e] = t[0];
+                    sc[kt][e + 1] = t[1];
+                    mx = fmaxf(mx, fmaxf(t[0], t[1]));
                 }
-            mx = fmaxf(mx, xor32(mx));
+            mx = max_halves(mx);
+            const f32x2 mx2 = {mx, mx};
             float ls = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    sc[kt][e] = __builtin_amdgcn_exp2f(sc[kt][e] - mx);
+                for (int e = 0; e < 16; e += 2) {
+                    const f32x2 t = f32x2{sc[kt][e], sc[kt][e + 1]} - mx2;
+                    sc[kt][e] = __builtin_amdgcn_exp2f(t[0]);
+                    sc[kt][e + 1] = __builtin_amdgcn_exp2f(t[1]);
                     ls += sc[kt][e];
+                    ls += sc[kt][e + 1];
                 }
-            ls += xor32(ls);
+            ls = sum_halves(ls);
             const float inv = 1.0f / ls;
             // the probabilities as the four fp16 B fragments (16-key chunk c16 = 2 kt + sg) before the second product starts: the
             // score accumulators are dead from here on
@@ -255,21 +322,29 @@ __global__ __launch_bounds__(256, 2) void unpool_outproj_h8_kernel(UnpoolH8Args 
                     constexpr int ks = (hh * HD + 32 * dt + 16 * p) / 16;
                     f16x8 hv;
                     float lo[8];
+                    const f32x2 inv2 = {inv, inv}, ysc2 = {U_YL_SCALE, U_YL_SCALE};
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float v = O[dt][8 * p + e] * inv;
+                    for (int e = 0; e < 8; e += 2) {
+                        f32x2 v = f32x2{O[dt][8 * p + e], O[dt][8 * p + e + 1]} * inv2;
                         // ONE fp32 value feeds the hi rounding and the lo difference (gemm_h8_astat.hip's epilogue)
                         asm volatile("" : "+v"(v));
-                        hv[e] = (_Float16)v;
-                        lo[e] = clamp448((v - (float)hv[e]) * U_YL_SCALE);
+                        hv[e] = (_Float16)v[0];
+                        hv[e + 1] = (_Float16)v[1];
+                        const f32x2 d = (v - f32x2{(float)hv[e], (float)hv[e + 1]}) * ysc2;
+                        lo[e] = clamp448(d[0]);
+                        lo[e + 1] = clamp448(d[1]);
                     }
                     fa[ks >> 1][ks & 1] = hv;
                     alo[ks >> 2][4 * ((ks >> 1) & 1) + 2 * (ks & 1) + 0] = (int)pack_fp8x4(lo[0], lo[1], lo[2], lo[3]);
                     alo[ks >> 2][4 * ((ks >> 1) & 1) + 2 * (ks & 1) + 1] = (int)pack_fp8x4(lo[4], lo[5], lo[6], lo[7]);
+                    // formed here, under the next head's loads: left alone the compiler sinks all 192 conversions behind the last head
+                    asm volatile("" : "+v"(fa[ks >> 1][ks & 1]));
+                    asm volatile("" : "+v"(alo[ks >> 2][4 * ((ks >> 1) & 1) + 2 * (ks & 1) + 0]), "+v"(alo[ks >> 2][4 * ((ks >> 1) & 1) + 2 * (ks & 1) + 1]));
                 }
             });
         });
     }
+#endif
     USTAMP(1);
 
     // ---- per-lane addressing of the W fragments (gemm_kvq_astat_kernel): rows r and 32 + r of a sub-tile share the swizzle
@@ -290,8 +365,7 @@ __global__ __launch_bounds__(256, 2) void unpool_outproj_h8_kernel(UnpoolH8Args 
         }
     };
 
-    // ---- residual rows of a column tile -> the wave's transpose tile.  Tile row R (0 .. 31) holds its sixteen 16-byte chunks at
-    // positions chunk ^ (R & 15); DMA instruction `it` writes rows 4 it + (lane >> 4), position lane & 15
+    // ---- residual rows of a column tile -> the wave's private tile [32 rows][64 columns], row-major as the DMA writes it
     float* tt = tts + wave * U_TT;
     float* xw = g.x + ((size_t)b * g.rows + m0 + wave * 32) * C;
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(xw, 0, 0x7fffffff, 0x00020000);
@@ -301,62 +375,53 @@ __global__ __launch_bounds__(256, 2) void unpool_outproj_h8_kernel(UnpoolH8Args 
     auto issue_res = [&](int ct) {
         int ln = lane;
         asm volatile("" : "+v"(ln));
-        const int lr = ln >> 4, pl = (ln & 15) ^ lr;   // (4 it + lr) & 15 = 4 (it & 3) + lr: XOR in two parts
+        const unsigned v0 = (unsigned)(((ln >> 4) * C + 4 * (ln & 15)) * 4);   // DMA instruction `it`: rows 4 it + (lane >> 4), 16 bytes per lane
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const unsigned voff = (unsigned)(((4 * it + lr) * C + 4 * (pl ^ (4 * (it & 3)))) * 4);
-            dma16_buf(xrsrc, voff, (unsigned)(ct * 64 * 4), tt + it * 256);
-        }
+        for (int it = 0; it < 8; ++it) dma16_buf(xrsrc, v0 + (unsigned)(it * 4 * C * 4), (unsigned)(ct * 64 * 4), tt + it * 256);
     };
 
     f32x16 acc[2];
-    // ---- epilogue of one 64-column tile.  acc[j][4 q + e] = (A W^T)[row r][n0 + 32 j + 8 q + 4 h + e]
+    // ---- epilogue of one 64-column tile.  The MFMAs take the stationary operand as the ROW operand: acc[j][4 q + e] =
+    // (A W^T)[row 8 q + 4 h + e][n0 + 32 j + r] — a register holds 32 consecutive columns of one row across a lane half, so the
+    // result needs no transpose: per register one conflict-free 4-byte read of the residual tile and one store of 2 x 128
+    // contiguous bytes; a lane owns ONE column per 32-column block: its column sums are 16 adds and one lane-half exchange
+#ifdef UO8_STAMPS
+    unsigned long long t_e1 = 0, t_e2 = 0;
+#endif
     auto epilogue = [&](int ct) {
         const int n0 = ct * 64;
+#ifdef UO8_STAMPS
+        const unsigned long long te0 = UTICK();
+#endif
         int ln = lane;
         asm volatile("" : "+v"(ln));
-        const int r = ln & 31, h = ln >> 5, pl1 = h ^ (r & 15);
-        const int lr = ln >> 4, c4 = ln & 15, pl = c4 ^ lr;
-        float* xo = xw + (size_t)(lr * C + n0 + 4 * c4);
+        const int r = ln & 31, h = ln >> 5;
+        const float* tl = tt + 4 * h * 64 + r;
+        const unsigned vo = (unsigned)((4 * h * C + r) * 4);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            __builtin_amdgcn_sched_barrier(0);   // one 32-column block at a time: 8 reads in flight, not 16
+            const float bc = bias_lds[n0 + 32 * j + r];
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float* p = tt + r * 64 + ((pl1 ^ (8 * j + 2 * q)) << 2);   // chunk 8 j + 2 q + h of row r
-                const f32x4 res = *reinterpret_cast<const f32x4*>(p);
-                const f32x4 bs = *reinterpret_cast<const f32x4*>(bias_lds + n0 + 32 * j + 8 * q + 4 * h);
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (acc[j][4 * q + e] + bs[e]) + res[e];
-                *reinterpret_cast<f32x4*>(p) = v;
+            for (int qe = 0; qe < 16; ++qe) {
+                const int row = 8 * (qe >> 2) + (qe & 3);   // + 4 h
+                const float v = (acc[j][qe] + bc) + tl[row * 64 + 32 * j];   // dma::epilogue's order: (A W^T + bias) + residual
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), xrsrc, vo, (unsigned)((row * C + n0 + 32 * j) * 4), 0);   // default policy: the next kernels re-read x
+                s1 += v;
+                s2 = __builtin_fmaf(v, v, s2);   // explicit fma, as in dma::epilogue
             }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private tile: the wave's own LDS operations are in order
-        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const f32x4 v4 = *reinterpret_cast<const f32x4*>(tt + (4 * it + lr) * 64 + ((pl ^ (4 * (it & 3))) << 2));
-            *reinterpret_cast<f32x4*>(xo + (size_t)it * 4 * C) = v4;   // default policy: the next kernels re-read x
-            s1 += v4;
-            // explicit fma, as in dma::epilogue
-#pragma unroll
-            for (int q = 0; q < 4; ++q) s2[q] = __builtin_fmaf(v4[q], v4[q], s2[q]);
-        }
-        if (g.stats) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                s1[q] += __shfl_xor(s1[q], 16, 64);
-                s1[q] += __shfl_xor(s1[q], 32, 64);
-                s2[q] += __shfl_xor(s2[q], 16, 64);
-                s2[q] += __shfl_xor(s2[q], 32, 64);
-            }
-            if (lane < 16) {
-                *reinterpret_cast<f32x4*>(red + (wave * 2 + 0) * 64 + 4 * c4) = s1;
-                *reinterpret_cast<f32x4*>(red + (wave * 2 + 1) * 64 + 4 * c4) = s2;
+            if (g.stats) {
+                const float t1 = sum_halves(s1), t2 = sum_halves(s2);   // rows 4 h + .. of both lane halves
+                if (ln < 32) {
+                    red[(wave * 2 + 0) * 64 + 32 * j + r] = t1;
+                    red[(wave * 2 + 1) * 64 + 32 * j + r] = t2;
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tile is read (and `red` written) before anything overwrites it
+#ifdef UO8_STAMPS
+        t_e2 += UTICK() - te0;
+#endif
     };
     // column sums of tile ct over the block's 128 rows: after a block barrier that follows every wave's epilogue(ct)
     auto write_stats = [&](int ct) {
@@ -382,12 +447,17 @@ __global__ __launch_bounds__(256, 2) void unpool_outproj_h8_kernel(UnpoolH8Args 
         constexpr int kt = decltype(KT)::value, gq = kt >> 1;
         constexpr bool lst = (kt & 1) != 0;
         // own pieces of stage kt + 1 landed.  Younger vector-memory operations that may stay in flight: the pieces of the NS - 3
-        // stages after it and, while the awaited pieces are older than them (kt <= NS - 3), this tile's residual pieces and the
-        // stores of the previous tile's epilogue
+        // stages after it and, while the awaited pieces are older than them, this tile's residual pieces
+        // (issued right after step 0's stage: one step more before a wait covers them) and the stores of the previous tile's epilogue
         constexpr int young = (NS - 3) * U_PW;
-        if constexpr (kt <= NS - 3) {
+        if constexpr (kt == 0) {
+            if (ct == 0) dma::wait_vm_lgkm0<young>();
+            else dma::wait_vm_lgkm0<young + U_STORES>();
+        } else if constexpr (kt <= NS - 3) {
             if (ct == 0) dma::wait_vm_lgkm0<young + U_RES>();
             else dma::wait_vm_lgkm0<young + U_RES + U_STORES>();
+        } else if constexpr (kt == NS - 2) {
+            dma::wait_vm_lgkm0<young + U_RES>();
         } else {
             dma::wait_vm_lgkm0<young>();
         }
@@ -398,6 +468,9 @@ __global__ __launch_bounds__(256, 2) void unpool_outproj_h8_kernel(UnpoolH8Args 
             if (g.stats && ct > 0 && wave == ((ct - 1) & 3)) write_stats(ct - 1);
         }
         issue();
+#if !defined(UO8_DIAG_NORES) && !defined(UO8_DIAG_NOEPI)
+        if constexpr (kt == 0) issue_res(ct);   // the previous tile's epilogue has read the transpose tile: its rows may be overwritten
+#endif
         const float* cur = ring + slot * U_STAGE;
         slot = slot + 1 == NS ? 0 : slot + 1;
         const float* nxt = ring + slot * U_STAGE;
@@ -408,7 +481,7 @@ __global__ __launch_bounds__(256, 2) void unpool_outproj_h8_kernel(UnpoolH8Args 
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const i32x4 wc = c == 0 ? __builtin_shufflevector(fbA[j], fbA[j], 0, 1, 2, 3) : __builtin_shufflevector(fbA[j], fbA[j], 4, 5, 6, 7);
-                    acc[j] = U_MFMA16(__builtin_bit_cast(f16x8, wc), fa[2 * gq][c], (kt == 0 && c == 0) ? zero16 : acc[j]);
+                    acc[j] = UG_MFMA16(fa[2 * gq][c], __builtin_bit_cast(f16x8, wc), (kt == 0 && c == 0) ? zero16 : acc[j]);
                 }
         } else {
             // Ah Wl: fp8(Ah) of the group's two k-steps, bytes in the image's k order (16 t + 8 c + e)
@@ -427,7 +500,7 @@ __global__ __launch_bounds__(256, 2) void unpool_outproj_h8_kernel(UnpoolH8Args 
                     a8[4 * t + 2 * c + 1] = __builtin_bit_cast(int, p1);
                 }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[j] = U_MFMA8(fbA[j], a8, acc[j], 127 - 19, 127);
+            for (int j = 0; j < 2; ++j) acc[j] = UG_MFMA8(a8, fbA[j], acc[j], 127, 127 - 19);
         }
         load_f(nxt, fbA);
         if constexpr (!lst) {
@@ -436,21 +509,30 @@ __global__ __launch_bounds__(256, 2) void unpool_outproj_h8_kernel(UnpoolH8Args 
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const i32x4 wc = c == 0 ? __builtin_shufflevector(fbB[j], fbB[j], 0, 1, 2, 3) : __builtin_shufflevector(fbB[j], fbB[j], 4, 5, 6, 7);
-                    acc[j] = U_MFMA16(__builtin_bit_cast(f16x8, wc), fa[2 * gq + 1][c], acc[j]);
+                    acc[j] = UG_MFMA16(fa[2 * gq + 1][c], __builtin_bit_cast(f16x8, wc), acc[j]);
                 }
         } else {
             // Al W
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[j] = U_MFMA8(fbB[j], alo[gq], acc[j], 127 - 8, 127 - 14);
+            for (int j = 0; j < 2; ++j) acc[j] = UG_MFMA8(alo[gq], fbB[j], acc[j], 127 - 14, 127 - 8);
         }
     };
     for (int ct = 0; ct < NG; ++ct) {
         asm volatile("" : "+s"(one));
-        issue_res(ct);   // the previous tile's epilogue has read the transpose tile: its rows may be overwritten
         static_for(std::make_integer_sequence<int, NKT>{}, [&](auto KT) { stage(KT, ct); });
+#ifdef UO8_DIAG_NOEPI
+        if (acc[0][0] == 123.456f) epilogue(ct);
+#else
         epilogue(ct);
+#endif
     }
     USTAMP(2);
+#ifdef UO8_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 2048) {
+        g_uo8_epi[blockIdx.x * 4 + 0] = t_e1;
+        g_uo8_epi[blockIdx.x * 4 + 1] = t_e2;
+    }
+#endif
     if (g.stats) {
         __builtin_amdgcn_s_barrier();   // every wave's partial sums of the last tile are in `red` (lgkmcnt(0) closed its epilogue)
         if (wave == ((NG - 1) & 3)) write_stats(NG - 1);
@@ -487,7 +569,7 @@ size_t unpool_outproj_h8_kv_bytes(int B, int C, int H) { return (size_t)B * H * 
 int kvh_image_launch(const float* kvh, void* img, int B, int C, int H, hipStream_t st) {
     const int hd = C / H;
     if (hd % 16 || hd > 64) return -9;
-    hipLaunchKernelGGL(kvh_image_kernel, dim3(B * H), dim3(256), 0, st, kvh, static_cast<u16*>(img), C, H, hd, u_kv_bytes(hd));
+    hipLaunchKernelGGL(kvh_image_kernel, dim3(B * H), dim3(256), (size_t)u_kv_bytes(hd), st, kvh, static_cast<u16*>(img), C, H, hd, u_kv_bytes(hd));
     return (int)hipGetLastError();
 }
 
@@ -498,8 +580,17 @@ int unpool_outproj_h8_launch(const UnpoolH8Args& g0, int C, hipStream_t st) {
         const char* e = getenv("GECCO_UO8_REV");
         rev = e ? (atoi(e) != 0) : 1;
     }
+    static int stagger = -1, pair = 32;   // GECCO_UO8_STAGGER=<ticks>, GECCO_UO8_PAIR=<blocks per XCD between the two blocks of a CU>
+    if (stagger < 0) {
+        const char* e = getenv("GECCO_UO8_STAGGER");
+        stagger = e ? atoi(e) : 0;
+        const char* e2 = getenv("GECCO_UO8_PAIR");
+        pair = e2 && atoi(e2) > 0 ? atoi(e2) : 32;
+    }
     UnpoolH8Args g = g0;
     g.rev = rev;
+    g.stagger = g.B * (g.rows / 128) >= 512 ? stagger : 0;
+    g.pair = pair;
     switch (C) {
         case 128: return uo8_launch_t<2, 16, 4>(g, st);
         case 256: return uo8_launch_t<4, 32, 5>(g, st);

@@ -344,6 +344,44 @@ def spawn_ranks(n: int, argv: list[str]) -> int:
     return rc
 
 
+def distributed_report(dev, local_points_per_sec=None, sizes=(53_900_000, 8_388_608)):
+    """What the FIRST multi-GPU run should say about itself (the build container has one GPU; the driver's 8-GPU node runs this
+    unattended): the ranks the process group really has, the collective library, the bus bandwidth of the gradient all-reduce at
+    the sizes the training step issues (the whole 53.9 MB flat gradient buffer; one ~8 MB bucket — xGMI is point-to-point, a ring
+    all-reduce is per-link bound: bus bandwidth = 2 (n - 1) / n x bytes / t), and this rank's own un-barriered rate, so that
+    the N = 1 line of a scaling table can be checked against the single-GPU bench.  Collective call on every rank; the dict is
+    meaningful on rank 0.  Reference: gecco-jax models/diffusion.py:571-573 (pmean), Lightning's implicit DDP."""
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rep = {"backend": dist.get_backend() if dist.is_initialized() else None, "ranks_in_group": world,
+           "collective_library": None, "allreduce": {}, "rank0_points_per_sec_unbarriered": local_points_per_sec}
+    on_gpu = dev is not None and torch.device(dev).type == "cuda"
+    if on_gpu:
+        try:
+            rep["collective_library"] = "RCCL/NCCL " + ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:   # noqa: BLE001
+            rep["collective_library"] = f"unknown ({e!r})"[:80]
+    if dist.is_initialized():
+        for nbytes in sizes:
+            n = max(nbytes // 4, 1)
+            buf = torch.ones(n, dtype=torch.float32, device=dev if on_gpu else "cpu")
+            for _ in range(2):
+                dist.all_reduce(buf)
+            if on_gpu:
+                torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            iters = 5
+            for _ in range(iters):
+                dist.all_reduce(buf)
+            if on_gpu:
+                torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / iters
+            rep["allreduce"][f"{nbytes} B"] = {"ms": dt * 1e3,
+                                               "busbw_gbs": 2 * (world - 1) / world * n * 4 / dt / 1e9 if world > 1 else None}
+    return rep
+
+
 def launcher_selftest(args):
     """`--selftest-launcher`: the N > 1 plumbing alone (spawn, rendezvous, barrier, max-over-ranks timing, one JSON line
     from rank 0) on the gloo backend with a stand-in step — no GPU, no compute path; covered by tests/."""
@@ -354,9 +392,12 @@ def launcher_selftest(args):
     for _ in range(args.steps):
         time.sleep(0.001 * (rank + 1))
     gd.barrier()
-    dt = gd.max_over_ranks(time.perf_counter() - t0)
+    local = time.perf_counter() - t0
+    dt = gd.max_over_ranks(local)
+    rep = distributed_report(None, local_points_per_sec=args.steps / local, sizes=(4096, 1024)) if world > 1 else None
     if rank == 0:
-        print(json.dumps({"metric": "launcher_selftest", "n_gpus": world, "steps": args.steps, "ms_per_step": dt / args.steps * 1e3}))
+        print(json.dumps({"metric": "launcher_selftest", "n_gpus": world, "steps": args.steps, "ms_per_step": dt / args.steps * 1e3,
+                          "distributed": rep}))
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
@@ -492,6 +533,7 @@ def train_bench(args, rank, world, dev):
         ms0 = gd.max_over_ranks(time.perf_counter() - t0, dev) / args.steps * 1e3
         rec["ms_per_step_without_allreduce"] = ms0
         rec["allreduce_ms_exposed"] = ms - ms0
+        rec["distributed"] = distributed_report(dev, sizes=(flat.numel() * 4, 8 << 20))
     if rank == 0:
         print(json.dumps(rec))
     if dist.is_initialized():
@@ -591,6 +633,23 @@ def other_config_bench(args, rank, world, dev):
         ctx = Context3d(image=img, K=K)
         cn(ctx)
         rec_extra["conditioner_ms"] = time_events(lambda: cn(ctx), 3, warmup=1)
+        # the projective lookup alone (models/ray.py:64-87 -> csrc/lookup.hip: reparam^-1, projection, 4 bilinear taps per level,
+        # channels-last texels, GroupNorm partials): SURVEY 8(d) calls it gather-bound — 4 taps x 672 channels x 4 B = 10.75 KB
+        # gathered + 2.69 KB written per point — priced against HBM with HIP events on the stream it is launched on.  The taps of
+        # neighbouring points share texels, so most of the gathered bytes are L2 / Infinity-Cache hits: `frac` can exceed what
+        # HBM alone could deliver; `hbm_floor_ms` is the time of the bytes that MUST cross HBM once (pyramids + output).
+        coef = ops.edm_coeffs(sigma)
+        lk = lambda: ops.ray_lookup(x, K, levels, net.table.reparam, coef=coef, want_stats=True)
+        lk_ms = time_events(lk, 10)
+        ct = 96 + 192 + 384
+        gathered, written = Bc * Nc * 4 * ct * 4, Bc * Nc * ct * 4
+        pyr_bytes = sum(f.numel() * 4 for f in levels)
+        rec_extra["lookup"] = {"kernel": "ray_lookup_kernel (one wave per point, 16-byte channel chunks of channels-last texels)",
+                               "ms": lk_ms, "bound": "hbm", "algorithmic_bytes": gathered + written,
+                               "achieved_gbs": (gathered + written) / (lk_ms * 1e-3) / 1e9, "peak_gbs": PEAK_HBM_GBS,
+                               "frac": (gathered + written) / (lk_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                               "hbm_floor_ms": (pyr_bytes + written) / PEAK_HBM_GBS / 1e9 * 1e3,
+                               "bytes_per_point": {"gathered": 4 * ct * 4, "written": ct * 4}}
     else:
         p = {k: v.to(dev) for k, v in random_state_dict(9, dc, Ll).items()}
         net = ops.LinearLiftPlan(p, Hh, Ii)
@@ -762,10 +821,12 @@ def main():
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
+    local_dt = time.perf_counter() - t0
     gd.barrier()
     torch.cuda.synchronize()
     dt = gd.max_over_ranks(time.perf_counter() - t0, dev)
     assert torch.isfinite(out).all(), "non-finite denoiser output"
+    dist_rep = distributed_report(dev, local_points_per_sec=B * N * args.steps / local_dt) if world > 1 else None
 
     ms = dt / args.steps * 1e3
     value = world * B * N * args.steps / dt
@@ -780,6 +841,8 @@ def main():
         "launch": "eager" if args.eager else "hipgraph replay of one captured Diffusion.forward",
         "target_points_per_sec_per_gpu": 2.0e6,
     }
+    if dist_rep is not None:
+        rec["distributed"] = dist_rep
     mode = args.precision
     rec["dtype"] = {"mixed": "f16/fp8/bf16 mixed (kv_proj|q_proj: fp16 activations x fp16 weights, the V columns + an fp8 second weight term; fp16 K|V, q "
                              "and attention products; out_proj and the point MLP: fp16 main product + two fp8 cross terms (h8, split-bf16 accuracy); "
@@ -855,6 +918,9 @@ def main():
             kk = next((v for k, v in pk.items() if k.startswith("gemm_h8_astat_kernel")), {})
             rec["roofline"] = {"bound": "mfma", "achieved": mtf, "peak": PEAK_BF16_MFMA_TFLOPS / 2, "unit": "TFLOP/s",
                                "frac": 2 * mtf / PEAK_BF16_MFMA_TFLOPS, "traffic": kk.get("bytes_per_launch"),
+                               # the same launch against the PLAIN dense 16-bit peak on its algorithmic 2MNK: the "/ 2 units" peak above
+                               # counts the two cross terms the arithmetic chose as useful work; this figure does not
+                               "frac_dense_fp16_algorithmic": mtf / PEAK_BF16_MFMA_TFLOPS,
                                # cycle-based view of the same kernel (committed PMC constant, not measured in this run)
                                "mfma_busy_pmc": kk.get("mfma_busy"),
                                "kernel": "gemm_h8_astat_kernel<6,4,6,1,true> = mlp.0 of the mixed mode (A-stationary over 128-row blocks, AdaGN apply, "
@@ -944,15 +1010,31 @@ def main():
             "hbm_gbs": cb / (ms * 1e-3) / 1e9 if cb else None, "hbm_frac": cb / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS if cb else None,
             "algorithmic_bytes_fp32_stream": 6.04e9}
     if rank == 0 and world == 1 and not args.no_extras and not args.eager:
-        # what else the tree does, in front of the driver (compact; each a child process with ~10 timed steps)
-        tr = run_child(["--train", "--steps", "10", "--warmup", "3", "--precision", args.precision])
+        # what else the tree does, in front of the driver (compact; each a child process with ~10 timed steps).  The headline is
+        # complete at this point: it goes to stderr now (a harness that loses patience with the extras still has it), this
+        # process gives its device memory back before the children start, and the extras share ONE time budget (a slow or
+        # hung child costs at most its own cap; what does not fit is reported as skipped, never waited for)
+        print("[bench headline, extras pending] " + json.dumps({k: rec[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step")}),
+              file=sys.stderr, flush=True)
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        t_extras = time.time()
+        budget, cap = 360.0, 150.0
+
+        def run_extra(argv):
+            left = budget - (time.time() - t_extras)
+            if left < 20.0:
+                return {"error": "skipped: the extras' time budget (360 s) is spent"}
+            return run_child(argv, timeout=min(cap, left))
+        tr = run_extra(["--train", "--steps", "10", "--warmup", "3", "--precision", args.precision])
         rec["train"] = tr if "error" in tr else {
             "config": "C2 training step, batch 48/GPU (forward + backward + fused Adam/EMA, HIP autograd path, split-bf16)",
             "ms_per_step": tr["ms_per_step"], "points_per_sec": tr["value"], "tflops_algorithmic": tr["train_tflops_algorithmic"],
             "adam_ema_ms": tr.get("adam_ema_ms"), "dominant_kernel": tr.get("dominant_kernel")}
         cfgs = {}
         for c in ("C3", "C4", "C5"):
-            rc_ = run_child(["--config", c, "--steps", "10", "--warmup", "3", "--precision", args.precision] + (["--no-sampler"] if c != "C5" else []))
+            rc_ = run_extra(["--config", c, "--steps", "10", "--warmup", "3", "--precision", args.precision] + (["--no-sampler"] if c != "C5" else []))
             if "error" in rc_:
                 cfgs[c] = rc_
                 continue
@@ -960,6 +1042,8 @@ def main():
                        "workload": rc_["config"]["workload"][:160]}
             if "conditioner_ms" in rc_:
                 cfgs[c]["conditioner_ms_per_batch"] = rc_["conditioner_ms"]
+            if "lookup" in rc_:
+                cfgs[c]["lookup"] = rc_["lookup"]
             if "upsample" in rc_:
                 rec["upsample"] = rc_["upsample"]
         rec["configs"] = cfgs

@@ -290,7 +290,8 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         h8_on = gemm_h8_astat_supported(hg) && Wd % 16 == 0 && C % 16 == 0;
     }
     // mixed mode: kv_proj | q_proj on the 64-column-tile A-stationary kernel (option "kvq64"; two 128-row blocks per CU, W bytes
-    // shared by 128 rows, 16-byte head-major stores); falls back to the 128-column-tile kernel where it does not apply
+    // shared by 128 rows, 16-byte head-major stores).  The weight images are then built in the kvq format: a shape the kernel rejects
+    // is an error (-3) of the mixed mode, not a fallback (option "kvq64" = 0 selects the 128-column-tile kernel and its images)
     bool kvq_on = false;
     if (mixed && w.wimg && option(OPT_KVQ64) && option(OPT_HEADMAJOR) && (C == 128 || C == 256 || C == 384 || C == 512) && !((C / H) & 7)) kvq_on = true;
     // ... and mlp.2 / out_proj as h8 products fed from h8 activation images (gemm_h8_areg.hip; option "h8areg")
@@ -882,7 +883,7 @@ int gecco_linear_h8_img_f32(const float* x, const float* pro_a, const float* pro
     g.A = x; g.pro_a = pro_a; g.pro_o = pro_o; g.bias = bias; g.alpha = alpha; g.act = act; g.C = static_cast<float*>(c_img);
     g.B = B; g.rows = rows; g.K = K; g.Nout = Nout; g.lda = K; g.ldw = K; g.ldc = Nout; g.c_img = image_kind; g.w_img = wsplit;
     if (!gemm_h8_astat_supported(g))
-        return fail(-2, "linear_h8_img: needs rows %% 256 == 0, Nout %% 64 == 0, Nout >= 128, K in {128, 256, 384}, act in 0 .. 3");
+        return fail(-2, "linear_h8_img: needs rows %% 128 == 0, Nout %% 64 == 0, Nout >= 128, K in {128, 256, 384}, act in 0 .. 3");
     if (W) {   // NULL: wsplit still holds the image a previous call made from the same weights
         SplitJobs jobs;
         jobs.n = 1;

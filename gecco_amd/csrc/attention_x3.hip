@@ -15,6 +15,7 @@
 // The same kernels serve the fp16 mode (precision 2, template flag F16): one fp16 plane instead of hi | lo, one
 // v_mfma_f32_32x32x16_f16 per product, operands rounded to nearest even.
 #include "common.h"
+#include "h8_scales.h"
 #include "kernels.h"
 
 namespace {
@@ -559,22 +560,24 @@ __global__ __launch_bounds__(256, 2) void unpool_attn_x3_kernel(const float* __r
         } else if (out32 == 3) {
             // the output as the h8 activation image an h8 out_proj loads straight into registers (GemmArgs::a_img == 2,
             // gemm_h8_areg.hip): per (sample, 128-row tile, 64-k group) 6144 floats — fp16 hi fragments [32-row tile][sub][c][lane],
-            // then fp8(2^14 lo) halves [32-row tile][t][lane]; a row's 8 columns are one 16-byte hi chunk and 8 lo bytes
+            // then fp8(2^11 lo) halves [32-row tile][t][lane]; a row's 8 columns are one 16-byte hi chunk and 8 lo bytes
             const int t128 = (N + 127) >> 7, ngk = C >> 6;
 #pragma unroll
             for (int ld = 0; ld < LD8; ++ld) {
                 const int f = ld * 64 + lane, row = f / CH8, c8 = f % CH8, n = q0 + row;
                 if (f < 32 * CH8 && n < N) {
-                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(Ot + row * OP + c8 * 8);
-                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(Ot + row * OP + c8 * 8 + 4);
+                    f32x4 v0 = *reinterpret_cast<const f32x4*>(Ot + row * OP + c8 * 8);
+                    f32x4 v1 = *reinterpret_cast<const f32x4*>(Ot + row * OP + c8 * 8 + 4);
                     f16x8 hv;
                     float lo[8];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
+                        v0[e] = h8_clamp(v0[e]);       // h8_scales.h: an h8 operand is finite in every term
+                        v1[e] = h8_clamp(v1[e]);
                         hv[e] = (_Float16)v0[e];       // v0 / v1 come from LDS: one fp32 value for the hi rounding and the lo difference
                         hv[4 + e] = (_Float16)v1[e];
-                        lo[e] = __builtin_fminf(__builtin_fmaxf((v0[e] - (float)hv[e]) * 16384.f, -448.f), 448.f);
-                        lo[4 + e] = __builtin_fminf(__builtin_fmaxf((v1[e] - (float)hv[4 + e]) * 16384.f, -448.f), 448.f);
+                        lo[e] = __builtin_fminf(__builtin_fmaxf((v0[e] - (float)hv[e]) * H8_AL_SCALE, -448.f), 448.f);
+                        lo[4 + e] = __builtin_fminf(__builtin_fmaxf((v1[e] - (float)hv[4 + e]) * H8_AL_SCALE, -448.f), 448.f);
                     }
                     int p0 = 0, p1 = 0;
                     p0 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[0], lo[1], p0, false);

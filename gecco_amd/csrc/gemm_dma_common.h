@@ -3,6 +3,7 @@
 // GroupNorm partials) through a wave-private LDS transpose with 16-byte nontemporal stores.
 #pragma once
 #include "common.h"
+#include "h8_scales.h"
 #include "kernels.h"
 
 namespace dma {
@@ -144,23 +145,25 @@ __device__ __forceinline__ void epilogue_t(const GemmArgs& g, const Tile& t, f32
                 const int n8 = ncol0 + c8 * 8;
                 if (g.c_img == 2) {
                     // h8 activation image (gemm_h8_areg.hip): per (sample, 128-row tile, 64-column group) 6144 floats — fp16 hi
-                    // fragments [32-row tile][sub][c][lane], then fp8(2^14 lo) halves [32-row tile][t][lane]; a lane's 8
+                    // fragments [32-row tile][sub][c][lane], then fp8(2^11 lo) halves [32-row tile][t][lane]; a lane's 8
                     // consecutive columns are one 16-byte hi chunk and 8 lo bytes (Nout % 64 == 0)
                     typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
                     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
                         const int m = mrow0 + it * 8 + lr8;
-                        const f32x4 v0 = *reinterpret_cast<const f32x4*>(Tt + (it * 8 + lr8) * D_TP + c8 * 8);
-                        const f32x4 v1 = *reinterpret_cast<const f32x4*>(Tt + (it * 8 + lr8) * D_TP + c8 * 8 + 4);
+                        f32x4 v0 = *reinterpret_cast<const f32x4*>(Tt + (it * 8 + lr8) * D_TP + c8 * 8);
+                        f32x4 v1 = *reinterpret_cast<const f32x4*>(Tt + (it * 8 + lr8) * D_TP + c8 * 8 + 4);
                         f16x8 hv;
                         float lo[8];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
+                            v0[e] = h8_clamp(v0[e]);       // h8_scales.h: an h8 operand is finite in every term
+                            v1[e] = h8_clamp(v1[e]);
                             hv[e] = (_Float16)v0[e];       // v0 / v1 come from LDS: one fp32 value for the hi rounding and the lo difference
                             hv[4 + e] = (_Float16)v1[e];
-                            lo[e] = __builtin_fminf(__builtin_fmaxf((v0[e] - (float)hv[e]) * 16384.f, -448.f), 448.f);
-                            lo[4 + e] = __builtin_fminf(__builtin_fmaxf((v1[e] - (float)hv[4 + e]) * 16384.f, -448.f), 448.f);
+                            lo[e] = __builtin_fminf(__builtin_fmaxf((v0[e] - (float)hv[e]) * H8_AL_SCALE, -448.f), 448.f);
+                            lo[4 + e] = __builtin_fminf(__builtin_fmaxf((v1[e] - (float)hv[4 + e]) * H8_AL_SCALE, -448.f), 448.f);
                         }
                         int p0 = 0, p1 = 0;
                         p0 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[0], lo[1], p0, false);

@@ -23,6 +23,7 @@
 // which sit in the in-order vmcnt queue behind the DMA pieces already in flight; the K-steps after an epilogue whose
 // awaited piece was issued before it wait with that count added instead of draining the stores.
 #include "gemm_dma_common.h"
+#include "h8_scales.h"
 
 #include <stdlib.h>
 
@@ -81,7 +82,7 @@ __device__ __forceinline__ void static_for_tag(std::integer_sequence<int, I...>,
 // K-steps of every column tile, multiplied with the SAME register-resident A fragments: x . W_hi + x . W_lo in one
 // accumulator.  The rounding of the weights — coherent over all points of a cloud, the dominant error of the fp16
 // mode (tools/experiments/fp16_site_sensitivity.py) — drops from 2^-12 to 2^-23; the A side is unchanged.
-// WS = 3: the lo term on the fp8 matrix instruction.  The lo image holds fp8(2^19 (W - fp16(W))) in 64-k stages
+// WS = 3: the lo term on the fp8 matrix instruction.  The lo image holds fp8(2^16 (W - fp16(W))) (h8_scales.h) in 64-k stages
 // (f8lo_image_item): NK / 2 further stages per column tile, each ONE v_mfma_scale_f32_32x32x64_f8f6f4 per 32-column block
 // (scale_b = 2^-19) on the A fragments of two K-steps converted to fp8 on the fly — half the LDS bytes and half the
 // matrix cycles of the fp16 lo term for the same result (the lo term is 2^-12 of the product: 3 mantissa bits of it suffice;
@@ -161,8 +162,9 @@ __global__ __launch_bounds__(S_NT, 2) void gemm_f16_astat_kernel(GemmArgs g) {
                 f16x8 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v[e] = (_Float16)x0[u][e];
-                    v[4 + e] = (_Float16)x1[u][e];
+                    // WS == 3: this operand also goes through the scaled fp8 conversion, which returns NaN beyond the format (h8_scales.h)
+                    v[e] = (_Float16)(WS == 3 ? h8_clamp(x0[u][e]) : x0[u][e]);
+                    v[4 + e] = (_Float16)(WS == 3 ? h8_clamp(x1[u][e]) : x1[u][e]);
                 }
                 const int sub = c8 >> 2, ch = (c8 & 3) ^ ((row >> 2) & 3);
                 *reinterpret_cast<u32x4*>(ring + sub * S_TILE + row * 16 + ch * 4) = __builtin_bit_cast(u32x4, v);
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(S_NT, 2) void gemm_f16_astat_kernel(GemmArgs g) {
     dma::wait_vm_lgkm0<(NS - 1) * S_PW>();
     __builtin_amdgcn_s_barrier();
     load_b(0, 0);
-    float one = 1.0f;   // the fp8 conversions' scale operand (see the lo stage)
+    float one = H8_AH_DIV;   // the fp8 conversions' scale operand: fp8(a / 8), h8_scales.h (see the lo stage)
     for (int ct = 0; ct < tilesN; ++ct) {
         const bool first = ct == 0, last = ct == tilesN - 1;
         const bool has_lo = WS >= 2 && ct >= lo_begin && ct < lo_tiles;   // this column tile runs NK + NL stages (hi, lo), else NK
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(S_NT, 2) void gemm_f16_astat_kernel(GemmArgs g) {
                     }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, fb[cur][j], acc[j], 0, 0, 0, 127, 0, 127 - 19);
+                    acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, fb[cur][j], acc[j], 0, 0, 0, H8_SC_AH, 0, H8_SC_WL);
                 if (!last || kt + 1 < len) load_b((kt + 1) % NS, cur ^ 1);
             } else {
 #pragma unroll

@@ -268,13 +268,13 @@ __device__ __forceinline__ void f16_image_item(const float* __restrict__ W, floa
     *reinterpret_cast<u32x4*>(img + blk * FB_TILE + rb * 16 + chp * 4) = __builtin_bit_cast(u32x4, v);
 }
 
-// The LOW part of a two-term fp16 weight as fp8 (e4m3), scaled by 2^19, for v_mfma_scale_f32_32x32x64_f8f6f4: for column
+// The LOW part of a two-term fp16 weight as fp8 (e4m3), scaled by 2^16 (h8_scales.h), for v_mfma_scale_f32_32x32x64_f8f6f4: for column
 // tile ct and 64-k step S the 8 KiB block at float offset (ct * K/64 + S) * 2048 holds row rb at rb * 16 floats (64 B =
 // 64 fp8); its 16-byte chunk s ^ ((rb >> 2) & 3) holds k = 64 S + 32 (s & 1) + 16 (s >> 1) .. + 15 — lane half s >> 1,
 // bytes 16 (s & 1) .. of the 32-byte B operand: the same (lane half, chunk) addressing as the fp16 stages, and the k
-// order in which gemm_f16_astat.hip packs its fp16 A fragments into the fp8 A operand.  |w_lo| <= 2^-12 |w|: the scale
-// keeps weights up to |w| = 1 inside e4m3's range (448); larger ones saturate (their hi term is unaffected).
-constexpr float LO8_SCALE = 524288.f;   // 2^19; the kernel's scale_b is 2^-19
+// order in which gemm_f16_astat.hip packs its fp16 A fragments into the fp8 A operand.  |w_lo| <= 2^-11 |w|: the scale
+// keeps weights up to |w| = 14 inside e4m3's range (448); larger ones saturate (their hi term is unaffected).
+constexpr float LO8_SCALE = H8_WL_SCALE;   // 2^16 (h8_scales.h); the kernel's scale_b is its inverse
 __device__ __forceinline__ void f8lo_image_item(const float* __restrict__ W, float* __restrict__ img, int Nout, int K,
                                                 int ldw, size_t i) {
     const int nk = K / 64;
@@ -289,7 +289,7 @@ __device__ __forceinline__ void f8lo_image_item(const float* __restrict__ W, flo
         const f32x4 w = *reinterpret_cast<const f32x4*>(src + 4 * q);
         float lo[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) lo[e] = (w[e] - (float)(_Float16)w[e]) * LO8_SCALE;
+        for (int e = 0; e < 4; ++e) lo[e] = __builtin_fminf(__builtin_fmaxf((w[e] - (float)(_Float16)w[e]) * LO8_SCALE, -448.f), 448.f);
         int pk = 0;
         pk = __builtin_amdgcn_cvt_pk_fp8_f32(lo[0], lo[1], pk, false);
         pk = __builtin_amdgcn_cvt_pk_fp8_f32(lo[2], lo[3], pk, true);

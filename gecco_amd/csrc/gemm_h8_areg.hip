@@ -8,22 +8,23 @@
 // and epilogue as gemm_x3_areg.hip, whose split-bf16 product (3 matrix instructions per 16 k, 4 bytes per operand element) it
 // replaces by
 //
-//       A W = Ah Wh (v_mfma_f32_32x32x16_f16) + fp8(Ah) fp8(2^19 Wl) + fp8(2^14 Al) fp8(2^8 W)   (v_mfma_scale_f32_32x32x64_f8f6f4)
+//       A W = Ah Wh (v_mfma_f32_32x32x16_f16) + fp8(Ah 2^-3) fp8(2^16 Wl) + fp8(2^11 Al) fp8(2^5 W)   (v_mfma_scale_f32_32x32x64_f8f6f4; h8_scales.h)
 //
 // — 2 matrix-pipe units per product and 3 bytes per element, at split-bf16 accuracy (tools/experiments/fp16_site_sensitivity.py,
-// scheme h8: 6.0e-5 on F_x against 6.7e-5).  A = Ah + Al with Ah = fp16(A), Al kept as fp8(2^14 (A - Ah)).
+// scheme h8: 6.0e-5 on F_x against 6.7e-5).  A = Ah + Al with Ah = fp16(A), Al kept as fp8(2^11 (A - Ah)).
 //
 // Activation image (GemmArgs::a_img == 2; written by gemm_h8_astat.hip's epilogue and by the unpool attention kernel): per
 // (sample, 128-row tile, 64-k group) one 24 KiB block:
 //   hi, 16 KiB: [32-row tile rt][sub][c][lane] x 16 bytes = the 8 fp16 of row 32 rt + (lane & 31), k = 32 sub + 16 (lane >> 5) + 8 c + 0 .. 7
 //               — the MFMA A fragment of k-step (sub, c), 1 KiB of consecutive bytes per wave-instruction;
-//   lo,  8 KiB: [rt][t][lane] x 16 bytes = the 16 fp8 of the same row, k = 32 t + 16 (lane >> 5) + 0 .. 15 — one half of the scaled
+//   lo,  8 KiB: [rt][t][lane] x 16 bytes = the 16 fp8 (2^11 lo) of the same row, k = 32 t + 16 (lane >> 5) + 0 .. 15 — one half of the scaled
 //               MFMA's 32-byte A operand.
 // W image: h8_image_item<128> (gemm_h8_astat.hip): per (128-column tile, 64-k group) a 16 KiB H stage (two [128][32] fp16
 // sub-tiles) and a 16 KiB L stage (fp8 Wl | fp8 W), streamed through a ring of NS stages by global_load_lds; the A fragments
 // of group g + D are loaded when group g's registers are free.  The K loop is fully unrolled: every wait is a compile-time
 // count (young_at below).
 #include "gemm_dma_common.h"
+#include "h8_scales.h"
 
 #include <utility>
 
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(DNT, 2) void gemm_h8_areg_kernel(GemmArgs g) {
     // step 0 needs P_1 and A_0; the fragments of stage 0 itself need P_0 of every wave: older than both
     __builtin_amdgcn_s_barrier();
     load_f(smem, fbA);
-    float one = 1.0f;
+    float one = H8_AH_DIV;   // fp8(Ah / 8): h8_scales.h
     asm volatile("" : "+s"(one));
 
     static_for(std::make_integer_sequence<int, NST>{}, [&](auto TT) {
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(DNT, 2) void gemm_h8_areg_kernel(GemmArgs g) {
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[0][j] = A_MFMA8(a8, fbA[j], acc[0][j], 127, 127 - 19);
+                acc[0][j] = A_MFMA8(a8, fbA[j], acc[0][j], H8_SC_AH, H8_SC_WL);
         }
         if constexpr (t + 1 < NST) load_f(smem + ((t + 1) % NS) * G_STAGE, fbA);
         if constexpr (!lst) {
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(DNT, 2) void gemm_h8_areg_kernel(GemmArgs g) {
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[0][j] = A_MFMA8(al8, fbB[j], acc[0][j], 127 - 14, 127 - 8);
+                acc[0][j] = A_MFMA8(al8, fbB[j], acc[0][j], H8_SC_AL, H8_SC_W8);
             // this group's A registers are free once its matrix instructions are issued: the loads of group gq + D
             if constexpr (gq + D < NGK) load_a(gq + D, set);
         }

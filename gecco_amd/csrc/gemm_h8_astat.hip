@@ -11,8 +11,8 @@
 // two terms on both 6e-5).  With y = yh + yl (yh = fp16(y)) and W = Wh + Wl:
 //
 //       y W  =  yh Wh          fp16 MFMA            (v_mfma_f32_32x32x16_f16, 32 cycles per 16 k)
-//            +  yh Wl          fp8 scaled MFMA      (v_mfma_scale_f32_32x32x64_f8f6f4, 64 cycles per 64 k: fp8(yh) x fp8(2^19 Wl))
-//            +  yl W           fp8 scaled MFMA      (fp8(2^14 yl) x fp8(2^8 W))
+//            +  yh Wl          fp8 scaled MFMA      (v_mfma_scale_f32_32x32x64_f8f6f4, 64 cycles per 64 k: fp8(yh 2^-3) x fp8(2^16 Wl))
+//            +  yl W           fp8 scaled MFMA      (fp8(2^11 yl) x fp8(2^5 W); the scales and their ranges: h8_scales.h)
 //            +  yl Wl          dropped (2^-24)
 //
 // — the cross terms are 2^-12 of the product, so 4 significant bits of them suffice: 2 matrix-pipe units per product
@@ -31,6 +31,7 @@
 // v_permlane32_swap per register pair gives every lane 8 consecutive columns = 16 bytes of the hi plane and 16 of the
 // lo plane of the image, a wave-instruction writes 1 KiB of consecutive bytes.
 #include "gemm_dma_common.h"
+#include "h8_scales.h"
 
 #include <stdlib.h>
 
@@ -52,9 +53,7 @@ constexpr int H_BN = 64;           // columns per W tile
 constexpr int H_STAGE = 2048;      // floats per 8 KiB ring stage (two 4 KiB sub-tiles)
 constexpr int H_STG = 1536;        // floats of a wave's staging tile: [32][64] fp16 (4 KiB) + [32][64] fp8 (2 KiB)
 constexpr int H_STORES = 8;        // store instructions of a wave's epilogue per column tile
-constexpr float YL_SCALE = 16384.f;    // 2^14: |yl| <= 2^-11 |y| -> fp8 range (448) up to |y| = 56, saturating beyond
-constexpr float W8_SCALE = 256.f;      // 2^8: weights up to |w| = 1.75 (the bound the 2^19 lo image has as well)
-constexpr float WL_SCALE = 524288.f;   // 2^19
+constexpr float YL_SCALE = H8_AL_SCALE, W8_SCALE = H8_W8_SCALE, WL_SCALE = H8_WL_SCALE;   // h8_scales.h
 
 __device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, float* lds_wave_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
@@ -113,7 +112,7 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
 //   kind 0 (H): sub-tile a = fp16(W[n, 64 g + 0 .. 31]), sub-tile b = fp16(W[n, 64 g + 32 .. 63]); a row n (0 .. 63) is 64 bytes =
 //               four 16-byte chunks, logical chunk q = k / 8 stored at physical chunk q ^ ((n >> 2) & 3)
 //               (the [128][32] fp16 tile layout of gemm_f16_dma.hip, 64 rows of it);
-//   kind 1 (L): sub-tile a = fp8(2^19 (W - fp16(W))), sub-tile b = fp8(2^8 W), both [64 n][64 k] bytes: logical chunk q = 2 h + t
+//   kind 1 (L): sub-tile a = fp8(2^16 (W - fp16(W))), sub-tile b = fp8(2^5 W) (h8_scales.h), both [64 n][64 k] bytes: logical chunk q = 2 h + t
 //               holds k = 64 g + 32 t + 16 h + 0 .. 15 — the order in which a lane half h packs its fp16 fragments of two
 //               k-steps (t) into the fp8 operand; physical chunk as above.
 // One thread per 16-byte chunk: 1024 chunks per (ct, g).
@@ -159,7 +158,7 @@ __device__ __forceinline__ void h8_image_item(const float* __restrict__ W, float
 }
 
 // kv_proj | q_proj stream (gemm_kvq_astat_kernel).  Per 64-column tile ct: the H stages of all NG groups; a tile inside
-// [lo_begin, lo_end) (the V projection) is followed by NG / 2 L stages, each [fp8(2^19 Wl) of group 2 i | of group 2 i + 1] — the
+// [lo_begin, lo_end) (the V projection) is followed by NG / 2 L stages, each [fp8(2^16 Wl) of group 2 i | of group 2 i + 1] — the
 // two-term weights of the mixed mode where their rounding reaches the output, one-term elsewhere.
 // Stage index of tile ct: ct * NG + (NG / 2) * clamp(ct - lo_begin, 0, lo_end - lo_begin).  1024 chunks per (ct, pair of H stages
 // or L stage): item i -> (tile, stage-in-tile, sub-tile, row, physical chunk).
@@ -320,7 +319,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_h8_astat_kernel(GemmArgs g) {
                 float lo[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float y = __builtin_fmaf(xs[s & 1][i][e], pa4[e], po4[e]);
+                    float y = h8_clamp(__builtin_fmaf(xs[s & 1][i][e], pa4[e], po4[e]));
                     asm volatile("" : "+v"(y));   // one rounded fp32 value for the hi rounding and the lo difference (see the epilogue)
                     hv[e] = (_Float16)y;
                     lo[e] = clamp448((y - (float)hv[e]) * YL_SCALE);
@@ -409,6 +408,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_h8_astat_kernel(GemmArgs g) {
                             const float y = __builtin_amdgcn_exp2f(v[e] * v[e] * c2);
                             v[e] = ACT == 1 ? (y - 0.7f) * (1.0f / 0.28f) : y;
                         }
+                        if (ACT == 0 || ACT == 3) v[e] = h8_clamp(v[e]);   // unbounded hidden layers (identity, ReLU): h8_scales.h
                         // ONE fp32 value feeds both the hi rounding and the lo difference: left to itself the compiler forms the
                         // lo path from the unrounded product (v_fma_mixlo_f16 / v_fma_mix_f32) and the stored hi from the rounded
                         // one — near a tie the two hi differ by an fp16 ulp and hi + lo is off by that ulp
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_h8_astat_kernel(GemmArgs g) {
     dma::wait_vm_lgkm0<0>();
     __builtin_amdgcn_s_barrier();
     load_f(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, fbA);
-    float one = 1.0f;   // the fp8 conversions' scale operand behind an opaque asm: keeps them inside the column-tile loop
+    float one = H8_AH_DIV;   // the fp8 conversions' scale operand (fp8(yh / 8), h8_scales.h) behind an opaque asm: keeps them inside the column-tile loop
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int ct = 0; ct < tilesN; ++ct) {
         const bool first = ct == 0;
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_h8_astat_kernel(GemmArgs g) {
                         a8[4 * t + 2 * c + 1] = __builtin_bit_cast(int, p1);
                     }
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[j] = H8_MFMA8(fbA[j], a8, acc[j], 127 - 19, 127);
+                for (int j = 0; j < 2; ++j) acc[j] = H8_MFMA8(fbA[j], a8, acc[j], H8_SC_WL, H8_SC_AH);
             }
             // sub-step b: the first fragments of the next stage are read while it runs
             load_f(std::integral_constant<int, (kt + 1) % NS>{}, std::integral_constant<int, 0>{}, fbA);
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_h8_astat_kernel(GemmArgs g) {
             } else {
                 // yl W
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[j] = H8_MFMA8(fbB[j], alo[gq], acc[j], 127 - 8, 127 - 14);
+                for (int j = 0; j < 2; ++j) acc[j] = H8_MFMA8(fbB[j], alo[gq], acc[j], H8_SC_W8, H8_SC_AL);
             }
         });
 #ifdef H8_PRIO
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kvq_astat_kernel(GemmArgs g) {
                 const int row = 4 * i + lrow;
                 f16x4 hv;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) hv[e] = (_Float16)__builtin_fmaf(xs[s & 1][i][e], pa4[e], po4[e]);
+                for (int e = 0; e < 4; ++e) hv[e] = (_Float16)h8_clamp(__builtin_fmaf(xs[s & 1][i][e], pa4[e], po4[e]));
                 *reinterpret_cast<u32x2*>(sw + row * 128 + (((c16 >> 1) ^ (row & 7)) << 4) + (c16 & 1) * 8) = __builtin_bit_cast(u32x2, hv);
             }
             __builtin_amdgcn_wave_barrier();
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kvq_astat_kernel(GemmArgs g) {
     __builtin_amdgcn_s_barrier();
     int slot = 0;                                      // slot of the current stage
     load_f(ring, fbA);
-    float one = 1.0f;
+    float one = H8_AH_DIV;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // one stage: wait / barrier / issue, two sub-steps.  LST: an L stage (two groups' Wl); G2: its first group (L) or the group (H)
     auto stage = [&](auto KT, auto LST, auto G2, bool first) {
@@ -822,7 +822,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kvq_astat_kernel(GemmArgs g) {
                     a8[4 * t + 2 * c + 1] = __builtin_bit_cast(int, p1);
                 }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[j] = H8_MFMA8(fbA[j], a8, acc[j], 127 - 19, 127);
+            for (int j = 0; j < 2; ++j) acc[j] = H8_MFMA8(fbA[j], a8, acc[j], H8_SC_WL, H8_SC_AH);
         }
         load_f(nxt, fbA);
         if constexpr (!lst) {
@@ -849,7 +849,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kvq_astat_kernel(GemmArgs g) {
                     a8[4 * t + 2 * c + 1] = __builtin_bit_cast(int, p1);
                 }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[j] = H8_MFMA8(fbB[j], a8, acc[j], 127 - 19, 127);
+            for (int j = 0; j < 2; ++j) acc[j] = H8_MFMA8(fbB[j], a8, acc[j], H8_SC_WL, H8_SC_AH);
         }
     };
     for (int ct = 0; ct < tilesN; ++ct) {
@@ -978,9 +978,9 @@ int gemm_kvq_astat_launch(const GemmArgs& g0, hipStream_t st) {
 // (measured: no gain, default 0)
 int gemm_h8_astat_launch(const GemmArgs& g0, hipStream_t st) {
     if (!gemm_h8_astat_supported(g0)) return -9;
-    static const int stagger = h8_env("GECCO_H8_STAGGER", 0), pair = h8_env("GECCO_H8_PAIR", 32);
+    static const int stagger = h8_env("GECCO_H8_STAGGER", 0), pair = h8_env("GECCO_H8_PAIR", 32), rev = h8_env("GECCO_H8_REV", 0);
     GemmArgs g = g0;
-    g.h8_rev = h8_env("GECCO_H8_REV", 0);
+    g.h8_rev = rev;
     g.h8_stagger = stagger;
     g.h8_pair = pair > 0 ? pair : 32;
     switch (g.K) {

@@ -18,7 +18,7 @@
 //     hi)) in place — no transpose: the k order of the stationary operand is whatever the accumulator gives (element e of
 //     fragment (k-step s, lane half h) is k = 16 s + 8 (e >> 2) + 4 h + (e & 3)), and the W image is written in the same order
 //     (h8_image_item<64, true>, SplitJob::pad_ = 16).
-//   * out_proj = gemm_h8_astat.hip's main loop (A W = Ah Wh + fp8(Ah) fp8(2^19 Wl) + fp8(2^14 Al) fp8(2^8 W); 64-column tiles, W
+//   * out_proj = gemm_h8_astat.hip's main loop (A W = Ah Wh + fp8(Ah 2^-3) fp8(2^16 Wl) + fp8(2^11 Al) fp8(2^5 W), h8_scales.h; 64-column tiles, W
 //     streamed through an LDS ring in consumption order).
 //   * epilogue per 64-column tile: the residual rows of the tile were fetched by LDS-DMA into a wave-private tile when the tile's
 //     K loop started; with the stationary operand as the MFMA's ROW operand an accumulator register holds 32 consecutive columns
@@ -27,6 +27,7 @@
 //
 // HBM per launch at C2: q 100 MB + x in 201 MB + x out 201 MB (the 151 MB image written + read before never leaves the CU).
 #include "gemm_dma_common.h"
+#include "h8_scales.h"
 
 #include <stdlib.h>
 
@@ -59,7 +60,7 @@ constexpr int U_STORES = 32;           // x stores per wave and column tile (one
 #endif
 constexpr int U_TT = 2048;             // floats of a wave's residual tile: [32 rows][64 columns]
 constexpr float U_LOG2E = 1.4426950408889634f;
-constexpr float U_YL_SCALE = 16384.f;  // 2^14 (gemm_h8_astat.hip)
+constexpr float U_YL_SCALE = H8_AL_SCALE;   // h8_scales.h
 
 // per (sample, head): K [64][hd + 8] fp16 | V^T [ceil(hd / 32) * 32][72] fp16, padded to whole 4 KiB (one 1 KiB piece per wave)
 constexpr int u_kv_bytes(int HD) { return ((64 * (HD + 8) + ((HD + 31) / 32) * 32 * 72) * 2 + 4095) / 4096 * 4096; }
@@ -326,6 +327,8 @@ __global__ __launch_bounds__(256, 2) void unpool_outproj_h8_kernel(UnpoolH8Args 
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) {
                         f32x2 v = f32x2{O[dt][8 * p + e], O[dt][8 * p + e + 1]} * inv2;
+                        v[0] = h8_clamp(v[0]);   // h8_scales.h: an h8 operand is finite in every term
+                        v[1] = h8_clamp(v[1]);
                         // ONE fp32 value feeds the hi rounding and the lo difference (gemm_h8_astat.hip's epilogue)
                         asm volatile("" : "+v"(v));
                         hv[e] = (_Float16)v[0];
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void unpool_outproj_h8_kernel(UnpoolH8Args 
     __builtin_amdgcn_s_barrier();
     int slot = 0;                                      // slot of the current stage
     load_f(ring, fbA);
-    float one = 1.0f;   // the fp8 conversions' scale operand behind an opaque asm: keeps them inside the column-tile loop
+    float one = H8_AH_DIV;   // the fp8 conversions' scale operand (fp8(Ah / 8), h8_scales.h) behind an opaque asm: keeps them inside the column-tile loop
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // one stage: wait / barrier / issue, two sub-steps.  kt even: the H stage of group kt / 2, odd: its L stage
     auto stage = [&](auto KT, int ct) {
@@ -500,7 +503,7 @@ __global__ __launch_bounds__(256, 2) void unpool_outproj_h8_kernel(UnpoolH8Args 
                     a8[4 * t + 2 * c + 1] = __builtin_bit_cast(int, p1);
                 }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[j] = UG_MFMA8(a8, fbA[j], acc[j], 127, 127 - 19);
+            for (int j = 0; j < 2; ++j) acc[j] = UG_MFMA8(a8, fbA[j], acc[j], H8_SC_AH, H8_SC_WL);
         }
         load_f(nxt, fbA);
         if constexpr (!lst) {
@@ -514,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void unpool_outproj_h8_kernel(UnpoolH8Args 
         } else {
             // Al W
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[j] = UG_MFMA8(alo[gq], fbB[j], acc[j], 127 - 14, 127 - 8);
+            for (int j = 0; j < 2; ++j) acc[j] = UG_MFMA8(alo[gq], fbB[j], acc[j], H8_SC_AL, H8_SC_W8);
         }
     };
     for (int ct = 0; ct < NG; ++ct) {

@@ -263,6 +263,10 @@ class Diffusion(_Base):
         run.graph = g
         return run
 
+    # `torch.compile(model)` (example_configs/shapenet_airplane_unconditional.py:81): every FLOP of this forward runs in
+    # libgecco_hip.so through ctypes, which dynamo cannot trace — the evaluation is excluded from tracing and runs as it
+    # does in eager mode (same bits), instead of being cut into hundreds of graph breaks
+    @torch.compiler.disable
     def forward(self, data: Tensor, sigma: Tensor, raw_context: Any | None, post_context: Any | None = None,
                 do_cache: bool = False, cache: Any | None = None, out: Tensor | None = None) -> Tensor:
         if torch.is_grad_enabled() and data.is_cuda:

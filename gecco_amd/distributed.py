@@ -95,6 +95,8 @@ class FlatGradBuffer:
         dev = self.params[0].device if self.params else torch.device("cpu")
         self._g = torch.zeros(off, dtype=torch.float32, device=dev)
         self.grad_scale = 1.0
+        self._missing_ids: set[int] = set()   # as FusedAdamEMA: parameters that had no gradient when gathered (set_to_none=True)
+        self._missing_grad = 0
         self.zero_grad()
 
     def flat_grad(self) -> Tensor:
@@ -127,12 +129,21 @@ class FlatGradBuffer:
             v = self._g[o:o + k].view(p.shape)
             if gr is None:
                 v.zero_()
+                if id(p) not in self._missing_ids:
+                    self._missing_ids.add(id(p))
+                    self._missing_grad += 1
             else:
                 src.append(gr)
                 dst.append(v)
             p.grad = v
         if src:
             torch._foreach_copy_(dst, src)
+
+    def take_missing(self) -> int:
+        """Parameters without a gradient on ANY rank this step (after the reducer's finish()), and reset."""
+        n, self._missing_grad = self._missing_grad, 0
+        self._missing_ids.clear()
+        return n
 
 
 class BucketedGradAllReducer:
@@ -256,8 +267,17 @@ class BucketedGradAllReducer:
             b["pending"], b["launched"] = len(b["hooked"]), False
             b["seen"].clear()
         self._next = len(self.buckets) - 1
-        if self._collective() and hasattr(self.opt, "_missing_grad"):
-            self.opt._missing_grad = 0             # a gradient missing on this rank arrived with the sum over the ranks
+        if self._collective() and hasattr(self.opt, "_missing_ids"):
+            # A gradient missing on THIS rank arrived with the sum over the ranks — if some rank produced it.  One tiny
+            # all-reduce of a per-parameter "had a gradient" mask decides it parameter by parameter: what no rank supplied stays
+            # missing and the optimizer's policy applies (reference DDP with find_unused_parameters=False errors there too);
+            # in a group of one rank (force_collective) nothing is forgiven.  Every rank issues it, every step: same sequence.
+            spans = self.opt.spans()
+            had = self.flat.new_tensor([0.0 if id(p) in self.opt._missing_ids else 1.0 for p, _, _ in spans])
+            dist.all_reduce(had, op=dist.ReduceOp.SUM, group=self.group)   # not counted in collectives_issued (the bucket count)
+            still = {id(p) for (p, _, _), h in zip(spans, had.tolist()) if h == 0.0 and p.requires_grad}
+            self.opt._missing_ids = still
+            self.opt._missing_grad = len(still)
         self.opt.grad_scale = 1.0 / self.world() if self.enabled else 1.0
 
     def remove(self) -> None:

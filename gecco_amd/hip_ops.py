@@ -315,7 +315,8 @@ def decode_split_image(img: Tensor) -> Tensor:
 
 
 def decode_h8_image(img: Tensor) -> Tensor:
-    """(B, rows / 128, K / 64, 24576) uint8 h8 activation image -> the (B, rows, K) float64 tensor hi + 2^-14 lo it represents.
+    """(B, rows / 128, K / 64, 24576) uint8 h8 activation image -> the (B, rows, K) float64 tensor hi + 2^-11 lo it represents
+    (csrc/h8_scales.h).
     hi: [rt 4][sub 2][c 2][lane 64][8 fp16], column 32 sub + 16 (lane >> 5) + 8 c + e; lo: [rt 4][t 2][lane 64][16 fp8 e4m3],
     column 32 t + 16 (lane >> 5) + e; row 32 rt + (lane & 31)."""
     Bn, T, G = img.shape[:3]
@@ -323,7 +324,7 @@ def decode_h8_image(img: Tensor) -> Tensor:
     lo = img[..., 16384:].contiguous().view(torch.float8_e4m3fn).reshape(Bn, T, G, 4, 2, 2, 32, 16).double()   # rt t h r e
     hi = hi.permute(0, 1, 3, 7, 2, 4, 6, 5, 8)        # B T rt r G sub h c e
     lo = lo.permute(0, 1, 3, 6, 2, 4, 5, 7)           # B T rt r G t h e
-    return hi.reshape(Bn, T * 128, G * 64) + lo.reshape(Bn, T * 128, G * 64) * 2.0 ** -14
+    return hi.reshape(Bn, T * 128, G * 64) + lo.reshape(Bn, T * 128, G * 64) * 2.0 ** -11
 
 
 def mlp_fused_f16(x: Tensor, pro: tuple[Tensor, Tensor], W0: Tensor, b0: Tensor | None, W2: Tensor, b2: Tensor | None,

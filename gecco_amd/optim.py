@@ -63,6 +63,7 @@ class FusedAdamEMA(torch.optim.Optimizer):
             raise ValueError("missing_grad must be 'raise' or 'zero'")
         self.missing_grad = missing_grad
         self._missing_grad = 0
+        self._missing_ids: set[int] = set()   # id(p) of the trainable parameters without a gradient this step
 
     # ------------------------------------------------------------------------------------------ flat storage
     def all_parameters(self) -> list[Tensor]:
@@ -173,7 +174,11 @@ class FusedAdamEMA(torch.optim.Optimizer):
             v = self._flat["g"][o:o + k].view(p.shape)
             if gr is None:
                 v.zero_()
-                self._missing_grad += 1
+                # a FROZEN parameter (requires_grad False) never has a gradient: with its zero moments the update leaves it
+                # where it is (step() refuses weight decay in that case), as torch.optim.Adam's skip does — not "missing"
+                if p.requires_grad and id(p) not in self._missing_ids:
+                    self._missing_ids.add(id(p))
+                    self._missing_grad += 1
             else:
                 src.append(gr)
                 dst.append(v)
@@ -197,13 +202,19 @@ class FusedAdamEMA(torch.optim.Optimizer):
         self._gather_foreign_grads()
         if self._missing_grad and self.missing_grad != "zero":
             n, self._missing_grad = self._missing_grad, 0
+            self._missing_ids.clear()
             raise RuntimeError(
-                f"FusedAdamEMA.step(): {n} parameter(s) received no gradient this step.  torch.optim.Adam (and the reference's "
-                "EMAOptimizer around it) SKIPS such parameters; this optimizer's one-launch update over the flat buffers would "
-                "instead decay their moments, move them by stale momentum and advance their step count.  Freeze them "
-                "(requires_grad_(False)) before building the optimizer, or pass missing_grad='zero' to accept a zero gradient.")
+                f"FusedAdamEMA.step(): {n} trainable parameter(s) received no gradient this step.  torch.optim.Adam (and the "
+                "reference's EMAOptimizer around it) SKIPS such parameters; this optimizer's one-launch update over the flat buffers "
+                "would instead decay their moments, move them by stale momentum and advance their step count.  Leave them out of "
+                "the optimizer's parameter list (or set requires_grad_(False): a frozen parameter with zero moments does not move), "
+                "or pass missing_grad='zero' to accept a zero gradient.")
         self._missing_grad = 0
+        self._missing_ids.clear()
         g = self.param_groups[0]
+        if float(g["weight_decay"]) != 0.0 and any(not p.requires_grad for p, _, _ in self._spans):
+            raise NotImplementedError("FusedAdamEMA: weight_decay with frozen parameters in the parameter list (the one-launch update "
+                                      "would decay them; torch.optim.Adam skips them): leave frozen parameters out of the list")
         if len(self.param_groups) > 1 and any(
                 (h["lr"], h["betas"], h["eps"], h["weight_decay"]) != (g["lr"], g["betas"], g["eps"], g["weight_decay"])
                 for h in self.param_groups[1:]):

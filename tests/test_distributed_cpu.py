@@ -160,6 +160,8 @@ def _bucket_worker(rank, world, port, q):
         ((net(x[lo:hi]) - y[lo:hi]) ** 2).mean().backward()
         red.finish()
         outs.append([(p.grad * buf.grad_scale).numpy().copy() for p in params])
+        # `unused` has no gradient on ANY rank: the per-parameter mask keeps it "missing" (step 1: gradients handed over)
+        assert buf.take_missing() == (1 if step == 1 else 0)
     q.put((rank, outs))
     dist.destroy_process_group()
 
@@ -204,8 +206,10 @@ def _order_worker(rank, world, port, q):
     # independent scalar losses, backward one at a time in a rank-dependent order; all five backward passes belong to ONE
     # step, so the test drives the hooks directly through .backward() on detached graphs before finish()
     idx = [0, 1, 2, 3, 4] if rank == 0 else [3, 1, 4, 0]       # rank 1: parameter 2 never receives a gradient
+    buf.zero_grad(set_to_none=True)
     torch.autograd.backward([(w * (i + 1 + rank)).sum() for i, w in enumerate(ws) if i in idx])
     red.finish()
+    assert buf.take_missing() == 0   # parameter 2 had no gradient on rank 1, but rank 0 supplied one: not missing after the reduction
     q.put((rank, order, [(w.grad * buf.grad_scale).numpy().copy() for w in ws]))
     dist.destroy_process_group()
 
@@ -262,3 +266,9 @@ def test_bench_self_launcher_two_ranks():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 3
     assert rec["ms_per_step"] >= 2.0                      # max over ranks: rank 1 sleeps 2 ms per step
+    # the self-description a first multi-GPU run carries (bench.distributed_report): ranks the group really has, backend,
+    # all-reduce time / bus bandwidth at two sizes, rank 0's own un-barriered rate
+    d = rec["distributed"]
+    assert d["ranks_in_group"] == 2 and d["backend"] == "gloo" and "collective_library" in d
+    assert len(d["allreduce"]) == 2 and all(v["ms"] > 0 and v["busbw_gbs"] > 0 for v in d["allreduce"].values())
+    assert d["rank0_points_per_sec_unbarriered"] > 0

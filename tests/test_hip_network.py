@@ -78,7 +78,8 @@ def test_cached_mode_golden(ops, golden_dir, precision, tol):
 
 @pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16x3", 2e-4), ("mixed", 2e-4), ("fp16", 1e-3)])
 @pytest.mark.parametrize("B,N,d,L", [(3, 333, 128, 2), (2, 2048, 384, 1), (1, 4096, 512, 1), (2, 100, 64, 3), (2, 130, 256, 1),
-                                     (2, 384, 384, 2), (1, 640, 512, 1), (3, 128, 256, 2), (2, 256, 64, 2), (2, 256, 192, 2), (1, 200, 320, 1)])
+                                     (2, 384, 384, 2), (1, 640, 512, 1), (3, 128, 256, 2), (2, 256, 64, 2), (2, 256, 192, 2), (1, 200, 320, 1),
+                                     (2, 2048, 128, 4)])   # the last: BASELINE config C1 (airplane: d = 128, 4 layers) at its true N
 def test_uncond_vs_oracle_ragged(ops, B, N, d, L, precision, tol):
     """Sizes the golden set does not hold (ragged N, d=512, N=4096, head dim 8 that stays on the fp32 attention
     kernels, rows < 128; N = 128, 384, 640: an odd number of 128-row tiles under the 256-row tiles and the activation
@@ -92,6 +93,56 @@ def test_uncond_vs_oracle_ragged(ops, B, N, d, L, precision, tol):
     den, raw = ops.LinearLiftPlan(_cuda(p), cases.H, cases.I, precision=precision).forward(x.cuda(), sigma.cuda(), return_raw=True)
     _close(den, ref, tol)
     _close(raw, raw_ref, tol)
+
+
+def _outlier_network(d, L, smax, wmax):
+    from oracle import weights as W
+    p = W.linear_lift_state_dict(131 + d, d, L, cases.I, cases.H)
+    rs = np.random.RandomState(d + L)
+    for li in range(L):
+        pre = f"inner.layers.{li}."
+        for key in ("broadcast.unpool.out_proj.weight", "mlp.0.weight", "mlp.2.weight"):
+            w = p[pre + key]
+            for _ in range(6):
+                w[rs.randint(w.shape[0]), rs.randint(w.shape[1])] = float(rs.choice([-1.0, 1.0, 0.6, -0.4])) * wmax
+        if smax:   # y = (1 + s) * GroupNorm(x) + b: single channels of the h8 operand at ~smax x unit scale
+            p[pre + "mlp_norm.scale.bias"][rs.randint(d)] = smax
+            p[pre + "mlp_norm.scale.bias"][rs.randint(d)] = -0.75 * smax
+            p[pre + "mlp_norm.bias.bias"][rs.randint(d)] = 0.5 * smax
+    return p
+
+
+@pytest.mark.parametrize("N,d,L", [(256, 128, 3), (384, 384, 2)])
+def test_mixed_mode_on_outlier_weights_and_channels(ops, N, d, L):
+    """Weights a trained checkpoint may hold, against the oracle, at the sites that run in h8 arithmetic (out_proj, mlp.0, mlp.2;
+    models/set_transformer.py:112, 164-166, normalization.py:36-44), on a batch that spans sigma = 0.002 .. 165.
+    (1) Isolated entries up to |w| = 8 in those matrices: the mode's bar (2e-4) holds — the fp8 operands' scales cover |w| <= 14
+    (csrc/h8_scales.h; round 3's covered 1.75).
+    (2) Outlier CHANNELS of the h8 operand y = AdaGN(x): the AdaGN scale / bias of mlp_norm puts single channels at |y| ~ 100 .. 500.
+    Such a channel feeds the GaussianActivation with pre-activations ~100 x larger, so every finite-precision arithmetic pays its
+    relative error on a ~100 x larger magnitude (tools/debug/outlier_dbg.py: the exact-fp32 HIP mode goes 6e-7 -> 9e-6, split-bf16
+    3e-5 -> 4e-4): the claim that can hold, and is asserted, is that the mixed mode degrades IN PROPORTION — finite, within 6 x the
+    split-bf16 mode on the same network (it is 2.4 x on well-conditioned ones) — where round 3's scales saturated the lo term
+    above |y| = 56 and produced NaN above 448."""
+    from oracle import weights as W
+    x, sigma = W.synthetic_cloud(N, 4, N)
+
+    def errors(p, modes):
+        with torch.no_grad():
+            raw_ref = cpu_ref.uncond_denoiser(p, "", cases.H)(x, sigma, return_raw=True)[1]
+        pc = _cuda(p)
+        out = {}
+        for pr in modes:
+            raw = ops.LinearLiftPlan(pc, cases.H, cases.I, precision=pr).forward(x.cuda(), sigma.cuda(), return_raw=True)[1]
+            assert torch.isfinite(raw).all()
+            out[pr] = cpu_ref.rel_err(raw.cpu(), raw_ref)[0]
+        return out
+    e = errors(_outlier_network(d, L, 0.0, 8.0), ("mixed",))
+    print(f"outlier network d={d} L={L}, |w| <= 8: mixed F_x {e['mixed']:.2e}")
+    assert e["mixed"] <= 2e-4, e
+    e = errors(_outlier_network(d, L, 120.0, 8.0), ("bf16x3", "mixed"))
+    print(f"outlier network d={d} L={L}, |w| <= 8, |y| ~ 500 channels: split-bf16 F_x {e['bf16x3']:.2e}, mixed F_x {e['mixed']:.2e}")
+    assert e["mixed"] <= 6 * e["bf16x3"] and e["mixed"] <= 5e-3, e
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3", "mixed", "fp16"])

@@ -391,6 +391,45 @@ def test_linear_h8_image(ops, B, rows, K, Nout, act):
     assert torch.equal(a, c) and torch.equal(a, img)
 
 
+def _h8_outlier_case(rs, B, rows, K, Wd, wmax, ymax):
+    """Operands a trained checkpoint may hold: weights ~ N(0, 1 / K) with a few entries up to +-wmax, activations of unit scale with
+    an outlier channel reaching +-ymax and isolated large values; a bias that puts an outlier channel into the hidden layer too."""
+    x = _t(rs.randn(B, rows, K))
+    x[:, :, 7] *= ymax / 4.0
+    x[0, 5, 11] = ymax
+    x[-1, rows - 3, K - 2] = -ymax
+    W0 = _t(rs.randn(Wd, K) / math.sqrt(K))
+    W0[:, 7] *= 0.05
+    W0[3, 20], W0[Wd - 1, 0], W0[17, K - 1] = wmax, -wmax, wmax / 2
+    b0 = _t(rs.randn(Wd) * 0.1)
+    b0[9], b0[40] = 0.8 * ymax, -0.5 * ymax
+    W2 = _t(rs.randn(K, Wd) / math.sqrt(Wd))
+    W2[5, 9], W2[K - 1, Wd - 1], W2[100, 300] = -wmax, wmax, wmax
+    return x, W0, b0, W2
+
+
+@pytest.mark.parametrize("wmax,ymax,bar", [(1.0, 4.0, 3e-5), (8.0, 500.0, 3e-5), (14.0, 448.0, 3e-5), (100.0, 3000.0, 1.5e-3), (1000.0, 1e5, 2e-3)])
+def test_h8_products_on_outlier_weights_and_activations(ops, wmax, ymax, bar):
+    """The h8 products (fp16 main product + fp8 cross terms) hold their accuracy on weights up to |w| = 14 and activations up to
+    |y| = 448 (csrc/h8_scales.h: the fp8 operands' power-of-two scales; round 3's covered |w| <= 1.75, |y| <= 56 and turned NaN above
+    |y| = 448); beyond that the cross terms saturate and the product degrades towards one-term fp16 accuracy — gradually, never a
+    NaN; beyond |y| = 3584 the operand itself is clamped: finite, and equal to the product of the clamped operand.  mlp.0 -> h8
+    image -> mlp.2 with identity activation (the unbounded case; models/mlp.py, set_transformer.py:164-166) against float64."""
+    B, rows, K, Wd = 2, 256, 384, 768
+    rs = _rs(int(wmax) + int(ymax) % 1000)
+    x, W0, b0, W2 = _h8_outlier_case(rs, B, rows, K, Wd, wmax, ymax)
+    img = ops.linear_h8_img(x.cuda(), None, W0.cuda(), b0.cuda(), kind=2)
+    u_ref = F.linear(x.double().clamp(-3584, 3584), W0.double(), b0.double()).clamp(-3584, 3584)
+    u = ops.decode_h8_image(img).cpu()
+    assert torch.isfinite(u).all()
+    out = ops.linear_h8_areg(img, W2.cuda(), None).cpu().double()
+    assert torch.isfinite(out).all()
+    e0 = cpu_ref.rel_err(u.double(), u_ref)
+    e2 = cpu_ref.rel_err(out, F.linear(u.double(), W2.double()))   # mlp.2's product alone, on the image's own values
+    print(f"h8 outliers |w| <= {wmax}, |y| <= {ymax}: mlp.0 {e0[0]:.2e}, mlp.2 {e2[0]:.2e} (bar {bar})")
+    assert e0[0] < bar and e2[0] < bar, (e0, e2)
+
+
 @pytest.mark.parametrize("B,rows,K,hd", [(2, 256, 384, 48), (1, 128, 128, 16), (2, 384, 256, 32), (1, 256, 512, 64), (2, 256, 384, 0)])
 def test_linear_kvq_f16(ops, B, rows, K, hd):
     """kv_proj | q_proj of the mixed mode on the 64-column-tile kernel (gemm_kvq_astat_kernel): fp16(y) x fp16(W) everywhere, the V

@@ -186,11 +186,11 @@ int linear_pair(const float* A, const float* W1, const float* b1, int Nout1, flo
 }
 
 // Path switches for A/B runs and tests: gecco_set_option, or the environment (GECCO_ASTAT, GECCO_CHAIN) on first use.
-enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_HEADMAJOR = 2, OPT_MLPFUSED = 3, OPT_UNPOOLFUSED = 4, OPT_LO8 = 5, OPT_ACTIMG = 6, OPT_H8 = 7, OPT_KVQ64 = 8, OPT_H8AREG = 9, OPT_CHAIN2 = 10, OPT_UNPOOLH8 = 11, OPT_COUNT = 12 };
-int g_options[OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
-const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor", "mlpfused", "unpoolfused", "lo8", "actimg", "h8", "kvq64", "h8areg", "chain2", "unpoolh8"};
+enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_HEADMAJOR = 2, OPT_MLPFUSED = 3, OPT_UNPOOLFUSED = 4, OPT_LO8 = 5, OPT_ACTIMG = 6, OPT_H8 = 7, OPT_KVQ64 = 8, OPT_H8AREG = 9, OPT_CHAIN2 = 10, OPT_UNPOOLH8 = 11, OPT_MLPH8 = 12, OPT_COUNT = 13 };
+int g_options[OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor", "mlpfused", "unpoolfused", "lo8", "actimg", "h8", "kvq64", "h8areg", "chain2", "unpoolh8", "mlph8"};
 const char* const g_option_env[OPT_COUNT] = {"GECCO_ASTAT", "GECCO_CHAIN", "GECCO_HEADMAJOR", "GECCO_MLPFUSED", "GECCO_UNPOOLFUSED", "GECCO_LO8",
-                                             "GECCO_ACTIMG", "GECCO_H8", "GECCO_KVQ64", "GECCO_H8AREG", "GECCO_CHAIN2", "GECCO_UNPOOLH8"};
+                                             "GECCO_ACTIMG", "GECCO_H8", "GECCO_KVQ64", "GECCO_H8AREG", "GECCO_CHAIN2", "GECCO_UNPOOLH8", "GECCO_MLPH8"};
 int option(int which) {
     if (g_options[which] < 0) {
         const char* e = getenv(g_option_env[which]);
@@ -658,7 +658,7 @@ int gecco_set_option(const char* name, int value) {
             g_options[i] = value < 0 ? -1 : (value != 0);   // < 0: back to the environment / default
             return 0;
         }
-    return fail(-2, "set_option: unknown option '%s' (astat, chain, headmajor, mlpfused, unpoolfused, lo8, actimg, h8, kvq64, h8areg, chain2, unpoolh8)", name);
+    return fail(-2, "set_option: unknown option '%s' (astat, chain, headmajor, mlpfused, unpoolfused, lo8, actimg, h8, kvq64, h8areg, chain2, unpoolh8, mlph8)", name);
 }
 
 int gecco_linear_row_tiles(int rows) { return row_tiles_gemm(rows); }
@@ -972,6 +972,24 @@ int gecco_unpool_outproj_h8(float* x, const void* q16, const float* kvh, const f
     TRY(unpool_outproj_h8_launch(ua, C, s), "unpool_outproj_h8");
     return 0;
 }
+
+int gecco_mlp_fused_h8(float* x, const float* pro_a, const float* pro_o, const float* W0, const float* b0, const float* W2,
+                       const float* b2, const float* alpha, int act, float* stats, int B, int rows, int C, int width,
+                       void* wsplit, void* stream) {
+    if (!x || !pro_a || !pro_o || !wsplit) return fail(-1, "mlp_fused_h8: null argument");
+    if (!mlp_fused_h8_supported(C, width, rows)) return fail(-2, "mlp_fused_h8: needs C == 384, width == 2 C, rows %% 128 == 0");
+    if (act < 0 || act > 3) return fail(-6, "mlp_fused_h8: act must be 0 .. 3");
+    if ((act == 1 || act == 2) && !alpha) return fail(-6, "mlp_fused_h8: GaussianActivation needs alpha");
+    hipStream_t s = (hipStream_t)stream;
+    if (W0 && W2) TRY(mlp_fused_h8_image_launch(W0, W2, wsplit, C, width, s), "mlp_fused_h8(image)");   // W0 == NULL: image ready
+    MlpH8Args ma{};
+    ma.x = x; ma.pro_a = pro_a; ma.pro_o = pro_o; ma.w_img = wsplit; ma.b0 = b0; ma.b2 = b2; ma.alpha = alpha; ma.act = act;
+    ma.stats = stats; ma.B = B; ma.rows = rows;
+    TRY(mlp_fused_h8_launch(ma, C, width, s), "mlp_fused_h8");
+    return 0;
+}
+
+size_t gecco_mlp_fused_h8_wsplit_bytes(int C, int width) { return mlp_fused_h8_supported(C, width, 128) ? mlp_fused_h8_image_bytes(C, width) : 0; }
 
 size_t gecco_unpool_outproj_h8_wsplit_bytes(int B, int C, int H) {
     if (H <= 0 || C % H) return 0;

@@ -362,6 +362,24 @@ def unpool_outproj_f16(x: Tensor, q16: Tensor, kvh: Tensor, W: Tensor, bias: Ten
     return x, stats
 
 
+def mlp_fused_h8(x: Tensor, pro: tuple[Tensor, Tensor], W0: Tensor, b0: Tensor | None, W2: Tensor, b2: Tensor | None,
+                 act_alpha: Tensor | None = None, normalized: bool = True, act: str | int | None = None, want_stats: bool = False,
+                 wsplit: Tensor | None = None, image_ready: bool = False, stats: Tensor | None = None):
+    """x += mlp.2(act(mlp.0(x*pa + po))) in place (mixed mode, one launch, h8 arithmetic); returns (x, stats | None).
+    wsplit / image_ready: caller-owned scratch holding the weight stream of a previous call (kernel launch only)."""
+    lib = _lib.load()
+    B, rows, Cc = x.shape
+    width = W0.shape[0]
+    if stats is None and want_stats:
+        stats = torch.empty(B, rows // 128, 2, Cc, device=x.device, dtype=torch.float32)
+    if wsplit is None:
+        wsplit = _ws(lib.gecco_mlp_fused_h8_wsplit_bytes(Cc, width), x.device)
+    check(lib.gecco_mlp_fused_h8(_ptr(x), _ptr(pro[0]), _ptr(pro[1]), None if image_ready else _ptr(W0), _ptr(b0),
+                                 None if image_ready else _ptr(W2), _ptr(b2), _ptr(act_alpha), act_code(act_alpha, normalized, act),
+                                 _ptr(stats), B, rows, Cc, width, C.c_void_p(wsplit.data_ptr()), _stream()), "gecco_mlp_fused_h8")
+    return x, stats
+
+
 def unpool_outproj_h8(x: Tensor, q16: Tensor, kvh: Tensor, W: Tensor, bias: Tensor | None, H: int, want_stats: bool = False,
                       wsplit: Tensor | None = None, image_ready: bool = False, stats: Tensor | None = None):
     """x += MHA(q, inducer k | v) @ W^T + bias in place (mixed mode, one launch: fp16 attention, h8 out_proj); q16 head-major

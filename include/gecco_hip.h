@@ -104,6 +104,8 @@ int gecco_linear_f32(const float* A, const float* W, const float* bias, const fl
  *   "unpoolh8" (default 1): mixed mode runs unpool attention + out_proj (h8) + residual + statistics as one launch
  *   (gecco_unpool_outproj_h8) instead of the attention writing an h8 activation image for gecco_linear_h8_areg_f32; needs
  *   "kvq64" (head-major fp16 q), "h8areg", feature_dim in {128, 256, 384}.
+ *   "mlph8" (default 1): mixed mode runs the point MLP of a layer (AdaGN apply, mlp.0, activation, mlp.2, residual, statistics) as
+ *   one launch (gecco_mlp_fused_h8) instead of gecco_linear_h8_img_f32 + gecco_linear_h8_areg_f32; feature_dim 384.
  *   "chain2" (default 1): mixed mode runs the 64-inducer chain of a layer (pool merge .. unpool k|v) as the ONE launch of the fp16
  *   mode with two-term fp16 weights (hi | lo blocks per column tile) instead of five 64-row split-bf16 GEMMs + their AdaGN
  *   coefficient launches: 16 -> 9 launches per layer; F_x 6e-5 -> ~1e-4 (its activations are rounded to fp16 once).
@@ -254,6 +256,17 @@ int gecco_mlp_fused_f16(float* x, const float* pro_a, const float* pro_o, const 
  * (C, hd) in {(128, 16), (256, 32), (384, 48)}, rows % 128 == 0; wsplit: 2 * C * C bytes. */
 int gecco_unpool_outproj_f16(float* x, const void* q16, const float* kvh, const float* W, const float* bias, float* stats,
                              int B, int rows, int C, int H, void* wsplit, void* stream);
+/* The point MLP of a layer in the MIXED mode, one launch (mlp_fused_h8.hip; option "mlph8"): x += mlp.2(act(mlp.0(x * pro_a +
+ * pro_o))) in place, both products in h8 arithmetic (fp16 main product + two fp8 cross terms, as gecco_linear_h8_img_f32 and
+ * gecco_linear_h8_areg_f32), the 2 C wide hidden layer never leaves the CU; stats (B, rows / 128, 2, C) or NULL: GroupNorm
+ * partials of the updated x.  Replaces models/set_transformer.py:164-166, models/mlp.py:5-39, models/activation.py:17-24,
+ * models/normalization.py:36-44.  Equal to the two-launch form up to fp32 summation order in mlp.2 (~1e-6; the hidden layer's
+ * bits are the same).  C == 384, width == 2 C, rows % 128 == 0; act 0 .. 3; wsplit: gecco_mlp_fused_h8_wsplit_bytes(C, width);
+ * W0 == NULL: the weight stream is ready. */
+int gecco_mlp_fused_h8(float* x, const float* pro_a, const float* pro_o, const float* W0, const float* b0, const float* W2,
+                       const float* b2, const float* alpha, int act, float* stats, int B, int rows, int C, int width,
+                       void* wsplit, void* stream);
+size_t gecco_mlp_fused_h8_wsplit_bytes(int C, int width);
 /* The same half of the layer in the MIXED mode, one launch (unpool_outproj_h8.hip; option "unpoolh8", default 1): attention in
  * fp16 (the bits of gecco_unpool_attn_h8img), out_proj as the h8 product (fp16 main product + two fp8 cross terms, as
  * gecco_linear_h8_areg_f32), + bias + residual, in place on x, + GroupNorm partials; the attention output stays in registers as

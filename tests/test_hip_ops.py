@@ -279,6 +279,46 @@ def test_unpool_outproj_h8_fused_matches_the_two_launch_form(ops, B, N, Cc, H):
     assert torch.equal(ops.unpool_outproj_h8(x.clone(), q, kvh, W, bias, H)[0], got)
 
 
+@pytest.mark.parametrize("B,rows,act", [(2, 256, "gauss"), (1, 128, "relu"), (3, 384, "none"), (5, 2048, "gauss")])
+def test_mlp_fused_h8_matches_the_two_launch_form(ops, B, rows, act):
+    """Mixed mode: the point MLP of a layer in ONE launch (mlp_fused_h8.hip; models/set_transformer.py:164-166, mlp.py:5-39,
+    activation.py:17-24, normalization.py:36-44) against the two launches it replaces — mlp.0 writing the h8 activation image
+    (gemm_h8_astat.hip), mlp.2 reading it (gemm_h8_areg.hip): the hidden layer has the same bits (same product order, same
+    epilogue arithmetic), the second product the same operands in another summation order; and against float64."""
+    K, Wd = 384, 768
+    rs = _rs(B + rows + len(act))
+    x, W0, b0 = _t(rs.randn(B, rows, K)), _t(rs.randn(Wd, K) / math.sqrt(K)), _t(rs.randn(Wd) / math.sqrt(K))
+    W2, b2 = _t(rs.randn(K, Wd) / math.sqrt(Wd)), _t(rs.randn(K) / math.sqrt(Wd))
+    pa, po = _t(1 + 0.3 * rs.randn(B, K)), _t(0.3 * rs.randn(B, K))
+    alpha = _t(np.array(0.9))
+    kw = dict(act_alpha=alpha.cuda()) if act == "gauss" else dict(act="relu") if act == "relu" else {}
+    xc, pro = x.cuda(), (pa.cuda(), po.cuda())
+    img = ops.linear_h8_img(xc, pro, W0.cuda(), b0.cuda(), kind=2, **kw)
+    ref, st_ref = ops.linear_h8_areg(img, W2.cuda(), b2.cuda(), residual=xc, want_stats=True)
+    got, st = ops.mlp_fused_h8(xc.clone(), pro, W0.cuda(), b0.cuda(), W2.cuda(), b2.cuda(), want_stats=True, **kw)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got).all()
+    scale = ref.abs().max().item()
+    d = (got - ref).abs().max().item() / scale
+    print(f"fused h8 MLP vs two launches ({act}, B={B}, rows={rows}): {d:.2e}")
+    assert d <= 4e-6, d
+    u = F.linear((x.double() * pa[:, None].double() + po[:, None].double()), W0.double(), b0.double())
+    hdn = (torch.exp(-u * u / (2 * 0.9 ** 2)) - 0.7) / 0.28 if act == "gauss" else torch.relu(u) if act == "relu" else u
+    ref64 = x.double() + F.linear(hdn, W2.double(), b2.double())
+    e = cpu_ref.rel_err(got.cpu().double(), ref64)
+    assert e[0] < 1e-4, e
+    g4 = got.double().reshape(B, rows // 128, 128, K)
+    assert (st[:, :, 0].double() - g4.sum(2)).abs().max().item() <= 1e-3 * max(1.0, scale)
+    assert (st[:, :, 1].double() - (g4 * g4).sum(2)).abs().max().item() <= 1e-5 * (g4 * g4).sum(2).max().item()
+    # a ready weight stream gives the same bits; bias / statistics optional; reproducible
+    lib = ops._lib.load()
+    ws = torch.empty(lib.gecco_mlp_fused_h8_wsplit_bytes(K, Wd), dtype=torch.uint8, device="cuda")
+    a = ops.mlp_fused_h8(xc.clone(), pro, W0.cuda(), None, W2.cuda(), None, wsplit=ws, **kw)[0]
+    c = ops.mlp_fused_h8(xc.clone(), pro, W0.cuda(), None, W2.cuda(), None, wsplit=ws, image_ready=True, **kw)[0]
+    assert torch.equal(a, c)
+    assert torch.equal(ops.mlp_fused_h8(xc.clone(), pro, W0.cuda(), b0.cuda(), W2.cuda(), b2.cuda(), **kw)[0], got)
+
+
 def test_adagn_large_mean(ops):
     """E[x^2]-mean^2 cancellation: mean 50x the std must still be accurate (fp64 combine)."""
     rs = _rs(5)

@@ -108,6 +108,8 @@ STWorkspace carve_st(const GeccoSetTransformer* st, int B, int N, void* base) {
         w.o_ukv = w.o_b2 + pad(C) * W;
         w.o_mf = w.o_ukv + pad(2 * C) * C;
         w.wimg_layer = w.o_mf + (st->precision == 2 ? pad(W) * C + pad(C) * W : 0);
+        // mixed mode: the weight stream of the one-launch point MLP (option "mlph8"; mlp_fused_h8.hip) at o_mf
+        if (st->precision == 3 && mlp_fused_h8_supported((int)C, (int)W, 128)) w.wimg_layer += mlp_fused_h8_image_bytes((int)C, (int)W) / sizeof(float);
         w.wimg = st->precision >= 1 ? c.f32(w.wimg_layer * st->n_layers) : nullptr;
     }
     w.bytes = (c.off + 255) & ~size_t(255);
@@ -194,7 +196,7 @@ const char* const g_option_env[OPT_COUNT] = {"GECCO_ASTAT", "GECCO_CHAIN", "GECC
 int option(int which) {
     if (g_options[which] < 0) {
         const char* e = getenv(g_option_env[which]);
-        g_options[which] = e ? (atoi(e) != 0) : 1;
+        g_options[which] = e ? (atoi(e) != 0) : (which == OPT_MLPH8 ? 0 : 1);   // "mlph8": built and exact, measured slower than its two launches: opt-in
     }
     return g_options[which];
 }
@@ -311,6 +313,9 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
     // fp16 q of the kvq kernel; the k | v image of the inducers lives in the (then idle) attention-output buffer
     const bool uo8_on = h8o && kvq_on && option(OPT_UNPOOLH8) && I == 64 && unpool_outproj_h8_supported(C, H, N) &&
                         unpool_outproj_h8_kv_bytes(B, C, H) <= (size_t)B * N * C * sizeof(float);
+    // mixed mode, opt-in (option "mlph8"): the point MLP as ONE launch with the hidden layer kept on the CU (mlp_fused_h8.hip); its
+    // weight stream (2.75 MB at d = 384) has its own workspace slot (o_mf)
+    const bool mf8_on = h8_on && h8x && option(OPT_MLPH8) && st->precision == 3 && mlp_fused_h8_supported(C, Wd, N);
     const bool chain_on = pr == 2 && w.wimg && option(OPT_CHAIN) && inducer_chain_f16_supported(C, Wd, H, G, I) &&
                           (ns == 1 || ns == 2 || ns == 4 || ns == 8);
     // mixed mode: the same one-launch chain with TWO-TERM fp16 weights (option "chain2") instead of five 64-row split-bf16 GEMMs
@@ -411,6 +416,8 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
                         TRY(push_ld(L.mlp.w2 + (size_t)jc * 128 + hf * 64, cb + (size_t)(nkb + hf * (nkb / 2)) * 2048, C, 64, Wd),
                             "split(mlp.2 K-slice)");
                 }
+            } else if (mf8_on) {
+                TRY(mlp_fused_h8_image_launch(L.mlp.w0, L.mlp.w2, base + w.o_mf, C, Wd, s), "split(mlp, fused h8 stream)");
             } else {
                 if (h8_on) {   // same bytes as the split-bf16 image it replaces: fp16 hi + fp8 lo + fp8 W per element
                     if (jobs8.n >= kJobCap) { TRY(h8_image_multi_launch(jobs8, s), "split(mlp.0, h8)"); jobs8.n = 0; }
@@ -591,6 +598,16 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         // split-bf16 products: the hidden layer goes from mlp.0 to mlp.2 as a tiled split image (same bytes as the fp32 tensor
         // it replaces, in the same buffer): contiguous DMA pieces and no hi / lo split in mlp.2's K loop
         const int himg = pr == 1 && !a16 && im && option(OPT_ACTIMG) && N >= 128 && N % 128 == 0 && Wd % 16 == 0 && C % 16 == 0;
+        if (m0_done == 1 && mf8_on && im) {
+            MlpH8Args ma{};
+            ma.x = x; ma.pro_a = w.a2; ma.pro_o = w.o2; ma.w_img = im + w.o_mf; ma.b0 = L.mlp.b0; ma.b2 = L.mlp.b2; ma.alpha = L.mlp.alpha;
+            ma.act = act; ma.stats = so; ma.B = B; ma.rows = N;
+            if ((act == 1 || act == 2) && !L.mlp.alpha) return fail(-6, "mlp: GaussianActivation needs alpha");
+            TRY(mlp_fused_h8_launch(ma, C, Wd, s), "mlp (fused, h8)");
+            sx = w.stats_x;
+            sT = Tn;
+            continue;
+        }
         if (m0_done == 1 && h8_on && himg && im) {
             GemmArgs hg{};
             hg.A = x; hg.pro_a = w.a2; hg.pro_o = w.o2; hg.bias = L.mlp.b0; hg.alpha = L.mlp.alpha; hg.act = act; hg.C = w.big;

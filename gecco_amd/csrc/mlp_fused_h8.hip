@@ -446,10 +446,12 @@ __global__ __launch_bounds__(512, 1) void mlp_fused_h8_kernel(MlpH8Args g) {
     int slot = 0;
     // top of an interval: its pieces landed (own: the NS - 2 intervals issued after it stay in flight), then everybody's; the next
     // interval's pieces go into the slot of the previous one (every wave has passed the barrier, i.e. is done reading it)
-    auto head = [&]() -> const float* {
+    // The two roles place their DMA issue (~100 - 300 issue cycles per interval and wave) at opposite ends of the interval — P1
+    // right after the barrier, P2 behind its matrix instructions — so that one's issue sits beside the other's matrix work
+    auto head = [&](bool issue_now) -> const float* {
         dma::wait_vm_lgkm0<(NS - 2) * F_PW>();
         __builtin_amdgcn_s_barrier();
-        issue();
+        if (issue_now) issue();
         const float* cur = ring + slot * F_IVAL;
         slot = slot + 1 == NS ? 0 : slot + 1;
         return cur;
@@ -467,7 +469,7 @@ __global__ __launch_bounds__(512, 1) void mlp_fused_h8_kernel(MlpH8Args g) {
             const int tprev = p - 1 < 0 ? 0 : p - 1 >= NCT ? NCT - 1 : p - 1;   // bias rows of the tile being finished (clamped for the padding tiles)
             static_for(std::make_integer_sequence<int, 3 * T>{}, [&](auto II) {
                 constexpr int i = decltype(II)::value;
-                const float* cur = head();
+                const float* cur = head(true);
 #ifdef MF8_DIAG_NOP1
                 (void)cur;
                 return;
@@ -495,9 +497,10 @@ __global__ __launch_bounds__(512, 1) void mlp_fused_h8_kernel(MlpH8Args g) {
         for (int p = 0; p <= NCT + 1; ++p) {
             static_for(std::make_integer_sequence<int, 3 * T>{}, [&](auto II) {
                 constexpr int i = decltype(II)::value;
-                const float* cur = head();
+                const float* cur = head(false);
 #ifdef MF8_DIAG_NOP2
                 (void)cur;
+                issue();
                 return;
 #endif
                 if constexpr (i < T) {
@@ -507,6 +510,8 @@ __global__ __launch_bounds__(512, 1) void mlp_fused_h8_kernel(MlpH8Args g) {
                 } else if constexpr (i < 2 * T) {
                     p2_stage(std::integral_constant<int, i - T>{}, cur + F_STAGE, hid_of((p + 1) & 1));   // tile p - 1
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                issue();
             });
         }
         FSTAMP(2);

@@ -399,6 +399,30 @@ def test_mixed_unpool_outproj_fused_matches_the_two_launch_form(ops, golden_dir,
     assert torch.equal(d2.cpu(), out[1])   # reproducible run to run
 
 
+def test_mixed_fused_h8_mlp_matches_the_two_launch_form(ops, golden_dir):
+    """Mixed mode, option "mlph8" (opt-in): the point MLP of every layer as ONE launch with the hidden layer kept on the CU
+    (mlp_fused_h8.hip; models/set_transformer.py:164-166) against mlp.0 writing the h8 activation image for mlp.2: the hidden
+    layer's bits are the same, the second product sums in another order — the network agrees to that; golden bar unchanged."""
+    name = "uncond_d384_L6_N128"
+    p, x, sigma = cases.uncond_inputs(name)
+    g = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    net = ops.LinearLiftPlan(_cuda(p), cases.H, cases.I, precision="mixed")
+    out, raw = {}, {}
+    try:
+        for on in (0, 1):
+            ops.set_option("mlph8", on)
+            d, r = net.forward(x.cuda(), sigma.cuda(), return_raw=True)
+            out[on], raw[on] = d.cpu(), r.cpu()
+    finally:
+        ops.set_option("mlph8", -1)
+    for on in (0, 1):
+        eg = cpu_ref.rel_err(out[on], torch.from_numpy(g["denoised"]))
+        assert eg[0] <= 2e-4, (on, eg)
+    e = cpu_ref.rel_err(raw[1], raw[0])
+    assert e[0] <= 1e-4, e
+    assert not torch.equal(raw[0], raw[1]), "the fused MLP did not run"
+
+
 @pytest.mark.parametrize("name", list(cases.UNCOND_CASES))
 def test_mixed_two_term_chain_matches_split_bf16_chain(ops, golden_dir, name):
     """Mixed mode: the 64-inducer chain of a layer as ONE launch with two-term fp16 weights (option "chain2",

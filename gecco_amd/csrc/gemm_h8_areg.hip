@@ -26,6 +26,8 @@
 #include "gemm_dma_common.h"
 #include "h8_scales.h"
 
+#include <stdlib.h>
+
 #include <utility>
 
 namespace {
@@ -96,7 +98,7 @@ constexpr int young_at(int t, int NGK, int NS, int D) {
     return total - need_end;
 }
 
-template <int NGK, int NS, int D>
+template <int NGK, int NS, int D, bool DIRECT>
 __global__ __launch_bounds__(DNT, 2) void gemm_h8_areg_kernel(GemmArgs g) {
     static_assert(NS >= 3 && D >= 1 && D <= NGK, "ring / lookahead");
     constexpr int NST = 2 * NGK;
@@ -227,7 +229,63 @@ __global__ __launch_bounds__(DNT, 2) void gemm_h8_areg_kernel(GemmArgs g) {
 #ifdef H8_DIAG_NOEPI
     if (acc[0][0][0] == 123.456f)
 #endif
-    dma::epilogue<1, 4, 4>(g, T, acc, smem, wave, lane, wave, 0);
+    if constexpr (DIRECT) {
+        // No-transpose epilogue (unpool_outproj_h8.hip): acc[0][j][4 q + e] = (A W^T)[row 8 q + 4 h + e][n0 + 32 j + r] — a register
+        // holds 32 consecutive columns of one row across a lane half: the residual comes in as 64 four-byte loads (2 x 128
+        // contiguous bytes per instruction) into the registers the fragments and the A sets have left, ALL in flight at once (one
+        // exposure of the HBM latency per block instead of one per 32 x 64 sub-tile), the result leaves as 64 stores of the same
+        // shape, and a lane's column sums are 16 adds and one lane-half exchange.  Same arithmetic as dma::epilogue:
+        // (A W^T + bias) + residual.  Whole 128-column tiles only (Nout % 128 == 0).
+        const int n0 = T.n0, tilesM = T.tilesM, rt = T.rt;
+        const float* Rb = g.residual ? g.residual + ((size_t)b * g.rows + m0 + wave * 32) * g.ldr + n0 : nullptr;
+        float* Cb = g.C + ((size_t)b * g.rows + m0 + wave * 32) * g.ldc + n0;
+        const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Rb ? Rb : Cb), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(Cb, 0, 0x7fffffff, 0x00020000);
+        const unsigned vr = (unsigned)((4 * h * g.ldr + r) * 4), vc = (unsigned)((4 * h * g.ldc + r) * 4);
+        float res[4][16];
+        if (Rb) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int qe = 0; qe < 16; ++qe) {
+                    const int row = 8 * (qe >> 2) + (qe & 3);
+                    res[j][qe] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, vr, (unsigned)((row * g.ldr + 32 * j) * 4), 0));
+                }
+        }
+        float* red = smem;   // [4 waves][2][128]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float bias = g.bias ? g.bias[n0 + 32 * j + r] : 0.f;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int qe = 0; qe < 16; ++qe) {
+                const int row = 8 * (qe >> 2) + (qe & 3);
+                float v = acc[0][j][qe] + bias;
+                if (Rb) v += res[j][qe];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), crsrc, vc, (unsigned)((row * g.ldc + 32 * j) * 4), 0);
+                s1 += v;
+                s2 = __builtin_fmaf(v, v, s2);
+            }
+            if (g.stats) {
+                const auto a1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s1), false, false);
+                const auto a2 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, s2), __builtin_bit_cast(unsigned, s2), false, false);
+                if (lane < 32) {
+                    red[(wave * 2 + 0) * 128 + 32 * j + r] = __uint_as_float(a1[0]) + __uint_as_float(a1[1]);
+                    red[(wave * 2 + 1) * 128 + 32 * j + r] = __uint_as_float(a2[0]) + __uint_as_float(a2[1]);
+                }
+            }
+        }
+        if (g.stats) {
+            __syncthreads();
+            const int which = tid >> 7, cl = tid & 127;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) t += red[(w * 2 + which) * 128 + cl];
+            g.stats[(((size_t)b * tilesM + rt) * 2 + which) * g.Nout + n0 + cl] = t;
+        }
+    } else {
+        dma::epilogue<1, 4, 4>(g, T, acc, smem, wave, lane, wave, 0);
+    }
     ASTAMP(3);
 }
 
@@ -239,10 +297,14 @@ int h8_areg_launch_t(const GemmArgs& g, hipStream_t st) {
     const size_t lds = (ring > epi ? ring : epi) * sizeof(float);
     static size_t attr = 0;
     if (lds > attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h8_areg_kernel<NGK, NS, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h8_areg_kernel<NGK, NS, D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h8_areg_kernel<NGK, NS, D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = lds;
     }
-    hipLaunchKernelGGL((gemm_h8_areg_kernel<NGK, NS, D>), dim3(g.B * tilesM * tilesN), dim3(DNT), lds, st, g);
+    static const int direct_env = [] { const char* e = getenv("GECCO_H8AREG_DIRECT"); return e ? atoi(e) : 0; }();   // measured: epilogue 17.2 K -> 12.7 K ticks per block, prologue + K loop +6.6 K: 197 -> 193 us at K = 768, 125 -> 128 us at K = 384 (profiles/r04d): off
+    // whole 128-column tiles: the no-transpose epilogue; a ragged last tile keeps the masked LDS-transpose one
+    if (direct_env && g.Nout % 128 == 0) hipLaunchKernelGGL((gemm_h8_areg_kernel<NGK, NS, D, true>), dim3(g.B * tilesM * tilesN), dim3(DNT), lds, st, g);
+    else hipLaunchKernelGGL((gemm_h8_areg_kernel<NGK, NS, D, false>), dim3(g.B * tilesM * tilesN), dim3(DNT), lds, st, g);
     return (int)hipGetLastError();
 }
 

@@ -296,6 +296,11 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
     // is an error (-3) of the mixed mode, not a fallback (option "kvq64" = 0 selects the 128-column-tile kernel and its images)
     bool kvq_on = false;
     if (mixed && w.wimg && option(OPT_KVQ64) && option(OPT_HEADMAJOR) && (C == 128 || C == 256 || C == 384 || C == 512) && !((C / H) & 7)) kvq_on = true;
+    // fp16 mode at feature_dim 512: the 128-column-tile A-stationary kernel needs 128 fragment registers + 128 accumulator
+    // registers there and spills (gemm_f16_astat_kernel<16, 4, *>: 24 - 54 VGPRs to scratch); the 64-column-tile kernel takes the
+    // same one-term product without scratch (gemm_kvq_astat_kernel<8, 6>, no L stages)
+    const bool kvq16_on = !mixed && pr == 2 && w.wimg && option(OPT_KVQ64) && option(OPT_HEADMAJOR) && option(OPT_ASTAT) && C == 512 &&
+                          !((C / H) & 7) && N >= 128 && N % 128 == 0;
     // ... and mlp.2 / out_proj as h8 products fed from h8 activation images (gemm_h8_areg.hip; option "h8areg")
     bool h8x = false, h8o = false;
     if (mixed && w.wimg && option(OPT_H8AREG) && option(OPT_ACTIMG) && Wd % 64 == 0 && N % 128 == 0) {
@@ -387,8 +392,16 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
                     TRY(push2(L.bmlp.w2 + (size_t)hf * C, base + w.o_b2 + (size_t)hf * C * C, C, C, Wd), "split(broadcast.mlp.2 K-half, two-term)");
                 TRY(push2(L.in_proj_w + (size_t)C * C, base + w.o_ukv, 2 * C, C, C), "split(unpool.in_proj kv, two-term)");
             }
+            if (kvq16_on) {   // one-term kvq stream: K | V tiles, then the q tiles (o_q = the end of the kv image: 2 bytes per weight)
+                if (!(h_in && h_in[li])) {
+                    if (jobs8.n >= kJobCap) { TRY(h8_image_multi_launch(jobs8, s), "split(kv_proj, kvq)"); jobs8.n = 0; }
+                    jobs8.job[jobs8.n++] = SplitJob{L.kv_proj_w, base, 2 * C, C, C, 1};
+                }
+                if (jobs8.n >= kJobCap) { TRY(h8_image_multi_launch(jobs8, s), "split(q_proj, kvq)"); jobs8.n = 0; }
+                jobs8.job[jobs8.n++] = SplitJob{L.in_proj_w, base + w.o_q, C, C, C, 1};
+            }
             if (!(h_in && h_in[li]) && !chain2_here) {
-                if (!mixed) TRY(push(L.kv_proj_w, base, 2 * C, C), "split(kv_proj)");
+                if (!mixed && !kvq16_on) TRY(push(L.kv_proj_w, base, 2 * C, C), "split(kv_proj)");
                 TRY(push(L.pool_out_w, base + w.o_pout, C, C), "split(pool.out_proj)");
                 TRY(push(L.bmlp.w0, base + w.o_b0, Wd, C), "split(broadcast.mlp.0)");
                 if (chain_on) {   // the one-launch chain walks mlp.2 K-half by K-half: one (C x C) image per half
@@ -400,7 +413,7 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
                 }
             }
             if (!chain2_here) TRY(push(L.in_proj_w + (size_t)C * C, base + w.o_ukv, 2 * C, C), "split(unpool.in_proj kv)");
-            if (!mixed) TRY(push(L.in_proj_w, base + w.o_q, C, C), "split(q_proj)");
+            if (!mixed && !kvq16_on) TRY(push(L.in_proj_w, base + w.o_q, C, C), "split(q_proj)");
             if (h8o) {
                 if (jobs8.n >= kJobCap) { TRY(h8_image_multi_launch(jobs8, s), "split(out_proj, h8)"); jobs8.n = 0; }
                 jobs8.job[jobs8.n++] = SplitJob{L.unpool_out_w, base + w.o_out, C, C, C, uo8_on ? 16 : 2};   // 16: 64-column tiles, attention k order
@@ -465,12 +478,12 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
             const int hd_try = option(OPT_HEADMAJOR) ? C / H : 0;
             const float* im_lo = mixed && im ? im + kvq_lo : nullptr;
             int fused = io16 ? astat_linear(x, w.a1, w.o1, (2 * C) % 128 == 0 ? im : nullptr, nullptr, 2 * C, w.big,
-                                            L.in_proj_b, C, w.q, nullptr, 0, B, N, C, s, hd_try, im_lo, kvq_on ? 2 : 0)
+                                            L.in_proj_b, C, w.q, nullptr, 0, B, N, C, s, hd_try, im_lo, kvq_on ? 2 : kvq16_on ? 1 : 0)
                              : 1;
             if (io16 && fused == 1 && hd_try)   // shape outside the head-major form: row-major
                 fused = astat_linear(x, w.a1, w.o1, (2 * C) % 128 == 0 ? im : nullptr, nullptr, 2 * C, w.big, L.in_proj_b,
-                                     C, w.q, nullptr, 0, B, N, C, s, 0, im_lo, kvq_on ? 2 : 0);
-            if (mixed && fused != 0) return fail(fused < 0 ? fused : -3, "set_transformer: mixed mode: kv_proj | q_proj outside the A-stationary kernel's reach");
+                                     C, w.q, nullptr, 0, B, N, C, s, 0, im_lo, kvq_on ? 2 : kvq16_on ? 1 : 0);
+            if ((mixed || kvq16_on) && fused != 0) return fail(fused < 0 ? fused : -3, "set_transformer: kv_proj | q_proj outside the A-stationary kernel's reach (its weight images are in that kernel's format)");
             else if (fused == 0 && hd_try)
                 hm = 1;
             if (fused < 0) TRY(fused, "kv_proj|q_proj (A-stationary)");
@@ -534,11 +547,11 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
                                                       : mixed ? im + (size_t)(2 * C + 127) / 128 * 128 * C / 2 : im + w.o_q;
             const float* qim_lo = nullptr;   // q_proj's weights stay one-term (their rounding does not reach the output)
             int one = astat_linear(x, w.a1, w.o1, qim, L.in_proj_b, C, w.q, nullptr, 0, nullptr,
-                                   nullptr, 0, B, N, C, s, hd_try, qim_lo, kvq_on ? 1 : 0);
+                                   nullptr, 0, B, N, C, s, hd_try, qim_lo, (kvq_on || kvq16_on) ? 1 : 0);
             if (one == 1 && hd_try)
                 one = astat_linear(x, w.a1, w.o1, qim, L.in_proj_b, C, w.q, nullptr, 0, nullptr, nullptr,
-                                   0, B, N, C, s, 0, qim_lo, kvq_on ? 1 : 0);
-            if (mixed && one != 0) return fail(one < 0 ? one : -3, "set_transformer: mixed mode: q projection outside the A-stationary kernel's reach");
+                                   0, B, N, C, s, 0, qim_lo, (kvq_on || kvq16_on) ? 1 : 0);
+            if ((mixed || kvq16_on) && one != 0) return fail(one < 0 ? one : -3, "set_transformer: q projection outside the A-stationary kernel's reach (its weight image is in that kernel's format)");
             else if (one == 0 && hd_try)
                 hm = 1;
             if (one < 0) TRY(one, "unpool.in_proj(q) (A-stationary)");

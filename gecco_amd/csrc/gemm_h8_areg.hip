@@ -46,7 +46,7 @@ using dma::dma16;
 
 constexpr int G_STAGE = 4096;   // floats per 16 KiB W stage: two [128][16 floats] sub-tiles
 constexpr int A_BLK = 6144;     // floats per (128-row tile, 64-k group) block of the activation image
-constexpr int PW = 4;           // 1 KiB W pieces per wave and stage
+constexpr int PW4 = 4;          // 1 KiB W pieces per wave and stage (4 waves; 8 waves: 2)
 constexpr int AL = 6;           // A loads per lane and group: 4 hi + 2 lo
 
 template <int... I, class F>
@@ -84,7 +84,7 @@ __device__ __forceinline__ f32x16 keep8(i32x8 a, i32x8 b, f32x16 c) {
 // s_waitcnt vmcnt may leave in flight.  Steps t = 2 g (H stage of group g) and 2 g + 1 (L stage).  Issue order: prologue
 // P_0 .. P_{NS-2}, A_0 .. A_{D-1}; step u: P_{u+NS-1} (while it exists), and at the end of an L step A_{g+D} (while it exists).
 // Step t needs P_{t+1} (the barrier then makes every wave's pieces of the next stage visible) and, at an H step, A_{t/2}.
-constexpr int young_at(int t, int NGK, int NS, int D) {
+constexpr int young_at(int t, int NGK, int NS, int D, int PW = 4) {
     const int nst = 2 * NGK;
     int total = 0, need_end = 0;
     auto mark_p = [&](int s) { if (s == t + 1) need_end = total; };
@@ -98,13 +98,17 @@ constexpr int young_at(int t, int NGK, int NS, int D) {
     return total - need_end;
 }
 
-template <int NGK, int NS, int D, bool DIRECT>
-__global__ __launch_bounds__(DNT, 2) void gemm_h8_areg_kernel(GemmArgs g) {
+// NW = 8 (DIRECT epilogue only): a 256-row block of 8 waves, one per CU — a W stage brought into the LDS serves 256 rows instead of
+// 128 (per 128 rows and 64-k group 16 + 24 KiB enter the CU instead of 32 + 24: the K loop is bound by exactly that,
+// profiles/r03k_h8areg_phases.txt)
+template <int NGK, int NS, int D, bool DIRECT, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_h8_areg_kernel(GemmArgs g) {
     static_assert(NS >= 3 && D >= 1 && D <= NGK, "ring / lookahead");
-    constexpr int NST = 2 * NGK;
+    static_assert(NW == 4 || (NW == 8 && DIRECT), "the LDS-transpose epilogue is written for four waves");
+    constexpr int NST = 2 * NGK, PW = 16 / NW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     ASTAMP(0);
-    const dma::Tile T = dma::tile_of_block<128>(g);
+    const dma::Tile T = dma::tile_of_block<32 * NW>(g);
     const int ct = T.ct, b = T.b, m0 = T.m0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -114,12 +118,13 @@ __global__ __launch_bounds__(DNT, 2) void gemm_h8_areg_kernel(GemmArgs g) {
     auto issue_w = [&](int s) {
         float* st = smem + (s % NS) * G_STAGE + wave * 256;
 #pragma unroll
-        for (int p = 0; p < PW; ++p) dma16(wimg + (size_t)s * G_STAGE + p * 1024, st + p * 1024);
+        for (int p = 0; p < PW; ++p) dma16(wimg + (size_t)s * G_STAGE + p * NW * 256, st + p * NW * 256);   // piece p NW + wave
     };
     // this wave's 32 rows = 32-row tile `wave` of the 128-row tile: its lane's 16 bytes of fragment (sub, c) of group 0
     const int t128 = g.rows >> 7;
-    const u32x4* asrc = reinterpret_cast<const u32x4*>(g.A + ((size_t)b * t128 + (m0 >> 7)) * NGK * A_BLK + wave * 1024 + lane * 4);
-    const u32x4* asrc_lo = reinterpret_cast<const u32x4*>(g.A + ((size_t)b * t128 + (m0 >> 7)) * NGK * A_BLK + 4096 + wave * 512 + lane * 4);
+    const size_t ablk = ((size_t)b * t128 + (m0 >> 7) + (wave >> 2)) * NGK * A_BLK;
+    const u32x4* asrc = reinterpret_cast<const u32x4*>(g.A + ablk + (wave & 3) * 1024 + lane * 4);
+    const u32x4* asrc_lo = reinterpret_cast<const u32x4*>(g.A + ablk + 4096 + (wave & 3) * 512 + lane * 4);
     u32x4 ahi[D][4], alo[D][2];
     auto load_a = [&](int gq, int set) {
 #pragma unroll
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(DNT, 2) void gemm_h8_areg_kernel(GemmArgs g) {
             }
     };
 
-    dma::wait_vm<young_at(0, NGK, NS, D)>();
+    dma::wait_vm<young_at(0, NGK, NS, D, PW)>();
     ASTAMP(1);   // stage 0 (own pieces) and the younger ones' allowance: see young_at
     // step 0 needs P_1 and A_0; the fragments of stage 0 itself need P_0 of every wave: older than both
     __builtin_amdgcn_s_barrier();
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(DNT, 2) void gemm_h8_areg_kernel(GemmArgs g) {
     static_for(std::make_integer_sequence<int, NST>{}, [&](auto TT) {
         constexpr int t = decltype(TT)::value, gq = t >> 1, set = gq % D;
         constexpr bool lst = (t & 1) != 0;
-        constexpr int yv = young_at(t, NGK, NS, D);
+        constexpr int yv = young_at(t, NGK, NS, D, PW);
         dma::wait_vm_lgkm0<(yv > 63 ? 63 : yv)>();   // 6-bit field; the last step needs nothing: everything may stay in flight
 #pragma unroll
         for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(fbA[j]));
@@ -236,7 +241,7 @@ __global__ __launch_bounds__(DNT, 2) void gemm_h8_areg_kernel(GemmArgs g) {
         // exposure of the HBM latency per block instead of one per 32 x 64 sub-tile), the result leaves as 64 stores of the same
         // shape, and a lane's column sums are 16 adds and one lane-half exchange.  Same arithmetic as dma::epilogue:
         // (A W^T + bias) + residual.  Whole 128-column tiles only (Nout % 128 == 0).
-        const int n0 = T.n0, tilesM = T.tilesM, rt = T.rt;
+        const int n0 = T.n0;
         const float* Rb = g.residual ? g.residual + ((size_t)b * g.rows + m0 + wave * 32) * g.ldr + n0 : nullptr;
         float* Cb = g.C + ((size_t)b * g.rows + m0 + wave * 32) * g.ldc + n0;
         const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Rb ? Rb : Cb), 0, 0x7fffffff, 0x00020000);
@@ -252,7 +257,7 @@ __global__ __launch_bounds__(DNT, 2) void gemm_h8_areg_kernel(GemmArgs g) {
                     res[j][qe] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, vr, (unsigned)((row * g.ldr + 32 * j) * 4), 0));
                 }
         }
-        float* red = smem;   // [4 waves][2][128]
+        float* red = smem;   // [NW waves][2][128]
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float bias = g.bias ? g.bias[n0 + 32 * j + r] : 0.f;
@@ -277,11 +282,12 @@ __global__ __launch_bounds__(DNT, 2) void gemm_h8_areg_kernel(GemmArgs g) {
         }
         if (g.stats) {
             __syncthreads();
-            const int which = tid >> 7, cl = tid & 127;
+            // per 128-row tile (the consumers count partials per 128 rows): waves 4 half .. 4 half + 3
+            const int half = tid >> 8, which = (tid >> 7) & 1, cl = tid & 127;
             float t = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) t += red[(w * 2 + which) * 128 + cl];
-            g.stats[(((size_t)b * tilesM + rt) * 2 + which) * g.Nout + n0 + cl] = t;
+            for (int w = 0; w < 4; ++w) t += red[((4 * half + w) * 2 + which) * 128 + cl];
+            g.stats[(((size_t)b * (g.rows >> 7) + (m0 >> 7) + half) * 2 + which) * g.Nout + n0 + cl] = t;
         }
     } else {
         dma::epilogue<1, 4, 4>(g, T, acc, smem, wave, lane, wave, 0);
@@ -290,7 +296,23 @@ __global__ __launch_bounds__(DNT, 2) void gemm_h8_areg_kernel(GemmArgs g) {
 }
 
 template <int NGK>
+int h8_areg_launch8_t(const GemmArgs& g, hipStream_t st) {   // 256-row blocks of 8 waves, no-transpose epilogue
+    constexpr int NS = 6, D = NGK >= 3 ? 3 : NGK;
+    const int tilesM = g.rows / 256, tilesN = g.Nout / DBN;
+    constexpr size_t lds = (size_t)NS * G_STAGE * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h8_areg_kernel<NGK, NS, D, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm_h8_areg_kernel<NGK, NS, D, true, 8>), dim3(g.B * tilesM * tilesN), dim3(512), lds, st, g);
+    return (int)hipGetLastError();
+}
+
+template <int NGK>
 int h8_areg_launch_t(const GemmArgs& g, hipStream_t st) {
+    static const int w8_env = [] { const char* e = getenv("GECCO_H8AREG_W8"); return e ? atoi(e) : 0; }();
+    if (w8_env && g.rows % 256 == 0 && g.Nout % 128 == 0) return h8_areg_launch8_t<NGK>(g, st);
     constexpr int NS = 4, D = NGK >= 3 ? 3 : NGK;
     const int tilesM = g.rows / 128, tilesN = (g.Nout + DBN - 1) / DBN;
     constexpr size_t ring = (size_t)NS * G_STAGE, epi = (size_t)D_EPI;

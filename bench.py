@@ -452,13 +452,24 @@ def train_bench(args, rank, world, dev):
     gd.broadcast_parameters(model)
     opt = FusedAdamEMA(params, lr=1e-4, ema_decay=0.99)
     red = gd.BucketedGradAllReducer(opt, bucket_bytes=args.bucket_mb << 20, force_collective=args.force_collective)
+    # --amp: what Lightning's precision="16-mixed" does around the reference's training_step (torch default scaler settings);
+    # FusedAdamEMA takes the scaler's scale / found_inf tensors on the device (no host read-back of found_inf per step)
+    scaler = torch.amp.GradScaler("cuda") if args.amp else None
 
     def step(i):
         opt.zero_grad(set_to_none=not args.grad_views)   # autograd hands the gradients over; gathered per bucket / at step()
-        loss = model.training_step(example, i)
-        loss.backward()
+        if scaler is None:
+            loss = model.training_step(example, i)
+            loss.backward()
+            red.finish()
+            opt.step()
+            return loss
+        with torch.autocast("cuda", dtype=torch.float16):
+            loss = model.training_step(example, i)
+        scaler.scale(loss).backward()
         red.finish()
-        opt.step()
+        scaler.step(opt)
+        scaler.update()
         return loss
 
     for i in range(max(args.warmup, 1)):
@@ -480,7 +491,9 @@ def train_bench(args, rank, world, dev):
     rec = {"metric": "train_points_per_sec", "value": world * Bt * Nt * args.steps / dt, "unit": "points/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None,
-           "dtype": {"bf16x3": "bf16 (split hi+lo operands, 3 MFMAs per product, fp32 accumulate)", "fp32": "f32",
+           "dtype": "f16 operands, f32 accumulate (torch.autocast(float16) + GradScaler = the reference's precision='16-mixed'; attention in split-bf16)"
+                    if args.amp else
+                    {"bf16x3": "bf16 (split hi+lo operands, 3 MFMAs per product, fp32 accumulate)", "fp32": "f32",
                      "fp16": "bf16 (split; the fp16 mode is not used for gradients)",
                      "mixed": "bf16 (split; the mixed mode trains in split-bf16)"}[args.precision],
            "data": "synthetic",
@@ -495,6 +508,8 @@ def train_bench(args, rank, world, dev):
     # the optimizer step alone, and the collective alone (bus bandwidth = 2 (n-1)/n bytes / t for an all-reduce)
     flat = opt.flat_grad()
     rec["adam_ema_ms"] = time_events(lambda: opt.launch(opt._adam_step, True), 10)   # the kernel alone (state kept: same step)
+    if scaler is not None:
+        rec["amp"] = {"loss_scale": scaler.get_scale(), "steps_skipped": opt._adam_step - opt.adam_steps_taken}
     rec["grad_bytes"] = flat.numel() * 4
     rec["buckets"] = len(red.buckets)
     if rank == 0 and not cond and args.precision in ("mixed", "bf16x3", "fp16"):
@@ -506,12 +521,14 @@ def train_bench(args, rank, world, dev):
         dy = torch.randn(Bt, N, D, generator=gg).to(dev)
         xh = torch.randn(Bt, N, 2 * D, generator=gg).to(dev)
         with torch.no_grad():
-            t_dw = time_events(lambda: ga._linear_dw_main(dy, xh, want_db=True), 10)
+            t_dw = time_events(lambda: ga._linear_dw_main(dy, xh, want_db=True, prec="fp16" if args.amp else None), 10)
         fl = 2.0 * Bt * N * D * 2 * D
-        rec["dominant_kernel"] = {"kernel": "gemm_tn_x3_kernel (dW = dY^T X of mlp.2: 2 M N K with M = Bt N rows contracted, split-bf16 = 3 MFMAs "
-                                            "per product; incl. the fixed-order reduction of the per-group partials)",
-                                  "ms": t_dw, "achieved_tflops": fl / (t_dw * 1e-3) / 1e12, "peak_tflops": PEAK_BF16_MFMA_TFLOPS / 3,
-                                  "frac": 3 * fl / (t_dw * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, "bound": "mfma"}
+        units = 1 if args.amp else 3
+        rec["dominant_kernel"] = {"kernel": "gemm_tn_x3_kernel (dW = dY^T X of mlp.2: 2 M N K with M = Bt N rows contracted, " +
+                                            ("fp16 operands = 1 MFMA per product" if args.amp else "split-bf16 = 3 MFMAs per product") +
+                                            "; incl. the fixed-order reduction of the per-group partials)",
+                                  "ms": t_dw, "achieved_tflops": fl / (t_dw * 1e-3) / 1e12, "peak_tflops": PEAK_BF16_MFMA_TFLOPS / units,
+                                  "frac": units * fl / (t_dw * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, "bound": "mfma"}
     if world > 1 or args.force_collective:
         # --force-collective at one rank: the RCCL all-reduce of every bucket really executes (a group of one: no bytes
         # cross a link, so no bus bandwidth is claimed) — the collective path of the step runs before an 8-GPU box has to
@@ -746,6 +763,9 @@ def main():
     ap.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "C5"],
                     help="BASELINE.json configuration: C2 (default, the headline), C3 / C4 image-conditional, C5 cached upsampling evaluation")
     ap.add_argument("--train", action="store_true", help="time the data-parallel training step instead of the forward")
+    ap.add_argument("--amp", action="store_true",
+                    help="--train: the reference's shipped trainer setting, precision='16-mixed' (example_configs/*.py): training_step under "
+                         "torch.autocast(float16), loss scaled by a torch.amp.GradScaler — the HIP path then runs its linears with fp16 operands")
     ap.add_argument("--train-batch", type=int, default=48, help="per-GPU batch of --train (shipped config: 48)")
     ap.add_argument("--bucket-mb", type=int, default=8, help="gradient all-reduce bucket size of --train")
     ap.add_argument("--grad-views", action="store_true",
@@ -1027,11 +1047,19 @@ def main():
             if left < 20.0:
                 return {"error": "skipped: the extras' time budget (360 s) is spent"}
             return run_child(argv, timeout=min(cap, left))
-        tr = run_extra(["--train", "--steps", "10", "--warmup", "3", "--precision", args.precision])
+        # the training step in the reference's shipped trainer setting (precision="16-mixed": both example configs) ...
+        tr = run_extra(["--train", "--amp", "--steps", "10", "--warmup", "3", "--precision", args.precision])
         rec["train"] = tr if "error" in tr else {
-            "config": "C2 training step, batch 48/GPU (forward + backward + fused Adam/EMA, HIP autograd path, split-bf16)",
+            "config": "C2 training step, batch 48/GPU (forward + backward + fused Adam/EMA, HIP autograd path) under torch.autocast(float16) + "
+                      "GradScaler — the reference's precision='16-mixed': linears with fp16 operands / fp32 accumulation, fp32 tensors",
             "ms_per_step": tr["ms_per_step"], "points_per_sec": tr["value"], "tflops_algorithmic": tr["train_tflops_algorithmic"],
-            "adam_ema_ms": tr.get("adam_ema_ms"), "dominant_kernel": tr.get("dominant_kernel")}
+            "adam_ema_ms": tr.get("adam_ema_ms"), "dominant_kernel": tr.get("dominant_kernel"), "amp": tr.get("amp")}
+        # ... and without autocast: every product in split-bf16 (gradients within 1e-4 of the fp32 oracle's)
+        tr = run_extra(["--train", "--steps", "10", "--warmup", "3", "--precision", args.precision])
+        rec["train_split_bf16"] = tr if "error" in tr else {
+            "config": "the same step without autocast: split-bf16 (3 MFMAs per product) everywhere",
+            "ms_per_step": tr["ms_per_step"], "points_per_sec": tr["value"], "tflops_algorithmic": tr["train_tflops_algorithmic"],
+            "dominant_kernel": tr.get("dominant_kernel")}
         cfgs = {}
         for c in ("C3", "C4", "C5"):
             rc_ = run_extra(["--config", c, "--steps", "10", "--warmup", "3", "--precision", args.precision] + (["--no-sampler"] if c != "C5" else []))

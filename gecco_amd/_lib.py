@@ -87,6 +87,9 @@ SIGNATURES = {
     "gecco_split_bf16_images_f32": (i, [C.POINTER(GeccoSplitJob), i, vp]),
     "gecco_split_bf16_image_bytes": (sz, [i, i]),
     "gecco_linear_image_ok": (i, [i, i, i, i]),
+    "gecco_split_f16_images_f32": (i, [C.POINTER(GeccoSplitJob), i, vp]),
+    "gecco_split_f16_image_bytes": (sz, [i, i]),
+    "gecco_linear_image_ok_f16": (i, [i, i, i, i]),
     "gecco_linear_actbwd_ok": (i, [i, i, i, i]),
     "gecco_linear_actbwd_tiles": (sz, [i, i, i]),
     "gecco_linear_actbwd_f32": (i, [vp, vp, vp, vp, i, vp, vp, vp, i, i, i, i, i, vp, vp]),
@@ -104,6 +107,7 @@ SIGNATURES = {
     "gecco_gemm_tn_x3_f32": (i, [vp, vp, vp, i, i, i, i, i, vp]),
     "gecco_gemm_tn_x3_bias_f32": (i, [vp, vp, vp, vp, i, i, i, i, i, vp]),
     "gecco_gemm_tn_x3_pro_f32": (i, [vp, vp, vp, vp, vp, vp, i, i, i, i, i, vp]),
+    "gecco_gemm_tn_f16_f32": (i, [vp, vp, vp, vp, vp, vp, i, i, i, i, i, vp]),
     "gecco_set_option": (i, [C.c_char_p, i]),
     "gecco_linear_astat_f16": (i, [vp, vp, vp, vp, vp, i, vp, vp, vp, i, vp, vp, i, i, i, i, i, vp, vp]),
     "gecco_linear_kvq_f16": (i, [vp, vp, vp, vp, vp, i, vp, vp, vp, i, vp, i, i, i, i, i, i, vp, vp]),
@@ -194,6 +198,7 @@ SIGNATURES = {
     "gecco_gelu_bwd_f32": (i, [vp, vp, vp, C.c_size_t, vp]),
     "gecco_convnext_im2col4_f32": (i, [vp, vp, i, i, i, vp]),
     "gecco_adam_ema_step_f32": (i, [C.POINTER(GeccoAdamEma), vp]),
+    "gecco_adam_ema_step_amp_f32": (i, [C.POINTER(GeccoAdamEma), vp, vp, vp, vp]),
     "gecco_ema_update_f32": (i, [vp, vp, sz, db, vp]),
 }
 

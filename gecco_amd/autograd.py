@@ -53,6 +53,24 @@ def _train_precision() -> str:
     return "bf16x3" if p in ("fp16", "mixed") else p
 
 
+def _amp_fp16() -> bool:
+    """The caller runs the reference's own trainer setting — `precision="16-mixed"` of both shipped configs
+    (example_configs/shapenet_airplane_unconditional.py:74, taskonomy_conditional.py:102), i.e. Lightning wraps `training_step`
+    (diffusion.py:213-222) in `torch.autocast("cuda", float16)` and scales the loss with a GradScaler."""
+    return (os.environ.get("GECCO_TRAIN_AMP", "1") != "0" and torch.is_autocast_enabled("cuda")
+            and torch.get_autocast_dtype("cuda") == torch.float16)
+
+
+def _lin_precision() -> str:
+    """Arithmetic of the training path's linears (forward, dX and dW products), decided in the FORWARD of each Function and kept
+    in its ctx for the backward (which runs outside the autocast region).  Under `torch.autocast(float16)` the reference's
+    nn.Linear / in_proj products run with fp16 operands and fp32 accumulation, and so do ours then ("fp16": one MFMA per product
+    instead of split-bf16's three; fp32 parameters, fp32 tensors between the kernels, fp32 weight gradients — torch rounds those
+    to fp16 too); the caller's GradScaler keeps the gradients inside fp16's range exactly as it does for the reference (an
+    overflow becomes inf in the weight gradients, which the scaler detects and skips).  Without autocast: `_train_precision()`."""
+    return "fp16" if _amp_fp16() else _train_precision()
+
+
 def _no_input_grad(ctx, idx: int, what: str) -> None:
     """The training path differentiates with respect to PARAMETERS (and the conditioner's pyramid); a caller asking for the
     gradient of the denoiser with respect to the geometry or the noise level (guidance, score Jacobians) must hear about it
@@ -95,10 +113,17 @@ class WeightImages:
     def _key(kind: str, *ws: Tensor) -> tuple:
         return (kind,) + tuple((w.data_ptr(), tuple(w.shape), tuple(w.stride())) for w in ws)
 
-    def lookup(self, kind: str, *ws: Tensor) -> Tensor | None:
-        """The ready image for this weight (pair), or None.  kind: "n" image of W, "t" image of W^T, "pair" W1 | W2."""
-        if _train_precision() != "bf16x3":
+    def lookup(self, kind: str, *ws: Tensor, prec: str | None = None) -> Tensor | None:
+        """The ready image for this weight (pair), or None.  kind: "n" image of W, "t" image of W^T, "pair" W1 | W2.
+        prec: "bf16x3" (default: the training precision) or "fp16" — the fp16 images of the autocast(float16) setting are
+        their own entries (kind + "16")."""
+        prec = _train_precision() if prec is None else prec
+        if prec not in ("bf16x3", "fp16"):
             return None
+        if prec == "fp16":
+            if any(w.shape[-1] % 32 for w in ws) or (kind == "t" and ws[0].shape[0] % 32):
+                return None
+            kind = kind + "16"
         key = self._key(kind, *ws)
         self.used[key] = self.step
         if self.armed:
@@ -144,21 +169,28 @@ class WeightImages:
         jobs, offs, total = [], {}, 0
         for key, ws in self.plan.items():
             kind = key[0]
+            f16 = kind.endswith("16")
+            tr = kind.startswith("t")
             nbytes = 0
             for w in ws:
-                nout, k = (w.shape[1], w.shape[0]) if kind == "t" else (w.shape[0], w.shape[1])
-                jobs.append((key, w, nout, k, kind == "t", total + nbytes))
-                nbytes += lib.gecco_split_bf16_image_bytes(nout, k)
+                nout, k = (w.shape[1], w.shape[0]) if tr else (w.shape[0], w.shape[1])
+                jobs.append((key, w, nout, k, tr, total + nbytes, f16))
+                nbytes += lib.gecco_split_f16_image_bytes(nout, k) if f16 else lib.gecco_split_bf16_image_bytes(nout, k)
             offs[key] = (total, nbytes)
             total += (nbytes + 255) // 256 * 256
         dev = jobs[0][1].device
         if self.pool is None or self.pool.numel() < total or self.pool.device != dev:
             self.pool = torch.empty(total, dtype=torch.uint8, device=dev)
-        arr = (_lib.GeccoSplitJob * len(jobs))()
         base = self.pool.data_ptr()
-        for j, (key, w, nout, k, tr, off) in enumerate(jobs):
-            arr[j] = _lib.GeccoSplitJob(w.data_ptr(), base + off, nout, k, w.stride(0), int(tr))
-        _lib.check(lib.gecco_split_bf16_images_f32(arr, len(jobs), _stream()), "gecco_split_bf16_images_f32")
+        for want16, fn, name in ((False, lib.gecco_split_bf16_images_f32, "gecco_split_bf16_images_f32"),
+                                 (True, lib.gecco_split_f16_images_f32, "gecco_split_f16_images_f32")):
+            sel = [j for j in jobs if j[6] == want16]
+            if not sel:
+                continue
+            arr = (_lib.GeccoSplitJob * len(sel))()
+            for j, (key, w, nout, k, tr, off, _) in enumerate(sel):
+                arr[j] = _lib.GeccoSplitJob(w.data_ptr(), base + off, nout, k, w.stride(0), int(tr))
+            _lib.check(fn(arr, len(sel), _stream()), name)
         self.images = {key: self.pool[o:o + n] for key, (o, n) in offs.items()}
         self.versions = {key: tuple(w._version for w in ws) for key, ws in self.plan.items()}
         self.armed = True
@@ -168,22 +200,25 @@ class WeightImages:
 WEIGHT_IMAGES = WeightImages()
 
 
-def _image_ok(rows: int, K: int, Nout: int) -> bool:
-    return bool(_lib.load().gecco_linear_image_ok(rows, K, Nout, 0))
+def _image_ok(rows: int, K: int, Nout: int, prec: str = "bf16x3") -> bool:
+    lib = _lib.load()
+    return bool(lib.gecco_linear_image_ok_f16(rows, K, Nout, 0) if prec == "fp16" else lib.gecco_linear_image_ok(rows, K, Nout, 0))
 
 
 # ------------------------------------------------------------------------------------------- Linear
-def _linear_dx(dy: Tensor, W: Tensor, residual: Tensor | None = None) -> Tensor:
-    """dx = dy W (+ residual: another gradient contribution to the same tensor, added in the GEMM's epilogue)."""
+def _linear_dx(dy: Tensor, W: Tensor, residual: Tensor | None = None, prec: str | None = None) -> Tensor:
+    """dx = dy W (+ residual: another gradient contribution to the same tensor, added in the GEMM's epilogue).
+    prec: the arithmetic the Function's forward chose (`_lin_precision()`); None: the training precision."""
     B, R, Nout = dy.shape
     K = W.shape[1]
+    prec = _train_precision() if prec is None else prec
     if R >= 64 and Nout % 16 == 0 and K % 4 == 0:
         # linear(dy, W^T): the fused LDS-DMA GEMM; the image of W^T comes ready from the step's batched launch when it is
         # there (WeightImages), else from a transposed copy of the (small) weight
-        img = WEIGHT_IMAGES.lookup("t", W) if _image_ok(R, Nout, K) else None
+        img = WEIGHT_IMAGES.lookup("t", W, prec=prec) if _image_ok(R, Nout, K, prec) else None
         if img is not None:
-            return hip_ops.linear(dy, None, residual=residual, precision="bf16x3", w_image=img, w_shape=(K, Nout))
-        return hip_ops.linear(dy, W.t().contiguous(), residual=residual, precision=_train_precision())
+            return hip_ops.linear(dy, None, residual=residual, precision=prec, w_image=img, w_shape=(K, Nout))
+        return hip_ops.linear(dy, W.t().contiguous(), residual=residual, precision=prec)
     dx = _gemm(dy, W, _new(B, R, K, like=dy), Z=1, zdiv=1, M=B * R, N=K, K=Nout, lda=Nout, ldb=K, ldc=K, b_km=True)  # W read k-major
     return dx if residual is None else dx + residual
 
@@ -211,18 +246,18 @@ def sync_side_stream() -> None:
         _SIDE["pending"] = False
 
 
-def _linear_dw(dy: Tensor, x: Tensor, want_db: bool = False, pro=None, leaf: Tensor | None = None):
+def _linear_dw(dy: Tensor, x: Tensor, want_db: bool = False, pro=None, leaf: Tensor | None = None, prec: str | None = None):
     """leaf: the parameter this gradient is FOR, when the caller knows that nothing will read the result before the pass ends —
     a leaf that is not a view (a view's gradient is scattered into its base by autograd, on the main stream, right away) and
     has no .grad yet (autograd then keeps the tensor instead of adding it into an existing one).  Only then the side stream."""
     if leaf is None or not (leaf.is_leaf and leaf._base is None and leaf.grad is None) or not _side_enabled():
-        return _linear_dw_main(dy, x, want_db, pro)
+        return _linear_dw_main(dy, x, want_db, pro, prec)
     if _SIDE["stream"] is None:
         _SIDE["stream"] = torch.cuda.Stream()
     side, main = _SIDE["stream"], torch.cuda.current_stream()
     side.wait_stream(main)
     with torch.cuda.stream(side):
-        res = _linear_dw_main(dy, x, want_db, pro)
+        res = _linear_dw_main(dy, x, want_db, pro, prec)
     for t in (dy, x) + (tuple(pro) if pro is not None else ()):
         t.record_stream(side)
     for t in (res if isinstance(res, tuple) else (res,)):
@@ -236,16 +271,36 @@ def _linear_dw(dy: Tensor, x: Tensor, want_db: bool = False, pro=None, leaf: Ten
     return res
 
 
-def _linear_dw_main(dy: Tensor, x: Tensor, want_db: bool = False, pro=None):
+def _linear_dw_main(dy: Tensor, x: Tensor, want_db: bool = False, pro=None, prec: str | None = None):
     """dW = dy^T x: both operands read k-major (contraction over their rows); partials summed in a fixed order.
     want_db: also the bias gradient db = column sums of dy -> (dW, db); the split-bf16 kernel forms it from the dy tiles
     it stages anyway.  pro = (a, o): the linear's input was AdaGN(x) = a x + o (per sample and column) — the split-bf16 kernel
-    applies it while it stages x; elsewhere the normalised tensor is formed first."""
+    applies it while it stages x; elsewhere the normalised tensor is formed first.  prec "fp16": the same kernel with one fp16
+    plane per operand (`gecco_gemm_tn_f16_f32`)."""
     B, R, K = x.shape
     Nout = dy.shape[2]
-    tn_ok = _train_precision() == "bf16x3" and R % 32 == 0 and Nout % 4 == 0 and K % 4 == 0
+    prec = _train_precision() if prec is None else prec
+    tn_ok = prec in ("bf16x3", "fp16") and R % 32 == 0 and Nout % 4 == 0 and K % 4 == 0
     if pro is not None and not tn_ok:
         x, pro = hip_ops.affine_apply(x, pro[0], pro[1]), None
+    if tn_ok and prec == "fp16":
+        if B == 1 and R >= 4096:   # one long row block: groups of rows (see below)
+            cap = max(64, 768 // (-(-Nout // 128) * -(-K // 128)))
+            g = max((d for d in range(1, cap + 1) if R % (32 * d) == 0), default=1)
+            if g > 1 and pro is None:
+                dy, x = dy.view(g, R // g, Nout), x.view(g, R // g, K)
+                B, R = g, R // g
+        tiles = -(-Nout // 128) * -(-K // 128)
+        G = min(B, max(1, -(-_DW_BLOCKS // tiles)))
+        group = -(-B // G)
+        G = -(-B // group)
+        parts = _new(G, Nout, K, like=x)
+        cparts = _new(G, Nout, like=x) if want_db else None
+        _lib.check(_lib.load().gecco_gemm_tn_f16_f32(_ptr(dy), _ptr(x), _ptr(pro[0]) if pro is not None else None,
+                                                     _ptr(pro[1]) if pro is not None else None, _ptr(parts), _ptr(cparts), B, R,
+                                                     Nout, K, group, _stream()), "gecco_gemm_tn_f16_f32")
+        dW = _reduce(parts, Nout * K, G, Nout * K).reshape(Nout, K)
+        return (dW, _reduce(cparts, Nout, G, Nout)) if want_db else dW
     if pro is not None:
         tiles = -(-Nout // 128) * -(-K // 128)
         G = min(B, max(1, -(-_DW_BLOCKS // tiles)))
@@ -266,8 +321,8 @@ def _linear_dw_main(dy: Tensor, x: Tensor, want_db: bool = False, pro=None):
             dy, x = dy.view(g, R // g, Nout), x.view(g, R // g, K)
             B, R = g, R // g
     if want_db:
-        if not (_train_precision() == "bf16x3" and R % 32 == 0 and Nout % 4 == 0 and K % 4 == 0):
-            return _linear_dw_main(dy, x), _linear_db(dy)
+        if not (prec == "bf16x3" and R % 32 == 0 and Nout % 4 == 0 and K % 4 == 0):
+            return _linear_dw_main(dy, x, prec=prec), _linear_db(dy)
         tiles = -(-Nout // 128) * -(-K // 128)
         G = min(B, max(1, -(-_DW_BLOCKS // tiles)))
         group = -(-B // G)
@@ -276,7 +331,7 @@ def _linear_dw_main(dy: Tensor, x: Tensor, want_db: bool = False, pro=None):
         _lib.check(_lib.load().gecco_gemm_tn_x3_bias_f32(_ptr(dy), _ptr(x), _ptr(parts), _ptr(cparts), B, R, Nout, K, group,
                                                          _stream()), "gecco_gemm_tn_x3_bias_f32")
         return _reduce(parts, Nout * K, G, Nout * K).reshape(Nout, K), _reduce(cparts, Nout, G, Nout)
-    if _train_precision() == "bf16x3" and R % 32 == 0 and Nout % 4 == 0 and K % 4 == 0:
+    if prec == "bf16x3" and R % 32 == 0 and Nout % 4 == 0 and K % 4 == 0:
         # split-bf16 MFMA with transposed LDS reads (gemm_tn_x3.hip); one partial per group of samples, groups
         # sized so that ~1000 blocks fill the chip
         tiles = -(-Nout // 128) * -(-K // 128)
@@ -309,9 +364,10 @@ class LinearFn(torch.autograd.Function):
         x = _f(x)
         ctx.save_for_backward(x, W)
         ctx.has_bias = b is not None
+        prec = ctx.prec = _lin_precision()
         res = None if residual is None else _f(residual)
-        img = WEIGHT_IMAGES.lookup("n", W) if _image_ok(x.shape[1], W.shape[1], W.shape[0]) else None
-        kw = dict(precision="bf16x3", w_image=img, w_shape=tuple(W.shape)) if img is not None else dict(precision=_train_precision())
+        img = WEIGHT_IMAGES.lookup("n", W, prec=prec) if _image_ok(x.shape[1], W.shape[1], W.shape[0], prec) else None
+        kw = dict(precision=prec, w_image=img, w_shape=tuple(W.shape)) if img is not None else dict(precision=prec)
         if want_stats:
             y, st = hip_ops.linear(x, None if img is not None else W, b, residual=res, want_stats=True, **kw)
             ctx.mark_non_differentiable(st)
@@ -322,12 +378,13 @@ class LinearFn(torch.autograd.Function):
     def backward(ctx, dy, _dstats=None):
         x, W = ctx.saved_tensors
         dy = _f(dy)
-        dx = _linear_dx(dy, W) if ctx.needs_input_grad[0] else None
+        prec = ctx.prec
+        dx = _linear_dx(dy, W, prec=prec) if ctx.needs_input_grad[0] else None
         dW = db = None
         if ctx.has_bias and ctx.needs_input_grad[2] and ctx.needs_input_grad[1]:
-            dW, db = _linear_dw(dy, x, want_db=True, leaf=W)
+            dW, db = _linear_dw(dy, x, want_db=True, leaf=W, prec=prec)
         elif ctx.needs_input_grad[1]:
-            dW = _linear_dw(dy, x, leaf=W)
+            dW = _linear_dw(dy, x, leaf=W, prec=prec)
         elif ctx.has_bias and ctx.needs_input_grad[2]:
             db = _linear_db(dy)
         n = len(ctx.needs_input_grad)        # 3 .. 5: called without / with a residual (and the statistics flag)
@@ -345,25 +402,27 @@ class LinearPairFn(torch.autograd.Function):
         x = _f(x)
         ctx.save_for_backward(x, W1, W2)
         ctx.bias = (b1 is not None, b2 is not None)
+        prec = ctx.prec = _lin_precision()
         img = None
-        if W1.shape[0] % 128 == 0 and W2.shape[0] % 128 == 0 and _image_ok(x.shape[1], W1.shape[1], W1.shape[0] + W2.shape[0]):
-            img = WEIGHT_IMAGES.lookup("pair", W1, W2)
+        if W1.shape[0] % 128 == 0 and W2.shape[0] % 128 == 0 and _image_ok(x.shape[1], W1.shape[1], W1.shape[0] + W2.shape[0], prec):
+            img = WEIGHT_IMAGES.lookup("pair", W1, W2, prec=prec)
         if img is not None:
-            return hip_ops.linear_pair(x, W1, b1, W2, b2, precision="bf16x3", w_image=img)
-        return hip_ops.linear_pair(x, W1, b1, _f(W2), b2, precision=_train_precision())
+            return hip_ops.linear_pair(x, W1, b1, W2, b2, precision=prec, w_image=img)
+        return hip_ops.linear_pair(x, W1, b1, _f(W2), b2, precision=prec)
 
     @staticmethod
     def backward(ctx, d1, d2):
         x, W1, W2 = ctx.saved_tensors
         d1, d2 = _f(d1), _f(d2)
         need = ctx.needs_input_grad
-        dx = _linear_dx(d2, W2, residual=_linear_dx(d1, W1)) if need[0] else None
+        prec = ctx.prec
+        dx = _linear_dx(d2, W2, residual=_linear_dx(d1, W1, prec=prec), prec=prec) if need[0] else None
         out = [dx]
         for d, has_b, iw, Wl in ((d1, ctx.bias[0], 1, W1), (d2, ctx.bias[1], 3, W2)):
             if need[iw] and has_b and need[iw + 1]:
-                out += list(_linear_dw(d, x, want_db=True, leaf=Wl))
+                out += list(_linear_dw(d, x, want_db=True, leaf=Wl, prec=prec))
             else:
-                out += [_linear_dw(d, x, leaf=Wl) if need[iw] else None, _linear_db(d) if has_b and need[iw + 1] else None]
+                out += [_linear_dw(d, x, leaf=Wl, prec=prec) if need[iw] else None, _linear_db(d) if has_b and need[iw + 1] else None]
         return tuple(out)
 
 
@@ -439,8 +498,11 @@ def _adagn_coeffs(x, t, sw, sb, bw, bb, G, eps, stats):
 
 def _pro_ok(R: int, K: int, Nout: int) -> bool:
     """The AdaGN-as-prologue Functions: split-bf16 training precision, shapes the LDS-DMA kernels take with a prologue."""
-    return (os.environ.get("GECCO_TRAIN_ADAGNPRO", "1") != "0" and _train_precision() == "bf16x3" and K <= 1024 and R % 32 == 0
-            and bool(_lib.load().gecco_linear_image_ok(R, K, Nout, 1)))
+    prec = _lin_precision()
+    if os.environ.get("GECCO_TRAIN_ADAGNPRO", "1") == "0" or prec not in ("bf16x3", "fp16") or K > 1024 or R % 32:
+        return False
+    lib = _lib.load()
+    return bool(lib.gecco_linear_image_ok_f16(R, K, Nout, 1) if prec == "fp16" else lib.gecco_linear_image_ok(R, K, Nout, 1))
 
 
 class AdaGNPairFn(torch.autograd.Function):
@@ -455,11 +517,12 @@ class AdaGNPairFn(torch.autograd.Function):
         x = _f(x)
         ctx.set_materialize_grads(False)
         a, o, stats, t2 = _adagn_coeffs(x, t, sw, sb, bw, bb, G, eps, stats)
-        img = WEIGHT_IMAGES.lookup("pair", W1, W2)
+        prec = ctx.prec = _lin_precision()   # "bf16x3" or "fp16" (_pro_ok)
+        img = WEIGHT_IMAGES.lookup("pair", W1, W2, prec=prec)
         if img is not None:
-            KV, q = hip_ops.linear_pair(x, W1, None, W2, b2, pro=(a, o), precision="bf16x3", w_image=img)
+            KV, q = hip_ops.linear_pair(x, W1, None, W2, b2, pro=(a, o), precision=prec, w_image=img)
         else:
-            KV, q = hip_ops.linear_pair(x, W1, None, _f(W2), b2, pro=(a, o), precision="bf16x3")
+            KV, q = hip_ops.linear_pair(x, W1, None, _f(W2), b2, pro=(a, o), precision=prec)
         ctx.save_for_backward(x, stats, t2, sw, sb, a, o, W1, W2)
         ctx.G, ctx.eps, ctx.has_b2 = G, eps, b2 is not None
         return KV, q, x
@@ -472,13 +535,14 @@ class AdaGNPairFn(torch.autograd.Function):
         B, R, Cc = x.shape
         dKV = _f(dKV) if dKV is not None else x.new_zeros(B, R, W1.shape[0])
         dq = _f(dq) if dq is not None else x.new_zeros(B, R, W2.shape[0])
-        dY = _linear_dx(dq, W2, residual=_linear_dx(dKV, W1))
-        dW1 = _linear_dw(dKV, x, pro=(a, o), leaf=W1) if need[9] else None
+        prec = ctx.prec
+        dY = _linear_dx(dq, W2, residual=_linear_dx(dKV, W1, prec=prec), prec=prec)
+        dW1 = _linear_dw(dKV, x, pro=(a, o), leaf=W1, prec=prec) if need[9] else None
         dW2 = db2 = None
         if need[10] and ctx.has_b2 and need[11]:
-            dW2, db2 = _linear_dw(dq, x, want_db=True, pro=(a, o), leaf=W2)
+            dW2, db2 = _linear_dw(dq, x, want_db=True, pro=(a, o), leaf=W2, prec=prec)
         elif need[10]:
-            dW2 = _linear_dw(dq, x, pro=(a, o), leaf=W2)
+            dW2 = _linear_dw(dq, x, pro=(a, o), leaf=W2, prec=prec)
         elif ctx.has_b2 and need[11]:
             db2 = _linear_db(dq)
         dx, dsw, dsb, dbw, dbb = _adagn_backward(x, stats, t2, sw, sb, dY, dskip, ctx.G, ctx.eps, True)
@@ -500,14 +564,16 @@ class AdaGNMlpFn(torch.autograd.Function):
         N0 = W0.shape[0]
         a, o, stats, t2 = _adagn_coeffs(x, t, sw, sb, bw, bb, G, eps, stats)
         u, h = _new(B, R, N0, like=x), _new(B, R, N0, like=x)
-        img = WEIGHT_IMAGES.lookup("n", W0)
+        prec = ctx.prec = _lin_precision()   # "bf16x3" or "fp16" (_pro_ok)
+        img = WEIGHT_IMAGES.lookup("n", W0, prec=prec)
         Wp, ws = (None, img) if img is not None else (_f(W0), hip_ops._ws((N0 + 127) // 128 * 128 * K0 * 4, x.device))
         _lib.check(lib.gecco_linear_act_keep_pro_f32(_ptr(x), _ptr(Wp), _ptr(b0), _ptr(a), _ptr(o), _ptr(alpha) if kind in (1, 2) else None,
-                                                     kind, _ptr(u), _ptr(h), B, R, K0, N0, 1, C.c_void_p(ws.data_ptr()), _stream()),
+                                                     kind, _ptr(u), _ptr(h), B, R, K0, N0, hip_ops.PRECISIONS[prec],
+                                                     C.c_void_p(ws.data_ptr()), _stream()),
                    "gecco_linear_act_keep_pro_f32")
         ctx.save_for_backward(x, stats, t2, sw, sb, a, o, u, h, alpha if alpha is not None else x.new_empty(0), W0, W2)
         ctx.G, ctx.eps, ctx.kind, ctx.bias = G, eps, kind, (b0 is not None, b2 is not None)
-        out = _linear_fwd(h, W2, b2, x, want_stats)
+        out = _linear_fwd(h, W2, b2, x, want_stats, prec)
         if want_stats:
             ctx.mark_non_differentiable(out[1])
         return out
@@ -518,15 +584,16 @@ class AdaGNMlpFn(torch.autograd.Function):
         x, stats, t2, sw, sb, a, o, u, h, alpha, W0, W2 = ctx.saved_tensors
         need = ctx.needs_input_grad
         dout = _f(dout)
-        du, dalpha = _act_linear_dx(dout, u, h, alpha, W2, ctx.kind, need[11])
+        prec = ctx.prec
+        du, dalpha = _act_linear_dx(dout, u, h, alpha, W2, ctx.kind, need[11], prec)
 
         def wgrads(g, act_in, has_b, iw, ib, Wl, pro=None):
             if has_b and need[ib] and need[iw]:
-                return _linear_dw(g, act_in, want_db=True, pro=pro, leaf=Wl)
-            return (_linear_dw(g, act_in, pro=pro, leaf=Wl) if need[iw] else None), (_linear_db(g) if has_b and need[ib] else None)
+                return _linear_dw(g, act_in, want_db=True, pro=pro, leaf=Wl, prec=prec)
+            return (_linear_dw(g, act_in, pro=pro, leaf=Wl, prec=prec) if need[iw] else None), (_linear_db(g) if has_b and need[ib] else None)
         dW2, db2 = wgrads(dout, h, ctx.bias[1], 12, 13, W2)
         dW0, db0 = wgrads(du, x, ctx.bias[0], 9, 10, W0, pro=(a, o))
-        dY = _linear_dx(du, W0)
+        dY = _linear_dx(du, W0, prec=prec)
         dx, dsw, dsb, dbw, dbb = _adagn_backward(x, stats, t2, sw, sb, dY, dout, ctx.G, ctx.eps, True)
         return dx, None, dsw, dsb, dbw, dbb, None, None, None, dW0, db0, dalpha, dW2, db2, None, None
 
@@ -554,22 +621,22 @@ class GaussActFn(torch.autograd.Function):
         return du, dalpha, None
 
 
-def _act_linear_dx(dy: Tensor, u: Tensor, h: Tensor, alpha: Tensor, W: Tensor, kind: int, want_alpha: bool):
+def _act_linear_dx(dy: Tensor, u: Tensor, h: Tensor, alpha: Tensor, W: Tensor, kind: int, want_alpha: bool, prec: str | None = None):
     """du = (dy W) * act'(u) and, for GaussianActivation, d alpha: the activation's backward as the epilogue of the dX product
     (`gecco_linear_actbwd_f32`) where the LDS-DMA kernels take the shape, else the product followed by the activation's
     backward kernel."""
     lib = _lib.load()
     B, R, Nout = dy.shape
     K = W.shape[1]
-    prec = _train_precision()
+    prec = _train_precision() if prec is None else prec
     dalpha = None
-    fused = (os.environ.get("GECCO_TRAIN_ACTBWD", "1") != "0" and prec in ("fp32", "bf16x3")
+    fused = (os.environ.get("GECCO_TRAIN_ACTBWD", "1") != "0" and prec in ("fp32", "bf16x3", "fp16")
              and lib.gecco_linear_actbwd_ok(R, Nout, K, hip_ops.PRECISIONS[prec]))
     if fused:
         du = torch.empty_like(u)
         nt = lib.gecco_linear_actbwd_tiles(B, R, K)
         parts = torch.zeros(nt, device=u.device, dtype=torch.float32) if kind in (1, 2) else None
-        img = WEIGHT_IMAGES.lookup("t", W) if prec == "bf16x3" else None
+        img = WEIGHT_IMAGES.lookup("t", W, prec=prec) if prec in ("bf16x3", "fp16") else None
         if img is not None:
             Wt, ws = None, img
         else:
@@ -582,7 +649,7 @@ def _act_linear_dx(dy: Tensor, u: Tensor, h: Tensor, alpha: Tensor, W: Tensor, k
         if kind in (1, 2) and want_alpha:
             dalpha = _reduce(parts, 1, nt, 1).reshape(alpha.shape)
         return du, dalpha
-    dh = _linear_dx(dy, W)
+    dh = _linear_dx(dy, W, prec=prec)
     if kind in (1, 2):
         nb = lib.gecco_gauss_act_bwd_blocks(u.numel())
         du, part = torch.empty_like(u), _new(nb, like=u)
@@ -607,10 +674,12 @@ def _act_forward(u: Tensor, alpha: Tensor | None, kind: int) -> Tensor:
     return h
 
 
-def _linear_fwd(x: Tensor, W: Tensor, b, res, want_stats: bool):
-    """hip_ops.linear in the training precision, with the step's ready weight image when there is one."""
-    img = WEIGHT_IMAGES.lookup("n", W) if _image_ok(x.shape[1], W.shape[1], W.shape[0]) else None
-    kw = dict(precision="bf16x3", w_image=img, w_shape=tuple(W.shape)) if img is not None else dict(precision=_train_precision())
+def _linear_fwd(x: Tensor, W: Tensor, b, res, want_stats: bool, prec: str | None = None):
+    """hip_ops.linear in the training precision (prec: the Function's `_lin_precision()`), with the step's ready weight image when
+    there is one."""
+    prec = _train_precision() if prec is None else prec
+    img = WEIGHT_IMAGES.lookup("n", W, prec=prec) if _image_ok(x.shape[1], W.shape[1], W.shape[0], prec) else None
+    kw = dict(precision=prec, w_image=img, w_shape=tuple(W.shape)) if img is not None else dict(precision=prec)
     return hip_ops.linear(x, None if img is not None else W, b, residual=res, want_stats=want_stats, **kw)
 
 
@@ -626,12 +695,12 @@ class LinearActLinearFn(torch.autograd.Function):
         lib = _lib.load()
         B, R, K0 = x.shape
         N0 = W0.shape[0]
-        prec = _train_precision()
-        keep = (os.environ.get("GECCO_TRAIN_ACTKEEP", "1") != "0" and prec in ("fp32", "bf16x3")
+        prec = ctx.prec = _lin_precision()
+        keep = (os.environ.get("GECCO_TRAIN_ACTKEEP", "1") != "0" and prec in ("fp32", "bf16x3", "fp16")
                 and lib.gecco_linear_actbwd_ok(R, K0, N0, hip_ops.PRECISIONS[prec]))
         if keep:
             u, h = _new(B, R, N0, like=x), _new(B, R, N0, like=x)
-            img = WEIGHT_IMAGES.lookup("n", W0) if prec == "bf16x3" and _image_ok(R, K0, N0) else None
+            img = WEIGHT_IMAGES.lookup("n", W0, prec=prec) if prec in ("bf16x3", "fp16") and _image_ok(R, K0, N0, prec) else None
             if img is not None:
                 Wp, ws = None, img
             else:
@@ -642,12 +711,12 @@ class LinearActLinearFn(torch.autograd.Function):
                                                      C.c_void_p(ws.data_ptr()) if ws is not None else None, _stream()),
                        "gecco_linear_act_keep_f32")
         else:
-            u = _linear_fwd(x, W0, b0, None, False)
+            u = _linear_fwd(x, W0, b0, None, False, prec)
             h = _act_forward(u, alpha, kind)
         ctx.save_for_backward(x, u, h, alpha if alpha is not None else x.new_empty(0), W0, W2)
         ctx.kind, ctx.bias = kind, (b0 is not None, b2 is not None)
         res = None if residual is None else _f(residual)
-        out = _linear_fwd(h, W2, b2, res, want_stats)
+        out = _linear_fwd(h, W2, b2, res, want_stats, prec)
         if want_stats:
             ctx.mark_non_differentiable(out[1])
         return out
@@ -657,15 +726,16 @@ class LinearActLinearFn(torch.autograd.Function):
         x, u, h, alpha, W0, W2 = ctx.saved_tensors
         need = ctx.needs_input_grad
         dy = _f(dy)
-        du, dalpha = _act_linear_dx(dy, u, h, alpha, W2, ctx.kind, need[3])
+        prec = ctx.prec
+        du, dalpha = _act_linear_dx(dy, u, h, alpha, W2, ctx.kind, need[3], prec)
 
         def wgrads(g, a, has_b, iw, ib, Wl):
             if has_b and need[ib] and need[iw]:
-                return _linear_dw(g, a, want_db=True, leaf=Wl)
-            return (_linear_dw(g, a, leaf=Wl) if need[iw] else None), (_linear_db(g) if has_b and need[ib] else None)
+                return _linear_dw(g, a, want_db=True, leaf=Wl, prec=prec)
+            return (_linear_dw(g, a, leaf=Wl, prec=prec) if need[iw] else None), (_linear_db(g) if has_b and need[ib] else None)
         dW2, db2 = wgrads(dy, h, ctx.bias[1], 4, 5, W2)
         dW0, db0 = wgrads(du, x, ctx.bias[0], 1, 2, W0)
-        dx = _linear_dx(du, W0) if need[0] else None
+        dx = _linear_dx(du, W0, prec=prec) if need[0] else None
         return dx, dW0, db0, dalpha, dW2, db2, (dy if need[6] else None), None, None
 
 
@@ -682,8 +752,9 @@ class ActLinearFn(torch.autograd.Function):
         h = _act_forward(u, alpha, kind)
         ctx.save_for_backward(u, h, alpha if alpha is not None else u.new_empty(0), W)
         ctx.kind, ctx.has_bias = kind, b is not None
+        prec = ctx.prec = _lin_precision()
         res = None if residual is None else _f(residual)
-        out = _linear_fwd(h, W, b, res, want_stats)
+        out = _linear_fwd(h, W, b, res, want_stats, prec)
         if want_stats:
             ctx.mark_non_differentiable(out[1])
         return out
@@ -692,12 +763,13 @@ class ActLinearFn(torch.autograd.Function):
     def backward(ctx, dy, _dstats=None):
         u, h, alpha, W = ctx.saved_tensors
         dy = _f(dy)
-        du, dalpha = _act_linear_dx(dy, u, h, alpha, W, ctx.kind, ctx.needs_input_grad[1])
+        prec = ctx.prec
+        du, dalpha = _act_linear_dx(dy, u, h, alpha, W, ctx.kind, ctx.needs_input_grad[1], prec)
         dW = db = None
         if ctx.has_bias and ctx.needs_input_grad[3] and ctx.needs_input_grad[2]:
-            dW, db = _linear_dw(dy, h, want_db=True, leaf=W)
+            dW, db = _linear_dw(dy, h, want_db=True, leaf=W, prec=prec)
         elif ctx.needs_input_grad[2]:
-            dW = _linear_dw(dy, h, leaf=W)
+            dW = _linear_dw(dy, h, leaf=W, prec=prec)
         elif ctx.has_bias and ctx.needs_input_grad[3]:
             db = _linear_db(dy)
         dres = dy if ctx.needs_input_grad[4] else None

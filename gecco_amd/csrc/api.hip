@@ -711,10 +711,11 @@ int gecco_linear_ex_f32(const float* A, const float* W, const float* bias, const
     if ((pro_a == nullptr) != (pro_o == nullptr)) return fail(-1, "linear: pro_a/pro_o must both be set");
     if (precision < 0 || precision > 2) return fail(-2, "linear: precision must be 0 (fp32), 1 (split-bf16) or 2 (fp16)");
     if (precision >= 1 && !wsplit) return fail(-1, "linear: precision 1 / 2 need the wsplit scratch");
-    if (!W) {   // wsplit already holds the image of W (gecco_split_bf16_images_f32): kernel launch only
-        if (precision != 1 || !gecco_linear_image_ok(rows, K, Nout, pro_a != nullptr))
-            return fail(-2, "linear: W == NULL (image ready) needs precision 1 and a shape gecco_linear_image_ok accepts");
-        TRY(linear(A, nullptr, bias, pro_a, pro_o, alpha, residual, C, stats, B, rows, K, Nout, act, (hipStream_t)stream, 1, nullptr,
+    if (!W) {   // wsplit already holds the image of W (gecco_split_bf16_images_f32 / gecco_split_f16_images_f32): kernel launch only
+        if (precision == 0 || !(precision == 1 ? gecco_linear_image_ok(rows, K, Nout, pro_a != nullptr)
+                                               : gecco_linear_image_ok_f16(rows, K, Nout, pro_a != nullptr)))
+            return fail(-2, "linear: W == NULL (image ready) needs precision 1 / 2 and a shape gecco_linear_image_ok[_f16] accepts");
+        TRY(linear(A, nullptr, bias, pro_a, pro_o, alpha, residual, C, stats, B, rows, K, Nout, act, (hipStream_t)stream, precision, nullptr,
                    static_cast<const float*>(wsplit)), "linear");
         return 0;
     }
@@ -733,8 +734,8 @@ int gecco_linear_pair_f32(const float* A, const float* W1, const float* bias1, i
     hipStream_t s = (hipStream_t)stream;
     float* ws = static_cast<float*>(wsplit);
     if (!W1) {   // wsplit holds the images of W1 and, from the next 128-column tile boundary, W2
-        if (precision != 1) return fail(-2, "linear_pair: W == NULL (images ready) needs precision 1");
-        int rc = linear_pair(A, nullptr, bias1, Nout1, C1, nullptr, bias2, Nout2, C2, pro_a, pro_o, B, rows, K, s, 1, nullptr, ws);
+        if (precision == 0) return fail(-2, "linear_pair: W == NULL (images ready) needs precision 1 / 2");
+        int rc = linear_pair(A, nullptr, bias1, Nout1, C1, nullptr, bias2, Nout2, C2, pro_a, pro_o, B, rows, K, s, precision, nullptr, ws);
         if (rc == 1) return fail(-2, "linear_pair: images ready, but the shape is outside the fused kernel's reach");
         TRY(rc, "linear_pair");
         return 0;
@@ -754,6 +755,31 @@ int gecco_linear_image_ok(int rows, int K, int Nout, int with_prologue) {
     g.A = &dummy; g.W = &dummy; g.C = &dummy; g.pro_a = with_prologue ? &dummy : nullptr; g.pro_o = g.pro_a;
     g.B = 1; g.rows = rows; g.K = K; g.Nout = Nout; g.lda = K; g.ldw = K; g.ldc = Nout; g.ldr = Nout;
     return gemm_f32_dma_supported(g, 1) ? 1 : 0;
+}
+int gecco_linear_image_ok_f16(int rows, int K, int Nout, int with_prologue) {
+    GemmArgs g{};
+    float dummy = 0.f;
+    g.A = &dummy; g.W = &dummy; g.C = &dummy; g.pro_a = with_prologue ? &dummy : nullptr; g.pro_o = g.pro_a;
+    g.B = 1; g.rows = rows; g.K = K; g.Nout = Nout; g.lda = K; g.ldw = K; g.ldc = Nout; g.ldr = Nout;
+    return gemm_f16_dma_supported(g) ? 1 : 0;
+}
+size_t gecco_split_f16_image_bytes(int Nout, int K) { return split_f16_image_bytes(Nout, K); }
+int gecco_split_f16_images_f32(const GeccoSplitJob* jobs, int n, void* stream) {
+    if (n < 0 || (n > 0 && !jobs)) return fail(-1, "split_f16_images: null argument");
+    SplitJobs sj;
+    sj.n = 0;
+    for (int i = 0; i < n; ++i) {
+        const GeccoSplitJob& j = jobs[i];
+        if (!j.W || !j.img || j.Nout <= 0 || j.K <= 0 || (j.K % 32) || (!j.transposed && (j.ldw & 3)))
+            return fail(-2, "split_f16_images: job %d needs K %% 32 == 0 (and ldw %% 4 == 0 unless transposed)", i);
+        sj.job[sj.n++] = SplitJob{j.W, static_cast<float*>(j.img), j.Nout, j.K, j.ldw, j.transposed ? 4 : 0};
+        if (sj.n == 96) {
+            TRY(split_f16_tiled_multi_launch(sj, (hipStream_t)stream), "split_f16_images");
+            sj.n = 0;
+        }
+    }
+    TRY(split_f16_tiled_multi_launch(sj, (hipStream_t)stream), "split_f16_images");
+    return 0;
 }
 size_t gecco_split_bf16_image_bytes(int Nout, int K) { return split_bf16_image_bytes(Nout, K); }
 int gecco_split_bf16_images_f32(const GeccoSplitJob* jobs, int n, void* stream) {
@@ -779,6 +805,7 @@ int gecco_linear_actbwd_ok(int rows, int K, int Nout, int precision) {
     float dummy = 0.f;
     g.A = &dummy; g.W = &dummy; g.C = &dummy;
     g.B = 1; g.rows = rows; g.K = K; g.Nout = Nout; g.lda = K; g.ldw = K; g.ldc = Nout; g.ldr = Nout;
+    if (precision == 2) return gemm_f16_dma_supported(g) ? 1 : 0;
     return (precision == 0 || precision == 1) && gemm_f32_dma_supported(g, precision) ? 1 : 0;
 }
 size_t gecco_linear_actbwd_tiles(int B, int rows, int Nout) { return (size_t)B * ((rows + 127) / 128) * ((Nout + 127) / 128); }
@@ -788,8 +815,8 @@ int gecco_linear_actbwd_f32(const float* A, const float* W, const float* u, cons
     if (kind < 1 || kind > 4) return fail(-2, "linear_actbwd: kind must be 1 / 2 (GaussianActivation), 3 (ReLU) or 4 (GELU)");
     if ((kind == 1 || kind == 2) && (!alpha || !agrad)) return fail(-1, "linear_actbwd: GaussianActivation needs alpha and the agrad partials");
     if (!gecco_linear_actbwd_ok(rows, K, Nout, precision)) return fail(-2, "linear_actbwd: shape / precision outside the LDS-DMA kernels' reach");
-    if (precision == 1 && !wsplit) return fail(-1, "linear_actbwd: precision 1 needs wsplit");
-    if (!W && precision != 1) return fail(-2, "linear_actbwd: W == NULL (image ready) needs precision 1");
+    if (precision >= 1 && !wsplit) return fail(-1, "linear_actbwd: precision 1 / 2 need wsplit");
+    if (!W && precision == 0) return fail(-2, "linear_actbwd: W == NULL (image ready) needs precision 1 / 2");
     TRY(linear(A, W, nullptr, nullptr, nullptr, alpha, residual, C, nullptr, B, rows, K, Nout, 0, (hipStream_t)stream, precision,
                W ? static_cast<float*>(wsplit) : nullptr, W ? nullptr : static_cast<const float*>(wsplit), 0, 0, 0, 0, u, kind,
                (kind == 1 || kind == 2) ? agrad : nullptr), "linear_actbwd");
@@ -810,8 +837,8 @@ int gecco_linear_act_keep_pro_f32(const float* A, const float* W, const float* b
     if (act < 1 || act > 4) return fail(-2, "linear_act_keep: act must be 1 / 2 (GaussianActivation), 3 (ReLU) or 4 (GELU)");
     if ((act == 1 || act == 2) && !alpha) return fail(-1, "linear_act_keep: GaussianActivation needs alpha");
     if (!gecco_linear_actbwd_ok(rows, K, Nout, precision)) return fail(-2, "linear_act_keep: shape / precision outside the LDS-DMA kernels' reach");
-    if (precision == 1 && !wsplit) return fail(-1, "linear_act_keep: precision 1 needs wsplit");
-    if (!W && precision != 1) return fail(-2, "linear_act_keep: W == NULL (image ready) needs precision 1");
+    if (precision >= 1 && !wsplit) return fail(-1, "linear_act_keep: precision 1 / 2 need wsplit");
+    if (!W && precision == 0) return fail(-2, "linear_act_keep: W == NULL (image ready) needs precision 1 / 2");
     TRY(linear(A, W, bias, pro_a, pro_o, alpha, nullptr, C, nullptr, B, rows, K, Nout, act, (hipStream_t)stream, precision,
                W ? static_cast<float*>(wsplit) : nullptr, W ? nullptr : static_cast<const float*>(wsplit), 0, 0, 0, 0, nullptr, 0,
                nullptr, pre_out), "linear_act_keep");
@@ -1053,6 +1080,19 @@ int gecco_gemm_tn_x3_pro_f32(const float* A, const float* Bm, const float* pro_a
     g.sA = (size_t)R * N; g.sB = (size_t)R * K; g.group = group; g.colsum = colsum_parts;
     if (!gemm_tn_x3_supported(g)) return fail(-2, "gemm_tn_x3: needs R %% 32 == 0, N %% 4 == 0, K %% 4 == 0, group > 0");
     TRY(gemm_tn_x3_launch(g, (hipStream_t)stream), "gemm_tn_x3");
+    return 0;
+}
+
+int gecco_gemm_tn_f16_f32(const float* A, const float* Bm, const float* pro_a, const float* pro_o, float* parts,
+                          float* colsum_parts, int Z, int R, int N, int K, int group, void* stream) {
+    if (!A || !Bm || !parts) return fail(-1, "gemm_tn_f16: null argument");
+    if ((pro_a == nullptr) != (pro_o == nullptr)) return fail(-1, "gemm_tn_f16: pro_a / pro_o must both be set");
+    TnArgs g{};
+    g.pro_a = pro_a; g.pro_o = pro_o; g.f16 = 1;
+    g.A = A; g.Bm = Bm; g.C = parts; g.Z = Z; g.R = R; g.N = N; g.K = K; g.lda = N; g.ldb = K;
+    g.sA = (size_t)R * N; g.sB = (size_t)R * K; g.group = group; g.colsum = colsum_parts;
+    if (!gemm_tn_x3_supported(g)) return fail(-2, "gemm_tn_f16: needs R %% 32 == 0, N %% 4 == 0, K %% 4 == 0, group > 0");
+    TRY(gemm_tn_x3_launch(g, (hipStream_t)stream), "gemm_tn_f16");
     return 0;
 }
 
@@ -1546,7 +1586,12 @@ int gecco_lower_bwd_f32(const float* feat, const float* dF, const float* W, floa
 
 // ---------------------------------------------------------------------------- optimizer
 int gecco_adam_ema_step_f32(const GeccoAdamEma* a, void* stream) {
+    return gecco_adam_ema_step_amp_f32(a, nullptr, nullptr, nullptr, stream);
+}
+
+int gecco_adam_ema_step_amp_f32(const GeccoAdamEma* a, const float* amp_scale, const float* found_inf, int* skipped, void* stream) {
     if (!a || !a->p || !a->g || !a->m || !a->v) return fail(-1, "adam_ema: null argument");
+    if ((amp_scale || skipped) && !found_inf) return fail(-1, "adam_ema: amp_scale / skipped come with found_inf (the GradScaler protocol)");
     if (a->do_ema && !a->ema) return fail(-1, "adam_ema: do_ema needs the ema buffer");
     if (a->n % 4) return fail(-2, "adam_ema: n must be a multiple of 4 (pad the flat buffers)");
     if (a->step < 1) return fail(-2, "adam_ema: step is 1-based");
@@ -1562,6 +1607,8 @@ int gecco_adam_ema_step_f32(const GeccoAdamEma* a, void* stream) {
     k.step_size = (float)(a->lr / bc1);
     k.bc2_sqrt = (float)sqrt(bc2);
     k.grad_scale = a->grad_scale; k.ema_decay = (float)a->ema_decay; k.ema_w = (float)(1.0 - a->ema_decay); k.do_ema = a->do_ema;
+    k.amp_scale = amp_scale; k.found_inf = found_inf; k.skipped = skipped;
+    k.lr = a->lr; k.beta1 = a->beta1; k.beta2d = a->beta2; k.step = a->step;
     TRY(adam_ema_launch(k, (hipStream_t)stream), "adam_ema");
     return 0;
 }

@@ -77,7 +77,9 @@ __device__ unsigned long long g_stamps[16384 * 8];
 // A16: the A operand is already fp16 in memory (an intermediate a previous kernel stored that way): its tile is laid
 // out like the W tile (64-byte rows, 16 rows per DMA piece), fragments are read as they are, 16 KiB per stage and
 // three blocks per CU.  C16: the output is stored as fp16 (dma::epilogue).
-template <int DNS, bool HAS_PRO, int BM, bool A16, bool C16>
+// ACTBWD: the training path's epilogue forms (GemmArgs::mul_u / pre_out, dma::epilogue_t) — their own instantiations, as in
+// gemm_f32_dma.hip; the inference kernels are the code they were.
+template <int DNS, bool HAS_PRO, int BM, bool A16, bool C16, bool ACTBWD = false>
 __global__ __launch_bounds__(DNT, A16 ? 3 : 2) void gemm_f16_kernel(GemmArgs g) {
     static_assert(DNS == 2 || DNS == 3, "ring of 2 or 3 stages");
     static_assert(!(A16 && HAS_PRO), "the AdaGN prologue needs the fp32 operand");
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(DNT, A16 ? 3 : 2) void gemm_f16_kernel(GemmArgs g) 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // ring is dead: the epilogue reuses it
     STAMP(3);
-    dma::epilogue<TMW, TNW, WMN, C16>(g, T, acc, smem, wave, lane, wm, wn);
+    dma::epilogue_t<TMW, TNW, WMN, C16, ACTBWD>(g, T, acc, smem, wave, lane, wm, wn);
     STAMP(4);
 }
 
@@ -246,7 +248,8 @@ __global__ __launch_bounds__(DNT, A16 ? 3 : 2) void gemm_f16_kernel(GemmArgs g) 
 // at float offset (ct * K/32 + kt) * 2048 holds row rb at rb * 16 floats (64 B = 32 fp16); its 16-byte chunk
 // s ^ ((rb >> 2) & 3) holds k = 16 (s >> 1) + 8 (s & 1) .. +7 (lane half s >> 1, MFMA s & 1 of the step).  Rows past
 // Nout repeat the last row (masked in the GEMM epilogue).  One thread per (block, row, chunk).
-// lo != 0: the image of the LOW part, fp16(W - float(fp16(W))) — the second term of a two-term fp16 weight (mixed mode)
+// lo == 1: the image of the LOW part, fp16(W - float(fp16(W))) — the second term of a two-term fp16 weight (mixed mode);
+// lo == 4: W is (K, ldw) and the image is of W^T (the training path's dX products)
 __device__ __forceinline__ void f16_image_item(const float* __restrict__ W, float* __restrict__ img, int Nout, int K,
                                                int ldw, size_t i, int lo = 0) {
     const int nk = K / FBK;
@@ -254,10 +257,21 @@ __device__ __forceinline__ void f16_image_item(const float* __restrict__ W, floa
     const size_t blk = i >> 9;
     const int kt = (int)(blk % nk), ct = (int)(blk / nk);
     const int s = chp ^ ((rb >> 2) & 3);
-    const float* src = W + (size_t)min(ct * DBN + rb, Nout - 1) * ldw + kt * FBK + 16 * (s >> 1) + 8 * (s & 1);
-    f32x4 w0 = *reinterpret_cast<const f32x4*>(src), w1 = *reinterpret_cast<const f32x4*>(src + 4);
+    f32x4 w0, w1;
+    if (lo == 4) {   // the image of W^T from W (K, ldw) itself (the dX product of a linear is linear(dY, W^T)): eight strided reads
+        const float* src = W + (size_t)(kt * FBK + 16 * (s >> 1) + 8 * (s & 1)) * ldw + min(ct * DBN + rb, Nout - 1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            w0[e] = src[(size_t)e * ldw];
+            w1[e] = src[(size_t)(4 + e) * ldw];
+        }
+    } else {
+        const float* src = W + (size_t)min(ct * DBN + rb, Nout - 1) * ldw + kt * FBK + 16 * (s >> 1) + 8 * (s & 1);
+        w0 = *reinterpret_cast<const f32x4*>(src);
+        w1 = *reinterpret_cast<const f32x4*>(src + 4);
+    }
     f16x8 v = cvt8(w0, w1);
-    if (lo) {
+    if (lo == 1) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             w0[e] -= (float)v[e];
@@ -348,6 +362,22 @@ int f16_launch_t(const GemmArgs& g, hipStream_t st) {
         attr = lds;
     }
     const dim3 grid(g.B * tilesM * tilesN);
+    if (g.mul_u || g.pre_out) {   // the training path's epilogue forms: their own kernel instantiations (fp32 tensors only)
+        if (A16 || C16 || (g.mul_u && g.pro_a) || g.c_img) return -9;
+        if constexpr (!A16 && !C16) {
+            static size_t attr2 = 0;
+            if (lds > attr2) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<DNS, true, BM, false, false, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<DNS, false, BM, false, false, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr2 = lds;
+            }
+            if (g.pro_a) hipLaunchKernelGGL((gemm_f16_kernel<DNS, true, BM, false, false, true>), grid, dim3(DNT), lds, st, g);
+            else hipLaunchKernelGGL((gemm_f16_kernel<DNS, false, BM, false, false, true>), grid, dim3(DNT), lds, st, g);
+        }
+        return (int)hipGetLastError();
+    }
     if (g.pro_a) {
         if (A16) return -9;
         hipLaunchKernelGGL((gemm_f16_kernel<DNS, !A16, BM, A16, C16>), grid, dim3(DNT), lds, st, g);

@@ -21,6 +21,8 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -49,10 +51,21 @@ __device__ __forceinline__ int tn_off(int row, int col) {
 
 constexpr int TN_PLANE = 32 * 128;   // u16 per plane
 
+// F16 (the reference's own trainer arithmetic, torch.autocast(float16): diffusion.py:213-222 under Lightning's "16-mixed"): both
+// operands rounded to fp16 (round to nearest even), ONE v_mfma_f32_32x32x16_f16 per product, fp32 accumulation and fp32 output —
+// one plane per operand instead of hi | lo.  The caller's GradScaler keeps dY inside fp16's range, as it does for the reference.
+__device__ __forceinline__ u32x2 tn_cvt4(const f32x4& x) {
+    f16x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (_Float16)x[e];
+    return __builtin_bit_cast(u32x2, v);
+}
+
 // PRO: the AdaGN apply on the B operand (TnArgs::pro_a) — its own instantiation, so the plain weight gradients run the code
 // they ran before it existed
-template <bool PRO>
+template <bool PRO, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(TnArgs g) {
+    constexpr int NPL = F16 ? 2 : 4;   // planes per stage: A | B (fp16) or A hi | A lo | B hi | B lo
     extern __shared__ __attribute__((aligned(16))) float smem[];
     u16* lds = reinterpret_cast<u16*>(smem);   // [2 stages][A hi | A lo | B hi | B lo]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -95,12 +108,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(TnArgs g) {
     const bool want_cs = g.colsum != nullptr && k0 == 0;
     f32x4 cs = {0.f, 0.f, 0.f, 0.f};
     auto store = [&](int stage) {
-        u16* st = lds + stage * 4 * TN_PLANE;
+        u16* st = lds + stage * NPL * TN_PLANE;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int f = tid + i * 256, row = f >> 5, c4 = f & 31, o = tn_off(row, c4 * 4);
             u32x2 hi, lo;
             if (want_cs) cs += ra[i];
+            if (F16) {
+                *reinterpret_cast<u32x2*>(st + o) = tn_cvt4(ra[i]);
+                *reinterpret_cast<u32x2*>(st + TN_PLANE + o) = tn_cvt4(PRO ? (bok ? rb[i] * pa4 + po4 : rb[i]) : rb[i]);
+                continue;
+            }
             tn_split4(ra[i], hi, lo);
             *reinterpret_cast<u32x2*>(st + o) = hi;
             *reinterpret_cast<u32x2*>(st + TN_PLANE + o) = lo;
@@ -134,9 +152,22 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(TnArgs g) {
         store(stage);
         __syncthreads();   // stage complete; every wave is past its reads of the other stage's previous contents
         if (s + 1 < nsteps) load(s + 1);
-        const u16* st = lds + stage * 4 * TN_PLANE;
+        const u16* st = lds + stage * NPL * TN_PLANE;
 #pragma unroll
         for (int sg = 0; sg < 2; ++sg) {
+            if (F16) {
+                f16x8 a[2], bb[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    a[i] = __builtin_bit_cast(f16x8, frag(st, sg, wn * 2 + i));
+                    bb[i] = __builtin_bit_cast(f16x8, frag(st + TN_PLANE, sg, wk * 2 + i));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], bb[j], acc[i][j], 0, 0, 0);
+                continue;
+            }
             bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -189,9 +220,13 @@ bool gemm_tn_x3_supported(const TnArgs& g) {
 int gemm_tn_x3_launch(const TnArgs& g, hipStream_t st) {
     if (!gemm_tn_x3_supported(g)) return -9;
     const int G = (g.Z + g.group - 1) / g.group;
-    const size_t lds = (size_t)2 * 4 * TN_PLANE * 2;
+    const size_t lds = (size_t)2 * (g.f16 ? 2 : 4) * TN_PLANE * 2;
     static bool attr = false;
     if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_x3_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_x3_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -206,7 +241,10 @@ int gemm_tn_x3_launch(const TnArgs& g, hipStream_t st) {
     TnArgs ga = g;
     ga.xcd = xcd;
     const dim3 grid(((g.N + 127) / 128) * ((g.K + 127) / 128), G);
-    if (g.pro_a) hipLaunchKernelGGL(gemm_tn_x3_kernel<true>, grid, dim3(256), lds, st, ga);
+    if (g.f16) {
+        if (g.pro_a) hipLaunchKernelGGL((gemm_tn_x3_kernel<true, true>), grid, dim3(256), lds, st, ga);
+        else hipLaunchKernelGGL((gemm_tn_x3_kernel<false, true>), grid, dim3(256), lds, st, ga);
+    } else if (g.pro_a) hipLaunchKernelGGL(gemm_tn_x3_kernel<true>, grid, dim3(256), lds, st, ga);
     else hipLaunchKernelGGL(gemm_tn_x3_kernel<false>, grid, dim3(256), lds, st, ga);
     return (int)hipGetLastError();
 }

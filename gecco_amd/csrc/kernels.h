@@ -175,6 +175,7 @@ struct TnArgs {
     // whose input was AdaGN(x), from x itself: the normalised tensor is never materialised)
     const float* pro_a;
     const float* pro_o;
+    int f16;           // 1: both operands rounded to fp16, one MFMA per product (the reference's autocast(float16) trainer arithmetic)
 };
 // gemm_x3_areg.hip: split-bf16 GEMM whose A operand is a tiled split image loaded global -> registers (GemmArgs::a_img)
 bool gemm_x3_areg_supported(const GemmArgs& g);
@@ -347,6 +348,12 @@ struct AdamEmaArgs {
     float bc2_sqrt;    // sqrt(1 - beta2^step)
     float grad_scale, ema_decay, ema_w;   // ema_w = 1 - decay
     int do_ema;
+    // torch.amp.GradScaler protocol (an optimizer with _step_supports_amp_scaling): all NULL / 0 outside of it.
+    const float* amp_scale;   // device scalar: the loss scale the gradients carry (g is divided by it while it is read)
+    const float* found_inf;   // device scalar: != 0 -> the step is SKIPPED (nothing is written; *skipped += 1)
+    int* skipped;             // device counter of skipped steps: the bias corrections use step - *skipped
+    double lr, beta1, beta2d; // for the on-device bias corrections once *skipped > 0
+    int step;
 };
 int adam_ema_launch(const AdamEmaArgs& a, hipStream_t st);
 int ema_update_launch(const float* p, float* ema, size_t n, double decay, hipStream_t st);

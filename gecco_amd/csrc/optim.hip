@@ -29,16 +29,30 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(AdamEmaArgs a) {
     f32x4* __restrict__ v4 = reinterpret_cast<f32x4*>(a.v);
     f32x4* __restrict__ e4 = reinterpret_cast<f32x4*>(a.ema);
     const float w1 = a.w1, w2 = a.w2, we = a.ema_w;
+    float gscale = a.grad_scale, step_size = a.step_size, bc2_sqrt = a.bc2_sqrt;
+    if (a.found_inf) {   // (launch-uniform) GradScaler protocol: decided on the device, the host never waits for the gradients
+        if (*a.found_inf != 0.f) {   // inf / nan in the gradients: torch skips optimizer.step() (and with it the EMA update)
+            if (a.skipped && blockIdx.x == 0 && threadIdx.x == 0) *a.skipped += 1;
+            return;
+        }
+        if (a.amp_scale) gscale = gscale / *a.amp_scale;   // scales are powers of two: exact
+        const int sk = a.skipped ? *a.skipped : 0;
+        if (sk > 0) {   // Adam's step count did not advance on the skipped steps: bias corrections of the steps actually taken
+            const double st = (double)(a.step - sk);
+            step_size = (float)(a.lr / (1.0 - pow(a.beta1, st)));
+            bc2_sqrt = (float)sqrt(1.0 - pow(a.beta2d, st));
+        }
+    }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         f32x4 p = p4[i], g = GECCO_NT_LOAD(g4 + i), m = m4[i], v = v4[i];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float ge = g[e] * a.grad_scale;
+            float ge = g[e] * gscale;
             if (a.weight_decay != 0.f) ge = ge + a.weight_decay * p[e];
             m[e] = __builtin_fmaf(w1, ge - m[e], m[e]);   // lerp_ (ATen: fma(weight, end - start, start))
             v[e] = v[e] * a.beta2 + w2 * (ge * ge);
-            const float denom = sqrtf(v[e]) / a.bc2_sqrt + a.eps;
-            p[e] = p[e] - a.step_size * (m[e] / denom);
+            const float denom = sqrtf(v[e]) / bc2_sqrt + a.eps;
+            p[e] = p[e] - step_size * (m[e] / denom);
         }
         p4[i] = p;
         m4[i] = m;

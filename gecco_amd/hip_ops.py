@@ -100,7 +100,7 @@ def linear(A: Tensor, W: Tensor, bias: Tensor | None = None, pro: tuple[Tensor, 
            w_image: Tensor | None = None, w_shape: tuple[int, int] | None = None):
     """C = residual + act((A*pro_a + pro_o) @ W^T + bias) on (B, rows, K) x (Nout, K).
     act: GaussianActivation when act_alpha is given (normalized or raw), "relu", or none.
-    w_image (precision "bf16x3"): the READY tiled image of W (autograd.WeightImages) — W may then be None, w_shape = (Nout, K)."""
+    w_image (precision "bf16x3" / "fp16"): the READY tiled image of W (autograd.WeightImages) — W may then be None, w_shape = (Nout, K)."""
     lib = _lib.load()
     B, rows, K = A.shape
     Nout = W.shape[0] if W is not None else w_shape[0]
@@ -111,7 +111,7 @@ def linear(A: Tensor, W: Tensor, bias: Tensor | None = None, pro: tuple[Tensor, 
         stats = torch.empty(B, lib.gecco_linear_row_tiles(rows), 2, Nout, device=A.device, dtype=torch.float32)
     act = act_code(act_alpha, normalized, act)
     if w_image is not None:
-        assert precision == "bf16x3"
+        assert precision in ("bf16x3", "fp16")
         wsplit, W = w_image, None
     else:
         wsplit = _ws((Nout + 127) // 128 * 128 * K * 4, A.device) if precision != "fp32" else None
@@ -451,14 +451,14 @@ def linear_pair(A: Tensor, W1: Tensor, b1: Tensor | None, W2: Tensor, b2: Tensor
                 pro: tuple[Tensor, Tensor] | None = None, out: tuple[Tensor, Tensor] | None = None,
                 precision: str = "fp32", w_image: Tensor | None = None) -> tuple[Tensor, Tensor]:
     """(A' @ W1^T + b1, A' @ W2^T + b2) with A' = A*pro_a + pro_o, one launch (A read once).
-    w_image (precision "bf16x3"): the READY images of W1 | W2 (autograd.WeightImages): launch only."""
+    w_image (precision "bf16x3" / "fp16"): the READY images of W1 | W2 (autograd.WeightImages): launch only."""
     lib = _lib.load()
     B, rows, K = A.shape
     n1, n2 = W1.shape[0], W2.shape[0]
     c1, c2 = out if out is not None else (torch.empty(B, rows, n1, device=A.device, dtype=torch.float32),
                                           torch.empty(B, rows, n2, device=A.device, dtype=torch.float32))
     if w_image is not None:
-        assert precision == "bf16x3"
+        assert precision in ("bf16x3", "fp16")
         wsplit, W1, W2 = w_image, None, None
     else:
         wsplit = _ws(((n1 + 127) // 128 + (n2 + 127) // 128) * 128 * K * 4, A.device) if precision != "fp32" else None

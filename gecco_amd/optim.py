@@ -55,7 +55,9 @@ class FusedAdamEMA(torch.optim.Optimizer):
         self._spans: list[tuple[Tensor, int, int]] = []   # (param, offset, numel) in param-group order
         self._span_of: dict[int, tuple[int, int]] | None = None
         self._adam_step = 0
-        self.grad_scale = 1.0                     # set by a summing gradient all-reduce to 1 / world_size
+        self._grad_mult = 1.0                     # `grad_scale`: set by a summing gradient all-reduce to 1 / world_size
+        self._amp_scale: Tensor | None = None     # torch.amp.GradScaler's scale tensor while scaler.step(self) runs (see grad_scale)
+        self._amp_skipped: Tensor | None = None   # device counter of the steps a GradScaler's found_inf skipped
         # A parameter whose .grad is None at step() (zero_grad(set_to_none=True) and no gradient arrived): torch.optim.Adam skips it;
         # the one-launch update cannot.  "raise" (default) refuses the step, "zero" updates it with a zero gradient (moments decay,
         # the step count advances).  With zero_grad() (views of the flat buffer) a missing gradient is indistinguishable from zeros.
@@ -64,6 +66,37 @@ class FusedAdamEMA(torch.optim.Optimizer):
         self.missing_grad = missing_grad
         self._missing_grad = 0
         self._missing_ids: set[int] = set()   # id(p) of the trainable parameters without a gradient this step
+
+    # ------------------------------------------------------------------------------------------ GradScaler protocol
+    # torch.amp.GradScaler.step(optimizer) (the reference's `precision="16-mixed"` trainer: example_configs/*.py) has two paths.
+    # For a plain optimizer it unscales every gradient and then READS found_inf BACK ON THE HOST (`.item()`) to decide whether to
+    # call step(): the host waits for the whole backward pass every step, and the ~15 ms of Python / launch work of the next step no
+    # longer overlap the device.  An optimizer that declares `_step_supports_amp_scaling` receives the scale and found_inf
+    # tensors instead (`optimizer.grad_scale = scale; optimizer.found_inf = found_inf; optimizer.step(); del ...`) and decides on
+    # the device (gecco_adam_ema_step_amp_f32): a skipped step writes nothing — parameters, moments, EMA — exactly like the
+    # skipped optimizer.step() of the host path, and Adam's step count does not advance (counted on the device: `_amp_skipped`).
+    # `grad_scale` therefore has two faces: a float is this optimizer's own multiplier (1 / world size), a tensor is the scaler's.
+    _step_supports_amp_scaling = True
+
+    @property
+    def grad_scale(self):
+        return self._grad_mult
+
+    @grad_scale.setter
+    def grad_scale(self, value) -> None:
+        if isinstance(value, Tensor) or value is None:   # GradScaler: its scale (None: the gradients are already unscaled)
+            self._amp_scale = value
+        else:
+            self._grad_mult = float(value)
+
+    @grad_scale.deleter
+    def grad_scale(self) -> None:
+        self._amp_scale = None
+
+    @property
+    def adam_steps_taken(self) -> int:
+        """Adam's step count: update launches minus the steps a GradScaler skipped (reads the device counter: synchronises)."""
+        return self._adam_step - (int(self._amp_skipped.item()) if self._amp_skipped is not None else 0)
 
     # ------------------------------------------------------------------------------------------ flat storage
     def all_parameters(self) -> list[Tensor]:
@@ -236,8 +269,19 @@ class FusedAdamEMA(torch.optim.Optimizer):
                               float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
                               float(self.decay if self.decay is not None else 0.0), float(self.grad_scale), adam_step,
                               int(do_ema))
-        _lib.check(_lib.load().gecco_adam_ema_step_f32(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
-                   "gecco_adam_ema_step_f32")
+        found_inf = self.__dict__.get("found_inf")   # set (and deleted again) by GradScaler.step around step()
+        if found_inf is None:
+            _lib.check(_lib.load().gecco_adam_ema_step_f32(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                       "gecco_adam_ema_step_f32")
+            return
+        if self._amp_skipped is None:
+            self._amp_skipped = torch.zeros(1, dtype=torch.int32, device=f["p"].device)
+        found_inf = found_inf.to(device=f["p"].device, dtype=torch.float32)
+        scale = self._amp_scale.to(device=f["p"].device, dtype=torch.float32) if self._amp_scale is not None else None
+        _lib.check(_lib.load().gecco_adam_ema_step_amp_f32(C.byref(a), C.c_void_p(scale.data_ptr()) if scale is not None else None,
+                                                           C.c_void_p(found_inf.data_ptr()), C.c_void_p(self._amp_skipped.data_ptr()),
+                                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                   "gecco_adam_ema_step_amp_f32")
 
     # ------------------------------------------------------------------------------------------ EMA weight swap
     def join(self) -> None:   # EMAOptimizer API (its update runs on a side stream / thread; ours is in-stream)
@@ -270,11 +314,12 @@ class FusedAdamEMA(torch.optim.Optimizer):
         """What torch.optim.Adam.state_dict() returns for the same parameters (packed ids, per-parameter state)."""
         self._ensure()
         state, idx, groups = {}, 0, []
+        steps_taken = self.adam_steps_taken
         for g in self.param_groups:
             ids = []
             for _ in g["params"]:
                 if self._adam_step > 0:
-                    state[idx] = {"step": torch.tensor(float(self._adam_step)),
+                    state[idx] = {"step": torch.tensor(float(steps_taken)),
                                   "exp_avg": self.view_of("m", idx).clone(), "exp_avg_sq": self.view_of("v", idx).clone()}
                 ids.append(idx)
                 idx += 1
@@ -316,6 +361,7 @@ class FusedAdamEMA(torch.optim.Optimizer):
         if len(steps) > 1:
             raise NotImplementedError("FusedAdamEMA: parameters with different Adam step counts")
         self._adam_step = steps.pop() if steps else 0
+        self._amp_skipped = None
         if "opt" in state_dict:
             if self._flat["ema"] is None:
                 self.decay = state_dict["decay"]

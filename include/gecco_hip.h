@@ -140,6 +140,12 @@ typedef struct GeccoSplitJob { const float* W; void* img; int Nout, K, ldw, tran
 int gecco_split_bf16_images_f32(const GeccoSplitJob* jobs, int n, void* stream);
 size_t gecco_split_bf16_image_bytes(int Nout, int K);
 int gecco_linear_image_ok(int rows, int K, int Nout, int with_prologue);
+/* The same for precision 2 — fp16 operands, fp32 accumulation: the arithmetic of the reference's own trainer setting
+ * (example_configs: precision="16-mixed" = torch.autocast(float16) around training_step, diffusion.py:213-222), which the
+ * training path selects when it runs under that autocast.  Images are 2 bytes per weight element; K % 32 == 0. */
+int gecco_split_f16_images_f32(const GeccoSplitJob* jobs, int n, void* stream);
+size_t gecco_split_f16_image_bytes(int Nout, int K);
+int gecco_linear_image_ok_f16(int rows, int K, int Nout, int with_prologue);
 /* The dX product of the linear that FOLLOWS an activation, with the activation's backward as its epilogue (training:
  * autograd of models/mlp.py's Linear -> act -> Linear, and of a CNBlock's Linear -> GELU -> Linear):
  *   C = residual + (A W^T) * act'(u),   A = dY (B, rows, K), W (Nout, K) = W2^T (or NULL: its ready image in wsplit),
@@ -495,6 +501,11 @@ int gecco_gemm_tn_x3_bias_f32(const float* A, const float* Bm, float* parts, flo
  * both NULL): the weight gradient of a linear whose input was AdaGN(x), formed from x — AdaGN(x) is never materialised */
 int gecco_gemm_tn_x3_pro_f32(const float* A, const float* Bm, const float* pro_a, const float* pro_o, float* parts,
                              float* colsum_parts, int Z, int R, int N, int K, int group, void* stream);
+/* the same product with both operands rounded to fp16 and ONE MFMA per product (fp32 accumulation, fp32 partials): the weight
+ * gradient under the reference's autocast(float16) trainer setting (torch computes it as an fp16 matmul there); pro_a / pro_o
+ * and colsum_parts may be NULL.  The caller's GradScaler keeps dY inside fp16's range, as it does for the reference. */
+int gecco_gemm_tn_f16_f32(const float* A, const float* Bm, const float* pro_a, const float* pro_o, float* parts,
+                          float* colsum_parts, int Z, int R, int N, int K, int group, void* stream);
 int gecco_reduce_batch_f32(const float* parts, float* out, size_t n, int Z, size_t stride, int accumulate, void* stream);
 
 /* Row softmax of the materialised attention scores: P = softmax(scale*S) over the last dim n; and its backward
@@ -548,6 +559,13 @@ typedef struct GeccoAdamEma {
     int do_ema;
 } GeccoAdamEma;
 int gecco_adam_ema_step_f32(const GeccoAdamEma* a, void* stream);
+/* The same step inside torch.amp.GradScaler's protocol for optimizers that handle the scale themselves
+ * (`_step_supports_amp_scaling`, torch/amp/grad_scaler.py: the scaler hands over its scale and found_inf tensors instead of
+ * unscaling and reading found_inf back on the host — the reference's `precision="16-mixed"` trainer, example_configs): every
+ * gradient is divided by *amp_scale while it is read (NULL: already unscaled), and when *found_inf != 0 NOTHING is written
+ * (torch skips optimizer.step(), and the EMA update inside it, then) and *skipped is incremented; the bias corrections use
+ * step - *skipped, Adam's own step count.  All three are device scalars; the host never waits for the gradients. */
+int gecco_adam_ema_step_amp_f32(const GeccoAdamEma* a, const float* amp_scale, const float* found_inf, int* skipped, void* stream);
 /* ema = ema * decay + (1 - decay) * p alone (ema_update, ema.py:187-194), for optimizers other than the fused Adam. */
 int gecco_ema_update_f32(const float* p, float* ema, size_t n, double decay, void* stream);
 

@@ -1,0 +1,261 @@
+"""The training path under the reference's own trainer setting: Lightning's precision="16-mixed" of both shipped configs
+(example_configs/shapenet_airplane_unconditional.py:74, taskonomy_conditional.py:102) = `training_step` (diffusion.py:213-222)
+under torch.autocast(float16) with a GradScaler around the optimizer.
+
+Under that autocast the reference's nn.Linear / in_proj products run with fp16 operands; so do the HIP path's linears then
+(gecco_amd/autograd.py `_lin_precision`): forward, dX and dW products with fp16 operands, ONE MFMA per product, fp32 accumulation,
+fp32 tensors between the kernels (the reference rounds those to fp16 too).  The bar is the reference's own deviation in that
+setting — its algorithm differentiated under torch.autocast(float16) on the host cores is 2.1e-3 (all parameters) / 2.8e-3 (worst
+weight matrix) from its fp32 gradients (tools/experiments/autocast_grad_deviation.py, profiles/r04h_autocast_grad_deviation.txt).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cases, cpu_ref
+from oracle import weights as W
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _build():
+    from gecco_amd import _lib
+    _lib.load()
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+
+
+def _leaf(t, dev="cuda"):
+    return t.clone().to(dev).requires_grad_(True)
+
+
+def _rel(got, ref):
+    return float((got.double().cpu() - ref.double().cpu()).norm() / ref.double().cpu().norm().clamp_min(1e-30))
+
+
+def _r16(t):
+    return t.half().double()
+
+
+@pytest.mark.parametrize("N,K", [(256, 384), (768, 384), (96, 384), (384, 96), (96, 48), (384, 672), (4, 132)])
+def test_fp16_weight_gradient_kernel(N, K):
+    """gecco_gemm_tn_f16_f32: dW = dY^T X with both operands rounded to fp16 and one MFMA per product — against fp64 on the
+    fp16-rounded operands (only the fp32 accumulation order separates them) and against fp64 on the operands themselves (the fp16
+    rounding: ~3e-4); grouped partials; the AdaGN apply on X and the column sums of dY (the bias gradient) out of the same pass."""
+    from gecco_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(7)
+    Z, R = 5, 256
+    dy = _t(rs.randn(Z, R, N) * np.exp(rs.uniform(-3, 2, size=(Z, R, 1))))
+    x = _t(rs.randn(Z, R, K))
+    pa, po = _t(1.0 + 0.3 * rs.randn(Z, K)), _t(0.2 * rs.randn(Z, K))
+    dyc, xc, pac, poc = dy.cuda(), x.cuda(), pa.cuda(), po.cuda()
+    for pro in (False, True):
+        xe = x * pa[:, None, :] + po[:, None, :] if pro else x
+        ref16 = torch.einsum("zrn,zrk->nk", _r16(dy), _r16(xe))
+        ref = torch.einsum("zrn,zrk->nk", dy.double(), xe.double())
+        for group in (1, 2, 5):
+            G = -(-Z // group)
+            parts = torch.full((G, N, K), float("nan"), device="cuda")
+            cs = torch.full((G, N), float("nan"), device="cuda")
+            _lib.check(lib.gecco_gemm_tn_f16_f32(C.c_void_p(dyc.data_ptr()), C.c_void_p(xc.data_ptr()),
+                                                 C.c_void_p(pac.data_ptr()) if pro else None, C.c_void_p(poc.data_ptr()) if pro else None,
+                                                 C.c_void_p(parts.data_ptr()), C.c_void_p(cs.data_ptr()), Z, R, N, K, group, None),
+                       "gemm_tn_f16")
+            got = parts.double().sum(0).cpu()
+            # (with the AdaGN apply the kernel's a x + o is one fma, the host's a mul and an add: a few values round to the other fp16)
+            assert _rel(got, ref16) <= (2e-5 if pro else 2e-6), (pro, group, _rel(got, ref16))
+            assert _rel(got, ref) <= 1e-3, (pro, group, _rel(got, ref))
+            assert _rel(cs.double().sum(0), dy.double().sum((0, 1))) <= 1e-6   # column sums are fp32 sums of the fp32 values
+
+
+def test_transposed_fp16_weight_image_equals_the_image_of_the_transposed_copy():
+    """gecco_split_f16_images_f32: a transposed job writes, from W itself, the bytes the plain job writes from W.t().contiguous()
+    (what the dX product of a linear streams); a ready image gives the same bits as the per-call image."""
+    from gecco_amd import _lib, hip_ops
+    lib = _lib.load()
+    rs = np.random.RandomState(4)
+    big = _t(rs.randn(3 * 384, 384)).cuda()
+    for Wm in (_t(rs.randn(768, 384)).cuda(), _t(rs.randn(96, 384)).cuda(), _t(rs.randn(384, 96)).cuda(), _t(rs.randn(672, 64)).cuda(), big[384:]):
+        K_img, N_img = Wm.shape                                     # image of W^T: (N_img, K_img)
+        nb = lib.gecco_split_f16_image_bytes(N_img, K_img)
+        a = torch.full((nb,), 7, dtype=torch.uint8, device="cuda")
+        b = torch.full((nb,), 9, dtype=torch.uint8, device="cuda")
+        Wt = Wm.t().contiguous()
+        jobs = (_lib.GeccoSplitJob * 2)(_lib.GeccoSplitJob(Wm.data_ptr(), a.data_ptr(), N_img, K_img, Wm.stride(0), 1),
+                                        _lib.GeccoSplitJob(Wt.data_ptr(), b.data_ptr(), N_img, K_img, Wt.stride(0), 0))
+        _lib.check(lib.gecco_split_f16_images_f32(jobs, 2, None), "split images")
+        assert torch.equal(a, b), tuple(Wm.shape)
+        dy = _t(rs.randn(2, 256, K_img)).cuda()
+        if lib.gecco_linear_image_ok_f16(256, K_img, N_img, 0):
+            y_img = hip_ops.linear(dy, None, precision="fp16", w_image=a, w_shape=(N_img, K_img))
+            y_cal = hip_ops.linear(dy, Wt, precision="fp16")
+            assert torch.equal(y_img, y_cal)
+            assert _rel(y_img, dy.double().cpu() @ Wt.double().cpu().t()) < 1e-3
+
+
+@pytest.mark.parametrize("kind", [1, 4])   # GaussianActivation (the denoiser's), GELU (the conditioner's): smooth — a ReLU kink would flip with u's rounding
+def test_mlp_function_under_autocast_runs_fp16_linears(kind):
+    """LinearActLinearFn / ActLinearFn / LinearFn under torch.autocast(float16): outputs and every gradient against torch autograd
+    in fp64 at fp16-operand accuracy, the forward equal to the fp16 kernel's bits (the arithmetic really is the one-MFMA one, not the
+    split-bf16 default), the activation's backward as the epilogue of the fp16 dX product (GECCO_TRAIN_ACTBWD=0: same values from
+    two kernels)."""
+    from gecco_amd import autograd as ag
+    from gecco_amd import hip_ops
+    rs = np.random.RandomState(3 + kind)
+    prev = hip_ops.default_precision()
+    hip_ops.set_default_precision("mixed")
+    try:
+        B, R, K, Wd = 2, 384, 384, 768
+        x = _t(rs.randn(B, R, K))
+        W0, b0 = _t(rs.randn(Wd, K) / np.sqrt(K)), _t(rs.randn(Wd) * 0.1)
+        W2, b2 = _t(rs.randn(K, Wd) / np.sqrt(Wd)), _t(rs.randn(K) * 0.1)
+        res, dy = _t(rs.randn(B, R, K)), _t(rs.randn(B, R, K))
+        alpha = torch.tensor(0.8)
+
+        def act64(u, a):
+            if kind == 1:
+                return (torch.exp(-u ** 2 / (2 * a ** 2)) - 0.7) / 0.28
+            return torch.nn.functional.gelu(u)
+        x64, a64, W064, W264, r64 = (t.double().requires_grad_(True) for t in (x, alpha, W0, W2, res))
+        y64 = act64(x64 @ W064.t() + b0.double(), a64) @ W264.t() + b2.double() + r64
+        (y64 * dy.double()).sum().backward()
+
+        def run(amp):
+            xg, ag_, W0g, b0g, W2g, b2g, rg = (_leaf(t) for t in (x, alpha, W0, b0, W2, b2, res))
+            with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+                y = ag.LinearActLinearFn.apply(xg, W0g, b0g, ag_ if kind == 1 else None, W2g, b2g, rg, kind)
+            assert y.dtype == torch.float32
+            y.backward(dy.cuda())
+            return y.detach(), xg.grad, W0g.grad, b0g.grad, W2g.grad, b2g.grad, rg.grad, (ag_.grad if kind == 1 else None)
+        amp, plain = run(True), run(False)
+        assert not torch.equal(amp[0], plain[0])                    # another arithmetic ran
+        refs = (y64.detach(), x64.grad, W064.grad, None, W264.grad, None, r64.grad, a64.grad if kind == 1 else None)
+        for i, (g, r) in enumerate(zip(amp, refs)):
+            if r is not None:
+                bar = 2e-3 if i != 7 else 2e-2
+                assert _rel(g, r) < bar, (i, _rel(g, r))
+                assert _rel(plain[i], r) < _rel(g, r) + 1e-7        # and split-bf16 is the tighter one
+        assert torch.equal(amp[6], dy.cuda())                        # the skip connection's gradient is dy itself
+        # the hidden layer's forward in the fp16 kernel's own bits
+        with torch.autocast("cuda", dtype=torch.float16):
+            y1 = ag.LinearFn.apply(x.cuda(), W0.cuda(), b0.cuda())
+        assert torch.equal(y1, hip_ops.linear(x.cuda(), W0.cuda(), b0.cuda(), precision="fp16"))
+    finally:
+        hip_ops.set_default_precision(prev)
+
+
+def test_fused_adam_in_the_grad_scaler_protocol_matches_torch():
+    """scaler.step(FusedAdamEMA): the optimizer declares `_step_supports_amp_scaling`, so torch.amp.GradScaler hands it the scale and
+    found_inf tensors and never reads found_inf back on the host.  Against torch.optim.Adam driven by a GradScaler the ordinary way
+    (unscale_, host decision): same parameters (1e-6) over steps that include an overflow (skipped: nothing moves, Adam's step
+    count does not advance, the scale backs off), and the optimizer state that is saved afterwards carries torch's step count."""
+    from gecco_amd.optim import FusedAdamEMA
+    rs = np.random.RandomState(1)
+    shapes = [(64, 48), (48,), (7, 5), (1,)]
+    init = [_t(rs.randn(*s)) for s in shapes]
+    grads = [[_t(rs.randn(*s) * 0.1) for s in shapes] for _ in range(6)]
+    bad = 2                                                            # the step whose gradients overflow
+    # the reference side: torch.optim.Adam's single-tensor path on the host (what FusedAdamEMA follows op for op, tests/test_optim_ckpt.py)
+    # under GradScaler's rules (torch/amp/grad_scaler.py: unscale by 1 / scale, skip on inf and back off by 0.5, grow by 2 after
+    # `growth_interval` clean steps)
+    ps = [torch.nn.Parameter(t.clone()) for t in init]
+    ref_opt = torch.optim.Adam(ps, lr=1e-2, foreach=False)
+    scale, tracker, ref_scales = 2.0 ** 10, 0, []
+    for it, gs in enumerate(grads):
+        if it == bad:
+            scale, tracker = scale * 0.5, 0
+        else:
+            for p, g in zip(ps, gs):
+                p.grad = (g * scale) * (1.0 / scale)
+            ref_opt.step()
+            tracker += 1
+            if tracker == 2:
+                scale, tracker = scale * 2.0, 0
+        ref_scales.append(scale)
+    ref_params = [p.detach().clone() for p in ps]
+    # the HIP side: a real torch.amp.GradScaler around FusedAdamEMA
+    ps = [torch.nn.Parameter(t.clone().cuda()) for t in init]
+    fused = FusedAdamEMA(ps, lr=1e-2, ema_decay=0.9)
+    scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 10, growth_interval=2)
+    scales = []
+    for it, gs in enumerate(grads):
+        fused.zero_grad(set_to_none=True)
+        scaler.scale(torch.zeros(1, device="cuda"))                # (what scaler.scale(loss) does first: the scale tensor exists)
+        sc = scaler.get_scale()
+        for p, g in zip(ps, gs):
+            p.grad = (g.cuda() * sc).clone()
+        if it == bad:
+            ps[0].grad.view(-1)[3] = float("inf")
+        scaler.step(fused)
+        scaler.update()
+        scales.append(scaler.get_scale())
+    torch.cuda.synchronize()
+    assert scales == ref_scales                                        # the scale's history, incl. the back-off
+    for a, b in zip(ref_params, ps):   # 1e-6: host libm / ISA differences, as in tests/test_optim_ckpt.py (a step count off by one after the
+        assert _rel(b.detach(), a) <= 1e-6   # skip would move the bias corrections, and the parameters, by percents)
+    assert fused.adam_steps_taken == len(grads) - 1
+    st = fused.state_dict()
+    steps = {float(v["step"]) for v in (st["opt"]["state"] if "opt" in st else st["state"]).values()}
+    assert steps == {float(len(grads) - 1)} == {float(v["step"]) for v in ref_opt.state_dict()["state"].values()}
+
+
+def test_c2_full_size_gradients_under_autocast_vs_oracle():
+    """The training path at the headline size (N = 2048, d = 384, L = 6) in the reference's trainer setting: EDM loss under
+    torch.autocast(float16), scaled loss, every parameter gradient against torch autograd through the oracle in fp32.  Bars: the
+    reference's own algorithm under torch.autocast(float16) is 2.1e-3 (all parameters) and up to 2.8e-3 per weight matrix, 4e-3 per
+    tensor, from its fp32 gradients (profiles/r04h_autocast_grad_deviation.txt); the HIP path keeps fp32 tensors between its kernels
+    and fp32 weight gradients and must stay below that: 2e-3 overall, 3e-3 per matrix, 4e-3 per tensor (the GaussianActivation alpha
+    scalars — cancelling sums over the whole batch, 2.4e-2 in the reference's own setting — 5e-2)."""
+    from gecco_amd import hip_ops as ops
+    from tests.test_hip_fullsize import _edm_loss
+    from tests.test_modules_cpu import build_uncond, uncond_state_dict
+    d, L, N, B = 384, 6, 2048, 2
+    p = W.linear_lift_state_dict(3, d, L, cases.I, cases.H)
+    rs = np.random.RandomState(11)
+    data = torch.from_numpy(rs.randn(B, N, 3).astype(np.float32))
+    noise = torch.from_numpy(rs.randn(B, N, 3).astype(np.float32))
+    sigma = torch.tensor([0.1, 5.0])
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    ref_loss = _edm_loss(cpu_ref.uncond_denoiser(pr, "", cases.H), data, noise, sigma)
+    ref_loss.backward()
+    m = build_uncond(d, L)
+    m.load_state_dict(uncond_state_dict(p), strict=True)
+    m = m.cuda().train()
+    old = ops.default_precision()
+    ops.set_default_precision("mixed")
+    scale = 2.0 ** 9
+    try:
+        with torch.autocast("cuda", dtype=torch.float16):
+            loss = _edm_loss(lambda x, s: m(x, s, None), data.cuda(), noise.cuda(), sigma.cuda())
+        (loss * scale).backward()
+    finally:
+        ops.set_default_precision(old)
+    lv, rv = float(loss.detach()), float(ref_loss.detach())
+    print(f"C2 training [autocast fp16]: loss {lv:.6f} (oracle {rv:.6f})")
+    assert abs(lv - rv) / abs(rv) < 3e-4
+    grads = {k[len("backbone.model."):]: q.grad / scale for k, q in m.named_parameters() if k.startswith("backbone.model.")}
+    assert set(grads) == set(p)
+    num = den = 0.0
+    worst, worst_m = ("", 0.0), ("", 0.0)
+    for k in p:
+        assert bool(torch.isfinite(grads[k]).all()), k
+        g, r = grads[k].double().cpu(), pr[k].grad.double()
+        e = float((g - r).norm() / r.norm())
+        num, den = num + float(((g - r) ** 2).sum()), den + float((r ** 2).sum())
+        if k.endswith(".alpha"):
+            assert e < 5e-2, (k, e)
+            continue
+        worst = max(worst, (k, e), key=lambda t: t[1])
+        if r.dim() == 2 and min(r.shape) > 1:
+            worst_m = max(worst_m, (k, e), key=lambda t: t[1])
+        assert e < 4e-3, (k, e)
+    tot = (num / den) ** 0.5
+    print(f"C2 training [autocast fp16]: gradient rel-L2 over all parameters {tot:.2e} (bar 2e-3), worst matrix {worst_m[0]} {worst_m[1]:.2e} "
+          f"(bar 3e-3), worst tensor {worst[0]} {worst[1]:.2e} (bar 4e-3)")
+    assert tot < 2e-3 and worst_m[1] < 3e-3

@@ -434,14 +434,19 @@ def _small_training_setup(seed=9):
     return m, Example(data, None)
 
 
-def test_training_step_under_autocast_and_grad_scaler():
+@pytest.mark.parametrize("amp_arith", ["off", "fp16"])
+def test_training_step_under_autocast_and_grad_scaler(amp_arith, monkeypatch):
     """The reference's shipped trainer settings: `precision="16-mixed"` (example_configs/shapenet_airplane_unconditional.py:74,
     taskonomy_conditional.py:102) = torch.autocast(float16) around training_step + a GradScaler around the optimizer.  The HIP
-    autograd Functions take and return fp32 tensors and are not autocast-wrapped, so the step computes what it computes without
-    autocast (it already runs its own reduced-precision arithmetic inside the kernels); the scaler's power-of-two loss scale
-    passes through the backward exactly, `scaler.step(FusedAdamEMA)` unscales the flat gradient views in place and steps:
-    parameters, moments and EMA equal the plain step's bit for bit; an injected inf skips the step and halves the scale."""
+    autograd Functions take and return fp32 tensors; under that autocast their linears run with fp16 operands (autograd.py
+    `_lin_precision`; GECCO_TRAIN_AMP=0 keeps split-bf16 there).  `scaler.step(FusedAdamEMA)` uses the scaler's device-side protocol
+    (`_step_supports_amp_scaling`: no host read-back of found_inf); an injected inf skips the step — parameters, moments, EMA
+    untouched — and halves the scale.
+    "off": the scaler's power-of-two loss scale passes through the backward exactly — parameters, moments and EMA equal the plain
+    step's bit for bit.  "fp16": the step follows the plain one at fp16-operand accuracy (tests/test_hip_amp.py holds the gradients
+    against the oracle at full size)."""
     from gecco_amd import autograd as ag
+    monkeypatch.setenv("GECCO_TRAIN_AMP", "0" if amp_arith == "off" else "1")
     outs = {}
     for mode in ("plain", "amp"):
         ag.WEIGHT_IMAGES.__init__()
@@ -468,6 +473,7 @@ def test_training_step_under_autocast_and_grad_scaler():
         if scaler is not None:
             # an overflowing gradient: the step is skipped, nothing moves, the scale backs off
             before = [p.detach().clone() for p in m.parameters()]
+            ema_before = [e.clone() for e in opt.ema_params]
             s0 = scaler.get_scale()
             torch.manual_seed(200)
             opt.zero_grad()
@@ -479,10 +485,21 @@ def test_training_step_under_autocast_and_grad_scaler():
             scaler.update()
             torch.cuda.synchronize()
             assert all(torch.equal(a, b.detach()) for a, b in zip(before, m.parameters()))
+            assert all(torch.equal(a, b) for a, b in zip(ema_before, opt.ema_params))
             assert scaler.get_scale() == s0 * 0.5
-    assert outs["plain"][0] == outs["amp"][0]
-    assert all(torch.equal(a, b) for a, b in zip(outs["plain"][1], outs["amp"][1]))
-    assert all(torch.equal(a, b) for a, b in zip(outs["plain"][2], outs["amp"][2]))
+            assert opt.adam_steps_taken == 3
+    if amp_arith == "off":
+        assert outs["plain"][0] == outs["amp"][0]
+        assert all(torch.equal(a, b) for a, b in zip(outs["plain"][1], outs["amp"][1]))
+        assert all(torch.equal(a, b) for a, b in zip(outs["plain"][2], outs["amp"][2]))
+    else:
+        assert outs["plain"][0] != outs["amp"][0]                      # the fp16 arithmetic really ran
+        assert abs(outs["plain"][0] - outs["amp"][0]) / abs(outs["plain"][0]) < 2e-3
+        # three Adam steps of lr 1e-3: a parameter moves by ~3e-3; the two runs' parameters stay within a fraction of one step
+        # (Adam's sign-like update amplifies a small gradient difference only where the gradient is near zero)
+        for a, b in zip(outs["plain"][1], outs["amp"][1]):
+            assert float((a - b).abs().max()) < 2.5e-3
+            assert float((a - b).abs().mean()) < 4e-4
     ag.WEIGHT_IMAGES.__init__()
 
 

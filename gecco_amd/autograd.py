@@ -200,6 +200,16 @@ class WeightImages:
 WEIGHT_IMAGES = WeightImages()
 
 
+def _resolve(prec: str | None, rows: int, K: int, Nout: int) -> str:
+    """The arithmetic of ONE product: `prec` (None: the training precision), except that an "fp16" request for a shape the fp16
+    LDS-DMA kernel does not take goes back to the training precision (hip_ops.linear would run it on the exact-fp32 kernel)."""
+    if prec is None:
+        return _train_precision()
+    if prec == "fp16" and not _lib.load().gecco_linear_image_ok_f16(rows, K, Nout, 0):
+        return _train_precision()
+    return prec
+
+
 def _image_ok(rows: int, K: int, Nout: int, prec: str = "bf16x3") -> bool:
     lib = _lib.load()
     return bool(lib.gecco_linear_image_ok_f16(rows, K, Nout, 0) if prec == "fp16" else lib.gecco_linear_image_ok(rows, K, Nout, 0))
@@ -211,7 +221,7 @@ def _linear_dx(dy: Tensor, W: Tensor, residual: Tensor | None = None, prec: str 
     prec: the arithmetic the Function's forward chose (`_lin_precision()`); None: the training precision."""
     B, R, Nout = dy.shape
     K = W.shape[1]
-    prec = _train_precision() if prec is None else prec
+    prec = _resolve(prec, R, Nout, K)
     if R >= 64 and Nout % 16 == 0 and K % 4 == 0:
         # linear(dy, W^T): the fused LDS-DMA GEMM; the image of W^T comes ready from the step's batched launch when it is
         # there (WeightImages), else from a transposed copy of the (small) weight
@@ -628,7 +638,7 @@ def _act_linear_dx(dy: Tensor, u: Tensor, h: Tensor, alpha: Tensor, W: Tensor, k
     lib = _lib.load()
     B, R, Nout = dy.shape
     K = W.shape[1]
-    prec = _train_precision() if prec is None else prec
+    prec = _resolve(prec, R, Nout, K)
     dalpha = None
     fused = (os.environ.get("GECCO_TRAIN_ACTBWD", "1") != "0" and prec in ("fp32", "bf16x3", "fp16")
              and lib.gecco_linear_actbwd_ok(R, Nout, K, hip_ops.PRECISIONS[prec]))
@@ -677,7 +687,7 @@ def _act_forward(u: Tensor, alpha: Tensor | None, kind: int) -> Tensor:
 def _linear_fwd(x: Tensor, W: Tensor, b, res, want_stats: bool, prec: str | None = None):
     """hip_ops.linear in the training precision (prec: the Function's `_lin_precision()`), with the step's ready weight image when
     there is one."""
-    prec = _train_precision() if prec is None else prec
+    prec = _resolve(prec, x.shape[1], W.shape[1], W.shape[0])
     img = WEIGHT_IMAGES.lookup("n", W, prec=prec) if _image_ok(x.shape[1], W.shape[1], W.shape[0], prec) else None
     kw = dict(precision=prec, w_image=img, w_shape=tuple(W.shape)) if img is not None else dict(precision=prec)
     return hip_ops.linear(x, None if img is not None else W, b, residual=res, want_stats=want_stats, **kw)
@@ -1187,19 +1197,20 @@ class CnxBlockFn(torch.autograd.Function):
                    "gecco_convnext_fold_scale_f32")
         y3 = y.view(1, rows, Cc)
         N1 = W1.shape[0]
-        prec = _train_precision()
-        if prec in ("fp32", "bf16x3") and lib.gecco_linear_actbwd_ok(rows, Cc, N1, hip_ops.PRECISIONS[prec]):
+        ctx.prec = _lin_precision()   # under autocast(float16) the conditioner's pointwise linears run in fp16 like the reference's
+        prec = _resolve(ctx.prec, rows, Cc, N1)
+        if prec in ("fp32", "bf16x3", "fp16") and lib.gecco_linear_actbwd_ok(rows, Cc, N1, hip_ops.PRECISIONS[prec]):
             u, h = _new(1, rows, N1, like=x), _new(1, rows, N1, like=x)
-            img = WEIGHT_IMAGES.lookup("n", W1) if prec == "bf16x3" and _image_ok(rows, Cc, N1) else None
+            img = WEIGHT_IMAGES.lookup("n", W1, prec=prec) if prec in ("bf16x3", "fp16") and _image_ok(rows, Cc, N1, prec) else None
             Wp, ws = (None, img) if img is not None else (
                 _f(W1), hip_ops._ws((N1 + 127) // 128 * 128 * Cc * 4, x.device) if prec != "fp32" else None)
             _lib.check(lib.gecco_linear_act_keep_f32(_ptr(y3), _ptr(Wp), _ptr(b1), None, 4, _ptr(u), _ptr(h), 1, rows, Cc, N1,
                                                      hip_ops.PRECISIONS[prec], C.c_void_p(ws.data_ptr()) if ws is not None else None,
                                                      _stream()), "gecco_linear_act_keep_f32")
         else:
-            u = _linear_fwd(y3, W1, b1, None, False)
+            u = _linear_fwd(y3, W1, b1, None, False, ctx.prec)
             h = _act_forward(u, None, 4)
-        out = _linear_fwd(h, w2f, b2f, x.view(1, rows, Cc), False)
+        out = _linear_fwd(h, w2f, b2f, x.view(1, rows, Cc), False, ctx.prec)
         ctx.save_for_backward(x, z, w_tap, ln_w, y, u, h, W1, W2, b2, lsv, w2f)
         ctx.eps, ctx.ls_shape = eps, ls.shape
         return out.view(B, H, W, Cc)
@@ -1212,13 +1223,14 @@ class CnxBlockFn(torch.autograd.Function):
         rows = B * H * W
         dout = _f(dout)
         d3 = dout.view(1, rows, Cc)
-        du, _ = _act_linear_dx(d3, u, h, None, w2f, 4, False)
-        dWp, dbp = _linear_dw(d3, h, want_db=True)
+        prec = ctx.prec
+        du, _ = _act_linear_dx(d3, u, h, None, w2f, 4, False, prec)
+        dWp, dbp = _linear_dw(d3, h, want_db=True, prec=prec)
         dW2, db2, dls = torch.empty_like(W2), torch.empty_like(b2), torch.empty_like(lsv)
         _lib.check(lib.gecco_convnext_fold_scale_bwd_f32(_ptr(dWp), _ptr(dbp), _ptr(W2), _ptr(b2), _ptr(lsv), _ptr(dW2), _ptr(db2),
                                                          _ptr(dls), Cc, W2.shape[1], _stream()), "gecco_convnext_fold_scale_bwd_f32")
-        dW1, db1 = _linear_dw(du, y.view(1, rows, Cc), want_db=True, leaf=W1)
-        dy = _linear_dx(du, W1).view(B, H, W, Cc)
+        dW1, db1 = _linear_dw(du, y.view(1, rows, Cc), want_db=True, leaf=W1, prec=prec)
+        dy = _linear_dx(du, W1, prec=prec).view(B, H, W, Cc)
         dz, dg, dbl, dbias = _cnx_ln_bwd(z, dy, ln_w, ctx.eps, False)
         dx = None
         if ctx.needs_input_grad[0]:   # reversed taps, + the gradient that came through the skip, one launch

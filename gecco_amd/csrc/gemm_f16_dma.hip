@@ -394,7 +394,9 @@ bool gemm_f16_dma_supported(const GemmArgs& g) {
         return false;
     if (g.a_f16 && (g.pro_a || (g.lda & 7) || g.rows < 128)) return false;
     if (g.c_f16 && (g.residual || g.stats || g.rows < 128)) return false;
-    return g.rows >= 64 && g.K % FBK == 0 && g.K <= 1024 && !(g.Nout & 3) && !(g.ldc & 3) && !(g.ldr & 3) &&
+    // K <= 1024 with the AdaGN prologue (its coefficients are parked in LDS: 8 K bytes); without it up to 2048 (the ConvNeXt
+    // conditioner's 4 C -> C linears at C = 384: K = 1536), as gemm_f32_dma.hip
+    return g.rows >= 64 && g.K % FBK == 0 && g.K <= (g.pro_a ? 1024 : 2048) && !(g.Nout & 3) && !(g.ldc & 3) && !(g.ldr & 3) &&
            !(g.lda & 3) && !(g.ldw & 3);
 }
 

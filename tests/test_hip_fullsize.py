@@ -246,9 +246,13 @@ def test_c2_full_size_gradients_vs_oracle(ops, precision):
     assert worst[1] > 0.0   # gradients were really compared
 
 
-@pytest.mark.parametrize("cfg", ["C3", "C4"])
+@pytest.mark.parametrize("cfg", ["C3", "C4", "C3-amp"])
 def test_conditional_full_size_training_step_vs_oracle(ops, cfg):
-    """The image-conditional training step at the C3 size (224 x 224 images -> ConvNeXt-T pyramids 96 / 192 / 384 channels ->
+    """"C3-amp": the same step in the reference's trainer setting (torch.autocast(float16), scaled loss: tests/test_hip_amp.py) — the
+    denoiser's AND the conditioner's linears with fp16 operands; bars from the reference's own deviation in that setting (2.1e-3
+    overall, 4e-3 per tensor at d = 384: profiles/r04h_autocast_grad_deviation.txt): 6e-3 per tensor here, where the conditioner's
+    small first-stage matrices sit behind three more stages of rounding.
+    The image-conditional training step at the C3 size (224 x 224 images -> ConvNeXt-T pyramids 96 / 192 / 384 channels ->
     projective lookup -> RayNetwork, N = 2048, d = 384, L = 6) and at the C4 size — BASELINE's data-parallel training
     configuration: 256 x 256 images, N = 4096, d = 512 — conditioner TRAINED as in the reference: the loss and the gradient of
     every parameter — conditioner and denoiser — against torch autograd through the oracle chain convnext_features ->
@@ -257,6 +261,8 @@ def test_conditional_full_size_training_step_vs_oracle(ops, cfg):
     from gecco_amd.structs import Context3d
     from tests.test_hip_convnext import _seeded_state
     from tests.test_modules_cpu import build_cond
+    amp = cfg.endswith("-amp")
+    cfg = cfg[:2]
     d, L, N, hw, B = (384, 6, 2048, 224, 2) if cfg == "C3" else (512, 6, 4096, 256, 2)
     cn = ConvNeXtExtractor(n_stages=3, model="tiny", pretrained=False)
     csd = _seeded_state(cn, 9)
@@ -283,13 +289,20 @@ def test_conditional_full_size_training_step_vs_oracle(ops, cfg):
     ops.set_default_precision("bf16x3")
     try:
         ctx = Context3d(image=img.cuda(), K=K.cuda())
-        loss = _edm_loss(lambda x, s: m(x, s, ctx), data.cuda(), noise.cuda(), sigma.cuda())
-        loss.backward()
+        scale = 2.0 ** 9 if amp else 1.0
+        with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+            loss = _edm_loss(lambda x, s: m(x, s, ctx), data.cuda(), noise.cuda(), sigma.cuda())
+        (loss * scale).backward()
+        if amp:
+            for q in m.parameters():
+                if q.grad is not None:
+                    q.grad /= scale
     finally:
         ops.set_default_precision(old)
     lv, rv = float(loss.detach()), float(ref_loss.detach())
-    print(f"{cfg} training: loss {lv:.6f} (oracle {rv:.6f})")
-    assert abs(lv - rv) / abs(rv) < 1e-4
+    print(f"{cfg} training{' [autocast fp16]' if amp else ''}: loss {lv:.6f} (oracle {rv:.6f})")
+    assert abs(lv - rv) / abs(rv) < (5e-4 if amp else 1e-4)
+    bar = 6e-3 if amp else 3e-3
     worst = {"conditioner": ("", 0.0), "denoiser": ("", 0.0), "denoiser matrices": ("", 0.0)}
     for k, q in m.named_parameters():
         if k.startswith("conditioner."):
@@ -303,8 +316,11 @@ def test_conditional_full_size_training_step_vs_oracle(ops, cfg):
             continue
         assert q.grad is not None and r is not None, k
         e = cpu_ref.rel_err(q.grad.cpu(), r)[0]
+        if amp and k.endswith(".alpha"):   # cancelling scalar sums: 2.4e-2 in the reference's own autocast run
+            assert e < 5e-2, (k, e)
+            continue
         worst[part] = max(worst[part], (k, e), key=lambda t: t[1])
-        assert e < 3e-3, (k, e)
+        assert e < bar, (k, e)
     for part, (k, e) in worst.items():
-        print(f"{cfg} training: worst {part} gradient {k} {e:.2e} (bar 3e-03)")
+        print(f"{cfg} training{' [autocast fp16]' if amp else ''}: worst {part} gradient {k} {e:.2e} (bar {bar:.0e})")
         assert e > 0.0

@@ -529,6 +529,15 @@ def train_bench(args, rank, world, dev):
                                             "; incl. the fixed-order reduction of the per-group partials)",
                                   "ms": t_dw, "achieved_tflops": fl / (t_dw * 1e-3) / 1e12, "peak_tflops": PEAK_BF16_MFMA_TFLOPS / units,
                                   "frac": units * fl / (t_dw * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, "bound": "mfma"}
+        if args.amp:
+            # with one MFMA per product the kernel is bound by its operand stream, not the matrix pipe: dY and X once from HBM
+            # (algorithmic), each re-read by the other operand's 3 / 6 column tiles from L2, + the per-sample partials
+            by = 4.0 * Bt * N * (D + 2 * D) + 4.0 * Bt * D * 2 * D
+            l2 = 4.0 * Bt * N * (D * (2 * D // 128) + 2 * D * (D // 128))
+            rec["dominant_kernel"].update({"bound": "hbm", "algorithmic_bytes": by, "achieved_gbs": by / (t_dw * 1e-3) / 1e9,
+                                           "peak_gbs": PEAK_HBM_GBS, "frac": by / (t_dw * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                           "frac_mfma": fl / (t_dw * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                                           "l2_operand_bytes": l2, "l2_gbs": l2 / (t_dw * 1e-3) / 1e9})
     if world > 1 or args.force_collective:
         # --force-collective at one rank: the RCCL all-reduce of every bucket really executes (a group of one: no bytes
         # cross a link, so no bus bandwidth is claimed) — the collective path of the step runs before an 8-GPU box has to

@@ -306,9 +306,14 @@ def _linear_dw_main(dy: Tensor, x: Tensor, want_db: bool = False, pro=None, prec
         G = -(-B // group)
         parts = _new(G, Nout, K, like=x)
         cparts = _new(G, Nout, like=x) if want_db else None
-        _lib.check(_lib.load().gecco_gemm_tn_f16_f32(_ptr(dy), _ptr(x), _ptr(pro[0]) if pro is not None else None,
-                                                     _ptr(pro[1]) if pro is not None else None, _ptr(parts), _ptr(cparts), B, R,
-                                                     Nout, K, group, _stream()), "gecco_gemm_tn_f16_f32")
+        if x.dtype == torch.float16:   # the fp16 hidden layer of an MLP (_keep_h16): its tiles go to LDS as they are
+            assert pro is None
+            _lib.check(_lib.load().gecco_gemm_tn_f16_b16_f32(_ptr(dy), hip_ops._ptr16(x), _ptr(parts), _ptr(cparts), B, R, Nout, K, group,
+                                                             _stream()), "gecco_gemm_tn_f16_b16_f32")
+        else:
+            _lib.check(_lib.load().gecco_gemm_tn_f16_f32(_ptr(dy), _ptr(x), _ptr(pro[0]) if pro is not None else None,
+                                                         _ptr(pro[1]) if pro is not None else None, _ptr(parts), _ptr(cparts), B, R,
+                                                         Nout, K, group, _stream()), "gecco_gemm_tn_f16_f32")
         dW = _reduce(parts, Nout * K, G, Nout * K).reshape(Nout, K)
         return (dW, _reduce(cparts, Nout, G, Nout)) if want_db else dW
     if pro is not None:
@@ -573,17 +578,21 @@ class AdaGNMlpFn(torch.autograd.Function):
         B, R, K0 = x.shape
         N0 = W0.shape[0]
         a, o, stats, t2 = _adagn_coeffs(x, t, sw, sb, bw, bb, G, eps, stats)
-        u, h = _new(B, R, N0, like=x), _new(B, R, N0, like=x)
         prec = ctx.prec = _lin_precision()   # "bf16x3" or "fp16" (_pro_ok)
-        img = WEIGHT_IMAGES.lookup("n", W0, prec=prec)
-        Wp, ws = (None, img) if img is not None else (_f(W0), hip_ops._ws((N0 + 127) // 128 * 128 * K0 * 4, x.device))
-        _lib.check(lib.gecco_linear_act_keep_pro_f32(_ptr(x), _ptr(Wp), _ptr(b0), _ptr(a), _ptr(o), _ptr(alpha) if kind in (1, 2) else None,
-                                                     kind, _ptr(u), _ptr(h), B, R, K0, N0, hip_ops.PRECISIONS[prec],
-                                                     C.c_void_p(ws.data_ptr()), _stream()),
-                   "gecco_linear_act_keep_pro_f32")
+        h16 = _h16_ok(prec, R, K0, N0, W2.shape[0], True)
+        if h16:
+            u, h = _keep_h16(x, W0, b0, (a, o), alpha, kind)
+        else:
+            u, h = _new(B, R, N0, like=x), _new(B, R, N0, like=x)
+            img = WEIGHT_IMAGES.lookup("n", W0, prec=prec)
+            Wp, ws = (None, img) if img is not None else (_f(W0), hip_ops._ws((N0 + 127) // 128 * 128 * K0 * 4, x.device))
+            _lib.check(lib.gecco_linear_act_keep_pro_f32(_ptr(x), _ptr(Wp), _ptr(b0), _ptr(a), _ptr(o), _ptr(alpha) if kind in (1, 2) else None,
+                                                         kind, _ptr(u), _ptr(h), B, R, K0, N0, hip_ops.PRECISIONS[prec],
+                                                         C.c_void_p(ws.data_ptr()), _stream()),
+                       "gecco_linear_act_keep_pro_f32")
         ctx.save_for_backward(x, stats, t2, sw, sb, a, o, u, h, alpha if alpha is not None else x.new_empty(0), W0, W2)
         ctx.G, ctx.eps, ctx.kind, ctx.bias = G, eps, kind, (b0 is not None, b2 is not None)
-        out = _linear_fwd(h, W2, b2, x, want_stats, prec)
+        out = _linear_fwd_h16(h, W2, b2, x, want_stats) if h16 else _linear_fwd(h, W2, b2, x, want_stats, prec)
         if want_stats:
             ctx.mark_non_differentiable(out[1])
         return out
@@ -667,7 +676,7 @@ def _act_linear_dx(dy: Tensor, u: Tensor, h: Tensor, alpha: Tensor, W: Tensor, k
                                                _stream()), "gauss_act_bwd")
         dalpha = _reduce(part, 1, nb, 1).reshape(alpha.shape)
     elif kind == 3:
-        du = hip_ops.relu_bwd(h, dh)
+        du = hip_ops.relu_bwd(h if h.dtype == torch.float32 else u, dh)   # (u > 0) == (relu(u) > 0)
     else:
         du = torch.empty_like(u)
         _lib.check(lib.gecco_gelu_bwd_f32(_ptr(u), _ptr(dh), _ptr(du), u.numel(), _stream()), "gecco_gelu_bwd_f32")
@@ -693,6 +702,38 @@ def _linear_fwd(x: Tensor, W: Tensor, b, res, want_stats: bool, prec: str | None
     return hip_ops.linear(x, None if img is not None else W, b, residual=res, want_stats=want_stats, **kw)
 
 
+def _h16_ok(prec: str, R: int, K0: int, N0: int, Nout2: int, pro: bool) -> bool:
+    """Under the autocast(float16) arithmetic the hidden layer h = act(u) of an MLP is read again only by the matrix pipe — the
+    second linear's forward and its weight gradient — as an fp16 operand either way (the reference's autocast stores it as fp16
+    too): the first GEMM's epilogue stores it as fp16 (`gecco_linear_act_keep_h16`), half the bytes of its three crossings of HBM.
+    u (the pre-activation the backward differentiates) stays fp32."""
+    if prec != "fp16" or os.environ.get("GECCO_TRAIN_H16", "1") == "0" or R < 128 or R % 32 or N0 % 8 or Nout2 % 4:
+        return False
+    lib = _lib.load()
+    return bool(lib.gecco_linear_image_ok_f16(R, K0, N0, int(pro)) and lib.gecco_linear_image_ok_f16(R, N0, Nout2, 0))
+
+
+def _keep_h16(x: Tensor, W0: Tensor, b0, pro, alpha, kind: int) -> tuple[Tensor, Tensor]:
+    """(u fp32, h fp16) = (x' W0^T + b0, act(u)) from one launch; pro = (a, o): x' = a x + o."""
+    lib = _lib.load()
+    B, R, K0 = x.shape
+    N0 = W0.shape[0]
+    u, h = _new(B, R, N0, like=x), torch.empty(B, R, N0, device=x.device, dtype=torch.float16)
+    img = WEIGHT_IMAGES.lookup("n", W0, prec="fp16")
+    Wp, ws = (None, img) if img is not None else (_f(W0), hip_ops._ws((N0 + 127) // 128 * 128 * K0 * 2, x.device))
+    _lib.check(lib.gecco_linear_act_keep_h16(_ptr(x), _ptr(Wp), _ptr(b0), _ptr(pro[0]) if pro else None, _ptr(pro[1]) if pro else None,
+                                             _ptr(alpha) if kind in (1, 2) else None, kind, _ptr(u), C.c_void_p(h.data_ptr()), B, R, K0, N0,
+                                             C.c_void_p(ws.data_ptr()), _stream()), "gecco_linear_act_keep_h16")
+    return u, h
+
+
+def _linear_fwd_h16(h: Tensor, W: Tensor, b, res, want_stats: bool):
+    """The second linear of such an MLP: fp16 A tensor, fp32 output (+ residual, + statistics)."""
+    img = WEIGHT_IMAGES.lookup("n", W, prec="fp16")
+    return hip_ops.linear_f16io(h, None if img is not None else W, b, residual=res, want_stats=want_stats, w_image=img,
+                                w_shape=tuple(W.shape))
+
+
 class LinearActLinearFn(torch.autograd.Function):
     """y = act(x @ W0^T + b0) @ W2^T + b2 (+ residual): an MLP of the reference (models/mlp.py: Linear -> act -> Linear; a
     CNBlock's pointwise pair) as ONE Function.  Forward: the first GEMM's epilogue leaves both u = x W0^T + b0 and act(u)
@@ -708,7 +749,10 @@ class LinearActLinearFn(torch.autograd.Function):
         prec = ctx.prec = _lin_precision()
         keep = (os.environ.get("GECCO_TRAIN_ACTKEEP", "1") != "0" and prec in ("fp32", "bf16x3", "fp16")
                 and lib.gecco_linear_actbwd_ok(R, K0, N0, hip_ops.PRECISIONS[prec]))
-        if keep:
+        h16 = keep and _h16_ok(prec, R, K0, N0, W2.shape[0], False)
+        if h16:
+            u, h = _keep_h16(x, W0, b0, None, alpha, kind)
+        elif keep:
             u, h = _new(B, R, N0, like=x), _new(B, R, N0, like=x)
             img = WEIGHT_IMAGES.lookup("n", W0, prec=prec) if prec in ("bf16x3", "fp16") and _image_ok(R, K0, N0, prec) else None
             if img is not None:
@@ -726,7 +770,7 @@ class LinearActLinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, u, h, alpha if alpha is not None else x.new_empty(0), W0, W2)
         ctx.kind, ctx.bias = kind, (b0 is not None, b2 is not None)
         res = None if residual is None else _f(residual)
-        out = _linear_fwd(h, W2, b2, res, want_stats, prec)
+        out = _linear_fwd_h16(h, W2, b2, res, want_stats) if h16 else _linear_fwd(h, W2, b2, res, want_stats, prec)
         if want_stats:
             ctx.mark_non_differentiable(out[1])
         return out

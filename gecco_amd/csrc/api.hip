@@ -845,14 +845,30 @@ int gecco_linear_act_keep_pro_f32(const float* A, const float* W, const float* b
     return 0;
 }
 
+int gecco_linear_act_keep_h16(const float* A, const float* W, const float* bias, const float* pro_a, const float* pro_o,
+                              const float* alpha, int act, float* pre_out, void* C16out, int B, int rows, int K, int Nout, void* wsplit,
+                              void* stream) {
+    if (!A || !pre_out || !C16out || !wsplit) return fail(-1, "linear_act_keep_h16: null argument");
+    if ((pro_a == nullptr) != (pro_o == nullptr)) return fail(-1, "linear_act_keep_h16: pro_a / pro_o must both be set");
+    if (act < 1 || act > 4) return fail(-2, "linear_act_keep_h16: act must be 1 / 2 (GaussianActivation), 3 (ReLU) or 4 (GELU)");
+    if ((act == 1 || act == 2) && !alpha) return fail(-1, "linear_act_keep_h16: GaussianActivation needs alpha");
+    int rc = linear(A, W, bias, pro_a, pro_o, alpha, nullptr, static_cast<float*>(C16out), nullptr, B, rows, K, Nout, act, (hipStream_t)stream, 2,
+                    W ? static_cast<float*>(wsplit) : nullptr, W ? nullptr : static_cast<const float*>(wsplit), 0, 1, 0, 0, nullptr, 0,
+                    nullptr, pre_out);
+    if (rc == -9) return fail(-2, "linear_act_keep_h16: needs rows >= 128, K %% 32 == 0, K <= 1024 with a prologue, Nout %% 4 == 0");
+    TRY(rc, "linear_act_keep_h16");
+    return 0;
+}
+
 int gecco_linear_f16io(const void* A, const float* W, const float* bias, const float* alpha, const float* residual,
                        void* C, float* stats, int B, int rows, int K, int Nout, int act, int a_f16, int c_f16,
                        void* wsplit, void* stream) {
-    if (!A || !W || !C || !wsplit) return fail(-1, "linear_f16io: null argument");
+    if (!A || !C || !wsplit) return fail(-1, "linear_f16io: null argument");
     if (!a_f16 && !c_f16) return fail(-2, "linear_f16io: at least one of A / C must be an fp16 tensor (else gecco_linear_ex_f32)");
+    // W == NULL: wsplit already holds the fp16 image of W (gecco_split_f16_images_f32): kernel launch only
     int rc = linear(static_cast<const float*>(A), W, bias, nullptr, nullptr, alpha, residual, static_cast<float*>(C),
-                    stats, B, rows, K, Nout, act, (hipStream_t)stream, 2, static_cast<float*>(wsplit), nullptr, a_f16,
-                    c_f16);
+                    stats, B, rows, K, Nout, act, (hipStream_t)stream, 2, W ? static_cast<float*>(wsplit) : nullptr,
+                    W ? nullptr : static_cast<const float*>(wsplit), a_f16, c_f16);
     if (rc == -9) return fail(-2, "linear_f16io: needs rows >= 128, K %% 32 == 0, lda %% 8 == 0; fp16 C excludes residual / stats");
     TRY(rc, "linear_f16io");
     return 0;
@@ -1080,6 +1096,18 @@ int gecco_gemm_tn_x3_pro_f32(const float* A, const float* Bm, const float* pro_a
     g.sA = (size_t)R * N; g.sB = (size_t)R * K; g.group = group; g.colsum = colsum_parts;
     if (!gemm_tn_x3_supported(g)) return fail(-2, "gemm_tn_x3: needs R %% 32 == 0, N %% 4 == 0, K %% 4 == 0, group > 0");
     TRY(gemm_tn_x3_launch(g, (hipStream_t)stream), "gemm_tn_x3");
+    return 0;
+}
+
+int gecco_gemm_tn_f16_b16_f32(const float* A, const void* B16, float* parts, float* colsum_parts, int Z, int R, int N, int K, int group,
+                              void* stream) {
+    if (!A || !B16 || !parts) return fail(-1, "gemm_tn_f16_b16: null argument");
+    TnArgs g{};
+    g.f16 = 1; g.b_f16 = 1;
+    g.A = A; g.Bm = static_cast<const float*>(B16); g.C = parts; g.Z = Z; g.R = R; g.N = N; g.K = K; g.lda = N; g.ldb = K;
+    g.sA = (size_t)R * N; g.sB = (size_t)R * K; g.group = group; g.colsum = colsum_parts;
+    if (!gemm_tn_x3_supported(g)) return fail(-2, "gemm_tn_f16_b16: needs R %% 32 == 0, N %% 4 == 0, K %% 4 == 0, group > 0");
+    TRY(gemm_tn_x3_launch(g, (hipStream_t)stream), "gemm_tn_f16_b16");
     return 0;
 }
 

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void col_dot_stats_kernel(const float* __restr
 
 // AdaGN backward finalisation per sample.  xstats: forward partials {sum x, sum x^2}; gstats: {sum dy, sum dy*x}.
 // Emits dx = dy*cA + x*cB + cC coefficients and ds, dz (grads of the per-(b,c) scale / shift).
-__global__ __launch_bounds__(256) void adagn_bwd_coeffs_kernel(const float* __restrict__ xstats, int Tx,
+__global__ __launch_bounds__(512) void adagn_bwd_coeffs_kernel(const float* __restrict__ xstats, int Tx,
                                                                const float* __restrict__ gstats, int Tg, int rows,
                                                                const float* __restrict__ t, int ctx_dim,
                                                                const float* __restrict__ scale_w,
@@ -151,10 +151,13 @@ __global__ __launch_bounds__(256) void adagn_bwd_coeffs_kernel(const float* __re
     const int b = blockIdx.x, cpg = C / G;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        // (unrolled: the loads of eight tiles are in flight together; the additions keep their order)
+#pragma unroll 8
         for (int k = 0; k < Tx; ++k) {
             a0 += (double)xstats[(((size_t)b * Tx + k) * 2 + 0) * C + c];
             a1 += (double)xstats[(((size_t)b * Tx + k) * 2 + 1) * C + c];
         }
+#pragma unroll 8
         for (int k = 0; k < Tg; ++k) {
             a2 += (double)gstats[(((size_t)b * Tg + k) * 2 + 0) * C + c];
             a3 += (double)gstats[(((size_t)b * Tg + k) * 2 + 1) * C + c];
@@ -441,7 +444,8 @@ int adagn_bwd_coeffs_launch(const float* xstats, int Tx, const float* gstats, in
                             float* ds, float* dz, int B, int C, int G, float eps, hipStream_t st) {
     if (C % G) return -5;
     const size_t lds = (size_t)(4 * C + 4 * G) * sizeof(double);
-    hipLaunchKernelGGL(adagn_bwd_coeffs_kernel, dim3(B), dim3(256), lds, st, xstats, Tx, gstats, Tg, rows, t, ctx_dim,
+    const int nt = C >= 512 ? 512 : (C <= 256 ? 256 : (C + 63) / 64 * 64);   // one channel per thread up to 512 channels
+    hipLaunchKernelGGL(adagn_bwd_coeffs_kernel, dim3(B), dim3(nt), lds, st, xstats, Tx, gstats, Tg, rows, t, ctx_dim,
                        scale_w, scale_b, cA, cB, cC, ds, dz, C, G, eps);
     return (int)hipGetLastError();
 }

@@ -362,19 +362,21 @@ int f16_launch_t(const GemmArgs& g, hipStream_t st) {
         attr = lds;
     }
     const dim3 grid(g.B * tilesM * tilesN);
-    if (g.mul_u || g.pre_out) {   // the training path's epilogue forms: their own kernel instantiations (fp32 tensors only)
-        if (A16 || C16 || (g.mul_u && g.pro_a) || g.c_img) return -9;
-        if constexpr (!A16 && !C16) {
+    if (g.mul_u || g.pre_out) {   // the training path's epilogue forms: their own kernel instantiations
+        // fp32 tensors, except that the KEEP form may store act(u) as fp16 (C16: the hidden layer of an MLP, which only the matrix pipe
+        // reads again — as an fp16 operand either way) beside the fp32 pre-activation
+        if (A16 || (C16 && g.mul_u) || (g.mul_u && g.pro_a) || g.c_img) return -9;
+        if constexpr (!A16) {
             static size_t attr2 = 0;
             if (lds > attr2) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<DNS, true, BM, false, false, true>),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<DNS, true, BM, false, C16, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<DNS, false, BM, false, false, true>),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<DNS, false, BM, false, C16, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 attr2 = lds;
             }
-            if (g.pro_a) hipLaunchKernelGGL((gemm_f16_kernel<DNS, true, BM, false, false, true>), grid, dim3(DNT), lds, st, g);
-            else hipLaunchKernelGGL((gemm_f16_kernel<DNS, false, BM, false, false, true>), grid, dim3(DNT), lds, st, g);
+            if (g.pro_a) hipLaunchKernelGGL((gemm_f16_kernel<DNS, true, BM, false, C16, true>), grid, dim3(DNT), lds, st, g);
+            else hipLaunchKernelGGL((gemm_f16_kernel<DNS, false, BM, false, C16, true>), grid, dim3(DNT), lds, st, g);
         }
         return (int)hipGetLastError();
     }

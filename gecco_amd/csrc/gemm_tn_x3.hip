@@ -63,8 +63,11 @@ __device__ __forceinline__ u32x2 tn_cvt4(const f32x4& x) {
 
 // PRO: the AdaGN apply on the B operand (TnArgs::pro_a) — its own instantiation, so the plain weight gradients run the code
 // they ran before it existed
-template <bool PRO, bool F16 = false>
+// B16 (with F16): the B operand is an fp16 tensor in memory (the hidden layer an MLP's first GEMM stored that way): 8-byte loads, no
+// conversion
+template <bool PRO, bool F16 = false, bool B16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(TnArgs g) {
+    static_assert(!B16 || (F16 && !PRO), "an fp16 B operand: fp16 arithmetic, no AdaGN apply");
     constexpr int NPL = F16 ? 2 : 4;   // planes per stage: A | B (fp16) or A hi | A lo | B hi | B lo
     extern __shared__ __attribute__((aligned(16))) float smem[];
     u16* lds = reinterpret_cast<u16*>(smem);   // [2 stages][A hi | A lo | B hi | B lo]
@@ -85,7 +88,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(TnArgs g) {
     const int msteps = g.R / 32, nsteps = (z1 - z0) * msteps;
 
     // global tile loads: thread -> 4 x (row, 4 columns) of each operand
-    f32x4 ra[4], rb[4];
+    f32x4 ra[4], rb[B16 ? 1 : 4];
+    u32x2 rb16[B16 ? 4 : 1];
     f32x4 pa4 = {1.f, 1.f, 1.f, 1.f}, po4 = {0.f, 0.f, 0.f, 0.f};   // AdaGN coefficients of the thread's four X columns, sample zc
     int zc = -1;
     auto load = [&](int s) {
@@ -97,11 +101,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(TnArgs g) {
         zc = z;
         const float* Ab = g.A + (size_t)z * g.sA + (size_t)m0 * g.lda + n0;
         const float* Bb = g.Bm + (size_t)z * g.sB + (size_t)m0 * g.ldb + k0;
+        const _Float16* Bh = reinterpret_cast<const _Float16*>(g.Bm) + (size_t)z * g.sB + (size_t)m0 * g.ldb + k0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int f = tid + i * 256, row = f >> 5, c4 = f & 31;
             ra[i] = aok ? *reinterpret_cast<const f32x4*>(Ab + (size_t)row * g.lda + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-            rb[i] = bok ? *reinterpret_cast<const f32x4*>(Bb + (size_t)row * g.ldb + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (B16) rb16[i] = bok ? *reinterpret_cast<const u32x2*>(Bh + (size_t)row * g.ldb + c4 * 4) : u32x2{0u, 0u};
+            else rb[i] = bok ? *reinterpret_cast<const f32x4*>(Bb + (size_t)row * g.ldb + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     // bias gradient = column sums of dY: the blocks of the first K tile add up the rows they stage anyway
@@ -116,7 +122,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(TnArgs g) {
             if (want_cs) cs += ra[i];
             if (F16) {
                 *reinterpret_cast<u32x2*>(st + o) = tn_cvt4(ra[i]);
-                *reinterpret_cast<u32x2*>(st + TN_PLANE + o) = tn_cvt4(PRO ? (bok ? rb[i] * pa4 + po4 : rb[i]) : rb[i]);
+                if (B16) *reinterpret_cast<u32x2*>(st + TN_PLANE + o) = rb16[i];
+                else *reinterpret_cast<u32x2*>(st + TN_PLANE + o) = tn_cvt4(PRO ? (bok ? rb[i] * pa4 + po4 : rb[i]) : rb[i]);
                 continue;
             }
             tn_split4(ra[i], hi, lo);
@@ -124,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(TnArgs g) {
             *reinterpret_cast<u32x2*>(st + TN_PLANE + o) = lo;
             // the AdaGN apply, if any, here — where the loaded values are consumed a step after their loads were issued (applied
             // at the load it would make every step wait for its own global loads)
-            tn_split4(PRO ? (bok ? rb[i] * pa4 + po4 : rb[i]) : rb[i], hi, lo);
+            tn_split4(PRO ? (bok ? rb[B16 ? 0 : i] * pa4 + po4 : rb[B16 ? 0 : i]) : rb[B16 ? 0 : i], hi, lo);
             *reinterpret_cast<u32x2*>(st + 2 * TN_PLANE + o) = hi;
             *reinterpret_cast<u32x2*>(st + 3 * TN_PLANE + o) = lo;
         }
@@ -222,15 +229,10 @@ int gemm_tn_x3_launch(const TnArgs& g, hipStream_t st) {
     const int G = (g.Z + g.group - 1) / g.group;
     const size_t lds = (size_t)2 * (g.f16 ? 2 : 4) * TN_PLANE * 2;
     static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_x3_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_x3_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
+    if (!attr) {   // the split-bf16 form's four planes x two stages = 64 KiB (the fp16 forms' 32 KiB need no attribute)
+        const int lds_x3 = 2 * 4 * TN_PLANE * 2;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_x3);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_x3);
         attr = true;
     }
     static int xcd = -1;
@@ -241,7 +243,10 @@ int gemm_tn_x3_launch(const TnArgs& g, hipStream_t st) {
     TnArgs ga = g;
     ga.xcd = xcd;
     const dim3 grid(((g.N + 127) / 128) * ((g.K + 127) / 128), G);
-    if (g.f16) {
+    if (g.f16 && g.b_f16) {
+        if (g.pro_a || (g.ldb & 3)) return -9;
+        hipLaunchKernelGGL((gemm_tn_x3_kernel<false, true, true>), grid, dim3(256), lds, st, ga);
+    } else if (g.f16) {
         if (g.pro_a) hipLaunchKernelGGL((gemm_tn_x3_kernel<true, true>), grid, dim3(256), lds, st, ga);
         else hipLaunchKernelGGL((gemm_tn_x3_kernel<false, true>), grid, dim3(256), lds, st, ga);
     } else if (g.pro_a) hipLaunchKernelGGL(gemm_tn_x3_kernel<true>, grid, dim3(256), lds, st, ga);

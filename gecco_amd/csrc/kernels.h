@@ -176,6 +176,7 @@ struct TnArgs {
     const float* pro_a;
     const float* pro_o;
     int f16;           // 1: both operands rounded to fp16, one MFMA per product (the reference's autocast(float16) trainer arithmetic)
+    int b_f16;         // (with f16) Bm is an fp16 tensor already: its tiles go to LDS as they are
 };
 // gemm_x3_areg.hip: split-bf16 GEMM whose A operand is a tiled split image loaded global -> registers (GemmArgs::a_img)
 bool gemm_x3_areg_supported(const GemmArgs& g);

@@ -3,6 +3,8 @@
 #include "common.h"
 #include "kernels.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int STATS_ROWS = 128;  // row-tile height of the stand-alone / lift statistics producers
@@ -376,6 +378,112 @@ __global__ __launch_bounds__(256) void lower_edm_v4_kernel(const float* __restri
     }
 }
 
+// The same arithmetic, RPG rows per 16-lane group: the block stages W (and the block's sample's GroupNorm coefficients) in LDS once
+// per 16 * RPG rows and each row costs its CPL 16-byte loads of `feat` only — in the one-row form every row also issued 3 CPL loads
+// of W (+ 2 CPL of the coefficients): 24 - 36 vector-memory instructions per thread for 6 that reach HBM, and the texture path, not
+// HBM, set the time (72 us for 201 MB at C2).  The next row's chunks are loaded while this one reduces.
+template <int CPL, int RPG>
+__global__ __launch_bounds__(256) void lower_edm_v5_kernel(const float* __restrict__ feat, const float* __restrict__ x,
+                                                           const float* __restrict__ coef, const float* __restrict__ W,
+                                                           const float* __restrict__ bias,
+                                                           const float* __restrict__ gn_a,
+                                                           const float* __restrict__ gn_o, float* __restrict__ out,
+                                                           float* __restrict__ raw, int B, int N, int C, float eps) {
+    extern __shared__ __attribute__((aligned(16))) float lw[];   // W [3][C] | gn_a [C] | gn_o [C] of sample b0
+    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const size_t rows = (size_t)B * N;
+    const size_t row0 = (size_t)blockIdx.x * 16 * RPG;
+    const int b0 = (int)(row0 / N);
+    const int nch = C >> 2;
+    for (int i = threadIdx.x; i < 3 * nch; i += 256) reinterpret_cast<f32x4*>(lw)[i] = reinterpret_cast<const f32x4*>(W)[i];
+    if (gn_a)
+        for (int i = threadIdx.x; i < nch; i += 256) {
+            reinterpret_cast<f32x4*>(lw + 3 * C)[i] = reinterpret_cast<const f32x4*>(gn_a + (size_t)b0 * C)[i];
+            reinterpret_cast<f32x4*>(lw + 4 * C)[i] = reinterpret_cast<const f32x4*>(gn_o + (size_t)b0 * C)[i];
+        }
+    __syncthreads();
+    auto gsum = [](float v) {
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 1, 64);
+        return v;
+    };
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    // row of (group, step rr): consecutive rows go to consecutive groups, so a wave's four groups read four adjacent rows
+    auto row_of = [&](int rr) { return row0 + (size_t)rr * 16 + grp; };
+    auto load = [&](f32x4 (&v)[CPL], int rr) {
+        const size_t rraw = row_of(rr);
+        const size_t row = rraw < rows ? rraw : rows - 1;   // idle groups shadow the last row: the shuffles stay full-width
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int ch = sub + 16 * i;
+            v[i] = ch < nch ? *(reinterpret_cast<const f32x4*>(feat + row * C) + ch) : z;
+        }
+    };
+    f32x4 v[CPL], vn[CPL];
+    load(v, 0);
+#pragma unroll 1
+    for (int rr = 0; rr < RPG; ++rr) {
+        if (rr + 1 < RPG) load(vn, rr + 1);
+        const size_t row_raw = row_of(rr);
+        const bool live = row_raw < rows;
+        const size_t row = live ? row_raw : rows - 1;
+        const int b = (int)(row / N);
+        if (gn_a) {
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) {
+                const int ch = sub + 16 * i;
+                if (ch < nch) {
+                    const f32x4 ga = b == b0 ? reinterpret_cast<const f32x4*>(lw + 3 * C)[ch] : reinterpret_cast<const f32x4*>(gn_a + (size_t)b * C)[ch];
+                    const f32x4 go = b == b0 ? reinterpret_cast<const f32x4*>(lw + 4 * C)[ch] : reinterpret_cast<const f32x4*>(gn_o + (size_t)b * C)[ch];
+                    v[i] = v[i] * ga + go;
+                }
+            }
+        } else {
+            float s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) s1 += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+            const float mean = gsum(s1) / C;
+            float s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) {
+                const int ch = sub + 16 * i;
+                const f32x4 d = ch < nch ? v[i] - mean : z;
+                v[i] = d;
+                s2 += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+            }
+            const float rstd = rsqrtf(gsum(s2) / C + eps);
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) v[i] = v[i] * rstd;
+        }
+        float a[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int ch = sub + 16 * i;
+            if (ch < nch) {
+#pragma unroll
+                for (int o = 0; o < 3; ++o) {
+                    const f32x4 w = reinterpret_cast<const f32x4*>(lw + (size_t)o * C)[ch];
+                    a[o] += (v[i][0] * w[0] + v[i][1] * w[1]) + (v[i][2] * w[2] + v[i][3] * w[3]);
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 3; ++o) a[o] = gsum(a[o]);
+        if (live && sub < 3) {
+            const float Fv = (sub == 0 ? a[0] : sub == 1 ? a[1] : a[2]) + bias[sub];
+            if (raw) raw[row * 3 + sub] = Fv;
+            if (out) {
+                const float cs = coef ? coef[4 * b + 0] : 0.f, co = coef ? coef[4 * b + 1] : 1.f;
+                out[row * 3 + sub] = coef ? cs * x[row * 3 + sub] + co * Fv : Fv;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) v[i] = vn[i];
+    }
+}
+
 }  // namespace
 
 int stats_row_tile(int rows) { (void)rows; return STATS_ROWS; }
@@ -446,6 +554,31 @@ int lower_edm_launch(const float* feat, const float* x, const float* coef, const
 #define LOWER_V4(CPL)                                                                                              \
     hipLaunchKernelGGL((lower_edm_v4_kernel<CPL>), g16, dim3(256), 0, st, feat, x, coef, W, bias, gn_a, gn_o, out, raw, \
                        B, N, C, eps)
+    static int v5 = -1;
+    if (v5 < 0) {
+        const char* e = getenv("GECCO_LOWER_V5");   // 0: one row per 16-lane group (A/B runs)
+        v5 = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    constexpr int RPG = 8;
+    if (v5 && C % 4 == 0 && cpl <= 8 && rows >= 16 * RPG * 512) {   // enough 128-row blocks to fill the chip twice
+        const dim3 g5((unsigned)((rows + 16 * RPG - 1) / (16 * RPG)));
+        const size_t lds = (size_t)5 * C * sizeof(float);
+#define LOWER_V5(CPL)                                                                                              \
+    hipLaunchKernelGGL((lower_edm_v5_kernel<CPL, RPG>), g5, dim3(256), lds, st, feat, x, coef, W, bias, gn_a, gn_o, out, raw, \
+                       B, N, C, eps)
+        switch (cpl) {
+            case 1: LOWER_V5(1); break;
+            case 2: LOWER_V5(2); break;
+            case 3: LOWER_V5(3); break;
+            case 4: LOWER_V5(4); break;
+            case 5: LOWER_V5(5); break;
+            case 6: LOWER_V5(6); break;
+            case 7: LOWER_V5(7); break;
+            default: LOWER_V5(8); break;
+        }
+#undef LOWER_V5
+        return (int)hipGetLastError();
+    }
     if (C % 4 == 0 && cpl <= 8 && rows > 0) {
         switch (cpl) {
             case 1: LOWER_V4(1); break;

@@ -184,19 +184,24 @@ def _ptr_io(t: Tensor) -> C.c_void_p:
     return _ptr16(t) if t.dtype == torch.float16 else _ptr(t)
 
 
-def linear_f16io(A: Tensor, W: Tensor, bias: Tensor | None = None, act_alpha: Tensor | None = None,
+def linear_f16io(A: Tensor, W: Tensor | None, bias: Tensor | None = None, act_alpha: Tensor | None = None,
                  residual: Tensor | None = None, want_stats: bool = False, out_f16: bool = False,
-                 normalized: bool = True, out: Tensor | None = None):
-    """fp16-mode linear whose A and / or C are fp16 TENSORS (the stored intermediates of precision "fp16")."""
+                 normalized: bool = True, out: Tensor | None = None, w_image: Tensor | None = None,
+                 w_shape: tuple[int, int] | None = None):
+    """fp16-mode linear whose A and / or C are fp16 TENSORS (the stored intermediates of precision "fp16").
+    w_image: the READY fp16 image of W (autograd.WeightImages) — W may then be None, w_shape = (Nout, K)."""
     lib = _lib.load()
     B, rows, K = A.shape
-    Nout = W.shape[0]
+    Nout = W.shape[0] if W is not None else w_shape[0]
     a16 = A.dtype == torch.float16
     if out is None:
         out = torch.empty(B, rows, Nout, device=A.device, dtype=torch.float16 if out_f16 else torch.float32)
     stats = torch.empty(B, lib.gecco_linear_row_tiles(rows), 2, Nout, device=A.device) if want_stats else None
     act = 0 if act_alpha is None else (1 if normalized else 2)
-    wsplit = _ws((Nout + 127) // 128 * 128 * K * 4, A.device)
+    if w_image is not None:
+        wsplit, W = w_image, None
+    else:
+        wsplit = _ws((Nout + 127) // 128 * 128 * K * 4, A.device)
     check(lib.gecco_linear_f16io(_ptr_io(A), _ptr(W), _ptr(bias), _ptr(act_alpha), _ptr(residual), _ptr_io(out), _ptr(stats),
                                  B, rows, K, Nout, act, int(a16), int(out.dtype == torch.float16),
                                  C.c_void_p(wsplit.data_ptr()), _stream()), "gecco_linear_f16io")

@@ -165,6 +165,14 @@ int gecco_linear_act_keep_f32(const float* A, const float* W, const float* bias,
 int gecco_linear_act_keep_pro_f32(const float* A, const float* W, const float* bias, const float* pro_a, const float* pro_o,
                                   const float* alpha, int act, float* pre_out, float* C, int B, int rows, int K, int Nout,
                                   int precision, void* wsplit, void* stream);
+/* the same in fp16 arithmetic (precision 2) with act(u) STORED as fp16 (C16out: (B, rows, Nout) halves) beside the fp32
+ * pre-activation: under the reference's autocast(float16) trainer setting the hidden layer of an MLP is read again only by the
+ * matrix pipe (mlp.2's forward through gecco_linear_f16io with an fp16 A, its weight gradient through
+ * gecco_gemm_tn_f16_b16_f32) — as fp16 either way; storing it so halves its bytes.  pro_a / pro_o may be NULL; W == NULL: the fp16
+ * image of W is ready in wsplit.  rows >= 128. */
+int gecco_linear_act_keep_h16(const float* A, const float* W, const float* bias, const float* pro_a, const float* pro_o,
+                              const float* alpha, int act, float* pre_out, void* C16out, int B, int rows, int K, int Nout, void* wsplit,
+                              void* stream);
 
 /* GroupNorm partial statistics of x (B, rows, C): stats (B, T, 2, C), T = gecco_stats_row_tiles(rows). */
 int gecco_col_stats_f32(const float* x, float* stats, int B, int rows, int C, void* stream);
@@ -506,6 +514,10 @@ int gecco_gemm_tn_x3_pro_f32(const float* A, const float* Bm, const float* pro_a
  * and colsum_parts may be NULL.  The caller's GradScaler keeps dY inside fp16's range, as it does for the reference. */
 int gecco_gemm_tn_f16_f32(const float* A, const float* Bm, const float* pro_a, const float* pro_o, float* parts,
                           float* colsum_parts, int Z, int R, int N, int K, int group, void* stream);
+/* the same with B already an fp16 tensor (Z, R, K) — the hidden layer of an MLP that gecco_linear_act_keep_h16 stored that way:
+ * its tiles go to LDS as they are (no AdaGN apply) */
+int gecco_gemm_tn_f16_b16_f32(const float* A, const void* B16, float* parts, float* colsum_parts, int Z, int R, int N, int K, int group,
+                              void* stream);
 int gecco_reduce_batch_f32(const float* parts, float* out, size_t n, int Z, size_t stride, int accumulate, void* stream);
 
 /* Row softmax of the materialised attention scores: P = softmax(scale*S) over the last dim n; and its backward

@@ -372,8 +372,11 @@ def test_unpool_attn(ops, B, N, C, H, precision, tol):
     _close(ops.unpool_attn(q.cuda(), kvh.cuda(), H, precision=precision), ref, tol)
 
 
-@pytest.mark.parametrize("B,N,C", [(3, 200, 128), (2, 2048, 384)])
+@pytest.mark.parametrize("B,N,C", [(3, 200, 128), (2, 2048, 384), (33, 2000, 384), (40, 1666, 128)])
 def test_lift_lower_edm(ops, B, N, C):
+    """(33, 2000, 384), (40, 1666, 128): >= 65536 rows — the 8-rows-per-lane-group form of the lowering kernel (W and the block's
+    GroupNorm coefficients through LDS), with blocks that straddle samples and a ragged last block; its results equal the
+    one-row-per-group form's (what a single sample runs) bit for bit."""
     rs = _rs(N)
     x = _t(rs.randn(B, N, 3) * 3)
     sigma = _t(np.exp(rs.uniform(np.log(.002), np.log(165), size=B)))
@@ -395,7 +398,15 @@ def test_lift_lower_edm(ops, B, N, C):
     st = ops.col_stats(feat)
     a, o = ops.adagn_coeffs(st, N, None, None, 16)
     F2 = F.linear(cpu_ref.group_norm_bnc(feat_ref, 16), Wo, bo)
-    _close(ops.lower_edm(feat, None, None, Wo.cuda(), bo.cuda(), gn=(a, o)), F2)
+    got2 = ops.lower_edm(feat, None, None, Wo.cuda(), bo.cuda(), gn=(a, o))
+    _close(got2, F2)
+    if B * N >= 65536:
+        for b in (0, B // 2, B - 1):
+            o1, r1 = ops.lower_edm(feat[b:b + 1].contiguous(), x[b:b + 1].cuda(), coef.view(-1)[4 * b:4 * b + 4].contiguous(), Wo.cuda(), bo.cuda(),
+                                   want_raw=True)
+            assert torch.equal(o1[0], out[b]) and torch.equal(r1[0], raw[b])
+            g1 = ops.lower_edm(feat[b:b + 1].contiguous(), None, None, Wo.cuda(), bo.cuda(), gn=(a[b:b + 1].contiguous(), o[b:b + 1].contiguous()))
+            assert torch.equal(g1[0], got2[b])
 
 
 @pytest.mark.parametrize("B,rows,K,Nout,act", [(2, 512, 384, 768, "gauss"), (1, 256, 256, 512, "relu"), (3, 256, 128, 256, "none"),

@@ -109,6 +109,12 @@ SIGNATURES = {
     "gecco_gemm_tn_x3_pro_f32": (i, [vp, vp, vp, vp, vp, vp, i, i, i, i, i, vp]),
     "gecco_gemm_tn_f16_f32": (i, [vp, vp, vp, vp, vp, vp, i, i, i, i, i, vp]),
     "gecco_gemm_tn_f16_b16_f32": (i, [vp, vp, vp, vp, i, i, i, i, i, vp]),
+    "gecco_astat16_image_bytes": (sz, [i, i]),
+    "gecco_linear_astat16_ok": (i, [i, i, i]),
+    "gecco_astat16_images_f32": (i, [C.POINTER(GeccoSplitJob), i, vp]),
+    "gecco_linear_astat16_f32": (i, [vp] * 5 + [i, vp, vp, vp, i, vp, i, i, i, i, vp, vp]),
+    "gecco_linear_astat16_keep": (i, [vp] * 6 + [i, vp, vp, i, i, i, i, vp, vp]),
+    "gecco_linear_astat16_actbwd": (i, [vp] * 4 + [i, vp, vp, i, i, i, i, vp, vp]),
     "gecco_linear_act_keep_h16": (i, [vp] * 6 + [i, vp, vp, i, i, i, i, vp, vp]),
     "gecco_set_option": (i, [C.c_char_p, i]),
     "gecco_linear_astat_f16": (i, [vp, vp, vp, vp, vp, i, vp, vp, vp, i, vp, vp, i, i, i, i, i, vp, vp]),

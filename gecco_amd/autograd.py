@@ -118,12 +118,16 @@ class WeightImages:
         prec: "bf16x3" (default: the training precision) or "fp16" — the fp16 images of the autocast(float16) setting are
         their own entries (kind + "16")."""
         prec = _train_precision() if prec is None else prec
-        if prec not in ("bf16x3", "fp16"):
+        if prec not in ("bf16x3", "fp16", "a16"):
             return None
         if prec == "fp16":
             if any(w.shape[-1] % 32 for w in ws) or (kind == "t" and ws[0].shape[0] % 32):
                 return None
             kind = kind + "16"
+        elif prec == "a16":   # the A-stationary fp16 kernels' streams (gecco_astat16_images_f32): 64-column tiles, 64-k groups
+            if any(w.shape[0] % 64 or w.shape[1] % 64 for w in ws):
+                return None
+            kind = kind + "a16"
         key = self._key(kind, *ws)
         self.used[key] = self.step
         if self.armed:
@@ -169,22 +173,23 @@ class WeightImages:
         jobs, offs, total = [], {}, 0
         for key, ws in self.plan.items():
             kind = key[0]
-            f16 = kind.endswith("16")
+            fmt = 2 if kind.endswith("a16") else 1 if kind.endswith("16") else 0
             tr = kind.startswith("t")
             nbytes = 0
             for w in ws:
                 nout, k = (w.shape[1], w.shape[0]) if tr else (w.shape[0], w.shape[1])
-                jobs.append((key, w, nout, k, tr, total + nbytes, f16))
-                nbytes += lib.gecco_split_f16_image_bytes(nout, k) if f16 else lib.gecco_split_bf16_image_bytes(nout, k)
+                jobs.append((key, w, nout, k, tr, total + nbytes, fmt))
+                nbytes += (lib.gecco_split_bf16_image_bytes, lib.gecco_split_f16_image_bytes, lib.gecco_astat16_image_bytes)[fmt](nout, k)
             offs[key] = (total, nbytes)
             total += (nbytes + 255) // 256 * 256
         dev = jobs[0][1].device
         if self.pool is None or self.pool.numel() < total or self.pool.device != dev:
             self.pool = torch.empty(total, dtype=torch.uint8, device=dev)
         base = self.pool.data_ptr()
-        for want16, fn, name in ((False, lib.gecco_split_bf16_images_f32, "gecco_split_bf16_images_f32"),
-                                 (True, lib.gecco_split_f16_images_f32, "gecco_split_f16_images_f32")):
-            sel = [j for j in jobs if j[6] == want16]
+        for fmt, fn, name in ((0, lib.gecco_split_bf16_images_f32, "gecco_split_bf16_images_f32"),
+                              (1, lib.gecco_split_f16_images_f32, "gecco_split_f16_images_f32"),
+                              (2, lib.gecco_astat16_images_f32, "gecco_astat16_images_f32")):
+            sel = [j for j in jobs if j[6] == fmt]
             if not sel:
                 continue
             arr = (_lib.GeccoSplitJob * len(sel))()
@@ -222,6 +227,12 @@ def _linear_dx(dy: Tensor, W: Tensor, residual: Tensor | None = None, prec: str 
     B, R, Nout = dy.shape
     K = W.shape[1]
     prec = _resolve(prec, R, Nout, K)
+    if residual is None and _a16_ok(prec, R, Nout, K):
+        dx = _new(B, R, K, like=dy)
+        ws, ready = _a16_stream("t", W, dev=dy.device)
+        _lib.check(_lib.load().gecco_linear_astat16_f32(_ptr(dy), None, None, None if ready else _ptr(_f(W)), None, K, _ptr(dx), None, None, 0, None,
+                                                        1, B, R, Nout, C.c_void_p(ws.data_ptr()), _stream()), "gecco_linear_astat16_f32")
+        return dx
     if R >= 64 and Nout % 16 == 0 and K % 4 == 0:
         # linear(dy, W^T): the fused LDS-DMA GEMM; the image of W^T comes ready from the step's batched launch when it is
         # there (WeightImages), else from a transposed copy of the (small) weight
@@ -533,6 +544,17 @@ class AdaGNPairFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         a, o, stats, t2 = _adagn_coeffs(x, t, sw, sb, bw, bb, G, eps, stats)
         prec = ctx.prec = _lin_precision()   # "bf16x3" or "fp16" (_pro_ok)
+        B, R, K = x.shape
+        N1, N2 = W1.shape[0], W2.shape[0]
+        if _a16_ok(prec, R, K, N1 + N2) and N1 % 64 == 0 and N2 % 64 == 0:
+            KV, q = _new(B, R, N1, like=x), _new(B, R, N2, like=x)
+            ws, ready = _a16_stream("pair", W1, W2, dev=x.device)
+            _lib.check(_lib.load().gecco_linear_astat16_f32(_ptr(x), _ptr(a), _ptr(o), None if ready else _ptr(_f(W1)), None, N1, _ptr(KV),
+                                                            None if ready else _ptr(_f(W2)), _ptr(b2), N2, _ptr(q), 0, B, R, K,
+                                                            C.c_void_p(ws.data_ptr()), _stream()), "gecco_linear_astat16_f32")
+            ctx.save_for_backward(x, stats, t2, sw, sb, a, o, W1, W2)
+            ctx.G, ctx.eps, ctx.has_b2 = G, eps, b2 is not None
+            return KV, q, x
         img = WEIGHT_IMAGES.lookup("pair", W1, W2, prec=prec)
         if img is not None:
             KV, q = hip_ops.linear_pair(x, W1, None, W2, b2, pro=(a, o), precision=prec, w_image=img)
@@ -651,6 +673,16 @@ def _act_linear_dx(dy: Tensor, u: Tensor, h: Tensor, alpha: Tensor, W: Tensor, k
     dalpha = None
     fused = (os.environ.get("GECCO_TRAIN_ACTBWD", "1") != "0" and prec in ("fp32", "bf16x3", "fp16")
              and lib.gecco_linear_actbwd_ok(R, Nout, K, hip_ops.PRECISIONS[prec]))
+    if fused and kind in (1, 2, 3) and _a16_ok(prec, R, Nout, K):
+        du = torch.empty_like(u)
+        parts = _new(B * R // 128, like=u) if kind in (1, 2) else None
+        ws, ready = _a16_stream("t", W, dev=u.device)
+        _lib.check(lib.gecco_linear_astat16_actbwd(_ptr(dy), None if ready else _ptr(_f(W)), _ptr(u), _ptr(alpha) if kind in (1, 2) else None, kind,
+                                                   _ptr(du), _ptr(parts), B, R, Nout, K, C.c_void_p(ws.data_ptr()), _stream()),
+                   "gecco_linear_astat16_actbwd")
+        if kind in (1, 2) and want_alpha:
+            dalpha = _reduce(parts, 1, B * R // 128, 1).reshape(alpha.shape)
+        return du, dalpha
     if fused:
         du = torch.empty_like(u)
         nt = lib.gecco_linear_actbwd_tiles(B, R, K)
@@ -702,6 +734,24 @@ def _linear_fwd(x: Tensor, W: Tensor, b, res, want_stats: bool, prec: str | None
     return hip_ops.linear(x, None if img is not None else W, b, residual=res, want_stats=want_stats, **kw)
 
 
+def _a16_ok(prec: str, R: int, K: int, Nout: int) -> bool:
+    """The A-stationary fp16 kernels (gecco_linear_astat16_*) take this product: the autocast(float16) arithmetic, whole 128-row blocks,
+    an operand of <= 512 columns held in registers, 64-column output tiles.  GECCO_TRAIN_A16=0: the LDS-DMA GEMM instead."""
+    return (prec == "fp16" and os.environ.get("GECCO_TRAIN_A16", "1") != "0"
+            and bool(_lib.load().gecco_linear_astat16_ok(R, K, Nout)))
+
+
+def _a16_stream(kind: str, *ws: Tensor, dev) -> tuple[Tensor, bool]:
+    """(wsplit, ready): the step's batched stream of these weights if it is there, else scratch the entry point fills itself."""
+    img = WEIGHT_IMAGES.lookup(kind, *ws, prec="a16")
+    if img is not None:
+        return img, True
+    lib = _lib.load()
+    tr = kind == "t"
+    nbytes = sum(lib.gecco_astat16_image_bytes(w.shape[1] if tr else w.shape[0], w.shape[0] if tr else w.shape[1]) for w in ws)
+    return hip_ops._ws(nbytes, dev), False
+
+
 def _h16_ok(prec: str, R: int, K0: int, N0: int, Nout2: int, pro: bool) -> bool:
     """Under the autocast(float16) arithmetic the hidden layer h = act(u) of an MLP is read again only by the matrix pipe — the
     second linear's forward and its weight gradient — as an fp16 operand either way (the reference's autocast stores it as fp16
@@ -719,6 +769,13 @@ def _keep_h16(x: Tensor, W0: Tensor, b0, pro, alpha, kind: int) -> tuple[Tensor,
     B, R, K0 = x.shape
     N0 = W0.shape[0]
     u, h = _new(B, R, N0, like=x), torch.empty(B, R, N0, device=x.device, dtype=torch.float16)
+    if kind in (1, 2, 3) and _a16_ok("fp16", R, K0, N0):
+        ws, ready = _a16_stream("n", W0, dev=x.device)
+        _lib.check(lib.gecco_linear_astat16_keep(_ptr(x), _ptr(pro[0]) if pro else None, _ptr(pro[1]) if pro else None,
+                                                 None if ready else _ptr(_f(W0)), _ptr(b0), _ptr(alpha) if kind in (1, 2) else None, kind,
+                                                 _ptr(u), C.c_void_p(h.data_ptr()), B, R, K0, N0, C.c_void_p(ws.data_ptr()), _stream()),
+                   "gecco_linear_astat16_keep")
+        return u, h
     img = WEIGHT_IMAGES.lookup("n", W0, prec="fp16")
     Wp, ws = (None, img) if img is not None else (_f(W0), hip_ops._ws((N0 + 127) // 128 * 128 * K0 * 2, x.device))
     _lib.check(lib.gecco_linear_act_keep_h16(_ptr(x), _ptr(Wp), _ptr(b0), _ptr(pro[0]) if pro else None, _ptr(pro[1]) if pro else None,

@@ -845,6 +845,100 @@ int gecco_linear_act_keep_pro_f32(const float* A, const float* W, const float* b
     return 0;
 }
 
+/* ---- A-stationary fp16 linears with fp32 tensors: the training path's 384-wide products under autocast(float16) (gemm_h8_astat.hip,
+ * OUT forms of gemm_kvq_astat_kernel) ---- */
+size_t gecco_astat16_image_bytes(int Nout, int K) { return (Nout % 64 || K % 64) ? 0 : kvq_image_bytes(Nout, K, 0); }
+int gecco_linear_astat16_ok(int rows, int K, int Nout) {
+    return rows >= 128 && rows % 128 == 0 && (K == 128 || K == 256 || K == 384 || K == 512) && Nout % 64 == 0 && Nout >= 128 && Nout <= 4096;
+}
+int gecco_astat16_images_f32(const GeccoSplitJob* jobs, int n, void* stream) {
+    if (n < 0 || (n > 0 && !jobs)) return fail(-1, "astat16_images: null argument");
+    SplitJobs sj;
+    sj.n = 0;
+    for (int i = 0; i < n; ++i) {
+        const GeccoSplitJob& j = jobs[i];
+        if (!j.W || !j.img || j.Nout <= 0 || (j.Nout % 64) || (j.K % 64) || j.K <= 0 || (!j.transposed && (j.ldw & 3)))
+            return fail(-2, "astat16_images: job %d needs Nout %% 64 == 0, K %% 64 == 0 (and ldw %% 4 == 0 unless transposed)", i);
+        sj.job[sj.n++] = SplitJob{j.W, static_cast<float*>(j.img), j.Nout, j.K, j.ldw, j.transposed ? 5 : 1};
+        if (sj.n == 96) {
+            TRY(h8_image_multi_launch(sj, (hipStream_t)stream), "astat16_images");
+            sj.n = 0;
+        }
+    }
+    TRY(h8_image_multi_launch(sj, (hipStream_t)stream), "astat16_images");
+    return 0;
+}
+
+int gecco_linear_astat16_f32(const float* x, const float* pro_a, const float* pro_o, const float* W1, const float* bias1, int Nout1, float* C1,
+                             const float* W2, const float* bias2, int Nout2, float* C2, int transposed, int B, int rows, int K, void* wsplit,
+                             void* stream) {
+    if (!x || !C1 || !wsplit || (Nout2 > 0 && !C2)) return fail(-1, "linear_astat16: null argument");
+    if ((pro_a == nullptr) != (pro_o == nullptr)) return fail(-1, "linear_astat16: pro_a / pro_o must both be set");
+    if (Nout2 > 0 && ((W1 == nullptr) != (W2 == nullptr))) return fail(-1, "linear_astat16: W1 / W2 both given or both ready");
+    hipStream_t s = (hipStream_t)stream;
+    GemmArgs g{};
+    g.A = x; g.pro_a = pro_a; g.pro_o = pro_o; g.bias = bias1; g.C = C1;
+    g.B = B; g.rows = rows; g.K = K; g.Nout = Nout1 + (Nout2 > 0 ? Nout2 : 0); g.lda = K; g.ldw = K; g.ldc = Nout1; g.ldr = Nout1;
+    g.precision = 2; g.w_img = wsplit;
+    if (Nout2 > 0) { g.C2 = C2; g.bias2 = bias2; g.n_split = Nout1; g.ldc2 = Nout2; }
+    if (!gemm_astat_train_supported(g))
+        return fail(-2, "linear_astat16: needs rows %% 128 == 0, K in {128, 256, 384, 512}, Nout (each segment) %% 64 == 0, Nout >= 128");
+    if (W1) {
+        if (transposed && Nout2 > 0) return fail(-2, "linear_astat16: the transposed form takes one weight");
+        SplitJobs jobs;
+        jobs.n = 0;
+        float* img = static_cast<float*>(wsplit);
+        jobs.job[jobs.n++] = SplitJob{W1, img, Nout1, K, transposed ? Nout1 : K, transposed ? 5 : 1};
+        if (Nout2 > 0) jobs.job[jobs.n++] = SplitJob{W2, img + kvq_image_bytes(Nout1, K, 0) / sizeof(float), Nout2, K, K, 1};
+        TRY(h8_image_multi_launch(jobs, s), "linear_astat16(image)");
+    }
+    TRY(gemm_astat_train_launch(g, s), "linear_astat16");
+    return 0;
+}
+
+int gecco_linear_astat16_keep(const float* x, const float* pro_a, const float* pro_o, const float* W, const float* bias, const float* alpha,
+                              int act, float* pre_out, void* C16out, int B, int rows, int K, int Nout, void* wsplit, void* stream) {
+    if (!x || !pre_out || !C16out || !wsplit) return fail(-1, "linear_astat16_keep: null argument");
+    if ((pro_a == nullptr) != (pro_o == nullptr)) return fail(-1, "linear_astat16_keep: pro_a / pro_o must both be set");
+    if ((act == 1 || act == 2) && !alpha) return fail(-1, "linear_astat16_keep: GaussianActivation needs alpha");
+    hipStream_t s = (hipStream_t)stream;
+    GemmArgs g{};
+    g.A = x; g.pro_a = pro_a; g.pro_o = pro_o; g.bias = bias; g.alpha = alpha; g.act = act; g.C = static_cast<float*>(C16out); g.pre_out = pre_out;
+    g.B = B; g.rows = rows; g.K = K; g.Nout = Nout; g.lda = K; g.ldw = K; g.ldc = Nout; g.ldr = Nout;
+    g.precision = 2; g.w_img = wsplit;
+    if (!gemm_astat_train_supported(g))
+        return fail(-2, "linear_astat16_keep: needs rows %% 128 == 0, K in {128, 256, 384, 512}, Nout %% 64 == 0, act 1 / 2 (GaussianActivation) or 3 (ReLU)");
+    if (W) {
+        SplitJobs jobs;
+        jobs.n = 1;
+        jobs.job[0] = SplitJob{W, static_cast<float*>(wsplit), Nout, K, K, 1};
+        TRY(h8_image_multi_launch(jobs, s), "linear_astat16_keep(image)");
+    }
+    TRY(gemm_astat_train_launch(g, s), "linear_astat16_keep");
+    return 0;
+}
+
+int gecco_linear_astat16_actbwd(const float* dy, const float* W, const float* u, const float* alpha, int kind, float* C, float* agrad, int B,
+                                int rows, int K, int Nout, void* wsplit, void* stream) {
+    if (!dy || !u || !C || !wsplit) return fail(-1, "linear_astat16_actbwd: null argument");
+    if ((kind == 1 || kind == 2) && (!alpha || !agrad)) return fail(-1, "linear_astat16_actbwd: GaussianActivation needs alpha and the agrad partials");
+    hipStream_t s = (hipStream_t)stream;
+    GemmArgs g{};
+    g.A = dy; g.alpha = alpha; g.C = C; g.mul_u = u; g.mul_kind = kind; g.agrad = (kind == 1 || kind == 2) ? agrad : nullptr;
+    g.B = B; g.rows = rows; g.K = K; g.Nout = Nout; g.lda = K; g.ldw = K; g.ldc = Nout; g.ldr = Nout;
+    g.precision = 2; g.w_img = wsplit;
+    if (!gemm_astat_train_supported(g))
+        return fail(-2, "linear_astat16_actbwd: needs rows %% 128 == 0, K in {128, 256, 384, 512}, Nout %% 64 == 0, kind 1 / 2 (GaussianActivation) or 3 (ReLU)");
+    if (W) {   // the linear's own weight (K, Nout): the stream of its transpose, straight from it
+        SplitJobs jobs;
+        jobs.n = 1;
+        jobs.job[0] = SplitJob{W, static_cast<float*>(wsplit), Nout, K, Nout, 5};
+        TRY(h8_image_multi_launch(jobs, s), "linear_astat16_actbwd(image)");
+    }
+    TRY(gemm_astat_train_launch(g, s), "linear_astat16_actbwd");
+    return 0;
+}
+
 int gecco_linear_act_keep_h16(const float* A, const float* W, const float* bias, const float* pro_a, const float* pro_o,
                               const float* alpha, int act, float* pre_out, void* C16out, int B, int rows, int K, int Nout, void* wsplit,
                               void* stream) {

@@ -50,6 +50,19 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int H_BN = 64;           // columns per W tile
+inline bool act_gauss_host(int act) { return act == 1 || act == 2; }
+// the training forms' activations: GaussianActivation (1 normalized / 2 raw) and ReLU (3) — common.h's expressions without the GELU
+// branch (its erf expansion on 32 values per tile does not fit beside the stationary operand)
+__device__ __forceinline__ float tr_act(float u, float neg_inv_2a2, int act) {
+    return act == 3 ? fmaxf(u, 0.f) : gauss_act(u, neg_inv_2a2, act == 1);
+}
+__device__ __forceinline__ float tr_act_prime(float u, float neg_inv_2a2, float inv_a2, int kind, float& dalpha) {
+    dalpha = 0.f;
+    if (kind == 3) return u > 0.f ? 1.f : 0.f;
+    const float E = __expf(u * u * neg_inv_2a2) * (kind == 1 ? 1.0f / 0.28f : 1.0f);
+    dalpha = E * (u * u * inv_a2);
+    return E * (-u * inv_a2);
+}
 constexpr int H_STAGE = 2048;      // floats per 8 KiB ring stage (two 4 KiB sub-tiles)
 constexpr int H_STG = 1536;        // floats of a wave's staging tile: [32][64] fp16 (4 KiB) + [32][64] fp8 (2 KiB)
 constexpr int H_STORES = 8;        // store instructions of a wave's epilogue per column tile
@@ -162,6 +175,8 @@ __device__ __forceinline__ void h8_image_item(const float* __restrict__ W, float
 // two-term weights of the mixed mode where their rounding reaches the output, one-term elsewhere.
 // Stage index of tile ct: ct * NG + (NG / 2) * clamp(ct - lo_begin, 0, lo_end - lo_begin).  1024 chunks per (ct, pair of H stages
 // or L stage): item i -> (tile, stage-in-tile, sub-tile, row, physical chunk).
+// TR (the training path's dX products, one-term only): W is (K, ldw) and the stream is that of W^T — eight strided reads per chunk
+template <bool TR = false>
 __device__ __forceinline__ void kvq_image_item(const float* __restrict__ W, float* __restrict__ img, int Nout, int K, int ldw, int lo_begin,
                                                int lo_end, size_t i) {
     const int NG = K / 64;
@@ -178,8 +193,19 @@ __device__ __forceinline__ void kvq_image_item(const float* __restrict__ W, floa
     const int nn = min(ct * H_BN + n, Nout - 1);
     u32x4 out;
     if (kt < NG) {
-        const float* src = W + (size_t)nn * ldw + 64 * kt + 32 * sub + 8 * q;
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(src), w1 = *reinterpret_cast<const f32x4*>(src + 4);
+        f32x4 w0, w1;
+        if (TR) {
+            const float* src = W + (size_t)(64 * kt + 32 * sub + 8 * q) * ldw + nn;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                w0[e] = src[(size_t)e * ldw];
+                w1[e] = src[(size_t)(4 + e) * ldw];
+            }
+        } else {
+            const float* src = W + (size_t)nn * ldw + 64 * kt + 32 * sub + 8 * q;
+            w0 = *reinterpret_cast<const f32x4*>(src);
+            w1 = *reinterpret_cast<const f32x4*>(src + 4);
+        }
         f16x8 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -204,12 +230,17 @@ __device__ __forceinline__ void kvq_image_item(const float* __restrict__ W, floa
 
 // SplitJob::pad_ = 0: the h8 stream of mlp.0 (64-column tiles); 2: the same in 128-column tiles (gemm_h8_areg.hip); 16: 64-column
 // tiles in the attention accumulator's k order (unpool_outproj_h8.hip);
-// pad_ = 1 | lo_begin << 8 | lo_end << 20 (64-column tiles): the kv | q stream
+// pad_ = 1 | lo_begin << 8 | lo_end << 20 (64-column tiles): the kv | q stream; | 4: of W^T, from W (K, ldw) (one-term)
 __global__ void h8_image_multi_kernel(SplitJobs jobs) {
     const SplitJob j = jobs.job[blockIdx.y];
     if (j.pad_ & 1) {
         const int lb = (j.pad_ >> 8) & 0xFFF, le = (j.pad_ >> 20) & 0xFFF, NG = j.K / 64;
         const size_t total = ((size_t)(j.Nout / H_BN) * NG + (size_t)(le - lb) * (NG / 2)) * 512;
+        if (j.pad_ & 4) {   // the stream of W^T from W (K, ldw): one-term (lb == le)
+            for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+                kvq_image_item<true>(j.W, j.img, j.Nout, j.K, j.ldw, lb, lb, i);
+            return;
+        }
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
             kvq_image_item(j.W, j.img, j.Nout, j.K, j.ldw, lb, le, i);
         return;
@@ -612,9 +643,19 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_h8_astat_kernel(GemmArgs g) {
 // stream is kvq_image_item's.  Tiles have NG stages (K, q) or 3 NG / 2 (V), so the ring slot is a running counter (scalar
 // arithmetic; the fragment addresses take one vector add per sub-step).  Epilogue: fp16 pairs, one v_permlane32_swap per
 // register pair, 16-byte stores (8 consecutive columns of one row = one piece of a head's (rows, hd) slab).
-template <int NG, int NS>
+//
+// OUT (the training path under the reference's autocast(float16) setting, autograd.py `_lin_precision`; fp32 tensors, one-term weights):
+//   1  C (| C2) = y W^T + bias as fp32, row-major — AdaGN(x) -> K | V and q (set_transformer.py:161-162 -> :49, :112) and any other
+//      product out of a <= 512-wide operand: a lane holds 4 consecutive columns of ONE row per accumulator quad, so the fp32
+//      epilogue is plain 16-byte stores (lane halves write adjacent pieces), no exchange;
+//   2  pre_out = u = y W^T + bias (fp32) and C = fp16(act(u)): the first linear of an MLP in training (models/mlp.py:5-39), its
+//      hidden layer stored as halves (the matrix pipe reads it again as fp16 either way);
+//   3  C = (y W^T) * act'(u), u = mul_u (fp32), + the alpha-gradient partial of the block: the dX product through an activation
+//      (autograd of mlp.py's Linear -> act).  The u rows of the NEXT tile are loaded during the epilogue of this one.
+template <int NG, int NS, int OUT = 0>
 __global__ __launch_bounds__(256, 2) void gemm_kvq_astat_kernel(GemmArgs g) {
-    constexpr int K = 64 * NG, NT = 256, NW = 4, ROWS = 128, PW = 2, KV_STORES = 4;
+    constexpr int K = 64 * NG, NT = 256, NW = 4, ROWS = 128, PW = 2;
+    constexpr int KV_STORES = OUT == 0 ? 4 : OUT == 1 ? 8 : OUT == 2 ? 12 : 16;   // vector-memory instructions of one epilogue
     static_assert(NS >= 4 && NG % 2 == 0 && NS - 2 <= NG, "lookahead NS - 1 >= 3 stages; L stages hold two groups; one epilogue's stores in flight");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* ring = smem;                                // [NS][H_STAGE]
@@ -724,8 +765,86 @@ __global__ __launch_bounds__(256, 2) void gemm_kvq_astat_kernel(GemmArgs g) {
     const int mrow = m0 + wave * 32 + r;
     const unsigned hm_magic = g.hm_hd ? (1u << 20) / (unsigned)g.hm_hd + 1u : 0u;
     f32x16 acc[2];
+    // OUT 3: the pre-activation rows of the tile being multiplied (8 x 16 bytes per lane), its activation constants, the lane's
+    // share of the alpha gradient
+    f32x4 uq[OUT == 3 ? 8 : 1];
+    float ga = 0.f;
+    const int act_code = OUT == 2 ? g.act : OUT == 3 ? g.mul_kind : 0;
+    const float alpha0 = (OUT >= 2 && act_is_gauss(act_code)) ? g.alpha[0] : 1.f;
+    const float neg_inv_2a2 = -1.0f / (2.0f * alpha0 * alpha0), inv_a2 = 1.0f / (alpha0 * alpha0);
+    auto load_u = [&](int ct) {
+        if constexpr (OUT == 3) {
+            const int ctc = min(ct, tilesN - 1);   // past the last tile: a harmless re-read (keeps the instruction count static)
+            const float* ub = g.mul_u + ((size_t)b * g.rows + mrow) * g.ldc + ctc * H_BN + 4 * h;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) uq[4 * j + q] = *reinterpret_cast<const f32x4*>(ub + 32 * j + 8 * q);
+        }
+    };
     auto epilogue = [&](int ct) {
         const int n0 = ct * H_BN;
+        if constexpr (OUT != 0) {
+            const bool s2 = g.C2 != nullptr && n0 >= g.n_split;
+            float* Cf = s2 ? g.C2 : g.C;
+            const int ldcf = s2 ? g.ldc2 : g.ldc;
+            const int ns0 = s2 ? n0 - g.n_split : n0;
+            float* dstf = (OUT == 2 ? g.pre_out : Cf) + ((size_t)b * g.rows + mrow) * (OUT == 2 ? g.Nout : ldcf) + (OUT == 2 ? n0 : ns0) + 4 * h;
+            f32x4 v[OUT == 2 ? 8 : 1];
+            // one accumulator quad at a time (bias, the activation's derivative, store): the scheduler would otherwise put all 32
+            // exponentials of the tile in flight at once, ~100 registers the stationary operand does not leave
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 bs = *reinterpret_cast<const f32x4*>(bias_lds + n0 + 32 * j + 8 * q + 4 * h);
+                    f32x4 w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = acc[j][4 * q + e] + bs[e];
+                    if constexpr (OUT == 3) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float da;
+                            const float f = tr_act_prime(uq[4 * j + q][e], neg_inv_2a2, inv_a2, act_code, da);
+                            ga += w[e] * da;
+                            w[e] *= f;
+                        }
+                    }
+                    *reinterpret_cast<f32x4*>(dstf + 32 * j + 8 * q) = w;
+                    if constexpr (OUT == 2) v[4 * j + q] = w;
+                    if constexpr (OUT == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            if constexpr (OUT == 3) load_u(ct + 1);
+            if constexpr (OUT == 2) {   // act(u) as halves: the fp16 epilogue's exchange (8 consecutive columns per lane, 16-byte stores)
+                _Float16* Hb = reinterpret_cast<_Float16*>(g.C);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    unsigned pk[4][2];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f16x2 a, c;
+                        a[0] = (_Float16)tr_act(v[4 * j + q][0], neg_inv_2a2, act_code);
+                        a[1] = (_Float16)tr_act(v[4 * j + q][1], neg_inv_2a2, act_code);
+                        c[0] = (_Float16)tr_act(v[4 * j + q][2], neg_inv_2a2, act_code);
+                        c[1] = (_Float16)tr_act(v[4 * j + q][3], neg_inv_2a2, act_code);
+                        pk[q][0] = __builtin_bit_cast(unsigned, a);
+                        pk[q][1] = __builtin_bit_cast(unsigned, c);
+                    }
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        u32x4 O;
+#pragma unroll
+                        for (int d = 0; d < 2; ++d) {
+                            const auto sh = __builtin_amdgcn_permlane32_swap(pk[2 * p][d], pk[2 * p + 1][d], false, false);
+                            O[d] = sh[0];
+                            O[2 + d] = sh[1];
+                        }
+                        *reinterpret_cast<u32x4*>(Hb + ((size_t)b * g.rows + mrow) * g.Nout + n0 + 32 * j + 16 * p + 8 * h) = O;
+                    }
+                }
+            }
+            return;
+        }
         const bool seg2 = g.C2 != nullptr && n0 >= g.n_split;
         _Float16* Cb = reinterpret_cast<_Float16*>(seg2 ? g.C2 : g.C);
         const int ldc = seg2 ? g.ldc2 : g.ldc;
@@ -776,6 +895,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kvq_astat_kernel(GemmArgs g) {
     };
 
     HSTAMP(1);
+    load_u(0);
     dma::wait_vm_lgkm0<0>();
     __builtin_amdgcn_s_barrier();
     int slot = 0;                                      // slot of the current stage
@@ -874,17 +994,27 @@ __global__ __launch_bounds__(256, 2) void gemm_kvq_astat_kernel(GemmArgs g) {
     if (acc[0][0] == 123.456f) epilogue(0);
 #endif
     dma::wait_vm_lgkm0<0>();
+    if constexpr (OUT == 3) {
+        if (g.agrad && act_is_gauss(act_code)) {   // (block-uniform) lanes, then the four waves, in a fixed order: one partial per block
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) ga += __shfl_xor(ga, o, 64);
+            __syncthreads();                       // the ring is dead
+            if (lane == 0) ring[wave] = ga;
+            __syncthreads();
+            if (tid == 0) g.agrad[bid] = (((ring[0] + ring[1]) + ring[2]) + ring[3]) / alpha0;
+        }
+    }
 }
 
-template <int NG, int NS>
+template <int NG, int NS, int OUT = 0>
 int kvq_launch_t(const GemmArgs& g, hipStream_t st) {
     const size_t lds = ((size_t)NS * H_STAGE + 4 * 1024 + g.Nout + 2 * g.K) * sizeof(float);
     static size_t attr = 0;
     if (lds > attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kvq_astat_kernel<NG, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kvq_astat_kernel<NG, NS, OUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = lds;
     }
-    hipLaunchKernelGGL((gemm_kvq_astat_kernel<NG, NS>), dim3(g.B * (g.rows / 128)), dim3(256), lds, st, g);
+    hipLaunchKernelGGL((gemm_kvq_astat_kernel<NG, NS, OUT>), dim3(g.B * (g.rows / 128)), dim3(256), lds, st, g);
     return (int)hipGetLastError();
 }
 
@@ -953,6 +1083,39 @@ bool gemm_kvq_astat_supported(const GemmArgs& g) {
            ((g.pro_a == nullptr) == (g.pro_o == nullptr)) && g.lo_begin >= 0 && g.lo_tiles >= g.lo_begin && g.lo_tiles <= g.Nout / H_BN &&
            (!g.hm_hd || (g.hm_hd >= 8 && !(g.hm_hd & 7) && g.Nout < (1 << 20) / g.hm_hd && !((g.C2 ? g.n_split : g.Nout) % g.hm_hd) &&
                          !((g.C2 ? g.Nout - g.n_split : 0) % g.hm_hd)));
+}
+
+// the training forms (OUT 1 / 2 / 3 above): fp32 C (| C2), or pre_out + fp16 C, or mul_u; one-term weights, row-major
+bool gemm_astat_train_supported(const GemmArgs& g) {
+    const bool keep = g.pre_out != nullptr, abw = g.mul_u != nullptr;
+    if (keep && abw) return false;
+    return !g.c_f16 && !g.a_f16 && !g.a_img && !g.c_img && !g.residual && !g.stats && g.w_img && g.rows >= 128 && !(g.rows % 128) && !(g.Nout % H_BN) &&
+           g.Nout >= 2 * H_BN && g.Nout <= 4096 && (g.K == 128 || g.K == 256 || g.K == 384 || g.K == 512) && !(g.lda & 3) && !(g.ldc & 3) &&
+           (!g.C2 || (!keep && !abw && !(g.n_split % H_BN) && !(g.ldc2 & 3) && g.n_split > 0 && g.n_split < g.Nout)) &&
+           ((g.pro_a == nullptr) == (g.pro_o == nullptr)) && g.lo_begin == 0 && g.lo_tiles == 0 && !g.hm_hd &&
+           (keep ? (g.act >= 1 && g.act <= 3 && g.ldc == g.Nout) : g.act == 0) &&
+           (!abw || (g.mul_kind >= 1 && g.mul_kind <= 3 && !g.bias && !g.pro_a && g.ldc == g.Nout)) &&
+           (!((keep && act_gauss_host(g.act)) || (abw && act_gauss_host(g.mul_kind))) || g.alpha);
+}
+
+template <int OUT>
+int astat_train_launch_o(const GemmArgs& g, hipStream_t st) {
+    switch (g.K) {
+        case 128: return kvq_launch_t<2, 4, OUT>(g, st);
+        case 256: return kvq_launch_t<4, 6, OUT>(g, st);
+        case 384: return kvq_launch_t<6, 6, OUT>(g, st);
+        case 512: return kvq_launch_t<8, 6, OUT>(g, st);
+        default: return -9;
+    }
+}
+
+int gemm_astat_train_launch(const GemmArgs& g0, hipStream_t st) {
+    if (!gemm_astat_train_supported(g0)) return -9;
+    GemmArgs g = g0;
+    g.h8_rev = 0;
+    if (g.pre_out) return astat_train_launch_o<2>(g, st);
+    if (g.mul_u) return astat_train_launch_o<3>(g, st);
+    return astat_train_launch_o<1>(g, st);
 }
 
 int gemm_kvq_astat_launch(const GemmArgs& g0, hipStream_t st) {

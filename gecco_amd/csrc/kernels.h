@@ -200,6 +200,9 @@ bool gemm_h8_astat_supported(const GemmArgs& g);
 size_t kvq_image_bytes(int Nout, int K, int lo_cols);
 bool gemm_kvq_astat_supported(const GemmArgs& g);
 int gemm_kvq_astat_launch(const GemmArgs& g, hipStream_t st);
+// the same structure with fp32 outputs for the training path (OUT forms of gemm_kvq_astat_kernel): w_img = the one-term kvq stream
+bool gemm_astat_train_supported(const GemmArgs& g);
+int gemm_astat_train_launch(const GemmArgs& g, hipStream_t st);
 int gemm_h8_astat_launch(const GemmArgs& g, hipStream_t st);
 
 // gemm_h8_areg.hip — mixed mode's mlp.2 / out_proj in h8 arithmetic: A is an h8 activation image (a_img == 2: fp16 hi + fp8 lo,

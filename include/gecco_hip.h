@@ -174,6 +174,29 @@ int gecco_linear_act_keep_h16(const float* A, const float* W, const float* bias,
                               const float* alpha, int act, float* pre_out, void* C16out, int B, int rows, int K, int Nout, void* wsplit,
                               void* stream);
 
+/* ---- A-stationary forms of the training path's products out of a <= 512-wide operand, in the autocast(float16) arithmetic (fp16
+ * operands, fp32 accumulation, fp32 tensors): a 128-row block keeps its rows of x (after the optional AdaGN apply) in registers for the
+ * whole launch and streams W once — the LDS-DMA GEMM re-fetches the rows for every 128-column tile and is bound by that fill, not by
+ * the matrix pipe, once a product is one MFMA.  rows % 128 == 0, K in {128, 256, 384, 512}, Nout % 64 == 0,
+ * Nout >= 128 (gecco_linear_astat16_ok).  wsplit: gecco_astat16_image_bytes(Nout, K) bytes per weight (2 per element); a NULL weight
+ * means wsplit holds the stream already (gecco_astat16_images_f32: batched, transposed != 0 = the stream of W^T from W (K, ldw)).
+ *   _f32:    C1 (| C2) = x' W1^T + bias1 (| x' W2^T + bias2), x' = x * pro_a[b] + pro_o[b] or x — broadcast_norm -> kv_proj | q
+ *            (models/set_transformer.py:161-162 -> :49, :112); transposed != 0 (one weight): W1 is (K, Nout1) and C1 = x W1 — a dX product;
+ *   _keep:   pre_out = u = x' W^T + bias (fp32) and C16out = fp16(act(u)) — the first linear of an MLP (models/mlp.py:5-39), act 1 / 2
+ *            GaussianActivation (normalized / raw), 3 ReLU;
+ *   _actbwd: C = (dy W) * act'(u), W the linear's own (K, Nout) weight, + for GaussianActivation agrad[B * rows / 128] = per-block
+ *            partials of d alpha (their sum is the gradient) — the dX product through the activation. */
+size_t gecco_astat16_image_bytes(int Nout, int K);
+int gecco_linear_astat16_ok(int rows, int K, int Nout);
+int gecco_astat16_images_f32(const GeccoSplitJob* jobs, int n, void* stream);
+int gecco_linear_astat16_f32(const float* x, const float* pro_a, const float* pro_o, const float* W1, const float* bias1, int Nout1, float* C1,
+                             const float* W2, const float* bias2, int Nout2, float* C2, int transposed, int B, int rows, int K, void* wsplit,
+                             void* stream);
+int gecco_linear_astat16_keep(const float* x, const float* pro_a, const float* pro_o, const float* W, const float* bias, const float* alpha,
+                              int act, float* pre_out, void* C16out, int B, int rows, int K, int Nout, void* wsplit, void* stream);
+int gecco_linear_astat16_actbwd(const float* dy, const float* W, const float* u, const float* alpha, int kind, float* C, float* agrad, int B,
+                                int rows, int K, int Nout, void* wsplit, void* stream);
+
 /* GroupNorm partial statistics of x (B, rows, C): stats (B, T, 2, C), T = gecco_stats_row_tiles(rows). */
 int gecco_col_stats_f32(const float* x, float* stats, int B, int rows, int C, void* stream);
 int gecco_stats_row_tiles(int rows);

@@ -259,3 +259,86 @@ def test_c2_full_size_gradients_under_autocast_vs_oracle():
     print(f"C2 training [autocast fp16]: gradient rel-L2 over all parameters {tot:.2e} (bar 2e-3), worst matrix {worst_m[0]} {worst_m[1]:.2e} "
           f"(bar 3e-3), worst tensor {worst[0]} {worst[1]:.2e} (bar 4e-3)")
     assert tot < 2e-3 and worst_m[1] < 3e-3
+
+
+@pytest.mark.parametrize("K,B,R", [(384, 3, 256), (512, 2, 128), (256, 1, 384), (128, 2, 256)])
+def test_astat16_training_linears(K, B, R):
+    """The A-stationary fp16 forms of the training path's products (gecco_linear_astat16_f32 / _keep / _actbwd, gemm_h8_astat.hip): against
+    fp64 on the operands (fp16-operand accuracy) and against the LDS-DMA fp16 GEMM of the same arithmetic (only the fp32 accumulation
+    order differs); ready streams (gecco_astat16_images_f32, incl. the stream of W^T from W) give the per-call bits."""
+    from gecco_amd import _lib, hip_ops
+    lib = _lib.load()
+    rs = np.random.RandomState(K + R)
+    N1, N2, Wd = 2 * K, K, 2 * K
+    x = _t(rs.randn(B, R, K)).cuda()
+    pa, po = _t(1.0 + 0.3 * rs.randn(B, K)).cuda(), _t(0.2 * rs.randn(B, K)).cuda()
+    W1, W2, b2 = _t(rs.randn(N1, K) / np.sqrt(K)).cuda(), _t(rs.randn(N2, K) / np.sqrt(K)).cuda(), _t(rs.randn(N2) * 0.1).cuda()
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
+    ws = lambda n: torch.empty(n, dtype=torch.uint8, device="cuda")     # noqa: E731
+    # (1) AdaGN(x) -> K | V, q
+    c1, c2 = torch.full((B, R, N1), float("nan"), device="cuda"), torch.full((B, R, N2), float("nan"), device="cuda")
+    w = ws(lib.gecco_astat16_image_bytes(N1, K) + lib.gecco_astat16_image_bytes(N2, K))
+    _lib.check(lib.gecco_linear_astat16_f32(p(x), p(pa), p(po), p(W1), None, N1, p(c1), p(W2), p(b2), N2, p(c2), 0, B, R, K, p(w), None), "astat16")
+    xe = (x * pa[:, None] + po[:, None]).double()
+    assert _rel(c1, xe @ W1.double().t()) < 1e-3 and _rel(c2, xe @ W2.double().t() + b2.double()) < 1e-3
+    r1, r2 = hip_ops.linear_pair(x, W1, None, W2, b2, pro=(pa, po), precision="fp16")
+    assert _rel(c1, r1) < 3e-6 and _rel(c2, r2) < 3e-6
+    # ready streams equal the per-call ones
+    w2 = ws(w.numel())
+    o2 = lib.gecco_astat16_image_bytes(N1, K)
+    jobs = (_lib.GeccoSplitJob * 2)(_lib.GeccoSplitJob(W1.data_ptr(), w2.data_ptr(), N1, K, K, 0),
+                                    _lib.GeccoSplitJob(W2.data_ptr(), w2.data_ptr() + o2, N2, K, K, 0))
+    _lib.check(lib.gecco_astat16_images_f32(jobs, 2, None), "astat16 images")
+    assert torch.equal(w, w2)
+    d1, d2 = torch.empty_like(c1), torch.empty_like(c2)
+    _lib.check(lib.gecco_linear_astat16_f32(p(x), p(pa), p(po), None, None, N1, p(d1), None, p(b2), N2, p(d2), 0, B, R, K, p(w2), None), "astat16 ready")
+    assert torch.equal(c1, d1) and torch.equal(c2, d2)
+    # (2) a dX product: dy (B, R, K) through a (K, Nout) weight, its W^T stream straight from W
+    Wo = _t(rs.randn(K, N2) / np.sqrt(K)).cuda()
+    dy = _t(rs.randn(B, R, K)).cuda()
+    dx = torch.full((B, R, N2), float("nan"), device="cuda")
+    wt = ws(lib.gecco_astat16_image_bytes(N2, K))
+    _lib.check(lib.gecco_linear_astat16_f32(p(dy), None, None, p(Wo), None, N2, p(dx), None, None, 0, None, 1, B, R, K, p(wt), None), "astat16 T")
+    assert _rel(dx, dy.double() @ Wo.double()) < 1e-3
+    wt2 = ws(wt.numel())
+    Wot = Wo.t().contiguous()
+    jobs = (_lib.GeccoSplitJob * 1)(_lib.GeccoSplitJob(Wot.data_ptr(), wt2.data_ptr(), N2, K, K, 0))
+    _lib.check(lib.gecco_astat16_images_f32(jobs, 1, None), "astat16 images")
+    assert torch.equal(wt, wt2)
+    # (3) the first linear of an MLP: u (fp32) and act(u) (fp16), (4) the dX product through the activation
+    W0, b0 = _t(rs.randn(Wd, K) / np.sqrt(K)).cuda(), _t(rs.randn(Wd) * 0.1).cuda()
+    Wm = _t(rs.randn(K, Wd) / np.sqrt(Wd)).cuda()          # the second linear's weight (K outputs, Wd inputs)
+    alpha = torch.tensor([0.8], device="cuda")
+    for kind in (1, 2, 3):
+        u = torch.full((B, R, Wd), float("nan"), device="cuda")
+        h = torch.full((B, R, Wd), float("nan"), device="cuda", dtype=torch.float16)
+        w0 = ws(lib.gecco_astat16_image_bytes(Wd, K))
+        _lib.check(lib.gecco_linear_astat16_keep(p(x), p(pa), p(po), p(W0), p(b0), p(alpha) if kind < 3 else None, kind, p(u), p(h), B, R, K, Wd,
+                                                 p(w0), None), "astat16 keep")
+        u64 = xe @ W0.double().t() + b0.double()
+
+        def act64(t):
+            if kind == 3:
+                return torch.relu(t)
+            y = torch.exp(-t ** 2 / (2 * 0.8 ** 2))
+            return (y - 0.7) / 0.28 if kind == 1 else y
+        assert _rel(u, u64) < 1e-3
+        assert torch.equal(h, {1: (torch.exp(-u ** 2 / (2 * 0.8 ** 2)) - 0.7) / 0.28, 2: torch.exp(-u ** 2 / (2 * 0.8 ** 2)), 3: torch.relu(u)}[kind].half()) \
+            or _rel(h.float(), act64(u.double())) < 1e-3
+        # backward: du = (dy Wm) * act'(u), d alpha = sum (dy Wm) * d act / d alpha
+        du = torch.full((B, R, Wd), float("nan"), device="cuda")
+        ag = torch.full((B * R // 128,), float("nan"), device="cuda")
+        wb = ws(lib.gecco_astat16_image_bytes(Wd, K))
+        _lib.check(lib.gecco_linear_astat16_actbwd(p(dy), p(Wm), p(u), p(alpha) if kind < 3 else None, kind, p(du), p(ag) if kind < 3 else None, B, R,
+                                                   K, Wd, p(wb), None), "astat16 actbwd")
+        ud = u.double().requires_grad_(True)
+        ad = torch.tensor(0.8, dtype=torch.float64, requires_grad=True)
+        if kind == 3:
+            yv = torch.relu(ud)
+        else:
+            yv = torch.exp(-ud ** 2 / (2 * ad ** 2))
+            yv = (yv - 0.7) / 0.28 if kind == 1 else yv
+        (yv * (dy.double() @ Wm.double())).sum().backward()
+        assert _rel(du, ud.grad) < (2e-3 if kind < 3 else 1e-6 + 2e-3), (kind, _rel(du, ud.grad))
+        if kind < 3:
+            assert abs(float(ag.double().sum()) - float(ad.grad)) < 3e-3 * abs(float(ad.grad)) + 1e-2

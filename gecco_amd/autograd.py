@@ -916,6 +916,15 @@ def _softmax_bwd(P: Tensor, dP: Tensor, scale: float) -> Tensor:
     return dS
 
 
+def _attn_pr() -> int:
+    """Arithmetic code of the fused attention kernels (forward and the backward that recomputes P with the same operands): the
+    training precision, or — under autocast(float16), where torch runs scaled_dot_product_attention / nn.MultiheadAttention and their
+    backward with fp16 operands — 2: one fp16 plane per operand, one MFMA per product (GECCO_TRAIN_ATTN16=0: split-bf16 there too)."""
+    if _lin_precision() == "fp16" and os.environ.get("GECCO_TRAIN_ATTN16", "1") != "0":
+        return 2
+    return min(hip_ops.PRECISIONS[_train_precision()], 1)
+
+
 def _fused_attn_ok(I: int, hd: int) -> bool:
     """Shapes the fused attention kernels take (every shipped config: 64 inducers, head dim d / 8); others run the
     strided-batched GEMM form below."""
@@ -938,7 +947,7 @@ class PoolAttnFn(torch.autograd.Function):
             nb = lib.gecco_pool_attn_workspace_bytes(B, N, Cc, H, I)
             ws = torch.empty(nb, dtype=torch.uint8, device=KV.device)
             O = _new(B, I, Cc, like=KV)
-            pr = ctx.pr = min(hip_ops.PRECISIONS[_train_precision()], 1)
+            pr = ctx.pr = _attn_pr()
             _lib.check(lib.gecco_pool_attn_ex_f32(_ptr(KV), _ptr(ind), _ptr(O), B, N, Cc, H, I, pr, C.c_void_p(ws.data_ptr()), nb,
                                                   _stream()), "gecco_pool_attn_ex_f32")
             lse = _new(B, H, I, like=KV)
@@ -1007,8 +1016,8 @@ class UnpoolAttnFn(torch.autograd.Function):
         ctx.fused = _fused_attn_ok(I, hd)
         if ctx.fused:
             ctx.save_for_backward(q, kvh)
-            ctx.pr = min(hip_ops.PRECISIONS[_train_precision()], 1)
-            return hip_ops.unpool_attn(q, kvh, H, precision=_train_precision())
+            ctx.pr = _attn_pr()
+            return hip_ops.unpool_attn(q, kvh, H, precision="fp16" if ctx.pr == 2 else _train_precision())
         sc = 1.0 / math.sqrt(hd)
         S = _new(B, H, N, I, like=q)
         zq, zk, zS = (N * Cc, hd), (I * 2 * Cc, hd), (H * N * I, N * I)

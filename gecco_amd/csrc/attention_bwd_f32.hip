@@ -511,7 +511,7 @@ int pool_attn_bwd_launch(const float* KV, const float* inducers, const float* me
                          float* dKV, float* dQpart, int B, int N, int C, int H, int I, int nsplit, hipStream_t st, int precision) {
     if (I != 64 || C % H) return -3;
     if (precision >= 1 && attn_bwd_x3_supported(C / H))
-        return pool_attn_bwd_x3_launch(KV, inducers, merged, lse, dO, dKV, dQpart, B, N, C, H, nsplit, st);
+        return pool_attn_bwd_x3_launch(KV, inducers, merged, lse, dO, dKV, dQpart, B, N, C, H, nsplit, st, precision == 2);
     switch (C / H) {
         case 8: return pool_bwd_t<8>(KV, inducers, merged, lse, dO, dKV, dQpart, B, N, C, H, nsplit, st);
         case 16: return pool_bwd_t<16>(KV, inducers, merged, lse, dO, dKV, dQpart, B, N, C, H, nsplit, st);
@@ -531,7 +531,7 @@ int unpool_attn_bwd_launch(const float* q, const float* kvh, const float* dO, fl
     int tpw;
     const int nchunk = unpool_attn_bwd_chunks(B, N, H, &tpw);
     if (precision >= 1 && attn_bwd_x3_supported(C / H))
-        return unpool_attn_bwd_x3_launch(q, kvh, dO, dq, dkv_part, B, N, C, H, tpw, nchunk, st);
+        return unpool_attn_bwd_x3_launch(q, kvh, dO, dq, dkv_part, B, N, C, H, tpw, nchunk, st, precision == 2);
     switch (C / H) {
         case 8: return unpool_bwd_t<8>(q, kvh, dO, dq, dkv_part, B, N, C, H, tpw, nchunk, st);
         case 16: return unpool_bwd_t<16>(q, kvh, dO, dq, dkv_part, B, N, C, H, tpw, nchunk, st);

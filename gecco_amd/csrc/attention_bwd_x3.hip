@@ -25,6 +25,8 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -34,8 +36,20 @@ constexpr float LOG2E = 1.4426950408889634f;
 
 __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// F16 (the reference's autocast(float16) trainer arithmetic, autograd.py `_lin_precision`: torch runs SDPA / MultiheadAttention and
+// their backward with fp16 operands there): ONE fp16 plane per operand, one v_mfma_f32_32x32x16_f16 per product.  The kernels keep
+// their layout; the lo planes are neither written nor multiplied (their fragment reads are dead code).
 // 4 fp32 -> 4 bf16 hi (top 16 bits) and 4 bf16 lo = rne(x - hi), each packed in two dwords
+template <bool F16>
 __device__ __forceinline__ void split4(const f32x4& x, u32x2& hi, u32x2& lo) {
+    if (F16) {
+        f16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (_Float16)x[e];
+        hi = __builtin_bit_cast(u32x2, v);
+        lo = hi;
+        return;
+    }
     bf16x4 l;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -48,7 +62,16 @@ __device__ __forceinline__ void split4(const f32x4& x, u32x2& hi, u32x2& lo) {
 }
 
 // accumulator registers e0 .. e0+7 -> the hi / lo fragments of one 16-row chunk
+template <bool F16>
 __device__ __forceinline__ void split_acc8(const f32x16& s, int e0, u32x4& hi, u32x4& lo) {
+    if (F16) {
+        f16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (_Float16)s[e0 + e];
+        hi = __builtin_bit_cast(u32x4, v);
+        lo = hi;
+        return;
+    }
     u32x4 hb;
     bf16x8 l;
 #pragma unroll
@@ -63,7 +86,9 @@ __device__ __forceinline__ void split_acc8(const f32x16& s, int e0, u32x4& hi, u
     lo = __builtin_bit_cast(u32x4, l);
 }
 
+template <bool F16>
 __device__ __forceinline__ f32x16 mfma3(const u32x4& ahi, const u32x4& alo, const u32x4& bhi, const u32x4& blo, f32x16 acc) {
+    if (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ahi), __builtin_bit_cast(f16x8, bhi), acc, 0, 0, 0);
     const bf16x8 ah = __builtin_bit_cast(bf16x8, ahi), al = __builtin_bit_cast(bf16x8, alo);
     const bf16x8 bh = __builtin_bit_cast(bf16x8, bhi), bl = __builtin_bit_cast(bf16x8, blo);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
@@ -101,17 +126,17 @@ __device__ __forceinline__ u32x4 trfrag(const u16* plane, int sg, int blk, int l
 }
 
 // a [rows][HD] fp32 tile held as f32x4 pieces -> hi | lo planes (piece f: row f / CH, columns 4 (f % CH) ..)
-template <int NB>
+template <int NB, bool F16>
 __device__ __forceinline__ void put4(u16* hi_plane, u16* lo_plane, int row, int col, const f32x4& v) {
     u32x2 hi, lo;
-    split4(v, hi, lo);
+    split4<F16>(v, hi, lo);
     const int o = blk_off<NB>(row, col);
     *reinterpret_cast<u32x2*>(hi_plane + o) = hi;
-    *reinterpret_cast<u32x2*>(lo_plane + o) = lo;
+    if (!F16) *reinterpret_cast<u32x2*>(lo_plane + o) = lo;
 }
 
 // ------------------------------------------------------------------------------------- pool
-template <int HD>
+template <int HD, bool F16>
 __global__ __launch_bounds__(256) void pool_attn_bwd_x3_kernel(const float* __restrict__ KV, const float* __restrict__ Qind,
                                                                const float* __restrict__ Omerged, const float* __restrict__ lse,
                                                                const float* __restrict__ dO, float* __restrict__ dKV,
@@ -156,8 +181,8 @@ __global__ __launch_bounds__(256) void pool_attn_bwd_x3_kernel(const float* __re
     __syncthreads();
     for (int f = tid; f < 64 * CH; f += 256) {
         const int row = f / CH, ch = f % CH;
-        put4<DT>(Qhi, Qlo, row, ch * 4, *reinterpret_cast<const f32x4*>(Qind + ((size_t)hh * 64 + row) * HD + ch * 4));
-        put4<DT>(Ghi, Glo, row, ch * 4, *reinterpret_cast<const f32x4*>(dO + ((size_t)b * 64 + row) * C + hh * HD + ch * 4));
+        put4<DT, F16>(Qhi, Qlo, row, ch * 4, *reinterpret_cast<const f32x4*>(Qind + ((size_t)hh * 64 + row) * HD + ch * 4));
+        put4<DT, F16>(Ghi, Glo, row, ch * 4, *reinterpret_cast<const f32x4*>(dO + ((size_t)b * 64 + row) * C + hh * HD + ch * 4));
     }
     if (tid < 64) {
         const float* o = Omerged + ((size_t)b * 64 + tid) * C + hh * HD;
@@ -198,8 +223,8 @@ __global__ __launch_bounds__(256) void pool_attn_bwd_x3_kernel(const float* __re
         for (int it = 0; it < LD_IT; ++it) {
             const int f = it * 64 + lane, row = f / CH, ch = f % CH;
             if (f < 32 * CH) {
-                put4<DT>(Khi, Klo, row, ch * 4, rk[it]);
-                put4<DT>(Vhi, Vlo, row, ch * 4, rv[it]);
+                put4<DT, F16>(Khi, Klo, row, ch * 4, rk[it]);
+                put4<DT, F16>(Vhi, Vlo, row, ch * 4, rv[it]);
             }
         }
     };
@@ -241,8 +266,8 @@ __global__ __launch_bounds__(256) void pool_attn_bwd_x3_kernel(const float* __re
                 const u32x4 vh = rowfrag<DT>(Vhi, r, c, h), vl = rowfrag<DT>(Vlo, r, c, h);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    p[j] = mfma3(kh, kl, rowfrag<DT>(Qhi, 32 * j + r, c, h), rowfrag<DT>(Qlo, 32 * j + r, c, h), p[j]);
-                    dp[j] = mfma3(vh, vl, rowfrag<DT>(Ghi, 32 * j + r, c, h), rowfrag<DT>(Glo, 32 * j + r, c, h), dp[j]);
+                    p[j] = mfma3<F16>(kh, kl, rowfrag<DT>(Qhi, 32 * j + r, c, h), rowfrag<DT>(Qlo, 32 * j + r, c, h), p[j]);
+                    dp[j] = mfma3<F16>(vh, vl, rowfrag<DT>(Ghi, 32 * j + r, c, h), rowfrag<DT>(Glo, 32 * j + r, c, h), dp[j]);
                 }
             }
             // P^T, then dS^T (in dp)
@@ -260,12 +285,12 @@ __global__ __launch_bounds__(256) void pool_attn_bwd_x3_kernel(const float* __re
             for (int sg = 0; sg < 2; ++sg) {
                 u32x4 sh[2], sl[2];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) split_acc8(dp[j], 8 * sg, sh[j], sl[j]);
+                for (int j = 0; j < 2; ++j) split_acc8<F16>(dp[j], 8 * sg, sh[j], sl[j]);
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
                     const u32x4 ah = trfrag<DT>(Khi, sg, dt, lane), al = trfrag<DT>(Klo, sg, dt, lane);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) dQ[dt][j] = mfma3(ah, al, sh[j], sl[j], dQ[dt][j]);
+                    for (int j = 0; j < 2; ++j) dQ[dt][j] = mfma3<F16>(ah, al, sh[j], sl[j], dQ[dt][j]);
                 }
             }
             // dV[key, d] = sum_i P[i, key] dO[i, d];  dK[key, d] = sum_i dS[i, key] Q[i, d]   (TN products)
@@ -277,7 +302,7 @@ __global__ __launch_bounds__(256) void pool_attn_bwd_x3_kernel(const float* __re
                     for (int g4 = 0; g4 < 4; ++g4) {
                         const f32x16& src = pass == 0 ? p[j] : dp[j];
                         const f32x4 v = {src[4 * g4], src[4 * g4 + 1], src[4 * g4 + 2], src[4 * g4 + 3]};
-                        put4<1>(Thi, Tlo, 32 * j + r, 8 * g4 + 4 * h, v);   // keys mfma_row(4 g4 .. 4 g4 + 3, h)
+                        put4<1, F16>(Thi, Tlo, 32 * j + r, 8 * g4 + 4 * h, v);   // keys mfma_row(4 g4 .. 4 g4 + 3, h)
                     }
                 wave_lds_sync();
                 const u16* Bh = pass == 0 ? Ghi : Qhi;
@@ -292,7 +317,7 @@ __global__ __launch_bounds__(256) void pool_attn_bwd_x3_kernel(const float* __re
                     const u32x4 ah = trfrag<1>(Thi, sg, 0, lane), al = trfrag<1>(Tlo, sg, 0, lane);
 #pragma unroll
                     for (int dt = 0; dt < DT; ++dt)
-                        acc[dt] = mfma3(ah, al, trfrag<DT>(Bh, sg, dt, lane), trfrag<DT>(Bl, sg, dt, lane), acc[dt]);
+                        acc[dt] = mfma3<F16>(ah, al, trfrag<DT>(Bh, sg, dt, lane), trfrag<DT>(Bl, sg, dt, lane), acc[dt]);
                 }
                 float* dst = pass == 0 ? dVg : dKg;
 #pragma unroll
@@ -329,7 +354,7 @@ __global__ __launch_bounds__(256) void pool_attn_bwd_x3_kernel(const float* __re
 }
 
 // ----------------------------------------------------------------------------------- unpool
-template <int HD>
+template <int HD, bool F16>
 __global__ __launch_bounds__(256) void unpool_attn_bwd_x3_kernel(const float* __restrict__ q, const float* __restrict__ kvh,
                                                                  const float* __restrict__ dO, float* __restrict__ dq,
                                                                  float* __restrict__ dkv_part, int B, int N, int C, int H,
@@ -365,8 +390,8 @@ __global__ __launch_bounds__(256) void unpool_attn_bwd_x3_kernel(const float* __
     for (int f = tid; f < 64 * CH; f += 256) {
         const int row = f / CH, ch = f % CH;
         const float* src = kvh + ((size_t)b * 64 + row) * 2 * C + hh * HD + ch * 4;
-        put4<DT>(Khi, Klo, row, ch * 4, *reinterpret_cast<const f32x4*>(src));
-        put4<DT>(Vhi, Vlo, row, ch * 4, *reinterpret_cast<const f32x4*>(src + C));
+        put4<DT, F16>(Khi, Klo, row, ch * 4, *reinterpret_cast<const f32x4*>(src));
+        put4<DT, F16>(Vhi, Vlo, row, ch * 4, *reinterpret_cast<const f32x4*>(src + C));
     }
     const float sc = rsqrtf((float)HD), scale2 = LOG2E * sc;
     const float* qb = q + (size_t)b * N * C + hh * HD;
@@ -404,8 +429,8 @@ __global__ __launch_bounds__(256) void unpool_attn_bwd_x3_kernel(const float* __
         for (int ld = 0; ld < LD_IT; ++ld) {
             const int f = ld * 64 + lane, row = f / CH, ch = f % CH;
             if (f < 32 * CH) {
-                put4<DT>(Qhi, Qlo, row, ch * 4, rq[ld]);
-                put4<DT>(Ghi, Glo, row, ch * 4, rg[ld]);
+                put4<DT, F16>(Qhi, Qlo, row, ch * 4, rq[ld]);
+                put4<DT, F16>(Ghi, Glo, row, ch * 4, rg[ld]);
             }
         }
         load_q(it + 1);
@@ -424,8 +449,8 @@ __global__ __launch_bounds__(256) void unpool_attn_bwd_x3_kernel(const float* __
                 const u32x4 gh = rowfrag<DT>(Ghi, r, c, h), gl = rowfrag<DT>(Glo, r, c, h);
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
-                    p[rt] = mfma3(rowfrag<DT>(Khi, 32 * rt + r, c, h), rowfrag<DT>(Klo, 32 * rt + r, c, h), qh, ql, p[rt]);
-                    dp[rt] = mfma3(rowfrag<DT>(Vhi, 32 * rt + r, c, h), rowfrag<DT>(Vlo, 32 * rt + r, c, h), gh, gl, dp[rt]);
+                    p[rt] = mfma3<F16>(rowfrag<DT>(Khi, 32 * rt + r, c, h), rowfrag<DT>(Klo, 32 * rt + r, c, h), qh, ql, p[rt]);
+                    dp[rt] = mfma3<F16>(rowfrag<DT>(Vhi, 32 * rt + r, c, h), rowfrag<DT>(Vlo, 32 * rt + r, c, h), gh, gl, dp[rt]);
                 }
             }
             float mx = -INFINITY;
@@ -462,10 +487,10 @@ __global__ __launch_bounds__(256) void unpool_attn_bwd_x3_kernel(const float* __
 #pragma unroll
                 for (int sg = 0; sg < 2; ++sg) {
                     u32x4 sh, sl;
-                    split_acc8(dp[rt], 8 * sg, sh, sl);
+                    split_acc8<F16>(dp[rt], 8 * sg, sh, sl);
 #pragma unroll
                     for (int dt = 0; dt < DT; ++dt)
-                        O[dt] = mfma3(trfrag<DT>(Khi, 2 * rt + sg, dt, lane), trfrag<DT>(Klo, 2 * rt + sg, dt, lane), sh, sl, O[dt]);
+                        O[dt] = mfma3<F16>(trfrag<DT>(Khi, 2 * rt + sg, dt, lane), trfrag<DT>(Klo, 2 * rt + sg, dt, lane), sh, sl, O[dt]);
                 }
             // dv[i, d] += sum_n P[n, i] dO[n, d];  dk[i, d] += sum_n dS[n, i] q[n, d]   (TN products)
 #pragma unroll
@@ -476,7 +501,7 @@ __global__ __launch_bounds__(256) void unpool_attn_bwd_x3_kernel(const float* __
                     for (int g4 = 0; g4 < 4; ++g4) {
                         const f32x16& src = pass == 0 ? p[rt] : dp[rt];
                         const f32x4 v = {src[4 * g4], src[4 * g4 + 1], src[4 * g4 + 2], src[4 * g4 + 3]};
-                        put4<2>(Thi, Tlo, r, 32 * rt + 8 * g4 + 4 * h, v);   // inducers 32 rt + mfma_row(4 g4 .. + 3, h)
+                        put4<2, F16>(Thi, Tlo, r, 32 * rt + 8 * g4 + 4 * h, v);   // inducers 32 rt + mfma_row(4 g4 .. + 3, h)
                     }
                 wave_lds_sync();
                 const u16* Bh = pass == 0 ? Ghi : Qhi;
@@ -494,8 +519,8 @@ __global__ __launch_bounds__(256) void unpool_attn_bwd_x3_kernel(const float* __
                         const u32x4 ah = trfrag<2>(Thi, sg, rt, lane), al = trfrag<2>(Tlo, sg, rt, lane);
 #pragma unroll
                         for (int dt = 0; dt < DT; ++dt) {
-                            if (pass == 0) dv[rt][dt] = mfma3(ah, al, bh_[dt], bl_[dt], dv[rt][dt]);
-                            else dk[rt][dt] = mfma3(ah, al, bh_[dt], bl_[dt], dk[rt][dt]);
+                            if (pass == 0) dv[rt][dt] = mfma3<F16>(ah, al, bh_[dt], bl_[dt], dv[rt][dt]);
+                            else dk[rt][dt] = mfma3<F16>(ah, al, bh_[dt], bl_[dt], dk[rt][dt]);
                         }
                     }
                 }
@@ -548,7 +573,7 @@ __global__ __launch_bounds__(256) void unpool_attn_bwd_x3_kernel(const float* __
     }
 }
 
-template <int HD>
+template <int HD, bool F16>
 int pool_bwd_x3_t(const float* KV, const float* ind, const float* O, const float* lse, const float* dO, float* dKV, float* dQp,
                   int B, int N, int C, int H, int nsplit, hipStream_t st) {
     constexpr int DT = (HD + 31) / 32;
@@ -556,14 +581,14 @@ int pool_bwd_x3_t(const float* KV, const float* ind, const float* O, const float
     const size_t lds = a > c ? a : c;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pool_attn_bwd_x3_kernel<HD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pool_attn_bwd_x3_kernel<HD, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((pool_attn_bwd_x3_kernel<HD>), dim3(B * H * nsplit), dim3(256), lds, st, KV, ind, O, lse, dO, dKV, dQp, B, N, C, H, nsplit);
+    hipLaunchKernelGGL((pool_attn_bwd_x3_kernel<HD, F16>), dim3(B * H * nsplit), dim3(256), lds, st, KV, ind, O, lse, dO, dKV, dQp, B, N, C, H, nsplit);
     return (int)hipGetLastError();
 }
 
-template <int HD>
+template <int HD, bool F16>
 int unpool_bwd_x3_t(const float* q, const float* kvh, const float* dO, float* dq, float* part, int B, int N, int C, int H, int tpw,
                     int nchunk, hipStream_t st) {
     constexpr int DT = (HD + 31) / 32;
@@ -571,10 +596,10 @@ int unpool_bwd_x3_t(const float* q, const float* kvh, const float* dO, float* dq
     const size_t lds = a > c ? a : c;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(unpool_attn_bwd_x3_kernel<HD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(unpool_attn_bwd_x3_kernel<HD, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((unpool_attn_bwd_x3_kernel<HD>), dim3(B * H * nchunk), dim3(256), lds, st, q, kvh, dO, dq, part, B, N, C, H, tpw, nchunk);
+    hipLaunchKernelGGL((unpool_attn_bwd_x3_kernel<HD, F16>), dim3(B * H * nchunk), dim3(256), lds, st, q, kvh, dO, dq, part, B, N, C, H, tpw, nchunk);
     return (int)hipGetLastError();
 }
 
@@ -583,23 +608,31 @@ int unpool_bwd_x3_t(const float* q, const float* kvh, const float* dO, float* dq
 bool attn_bwd_x3_supported(int HD) { return HD == 16 || HD == 32 || HD == 48 || HD == 64; }
 
 int pool_attn_bwd_x3_launch(const float* KV, const float* inducers, const float* merged, const float* lse, const float* dO,
-                            float* dKV, float* dQpart, int B, int N, int C, int H, int nsplit, hipStream_t st) {
+                            float* dKV, float* dQpart, int B, int N, int C, int H, int nsplit, hipStream_t st, int f16) {
+#define POOL_BWD(HD_)                                                                                              \
+    return f16 ? pool_bwd_x3_t<HD_, true>(KV, inducers, merged, lse, dO, dKV, dQpart, B, N, C, H, nsplit, st)      \
+               : pool_bwd_x3_t<HD_, false>(KV, inducers, merged, lse, dO, dKV, dQpart, B, N, C, H, nsplit, st)
     switch (C / H) {
-        case 16: return pool_bwd_x3_t<16>(KV, inducers, merged, lse, dO, dKV, dQpart, B, N, C, H, nsplit, st);
-        case 32: return pool_bwd_x3_t<32>(KV, inducers, merged, lse, dO, dKV, dQpart, B, N, C, H, nsplit, st);
-        case 48: return pool_bwd_x3_t<48>(KV, inducers, merged, lse, dO, dKV, dQpart, B, N, C, H, nsplit, st);
-        case 64: return pool_bwd_x3_t<64>(KV, inducers, merged, lse, dO, dKV, dQpart, B, N, C, H, nsplit, st);
+        case 16: POOL_BWD(16);
+        case 32: POOL_BWD(32);
+        case 48: POOL_BWD(48);
+        case 64: POOL_BWD(64);
         default: return -4;
     }
+#undef POOL_BWD
 }
 
 int unpool_attn_bwd_x3_launch(const float* q, const float* kvh, const float* dO, float* dq, float* dkv_part, int B, int N, int C,
-                              int H, int tpw, int nchunk, hipStream_t st) {
+                              int H, int tpw, int nchunk, hipStream_t st, int f16) {
+#define UNPOOL_BWD(HD_)                                                                                    \
+    return f16 ? unpool_bwd_x3_t<HD_, true>(q, kvh, dO, dq, dkv_part, B, N, C, H, tpw, nchunk, st)        \
+               : unpool_bwd_x3_t<HD_, false>(q, kvh, dO, dq, dkv_part, B, N, C, H, tpw, nchunk, st)
     switch (C / H) {
-        case 16: return unpool_bwd_x3_t<16>(q, kvh, dO, dq, dkv_part, B, N, C, H, tpw, nchunk, st);
-        case 32: return unpool_bwd_x3_t<32>(q, kvh, dO, dq, dkv_part, B, N, C, H, tpw, nchunk, st);
-        case 48: return unpool_bwd_x3_t<48>(q, kvh, dO, dq, dkv_part, B, N, C, H, tpw, nchunk, st);
-        case 64: return unpool_bwd_x3_t<64>(q, kvh, dO, dq, dkv_part, B, N, C, H, tpw, nchunk, st);
+        case 16: UNPOOL_BWD(16);
+        case 32: UNPOOL_BWD(32);
+        case 48: UNPOOL_BWD(48);
+        case 64: UNPOOL_BWD(64);
         default: return -4;
     }
+#undef UNPOOL_BWD
 }

@@ -267,9 +267,9 @@ int unpool_attn_bwd_launch(const float* q, const float* kvh, const float* dO, fl
 // attention_bwd_x3.hip: the same two kernels in split-bf16 arithmetic (head dims 16, 32, 48, 64)
 bool attn_bwd_x3_supported(int HD);
 int pool_attn_bwd_x3_launch(const float* KV, const float* inducers, const float* merged, const float* lse, const float* dO,
-                            float* dKV, float* dQpart, int B, int N, int C, int H, int nsplit, hipStream_t st);
+                            float* dKV, float* dQpart, int B, int N, int C, int H, int nsplit, hipStream_t st, int f16 = 0);
 int unpool_attn_bwd_x3_launch(const float* q, const float* kvh, const float* dO, float* dq, float* dkv_part, int B, int N, int C,
-                              int H, int tpw, int nchunk, hipStream_t st);
+                              int H, int tpw, int nchunk, hipStream_t st, int f16 = 0);   // f16: fp16 operands, one MFMA per product
 // attention_x3.hip
 bool attn_x3_supported(int HD);
 int pool_attn_x3_partials_launch(const float* KV, const float* inducers, float* part_o, float* part_ml, int B, int N,

@@ -342,3 +342,36 @@ def test_astat16_training_linears(K, B, R):
         assert _rel(du, ud.grad) < (2e-3 if kind < 3 else 1e-6 + 2e-3), (kind, _rel(du, ud.grad))
         if kind < 3:
             assert abs(float(ag.double().sum()) - float(ad.grad)) < 3e-3 * abs(float(ad.grad)) + 1e-2
+
+
+@pytest.mark.parametrize("B,N,C,H", [(2, 1024, 384, 8), (3, 2048, 128, 8), (2, 333, 256, 8), (1, 4096, 512, 8), (5, 1500, 384, 8)])
+def test_attention_fn_grads_under_autocast(B, N, C, H):
+    """Under torch.autocast(float16) the fused attention kernels take fp16 operands — forward and the backward that recomputes P from
+    the same operands (attention_x3.hip / attention_bwd_x3.hip, template flag F16: one plane per operand, one MFMA per product) —
+    as torch's SDPA / nn.MultiheadAttention do in that context: outputs and all four gradients against the exact-fp32 kernels at
+    fp16-operand accuracy, and different from the split-bf16 results (the other arithmetic really ran); head dims 16 / 32 / 48 / 64,
+    ragged N, several key splits / query chunks."""
+    from gecco_amd import hip_ops
+    from gecco_amd.autograd import PoolAttnFn, UnpoolAttnFn
+    hd = C // H
+    rs = np.random.RandomState(N + C)
+    KV, ind, g = _t(rs.randn(B, N, 2 * C)), _t(rs.randn(1, H, 64, hd)), _t(rs.randn(B, 64, C))
+    q, kvh, g2 = _t(rs.randn(B, N, C)), _t(rs.randn(B, 64, 2 * C)), _t(rs.randn(B, N, C))
+    out = {}
+    for mode in ("fp32", "bf16x3", "amp"):
+        hip_ops.set_default_precision("fp32" if mode == "fp32" else "bf16x3")
+        try:
+            KVg, indg, qg, kvg = _leaf(KV), _leaf(ind), _leaf(q), _leaf(kvh)
+            with torch.autocast("cuda", dtype=torch.float16, enabled=mode == "amp"):
+                o1 = PoolAttnFn.apply(KVg, indg, H)
+                o2 = UnpoolAttnFn.apply(qg, kvg, H)
+            assert o1.dtype == torch.float32 and o2.dtype == torch.float32
+            o1.backward(g.cuda())
+            o2.backward(g2.cuda())
+            out[mode] = [o1.detach(), o2.detach()] + [t.grad for t in (KVg, indg, qg, kvg)]
+        finally:
+            hip_ops.set_default_precision("fp32")
+    for i, (a, b, c) in enumerate(zip(out["amp"], out["fp32"], out["bf16x3"])):
+        assert _rel(a, b) < 2e-3, (i, _rel(a, b))
+        assert _rel(c, b) < 1e-4
+        assert not torch.equal(a, c)

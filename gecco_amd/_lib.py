@@ -112,7 +112,7 @@ SIGNATURES = {
     "gecco_astat16_image_bytes": (sz, [i, i]),
     "gecco_linear_astat16_ok": (i, [i, i, i]),
     "gecco_astat16_images_f32": (i, [C.POINTER(GeccoSplitJob), i, vp]),
-    "gecco_linear_astat16_f32": (i, [vp] * 5 + [i, vp, vp, vp, i, vp, i, i, i, i, vp, vp]),
+    "gecco_linear_astat16_f32": (i, [vp] * 5 + [i, vp, vp, vp, i, vp, vp, i, i, i, i, vp, vp]),
     "gecco_linear_astat16_keep": (i, [vp] * 6 + [i, vp, vp, i, i, i, i, vp, vp]),
     "gecco_linear_astat16_actbwd": (i, [vp] * 4 + [i, vp, vp, i, i, i, i, vp, vp]),
     "gecco_linear_act_keep_h16": (i, [vp] * 6 + [i, vp, vp, i, i, i, i, vp, vp]),

@@ -227,11 +227,13 @@ def _linear_dx(dy: Tensor, W: Tensor, residual: Tensor | None = None, prec: str 
     B, R, Nout = dy.shape
     K = W.shape[1]
     prec = _resolve(prec, R, Nout, K)
+    # (with a residual the A-stationary form measured the same as the LDS-DMA one, 19.31 vs 19.27 ms per step: only the plain product)
     if residual is None and _a16_ok(prec, R, Nout, K):
         dx = _new(B, R, K, like=dy)
         ws, ready = _a16_stream("t", W, dev=dy.device)
         _lib.check(_lib.load().gecco_linear_astat16_f32(_ptr(dy), None, None, None if ready else _ptr(_f(W)), None, K, _ptr(dx), None, None, 0, None,
-                                                        1, B, R, Nout, C.c_void_p(ws.data_ptr()), _stream()), "gecco_linear_astat16_f32")
+                                                        _ptr(residual), 1, B, R, Nout, C.c_void_p(ws.data_ptr()), _stream()),
+                   "gecco_linear_astat16_f32")
         return dx
     if R >= 64 and Nout % 16 == 0 and K % 4 == 0:
         # linear(dy, W^T): the fused LDS-DMA GEMM; the image of W^T comes ready from the step's batched launch when it is
@@ -550,7 +552,7 @@ class AdaGNPairFn(torch.autograd.Function):
             KV, q = _new(B, R, N1, like=x), _new(B, R, N2, like=x)
             ws, ready = _a16_stream("pair", W1, W2, dev=x.device)
             _lib.check(_lib.load().gecco_linear_astat16_f32(_ptr(x), _ptr(a), _ptr(o), None if ready else _ptr(_f(W1)), None, N1, _ptr(KV),
-                                                            None if ready else _ptr(_f(W2)), _ptr(b2), N2, _ptr(q), 0, B, R, K,
+                                                            None if ready else _ptr(_f(W2)), _ptr(b2), N2, _ptr(q), None, 0, B, R, K,
                                                             C.c_void_p(ws.data_ptr()), _stream()), "gecco_linear_astat16_f32")
             ctx.save_for_backward(x, stats, t2, sw, sb, a, o, W1, W2)
             ctx.G, ctx.eps, ctx.has_b2 = G, eps, b2 is not None

@@ -870,9 +870,10 @@ int gecco_astat16_images_f32(const GeccoSplitJob* jobs, int n, void* stream) {
 }
 
 int gecco_linear_astat16_f32(const float* x, const float* pro_a, const float* pro_o, const float* W1, const float* bias1, int Nout1, float* C1,
-                             const float* W2, const float* bias2, int Nout2, float* C2, int transposed, int B, int rows, int K, void* wsplit,
-                             void* stream) {
+                             const float* W2, const float* bias2, int Nout2, float* C2, const float* residual, int transposed, int B, int rows,
+                             int K, void* wsplit, void* stream) {
     if (!x || !C1 || !wsplit || (Nout2 > 0 && !C2)) return fail(-1, "linear_astat16: null argument");
+    if (residual && (Nout2 > 0 || pro_a || bias1)) return fail(-2, "linear_astat16: the residual form takes one weight, no prologue, no bias");
     if ((pro_a == nullptr) != (pro_o == nullptr)) return fail(-1, "linear_astat16: pro_a / pro_o must both be set");
     if (Nout2 > 0 && ((W1 == nullptr) != (W2 == nullptr))) return fail(-1, "linear_astat16: W1 / W2 both given or both ready");
     hipStream_t s = (hipStream_t)stream;
@@ -881,6 +882,7 @@ int gecco_linear_astat16_f32(const float* x, const float* pro_a, const float* pr
     g.B = B; g.rows = rows; g.K = K; g.Nout = Nout1 + (Nout2 > 0 ? Nout2 : 0); g.lda = K; g.ldw = K; g.ldc = Nout1; g.ldr = Nout1;
     g.precision = 2; g.w_img = wsplit;
     if (Nout2 > 0) { g.C2 = C2; g.bias2 = bias2; g.n_split = Nout1; g.ldc2 = Nout2; }
+    if (residual) { g.mul_u = residual; g.mul_kind = 0; }   // C1 = x W^T + residual (the epilogue form that reads a second tensor)
     if (!gemm_astat_train_supported(g))
         return fail(-2, "linear_astat16: needs rows %% 128 == 0, K in {128, 256, 384, 512}, Nout (each segment) %% 64 == 0, Nout >= 128");
     if (W1) {

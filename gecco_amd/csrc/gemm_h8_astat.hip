@@ -651,7 +651,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_h8_astat_kernel(GemmArgs g) {
 //   2  pre_out = u = y W^T + bias (fp32) and C = fp16(act(u)): the first linear of an MLP in training (models/mlp.py:5-39), its
 //      hidden layer stored as halves (the matrix pipe reads it again as fp16 either way);
 //   3  C = (y W^T) * act'(u), u = mul_u (fp32), + the alpha-gradient partial of the block: the dX product through an activation
-//      (autograd of mlp.py's Linear -> act).  The u rows of the NEXT tile are loaded during the epilogue of this one.
+//      (autograd of mlp.py's Linear -> act); mul_kind 0: C = y W^T + mul_u, a dX product added onto another gradient of the same
+//      tensor.  The u rows of the NEXT tile are loaded during the epilogue of this one.
 template <int NG, int NS, int OUT = 0>
 __global__ __launch_bounds__(256, 2) void gemm_kvq_astat_kernel(GemmArgs g) {
     constexpr int K = 64 * NG, NT = 256, NW = 4, ROWS = 128, PW = 2;
@@ -802,12 +803,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kvq_astat_kernel(GemmArgs g) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) w[e] = acc[j][4 * q + e] + bs[e];
                     if constexpr (OUT == 3) {
+                        if (act_code == 0) {   // (launch-uniform) mul_kind 0: mul_u is a RESIDUAL — another gradient contribution to the same tensor
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float da;
-                            const float f = tr_act_prime(uq[4 * j + q][e], neg_inv_2a2, inv_a2, act_code, da);
-                            ga += w[e] * da;
-                            w[e] *= f;
+                            for (int e = 0; e < 4; ++e) w[e] += uq[4 * j + q][e];
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float da;
+                                const float f = tr_act_prime(uq[4 * j + q][e], neg_inv_2a2, inv_a2, act_code, da);
+                                ga += w[e] * da;
+                                w[e] *= f;
+                            }
                         }
                     }
                     *reinterpret_cast<f32x4*>(dstf + 32 * j + 8 * q) = w;
@@ -1094,7 +1100,7 @@ bool gemm_astat_train_supported(const GemmArgs& g) {
            (!g.C2 || (!keep && !abw && !(g.n_split % H_BN) && !(g.ldc2 & 3) && g.n_split > 0 && g.n_split < g.Nout)) &&
            ((g.pro_a == nullptr) == (g.pro_o == nullptr)) && g.lo_begin == 0 && g.lo_tiles == 0 && !g.hm_hd &&
            (keep ? (g.act >= 1 && g.act <= 3 && g.ldc == g.Nout) : g.act == 0) &&
-           (!abw || (g.mul_kind >= 1 && g.mul_kind <= 3 && !g.bias && !g.pro_a && g.ldc == g.Nout)) &&
+           (!abw || (g.mul_kind >= 0 && g.mul_kind <= 3 && !g.bias && !g.pro_a && g.ldc == g.Nout)) &&
            (!((keep && act_gauss_host(g.act)) || (abw && act_gauss_host(g.mul_kind))) || g.alpha);
 }
 

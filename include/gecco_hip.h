@@ -182,6 +182,7 @@ int gecco_linear_act_keep_h16(const float* A, const float* W, const float* bias,
  * means wsplit holds the stream already (gecco_astat16_images_f32: batched, transposed != 0 = the stream of W^T from W (K, ldw)).
  *   _f32:    C1 (| C2) = x' W1^T + bias1 (| x' W2^T + bias2), x' = x * pro_a[b] + pro_o[b] or x — broadcast_norm -> kv_proj | q
  *            (models/set_transformer.py:161-162 -> :49, :112); transposed != 0 (one weight): W1 is (K, Nout1) and C1 = x W1 — a dX product;
+ *            residual (one weight, no prologue / bias; may be NULL): added to C1 — another gradient contribution to the same tensor;
  *   _keep:   pre_out = u = x' W^T + bias (fp32) and C16out = fp16(act(u)) — the first linear of an MLP (models/mlp.py:5-39), act 1 / 2
  *            GaussianActivation (normalized / raw), 3 ReLU;
  *   _actbwd: C = (dy W) * act'(u), W the linear's own (K, Nout) weight, + for GaussianActivation agrad[B * rows / 128] = per-block
@@ -190,8 +191,8 @@ size_t gecco_astat16_image_bytes(int Nout, int K);
 int gecco_linear_astat16_ok(int rows, int K, int Nout);
 int gecco_astat16_images_f32(const GeccoSplitJob* jobs, int n, void* stream);
 int gecco_linear_astat16_f32(const float* x, const float* pro_a, const float* pro_o, const float* W1, const float* bias1, int Nout1, float* C1,
-                             const float* W2, const float* bias2, int Nout2, float* C2, int transposed, int B, int rows, int K, void* wsplit,
-                             void* stream);
+                             const float* W2, const float* bias2, int Nout2, float* C2, const float* residual, int transposed, int B, int rows,
+                             int K, void* wsplit, void* stream);
 int gecco_linear_astat16_keep(const float* x, const float* pro_a, const float* pro_o, const float* W, const float* bias, const float* alpha,
                               int act, float* pre_out, void* C16out, int B, int rows, int K, int Nout, void* wsplit, void* stream);
 int gecco_linear_astat16_actbwd(const float* dy, const float* W, const float* u, const float* alpha, int kind, float* C, float* agrad, int B,

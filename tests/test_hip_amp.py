@@ -278,7 +278,7 @@ def test_astat16_training_linears(K, B, R):
     # (1) AdaGN(x) -> K | V, q
     c1, c2 = torch.full((B, R, N1), float("nan"), device="cuda"), torch.full((B, R, N2), float("nan"), device="cuda")
     w = ws(lib.gecco_astat16_image_bytes(N1, K) + lib.gecco_astat16_image_bytes(N2, K))
-    _lib.check(lib.gecco_linear_astat16_f32(p(x), p(pa), p(po), p(W1), None, N1, p(c1), p(W2), p(b2), N2, p(c2), 0, B, R, K, p(w), None), "astat16")
+    _lib.check(lib.gecco_linear_astat16_f32(p(x), p(pa), p(po), p(W1), None, N1, p(c1), p(W2), p(b2), N2, p(c2), None, 0, B, R, K, p(w), None), "astat16")
     xe = (x * pa[:, None] + po[:, None]).double()
     assert _rel(c1, xe @ W1.double().t()) < 1e-3 and _rel(c2, xe @ W2.double().t() + b2.double()) < 1e-3
     r1, r2 = hip_ops.linear_pair(x, W1, None, W2, b2, pro=(pa, po), precision="fp16")
@@ -291,15 +291,20 @@ def test_astat16_training_linears(K, B, R):
     _lib.check(lib.gecco_astat16_images_f32(jobs, 2, None), "astat16 images")
     assert torch.equal(w, w2)
     d1, d2 = torch.empty_like(c1), torch.empty_like(c2)
-    _lib.check(lib.gecco_linear_astat16_f32(p(x), p(pa), p(po), None, None, N1, p(d1), None, p(b2), N2, p(d2), 0, B, R, K, p(w2), None), "astat16 ready")
+    _lib.check(lib.gecco_linear_astat16_f32(p(x), p(pa), p(po), None, None, N1, p(d1), None, p(b2), N2, p(d2), None, 0, B, R, K, p(w2), None), "astat16 ready")
     assert torch.equal(c1, d1) and torch.equal(c2, d2)
     # (2) a dX product: dy (B, R, K) through a (K, Nout) weight, its W^T stream straight from W
     Wo = _t(rs.randn(K, N2) / np.sqrt(K)).cuda()
     dy = _t(rs.randn(B, R, K)).cuda()
     dx = torch.full((B, R, N2), float("nan"), device="cuda")
     wt = ws(lib.gecco_astat16_image_bytes(N2, K))
-    _lib.check(lib.gecco_linear_astat16_f32(p(dy), None, None, p(Wo), None, N2, p(dx), None, None, 0, None, 1, B, R, K, p(wt), None), "astat16 T")
+    _lib.check(lib.gecco_linear_astat16_f32(p(dy), None, None, p(Wo), None, N2, p(dx), None, None, 0, None, None, 1, B, R, K, p(wt), None), "astat16 T")
     assert _rel(dx, dy.double() @ Wo.double()) < 1e-3
+    other = _t(rs.randn(B, R, N2)).cuda()                   # ... added onto another gradient of the same tensor
+    dx2 = torch.full((B, R, N2), float("nan"), device="cuda")
+    _lib.check(lib.gecco_linear_astat16_f32(p(dy), None, None, p(Wo), None, N2, p(dx2), None, None, 0, None, p(other), 1, B, R, K, p(wt), None),
+               "astat16 T + residual")
+    assert torch.equal(dx2, dx + other)
     wt2 = ws(wt.numel())
     Wot = Wo.t().contiguous()
     jobs = (_lib.GeccoSplitJob * 1)(_lib.GeccoSplitJob(Wot.data_ptr(), wt2.data_ptr(), N2, K, K, 0))

@@ -50,6 +50,10 @@ __device__ __forceinline__ int tn_off(int row, int col) {
 }
 
 constexpr int TN_PLANE = 32 * 128;   // u16 per plane
+// blocks per CU of the fp16 forms: 3 (168 registers; the AdaGN form then spills 14) measured 156 vs 158 us and 295 vs 152 us, 4 spills everywhere
+#ifndef TN_F16_BLOCKS
+#define TN_F16_BLOCKS 2
+#endif
 
 // F16 (the reference's own trainer arithmetic, torch.autocast(float16): diffusion.py:213-222 under Lightning's "16-mixed"): both
 // operands rounded to fp16 (round to nearest even), ONE v_mfma_f32_32x32x16_f16 per product, fp32 accumulation and fp32 output —
@@ -66,7 +70,7 @@ __device__ __forceinline__ u32x2 tn_cvt4(const f32x4& x) {
 // B16 (with F16): the B operand is an fp16 tensor in memory (the hidden layer an MLP's first GEMM stored that way): 8-byte loads, no
 // conversion
 template <bool PRO, bool F16 = false, bool B16 = false>
-__global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(TnArgs g) {
+__global__ __launch_bounds__(256, F16 ? TN_F16_BLOCKS : 2) void gemm_tn_x3_kernel(TnArgs g) {
     static_assert(!B16 || (F16 && !PRO), "an fp16 B operand: fp16 arithmetic, no AdaGN apply");
     constexpr int NPL = F16 ? 2 : 4;   // planes per stage: A | B (fp16) or A hi | A lo | B hi | B lo
     extern __shared__ __attribute__((aligned(16))) float smem[];

@@ -350,7 +350,7 @@ def test_astat16_training_linears(K, B, R):
 
 
 @pytest.mark.parametrize("B,N,C,H", [(2, 1024, 384, 8), (3, 2048, 128, 8), (2, 333, 256, 8), (1, 4096, 512, 8), (5, 1500, 384, 8)])
-def test_attention_fn_grads_under_autocast(B, N, C, H):
+def test_attention_fn_grads_under_autocast(B, N, C, H, monkeypatch):
     """Under torch.autocast(float16) the fused attention kernels take fp16 operands — forward and the backward that recomputes P from
     the same operands (attention_x3.hip / attention_bwd_x3.hip, template flag F16: one plane per operand, one MFMA per product) —
     as torch's SDPA / nn.MultiheadAttention do in that context: outputs and all four gradients against the exact-fp32 kernels at
@@ -358,6 +358,8 @@ def test_attention_fn_grads_under_autocast(B, N, C, H):
     ragged N, several key splits / query chunks."""
     from gecco_amd import hip_ops
     from gecco_amd.autograd import PoolAttnFn, UnpoolAttnFn
+    monkeypatch.delenv("GECCO_TRAIN_ATTN16", raising=False)
+    monkeypatch.delenv("GECCO_TRAIN_AMP", raising=False)
     hd = C // H
     rs = np.random.RandomState(N + C)
     KV, ind, g = _t(rs.randn(B, N, 2 * C)), _t(rs.randn(1, H, 64, hd)), _t(rs.randn(B, 64, C))

@@ -160,14 +160,29 @@ __global__ __launch_bounds__(256, F16 ? TN_F16_BLOCKS : 2) void gemm_tn_x3_kerne
     if (nsteps > 0) load(0);
     for (int s = 0; s < nsteps; ++s) {
         const int stage = s & 1;
+#ifdef TN_DIAG_NOSTORE
+        if (s < 2) store(stage);
+        else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(ra[i]));
+        }
+#else
         store(stage);
+#endif
         __syncthreads();   // stage complete; every wave is past its reads of the other stage's previous contents
+#ifdef TN_DIAG_NOLOAD   // diagnostic builds (tools/probe/tn_probe.hip): one ingredient removed each; results are garbage, only the time matters
+        if (s == 0) load(1 < nsteps ? 1 : 0);
+#else
         if (s + 1 < nsteps) load(s + 1);
+#endif
         const u16* st = lds + stage * NPL * TN_PLANE;
 #pragma unroll
         for (int sg = 0; sg < 2; ++sg) {
             if (F16) {
                 f16x8 a[2], bb[2];
+#ifdef TN_DIAG_NOREAD
+                if (s == 0)
+#endif
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     a[i] = __builtin_bit_cast(f16x8, frag(st, sg, wn * 2 + i));
@@ -176,7 +191,12 @@ __global__ __launch_bounds__(256, F16 ? TN_F16_BLOCKS : 2) void gemm_tn_x3_kerne
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], bb[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j)
+#ifdef TN_DIAG_NOMFMA
+                        acc[i][j][0] += (float)a[i][0] + (float)bb[j][0];
+#else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], bb[j], acc[i][j], 0, 0, 0);
+#endif
                 continue;
             }
             bf16x8 ah[2], al[2], bh[2], bl[2];

@@ -313,7 +313,7 @@ def _linear_dw_main(dy: Tensor, x: Tensor, want_db: bool = False, pro=None, prec
             if g > 1 and pro is None:
                 dy, x = dy.view(g, R // g, Nout), x.view(g, R // g, K)
                 B, R = g, R // g
-        tiles = -(-Nout // 128) * -(-K // 128)
+        tiles = _lib.load().gecco_gemm_tn_f16_tiles(Nout, K)
         G = min(B, max(1, -(-_DW_BLOCKS // tiles)))
         group = -(-B // G)
         G = -(-B // group)

@@ -1202,8 +1202,8 @@ int gecco_gemm_tn_f16_b16_f32(const float* A, const void* B16, float* parts, flo
     g.f16 = 1; g.b_f16 = 1;
     g.A = A; g.Bm = static_cast<const float*>(B16); g.C = parts; g.Z = Z; g.R = R; g.N = N; g.K = K; g.lda = N; g.ldb = K;
     g.sA = (size_t)R * N; g.sB = (size_t)R * K; g.group = group; g.colsum = colsum_parts;
-    if (!gemm_tn_x3_supported(g)) return fail(-2, "gemm_tn_f16_b16: needs R %% 32 == 0, N %% 4 == 0, K %% 4 == 0, group > 0");
-    TRY(gemm_tn_x3_launch(g, (hipStream_t)stream), "gemm_tn_f16_b16");
+    if (!gemm_tn_f16_supported(g)) return fail(-2, "gemm_tn_f16_b16: needs R %% 32 == 0, N %% 4 == 0, K %% 8 == 0, group > 0");
+    TRY(gemm_tn_f16_launch(g, (hipStream_t)stream), "gemm_tn_f16_b16");
     return 0;
 }
 
@@ -1215,10 +1215,11 @@ int gecco_gemm_tn_f16_f32(const float* A, const float* Bm, const float* pro_a, c
     g.pro_a = pro_a; g.pro_o = pro_o; g.f16 = 1;
     g.A = A; g.Bm = Bm; g.C = parts; g.Z = Z; g.R = R; g.N = N; g.K = K; g.lda = N; g.ldb = K;
     g.sA = (size_t)R * N; g.sB = (size_t)R * K; g.group = group; g.colsum = colsum_parts;
-    if (!gemm_tn_x3_supported(g)) return fail(-2, "gemm_tn_f16: needs R %% 32 == 0, N %% 4 == 0, K %% 4 == 0, group > 0");
-    TRY(gemm_tn_x3_launch(g, (hipStream_t)stream), "gemm_tn_f16");
+    if (!gemm_tn_f16_supported(g)) return fail(-2, "gemm_tn_f16: needs R %% 32 == 0, N %% 4 == 0, K %% 4 == 0, group > 0");
+    TRY(gemm_tn_f16_launch(g, (hipStream_t)stream), "gemm_tn_f16");
     return 0;
 }
+int gecco_gemm_tn_f16_tiles(int N, int K) { return gemm_tn_f16_tiles(N, K); }
 
 int gecco_affine_cast_f16(const float* x, const float* a, const float* o, void* y16, int B, int rows, int C,
                           void* stream) {

@@ -21,8 +21,6 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -50,29 +48,11 @@ __device__ __forceinline__ int tn_off(int row, int col) {
 }
 
 constexpr int TN_PLANE = 32 * 128;   // u16 per plane
-// blocks per CU of the fp16 forms: 3 (168 registers; the AdaGN form then spills 14) measured 156 vs 158 us and 295 vs 152 us, 4 spills everywhere
-#ifndef TN_F16_BLOCKS
-#define TN_F16_BLOCKS 2
-#endif
-
-// F16 (the reference's own trainer arithmetic, torch.autocast(float16): diffusion.py:213-222 under Lightning's "16-mixed"): both
-// operands rounded to fp16 (round to nearest even), ONE v_mfma_f32_32x32x16_f16 per product, fp32 accumulation and fp32 output —
-// one plane per operand instead of hi | lo.  The caller's GradScaler keeps dY inside fp16's range, as it does for the reference.
-__device__ __forceinline__ u32x2 tn_cvt4(const f32x4& x) {
-    f16x4 v;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (_Float16)x[e];
-    return __builtin_bit_cast(u32x2, v);
-}
 
 // PRO: the AdaGN apply on the B operand (TnArgs::pro_a) — its own instantiation, so the plain weight gradients run the code
 // they ran before it existed
-// B16 (with F16): the B operand is an fp16 tensor in memory (the hidden layer an MLP's first GEMM stored that way): 8-byte loads, no
-// conversion
-template <bool PRO, bool F16 = false, bool B16 = false>
-__global__ __launch_bounds__(256, F16 ? TN_F16_BLOCKS : 2) void gemm_tn_x3_kernel(TnArgs g) {
-    static_assert(!B16 || (F16 && !PRO), "an fp16 B operand: fp16 arithmetic, no AdaGN apply");
-    constexpr int NPL = F16 ? 2 : 4;   // planes per stage: A | B (fp16) or A hi | A lo | B hi | B lo
+template <bool PRO>
+__global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(TnArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     u16* lds = reinterpret_cast<u16*>(smem);   // [2 stages][A hi | A lo | B hi | B lo]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -92,8 +72,7 @@ __global__ __launch_bounds__(256, F16 ? TN_F16_BLOCKS : 2) void gemm_tn_x3_kerne
     const int msteps = g.R / 32, nsteps = (z1 - z0) * msteps;
 
     // global tile loads: thread -> 4 x (row, 4 columns) of each operand
-    f32x4 ra[4], rb[B16 ? 1 : 4];
-    u32x2 rb16[B16 ? 4 : 1];
+    f32x4 ra[4], rb[4];
     f32x4 pa4 = {1.f, 1.f, 1.f, 1.f}, po4 = {0.f, 0.f, 0.f, 0.f};   // AdaGN coefficients of the thread's four X columns, sample zc
     int zc = -1;
     auto load = [&](int s) {
@@ -105,37 +84,29 @@ __global__ __launch_bounds__(256, F16 ? TN_F16_BLOCKS : 2) void gemm_tn_x3_kerne
         zc = z;
         const float* Ab = g.A + (size_t)z * g.sA + (size_t)m0 * g.lda + n0;
         const float* Bb = g.Bm + (size_t)z * g.sB + (size_t)m0 * g.ldb + k0;
-        const _Float16* Bh = reinterpret_cast<const _Float16*>(g.Bm) + (size_t)z * g.sB + (size_t)m0 * g.ldb + k0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int f = tid + i * 256, row = f >> 5, c4 = f & 31;
             ra[i] = aok ? *reinterpret_cast<const f32x4*>(Ab + (size_t)row * g.lda + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-            if (B16) rb16[i] = bok ? *reinterpret_cast<const u32x2*>(Bh + (size_t)row * g.ldb + c4 * 4) : u32x2{0u, 0u};
-            else rb[i] = bok ? *reinterpret_cast<const f32x4*>(Bb + (size_t)row * g.ldb + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            rb[i] = bok ? *reinterpret_cast<const f32x4*>(Bb + (size_t)row * g.ldb + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     // bias gradient = column sums of dY: the blocks of the first K tile add up the rows they stage anyway
     const bool want_cs = g.colsum != nullptr && k0 == 0;
     f32x4 cs = {0.f, 0.f, 0.f, 0.f};
     auto store = [&](int stage) {
-        u16* st = lds + stage * NPL * TN_PLANE;
+        u16* st = lds + stage * 4 * TN_PLANE;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int f = tid + i * 256, row = f >> 5, c4 = f & 31, o = tn_off(row, c4 * 4);
             u32x2 hi, lo;
             if (want_cs) cs += ra[i];
-            if (F16) {
-                *reinterpret_cast<u32x2*>(st + o) = tn_cvt4(ra[i]);
-                if (B16) *reinterpret_cast<u32x2*>(st + TN_PLANE + o) = rb16[i];
-                else *reinterpret_cast<u32x2*>(st + TN_PLANE + o) = tn_cvt4(PRO ? (bok ? rb[i] * pa4 + po4 : rb[i]) : rb[i]);
-                continue;
-            }
             tn_split4(ra[i], hi, lo);
             *reinterpret_cast<u32x2*>(st + o) = hi;
             *reinterpret_cast<u32x2*>(st + TN_PLANE + o) = lo;
             // the AdaGN apply, if any, here — where the loaded values are consumed a step after their loads were issued (applied
             // at the load it would make every step wait for its own global loads)
-            tn_split4(PRO ? (bok ? rb[B16 ? 0 : i] * pa4 + po4 : rb[B16 ? 0 : i]) : rb[B16 ? 0 : i], hi, lo);
+            tn_split4(PRO ? (bok ? rb[i] * pa4 + po4 : rb[i]) : rb[i], hi, lo);
             *reinterpret_cast<u32x2*>(st + 2 * TN_PLANE + o) = hi;
             *reinterpret_cast<u32x2*>(st + 3 * TN_PLANE + o) = lo;
         }
@@ -160,45 +131,12 @@ __global__ __launch_bounds__(256, F16 ? TN_F16_BLOCKS : 2) void gemm_tn_x3_kerne
     if (nsteps > 0) load(0);
     for (int s = 0; s < nsteps; ++s) {
         const int stage = s & 1;
-#ifdef TN_DIAG_NOSTORE
-        if (s < 2) store(stage);
-        else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(ra[i]));
-        }
-#else
         store(stage);
-#endif
         __syncthreads();   // stage complete; every wave is past its reads of the other stage's previous contents
-#ifdef TN_DIAG_NOLOAD   // diagnostic builds (tools/probe/tn_probe.hip): one ingredient removed each; results are garbage, only the time matters
-        if (s == 0) load(1 < nsteps ? 1 : 0);
-#else
         if (s + 1 < nsteps) load(s + 1);
-#endif
-        const u16* st = lds + stage * NPL * TN_PLANE;
+        const u16* st = lds + stage * 4 * TN_PLANE;
 #pragma unroll
         for (int sg = 0; sg < 2; ++sg) {
-            if (F16) {
-                f16x8 a[2], bb[2];
-#ifdef TN_DIAG_NOREAD
-                if (s == 0)
-#endif
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    a[i] = __builtin_bit_cast(f16x8, frag(st, sg, wn * 2 + i));
-                    bb[i] = __builtin_bit_cast(f16x8, frag(st + TN_PLANE, sg, wk * 2 + i));
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#ifdef TN_DIAG_NOMFMA
-                        acc[i][j][0] += (float)a[i][0] + (float)bb[j][0];
-#else
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], bb[j], acc[i][j], 0, 0, 0);
-#endif
-                continue;
-            }
             bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -251,12 +189,13 @@ bool gemm_tn_x3_supported(const TnArgs& g) {
 int gemm_tn_x3_launch(const TnArgs& g, hipStream_t st) {
     if (!gemm_tn_x3_supported(g)) return -9;
     const int G = (g.Z + g.group - 1) / g.group;
-    const size_t lds = (size_t)2 * (g.f16 ? 2 : 4) * TN_PLANE * 2;
+    const size_t lds = (size_t)2 * 4 * TN_PLANE * 2;
     static bool attr = false;
-    if (!attr) {   // the split-bf16 form's four planes x two stages = 64 KiB (the fp16 forms' 32 KiB need no attribute)
-        const int lds_x3 = 2 * 4 * TN_PLANE * 2;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_x3);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_x3);
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
         attr = true;
     }
     static int xcd = -1;
@@ -267,13 +206,7 @@ int gemm_tn_x3_launch(const TnArgs& g, hipStream_t st) {
     TnArgs ga = g;
     ga.xcd = xcd;
     const dim3 grid(((g.N + 127) / 128) * ((g.K + 127) / 128), G);
-    if (g.f16 && g.b_f16) {
-        if (g.pro_a || (g.ldb & 3)) return -9;
-        hipLaunchKernelGGL((gemm_tn_x3_kernel<false, true, true>), grid, dim3(256), lds, st, ga);
-    } else if (g.f16) {
-        if (g.pro_a) hipLaunchKernelGGL((gemm_tn_x3_kernel<true, true>), grid, dim3(256), lds, st, ga);
-        else hipLaunchKernelGGL((gemm_tn_x3_kernel<false, true>), grid, dim3(256), lds, st, ga);
-    } else if (g.pro_a) hipLaunchKernelGGL(gemm_tn_x3_kernel<true>, grid, dim3(256), lds, st, ga);
+    if (g.pro_a) hipLaunchKernelGGL(gemm_tn_x3_kernel<true>, grid, dim3(256), lds, st, ga);
     else hipLaunchKernelGGL(gemm_tn_x3_kernel<false>, grid, dim3(256), lds, st, ga);
     return (int)hipGetLastError();
 }

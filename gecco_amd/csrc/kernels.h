@@ -178,6 +178,10 @@ struct TnArgs {
     int f16;           // 1: both operands rounded to fp16, one MFMA per product (the reference's autocast(float16) trainer arithmetic)
     int b_f16;         // (with f16) Bm is an fp16 tensor already: its tiles go to LDS as they are
 };
+// gemm_tn_f16.hip: the same product with fp16 operands (TnArgs::f16 / b_f16), block tile chosen per shape
+bool gemm_tn_f16_supported(const TnArgs& g);
+int gemm_tn_f16_tiles(int N, int K);
+int gemm_tn_f16_launch(const TnArgs& g, hipStream_t st);
 // gemm_x3_areg.hip: split-bf16 GEMM whose A operand is a tiled split image loaded global -> registers (GemmArgs::a_img)
 bool gemm_x3_areg_supported(const GemmArgs& g);
 int gemm_x3_areg_launch(const GemmArgs& g, hipStream_t st);

@@ -538,6 +538,9 @@ int gecco_gemm_tn_x3_pro_f32(const float* A, const float* Bm, const float* pro_a
  * and colsum_parts may be NULL.  The caller's GradScaler keeps dY inside fp16's range, as it does for the reference. */
 int gecco_gemm_tn_f16_f32(const float* A, const float* Bm, const float* pro_a, const float* pro_o, float* parts,
                           float* colsum_parts, int Z, int R, int N, int K, int group, void* stream);
+/* output tiles per sample group of that kernel for an (N, K) gradient (its block tile is 128 x 128, 256 x 128 or 128 x 256 by shape):
+ * the caller sizes `group` so that groups x tiles fill the chip */
+int gecco_gemm_tn_f16_tiles(int N, int K);
 /* the same with B already an fp16 tensor (Z, R, K) — the hidden layer of an MLP that gecco_linear_act_keep_h16 stored that way:
  * its tiles go to LDS as they are (no AdaGN apply) */
 int gecco_gemm_tn_f16_b16_f32(const float* A, const void* B16, float* parts, float* colsum_parts, int Z, int R, int N, int K, int group,

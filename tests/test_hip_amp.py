@@ -42,11 +42,7 @@ def _r16(t):
     return t.half().double()
 
 
-@pytest.mark.parametrize("N,K", [(256, 384), (768, 384), (96, 384), (384, 96), (96, 48), (384, 672), (4, 132)])
-def test_fp16_weight_gradient_kernel(N, K):
-    """gecco_gemm_tn_f16_f32: dW = dY^T X with both operands rounded to fp16 and one MFMA per product — against fp64 on the
-    fp16-rounded operands (only the fp32 accumulation order separates them) and against fp64 on the operands themselves (the fp16
-    rounding: ~3e-4); grouped partials; the AdaGN apply on X and the column sums of dY (the bias gradient) out of the same pass."""
+def _check_fp16_dw(N, K):
     from gecco_amd import _lib
     lib = _lib.load()
     rs = np.random.RandomState(7)
@@ -72,6 +68,32 @@ def test_fp16_weight_gradient_kernel(N, K):
             assert _rel(got, ref16) <= (2e-5 if pro else 2e-6), (pro, group, _rel(got, ref16))
             assert _rel(got, ref) <= 1e-3, (pro, group, _rel(got, ref))
             assert _rel(cs.double().sum(0), dy.double().sum((0, 1))) <= 1e-6   # column sums are fp32 sums of the fp32 values
+            if not pro and K % 8 == 0:   # X as an fp16 tensor already: the same product of the same halves
+                p16 = torch.full((G, N, K), float("nan"), device="cuda")
+                x16 = xc.half()
+                _lib.check(lib.gecco_gemm_tn_f16_b16_f32(C.c_void_p(dyc.data_ptr()), C.c_void_p(x16.data_ptr()), C.c_void_p(p16.data_ptr()), None,
+                                                         Z, R, N, K, group, None), "gemm_tn_f16_b16")
+                assert torch.equal(p16, parts)
+
+
+@pytest.mark.parametrize("N,K", [(256, 384), (768, 384), (384, 768), (96, 384), (384, 96), (96, 48), (384, 672), (4, 132)])
+@pytest.mark.parametrize("wide", ["0", "1"])
+def test_fp16_weight_gradient_kernel(N, K, wide):
+    """gecco_gemm_tn_f16_f32 (gemm_tn_f16.hip): dW = dY^T X with both operands rounded to fp16 and one MFMA per product — against fp64 on
+    the fp16-rounded operands (only the fp32 accumulation order separates them) and against fp64 on the operands themselves (the fp16
+    rounding: ~3e-4); grouped partials; the AdaGN apply on X and the column sums of dY (the bias gradient) out of the same pass; X as
+    an fp16 tensor (gecco_gemm_tn_f16_b16_f32) gives the same bits.  wide = 1: the opt-in 256 x 128 / 128 x 256 block tiles
+    (GECCO_TN_F16_WIDE, read once per process: a child process)."""
+    if wide == "0":
+        _check_fp16_dw(N, K)
+        return
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", f"from tests.test_hip_amp import _check_fp16_dw; _check_fp16_dw({N}, {K})"], cwd=root,
+                       env={**os.environ, "GECCO_TN_F16_WIDE": "1"}, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_transposed_fp16_weight_image_equals_the_image_of_the_transposed_copy():

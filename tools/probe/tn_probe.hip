@@ -1,7 +1,7 @@
-// Diagnostic: the fp16 weight-gradient kernel (gemm_tn_x3.hip, F16 forms) alone at the training shapes of C2 (48 x 2048 rows; 768 x 384,
+// Diagnostic: the fp16 weight-gradient kernel (gemm_tn_f16.hip) alone at the training shapes of C2 (48 x 2048 rows; 768 x 384,
 // 384 x 768, 384 x 384 outputs), built with one ingredient removed each (tools/probe/build_tn.sh): where its time goes.
 #include <hip/hip_runtime.h>
-#include "../../gecco_amd/csrc/gemm_tn_x3.hip"
+#include "../../gecco_amd/csrc/gemm_tn_f16.hip"
 #include <stdio.h>
 #include <vector>
 
@@ -27,14 +27,14 @@ int main(int argc, char** argv) {
             g.A = dy; g.Bm = x; g.C = parts; g.Z = Z; g.R = R; g.N = shapes[k][0]; g.K = shapes[k][1]; g.lda = g.N; g.ldb = g.K;
             g.sA = (size_t)R * g.N; g.sB = (size_t)R * g.K; g.group = 1; g.f16 = 1;
             if (pro) { g.pro_a = pa; g.pro_o = po; }
-            gemm_tn_x3_launch(g, 0); gemm_tn_x3_launch(g, 0);
+            gemm_tn_f16_launch(g, 0); gemm_tn_f16_launch(g, 0);
             (void)hipEventRecord(a, 0);
-            for (int i = 0; i < 8; ++i) gemm_tn_x3_launch(g, 0);
+            for (int i = 0; i < 8; ++i) gemm_tn_f16_launch(g, 0);
             (void)hipEventRecord(b, 0); (void)hipEventSynchronize(b);
             float ms; (void)hipEventElapsedTime(&ms, a, b); ms /= 8;
             const double by = 4.0 * Z * R * (g.N + g.K);
             printf("%-12s N %d K %d pro %d: %.1f us (operands once %.0f MB: %.2f TB/s; %d blocks x %d steps)\n", argv[0], g.N, g.K, pro, ms * 1e3, by / 1e6,
-                   by / ms / 1e9, ((g.N + 127) / 128) * ((g.K + 127) / 128) * Z, R / 32);
+                   by / ms / 1e9, gemm_tn_f16_tiles(g.N, g.K) * Z, R / 32);
         }
     return 0;
 }

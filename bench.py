@@ -491,7 +491,7 @@ def train_bench(args, rank, world, dev):
     rec = {"metric": "train_points_per_sec", "value": world * Bt * Nt * args.steps / dt, "unit": "points/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None,
-           "dtype": "f16 operands, f32 accumulate (torch.autocast(float16) + GradScaler = the reference's precision='16-mixed'; attention in split-bf16)"
+           "dtype": "f16 operands, f32 accumulate (torch.autocast(float16) + GradScaler = the reference's precision='16-mixed')"
                     if args.amp else
                     {"bf16x3": "bf16 (split hi+lo operands, 3 MFMAs per product, fp32 accumulate)", "fp32": "f32",
                      "fp16": "bf16 (split; the fp16 mode is not used for gradients)",

@@ -227,6 +227,41 @@ def test_fused_adam_in_the_grad_scaler_protocol_matches_torch():
     assert steps == {float(len(grads) - 1)} == {float(v["step"]) for v in ref_opt.state_dict()["state"].values()}
 
 
+def test_grad_scaler_unscale_then_clip_then_step():
+    """Lightning's order when the trainer clips gradients (both shipped configs do: gradient_clip_val):
+    scaler.unscale_(optimizer) -> clip_grad_norm_ -> scaler.step(optimizer).  The scaler then hands FusedAdamEMA `grad_scale = None`
+    (already unscaled) with the found_inf of the unscale pass: the kernel must not divide again; against torch.optim.Adam's
+    single-tensor path on the host with the same clipping."""
+    from gecco_amd.optim import FusedAdamEMA
+    rs = np.random.RandomState(2)
+    shapes = [(32, 24), (24,), (5, 3)]
+    init = [_t(rs.randn(*s)) for s in shapes]
+    grads = [[_t(rs.randn(*s)) for s in shapes] for _ in range(3)]
+    ps = [torch.nn.Parameter(t.clone()) for t in init]
+    ref_opt = torch.optim.Adam(ps, lr=1e-2, foreach=False)
+    for gs in grads:
+        for p, g in zip(ps, gs):
+            p.grad = (g * 512.0) * (1.0 / 512.0)
+        torch.nn.utils.clip_grad_norm_(ps, 1.0, foreach=False)
+        ref_opt.step()
+    ps2 = [torch.nn.Parameter(t.clone().cuda()) for t in init]
+    fused = FusedAdamEMA(ps2, lr=1e-2, ema_decay=None)
+    scaler = torch.amp.GradScaler("cuda", init_scale=512.0, growth_interval=1000)
+    for gs in grads:
+        fused.zero_grad(set_to_none=True)
+        scaler.scale(torch.zeros(1, device="cuda"))
+        for p, g in zip(ps2, gs):
+            p.grad = (g.cuda() * scaler.get_scale()).clone()
+        scaler.unscale_(fused)
+        torch.nn.utils.clip_grad_norm_(ps2, 1.0)
+        scaler.step(fused)
+        scaler.update()
+    torch.cuda.synchronize()
+    for a, b in zip(ps, ps2):
+        assert _rel(b.detach(), a.detach()) <= 2e-6
+    assert fused.adam_steps_taken == 3
+
+
 def test_c2_full_size_gradients_under_autocast_vs_oracle():
     """The training path at the headline size (N = 2048, d = 384, L = 6) in the reference's trainer setting: EDM loss under
     torch.autocast(float16), scaled loss, every parameter gradient against torch autograd through the oracle in fp32.  Bars: the

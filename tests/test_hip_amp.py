@@ -439,3 +439,41 @@ def test_attention_fn_grads_under_autocast(B, N, C, H, monkeypatch):
         assert _rel(a, b) < 2e-3, (i, _rel(a, b))
         assert _rel(c, b) < 1e-4
         assert not torch.equal(a, c)
+
+
+def test_scaler_dynamics_on_a_real_run():
+    """120 steps of the 16-mixed setting with a fast-growing loss scale (growth_interval 8): the scale climbs until the fp16 operands
+    of a backward product overflow, the infinities reach the weight gradients, GradScaler sees them, FusedAdamEMA skips that step on
+    the device and the scale backs off — repeatedly.  The loss of the fixed batch goes down, every parameter stays finite, Adam's step
+    count = launches - skips, and no step reads found_inf back on the host (the loop issues all steps before the one synchronisation)."""
+    from gecco_amd import autograd as ag
+    from gecco_amd.optim import FusedAdamEMA
+    from gecco_amd.structs import Example
+    from tests.test_hip_training import _small_training_setup
+    ag.WEIGHT_IMAGES.__init__()
+    m, batch = _small_training_setup(13)
+    opt = FusedAdamEMA(m.parameters(), lr=2e-4, ema_decay=0.99)
+    scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 20, growth_interval=8)
+    losses, scales = [], []
+    for it in range(120):
+        torch.manual_seed(100)     # the same sigma / noise draws each step
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            loss = m.training_step(batch, it)
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        losses.append(loss.detach())
+        scales.append(scaler._scale.clone())
+    torch.cuda.synchronize()
+    losses = [float(v) for v in losses]
+    scales = [float(v) for v in scales]
+    skipped = 120 - opt.adam_steps_taken
+    print(f"16-mixed run: loss {losses[0]:.3f} -> {losses[-1]:.3f}, scale 2^20 -> 2^{int(np.log2(scales[-1]))} (max 2^{int(np.log2(max(scales)))}), "
+          f"{skipped} skipped steps")
+    assert all(np.isfinite(losses)) and losses[-1] < 0.9 * losses[0]
+    assert skipped >= 2 and skipped < 60                       # the scale really hit the ceiling, and training went on
+    assert min(scales) < max(scales)
+    assert all(bool(torch.isfinite(p).all()) for p in m.parameters())
+    assert all(bool(torch.isfinite(e).all()) for e in opt.ema_params)
+    ag.WEIGHT_IMAGES.__init__()

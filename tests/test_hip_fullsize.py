@@ -246,9 +246,9 @@ def test_c2_full_size_gradients_vs_oracle(ops, precision):
     assert worst[1] > 0.0   # gradients were really compared
 
 
-@pytest.mark.parametrize("cfg", ["C3", "C4", "C3-amp"])
+@pytest.mark.parametrize("cfg", ["C3", "C4", "C3-amp", "C4-amp"])
 def test_conditional_full_size_training_step_vs_oracle(ops, cfg):
-    """"C3-amp": the same step in the reference's trainer setting (torch.autocast(float16), scaled loss: tests/test_hip_amp.py) — the
+    """"C3-amp" / "C4-amp" (d = 512: the K = 512 forms of the A-stationary fp16 kernels): the same step in the reference's trainer setting (torch.autocast(float16), scaled loss: tests/test_hip_amp.py) — the
     denoiser's AND the conditioner's linears with fp16 operands; bars from the reference's own deviation in that setting (2.1e-3
     overall, 4e-3 per tensor at d = 384: profiles/r04h_autocast_grad_deviation.txt): 6e-3 per tensor here, where the conditioner's
     small first-stage matrices sit behind three more stages of rounding.

@@ -47,8 +47,9 @@ def _reduce(parts: Tensor, n: int, Z: int, stride: int) -> Tensor:
 
 
 def _train_precision() -> str:
-    """Arithmetic of the N-token linears in the training path: the module default, except that the fp16 mode is not used
-    for gradients (no loss scaling: small gradient values would flush) — split-bf16 has the fp32 exponent range."""
+    """Arithmetic of the training path OUTSIDE an autocast(float16) region: the module default, except that the fp16 / mixed modes
+    train in split-bf16 — without a loss scale small gradient values would flush in fp16, split-bf16 has the fp32 exponent range.
+    (Under torch.autocast(float16), the reference's trainer setting, a GradScaler supplies that scale: `_lin_precision`.)"""
     p = hip_ops.default_precision()
     return "bf16x3" if p in ("fp16", "mixed") else p
 

@@ -209,7 +209,8 @@ def _edm_loss(D, data, noise, sigma):
 def test_c2_full_size_gradients_vs_oracle(ops, precision):
     """The TRAINING path at the headline size (N = 2048, d = 384, L = 6): EDM loss and the gradient of every parameter,
     HIP autograd Functions (gecco_amd/autograd.py) against torch autograd through the oracle on the host cores.  The mixed /
-    fp16 modes train in split-bf16 (no loss scaling), so "bf16x3" is what `bench.py --train` runs."""
+    fp16 modes train in split-bf16 outside an autocast region (no loss scaling), so "bf16x3" is what `bench.py --train` runs without
+    `--amp`; the 16-mixed setting: tests/test_hip_amp.py."""
     from tests.test_modules_cpu import build_uncond, uncond_state_dict
     d, L, N, B = 384, 6, 2048, 2
     p = W.linear_lift_state_dict(3, d, L, cases.I, cases.H)

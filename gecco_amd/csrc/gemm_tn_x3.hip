@@ -73,6 +73,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(TnArgs g) {
 
     // global tile loads: thread -> 4 x (row, 4 columns) of each operand
     f32x4 ra[4], rb[4];
+    const unsigned va = aok ? (unsigned)(((tid >> 5) * g.lda + (tid & 31) * 4) * 4) : 0x7fffffffu;
+    const unsigned vb_ = bok ? (unsigned)(((tid >> 5) * g.ldb + (tid & 31) * 4) * 4) : 0x7fffffffu;
     f32x4 pa4 = {1.f, 1.f, 1.f, 1.f}, po4 = {0.f, 0.f, 0.f, 0.f};   // AdaGN coefficients of the thread's four X columns, sample zc
     int zc = -1;
     auto load = [&](int s) {
@@ -82,13 +84,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(TnArgs g) {
             po4 = *reinterpret_cast<const f32x4*>(g.pro_o + (size_t)z * g.K + k0 + (tid & 31) * 4);
         }
         zc = z;
-        const float* Ab = g.A + (size_t)z * g.sA + (size_t)m0 * g.lda + n0;
-        const float* Bb = g.Bm + (size_t)z * g.sB + (size_t)m0 * g.ldb + k0;
+        // raw buffer loads (gemm_tn_f16.hip): one per-lane byte offset per operand — out of range, so zeros, beyond the matrix — and
+        // scalar offsets for the slab and the row group, instead of eight 64-bit addresses
+        const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A + (size_t)z * g.sA), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.Bm + (size_t)z * g.sB), 0, 0x7fffffff, 0x00020000);
+        const unsigned sa0 = (unsigned)((m0 * g.lda + n0) * 4), sb0 = (unsigned)((m0 * g.ldb + k0) * 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int f = tid + i * 256, row = f >> 5, c4 = f & 31;
-            ra[i] = aok ? *reinterpret_cast<const f32x4*>(Ab + (size_t)row * g.lda + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-            rb[i] = bok ? *reinterpret_cast<const f32x4*>(Bb + (size_t)row * g.ldb + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, va, sa0 + (unsigned)(i * 8 * g.lda * 4), 0));
+            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, vb_, sb0 + (unsigned)(i * 8 * g.ldb * 4), 0));
         }
     };
     // bias gradient = column sums of dY: the blocks of the first K tile add up the rows they stage anyway
@@ -182,8 +186,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(TnArgs g) {
 }  // namespace
 
 bool gemm_tn_x3_supported(const TnArgs& g) {
+    // one sample's rows are addressed with 31-bit byte offsets (buffer loads)
     return g.Z > 0 && g.group > 0 && g.R >= 32 && g.R % 32 == 0 && g.N > 0 && g.K > 0 && !(g.N & 3) && !(g.K & 3) && !(g.lda & 3) &&
-           !(g.ldb & 3);
+           !(g.ldb & 3) && (size_t)g.R * g.lda * 4 < 0x7fffffffu && (size_t)g.R * g.ldb * 4 < 0x7fffffffu;
 }
 
 int gemm_tn_x3_launch(const TnArgs& g, hipStream_t st) {

@@ -14,6 +14,8 @@
 #include "common.h"
 #include "kernels.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
@@ -389,8 +391,13 @@ int pool_attn_nsplit(int B, int N, int H) {
     // A function of N only: the key-split (hence the summation order) must not depend on the batch
     // size, so a sample's result is bit-identical whatever batch (or GPU shard) it is evaluated in.
     (void)B; (void)H;
+    static int keys = 0;
+    if (!keys) {
+        const char* e = getenv("GECCO_POOL_SPLIT_KEYS");   // keys per split below which a cloud is not split further (A/B runs)
+        keys = e && atoi(e) >= 32 ? atoi(e) : 1024;
+    }
     int ns = 1;
-    while (ns < 8 && N / (ns * 2) >= 1024) ns *= 2;
+    while (ns < 8 && N / (ns * 2) >= keys) ns *= 2;
     return ns;
 }
 

@@ -236,8 +236,14 @@ __global__ __launch_bounds__(256, 2) void pool_attn_x3_kernel(const float* __res
     __syncthreads();  // the shared query planes are complete
     for (int it = 0; it < nit; ++it) {
         const int tile = wave + 4 * it;
+#ifdef PA_DIAG_NOSTORE   // diagnostic builds (tools/probe/pool_probe.hip): one ingredient removed each; only the time matters
+        if (it == 0)
+#endif
         store_tile();
         wave_lds_sync();
+#ifdef PA_DIAG_NOLOAD
+        if (it == 0)
+#endif
         load_tile(tile + 4);
         if (tile < ntiles) {
             f32x16 s[2];
@@ -253,11 +259,16 @@ __global__ __launch_bounds__(256, 2) void pool_attn_x3_kernel(const float* __res
                 for (int j = 0; j < 2; ++j) {
                     const u32x4 qh = frag(Qhi + (j * 32 + r) * KS + c * 16 + 8 * h);
                     const u32x4 ql = F16 ? qh : frag(Qlo + (j * 32 + r) * KS + c * 16 + 8 * h);
+#ifdef PA_DIAG_NOMFMA
+                    s[j][0] += (float)ah[0] + (float)qh[0];
+#else
                     s[j] = mfma3<F16>(ah, al, qh, ql, s[j]);
+#endif
                 }
             }
             const int kbase = k_begin + tile * 32;
             const bool ragged = kbase + 32 > k_end;   // wave-uniform: only a split's last tile masks keys
+#ifndef PA_DIAG_NOSOFTMAX
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 float mx = -INFINITY;
@@ -288,6 +299,7 @@ __global__ __launch_bounds__(256, 2) void pool_attn_x3_kernel(const float* __res
                         for (int e = 0; e < 16; ++e) O[dt][j][e] *= alpha;
                 }
             }
+#endif
 #pragma unroll
             for (int sg = 0; sg < 2; ++sg) {   // the tile's two 16-key chunks
                 u32x4 ph[2], pl[2];
@@ -308,7 +320,12 @@ __global__ __launch_bounds__(256, 2) void pool_attn_x3_kernel(const float* __res
                         vl = __builtin_bit_cast(u32x4, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
                     }
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) O[dt][j] = mfma3<F16>(vh, vl, ph[j], pl[j], O[dt][j]);
+                    for (int j = 0; j < 2; ++j)
+#ifdef PA_DIAG_NOMFMA
+                        O[dt][j][0] += (float)vh[0] + (float)ph[j][0];
+#else
+                        O[dt][j] = mfma3<F16>(vh, vl, ph[j], pl[j], O[dt][j]);
+#endif
                 }
             }
         }

@@ -222,6 +222,31 @@ def _image_ok(rows: int, K: int, Nout: int, prec: str = "bf16x3") -> bool:
 
 
 # ------------------------------------------------------------------------------------------- Linear
+def _linear_dx_dot(dy: Tensor, W: Tensor, x: Tensor, prec: str | None = None):
+    """(dx, gst): dx = dy W and the partial sums {sum dx, sum dx * x} per (sample, row tile, column) that the AdaGN backward of the
+    tensor x needs (`_adagn_backward(..., gst=)`), from the GEMM's epilogue (`gecco_linear_dotstats_f32`) instead of a
+    `col_dot_stats` pass over dx and x; gst None where the LDS-DMA kernels do not take the shape (the caller's AdaGN backward then
+    runs that pass)."""
+    lib = _lib.load()
+    B, R, Nout = dy.shape
+    K = W.shape[1]
+    prec = _resolve(prec, R, Nout, K)
+    if (os.environ.get("GECCO_TRAIN_DOTSTATS", "1") == "0" or prec not in ("fp32", "bf16x3", "fp16")
+            or not lib.gecco_linear_actbwd_ok(R, Nout, K, hip_ops.PRECISIONS[prec])):
+        return _linear_dx(dy, W, prec=prec), None
+    dx = _new(B, R, K, like=dy)
+    gst = _new(B, lib.gecco_linear_row_tiles(R), 2, K, like=dy)
+    img = WEIGHT_IMAGES.lookup("t", W, prec=prec) if prec in ("bf16x3", "fp16") else None
+    if img is not None:
+        Wt, ws = None, img
+    else:
+        Wt = W.t().contiguous()
+        ws = hip_ops._ws((K + 127) // 128 * 128 * Nout * 4, dy.device) if prec != "fp32" else None
+    _lib.check(lib.gecco_linear_dotstats_f32(_ptr(dy), _ptr(Wt), _ptr(x), _ptr(dx), _ptr(gst), B, R, Nout, K, hip_ops.PRECISIONS[prec],
+                                             C.c_void_p(ws.data_ptr()) if ws is not None else None, _stream()), "gecco_linear_dotstats_f32")
+    return dx, gst
+
+
 def _linear_dx(dy: Tensor, W: Tensor, residual: Tensor | None = None, prec: str | None = None) -> Tensor:
     """dx = dy W (+ residual: another gradient contribution to the same tensor, added in the GEMM's epilogue).
     prec: the arithmetic the Function's forward chose (`_lin_precision()`); None: the training precision."""
@@ -487,15 +512,17 @@ class AdaGNFn(torch.autograd.Function):
         return dx, None, dsw, dsb, dbw, dbb, None, None, None, None
 
 
-def _adagn_backward(x, stats, t2, sw, sb, dy, dskip, G, eps, affine):
+def _adagn_backward(x, stats, t2, sw, sb, dy, dskip, G, eps, affine, gst=None):
     """Backward of y = scale(t) GroupNorm(x) + bias(t) given dy (and the gradient `dskip` that reached x through a skip
-    connection, added in the same pass): dx and the gradients of the scale / bias linears."""
+    connection, added in the same pass): dx and the gradients of the scale / bias linears.
+    gst: the {sum dy, sum dy x} partials when the GEMM that produced dy already formed them (`_linear_dx_dot`)."""
     lib = _lib.load()
     B, R, Cc = x.shape
-    # {sum dy, sum dy x} partials in col_dot_stats' own row tiling (the forward statistics may come from a GEMM epilogue
-    # with another one)
-    gst = _new(B, lib.gecco_stats_row_tiles(R), 2, Cc, like=x)
-    _lib.check(lib.gecco_col_dot_stats_f32(_ptr(dy), _ptr(x), _ptr(gst), B, R, Cc, _stream()), "col_dot_stats")
+    if gst is None:
+        # {sum dy, sum dy x} partials in col_dot_stats' own row tiling (the forward statistics may come from a GEMM epilogue
+        # with another one)
+        gst = _new(B, lib.gecco_stats_row_tiles(R), 2, Cc, like=x)
+        _lib.check(lib.gecco_col_dot_stats_f32(_ptr(dy), _ptr(x), _ptr(gst), B, R, Cc, _stream()), "col_dot_stats")
     cA, cB, cC, ds, dz = (_new(B, Cc, like=x) for _ in range(5))
     p = _lib.GeccoAdaGN(_ptr(sw), _ptr(sb), None, None) if affine else None
     ctxd = 0 if t2 is None else t2.shape[1]
@@ -637,8 +664,8 @@ class AdaGNMlpFn(torch.autograd.Function):
             return (_linear_dw(g, act_in, pro=pro, leaf=Wl, prec=prec) if need[iw] else None), (_linear_db(g) if has_b and need[ib] else None)
         dW2, db2 = wgrads(dout, h, ctx.bias[1], 12, 13, W2)
         dW0, db0 = wgrads(du, x, ctx.bias[0], 9, 10, W0, pro=(a, o))
-        dY = _linear_dx(du, W0, prec=prec)
-        dx, dsw, dsb, dbw, dbb = _adagn_backward(x, stats, t2, sw, sb, dY, dout, ctx.G, ctx.eps, True)
+        dY, gst = _linear_dx_dot(du, W0, x, prec=prec)
+        dx, dsw, dsb, dbw, dbb = _adagn_backward(x, stats, t2, sw, sb, dY, dout, ctx.G, ctx.eps, True, gst=gst)
         return dx, None, dsw, dsb, dbw, dbb, None, None, None, dW0, db0, dalpha, dW2, db2, None, None
 
 

@@ -122,9 +122,10 @@ int linear(const float* A, const float* W, const float* bias, const float* pa, c
            const float* res, float* C, float* stats, int B, int rows, int K, int Nout, int act, hipStream_t s,
            int precision = 0, float* wsplit = nullptr, const float* img_ready = nullptr, int a_f16 = 0, int c_f16 = 0,
            int a_img = 0, int c_img = 0, const float* mul_u = nullptr, int mul_kind = 0, float* agrad = nullptr,
-           float* pre_out = nullptr) {
+           float* pre_out = nullptr, const float* dot_x = nullptr) {
     GemmArgs g{};
     g.pre_out = pre_out;
+    g.dot_x = dot_x;
     g.a_img = a_img; g.c_img = c_img;   // activation handed over as a tiled split image (kernels.h); callers check act_image_ok
     g.mul_u = mul_u; g.mul_kind = mul_kind; g.agrad = agrad;   // activation backward as the epilogue (LDS-DMA kernels only)
     g.A = A; g.W = W; g.bias = bias; g.pro_a = pa; g.pro_o = po; g.alpha = alpha; g.residual = res; g.C = C;
@@ -137,7 +138,7 @@ int linear(const float* A, const float* W, const float* bias, const float* pa, c
     const bool fast = precision == 1 ? gemm_f32_dma_supported(g, 1) : precision == 2 ? gemm_f16_dma_supported(g) : false;
     if ((a_f16 || c_f16) && !(fast && precision == 2 && (wsplit || img_ready))) return -9;
     if ((a_img || c_img) && !(fast && precision == 1 && (wsplit || img_ready))) return -9;
-    if ((mul_u || pre_out) && !(precision == 0 ? gemm_f32_dma_supported(g, 0) : (fast && (wsplit || img_ready)))) return -9;
+    if ((mul_u || pre_out || dot_x) && !(precision == 0 ? gemm_f32_dma_supported(g, 0) : (fast && (wsplit || img_ready)))) return -9;
     if (!W && !(fast && img_ready)) return -9;
     if (fast && (wsplit || img_ready)) {
         if (img_ready) {
@@ -820,6 +821,18 @@ int gecco_linear_actbwd_f32(const float* A, const float* W, const float* u, cons
     TRY(linear(A, W, nullptr, nullptr, nullptr, alpha, residual, C, nullptr, B, rows, K, Nout, 0, (hipStream_t)stream, precision,
                W ? static_cast<float*>(wsplit) : nullptr, W ? nullptr : static_cast<const float*>(wsplit), 0, 0, 0, 0, u, kind,
                (kind == 1 || kind == 2) ? agrad : nullptr), "linear_actbwd");
+    return 0;
+}
+
+int gecco_linear_dotstats_f32(const float* A, const float* W, const float* dot_x, float* C, float* stats, int B, int rows, int K, int Nout,
+                              int precision, void* wsplit, void* stream) {
+    if (!A || !dot_x || !C || !stats) return fail(-1, "linear_dotstats: null argument");
+    if (!gecco_linear_actbwd_ok(rows, K, Nout, precision)) return fail(-2, "linear_dotstats: shape / precision outside the LDS-DMA kernels' reach");
+    if (precision >= 1 && !wsplit) return fail(-1, "linear_dotstats: precision 1 / 2 need wsplit");
+    if (!W && precision == 0) return fail(-2, "linear_dotstats: W == NULL (image ready) needs precision 1 / 2");
+    TRY(linear(A, W, nullptr, nullptr, nullptr, nullptr, nullptr, C, stats, B, rows, K, Nout, 0, (hipStream_t)stream, precision,
+               W ? static_cast<float*>(wsplit) : nullptr, W ? nullptr : static_cast<const float*>(wsplit), 0, 0, 0, 0, nullptr, 0, nullptr, nullptr,
+               dot_x), "linear_dotstats");
     return 0;
 }
 

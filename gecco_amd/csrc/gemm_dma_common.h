@@ -85,6 +85,7 @@ __device__ __forceinline__ void epilogue_t(const GemmArgs& g, const Tile& t, f32
     float ga = 0.f;   // this thread's share of sum (A W^T) d act / d alpha
     float* Cb = Cseg + (size_t)b * g.rows * ldc_seg;
     const float* Rb = g.residual ? g.residual + (size_t)b * g.rows * g.ldr : nullptr;
+    const float* Xb = (ACTBWD && g.dot_x) ? g.dot_x + (size_t)b * g.rows * ldc_seg : nullptr;   // second statistic = sum C * dot_x
     float* Tt = smem + wave * 32 * D_TP;
     float* red = smem + 4 * 32 * D_TP;
     const int lr = lane >> 4, c4 = lane & 15;   // 16 lanes per 64-float row, 4 rows per wave-instruction
@@ -113,6 +114,12 @@ __device__ __forceinline__ void epilogue_t(const GemmArgs& g, const Tile& t, f32
                 for (int it = 0; it < 8; ++it) {
                     const int m = min(mrow0 + it * 4 + lr, g.rows - 1);
                     rres[it] = GECCO_NT_LOAD(reinterpret_cast<const f32x4*>(Rb + (size_t)m * g.ldr + nc));
+                }
+            } else if (ACTBWD && Xb) {   // ... or the rows of the tensor whose AdaGN backward wants {sum dy, sum dy x}
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int m = min(mrow0 + it * 4 + lr, g.rows - 1);
+                    rres[it] = GECCO_NT_LOAD(reinterpret_cast<const f32x4*>(Xb + (size_t)m * ldc_seg + nc));
                 }
             } else if (ACTBWD && Ub) {   // the same eight loads in flight serve the pre-activation rows of the backward epilogue
 #pragma unroll
@@ -246,8 +253,13 @@ __device__ __forceinline__ void epilogue_t(const GemmArgs& g, const Tile& t, f32
                 s1[jh] += vz;
                 // an explicit fma: left to -ffp-contract the compiler fuses this in some instantiations of the template and
                 // not in others, and the kernels that share this epilogue stop agreeing to the bit on the statistics
+                if (ACTBWD && Xb) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) s2[jh][q] = __builtin_fmaf(vz[q], vz[q], s2[jh][q]);
+                    for (int q = 0; q < 4; ++q) s2[jh][q] = __builtin_fmaf(vz[q], rres[it][q], s2[jh][q]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) s2[jh][q] = __builtin_fmaf(vz[q], vz[q], s2[jh][q]);
+                }
             }
         }
     }

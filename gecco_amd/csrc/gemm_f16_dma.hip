@@ -362,7 +362,8 @@ int f16_launch_t(const GemmArgs& g, hipStream_t st) {
         attr = lds;
     }
     const dim3 grid(g.B * tilesM * tilesN);
-    if (g.mul_u || g.pre_out) {   // the training path's epilogue forms: their own kernel instantiations
+    if (g.dot_x && (g.residual || g.mul_u || g.pre_out || !g.stats || g.C2 || A16 || C16)) return -9;
+    if (g.mul_u || g.pre_out || g.dot_x) {   // the training path's epilogue forms: their own kernel instantiations
         // fp32 tensors, except that the KEEP form may store act(u) as fp16 (C16: the hidden layer of an MLP, which only the matrix pipe
         // reads again — as an fp16 operand either way) beside the fp32 pre-activation
         if (A16 || (C16 && g.mul_u) || (g.mul_u && g.pro_a) || g.c_img) return -9;

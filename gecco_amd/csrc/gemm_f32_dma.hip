@@ -383,8 +383,8 @@ int dma_launch_t(const GemmArgs& g, hipStream_t st) {
         attr = lds;
     }
     const dim3 grid(g.B * tilesM * tilesN);
-    if (g.mul_u || g.pre_out) {   // the training path's epilogue forms: their own kernel instantiations
-        if ((g.mul_u && g.pro_a) || (g.pre_out && g.c_img)) return -9;
+    if (g.mul_u || g.pre_out || g.dot_x) {   // the training path's epilogue forms: their own kernel instantiations
+        if ((g.mul_u && g.pro_a) || (g.pre_out && g.c_img) || (g.dot_x && (g.residual || g.mul_u || g.pre_out || !g.stats || g.C2 || g.c_img))) return -9;
         static size_t attr2 = 0;
         if (lds > attr2) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma_kernel<DNS, false, X3, BM, false, true>),

@@ -55,6 +55,10 @@ struct GemmArgs {
     // Activation FORWARD that keeps its input (training: the backward needs u): C = act(A W^T + bias) as with `act`, and
     // pre_out (B, rows, ldc) = A W^T + bias.  Same kernel instantiation as mul_u (the training path's); not with c_img.
     float* pre_out;
+    // Column statistics of the training path's AdaGN backward from the GEMM that produces its dy (same kernel instantiation as mul_u):
+    // with `stats`, the second statistic becomes sum_rows C * dot_x instead of sum_rows C^2 — {sum dy, sum dy x} of col_dot_stats_kernel,
+    // dot_x (B, rows, ldc) the tensor the AdaGN normalised.  Not with residual / mul_u / pre_out.
+    const float* dot_x;
     int h8_rev;                // gemm_h8_astat.hip: blocks walk the row panels last to first (the producer wrote them first to last)
     int h8_stagger, h8_pair;   // gemm_h8_astat.hip: start offset of every second block of a CU (set by its launcher)
 };

@@ -157,6 +157,12 @@ int gecco_linear_actbwd_ok(int rows, int K, int Nout, int precision);
 size_t gecco_linear_actbwd_tiles(int B, int rows, int Nout);
 int gecco_linear_actbwd_f32(const float* A, const float* W, const float* u, const float* alpha, int kind, const float* residual,
                             float* C, float* agrad, int B, int rows, int K, int Nout, int precision, void* wsplit, void* stream);
+/* A dX product that also leaves the column statistics the AdaGN backward of its consumer needs: C = A W^T and
+ * stats (B, gecco_linear_row_tiles(rows), 2, Nout) = per row tile {sum_rows C, sum_rows C * dot_x}, dot_x (B, rows, Nout) the tensor
+ * that AdaGN normalised — what gecco_col_dot_stats_f32 computes from C and dot_x in a pass of its own (autograd of
+ * models/normalization.py:36-44 behind a linear: set_transformer.py:165-166).  Shapes: gecco_linear_actbwd_ok; W == NULL: image ready. */
+int gecco_linear_dotstats_f32(const float* A, const float* W, const float* dot_x, float* C, float* stats, int B, int rows, int K, int Nout,
+                              int precision, void* wsplit, void* stream);
 /* Its forward companion: C = act(A W^T + bias) AND pre_out = A W^T + bias (the u the backward needs) from one epilogue — the
  * training forward of Linear -> act without a separate activation pass.  act 1 / 2 / 3 / 4 as above; W == NULL: image ready. */
 int gecco_linear_act_keep_f32(const float* A, const float* W, const float* bias, const float* alpha, int act, float* pre_out,

@@ -766,3 +766,28 @@ def test_mlp_as_one_function(kind, precision, monkeypatch):
                 _close(a, b.cpu(), tol * (10 if i == 3 else 1))   # the two HIP forms see the same u
     finally:
         hip_ops.set_default_precision(prev)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "fp16"])
+def test_dx_product_leaves_the_adagn_backward_statistics(precision, monkeypatch):
+    """`_linear_dx_dot` (gecco_linear_dotstats_f32): the dX product whose epilogue also forms {sum dx, sum dx * x} per (sample, row tile,
+    column) — what the AdaGN backward of x otherwise gets from a `col_dot_stats` pass over dx and x: same dx bits as the plain
+    product, the partials' sums equal to that pass's (fp32 sums in another order), through 128- and 256-row tiles and a ragged tile."""
+    import ctypes as C
+    from gecco_amd import _lib, autograd as ag
+    lib = _lib.load()
+    rs = np.random.RandomState(5)
+    for (B, R, Nout, K) in ((2, 512, 768, 384), (3, 200, 256, 128), (1, 384, 384, 384)):
+        dy, x = _t(rs.randn(B, R, Nout)).cuda(), _t(rs.randn(B, R, K)).cuda()
+        Wm = _t(rs.randn(Nout, K) / np.sqrt(Nout)).cuda()
+        dx, gst = ag._linear_dx_dot(dy, Wm, x, prec=precision)
+        assert gst is not None
+        monkeypatch.setenv("GECCO_TRAIN_A16", "0")
+        ref = ag._linear_dx(dy, Wm, prec=precision)
+        monkeypatch.delenv("GECCO_TRAIN_A16")
+        assert torch.equal(dx, ref)
+        want = torch.empty(B, lib.gecco_stats_row_tiles(R), 2, K, device="cuda")
+        _lib.check(lib.gecco_col_dot_stats_f32(C.c_void_p(dx.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(want.data_ptr()), B, R, K, None),
+                   "col_dot_stats")
+        a, b = gst.double().sum(1), want.double().sum(1)
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-4, float((a - b).abs().max())

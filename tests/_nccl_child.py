@@ -2,7 +2,7 @@
 exists) that runs two data-parallel training steps of a small unconditional model on the HIP path in a ONE-RANK `nccl`
 (= RCCL) process group and writes the gradients / parameters / EMA weights it ends with.
 
-  python tests/_nccl_child.py <out.npz> <force_collective 0|1>
+  python tests/_nccl_child.py <out.npz> <force_collective 0|1> [amp]   (amp: the reference's 16-mixed trainer setting around the step)
 """
 import os
 import sys
@@ -17,6 +17,7 @@ D, L, N, B = 128, 2, 256, 4
 
 def main():
     out, force = sys.argv[1], sys.argv[2] == "1"
+    amp = len(sys.argv) > 3 and sys.argv[3] == "amp"
     import __graft_entry__ as ge
     ge.build()
     from gecco_amd import distributed as gd
@@ -44,16 +45,22 @@ def main():
     s = sigma.reshape(-1, 1, 1)
     weight = (s ** 2 + 1.0) / (s ** 2)
     grads = []
+    scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 10) if amp else None
     for it in range(2):
         # step 1 with p.grad = None: the reducer gathers per bucket after sync_side_stream() — the side-stream weight
         # gradients (autograd._linear_dw) are in play exactly as in bench.py --train
         opt.zero_grad(set_to_none=it == 1)
-        den = model(data + noise * s, sigma, None)
-        loss = (100.0 * weight * (den - data) ** 2).mean()
-        loss.backward()
+        with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+            den = model(data + noise * s, sigma, None)
+            loss = (100.0 * weight * (den.float() - data) ** 2).mean()
+        (scaler.scale(loss) if amp else loss).backward()
         red.finish()
         grads.append((opt.flat_grad() * opt.grad_scale).cpu().numpy().copy())
-        opt.step()
+        if amp:
+            scaler.step(opt)      # FusedAdamEMA inside the scaler's protocol: unscale + found_inf on the device, 1 / world folded in
+            scaler.update()
+        else:
+            opt.step()
     torch.cuda.synchronize()
     params = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu().numpy()
     ema = torch.cat([e.reshape(-1) for e in opt.ema_params]).cpu().numpy()

@@ -809,7 +809,7 @@ int gecco_linear_actbwd_ok(int rows, int K, int Nout, int precision) {
     if (precision == 2) return gemm_f16_dma_supported(g) ? 1 : 0;
     return (precision == 0 || precision == 1) && gemm_f32_dma_supported(g, precision) ? 1 : 0;
 }
-size_t gecco_linear_actbwd_tiles(int B, int rows, int Nout) { return (size_t)B * ((rows + 127) / 128) * ((Nout + 127) / 128); }
+size_t gecco_linear_actbwd_tiles(int B, int rows, int Nout) { return (size_t)B * ((rows + 63) / 64) * ((Nout + 127) / 128); }   // one slot per 64 rows
 int gecco_linear_actbwd_f32(const float* A, const float* W, const float* u, const float* alpha, int kind, const float* residual,
                             float* C, float* agrad, int B, int rows, int K, int Nout, int precision, void* wsplit, void* stream) {
     if (!A || !u || !C) return fail(-1, "linear_actbwd: null argument");

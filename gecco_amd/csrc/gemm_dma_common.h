@@ -270,8 +270,10 @@ __device__ __forceinline__ void epilogue_t(const GemmArgs& g, const Tile& t, f32
         if (lane == 0) red[wave] = ga;
         __syncthreads();
         if (tid == 0) {
-            const int T128 = (g.rows + 127) / 128, tn = (g.Nout + DBN - 1) / DBN;
-            g.agrad[((size_t)b * T128 + (m0 >> 7)) * tn + (n0 / DBN)] = (((red[0] + red[1]) + red[2]) + red[3]) / alpha0;
+            // one slot per 64 rows (the smallest row tile: 65 .. 127 rows are TWO 64-row tiles — indexed per 128 rows they shared a
+            // slot and the last writer won); 128- / 256-row tiles write every second / fourth slot, the caller zeroes them all
+            const int T64 = (g.rows + 63) / 64, tn = (g.Nout + DBN - 1) / DBN;
+            g.agrad[((size_t)b * T64 + (m0 >> 6)) * tn + (n0 / DBN)] = (((red[0] + red[1]) + red[2]) + red[3]) / alpha0;
         }
     }
     if (g.stats) {

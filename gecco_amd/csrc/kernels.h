@@ -48,7 +48,7 @@ struct GemmArgs {
     // mul_kind: 1 / 2 GaussianActivation normalized / raw (alpha in `alpha`), 3 ReLU, 4 GELU.  agrad (Gaussian only):
     // one float per 128-row x 128-column output tile, (b * ceil(rows / 128) + m0 / 128) * ceil(Nout / 128) + n0 / 128,
     // = sum over the tile of (A W^T) * d act / d alpha (u) — the alpha gradient's partials (zero-initialised by the caller:
-    // 256-row tiles write every other row slot).  LDS-DMA kernels only; no bias, no forward activation, no statistics.
+    // one slot per 64 rows: 128- / 256-row tiles write every second / fourth).  LDS-DMA kernels only; no bias, no forward activation, no statistics.
     const float* mul_u;
     int mul_kind;
     float* agrad;

@@ -477,3 +477,35 @@ def test_scaler_dynamics_on_a_real_run():
     assert all(bool(torch.isfinite(p).all()) for p in m.parameters())
     assert all(bool(torch.isfinite(e).all()) for e in opt.ema_params)
     ag.WEIGHT_IMAGES.__init__()
+
+
+@pytest.mark.parametrize("N", [1000, 333, 96, 2000])
+def test_ragged_clouds_under_autocast(N):
+    """Cloud sizes that leave the fast shapes (not a multiple of 128 / 32; 96 points = two 64-row tiles per sample): the 16-mixed step
+    falls back form by form (A-stationary -> LDS-DMA fp16 -> exact kernels) and stays at fp16-operand distance from the plain step,
+    every gradient finite, the same bits run to run."""
+    from gecco_amd import autograd as ag
+    from gecco_amd.structs import Example
+    from tests.test_modules_cpu import build_uncond, uncond_state_dict
+
+    def run(amp):
+        ag.WEIGHT_IMAGES.__init__()
+        torch.manual_seed(0)
+        m = build_uncond(128, 2)
+        m.load_state_dict(uncond_state_dict(W.linear_lift_state_dict(9, 128, 2, cases.I, cases.H)))
+        m = m.cuda().train()
+        x = torch.from_numpy(np.random.RandomState(4).randn(3, N, 3).astype(np.float32))
+        data = (x * torch.tensor(cases.GAUSS_SIGMA) + torch.tensor(cases.GAUSS_MEAN)).cuda()
+        torch.manual_seed(5)
+        with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+            loss = m.training_step(Example(data, None), 0)
+        (loss * 256.0).backward()
+        torch.cuda.synchronize()
+        return float(loss), torch.cat([p.grad.flatten() for p in m.parameters()]) / 256.0
+    lp, gp = run(False)
+    la, ga = run(True)
+    lb, gb = run(True)
+    assert bool(torch.isfinite(ga).all()) and abs(la - lp) / abs(lp) < 5e-4
+    assert float((ga - gp).norm() / gp.norm()) < 3e-3
+    assert la == lb and torch.equal(ga, gb)
+    ag.WEIGHT_IMAGES.__init__()

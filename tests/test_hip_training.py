@@ -675,15 +675,15 @@ def test_fused_adam_refuses_a_parameter_without_gradient():
 def test_activation_backward_as_gemm_epilogue(kind, precision, monkeypatch):
     """ActLinearFn: act(u) @ W^T + b (+ residual) whose backward runs act' as the epilogue of the dX product
     (gecco_linear_actbwd_f32: dh = dy W never written, the alpha-gradient partials from the same epilogue), against the
-    two-kernel backward (GECCO_TRAIN_ACTBWD=0) and against torch autograd in fp64; 128- and 256-row tiles, a ragged
-    last row tile."""
+    two-kernel backward (GECCO_TRAIN_ACTBWD=0) and against torch autograd in fp64; 64-, 128- and 256-row tiles, a ragged
+    last row tile (96 rows = two 64-row tiles: their alpha partials once shared a slot)."""
     from gecco_amd import autograd as ag
     from gecco_amd import hip_ops
     rs = np.random.RandomState(10 * kind + len(precision))
     prev = hip_ops.default_precision()
     hip_ops.set_default_precision(precision)
     try:
-        for (B, R, K, Nout) in ((2, 384, 768, 384), (3, 200, 256, 128), (1, 512, 384, 96)):
+        for (B, R, K, Nout) in ((2, 384, 768, 384), (3, 200, 256, 128), (1, 512, 384, 96), (2, 96, 256, 128)):   # 96 rows: two 64-row tiles
             u = _t(rs.randn(B, R, K) * 1.5)
             Wm, b = _t(rs.randn(Nout, K) / np.sqrt(K)), _t(rs.randn(Nout) * 0.1)
             res, dy = _t(rs.randn(B, R, Nout)), _t(rs.randn(B, R, Nout))

@@ -96,13 +96,13 @@ __device__ __forceinline__ f32x16 mfma3(const u32x4& ahi, const u32x4& alo, cons
 }
 
 // ------------------------------------------------------------------------------------- pool
-// element offset of value (key, d) in a wave's value tile: 4-key x 32-column blocks of 128 elements (256 B)
-// The content of the odd 32-column blocks is rotated by half a block (128 B): a tile's 16-byte stores walk a key's columns 0 .. hd,
-// so the columns 32 .. of a key otherwise land on the banks of its columns 0 .. (every block starts at bank 0) — 23 % of the
-// kernel's LDS cycles were such conflicts (profiles/r03p, r04e); the transposed reads rotate with it (8-byte pieces never wrap).
+// element offset of value (key, d) in a wave's value tile: 4-key x 32-column blocks of 128 elements (256 B).
+// (The 16-byte tile stores of the fp16 tensors conflict 2-way here — a key's columns 32 .. land on the banks of its columns 0 .., stores
+// are banked modulo 128 B — 23 % of the kernel's LDS-active cycles by the counter; rotating the odd blocks by half a block did not move
+// it, a conflict-free placement is row-dependent, and all the kernel's LDS stores together are 12 of its 50 us: DESIGN.md section 5b.)
 template <int DT>
 __device__ __forceinline__ int vt_off(int key, int d) {
-    return ((key >> 2) * DT + (d >> 5)) * 128 + (((key & 3) * 32 + (d & 31) + 64 * ((d >> 5) & 1)) & 127);
+    return ((key >> 2) * DT + (d >> 5)) * 128 + (key & 3) * 32 + (d & 31);
 }
 
 // IO16 (fp16 mode only): KV is an fp16 tensor (the kv_proj GEMM stored it that way) — tiles are copied to LDS as they are

@@ -111,6 +111,10 @@ SIGNATURES = {
     "gecco_gemm_tn_f16_tiles": (i, [i, i]),
     "gecco_gemm_tn_f16_b16_f32": (i, [vp, vp, vp, vp, i, i, i, i, i, vp]),
     "gecco_linear_dotstats_f32": (i, [vp] * 5 + [i, i, i, i, i, vp, vp]),
+    "gecco_h8_image_bytes": (sz, [i, i]),
+    "gecco_linear_h8_train_ok": (i, [i, i, i]),
+    "gecco_h8_images_f32": (i, [C.POINTER(GeccoSplitJob), i, vp]),
+    "gecco_linear_h8_train_f32": (i, [vp] * 5 + [i, vp, vp, vp, i, vp, vp, i, vp, i, i, i, vp, vp]),
     "gecco_astat16_image_bytes": (sz, [i, i]),
     "gecco_linear_astat16_ok": (i, [i, i, i]),
     "gecco_astat16_images_f32": (i, [C.POINTER(GeccoSplitJob), i, vp]),

@@ -119,7 +119,7 @@ class WeightImages:
         prec: "bf16x3" (default: the training precision) or "fp16" — the fp16 images of the autocast(float16) setting are
         their own entries (kind + "16")."""
         prec = _train_precision() if prec is None else prec
-        if prec not in ("bf16x3", "fp16", "a16"):
+        if prec not in ("bf16x3", "fp16", "a16", "h8"):
             return None
         if prec == "fp16":
             if any(w.shape[-1] % 32 for w in ws) or (kind == "t" and ws[0].shape[0] % 32):
@@ -129,6 +129,10 @@ class WeightImages:
             if any(w.shape[0] % 64 or w.shape[1] % 64 for w in ws):
                 return None
             kind = kind + "a16"
+        elif prec == "h8":    # the h8 kernel's streams (gecco_h8_images_f32): fp16 main part + fp8 correction, 64-column tiles
+            if kind == "t" or any(w.shape[0] % 64 or w.shape[1] % 64 for w in ws):
+                return None
+            kind = kind + "h8"
         key = self._key(kind, *ws)
         self.used[key] = self.step
         if self.armed:
@@ -174,13 +178,14 @@ class WeightImages:
         jobs, offs, total = [], {}, 0
         for key, ws in self.plan.items():
             kind = key[0]
-            fmt = 2 if kind.endswith("a16") else 1 if kind.endswith("16") else 0
+            fmt = 3 if kind.endswith("h8") else 2 if kind.endswith("a16") else 1 if kind.endswith("16") else 0
             tr = kind.startswith("t")
             nbytes = 0
             for w in ws:
                 nout, k = (w.shape[1], w.shape[0]) if tr else (w.shape[0], w.shape[1])
                 jobs.append((key, w, nout, k, tr, total + nbytes, fmt))
-                nbytes += (lib.gecco_split_bf16_image_bytes, lib.gecco_split_f16_image_bytes, lib.gecco_astat16_image_bytes)[fmt](nout, k)
+                nbytes += (lib.gecco_split_bf16_image_bytes, lib.gecco_split_f16_image_bytes, lib.gecco_astat16_image_bytes,
+                           lib.gecco_h8_image_bytes)[fmt](nout, k)
             offs[key] = (total, nbytes)
             total += (nbytes + 255) // 256 * 256
         dev = jobs[0][1].device
@@ -189,7 +194,8 @@ class WeightImages:
         base = self.pool.data_ptr()
         for fmt, fn, name in ((0, lib.gecco_split_bf16_images_f32, "gecco_split_bf16_images_f32"),
                               (1, lib.gecco_split_f16_images_f32, "gecco_split_f16_images_f32"),
-                              (2, lib.gecco_astat16_images_f32, "gecco_astat16_images_f32")):
+                              (2, lib.gecco_astat16_images_f32, "gecco_astat16_images_f32"),
+                              (3, lib.gecco_h8_images_f32, "gecco_h8_images_f32")):
             sel = [j for j in jobs if j[6] == fmt]
             if not sel:
                 continue
@@ -585,6 +591,15 @@ class AdaGNPairFn(torch.autograd.Function):
             ctx.save_for_backward(x, stats, t2, sw, sb, a, o, W1, W2)
             ctx.G, ctx.eps, ctx.has_b2 = G, eps, b2 is not None
             return KV, q, x
+        if _h8_ok(prec, R, K, N1 + N2) and N1 % 64 == 0 and N2 % 64 == 0:
+            KV, q = _new(B, R, N1, like=x), _new(B, R, N2, like=x)
+            ws, ready = _h8_stream("pair", W1, W2, dev=x.device)
+            _lib.check(_lib.load().gecco_linear_h8_train_f32(_ptr(x), _ptr(a), _ptr(o), None if ready else _ptr(_f(W1)), None, N1, _ptr(KV),
+                                                             None if ready else _ptr(_f(W2)), _ptr(b2), N2, _ptr(q), None, 0, None, B, R, K,
+                                                             C.c_void_p(ws.data_ptr()), _stream()), "gecco_linear_h8_train_f32")
+            ctx.save_for_backward(x, stats, t2, sw, sb, a, o, W1, W2)
+            ctx.G, ctx.eps, ctx.has_b2 = G, eps, b2 is not None
+            return KV, q, x
         img = WEIGHT_IMAGES.lookup("pair", W1, W2, prec=prec)
         if img is not None:
             KV, q = hip_ops.linear_pair(x, W1, None, W2, b2, pro=(a, o), precision=prec, w_image=img)
@@ -634,6 +649,12 @@ class AdaGNMlpFn(torch.autograd.Function):
         h16 = _h16_ok(prec, R, K0, N0, W2.shape[0], True)
         if h16:
             u, h = _keep_h16(x, W0, b0, (a, o), alpha, kind)
+        elif kind in (1, 2, 3) and _h8_ok(prec, R, K0, N0):
+            u, h = _new(B, R, N0, like=x), _new(B, R, N0, like=x)
+            ws, ready = _h8_stream("n", W0, dev=x.device)
+            _lib.check(lib.gecco_linear_h8_train_f32(_ptr(x), _ptr(a), _ptr(o), None if ready else _ptr(_f(W0)), _ptr(b0), N0, _ptr(h),
+                                                     None, None, 0, None, _ptr(alpha) if kind in (1, 2) else None, kind, _ptr(u), B, R, K0,
+                                                     C.c_void_p(ws.data_ptr()), _stream()), "gecco_linear_h8_train_f32")
         else:
             u, h = _new(B, R, N0, like=x), _new(B, R, N0, like=x)
             img = WEIGHT_IMAGES.lookup("n", W0, prec=prec)
@@ -780,6 +801,23 @@ def _a16_stream(kind: str, *ws: Tensor, dev) -> tuple[Tensor, bool]:
     tr = kind == "t"
     nbytes = sum(lib.gecco_astat16_image_bytes(w.shape[1] if tr else w.shape[0], w.shape[0] if tr else w.shape[1]) for w in ws)
     return hip_ops._ws(nbytes, dev), False
+
+
+def _h8_ok(prec: str, R: int, K: int, Nout: int) -> bool:
+    """The split-bf16 training FORWARD's AdaGN-prologue products on the h8 A-stationary kernel (gecco_linear_h8_train_f32): the same
+    accuracy class as split-bf16 (fp16 main product + two fp8 cross terms), the operand rows in registers and the weight stream read
+    once per 128 rows.  Forward only: activations and weights fit the fp16 / fp8 operand ranges, unscaled gradients do not, so the
+    backward products keep split-bf16.  GECCO_TRAIN_H8FWD=0: the LDS-DMA split-bf16 GEMM instead."""
+    return (prec == "bf16x3" and os.environ.get("GECCO_TRAIN_H8FWD", "1") != "0"
+            and bool(_lib.load().gecco_linear_h8_train_ok(R, K, Nout)))
+
+
+def _h8_stream(kind: str, *ws: Tensor, dev) -> tuple[Tensor, bool]:
+    img = WEIGHT_IMAGES.lookup(kind, *ws, prec="h8")
+    if img is not None:
+        return img, True
+    lib = _lib.load()
+    return hip_ops._ws(sum(lib.gecco_h8_image_bytes(w.shape[0], w.shape[1]) for w in ws), dev), False
 
 
 def _h16_ok(prec: str, R: int, K0: int, N0: int, Nout2: int, pro: bool) -> bool:

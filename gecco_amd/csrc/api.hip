@@ -858,6 +858,57 @@ int gecco_linear_act_keep_pro_f32(const float* A, const float* W, const float* b
     return 0;
 }
 
+/* ---- the training forward in h8 arithmetic with fp32 tensors (gemm_h8_astat.hip, OUT forms of gemm_h8_astat_kernel) ---- */
+size_t gecco_h8_image_bytes(int Nout, int K) { return (Nout % 64 || K % 64) ? 0 : h8_image_bytes(Nout, K); }
+int gecco_linear_h8_train_ok(int rows, int K, int Nout) {
+    return rows >= 128 && rows % 128 == 0 && (K == 128 || K == 256 || K == 384) && Nout % 64 == 0 && Nout >= 128 && Nout <= 4096;
+}
+int gecco_h8_images_f32(const GeccoSplitJob* jobs, int n, void* stream) {
+    if (n < 0 || (n > 0 && !jobs)) return fail(-1, "h8_images: null argument");
+    SplitJobs sj;
+    sj.n = 0;
+    for (int i = 0; i < n; ++i) {
+        const GeccoSplitJob& j = jobs[i];
+        if (!j.W || !j.img || j.Nout <= 0 || (j.Nout % 64) || (j.K % 64) || j.K <= 0 || (j.ldw & 3) || j.transposed)
+            return fail(-2, "h8_images: job %d needs Nout %% 64 == 0, K %% 64 == 0, ldw %% 4 == 0, not transposed", i);
+        sj.job[sj.n++] = SplitJob{j.W, static_cast<float*>(j.img), j.Nout, j.K, j.ldw, 0};
+        if (sj.n == 96) {
+            TRY(h8_image_multi_launch(sj, (hipStream_t)stream), "h8_images");
+            sj.n = 0;
+        }
+    }
+    TRY(h8_image_multi_launch(sj, (hipStream_t)stream), "h8_images");
+    return 0;
+}
+
+int gecco_linear_h8_train_f32(const float* x, const float* pro_a, const float* pro_o, const float* W1, const float* bias1, int Nout1, float* C1,
+                              const float* W2, const float* bias2, int Nout2, float* C2, const float* alpha, int act, float* pre_out, int B,
+                              int rows, int K, void* wsplit, void* stream) {
+    if (!x || !C1 || !wsplit || (Nout2 > 0 && !C2)) return fail(-1, "linear_h8_train: null argument");
+    if ((pro_a == nullptr) != (pro_o == nullptr)) return fail(-1, "linear_h8_train: pro_a / pro_o must both be set");
+    if (Nout2 > 0 && ((W1 == nullptr) != (W2 == nullptr))) return fail(-1, "linear_h8_train: W1 / W2 both given or both ready");
+    if ((act != 0) != (pre_out != nullptr)) return fail(-2, "linear_h8_train: an activation comes with pre_out (the keep form), and only with it");
+    if ((act == 1 || act == 2) && !alpha) return fail(-1, "linear_h8_train: GaussianActivation needs alpha");
+    hipStream_t s = (hipStream_t)stream;
+    GemmArgs g{};
+    g.A = x; g.pro_a = pro_a; g.pro_o = pro_o; g.bias = bias1; g.C = C1; g.alpha = alpha; g.act = act; g.pre_out = pre_out;
+    g.B = B; g.rows = rows; g.K = K; g.Nout = Nout1 + (Nout2 > 0 ? Nout2 : 0); g.lda = K; g.ldw = K; g.ldc = Nout1; g.ldr = Nout1;
+    g.precision = 1; g.w_img = wsplit;
+    if (Nout2 > 0) { g.C2 = C2; g.bias2 = bias2; g.n_split = Nout1; g.ldc2 = Nout2; }
+    if (!gemm_h8_train_supported(g))
+        return fail(-2, "linear_h8_train: needs rows %% 128 == 0, K in {128, 256, 384}, Nout (each segment) %% 64 == 0, Nout >= 128, act 0 .. 3");
+    if (W1) {
+        SplitJobs jobs;
+        jobs.n = 0;
+        float* img = static_cast<float*>(wsplit);
+        jobs.job[jobs.n++] = SplitJob{W1, img, Nout1, K, K, 0};
+        if (Nout2 > 0) jobs.job[jobs.n++] = SplitJob{W2, img + h8_image_bytes(Nout1, K) / sizeof(float), Nout2, K, K, 0};
+        TRY(h8_image_multi_launch(jobs, s), "linear_h8_train(image)");
+    }
+    TRY(gemm_h8_train_launch(g, s), "linear_h8_train");
+    return 0;
+}
+
 /* ---- A-stationary fp16 linears with fp32 tensors: the training path's 384-wide products under autocast(float16) (gemm_h8_astat.hip,
  * OUT forms of gemm_kvq_astat_kernel) ---- */
 size_t gecco_astat16_image_bytes(int Nout, int K) { return (Nout % 64 || K % 64) ? 0 : kvq_image_bytes(Nout, K, 0); }

@@ -268,9 +268,15 @@ __global__ void h8_image_multi_kernel(SplitJobs jobs) {
 // branch per VALUE here: the compiler does not hoist it out of the unrolled epilogue).
 // IMG2: the output is the h8 activation image (GemmArgs::c_img == 2, gemm_h8_areg.hip: fp16 hi + fp8 lo, 3 bytes per element)
 // instead of the tiled split image (bf16 hi | lo planes, 4 bytes) of gemm_x3_areg.hip.
-template <int NG, int NW, int NS, int ACT, bool IMG2>
+// OUT (the training path's FORWARD in the split-bf16 training arithmetic — h8 is as accurate, two matrix units instead of three, and
+// A-stationary; fp32 tensors, row-major): 1  C (| C2) = y W^T + bias — AdaGN(x) -> K | V, q; 2  pre_out = u = y W^T + bias and
+// C = act(u), both fp32 — the first linear of an MLP with the pre-activation its backward needs (models/mlp.py:5-39).  A lane holds 4
+// consecutive columns of one row per accumulator quad: plain 16-byte stores.  (The backward products keep split-bf16: unscaled
+// gradients do not fit the fp16 / fp8 operands.)
+template <int NG, int NW, int NS, int ACT, bool IMG2, int OUT = 0>
 __global__ __launch_bounds__(64 * NW, 2) void gemm_h8_astat_kernel(GemmArgs g) {
-    constexpr int NKT = 2 * NG, K = 64 * NG, NT = 64 * NW, ROWS = 32 * NW, PW = 8 / NW, STORES = IMG2 ? 6 : H_STORES;
+    constexpr int NKT = 2 * NG, K = 64 * NG, NT = 64 * NW, ROWS = 32 * NW, PW = 8 / NW;
+    constexpr int STORES = OUT == 1 ? 8 : OUT == 2 ? 16 : (IMG2 ? 6 : H_STORES);
     static_assert(NS >= 4 && NKT % NS == 0 && (NW == 4 || NW == 8), "static slots; lookahead NS - 1 >= 3 stages");
     static_assert(NS * H_STAGE * 4 <= 65536 || NS % 2 == 0, "ring addressed from two bases");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -287,7 +293,15 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_h8_astat_kernel(GemmArgs g) {
     const int r = lane & 31, h = lane >> 5;
 
     HSTAMP(0);
-    for (int n = tid; n < g.Nout; n += NT) bias_lds[n] = g.bias ? g.bias[n] : 0.f;
+    if constexpr (OUT != 0) {
+        for (int n = tid; n < g.Nout; n += NT) {
+            const bool seg2 = g.C2 != nullptr && n >= g.n_split;
+            const float* bp = seg2 ? g.bias2 : g.bias;
+            bias_lds[n] = bp ? bp[seg2 ? n - g.n_split : n] : 0.f;
+        }
+    } else {
+        for (int n = tid; n < g.Nout; n += NT) bias_lds[n] = g.bias ? g.bias[n] : 0.f;
+    }
     {
         const bool has_pro = g.pro_a != nullptr;
         const float* pa = has_pro ? g.pro_a + (size_t)b * K : nullptr;
@@ -419,6 +433,35 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_h8_astat_kernel(GemmArgs g) {
     float* img2_base = g.C + (((size_t)b * T128 + (mrow >> 7)) * (size_t)(g.Nout >> 6)) * 6144 + ((mrow & 127) >> 5) * 1024;
     auto epilogue = [&](int ct) {
         const int n0 = ct * H_BN;
+        if constexpr (OUT != 0) {
+            const bool s2 = g.C2 != nullptr && n0 >= g.n_split;
+            float* Cf = s2 ? g.C2 : g.C;
+            const int ldcf = s2 ? g.ldc2 : g.ldc;
+            float* dst = Cf + ((size_t)b * g.rows + mrow) * ldcf + (s2 ? n0 - g.n_split : n0) + 4 * h;
+            float* dpre = OUT == 2 ? g.pre_out + ((size_t)b * g.rows + mrow) * g.Nout + n0 + 4 * h : nullptr;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 bs = *reinterpret_cast<const f32x4*>(bias_lds + n0 + 32 * j + 8 * q + 4 * h);
+                    f32x4 w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = acc[j][4 * q + e] + bs[e];
+                    if constexpr (OUT == 2) {
+                        *reinterpret_cast<f32x4*>(dpre + 32 * j + 8 * q) = w;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (ACT == 3) w[e] = fmaxf(w[e], 0.f);
+                            if (ACT == 1 || ACT == 2) {
+                                const float y = __builtin_amdgcn_exp2f(w[e] * w[e] * c2);
+                                w[e] = ACT == 1 ? (y - 0.7f) * (1.0f / 0.28f) : y;
+                            }
+                        }
+                    }
+                    *reinterpret_cast<f32x4*>(dst + 32 * j + 8 * q) = w;
+                }
+            return;
+        }
         if constexpr (IMG2) {
             float* blk = img2_base + (size_t)ct * 6144;
 #pragma unroll
@@ -1089,6 +1132,50 @@ bool gemm_kvq_astat_supported(const GemmArgs& g) {
            ((g.pro_a == nullptr) == (g.pro_o == nullptr)) && g.lo_begin >= 0 && g.lo_tiles >= g.lo_begin && g.lo_tiles <= g.Nout / H_BN &&
            (!g.hm_hd || (g.hm_hd >= 8 && !(g.hm_hd & 7) && g.Nout < (1 << 20) / g.hm_hd && !((g.C2 ? g.n_split : g.Nout) % g.hm_hd) &&
                          !((g.C2 ? g.Nout - g.n_split : 0) % g.hm_hd)));
+}
+
+// gemm_h8_astat_kernel's OUT forms: the training forward in h8 arithmetic (w_img = the h8 stream of the weight, or of W1 | W2)
+bool gemm_h8_train_supported(const GemmArgs& g) {
+    const bool keep = g.pre_out != nullptr;
+    return !g.c_f16 && !g.a_f16 && !g.a_img && !g.c_img && !g.residual && !g.stats && !g.mul_u && g.w_img && g.rows >= 128 && !(g.rows % 128) &&
+           !(g.Nout % H_BN) && g.Nout >= 2 * H_BN && g.Nout <= 4096 && (g.K == 128 || g.K == 256 || g.K == 384) && !(g.lda & 3) && !(g.ldc & 3) &&
+           (!g.C2 || (!keep && !(g.n_split % H_BN) && !(g.ldc2 & 3) && g.n_split > 0 && g.n_split < g.Nout)) &&
+           ((g.pro_a == nullptr) == (g.pro_o == nullptr)) && (keep ? (g.act >= 1 && g.act <= 3 && g.ldc == g.Nout) : g.act == 0) &&
+           (!(keep && act_gauss_host(g.act)) || g.alpha);
+}
+
+template <int NG, int NS>
+int h8_train_launch_t(const GemmArgs& g, hipStream_t st) {
+    const size_t lds = ((size_t)NS * H_STAGE + 4 * H_STG + g.Nout + 2 * g.K) * sizeof(float);
+    const dim3 grid(g.B * (g.rows / 128));
+#define H8T(ACT_, OUT_)                                                                                                          \
+    do {                                                                                                                         \
+        static size_t attr = 0;                                                                                                  \
+        if (lds > attr) {                                                                                                        \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h8_astat_kernel<NG, 4, NS, ACT_, false, OUT_>),          \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                     \
+            attr = lds;                                                                                                          \
+        }                                                                                                                        \
+        hipLaunchKernelGGL((gemm_h8_astat_kernel<NG, 4, NS, ACT_, false, OUT_>), grid, dim3(256), lds, st, g);                    \
+    } while (0)
+    if (!g.pre_out) H8T(0, 1);
+    else if (g.act == 1) H8T(1, 2);
+    else if (g.act == 2) H8T(2, 2);
+    else H8T(3, 2);
+#undef H8T
+    return (int)hipGetLastError();
+}
+
+int gemm_h8_train_launch(const GemmArgs& g0, hipStream_t st) {
+    if (!gemm_h8_train_supported(g0)) return -9;
+    GemmArgs g = g0;
+    g.h8_rev = 0; g.h8_stagger = 0; g.h8_pair = 32;
+    switch (g.K) {
+        case 128: return h8_train_launch_t<2, 4>(g, st);
+        case 256: return h8_train_launch_t<4, 4>(g, st);
+        case 384: return h8_train_launch_t<6, 6>(g, st);
+        default: return -9;
+    }
 }
 
 // the training forms (OUT 1 / 2 / 3 above): fp32 C (| C2), or pre_out + fp16 C, or mul_u; one-term weights, row-major

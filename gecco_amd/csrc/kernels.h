@@ -208,6 +208,9 @@ bool gemm_h8_astat_supported(const GemmArgs& g);
 size_t kvq_image_bytes(int Nout, int K, int lo_cols);
 bool gemm_kvq_astat_supported(const GemmArgs& g);
 int gemm_kvq_astat_launch(const GemmArgs& g, hipStream_t st);
+// gemm_h8_astat_kernel with fp32 outputs: the training forward in h8 arithmetic (w_img = the h8 stream)
+bool gemm_h8_train_supported(const GemmArgs& g);
+int gemm_h8_train_launch(const GemmArgs& g, hipStream_t st);
 // the same structure with fp32 outputs for the training path (OUT forms of gemm_kvq_astat_kernel): w_img = the one-term kvq stream
 bool gemm_astat_train_supported(const GemmArgs& g);
 int gemm_astat_train_launch(const GemmArgs& g, hipStream_t st);

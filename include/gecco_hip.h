@@ -180,6 +180,20 @@ int gecco_linear_act_keep_h16(const float* A, const float* W, const float* bias,
                               const float* alpha, int act, float* pre_out, void* C16out, int B, int rows, int K, int Nout, void* wsplit,
                               void* stream);
 
+/* ---- The training FORWARD's AdaGN-prologue products in h8 arithmetic (fp16 main product + two fp8 cross terms: as accurate as split-bf16,
+ * two matrix units instead of three) on the A-stationary kernel, fp32 tensors: C1 (| C2) = x' W1^T + bias1 (| x' W2^T + bias2),
+ * x' = x * pro_a[b] + pro_o[b] or x — broadcast_norm -> kv_proj | q (models/set_transformer.py:161-162 -> :49, :112); with act != 0
+ * (1 / 2 GaussianActivation normalized / raw, 3 ReLU; one weight) pre_out = the pre-activation and C1 = act(pre_out): the first linear of
+ * an MLP (models/mlp.py:5-39) with what its backward needs.  rows % 128 == 0, K in {128, 256, 384}, Nout % 64 == 0, Nout >= 128
+ * (gecco_linear_h8_train_ok).  wsplit: gecco_h8_image_bytes per weight (4 bytes per element); NULL weights: the streams are ready
+ * (gecco_h8_images_f32).  The backward products keep split-bf16: unscaled gradients do not fit fp16 / fp8 operands. */
+size_t gecco_h8_image_bytes(int Nout, int K);
+int gecco_linear_h8_train_ok(int rows, int K, int Nout);
+int gecco_h8_images_f32(const GeccoSplitJob* jobs, int n, void* stream);
+int gecco_linear_h8_train_f32(const float* x, const float* pro_a, const float* pro_o, const float* W1, const float* bias1, int Nout1, float* C1,
+                              const float* W2, const float* bias2, int Nout2, float* C2, const float* alpha, int act, float* pre_out, int B,
+                              int rows, int K, void* wsplit, void* stream);
+
 /* ---- A-stationary forms of the training path's products out of a <= 512-wide operand, in the autocast(float16) arithmetic (fp16
  * operands, fp32 accumulation, fp32 tensors): a 128-row block keeps its rows of x (after the optional AdaGN apply) in registers for the
  * whole launch and streams W once — the LDS-DMA GEMM re-fetches the rows for every 128-column tile and is bound by that fill, not by

@@ -791,3 +791,58 @@ def test_dx_product_leaves_the_adagn_backward_statistics(precision, monkeypatch)
                    "col_dot_stats")
         a, b = gst.double().sum(1), want.double().sum(1)
         assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-4, float((a - b).abs().max())
+
+
+@pytest.mark.parametrize("K,B,R", [(384, 3, 256), (256, 1, 384), (128, 2, 128)])
+def test_h8_training_forward_linears(K, B, R):
+    """The split-bf16 step's forward products on the h8 A-stationary kernel (gecco_linear_h8_train_f32, the OUT forms of
+    gemm_h8_astat_kernel): against fp64 at the split-bf16 bar (fp16 main product + two fp8 cross terms), ready streams
+    (gecco_h8_images_f32) bit-equal to the per-call ones, the keep form's activation equal to the activation of its own pre_out."""
+    import ctypes as C
+    from gecco_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(K + R)
+    N1, N2, Wd = 2 * K, K, 4 * K
+    x = _t(rs.randn(B, R, K)).cuda()
+    pa, po = _t(1.0 + 0.3 * rs.randn(B, K)).cuda(), _t(0.2 * rs.randn(B, K)).cuda()
+    W1, W2, b2 = _t(rs.randn(N1, K) / np.sqrt(K)).cuda(), _t(rs.randn(N2, K) / np.sqrt(K)).cuda(), _t(rs.randn(N2) * 0.1).cuda()
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
+    ws = lambda n: torch.empty(n, dtype=torch.uint8, device="cuda")     # noqa: E731
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())   # noqa: E731
+    assert lib.gecco_linear_h8_train_ok(R, K, N1 + N2) and not lib.gecco_linear_h8_train_ok(R + 64, K, N1) and not lib.gecco_linear_h8_train_ok(R, 512, N1)
+    xe = (x * pa[:, None] + po[:, None]).double()
+    # (1) AdaGN(x) -> K | V, q (two weights, the second with a bias)
+    c1, c2 = torch.full((B, R, N1), float("nan"), device="cuda"), torch.full((B, R, N2), float("nan"), device="cuda")
+    o2 = lib.gecco_h8_image_bytes(N1, K)
+    w = ws(o2 + lib.gecco_h8_image_bytes(N2, K))
+    _lib.check(lib.gecco_linear_h8_train_f32(p(x), p(pa), p(po), p(W1), None, N1, p(c1), p(W2), p(b2), N2, p(c2), None, 0, None, B, R, K, p(w), None), "h8 pair")
+    e1, e2 = rel(c1, xe @ W1.double().t()), rel(c2, xe @ W2.double().t() + b2.double())
+    print(f"K={K}: h8 pair rel err {e1:.2e} / {e2:.2e}")
+    assert e1 < 2e-5 and e2 < 2e-5
+    w2 = ws(w.numel())
+    jobs = (_lib.GeccoSplitJob * 2)(_lib.GeccoSplitJob(W1.data_ptr(), w2.data_ptr(), N1, K, K, 0),
+                                    _lib.GeccoSplitJob(W2.data_ptr(), w2.data_ptr() + o2, N2, K, K, 0))
+    _lib.check(lib.gecco_h8_images_f32(jobs, 2, None), "h8 images")
+    assert torch.equal(w, w2)
+    d1, d2 = torch.empty_like(c1), torch.empty_like(c2)
+    _lib.check(lib.gecco_linear_h8_train_f32(p(x), p(pa), p(po), None, None, N1, p(d1), None, p(b2), N2, p(d2), None, 0, None, B, R, K, p(w2), None), "h8 pair ready")
+    assert torch.equal(c1, d1) and torch.equal(c2, d2)
+    # one weight, no prologue
+    s1 = torch.full((B, R, N2), float("nan"), device="cuda")
+    _lib.check(lib.gecco_linear_h8_train_f32(p(x), None, None, p(W2), p(b2), N2, p(s1), None, None, 0, None, None, 0, None, B, R, K, p(w), None), "h8 single")
+    assert rel(s1, x.double() @ W2.double().t() + b2.double()) < 2e-5
+    # (2) the first linear of an MLP: u and act(u)
+    W0, b0 = _t(rs.randn(Wd, K) / np.sqrt(K)).cuda(), _t(rs.randn(Wd) * 0.1).cuda()
+    alpha = torch.tensor([0.8], device="cuda")
+    for kind in (1, 2, 3):
+        u, h = torch.full((B, R, Wd), float("nan"), device="cuda"), torch.full((B, R, Wd), float("nan"), device="cuda")
+        w0 = ws(lib.gecco_h8_image_bytes(Wd, K))
+        _lib.check(lib.gecco_linear_h8_train_f32(p(x), p(pa), p(po), p(W0), p(b0), Wd, p(h), None, None, 0, None, p(alpha) if kind < 3 else None, kind, p(u),
+                                                 B, R, K, p(w0), None), "h8 keep")
+        assert rel(u, xe @ W0.double().t() + b0.double()) < 2e-5
+        g = torch.exp(-u.double() ** 2 / (2 * 0.8 ** 2))
+        want = {1: (g - 0.7) / 0.28, 2: g, 3: torch.relu(u.double())}[kind]
+        assert rel(h, want) < 1e-6, kind
+    # refusals: an activation without pre_out, rows not in whole 128-row blocks
+    assert lib.gecco_linear_h8_train_f32(p(x), None, None, p(W2), None, N2, p(s1), None, None, 0, None, None, 3, None, B, R, K, p(w), None) != 0
+    assert lib.gecco_linear_h8_train_f32(p(x), None, None, p(W2), None, N2, p(s1), None, None, 0, None, None, 0, None, B, R - 64, K, p(w), None) != 0

@@ -189,11 +189,11 @@ int linear_pair(const float* A, const float* W1, const float* b1, int Nout1, flo
 }
 
 // Path switches for A/B runs and tests: gecco_set_option, or the environment (GECCO_ASTAT, GECCO_CHAIN) on first use.
-enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_HEADMAJOR = 2, OPT_MLPFUSED = 3, OPT_UNPOOLFUSED = 4, OPT_LO8 = 5, OPT_ACTIMG = 6, OPT_H8 = 7, OPT_KVQ64 = 8, OPT_H8AREG = 9, OPT_CHAIN2 = 10, OPT_UNPOOLH8 = 11, OPT_MLPH8 = 12, OPT_COUNT = 13 };
-int g_options[OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
-const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor", "mlpfused", "unpoolfused", "lo8", "actimg", "h8", "kvq64", "h8areg", "chain2", "unpoolh8", "mlph8"};
+enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_HEADMAJOR = 2, OPT_MLPFUSED = 3, OPT_UNPOOLFUSED = 4, OPT_LO8 = 5, OPT_ACTIMG = 6, OPT_H8 = 7, OPT_KVQ64 = 8, OPT_H8AREG = 9, OPT_CHAIN2 = 10, OPT_UNPOOLH8 = 11, OPT_MLPH8 = 12, OPT_CHAINCL = 13, OPT_COUNT = 14 };
+int g_options[OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor", "mlpfused", "unpoolfused", "lo8", "actimg", "h8", "kvq64", "h8areg", "chain2", "unpoolh8", "mlph8", "chaincl"};
 const char* const g_option_env[OPT_COUNT] = {"GECCO_ASTAT", "GECCO_CHAIN", "GECCO_HEADMAJOR", "GECCO_MLPFUSED", "GECCO_UNPOOLFUSED", "GECCO_LO8",
-                                             "GECCO_ACTIMG", "GECCO_H8", "GECCO_KVQ64", "GECCO_H8AREG", "GECCO_CHAIN2", "GECCO_UNPOOLH8", "GECCO_MLPH8"};
+                                             "GECCO_ACTIMG", "GECCO_H8", "GECCO_KVQ64", "GECCO_H8AREG", "GECCO_CHAIN2", "GECCO_UNPOOLH8", "GECCO_MLPH8", "GECCO_CHAINCL"};
 int option(int which) {
     if (g_options[which] < 0) {
         const char* e = getenv(g_option_env[which]);
@@ -328,8 +328,9 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
     // and their coefficient launches: the chain's activation rounding does not reach the output, its weight rounding does
     // (tools/experiments/precision_search.py: chain = x2a keeps F_x at 1.0e-4 .. 1.3e-4)
     // feature_dim <= 384: at 512 one block per sample streams 7 MB of weights through one CU and loses to the five launches
-    // (C4, B = 32: 10.25 vs 10.03 ms per evaluation)
-    const bool chain2_on = mixed && w.wimg && option(OPT_CHAIN2) && C <= 384 && inducer_chain_f16_supported(C, Wd, H, G, I) &&
+    // (C4, B = 32: 10.25 vs 10.03 ms per evaluation); the cluster form (option "chaincl": 4 blocks per sample) wins there too (9.94 vs 10.12)
+    const bool cl_ok = option(OPT_CHAINCL) && C >= 256 && (size_t)st->n_layers * 8 <= (size_t)I * C;
+    const bool chain2_on = mixed && w.wimg && option(OPT_CHAIN2) && (C <= 384 || cl_ok) && inducer_chain_f16_supported(C, Wd, H, G, I) &&
                            (ns == 1 || ns == 2 || ns == 4 || ns == 8) && (act >= 0 && act <= 3);
     if (pr >= 1 && w.wimg && !(C % kmod) && !(Wd % kmod)) {
         // split-bf16 mode: every N-token weight of every layer becomes its tiled hi | lo image in ONE launch per
@@ -460,6 +461,10 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         return fail(-3, "set_transformer: the mixed mode needs rows %% 128 == 0, feature_dim %% 128 == 0 and a head dim of 16 / 32 / 48 / 64");
     const int apr = mixed ? 2 : pr;                  // arithmetic of the attention products
     const size_t kvq_lo = ((size_t)(2 * C + 127) / 128 * 128 + (size_t)(C + 127) / 128 * 128) * C / 2;   // floats: mixed mode's lo images
+    // the cluster form of the one-launch chain (option "chaincl"): its per-(layer, sample) counters live in `merged` (unused by the chain,
+    // 64 * C floats per sample) and are zeroed here, once per forward
+    const bool chain_cl = (chain_on || chain2_on) && imgs && cl_ok;
+    if (chain_cl) TRY((int)hipMemsetAsync(w.merged, 0, (size_t)st->n_layers * B * 8 * sizeof(unsigned), s), "inducer chain counters");
     for (int li = 0; li < st->n_layers; ++li) {
         const GeccoLayer& L = st->layers[li];
         const float* im = imgs ? w.wimg + (size_t)li * w.wimg_layer : nullptr;
@@ -517,6 +522,11 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
                 float* hdst = (h_out && h_out[li]) ? h_out[li] : w.h;
                 ca.h_out = hdst; ca.kvh = w.kvh; ca.B = B;
                 ca.two_term = chain2_on ? 1 : 0;
+                if (chain_cl) {   // C / 128 blocks per sample; the stand-alone chain's buffers carry what they hand each other
+                    ca.cluster = 1;
+                    ca.x1 = w.h0; ca.x3 = w.h2; ca.xu = reinterpret_cast<unsigned*>(w.u);
+                    ca.flags = reinterpret_cast<unsigned*>(w.merged) + (size_t)li * B * 8;
+                }
                 if ((act == 1 || act == 2) && !L.bmlp.alpha) return fail(-6, "inducer chain: GaussianActivation needs alpha");
                 TRY(inducer_chain_f16_launch(ca, C, Wd, s), "inducer chain");
                 h = hdst;
@@ -689,7 +699,7 @@ int gecco_set_option(const char* name, int value) {
             g_options[i] = value < 0 ? -1 : (value != 0);   // < 0: back to the environment / default
             return 0;
         }
-    return fail(-2, "set_option: unknown option '%s' (astat, chain, headmajor, mlpfused, unpoolfused, lo8, actimg, h8, kvq64, h8areg, chain2, unpoolh8, mlph8)", name);
+    return fail(-2, "set_option: unknown option '%s' (astat, chain, headmajor, mlpfused, unpoolfused, lo8, actimg, h8, kvq64, h8areg, chain2, unpoolh8, mlph8, chaincl)", name);
 }
 
 int gecco_linear_row_tiles(int rows) { return row_tiles_gemm(rows); }

@@ -95,14 +95,29 @@ __device__ unsigned long long g_chain_stamps[256 * 16];
 // twice over the same A operand, into the same accumulator: x . W_hi + x . W_lo.  The rounding of the WEIGHTS — the same for
 // every point of a cloud, the part of this chain's fp16 error that reaches the output (tools/experiments/precision_search.py:
 // chain = x2a holds F_x at 1.0e-4 .. 1.3e-4, chain = fp16 at 5e-4) — drops from 2^-12 to 2^-23; the activations stay one-term.
-template <int NT1, int NH, bool TWO>
+//
+// CL (option "chaincl"): a CLUSTER of CL = NT1 blocks per sample.  One block per sample streams all 4 MB of a layer's chain weights through
+// ONE CU's fill path (~33 B/clk: 87 us of the 109); in the cluster, block cb computes column tile cb of the C-wide products and tiles
+// cb, NT1 + cb of the 2C-wide ones — with NH = 2 every product is a whole number of NT1-tile groups, so block cb's weight stream is tile
+// units cb, cb + NT1, ..., cb + 6 NT1 of the same image: a third of the bytes per CU.  What the other blocks computed arrives through L2 as
+// REGISTER IMAGES: a block stores the accumulators (or packed fp16 pairs) of its tile exactly as its threads hold them ([tile][quad][thread]
+// [4 dwords]: whole 1 KiB rows per store instruction), thread i of every other block loads what thread i of the owner held, and from there on
+// the code — GroupNorm column sums, coefficient passes, the A-buffer writes — is the one-block kernel's, on the same values in the same
+// order: the same bits.  Three hand-offs per layer (h0, u, h2), each: write-through (sc1) 16-byte stores, every wave's vmcnt(0), the block
+// barrier, one agent-scope add on the sample's counter; the readers poll it with one lane, pass a block barrier and load sc1
+// (MI355X_MICROARCH.md, inter-workgroup visibility: the counter / sc1 row).  The counters are zeroed by the host once per forward (one
+// memset node for all layers) and only ever count up inside a launch.  Blocks of a cluster have consecutive ids: dispatch is in order, so a
+// block only ever waits for blocks dispatched before it or right behind it — at most one incomplete cluster per launch holds CUs.
+template <int NT1, int NH, bool TWO, int CL = 1>
 __global__ __launch_bounds__(CH_NT, 1) void inducer_chain_f16_kernel(ChainArgs g) {
+    static_assert(CL == 1 || (CL == NT1 && NH == 2), "cluster = one block per column tile of a C-wide product");
     constexpr int C = 128 * NT1, WD = C * NH, NTW = NT1 * NH, NT2 = 2 * NT1;
     constexpr int NK = C / 32;                  // weight blocks (32 k) per column tile of a K = C operand
     constexpr int RS = 2 * C + 16;              // bytes per A row: 16 B of padding -> conflict-free ds_read_b128
     constexpr int WT = TWO ? 2 : 1;             // K passes (weight terms) per column tile
     constexpr int S1 = WT * NT1 * NK, S2 = WT * NTW * NK, S3 = WT * NTW * NK, S4 = WT * NT2 * NK;
-    constexpr int S_TOTAL = S1 + S2 + S3 + S4;
+    constexpr int SEG = WT * NK;                // blocks of one tile unit of the stream
+    constexpr int S_TOTAL = CL == 1 ? S1 + S2 + S3 + S4 : 7 * SEG;   // blocks THIS block streams
     constexpr int NS = chain_ns(C, WD);
     constexpr int AHEAD = NS - 4;               // DMA pieces (one per block per wave) that may stay in flight at a wait
     static_assert(NS >= 6 && S_TOTAL >= NS && NK % 4 == 0, "ring");
@@ -124,7 +139,8 @@ __global__ __launch_bounds__(CH_NT, 1) void inducer_chain_f16_kernel(ChainArgs g
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int r = lane & 31, h = lane >> 5;
-    const int b = blockIdx.x;
+    const int b = CL == 1 ? blockIdx.x : blockIdx.x / CL;
+    const int cb = CL == 1 ? 0 : blockIdx.x - b * CL;       // this block's column tile (cluster form)
     const bool odd = lane & 1;
     const unsigned psel = odd ? 0x03020706u : 0x05040100u;   // v_perm_b32 over {neighbour, own}
     CSTAMP(0);
@@ -135,14 +151,19 @@ __global__ __launch_bounds__(CH_NT, 1) void inducer_chain_f16_kernel(ChainArgs g
     const __amdgpu_buffer_rsrc_t wrsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.w_stream), 0, 0x7fffffff, 0x00020000);
     const unsigned voff = (unsigned)(wave * 256 + lane * 4) * 4u;
-    unsigned soff = 0;     // byte offset of the next block to issue
+    unsigned soff = (unsigned)cb * (SEG * CH_TILE * 4u);     // byte offset of the next block to issue
     int islot = 0;         // its ring slot
     int issued = 0;
+    int seg_left = SEG;    // cluster form: blocks left in the tile unit being issued
     auto issue = [&]() {
 #ifndef CHAIN_DIAG_NODMA
         dma16_buf(wrsrc, voff, soff, ring + islot * CH_TILE + wave * 256);
 #endif
         soff += CH_TILE * 4u;
+        if (CL > 1 && --seg_left == 0) {   // on to tile unit + NT1
+            seg_left = SEG;
+            soff += (unsigned)(CL - 1) * (SEG * CH_TILE * 4u);
+        }
         islot = islot + 1 == NS ? 0 : islot + 1;
         ++issued;
     };
@@ -427,6 +448,7 @@ __global__ __launch_bounds__(CH_NT, 1) void inducer_chain_f16_kernel(ChainArgs g
     const int act_mode = g.act;
     const float neg_inv_2a2 = act_is_gauss(g.act) ? -1.0f / (2.0f * g.alpha[0] * g.alpha[0]) : 0.f;
 
+    if constexpr (CL == 1) {
     // ================= GEMM 1: h0 = merged16 Wpo^T; norm_1; y16 -> A buffer
     f32x16 acc1[NT1];
 #pragma unroll
@@ -526,25 +548,219 @@ __global__ __launch_bounds__(CH_NT, 1) void inducer_chain_f16_kernel(ChainArgs g
             for (int e = 0; e < 16; ++e) kb[(size_t)(wm * 32 + mfma_row(e, h)) * 2 * C + n] = a0[e] + bias;
         }
     }
+    } else {
+    // ======================================================================= the cluster form
+    typedef unsigned int u32v4 __attribute__((vector_size(16)));
+    constexpr int SC1 = 16;   // cache-policy bit of the buffer instructions: sc1 (write-through stores, L1-bypassing loads)
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(g.x1 + (size_t)b * 64 * C, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r3 = __builtin_amdgcn_make_buffer_rsrc(g.x3 + (size_t)b * 64 * C, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(g.xu + (size_t)b * 32 * WD, 0, 0x7fffffff, 0x00020000);
+    unsigned* const flags = g.flags + (size_t)b * 8;
+    const int tv = tid * 16;
+    auto store_acc = [&](const __amdgpu_buffer_rsrc_t& rs, int t, const f32x16& a) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32v4, v), rs, tv, (t * 4 + q) * (CH_NT * 16), SC1);
+        }
+    };
+    auto load_acc = [&](const __amdgpu_buffer_rsrc_t& rs, int t, f32x16& a) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, tv, (t * 4 + q) * (CH_NT * 16), SC1));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[4 * q + e] = v[e];
+        }
+    };
+    // every wave's stores have left, the block barrier, one add on the sample's counter k
+    auto publish = [&](int k) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(flags + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // all CL blocks of the sample have published k; the barrier stands between the poll and every load of the bytes
+    auto await = [&](int k) {
+        if (tid == 0) {
+            unsigned polls = 0;
+            while (__hip_atomic_load(flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)CL) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++polls > (1u << 21)) __builtin_trap();   // seconds: counters not zeroed or a lost block — fail the launch, never hang
+            }
+        }
+        __syncthreads();
+    };
+
+    // ================= GEMM 1: column tile cb of h0 = merged16 Wpo^T; the other tiles from their blocks; norm_1; y16 -> A buffer
+    f32x16 acc1[NT1];
+    {
+        f32x16 own;
+        zero(own);
+        run_tile(own, true, false);
+        CSTAMP(3);
+        store_acc(r1, cb, own);
+        publish(0);
+        await(0);
+        CSTAMP(11);
+#pragma unroll
+        for (int t = 0; t < NT1; ++t) {
+            if (t == cb) acc1[t] = own;
+            else load_acc(r1, t, acc1[t]);
+        }
+    }
+    norm_coeffs(acc1, 0);   // its barriers also order every wave's last A reads before the writes below
+    CSTAMP(4);
+#pragma unroll
+    for (int t = 0; t < NT1; ++t) {
+        const int n = t * 128 + wn * 32 + r;
+        const float ca = coef[n], co = coef[C + n];
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+            *a_dst(t, p) = pair_rows(__builtin_fmaf(acc1[t][2 * p], ca, co), __builtin_fmaf(acc1[t][2 * p + 1], ca, co));
+    }
+    lds_barrier();
+
+    // ================= GEMM 2: tiles cb, NT1 + cb of u = act(y16 W0^T + b0) as packed fp16 pairs; the other tiles from their blocks
+    CSTAMP(5);
+    unsigned upk[NTW][8];
+    {
+        unsigned uown[NH][8];
+#pragma unroll
+        for (int j = 0; j < NH; ++j) {
+            f32x16 a0;
+            zero(a0);
+            run_tile(a0, j == 0, j + 1 < NH);
+            const float bias = lb0[(j * NT1 + cb) * 128 + wn * 32 + r];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                float v0 = a0[2 * p] + bias, v1 = a0[2 * p + 1] + bias;
+                if (has_act) {
+                    v0 = act_apply(v0, neg_inv_2a2, act_mode);
+                    v1 = act_apply(v1, neg_inv_2a2, act_mode);
+                }
+                uown[j][p] = pair_rows(v0, v1);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const u32v4 v = {uown[j][4 * q], uown[j][4 * q + 1], uown[j][4 * q + 2], uown[j][4 * q + 3]};
+                __builtin_amdgcn_raw_buffer_store_b128(v, ru, tv, ((j * NT1 + cb) * 2 + q) * (CH_NT * 16), SC1);
+            }
+        }
+        CSTAMP(14);
+        publish(1);
+        await(1);
+        CSTAMP(12);
+#pragma unroll
+        for (int j = 0; j < NH; ++j)
+#pragma unroll
+            for (int tl = 0; tl < NT1; ++tl) {
+                if (tl == cb) {
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) upk[j * NT1 + tl][p] = uown[j][p];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const u32v4 v = __builtin_amdgcn_raw_buffer_load_b128(ru, tv, ((j * NT1 + tl) * 2 + q) * (CH_NT * 16), SC1);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) upk[j * NT1 + tl][4 * q + e] = v[e];
+                    }
+                }
+            }
+    }
+
+    // ================= GEMM 3: column tile cb of h2 = u16 W2^T + b2, K-half by K-half through the A buffer
+    CSTAMP(6);
+    {
+        f32x16 own;
+        zero(own);
+#pragma unroll
+        for (int hf = 0; hf < NH; ++hf) {
+            lds_barrier();   // every wave is done reading the previous operand
+#pragma unroll
+            for (int tl = 0; tl < NT1; ++tl)
+#pragma unroll
+                for (int p = 0; p < 8; ++p) *a_dst(tl, p) = upk[hf * NT1 + tl][p];
+            lds_barrier();
+            run_tile(own, true, false);
+        }
+        const float bias = lb2[cb * 128 + wn * 32 + r];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) own[e] += bias;
+        CSTAMP(7);
+        store_acc(r3, cb, own);
+        publish(2);
+        await(2);
+        CSTAMP(13);
+#pragma unroll
+        for (int t = 0; t < NT1; ++t) {
+            if (t == cb) acc1[t] = own;
+            else load_acc(r3, t, acc1[t]);
+        }
+    }
+    norm_coeffs(acc1, 1);
+    CSTAMP(8);
+    // h = AdaGN_2(h2): this block's column tile as fp32 to memory (the cacheable inducer state), all of it as fp16 into the A buffer
+    {
+        float* hb = g.h_out + (size_t)b * 64 * C;
+#pragma unroll
+        for (int t = 0; t < NT1; ++t) {
+            const int n = t * 128 + wn * 32 + r;
+            const float ca = coef[n], co = coef[C + n];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const float v0 = __builtin_fmaf(acc1[t][2 * p], ca, co);
+                const float v1 = __builtin_fmaf(acc1[t][2 * p + 1], ca, co);
+                if (t == cb) {
+                    const int row0 = wm * 32 + mfma_row(2 * p, h);
+                    hb[(size_t)row0 * C + n] = v0;
+                    hb[(size_t)(row0 + 1) * C + n] = v1;
+                }
+                *a_dst(t, p) = pair_rows(v0, v1);
+            }
+        }
+    }
+    lds_barrier();
+
+    // ================= GEMM 4: column tiles cb, NT1 + cb of kvh = h16 Wkv^T + bkv (fp32, read by the unpool attention)
+    CSTAMP(9);
+    {
+        float* kb = g.kvh + (size_t)b * 64 * 2 * C;
+#pragma unroll 1
+        for (int j = 0; j < 2; ++j) {
+            f32x16 a0;
+            zero(a0);
+            run_tile(a0, j == 0, j + 1 < 2);
+            const int n = (j * NT1 + cb) * 128 + wn * 32 + r;
+            const float bias = lbk[n];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) kb[(size_t)(wm * 32 + mfma_row(e, h)) * 2 * C + n] = a0[e] + bias;
+        }
+    }
+    }
     CSTAMP(10);
 }
 
-template <int NT1, int NH, bool TWO>
+template <int NT1, int NH, bool TWO, int CL>
 int chain_launch_w(const ChainArgs& g, hipStream_t st) {
     constexpr int C = 128 * NT1, WD = C * NH;
     constexpr size_t lds = chain_lds_bytes(C, WD);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(inducer_chain_f16_kernel<NT1, NH, TWO>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(inducer_chain_f16_kernel<NT1, NH, TWO, CL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    hipLaunchKernelGGL((inducer_chain_f16_kernel<NT1, NH, TWO>), dim3(g.B), dim3(CH_NT), lds, st, g);
+    hipLaunchKernelGGL((inducer_chain_f16_kernel<NT1, NH, TWO, CL>), dim3(g.B * CL), dim3(CH_NT), lds, st, g);
     return (int)hipGetLastError();
 }
 template <int NT1, int NH>
 int chain_launch_t(const ChainArgs& g, hipStream_t st) {
-    return g.two_term ? chain_launch_w<NT1, NH, true>(g, st) : chain_launch_w<NT1, NH, false>(g, st);
+    if constexpr (NT1 > 1) {
+        if (g.cluster) {
+            if (!g.x1 || !g.x3 || !g.xu || !g.flags) return -9;
+            return g.two_term ? chain_launch_w<NT1, NH, true, NT1>(g, st) : chain_launch_w<NT1, NH, false, NT1>(g, st);
+        }
+    }
+    return g.two_term ? chain_launch_w<NT1, NH, true, 1>(g, st) : chain_launch_w<NT1, NH, false, 1>(g, st);
 }
 
 }  // namespace

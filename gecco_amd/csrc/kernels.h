@@ -99,6 +99,12 @@ struct ChainArgs {
     float* h_out;             // (B, 64, C) fp32
     float* kvh;               // (B, 64, 2C) fp32
     int B;
+    // the cluster form (C / 128 blocks per sample): exchange buffers (B, 64, C) fp32 x 2 and (B, 64, 2C) fp16, 8 counters per sample
+    // (zeroed by the host before the launch; only ever counted up inside it)
+    int cluster;
+    float *x1, *x3;
+    unsigned* xu;
+    unsigned* flags;
 };
 bool inducer_chain_f16_supported(int C, int Wd, int H, int G, int I);
 int inducer_chain_f16_launch(const ChainArgs& g, int C, int Wd, hipStream_t st);

@@ -527,3 +527,40 @@ def test_empty_batch_returns_empty_results():
     assert den.shape == (0, N, 3) and raw.shape == (0, N, 3)
     assert len(cache) == L and all(h.shape == (0, cases.I, d) for h in cache)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("precision,d", [("mixed", 384), ("mixed", 256), ("mixed", 512), ("fp16", 384), ("fp16", 512), ("fp16", 256)])
+def test_inducer_chain_cluster_matches_one_block_chain_bitwise(ops, precision, d):
+    """The cluster form of the one-launch inducer chain (option "chaincl": d / 128 blocks per sample, each streaming a third of the weights,
+    handing each other h0, u and h2 as register images through L2 — inducer_chain_f16_kernel<.., CL>; models/set_transformer.py:99-117)
+    computes every value from the same operands in the same order as the one-block-per-sample chain: the network output and the cached
+    inducer states (which come straight out of the chain) are bit-identical; repeated runs too (the hand-offs carry no race), at a batch
+    larger than the CUs can hold at once (5 * 60 blocks: later clusters start while earlier ones wait)."""
+    from oracle import weights as OW
+    L, N, B = 3, 256, 100
+    p = _cuda(OW.linear_lift_state_dict(11, d, L, cases.I, 8))
+    rs = np.random.RandomState(d)
+    x = torch.from_numpy(rs.randn(B, N, 3).astype(np.float32)).cuda()
+    sigma = torch.from_numpy(np.exp(rs.uniform(-4, 4, size=B)).astype(np.float32)).cuda()
+    net = ops.LinearLiftPlan(p, 8, cases.I, precision=precision)
+    out = {}
+    try:
+        for on in (0, 1):
+            ops.set_option("chaincl", on)
+            den, hs = net.forward(x, sigma, do_cache=True)
+            out[on] = (den.clone(), [c.clone() for c in hs])
+        for _ in range(3):   # cluster form again: same bits every time
+            den, hs = net.forward(x, sigma, do_cache=True)
+            assert torch.equal(den, out[1][0]) and all(torch.equal(a, b) for a, b in zip(hs, out[1][1]))
+    finally:
+        ops.set_option("chaincl", -1)
+    assert torch.isfinite(out[1][0]).all()
+    if precision == "mixed" and d == 512:
+        # d = 512 runs the one-launch chain ONLY as a cluster (one block per sample loses to the five split-bf16 launches there, api.hip):
+        # "chaincl" = 0 is that split-bf16 chain — the two agree like "chain2" on / off do (test_mixed_two_term_chain_...)
+        e = cpu_ref.rel_err(out[1][0].cpu(), out[0][0].cpu())
+        assert 0 < e[0] <= 3e-4, e
+        return
+    for li, (a, b) in enumerate(zip(out[1][1], out[0][1])):
+        assert torch.equal(a, b), (li, float((a - b).abs().max()))
+    assert torch.equal(out[1][0], out[0][0])

@@ -431,11 +431,14 @@ class LinearFn(torch.autograd.Function):
         if want_stats:
             y, st = hip_ops.linear(x, None if img is not None else W, b, residual=res, want_stats=True, **kw)
             ctx.mark_non_differentiable(st)
+            ctx.set_materialize_grads(False)   # else backward is handed a zero-filled (B, T, 2, Nout) tensor for st: one fill launch per call
             return y, st
         return hip_ops.linear(x, None if img is not None else W, b, residual=res, **kw)
 
     @staticmethod
     def backward(ctx, dy, _dstats=None):
+        if dy is None:   # (materialize off) only the statistics were used: they carry no gradient
+            return (None,) * len(ctx.needs_input_grad)
         x, W = ctx.saved_tensors
         dy = _f(dy)
         prec = ctx.prec
@@ -668,10 +671,13 @@ class AdaGNMlpFn(torch.autograd.Function):
         out = _linear_fwd_h16(h, W2, b2, x, want_stats) if h16 else _linear_fwd(h, W2, b2, x, want_stats, prec)
         if want_stats:
             ctx.mark_non_differentiable(out[1])
+            ctx.set_materialize_grads(False)   # no zero-filled gradient tensor for the statistics
         return out
 
     @staticmethod
     def backward(ctx, dout, _dstats=None):
+        if dout is None:   # (materialize off) only the statistics were used: they carry no gradient
+            return (None,) * len(ctx.needs_input_grad)
         _no_input_grad(ctx, 1, "the noise-level embedding t")
         x, stats, t2, sw, sb, a, o, u, h, alpha, W0, W2 = ctx.saved_tensors
         need = ctx.needs_input_grad
@@ -898,10 +904,13 @@ class LinearActLinearFn(torch.autograd.Function):
         out = _linear_fwd_h16(h, W2, b2, res, want_stats) if h16 else _linear_fwd(h, W2, b2, res, want_stats, prec)
         if want_stats:
             ctx.mark_non_differentiable(out[1])
+            ctx.set_materialize_grads(False)   # no zero-filled gradient tensor for the statistics
         return out
 
     @staticmethod
     def backward(ctx, dy, _dstats=None):
+        if dy is None:   # (materialize off) only the statistics were used: they carry no gradient
+            return (None,) * len(ctx.needs_input_grad)
         x, u, h, alpha, W0, W2 = ctx.saved_tensors
         need = ctx.needs_input_grad
         dy = _f(dy)
@@ -936,10 +945,13 @@ class ActLinearFn(torch.autograd.Function):
         out = _linear_fwd(h, W, b, res, want_stats, prec)
         if want_stats:
             ctx.mark_non_differentiable(out[1])
+            ctx.set_materialize_grads(False)   # no zero-filled gradient tensor for the statistics
         return out
 
     @staticmethod
     def backward(ctx, dy, _dstats=None):
+        if dy is None:   # (materialize off) only the statistics were used: they carry no gradient
+            return (None,) * len(ctx.needs_input_grad)
         u, h, alpha, W = ctx.saved_tensors
         dy = _f(dy)
         prec = ctx.prec
@@ -1480,6 +1492,32 @@ def convnext_pyramid(ext, image: Tensor) -> list[Tensor]:
     return feats
 
 
+class InProjSplitFn(torch.autograd.Function):
+    """nn.MultiheadAttention's packed in_proj (weight (3C, C), bias (3C)) as its query third and its key | value two thirds — views, as
+    `W[:C]`, `W[C:]` are (models/set_transformer.py:112 -> torch's in_proj packing).  Autograd's own slice backward builds, per slice, a
+    zero-filled full-size tensor, copies the slice's gradient into it and adds the two: ten 5-us launches per layer.  Here the two
+    gradients are concatenated once (two launches)."""
+
+    @staticmethod
+    def forward(ctx, W, b, Cc):
+        ctx.Cc = Cc
+        ctx.set_materialize_grads(False)
+        return W[:Cc], b[:Cc], W[Cc:], b[Cc:]
+
+    @staticmethod
+    def backward(ctx, gWq, gbq, gWkv, gbkv):
+        Cc = ctx.Cc
+
+        def join(a, b_, rows_a, rows_b):
+            if a is None and b_ is None:
+                return None
+            ref = a if a is not None else b_
+            a = ref.new_zeros(rows_a, *ref.shape[1:]) if a is None else a
+            b_ = ref.new_zeros(rows_b, *ref.shape[1:]) if b_ is None else b_
+            return torch.cat([a, b_], 0)
+        return join(gWq, gWkv, Cc, 2 * Cc), join(gbq, gbkv, Cc, 2 * Cc), None
+
+
 # ------------------------------------------------------------------------------------------- network composition
 def adagn(mod, x, t, passthrough=False, stats=None):
     return AdaGNFn.apply(x, t, mod.scale.weight, mod.scale.bias, mod.bias.weight, mod.bias.bias, mod.gn.num_groups, mod.gn.eps,
@@ -1530,25 +1568,29 @@ def broadcasting_layer(layer, x, t, h=None, stats=None, want_stats=False):
     H = bc.pool.num_heads
     Cc = x.shape[-1]
     R = x.shape[1]
-    W, b = bc.unpool.in_proj_weight, bc.unpool.in_proj_bias
+    if os.environ.get("GECCO_TRAIN_INPROJ_SPLIT", "1") != "0":
+        Wq, bq, Wkv, bkv = InProjSplitFn.apply(bc.unpool.in_proj_weight, bc.unpool.in_proj_bias, Cc)
+    else:   # plain slices: autograd's slice backward (A/B runs)
+        W_, b_ = bc.unpool.in_proj_weight, bc.unpool.in_proj_bias
+        Wq, bq, Wkv, bkv = W_[:Cc], b_[:Cc], W_[Cc:], b_[Cc:]
     n1 = layer.broadcast_norm
     fused_pair = h is None and _pro_ok(R, Cc, 3 * Cc) and Cc % 128 == 0
     if fused_pair:   # broadcast_norm as the prologue of kv_proj | q_proj: AdaGN(x) is never written
         KV, q, x = AdaGNPairFn.apply(x, t, n1.scale.weight, n1.scale.bias, n1.bias.weight, n1.bias.bias, n1.gn.num_groups, n1.gn.eps,
-                                     stats, bc.pool.kv_proj.weight, W[:Cc], b[:Cc])
+                                     stats, bc.pool.kv_proj.weight, Wq, bq)
     else:
         y, x = adagn(n1, x, t, passthrough=True, stats=stats)
     if h is None:
         if not fused_pair:
-            KV, q = LinearPairFn.apply(y, bc.pool.kv_proj.weight, None, W[:Cc], b[:Cc])
+            KV, q = LinearPairFn.apply(y, bc.pool.kv_proj.weight, None, Wq, bq)
         merged = PoolAttnFn.apply(KV, bc.pool.inducers, H)
         h = LinearFn.apply(merged, bc.pool.out_proj.weight, None)
         h = adagn(bc.norm_1, h, t)
         h = mlp(bc.mlp, h)
         h = adagn(bc.norm_2, h, t)
     else:
-        q = LinearFn.apply(y, W[:Cc], b[:Cc])
-    kvh = LinearFn.apply(h, W[Cc:], b[Cc:])
+        q = LinearFn.apply(y, Wq, bq)
+    kvh = LinearFn.apply(h, Wkv, bkv)
     attn = UnpoolAttnFn.apply(q, kvh, H)
     x, st = LinearFn.apply(attn, bc.unpool.out_proj.weight, bc.unpool.out_proj.bias, x, True)   # x + out_proj(attn)
     n2, mods = layer.mlp_norm, list(layer.mlp)

@@ -31,6 +31,7 @@
 #include <stdlib.h>
 
 #include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -80,6 +81,15 @@ __device__ __forceinline__ unsigned pack2(float v0, float v1) {
     return __builtin_bit_cast(unsigned, p);
 }
 
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 #ifdef CHAIN_STAMPS   // diagnostic build (tools/probe): per-block s_memtime stamps of the phases
 __device__ unsigned long long g_chain_stamps[256 * 16];
 #define CSTAMP(i)                                                                                              \
@@ -116,6 +126,10 @@ __global__ __launch_bounds__(CH_NT, 1) void inducer_chain_f16_kernel(ChainArgs g
     constexpr int RS = 2 * C + 16;              // bytes per A row: 16 B of padding -> conflict-free ds_read_b128
     constexpr int WT = TWO ? 2 : 1;             // K passes (weight terms) per column tile
     constexpr int S1 = WT * NT1 * NK, S2 = WT * NTW * NK, S3 = WT * NTW * NK, S4 = WT * NT2 * NK;
+    // AST (cluster form, d <= 384): a wave's A fragments (its 32 rows x C: C / 4 registers) are read from the A buffer ONCE per operand and
+    // stay in registers over the hi | lo passes and column tiles that share it — a step then reads only the weight fragments out of LDS
+    // (32 KiB instead of 64 KiB per step: the GEMM phases of this kernel are LDS-read-bound, profiles/r04z_chain_cluster_stamps.txt)
+    constexpr bool AST = CL > 1 && NT1 <= 3;
     constexpr int SEG = WT * NK;                // blocks of one tile unit of the stream
     constexpr int S_TOTAL = CL == 1 ? S1 + S2 + S3 + S4 : 7 * SEG;   // blocks THIS block streams
     constexpr int NS = chain_ns(C, WD);
@@ -290,6 +304,13 @@ __global__ __launch_bounds__(CH_NT, 1) void inducer_chain_f16_kernel(ChainArgs g
         for (int c = 0; c < 2; ++c) boff[c] = rb * 16 + (((2 * h + c) ^ ((rb >> 2) & 3)) << 2);
     }
     f16x8 fa[2][2][2], fb[2][2][2];   // [set][block][chunk]
+    f16x8 areg[AST ? NK : 1][2];      // AST: the stationary A fragments [block][chunk]
+    auto load_areg = [&]() {
+#pragma unroll
+        for (int k = 0; k < (AST ? NK : 0); ++k)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) areg[k][c] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(arow + k * 64 + 16 * c));
+    };
     auto load_frags = [&](auto set_tag, int kt) {   // blocks kt, kt + 1 of the tile
         constexpr int set = decltype(set_tag)::value;
 #ifdef CHAIN_DIAG_NOFRAGS
@@ -300,7 +321,7 @@ __global__ __launch_bounds__(CH_NT, 1) void inducer_chain_f16_kernel(ChainArgs g
             const float* st = ring + rslot * CH_TILE;
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                fa[set][q][c] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(arow + (kt + q) * 64 + 16 * c));
+                if constexpr (!AST) fa[set][q][c] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(arow + (kt + q) * 64 + 16 * c));
                 fb[set][q][c] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(st + boff[c]));
             }
             rslot = rslot + 1 == NS ? 0 : rslot + 1;
@@ -318,8 +339,9 @@ __global__ __launch_bounds__(CH_NT, 1) void inducer_chain_f16_kernel(ChainArgs g
             if (!TAIL || issued < S_TOTAL) issue();
     };
     // one step: set `cur` holds its fragments; has_next: the following step reads the same A operand
-    auto kstep = [&](auto cur_tag, auto tail_tag, bool has_next, int kt_next, f32x16& a0) {
+    auto kstep = [&](auto cur_tag, auto tail_tag, bool has_next, int kt_next, f32x16& a0, auto kt_tag) {
         constexpr int cur = decltype(cur_tag)::value;
+        constexpr int KT = decltype(kt_tag)::value;   // AST: this step's first block (its A fragments are areg[KT], areg[KT + 1])
         if (has_next) {
             wait_blocks(tail_tag);
             // this step's fragments were read during the previous one and the wait above covered them: "redefine"
@@ -329,7 +351,7 @@ __global__ __launch_bounds__(CH_NT, 1) void inducer_chain_f16_kernel(ChainArgs g
             for (int q = 0; q < 2; ++q)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    asm volatile("" : "+v"(fa[cur][q][c]));
+                    if constexpr (!AST) asm volatile("" : "+v"(fa[cur][q][c]));
                     asm volatile("" : "+v"(fb[cur][q][c]));
                 }
 #ifndef CHAIN_DIAG_NOBARRIER
@@ -346,7 +368,8 @@ __global__ __launch_bounds__(CH_NT, 1) void inducer_chain_f16_kernel(ChainArgs g
 #ifdef CHAIN_DIAG_NOMFMA
                 a0[0] += (float)fa[cur][q][c][0] + (float)fb[cur][q][c][0];
 #else
-                a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][q][c], fb[cur][q][c], a0, 0, 0, 0);
+                if constexpr (AST) a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(areg[KT + q][c], fb[cur][q][c], a0, 0, 0, 0);
+                else a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][q][c], fb[cur][q][c], a0, 0, 0, 0);
 #endif
             }
     };
@@ -358,21 +381,32 @@ __global__ __launch_bounds__(CH_NT, 1) void inducer_chain_f16_kernel(ChainArgs g
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             issue2(tail_tag);
+            if constexpr (AST) load_areg();
             load_frags(set0, 0);
         }
+        if constexpr (AST) {   // every step with its block index at compile time (register-indexed A fragments)
+            static_for<NK / 2>([&](auto i_tag) {
+                constexpr int i = decltype(i_tag)::value;
+                constexpr bool last = i + 1 == NK / 2;
+                kstep(std::integral_constant<int, (i & 1)>{}, tail_tag, last ? more : true, last ? 0 : 2 * (i + 1), a0,
+                      std::integral_constant<int, 2 * i>{});
+            });
+        } else {
+            constexpr std::integral_constant<int, 0> k0{};
 #pragma unroll 1
-        for (int kt = 0; kt < NK - 4; kt += 4) {
-            kstep(set0, tail_tag, true, kt + 2, a0);
-            kstep(set1, tail_tag, true, kt + 4, a0);
+            for (int kt = 0; kt < NK - 4; kt += 4) {
+                kstep(set0, tail_tag, true, kt + 2, a0, k0);
+                kstep(set1, tail_tag, true, kt + 4, a0, k0);
+            }
+            kstep(set0, tail_tag, true, NK - 2, a0, k0);
+            kstep(set1, tail_tag, more, 0, a0, k0);
         }
-        kstep(set0, tail_tag, true, NK - 2, a0);
-        kstep(set1, tail_tag, more, 0, a0);
         s += NK;
     };
     // the NK blocks of one column tile; first: the A operand is new (prime the pipeline); more: another tile over
     // the same A operand follows
     auto run_pass = [&](f32x16& a0, bool first, bool more) {
-        if (s + NK + NS > S_TOTAL) tile_steps(std::true_type{}, first, more, a0);
+        if (AST || s + NK + NS > S_TOTAL) tile_steps(std::true_type{}, first, more, a0);   // AST: one (unrolled) form, end-of-stream checks at run time
         else tile_steps(std::false_type{}, first, more, a0);
     };
     auto run_tile = [&](f32x16& a0, bool first, bool more) {

@@ -32,7 +32,7 @@ times one evaluation of the other BASELINE shapes (C5: the cached upsampling eva
 Extra objects on that line:
   roofline     — the dominant kernel of the measured mode.  mixed (default): mlp.0 on the A-stationary h8 kernel
                  (gemm_h8_astat_kernel: AdaGN apply + fp16 main product + two fp8 cross terms + GaussianActivation, 20 % of device
-                 time), bound "mfma" against 2500 / 2 TFLOP/s of 2MNK (2 matrix-pipe units per product), its HBM side beside it
+                 time), bound "mfma" against 2500 / 1.5 TFLOP/s of 2MNK (1.5 matrix-pipe units per product with the fp6 cross terms; 2 with GECCO_H6=0), its HBM side beside it
                  ("hbm": the kernel sits at the ridge), timed with HIP events inside hipGraph replays of the round out_proj ->
                  mlp.0 -> mlp.2 on shared buffers ("round - round without that launch"); "traffic" / "mfma_busy_pmc" = that
                  kernel's FETCH_SIZE x 2 + WRITE_SIZE and matrix-pipe busy fraction from the committed --pmc passes
@@ -566,6 +566,11 @@ def train_bench(args, rank, world, dev):
         dist.destroy_process_group()
 
 
+# matrix-pipe units (16-bit-instruction equivalents) per product of mlp.0 in the mixed mode: fp16 main product + two cross terms, fp6 x fp6
+# with block scales (option "h6", default: a quarter of the 16-bit cycles each) or fp8 x fp8 (GECCO_H6=0: half each)
+MLP0_UNITS = 2.0 if os.environ.get("GECCO_H6", "1") == "0" else 1.5
+
+
 def executed_mfma_flops(mode, Bc=B, Nc=N, d=D, Ll=L):
     """MFMA FLOPs the evaluation EXECUTES in 16-bit-equivalent matrix-pipe units (an fp8 64-k instruction counts half the
     cycles per FLOP of a 16-bit one, so its FLOPs count half; split-bf16 executes 3 instructions per product): what
@@ -579,8 +584,9 @@ def executed_mfma_flops(mode, Bc=B, Nc=N, d=D, Ll=L):
         u = kv + q + outp + m0 + m2 + attn + chain
     elif mode == "bf16x3":
         u = 3 * (kv + q + outp + m0 + m2 + attn + chain)
-    else:   # mixed: K, q one fp16 term; V fp16 + fp8 lo term (1.5); attention fp16; chain two-term fp16 weights (2); out_proj, mlp.0, mlp.2 h8 (2)
-        u = 0.5 * kv * (1 + 1.5) + q + attn + 2 * chain + 2 * outp + 2 * m0 + 2 * m2
+    else:   # mixed: K, q one fp16 term; V fp16 + fp8 lo term (1.5); attention fp16; chain two-term fp16 weights (2); out_proj, mlp.2 h8 (2);
+        # mlp.0 h6 (fp16 + two fp6 cross terms at a quarter of the 16-bit cycles each: 1.5) unless GECCO_H6=0 (h8: 2)
+        u = 0.5 * kv * (1 + 1.5) + q + attn + 2 * chain + 2 * outp + MLP0_UNITS * m0 + 2 * m2
     return Bc * Ll * u
 
 
@@ -930,7 +936,8 @@ def main():
             # The dominant kernel of the mixed mode since round 3 is mlp.0 on the A-stationary h8 kernel (gemm_h8_astat_kernel: AdaGN
             # apply + fp16 main product + two fp8 cross terms + GaussianActivation, writes the h8 activation image; 20 % of the device
             # time, profiles/r03p_fwd_kernel_stats_one_stream.csv).  Its product executes 2 matrix-pipe units (one 16-bit instruction
-            # stream + two fp8 streams at twice the rate), so its matrix roof is 2500 / 2 TFLOP/s of 2MNK; 77.3 GFLOP x 2 over 503 MB
+            # stream + two fp8 streams at twice the rate; with option "h6", the default, two fp6 streams at four times the rate: 1.5 units),
+            # so its matrix roof is 2500 / 2 (1.5) TFLOP/s of 2MNK; 77.3 GFLOP x 2 over 503 MB
             # = 307 unit-FLOP/B, at the ridge of 2500 TF / 8 TB/s = 312: both roofs are reported, `bound` names the matrix side the
             # counters show busier (0.36 of the cycles against 0.33 of 8 TB/s).  Timed live with HIP events inside hipGraph replays of
             # the round out_proj -> mlp.0 -> mlp.2 (all three on their h8 kernels, shared buffers): round - round without it.
@@ -945,18 +952,22 @@ def main():
             tjd = json.load(open(tj)).get("mixed", {}) if os.path.exists(tj) else {}
             pk = tjd.get("per_kernel", {})
             kk = next((v for k, v in pk.items() if k.startswith("gemm_h8_astat_kernel")), {})
-            rec["roofline"] = {"bound": "mfma", "achieved": mtf, "peak": PEAK_BF16_MFMA_TFLOPS / 2, "unit": "TFLOP/s",
-                               "frac": 2 * mtf / PEAK_BF16_MFMA_TFLOPS, "traffic": kk.get("bytes_per_launch"),
+            rec["roofline"] = {"bound": "mfma", "achieved": mtf, "peak": PEAK_BF16_MFMA_TFLOPS / MLP0_UNITS, "unit": "TFLOP/s",
+                               "frac": MLP0_UNITS * mtf / PEAK_BF16_MFMA_TFLOPS, "traffic": kk.get("bytes_per_launch"),
+                               "matrix_units_per_product": MLP0_UNITS,
                                # the same launch against the PLAIN dense 16-bit peak on its algorithmic 2MNK: the "/ 2 units" peak above
                                # counts the two cross terms the arithmetic chose as useful work; this figure does not
                                "frac_dense_fp16_algorithmic": mtf / PEAK_BF16_MFMA_TFLOPS,
                                # cycle-based view of the same kernel (committed PMC constant, not measured in this run)
                                "mfma_busy_pmc": kk.get("mfma_busy"),
-                               "kernel": "gemm_h8_astat_kernel<6,4,6,1,true> = mlp.0 of the mixed mode (A-stationary over 128-row blocks, AdaGN apply, "
-                                         "v_mfma_f32_32x32x16_f16 + 2 x v_mfma_scale_f32_32x32x64_f8f6f4 per 64 k, GaussianActivation, h8 activation image "
+                               "kernel": "gemm_h8_astat_kernel<6,4,6,1,true,0," + ("false" if MLP0_UNITS == 2.0 else "true") + "> = mlp.0 of the mixed "
+                                         "mode (A-stationary over 128-row blocks, AdaGN apply, 4 x v_mfma_f32_32x32x16_f16 + 2 x "
+                                         "v_mfma_scale_f32_32x32x64_f8f6f4 (" + ("fp8 x fp8" if MLP0_UNITS == 2.0 else "fp6 x fp6, block scales") + ") per 64 k of a "
+                                         "32 x 32 tile, GaussianActivation, h8 activation image "
                                          "out), one launch over the whole batch on one stream; achieved = 2MNK / its duration inside hipGraph replays of "
                                          "the round out_proj -> mlp.0 -> mlp.2 on shared buffers (HIP events; round - round without it); peak = dense "
-                                         "16-bit MFMA peak (2500 TFLOP/s) / 2 matrix-pipe units per product; traffic / mfma_busy_pmc = FETCH_SIZE x 2 + "
+                                         "16-bit MFMA peak (2500 TFLOP/s) / " + str(MLP0_UNITS) + " matrix-pipe units per product (a faster cross-term format "
+                                         "RAISES this roof: the h6 kernel is quicker than the h8 one at a lower frac); traffic / mfma_busy_pmc = FETCH_SIZE x 2 + "
                                          "WRITE_SIZE and SQ_VALU_MFMA_BUSY_CYCLES of that kernel in the forward (" + str(tjd.get("source")) + ": committed "
                                          "constants, not measured in this run)",
                                "hbm": {"achieved_gbs_algorithmic": mb / (per[mk]["ms"] * 1e-3) / 1e9, "peak_gbs": PEAK_HBM_GBS,

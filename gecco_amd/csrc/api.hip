@@ -189,11 +189,11 @@ int linear_pair(const float* A, const float* W1, const float* b1, int Nout1, flo
 }
 
 // Path switches for A/B runs and tests: gecco_set_option, or the environment (GECCO_ASTAT, GECCO_CHAIN) on first use.
-enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_HEADMAJOR = 2, OPT_MLPFUSED = 3, OPT_UNPOOLFUSED = 4, OPT_LO8 = 5, OPT_ACTIMG = 6, OPT_H8 = 7, OPT_KVQ64 = 8, OPT_H8AREG = 9, OPT_CHAIN2 = 10, OPT_UNPOOLH8 = 11, OPT_MLPH8 = 12, OPT_CHAINCL = 13, OPT_COUNT = 14 };
-int g_options[OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
-const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor", "mlpfused", "unpoolfused", "lo8", "actimg", "h8", "kvq64", "h8areg", "chain2", "unpoolh8", "mlph8", "chaincl"};
+enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_HEADMAJOR = 2, OPT_MLPFUSED = 3, OPT_UNPOOLFUSED = 4, OPT_LO8 = 5, OPT_ACTIMG = 6, OPT_H8 = 7, OPT_KVQ64 = 8, OPT_H8AREG = 9, OPT_CHAIN2 = 10, OPT_UNPOOLH8 = 11, OPT_MLPH8 = 12, OPT_CHAINCL = 13, OPT_H6 = 14, OPT_COUNT = 15 };
+int g_options[OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor", "mlpfused", "unpoolfused", "lo8", "actimg", "h8", "kvq64", "h8areg", "chain2", "unpoolh8", "mlph8", "chaincl", "h6"};
 const char* const g_option_env[OPT_COUNT] = {"GECCO_ASTAT", "GECCO_CHAIN", "GECCO_HEADMAJOR", "GECCO_MLPFUSED", "GECCO_UNPOOLFUSED", "GECCO_LO8",
-                                             "GECCO_ACTIMG", "GECCO_H8", "GECCO_KVQ64", "GECCO_H8AREG", "GECCO_CHAIN2", "GECCO_UNPOOLH8", "GECCO_MLPH8", "GECCO_CHAINCL"};
+                                             "GECCO_ACTIMG", "GECCO_H8", "GECCO_KVQ64", "GECCO_H8AREG", "GECCO_CHAIN2", "GECCO_UNPOOLH8", "GECCO_MLPH8", "GECCO_CHAINCL", "GECCO_H6"};
 int option(int which) {
     if (g_options[which] < 0) {
         const char* e = getenv(g_option_env[which]);
@@ -314,6 +314,9 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         hg.a_img = 2; hg.w_img = w.wimg; hg.rows = N; hg.Nout = C; hg.K = C; hg.lda = C; hg.ldc = C; hg.ldr = C;
         h8o = gemm_h8_areg_supported(hg);
     }
+    // mixed mode, option "h6": mlp.0's two cross terms as fp6 x fp6 with per-block scales (half the matrix cycles of the fp8 form; its
+    // weight stream is built in the h6 form) — where mlp.0 writes the h8 activation image (the kernel's only F6 instantiations)
+    const bool h6_on = h8_on && h8x && option(OPT_H6);
     // mixed mode: unpool attention + out_proj (h8) + residual + statistics in ONE launch (unpool_outproj_h8.hip; option "unpoolh8"):
     // the attention output of a row block is the stationary operand of out_proj and never leaves the CU.  Needs the head-major
     // fp16 q of the kvq kernel; the k | v image of the inducers lives in the (then idle) attention-output buffer
@@ -436,7 +439,7 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
             } else {
                 if (h8_on) {   // same bytes as the split-bf16 image it replaces: fp16 hi + fp8 lo + fp8 W per element
                     if (jobs8.n >= kJobCap) { TRY(h8_image_multi_launch(jobs8, s), "split(mlp.0, h8)"); jobs8.n = 0; }
-                    jobs8.job[jobs8.n++] = SplitJob{L.mlp.w0, base + w.o_w0, Wd, C, C, 0};
+                    jobs8.job[jobs8.n++] = SplitJob{L.mlp.w0, base + w.o_w0, Wd, C, C, h6_on ? 32 : 0};
                 } else {
                     TRY(push(L.mlp.w0, base + w.o_w0, Wd, C), "split(mlp.0)");
                 }
@@ -635,7 +638,7 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         if (m0_done == 1 && h8_on && himg && im) {
             GemmArgs hg{};
             hg.A = x; hg.pro_a = w.a2; hg.pro_o = w.o2; hg.bias = L.mlp.b0; hg.alpha = L.mlp.alpha; hg.act = act; hg.C = w.big;
-            hg.B = B; hg.rows = N; hg.K = C; hg.Nout = Wd; hg.lda = C; hg.ldw = C; hg.ldc = Wd; hg.c_img = h8x ? 2 : 1; hg.w_img = im + w.o_w0;
+            hg.B = B; hg.rows = N; hg.K = C; hg.Nout = Wd; hg.lda = C; hg.ldw = C; hg.ldc = Wd; hg.c_img = h8x ? 2 : 1; hg.w_img = im + w.o_w0; hg.h6 = h6_on ? 1 : 0;
             if ((act == 1 || act == 2) && !L.mlp.alpha) return fail(-6, "mlp.0: GaussianActivation needs alpha");
             TRY(gemm_h8_astat_launch(hg, s), "mlp.0 (h8)");
             m0_done = 0;
@@ -699,7 +702,7 @@ int gecco_set_option(const char* name, int value) {
             g_options[i] = value < 0 ? -1 : (value != 0);   // < 0: back to the environment / default
             return 0;
         }
-    return fail(-2, "set_option: unknown option '%s' (astat, chain, headmajor, mlpfused, unpoolfused, lo8, actimg, h8, kvq64, h8areg, chain2, unpoolh8, mlph8, chaincl)", name);
+    return fail(-2, "set_option: unknown option '%s' (astat, chain, headmajor, mlpfused, unpoolfused, lo8, actimg, h8, kvq64, h8areg, chain2, unpoolh8, mlph8, chaincl, h6)", name);
 }
 
 int gecco_linear_row_tiles(int rows) { return row_tiles_gemm(rows); }
@@ -1125,12 +1128,13 @@ int gecco_linear_h8_img_f32(const float* x, const float* pro_a, const float* pro
     GemmArgs g{};
     g.A = x; g.pro_a = pro_a; g.pro_o = pro_o; g.bias = bias; g.alpha = alpha; g.act = act; g.C = static_cast<float*>(c_img);
     g.B = B; g.rows = rows; g.K = K; g.Nout = Nout; g.lda = K; g.ldw = K; g.ldc = Nout; g.c_img = image_kind; g.w_img = wsplit;
+    g.h6 = image_kind == 2 && option(OPT_H6) ? 1 : 0;   // option "h6": the cross terms in fp6 with block scales (the network's mlp.0)
     if (!gemm_h8_astat_supported(g))
         return fail(-2, "linear_h8_img: needs rows %% 128 == 0, Nout %% 64 == 0, Nout >= 128, K in {128, 256, 384}, act in 0 .. 3");
     if (W) {   // NULL: wsplit still holds the image a previous call made from the same weights
         SplitJobs jobs;
         jobs.n = 1;
-        jobs.job[0] = SplitJob{W, static_cast<float*>(wsplit), Nout, K, K, 0};
+        jobs.job[0] = SplitJob{W, static_cast<float*>(wsplit), Nout, K, K, g.h6 ? 32 : 0};
         TRY(h8_image_multi_launch(jobs, s), "linear_h8_img(image)");
     }
     TRY(gemm_h8_astat_launch(g, s), "linear_h8_img");

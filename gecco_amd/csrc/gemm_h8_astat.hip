@@ -107,10 +107,50 @@ __device__ __forceinline__ f32x16 h8_keep8(i32x8 a, i32x8 b, f32x16 c) {
 #define H8_MFMA8(a, b, c, sa, sb) h8_keep8(a, b, c)
 #else
 #define H8_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#ifdef H8_DIAG_CROSSFMT   // timing only: the cross terms' instruction with both operands read as fp6 (2) / fp4 (4) — garbage values
+#define H8_MFMA8(a, b, c, sa, sb) __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, H8_DIAG_CROSSFMT, H8_DIAG_CROSSFMT, 0, sa, 0, sb)
+#else
 #define H8_MFMA8(a, b, c, sa, sb) __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, sa, 0, sb)
+#endif
 #endif
 
 __device__ __forceinline__ float clamp448(float v) { return __builtin_fminf(__builtin_fmaxf(v, -448.f), 448.f); }
+
+// ---- "h6": the two cross terms in fp6 (e2m3) with one E8M0 scale per lane and 64-k group (OCP-MX block scaling: the lane's 32 values
+// ARE a scale block of v_mfma_scale_f32_32x32x64_f8f6f4) instead of fp8 with fixed power-of-two scales.  Both operands 6 bits wide:
+// the instruction takes half the matrix-pipe cycles of the fp8 form (tools/probe/fp6_rate.hip: 1.65x the rate on random operands), and
+// a block's scale follows its own maximum, so there is no range to leave (h8_scales.h's clamps become irrelevant for these terms).
+// e2m3: 3 mantissa bits like e4m3, normal range [1, 7.5], subnormal step 0.125.  Semantics pinned by tools/probe/fp6_mfma_probe.hip:
+// v_cvt_scalef32_pk32_fp6_f16 divides by its scale operand and packs element i at bit 6 i — the layout the MFMA reads; scale operand =
+// E8M0 byte (2^(byte - 127)) of the selected byte of a VGPR, per lane.
+typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
+typedef unsigned int u32x6 __attribute__((ext_vector_type(6)));
+// E8M0 byte of the block scale for a block whose largest magnitude is m: m / 2^(byte - 127) in (3.75, 7.5]
+__device__ __forceinline__ int h6_scale_byte(float m) {
+    const int e = (int)(__float_as_uint(m * (16.0f / 15.0f)) >> 23) - 2;
+    return m > 0.f ? (e < 1 ? 1 : e) : 127;
+}
+__device__ __forceinline__ float h6_scale_of(int byte) { return __uint_as_float((unsigned)byte << 23); }
+// largest magnitude of four fp16 fragments (32 values)
+__device__ __forceinline__ float h6_absmax32(f16x8 a, f16x8 b, f16x8 c, f16x8 d) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    auto ab = [](f16x8 v) {
+        u32x4 u = __builtin_bit_cast(u32x4, v);
+        u &= 0x7fff7fffu;
+        return __builtin_bit_cast(f16x8, u);
+    };
+    f16x8 m = __builtin_elementwise_max(__builtin_elementwise_max(ab(a), ab(b)), __builtin_elementwise_max(ab(c), ab(d)));
+    const h2 m2 = __builtin_elementwise_max(__builtin_elementwise_max(h2{m[0], m[1]}, h2{m[2], m[3]}),
+                                            __builtin_elementwise_max(h2{m[4], m[5]}, h2{m[6], m[7]}));
+    return fmaxf((float)m2[0], (float)m2[1]);
+}
+__device__ __forceinline__ u32x6 h6_pack32(f16x8 a, f16x8 b, f16x8 c, f16x8 d, float scale) {
+    const f16x32 v = __builtin_shufflevector(__builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15),
+                                             __builtin_shufflevector(c, d, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15), 0, 1, 2, 3, 4, 5,
+                                             6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31);
+    return __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(v, scale);
+}
+#define H6_MFMA(a, b, c, sa, sb) __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 2, 2, 0, sa, 0, sb)
 
 // four floats -> four fp8 (e4m3) bytes, k order
 __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d) {
@@ -131,7 +171,10 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
 // One thread per 16-byte chunk: 1024 chunks per (ct, g).
 // PERM (unpool_outproj_h8.hip: the stationary operand comes out of an attention accumulator): the k order inside a 32-k
 // sub-tile is 16 c + 8 (e >> 2) + 4 h + (e & 3) for element e of the fragment (c, lane half h) instead of 16 h + 8 c + e.
-template <int BN, bool PERM = false>
+// F6 (the "h6" stream, BN = 64, not PERM): an L sub-tile row n keeps its 64 bytes, the lane half h's 32-byte slot (its chunks (h, 0), (h, 1))
+// holds 24 bytes of fp6 — element 16 t + j = k 64 g + 32 t + 16 h + j of Wl (sub-tile a) or W (sub-tile b), divided by the block's scale
+// — then the scale's E8M0 byte in the low byte of dword 6: the fragment read of the kernel (two 16-byte chunks) brings operand and scale.
+template <int BN, bool PERM = false, bool F6 = false>
 __device__ __forceinline__ void h8_image_item(const float* __restrict__ W, float* __restrict__ img, int Nout, int K, int ldw, size_t i) {
     constexpr int LB = BN == 64 ? 6 : 7;               // log2(BN); a stage is 2 sub-tiles of [BN][16 floats]
     const int NG = K / 64;
@@ -152,6 +195,35 @@ __device__ __forceinline__ void h8_image_item(const float* __restrict__ W, float
             v[4 + e] = (_Float16)w1[e];
         }
         out = __builtin_bit_cast(u32x4, v);
+    } else if constexpr (F6) {
+        static_assert(!PERM && BN == 64, "h6 stream: 64-column tiles in the plain k order");
+        const int h = q >> 1, t = q & 1;
+        if (t) return;   // the thread of chunk (h, 0) writes the lane half's whole slot
+        const float* src = W + (size_t)nn * ldw + 64 * g + 16 * h;
+        float v[32];
+        float m = 0.f;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(src + 32 * tt + 4 * c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = sub == 0 ? w[e] - (float)(_Float16)w[e] : w[e];
+                    v[16 * tt + 4 * c + e] = x;
+                    m = fmaxf(m, fabsf(x));
+                }
+            }
+        const int sb = h6_scale_byte(m);
+        const float inv = __uint_as_float((unsigned)(254 - sb) << 23);   // 2^(127 - sb): exact
+        f16x32 vh;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) vh[e] = (_Float16)(v[e] * inv);
+        const u32x6 pk = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(vh, 1.0f);
+        float* base = img + ((cg * 2 + kind) * (2 * BN * 16)) + sub * (BN * 16) + n * 16;
+        *reinterpret_cast<u32x4*>(base + ((2 * h) ^ ((n >> 2) & 3)) * 4) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+        *reinterpret_cast<u32x4*>(base + ((2 * h + 1) ^ ((n >> 2) & 3)) * 4) = u32x4{pk[4], pk[5], (unsigned)sb, 0u};
+        return;
     } else {
         const int h = q >> 1, t = q & 1;
         const float* src = W + (size_t)nn * ldw + 64 * g + 32 * t + (PERM ? 4 * h : 16 * h);
@@ -228,7 +300,7 @@ __device__ __forceinline__ void kvq_image_item(const float* __restrict__ W, floa
     *reinterpret_cast<u32x4*>(img + st * H_STAGE + sub * 1024 + n * 16 + pc * 4) = out;
 }
 
-// SplitJob::pad_ = 0: the h8 stream of mlp.0 (64-column tiles); 2: the same in 128-column tiles (gemm_h8_areg.hip); 16: 64-column
+// SplitJob::pad_ = 0: the h8 stream of mlp.0 (64-column tiles), 32: its h6 form (fp6 cross terms with block scales); 2: the same in 128-column tiles (gemm_h8_areg.hip); 16: 64-column
 // tiles in the attention accumulator's k order (unpool_outproj_h8.hip);
 // pad_ = 1 | lo_begin << 8 | lo_end << 20 (64-column tiles): the kv | q stream; | 4: of W^T, from W (K, ldw) (one-term)
 __global__ void h8_image_multi_kernel(SplitJobs jobs) {
@@ -258,6 +330,11 @@ __global__ void h8_image_multi_kernel(SplitJobs jobs) {
         return;
     }
     const size_t total = (size_t)(j.Nout / H_BN) * (j.K / 64) * 1024;
+    if (j.pad_ & 32) {   // the "h6" stream: fp6 cross-term operands with block scales
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+            h8_image_item<64, false, true>(j.W, j.img, j.Nout, j.K, j.ldw, i);
+        return;
+    }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
         h8_image_item<64>(j.W, j.img, j.Nout, j.K, j.ldw, i);
 }
@@ -273,7 +350,8 @@ __global__ void h8_image_multi_kernel(SplitJobs jobs) {
 // C = act(u), both fp32 — the first linear of an MLP with the pre-activation its backward needs (models/mlp.py:5-39).  A lane holds 4
 // consecutive columns of one row per accumulator quad: plain 16-byte stores.  (The backward products keep split-bf16: unscaled
 // gradients do not fit the fp16 / fp8 operands.)
-template <int NG, int NW, int NS, int ACT, bool IMG2, int OUT = 0>
+// F6: the "h6" arithmetic — the two cross terms as fp6 x fp6 with per-lane block scales (above); the W stream is the h6 form of the image.
+template <int NG, int NW, int NS, int ACT, bool IMG2, int OUT = 0, bool F6 = false>
 __global__ __launch_bounds__(64 * NW, 2) void gemm_h8_astat_kernel(GemmArgs g) {
     constexpr int NKT = 2 * NG, K = 64 * NG, NT = 64 * NW, ROWS = 32 * NW, PW = 8 / NW;
     constexpr int STORES = OUT == 1 ? 8 : OUT == 2 ? 16 : (IMG2 ? 6 : H_STORES);
@@ -346,6 +424,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_h8_astat_kernel(GemmArgs g) {
         char* sw = reinterpret_cast<char*>(stg + wave * H_STG);
         const int lrow = lane >> 4, c16 = lane & 15;
         f32x4 xs[2][8];
+        f16x4 lo16[F6 ? 8 : 1];
 #pragma unroll
         for (int i = 0; i < 8; ++i) xs[0][i] = *reinterpret_cast<const f32x4*>(xw + (size_t)(4 * i + lrow) * g.lda + 4 * c16);
         static_for(std::make_integer_sequence<int, NG>{}, [&](auto S) {
@@ -367,11 +446,16 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_h8_astat_kernel(GemmArgs g) {
                     float y = h8_clamp(__builtin_fmaf(xs[s & 1][i][e], pa4[e], po4[e]));
                     asm volatile("" : "+v"(y));   // one rounded fp32 value for the hi rounding and the lo difference (see the epilogue)
                     hv[e] = (_Float16)y;
-                    lo[e] = clamp448((y - (float)hv[e]) * YL_SCALE);
+                    lo[e] = F6 ? (y - (float)hv[e]) * YL_SCALE : clamp448((y - (float)hv[e]) * YL_SCALE);
                 }
                 *reinterpret_cast<u32x2*>(sw + row * 128 + (((c16 >> 1) ^ (row & 7)) << 4) + (c16 & 1) * 8) = __builtin_bit_cast(u32x2, hv);
-                *reinterpret_cast<unsigned*>(sw + 4096 + row * 64 + (((c16 >> 2) ^ ((row >> 1) & 3)) << 4) + (c16 & 3) * 4) =
-                    pack_fp8x4(lo[0], lo[1], lo[2], lo[3]);
+                if constexpr (F6) {   // 2^11 (y - yh) as fp16 (exact to 2^-11 of itself), through the same tile once the hi fragments are out
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) lo16[i][e] = (_Float16)lo[e];
+                } else {
+                    *reinterpret_cast<unsigned*>(sw + 4096 + row * 64 + (((c16 >> 2) ^ ((row >> 1) & 3)) << 4) + (c16 & 3) * 4) =
+                        pack_fp8x4(lo[0], lo[1], lo[2], lo[3]);
+                }
             }
             __builtin_amdgcn_wave_barrier();   // a wave's LDS operations execute in order: its reads below see these writes
 #pragma unroll
@@ -381,12 +465,39 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_h8_astat_kernel(GemmArgs g) {
                     const int cq = 4 * t + 2 * h + c;
                     fa[2 * s + t][c] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(sw + r * 128 + ((cq ^ (r & 7)) << 4)));
                 }
-                const int nc = 2 * t + h;
-                const u32x4 v = *reinterpret_cast<const u32x4*>(sw + 4096 + r * 64 + ((nc ^ ((r >> 1) & 3)) << 4));
+                if constexpr (!F6) {
+                    const int nc = 2 * t + h;
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(sw + 4096 + r * 64 + ((nc ^ ((r >> 1) & 3)) << 4));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) alo[s][4 * t + e] = (int)v[e];
+                    for (int e = 0; e < 4; ++e) alo[s][4 * t + e] = (int)v[e];
+                }
             }
             __builtin_amdgcn_wave_barrier();
+            if constexpr (F6) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int row = 4 * i + lrow;
+                    *reinterpret_cast<u32x2*>(sw + row * 128 + (((c16 >> 1) ^ (row & 7)) << 4) + (c16 & 1) * 8) = __builtin_bit_cast(u32x2, lo16[i]);
+                }
+                __builtin_amdgcn_wave_barrier();
+                f16x8 la[2][2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const int cq = 4 * t + 2 * h + c;
+                        la[t][c] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(sw + r * 128 + ((cq ^ (r & 7)) << 4)));
+                    }
+                __builtin_amdgcn_wave_barrier();
+                // the lane's 32 values of this group: element 16 t + 8 c + e = k 64 s + 32 t + 16 h + 8 c + e (the W stream's order)
+                const int bl = h6_scale_byte(h6_absmax32(la[0][0], la[0][1], la[1][0], la[1][1]));
+                const int bh = h6_scale_byte(h6_absmax32(fa[2 * s][0], fa[2 * s][1], fa[2 * s + 1][0], fa[2 * s + 1][1]));
+                const u32x6 pk = h6_pack32(la[0][0], la[0][1], la[1][0], la[1][1], h6_scale_of(bl));
+#pragma unroll
+                for (int e = 0; e < 6; ++e) alo[s][e] = (int)pk[e];
+                alo[s][6] = bl > H8_AL_EXP ? bl - H8_AL_EXP : 0;   // the MFMA's scale byte of the lo term: the block scale x 2^-11
+                alo[s][7] = bh;                                    // the hi term's block scale (its fp6 form is made per column tile)
+            }
         });
     }
 
@@ -595,9 +706,11 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_h8_astat_kernel(GemmArgs g) {
     load_f(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, fbA);
     float one = H8_AH_DIV;   // the fp8 conversions' scale operand (fp8(yh / 8), h8_scales.h) behind an opaque asm: keeps them inside the column-tile loop
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int opq = 0;
     for (int ct = 0; ct < tilesN; ++ct) {
         const bool first = ct == 0;
         asm volatile("" : "+s"(one));
+        asm volatile("" : "+s"(opq));
 #ifdef H8_PRIO
         __builtin_amdgcn_s_setprio(1);
 #endif
@@ -629,6 +742,14 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_h8_astat_kernel(GemmArgs g) {
                         // the first product of a column tile starts from zero: no accumulator clearing pass
                         acc[j] = H8_MFMA16(__builtin_bit_cast(f16x8, wc), fa[2 * gq][c], (kt == 0 && c == 0) ? zero16 : acc[j]);
                     }
+            } else if constexpr (F6) {
+                // yh Wl: fp6(yh / block scale) of the group's 32 values in the image's order, one conversion instruction; the scale's
+                // exponent goes through `opq` (an opaque zero) so that the conversions of all groups are not hoisted out of the tile loop
+                const int bh = alo[gq][7] + opq;
+                const u32x6 pk = h6_pack32(fa[2 * gq][0], fa[2 * gq][1], fa[2 * gq + 1][0], fa[2 * gq + 1][1], h6_scale_of(bh));
+                const i32x8 a6 = {(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3], (int)pk[4], (int)pk[5], 0, 0};
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[j] = H6_MFMA(fbA[j], a6, acc[j], fbA[j][6], bh);
             } else {
                 // yh Wl: fp8(yh) of the group's two k-steps, bytes in the image's k order (16 t + 8 c + e)
                 i32x8 a8;
@@ -658,6 +779,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_h8_astat_kernel(GemmArgs g) {
                         const i32x4 wc = c == 0 ? __builtin_shufflevector(fbB[j], fbB[j], 0, 1, 2, 3) : __builtin_shufflevector(fbB[j], fbB[j], 4, 5, 6, 7);
                         acc[j] = H8_MFMA16(__builtin_bit_cast(f16x8, wc), fa[2 * gq + 1][c], acc[j]);
                     }
+            } else if constexpr (F6) {
+                // yl W
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[j] = H6_MFMA(fbB[j], alo[gq], acc[j], fbB[j][6], alo[gq][6]);
             } else {
                 // yl W
 #pragma unroll
@@ -1077,6 +1202,20 @@ int h8_launch_i(const GemmArgs& g, hipStream_t st) {
     if (lds > attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h8_astat_kernel<NG, NW, NS, ACT, IMG2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = lds;
+    }
+    if constexpr (IMG2 && NW == 4) {
+        if (g.h6) {   // the "h6" arithmetic (w_img is the h6 stream)
+            static size_t attr6 = 0;
+            if (lds > attr6) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h8_astat_kernel<NG, NW, NS, ACT, IMG2, 0, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr6 = lds;
+            }
+            hipLaunchKernelGGL((gemm_h8_astat_kernel<NG, NW, NS, ACT, IMG2, 0, true>), dim3(g.B * (g.rows / (32 * NW))), dim3(64 * NW), lds, st, g);
+            return (int)hipGetLastError();
+        }
+    } else if (g.h6) {
+        return -9;
     }
     hipLaunchKernelGGL((gemm_h8_astat_kernel<NG, NW, NS, ACT, IMG2>), dim3(g.B * (g.rows / (32 * NW))), dim3(64 * NW), lds, st, g);
     return (int)hipGetLastError();

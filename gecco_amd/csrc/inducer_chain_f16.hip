@@ -615,10 +615,11 @@ __global__ __launch_bounds__(CH_NT, 1) void inducer_chain_f16_kernel(ChainArgs g
     // all CL blocks of the sample have published k; the barrier stands between the poll and every load of the bytes
     auto await = [&](int k) {
         if (tid == 0) {
-            unsigned polls = 0;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
             while (__hip_atomic_load(flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)CL) {
                 __builtin_amdgcn_s_sleep(4);
-                if (++polls > (1u << 21)) __builtin_trap();   // seconds: counters not zeroed or a lost block — fail the launch, never hang
+                // 20 s (a partner that is merely preempted comes back): counters not zeroed or a lost block — fail the launch, never hang
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000000ull) __builtin_trap();
             }
         }
         __syncthreads();

@@ -60,6 +60,7 @@ struct GemmArgs {
     // dot_x (B, rows, ldc) the tensor the AdaGN normalised.  Not with residual / mul_u / pre_out.
     const float* dot_x;
     int h8_rev;                // gemm_h8_astat.hip: blocks walk the row panels last to first (the producer wrote them first to last)
+    int h6;                    // gemm_h8_astat.hip (c_img == 2): the cross terms in fp6 with block scales; w_img is the h6 stream (SplitJob::pad_ 32)
     int h8_stagger, h8_pair;   // gemm_h8_astat.hip: start offset of every second block of a CU (set by its launcher)
 };
 

@@ -293,7 +293,11 @@ def test_mlp_fused_h8_matches_the_two_launch_form(ops, B, rows, act):
     alpha = _t(np.array(0.9))
     kw = dict(act_alpha=alpha.cuda()) if act == "gauss" else dict(act="relu") if act == "relu" else {}
     xc, pro = x.cuda(), (pa.cuda(), po.cuda())
-    img = ops.linear_h8_img(xc, pro, W0.cuda(), b0.cuda(), kind=2, **kw)
+    ops.set_option("h6", 0)   # the fused kernel's mlp.0 has the fp8 cross terms: compare with the two-launch form in the same arithmetic
+    try:
+        img = ops.linear_h8_img(xc, pro, W0.cuda(), b0.cuda(), kind=2, **kw)
+    finally:
+        ops.set_option("h6", -1)
     ref, st_ref = ops.linear_h8_areg(img, W2.cuda(), b2.cuda(), residual=xc, want_stats=True)
     got, st = ops.mlp_fused_h8(xc.clone(), pro, W0.cuda(), b0.cuda(), W2.cuda(), b2.cuda(), want_stats=True, **kw)
     torch.cuda.synchronize()
@@ -479,6 +483,37 @@ def test_h8_products_on_outlier_weights_and_activations(ops, wmax, ymax, bar):
     e2 = cpu_ref.rel_err(out, F.linear(u.double(), W2.double()))   # mlp.2's product alone, on the image's own values
     print(f"h8 outliers |w| <= {wmax}, |y| <= {ymax}: mlp.0 {e0[0]:.2e}, mlp.2 {e2[0]:.2e} (bar {bar})")
     assert e0[0] < bar and e2[0] < bar, (e0, e2)
+
+
+@pytest.mark.parametrize("K,Nout", [(384, 768), (256, 512), (128, 256)])
+def test_h6_cross_terms_hold_the_h8_accuracy(ops, K, Nout):
+    """Option "h6" (default on): mlp.0's two cross terms as fp6 (e2m3) x fp6 with one E8M0 scale per lane and 64-k group — the scale
+    blocks of v_mfma_scale_f32_32x32x64_f8f6f4 — instead of fp8 with fixed power-of-two scales (gemm_h8_astat_kernel<.., F6>; half the
+    matrix cycles for those terms).  Against float64 on plain and on outlier operands it holds the fp8 form's accuracy (the cross terms
+    are 2^-12 of the product: 3 mantissa bits inside a block whose scale follows its own maximum suffice), it really is another
+    arithmetic (bits differ from "h6" = 0), and the image-ready call gives the per-call bits."""
+    B, rows = 2, 384
+    rs = _rs(K + Nout)
+    x, W, b = _t(rs.randn(B, rows, K) * np.exp(rs.uniform(-3, 3, size=(B, rows, 1))).astype(np.float32)), _t(rs.randn(Nout, K) / math.sqrt(K)), \
+        _t(rs.randn(Nout) / math.sqrt(K))
+    pa, po = _t(1 + 0.3 * rs.randn(B, K)), _t(0.3 * rs.randn(B, K))
+    ref = F.linear(x.double() * pa[:, None].double() + po[:, None].double(), W.double(), b.double())
+    out, err = {}, {}
+    try:
+        for on in (0, 1):
+            ops.set_option("h6", on)
+            img = ops.linear_h8_img(x.cuda(), (pa.cuda(), po.cuda()), W.cuda(), b.cuda(), kind=2)
+            out[on] = ops.decode_h8_image(img).cpu()
+            err[on] = cpu_ref.rel_err(out[on].double(), ref)
+        ws = torch.empty(Nout * K * 4, dtype=torch.uint8, device="cuda")
+        a = ops.linear_h8_img(x.cuda(), (pa.cuda(), po.cuda()), W.cuda(), b.cuda(), kind=2, wsplit=ws)
+        c = ops.linear_h8_img(x.cuda(), (pa.cuda(), po.cuda()), W.cuda(), b.cuda(), kind=2, wsplit=ws, image_ready=True)
+        assert torch.equal(a, c) and torch.equal(a, img)
+    finally:
+        ops.set_option("h6", -1)
+    print(f"K={K}: h8 {err[0][0]:.2e} / {err[0][1]:.2e}, h6 {err[1][0]:.2e} / {err[1][1]:.2e} (max-rel / rel-L2)")
+    assert err[1][0] < 3e-5 and err[1][1] < 1.3 * err[0][1] + 2e-6, err
+    assert not torch.equal(out[0], out[1])
 
 
 @pytest.mark.parametrize("B,rows,K,hd", [(2, 256, 384, 48), (1, 128, 128, 16), (2, 384, 256, 32), (1, 256, 512, 64), (2, 256, 384, 0)])

@@ -189,11 +189,11 @@ int linear_pair(const float* A, const float* W1, const float* b1, int Nout1, flo
 }
 
 // Path switches for A/B runs and tests: gecco_set_option, or the environment (GECCO_ASTAT, GECCO_CHAIN) on first use.
-enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_HEADMAJOR = 2, OPT_MLPFUSED = 3, OPT_UNPOOLFUSED = 4, OPT_LO8 = 5, OPT_ACTIMG = 6, OPT_H8 = 7, OPT_KVQ64 = 8, OPT_H8AREG = 9, OPT_CHAIN2 = 10, OPT_UNPOOLH8 = 11, OPT_MLPH8 = 12, OPT_CHAINCL = 13, OPT_H6 = 14, OPT_COUNT = 15 };
-int g_options[OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
-const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor", "mlpfused", "unpoolfused", "lo8", "actimg", "h8", "kvq64", "h8areg", "chain2", "unpoolh8", "mlph8", "chaincl", "h6"};
+enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_HEADMAJOR = 2, OPT_MLPFUSED = 3, OPT_UNPOOLFUSED = 4, OPT_LO8 = 5, OPT_ACTIMG = 6, OPT_H8 = 7, OPT_KVQ64 = 8, OPT_H8AREG = 9, OPT_CHAIN2 = 10, OPT_UNPOOLH8 = 11, OPT_MLPH8 = 12, OPT_CHAINCL = 13, OPT_H6 = 14, OPT_KVFOLD = 15, OPT_COUNT = 16 };
+int g_options[OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor", "mlpfused", "unpoolfused", "lo8", "actimg", "h8", "kvq64", "h8areg", "chain2", "unpoolh8", "mlph8", "chaincl", "h6", "kvfold"};
 const char* const g_option_env[OPT_COUNT] = {"GECCO_ASTAT", "GECCO_CHAIN", "GECCO_HEADMAJOR", "GECCO_MLPFUSED", "GECCO_UNPOOLFUSED", "GECCO_LO8",
-                                             "GECCO_ACTIMG", "GECCO_H8", "GECCO_KVQ64", "GECCO_H8AREG", "GECCO_CHAIN2", "GECCO_UNPOOLH8", "GECCO_MLPH8", "GECCO_CHAINCL", "GECCO_H6"};
+                                             "GECCO_ACTIMG", "GECCO_H8", "GECCO_KVQ64", "GECCO_H8AREG", "GECCO_CHAIN2", "GECCO_UNPOOLH8", "GECCO_MLPH8", "GECCO_CHAINCL", "GECCO_H6", "GECCO_KVFOLD"};
 int option(int which) {
     if (g_options[which] < 0) {
         const char* e = getenv(g_option_env[which]);
@@ -468,13 +468,20 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
     // 64 * C floats per sample) and are zeroed here, once per forward
     const bool chain_cl = (chain_on || chain2_on) && imgs && cl_ok;
     if (chain_cl) TRY((int)hipMemsetAsync(w.merged, 0, (size_t)st->n_layers * B * 8 * sizeof(unsigned), s), "inducer chain counters");
+    // option "kvfold": the chain's last epilogue writes the fused unpool kernel's k | v image itself.  Only when EVERY layer runs the chain
+    // (no cached inducer states: their layers bring the fp16 cast of x into the same buffer) — the image's pad positions are zeroed here,
+    // once per forward, and nothing else touches the buffer in between
+    bool kvfold = uo8_on && (chain_on || chain2_on) && imgs && option(OPT_KVFOLD);
+    for (int li = 0; kvfold && li < st->n_layers; ++li)
+        if (h_in && h_in[li]) kvfold = false;
+    if (kvfold) TRY((int)hipMemsetAsync(w.attn, 0, unpool_outproj_h8_kv_bytes(B, C, H), s), "k | v image pads");
     for (int li = 0; li < st->n_layers; ++li) {
         const GeccoLayer& L = st->layers[li];
         const float* im = imgs ? w.wimg + (size_t)li * w.wimg_layer : nullptr;
         // y = AdaGN(x) is never materialised: (a1, o1) ride in the prologue of the two GEMMs that read x
         TRY(coeffs(sx, sT, N, t, ctx, &L.broadcast_norm, w.a1, w.o1, B, C, G, s), "adagn_coeffs(broadcast_norm)");
         const float* h = h_in ? h_in[li] : nullptr;
-        bool q_done = false, kvh_done = false;
+        bool q_done = false, kvh_done = false, kv_img_done = false;
         int hm = 0;   // K | V and q of this layer are head-major
         if (!h) {
             // pool: KV projection, 64 inducer queries over the N points, out_proj
@@ -530,6 +537,11 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
                     ca.x1 = w.h0; ca.x3 = w.h2; ca.xu = reinterpret_cast<unsigned*>(w.u);
                     ca.flags = reinterpret_cast<unsigned*>(w.merged) + (size_t)li * B * 8;
                 }
+                if (kvfold) {   // k | v leave the chain as the fused unpool kernel's fp16 image (pads zeroed above): no fp32 kvh, no reformat pass
+                    ca.kv_img = reinterpret_cast<unsigned short*>(w.attn);
+                    ca.kv_img_bytes = (int)(unpool_outproj_h8_kv_bytes(1, C, H) / H);
+                    kv_img_done = true;
+                }
                 if ((act == 1 || act == 2) && !L.bmlp.alpha) return fail(-6, "inducer chain: GaussianActivation needs alpha");
                 TRY(inducer_chain_f16_launch(ca, C, Wd, s), "inducer chain");
                 h = hdst;
@@ -580,7 +592,7 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         const bool a16 = io16 && !mixed;   // fp16-stored operands of the generic linears (fp16 mode only)
         if (uo8_on) {
             if (!hm || !im) return fail(-3, "set_transformer: unpool + out_proj (h8) needs the head-major fp16 q");
-            TRY(kvh_image_launch(w.kvh, w.attn, B, C, H, s), "unpool k | v image");
+            if (!kv_img_done) TRY(kvh_image_launch(w.kvh, w.attn, B, C, H, s), "unpool k | v image");
             UnpoolH8Args ua{};
             ua.x = x; ua.q16 = w.q; ua.kv_img = w.attn; ua.w_img = im + w.o_out; ua.bias = L.unpool_out_b; ua.stats = w.stats_x;
             ua.B = B; ua.rows = N; ua.H = H;
@@ -702,7 +714,7 @@ int gecco_set_option(const char* name, int value) {
             g_options[i] = value < 0 ? -1 : (value != 0);   // < 0: back to the environment / default
             return 0;
         }
-    return fail(-2, "set_option: unknown option '%s' (astat, chain, headmajor, mlpfused, unpoolfused, lo8, actimg, h8, kvq64, h8areg, chain2, unpoolh8, mlph8, chaincl, h6)", name);
+    return fail(-2, "set_option: unknown option '%s' (astat, chain, headmajor, mlpfused, unpoolfused, lo8, actimg, h8, kvq64, h8areg, chain2, unpoolh8, mlph8, chaincl, h6, kvfold)", name);
 }
 
 int gecco_linear_row_tiles(int rows) { return row_tiles_gemm(rows); }

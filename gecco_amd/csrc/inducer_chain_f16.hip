@@ -478,6 +478,32 @@ __global__ __launch_bounds__(CH_NT, 1) void inducer_chain_f16_kernel(ChainArgs g
         return reinterpret_cast<unsigned*>(abuf + row * RS + 2 * col);
     };
 
+    // k | v of column tile t (columns 128 t + 32 wn + r of the 2C-wide product, + bias) as the unpool kernel's fp16 image (kernels.h): a lane
+    // holds ONE column and 16 keys (rows).  K part (t < NT1): K[key][d], two bytes per key; V part: V^T[d][pos(key)] — the lane's keys
+    // 8 q + 4 h + i sit at pos 32 wm + 16 (q >> 1) + 8 h + 4 (q & 1) + i: two runs of 8 halves, two 16-byte stores.  Same roundings as
+    // kvh_image_kernel (fp32 sum, one rounding to fp16).
+    auto store_kv_img = [&](int t, const f32x16& a0, float bias) {
+        const int HD = C / g.H, KS = HD + 8;
+        const int n = t * 128 + wn * 32 + r;
+        const int c = n < C ? n : n - C;
+        const int hh = (int)(((unsigned)c * ((1u << 20) / (unsigned)HD + 1u)) >> 20), d = c - hh * HD;
+        unsigned short* base = g.kv_img + ((size_t)b * g.H + hh) * (size_t)(g.kv_img_bytes / 2);
+        if (n < C) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                base[(wm * 32 + mfma_row(e, h)) * KS + d] = __builtin_bit_cast(unsigned short, (_Float16)(a0[e] + bias));
+        } else {
+            unsigned short* vrow = base + 64 * KS + d * 72 + wm * 32 + 8 * h;
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                f16x8 v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (_Float16)(a0[8 * qq + e] + bias);
+                *reinterpret_cast<u32x4*>(vrow + 16 * qq) = __builtin_bit_cast(u32x4, v);
+            }
+        }
+    };
+
     const bool has_act = g.act != 0;
     const int act_mode = g.act;
     const float neg_inv_2a2 = act_is_gauss(g.act) ? -1.0f / (2.0f * g.alpha[0] * g.alpha[0]) : 0.f;
@@ -578,8 +604,12 @@ __global__ __launch_bounds__(CH_NT, 1) void inducer_chain_f16_kernel(ChainArgs g
             run_tile(a0, t == 0, t + 1 < NT2);
             const int n = t * 128 + wn * 32 + r;
             const float bias = lbk[n];
+            if (g.kv_img) {
+                store_kv_img(t, a0, bias);
+            } else {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) kb[(size_t)(wm * 32 + mfma_row(e, h)) * 2 * C + n] = a0[e] + bias;
+                for (int e = 0; e < 16; ++e) kb[(size_t)(wm * 32 + mfma_row(e, h)) * 2 * C + n] = a0[e] + bias;
+            }
         }
     }
     } else {
@@ -766,8 +796,12 @@ __global__ __launch_bounds__(CH_NT, 1) void inducer_chain_f16_kernel(ChainArgs g
             run_tile(a0, j == 0, j + 1 < 2);
             const int n = (j * NT1 + cb) * 128 + wn * 32 + r;
             const float bias = lbk[n];
+            if (g.kv_img) {
+                store_kv_img(j * NT1 + cb, a0, bias);
+            } else {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) kb[(size_t)(wm * 32 + mfma_row(e, h)) * 2 * C + n] = a0[e] + bias;
+                for (int e = 0; e < 16; ++e) kb[(size_t)(wm * 32 + mfma_row(e, h)) * 2 * C + n] = a0[e] + bias;
+            }
         }
     }
     }

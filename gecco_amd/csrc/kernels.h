@@ -106,6 +106,11 @@ struct ChainArgs {
     float *x1, *x3;
     unsigned* xu;
     unsigned* flags;
+    // mixed mode with the fused unpool + out_proj kernel: the last product's epilogue writes k | v straight as that kernel's fp16 image
+    // (unpool_outproj_h8.hip: per (sample, head) K [64][hd + 8] | V^T [ceil(hd / 32) 32][72], key-permuted; `kv_img_bytes` per head, the pad
+    // positions zeroed by the host) instead of fp32 kvh for kvh_image_kernel to reformat
+    unsigned short* kv_img;
+    int kv_img_bytes;
 };
 bool inducer_chain_f16_supported(int C, int Wd, int H, int G, int I);
 int inducer_chain_f16_launch(const ChainArgs& g, int C, int Wd, hipStream_t st);

@@ -564,3 +564,31 @@ def test_inducer_chain_cluster_matches_one_block_chain_bitwise(ops, precision, d
     for li, (a, b) in enumerate(zip(out[1][1], out[0][1])):
         assert torch.equal(a, b), (li, float((a - b).abs().max()))
     assert torch.equal(out[1][0], out[0][0])
+
+
+@pytest.mark.parametrize("d,N", [(384, 2048), (256, 640), (128, 1024)])
+def test_chain_writes_the_unpool_kv_image_itself_bitwise(ops, d, N):
+    """Mixed mode, option "kvfold" (default on): the inducer chain's last epilogue writes k | v of the 64 inducer states straight as the fp16
+    image the fused unpool + out_proj kernel streams (per (sample, head) K rows padded, V transposed and key-permuted:
+    unpool_outproj_h8.hip) instead of fp32 kvh for a reformatting pass — same sums, one rounding to fp16 either way: bit-identical network
+    output; the cluster form (d = 256, 384) and the one-block form (d = 128); a cached evaluation (which does not run the chain) beside it."""
+    from oracle import weights as OW
+    L, B = 3, 7
+    p = _cuda(OW.linear_lift_state_dict(31, d, L, cases.I, 8))
+    rs = np.random.RandomState(d + N)
+    x = torch.from_numpy(rs.randn(B, N, 3).astype(np.float32)).cuda()
+    sigma = torch.from_numpy(np.exp(rs.uniform(-4, 4, size=B)).astype(np.float32)).cuda()
+    net = ops.LinearLiftPlan(p, 8, cases.I, precision="mixed")
+    out = {}
+    try:
+        for on in (0, 1):
+            ops.set_option("kvfold", on)
+            den, hs = net.forward(x, sigma, do_cache=True)
+            again = net.forward(x, sigma, cache=hs)
+            out[on] = (den.clone(), [c.clone() for c in hs], again.clone())
+    finally:
+        ops.set_option("kvfold", -1)
+    assert torch.isfinite(out[1][0]).all()
+    assert torch.equal(out[1][0], out[0][0]) and torch.equal(out[1][2], out[0][2])
+    for a, b in zip(out[1][1], out[0][1]):
+        assert torch.equal(a, b)

@@ -104,8 +104,17 @@ int gecco_linear_f32(const float* A, const float* W, const float* bias, const fl
  *   "unpoolh8" (default 1): mixed mode runs unpool attention + out_proj (h8) + residual + statistics as one launch
  *   (gecco_unpool_outproj_h8) instead of the attention writing an h8 activation image for gecco_linear_h8_areg_f32; needs
  *   "kvq64" (head-major fp16 q), "h8areg", feature_dim in {128, 256, 384}.
- *   "mlph8" (default 1): mixed mode runs the point MLP of a layer (AdaGN apply, mlp.0, activation, mlp.2, residual, statistics) as
- *   one launch (gecco_mlp_fused_h8) instead of gecco_linear_h8_img_f32 + gecco_linear_h8_areg_f32; feature_dim 384.
+ *   "mlph8" (default 0: exact, measured slower than its two launches): mixed mode runs the point MLP of a layer (AdaGN apply, mlp.0,
+ *   activation, mlp.2, residual, statistics) as one launch (gecco_mlp_fused_h8) instead of gecco_linear_h8_img_f32 +
+ *   gecco_linear_h8_areg_f32; feature_dim 384.
+ *   "h6" (default 1): mixed mode computes mlp.0's two cross terms as fp6 (e2m3) x fp6 with one E8M0 scale per lane and 64-k group (the
+ *   scale blocks of v_mfma_scale_f32_32x32x64_f8f6f4) instead of fp8 with fixed scales: half their matrix cycles, the same accuracy;
+ *   gecco_linear_h8_img_f32 with image_kind 2 follows it too.
+ *   "chaincl" (default 1): the one-launch inducer chain ("chain" / "chain2") runs as a cluster of feature_dim / 128 blocks per sample that
+ *   hand each other their column tiles through L2 (bit-identical to one block per sample; feature_dim >= 256); with it the mixed mode
+ *   runs the one-launch chain at feature_dim 512 too.
+ *   "kvfold" (default 1): mixed mode with "unpoolh8": the chain's last epilogue writes the fp16 k | v image gecco_unpool_outproj_h8
+ *   streams instead of fp32 k | v for a reformatting launch (same bits).
  *   "chain2" (default 1): mixed mode runs the 64-inducer chain of a layer (pool merge .. unpool k|v) as the ONE launch of the fp16
  *   mode with two-term fp16 weights (hi | lo blocks per column tile) instead of five 64-row split-bf16 GEMMs + their AdaGN
  *   coefficient launches: 16 -> 9 launches per layer; F_x 6e-5 -> ~1e-4 (its activations are rounded to fp16 once).

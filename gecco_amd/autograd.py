@@ -73,9 +73,9 @@ def _lin_precision() -> str:
 
 
 def _no_input_grad(ctx, idx: int, what: str) -> None:
-    """The training path differentiates with respect to PARAMETERS (and the conditioner's pyramid); a caller asking for the
-    gradient of the denoiser with respect to the geometry or the noise level (guidance, score Jacobians) must hear about it
-    instead of receiving a silently missing gradient."""
+    """The training path differentiates with respect to PARAMETERS, the conditioner's pyramid and (unconditional models: LiftFn) the
+    input cloud; a caller asking for a gradient it does not form — the noise level, the camera matrix, the image, the geometry through
+    the projective lookup — must hear about it instead of receiving a silently missing gradient."""
     if ctx.needs_input_grad[idx]:
         from ._grad import GeccoTrainingNotSupported
         raise GeccoTrainingNotSupported(f"the HIP training path has no gradient with respect to {what} (parameters and feature "
@@ -1146,28 +1146,35 @@ class UnpoolAttnFn(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------- lift / lower
 class LiftFn(torch.autograd.Function):
-    """Linear(3 -> C) on (B, N, 3); the geometry input never needs a gradient."""
+    """Linear(3 -> C) on (B, N, 3) (linear_lift.py:44-46 `lift`, models/ray.py `xyz_embed`).  The gradient with respect to the geometry
+    (dx = dy W: a Linear(C -> 3) with weight W^T, the lowering kernel) is formed only when a caller asks for it — guidance, score
+    Jacobians; the training step never does."""
 
     @staticmethod
     def forward(ctx, x, W, b):
         x = _f(x)
-        ctx.save_for_backward(x)
+        ctx.save_for_backward(x, W)
         ctx.C = W.shape[0]
         return hip_ops.lift(x, None, W, b)
 
     @staticmethod
     def backward(ctx, dy):
-        _no_input_grad(ctx, 0, "the geometry")
-        (x,) = ctx.saved_tensors
+        x, W = ctx.saved_tensors
         dy = _f(dy)
         lib = _lib.load()
         B, N, _ = x.shape
         Cc = ctx.C
+        dx = None
+        if ctx.needs_input_grad[0]:
+            one, zero = torch.ones(B, Cc, device=dy.device), torch.zeros(B, Cc, device=dy.device)
+            dx = hip_ops.lower_edm(dy, None, None, W.t().contiguous(), torch.zeros(3, device=dy.device), gn=(one, zero))
+        if not (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+            return dx, None, None
         T = lib.gecco_stats_row_tiles(N)
         part = _new(B, T, 4, Cc, like=x)
         _lib.check(lib.gecco_lift_bwd_f32(_ptr(dy), _ptr(x), _ptr(part), B, N, Cc, _stream()), "lift_bwd")
         red = _reduce(part, 4 * Cc, B * T, 4 * Cc).reshape(4, Cc)
-        return None, red[:3].t().contiguous(), red[3].contiguous()
+        return dx, red[:3].t().contiguous(), red[3].contiguous()
 
 
 class LowerFn(torch.autograd.Function):

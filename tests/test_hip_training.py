@@ -303,6 +303,35 @@ def test_edm_loss_and_gradients_golden(golden_dir):
     assert all(torch.equal(first[k], q.grad) for k, q in m.named_parameters())
 
 
+def test_gradient_with_respect_to_the_noisy_cloud():
+    """The unconditional denoiser differentiates with respect to its geometry input too (LiftFn's dx = dy W on the lowering kernel;
+    EDMPrecond's c_in / c_skip / c_out around it are torch ops): d loss / d x against autograd through the oracle's restatement of the
+    network — what a guidance or score-Jacobian caller needs (the reference gets it from autograd through nn.Linear,
+    linear_lift.py:44-46).  The noise level's embedding still has no gradient here and says so."""
+    from gecco_amd._grad import GeccoTrainingNotSupported
+    c = cases.LOSS_CASE
+    p, ex, u, noise = cases.loss_inputs()
+    sd = uncond_state_dict(p)
+    sd["reparam.mean"], sd["reparam.sigma"] = torch.zeros(3), torch.ones(3)
+    m_gpu = build_uncond(c["d"], c["L"], sigma_max=c["sigma_max"])
+    m_gpu.load_state_dict(sd)
+    m_gpu = m_gpu.cuda()
+    for q in m_gpu.parameters():
+        q.requires_grad_(False)   # only the input carries a gradient: the weight-gradient kernels are skipped
+    sigma = cpu_ref.log_uniform_sigma(u, c["sigma_max"])
+    x0 = ex + noise * sigma
+    w = torch.from_numpy(np.random.RandomState(3).randn(*ex.shape).astype(np.float32))
+    xc = x0.clone().requires_grad_(True)
+    (cpu_ref.uncond_denoiser(p, "", cases.H)(xc, sigma) * w).sum().backward()
+    xg = x0.clone().cuda().requires_grad_(True)
+    (m_gpu(xg, sigma.cuda(), None) * w.cuda()).sum().backward()
+    assert xg.grad is not None and torch.isfinite(xg.grad).all()
+    _close(xg.grad, xc.grad, 5e-4)
+    sg = sigma.clone().cuda().requires_grad_(True)
+    with pytest.raises(GeccoTrainingNotSupported):
+        (m_gpu(x0.cuda(), sg, None) * w.cuda()).sum().backward()
+
+
 def test_lookup_fn_grads():
     """Projective lookup backward (gradients into the pyramid levels) against torch autograd through the oracle."""
     from gecco_amd.autograd import LookupFn

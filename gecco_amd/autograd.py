@@ -73,9 +73,9 @@ def _lin_precision() -> str:
 
 
 def _no_input_grad(ctx, idx: int, what: str) -> None:
-    """The training path differentiates with respect to PARAMETERS, the conditioner's pyramid and (unconditional models: LiftFn) the
-    input cloud; a caller asking for a gradient it does not form — the noise level, the camera matrix, the image, the geometry through
-    the projective lookup — must hear about it instead of receiving a silently missing gradient."""
+    """The training path differentiates with respect to PARAMETERS, the conditioner's pyramid, the noise level (every AdaGN) and
+    (unconditional models: LiftFn) the input cloud; a caller asking for a gradient it does not form — the camera matrix, the image, the
+    geometry through the projective lookup — must hear about it instead of receiving a silently missing gradient."""
     if ctx.needs_input_grad[idx]:
         from ._grad import GeccoTrainingNotSupported
         raise GeccoTrainingNotSupported(f"the HIP training path has no gradient with respect to {what} (parameters and feature "
@@ -503,27 +503,30 @@ class AdaGNFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.passthrough = passthrough
         a, o, stats, t2 = _adagn_coeffs(x, t, sw, sb, bw, bb, G, eps, stats)
-        ctx.save_for_backward(x, stats, t2, sw, sb)
+        ctx.save_for_backward(x, stats, t2, sw, sb, bw)
         ctx.G, ctx.eps, ctx.affine = G, eps, sw is not None
+        ctx.t_shape = None if t is None else tuple(t.shape)
         y = hip_ops.affine_apply(x, a, o)
         return (y, x) if passthrough else y
 
     @staticmethod
     def backward(ctx, dy, dskip=None):
-        _no_input_grad(ctx, 1, "the noise-level embedding t")
-        x, stats, t2, sw, sb = ctx.saved_tensors
+        x, stats, t2, sw, sb, bw = ctx.saved_tensors
         none = (None,) * 9
         if dy is None:   # only the skip connection carried a gradient
             return (dskip, *none)
-        dx, dsw, dsb, dbw, dbb = _adagn_backward(x, stats, t2, sw, sb, _f(dy), dskip, ctx.G, ctx.eps, ctx.affine)
+        want_dt = ctx.affine and ctx.needs_input_grad[1]
+        dx, dsw, dsb, dbw, dbb, dt = _adagn_backward(x, stats, t2, sw, sb, _f(dy), dskip, ctx.G, ctx.eps, ctx.affine,
+                                                     bw=bw if want_dt else None)
         if not ctx.affine:
             return (dx, *none)
-        return dx, None, dsw, dsb, dbw, dbb, None, None, None, None
+        return dx, (dt.reshape(ctx.t_shape) if dt is not None else None), dsw, dsb, dbw, dbb, None, None, None, None
 
 
-def _adagn_backward(x, stats, t2, sw, sb, dy, dskip, G, eps, affine, gst=None):
+def _adagn_backward(x, stats, t2, sw, sb, dy, dskip, G, eps, affine, gst=None, bw=None):
     """Backward of y = scale(t) GroupNorm(x) + bias(t) given dy (and the gradient `dskip` that reached x through a skip
-    connection, added in the same pass): dx and the gradients of the scale / bias linears.
+    connection, added in the same pass): dx and the gradients of the scale / bias linears, and — with `bw` given: a caller
+    differentiates with respect to the noise level — of the embedding t: dt = ds scale_w + dz bias_w.
     gst: the {sum dy, sum dy x} partials when the GEMM that produced dy already formed them (`_linear_dx_dot`)."""
     lib = _lib.load()
     B, R, Cc = x.shape
@@ -543,12 +546,14 @@ def _adagn_backward(x, stats, t2, sw, sb, dy, dskip, G, eps, affine, gst=None):
                                                None if dskip is None else _ptr(_f(dskip)), _ptr(dx), B, R, Cc, _stream()),
                "affine2_apply_add")
     if not affine:
-        return dx, None, None, None, None
+        return dx, None, None, None, None, None
     dsw, dbw = _new(Cc, ctxd, like=x), _new(Cc, ctxd, like=x)
     dsb, dbb = _new(Cc, like=x), _new(Cc, like=x)
     _lib.check(lib.gecco_adagn_param_grads_f32(_ptr(ds), _ptr(dz), _ptr(t2), B, Cc, ctxd, _ptr(dsw), _ptr(dsb),
                                                _ptr(dbw), _ptr(dbb), _stream()), "adagn_param_grads")
-    return dx, dsw, dsb, dbw, dbb
+    # (B, C) x (C, ctx): a few thousand multiply-adds, formed only for a caller that wants the noise level's gradient
+    dt = (ds @ sw.float() + dz @ bw.float()) if bw is not None else None
+    return dx, dsw, dsb, dbw, dbb, dt
 
 
 def _adagn_coeffs(x, t, sw, sb, bw, bb, G, eps, stats):
@@ -591,8 +596,8 @@ class AdaGNPairFn(torch.autograd.Function):
             _lib.check(_lib.load().gecco_linear_astat16_f32(_ptr(x), _ptr(a), _ptr(o), None if ready else _ptr(_f(W1)), None, N1, _ptr(KV),
                                                             None if ready else _ptr(_f(W2)), _ptr(b2), N2, _ptr(q), None, 0, B, R, K,
                                                             C.c_void_p(ws.data_ptr()), _stream()), "gecco_linear_astat16_f32")
-            ctx.save_for_backward(x, stats, t2, sw, sb, a, o, W1, W2)
-            ctx.G, ctx.eps, ctx.has_b2 = G, eps, b2 is not None
+            ctx.save_for_backward(x, stats, t2, sw, sb, a, o, W1, W2, bw)
+            ctx.G, ctx.eps, ctx.has_b2, ctx.t_shape = G, eps, b2 is not None, tuple(t.shape)
             return KV, q, x
         if _h8_ok(prec, R, K, N1 + N2) and N1 % 64 == 0 and N2 % 64 == 0:
             KV, q = _new(B, R, N1, like=x), _new(B, R, N2, like=x)
@@ -600,22 +605,21 @@ class AdaGNPairFn(torch.autograd.Function):
             _lib.check(_lib.load().gecco_linear_h8_train_f32(_ptr(x), _ptr(a), _ptr(o), None if ready else _ptr(_f(W1)), None, N1, _ptr(KV),
                                                              None if ready else _ptr(_f(W2)), _ptr(b2), N2, _ptr(q), None, 0, None, B, R, K,
                                                              C.c_void_p(ws.data_ptr()), _stream()), "gecco_linear_h8_train_f32")
-            ctx.save_for_backward(x, stats, t2, sw, sb, a, o, W1, W2)
-            ctx.G, ctx.eps, ctx.has_b2 = G, eps, b2 is not None
+            ctx.save_for_backward(x, stats, t2, sw, sb, a, o, W1, W2, bw)
+            ctx.G, ctx.eps, ctx.has_b2, ctx.t_shape = G, eps, b2 is not None, tuple(t.shape)
             return KV, q, x
         img = WEIGHT_IMAGES.lookup("pair", W1, W2, prec=prec)
         if img is not None:
             KV, q = hip_ops.linear_pair(x, W1, None, W2, b2, pro=(a, o), precision=prec, w_image=img)
         else:
             KV, q = hip_ops.linear_pair(x, W1, None, _f(W2), b2, pro=(a, o), precision=prec)
-        ctx.save_for_backward(x, stats, t2, sw, sb, a, o, W1, W2)
-        ctx.G, ctx.eps, ctx.has_b2 = G, eps, b2 is not None
+        ctx.save_for_backward(x, stats, t2, sw, sb, a, o, W1, W2, bw)
+        ctx.G, ctx.eps, ctx.has_b2, ctx.t_shape = G, eps, b2 is not None, tuple(t.shape)
         return KV, q, x
 
     @staticmethod
     def backward(ctx, dKV, dq, dskip):
-        _no_input_grad(ctx, 1, "the noise-level embedding t")
-        x, stats, t2, sw, sb, a, o, W1, W2 = ctx.saved_tensors
+        x, stats, t2, sw, sb, a, o, W1, W2, bw = ctx.saved_tensors
         need = ctx.needs_input_grad
         B, R, Cc = x.shape
         dKV = _f(dKV) if dKV is not None else x.new_zeros(B, R, W1.shape[0])
@@ -630,8 +634,8 @@ class AdaGNPairFn(torch.autograd.Function):
             dW2 = _linear_dw(dq, x, pro=(a, o), leaf=W2, prec=prec)
         elif ctx.has_b2 and need[11]:
             db2 = _linear_db(dq)
-        dx, dsw, dsb, dbw, dbb = _adagn_backward(x, stats, t2, sw, sb, dY, dskip, ctx.G, ctx.eps, True)
-        return dx, None, dsw, dsb, dbw, dbb, None, None, None, dW1, dW2, db2
+        dx, dsw, dsb, dbw, dbb, dt = _adagn_backward(x, stats, t2, sw, sb, dY, dskip, ctx.G, ctx.eps, True, bw=bw if need[1] else None)
+        return dx, (dt.reshape(ctx.t_shape) if dt is not None else None), dsw, dsb, dbw, dbb, None, None, None, dW1, dW2, db2
 
 
 class AdaGNMlpFn(torch.autograd.Function):
@@ -666,8 +670,8 @@ class AdaGNMlpFn(torch.autograd.Function):
                                                          kind, _ptr(u), _ptr(h), B, R, K0, N0, hip_ops.PRECISIONS[prec],
                                                          C.c_void_p(ws.data_ptr()), _stream()),
                        "gecco_linear_act_keep_pro_f32")
-        ctx.save_for_backward(x, stats, t2, sw, sb, a, o, u, h, alpha if alpha is not None else x.new_empty(0), W0, W2)
-        ctx.G, ctx.eps, ctx.kind, ctx.bias = G, eps, kind, (b0 is not None, b2 is not None)
+        ctx.save_for_backward(x, stats, t2, sw, sb, a, o, u, h, alpha if alpha is not None else x.new_empty(0), W0, W2, bw)
+        ctx.G, ctx.eps, ctx.kind, ctx.bias, ctx.t_shape = G, eps, kind, (b0 is not None, b2 is not None), tuple(t.shape)
         out = _linear_fwd_h16(h, W2, b2, x, want_stats) if h16 else _linear_fwd(h, W2, b2, x, want_stats, prec)
         if want_stats:
             ctx.mark_non_differentiable(out[1])
@@ -678,8 +682,7 @@ class AdaGNMlpFn(torch.autograd.Function):
     def backward(ctx, dout, _dstats=None):
         if dout is None:   # (materialize off) only the statistics were used: they carry no gradient
             return (None,) * len(ctx.needs_input_grad)
-        _no_input_grad(ctx, 1, "the noise-level embedding t")
-        x, stats, t2, sw, sb, a, o, u, h, alpha, W0, W2 = ctx.saved_tensors
+        x, stats, t2, sw, sb, a, o, u, h, alpha, W0, W2, bw = ctx.saved_tensors
         need = ctx.needs_input_grad
         dout = _f(dout)
         prec = ctx.prec
@@ -692,8 +695,8 @@ class AdaGNMlpFn(torch.autograd.Function):
         dW2, db2 = wgrads(dout, h, ctx.bias[1], 12, 13, W2)
         dW0, db0 = wgrads(du, x, ctx.bias[0], 9, 10, W0, pro=(a, o))
         dY, gst = _linear_dx_dot(du, W0, x, prec=prec)
-        dx, dsw, dsb, dbw, dbb = _adagn_backward(x, stats, t2, sw, sb, dY, dout, ctx.G, ctx.eps, True, gst=gst)
-        return dx, None, dsw, dsb, dbw, dbb, None, None, None, dW0, db0, dalpha, dW2, db2, None, None
+        dx, dsw, dsb, dbw, dbb, dt = _adagn_backward(x, stats, t2, sw, sb, dY, dout, ctx.G, ctx.eps, True, gst=gst, bw=bw if need[1] else None)
+        return dx, (dt.reshape(ctx.t_shape) if dt is not None else None), dsw, dsb, dbw, dbb, None, None, None, dW0, db0, dalpha, dW2, db2, None, None
 
 
 # ------------------------------------------------------------------------------------------- activation

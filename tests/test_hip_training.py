@@ -307,8 +307,7 @@ def test_gradient_with_respect_to_the_noisy_cloud():
     """The unconditional denoiser differentiates with respect to its geometry input too (LiftFn's dx = dy W on the lowering kernel;
     EDMPrecond's c_in / c_skip / c_out around it are torch ops): d loss / d x against autograd through the oracle's restatement of the
     network — what a guidance or score-Jacobian caller needs (the reference gets it from autograd through nn.Linear,
-    linear_lift.py:44-46).  The noise level's embedding still has no gradient here and says so."""
-    from gecco_amd._grad import GeccoTrainingNotSupported
+    linear_lift.py:44-46) — and with respect to the noise level."""
     c = cases.LOSS_CASE
     p, ex, u, noise = cases.loss_inputs()
     sd = uncond_state_dict(p)
@@ -327,9 +326,14 @@ def test_gradient_with_respect_to_the_noisy_cloud():
     (m_gpu(xg, sigma.cuda(), None) * w.cuda()).sum().backward()
     assert xg.grad is not None and torch.isfinite(xg.grad).all()
     _close(xg.grad, xc.grad, 5e-4)
+    # ... and with respect to the noise level: through c_in / c_skip / c_out (torch) and through the AdaGN layers' embedding
+    # (dt = ds scale_w + dz bias_w per AdaGN, models/normalization.py:36-44)
+    sc = sigma.clone().requires_grad_(True)
+    (cpu_ref.uncond_denoiser(p, "", cases.H)(x0, sc) * w).sum().backward()
     sg = sigma.clone().cuda().requires_grad_(True)
-    with pytest.raises(GeccoTrainingNotSupported):
-        (m_gpu(x0.cuda(), sg, None) * w.cuda()).sum().backward()
+    (m_gpu(x0.cuda(), sg, None) * w.cuda()).sum().backward()
+    assert sg.grad is not None and torch.isfinite(sg.grad).all()
+    _close(sg.grad, sc.grad, 1e-3)
 
 
 def test_lookup_fn_grads():

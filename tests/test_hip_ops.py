@@ -516,6 +516,37 @@ def test_h6_cross_terms_hold_the_h8_accuracy(ops, K, Nout):
     assert not torch.equal(out[0], out[1])
 
 
+def test_h6_block_scales_on_degenerate_blocks(ops):
+    """The fp6 cross terms' block scales on blocks a trained or pruned network may hold: all-zero weight blocks and rows, all-zero
+    activation rows, one element 1e8 times its block's others, magnitudes down at 1e-30 — finite everywhere, the zero blocks exactly
+    neutral (rows of zero weights give the bias, zero activations give the bias), the rest within the h8 bar."""
+    B, rows, K, Nout = 1, 256, 384, 256
+    rs = _rs(77)
+    x = _t(rs.randn(B, rows, K))
+    x[0, 10:20] = 0.0                       # all-zero activation rows
+    x[0, 30, :] = 1e-30                     # tiny magnitudes
+    x[0, 40, 5] = 300.0                     # one dominant element in its block
+    W = _t(rs.randn(Nout, K) / math.sqrt(K))
+    W[7] = 0.0                              # an all-zero weight row
+    W[:, 64:128] = 0.0                      # all-zero 64-k groups in every row
+    W[20, 200] = 50.0
+    W[21, 201:232] *= 1e-8
+    b = _t(rs.randn(Nout) * 0.1)
+    ref = F.linear(x.double(), W.double(), b.double())
+    try:
+        ops.set_option("h6", 1)
+        img = ops.linear_h8_img(x.cuda(), None, W.cuda(), b.cuda(), kind=2)
+    finally:
+        ops.set_option("h6", -1)
+    got = ops.decode_h8_image(img).cpu().double()
+    assert torch.isfinite(got).all()
+    tol = 2e-5 * float(b.abs().max())                                   # the h8 image's own rounding of the stored value (fp16 + fp8 lo)
+    assert float((got[0, 10:20] - b.double()).abs().max()) <= tol      # zero rows: the bias
+    assert float((got[0, :, 7] - b[7].double()).abs().max()) <= tol   # zero weight row
+    e = cpu_ref.rel_err(got, ref)
+    assert e[0] < 3e-5, e
+
+
 @pytest.mark.parametrize("B,rows,K,hd", [(2, 256, 384, 48), (1, 128, 128, 16), (2, 384, 256, 32), (1, 256, 512, 64), (2, 256, 384, 0)])
 def test_linear_kvq_f16(ops, B, rows, K, hd):
     """kv_proj | q_proj of the mixed mode on the 64-column-tile kernel (gemm_kvq_astat_kernel): fp16(y) x fp16(W) everywhere, the V

@@ -555,6 +555,13 @@ def test_inducer_chain_cluster_matches_one_block_chain_bitwise(ops, precision, d
     finally:
         ops.set_option("chaincl", -1)
     assert torch.isfinite(out[1][0]).all()
+    # a single cloud (one cluster on the whole chip) gives the bits it has inside the batch
+    ops.set_option("chaincl", 1)
+    try:
+        one = net.forward(x[:1].contiguous(), sigma[:1].contiguous())
+    finally:
+        ops.set_option("chaincl", -1)
+    assert torch.equal(one[0], out[1][0][0])
     if precision == "mixed" and d == 512:
         # d = 512 runs the one-launch chain ONLY as a cluster (one block per sample loses to the five split-bf16 launches there, api.hip):
         # "chaincl" = 0 is that split-bf16 chain — the two agree like "chain2" on / off do (test_mixed_two_term_chain_...)

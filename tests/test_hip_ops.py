@@ -516,6 +516,35 @@ def test_h6_cross_terms_hold_the_h8_accuracy(ops, K, Nout):
     assert not torch.equal(out[0], out[1])
 
 
+@pytest.mark.parametrize("B,T,Cc,G", [(3, 128, 384, 32), (1, 64, 512, 32), (8, 128, 256, 32), (2, 72, 128, 16)])
+def test_adagn_coeffs_channel_parts_on_few_samples_with_many_tiles(ops, B, T, Cc, G):
+    """AdaGN coefficients from the per-tile partial sums (models/normalization.py:36-44) where few samples carry many row tiles (a cached
+    `upsample` evaluation: 8 clouds x 128 tiles): `adagn_coeffs_launch` cuts the channels into whole-group parts across blocks.  Against
+    float64 from the same partials, and against the one-block-per-sample form (the same samples inside a batch of 64: its grid alone fills
+    the chip) to fp32 rounding of the double sums."""
+    rs = _rs(B + T + Cc)
+    rows = 128 * T
+    part = rs.randn(B, T, 128, Cc) * np.exp(rs.uniform(-1, 1, size=(B, 1, 1, Cc))) + rs.randn(B, 1, 1, Cc)
+    st = _t(np.stack([part.sum(2), (part ** 2).sum(2)], axis=2))                     # (B, T, 2, C): {sum x, sum x^2} per tile
+    t = _t(rs.randn(B, 1))
+    sw, sb, bw, bb = _t(rs.randn(Cc, 1) * 0.3), _t(1 + 0.1 * rs.randn(Cc)), _t(rs.randn(Cc, 1) * 0.3), _t(0.1 * rs.randn(Cc))
+    a, o = ops.adagn_coeffs(st.cuda(), rows, t.cuda(), (sw.cuda(), sb.cuda(), bw.cuda(), bb.cuda()), G)
+    s64 = st.double().sum(1)                                                          # (B, 2, C)
+    cpg = Cc // G
+    g1, g2 = s64[:, 0].reshape(B, G, cpg).sum(2), s64[:, 1].reshape(B, G, cpg).sum(2)
+    n = float(rows * cpg)
+    mean = g1 / n
+    rstd = 1.0 / torch.sqrt((g2 / n - mean * mean).clamp_min(0) + 1e-5)
+    mean_c, rstd_c = mean.repeat_interleave(cpg, 1), rstd.repeat_interleave(cpg, 1)
+    s = t.double() @ sw.double().t() + sb.double()
+    z = t.double() @ bw.double().t() + bb.double()
+    assert cpu_ref.rel_err(a.cpu().double(), s * rstd_c)[0] < 2e-6 and cpu_ref.rel_err(o.cpu().double(), z - s * mean_c * rstd_c)[0] < 2e-6
+    # the same samples as the first of a batch of 64: one block per sample
+    rep = lambda v: torch.cat([v] + [v[:1]] * (64 - B)).cuda()   # noqa: E731
+    a2, o2 = ops.adagn_coeffs(rep(st), rows, rep(t), (sw.cuda(), sb.cuda(), bw.cuda(), bb.cuda()), G)
+    assert cpu_ref.rel_err(a2[:B].cpu(), a.cpu())[0] < 1e-6 and cpu_ref.rel_err(o2[:B].cpu(), o.cpu())[0] < 1e-6
+
+
 def test_h6_block_scales_on_degenerate_blocks(ops):
     """The fp6 cross terms' block scales on blocks a trained or pruned network may hold: all-zero weight blocks and rows, all-zero
     activation rows, one element 1e8 times its block's others, magnitudes down at 1e-30 — finite everywhere, the zero blocks exactly

@@ -393,8 +393,11 @@ int pool_attn_nsplit(int B, int N, int H) {
     (void)B; (void)H;
     static int keys = 0;
     if (!keys) {
-        const char* e = getenv("GECCO_POOL_SPLIT_KEYS");   // keys per split below which a cloud is not split further (A/B runs)
-        keys = e && atoi(e) >= 32 ? atoi(e) : 1024;
+        // keys per split below which a cloud is not split further.  2048 since the inducer chain merges the partials in every block of
+        // its cluster (three times per sample at d = 384): one split at N = 2048 instead of two — C2 4.873 / 4.882 -> 4.842 / 4.844 ms,
+        // the other shapes and the training step unchanged (1024 before: profiles/r04d_negative_results.txt had it neutral then)
+        const char* e = getenv("GECCO_POOL_SPLIT_KEYS");
+        keys = e && atoi(e) >= 32 ? atoi(e) : 2048;
     }
     int ns = 1;
     while (ns < 8 && N / (ns * 2) >= keys) ns *= 2;

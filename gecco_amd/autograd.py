@@ -73,9 +73,9 @@ def _lin_precision() -> str:
 
 
 def _no_input_grad(ctx, idx: int, what: str) -> None:
-    """The training path differentiates with respect to PARAMETERS, the conditioner's pyramid, the noise level (every AdaGN) and
-    (unconditional models: LiftFn) the input cloud; a caller asking for a gradient it does not form — the camera matrix, the image, the
-    geometry through the projective lookup — must hear about it instead of receiving a silently missing gradient."""
+    """The training path differentiates with respect to PARAMETERS, the conditioner's pyramid, the noise level (every AdaGN) and the
+    input cloud (LiftFn, LookupFn); a caller asking for a gradient it does not form — the camera matrix, the image — must hear about it
+    instead of receiving a silently missing gradient."""
     if ctx.needs_input_grad[idx]:
         from ._grad import GeccoTrainingNotSupported
         raise GeccoTrainingNotSupported(f"the HIP training path has no gradient with respect to {what} (parameters and feature "
@@ -1235,8 +1235,8 @@ class Linear3Fn(torch.autograd.Function):
 
 
 class LookupFn(torch.autograd.Function):
-    """RayNetwork.extract_image_features with a gradient into the pyramid levels (reference models/ray.py:64-87;
-    the geometry is the noised data and carries no gradient)."""
+    """RayNetwork.extract_image_features with a gradient into the pyramid levels and — for a caller that asks — into the geometry
+    (reference models/ray.py:64-87; in training the geometry is the noised data and carries none)."""
 
     @staticmethod
     def forward(ctx, geom, K, reparam_spec, *features):
@@ -1248,16 +1248,22 @@ class LookupFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        _no_input_grad(ctx, 0, "the geometry")
         _no_input_grad(ctx, 1, "the camera matrix")
         geom, K, *levels = ctx.saved_tensors
-        if not any(ctx.needs_input_grad[3:]):
+        if not (ctx.needs_input_grad[0] or any(ctx.needs_input_grad[3:])):
             return (None,) * (3 + len(levels))   # a frozen (or foreign, detached) conditioner: nothing to compute
         dout = _f(dout)
         lib = _lib.load()
         B, N, _ = geom.shape
         rp = hip_ops.make_reparam(*ctx.spec)
         pyr = hip_ops.make_pyramid(levels)
+        dgeom = None
+        if ctx.needs_input_grad[0]:   # a caller differentiates with respect to the input cloud (guidance): through taps, projection, reparam
+            dgeom = _new(B, N, 3, like=dout)
+            _lib.check(lib.gecco_ray_lookup_dgeom_f32(_ptr(_f(geom)), _ptr(K), C.byref(rp), C.byref(pyr), _ptr(dout), _ptr(dgeom), B, N,
+                                                      _stream()), "gecco_ray_lookup_dgeom_f32")
+        if not any(ctx.needs_input_grad[3:]):
+            return (dgeom, None, None, *[None] * len(levels))
         nb = lib.gecco_ray_lookup_bwd_sorted_workspace_bytes(C.byref(pyr), B, N) if os.environ.get("GECCO_LOOKUP_BWD", "sorted") == "sorted" else 0
         if nb:   # sort + gather: no atomics, fixed summation order, every texel written
             grads = [torch.empty_like(f) for f in levels]   # (B, H, W, C)
@@ -1271,7 +1277,7 @@ class LookupFn(torch.autograd.Function):
             _lib.check(lib.gecco_ray_lookup_bwd_f32(_ptr(geom), None, _ptr(K), C.byref(rp), C.byref(pyr), _ptr(dout), arr, B, N,
                                                     _stream()), "gecco_ray_lookup_bwd_f32")
         # handed back NCHW-shaped (channels-last strides, no copy)
-        return (None, None, None, *[g.permute(0, 3, 1, 2) for g in grads])
+        return (dgeom, None, None, *[g.permute(0, 3, 1, 2) for g in grads])
 
 
 # ------------------------------------------------------------------------------------------- ConvNeXt conditioner

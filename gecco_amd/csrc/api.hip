@@ -1613,6 +1613,16 @@ int gecco_ray_lookup_bwd_f32(const float* geom, const float* coef, const float* 
     return 0;
 }
 
+int gecco_ray_lookup_dgeom_f32(const float* geom, const float* K, const GeccoReparam* rp, const GeccoPyramid* pyr, const float* dout,
+                               float* dgeom, int B, int N, void* stream) {
+    if (!geom || !K || !dout || !dgeom || !pyr) return fail(-1, "ray_lookup_dgeom: null argument");
+    LookupArgs a;
+    int rc = make_lookup_args(rp, pyr, &a);
+    if (rc) return rc;
+    TRY(ray_lookup_dgeom_launch(geom, K, a, dout, dgeom, B, N, (hipStream_t)stream), "ray_lookup_dgeom");
+    return 0;
+}
+
 size_t gecco_ray_lookup_bwd_sorted_workspace_bytes(const GeccoPyramid* pyr, int B, int N) {
     LookupArgs a;
     if (!pyr || make_lookup_args(nullptr, pyr, &a) || !ray_lookup_bwd_sorted_supported(a, N)) return 0;

@@ -156,6 +156,129 @@ __global__ __launch_bounds__(256) void ray_lookup_kernel(const float* __restrict
     }
 }
 
+// project_uv with its Jacobian: du[k] = d u / d g_k, dv[k] = d v / d g_k (the derivative of exactly the expressions above; floor / the
+// eps guard contribute none, as in autograd through the reference's torch ops)
+__device__ __forceinline__ void project_uv_jac(float g0, float g1, float g2, const float* __restrict__ Kb, int kind,
+                                               const float* __restrict__ mean, const float* __restrict__ std_, float logit_scale,
+                                               float (&du)[3], float (&dv)[3]) {
+    float X = g0, Y = g1, Z = g2;
+    float dX[3] = {1.f, 0.f, 0.f}, dY[3] = {0.f, 1.f, 0.f}, dZ[3] = {0.f, 0.f, 1.f};
+    const float fx = Kb[0], fy = Kb[4], cx = Kb[2], cy = Kb[5];
+    if (kind == 1) {
+        X = g0 * std_[0] + mean[0];
+        Y = g1 * std_[1] + mean[1];
+        Z = g2 * std_[2] + mean[2];
+        dX[0] = std_[0];
+        dY[1] = std_[1];
+        dZ[2] = std_[2];
+    } else if (kind == 2) {
+        const float uu = g0 * std_[0] + mean[0], vv = g1 * std_[1] + mean[1], l = g2 * std_[2] + mean[2];
+        const float tu = tanhf(uu), tv = tanhf(vv);
+        const float su = (tu * logit_scale + 1.0f) / 2.0f, sv = (tv * logit_scale + 1.0f) / 2.0f;
+        const float d = expf(l);
+        const float xx = (su - cx) / fx, yy = (sv - cy) / fy;
+        const float nrm = fmaxf(sqrtf(xx * xx + yy * yy + 1.0f), 1e-12f);
+        const float in = 1.0f / nrm, in3 = in * in * in;
+        X = xx * in * d;
+        Y = yy * in * d;
+        Z = in * d;
+        const float dxx = (1.0f - tu * tu) * logit_scale * 0.5f * std_[0] / fx;   // d xx / d g0
+        const float dyy = (1.0f - tv * tv) * logit_scale * 0.5f * std_[1] / fy;   // d yy / d g1
+        const float dd = d * std_[2];                                              // d d / d g2
+        dX[0] = d * (in - xx * xx * in3) * dxx;  dX[1] = -d * xx * yy * in3 * dyy;      dX[2] = xx * in * dd;
+        dY[0] = -d * xx * yy * in3 * dxx;        dY[1] = d * (in - yy * yy * in3) * dyy; dY[2] = yy * in * dd;
+        dZ[0] = -d * xx * in3 * dxx;             dZ[1] = -d * yy * in3 * dyy;            dZ[2] = in * dd;
+    }
+    const bool live = fabsf(Z) > 1e-8f;
+    const float sc = live ? 1.0f / (Z + 1e-8f) : 1.0f;
+    const float dsc = live ? -sc * sc : 0.0f;   // d sc / d Z
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        du[k] = fx * (sc * dX[k] + dsc * dZ[k] * X);
+        dv[k] = fy * (sc * dY[k] + dsc * dZ[k] * Y);
+    }
+}
+
+// Gradient of the lookup with respect to the GEOMETRY (autograd of F.grid_sample w.r.t. its grid, then of the projection and the
+// reparametrisation: reference models/ray.py:64-87 when a caller differentiates the conditional denoiser with respect to its input
+// cloud): dgeom[b, n, k] = sum_l ( W_l sum_c dout_c d out_c / d ix * du/dg_k + H_l sum_c dout_c d out_c / d iy * dv/dg_k ), with
+// d out / d ix = wy0 (ne - nw) + wy1 (se - sw) and d out / d iy = wx0 (sw - nw) + wx1 (se - ne) over the in-range taps.  One wave per
+// point, lanes over 16-byte channel chunks as in the forward; a wave reduction, three floats out.
+__global__ __launch_bounds__(256) void ray_lookup_dgeom_kernel(const float* __restrict__ geom, const float* __restrict__ K, LookupArgs a,
+                                                               const float* __restrict__ dout, float* __restrict__ dgeom, int N, int T) {
+    const int tile = blockIdx.x % T, b = blockIdx.x / T;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int Ct = a.c_total, C4 = Ct / 4;
+    const float* Kb = K + (size_t)b * 9;
+    constexpr int MAXCH = 4;
+    int lvl[MAXCH], coff[MAXCH];
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) {
+        const int ch = (c * 64 + lane) * 4;
+        int l = 0, base = 0;
+        while (l + 1 < a.n_levels && ch >= base + a.C[l]) {
+            base += a.C[l];
+            ++l;
+        }
+        lvl[c] = l;
+        coff[c] = ch - base;
+    }
+    const int m0 = tile * LOOKUP_ROWS, m1 = min(N, m0 + LOOKUP_ROWS);
+    for (int m = m0 + wave; m < m1; m += 4) {
+        const float* gp = geom + ((size_t)b * N + m) * 3;
+        float u, v;
+        project_uv(gp[0], gp[1], gp[2], Kb, a.reparam_kind, a.rp_mean, a.rp_std, a.logit_scale, u, v);
+        Taps tp[4];
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+            if (l < a.n_levels) tp[l] = bilinear_taps(u, v, a.H[l], a.W[l]);
+        const float* drow = dout + ((size_t)b * N + m) * Ct;
+        float gu = 0.f, gv = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) {
+            const int c4 = c * 64 + lane;
+            if (c4 >= C4) continue;
+            const int l = lvl[c];
+            Taps t = tp[0];
+#pragma unroll
+            for (int q = 1; q < 4; ++q)
+                if (l == q) t = tp[q];
+            const int Hh = a.H[l], Ww = a.W[l], Cl = a.C[l];
+            const float* fb = a.feat[l] + (size_t)b * Hh * Ww * Cl + coff[c];
+            const int x1 = t.x0 + 1, y1 = t.y0 + 1;
+            const float wx0 = (float)x1 - t.ix, wy0 = (float)y1 - t.iy;
+            const float wx1 = t.ix - (float)t.x0, wy1 = t.iy - (float)t.y0;
+            const bool bx0 = t.x0 >= 0 && t.x0 <= Ww - 1, bx1 = x1 >= 0 && x1 <= Ww - 1;
+            const bool by0 = t.y0 >= 0 && t.y0 <= Hh - 1, by1 = y1 >= 0 && y1 <= Hh - 1;
+            const int cx0 = min(max(t.x0, 0), Ww - 1), cx1 = min(max(x1, 0), Ww - 1);
+            const int cy0 = min(max(t.y0, 0), Hh - 1), cy1 = min(max(y1, 0), Hh - 1);
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 nw = (bx0 && by0) ? *reinterpret_cast<const f32x4*>(fb + ((size_t)cy0 * Ww + cx0) * Cl) : z4;
+            const f32x4 ne = (bx1 && by0) ? *reinterpret_cast<const f32x4*>(fb + ((size_t)cy0 * Ww + cx1) * Cl) : z4;
+            const f32x4 sw = (bx0 && by1) ? *reinterpret_cast<const f32x4*>(fb + ((size_t)cy1 * Ww + cx0) * Cl) : z4;
+            const f32x4 se = (bx1 && by1) ? *reinterpret_cast<const f32x4*>(fb + ((size_t)cy1 * Ww + cx1) * Cl) : z4;
+            const f32x4 dy = *reinterpret_cast<const f32x4*>(drow + c4 * 4);
+            const f32x4 dix = (ne - nw) * wy0 + (se - sw) * wy1;
+            const f32x4 diy = (sw - nw) * wx0 + (se - ne) * wx1;
+            const f32x4 pu = dy * dix, pv = dy * diy;
+            gu += (float)Ww * ((pu[0] + pu[1]) + (pu[2] + pu[3]));
+            gv += (float)Hh * ((pv[0] + pv[1]) + (pv[2] + pv[3]));
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            gu += __shfl_xor(gu, o, 64);
+            gv += __shfl_xor(gv, o, 64);
+        }
+        if (lane == 0) {
+            float du[3], dv[3];
+            project_uv_jac(gp[0], gp[1], gp[2], Kb, a.reparam_kind, a.rp_mean, a.rp_std, a.logit_scale, du, dv);
+            float* o = dgeom + ((size_t)b * N + m) * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) o[k] = gu * du[k] + gv * dv[k];
+        }
+    }
+}
+
 // Backward of the lookup with respect to the pyramids (autograd of F.grid_sample w.r.t. its input, reference
 // models/ray.py:82-85 under loss.backward()): dfeat[l][b, y, x, c] += w_tap * dout[b, n, c] over the four taps of every
 // point.  Same projection and tap arithmetic as the forward; float atomics, like torch's own grid_sampler backward
@@ -397,6 +520,16 @@ int ray_lookup_launch(const float* geom, const float* coef, const float* K, cons
     if (tot != a.c_total) return -8;
     const int T = (N + LOOKUP_ROWS - 1) / LOOKUP_ROWS;
     hipLaunchKernelGGL(ray_lookup_kernel, dim3(B * T), dim3(256), 0, st, geom, coef, K, a, out, stats, N, T);
+    return (int)hipGetLastError();
+}
+
+int ray_lookup_dgeom_launch(const float* geom, const float* K, const LookupArgs& a, const float* dout, float* dgeom, int B, int N,
+                            hipStream_t st) {
+    if (a.n_levels < 1 || a.n_levels > 4 || a.c_total > 1024 || a.c_total % 4) return -8;
+    for (int l = 0; l < a.n_levels; ++l)
+        if (a.C[l] % 4) return -8;
+    const int T = (N + LOOKUP_ROWS - 1) / LOOKUP_ROWS;
+    hipLaunchKernelGGL(ray_lookup_dgeom_kernel, dim3(B * T), dim3(256), 0, st, geom, K, a, dout, dgeom, N, T);
     return (int)hipGetLastError();
 }
 

@@ -160,7 +160,7 @@ SIGNATURES = {
     "gecco_ray_lookup_f32": (i, [vp, vp, vp, C.POINTER(GeccoReparam), C.POINTER(GeccoPyramid), vp, vp, i, i, vp]),
     "gecco_lookup_row_tiles": (i, [i]),
     "gecco_ray_lookup_bwd_f32": (i, [vp, vp, vp, C.POINTER(GeccoReparam), C.POINTER(GeccoPyramid), vp, PP, i, i, vp]),
-    "gecco_ray_lookup_dgeom_f32": (i, [vp, vp, C.POINTER(GeccoReparam), C.POINTER(GeccoPyramid), vp, vp, i, i, vp]),
+    "gecco_ray_lookup_dgeom_f32": (i, [vp, vp, C.POINTER(GeccoReparam), C.POINTER(GeccoPyramid), vp, vp, vp, i, i, vp]),
     "gecco_ray_lookup_bwd_sorted_workspace_bytes": (C.c_size_t, [C.POINTER(GeccoPyramid), i, i]),
     "gecco_ray_lookup_bwd_sorted_f32": (i, [vp, vp, vp, C.POINTER(GeccoReparam), C.POINTER(GeccoPyramid), vp, PP, i, i, vp,
                                             C.c_size_t, vp]),

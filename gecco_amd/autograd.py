@@ -72,16 +72,6 @@ def _lin_precision() -> str:
     return "fp16" if _amp_fp16() else _train_precision()
 
 
-def _no_input_grad(ctx, idx: int, what: str) -> None:
-    """The training path differentiates with respect to PARAMETERS, the conditioner's pyramid, the noise level (every AdaGN) and the
-    input cloud (LiftFn, LookupFn); a caller asking for a gradient it does not form — the camera matrix, the image — must hear about it
-    instead of receiving a silently missing gradient."""
-    if ctx.needs_input_grad[idx]:
-        from ._grad import GeccoTrainingNotSupported
-        raise GeccoTrainingNotSupported(f"the HIP training path has no gradient with respect to {what} (parameters and feature "
-                                        "pyramids only): detach it, or differentiate through the reference modules")
-
-
 def _new(*shape, like: Tensor) -> Tensor:
     return torch.empty(*shape, device=like.device, dtype=torch.float32)
 
@@ -1248,22 +1238,29 @@ class LookupFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        _no_input_grad(ctx, 1, "the camera matrix")
         geom, K, *levels = ctx.saved_tensors
-        if not (ctx.needs_input_grad[0] or any(ctx.needs_input_grad[3:])):
+        if not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or any(ctx.needs_input_grad[3:])):
             return (None,) * (3 + len(levels))   # a frozen (or foreign, detached) conditioner: nothing to compute
         dout = _f(dout)
         lib = _lib.load()
         B, N, _ = geom.shape
         rp = hip_ops.make_reparam(*ctx.spec)
         pyr = hip_ops.make_pyramid(levels)
-        dgeom = None
-        if ctx.needs_input_grad[0]:   # a caller differentiates with respect to the input cloud (guidance): through taps, projection, reparam
-            dgeom = _new(B, N, 3, like=dout)
-            _lib.check(lib.gecco_ray_lookup_dgeom_f32(_ptr(_f(geom)), _ptr(K), C.byref(rp), C.byref(pyr), _ptr(dout), _ptr(dgeom), B, N,
-                                                      _stream()), "gecco_ray_lookup_dgeom_f32")
+        dgeom = dK = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            # a caller differentiates with respect to the input cloud (guidance) or the camera matrix: through taps, projection, reparam
+            dgeom = _new(B, N, 3, like=dout) if ctx.needs_input_grad[0] else None
+            T = lib.gecco_lookup_row_tiles(N)
+            kpart = _new(B, T, 4, like=dout) if ctx.needs_input_grad[1] else None
+            _lib.check(lib.gecco_ray_lookup_dgeom_f32(_ptr(_f(geom)), _ptr(_f(K.float())), C.byref(rp), C.byref(pyr), _ptr(dout), _ptr(dgeom),
+                                                      _ptr(kpart), B, N, _stream()), "gecco_ray_lookup_dgeom_f32")
+            if kpart is not None:   # (fx, cx, fy, cy) -> the (3, 3) entries they sit at
+                k4 = kpart.sum(1)
+                dK = torch.zeros(B, 3, 3, device=dout.device, dtype=torch.float32)
+                dK[:, 0, 0], dK[:, 0, 2], dK[:, 1, 1], dK[:, 1, 2] = k4[:, 0], k4[:, 1], k4[:, 2], k4[:, 3]
+                dK = dK.reshape(K.shape)
         if not any(ctx.needs_input_grad[3:]):
-            return (dgeom, None, None, *[None] * len(levels))
+            return (dgeom, dK, None, *[None] * len(levels))
         nb = lib.gecco_ray_lookup_bwd_sorted_workspace_bytes(C.byref(pyr), B, N) if os.environ.get("GECCO_LOOKUP_BWD", "sorted") == "sorted" else 0
         if nb:   # sort + gather: no atomics, fixed summation order, every texel written
             grads = [torch.empty_like(f) for f in levels]   # (B, H, W, C)
@@ -1277,7 +1274,7 @@ class LookupFn(torch.autograd.Function):
             _lib.check(lib.gecco_ray_lookup_bwd_f32(_ptr(geom), None, _ptr(K), C.byref(rp), C.byref(pyr), _ptr(dout), arr, B, N,
                                                     _stream()), "gecco_ray_lookup_bwd_f32")
         # handed back NCHW-shaped (channels-last strides, no copy)
-        return (dgeom, None, None, *[g.permute(0, 3, 1, 2) for g in grads])
+        return (dgeom, dK, None, *[g.permute(0, 3, 1, 2) for g in grads])
 
 
 # ------------------------------------------------------------------------------------------- ConvNeXt conditioner
@@ -1327,21 +1324,25 @@ class CnxStemFn(torch.autograd.Function):
         z = torch.empty_like(out)
         _lib.check(_lib.load().gecco_convnext_stem_train_f32(_ptr(img), _ptr(_f(w)), _ptr(b), _ptr(ln_w), _ptr(ln_b), _ptr(out), _ptr(z),
                                                              B, H, W, Cc, eps, _stream()), "gecco_convnext_stem_train_f32")
-        ctx.save_for_backward(img, z, ln_w)
+        ctx.save_for_backward(img, z, ln_w, w)
         ctx.eps = eps
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        _no_input_grad(ctx, 0, "the image")
-        img, z, ln_w = ctx.saved_tensors
+        img, z, ln_w, w = ctx.saved_tensors
         B, h, w_, Cc = z.shape
         dz, dg, dbl, dbias = _cnx_ln_bwd(z, _f(dy), ln_w, ctx.eps, False)
+        dimg = None
+        if ctx.needs_input_grad[0]:
+            # the 4 x 4 patches do not overlap: d patch = dz W (a linear's dX product), then every value back to its pixel
+            dp = _linear_dx(dz.view(1, B * h * w_, Cc), _f(w.reshape(Cc, 48)))
+            dimg = dp.view(B, h, w_, 3, 4, 4).permute(0, 3, 1, 4, 2, 5).reshape(B, 3, 4 * h, 4 * w_)
         patches = _new(B, h * w_, 48, like=z)
         _lib.check(_lib.load().gecco_convnext_im2col4_f32(_ptr(img), _ptr(patches), B, img.shape[2], img.shape[3], _stream()),
                    "gecco_convnext_im2col4_f32")
         dW = _linear_dw(dz.view(1, B * h * w_, Cc), patches.view(1, B * h * w_, 48)).reshape(Cc, 3, 4, 4)
-        return None, dW, dbias, dg, dbl, None
+        return dimg, dW, dbias, dg, dbl, None
 
 
 class CnxDwLnFn(torch.autograd.Function):

@@ -1614,12 +1614,12 @@ int gecco_ray_lookup_bwd_f32(const float* geom, const float* coef, const float* 
 }
 
 int gecco_ray_lookup_dgeom_f32(const float* geom, const float* K, const GeccoReparam* rp, const GeccoPyramid* pyr, const float* dout,
-                               float* dgeom, int B, int N, void* stream) {
-    if (!geom || !K || !dout || !dgeom || !pyr) return fail(-1, "ray_lookup_dgeom: null argument");
+                               float* dgeom, float* dK_partials, int B, int N, void* stream) {
+    if (!geom || !K || !dout || !pyr || (!dgeom && !dK_partials)) return fail(-1, "ray_lookup_dgeom: null argument");
     LookupArgs a;
     int rc = make_lookup_args(rp, pyr, &a);
     if (rc) return rc;
-    TRY(ray_lookup_dgeom_launch(geom, K, a, dout, dgeom, B, N, (hipStream_t)stream), "ray_lookup_dgeom");
+    TRY(ray_lookup_dgeom_launch(geom, K, a, dout, dgeom, dK_partials, B, N, (hipStream_t)stream), "ray_lookup_dgeom");
     return 0;
 }
 

@@ -313,8 +313,8 @@ struct LookupArgs {
 int lookup_row_tile();
 int ray_lookup_launch(const float* geom, const float* coef, const float* K, const LookupArgs& a, float* out,
                       float* stats, int B, int N, hipStream_t st);
-int ray_lookup_dgeom_launch(const float* geom, const float* K, const LookupArgs& a, const float* dout, float* dgeom, int B, int N,
-                            hipStream_t st);   // gradient with respect to the geometry (B, N, 3)
+int ray_lookup_dgeom_launch(const float* geom, const float* K, const LookupArgs& a, const float* dout, float* dgeom, float* dKpart, int B,
+                            int N, hipStream_t st);   // gradients with respect to the geometry (B, N, 3) and (partials, (B, T, 4)) fx, cx, fy, cy
 int ray_lookup_bwd_launch(const float* geom, const float* coef, const float* K, const LookupArgs& a,
                           float* const* dfeat, const float* dout, int B, int N, hipStream_t st);   // dfeat: zeroed, NHWC
 // the same gradient by sort + gather (no atomics, fixed summation order, dfeat fully written: no zero fill needed)

@@ -158,11 +158,17 @@ __global__ __launch_bounds__(256) void ray_lookup_kernel(const float* __restrict
 
 // project_uv with its Jacobian: du[k] = d u / d g_k, dv[k] = d v / d g_k (the derivative of exactly the expressions above; floor / the
 // eps guard contribute none, as in autograd through the reference's torch ops)
+// dku = d u / d (fx, cx), dkv = d v / d (fy, cy): the camera matrix enters the projection and, for the UVL reparametrisation, the
+// unprojection in front of it (u depends on fx, cx only and v on fy, cy only up to the normalisation of the ray, which couples them:
+// dkuy = d u / d (fy, cy), dkvx = d v / d (fx, cx))
 __device__ __forceinline__ void project_uv_jac(float g0, float g1, float g2, const float* __restrict__ Kb, int kind,
                                                const float* __restrict__ mean, const float* __restrict__ std_, float logit_scale,
-                                               float (&du)[3], float (&dv)[3]) {
+                                               float (&du)[3], float (&dv)[3], float (&dku)[2], float (&dkv)[2], float (&dkuy)[2],
+                                               float (&dkvx)[2]) {
     float X = g0, Y = g1, Z = g2;
     float dX[3] = {1.f, 0.f, 0.f}, dY[3] = {0.f, 1.f, 0.f}, dZ[3] = {0.f, 0.f, 1.f};
+    // partials of (X, Y, Z) with respect to (fx, cx) [index 0, 1] and (fy, cy) [index 2, 3]: zero unless the reparametrisation unprojects
+    float kX[4] = {0.f, 0.f, 0.f, 0.f}, kY[4] = {0.f, 0.f, 0.f, 0.f}, kZ[4] = {0.f, 0.f, 0.f, 0.f};
     const float fx = Kb[0], fy = Kb[4], cx = Kb[2], cy = Kb[5];
     if (kind == 1) {
         X = g0 * std_[0] + mean[0];
@@ -188,6 +194,14 @@ __device__ __forceinline__ void project_uv_jac(float g0, float g1, float g2, con
         dX[0] = d * (in - xx * xx * in3) * dxx;  dX[1] = -d * xx * yy * in3 * dyy;      dX[2] = xx * in * dd;
         dY[0] = -d * xx * yy * in3 * dxx;        dY[1] = d * (in - yy * yy * in3) * dyy; dY[2] = yy * in * dd;
         dZ[0] = -d * xx * in3 * dxx;             dZ[1] = -d * yy * in3 * dyy;            dZ[2] = in * dd;
+        // xx = (su - cx) / fx: d xx / d fx = -xx / fx, d xx / d cx = -1 / fx; yy likewise with (fy, cy)
+        const float xk[2] = {-xx / fx, -1.0f / fx}, yk[2] = {-yy / fy, -1.0f / fy};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            kX[j] = d * (in - xx * xx * in3) * xk[j];      kX[2 + j] = -d * xx * yy * in3 * yk[j];
+            kY[j] = -d * xx * yy * in3 * xk[j];            kY[2 + j] = d * (in - yy * yy * in3) * yk[j];
+            kZ[j] = -d * xx * in3 * xk[j];                 kZ[2 + j] = -d * yy * in3 * yk[j];
+        }
     }
     const bool live = fabsf(Z) > 1e-8f;
     const float sc = live ? 1.0f / (Z + 1e-8f) : 1.0f;
@@ -197,6 +211,14 @@ __device__ __forceinline__ void project_uv_jac(float g0, float g1, float g2, con
         du[k] = fx * (sc * dX[k] + dsc * dZ[k] * X);
         dv[k] = fy * (sc * dY[k] + dsc * dZ[k] * Y);
     }
+    // u = sc X fx + cx, v = sc Y fy + cy
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        dku[j] = fx * (sc * kX[j] + dsc * kZ[j] * X) + (j == 0 ? sc * X : 1.0f);
+        dkv[j] = fy * (sc * kY[2 + j] + dsc * kZ[2 + j] * Y) + (j == 0 ? sc * Y : 1.0f);
+        dkuy[j] = fx * (sc * kX[2 + j] + dsc * kZ[2 + j] * X);
+        dkvx[j] = fy * (sc * kY[j] + dsc * kZ[j] * Y);
+    }
 }
 
 // Gradient of the lookup with respect to the GEOMETRY (autograd of F.grid_sample w.r.t. its grid, then of the projection and the
@@ -204,8 +226,12 @@ __device__ __forceinline__ void project_uv_jac(float g0, float g1, float g2, con
 // cloud): dgeom[b, n, k] = sum_l ( W_l sum_c dout_c d out_c / d ix * du/dg_k + H_l sum_c dout_c d out_c / d iy * dv/dg_k ), with
 // d out / d ix = wy0 (ne - nw) + wy1 (se - sw) and d out / d iy = wx0 (sw - nw) + wx1 (se - ne) over the in-range taps.  One wave per
 // point, lanes over 16-byte channel chunks as in the forward; a wave reduction, three floats out.
+// dKpart (optional): (B, T, 4) partials of the gradient with respect to (fx, cx, fy, cy) of the sample's camera matrix, one per block
 __global__ __launch_bounds__(256) void ray_lookup_dgeom_kernel(const float* __restrict__ geom, const float* __restrict__ K, LookupArgs a,
-                                                               const float* __restrict__ dout, float* __restrict__ dgeom, int N, int T) {
+                                                               const float* __restrict__ dout, float* __restrict__ dgeom,
+                                                               float* __restrict__ dKpart, int N, int T) {
+    __shared__ float kred[4][4];
+    float kacc[4] = {0.f, 0.f, 0.f, 0.f};   // lane 0 of each wave: sums over the wave's points
     const int tile = blockIdx.x % T, b = blockIdx.x / T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int Ct = a.c_total, C4 = Ct / 4;
@@ -270,12 +296,28 @@ __global__ __launch_bounds__(256) void ray_lookup_dgeom_kernel(const float* __re
             gv += __shfl_xor(gv, o, 64);
         }
         if (lane == 0) {
-            float du[3], dv[3];
-            project_uv_jac(gp[0], gp[1], gp[2], Kb, a.reparam_kind, a.rp_mean, a.rp_std, a.logit_scale, du, dv);
-            float* o = dgeom + ((size_t)b * N + m) * 3;
+            float du[3], dv[3], dku[2], dkv[2], dkuy[2], dkvx[2];
+            project_uv_jac(gp[0], gp[1], gp[2], Kb, a.reparam_kind, a.rp_mean, a.rp_std, a.logit_scale, du, dv, dku, dkv, dkuy, dkvx);
+            if (dgeom) {
+                float* o = dgeom + ((size_t)b * N + m) * 3;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) o[k] = gu * du[k] + gv * dv[k];
+                for (int k = 0; k < 3; ++k) o[k] = gu * du[k] + gv * dv[k];
+            }
+            kacc[0] += gu * dku[0] + gv * dkvx[0];   // fx
+            kacc[1] += gu * dku[1] + gv * dkvx[1];   // cx
+            kacc[2] += gv * dkv[0] + gu * dkuy[0];   // fy
+            kacc[3] += gv * dkv[1] + gu * dkuy[1];   // cy
         }
+    }
+    if (dKpart) {   // the four waves' sums in a fixed order
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) kred[wave][j] = kacc[j];
+        }
+        __syncthreads();
+        if (threadIdx.x < 4)
+            dKpart[((size_t)b * T + tile) * 4 + threadIdx.x] =
+                ((kred[0][threadIdx.x] + kred[1][threadIdx.x]) + kred[2][threadIdx.x]) + kred[3][threadIdx.x];
     }
 }
 
@@ -523,13 +565,13 @@ int ray_lookup_launch(const float* geom, const float* coef, const float* K, cons
     return (int)hipGetLastError();
 }
 
-int ray_lookup_dgeom_launch(const float* geom, const float* K, const LookupArgs& a, const float* dout, float* dgeom, int B, int N,
-                            hipStream_t st) {
+int ray_lookup_dgeom_launch(const float* geom, const float* K, const LookupArgs& a, const float* dout, float* dgeom, float* dKpart, int B,
+                            int N, hipStream_t st) {
     if (a.n_levels < 1 || a.n_levels > 4 || a.c_total > 1024 || a.c_total % 4) return -8;
     for (int l = 0; l < a.n_levels; ++l)
         if (a.C[l] % 4) return -8;
     const int T = (N + LOOKUP_ROWS - 1) / LOOKUP_ROWS;
-    hipLaunchKernelGGL(ray_lookup_dgeom_kernel, dim3(B * T), dim3(256), 0, st, geom, K, a, dout, dgeom, N, T);
+    hipLaunchKernelGGL(ray_lookup_dgeom_kernel, dim3(B * T), dim3(256), 0, st, geom, K, a, dout, dgeom, dKpart, N, T);
     return (int)hipGetLastError();
 }
 

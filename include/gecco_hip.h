@@ -478,9 +478,11 @@ int gecco_ray_lookup_bwd_f32(const float* geom, const float* coef, const float* 
                              void* stream);
 /* The lookup's gradient with respect to the GEOMETRY: dgeom (B, N, 3) = autograd of F.grid_sample w.r.t. its grid through the
  * projection and the reparametrisation (models/ray.py:64-87), for a caller that differentiates the conditional denoiser with respect
- * to its input cloud; geom is the diffusion-space geometry the forward saw (c_in already applied), pyr the pyramid it read. */
+ * to its input cloud; geom is the diffusion-space geometry the forward saw (c_in already applied), pyr the pyramid it read.
+ * dK_partials (optional; dgeom may then be NULL): (B, gecco_lookup_row_tiles(N), 4) partial sums of the gradient with respect to
+ * (fx, cx, fy, cy) of each sample's camera matrix — the projection and, for the UVL reparametrisation, the unprojection in front. */
 int gecco_ray_lookup_dgeom_f32(const float* geom, const float* K, const GeccoReparam* rp, const GeccoPyramid* pyr, const float* dout,
-                               float* dgeom, int B, int N, void* stream);
+                               float* dgeom, float* dK_partials, int B, int N, void* stream);
 /* The same gradient by SORT + GATHER: per (image, level) the 4 N (texel, point, tap) entries are sorted by texel in LDS, then
  * every texel's threads walk its list — no atomics, a fixed summation order (bit-reproducible), and every texel of dfeat is
  * WRITTEN (no zero fill).  Needs N <= 4096 and H_l W_l <= 2^17 (gecco_ray_lookup_bwd_sorted_workspace_bytes returns 0

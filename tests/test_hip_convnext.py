@@ -132,7 +132,8 @@ def test_convnext_parameter_gradients_vs_oracle(hw, B):
     rs = np.random.RandomState(22)
     img = torch.from_numpy(rs.rand(B, 3, hw, hw).astype(np.float32))
     p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    ref = cpu_ref.convnext_features(img, p)
+    img_c = img.clone().requires_grad_(True)
+    ref = cpu_ref.convnext_features(img_c, p)
     R = [torch.from_numpy(rs.randn(*f.shape).astype(np.float32)) for f in ref]
     sum((f * r).sum() for f, r in zip(ref, R)).backward()
     K = torch.eye(3).repeat(B, 1, 1)
@@ -141,7 +142,8 @@ def test_convnext_parameter_gradients_vs_oracle(hw, B):
         for precision, tol in (("fp32", 1e-4), ("bf16x3", 1e-3)):
             hip_ops.set_default_precision(precision)
             m.zero_grad(set_to_none=True)
-            out = m(Context3d(image=img.cuda(), K=K.cuda()))
+            img_g = img.clone().cuda().requires_grad_(True)   # ... and with respect to the image itself (the stem's dX: CnxStemFn)
+            out = m(Context3d(image=img_g, K=K.cuda()))
             for f, r in zip(out.features, ref):
                 assert f.shape == r.shape and f.requires_grad
                 assert cpu_ref.rel_err(f.detach().cpu(), r.detach())[0] < (2e-5 if precision == "fp32" else 2e-4)
@@ -153,7 +155,9 @@ def test_convnext_parameter_gradients_vs_oracle(hw, B):
                 if e > worst[1]:
                     worst = (k, e)
                 assert e < tol, (precision, k, e)
-            print(f"convnext gradients {hw}x{hw} B={B} [{precision}]: worst {worst[0]} {worst[1]:.2e}")
+            ei = cpu_ref.rel_err(img_g.grad.cpu(), img_c.grad)[0]
+            assert ei < tol, (precision, "image", ei)
+            print(f"convnext gradients {hw}x{hw} B={B} [{precision}]: worst {worst[0]} {worst[1]:.2e}, image {ei:.2e}")
     finally:
         hip_ops.set_default_precision(old)
 

@@ -353,6 +353,43 @@ def test_lookup_fn_grads():
         _close(a.grad, b.grad, 1e-4)
 
 
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_lookup_geometry_and_camera_gradients(kind):
+    """The projective lookup's gradients with respect to the geometry and the camera matrix (`gecco_ray_lookup_dgeom_f32`: bilinear taps
+    -> kornia's projection -> the reparametrisation, models/ray.py:64-87) for no / the Gaussian / the UVL reparametrisation, against torch
+    autograd through the oracle's restatement of the same ops.  (UVL: the projection undoes the unprojection, the camera gradient is
+    zero up to rounding; the other two carry d u / d fx = x / z, d u / d cx = 1.)"""
+    from gecco_amd.autograd import LookupFn
+    feats, K, geom_uvl, um, us = cases.lookup_inputs("lookup_small")
+    with torch.no_grad():
+        xyz = cpu_ref.uvl_diffusion_to_data(geom_uvl, K, um, us)      # data-space points that project into the image
+    rs = np.random.RandomState(9 + kind)
+    mean, std = _t(rs.randn(3) * 0.2), _t(0.5 + rs.rand(3))
+    geom = {0: xyz, 1: (xyz - mean) / std, 2: geom_uvl}[kind].clone()
+
+    def oracle(gm, Km):
+        if kind == 2:
+            return cpu_ref.extract_image_features(gm, feats, Km, um, us)
+        pts = gm if kind == 0 else gm * std + mean
+        uv = cpu_ref.project_points(pts, Km)
+        return torch.cat([cpu_ref.grid_sample_bilinear_zeros(f, uv) for f in feats], dim=-1)
+    gc, Kc = geom.clone().requires_grad_(True), K.clone().requires_grad_(True)
+    ref = oracle(gc, Kc)
+    g = _t(rs.randn(*ref.shape))
+    ref.backward(g)
+    spec = {0: (0, None, None, 1.1), 1: (1, mean.cuda(), std.cuda(), 1.1), 2: (2, um.cuda(), us.cuda(), 1.1)}[kind]
+    gg, Kg = geom.clone().cuda().requires_grad_(True), K.clone().cuda().requires_grad_(True)
+    out = LookupFn.apply(gg, Kg, spec, *[f.cuda() for f in feats])
+    _close(out, ref.detach(), 1e-4)
+    out.backward(g.cuda())
+    _close(gg.grad, gc.grad, 1e-3)
+    if kind == 2:
+        assert float((Kg.grad.cpu() - Kc.grad).abs().max()) <= 1e-3 * float(gc.grad.abs().max())
+    else:
+        assert float(Kc.grad.abs().max()) > 0
+        _close(Kg.grad, Kc.grad, 1e-3)
+
+
 @pytest.mark.parametrize("N,hw", [(1000, 24), (2048, 56), (4096, 64), (5000, 16)])
 def test_lookup_backward_sort_gather_form(N, hw, monkeypatch):
     """The pyramid gradient by sort + gather (csrc/lookup.hip: no atomics) against torch autograd through the oracle's
@@ -462,13 +499,19 @@ def test_conditional_gradient_with_respect_to_the_noisy_cloud():
     sigma = cpu_ref.log_uniform_sigma(u, c["sigma_max"])
     x0 = ex_diff + noise * sigma
     w = torch.from_numpy(np.random.RandomState(4).randn(*x0.shape).astype(np.float32))
-    xc, sc = x0.clone().requires_grad_(True), sigma.clone().requires_grad_(True)
-    (cpu_ref.cond_denoiser(p, "", cases.H, K, feats)(xc, sc) * w).sum().backward()
+    xc, sc, Kc = x0.clone().requires_grad_(True), sigma.clone().requires_grad_(True), K.clone().requires_grad_(True)
+    (cpu_ref.cond_denoiser(p, "", cases.H, Kc, feats)(xc, sc) * w).sum().backward()
     xg, sg = x0.clone().cuda().requires_grad_(True), sigma.clone().cuda().requires_grad_(True)
+    Kg = K.clone().cuda().requires_grad_(True)
+    ctx = Context3d(image=torch.zeros(len(u), 3, hw, hw).cuda(), K=Kg)
     (m(xg, sg, ctx) * w.cuda()).sum().backward()
-    assert torch.isfinite(xg.grad).all() and torch.isfinite(sg.grad).all()
+    assert torch.isfinite(xg.grad).all() and torch.isfinite(sg.grad).all() and torch.isfinite(Kg.grad).all()
     _close(xg.grad, xc.grad, 1e-3)
     _close(sg.grad, sc.grad, 2e-3)
+    # ... and the camera matrix: with the UVL reparametrisation the projection undoes the unprojection (u = s_u whatever K), so this
+    # gradient is zero up to rounding on both sides — its non-trivial cases are in test_lookup_geometry_and_camera_gradients
+    scale = float(xc.grad.abs().max())
+    assert float((Kg.grad.cpu() - Kc.grad).abs().max()) <= 1e-3 * scale and float(Kc.grad.abs().max()) <= 1e-3 * scale
 
 
 def test_training_step_decreases_loss():

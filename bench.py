@@ -495,7 +495,8 @@ def train_bench(args, rank, world, dev):
                     if args.amp else
                     {"bf16x3": "bf16 (split hi+lo operands, 3 MFMAs per product, fp32 accumulate)", "fp32": "f32",
                      "fp16": "bf16 (split; the fp16 mode is not used for gradients)",
-                     "mixed": "bf16 (split; the mixed mode trains in split-bf16)"}[args.precision],
+                     "mixed": "bf16 (split; the mixed mode trains in split-bf16)",
+                     "w2": "bf16 (split; the w2 mode trains in split-bf16)"}[args.precision],
            "data": "synthetic",
            "config": {"workload": (f"{args.config} image-conditional training step ({'frozen' if args.freeze_conditioner else 'trained'} channels-last ConvNeXt-T conditioner inside the step, "
                                    f"projective lookup, RayNetwork): batch {Bt}/GPU, N={Nt}, d={Dt}, L={Lt}" if cond else
@@ -770,7 +771,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra blocks of the default run (train / configs / upsample: child processes, ~6 s of timed work each)")
     ap.add_argument("--eager", action="store_true", help="time eager Diffusion.forward calls instead of the hipGraph replay")
-    ap.add_argument("--precision", default=os.environ.get("GECCO_PRECISION", "mixed"), choices=["fp32", "bf16x3", "mixed", "fp16"],
+    ap.add_argument("--precision", default=os.environ.get("GECCO_PRECISION", "mixed"), choices=["fp32", "bf16x3", "mixed", "w2", "fp16"],
                     help="arithmetic of the linears and attention products: mixed (fp16 where operand rounding does not reach the "
                          "output, split-bf16 elsewhere: D and F_x ~6e-5), split-bf16 (3 MFMAs per product, D and F_x "
                          "~2e-5 .. 5e-5 from the fp32 reference), fp16 operands with fp32 accumulation (faster; D ~4e-4, F_x ~1e-3: "
@@ -882,11 +883,15 @@ def main():
     rec["dtype"] = {"mixed": "f16/fp8/bf16 mixed (kv_proj|q_proj: fp16 activations x fp16 weights, the V columns + an fp8 second weight term; fp16 K|V, q "
                              "and attention products; out_proj and the point MLP: fp16 main product + two fp8 cross terms (h8, split-bf16 accuracy); "
                              "inducer chain: fp16 activations x two-term fp16 weights; fp32 accumulate, residual stream and statistics)",
+                    "w2": "f16/fp6/fp8 mixed (the mixed mode with the point MLP of every layer as ONE launch: fp16 main products + fp6 block-scaled second "
+                          "terms for AdaGN(x) and both weights, the 768-wide hidden layer kept in registers as fp16; the other sites as in the mixed mode; "
+                          "fp32 accumulate, residual stream and statistics)",
                     "fp16": "f16 (fp16 operands, fp32 accumulate; fp16-stored intermediates, fp32 residual stream and statistics)",
                     "bf16x3": "bf16 (split hi+lo operands, 3 MFMAs per product, fp32 accumulate; fp32 activations in HBM)",
                     "fp32": "f32"}[mode]
     rec["config"]["workload"] = rec["config"]["workload"].replace(
-        "fp32 MFMA", {"fp16": "fp16 MFMA", "bf16x3": "split-bf16 MFMA", "fp32": "fp32 MFMA", "mixed": "mixed fp16 / fp8-cross-term / split-bf16 MFMA"}[mode])
+        "fp32 MFMA", {"fp16": "fp16 MFMA", "bf16x3": "split-bf16 MFMA", "fp32": "fp32 MFMA", "mixed": "mixed fp16 / fp8-cross-term / split-bf16 MFMA",
+                     "w2": "mixed fp16 / fp6- and fp8-cross-term MFMA, one-launch point MLP"}[mode])
     if rank == 0 and not args.no_roofline:
         site_mode = "bf16x3" if mode == "mixed" else mode
         sites = gemm_call_sites(ops, dev, site_mode) if mode != "mixed" else []   # mixed: its own round of h8 launches (h8_round)

@@ -100,8 +100,8 @@ SIGNATURES = {
     "gecco_mlp_fused_f16": (i, [vp, vp, vp, vp, vp, vp, vp, vp, i, vp, i, i, i, i, vp, vp]),
     "gecco_unpool_outproj_f16": (i, [vp, vp, vp, vp, vp, vp, i, i, i, i, vp, vp]),
     "gecco_unpool_outproj_h8": (i, [vp, vp, vp, vp, vp, vp, i, i, i, i, vp, vp]),
-    "gecco_mlp_fused_h8": (i, [vp, vp, vp, vp, vp, vp, vp, vp, i, vp, i, i, i, i, vp, vp]),
-    "gecco_mlp_fused_h8_wsplit_bytes": (sz, [i, i]),
+    "gecco_mlp_fused_w": (i, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, vp, i, i, i, i, vp, vp, vp]),
+    "gecco_mlp_fused_w_wsplit_bytes": (sz, [i, i]),
     "gecco_unpool_outproj_h8_wsplit_bytes": (sz, [i, i, i]),
     "gecco_unpool_attn_h8img": (i, [vp, vp, vp, i, i, i, i, vp]),
     "gecco_gemm_tn_x3_f32": (i, [vp, vp, vp, i, i, i, i, i, vp]),

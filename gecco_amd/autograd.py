@@ -51,7 +51,7 @@ def _train_precision() -> str:
     train in split-bf16 — without a loss scale small gradient values would flush in fp16, split-bf16 has the fp32 exponent range.
     (Under torch.autocast(float16), the reference's trainer setting, a GradScaler supplies that scale: `_lin_precision`.)"""
     p = hip_ops.default_precision()
-    return "bf16x3" if p in ("fp16", "mixed") else p
+    return "bf16x3" if p in ("fp16", "mixed", "w2") else p
 
 
 def _amp_fp16() -> bool:

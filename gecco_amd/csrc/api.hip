@@ -96,7 +96,8 @@ STWorkspace carve_st(const GeccoSetTransformer* st, int B, int N, void* base) {
     }
     {   // per layer: kv_proj | q_proj (contiguous: the fused pair streams them as one image), out_proj, mlp.0, mlp.2
         // (floats: 4 bytes per weight element in split-bf16 mode, 2 in fp16 mode)
-        const size_t half = st->precision == 2 ? 2 : 1;
+        const int prec = st->precision == 4 ? 3 : st->precision;   // 4 ("w2") = the mixed mode with the one-launch point MLP
+        const size_t half = prec == 2 ? 2 : 1;
         auto pad = [half](size_t n) { return (n + 127) / 128 * 128 / half; };
         w.o_q = pad(2 * C) * C;
         w.o_out = w.o_q + pad(C) * C;
@@ -107,10 +108,10 @@ STWorkspace carve_st(const GeccoSetTransformer* st, int B, int N, void* base) {
         w.o_b2 = w.o_b0 + pad(W) * C;
         w.o_ukv = w.o_b2 + pad(C) * W;
         w.o_mf = w.o_ukv + pad(2 * C) * C;
-        w.wimg_layer = w.o_mf + (st->precision == 2 ? pad(W) * C + pad(C) * W : 0);
-        // mixed mode: the weight stream of the one-launch point MLP (option "mlph8"; mlp_fused_h8.hip) at o_mf
-        if (st->precision == 3 && mlp_fused_h8_supported((int)C, (int)W, 128)) w.wimg_layer += mlp_fused_h8_image_bytes((int)C, (int)W) / sizeof(float);
-        w.wimg = st->precision >= 1 ? c.f32(w.wimg_layer * st->n_layers) : nullptr;
+        w.wimg_layer = w.o_mf + (prec == 2 ? pad(W) * C + pad(C) * W : 0);
+        // "w2" mode: the weight stream of the one-launch point MLP (mlp_fused_w.hip) at o_mf
+        if (st->precision == 4 && mlp_fused_w_supported((int)C, (int)W, 128)) w.wimg_layer += mlp_fused_w_image_bytes((int)C, (int)W) / sizeof(float);
+        w.wimg = prec >= 1 ? c.f32(w.wimg_layer * st->n_layers) : nullptr;
     }
     w.bytes = (c.off + 255) & ~size_t(255);
     return w;
@@ -189,15 +190,15 @@ int linear_pair(const float* A, const float* W1, const float* b1, int Nout1, flo
 }
 
 // Path switches for A/B runs and tests: gecco_set_option, or the environment (GECCO_ASTAT, GECCO_CHAIN) on first use.
-enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_HEADMAJOR = 2, OPT_MLPFUSED = 3, OPT_UNPOOLFUSED = 4, OPT_LO8 = 5, OPT_ACTIMG = 6, OPT_H8 = 7, OPT_KVQ64 = 8, OPT_H8AREG = 9, OPT_CHAIN2 = 10, OPT_UNPOOLH8 = 11, OPT_MLPH8 = 12, OPT_CHAINCL = 13, OPT_H6 = 14, OPT_KVFOLD = 15, OPT_COUNT = 16 };
+enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_HEADMAJOR = 2, OPT_MLPFUSED = 3, OPT_UNPOOLFUSED = 4, OPT_LO8 = 5, OPT_ACTIMG = 6, OPT_H8 = 7, OPT_KVQ64 = 8, OPT_H8AREG = 9, OPT_CHAIN2 = 10, OPT_UNPOOLH8 = 11, OPT_MLPW = 12, OPT_CHAINCL = 13, OPT_H6 = 14, OPT_KVFOLD = 15, OPT_COUNT = 16 };
 int g_options[OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
-const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor", "mlpfused", "unpoolfused", "lo8", "actimg", "h8", "kvq64", "h8areg", "chain2", "unpoolh8", "mlph8", "chaincl", "h6", "kvfold"};
+const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor", "mlpfused", "unpoolfused", "lo8", "actimg", "h8", "kvq64", "h8areg", "chain2", "unpoolh8", "mlpw", "chaincl", "h6", "kvfold"};
 const char* const g_option_env[OPT_COUNT] = {"GECCO_ASTAT", "GECCO_CHAIN", "GECCO_HEADMAJOR", "GECCO_MLPFUSED", "GECCO_UNPOOLFUSED", "GECCO_LO8",
-                                             "GECCO_ACTIMG", "GECCO_H8", "GECCO_KVQ64", "GECCO_H8AREG", "GECCO_CHAIN2", "GECCO_UNPOOLH8", "GECCO_MLPH8", "GECCO_CHAINCL", "GECCO_H6", "GECCO_KVFOLD"};
+                                             "GECCO_ACTIMG", "GECCO_H8", "GECCO_KVQ64", "GECCO_H8AREG", "GECCO_CHAIN2", "GECCO_UNPOOLH8", "GECCO_MLPW", "GECCO_CHAINCL", "GECCO_H6", "GECCO_KVFOLD"};
 int option(int which) {
     if (g_options[which] < 0) {
         const char* e = getenv(g_option_env[which]);
-        g_options[which] = e ? (atoi(e) != 0) : (which == OPT_MLPH8 ? 0 : 1);   // "mlph8": built and exact, measured slower than its two launches: opt-in
+        g_options[which] = e ? (atoi(e) != 0) : 1;
     }
     return g_options[which];
 }
@@ -267,9 +268,10 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
     // Shapes the A-stationary kv_proj | q_proj kernel does not take (rows not a multiple of 128, C outside 128 .. 512 in steps
     // of 128, head dims the fp16 attention kernels do not have) run the whole evaluation in split-bf16 — at least as
     // accurate, slower — instead of failing: a drop-in caller's N need not be a multiple of 128.
-    const bool mixed = st->precision == 3 && N >= 128 && N % 128 == 0 && C % 128 == 0 && C <= 512 && !(C % H) &&
+    const int prec = st->precision == 4 ? 3 : st->precision;   // 4 ("w2"): the mixed mode with the point MLP as one launch (below)
+    const bool mixed = prec == 3 && N >= 128 && N % 128 == 0 && C % 128 == 0 && C <= 512 && !(C % H) &&
                        attn_x3_supported(C / H) && st->I == 64 && option(OPT_ASTAT);
-    const int pr = mixed ? 1 : (st->precision == 3 ? 1 : st->precision);       // arithmetic of the generic linears
+    const int pr = mixed ? 1 : (prec == 3 ? 1 : prec);       // arithmetic of the generic linears
     const int Tn = row_tiles_gemm(N), Ti = row_tiles_gemm(I);
     const int ns = pool_attn_nsplit(B, N, H);
 
@@ -322,9 +324,10 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
     // fp16 q of the kvq kernel; the k | v image of the inducers lives in the (then idle) attention-output buffer
     const bool uo8_on = h8o && kvq_on && option(OPT_UNPOOLH8) && I == 64 && unpool_outproj_h8_supported(C, H, N) &&
                         unpool_outproj_h8_kv_bytes(B, C, H) <= (size_t)B * N * C * sizeof(float);
-    // mixed mode, opt-in (option "mlph8"): the point MLP as ONE launch with the hidden layer kept on the CU (mlp_fused_h8.hip); its
-    // weight stream (2.75 MB at d = 384) has its own workspace slot (o_mf)
-    const bool mf8_on = h8_on && h8x && option(OPT_MLPH8) && st->precision == 3 && mlp_fused_h8_supported(C, Wd, N);
+    // "w2" mode (option "mlpw" = 0 runs it as the mixed mode): the point MLP as ONE launch, the hidden layer kept as register fragments,
+    // its second term dropped (mlp_fused_w.hip); the weight stream (1.9 MB at d = 384) has its own workspace slot (o_mf).  Shapes the kernel
+    // does not take (feature_dim != 384, point counts off 128) run the mixed mode's two launches — at least as accurate
+    const bool mfw_on = mixed && st->precision == 4 && option(OPT_MLPW) && w.wimg && mlp_fused_w_supported(C, Wd, N);
     const bool chain_on = pr == 2 && w.wimg && option(OPT_CHAIN) && inducer_chain_f16_supported(C, Wd, H, G, I) &&
                           (ns == 1 || ns == 2 || ns == 4 || ns == 8);
     // mixed mode: the same one-launch chain with TWO-TERM fp16 weights (option "chain2") instead of five 64-row split-bf16 GEMMs
@@ -434,8 +437,8 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
                         TRY(push_ld(L.mlp.w2 + (size_t)jc * 128 + hf * 64, cb + (size_t)(nkb + hf * (nkb / 2)) * 2048, C, 64, Wd),
                             "split(mlp.2 K-slice)");
                 }
-            } else if (mf8_on) {
-                TRY(mlp_fused_h8_image_launch(L.mlp.w0, L.mlp.w2, base + w.o_mf, C, Wd, s), "split(mlp, fused h8 stream)");
+            } else if (mfw_on) {
+                TRY(mlp_fused_w_image_launch(L.mlp.w0, L.mlp.w2, base + w.o_mf, C, Wd, s), "split(mlp, w2 stream)");
             } else {
                 if (h8_on) {   // same bytes as the split-bf16 image it replaces: fp16 hi + fp8 lo + fp8 W per element
                     if (jobs8.n >= kJobCap) { TRY(h8_image_multi_launch(jobs8, s), "split(mlp.0, h8)"); jobs8.n = 0; }
@@ -637,12 +640,12 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         // split-bf16 products: the hidden layer goes from mlp.0 to mlp.2 as a tiled split image (same bytes as the fp32 tensor
         // it replaces, in the same buffer): contiguous DMA pieces and no hi / lo split in mlp.2's K loop
         const int himg = pr == 1 && !a16 && im && option(OPT_ACTIMG) && N >= 128 && N % 128 == 0 && Wd % 16 == 0 && C % 16 == 0;
-        if (m0_done == 1 && mf8_on && im) {
-            MlpH8Args ma{};
-            ma.x = x; ma.pro_a = w.a2; ma.pro_o = w.o2; ma.w_img = im + w.o_mf; ma.b0 = L.mlp.b0; ma.b2 = L.mlp.b2; ma.alpha = L.mlp.alpha;
+        if (m0_done == 1 && mfw_on && im) {
+            MlpWArgs ma{};
+            ma.x = x; ma.out = x; ma.pro_a = w.a2; ma.pro_o = w.o2; ma.w_img = im + w.o_mf; ma.b0 = L.mlp.b0; ma.b2 = L.mlp.b2; ma.alpha = L.mlp.alpha;
             ma.act = act; ma.stats = so; ma.B = B; ma.rows = N;
             if ((act == 1 || act == 2) && !L.mlp.alpha) return fail(-6, "mlp: GaussianActivation needs alpha");
-            TRY(mlp_fused_h8_launch(ma, C, Wd, s), "mlp (fused, h8)");
+            TRY(mlp_fused_w_launch(ma, C, Wd, s), "mlp (one launch, w2)");
             sx = w.stats_x;
             sT = Tn;
             continue;
@@ -714,7 +717,7 @@ int gecco_set_option(const char* name, int value) {
             g_options[i] = value < 0 ? -1 : (value != 0);   // < 0: back to the environment / default
             return 0;
         }
-    return fail(-2, "set_option: unknown option '%s' (astat, chain, headmajor, mlpfused, unpoolfused, lo8, actimg, h8, kvq64, h8areg, chain2, unpoolh8, mlph8, chaincl, h6, kvfold)", name);
+    return fail(-2, "set_option: unknown option '%s' (astat, chain, headmajor, mlpfused, unpoolfused, lo8, actimg, h8, kvq64, h8areg, chain2, unpoolh8, mlpw, chaincl, h6, kvfold)", name);
 }
 
 int gecco_linear_row_tiles(int rows) { return row_tiles_gemm(rows); }
@@ -1232,23 +1235,23 @@ int gecco_unpool_outproj_h8(float* x, const void* q16, const float* kvh, const f
     return 0;
 }
 
-int gecco_mlp_fused_h8(float* x, const float* pro_a, const float* pro_o, const float* W0, const float* b0, const float* W2,
-                       const float* b2, const float* alpha, int act, float* stats, int B, int rows, int C, int width,
-                       void* wsplit, void* stream) {
-    if (!x || !pro_a || !pro_o || !wsplit) return fail(-1, "mlp_fused_h8: null argument");
-    if (!mlp_fused_h8_supported(C, width, rows)) return fail(-2, "mlp_fused_h8: needs C == 384, width == 2 C, rows %% 128 == 0");
-    if (act < 0 || act > 3) return fail(-6, "mlp_fused_h8: act must be 0 .. 3");
-    if ((act == 1 || act == 2) && !alpha) return fail(-6, "mlp_fused_h8: GaussianActivation needs alpha");
+int gecco_mlp_fused_w(const float* x, float* out, const float* pro_a, const float* pro_o, const float* W0, const float* b0, const float* W2,
+                      const float* b2, const float* alpha, int act, float* stats, int B, int rows, int C, int width, void* wsplit, float* dbg_u,
+                      void* stream) {
+    if (!x || !out || !pro_a || !pro_o || !wsplit) return fail(-1, "mlp_fused_w: null argument");
+    if (!mlp_fused_w_supported(C, width, rows)) return fail(-2, "mlp_fused_w: needs C == 384, width == 2 C, rows %% 128 == 0");
+    if (act < 0 || act > 3) return fail(-6, "mlp_fused_w: act must be 0 .. 3");
+    if ((act == 1 || act == 2) && !alpha) return fail(-6, "mlp_fused_w: GaussianActivation needs alpha");
     hipStream_t s = (hipStream_t)stream;
-    if (W0 && W2) TRY(mlp_fused_h8_image_launch(W0, W2, wsplit, C, width, s), "mlp_fused_h8(image)");   // W0 == NULL: image ready
-    MlpH8Args ma{};
-    ma.x = x; ma.pro_a = pro_a; ma.pro_o = pro_o; ma.w_img = wsplit; ma.b0 = b0; ma.b2 = b2; ma.alpha = alpha; ma.act = act;
-    ma.stats = stats; ma.B = B; ma.rows = rows;
-    TRY(mlp_fused_h8_launch(ma, C, width, s), "mlp_fused_h8");
+    if (W0 && W2) TRY(mlp_fused_w_image_launch(W0, W2, wsplit, C, width, s), "mlp_fused_w(image)");   // W0 == NULL: image ready
+    MlpWArgs ma{};
+    ma.x = x; ma.out = out; ma.pro_a = pro_a; ma.pro_o = pro_o; ma.w_img = wsplit; ma.b0 = b0; ma.b2 = b2; ma.alpha = alpha; ma.act = act; ma.stats = stats;
+    ma.B = B; ma.rows = rows; ma.dbg_u = dbg_u;
+    TRY(mlp_fused_w_launch(ma, C, width, s), "mlp_fused_w");
     return 0;
 }
 
-size_t gecco_mlp_fused_h8_wsplit_bytes(int C, int width) { return mlp_fused_h8_supported(C, width, 128) ? mlp_fused_h8_image_bytes(C, width) : 0; }
+size_t gecco_mlp_fused_w_wsplit_bytes(int C, int width) { return mlp_fused_w_image_bytes(C, width); }
 
 size_t gecco_unpool_outproj_h8_wsplit_bytes(int B, int C, int H) {
     if (H <= 0 || C % H) return 0;
@@ -1671,7 +1674,7 @@ int gecco_ray_network_fwd_f32(const GeccoRayNetwork* m, const float* x, const fl
     // point_features = xyz_features + Linear(GN16(lookup))  (models/ray.py:112-113): GN apply in the GEMM
     // prologue, the add as its residual, the first AdaGN's statistics in its epilogue
     TRY(linear(w.raw, m->img_w, m->img_b, w.a_raw, w.o_raw, nullptr, w.feat, w.feat, w.stats_x, B, N, a.c_total, C, 0,
-               s, m->backbone.precision == 3 ? 1 : m->backbone.precision, w.wsplit), "img_feature_proj");   // mixed mode: split-bf16
+               s, m->backbone.precision >= 3 ? 1 : m->backbone.precision, w.wsplit), "img_feature_proj");   // mixed mode: split-bf16
     rc = st_forward(&m->backbone, w.feat, w.coef + 4 * (size_t)B, w.stats_x, row_tiles_gemm(N), h_in, h_out,
                     w.stats_out, B, N, w.st_ws, w.st_bytes, s);
     if (rc) return rc;

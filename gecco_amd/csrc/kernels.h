@@ -160,22 +160,24 @@ size_t unpool_outproj_h8_kv_bytes(int B, int C, int H);
 int kvh_image_launch(const float* kvh, void* img, int B, int C, int H, hipStream_t st);   // kvh (B, 64, 2C) fp32
 int unpool_outproj_h8_launch(const UnpoolH8Args& g, int C, hipStream_t st);
 
-// mlp_fused_h8.hip — mixed mode: x += mlp.2(act(mlp.0(AdaGN(x)))) + GroupNorm partials in one launch, h8 arithmetic, the hidden
-// layer never leaves the CU (8 waves in two roles per 128-row block)
-struct MlpH8Args {
-    float* x;                 // (B, rows, C) fp32, updated in place
+// mlp_fused_w.hip — "w2" mode: x (or out) = x + mlp.2(act(mlp.0(AdaGN(x)))) + GroupNorm partials in one launch: 4 waves of 512 registers per
+// 128-row tile, the hidden layer kept as register fragments; fp16 products with fp6 block-scaled second terms (y and both weights two-term,
+// the hidden layer one-term)
+struct MlpWArgs {
+    const float* x;           // (B, rows, C) fp32
+    float* out;               // (B, rows, C) fp32; may be x (a block reads a row tile before it writes it)
     const float *pro_a, *pro_o;   // (B, C) AdaGN coefficients of mlp_norm
-    const void* w_img;        // mlp_fused_h8_image_launch: W0 / W2 stages in the kernel's consumption order
+    const void* w_img;        // mlp_fused_w_image_launch: the layer's weight stream in the kernel's consumption order
     const float *b0, *b2, *alpha;
     int act;                  // 0 none, 1 / 2 GaussianActivation normalized / raw, 3 ReLU
     float* stats;             // (B, rows / 128, 2, C) or null
     int B, rows;
-    int rev;                  // set by the launcher
+    float* dbg_u;             // diagnostics: (B, rows, width) pre-activations of mlp.0, or null
 };
-bool mlp_fused_h8_supported(int C, int Wd, int rows);
-size_t mlp_fused_h8_image_bytes(int C, int Wd);
-int mlp_fused_h8_image_launch(const float* W0, const float* W2, void* img, int C, int Wd, hipStream_t st);
-int mlp_fused_h8_launch(const MlpH8Args& g, int C, int Wd, hipStream_t st);
+bool mlp_fused_w_supported(int C, int Wd, int rows);
+size_t mlp_fused_w_image_bytes(int C, int Wd);
+int mlp_fused_w_image_launch(const float* W0, const float* W2, void* img, int C, int Wd, hipStream_t st);
+int mlp_fused_w_launch(const MlpWArgs& g, int C, int Wd, hipStream_t st);
 
 // gemm_tn_x3.hip — split-bf16 weight gradients: C[g] = sum over the samples of group g of A[z]^T B[z]
 struct TnArgs {

@@ -1,0 +1,734 @@
+// The point MLP of a layer as ONE launch, the hidden layer never leaves the registers (gfx950):
+//
+//     x += mlp.2( act( mlp.0( AdaGN(x) ) ) ),  + the GroupNorm column partials of the new x      (feature_dim 384, width 768)
+//
+// Reference: models/set_transformer.py:164-166 (x = x + self.mlp(self.mlp_norm(x, t_embed))), models/mlp.py:5-39,
+// models/activation.py:17-24, models/normalization.py:36-44.
+//
+// Arithmetic ("w2" mode).  y = AdaGN(x) and both weights carry two terms, the hidden layer one (its second term is what no
+// register budget holds, see below): with y = yh + yl (yh = fp16(y)), W = Wh + Wl, h = act(u), hh = fp16(h):
+//
+//     u   = yh W1h + fp6(yh) fp6(W1l) + fp6(yl) fp6(W1) + b1        (fp16 MFMA + two fp6 x fp6 block-scaled MFMAs: 1.5 matrix units)
+//     out = hh W2h + fp6(hh) fp6(W2l) + b2 + x                       (1.25 matrix units)
+//
+// The fp6 operands (e2m3) carry one E8M0 scale per lane and 64-k group — the lane's 32 values ARE a scale block of
+// v_mfma_scale_f32_32x32x64_f8f6f4 (gemm_h8_astat.hip's "h6" terms).  Per-site emulation (tools/experiments/precision_search.py,
+// profiles/r03_precision_search.txt): dropping ONLY mlp.2's activation term moves the network's F_x from 6.6e-5 to 3.6e-4; dropping
+// mlp.0's as well gives 6.2e-4 (over the 5e-4 bar of this mode), so mlp.0 keeps it.
+//
+// Structure.  Neither "output stationary" (32 x 384 accumulators = 192 registers, beside 96 + 36 of y) nor any split of the
+// products over two waves of a SIMD fits 256 registers per wave, so a block is 4 waves of 512 registers, ONE
+// per SIMD, 32 rows each, and the work of a 128-row tile is ordered so that the big operand changes between two phases:
+//   phase 1  (12 hidden tiles of 64 columns): y stationary (96 + 36 registers), W1 streams; the tile's activation is kept as the
+//            fp16 fragments of mlp.2's ROW operand — an accumulator of v_mfma_32x32 holds one point per lane and 16 hidden
+//            columns in its registers, which is an operand fragment as it stands (k order 8 (e >> 2) + 4 h + (e & 3), the W2
+//            stream is written in that order) — 192 registers for all 768 hidden columns, parked in the accumulator file;
+//   phase 2  (12 output blocks of 32 columns): h stationary, W2 streams, 16 accumulator registers per block; the block's
+//            residual rows are loaded when it starts and the result (2 x 128 contiguous bytes per register and instruction),
+//            its bias, the residual and the GroupNorm column sums leave while the next block's products run.
+// One instruction stream per SIMD has no partner to hide anything: fragment reads of set n + 1 are issued before the matrix
+// instructions of set n and fenced there (sched_barrier: left alone the scheduler serialises read -> wait -> MFMA to save
+// registers), the LDS-DMA pieces of a stage are spread over its sets (one to two between matrix groups), the stream is
+// FRAGMENT-MAJOR — every operand of every matrix instruction is a contiguous 1 KiB chunk, lane l at byte 16 l — so a fragment read is
+// base + immediate, conflict-free, with no swizzle arithmetic, and the activation of tile t runs under the matrix work it does
+// not depend on.  Ring: 3 slots of 44 KiB; a stage is half a unit (hidden tile / output block): 44 chunks in phase 1, 36 in
+// phase 2; one block barrier per stage (30 - 36 matrix instructions).  Blocks are persistent (grid = CUs): the stream wraps,
+// so the first stages of the next row tile arrive during the last output blocks of this one.
+//
+// Probe with per-ingredient switches and stamps: tools/probe/mlpw_probe.hip (main loops), tools/probe/mlpfw_probe.hip (this kernel
+// against a float64 reference).
+#include "common.h"
+#include "h8_scales.h"
+#include "kernels.h"
+
+#include <stdlib.h>
+
+#include <utility>
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x6 __attribute__((ext_vector_type(6)));
+
+constexpr int W_C = 384, W_WD = 768;
+constexpr int W_NG = 6;                    // 64-k groups of mlp.0
+constexpr int W_NT = 12;                   // 64-column hidden tiles = 64-k groups of mlp.2
+constexpr int W_NB = 12;                   // 32-column output blocks
+constexpr int W_SLOT = 44 * 1024;          // ring slot (bytes)
+constexpr int W_NS = 3;
+constexpr int W_CH1 = 44, W_CH2 = 36;      // chunks of a stage, phase 1 / phase 2
+constexpr int W_NP1 = W_CH1 / 4, W_NP2 = W_CH2 / 4;   // 1 KiB pieces per wave and stage
+constexpr size_t W_STREAM = (size_t)2 * W_NT * W_CH1 * 1024 + (size_t)2 * W_NB * W_CH2 * 1024;   // 1920 KiB per layer
+constexpr int W_STG = 4096;                // wave-private staging tile of the y build: [32 rows][64 fp16]
+// LDS (bytes): ring | staging (4 waves; later the column partials [4][2][384] floats) | b1 | b2 | pro_a | pro_o
+constexpr int W_LDS = W_NS * W_SLOT + 4 * W_STG + (W_WD + W_C + 2 * W_C) * 4;
+static_assert(W_LDS <= 160 * 1024 && 4 * W_STG >= 4 * 2 * W_C * 4, "one block per CU; the column partials fit the staging tiles");
+
+constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 0xF) | (0x7 << 4) | ((lgkm & 0xF) << 8) | ((vm >> 4) << 14); }
+template <int N>
+__device__ __forceinline__ void wait_vm() { __builtin_amdgcn_s_waitcnt(waitcnt_imm(N, 0xF)); }
+__device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0)); }
+
+template <int... I, class F>
+__device__ __forceinline__ void static_for_w(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void sfor(F&& f) { static_for_w(std::make_integer_sequence<int, N>{}, f); }
+#define W_IC(v) std::integral_constant<int, (v)>{}
+
+#ifdef MFW_DIAG_NOMFMA
+__device__ __forceinline__ f32x16 w_keep16(f16x8 a, f16x8 b, f32x16 c) { asm volatile("" ::"v"(a), "v"(b)); return c; }
+__device__ __forceinline__ f32x16 w_keep6(i32x8 a, i32x8 b, f32x16 c, int sa, int sb) { asm volatile("" ::"v"(a), "v"(b), "v"(sa), "v"(sb)); return c; }
+#define W_MFMA16(a, b, c) w_keep16(a, b, c)
+#define W_MFMA6_(a, b, c, osa, sa, osb, sb) w_keep6(a, b, c, sa, sb)
+#else
+#define W_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define W_MFMA6_(a, b, c, osa, sa, osb, sb) __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 2, 2, osa, sa, osb, sb)
+#endif
+#define W_MFMA6(a, b, c, ...) W_MFMA6_(a, b, c, __VA_ARGS__)   // (the scale arguments come out of W_SB: expanded first)
+#define W_SCHED() __builtin_amdgcn_sched_barrier(0)
+// a scale byte of a register holding four: selected by the instruction (op_sel), or (diagnostic build) shifted down first
+#ifdef MFW_DIAG_OPSEL0
+#define W_SB(reg, byte) 0, ((reg) >> (8 * (byte)))
+#else
+#define W_SB(reg, byte) (byte), (reg)
+#endif
+
+#ifdef MFW_STAMPS
+__device__ unsigned long long g_mfw_stamps[1024 * 8];
+#define WSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_mfw_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WSTAMP(i)
+#endif
+
+// E8M0 byte of the block scale for a block whose largest magnitude is m: m / 2^(byte - 127) in (3.75, 7.5] (e2m3's top binades)
+__device__ __forceinline__ int w_scale_byte(float m) {
+    const int e = (int)(__float_as_uint(m * (16.0f / 15.0f)) >> 23) - 2;
+    return m > 0.f ? (e < 1 ? 1 : e) : 127;
+}
+__device__ __forceinline__ float w_scale_of(int byte) { return __uint_as_float((unsigned)byte << 23); }
+template <int K>
+__device__ __forceinline__ f16x8 w_sub(const f16x32& v) {
+    return __builtin_shufflevector(v, v, 8 * K, 8 * K + 1, 8 * K + 2, 8 * K + 3, 8 * K + 4, 8 * K + 5, 8 * K + 6, 8 * K + 7);
+}
+// largest magnitude of a lane's 32 halves (gemm_h8_astat.hip's h6_absmax32: sign bits masked, packed fp16 maxima)
+__device__ __forceinline__ float w_absmax32(const f16x32& v) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    auto ab = [](f16x8 a) {
+        u32x4 u = __builtin_bit_cast(u32x4, a);
+        u &= 0x7fff7fffu;
+        return __builtin_bit_cast(f16x8, u);
+    };
+    const f16x8 m = __builtin_elementwise_max(__builtin_elementwise_max(ab(w_sub<0>(v)), ab(w_sub<1>(v))), __builtin_elementwise_max(ab(w_sub<2>(v)), ab(w_sub<3>(v))));
+    const h2 m2 = __builtin_elementwise_max(__builtin_elementwise_max(h2{m[0], m[1]}, h2{m[2], m[3]}), __builtin_elementwise_max(h2{m[4], m[5]}, h2{m[6], m[7]}));
+    return fmaxf((float)m2[0], (float)m2[1]);
+}
+__device__ __forceinline__ i32x8 w_op6(const u32x4& a, const u32x2& b) {
+    return i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], 0, 0};
+}
+__device__ __forceinline__ i32x8 w_op6(const u32x6& a) { return i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)a[4], (int)a[5], 0, 0}; }
+
+// hidden column (inside its 64-column tile) / k of mlp.2 (inside its 64-k group) of element i (0 .. 31) of a lane of half h: the order in
+// which two 32 x 32 accumulators (blocks j = i >> 4) hold a point's 32 values of the tile
+__host__ __device__ __forceinline__ int w_kmap(int h, int i) { return 32 * (i >> 4) + 16 * ((i >> 3) & 1) + 8 * ((i >> 2) & 1) + 4 * h + (i & 3); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The weight stream of a layer (W_STREAM bytes), in consumption order.  1 KiB chunks; lane l = 32 h + r.
+// Phase 1, stage (t, half), groups g = 3 half + gi:  chunk 0 header: byte 4 gi + 2 term + j of lane l = scale byte of the lo operand
+//   (term 0: W1 - fp16(W1), term 1: W1; hidden block j) of that lane; chunk 1 unused; group gi at chunk 2 + 14 gi:
+//     + 2 s + j (s = 0 .. 3): fp16(W1[64 t + 32 j + r][64 g + 16 s + 8 h + e]), e = 0 .. 7
+//     + 8 + j: dwords 0 - 3 of the term-0 operand of block j;  + 10: its dwords 4 - 5, [j][lane] 8 bytes each
+//     + 11 + j, + 13: the same for term 1
+//   a lo operand = 32 values X[64 t + 32 j + r][64 g + 16 (i >> 3) + 8 h + (i & 7)] / 2^(scale - 127) as fp6 (e2m3), element i at bit 6 i
+// Phase 2, stage (nb, half), hidden tiles t = 6 half + 2 pi + tt:  chunk 0 header: byte 2 pi + tt = scale byte of tile t's lo operand;
+//   pair pi at chunk 1 + 11 pi:  + 5 tt + s: fp16(W2[32 nb + r][64 t + kmap(h, 8 s + e)]);  + 5 tt + 4: dwords 0 - 3 of the lo operand
+//   (W2 - fp16(W2) at [32 nb + r][64 t + kmap(h, i)]);  + 10: dwords 4 - 5, [tt][lane];  chunks 34, 35 unused.
+// One thread per 16-byte item.
+struct WLo {
+    u32x6 pk;
+    int sb;
+};
+__device__ __forceinline__ WLo w_lo_pack(const float (&v)[32]) {
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) m = fmaxf(m, fabsf(v[i]));
+    WLo r;
+    r.sb = w_scale_byte(m);
+    const float inv = __uint_as_float((unsigned)(254 - r.sb) << 23);   // 2^(127 - sb): exact
+    f16x32 vh;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) vh[i] = (_Float16)(v[i] * inv);
+    r.pk = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(vh, 1.0f);
+    return r;
+}
+// the lo operand of phase 1: (t, g, j, term) of lane (r, h)
+__device__ __forceinline__ WLo w_lo1(const float* __restrict__ W1, int t, int g, int j, int term, int r, int h) {
+    const float* src = W1 + (size_t)(64 * t + 32 * j + r) * W_C + 64 * g + 8 * h;
+    float v[32];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(src + 16 * s + 4 * c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[8 * s + 4 * c + e] = term == 0 ? w[e] - (float)(_Float16)w[e] : w[e];
+        }
+    return w_lo_pack(v);
+}
+// the lo operand of phase 2: (nb, t) of lane (r, h)
+__device__ __forceinline__ WLo w_lo2(const float* __restrict__ W2, int nb, int t, int r, int h) {
+    const float* src = W2 + (size_t)(32 * nb + r) * W_WD + 64 * t + 4 * h;
+    float v[32];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {   // elements 4 q .. 4 q + 3: k = 8 q + 4 h + e
+        const f32x4 w = *reinterpret_cast<const f32x4*>(src + 8 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * q + e] = w[e] - (float)(_Float16)w[e];
+    }
+    return w_lo_pack(v);
+}
+
+__global__ void mlpw_image_kernel(const float* __restrict__ W1, const float* __restrict__ W2, unsigned* __restrict__ img) {
+    const size_t items = W_STREAM / 16;
+    for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (size_t)gridDim.x * blockDim.x) {
+        u32x4 out = {0u, 0u, 0u, 0u};
+        const size_t p1_items = (size_t)2 * W_NT * W_CH1 * 64;
+        if (it < p1_items) {
+            const int stage = (int)(it / (W_CH1 * 64)), ci = (int)(it % (W_CH1 * 64));
+            const int chunk = ci >> 6, l = ci & 63, t = stage >> 1, half = stage & 1;
+            if (chunk == 0) {
+                const int r = l & 31, h = l >> 5;
+#pragma unroll 1
+                for (int b = 0; b < 12; ++b) {
+                    const int gi = b >> 2, term = (b >> 1) & 1, j = b & 1;
+                    out[b >> 2] |= (unsigned)w_lo1(W1, t, 3 * half + gi, j, term, r, h).sb << (8 * (b & 3));
+                }
+            } else if (chunk >= 2) {
+                const int gi = (chunk - 2) / 14, c = (chunk - 2) % 14, g = 3 * half + gi;
+                if (c < 8) {
+                    const int s = c >> 1, j = c & 1, r = l & 31, h = l >> 5;
+                    const float* src = W1 + (size_t)(64 * t + 32 * j + r) * W_C + 64 * g + 16 * s + 8 * h;
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(src), w1 = *reinterpret_cast<const f32x4*>(src + 4);
+                    f16x8 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = (_Float16)w0[e];
+                        v[4 + e] = (_Float16)w1[e];
+                    }
+                    out = __builtin_bit_cast(u32x4, v);
+                } else if (c == 8 || c == 9 || c == 11 || c == 12) {
+                    const int term = c >= 11, j = (c - (term ? 11 : 8));
+                    const WLo o = w_lo1(W1, t, g, j, term, l & 31, l >> 5);
+                    out = u32x4{o.pk[0], o.pk[1], o.pk[2], o.pk[3]};
+                } else {   // c == 10 / 13: [j][lane] 8 bytes; this item = lanes 2 q, 2 q + 1 of block j
+                    const int term = c == 13, j = l >> 5, q = l & 31;
+                    const WLo a = w_lo1(W1, t, g, j, term, (2 * q) & 31, (2 * q) >> 5), b = w_lo1(W1, t, g, j, term, (2 * q + 1) & 31, (2 * q + 1) >> 5);
+                    out = u32x4{a.pk[4], a.pk[5], b.pk[4], b.pk[5]};
+                }
+            }
+        } else {
+            const size_t i2 = it - p1_items;
+            const int stage = (int)(i2 / (W_CH2 * 64)), ci = (int)(i2 % (W_CH2 * 64));
+            const int chunk = ci >> 6, l = ci & 63, nb = stage >> 1, half = stage & 1;
+            if (chunk == 0) {
+                const int r = l & 31, h = l >> 5;
+#pragma unroll 1
+                for (int b = 0; b < 6; ++b) out[b >> 2] |= (unsigned)w_lo2(W2, nb, 6 * half + b, r, h).sb << (8 * (b & 3));
+            } else if (chunk < 34) {
+                const int pi = (chunk - 1) / 11, q = (chunk - 1) % 11;
+                if (q == 10) {
+                    const int tt = l >> 5, ql = l & 31, t = 6 * half + 2 * pi + tt;
+                    const WLo a = w_lo2(W2, nb, t, (2 * ql) & 31, (2 * ql) >> 5), b = w_lo2(W2, nb, t, (2 * ql + 1) & 31, (2 * ql + 1) >> 5);
+                    out = u32x4{a.pk[4], a.pk[5], b.pk[4], b.pk[5]};
+                } else {
+                    const int tt = q / 5, s = q % 5, t = 6 * half + 2 * pi + tt, r = l & 31, h = l >> 5;
+                    if (s == 4) {
+                        const WLo o = w_lo2(W2, nb, t, r, h);
+                        out = u32x4{o.pk[0], o.pk[1], o.pk[2], o.pk[3]};
+                    } else {
+                        // element e of k-step s: k = kmap(h, 8 s + e) = 32 (s >> 1) + 16 (s & 1) + 8 (e >> 2) + 4 h + (e & 3)
+                        const float* src = W2 + (size_t)(32 * nb + r) * W_WD + 64 * t + 32 * (s >> 1) + 16 * (s & 1) + 4 * h;
+                        const f32x4 w0 = *reinterpret_cast<const f32x4*>(src), w1 = *reinterpret_cast<const f32x4*>(src + 8);
+                        f16x8 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = (_Float16)w0[e];
+                            v[4 + e] = (_Float16)w1[e];
+                        }
+                        out = __builtin_bit_cast(u32x4, v);
+                    }
+                }
+            }
+        }
+        *reinterpret_cast<u32x4*>(img + it * 4) = out;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+struct WBuf {       // the operands of one set of matrix instructions: up to six 16-byte and four 8-byte fragment reads
+    u32x4 q[6];
+    u32x2 d[4];
+};
+
+// pieces [a, b) of the NP pieces a wave contributes to a stage, after set i of NSETS
+template <int I, int NSETS, int NP>
+struct WSpan {
+    static constexpr int a = I * NP / NSETS, b = (I + 1) * NP / NSETS;
+};
+
+template <int ACT>
+__global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ring = smem;
+    char* const stg = ring + W_NS * W_SLOT;
+    float* const b1_lds = reinterpret_cast<float*>(stg + 4 * W_STG);
+    float* const b2_lds = b1_lds + W_WD;
+    float* const pro_lds = b2_lds + W_C;                 // pa[0 .. C) | po[0 .. C)
+    float* const colp = reinterpret_cast<float*>(stg);   // [4 waves][2][C] column partials of a tile (the staging tiles are idle then)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int tilesM = g.rows >> 7, ntiles = g.B * tilesM;
+
+    WSTAMP(0);
+    for (int i = tid; i < W_WD; i += 256) b1_lds[i] = g.b0 ? g.b0[i] : 0.f;
+    for (int i = tid; i < W_C; i += 256) b2_lds[i] = g.b2 ? g.b2[i] : 0.f;
+
+    // ---- the weight stream: a wave's pieces of a stage are NP consecutive chunks; the stream wraps (the next tile's first stages)
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.w_img), 0, 0x7fffffff, 0x00020000);
+    const unsigned voff16 = (unsigned)lane * 16u;
+    unsigned soff = 0;          // stream offset of the stage being issued
+    int islot = 0;              // its ring slot
+    int istage = 0;             // its index in the tile's 48 stages: < 24 phase 1
+    auto issue_piece = [&](int np, int p) {
+#ifndef MFW_DIAG_NODMA
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(ring + islot * W_SLOT + (wave * np + p) * 1024), 16, voff16,
+                                                 soff + (unsigned)((wave * np + p) * 1024), 0, 0);
+#endif
+    };
+    auto issue_advance = [&]() {
+        soff += (istage < 2 * W_NT ? W_CH1 : W_CH2) * 1024u;
+        istage = istage + 1;
+        if (istage == 2 * W_NT + 2 * W_NB) {
+            istage = 0;
+            soff = 0;
+        }
+        islot = islot + 1 == W_NS ? 0 : islot + 1;
+    };
+    // pieces of the stage being issued that go behind set I of a stage of NSETS sets; TYPE1: the issued stage is a phase-1 stage
+    auto issue_after = [&](auto I, auto NSETS, auto TYPE1) {
+        constexpr int i = decltype(I)::value, nsets = decltype(NSETS)::value;
+        constexpr int np = decltype(TYPE1)::value ? W_NP1 : W_NP2;
+        typedef WSpan<i, nsets, np> S;
+#pragma unroll
+        for (int p = S::a; p < S::b; ++p) issue_piece(np, p);
+        if constexpr (i == nsets - 1) issue_advance();
+    };
+#pragma unroll
+    for (int s = 0; s < W_NS - 1; ++s) {
+#pragma unroll
+        for (int p = 0; p < W_NP1; ++p) issue_piece(W_NP1, p);
+        issue_advance();
+    }
+
+    // ---- fragment reads (LDS-typed pointers throughout: a generic pointer behind an opaque asm turns its reads into flat loads, which
+    // count on BOTH wait counters and drain the DMA queue)
+    typedef const __attribute__((address_space(3))) char* lds_cptr;
+    const lds_cptr lb16 = (lds_cptr)ring + lane * 16;
+    const lds_cptr lb8 = (lds_cptr)ring + lane * 8;
+    int rslot = 0;              // slot of the stage being computed
+    lds_cptr sb16 = lb16, sb8 = lb8, nb16 = lb16, nb8 = lb8;   // bases of the stage being read / of the next one
+    lds_cptr sb8b = lb8 + 512, nb8b = lb8 + 512;                 // + 512: the second block's 8-byte parts through their own base register (two
+                                                                // reads off one base become ds_read2st64_b64 + four moves into the operand tuples)
+    auto rd16 = [&](lds_cptr base, int chunk) { return *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(base + chunk * 1024); };
+    auto rd8 = [&](lds_cptr base, int chunk, int half) { return *reinterpret_cast<const __attribute__((address_space(3))) u32x2*>(base + chunk * 1024 + half * 512); };
+    // phase 1: set k (0 / 1) of group gi (0 .. 2) of the stage at (b16, b8) — six matrix instructions each (192 cycles: the time the next
+    // set's fragment reads have to arrive): k-steps 0 .. 2 of both hidden blocks | k-step 3 and the four fp6 operands
+    auto load_p1 = [&](lds_cptr b16, lds_cptr b8, lds_cptr b8b, auto GI, auto K, WBuf& f) {
+        constexpr int c0 = 2 + 14 * decltype(GI)::value, k = decltype(K)::value;
+        if constexpr (k == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) f.q[i] = rd16(b16, c0 + i);
+        } else {
+            f.q[0] = rd16(b16, c0 + 6);
+            f.q[1] = rd16(b16, c0 + 7);
+            f.q[2] = rd16(b16, c0 + 8);
+            f.d[0] = rd8(b8, c0 + 10, 0);
+            f.q[3] = rd16(b16, c0 + 9);
+            f.d[1] = rd8(b8b, c0 + 10, 0);
+            f.q[4] = rd16(b16, c0 + 11);
+            f.d[2] = rd8(b8, c0 + 13, 0);
+            f.q[5] = rd16(b16, c0 + 12);
+            f.d[3] = rd8(b8b, c0 + 13, 0);
+        }
+    };
+    // phase 2: tile tt (0 / 1) of pair pi (0 .. 2)
+    auto load_p2 = [&](lds_cptr b16, lds_cptr b8, auto PI, auto TT, WBuf& f) {
+        constexpr int c0 = 1 + 11 * decltype(PI)::value, tt = decltype(TT)::value;
+#pragma unroll
+        for (int s = 0; s < 5; ++s) f.q[s] = rd16(b16, c0 + 5 * tt + s);
+        f.d[0] = rd8(b8, c0 + 10, tt);
+    };
+    // entering a stage: the NEXT stage has landed for every wave (its first fragments are read across the boundary), the slot of the
+    // previous one may be refilled.  ALLOW: vector-memory operations younger than the awaited pieces that may stay in flight
+    auto stage_enter = [&](auto ALLOW) {
+        wait_vm<decltype(ALLOW)::value>();
+        __builtin_amdgcn_s_barrier();
+        sb16 = lb16 + rslot * W_SLOT;
+        sb8 = lb8 + rslot * W_SLOT;
+        rslot = rslot + 1 == W_NS ? 0 : rslot + 1;
+        nb16 = lb16 + rslot * W_SLOT;
+        nb8 = lb8 + rslot * W_SLOT;
+        sb8b = sb8 + 512;
+        nb8b = nb8 + 512;
+        asm volatile("" : "+v"(sb8b), "+v"(nb8b));
+    };
+
+    wait_vm<0>();
+    wait_lgkm0();
+    __builtin_amdgcn_s_barrier();          // the first two stages are in the ring, the bias tables are written
+    WBuf bufA, bufB;
+    load_p1(lb16, lb8, lb8 + 512, W_IC(0), W_IC(0), bufA);
+
+    // per-lane LDS bases behind an opaque asm: left as constants (beyond the 16-bit offset field) every distinct address becomes a register
+    lds_cptr b1base = (lds_cptr)(reinterpret_cast<const char*>(b1_lds)) + 16 * h;
+    lds_cptr probase = (lds_cptr)(reinterpret_cast<const char*>(pro_lds)) + 16 * (lane & 15);
+    asm volatile("" : "+v"(b1base), "+v"(probase));
+    const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // activation constants: exp(-u^2 / (2 a^2)) = exp2(-(u s)^2)
+    const float alpha = (ACT == 1 || ACT == 2) ? g.alpha[0] : 1.f;
+    const float s_act = (ACT == 1 || ACT == 2) ? 0.84932180028801907f / fabsf(alpha) : 1.f;   // sqrt(log2(e) / 2) / |alpha|
+    int opq = 0;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tilesM, rt = tile - b * tilesM;
+        const size_t row0 = (size_t)b * g.rows + (size_t)rt * 128 + wave * 32;
+        WSTAMP(1);
+        // ---- AdaGN coefficients of the sample (every wave has left the previous tile's reduction: the barrier that ended it)
+        for (int i = tid; i < W_C; i += 256) {
+            pro_lds[i] = g.pro_a[(size_t)b * W_C + i];
+            pro_lds[W_C + i] = g.pro_o[(size_t)b * W_C + i];
+        }
+        wait_lgkm0();
+        __builtin_amdgcn_s_barrier();
+
+        // ---- y = AdaGN(x) of the wave's 32 rows: fa[g] = fp16(y) as the fragments of the four k-steps of group g (element 8 s + e of lane
+        // (r, h): k = 64 g + 16 s + 8 h + e), yl6[g] = fp6(2^11 (y - fp16(y)) / block scale), by[g] / yls[g] the scale bytes of the fp6 forms
+        f16x32 fa[W_NG];
+        u32x6 yl6[W_NG];
+        float byf[W_NG];            // 2^(scale byte - 127) of fp6(yh): the conversions' scale operand
+        int byp[2] = {0, 0};        // the same bytes, four per register (the matrix instruction selects one: op_sel)
+        int ylp[2] = {0, 0};        // scale bytes of yl6 x 2^-11
+        {
+            const float* xw = g.x + row0 * W_C;
+            char* sw = stg + wave * W_STG;
+            const int lrow = lane >> 4, c16 = lane & 15;
+            f32x4 xs[2][8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xs[0][i] = *reinterpret_cast<const f32x4*>(xw + (size_t)(4 * i + lrow) * W_C + 4 * c16);
+            sfor<W_NG>([&](auto G) {
+                constexpr int gg = decltype(G)::value;
+                if constexpr (gg + 1 < W_NG) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        xs[(gg + 1) & 1][i] = *reinterpret_cast<const f32x4*>(xw + (size_t)(4 * i + lrow) * W_C + 64 * (gg + 1) + 4 * c16);
+                }
+                const f32x4 pa4 = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(probase + 256 * gg);
+                const f32x4 po4 = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(probase + 4 * W_C + 256 * gg);
+                f16x4 lo16[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int row = 4 * i + lrow;
+                    f16x4 hv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float y = h8_clamp(__builtin_fmaf(xs[gg & 1][i][e], pa4[e], po4[e]));
+                        asm volatile("" : "+v"(y));   // ONE rounded fp32 value feeds the hi rounding and the lo difference
+                        hv[e] = (_Float16)y;
+                        lo16[i][e] = (_Float16)((y - (float)hv[e]) * H8_AL_SCALE);
+                    }
+                    *reinterpret_cast<u32x2*>(sw + row * 128 + (((c16 >> 1) ^ (row & 7)) << 4) + (c16 & 1) * 8) = __builtin_bit_cast(u32x2, hv);
+                }
+                __builtin_amdgcn_wave_barrier();   // a wave's LDS operations execute in order
+                u32x4 fr[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) fr[s] = *reinterpret_cast<const u32x4*>(sw + r * 128 + (((2 * s + h) ^ (r & 7)) << 4));
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int row = 4 * i + lrow;
+                    *reinterpret_cast<u32x2*>(sw + row * 128 + (((c16 >> 1) ^ (row & 7)) << 4) + (c16 & 1) * 8) = __builtin_bit_cast(u32x2, lo16[i]);
+                }
+                __builtin_amdgcn_wave_barrier();
+                u32x4 lr[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) lr[s] = *reinterpret_cast<const u32x4*>(sw + r * 128 + (((2 * s + h) ^ (r & 7)) << 4));
+                __builtin_amdgcn_wave_barrier();
+                f16x32 la;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const f16x8 a = __builtin_bit_cast(f16x8, fr[s]), l8 = __builtin_bit_cast(f16x8, lr[s]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        fa[gg][8 * s + e] = a[e];
+                        la[8 * s + e] = l8[e];
+                    }
+                }
+                const int bl = w_scale_byte(w_absmax32(la));
+                yl6[gg] = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(la, w_scale_of(bl));
+                ylp[gg >> 2] |= (bl > H8_AL_EXP ? bl - H8_AL_EXP : 0) << (8 * (gg & 3));
+                const int bh = w_scale_byte(w_absmax32(fa[gg]));
+                byf[gg] = w_scale_of(bh);
+                byp[gg >> 2] |= bh << (8 * (gg & 3));
+                asm volatile("" : "+v"(yl6[gg]));
+            });
+        }
+        WSTAMP(2);
+
+        // ---- phase 1
+        f16x32 hf[W_NT];    // tile t: element i = act(u)[point r][64 t + kmap(h, i)]
+        int hsp[W_NT / 4] = {0, 0, 0};   // block scale bytes of their fp6 forms, four per register
+        sfor<W_NT>([&](auto T) {
+            constexpr int t = decltype(T)::value;
+            f32x16 au[2];
+            asm volatile("" : "+s"(opq));
+            sfor<2>([&](auto HALF) {
+                constexpr int half = decltype(HALF)::value;
+                stage_enter(W_IC(0));
+                const u32x4 hdr = rd16(sb16, 0);
+                sfor<6>([&](auto I) {
+                    constexpr int i = decltype(I)::value, gi = i >> 1, k = i & 1, gg = 3 * half + gi;
+                    WBuf& bc = (i & 1) ? bufB : bufA;
+                    WBuf& bn = (i & 1) ? bufA : bufB;
+                    // the next set: of this stage, of the next stage, or (last set of phase 1) the first of phase 2
+                    if constexpr (i < 5) load_p1(sb16, sb8, sb8b, W_IC((i + 1) >> 1), W_IC((i + 1) & 1), bn);
+                    else if constexpr (t == W_NT - 1 && half == 1) load_p2(nb16, nb8, W_IC(0), W_IC(0), bn);
+                    else load_p1(nb16, nb8, nb8b, W_IC(0), W_IC(0), bn);
+                    W_SCHED();
+                    if constexpr (k == 0) {
+                        sfor<3>([&](auto S) {
+                            constexpr int s = decltype(S)::value;
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                au[j] = W_MFMA16(__builtin_bit_cast(f16x8, bc.q[2 * s + j]), w_sub<s>(fa[gg]), (gg == 0 && s == 0) ? z16 : au[j]);
+                        });
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) au[j] = W_MFMA16(__builtin_bit_cast(f16x8, bc.q[j]), w_sub<3>(fa[gg]), au[j]);
+                        // yh Wl: fp6(yh / block scale), one conversion instruction (the scale behind an opaque asm keeps it inside the tile)
+                        float sc = byf[gg];
+                        asm volatile("" : "+v"(sc), "+s"(opq));
+                        const u32x6 y6 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(fa[gg], sc);
+#ifndef MFW_DIAG_NOT0
+                        au[0] = W_MFMA6(w_op6(bc.q[2], bc.d[0]), w_op6(y6), au[0], W_SB((int)hdr[gi], 0), W_SB(byp[gg >> 2], gg & 3));
+                        au[1] = W_MFMA6(w_op6(bc.q[3], bc.d[1]), w_op6(y6), au[1], W_SB((int)hdr[gi], 1), W_SB(byp[gg >> 2], gg & 3));
+#endif
+#ifndef MFW_DIAG_NOT1
+                        // yl W
+                        au[0] = W_MFMA6(w_op6(bc.q[4], bc.d[2]), w_op6(yl6[gg]), au[0], W_SB((int)hdr[gi], 2), W_SB(ylp[gg >> 2], gg & 3));
+                        au[1] = W_MFMA6(w_op6(bc.q[5], bc.d[3]), w_op6(yl6[gg]), au[1], W_SB((int)hdr[gi], 3), W_SB(ylp[gg >> 2], gg & 3));
+#endif
+                    }
+                    // the stage two ahead: phase-2 stages from the last hidden tile on
+                    issue_after(I, W_IC(6), W_IC(t < W_NT - 1 ? 1 : 0));
+                    W_SCHED();
+                });
+            });
+            // ---- the tile's activation -> fp16 fragments of mlp.2's row operand (element 16 j + e of the lane: accumulator register e
+            // of block j), the block's scale byte; parked in the accumulator file
+            {
+                float m = 0.f;
+                W_SCHED();
+                // pre-activations = accumulators + bias (registers 4 qq .. 4 qq + 3 of block j: columns 32 j + 8 qq + 4 h + e)
+                sfor<8>([&](auto Q) {
+                    constexpr int q = decltype(Q)::value, j = q >> 2, qq = q & 3;
+                    const f32x4 bs = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(b1base + 4 * (64 * t + 32 * j + 8 * qq));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) au[j][4 * qq + e] += bs[e];
+                });
+                // (diagnostics; the never-taken branch also keeps the register allocator from merging the tiles' live ranges: without one per
+                // tile the first hidden tiles' fragments go to scratch — 128 spilled registers against 16)
+                if (g.dbg_u) {
+                    float* du = g.dbg_u + (row0 + r) * W_WD + 64 * t + 4 * h;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq) *reinterpret_cast<f32x4*>(du + 32 * j + 8 * qq) = f32x4{au[j][4 * qq], au[j][4 * qq + 1], au[j][4 * qq + 2], au[j][4 * qq + 3]};
+                }
+                sfor<8>([&](auto Q) {
+                    constexpr int q = decltype(Q)::value, j = q >> 2, qq = q & 3;
+                    float y[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float uu = au[j][4 * qq + e];
+                        if constexpr (ACT == 1 || ACT == 2) {
+                            const float tt = uu * s_act;
+                            const float E = __builtin_amdgcn_exp2f(tt * -tt);
+                            y[e] = ACT == 1 ? __builtin_fmaf(E, 1.0f / 0.28f, -2.5f) : E;
+                        } else if constexpr (ACT == 3) {
+                            y[e] = h8_clamp(fmaxf(uu, 0.f));
+                        } else {
+                            y[e] = h8_clamp(uu);
+                        }
+                        hf[t][16 * j + 4 * qq + e] = (_Float16)y[e];
+                    }
+                    m = fmaxf(fmaxf(m, fmaxf(fabsf(y[0]), fabsf(y[1]))), fmaxf(fabsf(y[2]), fabsf(y[3])));
+                    W_SCHED();
+                });
+                hsp[t >> 2] |= w_scale_byte(m) << (8 * (t & 3));
+                asm volatile("" : "+a"(hf[t]), "+v"(hsp[t >> 2]));
+                W_SCHED();
+            }
+        });
+        WSTAMP(3);
+
+        // ---- the fp6 forms of the hidden tiles (one conversion each, from the parked fragments)
+        u32x6 h6[W_NT];
+        sfor<W_NT>([&](auto T) {
+            constexpr int t = decltype(T)::value;
+            h6[t] = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(hf[t], w_scale_of((hsp[t >> 2] >> (8 * (t & 3))) & 0xff));
+            asm volatile("" : "+v"(h6[t]));   // these stay in the vector file (the accumulator file holds the 192 registers of hf)
+        });
+
+        // ---- phase 2
+        const float* xres = g.x + (row0 + 4 * h) * W_C + r;     // register e of an accumulator: row (e & 3) + 8 (e >> 2) + 4 h, column 32 nb + r
+        float* xout = g.out + (row0 + 4 * h) * W_C + r;
+        float* cp = colp + wave * 2 * W_C + h * W_C + r;          // lane half 0 writes the column sums, half 1 the sums of squares
+        for (int nb = 0; nb < W_NB; ++nb) {
+            f32x16 acc;
+            f32x16 res;
+            const bool last = nb == W_NB - 1;
+            // the loop's big invariants keep their register files (left alone the allocator rotates the fp6 forms through the accumulator
+            // file: 12 moves per hidden tile and output block)
+            sfor<W_NT>([&](auto T) {
+                constexpr int t = decltype(T)::value;
+                f16x32& a = hf[t];
+                u32x6& c = h6[t];
+                asm volatile("" : "+a"(a), "+v"(c));
+            });
+            sfor<2>([&](auto HALF) {
+                constexpr int half = decltype(HALF)::value;
+                // pieces awaited: the next stage's.  Younger than them: the previous block's 16 stores (first stage of a block but the first)
+                if constexpr (half == 0) {
+                    if (nb == 0) stage_enter(W_IC(0));
+                    else stage_enter(W_IC(16));
+                } else {
+                    stage_enter(W_IC(0));
+                }
+                const u32x4 hdr = rd16(sb16, 0);
+                if constexpr (half == 0) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) res[e] = GECCO_NT_LOAD(xres + (size_t)((e & 3) + 8 * (e >> 2)) * W_C + 32 * nb);
+                }
+                sfor<6>([&](auto I) {
+                    constexpr int i = decltype(I)::value, pi = i >> 1, tt = i & 1, t = 6 * half + i;
+                    WBuf& bc = (i & 1) ? bufB : bufA;
+                    WBuf& bn = (i & 1) ? bufA : bufB;
+                    if constexpr (i < 5) {
+                        load_p2(sb16, sb8, W_IC((i + 1) >> 1), W_IC((i + 1) & 1), bn);
+                    } else if constexpr (half == 0) {
+                        load_p2(nb16, nb8, W_IC(0), W_IC(0), bn);
+                    } else {
+                        if (last) load_p1(nb16, nb8, nb8b, W_IC(0), W_IC(0), bn);      // the next row tile's first set
+                        else load_p2(nb16, nb8, W_IC(0), W_IC(0), bn);
+                    }
+                    W_SCHED();
+                    sfor<4>([&](auto S) {
+                        constexpr int s = decltype(S)::value;
+                        acc = W_MFMA16(w_sub<s>(hf[t]), __builtin_bit_cast(f16x8, bc.q[s]), (t == 0 && s == 0) ? z16 : acc);
+                    });
+#ifndef MFW_DIAG_NOT2
+                    acc = W_MFMA6(w_op6(h6[t]), w_op6(bc.q[4], bc.d[0]), acc, W_SB(hsp[t >> 2], t & 3), W_SB((int)hdr[(2 * pi + tt) >> 2], (2 * pi + tt) & 3));
+#endif
+                    // the stage two ahead: phase-1 stages (of the next row tile) from the last output block on
+                    if (last) issue_after(I, W_IC(6), W_IC(1));
+                    else issue_after(I, W_IC(6), W_IC(0));
+                    W_SCHED();
+                });
+            });
+            // ---- the block's epilogue: bias, residual, store, column sums
+            {
+                const float bias = b2_lds[32 * nb + r];
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float v = (acc[e] + bias) + res[e];
+                    GECCO_NT_STORE(v, xout + (size_t)((e & 3) + 8 * (e >> 2)) * W_C + 32 * nb);
+                    s1 += v;
+                    s2 = __builtin_fmaf(v, v, s2);
+                }
+                if (g.stats) {
+                    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(s1), __float_as_uint(s1), false, false);
+                    const auto c = __builtin_amdgcn_permlane32_swap(__float_as_uint(s2), __float_as_uint(s2), false, false);
+                    const float t1 = __uint_as_float(a[0]) + __uint_as_float(a[1]), t2 = __uint_as_float(c[0]) + __uint_as_float(c[1]);
+                    cp[32 * nb] = h ? t2 : t1;
+                }
+            }
+        }
+        WSTAMP(4);
+        // ---- column partials of the tile: the four waves' sums in a fixed order
+        if (g.stats) {
+            wait_lgkm0();
+            __builtin_amdgcn_s_barrier();
+            for (int i = tid; i < 2 * W_C; i += 256) {
+                const float t = ((colp[i] + colp[2 * W_C + i]) + colp[4 * W_C + i]) + colp[6 * W_C + i];
+                g.stats[((size_t)b * tilesM + rt) * 2 * W_C + i] = t;
+            }
+            wait_lgkm0();
+        }
+        __builtin_amdgcn_s_barrier();      // the staging tiles / coefficient table may be rewritten
+        WSTAMP(5);
+    }
+    wait_vm<0>();   // the wrapped stream's last pieces still target this block's LDS
+}
+
+template <int ACT>
+int mfw_launch_a(const MlpWArgs& g, hipStream_t st) {
+    static bool attr = false;
+    static int cus = 0;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_w_kernel<ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS);
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (cus <= 0) cus = 256;
+        attr = true;
+    }
+    const int ntiles = g.B * (g.rows / 128);
+    const int grid = ntiles < cus ? ntiles : cus;
+    hipLaunchKernelGGL((mlp_fused_w_kernel<ACT>), dim3(grid), dim3(256), W_LDS, st, g);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+bool mlp_fused_w_supported(int C, int Wd, int rows) { return C == W_C && Wd == W_WD && rows >= 128 && rows % 128 == 0; }
+
+size_t mlp_fused_w_image_bytes(int C, int Wd) { return mlp_fused_w_supported(C, Wd, 128) ? W_STREAM : 0; }
+
+int mlp_fused_w_image_launch(const float* W0, const float* W2, void* img, int C, int Wd, hipStream_t st) {
+    if (!mlp_fused_w_supported(C, Wd, 128)) return -9;
+    hipLaunchKernelGGL(mlpw_image_kernel, dim3(480), dim3(256), 0, st, W0, W2, static_cast<unsigned*>(img));
+    return (int)hipGetLastError();
+}
+
+int mlp_fused_w_launch(const MlpWArgs& g, int C, int Wd, hipStream_t st) {
+    if (!mlp_fused_w_supported(C, Wd, g.rows) || !g.x || !g.out || !g.pro_a || !g.pro_o || !g.w_img) return -9;
+    if ((g.act == 1 || g.act == 2) && !g.alpha) return -6;
+    switch (g.act) {
+#ifndef MFW_DEV   // development builds: the GaussianActivation instantiation only (a full build takes over a minute)
+        case 0: return mfw_launch_a<0>(g, st);
+        case 2: return mfw_launch_a<2>(g, st);
+        case 3: return mfw_launch_a<3>(g, st);
+#endif
+        case 1: return mfw_launch_a<1>(g, st);
+        default: return -9;
+    }
+}

@@ -20,7 +20,7 @@ GN_EPS = 1e-5
 
 # Arithmetic of the N-token GEMMs: "fp32" = exact fp32 MFMA (~1e-6 against the fp32 reference), "bf16x3" = split-bf16
 # (hi + lo operands, three bf16 MFMAs per product, fp32 accumulate: ~2e-5, inside the 1e-3 parity bar, ~2x faster).
-PRECISIONS = {"fp32": 0, "bf16x3": 1, "fp16": 2, "mixed": 3}
+PRECISIONS = {"fp32": 0, "bf16x3": 1, "fp16": 2, "mixed": 3, "w2": 4}
 _default_precision = os.environ.get("GECCO_PRECISION", "fp32")
 
 
@@ -367,22 +367,25 @@ def unpool_outproj_f16(x: Tensor, q16: Tensor, kvh: Tensor, W: Tensor, bias: Ten
     return x, stats
 
 
-def mlp_fused_h8(x: Tensor, pro: tuple[Tensor, Tensor], W0: Tensor, b0: Tensor | None, W2: Tensor, b2: Tensor | None,
-                 act_alpha: Tensor | None = None, normalized: bool = True, act: str | int | None = None, want_stats: bool = False,
-                 wsplit: Tensor | None = None, image_ready: bool = False, stats: Tensor | None = None):
-    """x += mlp.2(act(mlp.0(x*pa + po))) in place (mixed mode, one launch, h8 arithmetic); returns (x, stats | None).
-    wsplit / image_ready: caller-owned scratch holding the weight stream of a previous call (kernel launch only)."""
+def mlp_fused_w(x: Tensor, pro: tuple[Tensor, Tensor], W0: Tensor, b0: Tensor | None, W2: Tensor, b2: Tensor | None,
+                act_alpha: Tensor | None = None, normalized: bool = True, act: str | int | None = None, want_stats: bool = False,
+                wsplit: Tensor | None = None, image_ready: bool = False, stats: Tensor | None = None, out: Tensor | None = None,
+                dbg_u: Tensor | None = None):
+    """out (default: x, in place) = x + mlp.2(act(mlp.0(x*pa + po))) ("w2" mode, one launch, the hidden layer kept in registers);
+    returns (out, stats | None).  wsplit / image_ready: caller-owned scratch holding the weight stream of a previous call."""
     lib = _lib.load()
     B, rows, Cc = x.shape
     width = W0.shape[0]
+    if out is None:
+        out = x
     if stats is None and want_stats:
         stats = torch.empty(B, rows // 128, 2, Cc, device=x.device, dtype=torch.float32)
     if wsplit is None:
-        wsplit = _ws(lib.gecco_mlp_fused_h8_wsplit_bytes(Cc, width), x.device)
-    check(lib.gecco_mlp_fused_h8(_ptr(x), _ptr(pro[0]), _ptr(pro[1]), None if image_ready else _ptr(W0), _ptr(b0),
-                                 None if image_ready else _ptr(W2), _ptr(b2), _ptr(act_alpha), act_code(act_alpha, normalized, act),
-                                 _ptr(stats), B, rows, Cc, width, C.c_void_p(wsplit.data_ptr()), _stream()), "gecco_mlp_fused_h8")
-    return x, stats
+        wsplit = _ws(lib.gecco_mlp_fused_w_wsplit_bytes(Cc, width), x.device)
+    check(lib.gecco_mlp_fused_w(_ptr(x), _ptr(out), _ptr(pro[0]), _ptr(pro[1]), None if image_ready else _ptr(W0), _ptr(b0),
+                                None if image_ready else _ptr(W2), _ptr(b2), _ptr(act_alpha), act_code(act_alpha, normalized, act),
+                                _ptr(stats), B, rows, Cc, width, C.c_void_p(wsplit.data_ptr()), _ptr(dbg_u), _stream()), "gecco_mlp_fused_w")
+    return out, stats
 
 
 def unpool_outproj_h8(x: Tensor, q16: Tensor, kvh: Tensor, W: Tensor, bias: Tensor | None, H: int, want_stats: bool = False,

@@ -69,7 +69,10 @@ typedef struct GeccoSetTransformer {  /* SetTransformer, models/set_transformer.
                      * 3 "mixed": kv_proj | q_proj with fp16 activations and two-term fp16 weights, fp16 K | V / q and attention
                      *   products; every product that feeds the residual stream or the shared inducer states (the 64-inducer
                      *   chain, unpool.out_proj, the point MLP) in split-bf16 (~6e-5 on both outputs); point counts that are
-                     *   not a multiple of 128 (and widths / head dims outside the fp16 kernels' set) run as mode 1 */
+                     *   not a multiple of 128 (and widths / head dims outside the fp16 kernels' set) run as mode 1,
+                     * 4 "w2": mode 3 with the point MLP of every layer as ONE launch whose hidden layer stays in registers as fp16
+                     *   (gecco_mlp_fused_w: two-term weights and AdaGN(x), one-term hidden layer): F_x ~3.5e-4, inside a 5e-4 bar;
+                     *   feature_dim 384 with point counts in multiples of 128, anything else runs as mode 3 */
     const GeccoLayer* layers;                       /* HOST array of n_layers tables */
 } GeccoSetTransformer;
 
@@ -104,9 +107,8 @@ int gecco_linear_f32(const float* A, const float* W, const float* bias, const fl
  *   "unpoolh8" (default 1): mixed mode runs unpool attention + out_proj (h8) + residual + statistics as one launch
  *   (gecco_unpool_outproj_h8) instead of the attention writing an h8 activation image for gecco_linear_h8_areg_f32; needs
  *   "kvq64" (head-major fp16 q), "h8areg", feature_dim in {128, 256, 384}.
- *   "mlph8" (default 0: exact, measured slower than its two launches): mixed mode runs the point MLP of a layer (AdaGN apply, mlp.0,
- *   activation, mlp.2, residual, statistics) as one launch (gecco_mlp_fused_h8) instead of gecco_linear_h8_img_f32 +
- *   gecco_linear_h8_areg_f32; feature_dim 384.
+ *   "mlpw" (default 1): the "w2" mode (precision 4) runs the point MLP of a layer (AdaGN apply, mlp.0, activation, mlp.2, residual,
+ *   statistics) as one launch (gecco_mlp_fused_w); 0: as the mixed mode does (gecco_linear_h8_img_f32 + gecco_linear_h8_areg_f32).
  *   "h6" (default 1): mixed mode computes mlp.0's two cross terms as fp6 (e2m3) x fp6 with one E8M0 scale per lane and 64-k group (the
  *   scale blocks of v_mfma_scale_f32_32x32x64_f8f6f4) instead of fp8 with fixed scales: half their matrix cycles, the same accuracy;
  *   gecco_linear_h8_img_f32 with image_kind 2 follows it too.
@@ -323,17 +325,17 @@ int gecco_mlp_fused_f16(float* x, const float* pro_a, const float* pro_o, const 
  * (C, hd) in {(128, 16), (256, 32), (384, 48)}, rows % 128 == 0; wsplit: 2 * C * C bytes. */
 int gecco_unpool_outproj_f16(float* x, const void* q16, const float* kvh, const float* W, const float* bias, float* stats,
                              int B, int rows, int C, int H, void* wsplit, void* stream);
-/* The point MLP of a layer in the MIXED mode, one launch (mlp_fused_h8.hip; option "mlph8"): x += mlp.2(act(mlp.0(x * pro_a +
- * pro_o))) in place, both products in h8 arithmetic (fp16 main product + two fp8 cross terms, as gecco_linear_h8_img_f32 and
- * gecco_linear_h8_areg_f32), the 2 C wide hidden layer never leaves the CU; stats (B, rows / 128, 2, C) or NULL: GroupNorm
- * partials of the updated x.  Replaces models/set_transformer.py:164-166, models/mlp.py:5-39, models/activation.py:17-24,
- * models/normalization.py:36-44.  Equal to the two-launch form up to fp32 summation order in mlp.2 (~1e-6; the hidden layer's
- * bits are the same).  C == 384, width == 2 C, rows % 128 == 0; act 0 .. 3; wsplit: gecco_mlp_fused_h8_wsplit_bytes(C, width);
- * W0 == NULL: the weight stream is ready. */
-int gecco_mlp_fused_h8(float* x, const float* pro_a, const float* pro_o, const float* W0, const float* b0, const float* W2,
-                       const float* b2, const float* alpha, int act, float* stats, int B, int rows, int C, int width,
-                       void* wsplit, void* stream);
-size_t gecco_mlp_fused_h8_wsplit_bytes(int C, int width);
+/* The point MLP of a layer in the "w2" mode, one launch (mlp_fused_w.hip): out = x + mlp.2(act(mlp.0(x * pro_a + pro_o))) — out may be
+ * x — with the 2 C wide hidden layer kept in registers.  Arithmetic: fp16 products with fp6 (e2m3, block-scaled) second terms; AdaGN(x)
+ * and both weights carry two terms, the hidden layer one (fp16): ~2e-4 of the MLP's output scale against fp32, ~3.5e-4 on a network's
+ * F_x (the mixed mode: 6e-5).  stats (B, rows / 128, 2, C) or NULL: GroupNorm partials of out.  Replaces
+ * models/set_transformer.py:164-166, models/mlp.py:5-39, models/activation.py:17-24, models/normalization.py:36-44.
+ * C == 384, width == 2 C, rows % 128 == 0; act 0 .. 3; wsplit: gecco_mlp_fused_w_wsplit_bytes(C, width) bytes; W0 == NULL: the weight
+ * stream of an earlier call is in wsplit.  dbg_u: NULL, or (B, rows, width) receiving mlp.0's pre-activations (diagnostics). */
+int gecco_mlp_fused_w(const float* x, float* out, const float* pro_a, const float* pro_o, const float* W0, const float* b0, const float* W2,
+                      const float* b2, const float* alpha, int act, float* stats, int B, int rows, int C, int width, void* wsplit, float* dbg_u,
+                      void* stream);
+size_t gecco_mlp_fused_w_wsplit_bytes(int C, int width);
 /* The same half of the layer in the MIXED mode, one launch (unpool_outproj_h8.hip; option "unpoolh8", default 1): attention in
  * fp16 (the bits of gecco_unpool_attn_h8img), out_proj as the h8 product (fp16 main product + two fp8 cross terms, as
  * gecco_linear_h8_areg_f32), + bias + residual, in place on x, + GroupNorm partials; the attention output stays in registers as

@@ -24,9 +24,13 @@ pytestmark = pytest.mark.gpu
 # "mixed" = fp16 where the sensitivity analysis (tools/experiments/fp16_site_sensitivity.py) shows operand rounding does not
 # reach the output (kv_proj | q_proj activations, K | V, q, both attention products — with two-term fp16 weights for
 # kv_proj | q_proj), split-bf16 everywhere else: held to the split-bf16 bars.
-BARS = {"fp32": 5e-5, "bf16x3": 2e-4, "fp16": 1e-3, "mixed": 2e-4}
-BARS_FX = {"fp32": 5e-5, "bf16x3": 2e-4, "fp16": 2e-3, "mixed": 2e-4}
-MODES = ["fp32", "bf16x3", "mixed", "fp16"]
+# "w2" = the mixed mode with the point MLP of every layer as ONE launch (csrc/mlp_fused_w.hip): the 768-wide hidden layer stays in
+# registers as fp16 (no second term; AdaGN(x) and both weights keep theirs).  Bar 5e-4 on BOTH outputs, half the north star's 1e-3;
+# measured 2.5e-4 .. 4e-4 on F_x (the per-site emulation, profiles/r03_precision_search.txt, predicts 3.6e-4 at C2).  feature_dim 512
+# (C4) and shapes off the kernel's reach run the mixed mode's launches in this mode.
+BARS = {"fp32": 5e-5, "bf16x3": 2e-4, "fp16": 1e-3, "mixed": 2e-4, "w2": 5e-4}
+BARS_FX = {"fp32": 5e-5, "bf16x3": 2e-4, "fp16": 2e-3, "mixed": 2e-4, "w2": 5e-4}
+MODES = ["fp32", "bf16x3", "mixed", "w2", "fp16"]
 
 
 @pytest.fixture(scope="module")
@@ -85,7 +89,7 @@ def test_c2_full_size_vs_oracle(ops, c2_case, precision):
         _report(f"C2 {precision} D   vs exact-fp32 HIP mode", den, den32.cpu(), BARS[precision])
 
 
-@pytest.mark.parametrize("precision", ["mixed", "bf16x3"])
+@pytest.mark.parametrize("precision", ["mixed", "w2", "bf16x3"])
 def test_c2_headline_batch_vs_oracle(ops, precision):
     """The headline's exact launch shapes (bench.py: B = 64 clouds of N = 2048, d = 384, L = 6 in ONE evaluation) against the
     oracle directly: the samples of a batch are independent (SetTransformer has no cross-sample op), so the oracle runs on four
@@ -191,11 +195,11 @@ def test_fp16_deep_network_weight_staging(ops, d, L):
     x, sigma = _noisy(7, B, N, (0.2, 4.0))
     with torch.no_grad():
         ref, raw_ref = cpu_ref.uncond_denoiser(p, "", cases.H)(x, sigma, return_raw=True)
-    for precision in ("fp16", "bf16x3", "mixed"):
+    for precision in ("fp16", "bf16x3", "mixed", "w2"):   # ("w2": the one-launch point MLP at d = 384, the mixed mode's launches at 256 / 128)
         den, raw = ops.LinearLiftPlan(_cuda(p), cases.H, cases.I, precision=precision).forward(x.cuda(), sigma.cuda(), return_raw=True)
         # error grows with depth (each layer adds its own rounding); the bar stays the north star's
-        _report(f"d={d} L={L} {precision} D", den, ref, 1e-3 if precision == "fp16" else 3e-4)
-        _report(f"d={d} L={L} {precision} F_x", raw, raw_ref, 2e-3 if precision == "fp16" else 3e-4)
+        _report(f"d={d} L={L} {precision} D", den, ref, {"fp16": 1e-3, "w2": 5e-4}.get(precision, 3e-4))
+        _report(f"d={d} L={L} {precision} F_x", raw, raw_ref, {"fp16": 2e-3, "w2": 5e-4}.get(precision, 3e-4))
 
 
 # ------------------------------------------------------------------------------------------------- training path at full size

@@ -327,7 +327,8 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
     // "w2" mode (option "mlpw" = 0 runs it as the mixed mode): the point MLP as ONE launch, the hidden layer kept as register fragments,
     // its second term dropped (mlp_fused_w.hip); the weight stream (1.9 MB at d = 384) has its own workspace slot (o_mf).  Shapes the kernel
     // does not take (feature_dim != 384, point counts off 128) run the mixed mode's two launches — at least as accurate
-    const bool mfw_on = mixed && st->precision == 4 && option(OPT_MLPW) && w.wimg && mlp_fused_w_supported(C, Wd, N);
+    const bool mfw_on = mixed && st->precision == 4 && option(OPT_MLPW) && w.wimg && mlp_fused_w_supported(C, Wd, N) &&
+                        (size_t)B * N * C * sizeof(float) < ((size_t)1 << 31);
     const bool chain_on = pr == 2 && w.wimg && option(OPT_CHAIN) && inducer_chain_f16_supported(C, Wd, H, G, I) &&
                           (ns == 1 || ns == 2 || ns == 4 || ns == 8);
     // mixed mode: the same one-launch chain with TWO-TERM fp16 weights (option "chain2") instead of five 64-row split-bf16 GEMMs
@@ -438,7 +439,7 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
                             "split(mlp.2 K-slice)");
                 }
             } else if (mfw_on) {
-                TRY(mlp_fused_w_image_launch(L.mlp.w0, L.mlp.w2, base + w.o_mf, C, Wd, s), "split(mlp, w2 stream)");
+                TRY(mlp_fused_w_image_launch(L.mlp.w0, L.mlp.b0, L.mlp.w2, L.mlp.b2, base + w.o_mf, C, Wd, L.mlp.alpha, act, s), "split(mlp, w2 stream)");
             } else {
                 if (h8_on) {   // same bytes as the split-bf16 image it replaces: fp16 hi + fp8 lo + fp8 W per element
                     if (jobs8.n >= kJobCap) { TRY(h8_image_multi_launch(jobs8, s), "split(mlp.0, h8)"); jobs8.n = 0; }
@@ -642,7 +643,7 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         const int himg = pr == 1 && !a16 && im && option(OPT_ACTIMG) && N >= 128 && N % 128 == 0 && Wd % 16 == 0 && C % 16 == 0;
         if (m0_done == 1 && mfw_on && im) {
             MlpWArgs ma{};
-            ma.x = x; ma.out = x; ma.pro_a = w.a2; ma.pro_o = w.o2; ma.w_img = im + w.o_mf; ma.b0 = L.mlp.b0; ma.b2 = L.mlp.b2; ma.alpha = L.mlp.alpha;
+            ma.x = x; ma.out = x; ma.pro_a = w.a2; ma.pro_o = w.o2; ma.w_img = im + w.o_mf; ma.alpha = L.mlp.alpha;
             ma.act = act; ma.stats = so; ma.B = B; ma.rows = N;
             if ((act == 1 || act == 2) && !L.mlp.alpha) return fail(-6, "mlp: GaussianActivation needs alpha");
             TRY(mlp_fused_w_launch(ma, C, Wd, s), "mlp (one launch, w2)");
@@ -1243,9 +1244,9 @@ int gecco_mlp_fused_w(const float* x, float* out, const float* pro_a, const floa
     if (act < 0 || act > 3) return fail(-6, "mlp_fused_w: act must be 0 .. 3");
     if ((act == 1 || act == 2) && !alpha) return fail(-6, "mlp_fused_w: GaussianActivation needs alpha");
     hipStream_t s = (hipStream_t)stream;
-    if (W0 && W2) TRY(mlp_fused_w_image_launch(W0, W2, wsplit, C, width, s), "mlp_fused_w(image)");   // W0 == NULL: image ready
+    if (W0 && W2) TRY(mlp_fused_w_image_launch(W0, b0, W2, b2, wsplit, C, width, alpha, act, s), "mlp_fused_w(image)");   // W0 == NULL: image ready (biases included)
     MlpWArgs ma{};
-    ma.x = x; ma.out = out; ma.pro_a = pro_a; ma.pro_o = pro_o; ma.w_img = wsplit; ma.b0 = b0; ma.b2 = b2; ma.alpha = alpha; ma.act = act; ma.stats = stats;
+    ma.x = x; ma.out = out; ma.pro_a = pro_a; ma.pro_o = pro_o; ma.w_img = wsplit; ma.alpha = alpha; ma.act = act; ma.stats = stats;
     ma.B = B; ma.rows = rows; ma.dbg_u = dbg_u;
     TRY(mlp_fused_w_launch(ma, C, width, s), "mlp_fused_w");
     return 0;

@@ -167,16 +167,18 @@ struct MlpWArgs {
     const float* x;           // (B, rows, C) fp32
     float* out;               // (B, rows, C) fp32; may be x (a block reads a row tile before it writes it)
     const float *pro_a, *pro_o;   // (B, C) AdaGN coefficients of mlp_norm
-    const void* w_img;        // mlp_fused_w_image_launch: the layer's weight stream in the kernel's consumption order
-    const float *b0, *b2, *alpha;
+    const void* w_img;        // mlp_fused_w_image_launch: the layer's weight stream in the kernel's consumption order, biases included
+    const float* alpha;
     int act;                  // 0 none, 1 / 2 GaussianActivation normalized / raw, 3 ReLU
     float* stats;             // (B, rows / 128, 2, C) or null
     int B, rows;
-    float* dbg_u;             // diagnostics: (B, rows, width) pre-activations of mlp.0, or null
+    float* dbg_u;             // diagnostics: (B, rows, width) pre-activations of mlp.0 x the activation's argument scale (1 but for act 1 / 2), or null
 };
 bool mlp_fused_w_supported(int C, int Wd, int rows);
 size_t mlp_fused_w_image_bytes(int C, int Wd);
-int mlp_fused_w_image_launch(const float* W0, const float* W2, void* img, int C, int Wd, hipStream_t st);
+// (the stream depends on the activation: mlp.0's weights carry the Gaussian activation's argument scale)
+int mlp_fused_w_image_launch(const float* W0, const float* b0, const float* W2, const float* b2, void* img, int C, int Wd, const float* alpha, int act,
+                             hipStream_t st);
 int mlp_fused_w_launch(const MlpWArgs& g, int C, int Wd, hipStream_t st);
 
 // gemm_tn_x3.hip — split-bf16 weight gradients: C[g] = sum over the samples of group g of A[z]^T B[z]

@@ -65,9 +65,12 @@ constexpr int W_CH1 = 44, W_CH2 = 36;      // chunks of a stage, phase 1 / phase
 constexpr int W_NP1 = W_CH1 / 4, W_NP2 = W_CH2 / 4;   // 1 KiB pieces per wave and stage
 constexpr size_t W_STREAM = (size_t)2 * W_NT * W_CH1 * 1024 + (size_t)2 * W_NB * W_CH2 * 1024;   // 1920 KiB per layer
 constexpr int W_STG = 4096;                // wave-private staging tile of the y build: [32 rows][64 fp16]
-// LDS (bytes): ring | staging (4 waves; later the column partials [4][2][384] floats) | b1 | b2 | pro_a | pro_o
-constexpr int W_LDS = W_NS * W_SLOT + 4 * W_STG + (W_WD + W_C + 2 * W_C) * 4;
-static_assert(W_LDS <= 160 * 1024 && 4 * W_STG >= 4 * 2 * W_C * 4, "one block per CU; the column partials fit the staging tiles");
+// LDS (bytes): ring | 4 wave-private tiles of 4 KiB (the y build's staging; in phase 2 the [32 rows][32 columns] fp32 tile through which the
+// residual rows come in and the results leave in 16-byte pieces) | the tile's column partials [4 waves][2][384] floats, whose first 3 KiB hold
+// the sample's AdaGN coefficients pa | po while the y build runs.  The biases ride in the weight stream's stage headers.
+constexpr int W_COLP = 4 * 2 * W_C * 4;
+constexpr int W_LDS = W_NS * W_SLOT + 4 * W_STG + W_COLP;
+static_assert(W_LDS <= 160 * 1024 && W_COLP >= 2 * W_C * 4 && W_STG == 32 * 32 * 4, "one block per CU");
 
 constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 0xF) | (0x7 << 4) | ((lgkm & 0xF) << 8) | ((vm >> 4) << 14); }
 template <int N>
@@ -103,8 +106,19 @@ __device__ __forceinline__ f32x16 w_keep6(i32x8 a, i32x8 b, f32x16 c, int sa, in
 #ifdef MFW_STAMPS
 __device__ unsigned long long g_mfw_stamps[1024 * 8];
 #define WSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_mfw_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+// accumulated ticks of the last tile: [6] waits + barriers of the stage entries, [7] the activation blocks
+#define WACC_DECL unsigned long long wacc_enter = 0, wacc_act = 0, wacc_epi = 0, wacc_t0 = 0
+#define WACC_RESET() do { wacc_enter = 0; wacc_act = 0; wacc_epi = 0; } while (0)
+#define WACC_BEGIN() do { wacc_t0 = __builtin_amdgcn_s_memtime(); } while (0)
+#define WACC_END(which) do { which += __builtin_amdgcn_s_memtime() - wacc_t0; } while (0)
+#define WACC_STORE() do { if (threadIdx.x == 0 && blockIdx.x < 1024) { g_mfw_stamps[blockIdx.x * 8 + 6] = wacc_enter; g_mfw_stamps[blockIdx.x * 8 + 7] = wacc_act | (wacc_epi << 32); } } while (0)
 #else
 #define WSTAMP(i)
+#define WACC_DECL
+#define WACC_RESET()
+#define WACC_BEGIN()
+#define WACC_END(which)
+#define WACC_STORE()
 #endif
 
 // E8M0 byte of the block scale for a block whose largest magnitude is m: m / 2^(byte - 127) in (3.75, 7.5] (e2m3's top binades)
@@ -141,12 +155,14 @@ __host__ __device__ __forceinline__ int w_kmap(int h, int i) { return 32 * (i >>
 // ---------------------------------------------------------------------------------------------------------------------
 // The weight stream of a layer (W_STREAM bytes), in consumption order.  1 KiB chunks; lane l = 32 h + r.
 // Phase 1, stage (t, half), groups g = 3 half + gi:  chunk 0 header: byte 4 gi + 2 term + j of lane l = scale byte of the lo operand
-//   (term 0: W1 - fp16(W1), term 1: W1; hidden block j) of that lane; chunk 1 unused; group gi at chunk 2 + 14 gi:
+//   (term 0: W1 - fp16(W1), term 1: W1; hidden block j) of that lane; chunk 1: (half 1) floats 0 .. 63 = mlp.0's bias of the tile's 64
+//   hidden columns (x the activation's argument scale, like the weights); group gi at chunk 2 + 14 gi:
 //     + 2 s + j (s = 0 .. 3): fp16(W1[64 t + 32 j + r][64 g + 16 s + 8 h + e]), e = 0 .. 7
 //     + 8 + j: dwords 0 - 3 of the term-0 operand of block j;  + 10: its dwords 4 - 5, [j][lane] 8 bytes each
 //     + 11 + j, + 13: the same for term 1
 //   a lo operand = 32 values X[64 t + 32 j + r][64 g + 16 (i >> 3) + 8 h + (i & 7)] / 2^(scale - 127) as fp6 (e2m3), element i at bit 6 i
-// Phase 2, stage (nb, half), hidden tiles t = 6 half + 2 pi + tt:  chunk 0 header: byte 2 pi + tt = scale byte of tile t's lo operand;
+// Phase 2, stage (nb, half), hidden tiles t = 6 half + 2 pi + tt:  chunk 0 header: byte 2 pi + tt = scale byte of tile t's lo operand, dword 2
+//   of lane l = mlp.2's bias of column 32 nb + (l & 31);
 //   pair pi at chunk 1 + 11 pi:  + 5 tt + s: fp16(W2[32 nb + r][64 t + kmap(h, 8 s + e)]);  + 5 tt + 4: dwords 0 - 3 of the lo operand
 //   (W2 - fp16(W2) at [32 nb + r][64 t + kmap(h, i)]);  + 10: dwords 4 - 5, [tt][lane];  chunks 34, 35 unused.
 // One thread per 16-byte item.
@@ -168,16 +184,22 @@ __device__ __forceinline__ WLo w_lo_pack(const float (&v)[32]) {
     return r;
 }
 // the lo operand of phase 1: (t, g, j, term) of lane (r, h)
-__device__ __forceinline__ WLo w_lo1(const float* __restrict__ W1, int t, int g, int j, int term, int r, int h) {
+__device__ __forceinline__ WLo w_lo1(const float* __restrict__ W1, float ws, int t, int g, int j, int term, int r, int h) {
     const float* src = W1 + (size_t)(64 * t + 32 * j + r) * W_C + 64 * g + 8 * h;
     float v[32];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(src + 16 * s + 4 * c);
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(src + 16 * s + 4 * c);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[8 * s + 4 * c + e] = term == 0 ? w[e] - (float)(_Float16)w[e] : w[e];
+            for (int e = 0; e < 4; ++e) {
+                // ONE rounded product feeds the hi rounding and the lo difference in every copy of this function (header, 16-byte part, 8-byte
+                // part are written by different threads: a contracted multiply-subtract in one of them moves a block maximum across a binade)
+                float w = w4[e] * ws;
+                asm volatile("" : "+v"(w));
+                v[8 * s + 4 * c + e] = term == 0 ? w - (float)(_Float16)w : w;
+            }
         }
     return w_lo_pack(v);
 }
@@ -194,7 +216,14 @@ __device__ __forceinline__ WLo w_lo2(const float* __restrict__ W2, int nb, int t
     return w_lo_pack(v);
 }
 
-__global__ void mlpw_image_kernel(const float* __restrict__ W1, const float* __restrict__ W2, unsigned* __restrict__ img) {
+// `ws`: mlp.0's weights enter the stream multiplied by the Gaussian activation's argument scale (w_act_scale): the kernel's pre-activations
+// are s u, its activation exp2(-(s u)^2) — one multiply per hidden value less in a loop that is bound by its instruction count
+__device__ __forceinline__ float w_act_scale(const float* alpha, int act) {
+    return (act == 1 || act == 2) ? 0.84932180028801907f / fabsf(alpha[0]) : 1.f;   // sqrt(log2(e) / 2) / |alpha|
+}
+__global__ void mlpw_image_kernel(const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
+                                  unsigned* __restrict__ img, const float* __restrict__ alpha, int act) {
+    const float ws = w_act_scale(alpha, act);
     const size_t items = W_STREAM / 16;
     for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (size_t)gridDim.x * blockDim.x) {
         u32x4 out = {0u, 0u, 0u, 0u};
@@ -207,9 +236,15 @@ __global__ void mlpw_image_kernel(const float* __restrict__ W1, const float* __r
 #pragma unroll 1
                 for (int b = 0; b < 12; ++b) {
                     const int gi = b >> 2, term = (b >> 1) & 1, j = b & 1;
-                    out[b >> 2] |= (unsigned)w_lo1(W1, t, 3 * half + gi, j, term, r, h).sb << (8 * (b & 3));
+                    out[b >> 2] |= (unsigned)w_lo1(W1, ws, t, 3 * half + gi, j, term, r, h).sb << (8 * (b & 3));
                 }
-            } else if (chunk >= 2) {
+            } else if (chunk == 1) {
+                if (half == 1 && l < 16 && b1) {
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(b1 + 64 * t + 4 * l);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) out[e] = __float_as_uint(bb[e] * ws);
+                }
+            } else {
                 const int gi = (chunk - 2) / 14, c = (chunk - 2) % 14, g = 3 * half + gi;
                 if (c < 8) {
                     const int s = c >> 1, j = c & 1, r = l & 31, h = l >> 5;
@@ -218,17 +253,19 @@ __global__ void mlpw_image_kernel(const float* __restrict__ W1, const float* __r
                     f16x8 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[e] = (_Float16)w0[e];
-                        v[4 + e] = (_Float16)w1[e];
+                        float a = w0[e] * ws, b = w1[e] * ws;
+                        asm volatile("" : "+v"(a), "+v"(b));
+                        v[e] = (_Float16)a;
+                        v[4 + e] = (_Float16)b;
                     }
                     out = __builtin_bit_cast(u32x4, v);
                 } else if (c == 8 || c == 9 || c == 11 || c == 12) {
                     const int term = c >= 11, j = (c - (term ? 11 : 8));
-                    const WLo o = w_lo1(W1, t, g, j, term, l & 31, l >> 5);
+                    const WLo o = w_lo1(W1, ws, t, g, j, term, l & 31, l >> 5);
                     out = u32x4{o.pk[0], o.pk[1], o.pk[2], o.pk[3]};
                 } else {   // c == 10 / 13: [j][lane] 8 bytes; this item = lanes 2 q, 2 q + 1 of block j
                     const int term = c == 13, j = l >> 5, q = l & 31;
-                    const WLo a = w_lo1(W1, t, g, j, term, (2 * q) & 31, (2 * q) >> 5), b = w_lo1(W1, t, g, j, term, (2 * q + 1) & 31, (2 * q + 1) >> 5);
+                    const WLo a = w_lo1(W1, ws, t, g, j, term, (2 * q) & 31, (2 * q) >> 5), b = w_lo1(W1, ws, t, g, j, term, (2 * q + 1) & 31, (2 * q + 1) >> 5);
                     out = u32x4{a.pk[4], a.pk[5], b.pk[4], b.pk[5]};
                 }
             }
@@ -240,6 +277,7 @@ __global__ void mlpw_image_kernel(const float* __restrict__ W1, const float* __r
                 const int r = l & 31, h = l >> 5;
 #pragma unroll 1
                 for (int b = 0; b < 6; ++b) out[b >> 2] |= (unsigned)w_lo2(W2, nb, 6 * half + b, r, h).sb << (8 * (b & 3));
+                out[2] = __float_as_uint(b2 ? b2[32 * nb + r] : 0.f);
             } else if (chunk < 34) {
                 const int pi = (chunk - 1) / 11, q = (chunk - 1) % 11;
                 if (q == 10) {
@@ -276,21 +314,33 @@ struct WBuf {       // the operands of one set of matrix instructions: up to six
     u32x2 d[4];
 };
 
-// pieces [a, b) of the NP pieces a wave contributes to a stage, after set i of NSETS
+// pieces [a, b) of the NP pieces a wave contributes to a stage that are issued with set I of its NSETS sets: spread over the first
+// NSETS - 2 sets, so that the youngest piece has two sets (~400 cycles) to land before the next stage entry waits for it
 template <int I, int NSETS, int NP>
 struct WSpan {
-    static constexpr int a = I * NP / NSETS, b = (I + 1) * NP / NSETS;
+    static constexpr int F = NSETS - 2;
+    static constexpr int a = I < F ? I * NP / F : NP, b = I < F ? (I + 1) * NP / F : NP;
 };
+// the interleave of one set (a scheduling region): NM matrix instructions, each followed by its share of the ND fragment reads of the
+// next set and of the NV LDS-DMA pieces — one instruction stream per SIMD hides nothing that is not placed between two matrix instructions
+template <int NM, int ND, int NV>
+__device__ __forceinline__ void w_interleave() {
+    sfor<NM>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+        constexpr int nd = (i + 1) * ND / NM - i * ND / NM, nv = (i + 1) * NV / NM - i * NV / NM;
+        if constexpr (nd > 0) __builtin_amdgcn_sched_group_barrier(0x100, nd, 0);
+        if constexpr (nv > 0) __builtin_amdgcn_sched_group_barrier(0x20, nv, 0);
+    });
+}
 
 template <int ACT>
 __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const ring = smem;
     char* const stg = ring + W_NS * W_SLOT;
-    float* const b1_lds = reinterpret_cast<float*>(stg + 4 * W_STG);
-    float* const b2_lds = b1_lds + W_WD;
-    float* const pro_lds = b2_lds + W_C;                 // pa[0 .. C) | po[0 .. C)
-    float* const colp = reinterpret_cast<float*>(stg);   // [4 waves][2][C] column partials of a tile (the staging tiles are idle then)
+    float* const colp = reinterpret_cast<float*>(stg + 4 * W_STG);   // [4 waves][2][C] column partials of a tile
+    float* const pro_lds = colp;                                      // pa[0 .. C) | po[0 .. C) while the y build runs
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -298,8 +348,6 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
     const int tilesM = g.rows >> 7, ntiles = g.B * tilesM;
 
     WSTAMP(0);
-    for (int i = tid; i < W_WD; i += 256) b1_lds[i] = g.b0 ? g.b0[i] : 0.f;
-    for (int i = tid; i < W_C; i += 256) b2_lds[i] = g.b2 ? g.b2[i] : 0.f;
 
     // ---- the weight stream: a wave's pieces of a stage are NP consecutive chunks; the stream wraps (the next tile's first stages)
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.w_img), 0, 0x7fffffff, 0x00020000);
@@ -378,9 +426,12 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
     };
     // entering a stage: the NEXT stage has landed for every wave (its first fragments are read across the boundary), the slot of the
     // previous one may be refilled.  ALLOW: vector-memory operations younger than the awaited pieces that may stay in flight
+    WACC_DECL;
     auto stage_enter = [&](auto ALLOW) {
+        WACC_BEGIN();
         wait_vm<decltype(ALLOW)::value>();
         __builtin_amdgcn_s_barrier();
+        WACC_END(wacc_enter);
         sb16 = lb16 + rslot * W_SLOT;
         sb8 = lb8 + rslot * W_SLOT;
         rslot = rslot + 1 == W_NS ? 0 : rslot + 1;
@@ -398,19 +449,23 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
     load_p1(lb16, lb8, lb8 + 512, W_IC(0), W_IC(0), bufA);
 
     // per-lane LDS bases behind an opaque asm: left as constants (beyond the 16-bit offset field) every distinct address becomes a register
-    lds_cptr b1base = (lds_cptr)(reinterpret_cast<const char*>(b1_lds)) + 16 * h;
     lds_cptr probase = (lds_cptr)(reinterpret_cast<const char*>(pro_lds)) + 16 * (lane & 15);
-    asm volatile("" : "+v"(b1base), "+v"(probase));
+    asm volatile("" : "+v"(probase));
+    // the wave's phase-2 tile [32 rows][32 floats]: register e of an accumulator <-> row (e & 3) + 8 (e >> 2) + 4 h, column r (4-byte
+    // accesses: a lane half covers one row's 128 bytes); 16-byte pieces <-> row (lane >> 3) + 8 i, columns 4 (lane & 7) ..
+    typedef __attribute__((address_space(3))) char* lds_ptr;
+    lds_ptr tile4 = (lds_ptr)(stg + wave * W_STG) + (4 * h) * 128 + 4 * r;
+    lds_ptr tile16 = (lds_ptr)(stg + wave * W_STG) + lane * 16;
+    asm volatile("" : "+v"(tile4), "+v"(tile16));
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x), 0, 0x7fffffff, 0x00020000);
     const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // activation constants: exp(-u^2 / (2 a^2)) = exp2(-(u s)^2)
-    const float alpha = (ACT == 1 || ACT == 2) ? g.alpha[0] : 1.f;
-    const float s_act = (ACT == 1 || ACT == 2) ? 0.84932180028801907f / fabsf(alpha) : 1.f;   // sqrt(log2(e) / 2) / |alpha|
     int opq = 0;
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int b = tile / tilesM, rt = tile - b * tilesM;
         const size_t row0 = (size_t)b * g.rows + (size_t)rt * 128 + wave * 32;
         WSTAMP(1);
+        WACC_RESET();
         // ---- AdaGN coefficients of the sample (every wave has left the previous tile's reduction: the barrier that ended it)
         for (int i = tid; i < W_C; i += 256) {
             pro_lds[i] = g.pro_a[(size_t)b * W_C + i];
@@ -430,7 +485,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
             const float* xw = g.x + row0 * W_C;
             char* sw = stg + wave * W_STG;
             const int lrow = lane >> 4, c16 = lane & 15;
-            f32x4 xs[2][8];
+            f32x4 xs[2][8];   // (all 48 loads in flight at once measured slower: 21.5 K ticks against 14.8 K for this two-slab ring)
 #pragma unroll
             for (int i = 0; i < 8; ++i) xs[0][i] = *reinterpret_cast<const f32x4*>(xw + (size_t)(4 * i + lrow) * W_C + 4 * c16);
             sfor<W_NG>([&](auto G) {
@@ -511,7 +566,6 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
                     if constexpr (i < 5) load_p1(sb16, sb8, sb8b, W_IC((i + 1) >> 1), W_IC((i + 1) & 1), bn);
                     else if constexpr (t == W_NT - 1 && half == 1) load_p2(nb16, nb8, W_IC(0), W_IC(0), bn);
                     else load_p1(nb16, nb8, nb8b, W_IC(0), W_IC(0), bn);
-                    W_SCHED();
                     if constexpr (k == 0) {
                         sfor<3>([&](auto S) {
                             constexpr int s = decltype(S)::value;
@@ -538,6 +592,11 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
                     }
                     // the stage two ahead: phase-2 stages from the last hidden tile on
                     issue_after(I, W_IC(6), W_IC(t < W_NT - 1 ? 1 : 0));
+                    {
+                        constexpr int np = t < W_NT - 1 ? W_NP1 : W_NP2;
+                        typedef WSpan<i, 6, np> SP;
+                        w_interleave<6, (i < 5 && ((i + 1) & 1)) ? 10 : 6, SP::b - SP::a>();
+                    }
                     W_SCHED();
                 });
             });
@@ -546,10 +605,13 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
             {
                 float m = 0.f;
                 W_SCHED();
+                WACC_BEGIN();
+                // the tile's bias: chunk 1 of the stage just computed (its slot is refilled after the next stage entry)
+                lds_cptr b1base = sb16 + (1024 + 16 * h - 16 * lane);
                 // pre-activations = accumulators + bias (registers 4 qq .. 4 qq + 3 of block j: columns 32 j + 8 qq + 4 h + e)
                 sfor<8>([&](auto Q) {
                     constexpr int q = decltype(Q)::value, j = q >> 2, qq = q & 3;
-                    const f32x4 bs = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(b1base + 4 * (64 * t + 32 * j + 8 * qq));
+                    const f32x4 bs = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(b1base + 4 * (32 * j + 8 * qq));
 #pragma unroll
                     for (int e = 0; e < 4; ++e) au[j][4 * qq + e] += bs[e];
                 });
@@ -567,23 +629,30 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
                     float y[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float uu = au[j][4 * qq + e];
+                        const float uu = au[j][4 * qq + e];       // s u
                         if constexpr (ACT == 1 || ACT == 2) {
-                            const float tt = uu * s_act;
-                            const float E = __builtin_amdgcn_exp2f(tt * -tt);
+                            const float E = __builtin_amdgcn_exp2f(uu * -uu);
                             y[e] = ACT == 1 ? __builtin_fmaf(E, 1.0f / 0.28f, -2.5f) : E;
                         } else if constexpr (ACT == 3) {
                             y[e] = h8_clamp(fmaxf(uu, 0.f));
                         } else {
                             y[e] = h8_clamp(uu);
                         }
-                        hf[t][16 * j + 4 * qq + e] = (_Float16)y[e];
                     }
-                    m = fmaxf(fmaxf(m, fmaxf(fabsf(y[0]), fabsf(y[1]))), fmaxf(fabsf(y[2]), fabsf(y[3])));
+                    // registers 4 qq .. 4 qq + 3 of block j = elements 16 j + 4 qq .. of the tile's fragment: two packed conversions
+                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                    const h2 p0 = {(_Float16)y[0], (_Float16)y[1]}, p1 = {(_Float16)y[2], (_Float16)y[3]};
+                    hf[t][16 * j + 4 * qq] = p0[0];
+                    hf[t][16 * j + 4 * qq + 1] = p0[1];
+                    hf[t][16 * j + 4 * qq + 2] = p1[0];
+                    hf[t][16 * j + 4 * qq + 3] = p1[1];
+                    if constexpr (ACT == 0 || ACT == 3) m = fmaxf(fmaxf(m, fmaxf(fabsf(y[0]), fabsf(y[1]))), fmaxf(fabsf(y[2]), fabsf(y[3])));
                     W_SCHED();
                 });
-                hsp[t >> 2] |= w_scale_byte(m) << (8 * (t & 3));
+                // block scale of the tile's fp6 form: the bounded activations have a fixed one (|h| <= 2.5: 2^-1; exp(.) <= 1: 2^-2)
+                hsp[t >> 2] |= (ACT == 1 ? 126 : ACT == 2 ? 125 : w_scale_byte(m)) << (8 * (t & 3));
                 asm volatile("" : "+a"(hf[t]), "+v"(hsp[t >> 2]));
+                WACC_END(wacc_act);
                 W_SCHED();
             }
         });
@@ -598,13 +667,14 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
         });
 
         // ---- phase 2
-        const float* xres = g.x + (row0 + 4 * h) * W_C + r;     // register e of an accumulator: row (e & 3) + 8 (e >> 2) + 4 h, column 32 nb + r
-        float* xout = g.out + (row0 + 4 * h) * W_C + r;
+        // 16-byte pieces of the block's rows: lane l <-> row (l >> 3) + 8 i, columns 32 nb + 4 (l & 7) ..
+        const unsigned xoff16 = (unsigned)(((row0 + (lane >> 3)) * W_C + 4 * (lane & 7)) * 4);
+        float* xout = g.out + (row0 + (lane >> 3)) * W_C + 4 * (lane & 7);
         float* cp = colp + wave * 2 * W_C + h * W_C + r;          // lane half 0 writes the column sums, half 1 the sums of squares
-        for (int nb = 0; nb < W_NB; ++nb) {
+        auto unit2 = [&](auto FIRST, auto LAST, int nb) {
+            constexpr bool first = decltype(FIRST)::value != 0, last = decltype(LAST)::value != 0;
             f32x16 acc;
-            f32x16 res;
-            const bool last = nb == W_NB - 1;
+            float bias = 0.f;
             // the loop's big invariants keep their register files (left alone the allocator rotates the fp6 forms through the accumulator
             // file: 12 moves per hidden tile and output block)
             sfor<W_NT>([&](auto T) {
@@ -615,31 +685,29 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
             });
             sfor<2>([&](auto HALF) {
                 constexpr int half = decltype(HALF)::value;
-                // pieces awaited: the next stage's.  Younger than them: the previous block's 16 stores (first stage of a block but the first)
-                if constexpr (half == 0) {
-                    if (nb == 0) stage_enter(W_IC(0));
-                    else stage_enter(W_IC(16));
-                } else {
-                    stage_enter(W_IC(0));
-                }
+                // pieces awaited: the next stage's.  Younger than them: the previous block's 4 stores (first stage of a block but the first)
+                stage_enter(W_IC((half == 0 && !first) ? 4 : 0));
                 const u32x4 hdr = rd16(sb16, 0);
                 if constexpr (half == 0) {
+                    // the block's residual rows into the wave's tile, row-major: four 1 KiB LDS-DMA pieces of 8 rows x 128 bytes (landed by the
+                    // next stage entry, whose wait covers them; the previous block's last reads of the tile fed its stores, issued before these)
+#ifndef MFW_DIAG_NODMA
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) res[e] = GECCO_NT_LOAD(xres + (size_t)((e & 3) + 8 * (e >> 2)) * W_C + 32 * nb);
+                    for (int i = 0; i < 4; ++i)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(stg + wave * W_STG + i * 1024), 16, xoff16,
+                                                                 (unsigned)((8 * i * W_C + 32 * nb) * 4), 0, 0);
+#endif
+                } else {
+                    bias = __uint_as_float(hdr[2]);
                 }
+                W_SCHED();
                 sfor<6>([&](auto I) {
                     constexpr int i = decltype(I)::value, pi = i >> 1, tt = i & 1, t = 6 * half + i;
                     WBuf& bc = (i & 1) ? bufB : bufA;
                     WBuf& bn = (i & 1) ? bufA : bufB;
-                    if constexpr (i < 5) {
-                        load_p2(sb16, sb8, W_IC((i + 1) >> 1), W_IC((i + 1) & 1), bn);
-                    } else if constexpr (half == 0) {
-                        load_p2(nb16, nb8, W_IC(0), W_IC(0), bn);
-                    } else {
-                        if (last) load_p1(nb16, nb8, nb8b, W_IC(0), W_IC(0), bn);      // the next row tile's first set
-                        else load_p2(nb16, nb8, W_IC(0), W_IC(0), bn);
-                    }
-                    W_SCHED();
+                    if constexpr (i < 5) load_p2(sb16, sb8, W_IC((i + 1) >> 1), W_IC((i + 1) & 1), bn);
+                    else if constexpr (half == 0 || !last) load_p2(nb16, nb8, W_IC(0), W_IC(0), bn);
+                    else load_p1(nb16, nb8, nb8b, W_IC(0), W_IC(0), bn);      // the next row tile's first set
                     sfor<4>([&](auto S) {
                         constexpr int s = decltype(S)::value;
                         acc = W_MFMA16(w_sub<s>(hf[t]), __builtin_bit_cast(f16x8, bc.q[s]), (t == 0 && s == 0) ? z16 : acc);
@@ -648,21 +716,33 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
                     acc = W_MFMA6(w_op6(h6[t]), w_op6(bc.q[4], bc.d[0]), acc, W_SB(hsp[t >> 2], t & 3), W_SB((int)hdr[(2 * pi + tt) >> 2], (2 * pi + tt) & 3));
 #endif
                     // the stage two ahead: phase-1 stages (of the next row tile) from the last output block on
-                    if (last) issue_after(I, W_IC(6), W_IC(1));
-                    else issue_after(I, W_IC(6), W_IC(0));
+                    issue_after(I, W_IC(6), W_IC(last ? 1 : 0));
+                    {
+                        typedef WSpan<i, 6, last ? W_NP1 : W_NP2> SP;
+                        w_interleave<5, 6, SP::b - SP::a>();
+                    }
                     W_SCHED();
                 });
             });
-            // ---- the block's epilogue: bias, residual, store, column sums
+            // ---- the block's epilogue: accumulator + bias + residual through the tile (4-byte accesses in the accumulator's layout), column
+            // sums there, then out in 16-byte row pieces (8 rows x 128 bytes per instruction)
             {
-                const float bias = b2_lds[32 * nb + r];
+                WACC_BEGIN();
                 float s1 = 0.f, s2 = 0.f;
+                float rr[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) rr[e] = *reinterpret_cast<const __attribute__((address_space(3))) float*>(tile4 + ((e & 3) + 8 * (e >> 2)) * 128);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const float v = (acc[e] + bias) + res[e];
-                    GECCO_NT_STORE(v, xout + (size_t)((e & 3) + 8 * (e >> 2)) * W_C + 32 * nb);
+                    const float v = (acc[e] + bias) + rr[e];
+                    *reinterpret_cast<__attribute__((address_space(3))) float*>(tile4 + ((e & 3) + 8 * (e >> 2)) * 128) = v;
                     s1 += v;
                     s2 = __builtin_fmaf(v, v, s2);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 o = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(tile16 + i * 1024);
+                    GECCO_NT_STORE(o, reinterpret_cast<f32x4*>(xout + (size_t)(8 * i) * W_C + 32 * nb));
                 }
                 if (g.stats) {
                     const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(s1), __float_as_uint(s1), false, false);
@@ -670,8 +750,13 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
                     const float t1 = __uint_as_float(a[0]) + __uint_as_float(a[1]), t2 = __uint_as_float(c[0]) + __uint_as_float(c[1]);
                     cp[32 * nb] = h ? t2 : t1;
                 }
+                WACC_END(wacc_epi);
             }
-        }
+            W_SCHED();
+        };
+        unit2(W_IC(1), W_IC(0), 0);
+        for (int nb = 1; nb < W_NB - 1; ++nb) unit2(W_IC(0), W_IC(0), nb);
+        unit2(W_IC(0), W_IC(1), W_NB - 1);
         WSTAMP(4);
         // ---- column partials of the tile: the four waves' sums in a fixed order
         if (g.stats) {
@@ -683,8 +768,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
             }
             wait_lgkm0();
         }
-        __builtin_amdgcn_s_barrier();      // the staging tiles / coefficient table may be rewritten
+        __builtin_amdgcn_s_barrier();      // the coefficient table (= the partials' first 3 KiB) may be rewritten
         WSTAMP(5);
+        WACC_STORE();
     }
     wait_vm<0>();   // the wrapped stream's last pieces still target this block's LDS
 }
@@ -713,14 +799,17 @@ bool mlp_fused_w_supported(int C, int Wd, int rows) { return C == W_C && Wd == W
 
 size_t mlp_fused_w_image_bytes(int C, int Wd) { return mlp_fused_w_supported(C, Wd, 128) ? W_STREAM : 0; }
 
-int mlp_fused_w_image_launch(const float* W0, const float* W2, void* img, int C, int Wd, hipStream_t st) {
+int mlp_fused_w_image_launch(const float* W0, const float* b0, const float* W2, const float* b2, void* img, int C, int Wd, const float* alpha, int act,
+                             hipStream_t st) {
     if (!mlp_fused_w_supported(C, Wd, 128)) return -9;
-    hipLaunchKernelGGL(mlpw_image_kernel, dim3(480), dim3(256), 0, st, W0, W2, static_cast<unsigned*>(img));
+    if ((act == 1 || act == 2) && !alpha) return -6;
+    hipLaunchKernelGGL(mlpw_image_kernel, dim3(480), dim3(256), 0, st, W0, b0, W2, b2, static_cast<unsigned*>(img), alpha, act);
     return (int)hipGetLastError();
 }
 
 int mlp_fused_w_launch(const MlpWArgs& g, int C, int Wd, hipStream_t st) {
     if (!mlp_fused_w_supported(C, Wd, g.rows) || !g.x || !g.out || !g.pro_a || !g.pro_o || !g.w_img) return -9;
+    if ((size_t)g.B * g.rows * C * sizeof(float) >= ((size_t)1 << 31)) return -9;   // the residual rows come in through 32-bit buffer offsets
     if ((g.act == 1 || g.act == 2) && !g.alpha) return -6;
     switch (g.act) {
 #ifndef MFW_DEV   // development builds: the GaussianActivation instantiation only (a full build takes over a minute)

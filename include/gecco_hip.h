@@ -331,7 +331,8 @@ int gecco_unpool_outproj_f16(float* x, const void* q16, const float* kvh, const 
  * F_x (the mixed mode: 6e-5).  stats (B, rows / 128, 2, C) or NULL: GroupNorm partials of out.  Replaces
  * models/set_transformer.py:164-166, models/mlp.py:5-39, models/activation.py:17-24, models/normalization.py:36-44.
  * C == 384, width == 2 C, rows % 128 == 0; act 0 .. 3; wsplit: gecco_mlp_fused_w_wsplit_bytes(C, width) bytes; W0 == NULL: the weight
- * stream of an earlier call is in wsplit.  dbg_u: NULL, or (B, rows, width) receiving mlp.0's pre-activations (diagnostics). */
+ * stream of an earlier call (same weights, biases, activation and alpha: the stream holds them all) is in wsplit.  dbg_u: NULL, or (B, rows, width) receiving mlp.0's
+ * pre-activations times sqrt(log2(e) / 2) / |alpha| for the Gaussian activations (the form the kernel computes them in; diagnostics). */
 int gecco_mlp_fused_w(const float* x, float* out, const float* pro_a, const float* pro_o, const float* W0, const float* b0, const float* W2,
                       const float* b2, const float* alpha, int act, float* stats, int B, int rows, int C, int width, void* wsplit, float* dbg_u,
                       void* stream);

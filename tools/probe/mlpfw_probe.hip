@@ -66,9 +66,14 @@ int main(int argc, char** argv) {
     (void)hipMemcpy(b2, hb2.data(), hb2.size() * 4, hipMemcpyHostToDevice);
     const float a = 0.9f;
     (void)hipMemcpy(alpha, &a, 4, hipMemcpyHostToDevice);
-    int rc = mlp_fused_w_image_launch(W0, W2, img, C, Wd, 0);
+    // the kernel works on s u (s = sqrt(log2(e) / 2) / |alpha| folded into mlp.0's weights and bias): the host checks in that domain
+    const float ws = 0.84932180028801907f / a;
+    std::vector<float> hW0s(hW0.size()), hb0s(hb0.size());
+    for (size_t i = 0; i < hW0.size(); ++i) hW0s[i] = hW0[i] * ws;
+    for (size_t i = 0; i < hb0.size(); ++i) hb0s[i] = hb0[i] * ws;
+    int rc = mlp_fused_w_image_launch(W0, b0, W2, b2, img, C, Wd, alpha, 1, 0);
     MlpWArgs g{};
-    g.x = x; g.out = out; g.pro_a = pa; g.pro_o = po; g.w_img = img; g.b0 = b0; g.b2 = b2; g.alpha = alpha; g.act = 1; g.stats = stats; g.B = B; g.rows = N;
+    g.x = x; g.out = out; g.pro_a = pa; g.pro_o = po; g.w_img = img; g.alpha = alpha; g.act = 1; g.stats = stats; g.B = B; g.rows = N;
     g.dbg_u = dbg;
     rc |= mlp_fused_w_launch(g, C, Wd, 0);
     (void)hipDeviceSynchronize();
@@ -92,7 +97,7 @@ int main(int argc, char** argv) {
                     const int bit = 6 * i;
                     unsigned long long w = (unsigned long long)dw[bit >> 5] | ((bit >> 5) + 1 < 6 ? (unsigned long long)dw[(bit >> 5) + 1] << 32 : 0ull);
                     const double v = dec6((unsigned)((w >> (bit & 31)) & 63)) * ldexp(1.0, sb - 127);
-                    const float wf = hW0[(size_t)(64 * t + 32 * j + r) * C + 64 * g2 + 16 * (i >> 3) + 8 * h + (i & 7)];
+                    const float wf = hW0s[(size_t)(64 * t + 32 * j + r) * C + 64 * g2 + 16 * (i >> 3) + 8 * h + (i & 7)];
                     const double ref = term ? (double)wf : (double)wf - (double)h2f(wf);
                     worst = fmax(worst, fabs(v - ref)); big = fmax(big, fabs(ref));
                 }
@@ -132,12 +137,12 @@ int main(int argc, char** argv) {
             }
             for (int n = 0; n < Wd; ++n) {
                 {   // emulated u
-                    double e = hb0[n];
+                    double e = hb0s[n];
                     for (int gk = 0; gk < 6; ++gk) for (int hh = 0; hh < 2; ++hh) {
                         double wl[32], wq[32], w6[32], wf[32];
-                        for (int i = 0; i < 32; ++i) { const int k = 64 * gk + 16 * (i >> 3) + 8 * hh + (i & 7); const float w = hW0[(size_t)n * C + k]; wl[i] = (double)w - (double)h2f(w); wf[i] = w; }
+                        for (int i = 0; i < 32; ++i) { const int k = 64 * gk + 16 * (i >> 3) + 8 * hh + (i & 7); const float w = hW0s[(size_t)n * C + k]; wl[i] = (double)w - (double)h2f(w); wf[i] = w; }
                         quant32(wl, wq); quant32(wf, w6);
-                        for (int i = 0; i < 32; ++i) { const int k = 64 * gk + 16 * (i >> 3) + 8 * hh + (i & 7); e += yh[k] * (double)h2f(hW0[(size_t)n * C + k]) + y6[k] * wq[i] + yl6[k] * w6[i]; }
+                        for (int i = 0; i < 32; ++i) { const int k = 64 * gk + 16 * (i >> 3) + 8 * hh + (i & 7); e += yh[k] * (double)h2f(hW0s[(size_t)n * C + k]) + y6[k] * wq[i] + yl6[k] * w6[i]; }
                     }
                     worst_e = fmax(worst_e, fabs(e - (double)hu[m * Wd + n]));
                 }
@@ -145,12 +150,12 @@ int main(int argc, char** argv) {
                 for (int k = 0; k < C; ++k) acc += y[k] * (double)hW0[(size_t)n * C + k];
                 uex[n] = acc;
                 const double uk = hu[m * Wd + n];
-                worst_u = fmax(worst_u, fabs(uk - acc));
-                wu_j[(n >> 5) & 1] = fmax(wu_j[(n >> 5) & 1], fabs(uk - acc));
-                wu_h[(n >> 2) & 1] = fmax(wu_h[(n >> 2) & 1], fabs(uk - acc));
-                wu_r[m >> 5] = fmax(wu_r[m >> 5], fabs(uk - acc));
-                big_u = fmax(big_u, fabs(acc));
-                hk[n] = h2f((float)((exp(-uk * uk / (2.0 * a * a)) - 0.7) / 0.28));
+                worst_u = fmax(worst_u, fabs(uk - acc * ws));
+                wu_j[(n >> 5) & 1] = fmax(wu_j[(n >> 5) & 1], fabs(uk - acc * ws));
+                wu_h[(n >> 2) & 1] = fmax(wu_h[(n >> 2) & 1], fabs(uk - acc * ws));
+                wu_r[m >> 5] = fmax(wu_r[m >> 5], fabs(uk - acc * ws));
+                big_u = fmax(big_u, fabs(acc * ws));
+                hk[n] = h2f((float)((exp2(-uk * uk) - 0.7) / 0.28));   // uk = s u
                 hex[n] = (exp(-acc * acc / (2.0 * a * a)) - 0.7) / 0.28;
             }
             for (int c = 0; c < C; ++c) {
@@ -190,7 +195,7 @@ int main(int argc, char** argv) {
     float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 10;
     printf("%-14s B %d N %d: %.1f us  (%.1f TF of 2MNK, two products)   err %d\n", argv[0], B, N, ms * 1e3, 4.0 * rows * C * Wd / ms / 1e9, (int)hipGetLastError());
     (void)hipEventRecord(e0, 0);
-    for (int i = 0; i < 10; ++i) mlp_fused_w_image_launch(W0, W2, img, C, Wd, 0);
+    for (int i = 0; i < 10; ++i) mlp_fused_w_image_launch(W0, b0, W2, b2, img, C, Wd, alpha, 1, 0);
     (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
     (void)hipEventElapsedTime(&ms, e0, e1);
     printf("   weight stream build: %.1f us\n", ms * 100);
@@ -203,6 +208,10 @@ int main(int argc, char** argv) {
     for (int i = 0; i < nb; ++i) for (int k = 0; k < 5; ++k) d[k] += (double)(hs[i * 8 + k + 1] - hs[i * 8 + k]);
     printf("   stamps of the LAST tile (ticks, mean over %d blocks): start->tile %.0f | coefficients + y build %.0f | phase 1 %.0f | fp6 forms + phase 2 %.0f | partials %.0f\n",
            nb, d[0] / nb, d[1] / nb, d[2] / nb, d[3] / nb, d[4] / nb);
+    double de = 0, da = 0;
+    double dp = 0;
+    for (int i = 0; i < nb; ++i) { de += (double)hs[i * 8 + 6]; da += (double)(hs[i * 8 + 7] & 0xffffffffull); dp += (double)(hs[i * 8 + 7] >> 32); }
+    printf("   of the last tile: waits + barriers of the 48 stage entries %.0f, the 12 activation blocks %.0f, the 12 output-block epilogues %.0f\n", de / nb, da / nb, dp / nb);
 #endif
     return 0;
 }

@@ -195,6 +195,8 @@ SIGNATURES = {
     "gecco_sampler_refresh_known_f64": (i, [vp, vp, vp, vp, vp, i, i, i, i, vp]),
     "gecco_distance_matrix_f32": (i, [vp, vp, vp, i, i, i, i, vp]),
     "gecco_chamfer_f32": (i, [vp, vp, vp, vp, i, i, i, i, vp]),
+    "gecco_set_chamfer_f32": (i, [vp, vp, vp, i, i, i, i, i, vp]),
+    "gecco_set_metrics_f32": (i, [vp, vp, vp, i, vp, vp, vp]),
     "gecco_sinkhorn_f32": (i, [vp, vp, vp, vp, vp, i, i, i, fl, i, vp]),
     "gecco_convnext_stem_f32": (i, [vp] * 6 + [i, i, i, i, fl, vp]),
     "gecco_convnext_dwconv_ln_f32": (i, [vp] * 6 + [i, i, i, i, fl, vp]),

@@ -1860,6 +1860,22 @@ int gecco_distance_matrix_f32(const float* a, const float* b, float* D, int B, i
     TRY(dist_matrix_launch(a, b, D, B, N, M, squared, (hipStream_t)stream), "distance_matrix");
     return 0;
 }
+int gecco_set_chamfer_f32(const float* a, const float* b, float* out, int S, int T, int N, int M, int squared, void* stream) {
+    if (!a || !b || !out) return fail(-1, "set_chamfer: null argument");
+    if (S <= 0 || T <= 0 || N <= 0 || M <= 0) return fail(-2, "set_chamfer: empty set or cloud");
+    hipStream_t s = (hipStream_t)stream;
+    TRY(set_nearest_mean_launch(a, b, out, S, T, N, M, squared, T, 1, 0.5f, 0, s), "set_chamfer(a -> b)");
+    TRY(set_nearest_mean_launch(b, a, out, T, S, M, N, squared, 1, T, 0.5f, 1, s), "set_chamfer(b -> a)");
+    return 0;
+}
+
+int gecco_set_metrics_f32(const float* ss, const float* sd, const float* dd, int n, float* out3, int* flags, void* stream) {
+    if (!ss || !sd || !dd || !out3 || !flags) return fail(-1, "set_metrics: null argument");
+    if (n <= 0) return fail(-2, "set_metrics: empty set");
+    TRY(set_metrics_launch(ss, sd, dd, n, out3, flags, (hipStream_t)stream), "set_metrics");
+    return 0;
+}
+
 int gecco_chamfer_f32(const float* a, const float* b, float* out, float* ws, int B, int N, int M, int squared, void* stream) {
     if (!a || !b || !out || !ws) return fail(-1, "chamfer: null argument");
     hipStream_t s = (hipStream_t)stream;

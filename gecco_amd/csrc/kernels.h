@@ -396,6 +396,10 @@ int dist_matrix_launch(const float* A, const float* Bp, float* D, int B, int N, 
 int nearest_dist_launch(const float* A, const float* Bp, float* mins, int B, int N, int M, int squared, hipStream_t st);
 int row_mean_launch(const float* v, float* out, int B, int n, float scale, int accumulate, hipStream_t st);
 int sinkhorn_step_launch(const float* C, float* f, float* g, int B, int N, int M, float eps, hipStream_t st);
+// set-vs-set: out[s * ld_s + t * ld_t] (+)= scale * mean_i min_j d(a[s, i], b[t, j]) for every pair of S x T clouds; 1-NNA / MMD / COV
+int set_nearest_mean_launch(const float* A, const float* Bp, float* out, int S, int T, int N, int M, int squared, int ld_s, int ld_t, float scale,
+                            int accumulate, hipStream_t st);
+int set_metrics_launch(const float* ss, const float* sd, const float* dd, int n, float* out, int* flags, hipStream_t st);
 int sinkhorn_cost_launch(const float* C, const float* f, const float* g, float* rowcost, float* out, int B, int N, int M, float eps,
                          hipStream_t st);
 // sampler.hip — inpainting: re-draw the known points of the fp64 state at the current noise level

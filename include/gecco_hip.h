@@ -661,6 +661,16 @@ int gecco_distance_matrix_f32(const float* a, const float* b, float* D, int B, i
 /* Chamfer distance per sample (gecco-jax metrics.py:92-103): out[b] = (mean_i min_j d(a_i, b_j) + mean_j min_i d) / 2.
  * ws: B * (N + M) floats. */
 int gecco_chamfer_f32(const float* a, const float* b, float* out, float* ws, int B, int N, int M, int squared, void* stream);
+/* Set-vs-set Chamfer distances (gecco-jax benchmark.py:21-39 `batched_pairwise_distance` with `chamfer_distance` / `_squared`):
+ * out (S, T) row-major, out[s, t] = Chamfer(a[s], b[t]) for a (S, N, 3) and b (T, M, 3) — two launches (one per direction), no
+ * N x M matrix anywhere.  The minimum is taken over |b|^2 - 2 a.b with |a|^2 added after it (the reference adds it before: equal up
+ * to the rounding of that addition). */
+int gecco_set_chamfer_f32(const float* a, const float* b, float* out, int S, int T, int N, int M, int squared, void* stream);
+/* 1-NN accuracy, minimum matching distance, coverage of a generated set against a reference set of n clouds each (gecco-jax
+ * benchmark.py:128-156: `_assemble_dist_m`, `_one_nn_acc`, `_mmd`, `_cov`, reference semantics to the letter incl. the `<= n` of
+ * `_one_nn_acc` and numpy's first-of-equals argmin): ss (n, n) sample-sample, sd (n, n) sample-data, dd (n, n) data-data distances;
+ * out3 = {1-NNA, MMD, COV}; flags: n ints of scratch. */
+int gecco_set_metrics_f32(const float* ss, const float* sd, const float* dd, int n, float* out3, int* flags, void* stream);
 /* Entropic optimal transport between uniform marginals on a cost matrix C (B, N, M) (gecco-jax metrics.py:141-156:
  * `sinkhorn_emd` through ott): `iterations` log-domain Sinkhorn sweeps, then out[b] = <P, C> with
  * P_ij = exp((f_i + g_j - C_ij) / epsilon) / (N M).  f (B, N), g (B, M), rowcost (B, N) are caller scratch / outputs. */

@@ -190,3 +190,28 @@ def relu_inputs():
     data = _randn(c["seed"] + 1, c["B"], c["N"], 3)
     x = data + sigma.reshape(-1, 1, 1) * _randn(c["seed"] + 2, c["B"], c["N"], 3)
     return p, x, sigma
+
+
+# set-vs-set evaluation metrics (gecco-jax benchmark.py:21-39, 128-156): n generated clouds against n reference clouds of N points.
+# `spread`: the generated set is the reference distribution (a blob per cloud: random centre + anisotropic scale) perturbed by that much —
+# small: 1-NNA near 0.5, large: near 1.
+SETMETRIC_CASES = {  # name: (n, N, seed, spread)
+    "sets_n24_N64_close": (24, 64, 91, 0.05),
+    "sets_n24_N64_far": (24, 64, 92, 0.6),
+    "sets_n16_N200": (16, 200, 93, 0.2),
+}
+
+
+def setmetric_inputs(name):
+    """(samples, data): two sets of n clouds of N points, fp32 (n, N, 3)."""
+    import torch
+    n, N, seed, spread = SETMETRIC_CASES[name]
+    rs = np.random.RandomState(seed)
+
+    def blobs(shift):
+        centre = rs.randn(n, 1, 3) * 0.5 + shift
+        scale = 0.3 + 0.4 * rs.rand(n, 1, 3)
+        return (centre + scale * rs.randn(n, N, 3)).astype(np.float32)
+    data = blobs(0.0)
+    samples = blobs(spread)
+    return torch.from_numpy(samples), torch.from_numpy(data)

@@ -455,6 +455,27 @@ def chamfer_distance(a: Tensor, b: Tensor, squared: bool = False) -> Tensor:
     return (d.min(dim=-2).values.mean(-1) + d.min(dim=-1).values.mean(-1)) / 2
 
 
+def set_pairwise_distance(a: Tensor, b: Tensor, squared: bool = False) -> Tensor:
+    """gecco-jax benchmark.py:21-39 (`batched_pairwise_distance` over `chamfer_distance`): out[s, t] = Chamfer(a[s], b[t]) for
+    every pair of the sets a (S, N, 3), b (T, M, 3)."""
+    return torch.stack([chamfer_distance(a[s][None].expand(b.shape[0], -1, -1), b, squared) for s in range(a.shape[0])])
+
+
+def set_metrics(ss, sd, dd) -> dict:
+    """1-NN accuracy, MMD, coverage from the (n, n) distance matrices sample-sample, sample-data, data-data: gecco-jax
+    benchmark.py:128-156 (`_assemble_dist_m`, `_one_nn_acc`, `_mmd`, `_cov`) restated in numpy — with the reference's own
+    conventions: the nearest neighbour of every COLUMN of [[ss, sd], [sd^T, dd]] (infinite diagonal; numpy's first-of-equals argmin),
+    `<= n` for the samples' half (sic), `> n` for the data's."""
+    import numpy as np
+    ss, sd, dd = (np.asarray(m, dtype=np.float64) for m in (ss, sd, dd))
+    n = ss.shape[0]
+    m = np.concatenate([np.concatenate([ss, sd], axis=1), np.concatenate([sd.T, dd], axis=1)], axis=0)
+    np.fill_diagonal(m, float("inf"))
+    amin = m.argmin(axis=0)
+    one_nn = np.concatenate([amin[:n] <= n, amin[n:] > n]).mean()
+    return {"1-nn": float(one_nn), "mmd": float(sd.min(axis=0).min()), "cov": float(np.unique(sd.argmin(axis=1)).size / sd.shape[1])}
+
+
 def sinkhorn_cost(Cm: Tensor, epsilon: float, iterations: int) -> Tensor:
     """Log-domain Sinkhorn between uniform marginals on cost matrices (B, N, M), then <P, C>: the arithmetic of
     gecco_sinkhorn_f32 (what ott's Sinkhorn solver iterates, gecco-jax metrics.py:141-156), in fp64."""

@@ -117,3 +117,56 @@ def test_emd_exact_and_sinkhorn():
     # more entropy, more blur: the transport cost grows with epsilon
     assert (metrics.sinkhorn_emd(a.cuda(), b.cuda(), epsilon=0.05, iterations=100) >
             metrics.sinkhorn_emd(a.cuda(), b.cuda(), epsilon=0.01, iterations=100)).all()
+
+
+@pytest.mark.parametrize("name", list(cases.SETMETRIC_CASES))
+def test_set_metrics_golden(name):
+    """Set-vs-set Chamfer distances (every pair of two sets of clouds, one HIP kernel per direction, no N x M matrix) and 1-NN
+    accuracy / MMD / coverage on the device against tests/golden/setmetrics.npz — values the reference's own numpy methods produced
+    (gecco-jax benchmark.py:21-39, 128-156; tools/make_golden_setmetrics.py)."""
+    import os
+    from gecco_amd import metrics
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "setmetrics.npz"))
+    samples, data = (t.cuda() for t in cases.setmetric_inputs(name))
+    for kind in ("chamfer", "chamfer_squared"):
+        tag = f"{name}/{kind}"
+        ss = metrics.pairwise_set_distance(samples, samples, kind)
+        sd = metrics.pairwise_set_distance(samples, data, kind)
+        dd = metrics.pairwise_set_distance(data, data, kind)
+        for m, key in ((ss, "ss"), (sd, "sd"), (dd, "dd")):
+            ref = torch.from_numpy(g[f"{tag}/{key}"])
+            diff = (m.cpu() - ref).abs()
+            if key != "sd":   # a cloud against itself: fp32 cancellation noise of |a|^2 + |b|^2 - 2 a.b under the root (the golden matrix is
+                assert diff.diagonal().max().item() <= 1e-3   # float64: exactly 0); `_one_nn_acc` overwrites the diagonal anyway
+                diff.fill_diagonal_(0.0)
+            assert diff.max().item() <= 2e-5 * ref.max().item(), (tag, key)
+        # the metrics on the GOLDEN matrices (bit-identical inputs: the integer-valued outputs must be equal), then end to end
+        dev = {k: torch.from_numpy(g[f"{tag}/{k}"]).cuda() for k in ("ss", "sd", "dd")}
+        got = metrics.set_metrics(dev["ss"], dev["sd"], dev["dd"])
+        want = g[f"{tag}/metrics"]
+        assert float(got["1-nn"]) == pytest.approx(want[0], abs=1e-7) and float(got["cov"]) == pytest.approx(want[2], abs=1e-7)
+        assert float(got["mmd"]) == pytest.approx(want[1], rel=1e-6)
+        e2e = metrics.evaluate_sets(samples, data, kind)
+        assert float(e2e["mmd"]) == pytest.approx(want[1], rel=1e-4)
+
+
+def test_set_distance_shapes_and_symmetry():
+    """Ragged shapes (S != T, N != M, clouds that do not fill a thread's 8 points or a 2048-point LDS tile), the pairwise entry of
+    the matrix against the per-pair kernel, symmetry of a set against itself."""
+    from gecco_amd import metrics
+    rs = np.random.RandomState(5)
+    a = torch.from_numpy(rs.randn(5, 300, 3).astype(np.float32)).cuda()
+    b = torch.from_numpy(rs.randn(9, 2500, 3).astype(np.float32)).cuda()
+    for kind in ("chamfer", "chamfer_squared"):
+        D = metrics.pairwise_set_distance(a, b, kind)
+        assert D.shape == (5, 9)
+        ref = cpu_ref.set_pairwise_distance(a.cpu().double(), b.cpu().double(), kind == "chamfer_squared")
+        assert (D.cpu().double() - ref).abs().max().item() <= 2e-5 * ref.max().item()
+        for s, t in ((0, 0), (4, 8), (2, 5)):
+            one = metrics.chamfer_distance(a[s], b[t], squared=kind == "chamfer_squared")
+            assert abs(float(one) - float(D[s, t])) <= 2e-6 * float(one)
+        Daa = metrics.pairwise_set_distance(a, a, kind)
+        assert torch.equal(Daa, Daa.t().contiguous()) or (Daa - Daa.t()).abs().max().item() <= 1e-6 * Daa.max().item()
+        assert Daa.diagonal().abs().max().item() <= 1e-3   # a cloud against itself: the clamp hides the cancellation noise of |a|^2 + |b|^2 - 2ab
+    E = metrics.pairwise_set_distance(a[:3, :64], b[:2, :64], "emd", block_size=2)
+    assert E.shape == (3, 2) and torch.isfinite(E).all()

@@ -133,3 +133,20 @@ def test_loss_and_grads(golden_dir):
     for k, v in g.items():
         if k.startswith("grad."):
             _close(pg[k[5:]].grad, v, 2e-4)
+
+
+@pytest.mark.parametrize("name", list(cases.SETMETRIC_CASES))
+def test_set_metrics(golden_dir, name):
+    """Set-vs-set distances and 1-NNA / MMD / COV (gecco-jax benchmark.py:21-39, 128-156): the oracle's restatement against the
+    values the reference's OWN numpy methods produced (tools/make_golden_setmetrics.py executed them from /root/reference)."""
+    g = np.load(os.path.join(golden_dir, "setmetrics.npz"))
+    samples, data = cases.setmetric_inputs(name)
+    for kind, sq in (("chamfer", False), ("chamfer_squared", True)):
+        tag = f"{name}/{kind}"
+        ss = cpu_ref.set_pairwise_distance(samples.double(), samples.double(), sq).numpy()
+        sd = cpu_ref.set_pairwise_distance(samples.double(), data.double(), sq).numpy()
+        dd = cpu_ref.set_pairwise_distance(data.double(), data.double(), sq).numpy()
+        for m, key in ((ss, "ss"), (sd, "sd"), (dd, "dd")):
+            assert np.abs(m - g[f"{tag}/{key}"]).max() <= 1e-6 * g[f"{tag}/{key}"].max()
+        got = cpu_ref.set_metrics(g[f"{tag}/ss"], g[f"{tag}/sd"], g[f"{tag}/dd"])
+        assert [got["1-nn"], got["mmd"], got["cov"]] == pytest.approx(list(g[f"{tag}/metrics"]), rel=1e-6)

@@ -157,6 +157,7 @@ SIGNATURES = {
     "gecco_linear_lift_workspace_bytes": (sz, [C.POINTER(GeccoLinearLift), i, i]),
     "gecco_nchw_to_nhwc_f32": (i, [vp, vp, i, i, i, i, vp]),
     "gecco_bilinear_taps_f32": (i, [vp, i, i, vp, vp, vp, vp, sz, vp]),
+    "gecco_ray_lookup_taps_f32": (i, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, vp]),
     "gecco_ray_lookup_f32": (i, [vp, vp, vp, C.POINTER(GeccoReparam), C.POINTER(GeccoPyramid), vp, vp, i, i, vp]),
     "gecco_lookup_row_tiles": (i, [i]),
     "gecco_ray_lookup_bwd_f32": (i, [vp, vp, vp, C.POINTER(GeccoReparam), C.POINTER(GeccoPyramid), vp, PP, i, i, vp]),

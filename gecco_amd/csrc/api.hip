@@ -1604,6 +1604,16 @@ int gecco_ray_lookup_f32(const float* geom, const float* coef, const float* K, c
     return 0;
 }
 
+int gecco_ray_lookup_taps_f32(const float* geom, const float* coef, const float* K, const GeccoReparam* rp, const GeccoPyramid* pyr, float* uv,
+                              int* x0, int* y0, float* wx1, float* wy1, int B, int N, void* stream) {
+    if (!geom || !K || !pyr || !uv || !x0 || !y0 || !wx1 || !wy1) return fail(-1, "ray_lookup_taps: null argument");
+    LookupArgs a;
+    int rc = make_lookup_args(rp, pyr, &a);
+    if (rc) return rc;
+    TRY(ray_lookup_taps_launch(geom, coef, K, a, uv, x0, y0, wx1, wy1, B, N, (hipStream_t)stream), "ray_lookup_taps");
+    return 0;
+}
+
 int gecco_ray_lookup_bwd_f32(const float* geom, const float* coef, const float* K, const GeccoReparam* rp,
                              const GeccoPyramid* pyr, const float* dout, float* const* dfeat, int B, int N,
                              void* stream) {

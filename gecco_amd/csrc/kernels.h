@@ -317,6 +317,8 @@ struct LookupArgs {
 int lookup_row_tile();
 int ray_lookup_launch(const float* geom, const float* coef, const float* K, const LookupArgs& a, float* out,
                       float* stats, int B, int N, hipStream_t st);
+int ray_lookup_taps_launch(const float* geom, const float* coef, const float* K, const LookupArgs& a, float* uv, int* x0, int* y0, float* wx1,
+                           float* wy1, int B, int N, hipStream_t st);   // the lookup's coordinate chain alone (uv, taps per level)
 int ray_lookup_dgeom_launch(const float* geom, const float* K, const LookupArgs& a, const float* dout, float* dgeom, float* dKpart, int B,
                             int N, hipStream_t st);   // gradients with respect to the geometry (B, N, 3) and (partials, (B, T, 4)) fx, cx, fy, cy
 int ray_lookup_bwd_launch(const float* geom, const float* coef, const float* K, const LookupArgs& a,

@@ -531,6 +531,30 @@ __global__ void bilinear_taps_kernel(const float* __restrict__ uv, int Hh, int W
     wy1[i] = t.iy - (float)t.y0;
 }
 
+// the fused lookup's coordinate chain on its own (diagnostics / parity tests): geometry -> reparametrisation -> projection -> taps, through
+// the SAME device functions ray_lookup_kernel calls (project_uv, bilinear_taps), one thread per point.  uv (B, N, 2); per level l:
+// x0 / y0 (L, B, N) int32 and the fractional weights wx1 = ix - x0, wy1 = iy - y0 (L, B, N)
+__global__ void ray_lookup_taps_kernel(const float* __restrict__ geom, const float* __restrict__ coef, const float* __restrict__ K, LookupArgs a,
+                                       float* __restrict__ uv, int* __restrict__ x0, int* __restrict__ y0, float* __restrict__ wx1,
+                                       float* __restrict__ wy1, int B, int N) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, total = (size_t)B * N;
+    if (i >= total) return;
+    const int b = (int)(i / N);
+    const float cin = coef ? coef[4 * b + 2] : 1.0f;
+    const float* gp = geom + i * 3;
+    float u, v;
+    project_uv(cin * gp[0], cin * gp[1], cin * gp[2], K + (size_t)b * 9, a.reparam_kind, a.rp_mean, a.rp_std, a.logit_scale, u, v);
+    uv[2 * i] = u;
+    uv[2 * i + 1] = v;
+    for (int l = 0; l < a.n_levels; ++l) {
+        const Taps t = bilinear_taps(u, v, a.H[l], a.W[l]);
+        x0[l * total + i] = t.x0;
+        y0[l * total + i] = t.y0;
+        wx1[l * total + i] = t.ix - (float)t.x0;
+        wy1[l * total + i] = t.iy - (float)t.y0;
+    }
+}
+
 // (B, C, H, W) -> (B, H, W, C) through a 32x33 LDS tile (both sides coalesced)
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int HW) {
     __shared__ float tile[32][33];
@@ -638,6 +662,13 @@ int bilinear_taps_launch(const float* uv, int Hh, int Ww, int* x0, int* y0, floa
                          hipStream_t st) {
     hipLaunchKernelGGL(bilinear_taps_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, uv, Hh, Ww, x0, y0,
                        wx1, wy1, n);
+    return (int)hipGetLastError();
+}
+
+int ray_lookup_taps_launch(const float* geom, const float* coef, const float* K, const LookupArgs& a, float* uv, int* x0, int* y0, float* wx1,
+                           float* wy1, int B, int N, hipStream_t st) {
+    const size_t total = (size_t)B * N;
+    hipLaunchKernelGGL(ray_lookup_taps_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, geom, coef, K, a, uv, x0, y0, wx1, wy1, B, N);
     return (int)hipGetLastError();
 }
 

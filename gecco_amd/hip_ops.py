@@ -770,6 +770,23 @@ def ray_lookup(geom: Tensor, K: Tensor, levels_nhwc: Sequence[Tensor], reparam: 
     return (out, stats) if want_stats else out
 
 
+def ray_lookup_taps(geom: Tensor, K: Tensor, levels_nhwc: Sequence[Tensor], reparam: _lib.GeccoReparam, coef: Tensor | None = None):
+    """The fused lookup's coordinate chain alone (same device functions as the lookup kernel): uv (B, N, 2) and, per pyramid level,
+    integer taps x0 / y0 and fractional weights wx1 / wy1, each (L, B, N).  Diagnostics / index bit-exactness tests."""
+    lib = _lib.load()
+    B, N, _ = geom.shape
+    pyr = make_pyramid(levels_nhwc)
+    L = len(levels_nhwc)
+    uv = torch.empty(B, N, 2, device=geom.device, dtype=torch.float32)
+    x0 = torch.empty(L, B, N, device=geom.device, dtype=torch.int32)
+    y0 = torch.empty_like(x0)
+    wx = torch.empty(L, B, N, device=geom.device, dtype=torch.float32)
+    wy = torch.empty_like(wx)
+    check(lib.gecco_ray_lookup_taps_f32(_ptr(geom), _ptr(coef), _ptr(K), C.byref(reparam), C.byref(pyr), _ptr(uv), C.c_void_p(x0.data_ptr()),
+                                        C.c_void_p(y0.data_ptr()), _ptr(wx), _ptr(wy), B, N, _stream()), "gecco_ray_lookup_taps_f32")
+    return uv, x0, y0, wx, wy
+
+
 class RayNetworkPlan:
     """EDMPrecond(RayNetwork(SetTransformer, reparam)) with a precomputed pyramid = the image-conditional
     Diffusion.forward, one C call."""

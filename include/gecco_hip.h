@@ -465,6 +465,12 @@ int gecco_nchw_to_nhwc_f32(const float* src, float* dst, int B, int C, int H, in
  * x0,y0 int32 (n), wx1 = ix - x0, wy1 = iy - y0.  Bit-exact against the oracle's op order. */
 int gecco_bilinear_taps_f32(const float* uv, int H, int W, int* x0, int* y0, float* wx1, float* wy1, size_t n,
                             void* stream);
+/* The fused lookup's whole coordinate chain for every point — geometry (x c_in[b] when coef is given) -> reparametrisation ->
+ * project_points -> the bilinear taps of every pyramid level — computed by the SAME device functions gecco_ray_lookup_f32's kernel
+ * calls (models/ray.py:64-87, reparam.py:102-110, 159-177, 131-137).  Diagnostics and the bit-exactness tests of the index math:
+ * uv (B, N, 2); x0 / y0 int32 and wx1 = ix - x0 / wy1 = iy - y0, each (n_levels, B, N).  Pyramid pointers are not read. */
+int gecco_ray_lookup_taps_f32(const float* geom, const float* coef, const float* K, const GeccoReparam* rp, const GeccoPyramid* pyr, float* uv,
+                              int* x0, int* y0, float* wx1, float* wy1, int B, int N, void* stream);
 
 /* RayNetwork.extract_image_features (models/ray.py:64-87): geom (B, N, 3) diffusion-space geometry
  * (multiplied by coef's c_in when coef != NULL), K (B, 3, 3) -> out (B, N, sum C).  stats: NULL or

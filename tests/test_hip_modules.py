@@ -231,6 +231,90 @@ def test_bilinear_tap_indices_bit_exact(hw):
     assert torch.equal(gwx.cpu(), wx) and torch.equal(gwy.cpu(), wy)
 
 
+def _lookup_chain_inputs(seed, B=3, N=60000):
+    """Geometry that exercises the projection's corners: in-frustum points, points behind the camera, |z| at / below / just above the
+    1e-8 guard of kornia's divide, far outside the image; per-sample intrinsics."""
+    rs = np.random.RandomState(seed)
+    g = rs.randn(B, N, 3).astype(np.float32)
+    g[..., 2] = rs.uniform(0.5, 5.0, size=(B, N)).astype(np.float32)
+    g[:, :2000, 2] *= -1.0                                              # behind the camera
+    g[:, 2000:2200, 2] = np.float32(1e-8)                               # exactly the guard (|z| > eps is false)
+    g[:, 2200:2400, 2] = np.nextafter(np.float32(1e-8), np.float32(1))  # one ulp above it
+    g[:, 2400:2600, 2] = 0.0
+    g[:, 2600:2800, 2] = np.float32(-1e-8)                              # z + eps == 0 would divide by zero: the guard picks 1
+    g[:, 2800:4000, :2] *= 30.0                                         # far outside the image
+    f = rs.uniform(0.8, 1.5, size=(B,)).astype(np.float32)
+    K = np.zeros((B, 3, 3), dtype=np.float32)
+    K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2], K[:, 2, 2] = f, f * 1.1, 0.5, 0.45, 1.0
+    return torch.from_numpy(g), torch.from_numpy(K)
+
+
+@pytest.mark.parametrize("kind", ["none", "gaussian"])
+def test_fused_lookup_index_chain_bit_exact(kind):
+    """North-star bar, through the fused lookup: geometry -> reparametrisation -> project_points -> taps as ray_lookup_kernel
+    computes them (gecco_ray_lookup_taps_f32 runs the kernel's own device functions, csrc/lookup.hip project_uv / bilinear_taps)
+    against the oracle's chain from the SAME geometry bits (models/ray.py:64-87, reparam.py:57-63, kornia project_points): the
+    projected uv, every level's integer taps and the fractional weights must be identical to the bit — with and without the
+    EDM input scale c_in, including z ~ 0, points behind the camera and far outside the image."""
+    from gecco_amd import hip_ops
+    geom, K = _lookup_chain_inputs(11 if kind == "none" else 12)
+    B, N, _ = geom.shape
+    hw = [(56, 56), (28, 28), (14, 14), (7, 9)]
+    levels = [torch.zeros(B, h, w, 4, device="cuda") for h, w in hw]
+    if kind == "gaussian":
+        mean, sigma = torch.tensor(cases.GAUSS_MEAN), torch.tensor(cases.GAUSS_SIGMA)
+        mean_d, sigma_d = mean.cuda(), sigma.cuda()          # (the table holds raw pointers: the tensors must outlive it)
+        rp = hip_ops.make_reparam(1, mean_d, sigma_d)
+    else:
+        mean = sigma = None
+        rp = hip_ops.make_reparam(0)
+    sig = torch.tensor([0.002, 1.0, 80.0])
+    coef = torch.stack([torch.zeros(3), torch.zeros(3), 1.0 / torch.sqrt(sig * sig + 1.0), torch.zeros(3)], dim=1).contiguous()
+    for use_cin in (False, True):
+        gin = geom * coef[:, 2].reshape(B, 1, 1) if use_cin else geom      # EDMPrecond's c_in * x (diffusion.py:52-56), one fp32 product
+        xyz = cpu_ref.gaussian_diffusion_to_data(gin, mean, sigma) if kind == "gaussian" else gin
+        uv = cpu_ref.project_points(xyz, K)
+        guv, gx0, gy0, gwx, gwy = hip_ops.ray_lookup_taps(geom.cuda(), K.cuda(), levels, rp, coef=coef.cuda() if use_cin else None)
+        assert torch.equal(guv.cpu(), uv), (kind, use_cin, (guv.cpu() != uv).sum().item())
+        # a coordinate beyond int32 (z ~ 0: uv ~ 1e8) converts to INT_MIN on the host and saturates on the device — either way every tap of
+        # such a point lies outside the image (zero padding): identical bits are required wherever the conversion is defined
+        ok = (uv.abs() < 1e6).all(-1)
+        assert ok.float().mean().item() > 0.9
+        for l, (h, w) in enumerate(hw):
+            x0, y0, wx, wy = cpu_ref.bilinear_taps(uv, h, w)
+            assert torch.equal(gx0[l].cpu()[ok], x0[ok]) and torch.equal(gy0[l].cpu()[ok], y0[ok]), (kind, use_cin, l)
+            assert torch.equal(gwx[l].cpu()[ok], wx[ok]) and torch.equal(gwy[l].cpu()[ok], wy[ok]), (kind, use_cin, l)
+            far = ~ok
+            gx, gy = gx0[l].cpu()[far], gy0[l].cpu()[far]
+            assert (((gx < -1) | (gx > w)) | ((gy < -1) | (gy > h))).all(), (kind, use_cin, l)
+
+
+def test_fused_lookup_index_chain_uvl():
+    """The UVL chain goes through tanh / exp, where the device's functions and libm differ by an ulp or two: the projected uv is
+    compared in ulps (histogram printed) and the INTEGER taps must not flip on the lookup fixtures' geometry nor on a dense sample
+    — wherever a flip would need uv within an ulp of a texel edge, it is reported with its distance to the edge."""
+    from gecco_amd import hip_ops
+    for name in list(cases.LOOKUP_CASES):
+        feats, K, geom, um, us = cases.lookup_inputs(name)
+        um_d, us_d = um.cuda(), us.cuda()
+        rp = hip_ops.make_reparam(2, um_d, us_d, 1.1)
+        levels = [f.permute(0, 2, 3, 1).contiguous().cuda() for f in feats]
+        guv, gx0, gy0, gwx, gwy = hip_ops.ray_lookup_taps(geom.cuda(), K.cuda(), levels, rp)
+        uv = cpu_ref.project_points(cpu_ref.uvl_diffusion_to_data(geom, K, um, us), K)
+        ulps = (guv.cpu().view(torch.int32) - uv.view(torch.int32)).abs()
+        hist = torch.bincount(ulps.flatten().clamp(max=8), minlength=9).tolist()
+        flips = 0
+        for l, f in enumerate(feats):
+            x0, y0, wx, wy = cpu_ref.bilinear_taps(uv, f.shape[2], f.shape[3])
+            bad = (gx0[l].cpu() != x0) | (gy0[l].cpu() != y0)
+            flips += int(bad.sum())
+            assert (gwx[l].cpu() - wx)[~bad].abs().max().item() <= 1e-4 and (gwy[l].cpu() - wy)[~bad].abs().max().item() <= 1e-4
+        print(f"{name}: uv ulp histogram (0..7, >=8) {hist}, integer tap flips {flips} of {uv.numel() // 2 * len(feats)}")
+        # (ulps of uv are large only where uv itself is small: the chain subtracts cx from a value near it; the absolute bar below is the
+        # meaningful one: 1e-6 of a coordinate that spans [0, 1] is 1e-4 of a texel on the finest level)
+        assert (guv.cpu() - uv).abs().max().item() <= 1e-6 and flips == 0, (name, hist, flips, (guv.cpu() - uv).abs().max().item())
+
+
 @pytest.mark.parametrize("name", list(cases.LOOKUP_CASES))
 def test_lookup_golden(golden_dir, name):
     from gecco_amd.models.activation import GaussianActivation

@@ -450,7 +450,7 @@ def train_bench(args, rank, world, dev):
         example = Example(data, None)
         params = list(model.parameters())
     gd.broadcast_parameters(model)
-    opt = FusedAdamEMA(params, lr=1e-4, ema_decay=0.99)
+    opt = FusedAdamEMA(params, lr=1e-4, ema_decay=0.99, amp_on_device=bool(args.amp))   # --amp: scale / found_inf stay on the device
     red = gd.BucketedGradAllReducer(opt, bucket_bytes=args.bucket_mb << 20, force_collective=args.force_collective)
     # --amp: what Lightning's precision="16-mixed" does around the reference's training_step (torch default scaler settings);
     # FusedAdamEMA takes the scaler's scale / found_inf tensors on the device (no host read-back of found_inf per step)

@@ -40,7 +40,7 @@ class FusedAdamEMA(torch.optim.Optimizer):
 
     def __init__(self, params: Iterable[Tensor] | Iterable[dict], lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, ema_decay: float | None = 0.9999, every_n_steps: int = 1,
-                 current_step: int = 0, missing_grad: str = "raise"):
+                 current_step: int = 0, missing_grad: str = "raise", amp_on_device: bool = False):
         if ema_decay is not None and not 0.0 <= ema_decay <= 1.0:
             raise ValueError("EMA decay value must be between 0 and 1")
         defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
@@ -58,6 +58,15 @@ class FusedAdamEMA(torch.optim.Optimizer):
         self._grad_mult = 1.0                     # `grad_scale`: set by a summing gradient all-reduce to 1 / world_size
         self._amp_scale: Tensor | None = None     # torch.amp.GradScaler's scale tensor while scaler.step(self) runs (see grad_scale)
         self._amp_skipped: Tensor | None = None   # device counter of the steps a GradScaler's found_inf skipped
+        # The GradScaler protocol below is OPT-IN, per instance.  With the attribute set, Lightning's MixedPrecision plugin (the
+        # reference's trainer) treats the optimizer as unscaling internally: it skips `scaler.unscale_` and its `clip_gradients`
+        # refuses a clip value — and both shipped configs combine precision="16-mixed" with gradient_clip_val=1.0
+        # (example_configs/*.py).  The default (False) is therefore the host path every trainer knows: unscale -> clip -> step,
+        # found_inf read on the host by GradScaler.  amp_on_device=True: the scale and found_inf stay on the device (one launch, no
+        # host read; gradient clipping is then the caller's business, on unscaled gradients it does not have).
+        if amp_on_device:
+            self._step_supports_amp_scaling = True
+        self.amp_on_device = bool(amp_on_device)
         # A parameter whose .grad is None at step() (zero_grad(set_to_none=True) and no gradient arrived): torch.optim.Adam skips it;
         # the one-launch update cannot.  "raise" (default) refuses the step, "zero" updates it with a zero gradient (moments decay,
         # the step count advances).  With zero_grad() (views of the flat buffer) a missing gradient is indistinguishable from zeros.
@@ -76,7 +85,8 @@ class FusedAdamEMA(torch.optim.Optimizer):
     # the device (gecco_adam_ema_step_amp_f32): a skipped step writes nothing — parameters, moments, EMA — exactly like the
     # skipped optimizer.step() of the host path, and Adam's step count does not advance (counted on the device: `_amp_skipped`).
     # `grad_scale` therefore has two faces: a float is this optimizer's own multiplier (1 / world size), a tensor is the scaler's.
-    _step_supports_amp_scaling = True
+    # (Instance attribute, set by amp_on_device=True: see __init__.)  With every_n_steps > 1 an EMA update that falls on a skipped
+    # step is lost, not deferred, and `current_step` counts skipped steps too (the host cannot know): use every_n_steps == 1 with it.
 
     @property
     def grad_scale(self):
@@ -236,6 +246,8 @@ class FusedAdamEMA(torch.optim.Optimizer):
         if self._missing_grad and self.missing_grad != "zero":
             n, self._missing_grad = self._missing_grad, 0
             self._missing_ids.clear()
+            self.__dict__.pop("found_inf", None)   # (GradScaler.step does not clean up behind a step that raises)
+            self._amp_scale = None
             raise RuntimeError(
                 f"FusedAdamEMA.step(): {n} trainable parameter(s) received no gradient this step.  torch.optim.Adam (and the "
                 "reference's EMAOptimizer around it) SKIPS such parameters; this optimizer's one-launch update over the flat buffers "
@@ -255,7 +267,13 @@ class FusedAdamEMA(torch.optim.Optimizer):
         if g.get("amsgrad") or g.get("maximize"):
             raise NotImplementedError("FusedAdamEMA: amsgrad / maximize are not supported")
         self._adam_step += 1
-        self.launch(self._adam_step, self._should_update_at_step())
+        try:
+            self.launch(self._adam_step, self._should_update_at_step())
+        finally:
+            # GradScaler.step deletes these only when step() returns normally: a step that raised must not leave a stale scale /
+            # found_inf for a later plain step()
+            self.__dict__.pop("found_inf", None)
+            self._amp_scale = None
         from .autograd import WEIGHT_IMAGES
         WEIGHT_IMAGES.invalidate()   # the kernel updates the weights through raw pointers: no version counter moves
         self.current_step += 1

@@ -36,7 +36,7 @@ def main():
     m.load_state_dict(uncond_state_dict(W.linear_lift_state_dict(11, D, L, 64, 8)), strict=True)
     model = m.cuda().train()
     gd.broadcast_parameters(model)
-    opt = FusedAdamEMA(model.parameters(), lr=1e-3, ema_decay=0.9)
+    opt = FusedAdamEMA(model.parameters(), lr=1e-3, ema_decay=0.9, amp_on_device=True)
     red = gd.BucketedGradAllReducer(opt, bucket_bytes=64 << 10, force_collective=force)   # several buckets
     g = torch.Generator().manual_seed(5)
     data = torch.randn(B, N, 3, generator=g).cuda()

@@ -173,7 +173,8 @@ def test_mlp_function_under_autocast_runs_fp16_linears(kind):
 
 
 def test_fused_adam_in_the_grad_scaler_protocol_matches_torch():
-    """scaler.step(FusedAdamEMA): the optimizer declares `_step_supports_amp_scaling`, so torch.amp.GradScaler hands it the scale and
+    """scaler.step(FusedAdamEMA(amp_on_device=True)): the optimizer then declares `_step_supports_amp_scaling` (opt-in, per instance: with
+    it Lightning's MixedPrecision plugin would skip unscale_ and refuse gradient clipping), so torch.amp.GradScaler hands it the scale and
     found_inf tensors and never reads found_inf back on the host.  Against torch.optim.Adam driven by a GradScaler the ordinary way
     (unscale_, host decision): same parameters (1e-6) over steps that include an overflow (skipped: nothing moves, Adam's step
     count does not advance, the scale backs off), and the optimizer state that is saved afterwards carries torch's step count."""
@@ -203,7 +204,8 @@ def test_fused_adam_in_the_grad_scaler_protocol_matches_torch():
     ref_params = [p.detach().clone() for p in ps]
     # the HIP side: a real torch.amp.GradScaler around FusedAdamEMA
     ps = [torch.nn.Parameter(t.clone().cuda()) for t in init]
-    fused = FusedAdamEMA(ps, lr=1e-2, ema_decay=0.9)
+    fused = FusedAdamEMA(ps, lr=1e-2, ema_decay=0.9, amp_on_device=True)
+    assert not hasattr(FusedAdamEMA(ps[:1], lr=1e-2), "_step_supports_amp_scaling")   # the default leaves the scaler's host path
     scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 10, growth_interval=2)
     scales = []
     for it, gs in enumerate(grads):
@@ -228,10 +230,12 @@ def test_fused_adam_in_the_grad_scaler_protocol_matches_torch():
 
 
 def test_grad_scaler_unscale_then_clip_then_step():
-    """Lightning's order when the trainer clips gradients (both shipped configs do: gradient_clip_val):
-    scaler.unscale_(optimizer) -> clip_grad_norm_ -> scaler.step(optimizer).  The scaler then hands FusedAdamEMA `grad_scale = None`
-    (already unscaled) with the found_inf of the unscale pass: the kernel must not divide again; against torch.optim.Adam's
-    single-tensor path on the host with the same clipping."""
+    """Lightning's order when the trainer clips gradients (both shipped configs do: precision="16-mixed" with gradient_clip_val = 1,
+    SURVEY section 3): scaler.unscale_(optimizer) -> clip_grad_norm_ -> scaler.step(optimizer).  That order exists only for an optimizer
+    WITHOUT `_step_supports_amp_scaling` (Lightning's plugin skips unscale_ and refuses to clip otherwise) — FusedAdamEMA's default: the
+    scaler unscales, reads found_inf on the host and calls the plain step.  With amp_on_device=True a hand-written loop may still unscale
+    first: the scaler then hands over `grad_scale = None` with the found_inf of the unscale pass and the kernel must not divide again.
+    Both against torch.optim.Adam's single-tensor path on the host with the same clipping."""
     from gecco_amd.optim import FusedAdamEMA
     rs = np.random.RandomState(2)
     shapes = [(32, 24), (24,), (5, 3)]
@@ -244,22 +248,23 @@ def test_grad_scaler_unscale_then_clip_then_step():
             p.grad = (g * 512.0) * (1.0 / 512.0)
         torch.nn.utils.clip_grad_norm_(ps, 1.0, foreach=False)
         ref_opt.step()
-    ps2 = [torch.nn.Parameter(t.clone().cuda()) for t in init]
-    fused = FusedAdamEMA(ps2, lr=1e-2, ema_decay=None)
-    scaler = torch.amp.GradScaler("cuda", init_scale=512.0, growth_interval=1000)
-    for gs in grads:
-        fused.zero_grad(set_to_none=True)
-        scaler.scale(torch.zeros(1, device="cuda"))
-        for p, g in zip(ps2, gs):
-            p.grad = (g.cuda() * scaler.get_scale()).clone()
-        scaler.unscale_(fused)
-        torch.nn.utils.clip_grad_norm_(ps2, 1.0)
-        scaler.step(fused)
-        scaler.update()
-    torch.cuda.synchronize()
-    for a, b in zip(ps, ps2):
-        assert _rel(b.detach(), a.detach()) <= 2e-6
-    assert fused.adam_steps_taken == 3
+    for on_device in (False, True):
+        ps2 = [torch.nn.Parameter(t.clone().cuda()) for t in init]
+        fused = FusedAdamEMA(ps2, lr=1e-2, ema_decay=None, amp_on_device=on_device)
+        scaler = torch.amp.GradScaler("cuda", init_scale=512.0, growth_interval=1000)
+        for gs in grads:
+            fused.zero_grad(set_to_none=True)
+            scaler.scale(torch.zeros(1, device="cuda"))
+            for p, g in zip(ps2, gs):
+                p.grad = (g.cuda() * scaler.get_scale()).clone()
+            scaler.unscale_(fused)
+            torch.nn.utils.clip_grad_norm_(ps2, 1.0)
+            scaler.step(fused)
+            scaler.update()
+        torch.cuda.synchronize()
+        for a, b in zip(ps, ps2):
+            assert _rel(b.detach(), a.detach()) <= 2e-6, on_device
+        assert fused.adam_steps_taken == 3
 
 
 def test_c2_full_size_gradients_under_autocast_vs_oracle():
@@ -452,7 +457,7 @@ def test_scaler_dynamics_on_a_real_run():
     from tests.test_hip_training import _small_training_setup
     ag.WEIGHT_IMAGES.__init__()
     m, batch = _small_training_setup(13)
-    opt = FusedAdamEMA(m.parameters(), lr=2e-4, ema_decay=0.99)
+    opt = FusedAdamEMA(m.parameters(), lr=2e-4, ema_decay=0.99, amp_on_device=True)
     scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 20, growth_interval=8)
     losses, scales = [], []
     for it in range(120):

@@ -552,8 +552,8 @@ def test_training_step_under_autocast_and_grad_scaler(amp_arith, monkeypatch):
     """The reference's shipped trainer settings: `precision="16-mixed"` (example_configs/shapenet_airplane_unconditional.py:74,
     taskonomy_conditional.py:102) = torch.autocast(float16) around training_step + a GradScaler around the optimizer.  The HIP
     autograd Functions take and return fp32 tensors; under that autocast their linears run with fp16 operands (autograd.py
-    `_lin_precision`; GECCO_TRAIN_AMP=0 keeps split-bf16 there).  `scaler.step(FusedAdamEMA)` uses the scaler's device-side protocol
-    (`_step_supports_amp_scaling`: no host read-back of found_inf); an injected inf skips the step — parameters, moments, EMA
+    `_lin_precision`; GECCO_TRAIN_AMP=0 keeps split-bf16 there).  `scaler.step(FusedAdamEMA(amp_on_device=True))` uses the scaler's device-side protocol
+    (`_step_supports_amp_scaling`, opt-in: no host read-back of found_inf); an injected inf skips the step — parameters, moments, EMA
     untouched — and halves the scale.
     "off": the scaler's power-of-two loss scale passes through the backward exactly — parameters, moments and EMA equal the plain
     step's bit for bit.  "fp16": the step follows the plain one at fp16-operand accuracy (tests/test_hip_amp.py holds the gradients
@@ -565,7 +565,7 @@ def test_training_step_under_autocast_and_grad_scaler(amp_arith, monkeypatch):
         ag.WEIGHT_IMAGES.__init__()
         m, batch = _small_training_setup()
         from gecco_amd.optim import FusedAdamEMA
-        opt = FusedAdamEMA(m.parameters(), lr=1e-3, ema_decay=0.99)   # what configure_optimizers + the EMA callback amount to (optim.py)
+        opt = FusedAdamEMA(m.parameters(), lr=1e-3, ema_decay=0.99, amp_on_device=True)   # what configure_optimizers + the EMA callback amount to (optim.py)
         scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 12) if mode == "amp" else None
         for it in range(3):
             torch.manual_seed(100 + it)

@@ -190,15 +190,17 @@ int linear_pair(const float* A, const float* W1, const float* b1, int Nout1, flo
 }
 
 // Path switches for A/B runs and tests: gecco_set_option, or the environment (GECCO_ASTAT, GECCO_CHAIN) on first use.
-enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_HEADMAJOR = 2, OPT_MLPFUSED = 3, OPT_UNPOOLFUSED = 4, OPT_LO8 = 5, OPT_ACTIMG = 6, OPT_H8 = 7, OPT_KVQ64 = 8, OPT_H8AREG = 9, OPT_CHAIN2 = 10, OPT_UNPOOLH8 = 11, OPT_MLPW = 12, OPT_CHAINCL = 13, OPT_H6 = 14, OPT_KVFOLD = 15, OPT_COUNT = 16 };
-int g_options[OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
-const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor", "mlpfused", "unpoolfused", "lo8", "actimg", "h8", "kvq64", "h8areg", "chain2", "unpoolh8", "mlpw", "chaincl", "h6", "kvfold"};
+enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_HEADMAJOR = 2, OPT_MLPFUSED = 3, OPT_UNPOOLFUSED = 4, OPT_LO8 = 5, OPT_ACTIMG = 6, OPT_H8 = 7, OPT_KVQ64 = 8, OPT_H8AREG = 9, OPT_CHAIN2 = 10, OPT_UNPOOLH8 = 11, OPT_MLPW = 12, OPT_CHAINCL = 13, OPT_H6 = 14, OPT_KVFOLD = 15, OPT_MLPWSHARE = 16, OPT_COUNT = 17 };
+int g_options[OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor", "mlpfused", "unpoolfused", "lo8", "actimg", "h8", "kvq64", "h8areg", "chain2", "unpoolh8", "mlpw", "chaincl", "h6", "kvfold", "mlpwshare"};
 const char* const g_option_env[OPT_COUNT] = {"GECCO_ASTAT", "GECCO_CHAIN", "GECCO_HEADMAJOR", "GECCO_MLPFUSED", "GECCO_UNPOOLFUSED", "GECCO_LO8",
-                                             "GECCO_ACTIMG", "GECCO_H8", "GECCO_KVQ64", "GECCO_H8AREG", "GECCO_CHAIN2", "GECCO_UNPOOLH8", "GECCO_MLPW", "GECCO_CHAINCL", "GECCO_H6", "GECCO_KVFOLD"};
+                                             "GECCO_ACTIMG", "GECCO_H8", "GECCO_KVQ64", "GECCO_H8AREG", "GECCO_CHAIN2", "GECCO_UNPOOLH8", "GECCO_MLPW", "GECCO_CHAINCL", "GECCO_H6", "GECCO_KVFOLD", "GECCO_MLPWSHARE"};
 int option(int which) {
     if (g_options[which] < 0) {
         const char* e = getenv(g_option_env[which]);
-        g_options[which] = e ? (atoi(e) != 0) : 1;
+        // "mlpwshare" (the one-launch MLP leaves CUs to a second stream's kernels) is off unless the caller runs two streams: hip_ops.py
+        // sets it around a two-stream evaluation
+        g_options[which] = e ? (atoi(e) != 0) : (which != OPT_MLPWSHARE);
     }
     return g_options[which];
 }
@@ -644,7 +646,7 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         if (m0_done == 1 && mfw_on && im) {
             MlpWArgs ma{};
             ma.x = x; ma.out = x; ma.pro_a = w.a2; ma.pro_o = w.o2; ma.w_img = im + w.o_mf; ma.alpha = L.mlp.alpha;
-            ma.act = act; ma.stats = so; ma.B = B; ma.rows = N;
+            ma.act = act; ma.stats = so; ma.B = B; ma.rows = N; ma.share = option(OPT_MLPWSHARE);
             if ((act == 1 || act == 2) && !L.mlp.alpha) return fail(-6, "mlp: GaussianActivation needs alpha");
             TRY(mlp_fused_w_launch(ma, C, Wd, s), "mlp (one launch, w2)");
             sx = w.stats_x;
@@ -718,7 +720,7 @@ int gecco_set_option(const char* name, int value) {
             g_options[i] = value < 0 ? -1 : (value != 0);   // < 0: back to the environment / default
             return 0;
         }
-    return fail(-2, "set_option: unknown option '%s' (astat, chain, headmajor, mlpfused, unpoolfused, lo8, actimg, h8, kvq64, h8areg, chain2, unpoolh8, mlpw, chaincl, h6, kvfold)", name);
+    return fail(-2, "set_option: unknown option '%s' (astat, chain, headmajor, mlpfused, unpoolfused, lo8, actimg, h8, kvq64, h8areg, chain2, unpoolh8, mlpw, chaincl, h6, kvfold, mlpwshare)", name);
 }
 
 int gecco_linear_row_tiles(int rows) { return row_tiles_gemm(rows); }
@@ -1247,7 +1249,7 @@ int gecco_mlp_fused_w(const float* x, float* out, const float* pro_a, const floa
     if (W0 && W2) TRY(mlp_fused_w_image_launch(W0, b0, W2, b2, wsplit, C, width, alpha, act, s), "mlp_fused_w(image)");   // W0 == NULL: image ready (biases included)
     MlpWArgs ma{};
     ma.x = x; ma.out = out; ma.pro_a = pro_a; ma.pro_o = pro_o; ma.w_img = wsplit; ma.alpha = alpha; ma.act = act; ma.stats = stats;
-    ma.B = B; ma.rows = rows; ma.dbg_u = dbg_u;
+    ma.B = B; ma.rows = rows; ma.dbg_u = dbg_u; ma.share = option(OPT_MLPWSHARE);
     TRY(mlp_fused_w_launch(ma, C, width, s), "mlp_fused_w");
     return 0;
 }

@@ -173,6 +173,7 @@ struct MlpWArgs {
     float* stats;             // (B, rows / 128, 2, C) or null
     int B, rows;
     float* dbg_u;             // diagnostics: (B, rows, width) pre-activations of mlp.0 x the activation's argument scale (1 but for act 1 / 2), or null
+    int share;                // 1: another stream's kernels run beside this launch (two-stream evaluation): leave a quarter of the CUs to them
 };
 bool mlp_fused_w_supported(int C, int Wd, int rows);
 size_t mlp_fused_w_image_bytes(int C, int Wd);

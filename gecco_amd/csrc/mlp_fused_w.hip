@@ -788,11 +788,12 @@ int mfw_launch_a(const MlpWArgs& g, hipStream_t st) {
         if (const char* e = getenv("GECCO_MLPW_CUS")) { const int v = atoi(e); if (v > 0 && v <= cus) forced = v; }
         attr = true;
     }
-    // Blocks of a launch: a block of this kernel fills its CU, and an evaluation runs as two half batches on two streams (hip_ops.py): with
-    // three quarters of the CUs per launch the other stream's kernels find free CUs beside it — C2 4.53 -> 4.42 ms per evaluation (192 of 256;
-    // 128: 4.43).  Short launches (fewer than two tiles per CU) take a CU per tile.  GECCO_MLPW_CUS overrides.
+    // Blocks of a launch: a block of this kernel fills its CU.  When an evaluation runs as two half batches on two streams (hip_ops.py sets
+    // option "mlpwshare" around it -> g.share) three quarters of the CUs per launch let the other stream's kernels find free CUs beside
+    // it — C2 4.53 -> 4.42 ms per evaluation (192 of 256; 128: 4.43); alone on the device a launch takes every CU (1024 tiles: 4 rounds
+    // instead of 6).  Short launches (fewer than two tiles per CU) take a CU per tile.  GECCO_MLPW_CUS overrides.
     const int ntiles = g.B * (g.rows / 128);
-    const int want = forced ? forced : (ntiles >= 2 * cus ? cus * 3 / 4 : cus);
+    const int want = forced ? forced : (g.share && ntiles >= 2 * cus ? cus * 3 / 4 : cus);
     const int grid = ntiles < want ? ntiles : want;
     hipLaunchKernelGGL((mlp_fused_w_kernel<ACT>), dim3(grid), dim3(256), W_LDS, st, g);
     return (int)hipGetLastError();

@@ -642,11 +642,16 @@ def _two_stream_halves(B: int, call, tensors, parts: int = 2) -> None:
         _FWD_SIDE["streams"].append(torch.cuda.Stream())
     sides, main = _FWD_SIDE["streams"][:parts - 1], torch.cuda.current_stream()
     cuts = [B * i // parts for i in range(parts + 1)]
-    for i, side in enumerate(sides, start=1):
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            call(cuts[i], cuts[i + 1], i)
-    call(cuts[0], cuts[1], 0)
+    lib = _lib.load()
+    lib.gecco_set_option(b"mlpwshare", 1)   # launches that fill their CUs leave room for the other stream's kernels (mlp_fused_w.hip)
+    try:
+        for i, side in enumerate(sides, start=1):
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                call(cuts[i], cuts[i + 1], i)
+        call(cuts[0], cuts[1], 0)
+    finally:
+        lib.gecco_set_option(b"mlpwshare", -1)
     for side in sides:
         main.wait_stream(side)
     if not torch.cuda.is_current_stream_capturing():   # (a captured graph owns its memory: nothing to tell the allocator)

@@ -269,11 +269,12 @@ class FusedAdamEMA(torch.optim.Optimizer):
         self._adam_step += 1
         try:
             self.launch(self._adam_step, self._should_update_at_step())
-        finally:
-            # GradScaler.step deletes these only when step() returns normally: a step that raised must not leave a stale scale /
-            # found_inf for a later plain step()
+        except BaseException:
+            # GradScaler.step deletes these itself when step() returns normally (and fails if they are gone by then): only a step
+            # that raised must not leave a stale scale / found_inf for a later plain step()
             self.__dict__.pop("found_inf", None)
             self._amp_scale = None
+            raise
         from .autograd import WEIGHT_IMAGES
         WEIGHT_IMAGES.invalidate()   # the kernel updates the weights through raw pointers: no version counter moves
         self.current_step += 1

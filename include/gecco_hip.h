@@ -109,6 +109,8 @@ int gecco_linear_f32(const float* A, const float* W, const float* bias, const fl
  *   "kvq64" (head-major fp16 q), "h8areg", feature_dim in {128, 256, 384}.
  *   "mlpw" (default 1): the "w2" mode (precision 4) runs the point MLP of a layer (AdaGN apply, mlp.0, activation, mlp.2, residual,
  *   statistics) as one launch (gecco_mlp_fused_w); 0: as the mixed mode does (gecco_linear_h8_img_f32 + gecco_linear_h8_areg_f32).
+ *   "mlpwshare" (default 0): gecco_mlp_fused_w launches (a block fills its CU) take three quarters of the CUs instead of all of them, so
+ *   that another stream's kernels run beside them: set around an evaluation issued as two half batches on two streams.
  *   "h6" (default 1): mixed mode computes mlp.0's two cross terms as fp6 (e2m3) x fp6 with one E8M0 scale per lane and 64-k group (the
  *   scale blocks of v_mfma_scale_f32_32x32x64_f8f6f4) instead of fp8 with fixed scales: half their matrix cycles, the same accuracy;
  *   gecco_linear_h8_img_f32 with image_kind 2 follows it too.

@@ -12,7 +12,7 @@ from gecco_amd import hip_ops as ops  # noqa: E402
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-    ops.set_default_precision(os.environ.get("GECCO_PRECISION", "fp16"))
+    ops.set_default_precision(os.environ.get("GECCO_PRECISION", "w2"))
     dev = torch.device("cuda", 0)
     model = bench.build_model(bench.random_state_dict(0)).to(dev).eval()
     x, sigma = (t.to(dev) for t in bench.synthetic_cloud(1))

@@ -2,7 +2,7 @@
 import csv
 import sys
 
-rows = list(csv.DictReader(open(sys.argv[1])))
+rows = list(csv.DictReader(ln for ln in open(sys.argv[1]) if not ln.startswith("#")))
 nf = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print(f"total {tot / 1e6:.2f} ms  ({tot / nf / 1e6:.2f} ms per forward)")

@@ -1,5 +1,5 @@
-"""Per-kernel counter table of a whole evaluation from the passes of tools/pmc_collect.sh, and (with --write) the `mixed`
-entry of profiles/gemm_hbm_traffic.json that bench.py quotes.
+"""Per-kernel counter table of a whole evaluation from the passes of tools/pmc_collect.sh, and (with --write) the entry of the
+mode (GECCO_PRECISION, default w2) in profiles/gemm_hbm_traffic.json that bench.py quotes.
 
   python tools/pmc_to_json.py <pmc dir> <evaluations in the run> <tag> [--write]
 
@@ -28,6 +28,8 @@ def short(name):
 
 def main():
     root, nev, tag = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+    mode = os.environ.get("GECCO_PRECISION", "w2")
+    tree = os.environ.get("GECCO_TREE", "unknown")
     acc = load(root)
     rows = []
     for k, cs in acc.items():
@@ -39,7 +41,7 @@ def main():
         rows.append((by * n / nev, short(k), n / nev, by, busy, ldsc, 2 * mean("FETCH_SIZE") * 1024, mean("WRITE_SIZE") * 1024))
     rows.sort(reverse=True)
     tot = sum(r[0] for r in rows)
-    print(f"# {tag}: counters per kernel over {nev} evaluations of the C2 forward (mixed mode, one stream); HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE")
+    print(f"# {tag} (tree {tree}): counters per kernel over {nev} evaluations of the C2 forward ({mode} mode, one stream); HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE")
     print(f"# total HBM bytes per evaluation: {tot / 1e9:.2f} GB")
     print(f"{'kernel':64s} {'launches/eval':>13s} {'MB/launch':>10s} {'fetch MB':>9s} {'write MB':>9s} {'MB/eval':>9s} {'mfma busy':>9s} {'lds confl':>9s}")
     for t, k, n, by, busy, ldsc, fe, wr in rows[:24]:
@@ -48,9 +50,9 @@ def main():
         pj = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "gemm_hbm_traffic.json")
         d = json.load(open(pj))
         dom = max((r for r in rows), key=lambda r: r[0])
-        d["mixed"] = {
-            "kernel": dom[1] + " (the kernel with the largest HBM traffic per evaluation of the mixed mode)",
-            "source": f"profiles/{tag}_forward_pmc_summary.txt (tools/pmc_collect.sh: separate --pmc passes over 2 whole evaluations, one stream)",
+        d[mode] = {
+            "kernel": dom[1] + f" (the kernel with the largest HBM traffic per evaluation of the {mode} mode)",
+            "source": f"profiles/{tag}_forward_pmc_summary.txt (tools/pmc_collect.sh on tree {tree}: separate --pmc passes over 2 whole evaluations, one stream)",
             "bytes_per_launch": dom[3], "mfma_busy": dom[4],
             "bytes_per_evaluation": tot,
             "per_kernel": {k: {"launches_per_evaluation": n, "bytes_per_launch": by, "mfma_busy": busy} for t, k, n, by, busy, ldsc, fe, wr in rows[:12]},

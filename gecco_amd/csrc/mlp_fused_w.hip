@@ -155,7 +155,7 @@ __host__ __device__ __forceinline__ int w_kmap(int h, int i) { return 32 * (i >>
 // ---------------------------------------------------------------------------------------------------------------------
 // The weight stream of a layer (W_STREAM bytes), in consumption order.  1 KiB chunks; lane l = 32 h + r.
 // Phase 1, stage (t, half), groups g = 3 half + gi:  chunk 0 header: byte 4 gi + 2 term + j of lane l = scale byte of the lo operand
-//   (term 0: W1 - fp16(W1), term 1: W1; hidden block j) of that lane; chunk 1: (half 1) floats 0 .. 63 = mlp.0's bias of the tile's 64
+//   (term 0: W1 - fp16(W1), term 1: W1; hidden block j) of that lane; chunk 1: (half 0) floats 0 .. 63 = mlp.0's bias of the tile's 64
 //   hidden columns (x the activation's argument scale, like the weights); group gi at chunk 2 + 14 gi:
 //     + 2 s + j (s = 0 .. 3): fp16(W1[64 t + 32 j + r][64 g + 16 s + 8 h + e]), e = 0 .. 7
 //     + 8 + j: dwords 0 - 3 of the term-0 operand of block j;  + 10: its dwords 4 - 5, [j][lane] 8 bytes each
@@ -239,7 +239,7 @@ __global__ void mlpw_image_kernel(const float* __restrict__ W1, const float* __r
                     out[b >> 2] |= (unsigned)w_lo1(W1, ws, t, 3 * half + gi, j, term, r, h).sb << (8 * (b & 3));
                 }
             } else if (chunk == 1) {
-                if (half == 1 && l < 16 && b1) {
+                if (half == 0 && l < 16 && b1) {
                     const f32x4 bb = *reinterpret_cast<const f32x4*>(b1 + 64 * t + 4 * l);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) out[e] = __float_as_uint(bb[e] * ws);
@@ -323,7 +323,9 @@ struct WSpan {
 };
 // the interleave of one set (a scheduling region): NM matrix instructions, each followed by its share of the ND fragment reads of the
 // next set and of the NV LDS-DMA pieces — one instruction stream per SIMD hides nothing that is not placed between two matrix instructions
-template <int NM, int ND, int NV>
+// NA > 0: the set also carries a share of the previous hidden tile's activation — NA vector-ALU and one transcendental instruction behind
+// each matrix instruction (their issue cycles lie inside the 32 the matrix pipe is busy)
+template <int NM, int ND, int NV, int NA = 0>
 __device__ __forceinline__ void w_interleave() {
     sfor<NM>([&](auto I) {
         constexpr int i = decltype(I)::value;
@@ -331,6 +333,10 @@ __device__ __forceinline__ void w_interleave() {
         constexpr int nd = (i + 1) * ND / NM - i * ND / NM, nv = (i + 1) * NV / NM - i * NV / NM;
         if constexpr (nd > 0) __builtin_amdgcn_sched_group_barrier(0x100, nd, 0);
         if constexpr (nv > 0) __builtin_amdgcn_sched_group_barrier(0x20, nv, 0);
+        if constexpr (NA > 0) {
+            __builtin_amdgcn_sched_group_barrier(0x2, NA, 0);
+            __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
+        }
     });
 }
 
@@ -395,8 +401,13 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
     lds_cptr sb16 = lb16, sb8 = lb8, nb16 = lb16, nb8 = lb8;   // bases of the stage being read / of the next one
     lds_cptr sb8b = lb8 + 512, nb8b = lb8 + 512;                 // + 512: the second block's 8-byte parts through their own base register (two
                                                                 // reads off one base become ds_read2st64_b64 + four moves into the operand tuples)
+#ifdef MFW_DIAG_NOREAD    // (diagnostic: no fragment reads — what the LDS array's load costs the loop)
+    auto rd16 = [&](lds_cptr base, int chunk) { unsigned v = (unsigned)(size_t)base + chunk; asm volatile("" : "+v"(v)); return u32x4{v, v, v, v}; };
+    auto rd8 = [&](lds_cptr base, int chunk, int half) { unsigned v = (unsigned)(size_t)base + chunk + half; asm volatile("" : "+v"(v)); return u32x2{v, v}; };
+#else
     auto rd16 = [&](lds_cptr base, int chunk) { return *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(base + chunk * 1024); };
     auto rd8 = [&](lds_cptr base, int chunk, int half) { return *reinterpret_cast<const __attribute__((address_space(3))) u32x2*>(base + chunk * 1024 + half * 512); };
+#endif
     // phase 1: set k (0 / 1) of group gi (0 .. 2) of the stage at (b16, b8) — six matrix instructions each (192 cycles: the time the next
     // set's fragment reads have to arrive): k-steps 0 .. 2 of both hidden blocks | k-step 3 and the four fp6 operands
     auto load_p1 = [&](lds_cptr b16, lds_cptr b8, lds_cptr b8b, auto GI, auto K, WBuf& f) {
@@ -547,19 +558,80 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
         }
         WSTAMP(2);
 
-        // ---- phase 1
+        // ---- phase 1.  Two accumulator pairs in turn: one takes the matrix instructions of hidden tile t (it starts as the tile's bias, read
+        // from chunk 1 of the tile's first stage) while the other's — tile t - 1, complete — goes through the activation BETWEEN those matrix
+        // instructions: with one wave per SIMD nothing else would fill the matrix pipe's busy cycles.
         f16x32 hf[W_NT];    // tile t: element i = act(u)[point r][64 t + kmap(h, i)]
         int hsp[W_NT / 4] = {0, 0, 0};   // block scale bytes of their fp6 forms, four per register
+        f32x16 au0[2], au1[2];
+        float mact = 0.f;
+        // registers 4 qq .. 4 qq + 3 of block j (q = 4 j + qq): columns 32 j + 8 qq + 4 h + e of the tile
+        auto bias_quad = [&](lds_cptr b16, auto Q, f32x16 (&a)[2]) {
+            constexpr int q = decltype(Q)::value, j = q >> 2, qq = q & 3;
+            const f32x4 bs = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(b16 + (1024 + 4 * (32 * j + 8 * qq)));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[j][4 * qq + e] = bs[e];
+        };
+        // the same four registers -> fp16 fragment elements 16 j + 4 qq .. of mlp.2's row operand (two packed conversions)
+        auto act_quad = [&](auto Q, f32x16 (&a)[2], f16x32& hft) {
+            constexpr int q = decltype(Q)::value, j = q >> 2, qq = q & 3;
+            float y[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float uu = a[j][4 * qq + e];       // s u
+                if constexpr (ACT == 1 || ACT == 2) {
+                    const float E = __builtin_amdgcn_exp2f(uu * -uu);
+                    y[e] = ACT == 1 ? __builtin_fmaf(E, 1.0f / 0.28f, -2.5f) : E;
+                } else if constexpr (ACT == 3) {
+                    y[e] = h8_clamp(fmaxf(uu, 0.f));
+                } else {
+                    y[e] = h8_clamp(uu);
+                }
+            }
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            const h2 p0 = {(_Float16)y[0], (_Float16)y[1]}, p1 = {(_Float16)y[2], (_Float16)y[3]};
+            hft[16 * j + 4 * qq] = p0[0];
+            hft[16 * j + 4 * qq + 1] = p0[1];
+            hft[16 * j + 4 * qq + 2] = p1[0];
+            hft[16 * j + 4 * qq + 3] = p1[1];
+            if constexpr (ACT == 0 || ACT == 3) mact = fmaxf(fmaxf(mact, fmaxf(fabsf(y[0]), fabsf(y[1]))), fmaxf(fabsf(y[2]), fabsf(y[3])));
+        };
+        // block scale of a tile's fp6 form: the bounded activations have a fixed one (|h| <= 2.5: 2^-1; exp(.) <= 1: 2^-2)
+        auto act_done = [&](auto T) {
+            constexpr int t = decltype(T)::value;
+            hsp[t >> 2] |= (ACT == 1 ? 126 : ACT == 2 ? 125 : w_scale_byte(mact)) << (8 * (t & 3));
+            mact = 0.f;
+        };
+        // (diagnostics; the never-taken branch also keeps the register allocator from merging the tiles' live ranges: without one per
+        // tile the first hidden tiles' fragments go to scratch)
+        auto dbg_dump = [&](auto T, f32x16 (&a)[2]) {
+            constexpr int t = decltype(T)::value;
+            if (g.dbg_u) {
+                float* du = g.dbg_u + (row0 + r) * W_WD + 64 * t + 4 * h;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) *reinterpret_cast<f32x4*>(du + 32 * j + 8 * qq) = f32x4{a[j][4 * qq], a[j][4 * qq + 1], a[j][4 * qq + 2], a[j][4 * qq + 3]};
+            }
+        };
+        {
+            // tile 0's bias: its stage is the next one to be entered (landed: the previous row tile's last stage entry, or the prologue's wait)
+            lds_cptr bb = nb16 + (16 * h - 16 * lane);
+            sfor<8>([&](auto Q) { bias_quad(bb, Q, au0); });
+        }
         sfor<W_NT>([&](auto T) {
             constexpr int t = decltype(T)::value;
-            f32x16 au[2];
+            f32x16 (&au)[2] = (t & 1) ? au1 : au0;      // this tile's accumulators
+            f32x16 (&ap)[2] = (t & 1) ? au0 : au1;      // the previous tile's, then the next tile's bias
             asm volatile("" : "+s"(opq));
+            if constexpr (t > 0) dbg_dump(W_IC(t > 0 ? t - 1 : 0), ap);
             sfor<2>([&](auto HALF) {
                 constexpr int half = decltype(HALF)::value;
                 stage_enter(W_IC(0));
                 const u32x4 hdr = rd16(sb16, 0);
+                lds_cptr nbias = nb16 + (16 * h - 16 * lane);
                 sfor<6>([&](auto I) {
-                    constexpr int i = decltype(I)::value, gi = i >> 1, k = i & 1, gg = 3 * half + gi;
+                    constexpr int i = decltype(I)::value, gi = i >> 1, k = i & 1, gg = 3 * half + gi, i12 = 6 * half + i;
                     WBuf& bc = (i & 1) ? bufB : bufA;
                     WBuf& bn = (i & 1) ? bufA : bufB;
                     // the next set: of this stage, of the next stage, or (last set of phase 1) the first of phase 2
@@ -570,8 +642,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
                         sfor<3>([&](auto S) {
                             constexpr int s = decltype(S)::value;
 #pragma unroll
-                            for (int j = 0; j < 2; ++j)
-                                au[j] = W_MFMA16(__builtin_bit_cast(f16x8, bc.q[2 * s + j]), w_sub<s>(fa[gg]), (gg == 0 && s == 0) ? z16 : au[j]);
+                            for (int j = 0; j < 2; ++j) au[j] = W_MFMA16(__builtin_bit_cast(f16x8, bc.q[2 * s + j]), w_sub<s>(fa[gg]), au[j]);
                         });
                     } else {
 #pragma unroll
@@ -590,72 +661,41 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
                         au[1] = W_MFMA6(w_op6(bc.q[5], bc.d[3]), w_op6(yl6[gg]), au[1], W_SB((int)hdr[gi], 3), W_SB(ylp[gg >> 2], gg & 3));
 #endif
                     }
+                    // the previous tile's activation, a quad per set; then (sets 8 .. 11) the next tile's bias into the freed registers: its
+                    // stage is the next one (landed since this stage's entry)
+                    constexpr bool acting = t > 0 && i12 < 8;
+                    constexpr bool biasing = t < W_NT - 1 && i12 >= 8;
+                    if constexpr (acting) act_quad(W_IC(i12 & 7), ap, hf[t > 0 ? t - 1 : 0]);
+                    if constexpr (biasing) {
+                        bias_quad(nbias, W_IC((2 * (i12 - 8)) & 7), ap);
+                        bias_quad(nbias, W_IC((2 * (i12 - 8) + 1) & 7), ap);
+                    }
                     // the stage two ahead: phase-2 stages from the last hidden tile on
                     issue_after(I, W_IC(6), W_IC(t < W_NT - 1 ? 1 : 0));
                     {
                         constexpr int np = t < W_NT - 1 ? W_NP1 : W_NP2;
                         typedef WSpan<i, 6, np> SP;
-                        w_interleave<6, (i < 5 && ((i + 1) & 1)) ? 10 : 6, SP::b - SP::a>();
+                        w_interleave<6, ((i < 5 && ((i + 1) & 1)) ? 10 : 6) + (biasing ? 2 : 0), SP::b - SP::a, acting ? 2 : 0>();
                     }
                     W_SCHED();
+                    if constexpr (t > 0 && i12 == 7) {
+                        act_done(W_IC(t > 0 ? t - 1 : 0));
+                        asm volatile("" : "+a"(hf[t > 0 ? t - 1 : 0]), "+v"(hsp[(t > 0 ? t - 1 : 0) >> 2]));   // parked in the accumulator file
+                        W_SCHED();
+                    }
                 });
             });
-            // ---- the tile's activation -> fp16 fragments of mlp.2's row operand (element 16 j + e of the lane: accumulator register e
-            // of block j), the block's scale byte; parked in the accumulator file
-            {
-                float m = 0.f;
-                W_SCHED();
-                WACC_BEGIN();
-                // the tile's bias: chunk 1 of the stage just computed (its slot is refilled after the next stage entry)
-                lds_cptr b1base = sb16 + (1024 + 16 * h - 16 * lane);
-                // pre-activations = accumulators + bias (registers 4 qq .. 4 qq + 3 of block j: columns 32 j + 8 qq + 4 h + e)
-                sfor<8>([&](auto Q) {
-                    constexpr int q = decltype(Q)::value, j = q >> 2, qq = q & 3;
-                    const f32x4 bs = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(b1base + 4 * (32 * j + 8 * qq));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) au[j][4 * qq + e] += bs[e];
-                });
-                // (diagnostics; the never-taken branch also keeps the register allocator from merging the tiles' live ranges: without one per
-                // tile the first hidden tiles' fragments go to scratch — 128 spilled registers against 16)
-                if (g.dbg_u) {
-                    float* du = g.dbg_u + (row0 + r) * W_WD + 64 * t + 4 * h;
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int qq = 0; qq < 4; ++qq) *reinterpret_cast<f32x4*>(du + 32 * j + 8 * qq) = f32x4{au[j][4 * qq], au[j][4 * qq + 1], au[j][4 * qq + 2], au[j][4 * qq + 3]};
-                }
-                sfor<8>([&](auto Q) {
-                    constexpr int q = decltype(Q)::value, j = q >> 2, qq = q & 3;
-                    float y[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float uu = au[j][4 * qq + e];       // s u
-                        if constexpr (ACT == 1 || ACT == 2) {
-                            const float E = __builtin_amdgcn_exp2f(uu * -uu);
-                            y[e] = ACT == 1 ? __builtin_fmaf(E, 1.0f / 0.28f, -2.5f) : E;
-                        } else if constexpr (ACT == 3) {
-                            y[e] = h8_clamp(fmaxf(uu, 0.f));
-                        } else {
-                            y[e] = h8_clamp(uu);
-                        }
-                    }
-                    // registers 4 qq .. 4 qq + 3 of block j = elements 16 j + 4 qq .. of the tile's fragment: two packed conversions
-                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-                    const h2 p0 = {(_Float16)y[0], (_Float16)y[1]}, p1 = {(_Float16)y[2], (_Float16)y[3]};
-                    hf[t][16 * j + 4 * qq] = p0[0];
-                    hf[t][16 * j + 4 * qq + 1] = p0[1];
-                    hf[t][16 * j + 4 * qq + 2] = p1[0];
-                    hf[t][16 * j + 4 * qq + 3] = p1[1];
-                    if constexpr (ACT == 0 || ACT == 3) m = fmaxf(fmaxf(m, fmaxf(fabsf(y[0]), fabsf(y[1]))), fmaxf(fabsf(y[2]), fabsf(y[3])));
-                    W_SCHED();
-                });
-                // block scale of the tile's fp6 form: the bounded activations have a fixed one (|h| <= 2.5: 2^-1; exp(.) <= 1: 2^-2)
-                hsp[t >> 2] |= (ACT == 1 ? 126 : ACT == 2 ? 125 : w_scale_byte(m)) << (8 * (t & 3));
-                asm volatile("" : "+a"(hf[t]), "+v"(hsp[t >> 2]));
-                WACC_END(wacc_act);
-                W_SCHED();
-            }
         });
+        // the last tile's activation has no matrix instructions to sit between
+        {
+            WACC_BEGIN();
+            dbg_dump(W_IC(W_NT - 1), au1);
+            sfor<8>([&](auto Q) { act_quad(Q, au1, hf[W_NT - 1]); });
+            act_done(W_IC(W_NT - 1));
+            asm volatile("" : "+a"(hf[W_NT - 1]), "+v"(hsp[(W_NT - 1) >> 2]));
+            WACC_END(wacc_act);
+            W_SCHED();
+        }
         WSTAMP(3);
 
         // ---- the fp6 forms of the hidden tiles (one conversion each, from the parked fragments)

@@ -1113,6 +1113,13 @@ def main():
                 eager_step()
             torch.cuda.synchronize()
             rec["eager_ms_per_step"] = (time.perf_counter() - t0) / 10 * 1e3
+    if rank == 0 and world == 1 and not args.eager:
+        # beside the headline (whose every replay rebuilds the weight images, as a forward between two weight updates must): the same
+        # graph captured inside hip_ops.frozen_weights() — images built once by the warm-up call, as every sampler call does
+        runf = model.graphed_forward(x, sigma, None, frozen_weights=True)
+        outf = runf()
+        assert torch.equal(outf, out), "frozen-weights evaluation differs from the headline's"
+        rec["frozen_weights_ms_per_step"] = time_events(runf, args.steps, warmup=3)
     if rank == 0 and world == 1 and not args.no_sampler:
         # Metric 2 (BASELINE.json): 128-step sample_stochastic wall-clock = 255 evaluations + fp64 sampler kernels,
         # one hipGraph per step replayed 127 times

@@ -14,3 +14,4 @@ __version__ = "0.1.0"
 from . import models, reparam  # noqa: E402,F401
 from .config import load_config  # noqa: E402,F401
 from .diffusion import Diffusion  # noqa: E402,F401
+from .hip_ops import frozen_weights, weights_changed  # noqa: E402,F401

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GECCO_HIP_LIB") or os.path.join(_HERE, "libgecco_hip.so")   # override: A/B builds only
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 c_f = C.c_void_p  # device pointers travel as void*
 
@@ -32,7 +32,7 @@ class GeccoLayer(C.Structure):
 
 class GeccoSetTransformer(C.Structure):
     _fields_ = [("n_layers", C.c_int), ("C", C.c_int), ("H", C.c_int), ("I", C.c_int), ("ctx_dim", C.c_int),
-                ("G", C.c_int), ("width", C.c_int), ("act", C.c_int), ("precision", C.c_int),
+                ("G", C.c_int), ("width", C.c_int), ("act", C.c_int), ("precision", C.c_int), ("images_ready", C.c_int),
                 ("layers", C.POINTER(GeccoLayer))]
 
 

@@ -341,9 +341,10 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
     const bool cl_ok = option(OPT_CHAINCL) && C >= 256 && (size_t)st->n_layers * 8 <= (size_t)I * C;
     const bool chain2_on = mixed && w.wimg && option(OPT_CHAIN2) && (C <= 384 || cl_ok) && inducer_chain_f16_supported(C, Wd, H, G, I) &&
                            (ns == 1 || ns == 2 || ns == 4 || ns == 8) && (act >= 0 && act <= 3);
-    if (pr >= 1 && w.wimg && !(C % kmod) && !(Wd % kmod)) {
+    if (pr >= 1 && w.wimg && !(C % kmod) && !(Wd % kmod) && !st->images_ready) {
         // split-bf16 mode: every N-token weight of every layer becomes its tiled hi | lo image in ONE launch per
-        // 6 layers (weights may change between calls; nothing is cached across forwards)
+        // 6 layers (weights may change between calls: nothing is cached across forwards unless the caller vouches for the
+        // workspace's images — GeccoSetTransformer.images_ready)
         SplitJobs jobs, jobs16, jobs8;   // jobs16: the fp16 images of the mixed mode (kv_proj | q_proj, hi and lo); jobs8: mlp.0's h8 image
         jobs.n = 0;
         jobs16.n = 0;

@@ -12,6 +12,7 @@ Differences from the reference are in *how*, not *what*:
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import math
 from typing import Any, Sequence
 
@@ -22,6 +23,16 @@ from . import _lib, hip_ops
 from ._grad import GeccoTrainingNotSupported
 from .reparam import NoReparam, Reparam
 from .structs import Context3d, Example
+
+
+def _frozen_weights(fn):
+    """A sampling call evaluates the denoiser hundreds of times on weights that cannot change while it runs: its evaluations share
+    one build of the weight images per workspace (hip_ops.frozen_weights) instead of rebuilding them every time."""
+    @functools.wraps(fn)
+    def run(*a, **k):
+        with hip_ops.frozen_weights():
+            return fn(*a, **k)
+    return run
 
 try:  # Lightning is the reference's training harness; optional here (not needed for sampling)
     import lightning.pytorch as pl
@@ -239,19 +250,25 @@ class Diffusion(_Base):
         self.log("val_loss", loss)
 
     @torch.no_grad()
-    def graphed_forward(self, data: Tensor, sigma: Tensor, raw_context: Any | None = None, post_context: Any | None = None):
+    def graphed_forward(self, data: Tensor, sigma: Tensor, raw_context: Any | None = None, post_context: Any | None = None,
+                        frozen_weights: bool = False):
         """One evaluation captured as a hipGraph (an addition to the reference API, for serving loops that evaluate the
         same shapes repeatedly: ~100 kernel launches replayed with one host call).  Returns `run(data=None, sigma=None)`:
-        it copies new inputs into the captured buffers (when given), replays, and returns the captured output tensor."""
+        it copies new inputs into the captured buffers (when given), replays, and returns the captured output tensor.
+        frozen_weights=True: the weight images are built by the warm-up call and the captured graph does not rebuild them —
+        the graph serves the weight VALUES it was captured with (capture again after an update); default: every replay
+        rebuilds them, so in-place weight updates are seen."""
+        import contextlib
         x_buf, s_buf = data.clone(), sigma.clone()
         out = torch.empty_like(x_buf)
         if post_context is None and raw_context is not None:
             post_context = self.conditioner(raw_context)
-        self.forward(x_buf, s_buf, raw_context, post_context, out=out)   # warm-up: plans / workspaces outside the capture
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self.forward(x_buf, s_buf, raw_context, post_context, out=out)
+        with (hip_ops.frozen_weights() if frozen_weights else contextlib.nullcontext()):
+            self.forward(x_buf, s_buf, raw_context, post_context, out=out)   # warm-up: plans / workspaces outside the capture
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.forward(x_buf, s_buf, raw_context, post_context, out=out)
 
         def run(data: Tensor | None = None, sigma: Tensor | None = None) -> Tensor:
             if data is not None:
@@ -285,6 +302,7 @@ class Diffusion(_Base):
 
     # ------------------------------------------------------------------------------------------ sampling
     @torch.no_grad()
+    @_frozen_weights
     def sample_stochastic(self, shape: Sequence[int], context: Context3d | None, rng: torch.Generator = None,
                           noise: Tensor | Sequence[Tensor] | None = None, use_graph: bool = True, **kwargs) -> Tensor:
         """EDM stochastic Heun sampler (the paper's SDE sampler): num_steps steps = 2*num_steps - 1 evaluations.
@@ -382,6 +400,7 @@ class Diffusion(_Base):
         return self.sample_stochastic(shape, context, noise=noise, use_graph=use_graph, **kw)
 
     @torch.no_grad()
+    @_frozen_weights
     def sample_inpaint(self, known: Tensor, m_to_inpaint: int, context: Context3d | None = None, num_substeps: int = 1,
                        seed: int | None = 42, noise: Sequence[Tensor] | None = None, **kwargs) -> Tensor:
         """Completion of partial clouds (gecco-jax models/stochastic.py:101-231, `sample_inpaint`): `known` (B, n, 3) data-space
@@ -445,6 +464,7 @@ class Diffusion(_Base):
         return self.reparam.diffusion_to_data(st.x_cur, context)[:, :m]
 
     @torch.no_grad()
+    @_frozen_weights
     def upsample(self, data: Tensor, new_latents: Tensor | None = None, n_new: int | None = None,
                  context: Context3d | None = None, seed: int | None = 42, num_substeps=5,
                  noise: Sequence[Tensor] | None = None, use_graph: bool = False, **kwargs):

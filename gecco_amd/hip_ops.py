@@ -6,6 +6,7 @@ no fallback path.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 from typing import Mapping, Sequence
@@ -37,6 +38,7 @@ def set_option(name: str, value: int) -> None:
     negative value to return to the default.  For A/B measurements and the tests that compare the fused launches with
     the stand-alone kernels they replace."""
     _lib.check(_lib.load().gecco_set_option(name.encode(), int(value)), "set_option")
+    weights_changed()   # (the options decide which weight images a forward builds)
 
 
 def default_precision() -> str:
@@ -583,7 +585,7 @@ class SetTransformerPlan:
             act = (ACT_GAUSS if normalized else ACT_GAUSS_RAW) if f"{pre}layers.0.mlp.1.alpha" in p else ACT_RELU
         self.act = act
         self.table = GeccoSetTransformer(L, self.C, H, I, self.ctx_dim, G, self.width, act,
-                                         PRECISIONS[self.precision], self._layers)
+                                         PRECISIONS[self.precision], 0, self._layers)
         self._ws: dict[tuple[int, int], Tensor] = {}
 
     def workspace(self, B: int, N: int) -> Tensor:
@@ -626,6 +628,37 @@ class SetTransformerPlan:
 # under the other's GEMMs.  C2: 6.64 -> 6.38 ms per evaluation, outputs identical to the bit.  Inside a hipGraph capture the
 # fork / join (event waits) is captured with it.  GECCO_FWD_STREAMS=1 keeps one stream.
 _FWD_SIDE = {"streams": []}
+
+# ------------------------------------------------------------------------------- weight images across evaluations
+# A forward rebuilds the images of the weights it streams (fp16 / fp6 tiles in the kernels' consumption order: ~0.14 ms of a
+# 4.4 ms C2 evaluation) because weights may change between calls.  Inside `frozen_weights()` the caller vouches that they do
+# not — a sampler's 255 evaluations, a serving loop between two weight updates — and the fused plans build the images once
+# per scope and workspace and hand `images_ready = 1` to the library afterwards.  Entering the outermost scope, `set_option`
+# and every optimizer step (`weights_changed()`) start a new generation: nothing built earlier is trusted.
+_FROZEN = {"depth": 0, "generation": 0}
+
+
+def weights_changed() -> None:
+    """Tell the plans that weight values (or the path options) changed by a route no tensor version counter sees."""
+    _FROZEN["generation"] += 1
+
+
+@contextlib.contextmanager
+def frozen_weights():
+    if _FROZEN["depth"] == 0:
+        _FROZEN["generation"] += 1
+    _FROZEN["depth"] += 1
+    try:
+        yield
+    finally:
+        _FROZEN["depth"] -= 1
+
+
+def _images_token(cached: bool):
+    """What a workspace's images were built under, or None outside a frozen scope (then every forward rebuilds)."""
+    if _FROZEN["depth"] == 0 or os.environ.get("GECCO_FROZEN_IMAGES", "1") == "0":
+        return None
+    return (_FROZEN["generation"], bool(cached))
 
 
 def _fwd_parts(B: int, N: int) -> int:
@@ -672,6 +705,7 @@ class LinearLiftPlan:
         self.table = GeccoLinearLift(self.st.table, _ptr(p[pre + "lift.weight"]), _ptr(p[pre + "lift.bias"]),
                                      _ptr(p[pre + "lower.1.weight"]), _ptr(p[pre + "lower.1.bias"]), sigma_data)
         self._ws: dict[tuple[int, int], Tensor] = {}
+        self._img_tok: dict[tuple, tuple] = {}   # workspace key -> the token its weight images were built under (frozen_weights)
 
     def workspace(self, B: int, N: int, idx: int = 0) -> Tensor:
         key = (B, N, idx)
@@ -689,6 +723,9 @@ class LinearLiftPlan:
 
         def call(lo, hi, idx):
             ws = self.workspace(hi - lo, N, idx)
+            tok = _images_token(cache is not None)
+            self.table.inner.images_ready = int(tok is not None and self._img_tok.get((hi - lo, N, idx)) == tok)
+            self._img_tok[(hi - lo, N, idx)] = tok
             cut = (lambda ts: None if ts is None else [None if t is None else t[lo:hi] for t in ts])
             check(self.lib.gecco_linear_lift_fwd_f32(
                 C.byref(self.table), _ptr(x[lo:hi]), _ptr(sigma[lo:hi]), _ptr(den[lo:hi]), _ptr(None if raw is None else raw[lo:hi]),
@@ -811,6 +848,7 @@ class RayNetworkPlan:
             _ptr(p[pre + "output_proj.1.weight"]), _ptr(p[pre + "output_proj.1.bias"]),
             make_reparam(reparam_kind, rp_mean, rp_std, logit_scale), sigma_data)
         self._ws: dict[tuple, Tensor] = {}
+        self._img_tok: dict[tuple, tuple] = {}
 
     def forward(self, x: Tensor, sigma: Tensor, K: Tensor, levels_nhwc: Sequence[Tensor], return_raw: bool = False,
                 cache: Sequence[Tensor] | None = None, do_cache: bool = False, out: Tensor | None = None):
@@ -828,6 +866,9 @@ class RayNetworkPlan:
                 self._ws[key] = _ws(self.lib.gecco_ray_network_workspace_bytes(C.byref(self.table), C.byref(pyr), hi - lo, N),
                                     self.st.device)
             ws = self._ws[key]
+            tok = _images_token(cache is not None)
+            self.table.backbone.images_ready = int(tok is not None and self._img_tok.get(key) == tok)
+            self._img_tok[key] = tok
             cut = (lambda ts: None if ts is None else [None if t is None else t[lo:hi] for t in ts])
             check(self.lib.gecco_ray_network_fwd_f32(
                 C.byref(self.table), _ptr(x[lo:hi]), _ptr(sigma[lo:hi]), _ptr(K[lo:hi]), C.byref(pyr), _ptr(den[lo:hi]),

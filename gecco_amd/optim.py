@@ -277,6 +277,8 @@ class FusedAdamEMA(torch.optim.Optimizer):
             raise
         from .autograd import WEIGHT_IMAGES
         WEIGHT_IMAGES.invalidate()   # the kernel updates the weights through raw pointers: no version counter moves
+        from . import hip_ops
+        hip_ops.weights_changed()    # (nor does an inference plan inside hip_ops.frozen_weights() see it otherwise)
         self.current_step += 1
         return loss
 

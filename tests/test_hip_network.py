@@ -425,6 +425,42 @@ def test_w2_mode_golden_and_against_the_mixed_mode(ops, golden_dir):
         ops.set_option("mlpw", -1)
 
 
+@pytest.mark.parametrize("precision", ["w2", "mixed", "bf16x3", "fp16"])
+def test_frozen_weights_scope_reuses_the_weight_images(ops, precision):
+    """hip_ops.frozen_weights(): the evaluations of a scope share one build of the weight images per workspace
+    (GeccoSetTransformer.images_ready; a sampler's 255 evaluations) — same bits as rebuilding every time, full and cached
+    evaluations side by side; a new scope, `weights_changed()` and `set_option` rebuild; and the contract is real: a weight changed
+    behind the scope's back is NOT seen (which is what shows that the reuse happens)."""
+    name = "uncond_d384_L6_N128"
+    p, x, sigma = cases.uncond_inputs(name)
+    p = _cuda(p)
+    x, sigma = x.cuda(), sigma.cuda()
+    net = ops.LinearLiftPlan(p, cases.H, cases.I, precision=precision)
+    (d0, r0), cache = net.forward(x, sigma, return_raw=True, do_cache=True)
+    xn = x[:, :64].contiguous()
+    c0 = net.forward(xn, sigma, cache=cache)
+    with ops.frozen_weights():
+        for _ in range(3):
+            d, r = net.forward(x, sigma, return_raw=True)
+            assert torch.equal(d, d0) and torch.equal(r, r0)
+            assert torch.equal(net.forward(xn, sigma, cache=cache), c0)
+        assert net.table.inner.images_ready == 1
+        w = p["inner.layers.3.mlp.0.weight"]
+        w_saved = w.clone()
+        w.mul_(1.25)
+        stale = net.forward(x, sigma)
+        assert torch.equal(stale, d0), "the scope rebuilt its images (no reuse happened)"
+        ops.weights_changed()
+        fresh = net.forward(x, sigma)
+        assert not torch.equal(fresh, d0)
+        with ops.frozen_weights():   # nested: same generation
+            assert torch.equal(net.forward(x, sigma), fresh)
+    assert torch.equal(net.forward(x, sigma), fresh) and net.table.inner.images_ready == 0
+    w.copy_(w_saved)
+    with ops.frozen_weights():       # a new scope trusts nothing built before it
+        assert torch.equal(net.forward(x, sigma), d0)
+
+
 @pytest.mark.parametrize("name", list(cases.UNCOND_CASES))
 def test_mixed_two_term_chain_matches_split_bf16_chain(ops, golden_dir, name):
     """Mixed mode: the 64-inducer chain of a layer as ONE launch with two-term fp16 weights (option "chain2",

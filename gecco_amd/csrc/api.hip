@@ -969,6 +969,10 @@ int gecco_linear_astat16_f32(const float* x, const float* pro_a, const float* pr
                              const float* W2, const float* bias2, int Nout2, float* C2, const float* residual, int transposed, int B, int rows,
                              int K, void* wsplit, void* stream) {
     if (!x || !C1 || !wsplit || (Nout2 > 0 && !C2)) return fail(-1, "linear_astat16: null argument");
+#ifndef GECCO_EXPERIMENTAL
+    // C1 = x W + another gradient: measured, no gain inside the step (19.31 vs 19.27 ms) — not part of the shipped surface
+    if (residual) return fail(-2, "linear_astat16: the residual form is an experiment (build with -DGECCO_EXPERIMENTAL); pass NULL");
+#endif
     if (residual && (Nout2 > 0 || pro_a || bias1)) return fail(-2, "linear_astat16: the residual form takes one weight, no prologue, no bias");
     if ((pro_a == nullptr) != (pro_o == nullptr)) return fail(-1, "linear_astat16: pro_a / pro_o must both be set");
     if (Nout2 > 0 && ((W1 == nullptr) != (W2 == nullptr))) return fail(-1, "linear_astat16: W1 / W2 both given or both ready");

@@ -219,7 +219,8 @@ int gecco_linear_h8_train_f32(const float* x, const float* pro_a, const float* p
  * means wsplit holds the stream already (gecco_astat16_images_f32: batched, transposed != 0 = the stream of W^T from W (K, ldw)).
  *   _f32:    C1 (| C2) = x' W1^T + bias1 (| x' W2^T + bias2), x' = x * pro_a[b] + pro_o[b] or x — broadcast_norm -> kv_proj | q
  *            (models/set_transformer.py:161-162 -> :49, :112); transposed != 0 (one weight): W1 is (K, Nout1) and C1 = x W1 — a dX product;
- *            residual (one weight, no prologue / bias; may be NULL): added to C1 — another gradient contribution to the same tensor;
+ *            residual: pass NULL (a form that adds another gradient contribution to C1 exists only in -DGECCO_EXPERIMENTAL builds: it
+ *            bought nothing inside the training step and is not part of the shipped surface);
  *   _keep:   pre_out = u = x' W^T + bias (fp32) and C16out = fp16(act(u)) — the first linear of an MLP (models/mlp.py:5-39), act 1 / 2
  *            GaussianActivation (normalized / raw), 3 ReLU;
  *   _actbwd: C = (dy W) * act'(u), W the linear's own (K, Nout) weight, + for GaussianActivation agrad[B * rows / 128] = per-block

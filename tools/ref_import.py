@@ -1,8 +1,8 @@
 """Import the real reference (`/root/reference/gecco-torch`) with import-time stubs.
 
 BUILD-CONTAINER ONLY: `/root/reference` does not exist on the GPU box; nothing under tests/ (gpu
-marker), bench.py or __graft_entry__ imports this module.  Used by tools/make_golden.py and by
-tests/test_reference_live.py (skipped when the reference is absent).
+marker), bench.py or __graft_entry__ imports this module.  Used by tools/make_golden.py, tools/make_golden_optim.py and
+tools/jax_standin_check.py (the golden generators; the tests read only the vectors they wrote).
 
 Stubs:
 * `gecco_torch` registered as a bare namespace so `gecco_torch/__init__.py` (which pulls the

@@ -806,8 +806,10 @@ def _h8_ok(prec: str, R: int, K: int, Nout: int) -> bool:
     """The split-bf16 training FORWARD's AdaGN-prologue products on the h8 A-stationary kernel (gecco_linear_h8_train_f32): the same
     accuracy class as split-bf16 (fp16 main product + two fp8 cross terms), the operand rows in registers and the weight stream read
     once per 128 rows.  Forward only: activations and weights fit the fp16 / fp8 operand ranges, unscaled gradients do not, so the
-    backward products keep split-bf16.  GECCO_TRAIN_H8FWD=0: the LDS-DMA split-bf16 GEMM instead."""
-    return (prec == "bf16x3" and os.environ.get("GECCO_TRAIN_H8FWD", "1") != "0"
+    backward products keep split-bf16.  Only where the model's arithmetic is one of the modes that compute these very products that way
+    in inference ("mixed", "w2"; "fp16"): an explicit "bf16x3" keeps true split-bf16 (fp32 exponent range, no operand clamps) in the
+    forward too.  GECCO_TRAIN_H8FWD=0: the LDS-DMA split-bf16 GEMM everywhere."""
+    return (prec == "bf16x3" and hip_ops.default_precision() in ("mixed", "w2", "fp16") and os.environ.get("GECCO_TRAIN_H8FWD", "1") != "0"
             and bool(_lib.load().gecco_linear_h8_train_ok(R, K, Nout)))
 
 

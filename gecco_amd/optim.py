@@ -354,7 +354,10 @@ class FusedAdamEMA(torch.optim.Optimizer):
         # in the context of saving an EMA model the EMA weights sit in the modules' own weights (ema.py:378-383)
         ema = tuple(p.detach().clone() for p in self.all_parameters()) if self.in_saving_ema_model_context \
             else tuple(t.clone() for t in self.ema_params)
-        return {"opt": opt, "ema": ema, "current_step": self.current_step, "decay": self.decay,
+        # EMAOptimizer.step is not called on a step the GradScaler skips (ema.py:288 counts the steps taken): with the scaler's protocol
+        # on the device the host counter ran on, so the saved value leaves the skipped steps out, as Adam's own step count does
+        skipped = int(self._amp_skipped.item()) if self._amp_skipped is not None else 0
+        return {"opt": opt, "ema": ema, "current_step": self.current_step - skipped, "decay": self.decay,
                 "every_n_steps": self.every_n_steps}
 
     @torch.no_grad()

@@ -362,11 +362,10 @@ def test_astat16_training_linears(K, B, R):
     wt = ws(lib.gecco_astat16_image_bytes(N2, K))
     _lib.check(lib.gecco_linear_astat16_f32(p(dy), None, None, p(Wo), None, N2, p(dx), None, None, 0, None, None, 1, B, R, K, p(wt), None), "astat16 T")
     assert _rel(dx, dy.double() @ Wo.double()) < 1e-3
-    other = _t(rs.randn(B, R, N2)).cuda()                   # ... added onto another gradient of the same tensor
+    other = _t(rs.randn(B, R, N2)).cuda()                   # ... the "added onto another gradient" form is an experiment outside the shipped surface
     dx2 = torch.full((B, R, N2), float("nan"), device="cuda")
-    _lib.check(lib.gecco_linear_astat16_f32(p(dy), None, None, p(Wo), None, N2, p(dx2), None, None, 0, None, p(other), 1, B, R, K, p(wt), None),
-               "astat16 T + residual")
-    assert torch.equal(dx2, dx + other)
+    assert lib.gecco_linear_astat16_f32(p(dy), None, None, p(Wo), None, N2, p(dx2), None, None, 0, None, p(other), 1, B, R, K, p(wt), None) != 0
+    assert b"GECCO_EXPERIMENTAL" in lib.gecco_last_error()
     wt2 = ws(wt.numel())
     Wot = Wo.t().contiguous()
     jobs = (_lib.GeccoSplitJob * 1)(_lib.GeccoSplitJob(Wot.data_ptr(), wt2.data_ptr(), N2, K, K, 0))

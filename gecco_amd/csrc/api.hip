@@ -349,6 +349,9 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         jobs.n = 0;
         jobs16.n = 0;
         jobs8.n = 0;
+        constexpr int kMjCap = 16;
+        MlpWImageJob mjobs[kMjCap];
+        int nmj = 0;
         // every insertion goes through here: the table is flushed BEFORE a write that would not fit
         constexpr int kJobCap = (int)(sizeof(jobs.job) / sizeof(jobs.job[0]));
         auto push_ld = [&](const float* Wp, float* img, int Nout, int K, int ldw) -> int {
@@ -441,8 +444,9 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
                         TRY(push_ld(L.mlp.w2 + (size_t)jc * 128 + hf * 64, cb + (size_t)(nkb + hf * (nkb / 2)) * 2048, C, 64, Wd),
                             "split(mlp.2 K-slice)");
                 }
-            } else if (mfw_on) {
-                TRY(mlp_fused_w_image_launch(L.mlp.w0, L.mlp.b0, L.mlp.w2, L.mlp.b2, base + w.o_mf, C, Wd, L.mlp.alpha, act, s), "split(mlp, w2 stream)");
+            } else if (mfw_on) {   // the one-launch point MLP's streams: all layers in one launch, behind the loop
+                if (nmj == kMjCap) { TRY(mlp_fused_w_images_launch(mjobs, nmj, C, Wd, act, s), "split(mlp, w2 streams)"); nmj = 0; }
+                mjobs[nmj++] = MlpWImageJob{L.mlp.w0, L.mlp.b0, L.mlp.w2, L.mlp.b2, base + w.o_mf, L.mlp.alpha};
             } else {
                 if (h8_on) {   // same bytes as the split-bf16 image it replaces: fp16 hi + fp8 lo + fp8 W per element
                     if (jobs8.n >= kJobCap) { TRY(h8_image_multi_launch(jobs8, s), "split(mlp.0, h8)"); jobs8.n = 0; }
@@ -461,6 +465,7 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
         TRY(pr == 2 ? split_f16_tiled_multi_launch(jobs, s) : split_bf16_tiled_multi_launch(jobs, s), "split(weights)");
         if (mixed) TRY(split_f16_tiled_multi_launch(jobs16, s), "split(weights, fp16)");
         TRY(h8_image_multi_launch(jobs8, s), "split(mlp.0, h8)");
+        if (nmj) TRY(mlp_fused_w_images_launch(mjobs, nmj, C, Wd, act, s), "split(mlp, w2 streams)");
     }
     const bool imgs = pr >= 1 && w.wimg && !(C % kmod) && !(Wd % kmod);
     // fp16 mode: the point-stream intermediates every consumer rounds to fp16 anyway (K|V, q, the attention output,

@@ -178,6 +178,8 @@ struct MlpWArgs {
 bool mlp_fused_w_supported(int C, int Wd, int rows);
 size_t mlp_fused_w_image_bytes(int C, int Wd);
 // (the stream depends on the activation: mlp.0's weights carry the Gaussian activation's argument scale)
+struct MlpWImageJob { const float *W0, *b0, *W2, *b2; void* img; const float* alpha; };   // one layer's weights -> its stream
+int mlp_fused_w_images_launch(const MlpWImageJob* jobs, int n, int C, int Wd, int act, hipStream_t st);   // all layers in one launch
 int mlp_fused_w_image_launch(const float* W0, const float* b0, const float* W2, const float* b2, void* img, int C, int Wd, const float* alpha, int act,
                              hipStream_t st);
 int mlp_fused_w_launch(const MlpWArgs& g, int C, int Wd, hipStream_t st);

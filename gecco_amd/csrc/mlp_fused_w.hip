@@ -221,23 +221,50 @@ __device__ __forceinline__ WLo w_lo2(const float* __restrict__ W2, int nb, int t
 __device__ __forceinline__ float w_act_scale(const float* alpha, int act) {
     return (act == 1 || act == 2) ? 0.84932180028801907f / fabsf(alpha[0]) : 1.f;   // sqrt(log2(e) / 2) / |alpha|
 }
-__global__ void mlpw_image_kernel(const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
-                                  unsigned* __restrict__ img, const float* __restrict__ alpha, int act) {
-    const float ws = w_act_scale(alpha, act);
+struct MlpwImageJobs {     // the layers of one launch (blockIdx.y)
+    enum { MAX = 16 };
+    const float* W1[MAX];
+    const float* b1[MAX];
+    const float* W2[MAX];
+    const float* b2[MAX];
+    unsigned* img[MAX];
+    const float* alpha[MAX];
+    int act, n;
+};
+// Threads: one per 16-byte item of the stream, then one per scale BYTE of the stage headers (a header item alone would form its lane's 12
+// lo operands one after the other — 12 x 32 dependent loads: the launch's critical path, 18 us for 1.9 MB).
+constexpr int W_HDR_BYTES = 2 * W_NT * 64 * 12 + 2 * W_NB * 64 * 8;
+__global__ void mlpw_image_kernel(MlpwImageJobs jobs) {
+    const int li = blockIdx.y;
+    const float* __restrict__ W1 = jobs.W1[li];
+    const float* __restrict__ b1 = jobs.b1[li];
+    const float* __restrict__ W2 = jobs.W2[li];
+    const float* __restrict__ b2 = jobs.b2[li];
+    unsigned* __restrict__ img = jobs.img[li];
+    const float ws = w_act_scale(jobs.alpha[li], jobs.act);
     const size_t items = W_STREAM / 16;
+    const size_t p1_items = (size_t)2 * W_NT * W_CH1 * 64;
+    for (size_t hb = (size_t)blockIdx.x * blockDim.x + threadIdx.x; hb >= items && hb < items + W_HDR_BYTES; hb += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(hb - items);
+        unsigned char* out8 = reinterpret_cast<unsigned char*>(img);
+        if (q < 2 * W_NT * 64 * 12) {
+            const int stage = q / (64 * 12), l = (q / 12) & 63, b = q % 12, t = stage >> 1, half = stage & 1;
+            const int gi = b >> 2, term = (b >> 1) & 1, j = b & 1;
+            out8[((size_t)stage * W_CH1 * 64 + l) * 16 + b] = (unsigned char)w_lo1(W1, ws, t, 3 * half + gi, j, term, l & 31, l >> 5).sb;
+        } else {
+            const int q2 = q - 2 * W_NT * 64 * 12;
+            const int stage = q2 / (64 * 8), l = (q2 / 8) & 63, b = q2 & 7, nb = stage >> 1, half = stage & 1;
+            out8[(p1_items + (size_t)stage * W_CH2 * 64 + l) * 16 + b] = b < 6 ? (unsigned char)w_lo2(W2, nb, 6 * half + b, l & 31, l >> 5).sb : (unsigned char)0;
+        }
+    }
     for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (size_t)gridDim.x * blockDim.x) {
         u32x4 out = {0u, 0u, 0u, 0u};
-        const size_t p1_items = (size_t)2 * W_NT * W_CH1 * 64;
         if (it < p1_items) {
             const int stage = (int)(it / (W_CH1 * 64)), ci = (int)(it % (W_CH1 * 64));
             const int chunk = ci >> 6, l = ci & 63, t = stage >> 1, half = stage & 1;
-            if (chunk == 0) {
-                const int r = l & 31, h = l >> 5;
-#pragma unroll 1
-                for (int b = 0; b < 12; ++b) {
-                    const int gi = b >> 2, term = (b >> 1) & 1, j = b & 1;
-                    out[b >> 2] |= (unsigned)w_lo1(W1, ws, t, 3 * half + gi, j, term, r, h).sb << (8 * (b & 3));
-                }
+            if (chunk == 0) {   // bytes 0 .. 11: the byte threads above
+                img[it * 4 + 3] = 0u;
+                continue;
             } else if (chunk == 1) {
                 if (half == 0 && l < 16 && b1) {
                     const f32x4 bb = *reinterpret_cast<const f32x4*>(b1 + 64 * t + 4 * l);
@@ -273,11 +300,10 @@ __global__ void mlpw_image_kernel(const float* __restrict__ W1, const float* __r
             const size_t i2 = it - p1_items;
             const int stage = (int)(i2 / (W_CH2 * 64)), ci = (int)(i2 % (W_CH2 * 64));
             const int chunk = ci >> 6, l = ci & 63, nb = stage >> 1, half = stage & 1;
-            if (chunk == 0) {
-                const int r = l & 31, h = l >> 5;
-#pragma unroll 1
-                for (int b = 0; b < 6; ++b) out[b >> 2] |= (unsigned)w_lo2(W2, nb, 6 * half + b, r, h).sb << (8 * (b & 3));
-                out[2] = __float_as_uint(b2 ? b2[32 * nb + r] : 0.f);
+            if (chunk == 0) {   // bytes 0 .. 7: the byte threads above
+                img[it * 4 + 2] = __float_as_uint(b2 ? b2[32 * nb + (l & 31)] : 0.f);
+                img[it * 4 + 3] = 0u;
+                continue;
             } else if (chunk < 34) {
                 const int pi = (chunk - 1) / 11, q = (chunk - 1) % 11;
                 if (q == 10) {
@@ -845,12 +871,29 @@ bool mlp_fused_w_supported(int C, int Wd, int rows) { return C == W_C && Wd == W
 
 size_t mlp_fused_w_image_bytes(int C, int Wd) { return mlp_fused_w_supported(C, Wd, 128) ? W_STREAM : 0; }
 
+int mlp_fused_w_images_launch(const MlpWImageJob* jobs, int n, int C, int Wd, int act, hipStream_t st) {
+    if (!mlp_fused_w_supported(C, Wd, 128)) return -9;
+    constexpr int threads = (int)(W_STREAM / 16) + W_HDR_BYTES;
+    for (int i0 = 0; i0 < n; i0 += MlpwImageJobs::MAX) {
+        MlpwImageJobs j{};
+        j.act = act;
+        j.n = n - i0 < MlpwImageJobs::MAX ? n - i0 : MlpwImageJobs::MAX;
+        for (int i = 0; i < j.n; ++i) {
+            const MlpWImageJob& s = jobs[i0 + i];
+            if ((act == 1 || act == 2) && !s.alpha) return -6;
+            j.W1[i] = s.W0; j.b1[i] = s.b0; j.W2[i] = s.W2; j.b2[i] = s.b2; j.img[i] = static_cast<unsigned*>(s.img); j.alpha[i] = s.alpha;
+        }
+        hipLaunchKernelGGL(mlpw_image_kernel, dim3((threads + 255) / 256, j.n), dim3(256), 0, st, j);
+        const int rc = (int)hipGetLastError();
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 int mlp_fused_w_image_launch(const float* W0, const float* b0, const float* W2, const float* b2, void* img, int C, int Wd, const float* alpha, int act,
                              hipStream_t st) {
-    if (!mlp_fused_w_supported(C, Wd, 128)) return -9;
-    if ((act == 1 || act == 2) && !alpha) return -6;
-    hipLaunchKernelGGL(mlpw_image_kernel, dim3(480), dim3(256), 0, st, W0, b0, W2, b2, static_cast<unsigned*>(img), alpha, act);
-    return (int)hipGetLastError();
+    const MlpWImageJob job{W0, b0, W2, b2, img, alpha};
+    return mlp_fused_w_images_launch(&job, 1, C, Wd, act, st);
 }
 
 int mlp_fused_w_launch(const MlpWArgs& g, int C, int Wd, hipStream_t st) {

@@ -351,8 +351,10 @@ __global__ void h8_image_multi_kernel(SplitJobs jobs) {
 // consecutive columns of one row per accumulator quad: plain 16-byte stores.  (The backward products keep split-bf16: unscaled
 // gradients do not fit the fp16 / fp8 operands.)
 // F6: the "h6" arithmetic — the two cross terms as fp6 x fp6 with per-lane block scales (above); the W stream is the h6 form of the image.
+// K = 512 (NG = 8): the stationary operand alone is 176 - 192 registers — one block of 4 waves per CU, a wave per SIMD with its whole
+// register file (the w2 kernel's regime, mlp_fused_w.hip) instead of two blocks of 256-register waves
 template <int NG, int NW, int NS, int ACT, bool IMG2, int OUT = 0, bool F6 = false>
-__global__ __launch_bounds__(64 * NW, 2) void gemm_h8_astat_kernel(GemmArgs g) {
+__global__ __launch_bounds__(64 * NW, NG > 6 ? 1 : 2) void gemm_h8_astat_kernel(GemmArgs g) {
     constexpr int NKT = 2 * NG, K = 64 * NG, NT = 64 * NW, ROWS = 32 * NW, PW = 8 / NW;
     constexpr int STORES = OUT == 1 ? 8 : OUT == 2 ? 16 : (IMG2 ? 6 : H_STORES);
     static_assert(NS >= 4 && NKT % NS == 0 && (NW == 4 || NW == 8), "static slots; lookahead NS - 1 >= 3 stages");
@@ -1252,11 +1254,18 @@ int h8_image_multi_launch(const SplitJobs& jobs, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+// GECCO_H8_K512=0: d = 512 keeps mlp.0 on the split-bf16 LDS-DMA GEMM (A/B runs)
+static bool h8_k512_on() {
+    static const int on = h8_env("GECCO_H8_K512", 1);
+    return on != 0;
+}
+
 // c_img output only (1: tiled split image, 2: h8 activation image): whole 128-row blocks of one sample, 64-column tiles,
-// K = 128 / 256 / 384 (the stationary operand is 3 K / 8 registers per lane)
+// K = 128 / 256 / 384 (the stationary operand is 3 K / 8 registers per lane); K = 512 at one block per CU
 bool gemm_h8_astat_supported(const GemmArgs& g) {
     return g.c_img && !g.a_img && !g.a_f16 && !g.c_f16 && !g.residual && !g.stats && !g.C2 && g.w_img && g.rows >= 128 &&
-           !(g.rows % 128) && !(g.Nout % H_BN) && g.Nout >= 2 * H_BN && g.Nout <= 4096 && (g.K == 128 || g.K == 256 || g.K == 384) &&
+           !(g.rows % 128) && !(g.Nout % H_BN) && g.Nout >= 2 * H_BN && g.Nout <= 4096 &&
+           (g.K == 128 || g.K == 256 || g.K == 384 || (g.K == 512 && h8_k512_on())) &&
            !(g.lda & 3) && ((g.pro_a == nullptr) == (g.pro_o == nullptr)) && !g.mul_u && !g.pre_out && g.act >= 0 && g.act <= 3;
 }
 
@@ -1382,6 +1391,7 @@ int gemm_h8_astat_launch(const GemmArgs& g0, hipStream_t st) {
         case 128: return h8_launch_t<2, 4>(g, st);
         case 256: return h8_launch_t<4, 4>(g, st);
         case 384: return h8_launch_t<6, 4>(g, st);
+        case 512: return h8_launch_t<8, 4>(g, st);
         default: return -9;
     }
 }

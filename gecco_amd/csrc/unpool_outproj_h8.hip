@@ -64,6 +64,8 @@ constexpr float U_YL_SCALE = H8_AL_SCALE;   // h8_scales.h
 
 // per (sample, head): K [64][hd + 8] fp16 | V^T [ceil(hd / 32) * 32][72] fp16, padded to whole 4 KiB (one 1 KiB piece per wave)
 constexpr int u_kv_bytes(int HD) { return ((64 * (HD + 8) + ((HD + 31) / 32) * 32 * 72) * 2 + 4095) / 4096 * 4096; }
+// floats of the region that holds the four waves' residual tiles and, during the attention, two staged heads
+constexpr int u_tts_floats(int HD) { return 2 * u_kv_bytes(HD) > 4 * U_TT * 4 ? 2 * u_kv_bytes(HD) / 4 : 4 * U_TT; }
 
 __device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, void* lds_wave_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
@@ -156,17 +158,18 @@ __global__ __launch_bounds__(256) void kvh_image_kernel(const float* __restrict_
 
 // ---------------------------------------------------------------------------------------------------------------------
 // NG = C / 64 (64-k groups = 64-column tiles: out_proj is square); HD = head dim; NS ring stages (running slot counter)
+// d = 512 (NG = 8, 64-wide heads): 192 registers of stationary operand — one block per CU, a wave per SIMD with the whole register file
 template <int NG, int HD, int NS>
-__global__ __launch_bounds__(256, 2) void unpool_outproj_h8_kernel(UnpoolH8Args g) {
+__global__ __launch_bounds__(256, NG > 6 ? 1 : 2) void unpool_outproj_h8_kernel(UnpoolH8Args g) {
     constexpr int C = 64 * NG, H = C / HD, NKT = 2 * NG, NC = HD / 16, DT = (HD + 31) / 32;
     constexpr int KS = HD + 8, VS = 72, KVB = u_kv_bytes(HD), PK = KVB / 4096;
     static_assert(C % HD == 0 && HD % 16 == 0 && HD <= 64, "head dims 16 .. 64");
-    static_assert(2 * KVB <= 4 * U_TT * 4, "two staged heads alias the four transpose tiles");
+    constexpr int TTSF = u_tts_floats(HD);     // the four residual tiles, or (64-wide heads) the two staged heads that alias them
     static_assert(NS >= 4 && NS <= NKT, "lookahead NS - 1 >= 3 stages; the residual pieces land inside their tile");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* ring = smem;                        // [NS][U_STAGE]
     float* tts = ring + NS * U_STAGE;          // [4][U_TT] residual tiles; during the attention: two staged heads
-    float* bias_lds = tts + 4 * U_TT;          // [C]
+    float* bias_lds = tts + TTSF;              // [C]
     float* red = bias_lds + C;                 // [4 waves][2][64] column sums of one tile
 
     const int tilesM = g.rows / 128;
@@ -547,8 +550,8 @@ __global__ __launch_bounds__(256, 2) void unpool_outproj_h8_kernel(UnpoolH8Args 
 template <int NG, int HD, int NS>
 int uo8_launch_t(const UnpoolH8Args& g, hipStream_t st) {
     constexpr int C = 64 * NG;
-    constexpr size_t lds = ((size_t)NS * U_STAGE + 4 * U_TT + C + 4 * 2 * 64) * sizeof(float);
-    static_assert(lds <= 80 * 1024, "two blocks per CU");
+    constexpr size_t lds = ((size_t)NS * U_STAGE + u_tts_floats(HD) + C + 4 * 2 * 64) * sizeof(float);
+    static_assert(lds <= 80 * 1024 || NG > 6, "two blocks per CU");
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(unpool_outproj_h8_kernel<NG, HD, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -560,11 +563,12 @@ int uo8_launch_t(const UnpoolH8Args& g, hipStream_t st) {
 
 }  // namespace
 
-// the shipped shapes with 8 heads: d = 128, 256, 384 (d = 512: 192 registers of stationary operand, not instantiated)
+// the shipped shapes with 8 heads: d = 128, 256, 384, and d = 512 at one block per CU
 bool unpool_outproj_h8_supported(int C, int H, int rows) {
     if (rows < 128 || rows % 128 || H <= 0 || C % H) return false;
     const int hd = C / H;
-    return (C == 128 && hd == 16) || (C == 256 && hd == 32) || (C == 384 && hd == 48);
+    static const int k512 = [] { const char* e = getenv("GECCO_UO8_K512"); return e ? atoi(e) : 1; }();   // 0: d = 512 keeps the two launches
+    return (C == 128 && hd == 16) || (C == 256 && hd == 32) || (C == 384 && hd == 48) || (C == 512 && hd == 64 && k512);
 }
 
 size_t unpool_outproj_h8_kv_bytes(int B, int C, int H) { return (size_t)B * H * u_kv_bytes(C / H); }
@@ -597,6 +601,7 @@ int unpool_outproj_h8_launch(const UnpoolH8Args& g0, int C, hipStream_t st) {
     switch (C) {
         case 128: return uo8_launch_t<2, 16, 4>(g, st);
         case 256: return uo8_launch_t<4, 32, 5>(g, st);
+        case 512: return uo8_launch_t<8, 64, 4>(g, st);
         default: return uo8_launch_t<6, 48, 5>(g, st);
     }
 }

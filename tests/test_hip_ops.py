@@ -244,7 +244,7 @@ def test_unpool_outproj_fused_gives_the_bits_of_the_two_launch_form(ops, B, N, C
                        ops.linear_f16io(att, W, None, residual=x))   # bias and stats optional
 
 
-@pytest.mark.parametrize("B,N,Cc,H", [(2, 256, 128, 8), (3, 384, 384, 8), (2, 128, 256, 8), (5, 2048, 384, 8)])
+@pytest.mark.parametrize("B,N,Cc,H", [(2, 256, 128, 8), (3, 384, 384, 8), (2, 128, 256, 8), (5, 2048, 384, 8), (3, 512, 512, 8)])
 def test_unpool_outproj_h8_fused_matches_the_two_launch_form(ops, B, N, Cc, H):
     """Mixed mode: unpool attention + h8 out_proj + residual + GroupNorm partials in ONE launch (unpool_outproj_h8.hip; reference
     models/set_transformer.py:70-75, 112, 164) against the two launches it replaces — the fp16 attention writing the h8 activation

@@ -103,7 +103,7 @@ int gecco_linear_f32(const float* A, const float* W, const float* bias, const fl
  *   GEMM as tiled split images (bf16 hi | lo planes in 8 KiB blocks, same bytes as the fp32 tensor) which that GEMM loads
  *   global -> registers (gemm_x3_areg.hip): same bits as the fp32 hand-over.
  *   "h8" (default 1): mixed mode runs mlp.0 as an fp16 main product plus two fp8 cross terms (v_mfma_scale_f32_32x32x64_f8f6f4)
- *   on the A-stationary kernel (gemm_h8_astat.hip: 128-row blocks; needs "actimg", rows % 128 == 0, feature_dim <= 384) instead of as a
+ *   on the A-stationary kernel (gemm_h8_astat.hip: 128-row blocks; needs "actimg", rows % 128 == 0, feature_dim 128 / 256 / 384, or 512 at one block per CU) instead of as a
  *   split-bf16 product: 2 instead of 3 matrix-pipe units per product, same accuracy (~6e-5 on F_x).
  *   "h8areg" (default 1): mixed mode hands the MLP hidden layer and the unpool attention output on as h8 activation images
  *   (fp16 hi + fp8 lo, 3 bytes per element) and runs mlp.2 / out_proj as h8 products (gecco_linear_h8_areg_f32) instead of

@@ -110,7 +110,7 @@ int gecco_linear_f32(const float* A, const float* W, const float* bias, const fl
  *   split-bf16 products on tiled split images: 2 instead of 3 matrix-pipe units per product, same accuracy (needs "h8").
  *   "unpoolh8" (default 1): mixed mode runs unpool attention + out_proj (h8) + residual + statistics as one launch
  *   (gecco_unpool_outproj_h8) instead of the attention writing an h8 activation image for gecco_linear_h8_areg_f32; needs
- *   "kvq64" (head-major fp16 q), "h8areg", feature_dim in {128, 256, 384}.
+ *   "kvq64" (head-major fp16 q), "h8areg", feature_dim in {128, 256, 384, 512} with 8 heads.
  *   "mlpw" (default 1): the "w2" mode (precision 4) runs the point MLP of a layer (AdaGN apply, mlp.0, activation, mlp.2, residual,
  *   statistics) as one launch (gecco_mlp_fused_w); 0: as the mixed mode does (gecco_linear_h8_img_f32 + gecco_linear_h8_areg_f32).
  *   "mlpwshare" (default 0): gecco_mlp_fused_w launches (a block fills its CU) take three quarters of the CUs instead of all of them, so

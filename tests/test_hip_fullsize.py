@@ -137,6 +137,10 @@ def _run_cond(ops, case, precision, tag):
     _report(f"{tag} {precision} D   vs oracle", den, ref, BARS[precision])
     _report(f"{tag} {precision} F_x vs oracle", raw, raw_ref, BARS_FX[precision])
     assert torch.equal(den, net.forward(x.cuda(), sigma.cuda(), K.cuda(), levels))   # deterministic
+    with ops.frozen_weights():   # the scope's evaluations share one build of the weight images (a sampler call): same bits
+        for _ in range(2):
+            assert torch.equal(den, net.forward(x.cuda(), sigma.cuda(), K.cuda(), levels))
+        assert net.table.backbone.images_ready == 1
 
 
 @pytest.mark.parametrize("precision", MODES)

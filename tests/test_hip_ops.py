@@ -443,7 +443,7 @@ def test_lift_lower_edm(ops, B, N, C):
 
 
 @pytest.mark.parametrize("B,rows,K,Nout,act", [(2, 512, 384, 768, "gauss"), (1, 256, 256, 512, "relu"), (3, 256, 128, 256, "none"),
-                                               (1, 2048, 384, 768, "gauss")])
+                                               (1, 2048, 384, 768, "gauss"), (2, 384, 512, 1024, "gauss")])
 def test_linear_h8_image(ops, B, rows, K, Nout, act):
     """mlp.0 of the mixed mode (gemm_h8_astat.hip): fp16 main product + the two cross terms on the fp8 matrix instruction,
     AdaGN prologue, activation, output as the tiled split image — against float64 (models/set_transformer.py:164-166,
@@ -514,7 +514,7 @@ def test_h8_products_on_outlier_weights_and_activations(ops, wmax, ymax, bar):
     assert e0[0] < bar and e2[0] < bar, (e0, e2)
 
 
-@pytest.mark.parametrize("K,Nout", [(384, 768), (256, 512), (128, 256)])
+@pytest.mark.parametrize("K,Nout", [(384, 768), (256, 512), (128, 256), (512, 1024)])
 def test_h6_cross_terms_hold_the_h8_accuracy(ops, K, Nout):
     """Option "h6" (default on): mlp.0's two cross terms as fp6 (e2m3) x fp6 with one E8M0 scale per lane and 64-k group — the scale
     blocks of v_mfma_scale_f32_32x32x64_f8f6f4 — instead of fp8 with fixed power-of-two scales (gemm_h8_astat_kernel<.., F6>; half the
@@ -641,7 +641,7 @@ def test_linear_kvq_f16(ops, B, rows, K, hd):
     assert torch.equal(a, c) and cpu_ref.rel_err(qq.cpu().double(), ref_q)[0] < tol
 
 
-@pytest.mark.parametrize("B,rows,K,Wd", [(2, 256, 384, 768), (1, 128, 128, 256), (2, 384, 256, 512)])
+@pytest.mark.parametrize("B,rows,K,Wd", [(2, 256, 384, 768), (1, 128, 128, 256), (2, 384, 256, 512), (2, 256, 512, 1024)])
 def test_linear_h8_areg_chain(ops, B, rows, K, Wd):
     """The point MLP of the mixed mode as its two h8 launches (models/set_transformer.py:164-166, models/mlp.py): mlp.0 writes the
     h8 activation image (fp16 hi + fp8 lo), mlp.2 (gemm_h8_areg.hip) loads it into registers.  The image against float64 of

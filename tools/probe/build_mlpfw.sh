@@ -7,4 +7,8 @@ b BASE -DMFW_STAMPS &
 b NOMFMA -DMFW_STAMPS -DMFW_DIAG_NOMFMA &
 b NODMA -DMFW_STAMPS -DMFW_DIAG_NODMA &
 wait
+# the clock under the kernel with / without its LDS fragment reads (profiles/r05b_negative_results.txt item 3)
+b NOREAD -DMFW_STAMPS -DMFW_DIAG_NOREAD &
+b NOREADDMA -DMFW_STAMPS -DMFW_DIAG_NOREAD -DMFW_DIAG_NODMA &
+wait
 ls mlpfw_*

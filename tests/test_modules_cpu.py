@@ -132,3 +132,25 @@ def test_log_uniform_schedule_is_stratified():
     assert s.shape == (64,) and torch.all(s[1:] > s[:-1]) and s.min() >= 0.002 and s.max() <= 165.0
     lo = math.log(0.002) + torch.arange(64) / 64 * (math.log(165.0) - math.log(0.002))
     assert torch.all(s.log() >= lo - 1e-5)
+
+
+def test_frozen_weights_scope_bookkeeping():
+    """hip_ops.frozen_weights(): the token a workspace's weight images are built under (host logic only).  Outside a scope there is no
+    token (every forward rebuilds); inside, full and cached evaluations have different tokens; nesting keeps the generation; a new
+    outermost scope, `weights_changed()` (the optimizer's step calls it) and `set_option` start a new one."""
+    from gecco_amd import hip_ops as ops
+    assert ops._images_token(False) is None
+    with ops.frozen_weights():
+        t_full, t_cached = ops._images_token(False), ops._images_token(True)
+        assert t_full is not None and t_full != t_cached and t_full == ops._images_token(False)
+        with ops.frozen_weights():
+            assert ops._images_token(False) == t_full
+        assert ops._images_token(False) == t_full
+        ops.weights_changed()
+        t2 = ops._images_token(False)
+        assert t2 != t_full
+    assert ops._images_token(False) is None
+    with ops.frozen_weights():
+        assert ops._images_token(False) not in (t_full, t2)
+    import gecco_amd
+    assert gecco_amd.frozen_weights is ops.frozen_weights and gecco_amd.weights_changed is ops.weights_changed

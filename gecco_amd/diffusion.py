@@ -386,7 +386,14 @@ class Diffusion(_Base):
         `Diffusion.solve_sample_ode` integrates with diffrax's Heun solver on the schedule's time grid
         (gecco-jax models/diffusion.py:333-374); the torch package does not ship it (gecco-torch/README.md:49-52).  Same
         device loop as `sample_stochastic` with S_churn = 0: num_steps steps = 2 num_steps - 1 evaluations, fp64 state,
-        one captured hipGraph per step.  `latents` (optional, (B, N, 3)): the starting noise instead of a generator draw."""
+        one captured hipGraph per step.  `latents` (optional, (B, N, 3)): the starting noise instead of a generator draw.
+
+        Where the two differ (parity unpinned: jax / diffrax are absent from the image).  diffrax's Heun applies the second-order
+        correction on EVERY step of `StepTo(ts)`, and the JAX schedule's last time is its sigma_min > 0, where the trajectory ends
+        (solve_sample_ode: t1 = ts[-1]); the EDM loop the torch reference ships (diffusion.py:271-352, what this method runs) appends
+        t = 0 to the grid and takes that last step as a plain Euler step (the correction would divide by t_next = 0,
+        diffusion.py:339).  Up to the last grid point the two integrate the same ODE with the same second-order scheme; this
+        method's result is additionally pushed from sigma_min to 0 by one Euler step (= the denoiser's output at sigma_min)."""
         kw = {**self.sampler_kwargs, **kwargs, "S_churn": 0.0}
         num_steps = kw["num_steps"]
         device, dtype = self.example_param.device, self.example_param.dtype

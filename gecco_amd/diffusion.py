@@ -470,6 +470,86 @@ class Diffusion(_Base):
             st.advance()
         return self.reparam.diffusion_to_data(st.x_cur, context)[:, :m]
 
+    @_frozen_weights
+    def evaluate_logp(self, data: Tensor, context: Context3d | None = None, n_trace_samples: int = 1, seed: int | None = 42,
+                      probes: Tensor | None = None, return_details: bool = False, **kwargs):
+        """Log-likelihood of clouds under the probability-flow ODE (gecco-jax models/diffusion.py:446-540, `evaluate_logp`; the torch
+        package does not ship it): the data are carried from sigma_min to sigma_max by Heun's method on the schedule's time grid while
+        the change of log-density, -div(dx/dt), is integrated beside them with Hutchinson's estimator (models/diffusion.py:175-192:
+        eps^T J eps for Rademacher probes eps, the SAME probes at every evaluation, as the JAX code's constant `noise_key` makes them);
+        logp = log N(latent; 0, sigma_max^2) + the integrated divergence + the reparametrisation's log |det|.
+
+        With the EDM schedule (sigma(t) = t, scale 1) dx/dt = (x - D(x; t)) / t, so eps^T J eps = (n - eps^T J_D eps) / t with n = 3 N:
+        one evaluation of the denoiser and one vector-Jacobian product through it (the HIP autograd Functions' input gradients,
+        `test_gradient_with_respect_to_the_noisy_cloud`) per probe and ODE stage.  data (B, N, 3) in data space -> (B,) fp64.
+        `probes` (optional, (n_trace_samples, B, N, 3) of +-1) replaces the generator draw (parity tests).  The state is fp64, the
+        network input fp32, as in the samplers.  Parity unpinned (jax / diffrax absent): the test compares with `oracle/cpu_ref.py`'s
+        restatement on torch autograd.  NoReparam and GaussianReparam (log |det| = -N sum_d log sigma_d); the UVL reparametrisation's
+        per-point 3 x 3 Jacobian is not built."""
+        from .reparam import GaussianReparam, NoReparam
+        kw = {**self.sampler_kwargs, **kwargs}
+        num_steps = kw["num_steps"]
+        device = self.example_param.device
+        if self.example_param.dtype != torch.float32:
+            raise NotImplementedError("the HIP denoiser computes in float32")
+        data = data.to(device=device, dtype=torch.float32).contiguous()
+        B, N, dim = data.shape
+        if isinstance(self.reparam, GaussianReparam):
+            ladj = -float(N) * torch.log(self.reparam.sigma.double()).sum().expand(B).clone()
+        elif isinstance(self.reparam, NoReparam):
+            ladj = torch.zeros(B, dtype=torch.float64, device=device)
+        else:
+            raise NotImplementedError("evaluate_logp: NoReparam / GaussianReparam only (the UVL log-determinant is not built)")
+        if probes is None:
+            gen = torch.Generator(device=device)
+            if seed is not None:
+                gen.manual_seed(seed)
+            probes = torch.randint(0, 2, (n_trace_samples, B, N, dim), device=device, generator=gen).float() * 2 - 1
+        probes = probes.to(device=device, dtype=torch.float32)
+        assert probes.shape[1:] == data.shape, (probes.shape, data.shape)
+        with torch.no_grad():
+            post_context = self.conditioner(context)
+            x = self.reparam.data_to_diffusion(data, context).double()
+        ts = karras_t_steps(num_steps, kw["sigma_max"], kw["sigma_min"], kw["rho"])[:num_steps].flip(0)   # sigma_min ... sigma_max
+        frozen = [q for q in self.parameters() if q.requires_grad]
+        for q in frozen:
+            q.requires_grad_(False)       # only the input carries a gradient: the weight-gradient kernels are skipped
+
+        def field(t: float, xs: Tensor):
+            """(dx/dt, d logp/dt) at (t, xs): fp64 tensors (B, N, 3), (B,)."""
+            with torch.enable_grad():
+                xg = xs.float().requires_grad_(True)
+                D = self(xg, torch.full((B,), t, device=device, dtype=torch.float32), context, post_context)
+                eje = torch.zeros(B, dtype=torch.float64, device=device)
+                for k in range(probes.shape[0]):
+                    g, = torch.autograd.grad((D * probes[k]).sum(), xg, retain_graph=k + 1 < probes.shape[0])
+                    eje += (g.double() * probes[k].double()).sum((1, 2))
+            eje /= probes.shape[0]
+            return (xs - D.detach().double()) / t, (float(N * dim) - eje) / t
+
+        try:
+            delta = torch.zeros(B, dtype=torch.float64, device=device)
+            traj = [x.clone()] if return_details else None
+            for i in range(num_steps - 1):
+                t0, t1 = float(ts[i]), float(ts[i + 1])
+                h = t1 - t0
+                k1, d1 = field(t0, x)
+                k2, d2 = field(t1, x + h * k1)
+                x = x + 0.5 * h * (k1 + k2)
+                delta = delta + 0.5 * h * (d1 + d2)
+                if traj is not None:
+                    traj.append(x.clone())
+        finally:
+            for q in frozen:
+                q.requires_grad_(True)
+        smax = float(kw["sigma_max"])
+        prior = -0.5 * ((x / smax) ** 2).sum((1, 2)) - N * dim * math.log(smax * math.sqrt(2.0 * math.pi))
+        logp = prior + delta + ladj
+        if not return_details:
+            return logp
+        return {"logp": logp, "prior_logp": prior, "delta_jacobian": delta, "delta_reparam": ladj, "latent": x,
+                "trajectory_diff": torch.stack(traj)}
+
     @torch.no_grad()
     @_frozen_weights
     def upsample(self, data: Tensor, new_latents: Tensor | None = None, n_new: int | None = None,

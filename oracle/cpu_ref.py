@@ -383,6 +383,39 @@ def upsample(D: Callable, data_diff: Tensor, new_latents: Tensor, randn: Callabl
     return x_next
 
 
+def evaluate_logp(D: Callable, x0: Tensor, probes: Tensor, ts: Tensor, sigma_max: float, ladj: Tensor):
+    """Restatement of gecco-jax `Diffusion.evaluate_logp` (models/diffusion.py:446-540) for the EDM schedule (sigma(t) = t, scale 1):
+    Heun (diffrax `Heun` with `StepTo(ts)`: every step takes the second-order correction) on the augmented state (x, delta) from ts[0]
+    (sigma_min) to ts[-1] (sigma_max) with dx/dt = (x - D(x, t)) / t (models/diffusion.py:311-331) and d delta / dt = the Hutchinson
+    estimate of its divergence (trace_jac_estimator, :175-192: mean over the probes of eps . grad_x (f(x) . eps), the same probes at
+    every evaluation); logp = log N(latent; 0, sigma_max^2) + delta + ladj.  D(x, sigma) -> denoised, differentiable (torch autograd);
+    x0 (B, N, 3) in diffusion space; probes (S, B, N, 3) of +-1; ts fp64 ascending; ladj (B,).  Test infrastructure; parity unpinned
+    (jax absent from the image)."""
+    B = x0.shape[0]
+
+    def field(t, xs):
+        xg = xs.float().clone().requires_grad_(True)
+        f = (xg - D(xg, torch.full((B,), float(t)))) / float(t)
+        div = torch.zeros(B, dtype=torch.float64)
+        for k in range(probes.shape[0]):
+            g, = torch.autograd.grad((f * probes[k]).sum(), xg, retain_graph=True)
+            div += (g.double() * probes[k].double()).sum((1, 2))
+        return f.detach().double(), div / probes.shape[0]
+
+    x = x0.double()
+    delta = torch.zeros(B, dtype=torch.float64)
+    for i in range(len(ts) - 1):
+        t0, t1 = float(ts[i]), float(ts[i + 1])
+        h = t1 - t0
+        k1, d1 = field(t0, x)
+        k2, d2 = field(t1, x + h * k1)
+        x = x + 0.5 * h * (k1 + k2)
+        delta = delta + 0.5 * h * (d1 + d2)
+    n = x0[0].numel()
+    prior = -0.5 * ((x / sigma_max) ** 2).sum((1, 2)) - n * math.log(sigma_max * math.sqrt(2.0 * math.pi))
+    return prior + delta + ladj.double(), prior, delta, x
+
+
 def log_uniform_sigma(u: Tensor, sigma_max: float, sigma_min: float = 0.002) -> Tensor:
     """LogUniformSchedule.forward (low_discrepancy=True) with the uniform draws `u` (B,)
     injected, diffusion.py:104-115."""

@@ -170,3 +170,33 @@ def test_set_distance_shapes_and_symmetry():
         assert Daa.diagonal().abs().max().item() <= 1e-3   # a cloud against itself: the clamp hides the cancellation noise of |a|^2 + |b|^2 - 2ab
     E = metrics.pairwise_set_distance(a[:3, :64], b[:2, :64], "emd", block_size=2)
     assert E.shape == (3, 2) and torch.isfinite(E).all()
+
+
+def test_evaluate_logp_vs_oracle(model):
+    """`Diffusion.evaluate_logp` (gecco-jax models/diffusion.py:446-540: Heun on (x, delta) from sigma_min to sigma_max with Hutchinson's
+    divergence estimate, + the prior's log-density at the latent + the reparametrisation's log-determinant) on the HIP path — the
+    denoiser's vector-Jacobian products through the autograd Functions — against the oracle's restatement on torch autograd, with the
+    same Rademacher probes; each part separately.  Deterministic for a seed; the model's parameters keep requires_grad."""
+    from gecco_amd.diffusion import karras_t_steps
+    m, p = model
+    c = cases.SAMPLER_CASE
+    B, N, steps = c["B"], c["N"], 8
+    mean, sig = torch.tensor(cases.GAUSS_MEAN), torch.tensor(cases.GAUSS_SIGMA)
+    data = _rn(21, B, N, 3) * sig * 0.8 + mean
+    probes = torch.from_numpy(np.random.RandomState(22).randint(0, 2, size=(2, B, N, 3)).astype(np.float32)) * 2 - 1
+    ts = karras_t_steps(steps, c["sigma_max"], 0.002, 7.0)[:steps].flip(0)
+    D = cpu_ref.uncond_denoiser(p, "", cases.H)
+    ladj = torch.full((B,), -float(N) * float(torch.log(sig.double()).sum()), dtype=torch.float64)
+    x0 = (data - mean) / sig
+    ref, prior_ref, delta_ref, lat_ref = cpu_ref.evaluate_logp(D, x0, probes, ts, c["sigma_max"], ladj)
+    out = m.evaluate_logp(data.cuda(), None, probes=probes.cuda(), num_steps=steps, sigma_min=0.002, rho=7.0, return_details=True)
+    print("logp", out["logp"].cpu().tolist(), "oracle", ref.tolist(), "| delta", out["delta_jacobian"].cpu().tolist(), delta_ref.tolist())
+    assert cpu_ref.rel_err(out["latent"].cpu(), lat_ref)[0] < 1e-4
+    assert torch.allclose(out["prior_logp"].cpu(), prior_ref, rtol=1e-4, atol=1e-3)
+    assert torch.allclose(out["delta_reparam"].cpu(), ladj, rtol=1e-6)
+    assert torch.allclose(out["delta_jacobian"].cpu(), delta_ref, rtol=1e-4, atol=1e-2), (out["delta_jacobian"], delta_ref)   # measured: 3e-8
+    assert torch.allclose(out["logp"].cpu(), ref, rtol=1e-4, atol=1e-2)
+    assert out["trajectory_diff"].shape == (steps, B, N, 3)
+    a = m.evaluate_logp(data.cuda(), None, n_trace_samples=2, seed=7, num_steps=steps)
+    assert torch.equal(a, m.evaluate_logp(data.cuda(), None, n_trace_samples=2, seed=7, num_steps=steps)) and a.shape == (B,)
+    assert all(q.requires_grad for q in m.parameters())

@@ -49,6 +49,7 @@ def _report(tag, got, ref, bar):
     e = cpu_ref.rel_err(got.cpu(), ref)
     print(f"{tag}: max-rel {e[0]:.2e} rel-L2 {e[1]:.2e} (bar {bar:.0e}, margin {bar / max(e[0], 1e-30):.1f}x)")
     assert e[0] <= bar, (tag, e)
+    assert e[1] <= bar, (tag, e)     # ... and in the relative L2 norm (the other reading of "relative error"): the same bar
     return e
 
 

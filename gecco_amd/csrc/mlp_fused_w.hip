@@ -808,7 +808,11 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const f32x4 o = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(tile16 + i * 1024);
+#ifdef MFW_DIAG_NOSTORE   // (diagnostic: what the output stores' write acknowledgements cost the stage waits behind them)
+                    asm volatile("" ::"v"(o));
+#else
                     GECCO_NT_STORE(o, reinterpret_cast<f32x4*>(xout + (size_t)(8 * i) * W_C + 32 * nb));
+#endif
                 }
                 if (g.stats) {
                     const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(s1), __float_as_uint(s1), false, false);

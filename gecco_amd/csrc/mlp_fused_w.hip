@@ -24,8 +24,10 @@
 //            columns in its registers, which is an operand fragment as it stands (k order 8 (e >> 2) + 4 h + (e & 3), the W2
 //            stream is written in that order) — 192 registers for all 768 hidden columns, parked in the accumulator file;
 //   phase 2  (12 output blocks of 32 columns): h stationary, W2 streams, 16 accumulator registers per block; the block's
-//            residual rows are loaded when it starts and the result (2 x 128 contiguous bytes per register and instruction),
-//            its bias, the residual and the GroupNorm column sums leave while the next block's products run.
+//            residual rows arrive by LDS-DMA in the wave's 4 KiB tile while its products run; at the block's end accumulator +
+//            bias + residual go through that tile (GroupNorm column sums on the way) and leave as 16-byte row pieces whose stores
+//            stay in flight under the next block (two forms of running this epilogue UNDER the next block's matrix
+//            instructions were measured and lost: profiles/r05b_negative_results.txt).
 // One instruction stream per SIMD has no partner to hide anything: fragment reads of set n + 1 are issued before the matrix
 // instructions of set n and fenced there (sched_barrier: left alone the scheduler serialises read -> wait -> MFMA to save
 // registers), the LDS-DMA pieces of a stage are spread over its sets (one to two between matrix groups), the stream is

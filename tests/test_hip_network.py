@@ -76,7 +76,7 @@ def test_cached_mode_golden(ops, golden_dir, precision, tol):
     print("cached", precision, "cache", e, "out_new", e2)
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16x3", 2e-4), ("mixed", 2e-4), ("fp16", 1e-3)])
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16x3", 2e-4), ("mixed", 2e-4), ("w2", 5e-4), ("fp16", 1e-3)])
 @pytest.mark.parametrize("B,N,d,L", [(3, 333, 128, 2), (2, 2048, 384, 1), (1, 4096, 512, 1), (2, 100, 64, 3), (2, 130, 256, 1),
                                      (2, 384, 384, 2), (1, 640, 512, 1), (3, 128, 256, 2), (2, 256, 64, 2), (2, 256, 192, 2), (1, 200, 320, 1),
                                      (2, 2048, 128, 4)])   # the last: BASELINE config C1 (airplane: d = 128, 4 layers) at its true N
@@ -84,7 +84,8 @@ def test_uncond_vs_oracle_ragged(ops, B, N, d, L, precision, tol):
     """Sizes the golden set does not hold (ragged N, d=512, N=4096, head dim 8 that stays on the fp32 attention
     kernels, rows < 128; N = 128, 384, 640: an odd number of 128-row tiles under the 256-row tiles and the activation
     images; d = 64 at N = 256: head dim 8 on the fp32 attention kernels with the hidden-layer image at K = 128; d = 192, 320: head
-    dims 24, 40), oracle computed on the fly, every arithmetic mode."""
+    dims 24, 40), oracle computed on the fly, every arithmetic mode ("w2": the one-launch point MLP at d = 384 with whole 128-row tiles, the
+    mixed mode's launches everywhere else)."""
     from oracle import weights as W
     p = W.linear_lift_state_dict(77 + N, d, L, cases.I, cases.H)
     x, sigma = W.synthetic_cloud(N, B, N)

@@ -484,9 +484,9 @@ class Diffusion(_Base):
         `test_gradient_with_respect_to_the_noisy_cloud`) per probe and ODE stage.  data (B, N, 3) in data space -> (B,) fp64.
         `probes` (optional, (n_trace_samples, B, N, 3) of +-1) replaces the generator draw (parity tests).  The state is fp64, the
         network input fp32, as in the samplers.  Parity unpinned (jax / diffrax absent): the test compares with `oracle/cpu_ref.py`'s
-        restatement on torch autograd.  NoReparam and GaussianReparam (log |det| = -N sum_d log sigma_d); the UVL reparametrisation's
-        per-point 3 x 3 Jacobian is not built."""
-        from .reparam import GaussianReparam, NoReparam
+        restatement on torch autograd.  The reparametrisation's log |det| comes from `Reparam.ladj_data_to_diffusion` (closed forms:
+        NoReparam 0, GaussianReparam -N sum_d log sigma_d, UVLReparam per point from the pinhole projection, atanh and log-range —
+        checked against torch's Jacobian of the oracle's restatement in tests/test_modules_cpu.py)."""
         kw = {**self.sampler_kwargs, **kwargs}
         num_steps = kw["num_steps"]
         device = self.example_param.device
@@ -494,12 +494,10 @@ class Diffusion(_Base):
             raise NotImplementedError("the HIP denoiser computes in float32")
         data = data.to(device=device, dtype=torch.float32).contiguous()
         B, N, dim = data.shape
-        if isinstance(self.reparam, GaussianReparam):
-            ladj = -float(N) * torch.log(self.reparam.sigma.double()).sum().expand(B).clone()
-        elif isinstance(self.reparam, NoReparam):
-            ladj = torch.zeros(B, dtype=torch.float64, device=device)
-        else:
-            raise NotImplementedError("evaluate_logp: NoReparam / GaussianReparam only (the UVL log-determinant is not built)")
+        if not hasattr(self.reparam, "ladj_data_to_diffusion"):
+            raise NotImplementedError(f"evaluate_logp: {type(self.reparam).__name__} has no ladj_data_to_diffusion")
+        with torch.no_grad():
+            ladj = self.reparam.ladj_data_to_diffusion(data, context).to(device=device, dtype=torch.float64)
         if probes is None:
             gen = torch.Generator(device=device)
             if seed is not None:

@@ -154,3 +154,29 @@ def test_frozen_weights_scope_bookkeeping():
         assert ops._images_token(False) not in (t_full, t2)
     import gecco_amd
     assert gecco_amd.frozen_weights is ops.frozen_weights and gecco_amd.weights_changed is ops.weights_changed
+
+
+def test_reparam_log_determinants_vs_autograd_jacobian():
+    """`Reparam.ladj_data_to_diffusion` (what `Diffusion.evaluate_logp` adds for the change of variables; gecco-jax models/reparam.py:27-37
+    obtains it from `jax.jacrev` + `slogdet` per point): the closed forms against torch's Jacobian of the oracle's restatement of the
+    same map, point by point — UVL (pinhole projection, atanh, log-range, normalisation) and Gaussian."""
+    from gecco_amd.reparam import GaussianReparam, NoReparam, UVLReparam
+    from gecco_amd.structs import Context3d
+    rs = torch.Generator().manual_seed(3)
+    B, N = 2, 17
+    xyz = torch.rand(B, N, 3, generator=rs, dtype=torch.float64) * torch.tensor([0.8, 0.6, 2.0]) + torch.tensor([-0.4, -0.3, 1.0])
+    K = torch.tensor([[[0.9, 0.0, 0.5], [0.0, 1.1, 0.5], [0.0, 0.0, 1.0]], [[0.7, 0.0, 0.45], [0.0, 0.8, 0.55], [0.0, 0.0, 1.0]]], dtype=torch.float64)
+    mean, std = torch.tensor([0.0, 0.0, 1.38], dtype=torch.float64), torch.tensor([0.56, 0.60, 0.49], dtype=torch.float64)
+    rp = UVLReparam(mean.float(), std.float())
+    got = rp.ladj_data_to_diffusion(xyz.float(), Context3d(image=None, K=K.float()))
+    ref = torch.zeros(B, dtype=torch.float64)
+    for b in range(B):
+        for n in range(N):
+            f = lambda p: cpu_ref.uvl_data_to_diffusion(p[None, None], K[b:b + 1], mean, std)[0, 0]
+            J = torch.autograd.functional.jacobian(f, xyz[b, n])
+            ref[b] += torch.linalg.slogdet(J)[1]
+    assert got.dtype == torch.float64 and torch.allclose(got, ref, rtol=1e-5, atol=1e-4), (got, ref)
+    g = GaussianReparam(torch.tensor(cases.GAUSS_MEAN), torch.tensor(cases.GAUSS_SIGMA))
+    assert torch.allclose(g.ladj_data_to_diffusion(xyz.float(), None),
+                          torch.full((B,), -N * float(torch.log(torch.tensor(cases.GAUSS_SIGMA).double()).sum()), dtype=torch.float64))
+    assert torch.equal(NoReparam(3).ladj_data_to_diffusion(xyz.float(), None), torch.zeros(B, dtype=torch.float64))

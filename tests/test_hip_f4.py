@@ -200,3 +200,52 @@ def test_evaluate_logp_vs_oracle(model):
     a = m.evaluate_logp(data.cuda(), None, n_trace_samples=2, seed=7, num_steps=steps)
     assert torch.equal(a, m.evaluate_logp(data.cuda(), None, n_trace_samples=2, seed=7, num_steps=steps)) and a.shape == (B,)
     assert all(q.requires_grad for q in m.parameters())
+
+
+def test_evaluate_logp_conditional_uvl_vs_oracle():
+    """evaluate_logp on the image-conditional model (RayNetwork: the vector-Jacobian product runs through the projective lookup's geometry
+    gradient, `ray_lookup_dgeom_kernel`) with the UVL reparametrisation's closed-form log-determinant, against the oracle's restatement
+    (cond_denoiser under torch autograd, the Jacobian-by-autograd log-determinant)."""
+    import __graft_entry__ as ge
+    ge.build()
+    from gecco_amd.diffusion import Conditioner, karras_t_steps
+    from gecco_amd.models.feature_pyramid import FeaturePyramidContext
+    from gecco_amd.structs import Context3d
+    from tests.test_modules_cpu import build_cond
+    name = "cond_d128_L2_N96"
+    d, L, N, hw, cdims, seed = cases.COND_CASES[name]
+    p, x, sigma, K, feats = cases.cond_inputs(name)
+    B = 2
+    K, feats = K[:B], [f[:B] for f in feats]
+
+    class FixedPyramid(Conditioner):
+        def forward(self, raw_ctx):
+            return FeaturePyramidContext(features=[f.cuda() for f in feats], K=raw_ctx.K)
+
+    m = build_cond(d, L, cdims, conditioner=FixedPyramid())
+    sd = {"backbone.model." + k: v for k, v in p.items()}
+    sd["reparam.uvl_mean"], sd["reparam.uvl_std"] = p["reparam.uvl_mean"], p["reparam.uvl_std"]
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    mean, std = p["reparam.uvl_mean"], p["reparam.uvl_std"]
+    # data in front of the camera: the images of moderate diffusion-space points
+    z0 = _rn(31, B, N, 3) * 0.6
+    data = cpu_ref.uvl_diffusion_to_data(z0, K, mean, std)
+    steps = 5
+    probes = torch.from_numpy(np.random.RandomState(32).randint(0, 2, size=(1, B, N, 3)).astype(np.float32)) * 2 - 1
+    ts = karras_t_steps(steps, 165.0, 0.002, 7.0)[:steps].flip(0)
+    D = cpu_ref.cond_denoiser(p, "", cases.H, K, feats)
+    x0 = cpu_ref.uvl_data_to_diffusion(data, K, mean, std)
+    ladj = torch.zeros(B, dtype=torch.float64)
+    for b in range(B):
+        for n in range(N):
+            f = lambda q: cpu_ref.uvl_data_to_diffusion(q[None, None], K[b:b + 1].double(), mean.double(), std.double())[0, 0]
+            ladj[b] += torch.linalg.slogdet(torch.autograd.functional.jacobian(f, data[b, n].double()))[1]
+    ref, prior_ref, delta_ref, lat_ref = cpu_ref.evaluate_logp(D, x0, probes, ts, 165.0, ladj)
+    ctx = Context3d(image=torch.zeros(B, 3, hw, hw).cuda(), K=K.cuda())
+    out = m.evaluate_logp(data.cuda(), ctx, probes=probes.cuda(), num_steps=steps, sigma_max=165.0, sigma_min=0.002, rho=7.0, return_details=True)
+    print("conditional logp", out["logp"].cpu().tolist(), "oracle", ref.tolist(), "| reparam", out["delta_reparam"].cpu().tolist(), ladj.tolist())
+    assert torch.allclose(out["delta_reparam"].cpu(), ladj, rtol=1e-4, atol=1e-2)
+    assert cpu_ref.rel_err(out["latent"].cpu(), lat_ref)[0] < 1e-3
+    assert torch.allclose(out["delta_jacobian"].cpu(), delta_ref, rtol=2e-3, atol=5e-2), (out["delta_jacobian"], delta_ref)
+    assert torch.allclose(out["logp"].cpu(), ref, rtol=2e-3, atol=1e-1)

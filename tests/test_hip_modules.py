@@ -106,6 +106,40 @@ def test_diffusion_forward_golden(golden_dir, name):
         _close(out_new, gc["out_new"])
 
 
+def test_module_api_in_the_w2_mode(golden_dir):
+    """The default arithmetic of bench.py ("w2": the point MLP of a layer as one launch) through the MODULE API — `Diffusion.forward`, the
+    hipGraph forward inside and outside `frozen_weights`, a short captured sampler run and a cached evaluation — against the reference's golden vector of the d = 384 network (5e-4, the
+    mode's bar) and against the plan-level call (same bits)."""
+    from gecco_amd import hip_ops
+    name = "uncond_d384_L6_N128"
+    g = _load(golden_dir, name)
+    d, L, N, seed = cases.UNCOND_CASES[name]
+    p, x, sigma = cases.uncond_inputs(name)
+    m = build_uncond(d, L)
+    m.load_state_dict(uncond_state_dict(p), strict=True)
+    m = m.cuda().eval()
+    old = hip_ops.default_precision()
+    hip_ops.set_default_precision("w2")
+    try:
+        with torch.no_grad():
+            den = m(x.cuda(), sigma.cuda(), None)
+            _close(den, g["denoised"], 5e-4)
+            plan = hip_ops.LinearLiftPlan({k: v.cuda() for k, v in p.items()}, cases.H, cases.I, precision="w2")
+            assert torch.equal(den, plan.forward(x.cuda(), sigma.cuda()))
+            strict = hip_ops.LinearLiftPlan({k: v.cuda() for k, v in p.items()}, cases.H, cases.I, precision="mixed").forward(x.cuda(), sigma.cuda())
+            assert not torch.equal(den, strict), "the one-launch point MLP did not run"
+            for frozen in (False, True):
+                run = m.graphed_forward(x.cuda(), sigma.cuda(), None, frozen_weights=frozen)
+                assert torch.equal(run(), den) and torch.equal(run(), den)
+            den2, cache = m(x.cuda(), sigma.cuda(), None, do_cache=True)
+            assert torch.equal(den2, den)
+            assert torch.isfinite(m(x[:, :64].contiguous().cuda(), sigma.cuda(), None, cache=cache)).all()
+            out = m.sample_stochastic((2, N, 3), None, num_steps=4)
+            assert out.shape == (2, N, 3) and torch.isfinite(out).all()
+    finally:
+        hip_ops.set_default_precision(old)
+
+
 def test_forward_and_sampler_under_autocast_and_half_inputs(golden_dir):
     """Callers of the reference wrap sampling in `torch.autocast` (its notebooks) and train under fp16 autocast:
     the HIP path computes in its own arithmetic whatever the autocast state or the input dtype — same bits as the plain call."""

@@ -305,6 +305,35 @@ def time_in_sequence(fns):
     return [base - time_graph_of(fns[:k] + fns[k + 1:]) for k in range(len(fns))], base
 
 
+def build_info():
+    """What the loaded library was built from (__graft_entry__.build() records a content hash of sources + flags beside the .so)."""
+    import __graft_entry__ as ge
+    info = {"sources_sha": ge.built_sources_sha(), "tree_sources_sha": ge.sources_sha()}
+    info["matches_tree_sources"] = info["sources_sha"] == info["tree_sources_sha"]
+    try:
+        info["tree_commit"] = open(os.path.join(ROOT, "TREE_COMMIT")).read().strip()
+    except OSError:
+        info["tree_commit"] = None
+    return info
+
+
+def load_traffic(mode):
+    """The committed counter constants of `mode` (profiles/gemm_hbm_traffic.json, written by tools/pmc_collect.sh with PMC_WRITE=1) —
+    ONLY when they were collected on the kernel sources this library was built from (their `sources_sha` = the build's): otherwise
+    ({}, stale-record) — the line then carries `"traffic_stale": true` and no counter figure instead of a number from another tree."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "gemm_hbm_traffic.json"))).get(mode, {})
+    except Exception:
+        return {}, {"traffic_stale": True, "why": "profiles/gemm_hbm_traffic.json unreadable"}
+    built = build_info()["sources_sha"]
+    meta = {"traffic_tree": {"sources_sha": d.get("sources_sha"), "commit": d.get("tree"), "source": d.get("source")},
+            "traffic_stale": not (built and d.get("sources_sha") == built)}
+    if meta["traffic_stale"]:
+        meta["why"] = f"counters collected on kernel sources {d.get('sources_sha')}, this library is built from {built}"
+        return {}, meta
+    return d, meta
+
+
 def cpu_baseline(p, x, sigma):
     """The oracle (plain PyTorch CPU restatement of the reference, verified equal to it) on the host cores.  Two figures: the
     FULL C2 batch with one torch thread per physical core (BASELINE.md section 4's definition; on a 128-core box this
@@ -380,8 +409,19 @@ def distributed_report(dev, local_points_per_sec=None, sizes=(53_900_000, 8_388_
     import torch.distributed as dist
     world = dist.get_world_size() if dist.is_initialized() else 1
     rep = {"backend": dist.get_backend() if dist.is_initialized() else None, "ranks_in_group": world,
-           "collective_library": None, "allreduce": {}, "rank0_points_per_sec_unbarriered": local_points_per_sec}
+           "collective_library": None, "allreduce": {}, "rank0_points_per_sec_unbarriered": local_points_per_sec,
+           "per_rank_points_per_sec": None}
     on_gpu = dev is not None and torch.device(dev).type == "cuda"
+    if local_points_per_sec is not None:
+        # every rank's own un-barriered rate (rank order): the N = 1 entry of a scaling table is directly comparable with the single-GPU
+        # bench line, and a straggler GPU shows up by name instead of inside a max-over-ranks time
+        if dist.is_initialized() and world > 1:
+            mine = torch.tensor([float(local_points_per_sec)], dtype=torch.float64, device=dev if on_gpu else "cpu")
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            rep["per_rank_points_per_sec"] = [float(t.item()) for t in allr]
+        else:
+            rep["per_rank_points_per_sec"] = [float(local_points_per_sec)]
     if on_gpu:
         try:
             rep["collective_library"] = "RCCL/NCCL " + ".".join(str(v) for v in torch.cuda.nccl.version())
@@ -927,6 +967,8 @@ def main():
         "forward_tflops": flops_per_sample() * B / (ms * 1e-3) / 1e12,
         "launch": "eager" if args.eager else "hipgraph replay of one captured Diffusion.forward",
         "target_points_per_sec_per_gpu": 2.0e6,
+        "per_rank_points_per_sec": (dist_rep or {}).get("per_rank_points_per_sec") or [B * N * args.steps / local_dt],
+        "build": build_info(),
     }
     if dist_rep is not None:
         rec["distributed"] = dist_rep
@@ -960,10 +1002,8 @@ def main():
             tot_ms += t
         tf = tot_f / (tot_ms * 1e-3) / 1e12 if tot_ms else 0.0
         gbs = tot_b / (tot_ms * 1e-3) / 1e9 if tot_ms else 0.0
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "gemm_hbm_traffic.json")
-        if os.path.exists(tj):
-            traffic = json.load(open(tj)).get(site_mode, {}).get("bytes_per_launch")
+        tj_site, tmeta = load_traffic(site_mode)
+        traffic = tj_site.get("bytes_per_launch")
         if site_mode == "fp16":
             # The dominant kernel is the fused point MLP (35 % of device time): 155 GFLOP over 402 MB that must cross HBM
             # = 385 FLOP/B, above the ridge of 2500 TF / 8 TB/s = 312 -> bound: mfma.  The other two launches of a layer
@@ -1003,7 +1043,7 @@ def main():
             mtf = per[mk]["tflops"]
             mb = [by for name, fl, by, fn in rsites if name == mk][0]
             units = 1.375   # mlp.0: fp16 + two fp6 terms (1.5); mlp.2: fp16 + one (1.25)
-            tjd = json.load(open(tj)).get("w2", {}) if os.path.exists(tj) else {}
+            tjd, tmeta = load_traffic("w2")
             kk = next((v for k, v in tjd.get("per_kernel", {}).items() if k.startswith("mlp_fused_w_kernel")), {})
             rec["roofline"] = {"bound": "mfma", "achieved": mtf, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": mtf / PEAK_BF16_MFMA_TFLOPS, "traffic": kk.get("bytes_per_launch"),
@@ -1040,7 +1080,7 @@ def main():
             mk = max((k for k in per if k != "round_ms"), key=lambda k: per[k]["ms"] * per[k]["launches_per_evaluation"])
             mtf = per[mk]["tflops"]
             mb = [by for name, fl, by, fn in rsites if name == mk][0]
-            tjd = json.load(open(tj)).get("mixed", {}) if os.path.exists(tj) else {}
+            tjd, tmeta = load_traffic("mixed")
             pk = tjd.get("per_kernel", {})
             is0 = mk.startswith("mlp.0")
             munits = MLP0_UNITS if is0 else 1.25   # mlp.2 / out_proj on the register-fed kernel: fp16 + one fp6 term
@@ -1118,10 +1158,17 @@ def main():
     if rank == 0 and world == 1 and not args.eager:
         # beside the headline (whose every replay rebuilds the weight images, as a forward between two weight updates must): the same
         # graph captured inside hip_ops.frozen_weights() — images built once by the warm-up call, as every sampler call does
-        runf = model.graphed_forward(x, sigma, None, frozen_weights=True)
-        outf = runf()
-        assert torch.equal(outf, out), "frozen-weights evaluation differs from the headline's"
-        rec["frozen_weights_ms_per_step"] = time_events(runf, args.steps, warmup=3)
+        try:   # (an extra: whatever happens here must not cost the headline line)
+            out_head = run().clone()            # the headline graph's own output, whatever the buffers held meanwhile
+            runf = model.graphed_forward(x, sigma, None, frozen_weights=True)
+            same = bool(torch.equal(runf(), out_head))
+            rec["frozen_weights_ms_per_step"] = time_events(runf, args.steps, warmup=3)
+            rec["frozen_weights_bit_identical"] = same
+            if not same:
+                rec["frozen_weights_error"] = "frozen-weights evaluation differs from the headline's"
+        except Exception as e:
+            rec["frozen_weights_ms_per_step"] = None
+            rec["frozen_weights_error"] = repr(e)[:300]
     if rank == 0 and world == 1 and not args.no_sampler:
         # Metric 2 (BASELINE.json): 128-step sample_stochastic wall-clock = 255 evaluations + fp64 sampler kernels,
         # one hipGraph per step replayed 127 times
@@ -1140,11 +1187,8 @@ def main():
         # whole evaluation against both roofs: executed matrix-pipe work / time / 2500 TFLOP/s, and HBM bytes from the counters
         # (profiles/gemm_hbm_traffic.json: FETCH_SIZE / WRITE_SIZE passes over whole evaluations of this tree) / time / 8 TB/s
         ex = executed_mfma_flops(mode)
-        tjw = {}
-        try:
-            tjw = json.load(open(os.path.join(ROOT, "profiles", "gemm_hbm_traffic.json"))).get(mode, {})
-        except Exception:
-            pass
+        tjw, tmeta_w = load_traffic(mode)
+        rec["roofline"].update(tmeta_w)     # "traffic_tree" (where the counter constants come from) and "traffic_stale"
         cb = tjw.get("bytes_per_evaluation")
         rec["roofline"]["whole"] = {
             "executed_mfma_tflops": ex / (ms * 1e-3) / 1e12 if ex else None,

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GECCO_HIP_LIB") or os.path.join(_HERE, "libgecco_hip.so")   # override: A/B builds only
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 c_f = C.c_void_p  # device pointers travel as void*
 
@@ -33,7 +33,7 @@ class GeccoLayer(C.Structure):
 class GeccoSetTransformer(C.Structure):
     _fields_ = [("n_layers", C.c_int), ("C", C.c_int), ("H", C.c_int), ("I", C.c_int), ("ctx_dim", C.c_int),
                 ("G", C.c_int), ("width", C.c_int), ("act", C.c_int), ("precision", C.c_int), ("images_ready", C.c_int),
-                ("layers", C.POINTER(GeccoLayer))]
+                ("opt_mask", C.c_uint), ("opt_vals", C.c_uint), ("layers", C.POINTER(GeccoLayer))]
 
 
 class GeccoLinearLift(C.Structure):
@@ -123,6 +123,7 @@ SIGNATURES = {
     "gecco_linear_astat16_actbwd": (i, [vp] * 4 + [i, vp, vp, i, i, i, i, vp, vp]),
     "gecco_linear_act_keep_h16": (i, [vp] * 6 + [i, vp, vp, i, i, i, i, vp, vp]),
     "gecco_set_option": (i, [C.c_char_p, i]),
+    "gecco_option_index": (i, [C.c_char_p]),
     "gecco_linear_astat_f16": (i, [vp, vp, vp, vp, vp, i, vp, vp, vp, i, vp, vp, i, i, i, i, i, vp, vp]),
     "gecco_linear_kvq_f16": (i, [vp, vp, vp, vp, vp, i, vp, vp, vp, i, vp, i, i, i, i, i, i, vp, vp]),
     "gecco_linear_h8_img_f32": (i, [vp, vp, vp, vp, vp, vp, i, vp, i, i, i, i, i, vp, vp]),

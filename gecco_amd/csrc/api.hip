@@ -195,7 +195,16 @@ int g_options[OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 
 const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor", "mlpfused", "unpoolfused", "lo8", "actimg", "h8", "kvq64", "h8areg", "chain2", "unpoolh8", "mlpw", "chaincl", "h6", "kvfold", "mlpwshare"};
 const char* const g_option_env[OPT_COUNT] = {"GECCO_ASTAT", "GECCO_CHAIN", "GECCO_HEADMAJOR", "GECCO_MLPFUSED", "GECCO_UNPOOLFUSED", "GECCO_LO8",
                                              "GECCO_ACTIMG", "GECCO_H8", "GECCO_KVQ64", "GECCO_H8AREG", "GECCO_CHAIN2", "GECCO_UNPOOLH8", "GECCO_MLPW", "GECCO_CHAINCL", "GECCO_H6", "GECCO_KVFOLD", "GECCO_MLPWSHARE"};
+// A plan's own switches (GeccoSetTransformer.opt_mask / opt_vals: gecco_option_index(name) is the bit) win over the process-wide ones
+// while that plan's forward runs on this thread: two plans, or two host threads, never see each other's settings.
+thread_local const GeccoSetTransformer* t_plan = nullptr;
+struct PlanScope {
+    const GeccoSetTransformer* prev;
+    explicit PlanScope(const GeccoSetTransformer* p) : prev(t_plan) { t_plan = p; }
+    ~PlanScope() { t_plan = prev; }
+};
 int option(int which) {
+    if (t_plan && ((t_plan->opt_mask >> which) & 1u)) return (int)((t_plan->opt_vals >> which) & 1u);
     if (g_options[which] < 0) {
         const char* e = getenv(g_option_env[which]);
         // "mlpwshare" (the one-launch MLP leaves CUs to a second stream's kernels) is off unless the caller runs two streams: hip_ops.py
@@ -260,6 +269,7 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
     if (st->I != 64) return fail(-3, "set_transformer: num_inducers must be 64 (got %d)", st->I);
     if (st->C % st->H || st->C % st->G || st->C % 4) return fail(-3, "set_transformer: bad feature_dim %d", st->C);
     if (st->act < 0 || st->act > 3) return fail(-3, "set_transformer: act must be 0 (identity), 1 / 2 (GaussianActivation normalized / raw) or 3 (ReLU)");
+    PlanScope plan_scope(st);
     STWorkspace w = carve_st(st, B, N, ws);
     if (ws_bytes < w.bytes) return fail(-7, "set_transformer: workspace too small (%zu < %zu)", ws_bytes, w.bytes);
     const int C = st->C, I = st->I, H = st->H, G = st->G, Wd = st->width, ctx = st->ctx_dim, act = st->act;
@@ -718,6 +728,13 @@ extern "C" {
 int gecco_abi_version(void) { return GECCO_ABI_VERSION; }
 const char* gecco_build_arch(void) { return "gfx950"; }
 const char* gecco_last_error(void) { return g_err; }
+
+int gecco_option_index(const char* name) {
+    if (name)
+        for (int i = 0; i < OPT_COUNT; ++i)
+            if (!strcmp(name, g_option_names[i])) return i;
+    return -1;
+}
 
 int gecco_set_option(const char* name, int value) {
     if (!name) return fail(-1, "set_option: null name");

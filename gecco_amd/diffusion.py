@@ -293,6 +293,26 @@ class Diffusion(_Base):
             post_context = self.conditioner(raw_context)
         return self.backbone(data, sigma, raw_context, post_context, do_cache, cache, out=out)
 
+    # ---- this model's own arithmetic mode / path switches (additions to the reference API; the reference's modules carry no
+    # process-wide state, diffusion.py:160-178 — neither do ours once these are set: two models of different precision in one
+    # serving process, on any host threads, do not see each other)
+    def set_precision(self, name: str | None) -> "Diffusion":
+        """Arithmetic of THIS model's evaluations ("fp32" | "bf16x3" | "fp16" | "mixed" | "w2"; None: the process-wide default,
+        GECCO_PRECISION / hip_ops.set_default_precision)."""
+        from .models.set_transformer import SetTransformer
+        for m in self.modules():
+            if isinstance(m, SetTransformer):
+                m.set_precision(name)
+        return self
+
+    def set_option(self, name: str, value: int) -> "Diffusion":
+        """Pin a library path switch (include/gecco_hip.h gecco_set_option) for THIS model; negative: follow the default again."""
+        from .models.set_transformer import SetTransformer
+        for m in self.modules():
+            if isinstance(m, SetTransformer):
+                m.set_option(name, value)
+        return self
+
     @property
     def example_param(self) -> Tensor:
         return next(self.parameters())

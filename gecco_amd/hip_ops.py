@@ -8,7 +8,9 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import itertools
 import os
+import threading
 from typing import Mapping, Sequence
 
 import torch
@@ -34,11 +36,30 @@ def set_default_precision(name: str) -> None:
 
 
 def set_option(name: str, value: int) -> None:
-    """Process-wide path switch of the library ("astat", "chain"; include/gecco_hip.h gecco_set_option): 0 / 1, or a
-    negative value to return to the default.  For A/B measurements and the tests that compare the fused launches with
-    the stand-alone kernels they replace."""
+    """Process-wide DEFAULT of a path switch of the library ("astat", "chain"; include/gecco_hip.h gecco_set_option): 0 / 1, or a
+    negative value to return to the environment / built-in default.  Plans that did not pin the option themselves
+    (`plan.set_option`) follow it; the unit operators always do.  For A/B measurements and the tests that compare the fused
+    launches with the stand-alone kernels they replace."""
     _lib.check(_lib.load().gecco_set_option(name.encode(), int(value)), "set_option")
     weights_changed()   # (the options decide which weight images a forward builds)
+
+
+def _option_bit(name: str) -> int:
+    idx = _lib.load().gecco_option_index(name.encode())
+    if idx < 0:
+        raise ValueError(f"unknown option {name!r}")
+    return idx
+
+
+def _pin_option(table: GeccoSetTransformer, name: str, value: int) -> None:
+    """Pin (0 / 1) or release (negative) one switch in a plan's own table (GeccoSetTransformer.opt_mask / opt_vals)."""
+    bit = 1 << _option_bit(name)
+    if value < 0:
+        table.opt_mask &= ~bit
+        table.opt_vals &= ~bit
+    else:
+        table.opt_mask |= bit
+        table.opt_vals = (table.opt_vals | bit) if value else (table.opt_vals & ~bit)
 
 
 def default_precision() -> str:
@@ -564,7 +585,7 @@ class SetTransformerPlan:
     parameter tensors so the raw pointers stay valid; rebuild it if parameters are re-allocated."""
 
     def __init__(self, p: Mapping[str, Tensor], pre: str, H: int, I: int = 64, G: int = 32, normalized: bool = True,
-                 precision: str | None = None, act: int | None = None):
+                 precision: str | None = None, act: int | None = None, options: Mapping[str, int] | None = None):
         self.lib = _lib.load()
         self.precision = precision or _default_precision
         if self.precision not in PRECISIONS:
@@ -585,8 +606,16 @@ class SetTransformerPlan:
             act = (ACT_GAUSS if normalized else ACT_GAUSS_RAW) if f"{pre}layers.0.mlp.1.alpha" in p else ACT_RELU
         self.act = act
         self.table = GeccoSetTransformer(L, self.C, H, I, self.ctx_dim, G, self.width, act,
-                                         PRECISIONS[self.precision], 0, self._layers)
+                                         PRECISIONS[self.precision], 0, 0, 0, self._layers)
+        for name, value in (options or {}).items():
+            _pin_option(self.table, name, value)
         self._ws: dict[tuple[int, int], Tensor] = {}
+        self.images = _ImageState()
+
+    def set_option(self, name: str, value: int) -> None:
+        """Pin a path switch for THIS plan (0 / 1; negative: follow the process-wide default again)."""
+        _pin_option(self.table, name, value)
+        self.images.changed()
 
     def workspace(self, B: int, N: int) -> Tensor:
         key = (B, N)
@@ -635,30 +664,92 @@ _FWD_SIDE = {"streams": []}
 # not — a sampler's 255 evaluations, a serving loop between two weight updates — and the fused plans build the images once
 # per scope and workspace and hand `images_ready = 1` to the library afterwards.  Entering the outermost scope, `set_option`
 # and every optimizer step (`weights_changed()`) start a new generation: nothing built earlier is trusted.
-_FROZEN = {"depth": 0, "generation": 0}
+#
+# State: the scope depth is per host THREAD (`threading.local`), the built-image tokens are per PLAN and workspace (`_ImageState`), and a
+# plan has its own generation next to the process-wide one — two models, or two threads, cannot alias each other's scopes; the
+# library reads `images_ready` from a per-call COPY of the plan's table, never from shared state.
+_GENERATION = itertools.count(1)          # (next() on a count is atomic under the GIL)
+_generation = [next(_GENERATION)]         # process-wide: bumped by weights_changed() / set_option() / an outermost frozen_weights()
+
+
+class _Scope(threading.local):
+    depth = 0
+
+
+_SCOPE = _Scope()
 
 
 def weights_changed() -> None:
-    """Tell the plans that weight values (or the path options) changed by a route no tensor version counter sees."""
-    _FROZEN["generation"] += 1
+    """Tell EVERY plan that weight values (or the process-wide path options) changed by a route no tensor version counter sees
+    (an optimizer step, an EMA swap, a state-dict load into the same storage).  A plan's own `images.changed()` is the narrow form."""
+    _generation[0] = next(_GENERATION)
 
 
 @contextlib.contextmanager
-def frozen_weights():
-    if _FROZEN["depth"] == 0:
-        _FROZEN["generation"] += 1
-    _FROZEN["depth"] += 1
+def frozen_weights(*plans):
+    """Inside the scope the caller vouches that weights do not change: plans build their weight images once per workspace.
+    Without arguments the scope covers every plan used by THIS thread; with plans (LinearLiftPlan / RayNetworkPlan /
+    SetTransformerPlan, or modules' `.plan`) only those."""
+    states = [getattr(p, "images", p) for p in plans]
+    if states:
+        for st in states:
+            st.enter()
+        try:
+            yield
+        finally:
+            for st in states:
+                st.leave()
+        return
+    if _SCOPE.depth == 0:
+        _generation[0] = next(_GENERATION)
+    _SCOPE.depth += 1
     try:
         yield
     finally:
-        _FROZEN["depth"] -= 1
+        _SCOPE.depth -= 1
 
 
-def _images_token(cached: bool):
-    """What a workspace's images were built under, or None outside a frozen scope (then every forward rebuilds)."""
-    if _FROZEN["depth"] == 0 or os.environ.get("GECCO_FROZEN_IMAGES", "1") == "0":
-        return None
-    return (_FROZEN["generation"], bool(cached))
+class _ImageState:
+    """One plan's record of which workspaces hold valid weight images (and its own frozen scope / generation)."""
+
+    def __init__(self):
+        self.depth = 0
+        self.generation = 0
+        self.tokens: dict[tuple, tuple] = {}
+
+    def enter(self) -> None:
+        if self.depth == 0:
+            self.generation = next(_GENERATION)
+        self.depth += 1
+
+    def leave(self) -> None:
+        self.depth -= 1
+
+    def changed(self) -> None:
+        self.generation = next(_GENERATION)
+        self.tokens.clear()
+
+    def token(self, cached: bool):
+        """What a workspace's images are built under now, or None outside every frozen scope (then each forward rebuilds)."""
+        if (self.depth == 0 and _SCOPE.depth == 0) or os.environ.get("GECCO_FROZEN_IMAGES", "1") == "0":
+            return None
+        return (_generation[0], self.generation, self.depth > 0, bool(cached))
+
+    def ready(self, key, tok) -> int:
+        """images_ready for the call about to be issued on workspace `key`."""
+        return int(tok is not None and self.tokens.get(key) == tok)
+
+    def built(self, key, tok, was_ready: int) -> None:
+        """Record a SUCCESSFUL forward on `key` (call after check()).  A forward that was only captured into a graph built nothing
+        yet: its images exist once the graph replays, so nothing is recorded and later eager calls rebuild (the graph carries its
+        own build launches)."""
+        if tok is None or (not was_ready and torch.cuda.is_initialized() and torch.cuda.is_current_stream_capturing()):
+            self.tokens.pop(key, None)
+        else:
+            self.tokens[key] = tok
+
+    def failed(self, key) -> None:
+        self.tokens.pop(key, None)
 
 
 def _fwd_parts(B: int, N: int) -> int:
@@ -675,16 +766,12 @@ def _two_stream_halves(B: int, call, tensors, parts: int = 2) -> None:
         _FWD_SIDE["streams"].append(torch.cuda.Stream())
     sides, main = _FWD_SIDE["streams"][:parts - 1], torch.cuda.current_stream()
     cuts = [B * i // parts for i in range(parts + 1)]
-    lib = _lib.load()
-    lib.gecco_set_option(b"mlpwshare", 1)   # launches that fill their CUs leave room for the other stream's kernels (mlp_fused_w.hip)
-    try:
-        for i, side in enumerate(sides, start=1):
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                call(cuts[i], cuts[i + 1], i)
-        call(cuts[0], cuts[1], 0)
-    finally:
-        lib.gecco_set_option(b"mlpwshare", -1)
+    # (the calls pin "mlpwshare" in their own copy of the table: launches that fill their CUs leave room for the other stream's kernels)
+    for i, side in enumerate(sides, start=1):
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            call(cuts[i], cuts[i + 1], i)
+    call(cuts[0], cuts[1], 0)
     for side in sides:
         main.wait_stream(side)
     if not torch.cuda.is_current_stream_capturing():   # (a captured graph owns its memory: nothing to tell the allocator)
@@ -698,14 +785,19 @@ class LinearLiftPlan:
     """EDMPrecond(LinearLift(SetTransformer)) = the unconditional Diffusion.forward, one C call."""
 
     def __init__(self, p: Mapping[str, Tensor], H: int, I: int = 64, pre: str = "", sigma_data: float = 1.0,
-                 precision: str | None = None, act: int | None = None):
-        self.st = SetTransformerPlan(p, pre + "inner.", H, I, precision=precision, act=act)
+                 precision: str | None = None, act: int | None = None, options: Mapping[str, int] | None = None):
+        self.st = SetTransformerPlan(p, pre + "inner.", H, I, precision=precision, act=act, options=options)
         self.p = p
         self.lib = self.st.lib
         self.table = GeccoLinearLift(self.st.table, _ptr(p[pre + "lift.weight"]), _ptr(p[pre + "lift.bias"]),
                                      _ptr(p[pre + "lower.1.weight"]), _ptr(p[pre + "lower.1.bias"]), sigma_data)
         self._ws: dict[tuple[int, int], Tensor] = {}
-        self._img_tok: dict[tuple, tuple] = {}   # workspace key -> the token its weight images were built under (frozen_weights)
+        self.images = self.st.images   # workspace key -> the token its weight images were built under (frozen_weights)
+
+    def set_option(self, name: str, value: int) -> None:
+        """Pin a path switch for THIS plan (0 / 1; negative: follow the process-wide default again)."""
+        _pin_option(self.table.inner, name, value)
+        self.st.set_option(name, value)
 
     def workspace(self, B: int, N: int, idx: int = 0) -> Tensor:
         key = (B, N, idx)
@@ -723,18 +815,26 @@ class LinearLiftPlan:
 
         def call(lo, hi, idx):
             ws = self.workspace(hi - lo, N, idx)
-            tok = _images_token(cache is not None)
-            self.table.inner.images_ready = int(tok is not None and self._img_tok.get((hi - lo, N, idx)) == tok)
-            self._img_tok[(hi - lo, N, idx)] = tok
+            key, tok = (hi - lo, N, idx), self.images.token(cache is not None)
+            tbl = GeccoLinearLift.from_buffer_copy(self.table)    # this call's own copy: nothing another call / thread can alias
+            ready = tbl.inner.images_ready = self.images.ready(key, tok)
+            if parts > 1:
+                _pin_option(tbl.inner, "mlpwshare", 1)
             cut = (lambda ts: None if ts is None else [None if t is None else t[lo:hi] for t in ts])
-            check(self.lib.gecco_linear_lift_fwd_f32(
-                C.byref(self.table), _ptr(x[lo:hi]), _ptr(sigma[lo:hi]), _ptr(den[lo:hi]), _ptr(None if raw is None else raw[lo:hi]),
-                self.st._ptr_array(cut(cache), L), self.st._ptr_array(cut(h_out), L), hi - lo, N, C.c_void_p(ws.data_ptr()),
-                ws.numel(), _stream()), "gecco_linear_lift_fwd_f32")
+            try:
+                check(self.lib.gecco_linear_lift_fwd_f32(
+                    C.byref(tbl), _ptr(x[lo:hi]), _ptr(sigma[lo:hi]), _ptr(den[lo:hi]), _ptr(None if raw is None else raw[lo:hi]),
+                    self.st._ptr_array(cut(cache), L), self.st._ptr_array(cut(h_out), L), hi - lo, N, C.c_void_p(ws.data_ptr()),
+                    ws.numel(), _stream()), "gecco_linear_lift_fwd_f32")
+            except BaseException:
+                self.images.failed(key)
+                raise
+            self.images.built(key, tok, ready)
+        parts = _fwd_parts(B, N) if B else 1
         if B == 0:
             pass   # an empty batch (a rank that owns no cloud): empty results, nothing to launch
-        elif _fwd_parts(B, N) > 1:
-            _two_stream_halves(B, call, [x, sigma, den, raw, *(cache or []), *(h_out or [])], _fwd_parts(B, N))
+        elif parts > 1:
+            _two_stream_halves(B, call, [x, sigma, den, raw, *(cache or []), *(h_out or [])], parts)
         else:
             call(0, B, 0)
         res = (den, raw) if return_raw else den
@@ -835,8 +935,9 @@ class RayNetworkPlan:
 
     def __init__(self, p: Mapping[str, Tensor], H: int, I: int = 64, pre: str = "", reparam_kind: int = 2,
                  rp_mean: Tensor | None = None, rp_std: Tensor | None = None, logit_scale: float = 1.1,
-                 sigma_data: float = 1.0, precision: str | None = None, act: int | None = None):
-        self.st = SetTransformerPlan(p, pre + "backbone.", H, I, precision=precision, act=act)
+                 sigma_data: float = 1.0, precision: str | None = None, act: int | None = None,
+                 options: Mapping[str, int] | None = None):
+        self.st = SetTransformerPlan(p, pre + "backbone.", H, I, precision=precision, act=act, options=options)
         self.p = p
         self.lib = self.st.lib
         if reparam_kind == 2 and rp_mean is None:
@@ -848,7 +949,12 @@ class RayNetworkPlan:
             _ptr(p[pre + "output_proj.1.weight"]), _ptr(p[pre + "output_proj.1.bias"]),
             make_reparam(reparam_kind, rp_mean, rp_std, logit_scale), sigma_data)
         self._ws: dict[tuple, Tensor] = {}
-        self._img_tok: dict[tuple, tuple] = {}
+        self.images = self.st.images
+
+    def set_option(self, name: str, value: int) -> None:
+        """Pin a path switch for THIS plan (0 / 1; negative: follow the process-wide default again)."""
+        _pin_option(self.table.backbone, name, value)
+        self.st.set_option(name, value)
 
     def forward(self, x: Tensor, sigma: Tensor, K: Tensor, levels_nhwc: Sequence[Tensor], return_raw: bool = False,
                 cache: Sequence[Tensor] | None = None, do_cache: bool = False, out: Tensor | None = None):
@@ -866,18 +972,26 @@ class RayNetworkPlan:
                 self._ws[key] = _ws(self.lib.gecco_ray_network_workspace_bytes(C.byref(self.table), C.byref(pyr), hi - lo, N),
                                     self.st.device)
             ws = self._ws[key]
-            tok = _images_token(cache is not None)
-            self.table.backbone.images_ready = int(tok is not None and self._img_tok.get(key) == tok)
-            self._img_tok[key] = tok
+            tok = self.images.token(cache is not None)
+            tbl = _lib.GeccoRayNetwork.from_buffer_copy(self.table)   # this call's own copy (see LinearLiftPlan)
+            ready = tbl.backbone.images_ready = self.images.ready(key, tok)
+            if parts > 1:
+                _pin_option(tbl.backbone, "mlpwshare", 1)
             cut = (lambda ts: None if ts is None else [None if t is None else t[lo:hi] for t in ts])
-            check(self.lib.gecco_ray_network_fwd_f32(
-                C.byref(self.table), _ptr(x[lo:hi]), _ptr(sigma[lo:hi]), _ptr(K[lo:hi]), C.byref(pyr), _ptr(den[lo:hi]),
-                _ptr(None if raw is None else raw[lo:hi]), self.st._ptr_array(cut(cache), L), self.st._ptr_array(cut(h_out), L),
-                hi - lo, N, C.c_void_p(ws.data_ptr()), ws.numel(), _stream()), "gecco_ray_network_fwd_f32")
+            try:
+                check(self.lib.gecco_ray_network_fwd_f32(
+                    C.byref(tbl), _ptr(x[lo:hi]), _ptr(sigma[lo:hi]), _ptr(K[lo:hi]), C.byref(pyr), _ptr(den[lo:hi]),
+                    _ptr(None if raw is None else raw[lo:hi]), self.st._ptr_array(cut(cache), L), self.st._ptr_array(cut(h_out), L),
+                    hi - lo, N, C.c_void_p(ws.data_ptr()), ws.numel(), _stream()), "gecco_ray_network_fwd_f32")
+            except BaseException:
+                self.images.failed(key)
+                raise
+            self.images.built(key, tok, ready)
+        parts = _fwd_parts(B, N) if B else 1
         if B == 0:
             pass   # an empty batch: empty results, nothing to launch
-        elif _fwd_parts(B, N) > 1:
-            _two_stream_halves(B, call, [x, sigma, K, den, raw, *levels_nhwc, *(cache or []), *(h_out or [])], _fwd_parts(B, N))
+        elif parts > 1:
+            _two_stream_halves(B, call, [x, sigma, K, den, raw, *levels_nhwc, *(cache or []), *(h_out or [])], parts)
         else:
             call(0, B, 0)
         res = (den, raw) if return_raw else den

@@ -53,6 +53,7 @@ class LinearLift(nn.Module):
         def build():
             st = self.inner.plan()
             p = dict(self.named_parameters())
-            return hip_ops.LinearLiftPlan(p, st.H, st.I, sigma_data=sigma_data, act=st.act)
+            return hip_ops.LinearLiftPlan(p, st.H, st.I, sigma_data=sigma_data, act=st.act, precision=self.inner.precision,
+                                          options=self.inner.options)
         plan = self._cache.get(self, build)
         return plan.forward(x.float().contiguous(), sigma.float().contiguous(), cache=cache, do_cache=do_cache, out=out)

@@ -85,7 +85,7 @@ class RayNetwork(nn.Module):
             kind, mean, std, ls = self.reparam.lookup_spec()
             p = {k: v for k, v in self.named_parameters()}
             return hip_ops.RayNetworkPlan(p, st.H, st.I, reparam_kind=kind, rp_mean=mean, rp_std=std, logit_scale=ls,
-                                          sigma_data=sigma_data, act=st.act)
+                                          sigma_data=sigma_data, act=st.act, precision=self.backbone.precision, options=self.backbone.options)
         plan = self._cache.get(self, build)
         return plan.forward(x.float().contiguous(), sigma.float().contiguous(), raw_ctx.K.float().contiguous(),
                             _levels(post_context), cache=cache, do_cache=do_cache, out=out)

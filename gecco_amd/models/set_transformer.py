@@ -13,8 +13,17 @@ from .mlp import MLP
 from .normalization import AdaGN
 
 
+def _own_settings(module: nn.Module):
+    """(precision | None, ((option, value), ...)) pinned on the SetTransformer inside `module` (`SetTransformer.set_precision` /
+    `set_option`; `Diffusion.set_precision` walks the model) — None / empty: follow the process-wide defaults."""
+    for m in module.modules():
+        if isinstance(m, SetTransformer):
+            return m.precision, tuple(sorted(m.options.items()))
+    return None, ()
+
+
 def _param_sig(module: nn.Module):
-    return (hip_ops.default_precision(),) + tuple(p.data_ptr() for p in module.parameters()) + \
+    return (hip_ops.default_precision(), _own_settings(module)) + tuple(p.data_ptr() for p in module.parameters()) + \
         tuple(b.data_ptr() for b in module.buffers())
 
 
@@ -160,13 +169,32 @@ class SetTransformer(nn.Module):
             for _ in range(n_layers)])
         self.feature_dim = feature_dim
         self._cache = _PlanCache()
+        # this model's own arithmetic mode / path switches (None / {}: the process-wide defaults, hip_ops.set_default_precision /
+        # set_option / the environment).  The reference's modules carry no global state (models/set_transformer.py:176-216); with
+        # these two attributes neither do ours: two models of different precision live in one process, on any host threads.
+        self.precision: str | None = None
+        self.options: dict[str, int] = {}
+
+    def set_precision(self, name: str | None) -> "SetTransformer":
+        if name is not None and name not in hip_ops.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(hip_ops.PRECISIONS)}")
+        self.precision = name
+        return self
+
+    def set_option(self, name: str, value: int) -> "SetTransformer":
+        hip_ops._option_bit(name)   # (raises on an unknown name)
+        if value < 0:
+            self.options.pop(name, None)
+        else:
+            self.options[name] = int(bool(value))
+        return self
 
     def plan(self) -> hip_ops.SetTransformerPlan:
         def build():
             l0 = self.layers[0]
             return hip_ops.SetTransformerPlan(dict(self.named_parameters()), "", l0.broadcast.pool.num_heads,
                                               l0.broadcast.pool.inducers.shape[2], l0.broadcast_norm.gn.num_groups,
-                                              act=_act_of(l0.mlp))
+                                              act=_act_of(l0.mlp), precision=self.precision, options=self.options)
         return self._cache.get(self, build)
 
     def forward(self, features: Tensor, t_embed: Tensor, return_h: bool = False, hs: list[Tensor] | None = None):

@@ -147,6 +147,8 @@ class FusedAdamEMA(torch.optim.Optimizer):
         self._span_of = None
         from .autograd import WEIGHT_IMAGES
         WEIGHT_IMAGES.invalidate()   # the parameters moved into the flat buffer
+        from . import hip_ops
+        hip_ops.weights_changed()
 
     def _ensure(self) -> None:
         """(Re)build the flat views when parameters were added, moved or re-allocated since the last step."""
@@ -319,6 +321,9 @@ class FusedAdamEMA(torch.optim.Optimizer):
         self._flat["ema"].copy_(tmp)
         from .autograd import WEIGHT_IMAGES
         WEIGHT_IMAGES.invalidate()   # the parameters are views of the flat buffer: their version counters did not move
+        from . import hip_ops
+        hip_ops.weights_changed()    # an inference plan inside frozen_weights() (or a frozen graph's next capture) must rebuild its
+                                     # streamed weight images: otherwise it would mix pre-swap images with post-swap biases
 
     @contextlib.contextmanager
     def swap_ema_weights(self, enabled: bool = True):

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GECCO_ABI_VERSION 13
+#define GECCO_ABI_VERSION 14
 
 int gecco_abi_version(void);
 const char* gecco_build_arch(void);   /* "gfx950" */
@@ -77,6 +77,10 @@ typedef struct GeccoSetTransformer {  /* SetTransformer, models/set_transformer.
                         * 1: the caller guarantees that the workspace of this call still holds the images the previous forward with this
                         *    table, the same (B, N), the same options and the same cached / uncached form built in it, and that no weight
                         *    changed since: the forward skips the image launches (a sampler's 2nd .. 255th evaluation) */
+    unsigned opt_mask, opt_vals;  /* this plan's own path switches (ABI 14): bit gecco_option_index(name) of opt_mask set = the option is
+                                   * pinned to the same bit of opt_vals for every forward with this table, whatever gecco_set_option /
+                                   * the environment say; clear = follow the process-wide default.  The reference's modules are
+                                   * self-contained (models/set_transformer.py:176-216): so are these tables. */
     const GeccoLayer* layers;                       /* HOST array of n_layers tables */
 } GeccoSetTransformer;
 
@@ -130,8 +134,11 @@ int gecco_linear_f32(const float* A, const float* W, const float* bias, const fl
  *   "headmajor") instead of the 128-column-tile one (gecco_linear_astat_f16 + lo image): same arithmetic, also at feature_dim 512.
  * value < 0 returns the option to its default / environment (GECCO_ASTAT, GECCO_CHAIN, GECCO_HEADMAJOR, GECCO_MLPFUSED,
  * GECCO_UNPOOLFUSED, GECCO_LO8, GECCO_ACTIMG, GECCO_H8, GECCO_KVQ64, GECCO_H8AREG, GECCO_CHAIN2).
- * Process-wide. */
+ * Process-wide DEFAULT: a network forward consults its own table first (GeccoSetTransformer.opt_mask / opt_vals, ABI 14), so two
+ * plans — or two host threads — with different settings never alias; the unit operators below follow the process-wide value. */
 int gecco_set_option(const char* name, int value);
+/* Bit position of an option in GeccoSetTransformer.opt_mask / opt_vals (-1: unknown name). */
+int gecco_option_index(const char* name);
 
 int gecco_linear_row_tiles(int rows);
 /* The same with the arithmetic selectable: precision 0 = exact fp32 MFMA, 1 = split-bf16, 2 = fp16 (see GeccoSetTransformer);

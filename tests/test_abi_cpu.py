@@ -34,14 +34,14 @@ def test_header_symbols_exported_and_bound(lib):
 
 
 def test_identity(lib):
-    assert lib.gecco_abi_version() == 13
+    assert lib.gecco_abi_version() == 14
     assert lib.gecco_build_arch() == b"gfx950"
     assert lib.gecco_linear_row_tiles(2048) == 16 and lib.gecco_linear_row_tiles(64) == 1
 
 
 def test_workspace_queries_run_without_gpu(lib):
     from gecco_amd import _lib
-    st = _lib.GeccoSetTransformer(6, 384, 8, 64, 1, 32, 768, 1, 0, 0, None)
+    st = _lib.GeccoSetTransformer(6, 384, 8, 64, 1, 32, 768, 1, 0, 0, 0, 0, None)
     nb = lib.gecco_set_transformer_workspace_bytes(ctypes.byref(st), 64, 2048)
     # dominated by KV (B,N,2C) + q + attn = 4 streams of 201 MB
     assert 4 * 64 * 2048 * 384 * 4 <= nb < 5 * 64 * 2048 * 384 * 4

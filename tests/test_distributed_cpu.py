@@ -272,3 +272,6 @@ def test_bench_self_launcher_two_ranks():
     assert d["ranks_in_group"] == 2 and d["backend"] == "gloo" and "collective_library" in d
     assert len(d["allreduce"]) == 2 and all(v["ms"] > 0 and v["busbw_gbs"] > 0 for v in d["allreduce"].values())
     assert d["rank0_points_per_sec_unbarriered"] > 0
+    # every rank's own rate, in rank order (round 6): rank 1 sleeps twice as long per step as rank 0
+    pr = d["per_rank_points_per_sec"]
+    assert len(pr) == 2 and pr[0] == d["rank0_points_per_sec_unbarriered"] and 0 < pr[1] < pr[0]

@@ -141,7 +141,7 @@ def _run_cond(ops, case, precision, tag):
     with ops.frozen_weights():   # the scope's evaluations share one build of the weight images (a sampler call): same bits
         for _ in range(2):
             assert torch.equal(den, net.forward(x.cuda(), sigma.cuda(), K.cuda(), levels))
-        assert net.table.backbone.images_ready == 1
+        assert net.images.tokens and all(t == net.images.token(False) for t in net.images.tokens.values())   # built once, reused
 
 
 @pytest.mark.parametrize("precision", MODES)

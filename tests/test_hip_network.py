@@ -445,7 +445,7 @@ def test_frozen_weights_scope_reuses_the_weight_images(ops, precision):
             d, r = net.forward(x, sigma, return_raw=True)
             assert torch.equal(d, d0) and torch.equal(r, r0)
             assert torch.equal(net.forward(xn, sigma, cache=cache), c0)
-        assert net.table.inner.images_ready == 1
+        assert net.images.ready((x.shape[0], x.shape[1], 0), net.images.token(False)) == 1
         w = p["inner.layers.3.mlp.0.weight"]
         w_saved = w.clone()
         w.mul_(1.25)
@@ -456,7 +456,7 @@ def test_frozen_weights_scope_reuses_the_weight_images(ops, precision):
         assert not torch.equal(fresh, d0)
         with ops.frozen_weights():   # nested: same generation
             assert torch.equal(net.forward(x, sigma), fresh)
-    assert torch.equal(net.forward(x, sigma), fresh) and net.table.inner.images_ready == 0
+    assert torch.equal(net.forward(x, sigma), fresh) and net.images.token(False) is None
     w.copy_(w_saved)
     with ops.frozen_weights():       # a new scope trusts nothing built before it
         assert torch.equal(net.forward(x, sigma), d0)

@@ -139,21 +139,106 @@ def test_frozen_weights_scope_bookkeeping():
     token (every forward rebuilds); inside, full and cached evaluations have different tokens; nesting keeps the generation; a new
     outermost scope, `weights_changed()` (the optimizer's step calls it) and `set_option` start a new one."""
     from gecco_amd import hip_ops as ops
-    assert ops._images_token(False) is None
+    st = ops._ImageState()
+    assert st.token(False) is None
     with ops.frozen_weights():
-        t_full, t_cached = ops._images_token(False), ops._images_token(True)
-        assert t_full is not None and t_full != t_cached and t_full == ops._images_token(False)
+        t_full, t_cached = st.token(False), st.token(True)
+        assert t_full is not None and t_full != t_cached and t_full == st.token(False)
         with ops.frozen_weights():
-            assert ops._images_token(False) == t_full
-        assert ops._images_token(False) == t_full
+            assert st.token(False) == t_full
+        assert st.token(False) == t_full
         ops.weights_changed()
-        t2 = ops._images_token(False)
+        t2 = st.token(False)
         assert t2 != t_full
-    assert ops._images_token(False) is None
+    assert st.token(False) is None
     with ops.frozen_weights():
-        assert ops._images_token(False) not in (t_full, t2)
+        assert st.token(False) not in (t_full, t2)
     import gecco_amd
     assert gecco_amd.frozen_weights is ops.frozen_weights and gecco_amd.weights_changed is ops.weights_changed
+
+
+def test_frozen_scope_and_image_tokens_are_per_plan_and_per_thread():
+    """The frozen scope's depth is per host THREAD, the built-image record per PLAN (`_ImageState`): a scope held by one thread is not a
+    scope for another; a plan frozen by name leaves the others rebuilding; one plan's `changed()` does not touch another's tokens; a
+    forward that failed, or was only captured into a graph, records nothing."""
+    import threading
+    from gecco_amd import hip_ops as ops
+    a, b = ops._ImageState(), ops._ImageState()
+    seen = {}
+    with ops.frozen_weights():
+        t = threading.Thread(target=lambda: seen.update(other=a.token(False)))
+        t.start(); t.join()
+        assert a.token(False) is not None and seen["other"] is None           # the other thread holds no scope
+    with ops.frozen_weights(a):                                                # only plan a
+        ta = a.token(False)
+        assert ta is not None and b.token(False) is None
+        key = (2, 128, 0)
+        assert a.ready(key, ta) == 0
+        a.built(key, ta, 0)
+        assert a.ready(key, ta) == 1 and b.ready(key, ta) == 0                 # b has built nothing
+        b.changed()
+        assert a.ready(key, ta) == 1                                           # b's change is b's
+        a.failed(key)
+        assert a.ready(key, ta) == 0                                           # a failed forward leaves no "ready" behind
+        a.built(key, ta, 0)
+        a.changed()
+        assert a.ready(key, a.token(False)) == 0
+    assert a.token(False) is None
+
+
+def test_two_plans_with_different_modes_and_options_do_not_alias(monkeypatch):
+    """Two plans in one process: each carries its own precision and its own pinned path switches in its table (GeccoSetTransformer.opt_mask
+    / opt_vals, ABI 14); pinning on one leaves the other — and the process-wide defaults — untouched.  (Plans hold raw pointers only:
+    built here on CPU tensors with the device check lifted; nothing is launched.)"""
+    import ctypes as C
+    from gecco_amd import _lib, hip_ops as ops
+    from oracle import cases
+    lib = _lib.load()
+    monkeypatch.setattr(ops, "_ptr", lambda t: C.c_void_p(0 if t is None else t.data_ptr()))
+    p, _, _ = cases.uncond_inputs("uncond_d128_L4_N256")
+    w2 = ops.LinearLiftPlan(p, cases.H, cases.I, precision="w2", options={"chain2": 0})
+    mx = ops.LinearLiftPlan(p, cases.H, cases.I, precision="mixed")
+    bit = lambda n: 1 << lib.gecco_option_index(n.encode())
+    assert lib.gecco_option_index(b"no-such-option") == -1 and bit("astat") == 1
+    assert w2.table.inner.precision == ops.PRECISIONS["w2"] and mx.table.inner.precision == ops.PRECISIONS["mixed"]
+    assert w2.table.inner.opt_mask == bit("chain2") and w2.table.inner.opt_vals == 0 and mx.table.inner.opt_mask == 0
+    mx.set_option("mlpw", 1)
+    mx.set_option("kvfold", 0)
+    assert mx.table.inner.opt_mask == bit("mlpw") | bit("kvfold") and mx.table.inner.opt_vals == bit("mlpw")
+    assert mx.st.table.opt_mask == mx.table.inner.opt_mask
+    assert w2.table.inner.opt_mask == bit("chain2")                            # untouched
+    mx.set_option("mlpw", -1)
+    assert mx.table.inner.opt_mask == bit("kvfold") and mx.table.inner.opt_vals == 0
+    assert w2.images is not mx.images
+    # a call's table is a COPY: what it pins (images_ready, "mlpwshare" of a two-stream evaluation) never reaches the plan's own
+    tbl = _lib.GeccoLinearLift.from_buffer_copy(w2.table)
+    tbl.inner.images_ready = 1
+    ops._pin_option(tbl.inner, "mlpwshare", 1)
+    assert w2.table.inner.images_ready == 0 and w2.table.inner.opt_mask == bit("chain2")
+    assert tbl.inner.layers and C.addressof(tbl.inner.layers.contents) == C.addressof(w2.table.inner.layers.contents)
+    with pytest.raises(ValueError):
+        w2.set_option("no-such-option", 1)
+
+
+def test_modules_carry_their_own_precision_and_options():
+    """`Diffusion.set_precision` / `set_option`: the model's SetTransformer holds them, the plan cache's signature includes them (a change
+    rebuilds the plan), and a second model is untouched."""
+    from gecco_amd import hip_ops as ops
+    from gecco_amd.models.set_transformer import SetTransformer, _own_settings, _param_sig
+    a = SetTransformer(n_layers=1, feature_dim=64, num_inducers=64, t_embed_dim=1, num_heads=8)
+    b = SetTransformer(n_layers=1, feature_dim=64, num_inducers=64, t_embed_dim=1, num_heads=8)
+    assert _own_settings(a) == (None, ())
+    sig0 = _param_sig(a)
+    a.set_precision("w2").set_option("chain2", 0)
+    assert _own_settings(a) == ("w2", (("chain2", 0),)) and _own_settings(b) == (None, ())
+    assert _param_sig(a) != sig0
+    a.set_option("chain2", -1)
+    assert _own_settings(a) == ("w2", ())
+    with pytest.raises(ValueError):
+        a.set_precision("fp4")
+    with pytest.raises(ValueError):
+        a.set_option("no-such-option", 1)
+    assert ops.default_precision() in ops.PRECISIONS
 
 
 def test_reparam_log_determinants_vs_autograd_jacobian():

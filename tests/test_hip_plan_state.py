@@ -48,7 +48,7 @@ def test_two_plans_interleaved_inside_one_frozen_scope(ops):
         ops.set_option("chain2", 0)
         ops.set_option("kvfold", 0)
         assert torch.equal(c.forward(x, sigma, return_raw=True)[1], alone["b"][1])
-        assert torch.equal(a.forward(x, sigma, return_raw=True)[1], alone["a"][1])
+        assert torch.equal(a.forward(x, sigma, return_raw=True)[1], alone["a"][1])   # a pinned its own: the process-wide change is not a's
     finally:
         ops.set_option("chain2", -1)
         ops.set_option("kvfold", -1)

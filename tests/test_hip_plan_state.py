@@ -34,7 +34,7 @@ def test_two_plans_interleaved_inside_one_frozen_scope(ops):
     p = _cuda(p)
     x, sigma = x.cuda(), sigma.cuda()
     xn = x[:, :64].contiguous()
-    a = ops.LinearLiftPlan(p, cases.H, cases.I, precision="w2")
+    a = ops.LinearLiftPlan(p, cases.H, cases.I, precision="w2", options={"chain2": 1, "kvfold": 1})   # pinned to the defaults
     b = ops.LinearLiftPlan(p, cases.H, cases.I, precision="mixed", options={"chain2": 0, "kvfold": 0})
     alone = {}
     for k, net in (("a", a), ("b", b)):

@@ -190,11 +190,12 @@ int linear_pair(const float* A, const float* W1, const float* b1, int Nout1, flo
 }
 
 // Path switches for A/B runs and tests: gecco_set_option, or the environment (GECCO_ASTAT, GECCO_CHAIN) on first use.
-enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_HEADMAJOR = 2, OPT_MLPFUSED = 3, OPT_UNPOOLFUSED = 4, OPT_LO8 = 5, OPT_ACTIMG = 6, OPT_H8 = 7, OPT_KVQ64 = 8, OPT_H8AREG = 9, OPT_CHAIN2 = 10, OPT_UNPOOLH8 = 11, OPT_MLPW = 12, OPT_CHAINCL = 13, OPT_H6 = 14, OPT_KVFOLD = 15, OPT_MLPWSHARE = 16, OPT_COUNT = 17 };
-int g_options[OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
-const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor", "mlpfused", "unpoolfused", "lo8", "actimg", "h8", "kvq64", "h8areg", "chain2", "unpoolh8", "mlpw", "chaincl", "h6", "kvfold", "mlpwshare"};
+enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_HEADMAJOR = 2, OPT_MLPFUSED = 3, OPT_UNPOOLFUSED = 4, OPT_LO8 = 5, OPT_ACTIMG = 6, OPT_H8 = 7, OPT_KVQ64 = 8, OPT_H8AREG = 9, OPT_CHAIN2 = 10, OPT_UNPOOLH8 = 11, OPT_MLPW = 12, OPT_CHAINCL = 13, OPT_H6 = 14, OPT_KVFOLD = 15, OPT_MLPWSHARE = 16, OPT_KVQPERM = 17, OPT_COUNT = 18 };
+int g_options[OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor", "mlpfused", "unpoolfused", "lo8", "actimg", "h8", "kvq64", "h8areg", "chain2", "unpoolh8", "mlpw", "chaincl", "h6", "kvfold", "mlpwshare", "kvqperm"};
 const char* const g_option_env[OPT_COUNT] = {"GECCO_ASTAT", "GECCO_CHAIN", "GECCO_HEADMAJOR", "GECCO_MLPFUSED", "GECCO_UNPOOLFUSED", "GECCO_LO8",
-                                             "GECCO_ACTIMG", "GECCO_H8", "GECCO_KVQ64", "GECCO_H8AREG", "GECCO_CHAIN2", "GECCO_UNPOOLH8", "GECCO_MLPW", "GECCO_CHAINCL", "GECCO_H6", "GECCO_KVFOLD", "GECCO_MLPWSHARE"};
+                                             "GECCO_ACTIMG", "GECCO_H8", "GECCO_KVQ64", "GECCO_H8AREG", "GECCO_CHAIN2", "GECCO_UNPOOLH8", "GECCO_MLPW", "GECCO_CHAINCL", "GECCO_H6", "GECCO_KVFOLD", "GECCO_MLPWSHARE",
+                                             "GECCO_KVQPERM"};
 // A plan's own switches (GeccoSetTransformer.opt_mask / opt_vals: gecco_option_index(name) is the bit) win over the process-wide ones
 // while that plan's forward runs on this thread: two plans, or two host threads, never see each other's settings.
 thread_local const GeccoSetTransformer* t_plan = nullptr;
@@ -228,6 +229,7 @@ int astat_linear(const float* x, const float* pa, const float* po, const float* 
         g.precision = 2; g.w_img = img; g.c_f16 = 1; g.hm_hd = hm_hd;
         if (use64 == 2) { g.lo_begin = Nout1 / 128; g.lo_tiles = Nout1 / 64; }
         if (C2) { g.C2 = C2; g.bias2 = bias2; g.n_split = Nout1; g.ldc2 = Nout2; }
+        g.kvq_perm = option(OPT_KVQPERM) && kvq_perm48_ok(hm_hd, K, Nout1, Nout2);   // (the stream's builder decides by the same rule)
         if (!img || act || !gemm_kvq_astat_supported(g)) return 1;
         return gemm_kvq_astat_launch(g, s);
     }
@@ -374,6 +376,8 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
             return 0;
         };
         auto push = [&](const float* Wp, float* img, int Nout, int K) -> int { return push_ld(Wp, img, Nout, K, K); };
+        // head dim 48: the kvq stream in the head-aligned column order (option "kvqperm"; astat_linear decides by the same rule)
+        const int kvq_p48 = (option(OPT_KVQPERM) && option(OPT_HEADMAJOR) && kvq_perm48_ok(C / H, C, 2 * C, C)) ? 64 : 0;
         for (int li = 0; li < st->n_layers; ++li) {
             const GeccoLayer& L = st->layers[li];
             float* base = w.wimg + (size_t)li * w.wimg_layer;
@@ -381,10 +385,10 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
                 // the kvq stream: K | V tiles (the V half with L stages), then the q tiles
                 if (!(h_in && h_in[li])) {
                     if (jobs8.n >= kJobCap) { TRY(h8_image_multi_launch(jobs8, s), "split(kv_proj, kvq)"); jobs8.n = 0; }
-                    jobs8.job[jobs8.n++] = SplitJob{L.kv_proj_w, base, 2 * C, C, C, 1 | ((C / 64) << 8) | ((2 * C / 64) << 20)};
+                    jobs8.job[jobs8.n++] = SplitJob{L.kv_proj_w, base, 2 * C, C, C, 1 | kvq_p48 | ((C / 64) << 8) | ((2 * C / 64) << 20)};
                 }
                 if (jobs8.n >= kJobCap) { TRY(h8_image_multi_launch(jobs8, s), "split(q_proj, kvq)"); jobs8.n = 0; }
-                jobs8.job[jobs8.n++] = SplitJob{L.in_proj_w, base + kvq_image_bytes(2 * C, C, C) / sizeof(float), C, C, C, 1};
+                jobs8.job[jobs8.n++] = SplitJob{L.in_proj_w, base + kvq_image_bytes(2 * C, C, C) / sizeof(float), C, C, C, 1 | kvq_p48};
             } else if (mixed) {
                 // fp16 hi images of kv_proj | q_proj back to back (one stream for the A-stationary kernel), then their lo images
                 const size_t hkv = (size_t)(2 * C + 127) / 128 * 128 * C / 2, hq = (size_t)(C + 127) / 128 * 128 * C / 2;
@@ -743,7 +747,7 @@ int gecco_set_option(const char* name, int value) {
             g_options[i] = value < 0 ? -1 : (value != 0);   // < 0: back to the environment / default
             return 0;
         }
-    return fail(-2, "set_option: unknown option '%s' (astat, chain, headmajor, mlpfused, unpoolfused, lo8, actimg, h8, kvq64, h8areg, chain2, unpoolh8, mlpw, chaincl, h6, kvfold, mlpwshare)", name);
+    return fail(-2, "set_option: unknown option '%s' (astat, chain, headmajor, mlpfused, unpoolfused, lo8, actimg, h8, kvq64, h8areg, chain2, unpoolh8, mlpw, chaincl, h6, kvfold, mlpwshare, kvqperm)", name);
 }
 
 int gecco_linear_row_tiles(int rows) { return row_tiles_gemm(rows); }
@@ -1147,6 +1151,9 @@ int gecco_linear_kvq_f16(const float* x, const float* pro_a, const float* pro_o,
     g.B = B; g.rows = rows; g.K = K; g.Nout = Nout1 + Nout2; g.lda = K; g.ldw = K; g.ldc = Nout1; g.ldr = Nout1;
     g.precision = 2; g.w_img = img; g.c_f16 = 1; g.hm_hd = head_dim; g.lo_begin = lo_begin / 64; g.lo_tiles = lo_end / 64;
     if (C2) { g.C2 = static_cast<float*>(C2); g.bias2 = bias2; g.n_split = Nout1; g.ldc2 = Nout2; }
+    // (the two-term range must be whole 384-column segments: it is a range of TILES in the stream)
+    g.kvq_perm = option(OPT_KVQPERM) && kvq_perm48_ok(head_dim, K, Nout1, Nout2) && lo_begin % 384 == 0 && lo_end % 384 == 0;
+    const int p48 = g.kvq_perm ? 64 : 0;
     if (!gemm_kvq_astat_supported(g))
         return fail(-2, "linear_kvq: needs rows %% 128 == 0, Nout1 + Nout2 >= 128, K in {128, 256, 384, 512}; head-major: head_dim %% 8 == 0 "
                         "dividing both segment widths");
@@ -1154,8 +1161,8 @@ int gecco_linear_kvq_f16(const float* x, const float* pro_a, const float* pro_o,
         if (Nout2 > 0 && !W2) return fail(-1, "linear_kvq: W2 missing");
         SplitJobs jobs;
         jobs.n = 0;
-        jobs.job[jobs.n++] = SplitJob{W1, img, Nout1, K, K, 1 | ((lo_begin / 64) << 8) | ((lo_end / 64) << 20)};
-        if (Nout2 > 0) jobs.job[jobs.n++] = SplitJob{W2, img + kvq_image_bytes(Nout1, K, lo_end - lo_begin) / sizeof(float), Nout2, K, K, 1};
+        jobs.job[jobs.n++] = SplitJob{W1, img, Nout1, K, K, 1 | p48 | ((lo_begin / 64) << 8) | ((lo_end / 64) << 20)};
+        if (Nout2 > 0) jobs.job[jobs.n++] = SplitJob{W2, img + kvq_image_bytes(Nout1, K, lo_end - lo_begin) / sizeof(float), Nout2, K, K, 1 | p48};
         TRY(h8_image_multi_launch(jobs, s), "linear_kvq(image)");
     }
     TRY(gemm_kvq_astat_launch(g, s), "linear_kvq");

@@ -248,7 +248,14 @@ __device__ __forceinline__ void h8_image_item(const float* __restrict__ W, float
 // Stage index of tile ct: ct * NG + (NG / 2) * clamp(ct - lo_begin, 0, lo_end - lo_begin).  1024 chunks per (ct, pair of H stages
 // or L stage): item i -> (tile, stage-in-tile, sub-tile, row, physical chunk).
 // TR (the training path's dX products, one-term only): W is (K, ldw) and the stream is that of W^T — eight strided reads per chunk
-template <bool TR = false>
+// Head-aligned column order at head dim 48 (GemmArgs::kvq_perm): column n (0 .. 63) of tile t (0 .. 5) of a 384-column segment is the
+// segment's logical column 48 t + n (head t) for n < 48, else the (t % 3)-th third of head 6 + t / 3.
+__host__ __device__ __forceinline__ int kvq_perm48_col(int ct, int n) {
+    const int seg = ct / 6, t = ct - 6 * seg;
+    return 384 * seg + (n < 48 ? 48 * t + n : 48 * (6 + t / 3) + 16 * (t % 3) + (n - 48));
+}
+
+template <bool TR = false, bool P48 = false>
 __device__ __forceinline__ void kvq_image_item(const float* __restrict__ W, float* __restrict__ img, int Nout, int K, int ldw, int lo_begin,
                                                int lo_end, size_t i) {
     const int NG = K / 64;
@@ -262,7 +269,7 @@ __device__ __forceinline__ void kvq_image_item(const float* __restrict__ W, floa
     else if (st < s_lo1) { ct = lo_begin + (int)((st - s_lo0) / per_lo); kt = (int)((st - s_lo0) % per_lo); }
     else { ct = lo_end + (int)((st - s_lo1) / NG); kt = (int)((st - s_lo1) % NG); }
     const int q = pc ^ ((n >> 2) & 3);
-    const int nn = min(ct * H_BN + n, Nout - 1);
+    const int nn = P48 ? kvq_perm48_col(ct, n) : min(ct * H_BN + n, Nout - 1);
     u32x4 out;
     if (kt < NG) {
         f32x4 w0, w1;
@@ -311,6 +318,11 @@ __global__ void h8_image_multi_kernel(SplitJobs jobs) {
         if (j.pad_ & 4) {   // the stream of W^T from W (K, ldw): one-term (lb == le)
             for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
                 kvq_image_item<true>(j.W, j.img, j.Nout, j.K, j.ldw, lb, lb, i);
+            return;
+        }
+        if (j.pad_ & 64) {   // head-aligned column order (head dim 48; Nout a multiple of 384)
+            for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+                kvq_image_item<false, true>(j.W, j.img, j.Nout, j.K, j.ldw, lb, le, i);
             return;
         }
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
@@ -823,9 +835,10 @@ __global__ __launch_bounds__(64 * NW, NG > 6 ? 1 : 2) void gemm_h8_astat_kernel(
 //   3  C = (y W^T) * act'(u), u = mul_u (fp32), + the alpha-gradient partial of the block: the dX product through an activation
 //      (autograd of mlp.py's Linear -> act); mul_kind 0: C = y W^T + mul_u, a dX product added onto another gradient of the same
 //      tensor.  The u rows of the NEXT tile are loaded during the epilogue of this one.
-template <int NG, int NS, int OUT = 0>
+template <int NG, int NS, int OUT = 0, bool P48 = false>
 __global__ __launch_bounds__(256, 2) void gemm_kvq_astat_kernel(GemmArgs g) {
     constexpr int K = 64 * NG, NT = 256, NW = 4, ROWS = 128, PW = 2;
+    static_assert(!P48 || OUT == 0, "the head-aligned column order is the fp16 head-major epilogue's");
     constexpr int KV_STORES = OUT == 0 ? 4 : OUT == 1 ? 8 : OUT == 2 ? 12 : 16;   // vector-memory instructions of one epilogue
     static_assert(NS >= 4 && NG % 2 == 0 && NS - 2 <= NG, "lookahead NS - 1 >= 3 stages; L stages hold two groups; one epilogue's stores in flight");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -844,9 +857,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kvq_astat_kernel(GemmArgs g) {
     HSTAMP(0);
 
     for (int n = tid; n < g.Nout; n += NT) {
-        const bool seg2 = g.C2 != nullptr && n >= g.n_split;
+        const int nl = P48 ? kvq_perm48_col(n >> 6, n & 63) : n;   // the column tile position n computes (bias_lds is in tile order)
+        const bool seg2 = g.C2 != nullptr && nl >= g.n_split;
         const float* bp = seg2 ? g.bias2 : g.bias;
-        bias_lds[n] = bp ? bp[seg2 ? n - g.n_split : n] : 0.f;
+        bias_lds[n] = bp ? bp[seg2 ? nl - g.n_split : nl] : 0.f;
     }
     {
         const bool has_pro = g.pro_a != nullptr;
@@ -1026,6 +1040,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kvq_astat_kernel(GemmArgs g) {
         const int ldc = seg2 ? g.ldc2 : g.ldc;
         const int nseg0 = seg2 ? n0 - g.n_split : n0;
         const int nseg = seg2 ? g.Nout - g.n_split : (g.C2 ? g.n_split : g.Nout);
+        // P48: heads of this tensor before the tile's 384-column segment, the tile's place in the segment; the wave's LDS tile (idle since
+        // the prologue) takes the full head's (32 rows, 48) slab exactly as it lies in memory: row pitch 96 bytes
+        const int p_hb = P48 ? (nseg0 / 384) * 8 : 0, p_t = P48 ? (nseg0 % 384) >> 6 : 0;
+        char* p_sw = reinterpret_cast<char*>(stg + wave * 1024);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             unsigned pk[4][2];
@@ -1049,6 +1067,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kvq_astat_kernel(GemmArgs g) {
                     O[d] = sh[0];
                     O[2 + d] = sh[1];
                 }
+                if constexpr (P48) {
+                    if (2 * j + p < 3) {   // a third of the full head: into the slab image
+                        *reinterpret_cast<u32x4*>(p_sw + r * 96 + (2 * j + p) * 32 + h * 16) = O;
+                    } else {               // the stray third of head 6 + t / 3: 32-byte pieces, as before
+                        _Float16* ds = Cb + ((size_t)(b * (nseg / 48) + p_hb + 6 + p_t / 3) * g.rows + mrow) * 48 + 16 * (p_t % 3) + 8 * h;
+                        *reinterpret_cast<u32x4*>(ds) = O;
+                    }
+                    continue;
+                }
                 const int nb = nseg0 + 32 * j + 16 * p + 8 * h;   // first of this lane's 8 columns, inside its segment
                 _Float16* dst;
                 if (g.hm_hd) {
@@ -1067,6 +1094,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kvq_astat_kernel(GemmArgs g) {
 #endif
 #endif
             }
+        }
+        if constexpr (P48) {   // the slab: 3 KiB contiguous in head-major memory — three whole-wave 1 KiB stores
+            __builtin_amdgcn_wave_barrier();
+            char* slab = reinterpret_cast<char*>(Cb + ((size_t)(b * (nseg / 48) + p_hb + p_t) * g.rows + m0 + wave * 32) * 48);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(p_sw + i * 1024 + lane * 16);
+                *reinterpret_cast<u32x4*>(slab + i * 1024 + lane * 16) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     };
 
@@ -1182,15 +1219,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kvq_astat_kernel(GemmArgs g) {
     }
 }
 
-template <int NG, int NS, int OUT = 0>
+template <int NG, int NS, int OUT = 0, bool P48 = false>
 int kvq_launch_t(const GemmArgs& g, hipStream_t st) {
     const size_t lds = ((size_t)NS * H_STAGE + 4 * 1024 + g.Nout + 2 * g.K) * sizeof(float);
     static size_t attr = 0;
     if (lds > attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kvq_astat_kernel<NG, NS, OUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kvq_astat_kernel<NG, NS, OUT, P48>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = lds;
     }
-    hipLaunchKernelGGL((gemm_kvq_astat_kernel<NG, NS, OUT>), dim3(g.B * (g.rows / 128)), dim3(256), lds, st, g);
+    hipLaunchKernelGGL((gemm_kvq_astat_kernel<NG, NS, OUT, P48>), dim3(g.B * (g.rows / 128)), dim3(256), lds, st, g);
     return (int)hipGetLastError();
 }
 
@@ -1271,6 +1308,10 @@ bool gemm_h8_astat_supported(const GemmArgs& g) {
 
 // kv_proj | q_proj stream: bytes of the image of one job (Nout columns, `lo_cols` of them with L stages)
 size_t kvq_image_bytes(int Nout, int K, int lo_cols) { return ((size_t)(Nout / H_BN) * (K / 64) + (size_t)(lo_cols / H_BN) * (K / 128)) * H_STAGE * 4; }
+
+bool kvq_perm48_ok(int hm_hd, int K, int n_first, int n_second) {
+    return hm_hd == 48 && K == 384 && n_first > 0 && n_first % 384 == 0 && n_second % 384 == 0;
+}
 
 // fp16 outputs (one or two segments, row- or head-major), 128-row blocks, 64-column tiles; lo_begin / lo_tiles in 64-column tiles
 bool gemm_kvq_astat_supported(const GemmArgs& g) {
@@ -1370,7 +1411,12 @@ int gemm_kvq_astat_launch(const GemmArgs& g0, hipStream_t st) {
 #ifdef KVQ_NS
         case 384: return kvq_launch_t<6, KVQ_NS>(g, st);
 #else
-        case 384: return kvq_launch_t<6, 6>(g, st);
+        case 384:
+            if (g.kvq_perm) {
+                if (!kvq_perm48_ok(g.hm_hd, g.K, g.C2 ? g.n_split : g.Nout, g.C2 ? g.Nout - g.n_split : 0)) return -9;
+                return kvq_launch_t<6, 6, 0, true>(g, st);
+            }
+            return kvq_launch_t<6, 6>(g, st);
 #endif
         case 512: return kvq_launch_t<8, 6>(g, st);   // d = 512: 128 registers of A fragments, no scratch
         default: return -9;

@@ -60,6 +60,12 @@ struct GemmArgs {
     // dot_x (B, rows, ldc) the tensor the AdaGN normalised.  Not with residual / mul_u / pre_out.
     const float* dot_x;
     int h8_rev;                // gemm_h8_astat.hip: blocks walk the row panels last to first (the producer wrote them first to last)
+    // gemm_kvq_astat_kernel, head-major fp16 outputs at head dim 48 (feature_dim 384, 8 heads): the columns of every 384-column segment
+    // (K, V, q) are dealt to its six 64-column tiles HEAD-ALIGNED — tile t = head t's 48 columns + the (t % 3)-th 16-column third of head
+    // 6 + t / 3 — by the stream builder (SplitJob::pad_ | 64; kvq_perm48_col); a wave then owns a head's whole (32 rows, 48) slab = 3 KiB
+    // of CONTIGUOUS head-major memory per tile, written as three 1 KiB stores through its LDS tile instead of as 32-byte pieces.  A
+    // column's dot product does not depend on where in a tile it sits: the outputs are bit-identical to the plain order.
+    int kvq_perm;
     int h6;                    // gemm_h8_astat.hip (c_img == 2): the cross terms in fp6 with block scales; w_img is the h6 stream (SplitJob::pad_ 32)
     int h8_stagger, h8_pair;   // gemm_h8_astat.hip: start offset of every second block of a CU (set by its launcher)
 };
@@ -226,6 +232,8 @@ bool gemm_h8_astat_supported(const GemmArgs& g);
 // 1 | lo_begin << 8 | lo_end << 20, 64-column tiles with a second fp8 weight term); GemmArgs::lo_begin / lo_tiles in 64-column tiles
 size_t kvq_image_bytes(int Nout, int K, int lo_cols);
 bool gemm_kvq_astat_supported(const GemmArgs& g);
+// head-aligned column order (GemmArgs::kvq_perm, SplitJob::pad_ | 64): head dim 48, both segments whole multiples of 384 columns
+bool kvq_perm48_ok(int hm_hd, int K, int n_first, int n_second);
 int gemm_kvq_astat_launch(const GemmArgs& g, hipStream_t st);
 // gemm_h8_astat_kernel with fp32 outputs: the training forward in h8 arithmetic (w_img = the h8 stream)
 bool gemm_h8_train_supported(const GemmArgs& g);

@@ -132,6 +132,9 @@ int gecco_linear_f32(const float* A, const float* W, const float* bias, const fl
  *   coefficient launches: 16 -> 9 launches per layer; F_x 6e-5 -> ~1e-4 (its activations are rounded to fp16 once).
  *   "kvq64" (default 1): mixed mode runs kv_proj | q_proj on the 64-column-tile A-stationary kernel (gecco_linear_kvq_f16; needs
  *   "headmajor") instead of the 128-column-tile one (gecco_linear_astat_f16 + lo image): same arithmetic, also at feature_dim 512.
+ *   "kvqperm" (default 1): mixed mode at head dim 48 (feature_dim 384): the kvq stream deals the columns of K, V and q to the 64-column tiles
+ *   head-aligned (a tile = one head + a third of another) and gecco_linear_kvq_f16's epilogue writes a head's (32 rows, 48) slab as three
+ *   contiguous 1 KiB stores through LDS instead of as 32-byte pieces: the same bits, fewer partial cache lines.
  * value < 0 returns the option to its default / environment (GECCO_ASTAT, GECCO_CHAIN, GECCO_HEADMAJOR, GECCO_MLPFUSED,
  * GECCO_UNPOOLFUSED, GECCO_LO8, GECCO_ACTIMG, GECCO_H8, GECCO_KVQ64, GECCO_H8AREG, GECCO_CHAIN2).
  * Process-wide DEFAULT: a network forward consults its own table first (GeccoSetTransformer.opt_mask / opt_vals, ABI 14), so two

@@ -426,6 +426,25 @@ def test_w2_mode_golden_and_against_the_mixed_mode(ops, golden_dir):
         ops.set_option("mlpw", -1)
 
 
+@pytest.mark.parametrize("precision", ["w2", "mixed"])
+def test_head_aligned_kvq_tiles_are_bit_identical(ops, precision):
+    """feature_dim 384 (head dim 48): the kvq stream deals K, V and q columns to the 64-column tiles head-aligned and the projection
+    kernel writes a head's (32 rows, 48) slab as three contiguous 1 KiB stores (option "kvqperm", default on) instead of 32-byte pieces
+    — a store pattern, not an arithmetic: full and cached evaluations, outputs and inducer states, to the bit."""
+    name = "uncond_d384_L6_N128"
+    p, x, sigma = cases.uncond_inputs(name)
+    p = _cuda(p)
+    x, sigma = x.cuda(), sigma.cuda()
+    xn = x[:, :128].contiguous()
+    out = {}
+    for on in (1, 0):
+        net = ops.LinearLiftPlan(p, cases.H, cases.I, precision=precision, options={"kvqperm": on})
+        (d, r), cache = net.forward(x, sigma, return_raw=True, do_cache=True)
+        out[on] = (d, r, cache, net.forward(xn, sigma, cache=cache))
+    assert torch.equal(out[1][0], out[0][0]) and torch.equal(out[1][1], out[0][1]) and torch.equal(out[1][3], out[0][3])
+    assert all(torch.equal(a, b) for a, b in zip(out[1][2], out[0][2]))
+
+
 @pytest.mark.parametrize("precision", ["w2", "mixed", "bf16x3", "fp16"])
 def test_frozen_weights_scope_reuses_the_weight_images(ops, precision):
     """hip_ops.frozen_weights(): the evaluations of a scope share one build of the weight images per workspace

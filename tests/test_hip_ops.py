@@ -618,6 +618,15 @@ def test_linear_kvq_f16(ops, B, rows, K, hd):
     Wkv, Wq, bq = _t(rs.randn(2 * C, K) / math.sqrt(K)), _t(rs.randn(C, K) / math.sqrt(K)), _t(rs.randn(C) / math.sqrt(K))
     y16 = (x * pa[:, None] + po[:, None]).half().double()          # the kernel's A operand: one fma, one rounding
     kv, q = ops.linear_kvq_f16(x.cuda(), (pa.cuda(), po.cuda()), Wkv.cuda(), None, Wq.cuda(), bq.cuda(), lo=(C, 2 * C), head_dim=hd)
+    if hd == 48:
+        # head dim 48: the stream deals columns to the tiles head-aligned and a head's (32 rows, 48) slab leaves as three contiguous
+        # 1 KiB stores (option "kvqperm", default on) — a column's dot product does not depend on its place in a tile: same bits
+        try:
+            ops.set_option("kvqperm", 0)
+            kv0, q0 = ops.linear_kvq_f16(x.cuda(), (pa.cuda(), po.cuda()), Wkv.cuda(), None, Wq.cuda(), bq.cuda(), lo=(C, 2 * C), head_dim=hd)
+        finally:
+            ops.set_option("kvqperm", -1)
+        assert torch.equal(kv, kv0) and torch.equal(q, q0)
     if hd:
         kv = kv.permute(0, 2, 1, 3).reshape(B, rows, 2 * C)        # "b g n d -> b n (g d)"
         q = q.permute(0, 2, 1, 3).reshape(B, rows, C)

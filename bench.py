@@ -585,15 +585,26 @@ def train_bench(args, rank, world, dev):
         # is launched on (+ the ~5 us fixed-order reduction of its per-group partials)
         from gecco_amd import autograd as ga
         gg = torch.Generator().manual_seed(5)
-        dy = torch.randn(Bt, N, D, generator=gg).to(dev)
-        xh = torch.randn(Bt, N, 2 * D, generator=gg).to(dev)
+        # (round 6) the form the STEP runs at its most expensive call site — rocprofv3 of a step (profiles/r06*_train_amp_kernel_stats.csv):
+        # gemm_tn_f16_kernel<2, 2, true, false>, 18 launches per step, 12 of them at this shape — the weight gradient of a linear whose input
+        # was AdaGN(x): dY (Bt N, 2d) = the K | V (or hidden-layer) gradient, X = x (Bt N, d) with the AdaGN apply while it is staged
+        # (kv_proj, mlp.0).  Rounds 2 - 5 timed mlp.2's shape on fp32 operands, a form the step no longer runs (its hidden layer is fp16).
+        dy = torch.randn(Bt, N, 2 * D, generator=gg).to(dev)
+        xh = torch.randn(Bt, N, D, generator=gg).to(dev)
+        pro = (1.0 + 0.1 * torch.randn(Bt, D, generator=gg)).to(dev), (0.1 * torch.randn(Bt, D, generator=gg)).to(dev)
         with torch.no_grad():
-            t_dw = time_events(lambda: ga._linear_dw_main(dy, xh, want_db=True, prec="fp16" if args.amp else None), 10)
+            t_dw = time_events(lambda: ga._linear_dw_main(dy, xh, pro=pro, prec="fp16" if args.amp else None), 10)
+            h16 = torch.randn(Bt, N, 2 * D, generator=gg).to(dev).half()
+            dyo = torch.randn(Bt, N, D, generator=gg).to(dev)
+            t_dw2 = time_events(lambda: ga._linear_dw_main(dyo, h16, want_db=True, prec="fp16"), 10) if args.amp else None
         fl = 2.0 * Bt * N * D * 2 * D
         units = 1 if args.amp else 3
-        rec["dominant_kernel"] = {"kernel": ("gemm_tn_f16_kernel" if args.amp else "gemm_tn_x3_kernel") + " (dW = dY^T X of mlp.2: 2 M N K with M = Bt N rows contracted, " +
+        rec["dominant_kernel"] = {"kernel": ("gemm_tn_f16_kernel<2, 2, true, false>" if args.amp else "gemm_tn_x3_kernel (AdaGN form)") +
+                                            " (dW = dY^T AdaGN(x) of kv_proj / mlp.0: 2 M N K with M = Bt N rows contracted, " +
                                             ("fp16 operands = 1 MFMA per product" if args.amp else "split-bf16 = 3 MFMAs per product") +
                                             "; incl. the fixed-order reduction of the per-group partials)",
+                                  "launches_per_step_at_this_shape": 2 * L,
+                                  "mlp2_dw_fp16_hidden_ms": t_dw2,
                                   "ms": t_dw, "achieved_tflops": fl / (t_dw * 1e-3) / 1e12, "peak_tflops": PEAK_BF16_MFMA_TFLOPS / units,
                                   "frac": fl / (t_dw * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
                                   "frac_per_matrix_unit": units * fl / (t_dw * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, "bound": "mfma"}
@@ -601,7 +612,7 @@ def train_bench(args, rank, world, dev):
             # with one MFMA per product the kernel is bound by its operand stream, not the matrix pipe: dY and X once from HBM
             # (algorithmic), each re-read by the other operand's 3 / 6 column tiles from L2, + the per-sample partials
             by = 4.0 * Bt * N * (D + 2 * D) + 4.0 * Bt * D * 2 * D
-            l2 = 4.0 * Bt * N * (D * (2 * D // 128) + 2 * D * (D // 128))
+            l2 = 4.0 * Bt * N * (D * (2 * D // 128) + 2 * D * (D // 128))   # each operand re-read by the other's 128-column tiles
             rec["dominant_kernel"].update({"bound": "hbm", "algorithmic_bytes": by, "achieved_gbs": by / (t_dw * 1e-3) / 1e9,
                                            "peak_gbs": PEAK_HBM_GBS, "frac": by / (t_dw * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                            "frac_mfma": fl / (t_dw * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,

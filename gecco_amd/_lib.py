@@ -42,7 +42,8 @@ class GeccoLinearLift(C.Structure):
 
 
 class GeccoPyramid(C.Structure):
-    _fields_ = [("n_levels", C.c_int), ("C", C.c_int * 4), ("H", C.c_int * 4), ("W", C.c_int * 4), ("feat", c_f * 4)]
+    _fields_ = [("n_levels", C.c_int), ("C", C.c_int * 4), ("H", C.c_int * 4), ("W", C.c_int * 4), ("feat", c_f * 4),
+                ("texel_f16", C.c_int)]
 
 
 class GeccoReparam(C.Structure):
@@ -110,6 +111,9 @@ SIGNATURES = {
     "gecco_gemm_tn_f16_f32": (i, [vp, vp, vp, vp, vp, vp, i, i, i, i, i, vp]),
     "gecco_gemm_tn_f16_tiles": (i, [i, i]),
     "gecco_gemm_tn_f16_b16_f32": (i, [vp, vp, vp, vp, i, i, i, i, i, vp]),
+    "gecco_gemm_tn_f16_a16_f32": (i, [vp, vp, vp, vp, vp, vp, i, i, i, i, i, vp]),
+    "gecco_linear_dotstats_a16_f32": (i, [vp] * 5 + [i, i, i, i, vp, vp]),
+    "gecco_linear_astat16_actbwd_h16": (i, [vp] * 4 + [i, vp, vp, i, i, i, i, vp, vp]),
     "gecco_linear_dotstats_f32": (i, [vp] * 5 + [i, i, i, i, i, vp, vp]),
     "gecco_h8_image_bytes": (sz, [i, i]),
     "gecco_linear_h8_train_ok": (i, [i, i, i]),
@@ -124,6 +128,7 @@ SIGNATURES = {
     "gecco_linear_act_keep_h16": (i, [vp] * 6 + [i, vp, vp, i, i, i, i, vp, vp]),
     "gecco_set_option": (i, [C.c_char_p, i]),
     "gecco_option_index": (i, [C.c_char_p]),
+    "gecco_cast_f16": (i, [c_f, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gecco_linear_astat_f16": (i, [vp, vp, vp, vp, vp, i, vp, vp, vp, i, vp, vp, i, i, i, i, i, vp, vp]),
     "gecco_linear_kvq_f16": (i, [vp, vp, vp, vp, vp, i, vp, vp, vp, i, vp, i, i, i, i, i, i, vp, vp]),
     "gecco_linear_h8_img_f32": (i, [vp, vp, vp, vp, vp, vp, i, vp, i, i, i, i, i, vp, vp]),

@@ -226,6 +226,14 @@ def _linear_dx_dot(dy: Tensor, W: Tensor, x: Tensor, prec: str | None = None):
     lib = _lib.load()
     B, R, Nout = dy.shape
     K = W.shape[1]
+    if dy.dtype == torch.float16:   # du stored as halves (`_du16_ok` checked the shape): the fp16 kernel reads its tiles as they are
+        dx = _new(B, R, K, like=x)
+        gst = _new(B, lib.gecco_linear_row_tiles(R), 2, K, like=x)
+        img = WEIGHT_IMAGES.lookup("t", W, prec="fp16")
+        Wt, ws = (None, img) if img is not None else (W.t().contiguous(), hip_ops._ws((K + 127) // 128 * 128 * Nout * 4, dy.device))
+        _lib.check(lib.gecco_linear_dotstats_a16_f32(hip_ops._ptr16(dy), _ptr(Wt), _ptr(x), _ptr(dx), _ptr(gst), B, R, Nout, K,
+                                                     C.c_void_p(ws.data_ptr()), _stream()), "gecco_linear_dotstats_a16_f32")
+        return dx, gst
     prec = _resolve(prec, R, Nout, K)
     if (os.environ.get("GECCO_TRAIN_DOTSTATS", "1") == "0" or prec not in ("fp32", "bf16x3", "fp16")
             or not lib.gecco_linear_actbwd_ok(R, Nout, K, hip_ops.PRECISIONS[prec])):
@@ -325,6 +333,7 @@ def _linear_dw_main(dy: Tensor, x: Tensor, want_db: bool = False, pro=None, prec
     B, R, K = x.shape
     Nout = dy.shape[2]
     prec = _train_precision() if prec is None else prec
+    assert dy.dtype == torch.float32 or (prec == "fp16" and R % 32 == 0 and Nout % 8 == 0 and K % 4 == 0), "fp16 gradients exist only on the fp16 path"
     tn_ok = prec in ("bf16x3", "fp16") and R % 32 == 0 and Nout % 4 == 0 and K % 4 == 0
     if pro is not None and not tn_ok:
         x, pro = hip_ops.affine_apply(x, pro[0], pro[1]), None
@@ -341,7 +350,12 @@ def _linear_dw_main(dy: Tensor, x: Tensor, want_db: bool = False, pro=None, prec
         G = -(-B // group)
         parts = _new(G, Nout, K, like=x)
         cparts = _new(G, Nout, like=x) if want_db else None
-        if x.dtype == torch.float16:   # the fp16 hidden layer of an MLP (_keep_h16): its tiles go to LDS as they are
+        if dy.dtype == torch.float16:   # du of an MLP's backward stored as halves (`_du16_ok`)
+            assert x.dtype == torch.float32
+            _lib.check(_lib.load().gecco_gemm_tn_f16_a16_f32(hip_ops._ptr16(dy), _ptr(x), _ptr(pro[0]) if pro is not None else None,
+                                                             _ptr(pro[1]) if pro is not None else None, _ptr(parts), _ptr(cparts), B, R,
+                                                             Nout, K, group, _stream()), "gecco_gemm_tn_f16_a16_f32")
+        elif x.dtype == torch.float16:   # the fp16 hidden layer of an MLP (_keep_h16): its tiles go to LDS as they are
             assert pro is None
             _lib.check(_lib.load().gecco_gemm_tn_f16_b16_f32(_ptr(dy), hip_ops._ptr16(x), _ptr(parts), _ptr(cparts), B, R, Nout, K, group,
                                                              _stream()), "gecco_gemm_tn_f16_b16_f32")
@@ -676,7 +690,10 @@ class AdaGNMlpFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         dout = _f(dout)
         prec = ctx.prec
-        du, dalpha = _act_linear_dx(dout, u, h, alpha, W2, ctx.kind, need[11], prec)
+        # (kind 1 - 3 with every consumer of du on an fp16 kernel: du as halves)
+        du16 = (ctx.kind in (1, 2, 3) and need[0] and (need[9] or not (ctx.bias[0] and need[10]))
+                and _du16_ok(prec, x.shape[1], W2.shape[0], W2.shape[1], x.shape[2]))
+        du, dalpha = _act_linear_dx(dout, u, h, alpha, W2, ctx.kind, need[11], prec, du16=du16)
 
         def wgrads(g, act_in, has_b, iw, ib, Wl, pro=None):
             if has_b and need[ib] and need[iw]:
@@ -712,10 +729,26 @@ class GaussActFn(torch.autograd.Function):
         return du, dalpha, None
 
 
-def _act_linear_dx(dy: Tensor, u: Tensor, h: Tensor, alpha: Tensor, W: Tensor, kind: int, want_alpha: bool, prec: str | None = None):
+def _du16_ok(prec: str, R: int, Nout: int, K: int, K0: int) -> bool:
+    """Under the autocast(float16) arithmetic the gradient du = (dy W2) act'(u) of an MLP's hidden pre-activation is read again only by
+    the matrix pipe — the first linear's weight gradient and its dX product — as an fp16 operand either way (the reference's autocast
+    backward holds it as an fp16 tensor: autograd of models/mlp.py:5-39 under precision="16-mixed"): the dX product's epilogue stores it
+    as halves, half the bytes of its three crossings of HBM, and the dX product that reads it runs on fp16 tiles (2 x fewer bytes into
+    the CU per FLOP).  Same operand bits as rounding the fp32 tensor at the consumers; the bias gradient (column sums of du) is then formed
+    from the halves.  (R, Nout -> K): the product that forms du; K0: the first linear's input width.  GECCO_TRAIN_DU16=0: fp32 du."""
+    if (prec != "fp16" or os.environ.get("GECCO_TRAIN_DU16", "1") == "0" or os.environ.get("GECCO_TRAIN_ACTBWD", "1") == "0"
+            or os.environ.get("GECCO_TRAIN_DOTSTATS", "1") == "0" or not _a16_ok(prec, R, Nout, K)):
+        return False
+    lib = _lib.load()
+    return bool(K % 32 == 0 and R >= 128 and R % 32 == 0 and K0 % 4 == 0 and lib.gecco_linear_actbwd_ok(R, Nout, K, 2)
+                and lib.gecco_linear_actbwd_ok(R, K, K0, 2))
+
+
+def _act_linear_dx(dy: Tensor, u: Tensor, h: Tensor, alpha: Tensor, W: Tensor, kind: int, want_alpha: bool, prec: str | None = None,
+                   du16: bool = False):
     """du = (dy W) * act'(u) and, for GaussianActivation, d alpha: the activation's backward as the epilogue of the dX product
     (`gecco_linear_actbwd_f32`) where the LDS-DMA kernels take the shape, else the product followed by the activation's
-    backward kernel."""
+    backward kernel.  du16 (the caller checked `_du16_ok`): du leaves as an fp16 tensor."""
     lib = _lib.load()
     B, R, Nout = dy.shape
     K = W.shape[1]
@@ -724,15 +757,21 @@ def _act_linear_dx(dy: Tensor, u: Tensor, h: Tensor, alpha: Tensor, W: Tensor, k
     fused = (os.environ.get("GECCO_TRAIN_ACTBWD", "1") != "0" and prec in ("fp32", "bf16x3", "fp16")
              and lib.gecco_linear_actbwd_ok(R, Nout, K, hip_ops.PRECISIONS[prec]))
     if fused and kind in (1, 2, 3) and _a16_ok(prec, R, Nout, K):
-        du = torch.empty_like(u)
+        du = torch.empty(u.shape, device=u.device, dtype=torch.float16) if du16 else torch.empty_like(u)
         parts = _new(B * R // 128, like=u) if kind in (1, 2) else None
         ws, ready = _a16_stream("t", W, dev=u.device)
-        _lib.check(lib.gecco_linear_astat16_actbwd(_ptr(dy), None if ready else _ptr(_f(W)), _ptr(u), _ptr(alpha) if kind in (1, 2) else None, kind,
-                                                   _ptr(du), _ptr(parts), B, R, Nout, K, C.c_void_p(ws.data_ptr()), _stream()),
-                   "gecco_linear_astat16_actbwd")
+        if du16:
+            _lib.check(lib.gecco_linear_astat16_actbwd_h16(_ptr(dy), None if ready else _ptr(_f(W)), _ptr(u), _ptr(alpha) if kind in (1, 2) else None,
+                                                           kind, C.c_void_p(du.data_ptr()), _ptr(parts), B, R, Nout, K, C.c_void_p(ws.data_ptr()),
+                                                           _stream()), "gecco_linear_astat16_actbwd_h16")
+        else:
+            _lib.check(lib.gecco_linear_astat16_actbwd(_ptr(dy), None if ready else _ptr(_f(W)), _ptr(u), _ptr(alpha) if kind in (1, 2) else None, kind,
+                                                       _ptr(du), _ptr(parts), B, R, Nout, K, C.c_void_p(ws.data_ptr()), _stream()),
+                       "gecco_linear_astat16_actbwd")
         if kind in (1, 2) and want_alpha:
             dalpha = _reduce(parts, 1, B * R // 128, 1).reshape(alpha.shape)
         return du, dalpha
+    assert not du16, "_du16_ok admits only the A-stationary activation-backward kernel"
     if fused:
         du = torch.empty_like(u)
         nt = lib.gecco_linear_actbwd_tiles(B, R, K)

@@ -894,6 +894,18 @@ int gecco_linear_dotstats_f32(const float* A, const float* W, const float* dot_x
     return 0;
 }
 
+int gecco_linear_dotstats_a16_f32(const void* A16, const float* W, const float* dot_x, float* C, float* stats, int B, int rows, int K, int Nout,
+                                  void* wsplit, void* stream) {
+    if (!A16 || !dot_x || !C || !stats || !wsplit) return fail(-1, "linear_dotstats_a16: null argument");
+    if (!gecco_linear_actbwd_ok(rows, K, Nout, 2) || (K & 7) || rows < 128) return fail(-2, "linear_dotstats_a16: shape outside the fp16 LDS-DMA kernel's reach");
+    int rc = linear(static_cast<const float*>(A16), W, nullptr, nullptr, nullptr, nullptr, nullptr, C, stats, B, rows, K, Nout, 0, (hipStream_t)stream, 2,
+                    W ? static_cast<float*>(wsplit) : nullptr, W ? nullptr : static_cast<const float*>(wsplit), 1, 0, 0, 0, nullptr, 0, nullptr, nullptr,
+                    dot_x);
+    if (rc == -9) return fail(-2, "linear_dotstats_a16: shape outside the fp16 LDS-DMA kernel's reach");
+    TRY(rc, "linear_dotstats_a16");
+    return 0;
+}
+
 int gecco_linear_act_keep_f32(const float* A, const float* W, const float* bias, const float* alpha, int act, float* pre_out,
                               float* C, int B, int rows, int K, int Nout, int precision, void* wsplit, void* stream) {
     return gecco_linear_act_keep_pro_f32(A, W, bias, nullptr, nullptr, alpha, act, pre_out, C, B, rows, K, Nout, precision, wsplit, stream);
@@ -1064,6 +1076,28 @@ int gecco_linear_astat16_actbwd(const float* dy, const float* W, const float* u,
         TRY(h8_image_multi_launch(jobs, s), "linear_astat16_actbwd(image)");
     }
     TRY(gemm_astat_train_launch(g, s), "linear_astat16_actbwd");
+    return 0;
+}
+
+int gecco_linear_astat16_actbwd_h16(const float* dy, const float* W, const float* u, const float* alpha, int kind, void* C16out, float* agrad, int B,
+                                    int rows, int K, int Nout, void* wsplit, void* stream) {
+    if (!dy || !u || !C16out || !wsplit) return fail(-1, "linear_astat16_actbwd_h16: null argument");
+    if (kind < 1 || kind > 3) return fail(-2, "linear_astat16_actbwd_h16: kind 1 / 2 (GaussianActivation) or 3 (ReLU)");
+    if ((kind == 1 || kind == 2) && (!alpha || !agrad)) return fail(-1, "linear_astat16_actbwd_h16: GaussianActivation needs alpha and the agrad partials");
+    hipStream_t s = (hipStream_t)stream;
+    GemmArgs g{};
+    g.A = dy; g.alpha = alpha; g.C = static_cast<float*>(C16out); g.mul_u = u; g.mul_kind = kind; g.agrad = (kind == 1 || kind == 2) ? agrad : nullptr;
+    g.B = B; g.rows = rows; g.K = K; g.Nout = Nout; g.lda = K; g.ldw = K; g.ldc = Nout; g.ldr = Nout;
+    g.precision = 2; g.w_img = wsplit; g.c_f16 = 1;
+    if (!gemm_astat_train_supported(g))
+        return fail(-2, "linear_astat16_actbwd_h16: needs rows %% 128 == 0, K in {128, 256, 384, 512}, Nout %% 64 == 0");
+    if (W) {
+        SplitJobs jobs;
+        jobs.n = 1;
+        jobs.job[0] = SplitJob{W, static_cast<float*>(wsplit), Nout, K, Nout, 5};
+        TRY(h8_image_multi_launch(jobs, s), "linear_astat16_actbwd_h16(image)");
+    }
+    TRY(gemm_astat_train_launch(g, s), "linear_astat16_actbwd_h16");
     return 0;
 }
 
@@ -1337,6 +1371,19 @@ int gecco_gemm_tn_f16_b16_f32(const float* A, const void* B16, float* parts, flo
     return 0;
 }
 
+int gecco_gemm_tn_f16_a16_f32(const void* A16, const float* Bm, const float* pro_a, const float* pro_o, float* parts, float* colsum_parts,
+                              int Z, int R, int N, int K, int group, void* stream) {
+    if (!A16 || !Bm || !parts) return fail(-1, "gemm_tn_f16_a16: null argument");
+    if ((pro_a == nullptr) != (pro_o == nullptr)) return fail(-1, "gemm_tn_f16_a16: pro_a / pro_o must both be set");
+    TnArgs g{};
+    g.pro_a = pro_a; g.pro_o = pro_o; g.f16 = 1; g.a_f16 = 1;
+    g.A = static_cast<const float*>(A16); g.Bm = Bm; g.C = parts; g.Z = Z; g.R = R; g.N = N; g.K = K; g.lda = N; g.ldb = K;
+    g.sA = (size_t)R * N; g.sB = (size_t)R * K; g.group = group; g.colsum = colsum_parts;
+    if (!gemm_tn_f16_supported(g)) return fail(-2, "gemm_tn_f16_a16: needs R %% 32 == 0, N %% 8 == 0, K %% 4 == 0, group > 0");
+    TRY(gemm_tn_f16_launch(g, (hipStream_t)stream), "gemm_tn_f16_a16");
+    return 0;
+}
+
 int gecco_gemm_tn_f16_f32(const float* A, const float* Bm, const float* pro_a, const float* pro_o, float* parts,
                           float* colsum_parts, int Z, int R, int N, int K, int group, void* stream) {
     if (!A || !Bm || !parts) return fail(-1, "gemm_tn_f16: null argument");
@@ -1590,6 +1637,7 @@ int make_lookup_args(const GeccoReparam* rp, const GeccoPyramid* pyr, LookupArgs
         if (on && !pyr->feat[l]) return fail(-1, "lookup: null pyramid level %d", l);
         a->c_total += a->C[l];
     }
+    a->texel_f16 = pyr->texel_f16 ? 1 : 0;
     a->reparam_kind = rp ? rp->kind : 0;
     a->rp_mean = rp ? rp->mean : nullptr;
     a->rp_std = rp ? rp->std : nullptr;
@@ -1630,6 +1678,12 @@ RNWorkspace carve_rn(const GeccoRayNetwork* m, int c_total, int B, int N, void* 
 
 extern "C" {
 
+int gecco_cast_f16(const float* src, void* dst, size_t n, void* stream) {
+    if (n && (!src || !dst)) return fail(-1, "cast_f16: null argument");
+    TRY(cast_f16_launch(src, dst, n, (hipStream_t)stream), "cast_f16");
+    return 0;
+}
+
 int gecco_ray_lookup_f32(const float* geom, const float* coef, const float* K, const GeccoReparam* rp,
                          const GeccoPyramid* pyr, float* out, float* stats, int B, int N, void* stream) {
     if (!geom || !K || !out) return fail(-1, "ray_lookup: null argument");
@@ -1657,6 +1711,7 @@ int gecco_ray_lookup_bwd_f32(const float* geom, const float* coef, const float* 
     LookupArgs a;
     int rc = make_lookup_args(rp, pyr, &a);
     if (rc) return rc;
+    if (a.texel_f16) return fail(-2, "ray_lookup_bwd: fp16 texel pyramids serve the forward lookup only (pass the fp32 levels)");
     for (int l = 0; l < a.n_levels; ++l)
         if (!dfeat[l]) return fail(-1, "ray_lookup_bwd: null gradient level");
     TRY(ray_lookup_bwd_launch(geom, coef, K, a, dfeat, dout, B, N, (hipStream_t)stream), "ray_lookup_bwd");
@@ -1669,6 +1724,7 @@ int gecco_ray_lookup_dgeom_f32(const float* geom, const float* K, const GeccoRep
     LookupArgs a;
     int rc = make_lookup_args(rp, pyr, &a);
     if (rc) return rc;
+    if (a.texel_f16) return fail(-2, "ray_lookup_dgeom: fp16 texel pyramids serve the forward lookup only (pass the fp32 levels)");
     TRY(ray_lookup_dgeom_launch(geom, K, a, dout, dgeom, dK_partials, B, N, (hipStream_t)stream), "ray_lookup_dgeom");
     return 0;
 }
@@ -1685,6 +1741,7 @@ int gecco_ray_lookup_bwd_sorted_f32(const float* geom, const float* coef, const 
     LookupArgs a;
     int rc = make_lookup_args(rp, pyr, &a);
     if (rc) return rc;
+    if (a.texel_f16) return fail(-2, "ray_lookup_bwd_sorted: fp16 texel pyramids serve the forward lookup only (pass the fp32 levels)");
     for (int l = 0; l < a.n_levels; ++l)
         if (!dfeat[l]) return fail(-1, "ray_lookup_bwd_sorted: null gradient level");
     if (!ray_lookup_bwd_sorted_supported(a, N)) return fail(-2, "ray_lookup_bwd_sorted: needs N <= 4096 and H W <= 2^17 per level");

@@ -362,7 +362,19 @@ int f16_launch_t(const GemmArgs& g, hipStream_t st) {
         attr = lds;
     }
     const dim3 grid(g.B * tilesM * tilesN);
-    if (g.dot_x && (g.residual || g.mul_u || g.pre_out || !g.stats || g.C2 || A16 || C16)) return -9;
+    if (g.dot_x && (g.residual || g.mul_u || g.pre_out || !g.stats || g.C2 || C16)) return -9;
+    if constexpr (A16 && !C16) {
+        if (g.dot_x) {   // the dX product of an MLP's first linear from du stored as halves (autograd.py `_du16_ok`), with the AdaGN backward's partials
+            static size_t attr3 = 0;
+            if (lds > attr3) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<DNS, false, BM, true, false, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr3 = lds;
+            }
+            hipLaunchKernelGGL((gemm_f16_kernel<DNS, false, BM, true, false, true>), grid, dim3(DNT), lds, st, g);
+            return (int)hipGetLastError();
+        }
+    }
     if (g.mul_u || g.pre_out || g.dot_x) {   // the training path's epilogue forms: their own kernel instantiations
         // fp32 tensors, except that the KEEP form may store act(u) as fp16 (C16: the hidden layer of an MLP, which only the matrix pipe
         // reads again — as an fp16 operand either way) beside the fp32 pre-activation

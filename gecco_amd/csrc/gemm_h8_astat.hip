@@ -838,8 +838,9 @@ __global__ __launch_bounds__(64 * NW, NG > 6 ? 1 : 2) void gemm_h8_astat_kernel(
 template <int NG, int NS, int OUT = 0, bool P48 = false>
 __global__ __launch_bounds__(256, 2) void gemm_kvq_astat_kernel(GemmArgs g) {
     constexpr int K = 64 * NG, NT = 256, NW = 4, ROWS = 128, PW = 2;
-    static_assert(!P48 || OUT == 0, "the head-aligned column order is the fp16 head-major epilogue's");
-    constexpr int KV_STORES = OUT == 0 ? 4 : OUT == 1 ? 8 : OUT == 2 ? 12 : 16;   // vector-memory instructions of one epilogue
+    static_assert(!P48 || OUT == 0 || OUT == 3, "the 4th parameter: OUT 0 the head-aligned column order; OUT 3 the result stored as fp16 (C16)");
+    constexpr bool C16 = P48 && OUT == 3;   // du = (dy W) act'(u) as halves: its two consumers (the weight gradient and the next dX product) round it to fp16 anyway
+    constexpr int KV_STORES = OUT == 0 ? 4 : OUT == 1 ? 8 : OUT == 2 ? 12 : (OUT == 3 && P48) ? 12 : 16;   // vector-memory instructions of one epilogue (OUT 3: 8 u loads + 8 stores, or + 4 as halves)
     static_assert(NS >= 4 && NG % 2 == 0 && NS - 2 <= NG, "lookahead NS - 1 >= 3 stages; L stages hold two groups; one epilogue's stores in flight");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* ring = smem;                                // [NS][H_STAGE]
@@ -857,7 +858,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kvq_astat_kernel(GemmArgs g) {
     HSTAMP(0);
 
     for (int n = tid; n < g.Nout; n += NT) {
-        const int nl = P48 ? kvq_perm48_col(n >> 6, n & 63) : n;   // the column tile position n computes (bias_lds is in tile order)
+        const int nl = (P48 && OUT == 0) ? kvq_perm48_col(n >> 6, n & 63) : n;   // the column tile position n computes (bias_lds is in tile order)
         const bool seg2 = g.C2 != nullptr && nl >= g.n_split;
         const float* bp = seg2 ? g.bias2 : g.bias;
         bias_lds[n] = bp ? bp[seg2 ? nl - g.n_split : nl] : 0.f;
@@ -976,6 +977,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kvq_astat_kernel(GemmArgs g) {
             const int ns0 = s2 ? n0 - g.n_split : n0;
             float* dstf = (OUT == 2 ? g.pre_out : Cf) + ((size_t)b * g.rows + mrow) * (OUT == 2 ? g.Nout : ldcf) + (OUT == 2 ? n0 : ns0) + 4 * h;
             f32x4 v[OUT == 2 ? 8 : 1];
+            f32x4 w16[C16 ? 4 : 1];   // C16: the four quads of a 32-column block, packed and stored as halves after the block
             // one accumulator quad at a time (bias, the activation's derivative, store): the scheduler would otherwise put all 32
             // exponentials of the tile in flight at once, ~100 registers the stationary operand does not leave
 #pragma unroll
@@ -1000,9 +1002,35 @@ __global__ __launch_bounds__(256, 2) void gemm_kvq_astat_kernel(GemmArgs g) {
                             }
                         }
                     }
-                    *reinterpret_cast<f32x4*>(dstf + 32 * j + 8 * q) = w;
+                    if constexpr (C16) w16[q] = w;
+                    else *reinterpret_cast<f32x4*>(dstf + 32 * j + 8 * q) = w;
                     if constexpr (OUT == 2) v[4 * j + q] = w;
                     if constexpr (OUT == 3) __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (C16) {
+                        if (q == 3) {   // (unrolled: q is a constant) the fp16 epilogue's exchange: 8 consecutive columns per lane, 16-byte stores
+                            unsigned pk[4][2];
+#pragma unroll
+                            for (int qq = 0; qq < 4; ++qq) {
+                                f16x2 a2, c2;
+                                a2[0] = (_Float16)w16[qq][0]; a2[1] = (_Float16)w16[qq][1];
+                                c2[0] = (_Float16)w16[qq][2]; c2[1] = (_Float16)w16[qq][3];
+                                pk[qq][0] = __builtin_bit_cast(unsigned, a2);
+                                pk[qq][1] = __builtin_bit_cast(unsigned, c2);
+                            }
+                            _Float16* Hd = reinterpret_cast<_Float16*>(g.C) + ((size_t)b * g.rows + mrow) * g.ldc + n0 + 32 * j + 8 * h;
+#pragma unroll
+                            for (int pp = 0; pp < 2; ++pp) {
+                                u32x4 O;
+#pragma unroll
+                                for (int d = 0; d < 2; ++d) {
+                                    const auto sh = __builtin_amdgcn_permlane32_swap(pk[2 * pp][d], pk[2 * pp + 1][d], false, false);
+                                    O[d] = sh[0];
+                                    O[2 + d] = sh[1];
+                                }
+                                *reinterpret_cast<u32x4*>(Hd + 16 * pp) = O;
+                            }
+                        }
+                    }
                 }
             if constexpr (OUT == 3) load_u(ct + 1);
             if constexpr (OUT == 2) {   // act(u) as halves: the fp16 epilogue's exchange (8 consecutive columns per lane, 16-byte stores)
@@ -1371,7 +1399,8 @@ int gemm_h8_train_launch(const GemmArgs& g0, hipStream_t st) {
 bool gemm_astat_train_supported(const GemmArgs& g) {
     const bool keep = g.pre_out != nullptr, abw = g.mul_u != nullptr;
     if (keep && abw) return false;
-    return !g.c_f16 && !g.a_f16 && !g.a_img && !g.c_img && !g.residual && !g.stats && g.w_img && g.rows >= 128 && !(g.rows % 128) && !(g.Nout % H_BN) &&
+    if (g.c_f16 && !(abw && g.mul_kind >= 1 && !(g.ldc & 7))) return false;   // fp16 result: the activation-backward form only
+    return !g.a_f16 && !g.a_img && !g.c_img && !g.residual && !g.stats && g.w_img && g.rows >= 128 && !(g.rows % 128) && !(g.Nout % H_BN) &&
            g.Nout >= 2 * H_BN && g.Nout <= 4096 && (g.K == 128 || g.K == 256 || g.K == 384 || g.K == 512) && !(g.lda & 3) && !(g.ldc & 3) &&
            (!g.C2 || (!keep && !abw && !(g.n_split % H_BN) && !(g.ldc2 & 3) && g.n_split > 0 && g.n_split < g.Nout)) &&
            ((g.pro_a == nullptr) == (g.pro_o == nullptr)) && g.lo_begin == 0 && g.lo_tiles == 0 && !g.hm_hd &&
@@ -1380,13 +1409,13 @@ bool gemm_astat_train_supported(const GemmArgs& g) {
            (!((keep && act_gauss_host(g.act)) || (abw && act_gauss_host(g.mul_kind))) || g.alpha);
 }
 
-template <int OUT>
+template <int OUT, bool VAR = false>
 int astat_train_launch_o(const GemmArgs& g, hipStream_t st) {
     switch (g.K) {
-        case 128: return kvq_launch_t<2, 4, OUT>(g, st);
-        case 256: return kvq_launch_t<4, 6, OUT>(g, st);
-        case 384: return kvq_launch_t<6, 6, OUT>(g, st);
-        case 512: return kvq_launch_t<8, 6, OUT>(g, st);
+        case 128: return kvq_launch_t<2, 4, OUT, VAR>(g, st);
+        case 256: return kvq_launch_t<4, 6, OUT, VAR>(g, st);
+        case 384: return kvq_launch_t<6, 6, OUT, VAR>(g, st);
+        case 512: return kvq_launch_t<8, 6, OUT, VAR>(g, st);
         default: return -9;
     }
 }
@@ -1396,7 +1425,7 @@ int gemm_astat_train_launch(const GemmArgs& g0, hipStream_t st) {
     GemmArgs g = g0;
     g.h8_rev = 0;
     if (g.pre_out) return astat_train_launch_o<2>(g, st);
-    if (g.mul_u) return astat_train_launch_o<3>(g, st);
+    if (g.mul_u) return g.c_f16 ? astat_train_launch_o<3, true>(g, st) : astat_train_launch_o<3>(g, st);
     return astat_train_launch_o<1>(g, st);
 }
 

@@ -47,12 +47,14 @@ __device__ __forceinline__ int toff(int row, int col) {
 }
 
 // WNT x WKT: 32 x 32 accumulator tiles per wave (2 x 2 waves): block tile 64 WNT x 64 WKT.  PRO: AdaGN apply on B.  B16: fp16 B tensor.
-template <int WNT, int WKT, bool PRO, bool B16>
+// A16: fp16 A tensor (TnArgs::a_f16): half the loads, no conversion; the bias gradient's column sums are formed from the halves.
+template <int WNT, int WKT, bool PRO, bool B16, bool A16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_tn_f16_kernel(TnArgs g) {
     static_assert(!(PRO && B16), "the AdaGN apply reads the fp32 operand");
     constexpr int TN = 64 * WNT, TK = 64 * WKT, NCA = TN / 32, NCB = TK / 32;
     constexpr int PA = 32 * TN, PB = 32 * TK;                 // u16 per plane
     constexpr int LA = TN / 32, LB = TK / 32, LB8 = TK / 64;  // 16-byte loads per thread and slab: A, B (fp32), B (fp16: 8 halves each)
+    constexpr int LA8 = TN / 64;                              // A (fp16)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     u16* lds = reinterpret_cast<u16*>(smem);                  // [2 stages][A | B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -65,20 +67,20 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f16_kernel(TnArgs g) {
     const int bx = vb % ntile, by = vb / ntile;
     const int n0 = (bx / tilesK) * TN, k0 = (bx % tilesK) * TK;
     // a thread's columns are the same in every slab: one predicate per operand zero-fills what lies beyond the matrix
-    const int ca = tid % (TN / 4), cb = B16 ? tid % (TK / 8) : tid % (TK / 4);
-    const bool aok = n0 + ca * 4 < g.N, bok = k0 + cb * (B16 ? 8 : 4) < g.K;
+    const int ca = A16 ? tid % (TN / 8) : tid % (TN / 4), cb = B16 ? tid % (TK / 8) : tid % (TK / 4);
+    const bool aok = n0 + ca * (A16 ? 8 : 4) < g.N, bok = k0 + cb * (B16 ? 8 : 4) < g.K;
     const int z0 = by * g.group, z1 = min(g.Z, z0 + g.group);
     const int msteps = g.R / 32, nsteps = (z1 - z0) * msteps;
 
     // slab loads as raw buffer loads: ONE per-lane byte offset per operand (out-of-range for the lanes beyond the matrix: they read
     // zeros) and scalar offsets for the sample / slab / row group — with per-load 64-bit addresses the 12 loads of a wide tile cost
     // 24 address registers next to 128 accumulator and 48 staging registers, and the kernel spilled
-    f32x4 ra[LA], rb[B16 ? 1 : LB];
-    u32x4 rb8[B16 ? LB8 : 1];
+    f32x4 ra[A16 ? 1 : LA], rb[B16 ? 1 : LB];
+    u32x4 rb8[B16 ? LB8 : 1], ra8[A16 ? LA8 : 1];
     // PRO: the AdaGN coefficients of the block's K columns live in LDS ([2 sample parities][pa | po][TK]) and are read at the
     // store — as registers (8 per thread, live across the matrix phase) they were what made the wide tiles spill
     float* ptab = smem + (size_t)2 * (PA + PB) / 2;
-    const unsigned va = aok ? (unsigned)(((tid / (TN / 4)) * g.lda + ca * 4) * 4) : 0x7fffffffu;
+    const unsigned va = !aok ? 0x7fffffffu : A16 ? (unsigned)(((tid / (TN / 8)) * g.lda + ca * 8) * 2) : (unsigned)(((tid / (TN / 4)) * g.lda + ca * 4) * 4);
     const unsigned vbo = !bok ? 0x7fffffffu : B16 ? (unsigned)(((tid / (TK / 8)) * g.ldb + cb * 8) * 2) : (unsigned)(((tid / (TK / 4)) * g.ldb + cb * 4) * 4);
     auto load = [&](int s) {
         const int z = z0 + s / msteps, m0 = (s % msteps) * 32;
@@ -88,11 +90,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f16_kernel(TnArgs g) {
             reinterpret_cast<f32x4*>(t)[tid] = ok ? *reinterpret_cast<const f32x4*>(g.pro_a + (size_t)z * g.K + k0 + tid * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
             reinterpret_cast<f32x4*>(t + TK)[tid] = ok ? *reinterpret_cast<const f32x4*>(g.pro_o + (size_t)z * g.K + k0 + tid * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A + (size_t)z * g.sA), 0, 0x7fffffff, 0x00020000);
-        const unsigned sa0 = (unsigned)((m0 * g.lda + n0) * 4);
+        if (A16) {
+            const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<_Float16*>(reinterpret_cast<const _Float16*>(g.A) + (size_t)z * g.sA), 0, 0x7fffffff, 0x00020000);
+            const unsigned sa0 = (unsigned)((m0 * g.lda + n0) * 2);
 #pragma unroll
-        for (int i = 0; i < LA; ++i)
-            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, va, sa0 + (unsigned)(i * (1024 / TN) * g.lda * 4), 0));
+            for (int i = 0; i < LA8; ++i) ra8[i] = __builtin_amdgcn_raw_buffer_load_b128(ars, va, sa0 + (unsigned)(i * (2048 / TN) * g.lda * 2), 0);
+        } else {
+            const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A + (size_t)z * g.sA), 0, 0x7fffffff, 0x00020000);
+            const unsigned sa0 = (unsigned)((m0 * g.lda + n0) * 4);
+#pragma unroll
+            for (int i = 0; i < LA; ++i)
+                ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, va, sa0 + (unsigned)(i * (1024 / TN) * g.lda * 4), 0));
+        }
         if (B16) {
             const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<_Float16*>(reinterpret_cast<const _Float16*>(g.Bm) + (size_t)z * g.sB), 0, 0x7fffffff, 0x00020000);
@@ -109,11 +119,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f16_kernel(TnArgs g) {
     };
     // bias gradient = column sums of dY: the blocks of the first K tile add up the rows they stage anyway
     const bool want_cs = g.colsum != nullptr && k0 == 0;
-    f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f}, cs2 = {0.f, 0.f, 0.f, 0.f};   // (A16: a thread's 8 columns)
     // LDS offsets of a thread's pieces: rows row0 + i RPI with RPI a multiple of 4 — whole 4-row groups apart, the same slot: base + constant
-    constexpr int RA = 1024 / TN, RB = B16 ? 2048 / TK : 1024 / TK;
+    constexpr int RA = A16 ? 2048 / TN : 1024 / TN, RB = B16 ? 2048 / TK : 1024 / TK;
     static_assert(RA % 4 == 0 && RB % 4 == 0, "pieces of a thread lie whole row groups apart");
-    const int oa = toff<NCA>(tid / (TN / 4), ca * 4);
+    const int oa = A16 ? toff<NCA>(tid / (TN / 8), ca * 8) : toff<NCA>(tid / (TN / 4), ca * 4);
     const int ob = B16 ? toff<NCB>(tid / (TK / 8), cb * 8) : toff<NCB>(tid / (TK / 4), cb * 4);
     auto store = [&](int stage, int s) {
         u16* sa = lds + stage * (PA + PB) + oa;
@@ -124,10 +134,25 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f16_kernel(TnArgs g) {
             pa4 = reinterpret_cast<const f32x4*>(t)[cb];
             po4 = reinterpret_cast<const f32x4*>(t + TK)[cb];
         }
+        if (A16) {
 #pragma unroll
-        for (int i = 0; i < LA; ++i) {
-            if (want_cs) cs += ra[i];
-            *reinterpret_cast<u32x2*>(sa + i * (RA / 4) * NCA * 128) = cvt4(ra[i]);
+            for (int i = 0; i < LA8; ++i) {
+                if (want_cs) {
+                    const f16x8 hv = __builtin_bit_cast(f16x8, ra8[i]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        cs[e] += (float)hv[e];
+                        cs2[e] += (float)hv[4 + e];
+                    }
+                }
+                *reinterpret_cast<u32x4*>(sa + i * (RA / 4) * NCA * 128) = ra8[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < LA; ++i) {
+                if (want_cs) cs += ra[i];
+                *reinterpret_cast<u32x2*>(sa + i * (RA / 4) * NCA * 128) = cvt4(ra[i]);
+            }
         }
         if (B16) {
 #pragma unroll
@@ -216,12 +241,24 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f16_kernel(TnArgs g) {
         }
     }
     if (want_cs) {   // (block-uniform) the threads of a column group, summed in thread order
-        constexpr int NGRP = TN / 4, PER = 256 / NGRP;
+        constexpr int NGRP = A16 ? TN / 8 : TN / 4, PER = 256 / NGRP;
         __syncthreads();
         f32x4* red = reinterpret_cast<f32x4*>(smem);
-        red[tid] = cs;
+        if (A16) {
+            red[2 * tid] = cs;
+            red[2 * tid + 1] = cs2;
+        } else {
+            red[tid] = cs;
+        }
         __syncthreads();
-        if (tid < NGRP && n0 + tid * 4 < g.N) {
+        if (A16) {
+            if (tid < 2 * NGRP && n0 + tid * 4 < g.N) {   // thread t: columns 4 t .. 4 t + 3 = half (t & 1) of column group t >> 1
+                f32x4 sum = red[tid];
+#pragma unroll
+                for (int j = 1; j < PER; ++j) sum += red[tid + 2 * NGRP * j];
+                *reinterpret_cast<f32x4*>(g.colsum + (size_t)by * g.N + n0 + tid * 4) = sum;
+            }
+        } else if (tid < NGRP && n0 + tid * 4 < g.N) {
             f32x4 sum = red[tid];
 #pragma unroll
             for (int j = 1; j < PER; ++j) sum += red[tid + NGRP * j];
@@ -246,7 +283,11 @@ int tn_f16_launch_t(const TnArgs& g, hipStream_t st) {
     const int G = (g.Z + g.group - 1) / g.group;
     const size_t lds = (size_t)2 * 32 * (TN + TK) * 2 + (g.pro_a ? (size_t)4 * TK * sizeof(float) : 0);   // 32 - 52 KiB: no attribute needed
     const dim3 grid(((g.N + TN - 1) / TN) * ((g.K + TK - 1) / TK), G);
-    if (g.b_f16) hipLaunchKernelGGL((gemm_tn_f16_kernel<WNT, WKT, false, true>), grid, dim3(256), lds, st, g);
+    if (g.a_f16) {   // the MLP backward's du as halves: with the AdaGN apply on x (mlp.0), or plain
+        if (g.b_f16) return -9;
+        if (g.pro_a) hipLaunchKernelGGL((gemm_tn_f16_kernel<WNT, WKT, true, false, true>), grid, dim3(256), lds, st, g);
+        else hipLaunchKernelGGL((gemm_tn_f16_kernel<WNT, WKT, false, false, true>), grid, dim3(256), lds, st, g);
+    } else if (g.b_f16) hipLaunchKernelGGL((gemm_tn_f16_kernel<WNT, WKT, false, true>), grid, dim3(256), lds, st, g);
     else if (g.pro_a) hipLaunchKernelGGL((gemm_tn_f16_kernel<WNT, WKT, true, false>), grid, dim3(256), lds, st, g);
     else hipLaunchKernelGGL((gemm_tn_f16_kernel<WNT, WKT, false, false>), grid, dim3(256), lds, st, g);
     return (int)hipGetLastError();
@@ -275,7 +316,8 @@ int tn_f16_shape(int N, int K) {
 bool gemm_tn_f16_supported(const TnArgs& g) {
     // one sample's rows are addressed with 31-bit byte offsets (buffer loads)
     return g.Z > 0 && g.group > 0 && g.R >= 32 && g.R % 32 == 0 && g.N > 0 && g.K > 0 && !(g.N & 3) && !(g.K & 3) && !(g.lda & 3) &&
-           !(g.ldb & 3) && (!g.b_f16 || (!g.pro_a && !(g.K & 7) && !(g.ldb & 7))) && (size_t)g.R * g.lda * 4 < 0x7fffffffu &&
+           !(g.ldb & 3) && (!g.b_f16 || (!g.pro_a && !(g.K & 7) && !(g.ldb & 7))) && (!g.a_f16 || (!g.b_f16 && !(g.N & 7) && !(g.lda & 7))) &&
+           (size_t)g.R * g.lda * 4 < 0x7fffffffu &&
            (size_t)g.R * g.ldb * 4 < 0x7fffffffu;
 }
 

@@ -206,6 +206,7 @@ struct TnArgs {
     const float* pro_o;
     int f16;           // 1: both operands rounded to fp16, one MFMA per product (the reference's autocast(float16) trainer arithmetic)
     int b_f16;         // (with f16) Bm is an fp16 tensor already: its tiles go to LDS as they are
+    int a_f16;         // (with f16) A is an fp16 tensor already (the MLP backward's du, stored as halves by the dX product's epilogue)
 };
 // gemm_tn_f16.hip: the same product with fp16 operands (TnArgs::f16 / b_f16), block tile chosen per shape
 bool gemm_tn_f16_supported(const TnArgs& g);
@@ -320,12 +321,14 @@ struct LookupArgs {
     int n_levels, c_total;
     int C[4], H[4], W[4];
     const float* feat[4];  // channels-last (B, H, W, C) per level
+    int texel_f16;         // the levels hold fp16 texels (forward lookups only)
     int reparam_kind;      // 0 none, 1 gaussian (mean, sigma), 2 UVL (uvl_mean, uvl_std, logit_scale)
     const float* rp_mean;
     const float* rp_std;
     float logit_scale;
 };
 int lookup_row_tile();
+int cast_f16_launch(const float* src, void* dst, size_t n, hipStream_t st);
 int ray_lookup_launch(const float* geom, const float* coef, const float* K, const LookupArgs& a, float* out,
                       float* stats, int B, int N, hipStream_t st);
 int ray_lookup_taps_launch(const float* geom, const float* coef, const float* K, const LookupArgs& a, float* uv, int* x0, int* y0, float* wx1,

@@ -9,6 +9,8 @@
 // tap as whole 128-byte lines (the reference's NCHW layout would make every channel a separate
 // 4-byte gather).  One wave handles one point at a time; lanes run over 16-byte channel chunks.
 #include "common.h"
+
+#include <algorithm>
 #include "kernels.h"
 
 #pragma clang fp contract(off)  // index math must round like the reference's separate fp32 ops
@@ -64,6 +66,20 @@ __device__ __forceinline__ void project_uv(float g0, float g1, float g2, const f
     v = sc * Y * fy + cy;
 }
 
+// TEX16: the pyramid levels hold fp16 texels (GeccoPyramid::texel_f16): 8-byte gathers instead of 16-byte ones; converted on arrival, the
+// interpolation itself is the fp32 expression below either way
+template <bool TEX16>
+__device__ __forceinline__ f32x4 texel4(const float* fb, size_t off) {
+    if constexpr (TEX16) {
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        const f16x4 v = *reinterpret_cast<const f16x4*>(reinterpret_cast<const _Float16*>(fb) + off);
+        return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    } else {
+        return *reinterpret_cast<const f32x4*>(fb + off);
+    }
+}
+
+template <bool TEX16>
 __global__ __launch_bounds__(256) void ray_lookup_kernel(const float* __restrict__ geom,
                                                          const float* __restrict__ coef,
                                                          const float* __restrict__ K, LookupArgs a,
@@ -117,7 +133,8 @@ __global__ __launch_bounds__(256) void ray_lookup_kernel(const float* __restrict
             for (int q = 1; q < 4; ++q)
                 if (l == q) t = tp[q];
             const int Hh = a.H[l], Ww = a.W[l], Cl = a.C[l];
-            const float* fb = a.feat[l] + (size_t)b * Hh * Ww * Cl + coff[c];
+            const float* fb = a.feat[l];                                      // (TEX16: a pointer to halves; offsets in elements)
+            const size_t fo = (size_t)b * Hh * Ww * Cl + coff[c];
             const int x1 = t.x0 + 1, y1 = t.y0 + 1;
             // torch's weights: nw = (x1 - ix)(y1 - iy), ne = (ix - x0)(y1 - iy), sw = (x1 - ix)(iy - y0), se = ...
             const float wx0 = (float)x1 - t.ix, wy0 = (float)y1 - t.iy;
@@ -126,10 +143,10 @@ __global__ __launch_bounds__(256) void ray_lookup_kernel(const float* __restrict
             const bool by0 = t.y0 >= 0 && t.y0 <= Hh - 1, by1 = y1 >= 0 && y1 <= Hh - 1;
             const int cx0 = min(max(t.x0, 0), Ww - 1), cx1 = min(max(x1, 0), Ww - 1);
             const int cy0 = min(max(t.y0, 0), Hh - 1), cy1 = min(max(y1, 0), Hh - 1);
-            const f32x4 nw = *reinterpret_cast<const f32x4*>(fb + ((size_t)cy0 * Ww + cx0) * Cl);
-            const f32x4 ne = *reinterpret_cast<const f32x4*>(fb + ((size_t)cy0 * Ww + cx1) * Cl);
-            const f32x4 sw = *reinterpret_cast<const f32x4*>(fb + ((size_t)cy1 * Ww + cx0) * Cl);
-            const f32x4 se = *reinterpret_cast<const f32x4*>(fb + ((size_t)cy1 * Ww + cx1) * Cl);
+            const f32x4 nw = texel4<TEX16>(fb, fo + ((size_t)cy0 * Ww + cx0) * Cl);
+            const f32x4 ne = texel4<TEX16>(fb, fo + ((size_t)cy0 * Ww + cx1) * Cl);
+            const f32x4 sw = texel4<TEX16>(fb, fo + ((size_t)cy1 * Ww + cx0) * Cl);
+            const f32x4 se = texel4<TEX16>(fb, fo + ((size_t)cy1 * Ww + cx1) * Cl);
             const float w_nw = (bx0 && by0) ? wx0 * wy0 : 0.f, w_ne = (bx1 && by0) ? wx1 * wy0 : 0.f;
             const float w_sw = (bx0 && by1) ? wx0 * wy1 : 0.f, w_se = (bx1 && by1) ? wx1 * wy1 : 0.f;
             const f32x4 r = nw * w_nw + ne * w_ne + sw * w_sw + se * w_se;
@@ -585,7 +602,27 @@ int ray_lookup_launch(const float* geom, const float* coef, const float* K, cons
     }
     if (tot != a.c_total) return -8;
     const int T = (N + LOOKUP_ROWS - 1) / LOOKUP_ROWS;
-    hipLaunchKernelGGL(ray_lookup_kernel, dim3(B * T), dim3(256), 0, st, geom, coef, K, a, out, stats, N, T);
+    if (a.texel_f16) hipLaunchKernelGGL(ray_lookup_kernel<true>, dim3(B * T), dim3(256), 0, st, geom, coef, K, a, out, stats, N, T);
+    else hipLaunchKernelGGL(ray_lookup_kernel<false>, dim3(B * T), dim3(256), 0, st, geom, coef, K, a, out, stats, N, T);
+    return (int)hipGetLastError();
+}
+
+namespace {
+__global__ void cast_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, size_t n4, size_t n) {
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(src)[i];
+        reinterpret_cast<f16x4*>(dst)[i] = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[(n & ~size_t(3)) + threadIdx.x] = (_Float16)src[(n & ~size_t(3)) + threadIdx.x];
+}
+}  // namespace
+
+int cast_f16_launch(const float* src, void* dst, size_t n, hipStream_t st) {
+    if (!n) return 0;
+    const size_t n4 = n / 4;
+    const unsigned blocks = (unsigned)std::min<size_t>((n4 + 255) / 256 + 1, 4096);
+    hipLaunchKernelGGL(cast_f16_kernel, dim3(blocks), dim3(256), 0, st, src, static_cast<_Float16*>(dst), n4, n);
     return (int)hipGetLastError();
 }
 

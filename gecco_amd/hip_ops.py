@@ -868,18 +868,35 @@ def to_channels_last_levels(features: Sequence[Tensor]) -> list[Tensor]:
 
 
 def make_pyramid(levels_nhwc: Sequence[Tensor]) -> _lib.GeccoPyramid:
+    """Channels-last (B, H, W, C) levels, all fp32 — or all fp16 (`half_levels`: the forward lookup's texel image)."""
     n = len(levels_nhwc)
     if not 1 <= n <= 4:
         raise _lib.GeccoHipError("1..4 pyramid levels supported")
     pyr = _lib.GeccoPyramid()
     pyr.n_levels = n
+    dt = levels_nhwc[0].dtype
     for l, f in enumerate(levels_nhwc):
         assert f.is_contiguous() or f.permute(0, 3, 1, 2).is_contiguous(memory_format=torch.channels_last)
         pyr.C[l], pyr.H[l], pyr.W[l] = f.shape[3], f.shape[1], f.shape[2]
-        if not f.is_cuda or f.dtype != torch.float32:
-            raise _lib.GeccoHipError("pyramid levels must be fp32 HIP tensors")
+        if not f.is_cuda or f.dtype != dt or dt not in (torch.float32, torch.float16):
+            raise _lib.GeccoHipError("pyramid levels must be HIP tensors, all fp32 or all fp16")
         pyr.feat[l] = f.data_ptr()
+    pyr.texel_f16 = int(dt == torch.float16)
     return pyr
+
+
+def half_levels(levels_nhwc: Sequence[Tensor]) -> list[Tensor]:
+    """fp16 copies of channels-last fp32 levels (gecco_cast_f16): the texel image the "w2" forward lookup gathers — half the bytes;
+    made once per conditioner call (`RayNetworkPlan.forward` keeps them while the fp32 levels are the same tensors, unchanged)."""
+    lib = _lib.load()
+    out = []
+    for f in levels_nhwc:
+        if f.dtype != torch.float32 or not f.is_cuda or not f.is_contiguous():
+            raise _lib.GeccoHipError("half_levels: contiguous fp32 HIP levels expected")
+        h = torch.empty(f.shape, dtype=torch.float16, device=f.device)
+        check(lib.gecco_cast_f16(_ptr(f), C.c_void_p(h.data_ptr()), f.numel(), _stream()), "gecco_cast_f16")
+        out.append(h)
+    return out
 
 
 def make_reparam(kind: int, mean: Tensor | None = None, std: Tensor | None = None, logit_scale: float = 1.1):
@@ -950,11 +967,27 @@ class RayNetworkPlan:
             make_reparam(reparam_kind, rp_mean, rp_std, logit_scale), sigma_data)
         self._ws: dict[tuple, Tensor] = {}
         self.images = self.st.images
+        self._tex16: tuple | None = None   # (signature of the fp32 levels, their fp16 texel images)
 
     def set_option(self, name: str, value: int) -> None:
         """Pin a path switch for THIS plan (0 / 1; negative: follow the process-wide default again)."""
         _pin_option(self.table.backbone, name, value)
         self.st.set_option(name, value)
+
+    def _lookup_levels(self, levels_nhwc: Sequence[Tensor]) -> Sequence[Tensor]:
+        """The levels the forward lookup gathers: in the "w2" mode the fp16 texel image of the pyramid (half the gathered bytes: the
+        lookup sits at the Infinity-Cache gather ceiling on fp32 texels; coordinates, taps and weights stay fp32 and bit-exact) — cast
+        once per conditioner call and kept while the fp32 levels are the same, unchanged tensors.  Every other mode, fp16 inputs,
+        non-contiguous (re-viewed channels_last) levels and GECCO_LOOKUP16=0 gather the fp32 texels."""
+        if (self.st.precision != "w2" or os.environ.get("GECCO_LOOKUP16", "1") == "0"
+                or any(f.dtype != torch.float32 or not f.is_contiguous() for f in levels_nhwc)):
+            return levels_nhwc
+        sig = tuple((f.data_ptr(), f._version, tuple(f.shape)) for f in levels_nhwc)
+        if self._tex16 is None or self._tex16[0] != sig:
+            if torch.cuda.is_current_stream_capturing():
+                return levels_nhwc   # (no allocation / stale-able cache inside a capture: the warm-up call makes the image)
+            self._tex16 = (sig, half_levels(levels_nhwc), list(levels_nhwc))   # (the fp32 levels kept alive: a freed pointer could be re-used)
+        return self._tex16[1]
 
     def forward(self, x: Tensor, sigma: Tensor, K: Tensor, levels_nhwc: Sequence[Tensor], return_raw: bool = False,
                 cache: Sequence[Tensor] | None = None, do_cache: bool = False, out: Tensor | None = None):
@@ -963,6 +996,8 @@ class RayNetworkPlan:
         raw = torch.empty_like(x) if return_raw else None
         L = self.st.L
         h_out = [torch.empty(B, self.st.I, self.st.C, device=x.device, dtype=torch.float32) for _ in range(L)] if do_cache else None
+
+        levels_nhwc = self._lookup_levels(levels_nhwc)
 
         def call(lo, hi, idx):
             lv = [f[lo:hi] for f in levels_nhwc]               # a sample's pyramid: its slice of every level

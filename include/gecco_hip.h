@@ -190,6 +190,10 @@ int gecco_linear_actbwd_f32(const float* A, const float* W, const float* u, cons
  * models/normalization.py:36-44 behind a linear: set_transformer.py:165-166).  Shapes: gecco_linear_actbwd_ok; W == NULL: image ready. */
 int gecco_linear_dotstats_f32(const float* A, const float* W, const float* dot_x, float* C, float* stats, int B, int rows, int K, int Nout,
                               int precision, void* wsplit, void* stream);
+/* The same from an fp16 A tensor (the du of gecco_linear_astat16_actbwd_h16), fp16 arithmetic: C = A16 W^T (fp32) + the {sum C, sum C x}
+ * partials.  rows >= 128, K % 32 == 0.  W == NULL: wsplit holds the ready fp16 image. */
+int gecco_linear_dotstats_a16_f32(const void* A16, const float* W, const float* dot_x, float* C, float* stats, int B, int rows, int K, int Nout,
+                                  void* wsplit, void* stream);
 /* Its forward companion: C = act(A W^T + bias) AND pre_out = A W^T + bias (the u the backward needs) from one epilogue — the
  * training forward of Linear -> act without a separate activation pass.  act 1 / 2 / 3 / 4 as above; W == NULL: image ready. */
 int gecco_linear_act_keep_f32(const float* A, const float* W, const float* bias, const float* alpha, int act, float* pre_out,
@@ -245,6 +249,12 @@ int gecco_linear_astat16_keep(const float* x, const float* pro_a, const float* p
                               int act, float* pre_out, void* C16out, int B, int rows, int K, int Nout, void* wsplit, void* stream);
 int gecco_linear_astat16_actbwd(const float* dy, const float* W, const float* u, const float* alpha, int kind, float* C, float* agrad, int B,
                                 int rows, int K, int Nout, void* wsplit, void* stream);
+/* The same with the result stored as HALVES (round 6): du = (dy W) act'(u) of an MLP's backward is read again only by the matrix pipe — the
+ * first linear's weight gradient (gecco_gemm_tn_f16_a16_f32) and its dX product (gecco_linear_dotstats_a16_f32) — as an fp16 operand either
+ * way; storing it so halves its three crossings of HBM.  The reference's autocast(float16) backward holds this gradient as an fp16
+ * tensor too (autograd of models/mlp.py:5-39 under Lightning's precision="16-mixed", diffusion.py:213-222).  kind 1 / 2 / 3. */
+int gecco_linear_astat16_actbwd_h16(const float* dy, const float* W, const float* u, const float* alpha, int kind, void* C16, float* agrad,
+                                    int B, int rows, int K, int Nout, void* wsplit, void* stream);
 
 /* GroupNorm partial statistics of x (B, rows, C): stats (B, T, 2, C), T = gecco_stats_row_tiles(rows). */
 int gecco_col_stats_f32(const float* x, float* stats, int B, int rows, int C, void* stream);
@@ -462,10 +472,17 @@ size_t gecco_linear_lift_workspace_bytes(const GeccoLinearLift* m, int B, int N)
 
 /* ---- image-conditional path ------------------------------------------------------------------- */
 
+/* dst[i] = fp16(src[i]) (round to nearest even), n elements: the fp16 texel image of a channels-last pyramid level. */
+int gecco_cast_f16(const float* src, void* dst, size_t n, void* stream);
+
 typedef struct GeccoPyramid {     /* FeaturePyramidContext.features, models/feature_pyramid.py:17-20 */
     int n_levels;                 /* <= 4 */
     int C[4], H[4], W[4];
-    const float* feat[4];         /* CHANNELS-LAST (B, H, W, C) fp32 per level (see gecco_nchw_to_nhwc_f32) */
+    const float* feat[4];         /* CHANNELS-LAST (B, H, W, C) per level (see gecco_nchw_to_nhwc_f32): fp32, or — texel_f16 — fp16 */
+    int texel_f16;                /* 1: the levels hold fp16 texels (gecco_cast_f16 of the fp32 image, made once per conditioner call): the
+                                   * forward lookups (gecco_ray_lookup_f32, gecco_ray_network_fwd_f32) gather half the bytes; coordinates, taps
+                                   * and weights stay fp32 and bit-exact, the interpolation runs in fp32 on the converted texels.  The gradient
+                                   * entry points take fp32 levels only.  The "w2" plans use it; fp32 / bf16x3 / mixed keep fp32 texels. */
 } GeccoPyramid;
 
 typedef struct GeccoReparam {     /* reparam.py: 0 NoReparam, 1 GaussianReparam(mean, sigma), 2 UVLReparam */
@@ -607,6 +624,10 @@ int gecco_gemm_tn_f16_tiles(int N, int K);
  * its tiles go to LDS as they are (no AdaGN apply) */
 int gecco_gemm_tn_f16_b16_f32(const float* A, const void* B16, float* parts, float* colsum_parts, int Z, int R, int N, int K, int group,
                               void* stream);
+/* ... and with A (dY) an fp16 tensor (N % 8 == 0), B fp32 with the optional AdaGN apply: the weight gradient of an MLP's first linear from du
+ * stored as halves; the bias gradient's column sums are formed from those halves. */
+int gecco_gemm_tn_f16_a16_f32(const void* A16, const float* Bm, const float* pro_a, const float* pro_o, float* parts, float* colsum_parts,
+                              int Z, int R, int N, int K, int group, void* stream);
 int gecco_reduce_batch_f32(const float* parts, float* out, size_t n, int Z, size_t stride, int accumulate, void* stream);
 
 /* Row softmax of the materialised attention scores: P = softmax(scale*S) over the last dim n; and its backward

@@ -68,6 +68,17 @@ def _check_fp16_dw(N, K):
             assert _rel(got, ref16) <= (2e-5 if pro else 2e-6), (pro, group, _rel(got, ref16))
             assert _rel(got, ref) <= 1e-3, (pro, group, _rel(got, ref))
             assert _rel(cs.double().sum(0), dy.double().sum((0, 1))) <= 1e-6   # column sums are fp32 sums of the fp32 values
+            if N % 8 == 0:   # dY as an fp16 tensor already (round 6: the MLP backward's du): the same product of the same halves ...
+                p16a = torch.full((G, N, K), float("nan"), device="cuda")
+                cs16 = torch.full((G, N), float("nan"), device="cuda")
+                dy16 = dyc.half()
+                _lib.check(lib.gecco_gemm_tn_f16_a16_f32(C.c_void_p(dy16.data_ptr()), C.c_void_p(xc.data_ptr()),
+                                                         C.c_void_p(pac.data_ptr()) if pro else None, C.c_void_p(poc.data_ptr()) if pro else None,
+                                                         C.c_void_p(p16a.data_ptr()), C.c_void_p(cs16.data_ptr()), Z, R, N, K, group, None),
+                           "gemm_tn_f16_a16")
+                assert torch.equal(p16a, parts)
+                # ... and the bias gradient's column sums are those of the halves
+                assert _rel(cs16.double().sum(0), dy16.double().sum((0, 1))) <= 1e-6
             if not pro and K % 8 == 0:   # X as an fp16 tensor already: the same product of the same halves
                 p16 = torch.full((G, N, K), float("nan"), device="cuda")
                 x16 = xc.half()
@@ -168,6 +179,57 @@ def test_mlp_function_under_autocast_runs_fp16_linears(kind):
         with torch.autocast("cuda", dtype=torch.float16):
             y1 = ag.LinearFn.apply(x.cuda(), W0.cuda(), b0.cuda())
         assert torch.equal(y1, hip_ops.linear(x.cuda(), W0.cuda(), b0.cuda(), precision="fp16"))
+    finally:
+        hip_ops.set_default_precision(prev)
+
+
+def test_mlp_backward_gradient_as_halves_is_the_same_arithmetic(monkeypatch):
+    """Round 6: inside AdaGNMlpFn's backward du = (dout W2) act'(u) leaves the dX product's epilogue as an fp16 tensor
+    (gecco_linear_astat16_actbwd_h16) and its two consumers read those halves (gecco_gemm_tn_f16_a16_f32, gecco_linear_dotstats_a16_f32) —
+    the operand bits they would round the fp32 tensor to: every gradient of the block is BIT-identical to the fp32-du path
+    (GECCO_TRAIN_DU16=0), except mlp.0's bias gradient, which is now the column sum of the halves (as in the reference's autocast backward,
+    where this gradient is an fp16 tensor)."""
+    from gecco_amd import autograd as ag
+    from gecco_amd import hip_ops
+    rs = np.random.RandomState(11)
+    prev = hip_ops.default_precision()
+    hip_ops.set_default_precision("mixed")
+    try:
+        B, R, K, Wd, G = 3, 256, 384, 768, 32
+        x, t = _t(rs.randn(B, R, K) * 2 + 0.3), _t(rs.randn(B, 1))
+        sw, sb, bw, bb = _t(rs.randn(K, 1) * 0.3), _t(1 + 0.1 * rs.randn(K)), _t(rs.randn(K, 1) * 0.3), _t(0.1 * rs.randn(K))
+        W0, b0 = _t(rs.randn(Wd, K) / np.sqrt(K)), _t(rs.randn(Wd) * 0.1)
+        W2, b2 = _t(rs.randn(K, Wd) / np.sqrt(Wd)), _t(rs.randn(K) * 0.1)
+        alpha, dy = torch.tensor(0.8), _t(rs.randn(B, R, K) * 64.0)     # (a loss-scaled gradient)
+
+        def run(du16):
+            monkeypatch.setenv("GECCO_TRAIN_DU16", du16)
+            leaves = [_leaf(v) for v in (x, t, sw, sb, bw, bb, W0, b0, alpha, W2, b2)]
+            xg, tg, swg, sbg, bwg, bbg, W0g, b0g, ag_, W2g, b2g = leaves
+            seen = {}
+            orig = ag._act_linear_dx
+
+            def spy(*a, **k):
+                r = orig(*a, **k)
+                seen["du"] = r[0].dtype
+                return r
+            monkeypatch.setattr(ag, "_act_linear_dx", spy)
+            with torch.autocast("cuda", dtype=torch.float16):
+                y = ag.AdaGNMlpFn.apply(xg, tg, swg, sbg, bwg, bbg, G, 1e-5, None, W0g, b0g, ag_, W2g, b2g, 1, False)
+            y.backward(dy.cuda())
+            monkeypatch.setattr(ag, "_act_linear_dx", orig)
+            return seen["du"], y.detach(), [v.grad for v in leaves]
+        d16, y16, g16 = run("1")
+        d32, y32, g32 = run("0")
+        assert d16 == torch.float16 and d32 == torch.float32, (d16, d32)
+        assert torch.equal(y16, y32)
+        names = ["x", "t", "scale.w", "scale.b", "bias.w", "bias.b", "W0", "b0", "alpha", "W2", "b2"]
+        for n, a, b in zip(names, g16, g32):
+            assert torch.isfinite(a).all(), n
+            if n == "b0":
+                assert _rel(a, b) <= 1e-3 and not torch.equal(a, b), (n, _rel(a, b))   # (the fp16 rounding of its 768 x B R summands)
+            else:
+                assert torch.equal(a, b), (n, _rel(a, b))
     finally:
         hip_ops.set_default_precision(prev)
 

@@ -142,6 +142,12 @@ def _run_cond(ops, case, precision, tag):
         for _ in range(2):
             assert torch.equal(den, net.forward(x.cuda(), sigma.cuda(), K.cuda(), levels))
         assert net.images.tokens and all(t == net.images.token(False) for t in net.images.tokens.values())   # built once, reused
+    # the "w2" mode gathers the pyramid's fp16 texel image (cast once, kept while the fp32 levels are the same tensors); the others fp32 texels
+    assert (net._tex16 is not None) == (precision == "w2")
+    if precision == "w2":
+        img16 = net._tex16[1]
+        net.forward(x.cuda(), sigma.cuda(), K.cuda(), levels)
+        assert net._tex16[1] is img16
 
 
 @pytest.mark.parametrize("precision", MODES)
@@ -205,6 +211,40 @@ def test_fp16_deep_network_weight_staging(ops, d, L):
         # error grows with depth (each layer adds its own rounding); the bar stays the north star's
         _report(f"d={d} L={L} {precision} D", den, ref, {"fp16": 1e-3, "w2": 5e-4}.get(precision, 3e-4))
         _report(f"d={d} L={L} {precision} F_x", raw, raw_ref, {"fp16": 2e-3, "w2": 5e-4}.get(precision, 3e-4))
+
+
+@pytest.mark.parametrize("seed", [11, 23, 37])
+def test_w2_margin_over_weight_seeds(ops, seed):
+    """The headline mode's 5e-4 bar at the headline shape on OTHER draws of the weights (the full-size tests above all use seed 3): the
+    one-term hidden layer's error depends on the activation statistics of the weights at hand, so the margin is measured over draws, not
+    taken from one (the strict `mixed` mode beside it for scale)."""
+    d, L, N = 384, 6, 2048
+    p = W.linear_lift_state_dict(seed, d, L, cases.I, cases.H)
+    x, sigma = _noisy(seed + 1, 2, N, (0.05, 5.0))
+    with torch.no_grad():
+        ref, raw_ref = cpu_ref.uncond_denoiser(p, "", cases.H)(x, sigma, return_raw=True)
+    for precision in ("w2", "mixed"):
+        den, raw = ops.LinearLiftPlan(_cuda(p), cases.H, cases.I, precision=precision).forward(x.cuda(), sigma.cuda(), return_raw=True)
+        _report(f"seed {seed} {precision} D", den, ref, BARS[precision])
+        _report(f"seed {seed} {precision} F_x", raw, raw_ref, BARS_FX[precision])
+
+
+@pytest.mark.parametrize("L", [10, 14])
+def test_w2_deep_networks_at_the_fused_width(ops, L):
+    """d = 384 (the width the one-launch point MLP exists for) at depths the shipped configs do not reach: every layer adds its own
+    one-term rounding, so F_x grows with depth — measured and printed; asserted against the north star's 1e-3 (the mode's own 5e-4 bar is
+    a statement about the shipped depth L = 6, held by the tests above), the strict mode against its own bar."""
+    d, N = 384, 1024
+    p = W.linear_lift_state_dict(200 + L, d, L, cases.I, cases.H)
+    x, sigma = _noisy(9, 2, N, (0.2, 4.0))
+    with torch.no_grad():
+        ref, raw_ref = cpu_ref.uncond_denoiser(p, "", cases.H)(x, sigma, return_raw=True)
+    den, raw = ops.LinearLiftPlan(_cuda(p), cases.H, cases.I, precision="w2").forward(x.cuda(), sigma.cuda(), return_raw=True)
+    _report(f"d=384 L={L} w2 D", den, ref, 1e-3)
+    _report(f"d=384 L={L} w2 F_x", raw, raw_ref, 1e-3)
+    denm, rawm = ops.LinearLiftPlan(_cuda(p), cases.H, cases.I, precision="mixed").forward(x.cuda(), sigma.cuda(), return_raw=True)
+    assert not torch.equal(raw, rawm)   # the fused launch ran
+    _report(f"d=384 L={L} mixed F_x", rawm, raw_ref, 3e-4)
 
 
 # ------------------------------------------------------------------------------------------------- training path at full size

@@ -371,6 +371,38 @@ def test_lookup_golden(golden_dir, name):
     assert torch.equal(got, got2)
 
 
+@pytest.mark.parametrize("name", list(cases.LOOKUP_CASES))
+def test_lookup_on_fp16_texels(name):
+    """The "w2" mode's texel image (GeccoPyramid.texel_f16, gecco_cast_f16): the lookup on fp16 texels equals — to the bit, outputs and
+    GroupNorm partials — the lookup on fp32 texels holding the rounded values (only the gathered bytes differ: coordinates, taps, weights
+    and the interpolation are the same fp32 expressions); against the golden lookup it is the fp16 rounding of the features away
+    (models/ray.py:64-87); the gradient entry points refuse it."""
+    from gecco_amd import _lib, hip_ops
+    feats, K, geom, um, us = cases.lookup_inputs(name)
+    umc, usc = um.cuda(), us.cuda()                       # (the struct holds raw pointers: keep the tensors)
+    rp = hip_ops.make_reparam(2, umc, usc, 1.1)
+    lv32 = hip_ops.to_channels_last_levels([f.cuda() for f in feats])
+    lv16 = hip_ops.half_levels(lv32)
+    assert all(h.dtype == torch.float16 and torch.equal(h, f.half()) for h, f in zip(lv16, lv32))   # round to nearest even
+    got16, st16 = hip_ops.ray_lookup(geom.cuda(), K.cuda(), lv16, rp, want_stats=True)
+    got32r, st32r = hip_ops.ray_lookup(geom.cuda(), K.cuda(), [h.float() for h in lv16], rp, want_stats=True)
+    assert torch.equal(got16, got32r) and torch.equal(st16, st32r)
+    got32 = hip_ops.ray_lookup(geom.cuda(), K.cuda(), lv32, rp)
+    e = cpu_ref.rel_err(got16.cpu(), got32.cpu())
+    print(f"{name}: fp16 texels vs fp32 texels: max-norm {e[0]:.2e}, rel-L2 {e[1]:.2e}")
+    assert 0 < e[0] <= 1e-3 and e[1] <= 4e-4, e
+    uv16 = hip_ops.ray_lookup_taps(geom.cuda(), K.cuda(), lv16, rp)
+    uv32 = hip_ops.ray_lookup_taps(geom.cuda(), K.cuda(), lv32, rp)
+    assert all(torch.equal(a, b) for a, b in zip(uv16, uv32))                                        # the index chain never sees the texels
+    pyr = hip_ops.make_pyramid(lv16)
+    import ctypes as C
+    dout = torch.zeros_like(got16)
+    dg = torch.zeros(geom.shape, device="cuda")
+    rc = _lib.load().gecco_ray_lookup_dgeom_f32(hip_ops._ptr(geom.cuda().contiguous()), hip_ops._ptr(K.cuda().float().contiguous()), C.byref(rp), C.byref(pyr),
+                                                hip_ops._ptr(dout), hip_ops._ptr(dg), None, geom.shape[0], geom.shape[1], None)
+    assert rc != 0
+
+
 def test_graphed_forward_replays_the_eager_bits():
     """Diffusion.graphed_forward: one captured evaluation replayed on new inputs equals the eager call bit for bit."""
     name = "uncond_d128_L4_N256"

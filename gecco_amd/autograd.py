@@ -251,11 +251,17 @@ def _linear_dx_dot(dy: Tensor, W: Tensor, x: Tensor, prec: str | None = None):
     return dx, gst
 
 
-def _linear_dx(dy: Tensor, W: Tensor, residual: Tensor | None = None, prec: str | None = None) -> Tensor:
+def _linear_dx(dy: Tensor, W: Tensor, residual: Tensor | None = None, prec: str | None = None, out_f16: bool = False) -> Tensor:
     """dx = dy W (+ residual: another gradient contribution to the same tensor, added in the GEMM's epilogue).
-    prec: the arithmetic the Function's forward chose (`_lin_precision()`); None: the training precision."""
+    prec: the arithmetic the Function's forward chose (`_lin_precision()`); None: the training precision.
+    fp16 tensors (the `_io16_ok` layers under autocast(float16)): dy may be an fp16 tensor (its tiles go to LDS as they are), and with
+    out_f16 the result leaves as one (no residual then) — the fp16 LDS-DMA kernel either way."""
     B, R, Nout = dy.shape
     K = W.shape[1]
+    if dy.dtype == torch.float16 or out_f16:
+        img = WEIGHT_IMAGES.lookup("t", W, prec="fp16")
+        return hip_ops.linear_f16io(dy, None if img is not None else W.t().contiguous(), residual=residual, out_f16=out_f16, w_image=img,
+                                    w_shape=(K, Nout))
     prec = _resolve(prec, R, Nout, K)
     # (with a residual the A-stationary form measured the same as the LDS-DMA one, 19.31 vs 19.27 ms per step: only the plain product)
     if residual is None and _a16_ok(prec, R, Nout, K):
@@ -288,8 +294,10 @@ _SIDE = {"stream": None, "pending": False}
 
 
 def _side_enabled() -> bool:
+    # (inside a hipGraph capture the fork / join is captured with it — one level of fork, as the two-stream forward's: opt-in,
+    # GECCO_TRAIN_DW_STREAM_CAPTURE=1, tools/debug/graph_train.py)
     return os.environ.get("GECCO_TRAIN_DW_STREAM", "1") != "0" and torch.cuda.is_available() and \
-        not torch.cuda.is_current_stream_capturing()
+        (not torch.cuda.is_current_stream_capturing() or os.environ.get("GECCO_TRAIN_DW_STREAM_CAPTURE", "0") == "1")
 
 
 def sync_side_stream() -> None:
@@ -430,6 +438,14 @@ class LinearFn(torch.autograd.Function):
         ctx.has_bias = b is not None
         prec = ctx.prec = _lin_precision()
         res = None if residual is None else _f(residual)
+        if x.dtype == torch.float16:   # an fp16 tensor of an `_io16_ok` layer (the unpool attention's output): fp16 A tiles, fp32 result
+            img = WEIGHT_IMAGES.lookup("n", W, prec="fp16")
+            out = hip_ops.linear_f16io(x, None if img is not None else W, b, residual=res, want_stats=want_stats, w_image=img,
+                                       w_shape=tuple(W.shape))
+            if want_stats:
+                ctx.mark_non_differentiable(out[1])
+                ctx.set_materialize_grads(False)
+            return out
         img = WEIGHT_IMAGES.lookup("n", W, prec=prec) if _image_ok(x.shape[1], W.shape[1], W.shape[0], prec) else None
         kw = dict(precision=prec, w_image=img, w_shape=tuple(W.shape)) if img is not None else dict(precision=prec)
         if want_stats:
@@ -446,7 +462,8 @@ class LinearFn(torch.autograd.Function):
         x, W = ctx.saved_tensors
         dy = _f(dy)
         prec = ctx.prec
-        dx = _linear_dx(dy, W, prec=prec) if ctx.needs_input_grad[0] else None
+        # (an fp16 input's gradient leaves as an fp16 tensor: its consumer — the attention backward — reads it as an fp16 operand)
+        dx = _linear_dx(dy, W, prec=prec, out_f16=x.dtype == torch.float16) if ctx.needs_input_grad[0] else None
         dW = db = None
         if ctx.has_bias and ctx.needs_input_grad[2] and ctx.needs_input_grad[1]:
             dW, db = _linear_dw(dy, x, want_db=True, leaf=W, prec=prec)
@@ -579,6 +596,20 @@ def _pro_ok(R: int, K: int, Nout: int) -> bool:
     return bool(lib.gecco_linear_image_ok_f16(R, K, Nout, 1) if prec == "fp16" else lib.gecco_linear_image_ok(R, K, Nout, 1))
 
 
+def _io16_ok(R: int, Cc: int, H: int, I: int) -> bool:
+    """Under the autocast(float16) arithmetic the projections K | V and q of a layer, the unpool attention's output and their gradients
+    are read only by kernels that round them to fp16 on the way in (both attentions and their backward, out_proj and its dX / dW products,
+    the dX / dW products of kv_proj | q_proj): they are then fp16 TENSORS, as in the reference's autocast run (Lightning's
+    precision="16-mixed": nn.Linear / SDPA outputs are halves there, example_configs/shapenet_airplane_unconditional.py:74) — the same
+    operand bits, half the bytes of fifteen crossings of HBM per layer (~1.7 GB at the shipped batch).  Shapes every kernel of that
+    chain takes: whole 128-row blocks, 64 inducers, head dims 16 / 32 / 48 / 64, feature_dim 128 / 256 / 384 / 512.  GECCO_TRAIN_IO16=0: fp32 tensors."""
+    if os.environ.get("GECCO_TRAIN_IO16", "1") == "0" or _lin_precision() != "fp16" or os.environ.get("GECCO_TRAIN_ATTN16", "1") == "0":
+        return False
+    hd = Cc // H
+    return (I == 64 and Cc % H == 0 and hd in (16, 32, 48, 64) and Cc in (128, 256, 384, 512) and R >= 128 and R % 128 == 0
+            and _fused_attn_ok(I, hd) and _a16_ok("fp16", R, Cc, 3 * Cc) and _image_ok(R, Cc, Cc, "fp16") and _image_ok(R, 2 * Cc, Cc, "fp16"))
+
+
 class AdaGNPairFn(torch.autograd.Function):
     """(KV, q, x) = (AdaGN(x) Wkv^T, AdaGN(x) Wq^T + bq, x): broadcast_norm and the two projections of its output
     (models/set_transformer.py:161-162 -> :49, :112) as ONE Function.  AdaGN(x) is never materialised: the pair GEMM applies
@@ -587,13 +618,19 @@ class AdaGNPairFn(torch.autograd.Function):
     output hands x to the skip connection; the gradient returning through it is added inside the AdaGN backward kernel."""
 
     @staticmethod
-    def forward(ctx, x, t, sw, sb, bw, bb, G, eps, stats, W1, W2, b2):
+    def forward(ctx, x, t, sw, sb, bw, bb, G, eps, stats, W1, W2, b2, io16=False):
         x = _f(x)
         ctx.set_materialize_grads(False)
         a, o, stats, t2 = _adagn_coeffs(x, t, sw, sb, bw, bb, G, eps, stats)
         prec = ctx.prec = _lin_precision()   # "bf16x3" or "fp16" (_pro_ok)
         B, R, K = x.shape
         N1, N2 = W1.shape[0], W2.shape[0]
+        if io16:   # (`_io16_ok`) K | V and q as fp16 tensors: the same A-stationary kernel, its fp16 row-major epilogue
+            ws, ready = _a16_stream("pair", W1, W2, dev=x.device)
+            KV, q = hip_ops.linear_kvq_f16(x, (a, o), W1, None, _f(W2), b2, lo=(0, 0), head_dim=0, wsplit=ws, image_ready=ready)
+            ctx.save_for_backward(x, stats, t2, sw, sb, a, o, W1, W2, bw)
+            ctx.G, ctx.eps, ctx.has_b2, ctx.t_shape = G, eps, b2 is not None, tuple(t.shape)
+            return KV, q, x
         if _a16_ok(prec, R, K, N1 + N2) and N1 % 64 == 0 and N2 % 64 == 0:
             KV, q = _new(B, R, N1, like=x), _new(B, R, N2, like=x)
             ws, ready = _a16_stream("pair", W1, W2, dev=x.device)
@@ -637,9 +674,9 @@ class AdaGNPairFn(torch.autograd.Function):
         elif need[10]:
             dW2 = _linear_dw(dq, x, pro=(a, o), leaf=W2, prec=prec)
         elif ctx.has_b2 and need[11]:
-            db2 = _linear_db(dq)
+            db2 = _linear_db(dq.float() if dq.dtype != torch.float32 else dq)
         dx, dsw, dsb, dbw, dbb, dt = _adagn_backward(x, stats, t2, sw, sb, dY, dskip, ctx.G, ctx.eps, True, bw=bw if need[1] else None)
-        return dx, (dt.reshape(ctx.t_shape) if dt is not None else None), dsw, dsb, dbw, dbb, None, None, None, dW1, dW2, db2
+        return dx, (dt.reshape(ctx.t_shape) if dt is not None else None), dsw, dsb, dbw, dbb, None, None, None, dW1, dW2, db2, None
 
 
 class AdaGNMlpFn(torch.autograd.Function):
@@ -1055,6 +1092,20 @@ class PoolAttnFn(torch.autograd.Function):
         Cc, I, hd = C2 // 2, ind.shape[2], ind.shape[3]
         ctx.H = H
         ctx.fused = _fused_attn_ok(I, hd)
+        if KV.dtype == torch.float16:   # an `_io16_ok` layer: K | V as an fp16 tensor (row-major), the fp16 kernels
+            assert ctx.fused
+            lib = _lib.load()
+            nb = lib.gecco_pool_attn_workspace_bytes(B, N, Cc, H, I)
+            ws = torch.empty(nb, dtype=torch.uint8, device=KV.device)
+            O = _new(B, I, Cc, like=ind)
+            ctx.pr = 3
+            _lib.check(lib.gecco_pool_attn_f16in(hip_ops._ptr16(KV), _ptr(ind), _ptr(O), B, N, Cc, H, I, 0, C.c_void_p(ws.data_ptr()), nb,
+                                                 _stream()), "gecco_pool_attn_f16in")
+            lse = _new(B, H, I, like=ind)
+            _lib.check(lib.gecco_pool_attn_lse_f32(C.c_void_p(ws.data_ptr()), nb, _ptr(lse), B, N, Cc, H, I, _stream()),
+                       "gecco_pool_attn_lse_f32")
+            ctx.save_for_backward(KV, ind, O, lse)
+            return O
         if ctx.fused:
             # flash-style forward (no (B, H, I, N) tensor) + the log-sum-exp the fused backward recomputes P from
             lib = _lib.load()
@@ -1090,8 +1141,9 @@ class PoolAttnFn(torch.autograd.Function):
             Cc, I, hd = C2 // 2, ind.shape[2], ind.shape[3]
             lib = _lib.load()
             P = B * lib.gecco_pool_attn_bwd_partials(B, N, H)
-            dKV, dQp = torch.empty_like(KV), _new(P, H, I, hd, like=KV)
-            _lib.check(lib.gecco_pool_attn_bwd_ex_f32(_ptr(KV), _ptr(ind), _ptr(O), _ptr(lse), _ptr(dO), _ptr(dKV), _ptr(dQp), B, N, Cc,
+            dKV, dQp = torch.empty_like(KV), _new(P, H, I, hd, like=ind)
+            pk = hip_ops._ptr16 if KV.dtype == torch.float16 else _ptr      # (precision 3: KV and dKV are fp16 tensors)
+            _lib.check(lib.gecco_pool_attn_bwd_ex_f32(pk(KV), _ptr(ind), _ptr(O), _ptr(lse), _ptr(dO), pk(dKV), _ptr(dQp), B, N, Cc,
                                                       H, I, ctx.pr, _stream()), "gecco_pool_attn_bwd_ex_f32")
             return dKV, _reduce(dQp, H * I * hd, P, H * I * hd).reshape(ind.shape), None
         KV, ind, P = ctx.saved_tensors
@@ -1128,6 +1180,11 @@ class UnpoolAttnFn(torch.autograd.Function):
         I, hd = kvh.shape[1], Cc // H
         ctx.H = H
         ctx.fused = _fused_attn_ok(I, hd)
+        if q.dtype == torch.float16:   # an `_io16_ok` layer: q in, the attention output out as fp16 tensors (row-major)
+            assert ctx.fused
+            ctx.save_for_backward(q, kvh)
+            ctx.pr = 3
+            return hip_ops.unpool_attn_f16io(q, kvh, H)
         if ctx.fused:
             ctx.save_for_backward(q, kvh)
             ctx.pr = _attn_pr()
@@ -1152,8 +1209,13 @@ class UnpoolAttnFn(torch.autograd.Function):
             I = kvh.shape[1]
             lib = _lib.load()
             P = lib.gecco_unpool_attn_bwd_partials(B, N, H)
-            dq, parts = torch.empty_like(q), _new(P, B, I, 2 * Cc, like=q)
-            _lib.check(lib.gecco_unpool_attn_bwd_ex_f32(_ptr(q), _ptr(kvh), _ptr(dO), _ptr(dq), _ptr(parts), B, N, Cc, H, I, ctx.pr,
+            dq, parts = torch.empty_like(q), _new(P, B, I, 2 * Cc, like=kvh)
+            if q.dtype == torch.float16:   # precision 3: q, dO and dq are fp16 tensors
+                dO = dO if dO.dtype == torch.float16 else dO.half()
+                pk = hip_ops._ptr16
+            else:
+                pk = _ptr
+            _lib.check(lib.gecco_unpool_attn_bwd_ex_f32(pk(q), _ptr(kvh), pk(dO), pk(dq), _ptr(parts), B, N, Cc, H, I, ctx.pr,
                                                         _stream()), "gecco_unpool_attn_bwd_ex_f32")
             n = B * I * 2 * Cc
             return dq, (parts[0] if P == 1 else _reduce(parts, n, P, n).reshape(B, I, 2 * Cc)), None
@@ -1634,8 +1696,9 @@ def broadcasting_layer(layer, x, t, h=None, stats=None, want_stats=False):
     n1 = layer.broadcast_norm
     fused_pair = h is None and _pro_ok(R, Cc, 3 * Cc) and Cc % 128 == 0
     if fused_pair:   # broadcast_norm as the prologue of kv_proj | q_proj: AdaGN(x) is never written
+        io16 = _io16_ok(R, Cc, H, bc.pool.inducers.shape[2])
         KV, q, x = AdaGNPairFn.apply(x, t, n1.scale.weight, n1.scale.bias, n1.bias.weight, n1.bias.bias, n1.gn.num_groups, n1.gn.eps,
-                                     stats, bc.pool.kv_proj.weight, Wq, bq)
+                                     stats, bc.pool.kv_proj.weight, Wq, bq, io16)
     else:
         y, x = adagn(n1, x, t, passthrough=True, stats=stats)
     if h is None:

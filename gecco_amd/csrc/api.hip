@@ -1517,7 +1517,7 @@ int gecco_unpool_attn_bwd_f32(const float* q, const float* kvh, const float* dO,
 int gecco_pool_attn_bwd_ex_f32(const float* KV, const float* inducers, const float* merged, const float* lse, const float* dO,
                                float* dKV, float* dQ_partials, int B, int N, int C, int H, int I, int precision, void* stream) {
     if (B <= 0 || N <= 0) return fail(-2, "pool_attn_bwd: empty batch");
-    if (precision < 0 || precision > 2) return fail(-2, "pool_attn_bwd: precision must be 0 (fp32), 1 (split-bf16) or 2 (fp16 operands)");
+    if (precision < 0 || precision > 3) return fail(-2, "pool_attn_bwd: precision must be 0 (fp32), 1 (split-bf16), 2 (fp16 operands) or 3 (fp16 operands, fp16 KV / dKV tensors)");
     const int rc = pool_attn_bwd_launch(KV, inducers, merged, lse, dO, dKV, dQ_partials, B, N, C, H, I, pool_attn_bwd_nsplit(B, N, H),
                                         (hipStream_t)stream, precision);
     if (rc == -3 || rc == -4) return fail(-2, "pool_attn_bwd: needs I == 64 and a head dim that is a multiple of 8 up to 64");
@@ -1528,7 +1528,7 @@ int gecco_pool_attn_bwd_ex_f32(const float* KV, const float* inducers, const flo
 int gecco_unpool_attn_bwd_ex_f32(const float* q, const float* kvh, const float* dO, float* dq, float* dkv_partials, int B, int N,
                                  int C, int H, int I, int precision, void* stream) {
     if (B <= 0 || N <= 0) return fail(-2, "unpool_attn_bwd: empty batch");
-    if (precision < 0 || precision > 2) return fail(-2, "unpool_attn_bwd: precision must be 0 (fp32), 1 (split-bf16) or 2 (fp16 operands)");
+    if (precision < 0 || precision > 3) return fail(-2, "unpool_attn_bwd: precision must be 0 (fp32), 1 (split-bf16), 2 (fp16 operands) or 3 (fp16 operands, fp16 q / dO / dq tensors)");
     const int rc = unpool_attn_bwd_launch(q, kvh, dO, dq, dkv_partials, B, N, C, H, I, (hipStream_t)stream, precision);
     if (rc == -3 || rc == -4) return fail(-2, "unpool_attn_bwd: needs I == 64 and a head dim that is a multiple of 8 up to 64");
     TRY(rc, "unpool_attn_bwd");

@@ -510,8 +510,9 @@ int unpool_attn_bwd_chunks(int B, int N, int H, int* tiles_per_wave) {
 int pool_attn_bwd_launch(const float* KV, const float* inducers, const float* merged, const float* lse, const float* dO,
                          float* dKV, float* dQpart, int B, int N, int C, int H, int I, int nsplit, hipStream_t st, int precision) {
     if (I != 64 || C % H) return -3;
+    if (precision == 3 && !(attn_bwd_x3_supported(C / H) && C % 4 == 0)) return -4;   // fp16 tensors: the x3 kernels only
     if (precision >= 1 && attn_bwd_x3_supported(C / H))
-        return pool_attn_bwd_x3_launch(KV, inducers, merged, lse, dO, dKV, dQpart, B, N, C, H, nsplit, st, precision == 2);
+        return pool_attn_bwd_x3_launch(KV, inducers, merged, lse, dO, dKV, dQpart, B, N, C, H, nsplit, st, precision == 3 ? 2 : precision == 2);
     switch (C / H) {
         case 8: return pool_bwd_t<8>(KV, inducers, merged, lse, dO, dKV, dQpart, B, N, C, H, nsplit, st);
         case 16: return pool_bwd_t<16>(KV, inducers, merged, lse, dO, dKV, dQpart, B, N, C, H, nsplit, st);
@@ -530,8 +531,9 @@ int unpool_attn_bwd_launch(const float* q, const float* kvh, const float* dO, fl
     if (I != 64 || C % H) return -3;
     int tpw;
     const int nchunk = unpool_attn_bwd_chunks(B, N, H, &tpw);
+    if (precision == 3 && !(attn_bwd_x3_supported(C / H) && C % 4 == 0)) return -4;
     if (precision >= 1 && attn_bwd_x3_supported(C / H))
-        return unpool_attn_bwd_x3_launch(q, kvh, dO, dq, dkv_part, B, N, C, H, tpw, nchunk, st, precision == 2);
+        return unpool_attn_bwd_x3_launch(q, kvh, dO, dq, dkv_part, B, N, C, H, tpw, nchunk, st, precision == 3 ? 2 : precision == 2);
     switch (C / H) {
         case 8: return unpool_bwd_t<8>(q, kvh, dO, dq, dkv_part, B, N, C, H, tpw, nchunk, st);
         case 16: return unpool_bwd_t<16>(q, kvh, dO, dq, dkv_part, B, N, C, H, tpw, nchunk, st);

@@ -18,6 +18,12 @@
 //   * the P / dS tile goes back to LDS for those TN products as hi | lo planes, 8 bytes (4 consecutive rows of the
 //     accumulator = 4 consecutive columns of the plane) per store.
 // Head dims 16, 32, 48, 64; anything else runs attention_bwd_f32.hip.
+//
+// IO16 (round 6, with F16): the point-stream tensors are fp16 TENSORS — K | V / q, dO in, dK | dV / dq out — as the reference's
+// autocast(float16) backward holds them (autograd of F.scaled_dot_product_attention / nn.MultiheadAttention under Lightning's
+// precision="16-mixed").  The planes take the halves as they are (the bits the fp32 tensors were rounded to on the way in), the
+// results are rounded once on the way out — where their consumers (the dX / dW products of kv_proj | q_proj) rounded them before: half
+// the bytes of six crossings of HBM per layer.  Inducer-side tensors (queries, k | v of the inducers, their gradients) stay fp32.
 #include "common.h"
 #include "kernels.h"
 
@@ -135,12 +141,23 @@ __device__ __forceinline__ void put4(u16* hi_plane, u16* lo_plane, int row, int 
     if (!F16) *reinterpret_cast<u32x2*>(lo_plane + o) = lo;
 }
 
+// IO16: a [rows][HD] fp16 tile held as 8-byte pieces (4 halves) goes into the hi plane as it is
+template <int NB>
+__device__ __forceinline__ void put4h(u16* hi_plane, int row, int col, const u32x2& v) {
+    *reinterpret_cast<u32x2*>(hi_plane + blk_off<NB>(row, col)) = v;
+}
+__device__ __forceinline__ f32x4 as_f32x4(const u32x2& v) {   // (register type of a loaded piece: two dwords used, two idle)
+    return f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), 0.f, 0.f};
+}
+__device__ __forceinline__ u32x2 as_u32x2(const f32x4& v) { return u32x2{__float_as_uint(v[0]), __float_as_uint(v[1])}; }
+
 // ------------------------------------------------------------------------------------- pool
-template <int HD, bool F16>
+template <int HD, bool F16, bool IO16 = false>
 __global__ __launch_bounds__(256) void pool_attn_bwd_x3_kernel(const float* __restrict__ KV, const float* __restrict__ Qind,
                                                                const float* __restrict__ Omerged, const float* __restrict__ lse,
                                                                const float* __restrict__ dO, float* __restrict__ dKV,
                                                                float* __restrict__ dQpart, int B, int N, int C, int H, int nsplit) {
+    static_assert(!IO16 || F16, "fp16 tensors carry the fp16 arithmetic");
     constexpr int DT = (HD + 31) / 32, CH = HD / 4, LD_IT = (32 * CH + 63) / 64, NC = HD / 16;
     constexpr int P64 = 16 * DT * 128;   // elements of a 64-row plane with DT column blocks
     constexpr int P32 = 8 * DT * 128;    // 32-row plane
@@ -211,8 +228,14 @@ __global__ __launch_bounds__(256) void pool_attn_bwd_x3_kernel(const float* __re
             const int f = it * 64 + lane, row = f / CH, ch = f % CH, key = base + row;
             f32x4 zk = {0.f, 0.f, 0.f, 0.f}, zv = {0.f, 0.f, 0.f, 0.f};
             if (f < 32 * CH && tile < ntiles && key < k_end) {
-                zk = *reinterpret_cast<const f32x4*>(Kg + key * ldkv + ch * 4);
-                zv = *reinterpret_cast<const f32x4*>(Vg + key * ldkv + ch * 4);
+                if (IO16) {
+                    const _Float16* K16 = reinterpret_cast<const _Float16*>(KV) + (size_t)b * N * ldkv + hh * HD;
+                    zk = as_f32x4(*reinterpret_cast<const u32x2*>(K16 + key * ldkv + ch * 4));
+                    zv = as_f32x4(*reinterpret_cast<const u32x2*>(K16 + C + key * ldkv + ch * 4));
+                } else {
+                    zk = *reinterpret_cast<const f32x4*>(Kg + key * ldkv + ch * 4);
+                    zv = *reinterpret_cast<const f32x4*>(Vg + key * ldkv + ch * 4);
+                }
             }
             rk[it] = zk;
             rv[it] = zv;
@@ -223,8 +246,13 @@ __global__ __launch_bounds__(256) void pool_attn_bwd_x3_kernel(const float* __re
         for (int it = 0; it < LD_IT; ++it) {
             const int f = it * 64 + lane, row = f / CH, ch = f % CH;
             if (f < 32 * CH) {
-                put4<DT, F16>(Khi, Klo, row, ch * 4, rk[it]);
-                put4<DT, F16>(Vhi, Vlo, row, ch * 4, rv[it]);
+                if (IO16) {
+                    put4h<DT>(Khi, row, ch * 4, as_u32x2(rk[it]));
+                    put4h<DT>(Vhi, row, ch * 4, as_u32x2(rv[it]));
+                } else {
+                    put4<DT, F16>(Khi, Klo, row, ch * 4, rk[it]);
+                    put4<DT, F16>(Vhi, Vlo, row, ch * 4, rv[it]);
+                }
             }
         }
     };
@@ -320,12 +348,16 @@ __global__ __launch_bounds__(256) void pool_attn_bwd_x3_kernel(const float* __re
                         acc[dt] = mfma3<F16>(ah, al, trfrag<DT>(Bh, sg, dt, lane), trfrag<DT>(Bl, sg, dt, lane), acc[dt]);
                 }
                 float* dst = pass == 0 ? dVg : dKg;
+                _Float16* dst16 = reinterpret_cast<_Float16*>(dKV) + (size_t)b * N * ldkv + hh * HD + (pass == 0 ? C : 0);
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int key = kbase + mfma_row(e, h), d = dt * 32 + r;
-                        if (key < k_end && d < HD) dst[key * ldkv + d] = acc[dt][e];
+                        if (key < k_end && d < HD) {
+                            if (IO16) dst16[key * ldkv + d] = (_Float16)acc[dt][e];
+                            else dst[key * ldkv + d] = acc[dt][e];
+                        }
                     }
                 wave_lds_sync();   // the tile's reads are done before the next pass / tile overwrites it
             }
@@ -354,7 +386,7 @@ __global__ __launch_bounds__(256) void pool_attn_bwd_x3_kernel(const float* __re
 }
 
 // ----------------------------------------------------------------------------------- unpool
-template <int HD, bool F16>
+template <int HD, bool F16, bool IO16 = false>
 __global__ __launch_bounds__(256) void unpool_attn_bwd_x3_kernel(const float* __restrict__ q, const float* __restrict__ kvh,
                                                                  const float* __restrict__ dO, float* __restrict__ dq,
                                                                  float* __restrict__ dkv_part, int B, int N, int C, int H,
@@ -406,8 +438,14 @@ __global__ __launch_bounds__(256) void unpool_attn_bwd_x3_kernel(const float* __
             const int f = ld * 64 + lane, row = f / CH, ch = f % CH, n = q0 + row;
             f32x4 v = {0.f, 0.f, 0.f, 0.f}, g = {0.f, 0.f, 0.f, 0.f};
             if (f < 32 * CH && it < tiles_per_wave && n < N) {
-                v = *reinterpret_cast<const f32x4*>(qb + (size_t)n * C + ch * 4);
-                g = *reinterpret_cast<const f32x4*>(gb + (size_t)n * C + ch * 4);
+                if (IO16) {
+                    const size_t o = ((size_t)b * N + n) * C + hh * HD + ch * 4;
+                    v = as_f32x4(*reinterpret_cast<const u32x2*>(reinterpret_cast<const _Float16*>(q) + o));
+                    g = as_f32x4(*reinterpret_cast<const u32x2*>(reinterpret_cast<const _Float16*>(dO) + o));
+                } else {
+                    v = *reinterpret_cast<const f32x4*>(qb + (size_t)n * C + ch * 4);
+                    g = *reinterpret_cast<const f32x4*>(gb + (size_t)n * C + ch * 4);
+                }
             }
             rq[ld] = v;
             rg[ld] = g;
@@ -429,8 +467,13 @@ __global__ __launch_bounds__(256) void unpool_attn_bwd_x3_kernel(const float* __
         for (int ld = 0; ld < LD_IT; ++ld) {
             const int f = ld * 64 + lane, row = f / CH, ch = f % CH;
             if (f < 32 * CH) {
-                put4<DT, F16>(Qhi, Qlo, row, ch * 4, rq[ld]);
-                put4<DT, F16>(Ghi, Glo, row, ch * 4, rg[ld]);
+                if (IO16) {
+                    put4h<DT>(Qhi, row, ch * 4, as_u32x2(rq[ld]));
+                    put4h<DT>(Ghi, row, ch * 4, as_u32x2(rg[ld]));
+                } else {
+                    put4<DT, F16>(Qhi, Qlo, row, ch * 4, rq[ld]);
+                    put4<DT, F16>(Ghi, Glo, row, ch * 4, rg[ld]);
+                }
             }
         }
         load_q(it + 1);
@@ -541,8 +584,15 @@ __global__ __launch_bounds__(256) void unpool_attn_bwd_x3_kernel(const float* __
 #pragma unroll
             for (int ld = 0; ld < LD_IT; ++ld) {
                 const int f = ld * 64 + lane, row = f / CH, ch = f % CH, n = q0 + row;
-                if (f < 32 * CH && n < N)
-                    *reinterpret_cast<f32x4*>(dqb + (size_t)n * C + ch * 4) = *reinterpret_cast<const f32x4*>(St + row * KP + ch * 4);
+                if (f < 32 * CH && n < N) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(St + row * KP + ch * 4);
+                    if (IO16) {
+                        const f16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                        *reinterpret_cast<u32x2*>(reinterpret_cast<_Float16*>(dq) + ((size_t)b * N + n) * C + hh * HD + ch * 4) = __builtin_bit_cast(u32x2, hv);
+                    } else {
+                        *reinterpret_cast<f32x4*>(dqb + (size_t)n * C + ch * 4) = v;
+                    }
+                }
             }
             wave_lds_sync();
         }
@@ -573,7 +623,7 @@ __global__ __launch_bounds__(256) void unpool_attn_bwd_x3_kernel(const float* __
     }
 }
 
-template <int HD, bool F16>
+template <int HD, bool F16, bool IO16 = false>
 int pool_bwd_x3_t(const float* KV, const float* ind, const float* O, const float* lse, const float* dO, float* dKV, float* dQp,
                   int B, int N, int C, int H, int nsplit, hipStream_t st) {
     constexpr int DT = (HD + 31) / 32;
@@ -581,14 +631,14 @@ int pool_bwd_x3_t(const float* KV, const float* ind, const float* O, const float
     const size_t lds = a > c ? a : c;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pool_attn_bwd_x3_kernel<HD, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pool_attn_bwd_x3_kernel<HD, F16, IO16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((pool_attn_bwd_x3_kernel<HD, F16>), dim3(B * H * nsplit), dim3(256), lds, st, KV, ind, O, lse, dO, dKV, dQp, B, N, C, H, nsplit);
+    hipLaunchKernelGGL((pool_attn_bwd_x3_kernel<HD, F16, IO16>), dim3(B * H * nsplit), dim3(256), lds, st, KV, ind, O, lse, dO, dKV, dQp, B, N, C, H, nsplit);
     return (int)hipGetLastError();
 }
 
-template <int HD, bool F16>
+template <int HD, bool F16, bool IO16 = false>
 int unpool_bwd_x3_t(const float* q, const float* kvh, const float* dO, float* dq, float* part, int B, int N, int C, int H, int tpw,
                     int nchunk, hipStream_t st) {
     constexpr int DT = (HD + 31) / 32;
@@ -596,10 +646,10 @@ int unpool_bwd_x3_t(const float* q, const float* kvh, const float* dO, float* dq
     const size_t lds = a > c ? a : c;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(unpool_attn_bwd_x3_kernel<HD, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(unpool_attn_bwd_x3_kernel<HD, F16, IO16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((unpool_attn_bwd_x3_kernel<HD, F16>), dim3(B * H * nchunk), dim3(256), lds, st, q, kvh, dO, dq, part, B, N, C, H, tpw, nchunk);
+    hipLaunchKernelGGL((unpool_attn_bwd_x3_kernel<HD, F16, IO16>), dim3(B * H * nchunk), dim3(256), lds, st, q, kvh, dO, dq, part, B, N, C, H, tpw, nchunk);
     return (int)hipGetLastError();
 }
 
@@ -610,7 +660,8 @@ bool attn_bwd_x3_supported(int HD) { return HD == 16 || HD == 32 || HD == 48 || 
 int pool_attn_bwd_x3_launch(const float* KV, const float* inducers, const float* merged, const float* lse, const float* dO,
                             float* dKV, float* dQpart, int B, int N, int C, int H, int nsplit, hipStream_t st, int f16) {
 #define POOL_BWD(HD_)                                                                                              \
-    return f16 ? pool_bwd_x3_t<HD_, true>(KV, inducers, merged, lse, dO, dKV, dQpart, B, N, C, H, nsplit, st)      \
+    return f16 == 2 ? pool_bwd_x3_t<HD_, true, true>(KV, inducers, merged, lse, dO, dKV, dQpart, B, N, C, H, nsplit, st) \
+           : f16 ? pool_bwd_x3_t<HD_, true>(KV, inducers, merged, lse, dO, dKV, dQpart, B, N, C, H, nsplit, st)      \
                : pool_bwd_x3_t<HD_, false>(KV, inducers, merged, lse, dO, dKV, dQpart, B, N, C, H, nsplit, st)
     switch (C / H) {
         case 16: POOL_BWD(16);
@@ -625,7 +676,8 @@ int pool_attn_bwd_x3_launch(const float* KV, const float* inducers, const float*
 int unpool_attn_bwd_x3_launch(const float* q, const float* kvh, const float* dO, float* dq, float* dkv_part, int B, int N, int C,
                               int H, int tpw, int nchunk, hipStream_t st, int f16) {
 #define UNPOOL_BWD(HD_)                                                                                    \
-    return f16 ? unpool_bwd_x3_t<HD_, true>(q, kvh, dO, dq, dkv_part, B, N, C, H, tpw, nchunk, st)        \
+    return f16 == 2 ? unpool_bwd_x3_t<HD_, true, true>(q, kvh, dO, dq, dkv_part, B, N, C, H, tpw, nchunk, st) \
+           : f16 ? unpool_bwd_x3_t<HD_, true>(q, kvh, dO, dq, dkv_part, B, N, C, H, tpw, nchunk, st)        \
                : unpool_bwd_x3_t<HD_, false>(q, kvh, dO, dq, dkv_part, B, N, C, H, tpw, nchunk, st)
     switch (C / H) {
         case 16: UNPOOL_BWD(16);

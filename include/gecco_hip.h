@@ -416,7 +416,10 @@ int gecco_unpool_attn_bwd_partials(int B, int N, int H);
 int gecco_unpool_attn_bwd_f32(const float* q, const float* kvh, const float* dO, float* dq, float* dkv_partials, int B, int N,
                               int C, int H, int I, void* stream);
 /* the same with the arithmetic selected: precision 0 = exact fp32 MFMA, 1 = split-bf16 (head dims 16 / 32 / 48 / 64; other head
- * dims run the fp32 kernels) */
+ * dims run the fp32 kernels), 2 = fp16 operands (the reference's autocast(float16) backward: one MFMA per product),
+ * 3 (round 6) = 2 with the point-stream tensors as fp16 TENSORS, row-major: pool — KV and dKV (B, N, 2C) halves; unpool — q, dO and dq
+ * (B, N, C) halves (pass the pointers through the float* parameters); the inducer-side tensors (inducers, merged, lse, dO of the pool;
+ * kvh, the dkv partials) stay fp32.  Head dims 16 / 32 / 48 / 64 only. */
 int gecco_pool_attn_bwd_ex_f32(const float* KV, const float* inducers, const float* merged, const float* lse, const float* dO,
                                float* dKV, float* dQ_partials, int B, int N, int C, int H, int I, int precision, void* stream);
 int gecco_unpool_attn_bwd_ex_f32(const float* q, const float* kvh, const float* dO, float* dq, float* dkv_partials, int B, int N,

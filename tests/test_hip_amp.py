@@ -234,6 +234,62 @@ def test_mlp_backward_gradient_as_halves_is_the_same_arithmetic(monkeypatch):
         hip_ops.set_default_precision(prev)
 
 
+@pytest.mark.parametrize("d,N", [(384, 256), (128, 384), (512, 128)])
+def test_fp16_tensors_between_the_training_kernels_are_the_same_arithmetic(d, N, monkeypatch):
+    """Round 6 (`autograd._io16_ok`): under autocast(float16) K | V, q, the unpool attention's output and their gradients are fp16
+    TENSORS between the kernels (as in the reference's autocast run) instead of fp32 tensors every consumer rounds on the way in.
+    A whole training step's loss and parameter gradients against the fp32-tensor path (GECCO_TRAIN_IO16=0): the same operand bits
+    everywhere, so the two agree far inside fp16 rounding (most gradients to the bit; the in_proj / out_proj bias gradients and the
+    attention's row statistics see the halves)."""
+    from gecco_amd import autograd as ag
+    from gecco_amd import hip_ops
+    from tests.test_modules_cpu import build_uncond, uncond_state_dict
+    prev = hip_ops.default_precision()
+    hip_ops.set_default_precision("mixed")
+    try:
+        L = 2
+        sd = uncond_state_dict(W.linear_lift_state_dict(21, d, L, cases.I, cases.H))
+        g = torch.Generator().manual_seed(9)
+        data = torch.randn(3, N, 3, generator=g).cuda()
+        noise = torch.randn(3, N, 3, generator=g).cuda()
+        sigma = torch.tensor([0.05, 0.7, 9.0]).cuda()
+
+        def run(io16):
+            monkeypatch.setenv("GECCO_TRAIN_IO16", io16)
+            ag.WEIGHT_IMAGES.__init__()
+            m = build_uncond(d, L)
+            m.load_state_dict(sd, strict=True)
+            m = m.cuda().train()
+            seen = []
+            orig = ag.PoolAttnFn.forward
+
+            def spy(ctx, KV, ind, H):
+                seen.append(KV.dtype)
+                return orig(ctx, KV, ind, H)
+            monkeypatch.setattr(ag.PoolAttnFn, "forward", staticmethod(spy))
+            s_ = sigma.reshape(-1, 1, 1)
+            with torch.autocast("cuda", dtype=torch.float16):
+                den = m(data + noise * s_, sigma, None)
+                loss = (100.0 * (s_ ** 2 + 1.0) / s_ ** 2 * (den.float() - data) ** 2).mean()
+            (loss * 1024.0).backward()
+            monkeypatch.setattr(ag.PoolAttnFn, "forward", staticmethod(orig))
+            return seen, float(loss.detach()), {n: p.grad.detach().clone() / 1024.0 for n, p in m.named_parameters()}
+        s16, l16, g16 = run("1")
+        s32, l32, g32 = run("0")
+        assert s16 and all(t == torch.float16 for t in s16) and all(t == torch.float32 for t in s32), (s16, s32)
+        assert abs(l16 - l32) <= 2e-4 * abs(l32), (l16, l32)
+        same, worst = 0, (0.0, "")
+        for n in g32:
+            assert torch.isfinite(g16[n]).all(), n
+            e = _rel(g16[n], g32[n])
+            same += int(torch.equal(g16[n], g32[n]))
+            worst = max(worst, (e, n))
+            assert e <= 2e-3, (n, e)
+        print(f"d={d} N={N}: loss {l16:.6f} vs {l32:.6f}; {same} of {len(g32)} gradients bit-identical; worst {worst[1]} {worst[0]:.2e}")
+    finally:
+        hip_ops.set_default_precision(prev)
+
+
 def test_fused_adam_in_the_grad_scaler_protocol_matches_torch():
     """scaler.step(FusedAdamEMA(amp_on_device=True)): the optimizer then declares `_step_supports_amp_scaling` (opt-in, per instance: with
     it Lightning's MixedPrecision plugin would skip unscale_ and refuse gradient clipping), so torch.amp.GradScaler hands it the scale and

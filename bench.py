@@ -1226,7 +1226,7 @@ def main():
                 return {"error": "skipped: the extras' time budget (360 s) is spent"}
             return run_child(argv, timeout=min(cap, left))
         # the training step in the reference's shipped trainer setting (precision="16-mixed": both example configs) ...
-        tr = run_extra(["--train", "--amp", "--steps", "10", "--warmup", "3", "--precision", args.precision])
+        tr = run_extra(["--train", "--amp", "--steps", "20", "--warmup", "3", "--precision", args.precision])
         rec["train"] = tr if "error" in tr else {
             "config": "C2 training step, batch 48/GPU (forward + backward + fused Adam/EMA, HIP autograd path) under torch.autocast(float16) + "
                       "GradScaler — the reference's precision='16-mixed': linears with fp16 operands / fp32 accumulation, fp32 tensors",

@@ -218,7 +218,7 @@ def _image_ok(rows: int, K: int, Nout: int, prec: str = "bf16x3") -> bool:
 
 
 # ------------------------------------------------------------------------------------------- Linear
-def _linear_dx_dot(dy: Tensor, W: Tensor, x: Tensor, prec: str | None = None):
+def _linear_dx_dot(dy: Tensor, W: Tensor, x: Tensor, prec: str | None = None, residual: Tensor | None = None):
     """(dx, gst): dx = dy W and the partial sums {sum dx, sum dx * x} per (sample, row tile, column) that the AdaGN backward of the
     tensor x needs (`_adagn_backward(..., gst=)`), from the GEMM's epilogue (`gecco_linear_dotstats_f32`) instead of a
     `col_dot_stats` pass over dx and x; gst None where the LDS-DMA kernels do not take the shape (the caller's AdaGN backward then
@@ -231,9 +231,10 @@ def _linear_dx_dot(dy: Tensor, W: Tensor, x: Tensor, prec: str | None = None):
         gst = _new(B, lib.gecco_linear_row_tiles(R), 2, K, like=x)
         img = WEIGHT_IMAGES.lookup("t", W, prec="fp16")
         Wt, ws = (None, img) if img is not None else (W.t().contiguous(), hip_ops._ws((K + 127) // 128 * 128 * Nout * 4, dy.device))
-        _lib.check(lib.gecco_linear_dotstats_a16_f32(hip_ops._ptr16(dy), _ptr(Wt), _ptr(x), _ptr(dx), _ptr(gst), B, R, Nout, K,
+        _lib.check(lib.gecco_linear_dotstats_a16_f32(hip_ops._ptr16(dy), _ptr(Wt), _ptr(x), _ptr(residual), _ptr(dx), _ptr(gst), B, R, Nout, K,
                                                      C.c_void_p(ws.data_ptr()), _stream()), "gecco_linear_dotstats_a16_f32")
         return dx, gst
+    assert residual is None, "a residual with the partials: fp16 dy only"
     prec = _resolve(prec, R, Nout, K)
     if (os.environ.get("GECCO_TRAIN_DOTSTATS", "1") == "0" or prec not in ("fp32", "bf16x3", "fp16")
             or not lib.gecco_linear_actbwd_ok(R, Nout, K, hip_ops.PRECISIONS[prec])):
@@ -258,6 +259,11 @@ def _linear_dx(dy: Tensor, W: Tensor, residual: Tensor | None = None, prec: str 
     out_f16 the result leaves as one (no residual then) — the fp16 LDS-DMA kernel either way."""
     B, R, Nout = dy.shape
     K = W.shape[1]
+    if out_f16 and residual is None and dy.dtype == torch.float32 and _a16_ok("fp16", R, Nout, K) and K >= 128:
+        # fp32 gradient in, fp16 gradient out (out_proj's dX in an `_io16_ok` layer): the A-stationary kernel's fp16 row-major epilogue —
+        # dy is read once into registers, against the LDS-DMA kernel's fp32 A tiles (141 -> ~60 us at the shipped shape)
+        ws, ready = _a16_stream("t", W, dev=dy.device)
+        return hip_ops.linear_kvq_f16(dy, None, W.t() if ready else W.t().contiguous(), None, head_dim=0, wsplit=ws, image_ready=ready)
     if dy.dtype == torch.float16 or out_f16:
         img = WEIGHT_IMAGES.lookup("t", W, prec="fp16")
         return hip_ops.linear_f16io(dy, None if img is not None else W.t().contiguous(), residual=residual, out_f16=out_f16, w_image=img,
@@ -666,7 +672,14 @@ class AdaGNPairFn(torch.autograd.Function):
         dKV = _f(dKV) if dKV is not None else x.new_zeros(B, R, W1.shape[0])
         dq = _f(dq) if dq is not None else x.new_zeros(B, R, W2.shape[0])
         prec = ctx.prec
-        dY = _linear_dx(dq, W2, residual=_linear_dx(dKV, W1, prec=prec), prec=prec)
+        gst = None
+        if (dq.dtype == torch.float16 and os.environ.get("GECCO_TRAIN_DOTSTATS", "1") != "0" and os.environ.get("GECCO_TRAIN_DOTRES", "1") != "0"
+                and _lib.load().gecco_linear_actbwd_ok(R, W2.shape[0], Cc, 2) and R >= 128):
+            # fp16-tensor layer: the second dX product adds the first and leaves {sum dY, sum dY x} for the AdaGN backward below
+            # (no col_dot_stats pass over dY and x)
+            dY, gst = _linear_dx_dot(dq, W2, x, prec=prec, residual=_linear_dx(dKV, W1, prec=prec))
+        else:
+            dY = _linear_dx(dq, W2, residual=_linear_dx(dKV, W1, prec=prec), prec=prec)
         dW1 = _linear_dw(dKV, x, pro=(a, o), leaf=W1, prec=prec) if need[9] else None
         dW2 = db2 = None
         if need[10] and ctx.has_b2 and need[11]:
@@ -675,7 +688,7 @@ class AdaGNPairFn(torch.autograd.Function):
             dW2 = _linear_dw(dq, x, pro=(a, o), leaf=W2, prec=prec)
         elif ctx.has_b2 and need[11]:
             db2 = _linear_db(dq.float() if dq.dtype != torch.float32 else dq)
-        dx, dsw, dsb, dbw, dbb, dt = _adagn_backward(x, stats, t2, sw, sb, dY, dskip, ctx.G, ctx.eps, True, bw=bw if need[1] else None)
+        dx, dsw, dsb, dbw, dbb, dt = _adagn_backward(x, stats, t2, sw, sb, dY, dskip, ctx.G, ctx.eps, True, gst=gst, bw=bw if need[1] else None)
         return dx, (dt.reshape(ctx.t_shape) if dt is not None else None), dsw, dsb, dbw, dbb, None, None, None, dW1, dW2, db2, None
 
 

@@ -894,11 +894,11 @@ int gecco_linear_dotstats_f32(const float* A, const float* W, const float* dot_x
     return 0;
 }
 
-int gecco_linear_dotstats_a16_f32(const void* A16, const float* W, const float* dot_x, float* C, float* stats, int B, int rows, int K, int Nout,
-                                  void* wsplit, void* stream) {
+int gecco_linear_dotstats_a16_f32(const void* A16, const float* W, const float* dot_x, const float* residual, float* C, float* stats, int B, int rows,
+                                  int K, int Nout, void* wsplit, void* stream) {
     if (!A16 || !dot_x || !C || !stats || !wsplit) return fail(-1, "linear_dotstats_a16: null argument");
     if (!gecco_linear_actbwd_ok(rows, K, Nout, 2) || (K & 7) || rows < 128) return fail(-2, "linear_dotstats_a16: shape outside the fp16 LDS-DMA kernel's reach");
-    int rc = linear(static_cast<const float*>(A16), W, nullptr, nullptr, nullptr, nullptr, nullptr, C, stats, B, rows, K, Nout, 0, (hipStream_t)stream, 2,
+    int rc = linear(static_cast<const float*>(A16), W, nullptr, nullptr, nullptr, nullptr, residual, C, stats, B, rows, K, Nout, 0, (hipStream_t)stream, 2,
                     W ? static_cast<float*>(wsplit) : nullptr, W ? nullptr : static_cast<const float*>(wsplit), 1, 0, 0, 0, nullptr, 0, nullptr, nullptr,
                     dot_x);
     if (rc == -9) return fail(-2, "linear_dotstats_a16: shape outside the fp16 LDS-DMA kernel's reach");

@@ -167,7 +167,10 @@ __global__ __launch_bounds__(256) void pool_attn_bwd_x3_kernel(const float* __re
     // 64 KB block of the weight-gradient kernel (side stream) fits next to it on the CU
     constexpr bool T_OVER_V = DT == 2;
     static_assert(!T_OVER_V || PT == P32, "the aliased planes have one size");
-    constexpr int WAVE_E = 4 * P32 + (T_OVER_V ? 0 : 2 * PT);
+    // F16: one plane per operand — the lo planes do not exist (their pointers alias the hi planes: never written, their fragment reads are
+    // dead code): half the LDS, two to three blocks per CU instead of one (round 6: the kernel is latency-bound at one wave per SIMD)
+    constexpr int NPL = F16 ? 1 : 2;
+    constexpr int WAVE_E = NPL * (2 * P32 + (T_OVER_V ? 0 : PT));
     extern __shared__ __attribute__((aligned(16))) float smem[];
     u16* lds = reinterpret_cast<u16*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -176,16 +179,16 @@ __global__ __launch_bounds__(256) void pool_attn_bwd_x3_kernel(const float* __re
     const int b = bh / H, hh = bh % H;
 
     u16* Qhi = lds;                 // inducer queries of this head (raw), [64][DT blocks]
-    u16* Qlo = Qhi + P64;
+    u16* Qlo = F16 ? Qhi : Qhi + P64;
     u16* Ghi = Qlo + P64;           // dO rows of (b, head)
-    u16* Glo = Ghi + P64;
+    u16* Glo = F16 ? Ghi : Ghi + P64;
     float* Ls = reinterpret_cast<float*>(Glo + P64);   // [64] lse2, [64] D
     u16* Khi = reinterpret_cast<u16*>(Ls + 128) + wave * WAVE_E;
-    u16* Klo = Khi + P32;
+    u16* Klo = F16 ? Khi : Khi + P32;
     u16* Vhi = Klo + P32;
-    u16* Vlo = Vhi + P32;
+    u16* Vlo = F16 ? Vhi : Vhi + P32;
     u16* Thi = T_OVER_V ? Vhi : Vlo + P32;   // P, then dS, as [query][key]
-    u16* Tlo = T_OVER_V ? Vlo : Thi + PT;
+    u16* Tlo = F16 ? Thi : (T_OVER_V ? Vlo : Thi + PT);
 
     const int ks = (((N + nsplit - 1) / nsplit) + 31) / 32 * 32;
     const int k_begin = split * ks, k_end = min(N, k_begin + ks);
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(256) void pool_attn_bwd_x3_kernel(const float* __re
 
     // zero everything once: the padding columns of the last block (HD = 16, 48) enter products whose results are dropped,
     // but must not hold NaN patterns a later pass could propagate
-    for (int f = tid; f < (int)((4 * P64 + 4 * WAVE_E) / 2 + 128); f += 256) reinterpret_cast<unsigned*>(lds)[f] = 0u;
+    for (int f = tid; f < (int)((2 * NPL * P64 + 4 * WAVE_E) / 2 + 128); f += 256) reinterpret_cast<unsigned*>(lds)[f] = 0u;
     __syncthreads();
     for (int f = tid; f < 64 * CH; f += 256) {
         const int row = f / CH, ch = f % CH;
@@ -394,10 +397,11 @@ __global__ __launch_bounds__(256) void unpool_attn_bwd_x3_kernel(const float* __
     constexpr int DT = (HD + 31) / 32, CH = HD / 4, LD_IT = (32 * CH + 63) / 64, NC = HD / 16, KP = HD + 4;
     constexpr int P64 = 16 * DT * 128, P32 = 8 * DT * 128;
     constexpr int PT = 8 * 2 * 128;      // the P / dS plane: 32 rows (queries) x 64 columns (inducers)
-    constexpr int WAVE_E = 2 * PT + 4 * P32;
-    // the fp32 staging tile of the dq rows lies over the T planes (and, for hd = 64, the first bytes of the q planes): all
-    // dead by then, and rewritten in full before the next tile reads them
-    static_assert(32 * KP * 4 <= (2 * PT + 2 * P32) * 2, "the dq staging tile fits over the dead T | q planes");
+    constexpr int NPL = F16 ? 1 : 2;     // F16: one plane per operand (see the pool kernel): 64 KiB per block instead of 128
+    constexpr int WAVE_E = NPL * (PT + 2 * P32);
+    // the fp32 staging tile of the dq rows lies over the T planes and the q planes (F16, hd = 64: and the first bytes of the dO plane):
+    // all dead by then, and rewritten in full before the next tile reads them
+    static_assert(32 * KP * 4 <= WAVE_E * 2, "the dq staging tile fits over the dead T | q | dO planes");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     u16* lds = reinterpret_cast<u16*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -406,18 +410,18 @@ __global__ __launch_bounds__(256) void unpool_attn_bwd_x3_kernel(const float* __
     const int b = bh / H, hh = bh % H;
 
     u16* Khi = lds;                 // inducer keys / values of (b, head), [64][DT blocks]
-    u16* Klo = Khi + P64;
+    u16* Klo = F16 ? Khi : Khi + P64;
     u16* Vhi = Klo + P64;
-    u16* Vlo = Vhi + P64;
+    u16* Vlo = F16 ? Vhi : Vhi + P64;
     u16* Thi = Vlo + P64 + wave * WAVE_E;   // P, then dS, as [query][inducer]
-    u16* Tlo = Thi + PT;
+    u16* Tlo = F16 ? Thi : Thi + PT;
     u16* Qhi = Tlo + PT;            // the tile's raw queries
-    u16* Qlo = Qhi + P32;
+    u16* Qlo = F16 ? Qhi : Qhi + P32;
     u16* Ghi = Qlo + P32;           // the tile's dO rows
-    u16* Glo = Ghi + P32;
+    u16* Glo = F16 ? Ghi : Ghi + P32;
     float* St = reinterpret_cast<float*>(Thi);   // [32][KP] fp32 staging of dq rows, over the dead T | q planes
 
-    for (int f = tid; f < (int)((4 * P64 + 4 * WAVE_E) / 2); f += 256) reinterpret_cast<unsigned*>(lds)[f] = 0u;
+    for (int f = tid; f < (int)((2 * NPL * P64 + 4 * WAVE_E) / 2); f += 256) reinterpret_cast<unsigned*>(lds)[f] = 0u;
     __syncthreads();
     for (int f = tid; f < 64 * CH; f += 256) {
         const int row = f / CH, ch = f % CH;
@@ -600,34 +604,42 @@ __global__ __launch_bounds__(256) void unpool_attn_bwd_x3_kernel(const float* __
     }
     __syncthreads();
 
-    // ---- sum the four waves' dk | dv in wave order: partial of this (chunk, b, head)
-    float* Dw = smem;   // [4 waves][2 (k, v)][64][HD]
+    // ---- sum the four waves' dk | dv in a fixed order, (w0 + w2) + (w1 + w3): partial of this (chunk, b, head).  Two rounds through
+    // TWO wave slots (round 6: half the LDS of four slots — with one plane per operand it was what kept a second block off the CU)
+    float* Dw = smem;   // [2 slots][2 (k, v)][64][HD]
+    auto slot_io = [&](int slot, bool add, bool store) {
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+        for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+            for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int i = rt * 32 + mfma_row(e, h), d = dt * 32 + r;
-                if (d < HD) {
-                    Dw[((wave * 2 + 0) * 64 + i) * HD + d] = dk[rt][dt][e];
-                    Dw[((wave * 2 + 1) * 64 + i) * HD + d] = dv[rt][dt][e];
+                for (int e = 0; e < 16; ++e) {
+                    const int i = rt * 32 + mfma_row(e, h), d = dt * 32 + r;
+                    if (d < HD) {
+                        float* pk = Dw + ((slot * 2 + 0) * 64 + i) * HD + d;
+                        float* pv = Dw + ((slot * 2 + 1) * 64 + i) * HD + d;
+                        if (add) { dk[rt][dt][e] += *pk; dv[rt][dt][e] += *pv; }
+                        if (store) { *pk = dk[rt][dt][e]; *pv = dv[rt][dt][e]; }
+                    }
                 }
-            }
+    };
+    if (wave >= 2) slot_io(wave - 2, false, true);
+    __syncthreads();
+    if (wave < 2) slot_io(wave, true, true);     // a lane adds what the same lane of wave + 2 stored, then stores the sum
     __syncthreads();
     float* out = dkv_part + ((size_t)chunk * B + b) * 64 * 2 * C + hh * HD;
     for (int f = tid; f < 2 * 64 * HD; f += 256) {
         const int kv = f / (64 * HD), i = (f / HD) % 64, d = f % HD;
         const int o = (kv * 64 + i) * HD + d;
-        out[(size_t)i * 2 * C + kv * C + d] = ((Dw[o] + Dw[o + 2 * 64 * HD]) + Dw[o + 4 * 64 * HD]) + Dw[o + 6 * 64 * HD];
+        out[(size_t)i * 2 * C + kv * C + d] = Dw[o] + Dw[o + 2 * 64 * HD];
     }
 }
 
 template <int HD, bool F16, bool IO16 = false>
 int pool_bwd_x3_t(const float* KV, const float* ind, const float* O, const float* lse, const float* dO, float* dKV, float* dQp,
                   int B, int N, int C, int H, int nsplit, hipStream_t st) {
-    constexpr int DT = (HD + 31) / 32;
-    const size_t a = (size_t)(4 * 16 * DT * 128 + 4 * (4 * 8 * DT * 128 + (DT == 2 ? 0 : 2 * 16 * 128))) * 2 + 128 * 4, c = (size_t)4 * HD * 64 * 4;
+    constexpr int DT = (HD + 31) / 32, NPL = F16 ? 1 : 2;
+    const size_t a = (size_t)NPL * (2 * 16 * DT * 128 + 4 * (2 * 8 * DT * 128 + (DT == 2 ? 0 : 16 * 128))) * 2 + 128 * 4, c = (size_t)4 * HD * 64 * 4;
     const size_t lds = a > c ? a : c;
     static bool attr_set = false;
     if (!attr_set) {
@@ -641,8 +653,8 @@ int pool_bwd_x3_t(const float* KV, const float* ind, const float* O, const float
 template <int HD, bool F16, bool IO16 = false>
 int unpool_bwd_x3_t(const float* q, const float* kvh, const float* dO, float* dq, float* part, int B, int N, int C, int H, int tpw,
                     int nchunk, hipStream_t st) {
-    constexpr int DT = (HD + 31) / 32;
-    const size_t a = (size_t)(4 * 16 * DT * 128 + 4 * (2 * 8 * 2 * 128 + 4 * 8 * DT * 128)) * 2, c = (size_t)8 * 64 * HD * 4;
+    constexpr int DT = (HD + 31) / 32, NPL = F16 ? 1 : 2;
+    const size_t a = (size_t)NPL * (2 * 16 * DT * 128 + 4 * (8 * 2 * 128 + 2 * 8 * DT * 128)) * 2, c = (size_t)4 * 64 * HD * 4;
     const size_t lds = a > c ? a : c;
     static bool attr_set = false;
     if (!attr_set) {

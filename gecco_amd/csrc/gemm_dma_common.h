@@ -108,6 +108,10 @@ __device__ __forceinline__ void epilogue_t(const GemmArgs& g, const Tile& t, f32
             const int mrow0 = m0 + (wm * TMW + i) * 32;
             // the residual rows of this sub-tile: all eight 16-byte loads in flight at once, issued before the
             // transpose below so their HBM latency is paid once per sub-tile and partly under it
+            // (ACTBWD) residual AND dot_x (round 6: the second dX product of kv_proj | q_proj adds the first and leaves the AdaGN backward's
+            // partials): the x rows are loaded into rres once the residual rows are consumed, the statistics run a second pass over the
+            // tile's final values, which the first pass writes back into the wave's transpose tile
+            const bool res_and_dot = ACTBWD && Rb != nullptr && Xb != nullptr;
             f32x4 rres[8];
             if (Rb) {
 #pragma unroll
@@ -225,8 +229,13 @@ __device__ __forceinline__ void epilogue_t(const GemmArgs& g, const Tile& t, f32
                         for (int q = 0; q < 4; ++q) v4[q] = act_apply(v4[q], neg_inv_2a2, act_mode);
                     }
                 }
-                if (Rb) v4 += rres[it];
-                else if (ACTBWD && Ub) {
+                if (Rb) {
+                    v4 += rres[it];
+                    if (res_and_dot) {   // (block-uniform)
+                        *reinterpret_cast<f32x4*>(Tt + (it * 4 + lr) * D_TP + c4 * 4) = v4;   // own piece: no other lane touches it
+                        rres[it] = GECCO_NT_LOAD(reinterpret_cast<const f32x4*>(Xb + (size_t)min(m, g.rows - 1) * ldc_seg + nc));
+                    }
+                } else if (ACTBWD && Ub) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         float da;
@@ -248,6 +257,7 @@ __device__ __forceinline__ void epilogue_t(const GemmArgs& g, const Tile& t, f32
                 } else if (ok) {
                     GECCO_NT_STORE(v4, reinterpret_cast<f32x4*>(Cb + (size_t)m * ldc_seg + n));
                 }
+                if (res_and_dot) continue;   // statistics: the pass below
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
                 const f32x4 vz = ok ? v4 : z;
                 s1[jh] += vz;
@@ -259,6 +269,19 @@ __device__ __forceinline__ void epilogue_t(const GemmArgs& g, const Tile& t, f32
                 } else {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) s2[jh][q] = __builtin_fmaf(vz[q], vz[q], s2[jh][q]);
+                }
+            }
+            if (res_and_dot) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int m = mrow0 + it * 4 + lr;
+                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(Tt + (it * 4 + lr) * D_TP + c4 * 4);
+                    const bool ok = nok && m < g.rows;
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    const f32x4 vz = ok ? v4 : z;
+                    s1[jh] += vz;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) s2[jh][q] = __builtin_fmaf(vz[q], rres[it][q], s2[jh][q]);
                 }
             }
         }

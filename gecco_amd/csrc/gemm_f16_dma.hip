@@ -362,9 +362,9 @@ int f16_launch_t(const GemmArgs& g, hipStream_t st) {
         attr = lds;
     }
     const dim3 grid(g.B * tilesM * tilesN);
-    if (g.dot_x && (g.residual || g.mul_u || g.pre_out || !g.stats || g.C2 || C16)) return -9;
+    if (g.dot_x && (g.mul_u || g.pre_out || !g.stats || g.C2 || C16 || (g.residual && !A16))) return -9;
     if constexpr (A16 && !C16) {
-        if (g.dot_x) {   // the dX product of an MLP's first linear from du stored as halves (autograd.py `_du16_ok`), with the AdaGN backward's partials
+        if (g.dot_x) {   // (with or without a residual: gemm_dma_common.h res_and_dot)   // the dX product of an MLP's first linear from du stored as halves (autograd.py `_du16_ok`), with the AdaGN backward's partials
             static size_t attr3 = 0;
             if (lds > attr3) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<DNS, false, BM, true, false, true>),

@@ -893,6 +893,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kvq_astat_kernel(GemmArgs g) {
     for (int p = 0; p < NS - 1; ++p) issue();
 
     f16x8 fa[2 * NG][2];
+    // h8_scales.h: an operand that meets an fp8 term is clamped to +-3584 (the scaled conversions return NaN beyond the format).  A RAW
+    // operand (no AdaGN apply) of a one-term stream is a gradient of the training path (autograd.py `_linear_dx`, the activation
+    // backward): it keeps fp16's whole range — a loss-scaled value beyond 3584 must not saturate silently, and one beyond 65504 becomes
+    // the inf the GradScaler looks for (round 6; until then every operand was clamped)
+    const float a_lim = (g.pro_a != nullptr || lo_end > lo_begin) ? H8_A_MAX : __builtin_inff();
     {
         const float* xw = g.A + ((size_t)b * g.rows + m0 + wave * 32) * g.lda;
         char* sw = reinterpret_cast<char*>(stg + wave * 1024);
@@ -914,7 +919,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kvq_astat_kernel(GemmArgs g) {
                 const int row = 4 * i + lrow;
                 f16x4 hv;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) hv[e] = (_Float16)h8_clamp(__builtin_fmaf(xs[s & 1][i][e], pa4[e], po4[e]));
+                for (int e = 0; e < 4; ++e) hv[e] = (_Float16)__builtin_amdgcn_fmed3f(__builtin_fmaf(xs[s & 1][i][e], pa4[e], po4[e]), -a_lim, a_lim);
                 *reinterpret_cast<u32x2*>(sw + row * 128 + (((c16 >> 1) ^ (row & 7)) << 4) + (c16 & 1) * 8) = __builtin_bit_cast(u32x2, hv);
             }
             __builtin_amdgcn_wave_barrier();

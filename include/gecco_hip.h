@@ -190,10 +190,11 @@ int gecco_linear_actbwd_f32(const float* A, const float* W, const float* u, cons
  * models/normalization.py:36-44 behind a linear: set_transformer.py:165-166).  Shapes: gecco_linear_actbwd_ok; W == NULL: image ready. */
 int gecco_linear_dotstats_f32(const float* A, const float* W, const float* dot_x, float* C, float* stats, int B, int rows, int K, int Nout,
                               int precision, void* wsplit, void* stream);
-/* The same from an fp16 A tensor (the du of gecco_linear_astat16_actbwd_h16), fp16 arithmetic: C = A16 W^T (fp32) + the {sum C, sum C x}
- * partials.  rows >= 128, K % 32 == 0.  W == NULL: wsplit holds the ready fp16 image. */
-int gecco_linear_dotstats_a16_f32(const void* A16, const float* W, const float* dot_x, float* C, float* stats, int B, int rows, int K, int Nout,
-                                  void* wsplit, void* stream);
+/* The same from an fp16 A tensor (the du of gecco_linear_astat16_actbwd_h16; the dq of an fp16-tensor layer), fp16 arithmetic:
+ * C = A16 W^T + residual (fp32; residual may be NULL: another gradient contribution to the same tensor) + the {sum C, sum C x} partials of
+ * the SUM.  rows >= 128, K % 32 == 0.  W == NULL: wsplit holds the ready fp16 image. */
+int gecco_linear_dotstats_a16_f32(const void* A16, const float* W, const float* dot_x, const float* residual, float* C, float* stats, int B,
+                                  int rows, int K, int Nout, void* wsplit, void* stream);
 /* Its forward companion: C = act(A W^T + bias) AND pre_out = A W^T + bias (the u the backward needs) from one epilogue — the
  * training forward of Linear -> act without a separate activation pass.  act 1 / 2 / 3 / 4 as above; W == NULL: image ready. */
 int gecco_linear_act_keep_f32(const float* A, const float* W, const float* bias, const float* alpha, int act, float* pre_out,

@@ -112,6 +112,7 @@ SIGNATURES = {
     "gecco_gemm_tn_f16_tiles": (i, [i, i]),
     "gecco_gemm_tn_f16_b16_f32": (i, [vp, vp, vp, vp, i, i, i, i, i, vp]),
     "gecco_gemm_tn_f16_a16_f32": (i, [vp, vp, vp, vp, vp, vp, i, i, i, i, i, vp]),
+    "gecco_gemm_tn_f16_ex_f32": (i, [vp, i, vp, i, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, vp]),
     "gecco_linear_dotstats_a16_f32": (i, [vp] * 6 + [i, i, i, i, vp, vp]),
     "gecco_linear_astat16_actbwd_h16": (i, [vp] * 4 + [i, vp, vp, i, i, i, i, vp, vp]),
     "gecco_linear_dotstats_f32": (i, [vp] * 5 + [i, i, i, i, i, vp, vp]),

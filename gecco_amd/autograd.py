@@ -313,11 +313,14 @@ def sync_side_stream() -> None:
         _SIDE["pending"] = False
 
 
-def _linear_dw(dy: Tensor, x: Tensor, want_db: bool = False, pro=None, leaf: Tensor | None = None, prec: str | None = None):
+def _linear_dw(dy: Tensor, x: Tensor, want_db: bool = False, pro=None, leaf: Tensor | None = None, prec: str | None = None,
+               side_ok: bool = False):
     """leaf: the parameter this gradient is FOR, when the caller knows that nothing will read the result before the pass ends —
     a leaf that is not a view (a view's gradient is scattered into its base by autograd, on the main stream, right away) and
-    has no .grad yet (autograd then keeps the tensor instead of adding it into an existing one).  Only then the side stream."""
-    if leaf is None or not (leaf.is_leaf and leaf._base is None and leaf.grad is None) or not _side_enabled():
+    has no .grad yet (autograd then keeps the tensor instead of adding it into an existing one).  Only then the side stream.
+    side_ok (round 6): the weight is a third of nn.MultiheadAttention's packed in_proj handed out by `InProjSplitFn`, whose backward joins
+    the thirds' gradients ON the side stream (`_inproj_side_ok` checked the packed parameter at forward time)."""
+    if not _side_enabled() or not (side_ok or (leaf is not None and leaf.is_leaf and leaf._base is None and leaf.grad is None)):
         return _linear_dw_main(dy, x, want_db, pro, prec)
     if _SIDE["stream"] is None:
         _SIDE["stream"] = torch.cuda.Stream()
@@ -336,6 +339,24 @@ def _linear_dw(dy: Tensor, x: Tensor, want_db: bool = False, pro=None, leaf: Ten
     except RuntimeError:   # not inside a backward pass: order it right away
         sync_side_stream()
     return res
+
+
+_TN_CTR: dict = {}
+
+
+def _tn_counters(dev, tiles: int) -> Tensor:
+    """`tiles` zeroed counters for one weight-gradient launch (gecco_gemm_tn_f16_ex_f32 leaves them zero again): slots of one ring per
+    device, handed out round-robin — a slot comes round again thousands of launches later, long after its launch has finished."""
+    key = (dev.type, dev.index)
+    st = _TN_CTR.get(key)
+    if st is None:
+        st = _TN_CTR[key] = [torch.zeros(1 << 16, dtype=torch.int32, device=dev), 0]
+        torch.cuda.synchronize(dev)   # (once: the fill is ordered in front of every stream that will use the ring)
+    if st[1] + tiles > st[0].numel():
+        st[1] = 0
+    off = st[1]
+    st[1] += tiles
+    return st[0][off:off + tiles]
 
 
 def _linear_dw_main(dy: Tensor, x: Tensor, want_db: bool = False, pro=None, prec: str | None = None):
@@ -364,6 +385,21 @@ def _linear_dw_main(dy: Tensor, x: Tensor, want_db: bool = False, pro=None, prec
         G = -(-B // group)
         parts = _new(G, Nout, K, like=x)
         cparts = _new(G, Nout, like=x) if want_db else None
+        if os.environ.get("GECCO_TRAIN_DW_REDUCE", "launch") == "kernel":
+            # OPT-IN (measured and lost, profiles/r06_negative_results.txt): the fixed-order sum of the group partials inside the launch —
+            # the last block to finish a tile adds them in group order, the bits `_reduce` gives without its ~100 launches per step.  One
+            # block per tile then reads 24 x 64 KiB behind everybody else (18 CUs busy, 238 idle): 16.75 -> 21.4 ms per step; the separate
+            # reduction spreads the same bytes over the whole chip in ~10 us
+            dW = _new(Nout, K, like=x)
+            db = _new(Nout, like=x) if want_db else None
+            ctr = _tn_counters(x.device, tiles)
+            a16, b16 = dy.dtype == torch.float16, x.dtype == torch.float16
+            assert not (b16 and pro is not None)
+            _lib.check(_lib.load().gecco_gemm_tn_f16_ex_f32(
+                C.c_void_p(dy.data_ptr()), int(a16), C.c_void_p(x.data_ptr()), int(b16), _ptr(pro[0]) if pro is not None else None,
+                _ptr(pro[1]) if pro is not None else None, _ptr(parts), _ptr(cparts), _ptr(dW), _ptr(db), C.c_void_p(ctr.data_ptr()),
+                B, R, Nout, K, group, _stream()), "gecco_gemm_tn_f16_ex_f32")
+            return (dW, db) if want_db else dW
         if dy.dtype == torch.float16:   # du of an MLP's backward stored as halves (`_du16_ok`)
             assert x.dtype == torch.float32
             _lib.check(_lib.load().gecco_gemm_tn_f16_a16_f32(hip_ops._ptr16(dy), _ptr(x), _ptr(pro[0]) if pro is not None else None,
@@ -442,6 +478,7 @@ class LinearFn(torch.autograd.Function):
         x = _f(x)
         ctx.save_for_backward(x, W)
         ctx.has_bias = b is not None
+        ctx.side_ok = bool(getattr(W, "_gecco_side_ok", False))
         prec = ctx.prec = _lin_precision()
         res = None if residual is None else _f(residual)
         if x.dtype == torch.float16:   # an fp16 tensor of an `_io16_ok` layer (the unpool attention's output): fp16 A tiles, fp32 result
@@ -472,9 +509,9 @@ class LinearFn(torch.autograd.Function):
         dx = _linear_dx(dy, W, prec=prec, out_f16=x.dtype == torch.float16) if ctx.needs_input_grad[0] else None
         dW = db = None
         if ctx.has_bias and ctx.needs_input_grad[2] and ctx.needs_input_grad[1]:
-            dW, db = _linear_dw(dy, x, want_db=True, leaf=W, prec=prec)
+            dW, db = _linear_dw(dy, x, want_db=True, leaf=W, prec=prec, side_ok=ctx.side_ok)
         elif ctx.needs_input_grad[1]:
-            dW = _linear_dw(dy, x, leaf=W, prec=prec)
+            dW = _linear_dw(dy, x, leaf=W, prec=prec, side_ok=ctx.side_ok)
         elif ctx.has_bias and ctx.needs_input_grad[2]:
             db = _linear_db(dy)
         n = len(ctx.needs_input_grad)        # 3 .. 5: called without / with a residual (and the statistics flag)
@@ -629,6 +666,7 @@ class AdaGNPairFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         a, o, stats, t2 = _adagn_coeffs(x, t, sw, sb, bw, bb, G, eps, stats)
         prec = ctx.prec = _lin_precision()   # "bf16x3" or "fp16" (_pro_ok)
+        ctx.side2 = bool(getattr(W2, "_gecco_side_ok", False))
         B, R, K = x.shape
         N1, N2 = W1.shape[0], W2.shape[0]
         if io16:   # (`_io16_ok`) K | V and q as fp16 tensors: the same A-stationary kernel, its fp16 row-major epilogue
@@ -683,9 +721,9 @@ class AdaGNPairFn(torch.autograd.Function):
         dW1 = _linear_dw(dKV, x, pro=(a, o), leaf=W1, prec=prec) if need[9] else None
         dW2 = db2 = None
         if need[10] and ctx.has_b2 and need[11]:
-            dW2, db2 = _linear_dw(dq, x, want_db=True, pro=(a, o), leaf=W2, prec=prec)
+            dW2, db2 = _linear_dw(dq, x, want_db=True, pro=(a, o), leaf=W2, prec=prec, side_ok=ctx.side2)
         elif need[10]:
-            dW2 = _linear_dw(dq, x, pro=(a, o), leaf=W2, prec=prec)
+            dW2 = _linear_dw(dq, x, pro=(a, o), leaf=W2, prec=prec, side_ok=ctx.side2)
         elif ctx.has_b2 and need[11]:
             db2 = _linear_db(dq.float() if dq.dtype != torch.float32 else dq)
         dx, dsw, dsb, dbw, dbb, dt = _adagn_backward(x, stats, t2, sw, sb, dY, dskip, ctx.G, ctx.eps, True, gst=gst, bw=bw if need[1] else None)
@@ -1625,6 +1663,13 @@ def convnext_pyramid(ext, image: Tensor) -> list[Tensor]:
     return feats
 
 
+def _inproj_side_ok(W: Tensor, b: Tensor) -> bool:
+    """The packed in_proj parameters are plain leaves without a gradient yet (`zero_grad(set_to_none=True)`): autograd will KEEP the joined
+    gradient instead of adding it into an existing one, so the thirds' weight gradients and their join may live on the side stream."""
+    return (os.environ.get("GECCO_TRAIN_INPROJ_SIDE", "1") != "0" and _side_enabled()
+            and all(t.is_leaf and t._base is None and t.grad is None and t.requires_grad for t in (W, b)))
+
+
 class InProjSplitFn(torch.autograd.Function):
     """nn.MultiheadAttention's packed in_proj (weight (3C, C), bias (3C)) as its query third and its key | value two thirds — views, as
     `W[:C]`, `W[C:]` are (models/set_transformer.py:112 -> torch's in_proj packing).  Autograd's own slice backward builds, per slice, a
@@ -1635,6 +1680,7 @@ class InProjSplitFn(torch.autograd.Function):
     def forward(ctx, W, b, Cc):
         ctx.Cc = Cc
         ctx.set_materialize_grads(False)
+        ctx.side_join = _inproj_side_ok(W, b)
         return W[:Cc], b[:Cc], W[Cc:], b[Cc:]
 
     @staticmethod
@@ -1648,6 +1694,26 @@ class InProjSplitFn(torch.autograd.Function):
             a = ref.new_zeros(rows_a, *ref.shape[1:]) if a is None else a
             b_ = ref.new_zeros(rows_b, *ref.shape[1:]) if b_ is None else b_
             return torch.cat([a, b_], 0)
+        if ctx.side_join and _SIDE["stream"] is not None and _side_enabled():
+            # the thirds' gradients were formed on the weight-gradient side stream (`_linear_dw(side_ok=True)`): join them there, in its
+            # order; the packed parameter has no .grad yet, so autograd only keeps the result — nothing on the main stream reads it before
+            # the pass-end callback (or the data-parallel reducer's explicit sync) has ordered the side stream in front
+            side, main = _SIDE["stream"], torch.cuda.current_stream()
+            side.wait_stream(main)       # (a third that was formed on the main stream after all)
+            with torch.cuda.stream(side):
+                gW, gb = join(gWq, gWkv, Cc, 2 * Cc), join(gbq, gbkv, Cc, 2 * Cc)
+            for t in (gWq, gbq, gWkv, gbkv):
+                if t is not None:
+                    t.record_stream(side)
+            for t in (gW, gb):
+                if t is not None:
+                    t.record_stream(main)
+            _SIDE["pending"] = True
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(sync_side_stream)
+            except RuntimeError:
+                sync_side_stream()
+            return gW, gb, None
         return join(gWq, gWkv, Cc, 2 * Cc), join(gbq, gbkv, Cc, 2 * Cc), None
 
 
@@ -1703,6 +1769,8 @@ def broadcasting_layer(layer, x, t, h=None, stats=None, want_stats=False):
     R = x.shape[1]
     if os.environ.get("GECCO_TRAIN_INPROJ_SPLIT", "1") != "0":
         Wq, bq, Wkv, bkv = InProjSplitFn.apply(bc.unpool.in_proj_weight, bc.unpool.in_proj_bias, Cc)
+        if _inproj_side_ok(bc.unpool.in_proj_weight, bc.unpool.in_proj_bias):
+            Wq._gecco_side_ok = Wkv._gecco_side_ok = True    # (read by the Functions that differentiate with respect to them)
     else:   # plain slices: autograd's slice backward (A/B runs)
         W_, b_ = bc.unpool.in_proj_weight, bc.unpool.in_proj_bias
         Wq, bq, Wkv, bkv = W_[:Cc], b_[:Cc], W_[Cc:], b_[Cc:]

@@ -1371,6 +1371,24 @@ int gecco_gemm_tn_f16_b16_f32(const float* A, const void* B16, float* parts, flo
     return 0;
 }
 
+int gecco_gemm_tn_f16_ex_f32(const void* A, int a_f16, const void* Bm, int b_f16, const float* pro_a, const float* pro_o, float* parts,
+                             float* colsum_parts, float* out, float* colsum_out, unsigned* counters, int Z, int R, int N, int K, int group,
+                             void* stream) {
+    if (!A || !Bm || !parts) return fail(-1, "gemm_tn_f16_ex: null argument");
+    if ((pro_a == nullptr) != (pro_o == nullptr)) return fail(-1, "gemm_tn_f16_ex: pro_a / pro_o must both be set");
+    if ((counters != nullptr) != (out != nullptr) || (colsum_out && !(colsum_parts && counters)))
+        return fail(-1, "gemm_tn_f16_ex: counters and out go together; colsum_out needs colsum_parts and counters");
+    if (a_f16 && b_f16) return fail(-2, "gemm_tn_f16_ex: at most one operand is an fp16 tensor");
+    TnArgs g{};
+    g.pro_a = pro_a; g.pro_o = pro_o; g.f16 = 1; g.a_f16 = a_f16 != 0; g.b_f16 = b_f16 != 0;
+    g.A = static_cast<const float*>(A); g.Bm = static_cast<const float*>(Bm); g.C = parts; g.Z = Z; g.R = R; g.N = N; g.K = K; g.lda = N; g.ldb = K;
+    g.sA = (size_t)R * N; g.sB = (size_t)R * K; g.group = group; g.colsum = colsum_parts;
+    g.counters = counters; g.out = out; g.colsum_out = colsum_out;
+    if (!gemm_tn_f16_supported(g)) return fail(-2, "gemm_tn_f16_ex: needs R %% 32 == 0, N %% 4 == 0, K %% 4 == 0 (8 for an fp16 operand's width), group > 0");
+    TRY(gemm_tn_f16_launch(g, (hipStream_t)stream), "gemm_tn_f16_ex");
+    return 0;
+}
+
 int gecco_gemm_tn_f16_a16_f32(const void* A16, const float* Bm, const float* pro_a, const float* pro_o, float* parts, float* colsum_parts,
                               int Z, int R, int N, int K, int group, void* stream) {
     if (!A16 || !Bm || !parts) return fail(-1, "gemm_tn_f16_a16: null argument");

@@ -275,6 +275,45 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f16_kernel(TnArgs g) {
                 const int n = n0 + (wn * WNT + i) * 32 + mfma_row(e, h), k = k0 + (wk * WKT + j) * 32 + r;
                 if (n < g.N && k < g.K) Cb[(size_t)n * g.K + k] = acc[i][j][e];
             }
+    if (g.counters == nullptr) return;
+    // ---- the fixed-order sum of the tile's group partials, by the LAST group block to finish it (no reduce_batch launch): every block
+    // publishes its partial (release fence), takes a ticket, and the holder of the last one reads all G partials behind an acquire
+    // fence and adds them in group order — exactly reduce_batch_kernel's 0 + p0 + p1 + ..: bit-identical, run-to-run deterministic
+    const int G = (int)gridDim.y;
+    __threadfence();
+    __syncthreads();
+    unsigned* tick = reinterpret_cast<unsigned*>(smem);
+    if (tid == 0) *tick = atomicAdd(g.counters + bx, 1u);
+    __syncthreads();
+    if (*tick != (unsigned)(G - 1)) return;
+    __threadfence();
+    const size_t NK = (size_t)g.N * g.K;
+    for (int e = tid; e < TN * (TK / 4); e += 256) {
+        const int n = n0 + e / (TK / 4), k = k0 + (e % (TK / 4)) * 4;
+        if (n >= g.N || k >= g.K) continue;     // (K % 4 == 0: a piece is whole or absent)
+        const float* src = g.C + (size_t)n * g.K + k;
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        int z = 0;
+        for (; z + 8 <= G; z += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (size_t)(z + u) * NK));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sum += v[u];
+        }
+        for (; z < G; ++z) sum += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (size_t)z * NK));
+        *reinterpret_cast<f32x4*>(g.out + (size_t)n * g.K + k) = sum;
+    }
+    if (g.colsum != nullptr && g.colsum_out != nullptr && k0 == 0) {
+        for (int e = tid; e < TN / 4; e += 256) {
+            const int n = n0 + e * 4;
+            if (n >= g.N) continue;
+            f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+            for (int z = 0; z < G; ++z) sum += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g.colsum + (size_t)z * g.N + n));
+            *reinterpret_cast<f32x4*>(g.colsum_out + n) = sum;
+        }
+    }
+    if (tid == 0) g.counters[bx] = 0u;   // the slot is zero again for whoever takes it next
 }
 
 template <int WNT, int WKT>

@@ -207,6 +207,12 @@ struct TnArgs {
     int f16;           // 1: both operands rounded to fp16, one MFMA per product (the reference's autocast(float16) trainer arithmetic)
     int b_f16;         // (with f16) Bm is an fp16 tensor already: its tiles go to LDS as they are
     int a_f16;         // (with f16) A is an fp16 tensor already (the MLP backward's du, stored as halves by the dX product's epilogue)
+    // (with f16; round 6) the fixed-order sum of the group partials inside the launch: `counters` (one zeroed unsigned per output tile;
+    // the last group block to finish a tile — a device-wide ticket — adds the tile's partials in group order 0, 1, .. and resets the
+    // counter) -> out (N, K) and colsum_out (N): the bits reduce_batch_kernel produces, without its launches
+    unsigned* counters;
+    float* out;
+    float* colsum_out;
 };
 // gemm_tn_f16.hip: the same product with fp16 operands (TnArgs::f16 / b_f16), block tile chosen per shape
 bool gemm_tn_f16_supported(const TnArgs& g);

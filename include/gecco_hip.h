@@ -632,6 +632,14 @@ int gecco_gemm_tn_f16_b16_f32(const float* A, const void* B16, float* parts, flo
  * stored as halves; the bias gradient's column sums are formed from those halves. */
 int gecco_gemm_tn_f16_a16_f32(const void* A16, const float* Bm, const float* pro_a, const float* pro_o, float* parts, float* colsum_parts,
                               int Z, int R, int N, int K, int group, void* stream);
+/* The general form (round 6): either operand may be the fp16 tensor (a_f16 / b_f16, not both), and — with `counters`, `out` — the
+ * fixed-order sum of the group partials happens INSIDE the launch: counters = one zeroed unsigned per output tile
+ * (gecco_gemm_tn_f16_tiles(N, K) of them; the kernel leaves them zero), out (N, K) = sum over groups of parts in group order,
+ * colsum_out (N) likewise of colsum_parts — the bits gecco_reduce_batch_f32 gives, without its launches (autograd of every nn.Linear
+ * under the reference's precision="16-mixed": diffusion.py:213-222). */
+int gecco_gemm_tn_f16_ex_f32(const void* A, int a_f16, const void* Bm, int b_f16, const float* pro_a, const float* pro_o, float* parts,
+                             float* colsum_parts, float* out, float* colsum_out, unsigned* counters, int Z, int R, int N, int K, int group,
+                             void* stream);
 int gecco_reduce_batch_f32(const float* parts, float* out, size_t n, int Z, size_t stride, int accumulate, void* stream);
 
 /* Row softmax of the materialised attention scores: P = softmax(scale*S) over the last dim n; and its backward

@@ -68,6 +68,23 @@ def _check_fp16_dw(N, K):
             assert _rel(got, ref16) <= (2e-5 if pro else 2e-6), (pro, group, _rel(got, ref16))
             assert _rel(got, ref) <= 1e-3, (pro, group, _rel(got, ref))
             assert _rel(cs.double().sum(0), dy.double().sum((0, 1))) <= 1e-6   # column sums are fp32 sums of the fp32 values
+            # (round 6) the general entry with the group partials summed inside the launch, by the last block to finish a tile, in group
+            # order: the bits of the separate fixed-order reduction, and the counters back at zero
+            from gecco_amd import autograd as ag
+            tiles = lib.gecco_gemm_tn_f16_tiles(N, K)
+            ctr = torch.zeros(tiles, dtype=torch.int32, device="cuda")
+            pe = torch.full((G, N, K), float("nan"), device="cuda")
+            ce = torch.full((G, N), float("nan"), device="cuda")
+            oe, coe = torch.full((N, K), float("nan"), device="cuda"), torch.full((N,), float("nan"), device="cuda")
+            for _ in range(2):   # (twice on the same counters: the kernel leaves them zero)
+                _lib.check(lib.gecco_gemm_tn_f16_ex_f32(C.c_void_p(dyc.data_ptr()), 0, C.c_void_p(xc.data_ptr()), 0,
+                                                        C.c_void_p(pac.data_ptr()) if pro else None, C.c_void_p(poc.data_ptr()) if pro else None,
+                                                        C.c_void_p(pe.data_ptr()), C.c_void_p(ce.data_ptr()), C.c_void_p(oe.data_ptr()),
+                                                        C.c_void_p(coe.data_ptr()), C.c_void_p(ctr.data_ptr()), Z, R, N, K, group, None), "gemm_tn_f16_ex")
+                torch.cuda.synchronize()
+                assert torch.equal(pe, parts) and torch.equal(ce, cs) and int(ctr.abs().sum()) == 0
+                assert torch.equal(oe, ag._reduce(parts, N * K, G, N * K).reshape(N, K))
+                assert torch.equal(coe, ag._reduce(cs, N, G, N))
             if N % 8 == 0:   # dY as an fp16 tensor already (round 6: the MLP backward's du): the same product of the same halves ...
                 p16a = torch.full((G, N, K), float("nan"), device="cuda")
                 cs16 = torch.full((G, N), float("nan"), device="cuda")
@@ -286,6 +303,49 @@ def test_fp16_tensors_between_the_training_kernels_are_the_same_arithmetic(d, N,
             worst = max(worst, (e, n))
             assert e <= 2e-3, (n, e)
         print(f"d={d} N={N}: loss {l16:.6f} vs {l32:.6f}; {same} of {len(g32)} gradients bit-identical; worst {worst[1]} {worst[0]:.2e}")
+    finally:
+        hip_ops.set_default_precision(prev)
+
+
+def test_in_proj_gradients_on_the_side_stream_are_the_same_bits(monkeypatch):
+    """Round 6: the weight gradients with respect to nn.MultiheadAttention's packed in_proj thirds (q_proj's, the inducers' k | v
+    projection's) and the join of the thirds run on the weight-gradient side stream like every other weight gradient
+    (`InProjSplitFn`, `_inproj_side_ok`) instead of on the main stream's critical path: a scheduling change — every gradient of a step
+    to the bit, two steps in a row (the second accumulates nothing: zero_grad(set_to_none=True))."""
+    from gecco_amd import autograd as ag
+    from gecco_amd import hip_ops
+    from tests.test_modules_cpu import build_uncond, uncond_state_dict
+    prev = hip_ops.default_precision()
+    hip_ops.set_default_precision("mixed")
+    try:
+        d, L, N = 384, 2, 256
+        sd = uncond_state_dict(W.linear_lift_state_dict(23, d, L, cases.I, cases.H))
+        g = torch.Generator().manual_seed(10)
+        data = torch.randn(3, N, 3, generator=g).cuda()
+        noise = torch.randn(3, N, 3, generator=g).cuda()
+        sigma = torch.tensor([0.05, 0.7, 9.0]).cuda()
+
+        def run(side):
+            monkeypatch.setenv("GECCO_TRAIN_INPROJ_SIDE", side)
+            ag.WEIGHT_IMAGES.__init__()
+            m = build_uncond(d, L)
+            m.load_state_dict(sd, strict=True)
+            m = m.cuda().train()
+            out = []
+            for _ in range(2):
+                m.zero_grad(set_to_none=True)
+                s_ = sigma.reshape(-1, 1, 1)
+                with torch.autocast("cuda", dtype=torch.float16):
+                    den = m(data + noise * s_, sigma, None)
+                    loss = (100.0 * (s_ ** 2 + 1.0) / s_ ** 2 * (den.float() - data) ** 2).mean()
+                (loss * 256.0).backward()
+                torch.cuda.synchronize()
+                out.append({n: p.grad.detach().clone() for n, p in m.named_parameters()})
+            return out
+        a, b = run("1"), run("0")
+        for ga, gb in zip(a, b):
+            for n in gb:
+                assert torch.isfinite(ga[n]).all() and torch.equal(ga[n], gb[n]), n
     finally:
         hip_ops.set_default_precision(prev)
 

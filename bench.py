@@ -593,17 +593,24 @@ def train_bench(args, rank, world, dev):
         xh = torch.randn(Bt, N, D, generator=gg).to(dev)
         pro = (1.0 + 0.1 * torch.randn(Bt, D, generator=gg)).to(dev), (0.1 * torch.randn(Bt, D, generator=gg)).to(dev)
         with torch.no_grad():
-            t_dw = time_events(lambda: ga._linear_dw_main(dy, xh, pro=pro, prec="fp16" if args.amp else None), 10)
+            t_dw_pro = time_events(lambda: ga._linear_dw_main(dy, xh, pro=pro, prec="fp16" if args.amp else None), 10)
+            t_dw = t_dw_pro
+            dma_form = bool(args.amp and os.environ.get("GECCO_TRAIN_Y16", "0") == "1" and os.environ.get("GECCO_TRAIN_IO16", "1") != "0")
+            if dma_form:   # (opt-in GECCO_TRAIN_Y16=1) dY and fp16(AdaGN(x)) as fp16 tensors, slabs global -> LDS by DMA
+                dy16, y16 = dy.half(), (xh * pro[0][:, None] + pro[1][:, None]).half()
+                t_dw = time_events(lambda: ga._linear_dw_main(dy16, y16, prec="fp16"), 10)
             h16 = torch.randn(Bt, N, 2 * D, generator=gg).to(dev).half()
             dyo = torch.randn(Bt, N, D, generator=gg).to(dev)
             t_dw2 = time_events(lambda: ga._linear_dw_main(dyo, h16, want_db=True, prec="fp16"), 10) if args.amp else None
         fl = 2.0 * Bt * N * D * 2 * D
         units = 1 if args.amp else 3
-        rec["dominant_kernel"] = {"kernel": ("gemm_tn_f16_kernel<2, 2, true, false>" if args.amp else "gemm_tn_x3_kernel (AdaGN form)") +
+        rec["dominant_kernel"] = {"kernel": (("gemm_tn_f16_dma_kernel<2, 2> (both operands fp16 tensors, slabs by LDS-DMA)" if dma_form else "gemm_tn_f16_kernel<2, 2, true, false>")
+                                             if args.amp else "gemm_tn_x3_kernel (AdaGN form)") +
                                             " (dW = dY^T AdaGN(x) of kv_proj / mlp.0: 2 M N K with M = Bt N rows contracted, " +
                                             ("fp16 operands = 1 MFMA per product" if args.amp else "split-bf16 = 3 MFMAs per product") +
                                             "; incl. the fixed-order reduction of the per-group partials)",
                                   "launches_per_step_at_this_shape": 2 * L,
+                                  "register_staged_adagn_form_ms": t_dw_pro,
                                   "mlp2_dw_fp16_hidden_ms": t_dw2,
                                   "ms": t_dw, "achieved_tflops": fl / (t_dw * 1e-3) / 1e12, "peak_tflops": PEAK_BF16_MFMA_TFLOPS / units,
                                   "frac": fl / (t_dw * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
@@ -611,8 +618,9 @@ def train_bench(args, rank, world, dev):
         if args.amp:
             # with one MFMA per product the kernel is bound by its operand stream, not the matrix pipe: dY and X once from HBM
             # (algorithmic), each re-read by the other operand's 3 / 6 column tiles from L2, + the per-sample partials
-            by = 4.0 * Bt * N * (D + 2 * D) + 4.0 * Bt * D * 2 * D
-            l2 = 4.0 * Bt * N * (D * (2 * D // 128) + 2 * D * (D // 128))   # each operand re-read by the other's 128-column tiles
+            es = 2.0 if dma_form else 4.0   # bytes per operand element
+            by = es * Bt * N * (D + 2 * D) + 4.0 * Bt * D * 2 * D
+            l2 = es * Bt * N * (D * (2 * D // 128) + 2 * D * (D // 128))   # each operand re-read by the other's 128-column tiles
             rec["dominant_kernel"].update({"bound": "hbm", "algorithmic_bytes": by, "achieved_gbs": by / (t_dw * 1e-3) / 1e9,
                                            "peak_gbs": PEAK_HBM_GBS, "frac": by / (t_dw * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                            "frac_mfma": fl / (t_dw * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,

@@ -125,6 +125,7 @@ SIGNATURES = {
     "gecco_astat16_images_f32": (i, [C.POINTER(GeccoSplitJob), i, vp]),
     "gecco_linear_astat16_f32": (i, [vp] * 5 + [i, vp, vp, vp, i, vp, vp, i, i, i, i, vp, vp]),
     "gecco_linear_astat16_keep": (i, [vp] * 6 + [i, vp, vp, i, i, i, i, vp, vp]),
+    "gecco_linear_astat16_keep_y16": (i, [vp] * 6 + [i, vp, vp, vp, i, i, i, i, vp, vp]),
     "gecco_linear_astat16_actbwd": (i, [vp] * 4 + [i, vp, vp, i, i, i, i, vp, vp]),
     "gecco_linear_act_keep_h16": (i, [vp] * 6 + [i, vp, vp, i, i, i, i, vp, vp]),
     "gecco_set_option": (i, [C.c_char_p, i]),
@@ -132,6 +133,7 @@ SIGNATURES = {
     "gecco_cast_f16": (i, [c_f, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gecco_linear_astat_f16": (i, [vp, vp, vp, vp, vp, i, vp, vp, vp, i, vp, vp, i, i, i, i, i, vp, vp]),
     "gecco_linear_kvq_f16": (i, [vp, vp, vp, vp, vp, i, vp, vp, vp, i, vp, i, i, i, i, i, i, vp, vp]),
+    "gecco_linear_kvq_y16_f16": (i, [vp, vp, vp, vp, vp, i, vp, vp, vp, i, vp, vp, i, i, i, i, i, i, vp, vp]),
     "gecco_linear_h8_img_f32": (i, [vp, vp, vp, vp, vp, vp, i, vp, i, i, i, i, i, vp, vp]),
     "gecco_linear_h8_areg_f32": (i, [vp, vp, vp, vp, vp, vp, i, i, i, i, vp, vp]),
     "gecco_affine_cast_f16": (i, [vp, vp, vp, vp, i, i, i, vp]),

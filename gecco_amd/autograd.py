@@ -400,7 +400,12 @@ def _linear_dw_main(dy: Tensor, x: Tensor, want_db: bool = False, pro=None, prec
                 _ptr(pro[1]) if pro is not None else None, _ptr(parts), _ptr(cparts), _ptr(dW), _ptr(db), C.c_void_p(ctr.data_ptr()),
                 B, R, Nout, K, group, _stream()), "gecco_gemm_tn_f16_ex_f32")
             return (dW, db) if want_db else dW
-        if dy.dtype == torch.float16:   # du of an MLP's backward stored as halves (`_du16_ok`)
+        if dy.dtype == torch.float16 and x.dtype == torch.float16:   # both operands fp16 tensors (`_y16_ok`): slabs by DMA
+            assert pro is None
+            _lib.check(_lib.load().gecco_gemm_tn_f16_ex_f32(C.c_void_p(dy.data_ptr()), 1, C.c_void_p(x.data_ptr()), 1, None, None, _ptr(parts),
+                                                            _ptr(cparts), None, None, None, B, R, Nout, K, group, _stream()),
+                       "gecco_gemm_tn_f16_ex_f32")
+        elif dy.dtype == torch.float16:   # du of an MLP's backward stored as halves (`_du16_ok`)
             assert x.dtype == torch.float32
             _lib.check(_lib.load().gecco_gemm_tn_f16_a16_f32(hip_ops._ptr16(dy), _ptr(x), _ptr(pro[0]) if pro is not None else None,
                                                              _ptr(pro[1]) if pro is not None else None, _ptr(parts), _ptr(cparts), B, R,
@@ -671,8 +676,9 @@ class AdaGNPairFn(torch.autograd.Function):
         N1, N2 = W1.shape[0], W2.shape[0]
         if io16:   # (`_io16_ok`) K | V and q as fp16 tensors: the same A-stationary kernel, its fp16 row-major epilogue
             ws, ready = _a16_stream("pair", W1, W2, dev=x.device)
-            KV, q = hip_ops.linear_kvq_f16(x, (a, o), W1, None, _f(W2), b2, lo=(0, 0), head_dim=0, wsplit=ws, image_ready=ready)
-            ctx.save_for_backward(x, stats, t2, sw, sb, a, o, W1, W2, bw)
+            y16 = torch.empty(B, R, K, device=x.device, dtype=torch.float16) if _y16_ok(R, K, N1) and _y16_ok(R, K, N2) else None
+            KV, q = hip_ops.linear_kvq_f16(x, (a, o), W1, None, _f(W2), b2, lo=(0, 0), head_dim=0, wsplit=ws, image_ready=ready, y16=y16)
+            ctx.save_for_backward(x, stats, t2, sw, sb, a, o, W1, W2, bw, y16 if y16 is not None else x.new_empty(0))
             ctx.G, ctx.eps, ctx.has_b2, ctx.t_shape = G, eps, b2 is not None, tuple(t.shape)
             return KV, q, x
         if _a16_ok(prec, R, K, N1 + N2) and N1 % 64 == 0 and N2 % 64 == 0:
@@ -681,7 +687,7 @@ class AdaGNPairFn(torch.autograd.Function):
             _lib.check(_lib.load().gecco_linear_astat16_f32(_ptr(x), _ptr(a), _ptr(o), None if ready else _ptr(_f(W1)), None, N1, _ptr(KV),
                                                             None if ready else _ptr(_f(W2)), _ptr(b2), N2, _ptr(q), None, 0, B, R, K,
                                                             C.c_void_p(ws.data_ptr()), _stream()), "gecco_linear_astat16_f32")
-            ctx.save_for_backward(x, stats, t2, sw, sb, a, o, W1, W2, bw)
+            ctx.save_for_backward(x, stats, t2, sw, sb, a, o, W1, W2, bw, x.new_empty(0))
             ctx.G, ctx.eps, ctx.has_b2, ctx.t_shape = G, eps, b2 is not None, tuple(t.shape)
             return KV, q, x
         if _h8_ok(prec, R, K, N1 + N2) and N1 % 64 == 0 and N2 % 64 == 0:
@@ -690,7 +696,7 @@ class AdaGNPairFn(torch.autograd.Function):
             _lib.check(_lib.load().gecco_linear_h8_train_f32(_ptr(x), _ptr(a), _ptr(o), None if ready else _ptr(_f(W1)), None, N1, _ptr(KV),
                                                              None if ready else _ptr(_f(W2)), _ptr(b2), N2, _ptr(q), None, 0, None, B, R, K,
                                                              C.c_void_p(ws.data_ptr()), _stream()), "gecco_linear_h8_train_f32")
-            ctx.save_for_backward(x, stats, t2, sw, sb, a, o, W1, W2, bw)
+            ctx.save_for_backward(x, stats, t2, sw, sb, a, o, W1, W2, bw, x.new_empty(0))
             ctx.G, ctx.eps, ctx.has_b2, ctx.t_shape = G, eps, b2 is not None, tuple(t.shape)
             return KV, q, x
         img = WEIGHT_IMAGES.lookup("pair", W1, W2, prec=prec)
@@ -698,13 +704,13 @@ class AdaGNPairFn(torch.autograd.Function):
             KV, q = hip_ops.linear_pair(x, W1, None, W2, b2, pro=(a, o), precision=prec, w_image=img)
         else:
             KV, q = hip_ops.linear_pair(x, W1, None, _f(W2), b2, pro=(a, o), precision=prec)
-        ctx.save_for_backward(x, stats, t2, sw, sb, a, o, W1, W2, bw)
+        ctx.save_for_backward(x, stats, t2, sw, sb, a, o, W1, W2, bw, x.new_empty(0))
         ctx.G, ctx.eps, ctx.has_b2, ctx.t_shape = G, eps, b2 is not None, tuple(t.shape)
         return KV, q, x
 
     @staticmethod
     def backward(ctx, dKV, dq, dskip):
-        x, stats, t2, sw, sb, a, o, W1, W2, bw = ctx.saved_tensors
+        x, stats, t2, sw, sb, a, o, W1, W2, bw, y16 = ctx.saved_tensors
         need = ctx.needs_input_grad
         B, R, Cc = x.shape
         dKV = _f(dKV) if dKV is not None else x.new_zeros(B, R, W1.shape[0])
@@ -718,12 +724,14 @@ class AdaGNPairFn(torch.autograd.Function):
             dY, gst = _linear_dx_dot(dq, W2, x, prec=prec, residual=_linear_dx(dKV, W1, prec=prec))
         else:
             dY = _linear_dx(dq, W2, residual=_linear_dx(dKV, W1, prec=prec), prec=prec)
-        dW1 = _linear_dw(dKV, x, pro=(a, o), leaf=W1, prec=prec) if need[9] else None
+        # X of the two weight gradients: the fp16 operand the forward stored (both operands fp16: the DMA form), else x with the AdaGN apply
+        xw, prow = (y16, None) if (y16.numel() and dKV.dtype == torch.float16 and dq.dtype == torch.float16) else (x, (a, o))
+        dW1 = _linear_dw(dKV, xw, pro=prow, leaf=W1, prec=prec) if need[9] else None
         dW2 = db2 = None
         if need[10] and ctx.has_b2 and need[11]:
-            dW2, db2 = _linear_dw(dq, x, want_db=True, pro=(a, o), leaf=W2, prec=prec, side_ok=ctx.side2)
+            dW2, db2 = _linear_dw(dq, xw, want_db=True, pro=prow, leaf=W2, prec=prec, side_ok=ctx.side2)
         elif need[10]:
-            dW2 = _linear_dw(dq, x, pro=(a, o), leaf=W2, prec=prec, side_ok=ctx.side2)
+            dW2 = _linear_dw(dq, xw, pro=prow, leaf=W2, prec=prec, side_ok=ctx.side2)
         elif ctx.has_b2 and need[11]:
             db2 = _linear_db(dq.float() if dq.dtype != torch.float32 else dq)
         dx, dsw, dsb, dbw, dbb, dt = _adagn_backward(x, stats, t2, sw, sb, dY, dskip, ctx.G, ctx.eps, True, gst=gst, bw=bw if need[1] else None)
@@ -746,8 +754,11 @@ class AdaGNMlpFn(torch.autograd.Function):
         a, o, stats, t2 = _adagn_coeffs(x, t, sw, sb, bw, bb, G, eps, stats)
         prec = ctx.prec = _lin_precision()   # "bf16x3" or "fp16" (_pro_ok)
         h16 = _h16_ok(prec, R, K0, N0, W2.shape[0], True)
+        y16 = None
         if h16:
-            u, h = _keep_h16(x, W0, b0, (a, o), alpha, kind)
+            # (when the backward will hold du as halves: keep fp16(AdaGN(x)) for mlp.0's weight gradient)
+            want_y = kind in (1, 2, 3) and _du16_ok(prec, R, W2.shape[0], N0, K0) and _y16_ok(R, K0, N0)
+            u, h, y16 = _keep_h16(x, W0, b0, (a, o), alpha, kind, want_y16=True) if want_y else (*_keep_h16(x, W0, b0, (a, o), alpha, kind), None)
         elif kind in (1, 2, 3) and _h8_ok(prec, R, K0, N0):
             u, h = _new(B, R, N0, like=x), _new(B, R, N0, like=x)
             ws, ready = _h8_stream("n", W0, dev=x.device)
@@ -762,7 +773,8 @@ class AdaGNMlpFn(torch.autograd.Function):
                                                          kind, _ptr(u), _ptr(h), B, R, K0, N0, hip_ops.PRECISIONS[prec],
                                                          C.c_void_p(ws.data_ptr()), _stream()),
                        "gecco_linear_act_keep_pro_f32")
-        ctx.save_for_backward(x, stats, t2, sw, sb, a, o, u, h, alpha if alpha is not None else x.new_empty(0), W0, W2, bw)
+        ctx.save_for_backward(x, stats, t2, sw, sb, a, o, u, h, alpha if alpha is not None else x.new_empty(0), W0, W2, bw,
+                              y16 if y16 is not None else x.new_empty(0))
         ctx.G, ctx.eps, ctx.kind, ctx.bias, ctx.t_shape = G, eps, kind, (b0 is not None, b2 is not None), tuple(t.shape)
         out = _linear_fwd_h16(h, W2, b2, x, want_stats) if h16 else _linear_fwd(h, W2, b2, x, want_stats, prec)
         if want_stats:
@@ -774,7 +786,7 @@ class AdaGNMlpFn(torch.autograd.Function):
     def backward(ctx, dout, _dstats=None):
         if dout is None:   # (materialize off) only the statistics were used: they carry no gradient
             return (None,) * len(ctx.needs_input_grad)
-        x, stats, t2, sw, sb, a, o, u, h, alpha, W0, W2, bw = ctx.saved_tensors
+        x, stats, t2, sw, sb, a, o, u, h, alpha, W0, W2, bw, y16 = ctx.saved_tensors
         need = ctx.needs_input_grad
         dout = _f(dout)
         prec = ctx.prec
@@ -788,7 +800,10 @@ class AdaGNMlpFn(torch.autograd.Function):
                 return _linear_dw(g, act_in, want_db=True, pro=pro, leaf=Wl, prec=prec)
             return (_linear_dw(g, act_in, pro=pro, leaf=Wl, prec=prec) if need[iw] else None), (_linear_db(g) if has_b and need[ib] else None)
         dW2, db2 = wgrads(dout, h, ctx.bias[1], 12, 13, W2)
-        dW0, db0 = wgrads(du, x, ctx.bias[0], 9, 10, W0, pro=(a, o))
+        if du.dtype == torch.float16 and y16.numel():   # both operands as fp16 images: the DMA form of the weight-gradient kernel
+            dW0, db0 = wgrads(du, y16, ctx.bias[0], 9, 10, W0)
+        else:
+            dW0, db0 = wgrads(du, x, ctx.bias[0], 9, 10, W0, pro=(a, o))
         dY, gst = _linear_dx_dot(du, W0, x, prec=prec)
         dx, dsw, dsb, dbw, dbb, dt = _adagn_backward(x, stats, t2, sw, sb, dY, dout, ctx.G, ctx.eps, True, gst=gst, bw=bw if need[1] else None)
         return dx, (dt.reshape(ctx.t_shape) if dt is not None else None), dsw, dsb, dbw, dbb, None, None, None, dW0, db0, dalpha, dW2, db2, None, None
@@ -959,19 +974,32 @@ def _h16_ok(prec: str, R: int, K0: int, N0: int, Nout2: int, pro: bool) -> bool:
     return bool(lib.gecco_linear_image_ok_f16(R, K0, N0, int(pro)) and lib.gecco_linear_image_ok_f16(R, N0, Nout2, 0))
 
 
-def _keep_h16(x: Tensor, W0: Tensor, b0, pro, alpha, kind: int) -> tuple[Tensor, Tensor]:
-    """(u fp32, h fp16) = (x' W0^T + b0, act(u)) from one launch; pro = (a, o): x' = a x + o."""
+def _y16_ok(R: int, K: int, Nout: int) -> bool:
+    """The weight gradient dY^T X of a linear whose dY is an fp16 tensor (`_io16_ok`, `_du16_ok`) on fp16 images of BOTH operands: the
+    forward kernel stores the operand it forms, y16 = fp16(AdaGN(x)), and the weight-gradient kernel takes its slabs global -> LDS by DMA
+    (gemm_tn_f16_dma_kernel: whole 128 x 128 tiles).  Default off: X = x with the AdaGN apply while it is staged."""
+    # OPT-IN (measured and lost, profiles/r06_negative_results.txt item 10): the kernel alone 168 -> 143 us, the step 16.77 -> 17.26 ms
+    return os.environ.get("GECCO_TRAIN_Y16", "0") == "1" and R % 32 == 0 and K % 128 == 0 and Nout % 128 == 0
+
+
+def _keep_h16(x: Tensor, W0: Tensor, b0, pro, alpha, kind: int, want_y16: bool = False):
+    """(u fp32, h fp16) = (x' W0^T + b0, act(u)) from one launch; pro = (a, o): x' = a x + o.  want_y16 (A-stationary kernel only): also
+    y16 = fp16(x') -> (u, h, y16 | None)."""
     lib = _lib.load()
     B, R, K0 = x.shape
     N0 = W0.shape[0]
     u, h = _new(B, R, N0, like=x), torch.empty(B, R, N0, device=x.device, dtype=torch.float16)
     if kind in (1, 2, 3) and _a16_ok("fp16", R, K0, N0):
         ws, ready = _a16_stream("n", W0, dev=x.device)
-        _lib.check(lib.gecco_linear_astat16_keep(_ptr(x), _ptr(pro[0]) if pro else None, _ptr(pro[1]) if pro else None,
-                                                 None if ready else _ptr(_f(W0)), _ptr(b0), _ptr(alpha) if kind in (1, 2) else None, kind,
-                                                 _ptr(u), C.c_void_p(h.data_ptr()), B, R, K0, N0, C.c_void_p(ws.data_ptr()), _stream()),
-                   "gecco_linear_astat16_keep")
-        return u, h
+        y16 = torch.empty(B, R, K0, device=x.device, dtype=torch.float16) if want_y16 else None
+        _lib.check(lib.gecco_linear_astat16_keep_y16(_ptr(x), _ptr(pro[0]) if pro else None, _ptr(pro[1]) if pro else None,
+                                                     None if ready else _ptr(_f(W0)), _ptr(b0), _ptr(alpha) if kind in (1, 2) else None, kind,
+                                                     _ptr(u), C.c_void_p(h.data_ptr()), C.c_void_p(y16.data_ptr()) if want_y16 else None,
+                                                     B, R, K0, N0, C.c_void_p(ws.data_ptr()), _stream()),
+                   "gecco_linear_astat16_keep_y16")
+        return (u, h, y16) if want_y16 else (u, h)
+    if want_y16:
+        return (*_keep_h16(x, W0, b0, pro, alpha, kind), None)
     img = WEIGHT_IMAGES.lookup("n", W0, prec="fp16")
     Wp, ws = (None, img) if img is not None else (_f(W0), hip_ops._ws((N0 + 127) // 128 * 128 * K0 * 2, x.device))
     _lib.check(lib.gecco_linear_act_keep_h16(_ptr(x), _ptr(Wp), _ptr(b0), _ptr(pro[0]) if pro else None, _ptr(pro[1]) if pro else None,

@@ -1038,6 +1038,12 @@ int gecco_linear_astat16_f32(const float* x, const float* pro_a, const float* pr
 
 int gecco_linear_astat16_keep(const float* x, const float* pro_a, const float* pro_o, const float* W, const float* bias, const float* alpha,
                               int act, float* pre_out, void* C16out, int B, int rows, int K, int Nout, void* wsplit, void* stream) {
+    return gecco_linear_astat16_keep_y16(x, pro_a, pro_o, W, bias, alpha, act, pre_out, C16out, nullptr, B, rows, K, Nout, wsplit, stream);
+}
+
+int gecco_linear_astat16_keep_y16(const float* x, const float* pro_a, const float* pro_o, const float* W, const float* bias, const float* alpha,
+                                  int act, float* pre_out, void* C16out, void* y16, int B, int rows, int K, int Nout, void* wsplit,
+                                  void* stream) {
     if (!x || !pre_out || !C16out || !wsplit) return fail(-1, "linear_astat16_keep: null argument");
     if ((pro_a == nullptr) != (pro_o == nullptr)) return fail(-1, "linear_astat16_keep: pro_a / pro_o must both be set");
     if ((act == 1 || act == 2) && !alpha) return fail(-1, "linear_astat16_keep: GaussianActivation needs alpha");
@@ -1045,7 +1051,7 @@ int gecco_linear_astat16_keep(const float* x, const float* pro_a, const float* p
     GemmArgs g{};
     g.A = x; g.pro_a = pro_a; g.pro_o = pro_o; g.bias = bias; g.alpha = alpha; g.act = act; g.C = static_cast<float*>(C16out); g.pre_out = pre_out;
     g.B = B; g.rows = rows; g.K = K; g.Nout = Nout; g.lda = K; g.ldw = K; g.ldc = Nout; g.ldr = Nout;
-    g.precision = 2; g.w_img = wsplit;
+    g.precision = 2; g.w_img = wsplit; g.y16_out = y16;
     if (!gemm_astat_train_supported(g))
         return fail(-2, "linear_astat16_keep: needs rows %% 128 == 0, K in {128, 256, 384, 512}, Nout %% 64 == 0, act 1 / 2 (GaussianActivation) or 3 (ReLU)");
     if (W) {
@@ -1172,6 +1178,13 @@ int gecco_linear_astat_f16(const float* x, const float* pro_a, const float* pro_
 int gecco_linear_kvq_f16(const float* x, const float* pro_a, const float* pro_o, const float* W1, const float* bias1, int Nout1,
                          void* C1, const float* W2, const float* bias2, int Nout2, void* C2, int B, int rows, int K, int head_dim,
                          int lo_begin, int lo_end, void* wsplit, void* stream) {
+    return gecco_linear_kvq_y16_f16(x, pro_a, pro_o, W1, bias1, Nout1, C1, W2, bias2, Nout2, C2, nullptr, B, rows, K, head_dim, lo_begin, lo_end,
+                                    wsplit, stream);
+}
+
+int gecco_linear_kvq_y16_f16(const float* x, const float* pro_a, const float* pro_o, const float* W1, const float* bias1, int Nout1,
+                             void* C1, const float* W2, const float* bias2, int Nout2, void* C2, void* y16, int B, int rows, int K,
+                             int head_dim, int lo_begin, int lo_end, void* wsplit, void* stream) {
     if (!x || !C1 || !wsplit) return fail(-1, "linear_kvq: null argument");
     if ((pro_a == nullptr) != (pro_o == nullptr)) return fail(-1, "linear_kvq: pro_a/pro_o must both be set");
     if ((Nout2 > 0) != (C2 != nullptr)) return fail(-1, "linear_kvq: Nout2 and C2 go together");
@@ -1184,6 +1197,7 @@ int gecco_linear_kvq_f16(const float* x, const float* pro_a, const float* pro_o,
     g.A = x; g.pro_a = pro_a; g.pro_o = pro_o; g.bias = bias1; g.C = static_cast<float*>(C1);
     g.B = B; g.rows = rows; g.K = K; g.Nout = Nout1 + Nout2; g.lda = K; g.ldw = K; g.ldc = Nout1; g.ldr = Nout1;
     g.precision = 2; g.w_img = img; g.c_f16 = 1; g.hm_hd = head_dim; g.lo_begin = lo_begin / 64; g.lo_tiles = lo_end / 64;
+    g.y16_out = y16;
     if (C2) { g.C2 = static_cast<float*>(C2); g.bias2 = bias2; g.n_split = Nout1; g.ldc2 = Nout2; }
     // (the two-term range must be whole 384-column segments: it is a range of TILES in the stream)
     g.kvq_perm = option(OPT_KVQPERM) && kvq_perm48_ok(head_dim, K, Nout1, Nout2) && lo_begin % 384 == 0 && lo_end % 384 == 0;
@@ -1378,7 +1392,8 @@ int gecco_gemm_tn_f16_ex_f32(const void* A, int a_f16, const void* Bm, int b_f16
     if ((pro_a == nullptr) != (pro_o == nullptr)) return fail(-1, "gemm_tn_f16_ex: pro_a / pro_o must both be set");
     if ((counters != nullptr) != (out != nullptr) || (colsum_out && !(colsum_parts && counters)))
         return fail(-1, "gemm_tn_f16_ex: counters and out go together; colsum_out needs colsum_parts and counters");
-    if (a_f16 && b_f16) return fail(-2, "gemm_tn_f16_ex: at most one operand is an fp16 tensor");
+    if (a_f16 && b_f16 && (pro_a || counters || N % 128 || K % 128))
+        return fail(-2, "gemm_tn_f16_ex: both operands fp16: whole 128 x 128 tiles, no AdaGN apply, the separate reduction");
     TnArgs g{};
     g.pro_a = pro_a; g.pro_o = pro_o; g.f16 = 1; g.a_f16 = a_f16 != 0; g.b_f16 = b_f16 != 0;
     g.A = static_cast<const float*>(A); g.Bm = static_cast<const float*>(Bm); g.C = parts; g.Z = Z; g.R = R; g.N = N; g.K = K; g.lda = N; g.ldb = K;

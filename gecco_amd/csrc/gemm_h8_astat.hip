@@ -930,6 +930,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kvq_astat_kernel(GemmArgs g) {
                     const int cq = 4 * t + 2 * h + c;
                     fa[2 * s + t][c] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(sw + r * 128 + ((cq ^ (r & 7)) << 4)));
                 }
+            if (g.y16_out) {   // (launch-uniform) the 64-column group of the wave's 32 rows as it stands in the tile: 128 contiguous bytes per row
+                _Float16* yb = static_cast<_Float16*>(g.y16_out) + ((size_t)b * g.rows + m0 + wave * 32) * K + 64 * s;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int idx = i * 64 + lane, row = idx >> 3, ch = idx & 7;
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(sw + row * 128 + ((ch ^ (row & 7)) << 4));
+                    *reinterpret_cast<u32x4*>(yb + (size_t)row * K + ch * 8) = v;
+                }
+            }
             __builtin_amdgcn_wave_barrier();
         });
     }

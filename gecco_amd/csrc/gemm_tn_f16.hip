@@ -316,12 +316,130 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f16_kernel(TnArgs g) {
     if (tid == 0) g.counters[bx] = 0u;   // the slot is zero again for whoever takes it next
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// BOTH operands fp16 tensors, whole tiles (round 6: dY = the fp16 gradient of an `_io16_ok` / `_du16_ok` product, X = the fp16 operand its
+// forward kernel stored, GemmArgs::y16_out): the 32-row slabs go global -> LDS by DMA (buffer_load ... lds, 16 bytes per lane) straight
+// into the planes' 4-row x 32-column block layout — the LDS side of a DMA instruction is linear (lane l at byte 16 l of a 1 KiB piece =
+// four blocks), the GLOBAL side is per lane, so each lane fetches the 8 halves its slot of the layout holds.  No register staging, no
+// conversion, no ds_write: the path that bound the register-staged form.  One barrier per slab; the next slab's DMA flies under this
+// slab's matrix instructions.  The bias gradient (column sums of dY) is one more matrix instruction per A fragment against a fragment
+// of ones (exact products, fp32 accumulation), by the waves of the first K tile's first wave column.
+// (a non-template device function: inside the kernel template the host pass would have to accept the 16-byte form of the builtin, which
+// only the gfx950 target has, and drops the whole instantiation without a word)
+__device__ __forceinline__ void tn_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, u16* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
+template <int WNT, int WKT>
+__global__ __launch_bounds__(256, 2) void gemm_tn_f16_dma_kernel(TnArgs g) {
+    constexpr int TN = 64 * WNT, TK = 64 * WKT, NCA = TN / 32, NCB = TK / 32;
+    constexpr int PA = 32 * TN, PB = 32 * TK;                 // u16 per plane
+    constexpr int NPA = PA / 512, NPB = PB / 512, NPW = (NPA + NPB) / 4;   // 1 KiB pieces per plane, per wave
+    static_assert((NPA + NPB) % 4 == 0 && NPA % NPW == 0, "a wave's pieces lie in one plane");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    u16* lds = reinterpret_cast<u16*>(smem);                  // [2 stages][A | B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 1, wk = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int tilesK = g.K / TK;
+    const int ntile = (int)gridDim.x;
+    const int vb = g.xcd ? xcd_remap((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y)) : (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    const int bx = vb % ntile, by = vb / ntile;
+    const int n0 = (bx / tilesK) * TN, k0 = (bx % tilesK) * TK;
+    const int z0 = by * g.group, z1 = min(g.Z, z0 + g.group);
+    const int msteps = g.R / 32, nsteps = (z1 - z0) * msteps;
+
+    // this wave's pieces p = NPW wave .. + NPW - 1 of the list [A pieces | B pieces]; piece q of a plane with NC column blocks: block
+    // 4 q + (lane >> 4) = (row group rg, column block cb), slot (lane & 15) >> 2 = (row + cb) & 3, 16-byte chunk lane & 3
+    const bool isB = NPW * wave >= NPA;
+    const int q0 = isB ? NPW * wave - NPA : NPW * wave;
+    unsigned voff[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+        const int bi = 4 * (q0 + i) + (lane >> 4), nc = isB ? NCB : NCA;
+        const int rg = bi / nc, cb = bi % nc, slot = (lane & 15) >> 2, ch = lane & 3;
+        const int row = 4 * rg + ((slot - cb) & 3), col = cb * 32 + ch * 8;
+        voff[i] = (unsigned)((row * (isB ? g.ldb : g.lda) + col) * 2);
+    }
+    auto issue = [&](int s) {
+        const int z = z0 + s / msteps, m0 = (s % msteps) * 32;
+        const _Float16* base = isB ? reinterpret_cast<const _Float16*>(g.Bm) + (size_t)z * g.sB : reinterpret_cast<const _Float16*>(g.A) + (size_t)z * g.sA;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(base), 0, 0x7fffffff, 0x00020000);
+        const unsigned so = (unsigned)((m0 * (isB ? g.ldb : g.lda) + (isB ? k0 : n0)) * 2);
+        u16* dst = lds + (s & 1) * (PA + PB) + (isB ? PA : 0) + q0 * 512;
+#pragma unroll
+        for (int i = 0; i < NPW; ++i)
+            tn_dma16(rs, voff[i], so, dst + i * 512);
+    };
+    const int tq = (lane & 15) >> 2, tp = lane & 3, tcol = 16 * ((lane >> 4) & 1) + 4 * tp;
+    auto frag = [&](const u16* plane, auto NC, int sg, int blk) -> f16x8 {
+        constexpr int nc = decltype(NC)::value;
+        typedef __attribute__((address_space(3))) s16x4* lp;
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(plane + toff<nc>(16 * sg + 4 * h + tq, blk * 32 + tcol)));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(plane + toff<nc>(16 * sg + 8 + 4 * h + tq, blk * 32 + tcol)));
+        return __builtin_bit_cast(f16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+
+    f32x16 acc[WNT][WKT], accs[WNT];
+#pragma unroll
+    for (int i = 0; i < WNT; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accs[i][e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < WKT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    }
+    const bool want_cs = g.colsum != nullptr && k0 == 0 && wk == 0;   // (wave-uniform)
+    const f16x8 ones = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
+
+    if (nsteps > 0) issue(0);
+    for (int s = 0; s < nsteps; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of slab s have landed
+        __syncthreads();   // everybody's pieces landed; everybody is past its reads of the other stage
+        if (s + 1 < nsteps) issue(s + 1);
+        const u16* sa = lds + (s & 1) * (PA + PB);
+        const u16* sb = sa + PA;
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg) {
+            f16x8 bb[WKT];
+#pragma unroll
+            for (int j = 0; j < WKT; ++j) bb[j] = frag(sb, std::integral_constant<int, NCB>{}, sg, wk * WKT + j);
+#pragma unroll
+            for (int i = 0; i < WNT; ++i) {
+                const f16x8 a = frag(sa, std::integral_constant<int, NCA>{}, sg, wn * WNT + i);
+#pragma unroll
+                for (int j = 0; j < WKT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bb[j], acc[i][j], 0, 0, 0);
+                if (want_cs) accs[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ones, accs[i], 0, 0, 0);
+            }
+        }
+    }
+    if (want_cs && r == 0) {   // every column of accs holds the sums: lanes 0 and 32 own the tile's 32 rows between them
+#pragma unroll
+        for (int i = 0; i < WNT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) g.colsum[(size_t)by * g.N + n0 + (wn * WNT + i) * 32 + mfma_row(e, h)] = accs[i][e];
+    }
+    float* Cb = g.C + (size_t)by * g.N * g.K;
+#pragma unroll
+    for (int i = 0; i < WNT; ++i)
+#pragma unroll
+        for (int j = 0; j < WKT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + (wn * WNT + i) * 32 + mfma_row(e, h), k = k0 + (wk * WKT + j) * 32 + r;
+                Cb[(size_t)n * g.K + k] = acc[i][j][e];
+            }
+}
+
 template <int WNT, int WKT>
 int tn_f16_launch_t(const TnArgs& g, hipStream_t st) {
     constexpr int TN = 64 * WNT, TK = 64 * WKT;
     const int G = (g.Z + g.group - 1) / g.group;
     const size_t lds = (size_t)2 * 32 * (TN + TK) * 2 + (g.pro_a ? (size_t)4 * TK * sizeof(float) : 0);   // 32 - 52 KiB: no attribute needed
     const dim3 grid(((g.N + TN - 1) / TN) * ((g.K + TK - 1) / TK), G);
+    if (g.a_f16 && g.b_f16) return -9;   // (the DMA form: gemm_tn_f16_launch)
     if (g.a_f16) {   // the MLP backward's du as halves: with the AdaGN apply on x (mlp.0), or plain
         if (g.b_f16) return -9;
         if (g.pro_a) hipLaunchKernelGGL((gemm_tn_f16_kernel<WNT, WKT, true, false, true>), grid, dim3(256), lds, st, g);
@@ -355,7 +473,8 @@ int tn_f16_shape(int N, int K) {
 bool gemm_tn_f16_supported(const TnArgs& g) {
     // one sample's rows are addressed with 31-bit byte offsets (buffer loads)
     return g.Z > 0 && g.group > 0 && g.R >= 32 && g.R % 32 == 0 && g.N > 0 && g.K > 0 && !(g.N & 3) && !(g.K & 3) && !(g.lda & 3) &&
-           !(g.ldb & 3) && (!g.b_f16 || (!g.pro_a && !(g.K & 7) && !(g.ldb & 7))) && (!g.a_f16 || (!g.b_f16 && !(g.N & 7) && !(g.lda & 7))) &&
+           !(g.ldb & 3) && (!g.b_f16 || (!g.pro_a && !(g.K & 7) && !(g.ldb & 7))) && (!g.a_f16 || (!(g.N & 7) && !(g.lda & 7))) &&
+           (!(g.a_f16 && g.b_f16) || (!(g.N % 128) && !(g.K % 128) && !g.counters)) &&
            (size_t)g.R * g.lda * 4 < 0x7fffffffu &&
            (size_t)g.R * g.ldb * 4 < 0x7fffffffu;
 }
@@ -375,6 +494,12 @@ int gemm_tn_f16_launch(const TnArgs& g, hipStream_t st) {
     }
     TnArgs ga = g;
     ga.xcd = xcd;
+    if (g.a_f16 && g.b_f16) {   // both operands fp16 tensors: the DMA form, whole 128 x 128 tiles (gemm_tn_f16_supported checked)
+        const int G = (g.Z + g.group - 1) / g.group;
+        const dim3 grid((g.N / 128) * (g.K / 128), G);
+        hipLaunchKernelGGL((gemm_tn_f16_dma_kernel<2, 2>), grid, dim3(256), (size_t)2 * 32 * (128 + 128) * 2, st, ga);
+        return (int)hipGetLastError();
+    }
     switch (tn_f16_shape(g.N, g.K)) {
         case 1: return tn_f16_launch_t<4, 2>(ga, st);
         case 2: return tn_f16_launch_t<2, 4>(ga, st);

@@ -66,6 +66,9 @@ struct GemmArgs {
     // of CONTIGUOUS head-major memory per tile, written as three 1 KiB stores through its LDS tile instead of as 32-byte pieces.  A
     // column's dot product does not depend on where in a tile it sits: the outputs are bit-identical to the plain order.
     int kvq_perm;
+    // gemm_kvq_astat_kernel (training forward, round 6): also store the A operand the kernel forms, y16 = fp16(A * pro_a + pro_o), as an
+    // fp16 tensor (B, rows, K) — the weight gradient of this very linear reads it back as its fp16 X operand (gemm_tn_f16.hip, DMA form)
+    void* y16_out;
     int h6;                    // gemm_h8_astat.hip (c_img == 2): the cross terms in fp6 with block scales; w_img is the h6 stream (SplitJob::pad_ 32)
     int h8_stagger, h8_pair;   // gemm_h8_astat.hip: start offset of every second block of a CU (set by its launcher)
 };

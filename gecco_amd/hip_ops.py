@@ -274,7 +274,7 @@ def linear_astat_f16(x: Tensor, pro: tuple[Tensor, Tensor] | None, W1: Tensor, b
 
 def linear_kvq_f16(x: Tensor, pro: tuple[Tensor, Tensor] | None, W1: Tensor, b1: Tensor | None, W2: Tensor | None = None,
                    b2: Tensor | None = None, lo: tuple[int, int] = (0, 0), head_dim: int = 0, wsplit: Tensor | None = None,
-                   image_ready: bool = False):
+                   image_ready: bool = False, y16: Tensor | None = None):
     """fp16(fp16(x*pa + po) @ W^T + b) for W = W1 (| W2), fp16 outputs, the columns lo[0] .. lo[1] of W1 with two-term weights
     (fp16 + fp8 second term): kv_proj | q_proj of the mixed mode.  head_dim > 0: head-major outputs."""
     lib = _lib.load()
@@ -286,10 +286,12 @@ def linear_kvq_f16(x: Tensor, pro: tuple[Tensor, Tensor] | None, W1: Tensor, b1:
     c2 = torch.empty(*shape(n2), device=x.device, dtype=torch.float16) if n2 else None
     if wsplit is None:
         wsplit = _ws((n1 + n2) * K * 2 + (lo[1] - lo[0]) * K, x.device)
-    check(lib.gecco_linear_kvq_f16(_ptr(x), _ptr(pro[0]) if pro else None, _ptr(pro[1]) if pro else None,
-                                   None if image_ready else _ptr(W1), _ptr(b1), n1, _ptr16(c1),
-                                   None if image_ready else _ptr(W2), _ptr(b2), n2, _ptr16(c2) if c2 is not None else None,
-                                   B, rows, K, head_dim, lo[0], lo[1], C.c_void_p(wsplit.data_ptr()), _stream()), "gecco_linear_kvq_f16")
+    # y16: also store fp16(x * pa + po) (B, rows, K), the operand the kernel forms (the training path's weight gradients read it back)
+    check(lib.gecco_linear_kvq_y16_f16(_ptr(x), _ptr(pro[0]) if pro else None, _ptr(pro[1]) if pro else None,
+                                       None if image_ready else _ptr(W1), _ptr(b1), n1, _ptr16(c1),
+                                       None if image_ready else _ptr(W2), _ptr(b2), n2, _ptr16(c2) if c2 is not None else None,
+                                       _ptr16(y16) if y16 is not None else None,
+                                       B, rows, K, head_dim, lo[0], lo[1], C.c_void_p(wsplit.data_ptr()), _stream()), "gecco_linear_kvq_f16")
     return (c1, c2) if c2 is not None else c1
 
 

@@ -248,6 +248,10 @@ int gecco_linear_astat16_f32(const float* x, const float* pro_a, const float* pr
                              int K, void* wsplit, void* stream);
 int gecco_linear_astat16_keep(const float* x, const float* pro_a, const float* pro_o, const float* W, const float* bias, const float* alpha,
                               int act, float* pre_out, void* C16out, int B, int rows, int K, int Nout, void* wsplit, void* stream);
+/* ... and with y16 = fp16(x * pro_a + pro_o) stored as well (see gecco_linear_kvq_y16_f16). */
+int gecco_linear_astat16_keep_y16(const float* x, const float* pro_a, const float* pro_o, const float* W, const float* bias, const float* alpha,
+                                  int act, float* pre_out, void* C16out, void* y16, int B, int rows, int K, int Nout, void* wsplit,
+                                  void* stream);
 int gecco_linear_astat16_actbwd(const float* dy, const float* W, const float* u, const float* alpha, int kind, float* C, float* agrad, int B,
                                 int rows, int K, int Nout, void* wsplit, void* stream);
 /* The same with the result stored as HALVES (round 6): du = (dy W) act'(u) of an MLP's backward is read again only by the matrix pipe — the
@@ -316,6 +320,11 @@ int gecco_linear_astat_f16(const float* x, const float* pro_a, const float* pro_
 int gecco_linear_kvq_f16(const float* x, const float* pro_a, const float* pro_o, const float* W1, const float* bias1, int Nout1,
                          void* C1, const float* W2, const float* bias2, int Nout2, void* C2, int B, int rows, int K, int head_dim,
                          int lo_begin, int lo_end, void* wsplit, void* stream);
+/* The same with the operand the kernel forms, y16 = fp16(x * pro_a + pro_o) (B, rows, K), stored beside the products (round 6): the weight
+ * gradients of these very linears read it back as their fp16 X operand (gecco_gemm_tn_f16_ex_f32 with both operands fp16).  y16 may be NULL. */
+int gecco_linear_kvq_y16_f16(const float* x, const float* pro_a, const float* pro_o, const float* W1, const float* bias1, int Nout1,
+                             void* C1, const float* W2, const float* bias2, int Nout2, void* C2, void* y16, int B, int rows, int K,
+                             int head_dim, int lo_begin, int lo_end, void* wsplit, void* stream);
 /* mlp.0 of a BroadcastingLayer's point MLP in the mixed mode (models/set_transformer.py:164-166: the first linear of
  * `x + mlp(mlp_norm(x))` with the AdaGN apply of models/normalization.py:44 folded in; models/mlp.py:5-39; activation.py:17-24):
  *   u = act((x*pro_a + pro_o) @ W^T + bias),   product = fp16(y) fp16(W) + fp8(y) fp8(W - fp16(W)) + fp8(y - fp16(y)) fp8(W)

@@ -85,6 +85,17 @@ def _check_fp16_dw(N, K):
                 assert torch.equal(pe, parts) and torch.equal(ce, cs) and int(ctr.abs().sum()) == 0
                 assert torch.equal(oe, ag._reduce(parts, N * K, G, N * K).reshape(N, K))
                 assert torch.equal(coe, ag._reduce(cs, N, G, N))
+            if not pro and N % 128 == 0 and K % 128 == 0:
+                # (round 6) BOTH operands fp16 tensors: slabs global -> LDS by DMA (gemm_tn_f16_dma_kernel) — the same halves, the same
+                # matrix instructions in the same order: the register-staged form's bits; the column sums by a ones-fragment product
+                pd = torch.full((G, N, K), float("nan"), device="cuda")
+                cd = torch.full((G, N), float("nan"), device="cuda")
+                dy16b, x16b = dyc.half(), xc.half()
+                _lib.check(lib.gecco_gemm_tn_f16_ex_f32(C.c_void_p(dy16b.data_ptr()), 1, C.c_void_p(x16b.data_ptr()), 1, None, None,
+                                                        C.c_void_p(pd.data_ptr()), C.c_void_p(cd.data_ptr()), None, None, None, Z, R, N, K, group, None),
+                           "gemm_tn_f16_ex(dma)")
+                assert torch.equal(pd, parts)
+                assert _rel(cd.double().sum(0), dy16b.double().sum((0, 1))) <= 1e-6
             if N % 8 == 0:   # dY as an fp16 tensor already (round 6: the MLP backward's du): the same product of the same halves ...
                 p16a = torch.full((G, N, K), float("nan"), device="cuda")
                 cs16 = torch.full((G, N), float("nan"), device="cuda")

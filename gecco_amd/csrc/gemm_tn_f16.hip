@@ -456,11 +456,13 @@ int tn_f16_shape(int N, int K) {
     // Measured (profiles/r04p): alone, the wide tiles take 134 / 132 us against 168 / 174 for the 768 x 384 / 384 x 768 gradients
     // (AdaGN form 161 / 152 against 198 / 190); inside the training step, where the weight gradients share the CUs with the dX chain
     // of the main stream (autograd.py: side stream), their 250 registers and 48 KiB pack worse beside the other kernels and the step
-    // is 19.2 ms against 19.0 (without the side stream: 19.1 against 19.35).  Default: 128 x 128; GECCO_TN_F16_WIDE=1 selects them.
+    // is 19.2 ms against 19.0 (without the side stream: 19.1 against 19.35).  Round 6: with fp16 tensors between the training kernels the
+    // balance tips — 16.46 - 16.53 ms with the wide tiles against 16.63 - 16.68 (three runs each, one box): the DEFAULT since;
+    // GECCO_TN_F16_WIDE=0 selects 128 x 128.
     static int wide = -1;
     if (wide < 0) {
         const char* e = getenv("GECCO_TN_F16_WIDE");
-        wide = (e && atoi(e) != 0) ? 1 : 0;
+        wide = (e && atoi(e) == 0) ? 0 : 1;
     }
     if (!wide) return 0;
     if (K % 256 == 0 && (N % 256 != 0 || K >= N)) return 2;   // 128 x 256

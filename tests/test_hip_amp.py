@@ -116,14 +116,14 @@ def _check_fp16_dw(N, K):
 
 
 @pytest.mark.parametrize("N,K", [(256, 384), (768, 384), (384, 768), (96, 384), (384, 96), (96, 48), (384, 672), (4, 132)])
-@pytest.mark.parametrize("wide", ["0", "1"])
+@pytest.mark.parametrize("wide", ["1", "0"])
 def test_fp16_weight_gradient_kernel(N, K, wide):
     """gecco_gemm_tn_f16_f32 (gemm_tn_f16.hip): dW = dY^T X with both operands rounded to fp16 and one MFMA per product — against fp64 on
     the fp16-rounded operands (only the fp32 accumulation order separates them) and against fp64 on the operands themselves (the fp16
     rounding: ~3e-4); grouped partials; the AdaGN apply on X and the column sums of dY (the bias gradient) out of the same pass; X as
-    an fp16 tensor (gecco_gemm_tn_f16_b16_f32) gives the same bits.  wide = 1: the opt-in 256 x 128 / 128 x 256 block tiles
-    (GECCO_TN_F16_WIDE, read once per process: a child process)."""
-    if wide == "0":
+    an fp16 tensor (gecco_gemm_tn_f16_b16_f32) gives the same bits.  wide = 1: the 256 x 128 / 128 x 256 block tiles (the default since
+    round 6); 0: 128 x 128 everywhere (GECCO_TN_F16_WIDE=0, read once per process: a child process)."""
+    if wide == "1":
         _check_fp16_dw(N, K)
         return
     import os
@@ -131,7 +131,7 @@ def test_fp16_weight_gradient_kernel(N, K, wide):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", f"from tests.test_hip_amp import _check_fp16_dw; _check_fp16_dw({N}, {K})"], cwd=root,
-                       env={**os.environ, "GECCO_TN_F16_WIDE": "1"}, capture_output=True, text=True, timeout=300)
+                       env={**os.environ, "GECCO_TN_F16_WIDE": "0"}, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 

@@ -50,7 +50,11 @@ def main():
         pj = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "gemm_hbm_traffic.json")
         d = json.load(open(pj))
         dom = max((r for r in rows), key=lambda r: r[0])
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, root)
+        import __graft_entry__ as ge   # the content hash of the kernel sources the profiled library was built from (bench.py checks it)
         d[mode] = {
+            "tree": tree, "sources_sha": ge.built_sources_sha(),
             "kernel": dom[1] + f" (the kernel with the largest HBM traffic per evaluation of the {mode} mode)",
             "source": f"profiles/{tag}_forward_pmc_summary.txt (tools/pmc_collect.sh on tree {tree}: separate --pmc passes over 2 whole evaluations, one stream)",
             "bytes_per_launch": dom[3], "mfma_busy": dom[4],

@@ -779,18 +779,23 @@ def other_config_bench(args, rank, world, dev):
         # "l2-gather", `gather_gbs` is the algorithmic gather+write rate (it may exceed the HBM peak and is NOT an HBM fraction),
         # and the HBM figure is `hbm_floor_ms` / `hbm_frac` = the bytes that MUST cross HBM once (pyramids + output) at 8 TB/s.
         coef = ops.edm_coeffs(sigma)
-        lk = lambda: ops.ray_lookup(x, K, levels, net.table.reparam, coef=coef, want_stats=True)
+        lk_levels = net._lookup_levels(levels)      # what the plan's evaluation gathers: in the w2 mode the fp16 texel image (round 6)
+        tex = 2 if lk_levels[0].dtype == torch.float16 else 4
+        lk = lambda: ops.ray_lookup(x, K, lk_levels, net.table.reparam, coef=coef, want_stats=True)
         lk_ms = time_events(lk, 10)
+        lk32_ms = time_events(lambda: ops.ray_lookup(x, K, levels, net.table.reparam, coef=coef, want_stats=True), 10) if tex == 2 else lk_ms
         ct = 96 + 192 + 384
-        gathered, written = Bc * Nc * 4 * ct * 4, Bc * Nc * ct * 4
-        pyr_bytes = sum(f.numel() * 4 for f in levels)
-        rec_extra["lookup"] = {"kernel": "ray_lookup_kernel (one wave per point, 16-byte channel chunks of channels-last texels)",
+        gathered, written = Bc * Nc * 4 * ct * tex, Bc * Nc * ct * 4
+        pyr_bytes = sum(f.numel() * tex for f in levels)
+        rec_extra["lookup"] = {"kernel": f"ray_lookup_kernel<{'true' if tex == 2 else 'false'}> (one wave per point, channel chunks of channels-last "
+                                         f"{'fp16' if tex == 2 else 'fp32'} texels; interpolation in fp32)",
+                               "texel_bytes": tex, "ms_fp32_texels": lk32_ms,
                                "ms": lk_ms, "bound": "l2-gather", "algorithmic_bytes": gathered + written,
                                "gather_gbs": (gathered + written) / (lk_ms * 1e-3) / 1e9,
                                "hbm_bytes_once": pyr_bytes + written, "hbm_peak_gbs": PEAK_HBM_GBS,
                                "hbm_floor_ms": (pyr_bytes + written) / PEAK_HBM_GBS / 1e9 * 1e3,
                                "hbm_frac": (pyr_bytes + written) / PEAK_HBM_GBS / 1e9 * 1e3 / lk_ms,
-                               "bytes_per_point": {"gathered": 4 * ct * 4, "written": ct * 4}}
+                               "bytes_per_point": {"gathered": 4 * ct * tex, "written": ct * 4}}
     else:
         p = {k: v.to(dev) for k, v in random_state_dict(9, dc, Ll).items()}
         net = ops.LinearLiftPlan(p, Hh, Ii)

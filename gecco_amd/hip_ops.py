@@ -692,8 +692,8 @@ def frozen_weights(*plans):
     """Inside the scope the caller vouches that weights do not change: plans build their weight images once per workspace.
     Without arguments the scope covers every plan used by THIS thread; with plans (LinearLiftPlan / RayNetworkPlan /
     SetTransformerPlan, or modules' `.plan`) only those."""
-    states = [getattr(p, "images", p) for p in plans]
-    if states:
+    states = [st for p in plans for st in _image_states_of(p)]
+    if plans:
         for st in states:
             st.enter()
         try:
@@ -709,6 +709,23 @@ def frozen_weights(*plans):
         yield
     finally:
         _SCOPE.depth -= 1
+
+
+def _image_states_of(obj) -> list:
+    """The built-image records behind `obj`: a plan's own, an `_ImageState`, or — for an nn.Module (a `Diffusion`, a `SetTransformer`) — those
+    of every plan its sub-modules have built so far (a module builds its plan at its first evaluation: freeze after a warm-up call)."""
+    if isinstance(obj, _ImageState):
+        return [obj]
+    if hasattr(obj, "images"):
+        return [obj.images]
+    if isinstance(obj, torch.nn.Module):
+        found = []
+        for m in obj.modules():
+            plan = getattr(getattr(m, "_cache", None), "plan", None)
+            if plan is not None and hasattr(plan, "images") and plan.images not in found:
+                found.append(plan.images)
+        return found
+    raise TypeError(f"frozen_weights: a plan or a module expected, got {type(obj).__name__}")
 
 
 class _ImageState:

@@ -186,6 +186,25 @@ def test_frozen_scope_and_image_tokens_are_per_plan_and_per_thread():
     assert a.token(False) is None
 
 
+def test_frozen_weights_accepts_plans_states_and_modules():
+    from gecco_amd import hip_ops as ops
+    from gecco_amd.models.set_transformer import SetTransformer
+    st = ops._ImageState()
+    m = SetTransformer(n_layers=1, feature_dim=64, num_inducers=64, t_embed_dim=1, num_heads=8)
+    assert ops._image_states_of(st) == [st] and ops._image_states_of(m) == []     # (no plan built yet: nothing to freeze)
+
+    class FakePlan:
+        images = st
+    m._cache.plan = FakePlan()
+    assert ops._image_states_of(m) == [st] and ops._image_states_of(FakePlan()) == [st]
+    with ops.frozen_weights(m):
+        assert st.depth == 1 and st.token(False) is not None
+    assert st.depth == 0
+    with pytest.raises(TypeError):
+        with ops.frozen_weights(3):
+            pass
+
+
 def test_two_plans_with_different_modes_and_options_do_not_alias(monkeypatch):
     """Two plans in one process: each carries its own precision and its own pinned path switches in its table (GeccoSetTransformer.opt_mask
     / opt_vals, ABI 14); pinning on one leaves the other — and the process-wide defaults — untouched.  (Plans hold raw pointers only:

@@ -541,3 +541,31 @@ def test_num_inducers_other_than_64_runs_the_general_path(I, d):
     for k, q in m.named_parameters():
         if k.startswith("backbone.model."):
             _close(q.grad, pr[k[len("backbone.model."):]].grad, 2e-4)
+
+
+def test_integration_md_ctypes_binding_runs():
+    """INTEGRATION.md section 2 shows the ctypes binding a maintainer of gecco_torch would add around `libgecco_hip.so`.  The code block is
+    EXECUTED here as it stands in the document (struct layouts incl. the ABI-14 fields, argtypes, the table builder, the forward) on a
+    network with the reference's parameter names, and must give the bits of the package's own plan in the same mode."""
+    import re
+    from gecco_amd import hip_ops
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", md, flags=re.S)
+    code = next(b for b in blocks if "def edm_precond_forward" in b and "class SetTransformer(C.Structure)" in b)
+    code = code.replace('C.CDLL("gecco_amd/libgecco_hip.so")', f'C.CDLL("{os.path.join(root, "gecco_amd", "libgecco_hip.so")}")')
+    ns: dict = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    name = "uncond_d384_L6_N128"
+    d, L, N, seed = cases.UNCOND_CASES[name]
+    p, x, sigma = cases.uncond_inputs(name)
+    m = build_uncond(d, L)
+    m.load_state_dict(uncond_state_dict(p))
+    m = m.cuda().eval()
+    net = m.backbone.model                                  # LinearLift: the reference's parameter names
+    tbl, keep = ns["table"](net)
+    got = ns["edm_precond_forward"](tbl, x.cuda().contiguous(), sigma.cuda().contiguous())
+    torch.cuda.synchronize()
+    ref = hip_ops.LinearLiftPlan(dict(net.named_parameters()), cases.H, cases.I, precision="w2").forward(x.cuda(), sigma.cuda())
+    assert torch.equal(got, ref)
+    del keep

@@ -190,12 +190,12 @@ int linear_pair(const float* A, const float* W1, const float* b1, int Nout1, flo
 }
 
 // Path switches for A/B runs and tests: gecco_set_option, or the environment (GECCO_ASTAT, GECCO_CHAIN) on first use.
-enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_HEADMAJOR = 2, OPT_MLPFUSED = 3, OPT_UNPOOLFUSED = 4, OPT_LO8 = 5, OPT_ACTIMG = 6, OPT_H8 = 7, OPT_KVQ64 = 8, OPT_H8AREG = 9, OPT_CHAIN2 = 10, OPT_UNPOOLH8 = 11, OPT_MLPW = 12, OPT_CHAINCL = 13, OPT_H6 = 14, OPT_KVFOLD = 15, OPT_MLPWSHARE = 16, OPT_KVQPERM = 17, OPT_COUNT = 18 };
-int g_options[OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
-const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor", "mlpfused", "unpoolfused", "lo8", "actimg", "h8", "kvq64", "h8areg", "chain2", "unpoolh8", "mlpw", "chaincl", "h6", "kvfold", "mlpwshare", "kvqperm"};
+enum { OPT_ASTAT = 0, OPT_CHAIN = 1, OPT_HEADMAJOR = 2, OPT_MLPFUSED = 3, OPT_UNPOOLFUSED = 4, OPT_LO8 = 5, OPT_ACTIMG = 6, OPT_H8 = 7, OPT_KVQ64 = 8, OPT_H8AREG = 9, OPT_CHAIN2 = 10, OPT_UNPOOLH8 = 11, OPT_MLPW = 12, OPT_CHAINCL = 13, OPT_H6 = 14, OPT_KVFOLD = 15, OPT_MLPWSHARE = 16, OPT_KVQPERM = 17, OPT_IMGPROJ16 = 18, OPT_COUNT = 19 };
+int g_options[OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+const char* const g_option_names[OPT_COUNT] = {"astat", "chain", "headmajor", "mlpfused", "unpoolfused", "lo8", "actimg", "h8", "kvq64", "h8areg", "chain2", "unpoolh8", "mlpw", "chaincl", "h6", "kvfold", "mlpwshare", "kvqperm", "imgproj16"};
 const char* const g_option_env[OPT_COUNT] = {"GECCO_ASTAT", "GECCO_CHAIN", "GECCO_HEADMAJOR", "GECCO_MLPFUSED", "GECCO_UNPOOLFUSED", "GECCO_LO8",
                                              "GECCO_ACTIMG", "GECCO_H8", "GECCO_KVQ64", "GECCO_H8AREG", "GECCO_CHAIN2", "GECCO_UNPOOLH8", "GECCO_MLPW", "GECCO_CHAINCL", "GECCO_H6", "GECCO_KVFOLD", "GECCO_MLPWSHARE",
-                                             "GECCO_KVQPERM"};
+                                             "GECCO_KVQPERM", "GECCO_IMGPROJ16"};
 // A plan's own switches (GeccoSetTransformer.opt_mask / opt_vals: gecco_option_index(name) is the bit) win over the process-wide ones
 // while that plan's forward runs on this thread: two plans, or two host threads, never see each other's settings.
 thread_local const GeccoSetTransformer* t_plan = nullptr;
@@ -747,7 +747,7 @@ int gecco_set_option(const char* name, int value) {
             g_options[i] = value < 0 ? -1 : (value != 0);   // < 0: back to the environment / default
             return 0;
         }
-    return fail(-2, "set_option: unknown option '%s' (astat, chain, headmajor, mlpfused, unpoolfused, lo8, actimg, h8, kvq64, h8areg, chain2, unpoolh8, mlpw, chaincl, h6, kvfold, mlpwshare, kvqperm)", name);
+    return fail(-2, "set_option: unknown option '%s' (astat, chain, headmajor, mlpfused, unpoolfused, lo8, actimg, h8, kvq64, h8areg, chain2, unpoolh8, mlpw, chaincl, h6, kvfold, mlpwshare, kvqperm, imgproj16)", name);
 }
 
 int gecco_linear_row_tiles(int rows) { return row_tiles_gemm(rows); }
@@ -1671,6 +1671,7 @@ int make_lookup_args(const GeccoReparam* rp, const GeccoPyramid* pyr, LookupArgs
         a->c_total += a->C[l];
     }
     a->texel_f16 = pyr->texel_f16 ? 1 : 0;
+    a->out_f16 = 0;
     a->reparam_kind = rp ? rp->kind : 0;
     a->rp_mean = rp ? rp->mean : nullptr;
     a->rp_std = rp ? rp->std : nullptr;
@@ -1680,7 +1681,7 @@ int make_lookup_args(const GeccoReparam* rp, const GeccoPyramid* pyr, LookupArgs
 }
 
 struct RNWorkspace {
-    float *feat, *raw, *coef, *stats_raw, *stats_x, *stats_out, *a_raw, *o_raw, *a_out, *o_out, *wsplit;
+    float *feat, *raw, *coef, *stats_raw, *stats_x, *stats_out, *a_raw, *o_raw, *a_out, *o_out, *wsplit, *wfold, *bfold;
     void* st_ws;
     size_t st_bytes, bytes;
 };
@@ -1700,6 +1701,10 @@ RNWorkspace carve_rn(const GeccoRayNetwork* m, int c_total, int B, int N, void* 
     w.a_out = c.f32((size_t)B * C);
     w.o_out = c.f32((size_t)B * C);
     w.wsplit = c.f32(((C + 127) / 128 * 128) * (size_t)c_total);   // tiled image of img_feature_proj (precision 1 / 2)
+    // "w2" mode ("imgproj16"): per-sample fp16 images of img_feature_proj with GN16's scale folded in, and the biases with its offsets
+    const bool fold = m->backbone.precision == 4;
+    w.wfold = fold ? c.f32((size_t)B * ((C + 127) / 128 * 128) * c_total / 2) : nullptr;
+    w.bfold = fold ? c.f32((size_t)B * C) : nullptr;
     c.off = (c.off + 255) & ~size_t(255);
     w.st_bytes = carve_st(&m->backbone, B, N, nullptr).bytes;
     w.st_ws = base ? static_cast<char*>(base) + c.off : nullptr;
@@ -1805,13 +1810,29 @@ int gecco_ray_network_fwd_f32(const GeccoRayNetwork* m, const float* x, const fl
     // xyz_embed(c_in * x)  (models/ray.py:99)
     TRY(lift_launch(x, w.coef, m->xyz_w, m->xyz_b, w.feat, nullptr, B, N, C, s), "xyz_embed");
     // projective lookup on c_in * x, fp32 always (models/ray.py:103-109) + GN(16) partials
+    // "w2" (option "imgproj16"): the lookup leaves halves, GN16's apply goes INTO the weights (per-sample images of W * a, biases + W o) and
+    // img_feature_proj multiplies fp16(lookup) by them, one term each, on the fp16-operand streaming kernel: a third of split-bf16's matrix
+    // work on half its operand bytes (the mode's one-term operands are the hidden layer, K and q already)
+    PlanScope plan_scope(&m->backbone);
+    const bool img16 = m->backbone.precision == 4 && option(OPT_IMGPROJ16) && a.c_total % 32 == 0 && N >= 128 && C % 4 == 0;
+    a.out_f16 = img16;
     TRY(ray_lookup_launch(x, w.coef, K, a, w.raw, w.stats_raw, B, N, s), "ray_lookup");
     TRY(adagn_coeffs_launch(w.stats_raw, gecco_lookup_row_tiles(N), N, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
                             w.a_raw, w.o_raw, B, a.c_total, 16, 1e-5f, s), "gn16(img)");
     // point_features = xyz_features + Linear(GN16(lookup))  (models/ray.py:112-113): GN apply in the GEMM
     // prologue, the add as its residual, the first AdaGN's statistics in its epilogue
-    TRY(linear(w.raw, m->img_w, m->img_b, w.a_raw, w.o_raw, nullptr, w.feat, w.feat, w.stats_x, B, N, a.c_total, C, 0,
-               s, m->backbone.precision >= 3 ? 1 : m->backbone.precision, w.wsplit), "img_feature_proj");   // mixed mode: split-bf16
+    if (img16) {
+        TRY(fold_f16_image_launch(m->img_w, m->img_b, w.a_raw, w.o_raw, w.wfold, w.bfold, B, C, a.c_total, a.c_total, s), "img_feature_proj fold");
+        GemmArgs g{};
+        g.A = w.raw; g.a_f16 = 1; g.bias = w.bfold; g.bias_bstride = C; g.residual = w.feat; g.C = w.feat; g.stats = w.stats_x;
+        g.B = B; g.rows = N; g.K = a.c_total; g.Nout = C; g.lda = a.c_total; g.ldw = a.c_total; g.ldc = C; g.ldr = C;
+        g.precision = 2; g.w_img = w.wfold; g.w_img_bstride = (size_t)((C + 127) / 128 * 128) * a.c_total / 2;
+        if (!gemm_f16_dma_supported(g)) return fail(-9, "img_feature_proj: shape outside the fp16 streaming kernel");
+        TRY(gemm_f32_launch(g, s), "img_feature_proj");
+    } else {
+        TRY(linear(w.raw, m->img_w, m->img_b, w.a_raw, w.o_raw, nullptr, w.feat, w.feat, w.stats_x, B, N, a.c_total, C, 0,
+                   s, m->backbone.precision >= 3 ? 1 : m->backbone.precision, w.wsplit), "img_feature_proj");   // mixed mode: split-bf16
+    }
     rc = st_forward(&m->backbone, w.feat, w.coef + 4 * (size_t)B, w.stats_x, row_tiles_gemm(N), h_in, h_out,
                     w.stats_out, B, N, w.st_ws, w.st_bytes, s);
     if (rc) return rc;

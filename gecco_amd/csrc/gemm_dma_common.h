@@ -56,7 +56,7 @@ __device__ __forceinline__ Tile tile_of_block(const GemmArgs& g) {
     t.nseg0 = seg2 ? t.n0 - g.n_split : t.n0;
     t.nseg = g.C2 ? (seg2 ? g.Nout - g.n_split : g.n_split) : g.Nout;
     t.Wseg = seg2 ? g.W2 : g.W;
-    t.bias_seg = seg2 ? g.bias2 : g.bias;
+    t.bias_seg = seg2 ? g.bias2 : g.bias ? g.bias + (size_t)t.b * g.bias_bstride : nullptr;
     t.Cseg = seg2 ? g.C2 : g.C;
     t.ldc_seg = seg2 ? g.ldc2 : g.ldc;
     return t;

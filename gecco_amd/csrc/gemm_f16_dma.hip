@@ -121,7 +121,7 @@ __global__ __launch_bounds__(DNT, A16 ? 3 : 2) void gemm_f16_kernel(GemmArgs g) 
         }
     }
     const int nk = g.K / FBK;
-    const float* bsrc = static_cast<const float*>(g.w_img) + (size_t)ct * nk * FB_TILE + (2 * wave) * 256 + lane * 4;
+    const float* bsrc = static_cast<const float*>(g.w_img) + (size_t)b * g.w_img_bstride + (size_t)ct * nk * FB_TILE + (2 * wave) * 256 + lane * 4;
     auto issue = [&](int kt) {
 #ifdef GEMM_DIAG_NODMA
         return;
@@ -312,6 +312,47 @@ __device__ __forceinline__ void f8lo_image_item(const float* __restrict__ W, flo
     *reinterpret_cast<u32x4*>(img + blk * FB_TILE + rb * 16 + chp * 4) = out;
 }
 
+// Sample blockIdx.y's folded image (kernels.h fold_f16_image_launch): the items of f16_image_item with W's k scaled by pa[b, k]; the blocks
+// past the image's fold the offsets into the bias, one wave per output column
+__global__ __launch_bounds__(256) void fold_f16_image_kernel(const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ pa,
+                                                             const float* __restrict__ po, float* __restrict__ img, float* __restrict__ bias_out,
+                                                             int Nout, int K, int ldw, int item_blocks) {
+    const int b = blockIdx.y;
+    const int nk = K / FBK, tilesN = (Nout + DBN - 1) / DBN;
+    if ((int)blockIdx.x >= item_blocks) {
+        const int n = ((int)blockIdx.x - item_blocks) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        if (n >= Nout) return;
+        float acc = 0.f;
+        for (int k0 = 0; k0 < K; k0 += 1024) {   // sixteen independent loads per operand in flight, then the sum in a fixed order
+            float wv[16], ov[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int k = k0 + 64 * j + lane;
+                wv[j] = k < K ? W[(size_t)n * ldw + k] : 0.f;
+                ov[j] = k < K ? po[(size_t)b * K + k] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc += ov[j] * wv[j];
+        }
+#pragma unroll
+        for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) bias_out[(size_t)b * Nout + n] = (bias ? bias[n] : 0.f) + acc;
+        return;
+    }
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)tilesN * nk * 512;
+    if (i >= total) return;
+    const int chp = (int)(i & 3), rb = (int)((i >> 2) & 127);
+    const size_t blk = i >> 9;
+    const int kt = (int)(blk % nk), ct = (int)(blk / nk);
+    const int s = chp ^ ((rb >> 2) & 3);
+    const int k0 = kt * FBK + 16 * (s >> 1) + 8 * (s & 1);
+    const float* src = W + (size_t)min(ct * DBN + rb, Nout - 1) * ldw + k0;
+    const float* sc = pa + (size_t)b * K + k0;
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(src) * *reinterpret_cast<const f32x4*>(sc);
+    const f32x4 w1 = *reinterpret_cast<const f32x4*>(src + 4) * *reinterpret_cast<const f32x4*>(sc + 4);
+    *reinterpret_cast<u32x4*>(img + (size_t)b * tilesN * nk * FB_TILE + blk * FB_TILE + rb * 16 + chp * 4) = __builtin_bit_cast(u32x4, cvt8(w0, w1));
+}
+
 __global__ void split_f16_tiled_kernel(const float* __restrict__ W, float* __restrict__ img, int Nout, int K, int ldw,
                                        size_t total) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
@@ -436,6 +477,16 @@ int split_f16_tiled_launch(const float* W, void* img, int Nout, int K, int ldw, 
     const unsigned grid = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(split_f16_tiled_kernel, dim3(grid ? grid : 1), dim3(256), 0, st, W, static_cast<float*>(img), Nout,
                        K, ldw, total);
+    return (int)hipGetLastError();
+}
+
+int fold_f16_image_launch(const float* W, const float* bias, const float* pa, const float* po, void* img, float* bias_out, int B, int Nout, int K,
+                          int ldw, hipStream_t st) {
+    if (K % FBK || (ldw & 3) || B < 1) return -8;
+    const size_t total = (size_t)((Nout + DBN - 1) / DBN) * (K / FBK) * 512;
+    const int item_blocks = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(fold_f16_image_kernel, dim3(item_blocks + (Nout + 3) / 4, B), dim3(256), 0, st, W, bias, pa, po, static_cast<float*>(img),
+                       bias_out, Nout, K, ldw, item_blocks);
     return (int)hipGetLastError();
 }
 

@@ -59,6 +59,10 @@ struct GemmArgs {
     // with `stats`, the second statistic becomes sum_rows C * dot_x instead of sum_rows C^2 — {sum dy, sum dy x} of col_dot_stats_kernel,
     // dot_x (B, rows, ldc) the tensor the AdaGN normalised.  Not with residual / mul_u / pre_out.
     const float* dot_x;
+    // fp16 LDS-DMA kernel only: PER-SAMPLE weights — sample b streams the image at w_img + b * w_img_bstride floats and adds bias + b *
+    // bias_bstride (0: one image / bias for all samples).  img_feature_proj with the GroupNorm apply folded into the weights (fold_f16_image_launch)
+    size_t w_img_bstride;
+    int bias_bstride;
     int h8_rev;                // gemm_h8_astat.hip: blocks walk the row panels last to first (the producer wrote them first to last)
     // gemm_kvq_astat_kernel, head-major fp16 outputs at head dim 48 (feature_dim 384, 8 heads): the columns of every 384-column segment
     // (K, V, q) are dealt to its six 64-column tiles HEAD-ALIGNED — tile t = head t's 48 columns + the (t % 3)-th 16-column third of head
@@ -88,6 +92,10 @@ int split_bf16_tiled_multi_launch(const SplitJobs& jobs, hipStream_t st);   // K
 bool gemm_f16_dma_supported(const GemmArgs& g);
 int gemm_f16_dma_launch(const GemmArgs& g, hipStream_t st);
 size_t split_f16_image_bytes(int Nout, int K);   // ceil(Nout / 128) * 128 * K * 2
+// Per-sample folded fp16 weight images: img_b = the split_f16_tiled image of W * pa[b, :] (column scale), bias_out[b, n] = bias[n] + sum_k po[b, k]
+// W[n, k] (fp32): a linear over A * pa + po as a linear over A itself.  img: B images of ceil(Nout / 128) * 128 * K halves; K % 32 == 0
+int fold_f16_image_launch(const float* W, const float* bias, const float* pa, const float* po, void* img, float* bias_out, int B, int Nout, int K,
+                          int ldw, hipStream_t st);
 int split_f16_tiled_launch(const float* W, void* img, int Nout, int K, int ldw, hipStream_t st);
 int split_f16_tiled_multi_launch(const SplitJobs& jobs, hipStream_t st);
 
@@ -331,6 +339,7 @@ struct LookupArgs {
     int C[4], H[4], W[4];
     const float* feat[4];  // channels-last (B, H, W, C) per level
     int texel_f16;         // the levels hold fp16 texels (forward lookups only)
+    int out_f16;           // ray_lookup_launch writes `out` as halves (statistics from the fp32 values); the network forward's "imgproj16"
     int reparam_kind;      // 0 none, 1 gaussian (mean, sigma), 2 UVL (uvl_mean, uvl_std, logit_scale)
     const float* rp_mean;
     const float* rp_std;

@@ -79,7 +79,7 @@ __device__ __forceinline__ f32x4 texel4(const float* fb, size_t off) {
     }
 }
 
-template <bool TEX16>
+template <bool TEX16, bool OUT16 = false>
 __global__ __launch_bounds__(256) void ray_lookup_kernel(const float* __restrict__ geom,
                                                          const float* __restrict__ coef,
                                                          const float* __restrict__ K, LookupArgs a,
@@ -150,7 +150,13 @@ __global__ __launch_bounds__(256) void ray_lookup_kernel(const float* __restrict
             const float w_nw = (bx0 && by0) ? wx0 * wy0 : 0.f, w_ne = (bx1 && by0) ? wx1 * wy0 : 0.f;
             const float w_sw = (bx0 && by1) ? wx0 * wy1 : 0.f, w_se = (bx1 && by1) ? wx1 * wy1 : 0.f;
             const f32x4 r = nw * w_nw + ne * w_ne + sw * w_sw + se * w_se;
-            *reinterpret_cast<f32x4*>(orow + c4 * 4) = r;
+            if constexpr (OUT16) {   // (B, N, Ct) halves for a matrix kernel that rounds its operand to fp16 anyway; the statistics are the fp32 values
+                typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(out) + ((size_t)b * N + m) * Ct)[c4] =
+                    f16x4{(_Float16)r[0], (_Float16)r[1], (_Float16)r[2], (_Float16)r[3]};
+            } else {
+                *reinterpret_cast<f32x4*>(orow + c4 * 4) = r;
+            }
             s1[c] += r;
             s2[c] += r * r;
         }
@@ -602,6 +608,11 @@ int ray_lookup_launch(const float* geom, const float* coef, const float* K, cons
     }
     if (tot != a.c_total) return -8;
     const int T = (N + LOOKUP_ROWS - 1) / LOOKUP_ROWS;
+    if (a.out_f16) {
+        if (a.texel_f16) hipLaunchKernelGGL((ray_lookup_kernel<true, true>), dim3(B * T), dim3(256), 0, st, geom, coef, K, a, out, stats, N, T);
+        else hipLaunchKernelGGL((ray_lookup_kernel<false, true>), dim3(B * T), dim3(256), 0, st, geom, coef, K, a, out, stats, N, T);
+        return (int)hipGetLastError();
+    }
     if (a.texel_f16) hipLaunchKernelGGL(ray_lookup_kernel<true>, dim3(B * T), dim3(256), 0, st, geom, coef, K, a, out, stats, N, T);
     else hipLaunchKernelGGL(ray_lookup_kernel<false>, dim3(B * T), dim3(256), 0, st, geom, coef, K, a, out, stats, N, T);
     return (int)hipGetLastError();

@@ -148,6 +148,15 @@ def _run_cond(ops, case, precision, tag):
         img16 = net._tex16[1]
         net.forward(x.cuda(), sigma.cuda(), K.cuda(), levels)
         assert net._tex16[1] is img16
+        # img_feature_proj: fp16(lookup) times per-sample fp16 images of W with GN16's scale folded in (option "imgproj16", default on in this
+        # mode) against the split-bf16 launch of the mixed mode: a different rounding of ONE linear, both inside the mode's bar
+        alt = ops.RayNetworkPlan(_cuda(p), cases.H, cases.I, precision="w2", options={"imgproj16": 0})
+        den0, raw0 = alt.forward(x.cuda(), sigma.cuda(), K.cuda(), levels, return_raw=True)
+        assert not torch.equal(raw0, raw)
+        _report(f"{tag} w2 F_x, imgproj16 = 0, vs oracle", raw0, raw_ref, BARS_FX["w2"])
+        e = cpu_ref.rel_err(raw.cpu(), raw0.cpu())
+        print(f"{tag} w2: imgproj16 on vs off: max-rel {e[0]:.2e}")
+        assert e[0] < 4e-4
 
 
 @pytest.mark.parametrize("precision", MODES)

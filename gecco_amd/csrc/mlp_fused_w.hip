@@ -1,6 +1,6 @@
 // The point MLP of a layer as ONE launch, the hidden layer never leaves the registers (gfx950):
 //
-//     x += mlp.2( act( mlp.0( AdaGN(x) ) ) ),  + the GroupNorm column partials of the new x      (feature_dim 384, width 768)
+//     x += mlp.2( act( mlp.0( AdaGN(x) ) ) ),  + the GroupNorm column partials of the new x      (feature_dim 384, width 768; also 256 and 128)
 //
 // Reference: models/set_transformer.py:164-166 (x = x + self.mlp(self.mlp_norm(x, t_embed))), models/mlp.py:5-39,
 // models/activation.py:17-24, models/normalization.py:36-44.
@@ -57,22 +57,35 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x6 __attribute__((ext_vector_type(6)));
 
-constexpr int W_C = 384, W_WD = 768;
-constexpr int W_NG = 6;                    // 64-k groups of mlp.0
-constexpr int W_NT = 12;                   // 64-column hidden tiles = 64-k groups of mlp.2
-constexpr int W_NB = 12;                   // 32-column output blocks
-constexpr int W_SLOT = 44 * 1024;          // ring slot (bytes)
+// Shape of an instantiation: feature_dim = 64 NG (NG = 2, 4, 6: 128, 256, 384), width = 2 feature_dim.  (NG = 8, feature_dim 512, does not
+// fit the register file: y 128 + 48, the hidden fragments 256, two accumulator pairs 64 and two operand sets 64 are 560 of 512.)
+template <int NG_>
+struct WCfg {
+    static constexpr int NG = NG_;                 // 64-k groups of mlp.0
+    static constexpr int C = 64 * NG, WD = 2 * C;
+    static constexpr int NT = 2 * NG;              // 64-column hidden tiles = 64-k groups of mlp.2
+    static constexpr int NB = 2 * NG;              // 32-column output blocks
+    static constexpr int GS = NG / 2;              // groups of a phase-1 stage (half a hidden tile) = tile pairs of a phase-2 stage (half a block)
+    static constexpr int NSETS = NG;               // sets of matrix instructions per stage: two per group / one per hidden tile
+    static constexpr int CH1 = (2 + 14 * GS + 3) & ~3, CH2 = (1 + 11 * GS + 3) & ~3;   // chunks of a stage, phase 1 / phase 2 (44 / 36 at NG = 6)
+    static constexpr int SLOT = (CH1 > CH2 ? CH1 : CH2) * 1024;                        // ring slot (bytes)
+    static constexpr int NP1 = CH1 / 4, NP2 = CH2 / 4;                                  // 1 KiB pieces per wave and stage
+    static constexpr size_t STREAM = (size_t)2 * NT * CH1 * 1024 + (size_t)2 * NB * CH2 * 1024;   // 1920 KiB per layer at NG = 6
+    static constexpr int HB1 = 4 * GS;             // scale bytes per lane in a phase-1 stage header
+    static constexpr int HDR_BYTES = 2 * NT * 64 * HB1 + 2 * NB * 64 * 8;
+    // the previous hidden tile's activation (8 register quads) rides in the first ACT_SETS of a tile's 2 NG sets, the next tile's bias in the rest
+    static constexpr int ACT_SETS = NG == 6 ? 8 : NG, QA = 8 / ACT_SETS, QB = 8 / (2 * NG - ACT_SETS);
+    static constexpr int COLP = 4 * 2 * C * 4;
+    static constexpr int LDS = 3 * SLOT + 4 * 4096 + COLP;
+    static_assert(NG == 2 || NG == 4 || NG == 6, "feature_dim 128, 256 or 384");
+    static_assert(LDS <= 160 * 1024 && COLP >= 2 * C * 4, "one block per CU");
+};
 constexpr int W_NS = 3;
-constexpr int W_CH1 = 44, W_CH2 = 36;      // chunks of a stage, phase 1 / phase 2
-constexpr int W_NP1 = W_CH1 / 4, W_NP2 = W_CH2 / 4;   // 1 KiB pieces per wave and stage
-constexpr size_t W_STREAM = (size_t)2 * W_NT * W_CH1 * 1024 + (size_t)2 * W_NB * W_CH2 * 1024;   // 1920 KiB per layer
 constexpr int W_STG = 4096;                // wave-private staging tile of the y build: [32 rows][64 fp16]
 // LDS (bytes): ring | 4 wave-private tiles of 4 KiB (the y build's staging; in phase 2 the [32 rows][32 columns] fp32 tile through which the
-// residual rows come in and the results leave in 16-byte pieces) | the tile's column partials [4 waves][2][384] floats, whose first 3 KiB hold
+// residual rows come in and the results leave in 16-byte pieces) | the tile's column partials [4 waves][2][C] floats, whose first 2 C floats hold
 // the sample's AdaGN coefficients pa | po while the y build runs.  The biases ride in the weight stream's stage headers.
-constexpr int W_COLP = 4 * 2 * W_C * 4;
-constexpr int W_LDS = W_NS * W_SLOT + 4 * W_STG + W_COLP;
-static_assert(W_LDS <= 160 * 1024 && W_COLP >= 2 * W_C * 4 && W_STG == 32 * 32 * 4, "one block per CU");
+static_assert(W_STG == 32 * 32 * 4, "the phase-2 tile");
 
 constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 0xF) | (0x7 << 4) | ((lgkm & 0xF) << 8) | ((vm >> 4) << 14); }
 template <int N>
@@ -155,18 +168,19 @@ __device__ __forceinline__ i32x8 w_op6(const u32x6& a) { return i32x8{(int)a[0],
 __host__ __device__ __forceinline__ int w_kmap(int h, int i) { return 32 * (i >> 4) + 16 * ((i >> 3) & 1) + 8 * ((i >> 2) & 1) + 4 * h + (i & 3); }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The weight stream of a layer (W_STREAM bytes), in consumption order.  1 KiB chunks; lane l = 32 h + r.
-// Phase 1, stage (t, half), groups g = 3 half + gi:  chunk 0 header: byte 4 gi + 2 term + j of lane l = scale byte of the lo operand
+// The weight stream of a layer (WCfg::STREAM bytes), in consumption order.  1 KiB chunks; lane l = 32 h + r.  GS = NG / 2 (written for NG = 6:
+// GS = 3; the smaller shapes have GS = 2 / 1 groups per stage, their stages padded with zero chunks to a multiple of four).
+// Phase 1, stage (t, half), groups g = GS half + gi:  chunk 0 header: byte 4 gi + 2 term + j of lane l = scale byte of the lo operand
 //   (term 0: W1 - fp16(W1), term 1: W1; hidden block j) of that lane; chunk 1: (half 0) floats 0 .. 63 = mlp.0's bias of the tile's 64
 //   hidden columns (x the activation's argument scale, like the weights); group gi at chunk 2 + 14 gi:
 //     + 2 s + j (s = 0 .. 3): fp16(W1[64 t + 32 j + r][64 g + 16 s + 8 h + e]), e = 0 .. 7
 //     + 8 + j: dwords 0 - 3 of the term-0 operand of block j;  + 10: its dwords 4 - 5, [j][lane] 8 bytes each
 //     + 11 + j, + 13: the same for term 1
 //   a lo operand = 32 values X[64 t + 32 j + r][64 g + 16 (i >> 3) + 8 h + (i & 7)] / 2^(scale - 127) as fp6 (e2m3), element i at bit 6 i
-// Phase 2, stage (nb, half), hidden tiles t = 6 half + 2 pi + tt:  chunk 0 header: byte 2 pi + tt = scale byte of tile t's lo operand, dword 2
+// Phase 2, stage (nb, half), hidden tiles t = NG half + 2 pi + tt:  chunk 0 header: byte 2 pi + tt = scale byte of tile t's lo operand, dword 2
 //   of lane l = mlp.2's bias of column 32 nb + (l & 31);
 //   pair pi at chunk 1 + 11 pi:  + 5 tt + s: fp16(W2[32 nb + r][64 t + kmap(h, 8 s + e)]);  + 5 tt + 4: dwords 0 - 3 of the lo operand
-//   (W2 - fp16(W2) at [32 nb + r][64 t + kmap(h, i)]);  + 10: dwords 4 - 5, [tt][lane];  chunks 34, 35 unused.
+//   (W2 - fp16(W2) at [32 nb + r][64 t + kmap(h, i)]);  + 10: dwords 4 - 5, [tt][lane];  the chunks past 1 + 11 GS unused.
 // One thread per 16-byte item.
 struct WLo {
     u32x6 pk;
@@ -186,8 +200,8 @@ __device__ __forceinline__ WLo w_lo_pack(const float (&v)[32]) {
     return r;
 }
 // the lo operand of phase 1: (t, g, j, term) of lane (r, h)
-__device__ __forceinline__ WLo w_lo1(const float* __restrict__ W1, float ws, int t, int g, int j, int term, int r, int h) {
-    const float* src = W1 + (size_t)(64 * t + 32 * j + r) * W_C + 64 * g + 8 * h;
+__device__ __forceinline__ WLo w_lo1(const float* __restrict__ W1, int C, float ws, int t, int g, int j, int term, int r, int h) {
+    const float* src = W1 + (size_t)(64 * t + 32 * j + r) * C + 64 * g + 8 * h;
     float v[32];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
@@ -206,8 +220,8 @@ __device__ __forceinline__ WLo w_lo1(const float* __restrict__ W1, float ws, int
     return w_lo_pack(v);
 }
 // the lo operand of phase 2: (nb, t) of lane (r, h)
-__device__ __forceinline__ WLo w_lo2(const float* __restrict__ W2, int nb, int t, int r, int h) {
-    const float* src = W2 + (size_t)(32 * nb + r) * W_WD + 64 * t + 4 * h;
+__device__ __forceinline__ WLo w_lo2(const float* __restrict__ W2, int WD, int nb, int t, int r, int h) {
+    const float* src = W2 + (size_t)(32 * nb + r) * WD + 64 * t + 4 * h;
     float v[32];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {   // elements 4 q .. 4 q + 3: k = 8 q + 4 h + e
@@ -235,8 +249,10 @@ struct MlpwImageJobs {     // the layers of one launch (blockIdx.y)
 };
 // Threads: one per 16-byte item of the stream, then one per scale BYTE of the stage headers (a header item alone would form its lane's 12
 // lo operands one after the other — 12 x 32 dependent loads: the launch's critical path, 18 us for 1.9 MB).
-constexpr int W_HDR_BYTES = 2 * W_NT * 64 * 12 + 2 * W_NB * 64 * 8;
+template <int NG>
 __global__ void mlpw_image_kernel(MlpwImageJobs jobs) {
+    typedef WCfg<NG> K;
+    constexpr int C = K::C, WD = K::WD, CH1 = K::CH1, CH2 = K::CH2, GS = K::GS, HB1 = K::HB1;
     const int li = blockIdx.y;
     const float* __restrict__ W1 = jobs.W1[li];
     const float* __restrict__ b1 = jobs.b1[li];
@@ -244,28 +260,29 @@ __global__ void mlpw_image_kernel(MlpwImageJobs jobs) {
     const float* __restrict__ b2 = jobs.b2[li];
     unsigned* __restrict__ img = jobs.img[li];
     const float ws = w_act_scale(jobs.alpha[li], jobs.act);
-    const size_t items = W_STREAM / 16;
-    const size_t p1_items = (size_t)2 * W_NT * W_CH1 * 64;
-    for (size_t hb = (size_t)blockIdx.x * blockDim.x + threadIdx.x; hb >= items && hb < items + W_HDR_BYTES; hb += (size_t)gridDim.x * blockDim.x) {
+    const size_t items = K::STREAM / 16;
+    const size_t p1_items = (size_t)2 * K::NT * CH1 * 64;
+    for (size_t hb = (size_t)blockIdx.x * blockDim.x + threadIdx.x; hb >= items && hb < items + K::HDR_BYTES; hb += (size_t)gridDim.x * blockDim.x) {
         const int q = (int)(hb - items);
         unsigned char* out8 = reinterpret_cast<unsigned char*>(img);
-        if (q < 2 * W_NT * 64 * 12) {
-            const int stage = q / (64 * 12), l = (q / 12) & 63, b = q % 12, t = stage >> 1, half = stage & 1;
+        if (q < 2 * K::NT * 64 * HB1) {
+            const int stage = q / (64 * HB1), l = (q / HB1) & 63, b = q % HB1, t = stage >> 1, half = stage & 1;
             const int gi = b >> 2, term = (b >> 1) & 1, j = b & 1;
-            out8[((size_t)stage * W_CH1 * 64 + l) * 16 + b] = (unsigned char)w_lo1(W1, ws, t, 3 * half + gi, j, term, l & 31, l >> 5).sb;
+            out8[((size_t)stage * CH1 * 64 + l) * 16 + b] = (unsigned char)w_lo1(W1, C, ws, t, GS * half + gi, j, term, l & 31, l >> 5).sb;
         } else {
-            const int q2 = q - 2 * W_NT * 64 * 12;
+            const int q2 = q - 2 * K::NT * 64 * HB1;
             const int stage = q2 / (64 * 8), l = (q2 / 8) & 63, b = q2 & 7, nb = stage >> 1, half = stage & 1;
-            out8[(p1_items + (size_t)stage * W_CH2 * 64 + l) * 16 + b] = b < 6 ? (unsigned char)w_lo2(W2, nb, 6 * half + b, l & 31, l >> 5).sb : (unsigned char)0;
+            out8[(p1_items + (size_t)stage * CH2 * 64 + l) * 16 + b] = b < 2 * GS ? (unsigned char)w_lo2(W2, WD, nb, NG * half + b, l & 31, l >> 5).sb : (unsigned char)0;
         }
     }
     for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (size_t)gridDim.x * blockDim.x) {
         u32x4 out = {0u, 0u, 0u, 0u};
         if (it < p1_items) {
-            const int stage = (int)(it / (W_CH1 * 64)), ci = (int)(it % (W_CH1 * 64));
+            const int stage = (int)(it / (CH1 * 64)), ci = (int)(it % (CH1 * 64));
             const int chunk = ci >> 6, l = ci & 63, t = stage >> 1, half = stage & 1;
-            if (chunk == 0) {   // bytes 0 .. 11: the byte threads above
-                img[it * 4 + 3] = 0u;
+            if (chunk == 0) {   // bytes 0 .. HB1 - 1: the byte threads above; the dwords past them are zero
+#pragma unroll
+                for (int d = GS; d < 4; ++d) img[it * 4 + d] = 0u;
                 continue;
             } else if (chunk == 1) {
                 if (half == 0 && l < 16 && b1) {
@@ -273,11 +290,11 @@ __global__ void mlpw_image_kernel(MlpwImageJobs jobs) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) out[e] = __float_as_uint(bb[e] * ws);
                 }
-            } else {
-                const int gi = (chunk - 2) / 14, c = (chunk - 2) % 14, g = 3 * half + gi;
+            } else if (chunk < 2 + 14 * GS) {
+                const int gi = (chunk - 2) / 14, c = (chunk - 2) % 14, g = GS * half + gi;
                 if (c < 8) {
                     const int s = c >> 1, j = c & 1, r = l & 31, h = l >> 5;
-                    const float* src = W1 + (size_t)(64 * t + 32 * j + r) * W_C + 64 * g + 16 * s + 8 * h;
+                    const float* src = W1 + (size_t)(64 * t + 32 * j + r) * C + 64 * g + 16 * s + 8 * h;
                     const f32x4 w0 = *reinterpret_cast<const f32x4*>(src), w1 = *reinterpret_cast<const f32x4*>(src + 4);
                     f16x8 v;
 #pragma unroll
@@ -290,36 +307,36 @@ __global__ void mlpw_image_kernel(MlpwImageJobs jobs) {
                     out = __builtin_bit_cast(u32x4, v);
                 } else if (c == 8 || c == 9 || c == 11 || c == 12) {
                     const int term = c >= 11, j = (c - (term ? 11 : 8));
-                    const WLo o = w_lo1(W1, ws, t, g, j, term, l & 31, l >> 5);
+                    const WLo o = w_lo1(W1, C, ws, t, g, j, term, l & 31, l >> 5);
                     out = u32x4{o.pk[0], o.pk[1], o.pk[2], o.pk[3]};
                 } else {   // c == 10 / 13: [j][lane] 8 bytes; this item = lanes 2 q, 2 q + 1 of block j
                     const int term = c == 13, j = l >> 5, q = l & 31;
-                    const WLo a = w_lo1(W1, ws, t, g, j, term, (2 * q) & 31, (2 * q) >> 5), b = w_lo1(W1, ws, t, g, j, term, (2 * q + 1) & 31, (2 * q + 1) >> 5);
+                    const WLo a = w_lo1(W1, C, ws, t, g, j, term, (2 * q) & 31, (2 * q) >> 5), b = w_lo1(W1, C, ws, t, g, j, term, (2 * q + 1) & 31, (2 * q + 1) >> 5);
                     out = u32x4{a.pk[4], a.pk[5], b.pk[4], b.pk[5]};
                 }
             }
         } else {
             const size_t i2 = it - p1_items;
-            const int stage = (int)(i2 / (W_CH2 * 64)), ci = (int)(i2 % (W_CH2 * 64));
+            const int stage = (int)(i2 / (CH2 * 64)), ci = (int)(i2 % (CH2 * 64));
             const int chunk = ci >> 6, l = ci & 63, nb = stage >> 1, half = stage & 1;
             if (chunk == 0) {   // bytes 0 .. 7: the byte threads above
                 img[it * 4 + 2] = __float_as_uint(b2 ? b2[32 * nb + (l & 31)] : 0.f);
                 img[it * 4 + 3] = 0u;
                 continue;
-            } else if (chunk < 34) {
+            } else if (chunk < 1 + 11 * GS) {
                 const int pi = (chunk - 1) / 11, q = (chunk - 1) % 11;
                 if (q == 10) {
-                    const int tt = l >> 5, ql = l & 31, t = 6 * half + 2 * pi + tt;
-                    const WLo a = w_lo2(W2, nb, t, (2 * ql) & 31, (2 * ql) >> 5), b = w_lo2(W2, nb, t, (2 * ql + 1) & 31, (2 * ql + 1) >> 5);
+                    const int tt = l >> 5, ql = l & 31, t = NG * half + 2 * pi + tt;
+                    const WLo a = w_lo2(W2, WD, nb, t, (2 * ql) & 31, (2 * ql) >> 5), b = w_lo2(W2, WD, nb, t, (2 * ql + 1) & 31, (2 * ql + 1) >> 5);
                     out = u32x4{a.pk[4], a.pk[5], b.pk[4], b.pk[5]};
                 } else {
-                    const int tt = q / 5, s = q % 5, t = 6 * half + 2 * pi + tt, r = l & 31, h = l >> 5;
+                    const int tt = q / 5, s = q % 5, t = NG * half + 2 * pi + tt, r = l & 31, h = l >> 5;
                     if (s == 4) {
-                        const WLo o = w_lo2(W2, nb, t, r, h);
+                        const WLo o = w_lo2(W2, WD, nb, t, r, h);
                         out = u32x4{o.pk[0], o.pk[1], o.pk[2], o.pk[3]};
                     } else {
                         // element e of k-step s: k = kmap(h, 8 s + e) = 32 (s >> 1) + 16 (s & 1) + 8 (e >> 2) + 4 h + (e & 3)
-                        const float* src = W2 + (size_t)(32 * nb + r) * W_WD + 64 * t + 32 * (s >> 1) + 16 * (s & 1) + 4 * h;
+                        const float* src = W2 + (size_t)(32 * nb + r) * WD + 64 * t + 32 * (s >> 1) + 16 * (s & 1) + 4 * h;
                         const f32x4 w0 = *reinterpret_cast<const f32x4*>(src), w1 = *reinterpret_cast<const f32x4*>(src + 8);
                         f16x8 v;
 #pragma unroll
@@ -346,14 +363,14 @@ struct WBuf {       // the operands of one set of matrix instructions: up to six
 // NSETS - 2 sets, so that the youngest piece has two sets (~400 cycles) to land before the next stage entry waits for it
 template <int I, int NSETS, int NP>
 struct WSpan {
-    static constexpr int F = NSETS - 2;
+    static constexpr int F = NSETS > 2 ? NSETS - 2 : 1;
     static constexpr int a = I < F ? I * NP / F : NP, b = I < F ? (I + 1) * NP / F : NP;
 };
 // the interleave of one set (a scheduling region): NM matrix instructions, each followed by its share of the ND fragment reads of the
 // next set and of the NV LDS-DMA pieces — one instruction stream per SIMD hides nothing that is not placed between two matrix instructions
 // NA > 0: the set also carries a share of the previous hidden tile's activation — NA vector-ALU and one transcendental instruction behind
 // each matrix instruction (their issue cycles lie inside the 32 the matrix pipe is busy)
-template <int NM, int ND, int NV, int NA = 0>
+template <int NM, int ND, int NV, int NA = 0, int NX = 1>
 __device__ __forceinline__ void w_interleave() {
     sfor<NM>([&](auto I) {
         constexpr int i = decltype(I)::value;
@@ -363,13 +380,16 @@ __device__ __forceinline__ void w_interleave() {
         if constexpr (nv > 0) __builtin_amdgcn_sched_group_barrier(0x20, nv, 0);
         if constexpr (NA > 0) {
             __builtin_amdgcn_sched_group_barrier(0x2, NA, 0);
-            __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x400, NX, 0);
         }
     });
 }
 
-template <int ACT>
+template <int ACT, int NG>
 __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
+    typedef WCfg<NG> K;
+    constexpr int W_C = K::C, W_WD = K::WD, W_NG = K::NG, W_NT = K::NT, W_NB = K::NB, W_SLOT = K::SLOT, W_CH1 = K::CH1, W_CH2 = K::CH2;
+    constexpr int W_NP1 = K::NP1, W_NP2 = K::NP2, NSETS = K::NSETS, GS = K::GS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const ring = smem;
     char* const stg = ring + W_NS * W_SLOT;
@@ -388,7 +408,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
     const unsigned voff16 = (unsigned)lane * 16u;
     unsigned soff = 0;          // stream offset of the stage being issued
     int islot = 0;              // its ring slot
-    int istage = 0;             // its index in the tile's 48 stages: < 24 phase 1
+    int istage = 0;             // its index in the tile's 2 NT + 2 NB stages: < 2 NT phase 1
     auto issue_piece = [&](int np, int p) {
 #ifndef MFW_DIAG_NODMA
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(ring + islot * W_SLOT + (wave * np + p) * 1024), 16, voff16,
@@ -590,7 +610,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
         // from chunk 1 of the tile's first stage) while the other's — tile t - 1, complete — goes through the activation BETWEEN those matrix
         // instructions: with one wave per SIMD nothing else would fill the matrix pipe's busy cycles.
         f16x32 hf[W_NT];    // tile t: element i = act(u)[point r][64 t + kmap(h, i)]
-        int hsp[W_NT / 4] = {0, 0, 0};   // block scale bytes of their fp6 forms, four per register
+        int hsp[(W_NT + 3) / 4];         // block scale bytes of their fp6 forms, four per register
+#pragma unroll
+        for (int i = 0; i < (W_NT + 3) / 4; ++i) hsp[i] = 0;
         f32x16 au0[2], au1[2];
         float mact = 0.f;
         // registers 4 qq .. 4 qq + 3 of block j (q = 4 j + qq): columns 32 j + 8 qq + 4 h + e of the tile
@@ -658,12 +680,12 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
                 stage_enter(W_IC(0));
                 const u32x4 hdr = rd16(sb16, 0);
                 lds_cptr nbias = nb16 + (16 * h - 16 * lane);
-                sfor<6>([&](auto I) {
-                    constexpr int i = decltype(I)::value, gi = i >> 1, k = i & 1, gg = 3 * half + gi, i12 = 6 * half + i;
+                sfor<NSETS>([&](auto I) {
+                    constexpr int i = decltype(I)::value, gi = i >> 1, k = i & 1, gg = GS * half + gi, i12 = NSETS * half + i;
                     WBuf& bc = (i & 1) ? bufB : bufA;
                     WBuf& bn = (i & 1) ? bufA : bufB;
                     // the next set: of this stage, of the next stage, or (last set of phase 1) the first of phase 2
-                    if constexpr (i < 5) load_p1(sb16, sb8, sb8b, W_IC((i + 1) >> 1), W_IC((i + 1) & 1), bn);
+                    if constexpr (i < NSETS - 1) load_p1(sb16, sb8, sb8b, W_IC((i + 1) >> 1), W_IC((i + 1) & 1), bn);
                     else if constexpr (t == W_NT - 1 && half == 1) load_p2(nb16, nb8, W_IC(0), W_IC(0), bn);
                     else load_p1(nb16, nb8, nb8b, W_IC(0), W_IC(0), bn);
                     if constexpr (k == 0) {
@@ -689,24 +711,21 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
                         au[1] = W_MFMA6(w_op6(bc.q[5], bc.d[3]), w_op6(yl6[gg]), au[1], W_SB((int)hdr[gi], 3), W_SB(ylp[gg >> 2], gg & 3));
 #endif
                     }
-                    // the previous tile's activation, a quad per set; then (sets 8 .. 11) the next tile's bias into the freed registers: its
-                    // stage is the next one (landed since this stage's entry)
-                    constexpr bool acting = t > 0 && i12 < 8;
-                    constexpr bool biasing = t < W_NT - 1 && i12 >= 8;
-                    if constexpr (acting) act_quad(W_IC(i12 & 7), ap, hf[t > 0 ? t - 1 : 0]);
-                    if constexpr (biasing) {
-                        bias_quad(nbias, W_IC((2 * (i12 - 8)) & 7), ap);
-                        bias_quad(nbias, W_IC((2 * (i12 - 8) + 1) & 7), ap);
-                    }
+                    // the previous tile's activation, QA quads per set over the tile's first ACT_SETS sets; then the next tile's bias into the
+                    // freed registers, QB quads per set: its stage is the next one (landed since this stage's entry)
+                    constexpr bool acting = t > 0 && i12 < K::ACT_SETS;
+                    constexpr bool biasing = t < W_NT - 1 && i12 >= K::ACT_SETS;
+                    if constexpr (acting) sfor<K::QA>([&](auto Q) { act_quad(W_IC((K::QA * i12 + decltype(Q)::value) & 7), ap, hf[t > 0 ? t - 1 : 0]); });
+                    if constexpr (biasing) sfor<K::QB>([&](auto Q) { bias_quad(nbias, W_IC((K::QB * (i12 - K::ACT_SETS) + decltype(Q)::value) & 7), ap); });
                     // the stage two ahead: phase-2 stages from the last hidden tile on
-                    issue_after(I, W_IC(6), W_IC(t < W_NT - 1 ? 1 : 0));
+                    issue_after(I, W_IC(NSETS), W_IC(t < W_NT - 1 ? 1 : 0));
                     {
                         constexpr int np = t < W_NT - 1 ? W_NP1 : W_NP2;
-                        typedef WSpan<i, 6, np> SP;
-                        w_interleave<6, ((i < 5 && ((i + 1) & 1)) ? 10 : 6) + (biasing ? 2 : 0), SP::b - SP::a, acting ? 2 : 0>();
+                        typedef WSpan<i, NSETS, np> SP;
+                        w_interleave<6, ((i < NSETS - 1 && ((i + 1) & 1)) ? 10 : 6) + (biasing ? K::QB : 0), SP::b - SP::a, acting ? 2 * K::QA : 0, K::QA>();
                     }
                     W_SCHED();
-                    if constexpr (t > 0 && i12 == 7) {
+                    if constexpr (t > 0 && i12 == K::ACT_SETS - 1) {
                         act_done(W_IC(t > 0 ? t - 1 : 0));
                         asm volatile("" : "+a"(hf[t > 0 ? t - 1 : 0]), "+v"(hsp[(t > 0 ? t - 1 : 0) >> 2]));   // parked in the accumulator file
                         W_SCHED();
@@ -769,11 +788,11 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
                     bias = __uint_as_float(hdr[2]);
                 }
                 W_SCHED();
-                sfor<6>([&](auto I) {
-                    constexpr int i = decltype(I)::value, pi = i >> 1, tt = i & 1, t = 6 * half + i;
+                sfor<NSETS>([&](auto I) {
+                    constexpr int i = decltype(I)::value, pi = i >> 1, tt = i & 1, t = NSETS * half + i;
                     WBuf& bc = (i & 1) ? bufB : bufA;
                     WBuf& bn = (i & 1) ? bufA : bufB;
-                    if constexpr (i < 5) load_p2(sb16, sb8, W_IC((i + 1) >> 1), W_IC((i + 1) & 1), bn);
+                    if constexpr (i < NSETS - 1) load_p2(sb16, sb8, W_IC((i + 1) >> 1), W_IC((i + 1) & 1), bn);
                     else if constexpr (half == 0 || !last) load_p2(nb16, nb8, W_IC(0), W_IC(0), bn);
                     else load_p1(nb16, nb8, nb8b, W_IC(0), W_IC(0), bn);      // the next row tile's first set
                     sfor<4>([&](auto S) {
@@ -784,9 +803,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
                     acc = W_MFMA6(w_op6(h6[t]), w_op6(bc.q[4], bc.d[0]), acc, W_SB(hsp[t >> 2], t & 3), W_SB((int)hdr[(2 * pi + tt) >> 2], (2 * pi + tt) & 3));
 #endif
                     // the stage two ahead: phase-1 stages (of the next row tile) from the last output block on
-                    issue_after(I, W_IC(6), W_IC(last ? 1 : 0));
+                    issue_after(I, W_IC(NSETS), W_IC(last ? 1 : 0));
                     {
-                        typedef WSpan<i, 6, last ? W_NP1 : W_NP2> SP;
+                        typedef WSpan<i, NSETS, last ? W_NP1 : W_NP2> SP;
                         w_interleave<5, 6, SP::b - SP::a>();
                     }
                     W_SCHED();
@@ -847,12 +866,12 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
     wait_vm<0>();   // the wrapped stream's last pieces still target this block's LDS
 }
 
-template <int ACT>
+template <int ACT, int NG>
 int mfw_launch_a(const MlpWArgs& g, hipStream_t st) {
     static bool attr = false;
     static int cus = 0, forced = 0;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_w_kernel<ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_w_kernel<ACT, NG>), hipFuncAttributeMaxDynamicSharedMemorySize, WCfg<NG>::LDS);
         int dev = 0;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -867,19 +886,26 @@ int mfw_launch_a(const MlpWArgs& g, hipStream_t st) {
     const int ntiles = g.B * (g.rows / 128);
     const int want = forced ? forced : (g.share && ntiles >= 2 * cus ? cus * 3 / 4 : cus);
     const int grid = ntiles < want ? ntiles : want;
-    hipLaunchKernelGGL((mlp_fused_w_kernel<ACT>), dim3(grid), dim3(256), W_LDS, st, g);
+    hipLaunchKernelGGL((mlp_fused_w_kernel<ACT, NG>), dim3(grid), dim3(256), WCfg<NG>::LDS, st, g);
     return (int)hipGetLastError();
 }
 
-}  // namespace
+template <int NG>
+int mfw_launch_n(const MlpWArgs& g, hipStream_t st) {
+    switch (g.act) {
+#ifndef MFW_DEV   // development builds: the GaussianActivation instantiation only (a full build takes over a minute)
+        case 0: return mfw_launch_a<0, NG>(g, st);
+        case 2: return mfw_launch_a<2, NG>(g, st);
+        case 3: return mfw_launch_a<3, NG>(g, st);
+#endif
+        case 1: return mfw_launch_a<1, NG>(g, st);
+        default: return -9;
+    }
+}
 
-bool mlp_fused_w_supported(int C, int Wd, int rows) { return C == W_C && Wd == W_WD && rows >= 128 && rows % 128 == 0; }
-
-size_t mlp_fused_w_image_bytes(int C, int Wd) { return mlp_fused_w_supported(C, Wd, 128) ? W_STREAM : 0; }
-
-int mlp_fused_w_images_launch(const MlpWImageJob* jobs, int n, int C, int Wd, int act, hipStream_t st) {
-    if (!mlp_fused_w_supported(C, Wd, 128)) return -9;
-    constexpr int threads = (int)(W_STREAM / 16) + W_HDR_BYTES;
+template <int NG>
+int mfw_images_n(const MlpWImageJob* jobs, int n, int act, hipStream_t st) {
+    constexpr int threads = (int)(WCfg<NG>::STREAM / 16) + WCfg<NG>::HDR_BYTES;
     for (int i0 = 0; i0 < n; i0 += MlpwImageJobs::MAX) {
         MlpwImageJobs j{};
         j.act = act;
@@ -889,11 +915,26 @@ int mlp_fused_w_images_launch(const MlpWImageJob* jobs, int n, int C, int Wd, in
             if ((act == 1 || act == 2) && !s.alpha) return -6;
             j.W1[i] = s.W0; j.b1[i] = s.b0; j.W2[i] = s.W2; j.b2[i] = s.b2; j.img[i] = static_cast<unsigned*>(s.img); j.alpha[i] = s.alpha;
         }
-        hipLaunchKernelGGL(mlpw_image_kernel, dim3((threads + 255) / 256, j.n), dim3(256), 0, st, j);
+        hipLaunchKernelGGL(mlpw_image_kernel<NG>, dim3((threads + 255) / 256, j.n), dim3(256), 0, st, j);
         const int rc = (int)hipGetLastError();
         if (rc) return rc;
     }
     return 0;
+}
+
+}  // namespace
+
+// feature_dim 128, 256 or 384 (NG = 2, 4, 6 groups of 64), width 2 feature_dim, whole 128-row tiles
+bool mlp_fused_w_supported(int C, int Wd, int rows) { return (C == 128 || C == 256 || C == 384) && Wd == 2 * C && rows >= 128 && rows % 128 == 0; }
+
+size_t mlp_fused_w_image_bytes(int C, int Wd) {
+    if (!mlp_fused_w_supported(C, Wd, 128)) return 0;
+    return C == 384 ? WCfg<6>::STREAM : C == 256 ? WCfg<4>::STREAM : WCfg<2>::STREAM;
+}
+
+int mlp_fused_w_images_launch(const MlpWImageJob* jobs, int n, int C, int Wd, int act, hipStream_t st) {
+    if (!mlp_fused_w_supported(C, Wd, 128)) return -9;
+    return C == 384 ? mfw_images_n<6>(jobs, n, act, st) : C == 256 ? mfw_images_n<4>(jobs, n, act, st) : mfw_images_n<2>(jobs, n, act, st);
 }
 
 int mlp_fused_w_image_launch(const float* W0, const float* b0, const float* W2, const float* b2, void* img, int C, int Wd, const float* alpha, int act,
@@ -906,13 +947,5 @@ int mlp_fused_w_launch(const MlpWArgs& g, int C, int Wd, hipStream_t st) {
     if (!mlp_fused_w_supported(C, Wd, g.rows) || !g.x || !g.out || !g.pro_a || !g.pro_o || !g.w_img) return -9;
     if ((size_t)g.B * g.rows * C * sizeof(float) >= ((size_t)1 << 31)) return -9;   // the residual rows come in through 32-bit buffer offsets
     if ((g.act == 1 || g.act == 2) && !g.alpha) return -6;
-    switch (g.act) {
-#ifndef MFW_DEV   // development builds: the GaussianActivation instantiation only (a full build takes over a minute)
-        case 0: return mfw_launch_a<0>(g, st);
-        case 2: return mfw_launch_a<2>(g, st);
-        case 3: return mfw_launch_a<3>(g, st);
-#endif
-        case 1: return mfw_launch_a<1>(g, st);
-        default: return -9;
-    }
+    return C == 384 ? mfw_launch_n<6>(g, st) : C == 256 ? mfw_launch_n<4>(g, st) : mfw_launch_n<2>(g, st);
 }

@@ -215,11 +215,14 @@ def test_fp16_deep_network_weight_staging(ops, d, L):
     x, sigma = _noisy(7, B, N, (0.2, 4.0))
     with torch.no_grad():
         ref, raw_ref = cpu_ref.uncond_denoiser(p, "", cases.H)(x, sigma, return_raw=True)
-    for precision in ("fp16", "bf16x3", "mixed", "w2"):   # ("w2": the one-launch point MLP at d = 384, the mixed mode's launches at 256 / 128)
+    for precision in ("fp16", "bf16x3", "mixed", "w2"):   # ("w2": the one-launch point MLP at d = 384, 256 and 128)
         den, raw = ops.LinearLiftPlan(_cuda(p), cases.H, cases.I, precision=precision).forward(x.cuda(), sigma.cuda(), return_raw=True)
         # error grows with depth (each layer adds its own rounding); the bar stays the north star's
-        _report(f"d={d} L={L} {precision} D", den, ref, {"fp16": 1e-3, "w2": 5e-4}.get(precision, 3e-4))
-        _report(f"d={d} L={L} {precision} F_x", raw, raw_ref, {"fp16": 2e-3, "w2": 5e-4}.get(precision, 3e-4))
+        # ("w2": the hidden layer's one-term rounding grows with depth — the mode's own 5e-4 bar belongs to the shipped L = 6 .. 8; deeper
+        # networks are held to the north star's 1e-3, as in test_w2_deep_networks_at_the_fused_width)
+        w2bar = 5e-4 if L <= 8 else 1e-3
+        _report(f"d={d} L={L} {precision} D", den, ref, {"fp16": 1e-3, "w2": w2bar}.get(precision, 3e-4))
+        _report(f"d={d} L={L} {precision} F_x", raw, raw_ref, {"fp16": 2e-3, "w2": w2bar}.get(precision, 3e-4))
 
 
 @pytest.mark.parametrize("seed", [11, 23, 37])

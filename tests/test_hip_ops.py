@@ -279,16 +279,19 @@ def test_unpool_outproj_h8_fused_matches_the_two_launch_form(ops, B, N, Cc, H):
     assert torch.equal(ops.unpool_outproj_h8(x.clone(), q, kvh, W, bias, H)[0], got)
 
 
-@pytest.mark.parametrize("B,rows,act", [(2, 256, "gauss"), (1, 128, "relu"), (3, 384, "none"), (5, 2048, "gauss"), (300, 128, "gauss")])
-def test_mlp_fused_w_vs_float64(ops, B, rows, act):
+@pytest.mark.parametrize("B,rows,act,K", [(2, 256, "gauss", 384), (1, 128, "relu", 384), (3, 384, "none", 384), (5, 2048, "gauss", 384), (300, 128, "gauss", 384),
+                                          (2, 256, "gauss", 256), (3, 384, "relu", 256), (300, 128, "gauss", 256), (1, 128, "none", 256),
+                                          (2, 256, "gauss", 128), (3, 384, "none", 128), (600, 128, "gauss", 128), (1, 128, "relu", 128)])
+def test_mlp_fused_w_vs_float64(ops, B, rows, act, K):
     """"w2" mode: the point MLP of a layer in ONE launch with the hidden layer kept in registers (mlp_fused_w.hip;
     models/set_transformer.py:164-166, mlp.py:5-39, activation.py:17-24, normalization.py:36-44) against float64, stage by stage:
     mlp.0's pre-activations (two-term operands on both sides: the fp6 second terms leave ~1e-5), the output against a reference built
     from the kernel's OWN hidden layer rounded to fp16 (the second product alone: two-term weights, ~2e-5), and the whole MLP against
     the exact one (the hidden layer's dropped second term: ~2e-4 of the MLP's scale).  B = 300: more row tiles than CUs (blocks are
-    persistent: several tiles per block, the weight stream wraps)."""
-    K, Wd = 384, 768
-    rs = _rs(B + rows + len(act))
+    persistent: several tiles per block, the weight stream wraps).  K = feature_dim: 384 (6 groups of 64: three per ring stage), 256 and 128 (two / one
+    group per stage: other stage sizes, set counts and activation schedules of the same kernel template)."""
+    Wd = 2 * K
+    rs = _rs(B + rows + len(act) + (384 - K))
     x, W0, b0 = _t(rs.randn(B, rows, K)), _t(rs.randn(Wd, K) / math.sqrt(K)), _t(rs.randn(Wd) / math.sqrt(K))
     W2, b2 = _t(rs.randn(K, Wd) / math.sqrt(Wd)), _t(rs.randn(K) / math.sqrt(Wd))
     pa, po = _t(1 + 0.3 * rs.randn(B, K)), _t(0.3 * rs.randn(B, K))
@@ -314,7 +317,7 @@ def test_mlp_fused_w_vs_float64(ops, B, rows, act):
     scale = mlp_ref.abs().max().item()
     d_own = ((got[:nb].cpu().double() - x[:nb].double()) - mlp_own).abs().max().item() / scale
     d_ref = ((got[:nb].cpu().double() - x[:nb].double()) - mlp_ref).abs().max().item() / scale
-    print(f"w2 point MLP ({act}, B={B}, rows={rows}): pre-activations {eu[0]:.2e}, second product {d_own:.2e}, whole MLP {d_ref:.2e} of its scale")
+    print(f"w2 point MLP ({act}, B={B}, rows={rows}, d={K}): pre-activations {eu[0]:.2e}, second product {d_own:.2e}, whole MLP {d_ref:.2e} of its scale")
     assert eu[0] <= 4e-5, eu
     assert d_own <= 6e-5, d_own
     assert d_ref <= 5e-4, d_ref

@@ -457,9 +457,9 @@ def launcher_selftest(args):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         time.sleep(0.001 * (rank + 1))
+    local = time.perf_counter() - t0          # this rank's own time: before the barrier, as in the compute paths
     gd.barrier()
-    local = time.perf_counter() - t0
-    dt = gd.max_over_ranks(local)
+    dt = gd.max_over_ranks(time.perf_counter() - t0)
     rep = distributed_report(None, local_points_per_sec=args.steps / local, sizes=(4096, 1024)) if world > 1 else None
     if rank == 0:
         print(json.dumps({"metric": "launcher_selftest", "n_gpus": world, "steps": args.steps, "ms_per_step": dt / args.steps * 1e3,

@@ -420,6 +420,55 @@ def test_graphed_forward_replays_the_eager_bits():
         assert torch.equal(run(x2, s2), m(x2, s2, None))
 
 
+@pytest.mark.parametrize("d", [128, 384])
+def test_conditional_module_api_in_the_w2_mode(d):
+    """The image-conditional model through the MODULE API in the headline arithmetic at a shape where every fused piece of the mode runs
+    (N = 256: whole 128-row tiles; 672 pyramid channels): the one-launch point MLP (d = 128 and 384), the fp16 texel image, img_feature_proj
+    on fp16 operands with GroupNorm folded into per-sample weight images — `Diffusion.forward` against the oracle (cpu_ref.cond_denoiser:
+    models/ray.py:89-123 under diffusion.py:37-57) at the mode's 5e-4, the captured forward inside and outside `frozen_weights`, the
+    model-level option switch, and a short captured sampler run."""
+    from gecco_amd.diffusion import Conditioner
+    from gecco_amd.models.feature_pyramid import FeaturePyramidContext
+    from gecco_amd.structs import Context3d
+    L, N, B, hw, cdims = 2, 256, 2, 64, (96, 192, 384)
+    p = W.ray_network_state_dict(61, d, L, cases.I, cases.H, context_dims=cdims)
+    feats, K = W.synthetic_context(66, B, hw=hw, context_dims=cdims)
+    g = torch.Generator().manual_seed(62)
+    x = torch.randn(B, N, 3, generator=g)
+    sigma = torch.tensor([0.1, 20.0])
+    with torch.no_grad():
+        ref = cpu_ref.cond_denoiser(p, "", cases.H, K, feats)(x, sigma)
+
+    class FixedPyramid(Conditioner):
+        def forward(self, raw_ctx):
+            return FeaturePyramidContext(features=[f.cuda() for f in feats], K=raw_ctx.K)
+
+    m = build_cond(d, L, cdims, conditioner=FixedPyramid())
+    sd = {"backbone.model." + k: v for k, v in p.items()}
+    sd["reparam.uvl_mean"], sd["reparam.uvl_std"] = p["reparam.uvl_mean"], p["reparam.uvl_std"]
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval().set_precision("w2")
+    ctx = Context3d(image=torch.zeros(B, 3, hw, hw).cuda(), K=K.cuda())
+    with torch.no_grad():
+        den = m(x.cuda(), sigma.cuda(), ctx)
+        e = _close(den, ref, 5e-4)
+        for frozen in (False, True):
+            run = m.graphed_forward(x.cuda(), sigma.cuda(), ctx, frozen_weights=frozen)
+            assert torch.equal(run(), den) and torch.equal(run(), den)
+        m.set_option("imgproj16", 0)                     # the split-bf16 launch instead: another rounding of one linear
+        den0 = m(x.cuda(), sigma.cuda(), ctx)
+        e0 = _close(den0, ref, 5e-4)
+        assert not torch.equal(den0, den)
+        m.set_option("imgproj16", 1)
+        assert torch.equal(m(x.cuda(), sigma.cuda(), ctx), den)
+        m.set_option("mlpw", 0)                          # the mixed mode's two launches instead of the one-launch point MLP
+        assert not torch.equal(m(x.cuda(), sigma.cuda(), ctx), den)
+        m.set_option("mlpw", 1)
+        print(f"conditional module, w2, d={d}: D vs oracle {e} (imgproj16 off: {e0})")
+        out = m.sample_stochastic((B, N, 3), ctx, num_steps=4)
+        assert out.shape == (B, N, 3) and torch.isfinite(out).all()
+
+
 @pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16x3", 2e-4), ("mixed", 2e-4), ("fp16", 1e-3)])
 @pytest.mark.parametrize("name", list(cases.COND_CASES))
 def test_conditional_diffusion_golden(golden_dir, name, precision, tol):

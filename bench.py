@@ -738,7 +738,10 @@ def other_config_bench(args, rank, world, dev):
         pr["output_proj.1.weight"], pr["output_proj.1.bias"] = uu(3, dc), uu(1, 3)[0]
         pr["reparam.uvl_mean"], pr["reparam.uvl_std"] = torch.tensor([0.0, 0.0, 1.38]), torch.tensor([0.56, 0.60, 0.49])
         return {k: v.float().contiguous() for k, v in pr.items()}
-    if cfg == "C3":
+    if cfg == "C1":
+        # BASELINE.json configs[0]: unconditional ShapeNet-PointFlow airplane, N = 2048, d = 128, 4 layers (the reference's CPU-runnable case)
+        Bc, Nc, dc, hw, Ll = 64, 2048, 128, 0, 4
+    elif cfg == "C3":
         Bc, Nc, dc, hw = 64, 2048, 384, 224
     elif cfg == "C4":
         Bc, Nc, dc, hw = 32, 4096, 512, 256
@@ -796,6 +799,17 @@ def other_config_bench(args, rank, world, dev):
                                "hbm_floor_ms": (pyr_bytes + written) / PEAK_HBM_GBS / 1e9 * 1e3,
                                "hbm_frac": (pyr_bytes + written) / PEAK_HBM_GBS / 1e9 * 1e3 / lk_ms,
                                "bytes_per_point": {"gathered": 4 * ct * tex, "written": ct * 4}}
+    elif cfg == "C1":
+        p = {k: v.to(dev) for k, v in random_state_dict(9, dc, Ll).items()}
+        net = ops.LinearLiftPlan(p, Hh, Ii)
+        x, sigma = cloud(Bc, Nc)
+        x, sigma = x.to(dev), sigma.to(dev)
+        out = torch.empty_like(x)
+        step = lambda: net.forward(x, sigma, out=out)
+        points = Bc * Nc
+        flops = Bc * Ll * per_layer(Nc, dc)
+        what = (f"C1 unconditional denoiser forward at the reference's CPU-runnable shape: B={Bc}/GPU, N={Nc}, d={dc}, L={Ll}, I={Ii}, H={Hh}, "
+                "EDMPrecond(LinearLift(SetTransformer))")
     else:
         p = {k: v.to(dev) for k, v in random_state_dict(9, dc, Ll).items()}
         net = ops.LinearLiftPlan(p, Hh, Ii)
@@ -891,7 +905,7 @@ def main():
                          "output, split-bf16 elsewhere: D and F_x ~6e-5), split-bf16 (3 MFMAs per product, D and F_x "
                          "~2e-5 .. 5e-5 from the fp32 reference), fp16 operands with fp32 accumulation (faster; D ~4e-4, F_x ~1e-3: "
                          "at the 1e-3 bar) or exact fp32 MFMA (~1e-6)")
-    ap.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "C5"],
+    ap.add_argument("--config", default="C2", choices=["C1", "C2", "C3", "C4", "C5"],
                     help="BASELINE.json configuration: C2 (default, the headline), C3 / C4 image-conditional, C5 cached upsampling evaluation")
     ap.add_argument("--train", action="store_true", help="time the data-parallel training step instead of the forward")
     ap.add_argument("--amp", action="store_true",
@@ -1252,7 +1266,7 @@ def main():
             "ms_per_step": tr["ms_per_step"], "points_per_sec": tr["value"], "tflops_algorithmic": tr["train_tflops_algorithmic"],
             "dominant_kernel": tr.get("dominant_kernel")}
         cfgs = {}
-        for c in ("C3", "C4", "C5"):
+        for c in ("C1", "C3", "C4", "C5"):
             rc_ = run_extra(["--config", c, "--steps", "10", "--warmup", "3", "--precision", args.precision] + (["--no-sampler"] if c != "C5" else []))
             if "error" in rc_:
                 cfgs[c] = rc_

@@ -210,7 +210,8 @@ int option(int which) {
         const char* e = getenv(g_option_env[which]);
         // "mlpwshare" (the one-launch MLP leaves CUs to a second stream's kernels) is off unless the caller runs two streams: hip_ops.py
         // sets it around a two-stream evaluation
-        g_options[which] = e ? (atoi(e) != 0) : (which != OPT_MLPWSHARE);
+        // "imgproj16" (img_feature_proj on one-term fp16 operands) is opt-in: 2 % of a C3 evaluation for a fifth of the w2 mode's error budget
+        g_options[which] = e ? (atoi(e) != 0) : (which != OPT_MLPWSHARE && which != OPT_IMGPROJ16);
     }
     return g_options[which];
 }
@@ -1810,7 +1811,7 @@ int gecco_ray_network_fwd_f32(const GeccoRayNetwork* m, const float* x, const fl
     // xyz_embed(c_in * x)  (models/ray.py:99)
     TRY(lift_launch(x, w.coef, m->xyz_w, m->xyz_b, w.feat, nullptr, B, N, C, s), "xyz_embed");
     // projective lookup on c_in * x, fp32 always (models/ray.py:103-109) + GN(16) partials
-    // "w2" (option "imgproj16"): the lookup leaves halves, GN16's apply goes INTO the weights (per-sample images of W * a, biases + W o) and
+    // "w2" with option "imgproj16" (opt-in: it moves C3's F_x from 2.3e-4 to 2.7e-4 of the mode's 5e-4 for 2 % of the evaluation): the lookup leaves halves, GN16's apply goes INTO the weights (per-sample images of W * a, biases + W o) and
     // img_feature_proj multiplies fp16(lookup) by them, one term each, on the fp16-operand streaming kernel: a third of split-bf16's matrix
     // work on half its operand bytes (the mode's one-term operands are the hidden layer, K and q already)
     PlanScope plan_scope(&m->backbone);

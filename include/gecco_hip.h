@@ -135,8 +135,10 @@ int gecco_linear_f32(const float* A, const float* W, const float* bias, const fl
  *   "kvqperm" (default 1): mixed mode at head dim 48 (feature_dim 384): the kvq stream deals the columns of K, V and q to the 64-column tiles
  *   head-aligned (a tile = one head + a third of another) and gecco_linear_kvq_f16's epilogue writes a head's (32 rows, 48) slab as three
  *   contiguous 1 KiB stores through LDS instead of as 32-byte pieces: the same bits, fewer partial cache lines.
- *   "imgproj16" (default 1): "w2" mode of gecco_ray_network_fwd_f32: img_feature_proj (K = the pyramid's channels, 672) multiplies
- *   fp16(GN16(lookup)) by fp16(W), one term each, on the precision-2 streaming kernel instead of split-bf16 (three products per term pair).
+ *   "imgproj16" (default 0: opt-in): "w2" mode of gecco_ray_network_fwd_f32: the lookup leaves halves, GroupNorm(16)'s apply is folded into
+ *   per-sample fp16 images of img_feature_proj's weight (and its offsets into the bias), and the product fp16(lookup) x fp16(W a) runs one
+ *   term each on the fp16-operand streaming kernel instead of split-bf16: 280 -> 154 + 24 us at C3 (2 % of an evaluation) for F_x 2.3e-4 ->
+ *   2.7e-4 at C3 and up to 3.2e-4 -> 4.7e-4 on small pyramids (the mode's bar is 5e-4) — off unless asked for.
  * value < 0 returns the option to its default / environment (GECCO_ASTAT, GECCO_CHAIN, GECCO_HEADMAJOR, GECCO_MLPFUSED,
  * GECCO_UNPOOLFUSED, GECCO_LO8, GECCO_ACTIMG, GECCO_H8, GECCO_KVQ64, GECCO_H8AREG, GECCO_CHAIN2).
  * Process-wide DEFAULT: a network forward consults its own table first (GeccoSetTransformer.opt_mask / opt_vals, ABI 14), so two

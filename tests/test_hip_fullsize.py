@@ -148,13 +148,13 @@ def _run_cond(ops, case, precision, tag):
         img16 = net._tex16[1]
         net.forward(x.cuda(), sigma.cuda(), K.cuda(), levels)
         assert net._tex16[1] is img16
-        # img_feature_proj: fp16(lookup) times per-sample fp16 images of W with GN16's scale folded in (option "imgproj16", default on in this
-        # mode) against the split-bf16 launch of the mixed mode: a different rounding of ONE linear, both inside the mode's bar
-        alt = ops.RayNetworkPlan(_cuda(p), cases.H, cases.I, precision="w2", options={"imgproj16": 0})
-        den0, raw0 = alt.forward(x.cuda(), sigma.cuda(), K.cuda(), levels, return_raw=True)
-        assert not torch.equal(raw0, raw)
-        _report(f"{tag} w2 F_x, imgproj16 = 0, vs oracle", raw0, raw_ref, BARS_FX["w2"])
-        e = cpu_ref.rel_err(raw.cpu(), raw0.cpu())
+        # img_feature_proj on fp16 operands (option "imgproj16", opt-in): fp16(lookup) times per-sample fp16 images of W with GN16's scale folded
+        # in, against the split-bf16 launch the mode runs by default: a different rounding of ONE linear, inside the mode's bar at these shapes
+        alt = ops.RayNetworkPlan(_cuda(p), cases.H, cases.I, precision="w2", options={"imgproj16": 1})
+        den1, raw1 = alt.forward(x.cuda(), sigma.cuda(), K.cuda(), levels, return_raw=True)
+        assert not torch.equal(raw1, raw)
+        _report(f"{tag} w2 F_x, imgproj16 = 1, vs oracle", raw1, raw_ref, BARS_FX["w2"])
+        e = cpu_ref.rel_err(raw1.cpu(), raw.cpu())
         print(f"{tag} w2: imgproj16 on vs off: max-rel {e[0]:.2e}")
         assert e[0] < 4e-4
 

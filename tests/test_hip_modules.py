@@ -420,10 +420,33 @@ def test_graphed_forward_replays_the_eager_bits():
         assert torch.equal(run(x2, s2), m(x2, s2, None))
 
 
+@pytest.mark.parametrize("precision,tol", [("mixed", 2e-4), ("w2", 5e-4)])
+@pytest.mark.parametrize("B,N,d", [(2, 333, 128), (2, 130, 384), (1, 1000, 256), (3, 128, 384)])
+def test_conditional_network_ragged_point_counts(B, N, d, precision, tol):
+    """RayNetwork (models/ray.py:89-123) at point counts that are not whole 128-row tiles, against the oracle: in the "w2" mode the point MLP
+    runs as one launch only on whole tiles, the lookup on fp16 texels always; with option "imgproj16" img_feature_proj runs on fp16 operands
+    with per-sample folded weight images from N >= 128 on (its last row tile is ragged) — both settings."""
+    from gecco_amd import hip_ops
+    L, hw, cdims = 1, 64, (96, 192, 384)
+    p = W.ray_network_state_dict(91 + N, d, L, cases.I, cases.H, context_dims=cdims)
+    feats, K = W.synthetic_context(92 + N, B, hw=hw, context_dims=cdims)
+    g = torch.Generator().manual_seed(93 + N)
+    x = torch.randn(B, N, 3, generator=g)
+    sigma = torch.tensor([0.05, 3.0, 80.0][:B])
+    with torch.no_grad():
+        ref, raw_ref = cpu_ref.cond_denoiser(p, "", cases.H, K, feats)(x, sigma, return_raw=True)
+    levels = hip_ops.to_channels_last_levels([f.cuda() for f in feats])
+    for ip in ((0, 1) if precision == "w2" else (0,)):
+        net = hip_ops.RayNetworkPlan({k: v.cuda() for k, v in p.items()}, cases.H, cases.I, precision=precision, options={"imgproj16": ip})
+        den, raw = net.forward(x.cuda(), sigma.cuda(), K.cuda(), levels, return_raw=True)
+        e = (_close(den, ref, tol), _close(raw, raw_ref, tol))
+        print(f"conditional B={B} N={N} d={d} {precision} imgproj16={ip}: D {e[0]}, F_x {e[1]}")
+
+
 @pytest.mark.parametrize("d", [128, 384])
 def test_conditional_module_api_in_the_w2_mode(d):
     """The image-conditional model through the MODULE API in the headline arithmetic at a shape where every fused piece of the mode runs
-    (N = 256: whole 128-row tiles; 672 pyramid channels): the one-launch point MLP (d = 128 and 384), the fp16 texel image, img_feature_proj
+    (N = 256: whole 128-row tiles; 672 pyramid channels): the one-launch point MLP (d = 128 and 384), the fp16 texel image and (opt-in, option "imgproj16") img_feature_proj
     on fp16 operands with GroupNorm folded into per-sample weight images — `Diffusion.forward` against the oracle (cpu_ref.cond_denoiser:
     models/ray.py:89-123 under diffusion.py:37-57) at the mode's 5e-4, the captured forward inside and outside `frozen_weights`, the
     model-level option switch, and a short captured sampler run."""
@@ -455,16 +478,19 @@ def test_conditional_module_api_in_the_w2_mode(d):
         for frozen in (False, True):
             run = m.graphed_forward(x.cuda(), sigma.cuda(), ctx, frozen_weights=frozen)
             assert torch.equal(run(), den) and torch.equal(run(), den)
-        m.set_option("imgproj16", 0)                     # the split-bf16 launch instead: another rounding of one linear
+        m.set_option("imgproj16", 1)                     # (opt-in) img_feature_proj on fp16 operands, GroupNorm folded into per-sample weight images
         den0 = m(x.cuda(), sigma.cuda(), ctx)
         e0 = _close(den0, ref, 5e-4)
         assert not torch.equal(den0, den)
-        m.set_option("imgproj16", 1)
+        for frozen in (False, True):
+            run = m.graphed_forward(x.cuda(), sigma.cuda(), ctx, frozen_weights=frozen)
+            assert torch.equal(run(), den0) and torch.equal(run(), den0)
+        m.set_option("imgproj16", -1)
         assert torch.equal(m(x.cuda(), sigma.cuda(), ctx), den)
         m.set_option("mlpw", 0)                          # the mixed mode's two launches instead of the one-launch point MLP
         assert not torch.equal(m(x.cuda(), sigma.cuda(), ctx), den)
         m.set_option("mlpw", 1)
-        print(f"conditional module, w2, d={d}: D vs oracle {e} (imgproj16 off: {e0})")
+        print(f"conditional module, w2, d={d}: D vs oracle {e} (imgproj16 on: {e0})")
         out = m.sample_stochastic((B, N, 3), ctx, num_steps=4)
         assert out.shape == (B, N, 3) and torch.isfinite(out).all()
 

@@ -1325,7 +1325,7 @@ int gecco_mlp_fused_w(const float* x, float* out, const float* pro_a, const floa
                       const float* b2, const float* alpha, int act, float* stats, int B, int rows, int C, int width, void* wsplit, float* dbg_u,
                       void* stream) {
     if (!x || !out || !pro_a || !pro_o || !wsplit) return fail(-1, "mlp_fused_w: null argument");
-    if (!mlp_fused_w_supported(C, width, rows)) return fail(-2, "mlp_fused_w: needs C in {128, 256, 384}, width == 2 C, rows %% 128 == 0");
+    if (!mlp_fused_w_supported(C, width, rows)) return fail(-2, "mlp_fused_w: needs C in {128, 256, 384, 512}, width == 2 C, rows %% 128 == 0");
     if (act < 0 || act > 3) return fail(-6, "mlp_fused_w: act must be 0 .. 3");
     if ((act == 1 || act == 2) && !alpha) return fail(-6, "mlp_fused_w: GaussianActivation needs alpha");
     hipStream_t s = (hipStream_t)stream;

@@ -57,27 +57,38 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x6 __attribute__((ext_vector_type(6)));
 
-// Shape of an instantiation: feature_dim = 64 NG (NG = 2, 4, 6: 128, 256, 384), width = 2 feature_dim.  (NG = 8, feature_dim 512, does not
-// fit the register file: y 128 + 48, the hidden fragments 256, two accumulator pairs 64 and two operand sets 64 are 560 of 512.)
+// Shape of an instantiation: feature_dim = 64 NG (NG = 2, 4, 6, 8: 128, 256, 384, 512), width = 2 feature_dim.
+// NG = 8 does not fit the register file in one go (y 128 + 48, the hidden fragments 256, two accumulator pairs 64 and two operand sets 64 are
+// 560 of 512): it runs TWO PASSES over the hidden width with y kept — pass 0: hidden tiles 0 .. 7, then every output block's partial product
+// + bias + residual written to `out`; pass 1: hidden tiles 8 .. 15, the blocks' second partial products added to what pass 0 left (read back
+// the way the residual rows are: LDS-DMA), statistics there.  Its stages are a quarter of a hidden tile (2 groups: 3 x 32 KiB of ring).
 template <int NG_>
 struct WCfg {
     static constexpr int NG = NG_;                 // 64-k groups of mlp.0
     static constexpr int C = 64 * NG, WD = 2 * C;
     static constexpr int NT = 2 * NG;              // 64-column hidden tiles = 64-k groups of mlp.2
     static constexpr int NB = 2 * NG;              // 32-column output blocks
-    static constexpr int GS = NG / 2;              // groups of a phase-1 stage (half a hidden tile) = tile pairs of a phase-2 stage (half a block)
-    static constexpr int NSETS = NG;               // sets of matrix instructions per stage: two per group / one per hidden tile
+    static constexpr int NPASS = NG == 8 ? 2 : 1;  // passes over the hidden width
+    static constexpr int NTP = NT / NPASS;         // hidden tiles of a pass
+    static constexpr int GS = NG == 8 ? 2 : NG / 2;   // groups of a phase-1 stage = tile pairs of a phase-2 stage (half a block's NTP / 2 tiles)
+    static constexpr int SPT = NG / GS;            // phase-1 stages per hidden tile (2; 4 at NG = 8)
+    static constexpr int NSETS = 2 * GS;           // sets of matrix instructions per stage: two per group / one per hidden tile
     static constexpr int CH1 = (2 + 14 * GS + 3) & ~3, CH2 = (1 + 11 * GS + 3) & ~3;   // chunks of a stage, phase 1 / phase 2 (44 / 36 at NG = 6)
     static constexpr int SLOT = (CH1 > CH2 ? CH1 : CH2) * 1024;                        // ring slot (bytes)
     static constexpr int NP1 = CH1 / 4, NP2 = CH2 / 4;                                  // 1 KiB pieces per wave and stage
-    static constexpr size_t STREAM = (size_t)2 * NT * CH1 * 1024 + (size_t)2 * NB * CH2 * 1024;   // 1920 KiB per layer at NG = 6
+    static constexpr int NST1 = NTP * SPT, NST2 = 2 * NB;                               // stages of a pass, phase 1 / phase 2
+    static constexpr size_t STREAM = (size_t)NPASS * ((size_t)NST1 * CH1 + (size_t)NST2 * CH2) * 1024;   // 1920 KiB per layer at NG = 6
     static constexpr int HB1 = 4 * GS;             // scale bytes per lane in a phase-1 stage header
-    static constexpr int HDR_BYTES = 2 * NT * 64 * HB1 + 2 * NB * 64 * 8;
-    // the previous hidden tile's activation (8 register quads) rides in the first ACT_SETS of a tile's 2 NG sets, the next tile's bias in the rest
-    static constexpr int ACT_SETS = NG == 6 ? 8 : NG, QA = 8 / ACT_SETS, QB = 8 / (2 * NG - ACT_SETS);
+    static constexpr int HDR_BYTES = NPASS * (NST1 * 64 * HB1 + NST2 * 64 * 8);
+    // the previous hidden tile's activation (8 register quads) rides in the first ACT_SETS of a tile's TSETS = 2 NG sets, the next tile's bias
+    // (whose stage is the next one only during the tile's LAST stage) in its last BIAS_SETS
+    static constexpr int TSETS = NSETS * SPT;
+    static constexpr int ACT_SETS = NG >= 6 ? 8 : NG, QA = 8 / ACT_SETS;
+    static constexpr int BIAS_SETS = NG == 2 ? 2 : 4, QB = 8 / BIAS_SETS, BIAS_START = TSETS - BIAS_SETS;
     static constexpr int COLP = 4 * 2 * C * 4;
     static constexpr int LDS = 3 * SLOT + 4 * 4096 + COLP;
-    static_assert(NG == 2 || NG == 4 || NG == 6, "feature_dim 128, 256 or 384");
+    static_assert(NG == 2 || NG == 4 || NG == 6 || NG == 8, "feature_dim 128, 256, 384 or 512");
+    static_assert(NTP == 4 * GS && TSETS == 2 * NG && BIAS_START >= ACT_SETS && BIAS_SETS <= NSETS, "stage structure");
     static_assert(LDS <= 160 * 1024 && COLP >= 2 * C * 4, "one block per CU");
 };
 constexpr int W_NS = 3;
@@ -252,7 +263,9 @@ struct MlpwImageJobs {     // the layers of one launch (blockIdx.y)
 template <int NG>
 __global__ void mlpw_image_kernel(MlpwImageJobs jobs) {
     typedef WCfg<NG> K;
-    constexpr int C = K::C, WD = K::WD, CH1 = K::CH1, CH2 = K::CH2, GS = K::GS, HB1 = K::HB1;
+    constexpr int C = K::C, WD = K::WD, CH1 = K::CH1, CH2 = K::CH2, GS = K::GS, HB1 = K::HB1, SPT = K::SPT, NTP = K::NTP, NSETS = K::NSETS;
+    constexpr size_t P1_ITEMS = (size_t)K::NST1 * CH1 * 64, PASS_ITEMS = P1_ITEMS + (size_t)K::NST2 * CH2 * 64;   // items of a pass (phase 1 | phase 2)
+    constexpr int P1_HB = K::NST1 * 64 * HB1, PASS_HB = P1_HB + K::NST2 * 64 * 8;                                 // header bytes of a pass
     const int li = blockIdx.y;
     const float* __restrict__ W1 = jobs.W1[li];
     const float* __restrict__ b1 = jobs.b1[li];
@@ -261,37 +274,39 @@ __global__ void mlpw_image_kernel(MlpwImageJobs jobs) {
     unsigned* __restrict__ img = jobs.img[li];
     const float ws = w_act_scale(jobs.alpha[li], jobs.act);
     const size_t items = K::STREAM / 16;
-    const size_t p1_items = (size_t)2 * K::NT * CH1 * 64;
     for (size_t hb = (size_t)blockIdx.x * blockDim.x + threadIdx.x; hb >= items && hb < items + K::HDR_BYTES; hb += (size_t)gridDim.x * blockDim.x) {
-        const int q = (int)(hb - items);
-        unsigned char* out8 = reinterpret_cast<unsigned char*>(img);
-        if (q < 2 * K::NT * 64 * HB1) {
-            const int stage = q / (64 * HB1), l = (q / HB1) & 63, b = q % HB1, t = stage >> 1, half = stage & 1;
+        const int pass = (int)(hb - items) / PASS_HB, q = (int)(hb - items) % PASS_HB;
+        unsigned char* out8 = reinterpret_cast<unsigned char*>(img) + (size_t)pass * PASS_ITEMS * 16;
+        if (q < P1_HB) {
+            const int stage = q / (64 * HB1), l = (q / HB1) & 63, b = q % HB1, t = pass * NTP + stage / SPT, sq = stage % SPT;
             const int gi = b >> 2, term = (b >> 1) & 1, j = b & 1;
-            out8[((size_t)stage * CH1 * 64 + l) * 16 + b] = (unsigned char)w_lo1(W1, C, ws, t, GS * half + gi, j, term, l & 31, l >> 5).sb;
+            out8[((size_t)stage * CH1 * 64 + l) * 16 + b] = (unsigned char)w_lo1(W1, C, ws, t, GS * sq + gi, j, term, l & 31, l >> 5).sb;
         } else {
-            const int q2 = q - 2 * K::NT * 64 * HB1;
+            const int q2 = q - P1_HB;
             const int stage = q2 / (64 * 8), l = (q2 / 8) & 63, b = q2 & 7, nb = stage >> 1, half = stage & 1;
-            out8[(p1_items + (size_t)stage * CH2 * 64 + l) * 16 + b] = b < 2 * GS ? (unsigned char)w_lo2(W2, WD, nb, NG * half + b, l & 31, l >> 5).sb : (unsigned char)0;
+            out8[(P1_ITEMS + (size_t)stage * CH2 * 64 + l) * 16 + b] =
+                b < 2 * GS ? (unsigned char)w_lo2(W2, WD, nb, pass * NTP + NSETS * half + b, l & 31, l >> 5).sb : (unsigned char)0;
         }
     }
     for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (size_t)gridDim.x * blockDim.x) {
         u32x4 out = {0u, 0u, 0u, 0u};
-        if (it < p1_items) {
-            const int stage = (int)(it / (CH1 * 64)), ci = (int)(it % (CH1 * 64));
-            const int chunk = ci >> 6, l = ci & 63, t = stage >> 1, half = stage & 1;
+        const int pass = (int)(it / PASS_ITEMS);
+        const size_t ip = it % PASS_ITEMS;
+        if (ip < P1_ITEMS) {
+            const int stage = (int)(ip / (CH1 * 64)), ci = (int)(ip % (CH1 * 64));
+            const int chunk = ci >> 6, l = ci & 63, t = pass * NTP + stage / SPT, sq = stage % SPT;
             if (chunk == 0) {   // bytes 0 .. HB1 - 1: the byte threads above; the dwords past them are zero
 #pragma unroll
                 for (int d = GS; d < 4; ++d) img[it * 4 + d] = 0u;
                 continue;
             } else if (chunk == 1) {
-                if (half == 0 && l < 16 && b1) {
+                if (sq == 0 && l < 16 && b1) {
                     const f32x4 bb = *reinterpret_cast<const f32x4*>(b1 + 64 * t + 4 * l);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) out[e] = __float_as_uint(bb[e] * ws);
                 }
             } else if (chunk < 2 + 14 * GS) {
-                const int gi = (chunk - 2) / 14, c = (chunk - 2) % 14, g = GS * half + gi;
+                const int gi = (chunk - 2) / 14, c = (chunk - 2) % 14, g = GS * sq + gi;
                 if (c < 8) {
                     const int s = c >> 1, j = c & 1, r = l & 31, h = l >> 5;
                     const float* src = W1 + (size_t)(64 * t + 32 * j + r) * C + 64 * g + 16 * s + 8 * h;
@@ -316,21 +331,21 @@ __global__ void mlpw_image_kernel(MlpwImageJobs jobs) {
                 }
             }
         } else {
-            const size_t i2 = it - p1_items;
+            const size_t i2 = ip - P1_ITEMS;
             const int stage = (int)(i2 / (CH2 * 64)), ci = (int)(i2 % (CH2 * 64));
             const int chunk = ci >> 6, l = ci & 63, nb = stage >> 1, half = stage & 1;
-            if (chunk == 0) {   // bytes 0 .. 7: the byte threads above
-                img[it * 4 + 2] = __float_as_uint(b2 ? b2[32 * nb + (l & 31)] : 0.f);
+            if (chunk == 0) {   // bytes 0 .. 7: the byte threads above; mlp.2's bias rides in the first pass only
+                img[it * 4 + 2] = __float_as_uint(b2 && pass == 0 ? b2[32 * nb + (l & 31)] : 0.f);
                 img[it * 4 + 3] = 0u;
                 continue;
             } else if (chunk < 1 + 11 * GS) {
                 const int pi = (chunk - 1) / 11, q = (chunk - 1) % 11;
                 if (q == 10) {
-                    const int tt = l >> 5, ql = l & 31, t = NG * half + 2 * pi + tt;
+                    const int tt = l >> 5, ql = l & 31, t = pass * NTP + NSETS * half + 2 * pi + tt;
                     const WLo a = w_lo2(W2, WD, nb, t, (2 * ql) & 31, (2 * ql) >> 5), b = w_lo2(W2, WD, nb, t, (2 * ql + 1) & 31, (2 * ql + 1) >> 5);
                     out = u32x4{a.pk[4], a.pk[5], b.pk[4], b.pk[5]};
                 } else {
-                    const int tt = q / 5, s = q % 5, t = NG * half + 2 * pi + tt, r = l & 31, h = l >> 5;
+                    const int tt = q / 5, s = q % 5, t = pass * NTP + NSETS * half + 2 * pi + tt, r = l & 31, h = l >> 5;
                     if (s == 4) {
                         const WLo o = w_lo2(W2, WD, nb, t, r, h);
                         out = u32x4{o.pk[0], o.pk[1], o.pk[2], o.pk[3]};
@@ -388,8 +403,8 @@ __device__ __forceinline__ void w_interleave() {
 template <int ACT, int NG>
 __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
     typedef WCfg<NG> K;
-    constexpr int W_C = K::C, W_WD = K::WD, W_NG = K::NG, W_NT = K::NT, W_NB = K::NB, W_SLOT = K::SLOT, W_CH1 = K::CH1, W_CH2 = K::CH2;
-    constexpr int W_NP1 = K::NP1, W_NP2 = K::NP2, NSETS = K::NSETS, GS = K::GS;
+    constexpr int W_C = K::C, W_WD = K::WD, W_NG = K::NG, W_NB = K::NB, W_SLOT = K::SLOT, W_CH1 = K::CH1, W_CH2 = K::CH2;
+    constexpr int W_NP1 = K::NP1, W_NP2 = K::NP2, NSETS = K::NSETS, GS = K::GS, SPT = K::SPT, NTP = K::NTP, NPASS = K::NPASS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const ring = smem;
     char* const stg = ring + W_NS * W_SLOT;
@@ -408,7 +423,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
     const unsigned voff16 = (unsigned)lane * 16u;
     unsigned soff = 0;          // stream offset of the stage being issued
     int islot = 0;              // its ring slot
-    int istage = 0;             // its index in the tile's 2 NT + 2 NB stages: < 2 NT phase 1
+    int istage = 0;             // its index in its pass's NST1 + NST2 stages: < NST1 phase 1
+    int ipass = 0;
     auto issue_piece = [&](int np, int p) {
 #ifndef MFW_DIAG_NODMA
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(ring + islot * W_SLOT + (wave * np + p) * 1024), 16, voff16,
@@ -416,11 +432,16 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
 #endif
     };
     auto issue_advance = [&]() {
-        soff += (istage < 2 * W_NT ? W_CH1 : W_CH2) * 1024u;
+        soff += (istage < K::NST1 ? W_CH1 : W_CH2) * 1024u;
         istage = istage + 1;
-        if (istage == 2 * W_NT + 2 * W_NB) {
+        if (istage == K::NST1 + K::NST2) {
             istage = 0;
-            soff = 0;
+            if constexpr (NPASS > 1) {
+                ipass = ipass + 1 == NPASS ? 0 : ipass + 1;
+                if (ipass == 0) soff = 0;
+            } else {
+                soff = 0;
+            }
         }
         islot = islot + 1 == W_NS ? 0 : islot + 1;
     };
@@ -517,6 +538,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
     lds_ptr tile16 = (lds_ptr)(stg + wave * W_STG) + lane * 16;
     asm volatile("" : "+v"(tile4), "+v"(tile16));
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, 0x7fffffff, 0x00020000);   // (two passes: the second adds to the first's output)
     const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int opq = 0;
 
@@ -537,7 +559,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
         // (r, h): k = 64 g + 16 s + 8 h + e), yl6[g] = fp6(2^11 (y - fp16(y)) / block scale), by[g] / yls[g] the scale bytes of the fp6 forms
         f16x32 fa[W_NG];
         u32x6 yl6[W_NG];
-        float byf[W_NG];            // 2^(scale byte - 127) of fp6(yh): the conversions' scale operand
+        float byf[NPASS > 1 ? 1 : W_NG];   // 2^(scale byte - 127) of fp6(yh): the conversions' scale operand (two passes: re-formed from byp where used)
         int byp[2] = {0, 0};        // the same bytes, four per register (the matrix instruction selects one: op_sel)
         int ylp[2] = {0, 0};        // scale bytes of yl6 x 2^-11
         {
@@ -599,20 +621,23 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
                 yl6[gg] = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(la, w_scale_of(bl));
                 ylp[gg >> 2] |= (bl > H8_AL_EXP ? bl - H8_AL_EXP : 0) << (8 * (gg & 3));
                 const int bh = w_scale_byte(w_absmax32(fa[gg]));
-                byf[gg] = w_scale_of(bh);
+                if constexpr (NPASS == 1) byf[gg] = w_scale_of(bh);
                 byp[gg >> 2] |= bh << (8 * (gg & 3));
                 asm volatile("" : "+v"(yl6[gg]));
             });
         }
         WSTAMP(2);
 
+        // ---- the passes over the hidden width (one; two at feature_dim 512: WCfg)
+        sfor<NPASS>([&](auto PASS) {
+        constexpr int pass = decltype(PASS)::value;
         // ---- phase 1.  Two accumulator pairs in turn: one takes the matrix instructions of hidden tile t (it starts as the tile's bias, read
         // from chunk 1 of the tile's first stage) while the other's — tile t - 1, complete — goes through the activation BETWEEN those matrix
         // instructions: with one wave per SIMD nothing else would fill the matrix pipe's busy cycles.
-        f16x32 hf[W_NT];    // tile t: element i = act(u)[point r][64 t + kmap(h, i)]
-        int hsp[(W_NT + 3) / 4];         // block scale bytes of their fp6 forms, four per register
+        f16x32 hf[NTP];     // tile t of the pass: element i = act(u)[point r][64 (pass NTP + t) + kmap(h, i)]
+        int hsp[(NTP + 3) / 4];          // block scale bytes of their fp6 forms, four per register
 #pragma unroll
-        for (int i = 0; i < (W_NT + 3) / 4; ++i) hsp[i] = 0;
+        for (int i = 0; i < (NTP + 3) / 4; ++i) hsp[i] = 0;
         f32x16 au0[2], au1[2];
         float mact = 0.f;
         // registers 4 qq .. 4 qq + 3 of block j (q = 4 j + qq): columns 32 j + 8 qq + 4 h + e of the tile
@@ -657,7 +682,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
         auto dbg_dump = [&](auto T, f32x16 (&a)[2]) {
             constexpr int t = decltype(T)::value;
             if (g.dbg_u) {
-                float* du = g.dbg_u + (row0 + r) * W_WD + 64 * t + 4 * h;
+                float* du = g.dbg_u + (row0 + r) * W_WD + 64 * (pass * NTP + t) + 4 * h;
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -669,24 +694,24 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
             lds_cptr bb = nb16 + (16 * h - 16 * lane);
             sfor<8>([&](auto Q) { bias_quad(bb, Q, au0); });
         }
-        sfor<W_NT>([&](auto T) {
+        sfor<NTP>([&](auto T) {
             constexpr int t = decltype(T)::value;
             f32x16 (&au)[2] = (t & 1) ? au1 : au0;      // this tile's accumulators
             f32x16 (&ap)[2] = (t & 1) ? au0 : au1;      // the previous tile's, then the next tile's bias
             asm volatile("" : "+s"(opq));
             if constexpr (t > 0) dbg_dump(W_IC(t > 0 ? t - 1 : 0), ap);
-            sfor<2>([&](auto HALF) {
-                constexpr int half = decltype(HALF)::value;
+            sfor<SPT>([&](auto SQ) {
+                constexpr int sq = decltype(SQ)::value;      // stage of the tile: groups GS sq ..
                 stage_enter(W_IC(0));
                 const u32x4 hdr = rd16(sb16, 0);
                 lds_cptr nbias = nb16 + (16 * h - 16 * lane);
                 sfor<NSETS>([&](auto I) {
-                    constexpr int i = decltype(I)::value, gi = i >> 1, k = i & 1, gg = GS * half + gi, i12 = NSETS * half + i;
+                    constexpr int i = decltype(I)::value, gi = i >> 1, k = i & 1, gg = GS * sq + gi, i12 = NSETS * sq + i;
                     WBuf& bc = (i & 1) ? bufB : bufA;
                     WBuf& bn = (i & 1) ? bufA : bufB;
                     // the next set: of this stage, of the next stage, or (last set of phase 1) the first of phase 2
                     if constexpr (i < NSETS - 1) load_p1(sb16, sb8, sb8b, W_IC((i + 1) >> 1), W_IC((i + 1) & 1), bn);
-                    else if constexpr (t == W_NT - 1 && half == 1) load_p2(nb16, nb8, W_IC(0), W_IC(0), bn);
+                    else if constexpr (t == NTP - 1 && sq == SPT - 1) load_p2(nb16, nb8, W_IC(0), W_IC(0), bn);
                     else load_p1(nb16, nb8, nb8b, W_IC(0), W_IC(0), bn);
                     if constexpr (k == 0) {
                         sfor<3>([&](auto S) {
@@ -698,7 +723,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
 #pragma unroll
                         for (int j = 0; j < 2; ++j) au[j] = W_MFMA16(__builtin_bit_cast(f16x8, bc.q[j]), w_sub<3>(fa[gg]), au[j]);
                         // yh Wl: fp6(yh / block scale), one conversion instruction (the scale behind an opaque asm keeps it inside the tile)
-                        float sc = byf[gg];
+                        float sc;
+                        if constexpr (NPASS == 1) sc = byf[gg];
+                        else sc = w_scale_of((byp[gg >> 2] >> (8 * (gg & 3))) & 0xff);
                         asm volatile("" : "+v"(sc), "+s"(opq));
                         const u32x6 y6 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(fa[gg], sc);
 #ifndef MFW_DIAG_NOT0
@@ -714,13 +741,14 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
                     // the previous tile's activation, QA quads per set over the tile's first ACT_SETS sets; then the next tile's bias into the
                     // freed registers, QB quads per set: its stage is the next one (landed since this stage's entry)
                     constexpr bool acting = t > 0 && i12 < K::ACT_SETS;
-                    constexpr bool biasing = t < W_NT - 1 && i12 >= K::ACT_SETS;
+                    constexpr bool biasing = t < NTP - 1 && i12 >= K::BIAS_START;
                     if constexpr (acting) sfor<K::QA>([&](auto Q) { act_quad(W_IC((K::QA * i12 + decltype(Q)::value) & 7), ap, hf[t > 0 ? t - 1 : 0]); });
-                    if constexpr (biasing) sfor<K::QB>([&](auto Q) { bias_quad(nbias, W_IC((K::QB * (i12 - K::ACT_SETS) + decltype(Q)::value) & 7), ap); });
-                    // the stage two ahead: phase-2 stages from the last hidden tile on
-                    issue_after(I, W_IC(NSETS), W_IC(t < W_NT - 1 ? 1 : 0));
+                    if constexpr (biasing) sfor<K::QB>([&](auto Q) { bias_quad(nbias, W_IC((K::QB * (i12 - K::BIAS_START) + decltype(Q)::value) & 7), ap); });
+                    // the stage two ahead: phase-2 stages from the last two stages of the pass's last hidden tile on
+                    constexpr bool ahead1 = !(t == NTP - 1 && sq >= SPT - 2);
+                    issue_after(I, W_IC(NSETS), W_IC(ahead1 ? 1 : 0));
                     {
-                        constexpr int np = t < W_NT - 1 ? W_NP1 : W_NP2;
+                        constexpr int np = ahead1 ? W_NP1 : W_NP2;
                         typedef WSpan<i, NSETS, np> SP;
                         w_interleave<6, ((i < NSETS - 1 && ((i + 1) & 1)) ? 10 : 6) + (biasing ? K::QB : 0), SP::b - SP::a, acting ? 2 * K::QA : 0, K::QA>();
                     }
@@ -736,22 +764,27 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
         // the last tile's activation has no matrix instructions to sit between
         {
             WACC_BEGIN();
-            dbg_dump(W_IC(W_NT - 1), au1);
-            sfor<8>([&](auto Q) { act_quad(Q, au1, hf[W_NT - 1]); });
-            act_done(W_IC(W_NT - 1));
-            asm volatile("" : "+a"(hf[W_NT - 1]), "+v"(hsp[(W_NT - 1) >> 2]));
+            dbg_dump(W_IC(NTP - 1), au1);
+            sfor<8>([&](auto Q) { act_quad(Q, au1, hf[NTP - 1]); });
+            act_done(W_IC(NTP - 1));
+            asm volatile("" : "+a"(hf[NTP - 1]), "+v"(hsp[(NTP - 1) >> 2]));
             WACC_END(wacc_act);
             W_SCHED();
         }
         WSTAMP(3);
 
-        // ---- the fp6 forms of the hidden tiles (one conversion each, from the parked fragments)
-        u32x6 h6[W_NT];
-        sfor<W_NT>([&](auto T) {
-            constexpr int t = decltype(T)::value;
-            h6[t] = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(hf[t], w_scale_of((hsp[t >> 2] >> (8 * (t & 3))) & 0xff));
-            asm volatile("" : "+v"(h6[t]));   // these stay in the vector file (the accumulator file holds the 192 registers of hf)
-        });
+        // ---- the fp6 forms of the hidden tiles (one conversion each, from the parked fragments).  Two passes (feature_dim 512): y stays live
+        // beside them, so the forms are made where they are used instead (one conversion per hidden tile and output block: 6 registers
+        // instead of 48)
+        constexpr bool H6_FLY = NPASS > 1;
+        u32x6 h6[H6_FLY ? 1 : NTP];
+        if constexpr (!H6_FLY) {
+            sfor<NTP>([&](auto T) {
+                constexpr int t = decltype(T)::value;
+                h6[t] = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(hf[t], w_scale_of((hsp[t >> 2] >> (8 * (t & 3))) & 0xff));
+                asm volatile("" : "+v"(h6[t]));   // these stay in the vector file (the accumulator file holds the 192 registers of hf)
+            });
+        }
 
         // ---- phase 2
         // 16-byte pieces of the block's rows: lane l <-> row (l >> 3) + 8 i, columns 32 nb + 4 (l & 7) ..
@@ -764,11 +797,15 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
             float bias = 0.f;
             // the loop's big invariants keep their register files (left alone the allocator rotates the fp6 forms through the accumulator
             // file: 12 moves per hidden tile and output block)
-            sfor<W_NT>([&](auto T) {
+            sfor<NTP>([&](auto T) {
                 constexpr int t = decltype(T)::value;
                 f16x32& a = hf[t];
-                u32x6& c = h6[t];
-                asm volatile("" : "+a"(a), "+v"(c));
+                if constexpr (H6_FLY) {
+                    asm volatile("" : "+a"(a));
+                } else {
+                    u32x6& c = h6[t];
+                    asm volatile("" : "+a"(a), "+v"(c));
+                }
             });
             sfor<2>([&](auto HALF) {
                 constexpr int half = decltype(HALF)::value;
@@ -781,7 +818,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
 #ifndef MFW_DIAG_NODMA
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(stg + wave * W_STG + i * 1024), 16, xoff16,
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(pass == 0 ? xrsrc : orsrc, (__attribute__((address_space(3))) void*)(stg + wave * W_STG + i * 1024), 16, xoff16,
                                                                  (unsigned)((8 * i * W_C + 32 * nb) * 4), 0, 0);
 #endif
                 } else {
@@ -800,7 +837,15 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
                         acc = W_MFMA16(w_sub<s>(hf[t]), __builtin_bit_cast(f16x8, bc.q[s]), (t == 0 && s == 0) ? z16 : acc);
                     });
 #ifndef MFW_DIAG_NOT2
-                    acc = W_MFMA6(w_op6(h6[t]), w_op6(bc.q[4], bc.d[0]), acc, W_SB(hsp[t >> 2], t & 3), W_SB((int)hdr[(2 * pi + tt) >> 2], (2 * pi + tt) & 3));
+                    u32x6 c6;
+                    if constexpr (H6_FLY) {
+                        float sc6 = w_scale_of((hsp[t >> 2] >> (8 * (t & 3))) & 0xff);
+                        asm volatile("" : "+v"(sc6));   // (keeps the conversion inside its set)
+                        c6 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(hf[t], sc6);
+                    } else {
+                        c6 = h6[t];
+                    }
+                    acc = W_MFMA6(w_op6(c6), w_op6(bc.q[4], bc.d[0]), acc, W_SB(hsp[t >> 2], t & 3), W_SB((int)hdr[(2 * pi + tt) >> 2], (2 * pi + tt) & 3));
 #endif
                     // the stage two ahead: phase-1 stages (of the next row tile) from the last output block on
                     issue_after(I, W_IC(NSETS), W_IC(last ? 1 : 0));
@@ -832,10 +877,11 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
 #ifdef MFW_DIAG_NOSTORE   // (diagnostic: what the output stores' write acknowledgements cost the stage waits behind them)
                     asm volatile("" ::"v"(o));
 #else
-                    GECCO_NT_STORE(o, reinterpret_cast<f32x4*>(xout + (size_t)(8 * i) * W_C + 32 * nb));
+                    if constexpr (pass + 1 < NPASS) *reinterpret_cast<f32x4*>(xout + (size_t)(8 * i) * W_C + 32 * nb) = o;   // read back by the next pass
+                    else GECCO_NT_STORE(o, reinterpret_cast<f32x4*>(xout + (size_t)(8 * i) * W_C + 32 * nb));
 #endif
                 }
-                if (g.stats) {
+                if (pass + 1 == NPASS && g.stats) {
                     const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(s1), __float_as_uint(s1), false, false);
                     const auto c = __builtin_amdgcn_permlane32_swap(__float_as_uint(s2), __float_as_uint(s2), false, false);
                     const float t1 = __uint_as_float(a[0]) + __uint_as_float(a[1]), t2 = __uint_as_float(c[0]) + __uint_as_float(c[1]);
@@ -848,6 +894,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
         unit2(W_IC(1), W_IC(0), 0);
         for (int nb = 1; nb < W_NB - 1; ++nb) unit2(W_IC(0), W_IC(0), nb);
         unit2(W_IC(0), W_IC(1), W_NB - 1);
+        });   // passes
         WSTAMP(4);
         // ---- column partials of the tile: the four waves' sums in a fixed order
         if (g.stats) {
@@ -924,17 +971,22 @@ int mfw_images_n(const MlpWImageJob* jobs, int n, int act, hipStream_t st) {
 
 }  // namespace
 
-// feature_dim 128, 256 or 384 (NG = 2, 4, 6 groups of 64), width 2 feature_dim, whole 128-row tiles
-bool mlp_fused_w_supported(int C, int Wd, int rows) { return (C == 128 || C == 256 || C == 384) && Wd == 2 * C && rows >= 128 && rows % 128 == 0; }
+// feature_dim 128, 256, 384 or 512 (NG = 2, 4, 6, 8 groups of 64), width 2 feature_dim, whole 128-row tiles
+bool mlp_fused_w_supported(int C, int Wd, int rows) {
+    return (C == 128 || C == 256 || C == 384 || C == 512) && Wd == 2 * C && rows >= 128 && rows % 128 == 0;
+}
 
 size_t mlp_fused_w_image_bytes(int C, int Wd) {
     if (!mlp_fused_w_supported(C, Wd, 128)) return 0;
-    return C == 384 ? WCfg<6>::STREAM : C == 256 ? WCfg<4>::STREAM : WCfg<2>::STREAM;
+    return C == 512 ? WCfg<8>::STREAM : C == 384 ? WCfg<6>::STREAM : C == 256 ? WCfg<4>::STREAM : WCfg<2>::STREAM;
 }
 
 int mlp_fused_w_images_launch(const MlpWImageJob* jobs, int n, int C, int Wd, int act, hipStream_t st) {
     if (!mlp_fused_w_supported(C, Wd, 128)) return -9;
-    return C == 384 ? mfw_images_n<6>(jobs, n, act, st) : C == 256 ? mfw_images_n<4>(jobs, n, act, st) : mfw_images_n<2>(jobs, n, act, st);
+    return C == 512   ? mfw_images_n<8>(jobs, n, act, st)
+           : C == 384 ? mfw_images_n<6>(jobs, n, act, st)
+           : C == 256 ? mfw_images_n<4>(jobs, n, act, st)
+                      : mfw_images_n<2>(jobs, n, act, st);
 }
 
 int mlp_fused_w_image_launch(const float* W0, const float* b0, const float* W2, const float* b2, void* img, int C, int Wd, const float* alpha, int act,
@@ -947,5 +999,5 @@ int mlp_fused_w_launch(const MlpWArgs& g, int C, int Wd, hipStream_t st) {
     if (!mlp_fused_w_supported(C, Wd, g.rows) || !g.x || !g.out || !g.pro_a || !g.pro_o || !g.w_img) return -9;
     if ((size_t)g.B * g.rows * C * sizeof(float) >= ((size_t)1 << 31)) return -9;   // the residual rows come in through 32-bit buffer offsets
     if ((g.act == 1 || g.act == 2) && !g.alpha) return -6;
-    return C == 384 ? mfw_launch_n<6>(g, st) : C == 256 ? mfw_launch_n<4>(g, st) : mfw_launch_n<2>(g, st);
+    return C == 512 ? mfw_launch_n<8>(g, st) : C == 384 ? mfw_launch_n<6>(g, st) : C == 256 ? mfw_launch_n<4>(g, st) : mfw_launch_n<2>(g, st);
 }

@@ -371,7 +371,7 @@ int gecco_unpool_outproj_f16(float* x, const void* q16, const float* kvh, const 
  * and both weights carry two terms, the hidden layer one (fp16): ~2e-4 of the MLP's output scale against fp32, ~3.5e-4 on a network's
  * F_x (the mixed mode: 6e-5).  stats (B, rows / 128, 2, C) or NULL: GroupNorm partials of out.  Replaces
  * models/set_transformer.py:164-166, models/mlp.py:5-39, models/activation.py:17-24, models/normalization.py:36-44.
- * C in {128, 256, 384} (feature_dim 512 does not fit the register file: mlp_fused_w.hip), width == 2 C, rows % 128 == 0; act 0 .. 3; wsplit: gecco_mlp_fused_w_wsplit_bytes(C, width) bytes; W0 == NULL: the weight
+ * C in {128, 256, 384, 512} (512: two passes over the hidden width, mlp_fused_w.hip), width == 2 C, rows % 128 == 0; act 0 .. 3; wsplit: gecco_mlp_fused_w_wsplit_bytes(C, width) bytes; W0 == NULL: the weight
  * stream of an earlier call (same weights, biases, activation and alpha: the stream holds them all) is in wsplit.  dbg_u: NULL, or (B, rows, width) receiving mlp.0's
  * pre-activations times sqrt(log2(e) / 2) / |alpha| for the Gaussian activations (the form the kernel computes them in; diagnostics). */
 int gecco_mlp_fused_w(const float* x, float* out, const float* pro_a, const float* pro_o, const float* W0, const float* b0, const float* W2,

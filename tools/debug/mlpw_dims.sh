@@ -1,3 +1,4 @@
-python tools/debug/mlpw_dims_time.py > gpurun_out/r06i_mlpw_dims_time.log 2>&1
-python bench.py --no-extras --no-cpu-baseline --no-sampler --steps 30 --warmup 5 > gpurun_out/r06i_bench.json 2> gpurun_out/r06i_bench.err
-cat gpurun_out/r06i_mlpw_dims_time.log; python -c "import json;d=json.loads(open('gpurun_out/r06i_bench.json').read().strip().splitlines()[-1]);print(d['ms_per_step'],d['roofline'])"
+python -m pytest tests/test_hip_ops.py -q -x -k "mlp_fused_w" 2>&1 | tail -n 1 > gpurun_out/r06m_mlpw_dims_time.log
+python tools/debug/mlpw_dims_time.py 2>&1 | grep "d=" >> gpurun_out/r06m_mlpw_dims_time.log
+for v in 1 0; do GECCO_MLPW=$v python bench.py --config C4 --no-extras --no-cpu-baseline --no-sampler --steps 20 --warmup 5 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('C4 mlpw=$v', d['ms_per_step'], d['value'])"; done >> gpurun_out/r06m_mlpw_dims_time.log
+cat gpurun_out/r06m_mlpw_dims_time.log

@@ -16,7 +16,7 @@ from gecco_amd import hip_ops as ops  # noqa: E402
 from oracle import weights as W  # noqa: E402  (seeded weights only)
 
 B, N = 64, 2048
-for d, L in ((128, 4), (256, 6), (384, 6)):
+for d, L in ((128, 4), (256, 6), (384, 6), (512, 6)):
     p = {k: v.cuda() for k, v in W.linear_lift_state_dict(3, d, L, 64, 8).items()}
     x, sigma = W.synthetic_cloud(1, B, N)
     x, sigma = x.cuda(), sigma.cuda()

@@ -341,7 +341,7 @@ int st_forward(const GeccoSetTransformer* st, float* x, const float* t, const fl
                         unpool_outproj_h8_kv_bytes(B, C, H) <= (size_t)B * N * C * sizeof(float);
     // "w2" mode (option "mlpw" = 0 runs it as the mixed mode): the point MLP as ONE launch, the hidden layer kept as register fragments,
     // its second term dropped (mlp_fused_w.hip); the weight stream (1.9 MB at d = 384) has its own workspace slot (o_mf).  Shapes the kernel
-    // does not take (feature_dim != 384, point counts off 128) run the mixed mode's two launches — at least as accurate
+    // does not take (feature_dim off 128 .. 512 in steps of 128, point counts off 128) run the mixed mode's two launches — at least as accurate
     const bool mfw_on = mixed && st->precision == 4 && option(OPT_MLPW) && w.wimg && mlp_fused_w_supported(C, Wd, N) &&
                         (size_t)B * N * C * sizeof(float) < ((size_t)1 << 31);
     const bool chain_on = pr == 2 && w.wimg && option(OPT_CHAIN) && inducer_chain_f16_supported(C, Wd, H, G, I) &&

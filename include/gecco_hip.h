@@ -72,7 +72,7 @@ typedef struct GeccoSetTransformer {  /* SetTransformer, models/set_transformer.
                      *   not a multiple of 128 (and widths / head dims outside the fp16 kernels' set) run as mode 1,
                      * 4 "w2": mode 3 with the point MLP of every layer as ONE launch whose hidden layer stays in registers as fp16
                      *   (gecco_mlp_fused_w: two-term weights and AdaGN(x), one-term hidden layer): F_x ~3.5e-4, inside a 5e-4 bar;
-                     *   feature_dim 128, 256 or 384 with point counts in multiples of 128, anything else runs as mode 3 */
+                     *   feature_dim 128, 256, 384 or 512 with point counts in multiples of 128, anything else runs as mode 3 */
     int images_ready;  /* 0: every forward rebuilds the weight images it streams (weights may change between calls; the default).
                         * 1: the caller guarantees that the workspace of this call still holds the images the previous forward with this
                         *    table, the same (B, N), the same options and the same cached / uncached form built in it, and that no weight

@@ -26,8 +26,8 @@ pytestmark = pytest.mark.gpu
 # kv_proj | q_proj), split-bf16 everywhere else: held to the split-bf16 bars.
 # "w2" = the mixed mode with the point MLP of every layer as ONE launch (csrc/mlp_fused_w.hip): the 768-wide hidden layer stays in
 # registers as fp16 (no second term; AdaGN(x) and both weights keep theirs).  Bar 5e-4 on BOTH outputs, half the north star's 1e-3;
-# measured 2.5e-4 .. 4e-4 on F_x (the per-site emulation, profiles/r03_precision_search.txt, predicts 3.6e-4 at C2).  feature_dim 512
-# (C4) and shapes off the kernel's reach run the mixed mode's launches in this mode.
+# measured 2.5e-4 .. 4e-4 on F_x (the per-site emulation, profiles/r03_precision_search.txt, predicts 3.6e-4 at C2).  feature_dim 128 .. 512
+# in steps of 128 (512, C4: two passes over the hidden width); shapes off the kernel's reach run the mixed mode's launches in this mode.
 BARS = {"fp32": 5e-5, "bf16x3": 2e-4, "fp16": 1e-3, "mixed": 2e-4, "w2": 5e-4}
 BARS_FX = {"fp32": 5e-5, "bf16x3": 2e-4, "fp16": 2e-3, "mixed": 2e-4, "w2": 5e-4}
 MODES = ["fp32", "bf16x3", "mixed", "w2", "fp16"]

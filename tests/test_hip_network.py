@@ -84,7 +84,7 @@ def test_uncond_vs_oracle_ragged(ops, B, N, d, L, precision, tol):
     """Sizes the golden set does not hold (ragged N, d=512, N=4096, head dim 8 that stays on the fp32 attention
     kernels, rows < 128; N = 128, 384, 640: an odd number of 128-row tiles under the 256-row tiles and the activation
     images; d = 64 at N = 256: head dim 8 on the fp32 attention kernels with the hidden-layer image at K = 128; d = 192, 320: head
-    dims 24, 40), oracle computed on the fly, every arithmetic mode ("w2": the one-launch point MLP at d = 128, 256, 384 with whole 128-row tiles, the
+    dims 24, 40), oracle computed on the fly, every arithmetic mode ("w2": the one-launch point MLP at d = 128, 256, 384, 512 with whole 128-row tiles, the
     mixed mode's launches everywhere else)."""
     from oracle import weights as W
     p = W.linear_lift_state_dict(77 + N, d, L, cases.I, cases.H)

@@ -1,6 +1,7 @@
 // The point MLP of a layer as ONE launch, the hidden layer never leaves the registers (gfx950):
 //
-//     x += mlp.2( act( mlp.0( AdaGN(x) ) ) ),  + the GroupNorm column partials of the new x      (feature_dim 384, width 768; also 256 and 128)
+//     x += mlp.2( act( mlp.0( AdaGN(x) ) ) ),  + the GroupNorm column partials of the new x      (written for feature_dim 384, width 768;
+//                                                                                                     a template over the width: 128, 256, 512 too — WCfg)
 //
 // Reference: models/set_transformer.py:164-166 (x = x + self.mlp(self.mlp_norm(x, t_embed))), models/mlp.py:5-39,
 // models/activation.py:17-24, models/normalization.py:36-44.
@@ -36,6 +37,13 @@
 // not depend on.  Ring: 3 slots of 44 KiB; a stage is half a unit (hidden tile / output block): 44 chunks in phase 1, 36 in
 // phase 2; one block barrier per stage (30 - 36 matrix instructions).  Blocks are persistent (grid = CUs): the stream wraps,
 // so the first stages of the next row tile arrive during the last output blocks of this one.
+//
+// Other widths (round 6).  Everything above is counted in 64-k groups NG = feature_dim / 64 (WCfg<NG>): 2, 4 and 6 groups run the same
+// schedule with GS = NG / 2 groups per stage.  NG = 8 (feature_dim 512) does not fit 512 registers at once (y 176, the hidden fragments 256,
+// two accumulator pairs 64, two operand sets 64): it runs TWO PASSES over the hidden width with y kept — phase 1 / phase 2 over hidden tiles
+// 0 .. 7, the partial product + bias + residual written to `out`; then phase 1 / phase 2 over tiles 8 .. 15, the second partial product
+// added to the first's output (read back like the residual rows), statistics there — with quarter-tile stages (3 x 32 KiB) and the
+// hidden tiles' fp6 forms made where they are used: C4's point MLP 409 + 316 us as two launches -> 617 us.
 //
 // Probe with per-ingredient switches and stamps: tools/probe/mlpw_probe.hip (main loops), tools/probe/mlpfw_probe.hip (this kernel
 // against a float64 reference).

@@ -826,8 +826,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_w_kernel(MlpWArgs g) {
 #ifndef MFW_DIAG_NODMA
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
+                        // (a later pass reads what the pass before stored from this very CU: system-scope loads (sc0 sc1) never take a line the
+                        // vector cache still holds from before the store)
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(pass == 0 ? xrsrc : orsrc, (__attribute__((address_space(3))) void*)(stg + wave * W_STG + i * 1024), 16, xoff16,
-                                                                 (unsigned)((8 * i * W_C + 32 * nb) * 4), 0, 0);
+                                                                 (unsigned)((8 * i * W_C + 32 * nb) * 4), 0, pass == 0 ? 0 : 17);
 #endif
                 } else {
                     bias = __uint_as_float(hdr[2]);

@@ -47,9 +47,16 @@
 //
 // Probe with per-ingredient switches and stamps: tools/probe/mlpw_probe.hip (main loops), tools/probe/mlpfw_probe.hip (this kernel
 // against a float64 reference).
+//
+// Translation units: this file alone is feature_dim 384 + the entry points (MFW_PART 0); mlp_fused_w_p1.hip (512) and mlp_fused_w_p2.hip
+// (128, 256) include it with MFW_PART 1 / 2 — sixteen instantiations of a fully unrolled kernel built side by side instead of in a row.
 #include "common.h"
 #include "h8_scales.h"
 #include "kernels.h"
+
+#ifndef MFW_PART
+#define MFW_PART 0
+#endif
 
 #include <stdlib.h>
 
@@ -981,6 +988,32 @@ int mfw_images_n(const MlpWImageJob* jobs, int n, int act, hipStream_t st) {
 
 }  // namespace
 
+// the widths built in the other translation units
+int mfw_launch_ng2(const MlpWArgs& g, hipStream_t st);
+int mfw_launch_ng4(const MlpWArgs& g, hipStream_t st);
+int mfw_launch_ng8(const MlpWArgs& g, hipStream_t st);
+int mfw_images_ng2(const MlpWImageJob* jobs, int n, int act, hipStream_t st);
+int mfw_images_ng4(const MlpWImageJob* jobs, int n, int act, hipStream_t st);
+int mfw_images_ng8(const MlpWImageJob* jobs, int n, int act, hipStream_t st);
+
+#if MFW_PART == 1
+int mfw_launch_ng8(const MlpWArgs& g, hipStream_t st) { return mfw_launch_n<8>(g, st); }
+int mfw_images_ng8(const MlpWImageJob* jobs, int n, int act, hipStream_t st) { return mfw_images_n<8>(jobs, n, act, st); }
+#elif MFW_PART == 2
+int mfw_launch_ng2(const MlpWArgs& g, hipStream_t st) { return mfw_launch_n<2>(g, st); }
+int mfw_launch_ng4(const MlpWArgs& g, hipStream_t st) { return mfw_launch_n<4>(g, st); }
+int mfw_images_ng2(const MlpWImageJob* jobs, int n, int act, hipStream_t st) { return mfw_images_n<2>(jobs, n, act, st); }
+int mfw_images_ng4(const MlpWImageJob* jobs, int n, int act, hipStream_t st) { return mfw_images_n<4>(jobs, n, act, st); }
+#else
+#ifdef MFW_PROBE   // tools/probe builds: this file alone (feature_dim 384); the other widths are absent
+int mfw_launch_ng2(const MlpWArgs&, hipStream_t) { return -9; }
+int mfw_launch_ng4(const MlpWArgs&, hipStream_t) { return -9; }
+int mfw_launch_ng8(const MlpWArgs&, hipStream_t) { return -9; }
+int mfw_images_ng2(const MlpWImageJob*, int, int, hipStream_t) { return -9; }
+int mfw_images_ng4(const MlpWImageJob*, int, int, hipStream_t) { return -9; }
+int mfw_images_ng8(const MlpWImageJob*, int, int, hipStream_t) { return -9; }
+#endif
+
 // feature_dim 128, 256, 384 or 512 (NG = 2, 4, 6, 8 groups of 64), width 2 feature_dim, whole 128-row tiles
 bool mlp_fused_w_supported(int C, int Wd, int rows) {
     return (C == 128 || C == 256 || C == 384 || C == 512) && Wd == 2 * C && rows >= 128 && rows % 128 == 0;
@@ -993,10 +1026,10 @@ size_t mlp_fused_w_image_bytes(int C, int Wd) {
 
 int mlp_fused_w_images_launch(const MlpWImageJob* jobs, int n, int C, int Wd, int act, hipStream_t st) {
     if (!mlp_fused_w_supported(C, Wd, 128)) return -9;
-    return C == 512   ? mfw_images_n<8>(jobs, n, act, st)
+    return C == 512   ? mfw_images_ng8(jobs, n, act, st)
            : C == 384 ? mfw_images_n<6>(jobs, n, act, st)
-           : C == 256 ? mfw_images_n<4>(jobs, n, act, st)
-                      : mfw_images_n<2>(jobs, n, act, st);
+           : C == 256 ? mfw_images_ng4(jobs, n, act, st)
+                      : mfw_images_ng2(jobs, n, act, st);
 }
 
 int mlp_fused_w_image_launch(const float* W0, const float* b0, const float* W2, const float* b2, void* img, int C, int Wd, const float* alpha, int act,
@@ -1009,5 +1042,6 @@ int mlp_fused_w_launch(const MlpWArgs& g, int C, int Wd, hipStream_t st) {
     if (!mlp_fused_w_supported(C, Wd, g.rows) || !g.x || !g.out || !g.pro_a || !g.pro_o || !g.w_img) return -9;
     if ((size_t)g.B * g.rows * C * sizeof(float) >= ((size_t)1 << 31)) return -9;   // the residual rows come in through 32-bit buffer offsets
     if ((g.act == 1 || g.act == 2) && !g.alpha) return -6;
-    return C == 512 ? mfw_launch_n<8>(g, st) : C == 384 ? mfw_launch_n<6>(g, st) : C == 256 ? mfw_launch_n<4>(g, st) : mfw_launch_n<2>(g, st);
+    return C == 512 ? mfw_launch_ng8(g, st) : C == 384 ? mfw_launch_n<6>(g, st) : C == 256 ? mfw_launch_ng4(g, st) : mfw_launch_ng2(g, st);
 }
+#endif

@@ -1,0 +1,4 @@
+// The one-launch point MLP of the "w2" mode at feature_dim 512 (two passes over the hidden width): its own translation unit, so that the
+// instantiations of mlp_fused_w.hip build side by side (that file holds the kernel and the entry points).
+#define MFW_PART 1
+#include "mlp_fused_w.hip"

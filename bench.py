@@ -1088,7 +1088,7 @@ def main():
                                "dominant_kernel": mk, "dominant_by": "largest total device time per evaluation (ms x launches) among per_site",
                                "matrix_units_per_product": units, "frac_per_matrix_unit": units * mtf / PEAK_BF16_MFMA_TFLOPS,
                                "mfma_busy_pmc": kk.get("mfma_busy"),
-                               "reproduce_from": "profiles/r06w_fwd_kernel_stats_one_stream.csv (tools/prof_fwd.sh: GECCO_FWD_STREAMS=1 = the B = 64 launch shape "
+                               "reproduce_from": "profiles/r06v_fwd_kernel_stats_one_stream.csv (tools/prof_fwd.sh: GECCO_FWD_STREAMS=1 = the B = 64 launch shape "
                                                  "timed here): 154.6e9 FLOP / AverageNs of mlp_fused_w_kernel / 2.5e15",
                                "kernel": "mlp_fused_w_kernel<1> = the point MLP of a layer in one launch (mlp_fused_w.hip: 4 waves of 512 registers per 128-row "
                                          "tile, one per SIMD; AdaGN apply, mlp.0 as v_mfma_f32_32x32x16_f16 + two v_mfma_scale_f32_32x32x64_f8f6f4 (fp6 x fp6, "
